@@ -1,0 +1,434 @@
+/* CPU oracle for the nonlocal element-pair assembly path -- TEST INFRASTRUCTURE ONLY
+ * (see nl_oracle.h for scope and parity status).
+ *
+ * Each function cites the reference lines it restates; paths are relative to
+ * /root/reference/nl/PyNucleus_nl/ with
+ *   NO  = nonlocalOperator_{SCALAR}.pxi     NA  = nonlocalAssembly_{SCALAR}.pxi
+ *   FL2 = fractionalLaplacian2D.pyx         FL1 = fractionalLaplacian1D.pyx
+ *   KC  = kernelsCy.pyx                     Q   = ../../fem/PyNucleus_fem/quadrature.pyx
+ */
+#define _POSIX_C_SOURCE 199309L
+#include "nl_oracle.h"
+#include <math.h>
+#include <string.h>
+#include <stdlib.h>
+#include <time.h>
+
+#define MAXV 3     /* vertices per cell (dim+1 <= 3) */
+#define MAXDPE 6
+#define MAXE (2*MAXDPE*(2*MAXDPE+1)/2)
+
+static double now_s(void) {
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec + 1e-9*ts.tv_nsec;
+}
+
+/* KC:159-183 (fractional), KC:273-294 (indicator), KC:321-360 (peridynamic), finite variants KC:75-114:
+ * the interaction test comes first. */
+static inline double kernel_eval(const nlo_kernel *K, double d2) {
+    if (!(d2 <= K->horizon2)) return 0.;
+    switch (K->ktype) {
+    case 0: return K->scale*pow(d2, K->exponent);
+    case 1: return K->scale;
+    default: return K->scale/sqrt(d2);
+    }
+}
+
+/* nonlocalOperator.pyx:64-79 PermutationIndexer.rank (Lehmer code) */
+static int perm_rank(const int *perm, int n) {
+    static const int fact[4] = {1, 1, 2, 6};
+    int index = 0;
+    for (int i = 0; i < n; i++) {
+        int smaller = 0;
+        for (int j = 0; j < i; j++) smaller += (perm[j] < perm[i]);
+        index += (perm[i]-smaller)*fact[n-1-i];
+    }
+    return index;
+}
+
+static void simplex_of(const nlo_problem *P, int c, double s[MAXV][2], double center[2]) {
+    int nV = P->dim+1;
+    center[0] = center[1] = 0.;
+    for (int m = 0; m < nV; m++) {
+        int v = P->cells[c*nV+m];
+        for (int l = 0; l < P->dim; l++) {
+            s[m][l] = P->vertices[v*P->dim+l];
+            center[l] += s[m][l];
+        }
+    }
+    double fac = 1./nV;                         /* NO:116-126 */
+    for (int l = 0; l < P->dim; l++) center[l] *= fac;
+}
+
+/* FL2:622-642, FL1:234-253, boundary FL2:1226-1243, FL1:646-660 */
+static int quad_order(const nlo_order_formula *F, double H0, double h1, double h2, double d) {
+    double logdh1 = log(d/h1), logdh2 = log(d/h2);
+    double L1 = fabs(log(h1/H0)), L2 = fabs(log(h2/H0));
+    double Lm = fmax(L1, L2);
+    double n1 = logdh1, n2 = logdh2;
+    if (F->clip_num) { n1 = fmax(logdh1, 0.); n2 = fmax(logdh2, 0.); }
+    double p1 = ceil((F->c0 + F->a*L2 + F->b*Lm - F->e*n2)/(fmax(logdh1, 0.) + F->den0));
+    double p2 = ceil((F->c0 + F->a*L1 + F->b*Lm - F->e*n1)/(fmax(logdh2, 0.) + F->den0));
+    int q1 = (int)fmax(p1, 2.), q2 = (int)fmax(p2, 2.);
+    return q1 > q2 ? q1 : q2;
+}
+
+/* NO:280-378 getProtoPanelType + NO:493-540 getPanelType (constant-order kernel, infinite or finite horizon without cut handling) */
+int nlo_panel(const nlo_problem *P, int c1, int c2, int *perm1, int *perm2, int *perm) {
+    const int nV = P->dim+1, dpe = P->dpe;
+    if (c1 > c2) return NLO_IGNORED;
+    for (int k = 0; k < nV; k++) { perm1[k] = k; perm2[k] = k; }
+    for (int k = 0; k < dpe; k++) perm[k] = k;
+    if (c1 == c2) return -nV;                   /* IDENTICAL */
+    int mask1 = 0, mask2 = 0, common = 0;
+    for (int a = 0; a < nV; a++) {
+        int v1 = P->cells[c1*nV+a];
+        for (int b = 0; b < nV; b++) {
+            if (mask2 & (1 << b)) continue;
+            if (v1 == P->cells[c2*nV+b]) {
+                perm1[common] = a; perm2[common] = b;
+                mask1 += (1 << a); mask2 += (1 << b);
+                common++;
+                break;
+            }
+        }
+    }
+    if (common == 0) {
+        double s1[MAXV][2], s2[MAXV][2], ce1[2], ce2[2];
+        simplex_of(P, c1, s1, ce1);
+        simplex_of(P, c2, s2, ce2);
+        double d2 = 0.;
+        for (int j = 0; j < P->dim; j++) d2 += (ce1[j]-ce2[j])*(ce1[j]-ce2[j]);
+        return quad_order(&P->qo, P->H0, P->h[c1], P->h[c2], sqrt(d2));
+    }
+    int i = 0;
+    for (int k = common; k < nV; k++) { while (mask1 & (1 << i)) i++; perm1[k] = i; mask1 += (1 << i); }
+    i = 0;
+    for (int k = common; k < nV; k++) { while (mask2 & (1 << i)) i++; perm2[k] = i; mask2 += (1 << i); }
+    const int *t1 = P->dof_perm_table + perm_rank(perm1, nV)*dpe;
+    const int *t2 = P->dof_perm_table + perm_rank(perm2, nV)*dpe;
+    const int dpv = P->dofs_per_vertex, dped = P->dofs_per_edge;
+    for (int k = 0; k < dpe; k++) perm[k] = t1[k];
+    if (common == 1) {
+        for (int k = dpv; k < dpe; k++) perm[dpe+k-dpv] = dpe+t2[k];
+    } else if (common == 2) {
+        for (int k = 2*dpv; k < nV*dpv; k++) perm[dpe+k-2*dpv] = dpe+t2[k];
+        for (int k = nV*dpv+dped; k < dpe; k++) perm[dpe+k-2*dpv-dped] = dpe+t2[k];
+    }
+    return -common;
+}
+
+/* NO:549-600 addQuadRule: PSI[2 dpe][n*n], rows 0..dpe-1 = phi_I(x_i), rows dpe.. = -phi_I(y_j), k = i*n+j */
+static double *build_distant_psi(const nlo_problem *P, int order) {
+    const int dpe = P->dpe, off = P->dist_off[order], n = P->dist_off[order+1]-off;
+    const double *phi = P->dist_phi+(size_t)off*dpe;
+    double *PSI = (double*)malloc(sizeof(double)*2*dpe*(size_t)n*n);
+    for (int I = 0; I < dpe; I++)
+        for (int i = 0; i < n; i++)
+            for (int j = 0; j < n; j++) {
+                PSI[(size_t)I*n*n+i*n+j] = phi[i*dpe+I];
+                PSI[(size_t)(I+dpe)*n*n+i*n+j] = -phi[j*dpe+I];
+            }
+    return PSI;
+}
+
+/* NO:722-789 eval_distant, uncut branch.  scratch holds temp[n*n], x[n][2], y[n][2]. */
+static void eval_distant(const nlo_problem *P, double s1[MAXV][2], double s2[MAXV][2], double vol, int order,
+                         const double *PSI, double *scratch, double *contrib) {
+    const int dim = P->dim, nV = dim+1, dpe = P->dpe;
+    const int off = P->dist_off[order], n = P->dist_off[order+1]-off, nn = n*n;
+    const double *bary = P->dist_bary+3*off, *w = P->dist_w+off;
+    double *temp = scratch, *x = scratch+nn, *y = x+2*n;
+    for (int i = 0; i < n; i++)                 /* Q:76-87 nodesInGlobalCoords */
+        for (int m = 0; m < dim; m++) {
+            double a = 0., b = 0.;
+            for (int k = 0; k < nV; k++) { a += bary[3*i+k]*s1[k][m]; b += bary[3*i+k]*s2[k][m]; }
+            x[2*i+m] = a; y[2*i+m] = b;
+        }
+    int k = 0;
+    for (int i = 0; i < n; i++)
+        for (int j = 0; j < n; j++) {
+            double d2 = 0.;
+            for (int m = 0; m < dim; m++) d2 += (x[2*i+m]-y[2*j+m])*(x[2*i+m]-y[2*j+m]);
+            temp[k++] = (w[i]*w[j])*kernel_eval(&P->kernel, d2);   /* Q:224 weights[k] = w1[i]*w2[j] */
+        }
+    k = 0;
+    for (int I = 0; I < 2*dpe; I++)
+        for (int J = I; J < 2*dpe; J++) {
+            const double *pI = PSI+(size_t)I*nn, *pJ = PSI+(size_t)J*nn;
+            double val = 0.;
+            for (int i = 0; i < nn; i++) val += temp[i]*pI[i]*pJ[i];
+            contrib[k++] = val*vol;
+        }
+}
+
+/* NO:722-789 (uncut distant pairs) and FL2:823-891 / FL1:349-407 (singular pairs) */
+void nlo_eval(const nlo_problem *P, int c1, int c2, int panel, const int *perm1, const int *perm2, const int *perm,
+              double *contrib, int64_t *nevals) {
+    const int dim = P->dim, nV = dim+1, dpe = P->dpe;
+    const int E = (2*dpe)*(2*dpe+1)/2;
+    double s1[MAXV][2], s2[MAXV][2], ce[2];
+    simplex_of(P, c1, s1, ce);
+    simplex_of(P, c2, s2, ce);
+    for (int k = 0; k < E; k++) contrib[k] = 0.;
+    if (panel >= 1) {
+        const int off = P->dist_off[panel], n = P->dist_off[panel+1]-off;
+        double *PSI = build_distant_psi(P, panel);
+        double *scratch = (double*)malloc(sizeof(double)*((size_t)n*n+4*(size_t)n));
+        eval_distant(P, s1, s2, P->vol[c1]*P->vol[c2], panel, PSI, scratch, contrib);
+        *nevals += (int64_t)n*n;
+        free(scratch); free(PSI);
+        return;
+    }
+    const int slot = -panel-1;                  /* -1 vertex, -2 edge, -3 face */
+    const int M = P->sing_M[slot], rows = P->sing_rows[slot];
+    const double *nodes = P->sing_nodes[slot], *w = P->sing_w[slot], *PSI = P->sing_psi[slot];
+    const double vol = P->sing_fac*P->vol[c1]*P->vol[c2];
+    double *temp = (double*)malloc(sizeof(double)*M);
+    for (int m = 0; m < M; m++) {
+        double d2 = 0.;
+        for (int j = 0; j < dim; j++) {
+            double xx = 0., yy = 0.;
+            for (int k = 0; k < nV; k++) {
+                xx += s1[perm1[k]][j]*nodes[(size_t)k*M+m];
+                yy += s2[perm2[k]][j]*nodes[(size_t)(nV+k)*M+m];
+            }
+            d2 += (xx-yy)*(xx-yy);
+        }
+        temp[m] = w[m]*kernel_eval(&P->kernel, d2);
+    }
+    *nevals += M;
+    for (int I = 0; I < rows; I++) {
+        int i = perm[I];
+        for (int J = I; J < rows; J++) {
+            int j = perm[J];
+            int k = j < i ? 2*dpe*j-(j*(j+1) >> 1)+i : 2*dpe*i-(i*(i+1) >> 1)+j;
+            double val = 0.;
+            for (int m = 0; m < M; m++) val += temp[m]*PSI[(size_t)I*M+m]*PSI[(size_t)J*M+m];
+            contrib[k] = val*vol;
+        }
+    }
+    free(temp);
+}
+
+static void facet_of(const nlo_problem *P, int b, double s[MAXV][2], double center[2], double *vol) {
+    int nF = P->dim;
+    center[0] = center[1] = 0.;
+    for (int m = 0; m < nF; m++) {
+        int v = P->bcells[b*nF+m];
+        for (int l = 0; l < P->dim; l++) { s[m][l] = P->vertices[v*P->dim+l]; center[l] += s[m][l]; }
+    }
+    for (int l = 0; l < P->dim; l++) center[l] *= 1./nF;
+    if (P->dim == 2) *vol = sqrt((s[1][0]-s[0][0])*(s[1][0]-s[0][0]) + (s[1][1]-s[0][1])*(s[1][1]-s[0][1]));
+    else *vol = 1.;
+}
+
+/* NO:280-378 with cells2 = boundary facets (symmetricCells False), NO:515-533 */
+int nlo_panel_boundary(const nlo_problem *P, int c1, int b, int *perm1, int *perm2, int *perm) {
+    const int nV = P->dim+1, nF = P->dim, dpe = P->dpe;
+    for (int k = 0; k < nV; k++) perm1[k] = k;
+    for (int k = 0; k < nF; k++) perm2[k] = k;
+    for (int k = 0; k < dpe; k++) perm[k] = k;
+    int mask1 = 0, mask2 = 0, common = 0;
+    for (int a = 0; a < nV; a++) {
+        int v1 = P->cells[c1*nV+a];
+        for (int f = 0; f < nF; f++) {
+            if (mask2 & (1 << f)) continue;
+            if (v1 == P->bcells[b*nF+f]) {
+                perm1[common] = a; perm2[common] = f;
+                mask1 += (1 << a); mask2 += (1 << f);
+                common++;
+                break;
+            }
+        }
+    }
+    if (common == 0) {
+        double s1[MAXV][2], s2[MAXV][2], ce1[2], ce2[2], vol2;
+        simplex_of(P, c1, s1, ce1);
+        facet_of(P, b, s2, ce2, &vol2);
+        double d2 = 0.;
+        for (int j = 0; j < P->dim; j++) d2 += (ce1[j]-ce2[j])*(ce1[j]-ce2[j]);
+        /* h2 = get_h_surface_simplex: edge length in 2D, 1 in 1D (nonlocalOperator.pyx:121-122,164-171) */
+        return quad_order(&P->bqo, P->H0, P->h[c1], vol2, sqrt(d2));
+    }
+    int i = 0;
+    for (int k = common; k < nV; k++) { while (mask1 & (1 << i)) i++; perm1[k] = i; mask1 += (1 << i); }
+    i = 0;
+    for (int k = common; k < nF; k++) { while (mask2 & (1 << i)) i++; perm2[k] = i; mask2 += (1 << i); }
+    const int *t1 = P->dof_perm_table + perm_rank(perm1, nV)*dpe;
+    for (int k = 0; k < dpe; k++) perm[k] = t1[k];
+    return -common;
+}
+
+/* NO:1022-1108 eval_distant_boundary, FL2:1324-1407, FL1:726-785 */
+void nlo_eval_boundary(const nlo_problem *P, int c1, int b, int panel, const int *perm1, const int *perm2, const int *perm,
+                       double *contrib, int64_t *nevals) {
+    const int dim = P->dim, nV = dim+1, nF = dim, dpe = P->dpe;
+    const int E = dpe*(dpe+1)/2;
+    double s1[MAXV][2], s2[MAXV][2], ce[2], vol2, nrm[2] = {0., 0.};
+    simplex_of(P, c1, s1, ce);
+    facet_of(P, b, s2, ce, &vol2);
+    if (dim == 2) {
+        nrm[0] = s2[1][1]-s2[0][1];
+        nrm[1] = s2[0][0]-s2[1][0];
+        double v = 1./sqrt(nrm[0]*nrm[0]+nrm[1]*nrm[1]);
+        nrm[0] *= v; nrm[1] *= v;
+    }
+    for (int k = 0; k < E; k++) contrib[k] = 0.;
+    if (panel >= 1) {
+        const int off = P->dist_off[panel], n = P->dist_off[panel+1]-off;
+        const int foff = P->bfacet_off[panel], nf = P->bfacet_off[panel+1]-foff;
+        const double *bary = P->dist_bary+3*off, *w = P->dist_w+off, *phi = P->dist_phi+(size_t)off*dpe;
+        const double *fb = P->bfacet_bary+2*foff, *fw = P->bfacet_w+foff;
+        const double vol = P->vol[c1]*vol2;
+        double *temp = (double*)malloc(sizeof(double)*(size_t)n*nf);
+        for (int k = 0; k < n; k++)
+            for (int m = 0; m < nf; m++) {
+                double x[2] = {0., 0.}, y[2] = {0., 0.}, wv[2], normW = 0., nw;
+                for (int l = 0; l < dim; l++) {
+                    for (int q = 0; q < nV; q++) x[l] += bary[3*k+q]*s1[q][l];
+                    for (int q = 0; q < nF; q++) y[l] += fb[2*m+q]*s2[q][l];
+                }
+                double d2 = 0.;
+                for (int l = 0; l < dim; l++) d2 += (x[l]-y[l])*(x[l]-y[l]);
+                if (dim == 1) nw = 1.;
+                else {
+                    for (int l = 0; l < dim; l++) { wv[l] = y[l]-x[l]; normW += wv[l]*wv[l]; }
+                    normW = 1./sqrt(normW);
+                    nw = nrm[0]*wv[0]*normW + nrm[1]*wv[1]*normW;
+                }
+                temp[k*nf+m] = (w[k]*fw[m])*nw*kernel_eval(&P->bkernel, d2);
+            }
+        *nevals += (int64_t)n*nf;
+        int e = 0;
+        for (int I = 0; I < dpe; I++)
+            for (int J = I; J < dpe; J++) {
+                double val = 0.;
+                for (int k = 0; k < n; k++)
+                    for (int m = 0; m < nf; m++) val += temp[k*nf+m]*phi[k*dpe+I]*phi[k*dpe+J];
+                contrib[e++] = val*vol;
+            }
+        free(temp);
+        return;
+    }
+    const int slot = -panel-1;
+    const int M = P->bsing_M[slot];
+    const double *nodes = P->bsing_nodes[slot], *w = P->bsing_w[slot], *PHI = P->bsing_phi[slot];
+    const double vol = dim == 2 ? P->bsing_fac*P->vol[c1]*vol2 : P->bsing_fac*P->vol[c1];
+    double *temp = (double*)malloc(sizeof(double)*M);
+    for (int m = 0; m < M; m++) {
+        double wv[2] = {0., 0.}, normW = 0., nw = 1.;
+        for (int j = 0; j < dim; j++) {
+            double xx = 0., yy = 0.;
+            for (int k = 0; k < nV; k++) xx += s1[perm1[k]][j]*nodes[(size_t)k*M+m];
+            for (int k = 0; k < nF; k++) yy += s2[perm2[k]][j]*nodes[(size_t)(nV+k)*M+m];
+            wv[j] = xx-yy;
+            normW += wv[j]*wv[j];
+        }
+        if (dim == 2) {
+            double inv = 1./sqrt(normW);
+            nw = nrm[0]*wv[0]*inv + nrm[1]*wv[1]*inv;
+        }
+        temp[m] = w[m]*nw*kernel_eval(&P->bkernel, normW);
+    }
+    *nevals += M;
+    for (int I = 0; I < dpe; I++) {
+        int i = perm[I];
+        for (int J = I; J < dpe; J++) {
+            int j = perm[J];
+            int k = j < i ? dpe*j-(j*(j+1) >> 1)+i : dpe*i-(i*(i+1) >> 1)+j;
+            double val = 0.;
+            for (int m = 0; m < M; m++) val += temp[m]*PHI[(size_t)I*M+m]*PHI[(size_t)J*M+m];
+            contrib[k] = val*vol;
+        }
+    }
+    free(temp);
+}
+
+/* NA:204-221 addToMatrixElemElemSym */
+static void scatter_elem_elem_sym(double *A, int64_t N, const int *ld, int n2, const double *contrib, double fac) {
+    int k = 0;
+    for (int p = 0; p < n2; p++) {
+        int I = ld[p];
+        if (I >= 0) {
+            A[(int64_t)I*N+I] += fac*contrib[k];
+            k++;
+            for (int q = p+1; q < n2; q++) {
+                int J = ld[q];
+                if (J >= 0) {
+                    A[(int64_t)I*N+J] += fac*contrib[k];
+                    A[(int64_t)J*N+I] += fac*contrib[k];
+                }
+                k++;
+            }
+        } else k += n2-p;
+    }
+}
+
+/* NA:1262-1473 getDense: 'interior' loop NA:1386-1428 (symmetric cells/local matrix) and
+ * 'zeroExterior' loop NA:1430-1448 (scatter NA:152-168 is the same routine on dpe local DoFs). */
+int nlo_get_dense_rows(const nlo_problem *P, double *A, int zero_exterior, int cell_start, int cell_end,
+                       int64_t *counters, double *seconds, int store) {
+    const int dpe = P->dpe, nV = P->dim+1;
+    const int64_t N = P->num_dofs;
+    if (dpe > MAXDPE || nV > MAXV) return -1;
+    double contrib[MAXE];
+    int perm1[MAXV], perm2[MAXV], perm[2*MAXDPE], ld[2*MAXDPE];
+    double *psi_cache[NLO_MAX_ORDER+1];         /* distantQuadRulesPtr, NO:441-443 */
+    memset(psi_cache, 0, sizeof(psi_cache));
+    int nmax = 1;
+    for (int q = 0; q <= P->qmax; q++) { int n = P->dist_off[q+1]-P->dist_off[q]; if (n > nmax) nmax = n; }
+    double *scratch = (double*)malloc(sizeof(double)*((size_t)nmax*nmax+4*(size_t)nmax));
+    memset(counters, 0, sizeof(int64_t)*NLO_NUM_COUNTERS);
+    double t0 = now_s();
+    for (int c1 = cell_start; c1 < cell_end; c1++) {
+        for (int c2 = c1; c2 < P->nc; c2++) {
+            counters[0]++;
+            int skip = 1;                       /* NA:138-150 getDoFsElemElem */
+            for (int p = 0; p < dpe; p++) { ld[p] = P->dofs[c1*dpe+p]; skip = skip && ld[p] < 0; }
+            for (int p = 0; p < dpe; p++) { ld[dpe+p] = P->dofs[c2*dpe+p]; skip = skip && ld[dpe+p] < 0; }
+            if (skip) continue;
+            int panel = nlo_panel(P, c1, c2, perm1, perm2, perm);
+            if (panel == NLO_IGNORED) continue;
+            if (panel >= 1 && (panel > P->qmax || P->dist_off[panel+1] == P->dist_off[panel])) return -(1000+panel);
+            counters[1]++;
+            if (panel >= 1) counters[8+panel]++; else counters[8+NLO_MAX_ORDER+(-panel-1)]++;
+            if (panel >= 1) {
+                if (!psi_cache[panel]) psi_cache[panel] = build_distant_psi(P, panel);
+                double s1[MAXV][2], s2[MAXV][2], ce[2];
+                simplex_of(P, c1, s1, ce);
+                simplex_of(P, c2, s2, ce);
+                eval_distant(P, s1, s2, P->vol[c1]*P->vol[c2], panel, psi_cache[panel], scratch, contrib);
+                int n = P->dist_off[panel+1]-P->dist_off[panel];
+                counters[2] += (int64_t)n*n;
+            } else
+                nlo_eval(P, c1, c2, panel, perm1, perm2, perm, contrib, &counters[2]);
+            if (store) scatter_elem_elem_sym(A, N, ld, 2*dpe, contrib, c1 == c2 ? 1. : 2.);
+        }
+    }
+    double t1 = now_s();
+    if (zero_exterior) {
+        for (int c1 = cell_start; c1 < cell_end; c1++) {
+            for (int p = 0; p < dpe; p++) ld[p] = P->dofs[c1*dpe+p];
+            for (int b = 0; b < P->nb; b++) {
+                int panel = nlo_panel_boundary(P, c1, b, perm1, perm2, perm);
+                if (panel >= 1 && (panel > P->qmax || P->dist_off[panel+1] == P->dist_off[panel]
+                                   || P->bfacet_off[panel+1] == P->bfacet_off[panel])) return -(2000+panel);
+                counters[3]++;
+                nlo_eval_boundary(P, c1, b, panel, perm1, perm2, perm, contrib, &counters[4]);
+                if (store) scatter_elem_elem_sym(A, N, ld, dpe, contrib, 1.);
+            }
+        }
+    }
+    double t2 = now_s();
+    if (seconds) { seconds[0] = t1-t0; seconds[1] = t2-t1; }
+    for (int q = 0; q <= NLO_MAX_ORDER; q++) free(psi_cache[q]);
+    free(scratch);
+    return 0;
+}
+
+int nlo_get_dense(const nlo_problem *P, double *A, int zero_exterior, int cell_start, int cell_end,
+                  int64_t *counters, double *seconds) {
+    return nlo_get_dense_rows(P, A, zero_exterior, cell_start, cell_end, counters, seconds, 1);
+}

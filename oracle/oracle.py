@@ -1,0 +1,185 @@
+"""ctypes front end of the CPU oracle -- TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this
+module.  The reference cannot be built or imported in this environment (SURVEY.md
+section 8c), so there is no oracle/_ref: the oracle is the C restatement in
+nl_oracle.c fed with the same precomputed quadrature tables as the GPU library.
+"""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+NLO_MAX_ORDER = 120
+NLO_NUM_COUNTERS = 8+NLO_MAX_ORDER+3
+IGNORED = -6
+
+
+class nlo_order_formula(C.Structure):
+    _fields_ = [('c0', C.c_double), ('a', C.c_double), ('b', C.c_double), ('e', C.c_double), ('den0', C.c_double),
+                ('clip_num', C.c_int32), ('pad', C.c_int32)]
+
+
+class nlo_kernel(C.Structure):
+    _fields_ = [('ktype', C.c_int32), ('pad', C.c_int32), ('exponent', C.c_double), ('scale', C.c_double),
+                ('horizon2', C.c_double)]
+
+
+_P = C.c_void_p
+
+
+class nlo_problem(C.Structure):
+    _fields_ = [('dim', C.c_int32), ('dpe', C.c_int32), ('nc', C.c_int32), ('nv', C.c_int32), ('num_dofs', C.c_int32),
+                ('dofs_per_vertex', C.c_int32), ('dofs_per_edge', C.c_int32), ('pad0', C.c_int32),
+                ('vertices', _P), ('cells', _P), ('dofs', _P), ('vol', _P), ('h', _P),
+                ('H0', C.c_double), ('dof_perm_table', _P),
+                ('kernel', nlo_kernel), ('qo', nlo_order_formula),
+                ('qmax', C.c_int32), ('pad1', C.c_int32),
+                ('dist_off', _P), ('dist_bary', _P), ('dist_w', _P), ('dist_phi', _P),
+                ('sing_M', C.c_int32*3), ('sing_rows', C.c_int32*3),
+                ('sing_nodes', _P*3), ('sing_w', _P*3), ('sing_psi', _P*3), ('sing_fac', C.c_double),
+                ('nb', C.c_int32), ('pad2', C.c_int32), ('bcells', _P),
+                ('bkernel', nlo_kernel), ('bqo', nlo_order_formula),
+                ('bfacet_off', _P), ('bfacet_bary', _P), ('bfacet_w', _P),
+                ('bsing_M', C.c_int32*2), ('bpad', C.c_int32*2),
+                ('bsing_nodes', _P*2), ('bsing_w', _P*2), ('bsing_phi', _P*2), ('bsing_fac', C.c_double)]
+
+
+def build():
+    """compile libnl_oracle.so next to its source (gcc only)"""
+    subprocess.check_call(['make', '-s', '-C', _HERE, 'libnl_oracle.so'])
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        fn = os.path.join(_HERE, 'libnl_oracle.so')
+        if not os.path.exists(fn) or os.path.getmtime(fn) < os.path.getmtime(os.path.join(_HERE, 'nl_oracle.c')):
+            build()
+        L = C.CDLL(fn)
+        ip = C.POINTER(C.c_int)
+        L.nlo_panel.restype = C.c_int
+        L.nlo_panel.argtypes = [C.POINTER(nlo_problem), C.c_int, C.c_int, ip, ip, ip]
+        L.nlo_panel_boundary.restype = C.c_int
+        L.nlo_panel_boundary.argtypes = [C.POINTER(nlo_problem), C.c_int, C.c_int, ip, ip, ip]
+        L.nlo_eval.restype = None
+        L.nlo_eval.argtypes = [C.POINTER(nlo_problem), C.c_int, C.c_int, C.c_int, ip, ip, ip, _P, _P]
+        L.nlo_eval_boundary.restype = None
+        L.nlo_eval_boundary.argtypes = [C.POINTER(nlo_problem), C.c_int, C.c_int, C.c_int, ip, ip, ip, _P, _P]
+        L.nlo_get_dense_rows.restype = C.c_int
+        L.nlo_get_dense_rows.argtypes = [C.POINTER(nlo_problem), _P, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int]
+        _LIB = L
+    return _LIB
+
+
+def _kern(k):
+    p = k.device_params()
+    return nlo_kernel(p['ktype'], 0, p['exponent'], p['scale'], p['horizon2'])
+
+
+def _qo(f):
+    return nlo_order_formula(f.c0, f.a, f.b, f.e, f.den0, int(f.clip_num), 0)
+
+
+class OracleProblem:
+    """Holds the numpy arrays alive and exposes the C entry points."""
+
+    def __init__(self, tables):
+        T = self.tables = tables
+        dm, mesh = T.dm, T.dm.mesh
+        self._keep = []
+
+        def ptr(a, dtype):
+            a = np.ascontiguousarray(a, dtype=dtype)
+            self._keep.append(a)
+            return a.ctypes.data
+
+        P = self.P = nlo_problem()
+        P.dim, P.dpe, P.nc, P.nv, P.num_dofs = T.dim, T.dpe, mesh.num_cells, mesh.num_vertices, dm.num_dofs
+        P.dofs_per_vertex, P.dofs_per_edge = dm.dofs_per_vertex, dm.dofs_per_edge
+        P.vertices = ptr(mesh.vertices, np.float64)
+        P.cells = ptr(mesh.cells, np.int32)
+        P.dofs = ptr(dm.dofs, np.int32)
+        P.vol = ptr(mesh.volVector, np.float64)
+        P.h = ptr(mesh.hVector, np.float64)
+        P.H0 = T.H0
+        P.dof_perm_table = ptr(T.dof_perm_table, np.int32)
+        P.kernel = _kern(T.kernel)
+        P.qo = _qo(T.qo)
+        P.qmax = T.qcap
+        P.dist_off = ptr(T.dist_off, np.int32)
+        P.dist_bary = ptr(T.dist_bary, np.float64)
+        P.dist_w = ptr(T.dist_w, np.float64)
+        P.dist_phi = ptr(T.dist_phi, np.float64)
+        for panel, r in T.singular.items():
+            slot = -panel-1
+            P.sing_M[slot], P.sing_rows[slot] = r.num_nodes, r.rows
+            P.sing_nodes[slot] = ptr(r.nodes, np.float64)
+            P.sing_w[slot] = ptr(r.weights, np.float64)
+            P.sing_psi[slot] = ptr(r.psi, np.float64)
+        P.sing_fac = T.sing_fac
+        P.bfacet_off = ptr(T.bfacet_off, np.int32)
+        P.bfacet_bary = ptr(T.bfacet_bary, np.float64)
+        P.bfacet_w = ptr(T.bfacet_w, np.float64)
+        if T.zeroExterior:
+            P.nb = T.bcells.shape[0]
+            P.bcells = ptr(T.bcells, np.int32)
+            P.bkernel = _kern(T.boundaryKernel)
+            P.bqo = _qo(T.bqo)
+            for panel, r in T.bsingular.items():
+                slot = -panel-1
+                P.bsing_M[slot] = r.num_nodes
+                P.bsing_nodes[slot] = ptr(r.nodes, np.float64)
+                P.bsing_w[slot] = ptr(r.weights, np.float64)
+                P.bsing_phi[slot] = ptr(r.psi, np.float64)
+            P.bsing_fac = T.bsing_fac
+        self.E = (2*T.dpe)*(2*T.dpe+1)//2
+        self.nV = T.dim+1
+
+    # -- per-pair entry points -------------------------------------------
+    def panel(self, c1, c2):
+        p1, p2, p = (C.c_int*3)(), (C.c_int*3)(), (C.c_int*12)()
+        panel = lib().nlo_panel(C.byref(self.P), c1, c2, p1, p2, p)
+        return panel, list(p1)[:self.nV], list(p2)[:self.nV], list(p)[:2*self.tables.dpe]
+
+    def eval(self, c1, c2):
+        """(panel, contrib[E]) of the cell pair; contrib is None for IGNORED"""
+        p1, p2, p = (C.c_int*3)(), (C.c_int*3)(), (C.c_int*12)()
+        panel = lib().nlo_panel(C.byref(self.P), c1, c2, p1, p2, p)
+        if panel == IGNORED:
+            return panel, None
+        contrib = np.zeros(self.E)
+        ne = np.zeros(1, dtype=np.int64)
+        lib().nlo_eval(C.byref(self.P), c1, c2, panel, p1, p2, p, contrib.ctypes.data, ne.ctypes.data)
+        return panel, contrib
+
+    def eval_boundary(self, c1, b):
+        p1, p2, p = (C.c_int*3)(), (C.c_int*3)(), (C.c_int*12)()
+        panel = lib().nlo_panel_boundary(C.byref(self.P), c1, b, p1, p2, p)
+        contrib = np.zeros(self.tables.dpe*(self.tables.dpe+1)//2)
+        ne = np.zeros(1, dtype=np.int64)
+        lib().nlo_eval_boundary(C.byref(self.P), c1, b, panel, p1, p2, p, contrib.ctypes.data, ne.ctypes.data)
+        return panel, contrib
+
+    # -- whole-matrix entry point -----------------------------------------
+    def get_dense(self, cell_start=0, cell_end=None, store=True):
+        """returns (A or None, counters dict, seconds (interior, zeroExterior))"""
+        T = self.tables
+        nc = T.dm.mesh.num_cells
+        cell_end = nc if cell_end is None else cell_end
+        N = T.dm.num_dofs
+        A = np.zeros((N, N)) if store else None
+        counters = np.zeros(NLO_NUM_COUNTERS, dtype=np.int64)
+        seconds = np.zeros(2)
+        rc = lib().nlo_get_dense_rows(C.byref(self.P), A.ctypes.data if store else None, int(T.zeroExterior),
+                                      cell_start, cell_end, counters.ctypes.data, seconds.ctypes.data, int(store))
+        if rc != 0:
+            raise RuntimeError('oracle failed with code {}'.format(rc))
+        hist = {q: int(counters[8+q]) for q in range(NLO_MAX_ORDER) if counters[8+q]}
+        sing = {-1-k: int(counters[8+NLO_MAX_ORDER+k]) for k in range(3)}
+        cnt = dict(numCellPairs=int(counters[0]), numAssembledCellPairs=int(counters[1]), numIntegrations=int(counters[2]),
+                   numBoundaryPairs=int(counters[3]), numBoundaryIntegrations=int(counters[4]), orders=hist, singular=sing)
+        return A, cnt, (float(seconds[0]), float(seconds[1]))

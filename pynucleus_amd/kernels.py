@@ -1,0 +1,356 @@
+"""Kernel objects gamma(x,y) and their factories (host side).
+
+Keeps the reference's factory signatures and the attributes the builder reads
+(/root/reference/nl/PyNucleus_nl/kernels.py:109-231, kernelsCy.pxd:20-50,88-97).
+A kernel is reduced to a small POD parameter block for the HIP library:
+
+    gamma(x,y) = scale * (|x-y|^2)^exponent   [ * 1{|x-y|^2 <= horizon^2} ]
+
+Reference formulas followed (file:line under /root/reference/nl/PyNucleus_nl):
+  kernelsCy.pyx:159-183  fracKernelInfinite{1,2,3}D     C*pow(d2, -d/2-s)
+  kernelsCy.pyx:75-114   fracKernelFinite{1,2,3}D       same inside the interaction set
+  kernelsCy.pyx:216-240  boundary variants              C*pow(d2, -(d-1)/2-s)
+  kernelsCy.pyx:273-294  indicator kernel               C inside the interaction set
+  kernelsCy.pyx:321-360  peridynamic kernel             C/sqrt(d2) inside the interaction set
+  kernelsCy.pyx:1982-2027 getBoundaryKernel             phi = 1/s
+  kernelNormalization.pyx:70-91   constantFractionalLaplacianScaling
+  kernelNormalization.pyx:224-256 constantIntegrableScaling (indicator / peridynamic)
+"""
+import numpy as np
+from math import gamma as Gamma, pi
+
+FRACTIONAL = 0
+INDICATOR = 1
+PERIDYNAMIC = 2
+
+_KERNEL_NAMES = {'FRACTIONAL': FRACTIONAL, 'INDICATOR': INDICATOR, 'CONSTANT': INDICATOR,
+                 'PERIDYNAMIC': PERIDYNAMIC, 'INVERSEDISTANCE': PERIDYNAMIC, 'INVERSEOFDISTANCE': PERIDYNAMIC}
+
+
+def getKernelEnum(kernelTypeString):
+    if isinstance(kernelTypeString, (int, np.integer)):
+        return int(kernelTypeString)
+    try:
+        return _KERNEL_NAMES[kernelTypeString.upper()]
+    except KeyError:
+        raise NotImplementedError(kernelTypeString)
+
+
+class constant:
+    def __init__(self, value):
+        self.value = float(value)
+
+    def __call__(self, x):
+        return self.value
+
+    def __repr__(self):
+        return '{}'.format(self.value)
+
+
+class constFractionalOrder:
+    """s(x,y) = const (fractionalOrders.pyx:72-93)"""
+    symmetric = True
+    numParameters = 1
+
+    def __init__(self, s):
+        self.value = float(s)
+        self.min = self.max = self.value
+
+    def __call__(self, x, y):
+        return self.value
+
+    def __repr__(self):
+        return 's={}'.format(self.value)
+
+
+class constantTwoPoint:
+    symmetric = True
+
+    def __init__(self, value):
+        self.value = float(value)
+
+    def __call__(self, x, y):
+        return self.value
+
+    def __repr__(self):
+        return '{}'.format(self.value)
+
+
+class constantFractionalLaplacianScaling(constantTwoPoint):
+    def __init__(self, dim, s, horizon, tempered=0.):
+        self.dim = dim
+        if 1. < s < 2.:
+            s = s-1.
+        self.s = s
+        self.horizon = horizon
+        self.tempered = tempered
+        if horizon <= 0. or s <= 0. or s >= 1.:
+            value = np.nan
+        elif horizon < np.inf:
+            value = (2.-2*s)*pow(horizon, 2*s-2.)*dim*Gamma(0.5*dim)/pow(pi, 0.5*dim)*0.5
+        elif tempered == 0. or s == 0.5:
+            value = 2.0**(2.0*s)*s*Gamma(s+0.5*dim)/pow(pi, 0.5*dim)/Gamma(1.0-s)*0.5
+        else:
+            raise NotImplementedError('tempered kernels')
+        super().__init__(value)
+
+    def __repr__(self):
+        return 'constantFractionalLaplacianScaling({},{} -> {})'.format(self.s, self.horizon, self.value)
+
+
+class constantIntegrableScaling(constantTwoPoint):
+    def __init__(self, kType, interaction, dim, horizon):
+        self.kType, self.dim, self.horizon = kType, dim, horizon
+        if horizon <= 0.:
+            value = np.nan
+        elif kType == INDICATOR:
+            if dim == 1:
+                value = 3./horizon**3/2.
+            elif dim == 2:
+                value = 8./pi/horizon**4/2.
+            else:
+                raise NotImplementedError()
+        elif kType == PERIDYNAMIC:
+            if dim == 1:
+                value = 2./horizon**2/2.
+            elif dim == 2:
+                value = 6./pi/horizon**3/2.
+            else:
+                raise NotImplementedError()
+        else:
+            raise NotImplementedError()
+        super().__init__(value)
+
+
+class interactionDomain:
+    symmetric = True
+
+    def __init__(self, horizon):
+        self.horizon = horizon
+
+
+class fullSpace(interactionDomain):
+    def __init__(self):
+        super().__init__(np.inf)
+
+    def __repr__(self):
+        return 'R^d'
+
+
+class ball2_retriangulation(interactionDomain):
+    """l2 ball |x-y| <= horizon; elements cut by the horizon are re-triangulated
+    (interactionDomains.pyx:866-1100)."""
+
+    def __repr__(self):
+        return 'ball2({})'.format(self.horizon)
+
+
+class Kernel:
+    """gamma(x,y) = scale*(|x-y|^2)^exponent on the interaction set."""
+
+    def __init__(self, dim, kType, horizon, interaction=None, scaling=None, phi=None, piecewise=True, boundary=False,
+                 valueSize=1, max_horizon=np.nan):
+        self.dim = int(dim)
+        self.kernelType = kType
+        self.horizon = horizon if isinstance(horizon, constant) else constant(np.inf if horizon is None else horizon)
+        self.horizonValue = self.horizon.value
+        self.finiteHorizon = self.horizonValue != np.inf
+        if interaction is None:
+            interaction = fullSpace() if not self.finiteHorizon else ball2_retriangulation(self.horizonValue)
+        self.interaction = interaction
+        self.complement = False
+        self.scalingPrePhi = scaling
+        self.phi = phi
+        self.scaling = scaling
+        self.scalingValue = scaling.value*(phi.value if phi is not None else 1.)
+        self.piecewise = piecewise
+        self.boundary = boundary
+        self.valueSize = valueSize
+        self.max_horizon = self.horizonValue if np.isnan(max_horizon) else max_horizon
+        self.variable = self.variableOrder = self.variableHorizon = self.variableScaling = self.variableSingularity = False
+        self.symmetric = True
+        if kType == INDICATOR:
+            self.singularityValue = 0.
+        elif kType == PERIDYNAMIC:
+            self.singularityValue = -1. if not boundary else 0.
+        elif kType != FRACTIONAL:
+            raise NotImplementedError(kType)
+        if kType != FRACTIONAL:
+            self.min_singularity = self.max_singularity = self.singularityValue
+
+    # reference: Kernel.getSingularityValue / getHorizonValue / getScalingValue
+    def getSingularityValue(self):
+        return self.singularityValue
+
+    def getHorizonValue(self):
+        return self.horizonValue
+
+    def getHorizonValue2(self):
+        return self.horizonValue**2
+
+    def getScalingValue(self):
+        return self.scalingValue
+
+    @property
+    def exponent(self):
+        """power of |x-y|^2"""
+        return 0.5*self.singularityValue
+
+    def device_params(self):
+        """POD block handed to pnl_set_kernel: (type, dim, exponent, scale, horizon^2)."""
+        h2 = self.horizonValue**2 if self.finiteHorizon else np.inf
+        return dict(ktype=int(self.kernelType), dim=self.dim, exponent=float(self.exponent),
+                    scale=float(self.scalingValue), horizon2=float(h2), boundary=bool(self.boundary))
+
+    def __call__(self, x, y):
+        x = np.atleast_1d(np.asarray(x, dtype=float))
+        y = np.atleast_1d(np.asarray(y, dtype=float))
+        d2 = float(((x-y)**2).sum())
+        if self.finiteHorizon and not d2 <= self.horizonValue**2:
+            return 0.
+        return self.scalingValue*d2**self.exponent
+
+    def _integrable_boundary_scaling(self):
+        raise NotImplementedError('Gauss-theorem boundary kernels exist for fractional kernels only')
+
+    def getModifiedKernel(self, horizon=None, scaling=None):
+        raise NotImplementedError()
+
+    def getBoundaryKernel(self):
+        raise NotImplementedError()
+
+    def __repr__(self):
+        name = {FRACTIONAL: 'fractional', INDICATOR: 'indicator', PERIDYNAMIC: 'peridynamic'}[self.kernelType]
+        return 'kernel({}{}, {}, {})'.format(name, '-boundary' if self.boundary else '', self.interaction, self.scalingValue)
+
+
+class FractionalKernel(Kernel):
+    def __init__(self, dim, s, horizon, interaction, scaling, phi=None, piecewise=True, boundary=False,
+                 derivative=0, tempered=0., max_horizon=np.nan, manifold=False, normalized=True):
+        if derivative != 0 or tempered != 0. or manifold:
+            raise NotImplementedError('derivative / tempered / manifold fractional kernels')
+        if not isinstance(s, constFractionalOrder):
+            raise NotImplementedError('variable fractional orders')
+        self.s = s
+        self.sValue = s.value
+        self.derivative = derivative
+        self.temperedValue = tempered
+        self.manifold = manifold
+        self.normalized = normalized
+        # kernelsCy.pyx:1622-1634
+        if not boundary:
+            self.singularityValue = -dim-2*self.sValue
+        else:
+            self.singularityValue = 1.-dim-2*self.sValue
+        self.min_singularity = self.max_singularity = self.singularityValue
+        super().__init__(dim, FRACTIONAL, horizon, interaction, scaling, phi, piecewise, boundary, 1, max_horizon)
+
+    def getModifiedKernel(self, s=None, horizon=None, scaling=None):
+        s = self.s if s is None else s
+        if horizon is None:
+            horizon = self.horizon
+            interaction = self.interaction
+            if scaling is None:
+                scaling = self.scalingPrePhi
+        else:
+            interaction = None
+            if scaling is None and isinstance(self.scalingPrePhi, constantFractionalLaplacianScaling):
+                scaling = None if self.normalized else self.scalingPrePhi
+        return getFractionalKernel(self.dim, s, horizon, interaction, scaling, self.normalized, self.piecewise,
+                                   None, self.boundary)
+
+    def getBoundaryKernel(self):
+        """Kernel obtained by eliminating the exterior via Gauss' theorem:
+        Gamma_b = (C/s) |x-y|^{-(d-1)-2s}."""
+        return FractionalKernel(self.dim, self.s, self.horizon, None, self.scalingPrePhi,
+                                phi=constantTwoPoint(1./self.sValue), piecewise=self.piecewise, boundary=True,
+                                normalized=self.normalized)
+
+    def __repr__(self):
+        return 'kernel(fractional{}, {}, {}, {})'.format('-boundary' if self.boundary else '', self.s, self.interaction, self.scalingValue)
+
+
+def _getFractionalOrder(s):
+    if isinstance(s, constFractionalOrder):
+        return s
+    if isinstance(s, (float, int, np.floating)):
+        return constFractionalOrder(float(s))
+    raise NotImplementedError(s)
+
+
+def _getHorizon(horizon):
+    if horizon is None:
+        return constant(np.inf)
+    if isinstance(horizon, constant):
+        return horizon
+    return constant(float(horizon))
+
+
+def _getInteraction(interaction, horizon):
+    if isinstance(interaction, interactionDomain):
+        return interaction
+    if horizon.value == np.inf:
+        return fullSpace()
+    if interaction is None or interaction == 'ball2':
+        return ball2_retriangulation(horizon.value)
+    raise NotImplementedError('Interaction: {}'.format(interaction))
+
+
+def getFractionalKernel(dim, s, horizon=None, interaction=None, scaling=None, normalized=True, piecewise=True, phi=None,
+                        boundary=False, derivative=0, tempered=0., max_horizon=np.nan, manifold=False):
+    sFun = _getFractionalOrder(s)
+    horizonFun = _getHorizon(horizon)
+    interaction = _getInteraction(interaction, horizonFun)
+    if scaling is None:
+        if normalized:
+            scaling = constantFractionalLaplacianScaling(dim, sFun.value, horizonFun.value, tempered)
+        else:
+            scaling = constantTwoPoint(0.5)
+        if boundary:
+            fac = constantTwoPoint(1./sFun.value)
+            phi = fac if phi is None else constantTwoPoint(fac.value*phi.value)
+    return FractionalKernel(dim, sFun, horizonFun, interaction, scaling, phi, piecewise, boundary, derivative, tempered,
+                            max_horizon, manifold, normalized)
+
+
+def getIntegrableKernel(dim, kernel, horizon, scaling=None, interaction=None, normalized=True, piecewise=True, phi=None,
+                        boundary=False, max_horizon=np.nan, **kwargs):
+    kType = getKernelEnum(kernel)
+    horizonFun = _getHorizon(horizon)
+    interaction = _getInteraction(interaction, horizonFun)
+    if scaling is None:
+        if normalized:
+            scaling = constantIntegrableScaling(kType, interaction, dim, horizonFun.value)
+        else:
+            scaling = constantTwoPoint(0.5)
+    return Kernel(dim, kType, horizonFun, interaction, scaling, phi, piecewise, boundary, 1, max_horizon)
+
+
+def getKernel(dim, s=None, horizon=None, scaling=None, interaction=None, normalized=True, piecewise=True, phi=None,
+              kernel=FRACTIONAL, boundary=False, max_horizon=np.nan, variance=1., exponentialRate=1.0):
+    kType = getKernelEnum(kernel)
+    if kType == FRACTIONAL:
+        return getFractionalKernel(dim, s, horizon, interaction, scaling, normalized, piecewise, phi, boundary,
+                                   max_horizon=max_horizon)
+    return getIntegrableKernel(dim, kernel=kType, horizon=horizon, scaling=scaling, interaction=interaction,
+                               normalized=normalized, piecewise=piecewise, phi=phi, max_horizon=max_horizon)
+
+
+class _kernelFactory:
+    """nonlocalProblems.py:123-131"""
+
+    def __call__(self, name, **kwargs):
+        return self.build(name, **kwargs)
+
+    def build(self, name, **kwargs):
+        n = name.lower()
+        if n == 'fractional':
+            return getFractionalKernel(**kwargs)
+        if n in ('indicator', 'constant'):
+            return getIntegrableKernel(kernel=INDICATOR, **kwargs)
+        if n in ('inversedistance', 'inverseofdistance', 'peridynamic'):
+            return getIntegrableKernel(kernel=PERIDYNAMIC, **kwargs)
+        raise NotImplementedError(name)
+
+
+kernelFactory = _kernelFactory()

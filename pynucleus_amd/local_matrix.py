@@ -1,0 +1,278 @@
+"""Host-side setup of the element-pair quadrature: everything the reference's
+local-matrix objects precompute in their constructors, flattened into plain
+arrays that are uploaded once to the GPU.
+
+Reference behaviour followed (paths under /root/reference/nl/PyNucleus_nl):
+  fractionalLaplacian2D.pyx:587-620   setKernel: target order, quad_order_diagonal(V)
+  fractionalLaplacian2D.pyx:622-642   getQuadOrder (constants of the order formula)
+  fractionalLaplacian2D.pyx:644-813   getNearQuadRule: merged-DoF PSI tables
+  fractionalLaplacian2D.pyx:1207-1253 boundary setKernel / getQuadOrder
+  fractionalLaplacian2D.pyx:1255-1314 boundary getNearQuadRule
+  fractionalLaplacian1D.pyx:203-253, 255-330, 626-712   the same in 1D
+  nonlocalOperator_{SCALAR}.pxi:66-109  precomputePermutations (DoF permutation table)
+  nonlocalOperator_{SCALAR}.pxi:549-600, 988-1020 addQuadRule / addQuadRule_boundary
+"""
+from itertools import permutations
+import numpy as np
+from .quadrature import (COMMON_VERTEX, COMMON_EDGE, COMMON_FACE, simplexXiaoGimbutas, simplexDuffyTransformation,
+                         singularityCancelationQuadRule1D, singularityCancelationQuadRule1D_boundary,
+                         singularityCancelationQuadRule2D, singularityCancelationQuadRule2D_boundary)
+from .kernels import FRACTIONAL
+
+MAX_PANEL = 120       # nonlocalOperator.pyx:107
+QCAP_DEFAULT = 60     # highest distant order we tabulate up-front (the reference adds rules lazily)
+
+
+def lehmer_rank(perm):
+    n = len(perm)
+    fact = [1, 1, 2, 6, 24]
+    idx = 0
+    for i in range(n):
+        smaller = sum(1 for j in range(i) if perm[j] < perm[i])
+        idx += (perm[i]-smaller)*fact[n-1-i]
+    return idx
+
+
+def dof_permutation_table(dm):
+    """table[rank(perm), dofPerm] = dofOrig with nodes[dofPerm, j] == nodes[dofOrig, perm[j]]"""
+    nV = dm.mesh.manifold_dim+1
+    dpe = dm.dofs_per_element
+    table = np.zeros((int(np.prod(range(1, nV+1))), dpe), dtype=np.int32)
+    for p in permutations(range(nV)):
+        r = lehmer_rank(p)
+        for dofPerm in range(dpe):
+            for dofOrig in range(dpe):
+                if np.abs(dm.nodes[dofPerm, :]-dm.nodes[dofOrig, list(p)]).max() < 1e-10:
+                    table[r, dofPerm] = dofOrig
+                    break
+            else:
+                raise NotImplementedError()
+    return table
+
+
+class orderFormula:
+    """order = max(ceil((c0 + a*L_other + b*Lmax - e*logdh_other)/(max(logdh_self,0)+den0)), 2)"""
+
+    def __init__(self, c0, a, b, e, den0, clip_num):
+        self.c0, self.a, self.b, self.e, self.den0, self.clip_num = float(c0), float(a), float(b), float(e), float(den0), bool(clip_num)
+
+    def __call__(self, H0, h1, h2, d):
+        """vectorised host evaluation (used for statistics and tests only)"""
+        logdh1, logdh2 = np.log(d/h1), np.log(d/h2)
+        L1, L2 = np.abs(np.log(h1/H0)), np.abs(np.log(h2/H0))
+        Lm = np.maximum(L1, L2)
+        n1, n2 = (np.maximum(logdh1, 0.), np.maximum(logdh2, 0.)) if self.clip_num else (logdh1, logdh2)
+        p1 = np.ceil((self.c0+self.a*L2+self.b*Lm-self.e*n2)/(np.maximum(logdh1, 0.)+self.den0))
+        p2 = np.ceil((self.c0+self.a*L1+self.b*Lm-self.e*n1)/(np.maximum(logdh2, 0.)+self.den0))
+        return np.maximum(np.maximum(p1, 2.), np.maximum(p2, 2.)).astype(np.int64)
+
+
+class singularRule:
+    def __init__(self, qr, psi):
+        self.nodes = np.ascontiguousarray(qr.nodes)
+        self.weights = np.ascontiguousarray(qr.weights)
+        self.psi = np.ascontiguousarray(psi)
+        self.num_nodes = qr.num_nodes
+        self.rows = psi.shape[0]
+
+
+class nonlocalTables:
+    """All precomputed quadrature data for one (DoFMap, kernel, params) triple."""
+
+    def __init__(self, dm, kernel, params=None, zeroExterior=True, qcap=QCAP_DEFAULT):
+        params = params or {}
+        mesh = dm.mesh
+        self.dm, self.kernel = dm, kernel
+        self.dim = dim = mesh.dim
+        assert mesh.manifold_dim == dim and dim in (1, 2)
+        assert kernel.dim == dim, 'Kernel dimension must match dm.mesh dimension'
+        if not kernel.symmetric or kernel.variable:
+            raise NotImplementedError('non-symmetric / variable kernels')
+        self.dpe = dm.dofs_per_element
+        self.num_dofs = dm.num_dofs
+        self.hmin = mesh.hmin
+        self.H0 = mesh.diam/np.sqrt(8)                      # NO:435
+        self.dof_perm_table = dof_permutation_table(dm)
+        self.qcap = qcap
+        target_order = params.get('target_order', None)
+        self.zeroExterior = bool(zeroExterior) and not kernel.finiteHorizon      # NA:919-922
+
+        sing = kernel.getSingularityValue()
+        if dim == 2:
+            self._setup2D(kernel, target_order, params.get('quad_order_diagonal', None))
+        else:
+            self._setup1D(kernel, target_order, params.get('quad_order_diagonal', None))
+        self.singularityValue = sing
+        self._distant_rules(qcap)
+        if self.zeroExterior:
+            # NA:954: kernel.getModifiedKernel(horizon=inf).getBoundaryKernel(); zeroExterior implies horizon=inf already
+            if kernel.kernelType != FRACTIONAL:
+                raise NotImplementedError('zeroExterior needs a fractional kernel')
+            bk = kernel.getBoundaryKernel()
+            self.boundaryKernel = bk
+            if dim == 2:
+                self._setup2D_boundary(bk, target_order, params.get('quad_order_diagonal', None))
+            else:
+                self._setup1D_boundary(bk, target_order, params.get('quad_order_diagonal', None))
+            self._boundary_mesh()
+
+    # ------------------------------------------------------------------
+    def _psi_tables(self, rules):
+        """merged-DoF PSI tables (FL2:662-811, FL1:255-330)."""
+        dm, dim = self.dm, self.dim
+        nV = dim+1
+        dpe, dpv, dped = dm.dofs_per_element, dm.dofs_per_vertex, dm.dofs_per_edge
+        out = {}
+        for panel, qr in rules.items():
+            px = dm.evalShapeFunctions(qr.nodes[:nV])
+            py = dm.evalShapeFunctions(qr.nodes[nV:2*nV])
+            common = -panel
+            if common == nV:                                 # identical cells
+                psi = px-py
+            elif common == 1:
+                psi = np.zeros((2*dpe-dpv, qr.num_nodes))
+                for dof in range(dpv):
+                    psi[dof] = px[dof]-py[dof]
+                for dof in range(dpv, dpe):
+                    psi[dof] = px[dof]
+                    psi[dpe+dof-dpv] = -py[dof]
+            elif common == 2:
+                psi = np.zeros((2*dpe-2*dpv-dped, qr.num_nodes))
+                for dof in range(2*dpv):
+                    psi[dof] = px[dof]-py[dof]
+                for dof in range(nV*dpv, nV*dpv+dped):
+                    psi[dof] = px[dof]-py[dof]
+                for dof in range(2*dpv, nV*dpv):
+                    psi[dof] = px[dof]
+                    psi[dpe+dof-2*dpv] = -py[dof]
+                for dof in range(nV*dpv+dped, dpe):
+                    psi[dof] = px[dof]
+                    psi[dpe+dof-2*dpv-dped] = -py[dof]
+            else:
+                raise NotImplementedError()
+            out[panel] = singularRule(qr, psi)
+        return out
+
+    def _setup2D(self, kernel, target_order, quad_order_diagonal):
+        if target_order is None:
+            target_order = 0.5                               # FL2:600-604
+        self.target_order = target_order
+        smax = max(-0.5*(kernel.max_singularity+2), 0.)
+        logh = abs(np.log(self.hmin/self.H0))
+        if quad_order_diagonal is None:
+            qd = max(np.ceil((target_order+1.+smax)/0.43*logh), 4)
+            qdV = max(np.ceil((target_order+1.+smax)/0.7*logh), 4)
+        else:
+            qd = qdV = quad_order_diagonal
+        self.quad_order_diagonal, self.quad_order_diagonalV = int(qd), int(qdV)
+        sing = kernel.getSingularityValue()
+        # singularity cancellation: 2 orders within and (for continuous elements) across elements
+        rules = {COMMON_FACE: singularityCancelationQuadRule2D(COMMON_FACE, 2.+sing, self.quad_order_diagonal, self.quad_order_diagonalV),
+                 COMMON_EDGE: singularityCancelationQuadRule2D(COMMON_EDGE, 2.+sing, self.quad_order_diagonal, self.quad_order_diagonalV),
+                 COMMON_VERTEX: singularityCancelationQuadRule2D(COMMON_VERTEX, 2.+sing, self.quad_order_diagonal, self.quad_order_diagonalV)}
+        self.singular = self._psi_tables(rules)
+        self.sing_fac = 4.0                                  # FL2:851
+        s = max(-0.5*(sing+2), 0.)
+        c = (0.5*target_order+0.5)*np.log(self.num_dofs*self.H0**2)
+        self.qo = orderFormula(c, s-1., 1., s, 0.4, False)
+
+    def _setup1D(self, kernel, target_order, quad_order_diagonal):
+        smin = max(-0.5*(kernel.min_singularity+1), 0.)
+        smax = max(-0.5*(kernel.max_singularity+1), 0.)
+        if target_order is None:
+            target_order = self.dm.polynomialOrder+1-smin    # FL1:219-222
+        self.target_order = target_order
+        if quad_order_diagonal is None:
+            quad_order_diagonal = max(np.ceil(((target_order+2.)*np.log(self.num_dofs*self.H0) +
+                                               (2.*smax-1.)*abs(np.log(self.hmin/self.H0)))/0.8), 2)
+        self.quad_order_diagonal = self.quad_order_diagonalV = int(quad_order_diagonal)
+        sing = kernel.getSingularityValue()
+        dm_order = max(self.dm.polynomialOrder, 1)
+        rules = {COMMON_EDGE: singularityCancelationQuadRule1D(COMMON_EDGE, 2.+sing, self.quad_order_diagonal, 2*dm_order),
+                 COMMON_VERTEX: singularityCancelationQuadRule1D(COMMON_VERTEX, 2.+sing, self.quad_order_diagonal, 2*dm_order)}
+        self.singular = self._psi_tables(rules)
+        self.sing_fac = 1.0                                  # FL1:374
+        s = max(-0.5*(sing+1), 0.)
+        c = (target_order+2.)*np.log(self.num_dofs*self.H0)
+        self.qo = orderFormula(c, 2.*s-1., 0., 2.*s, 0.8, False)
+
+    def _setup2D_boundary(self, bk, target_order, quad_order_diagonal):
+        smax = max(0.5*(-bk.max_singularity-1.), 0.)
+        if target_order is None:
+            target_order = 0.5
+        if quad_order_diagonal is None:
+            quad_order_diagonal = max(np.ceil((target_order+0.5+smax)/0.35*abs(np.log(self.hmin/self.H0))), 2)
+        self.bquad_order_diagonal = qd = int(quad_order_diagonal)
+        sing = bk.getSingularityValue()
+        sg_edge = sing if sing > -2.+1e-3 else 2.+sing       # FL2:1271-1274
+        rules = {COMMON_EDGE: singularityCancelationQuadRule2D_boundary(COMMON_EDGE, sg_edge, qd, qd),
+                 COMMON_VERTEX: singularityCancelationQuadRule2D_boundary(COMMON_VERTEX, sing, qd, qd)}
+        self.bsingular = {p: singularRule(qr, self.dm.evalShapeFunctions(qr.nodes[:3])) for p, qr in rules.items()}
+        self.bsing_fac = -2.0                                # FL2:1375
+        s = max(0.5*(-sing-1.), 0.)
+        c = (0.5*target_order+0.25)*np.log(self.num_dofs*self.H0**2)
+        self.bqo = orderFormula(c, s-1., 1., s, 0.35, True)
+
+    def _setup1D_boundary(self, bk, target_order, quad_order_diagonal):
+        smin = max(0.5*(-bk.min_singularity), 0.)
+        smax = max(0.5*(-bk.max_singularity), 0.)
+        if target_order is None:
+            target_order = self.dm.polynomialOrder+1-smin
+        if quad_order_diagonal is None:
+            quad_order_diagonal = max(np.ceil(((target_order+1.)*np.log(self.num_dofs*self.H0) +
+                                               (2.*smax-1.)*abs(np.log(self.hmin/self.H0)))/0.8), 2)
+        self.bquad_order_diagonal = qd = int(quad_order_diagonal)
+        sing = bk.getSingularityValue()
+        sg = sing if sing > -1.+1e-3 else 2.+sing            # FL1:686-689
+        qr = singularityCancelationQuadRule1D_boundary(COMMON_VERTEX, sg, qd, 1)
+        self.bsingular = {COMMON_VERTEX: singularRule(qr, self.dm.evalShapeFunctions(qr.nodes[:2]))}
+        self.bsing_fac = 1.0
+        s = max(0.5*(-sing-1.), 0.)
+        c = (target_order+1.)*np.log(self.num_dofs*self.H0)
+        self.bqo = orderFormula(c, 2.*s-1., 0., 2.*s, 0.8, False)
+
+    # ------------------------------------------------------------------
+    def _distant_rules(self, qcap):
+        dim, dpe = self.dim, self.dpe
+        off = np.zeros(qcap+2, dtype=np.int32)
+        bary, w, phi = [], [], []
+        foff = np.zeros(qcap+2, dtype=np.int32)
+        fbary, fw = [], []
+        for q in range(qcap+1):
+            if q >= 2:
+                qr = simplexXiaoGimbutas(q, dim, dim)
+                b = np.zeros((qr.num_nodes, 3))
+                b[:, :dim+1] = qr.nodes.T
+                bary.append(b)
+                w.append(qr.weights)
+                phi.append(self.dm.evalShapeFunctions(qr.nodes).T)
+                off[q+1] = off[q]+qr.num_nodes
+                fr = simplexDuffyTransformation(q, dim, dim-1)       # NO:999
+                fb = np.zeros((fr.num_nodes, 2))
+                fb[:, :dim] = fr.nodes.T
+                fbary.append(fb)
+                fw.append(fr.weights)
+                foff[q+1] = foff[q]+fr.num_nodes
+            else:
+                off[q+1] = off[q]
+                foff[q+1] = foff[q]
+        self.dist_off = off
+        self.dist_bary = np.ascontiguousarray(np.concatenate(bary))
+        self.dist_w = np.ascontiguousarray(np.concatenate(w))
+        self.dist_phi = np.ascontiguousarray(np.concatenate(phi))
+        self.bfacet_off = foff
+        self.bfacet_bary = np.ascontiguousarray(np.concatenate(fbary))
+        self.bfacet_w = np.ascontiguousarray(np.concatenate(fw))
+
+    def num_points(self, q):
+        return int(self.dist_off[q+1]-self.dist_off[q])
+
+    def _boundary_mesh(self):
+        surface = self.dm.mesh.get_surface_mesh()
+        self.bcells = np.ascontiguousarray(surface.cells, dtype=np.int32)
+
+    def describe(self):
+        return dict(dim=self.dim, dpe=self.dpe, num_dofs=self.num_dofs, H0=self.H0, hmin=self.hmin,
+                    target_order=self.target_order, quad_order_diagonal=self.quad_order_diagonal,
+                    quad_order_diagonalV=self.quad_order_diagonalV,
+                    singular_points={p: r.num_nodes for p, r in self.singular.items()})
