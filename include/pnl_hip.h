@@ -1,0 +1,152 @@
+/* pnl_hip.h -- C ABI of the MI355X (gfx950) nonlocal-assembly library libpnl_hip.so.
+ *
+ * This is the drop-in boundary for the hot path of PyNucleus_nl's nonlocalBuilder:
+ * the double loop over element pairs that classifies the pair, integrates the
+ * kernel over it and scatters the local matrix (reference, Cython, CPU only):
+ *
+ *   nl/PyNucleus_nl/nonlocalAssembly_{SCALAR}.pxi:1262-1473   nonlocalBuilder.getDense
+ *   nl/PyNucleus_nl/nonlocalOperator_decl_{SCALAR}.pxi:8-91   the cdef seam it sits behind
+ *        (setMesh1/2, setCell1/2, getPanelType(), eval(contrib, panel, mask))
+ *   nl/PyNucleus_nl/kernelsCy.pxd:17                          kernel_fun_t(x, y, c_params)
+ *
+ * The reference has no C ABI of its own; every entry point below names the
+ * reference routine(s) whose work it takes over.  Plain pointers and sizes only --
+ * no Python, numpy or torch types.  Pointers named *_host are read on the CPU and
+ * copied into HBM by the library; pointers named *_dev must be device memory
+ * (hipMalloc / a torch.cuda tensor's data_ptr).  All indices are int32, all reals
+ * fp64, arrays are C-contiguous (the reference's INDEX_t / REAL_t, myTypes64.pxd).
+ *
+ * Error convention: every function returns 0 on success or a negative pnl_status;
+ * pnl_error_string() returns a description of the last failure of that context.
+ * The host layer maps PNL_ERR_UNSUPPORTED to NotImplementedError and
+ * PNL_ERR_INVALID to AssertionError like the reference (NA:915, 941, 1022, 1055).
+ * A context is single-caller like the reference's builder objects; internally
+ * every call is asynchronous on the context's HIP stream unless stated otherwise.
+ */
+#ifndef PNL_HIP_H
+#define PNL_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct pnl_context pnl_context;
+
+enum pnl_status {
+    PNL_OK = 0,
+    PNL_ERR_INVALID = -1,       /* bad argument / inconsistent sizes           */
+    PNL_ERR_UNSUPPORTED = -2,   /* (dim, element, kernel) combination not built */
+    PNL_ERR_HIP = -3,           /* a HIP runtime call failed                    */
+    PNL_ERR_STATE = -4,         /* called before the required uploads           */
+    PNL_ERR_ORDER = -5          /* a pair needs a quadrature order beyond the uploaded tables */
+};
+
+enum pnl_kernel_type { PNL_FRACTIONAL = 0, PNL_INDICATOR = 1, PNL_PERIDYNAMIC = 2 };
+
+/* gamma(x,y) = scale * (|x-y|^2)^exponent inside |x-y|^2 <= horizon2 (inf: everywhere).
+ * Replaces the opaque c_kernel_params block + kernelFun pointer (kernel_params.pxi:8-30,
+ * kernelsCy.pyx:75-294). */
+typedef struct {
+    int32_t ktype;
+    int32_t pad;
+    double exponent;
+    double scale;
+    double horizon2;
+} pnl_kernel;
+
+/* Distant-pair quadrature order (fractionalLaplacian2D.pyx:622-642, :1226-1243,
+ * fractionalLaplacian1D.pyx:234-253, :646-660):
+ * order = max(ceil((c0 + a*L_other + b*Lmax - e*logdh_other)/(max(logdh_self,0)+den0)), 2) */
+typedef struct {
+    double c0, a, b, e, den0;
+    int32_t clip_num;
+    int32_t pad;
+} pnl_order_formula;
+
+#define PNL_INTERIOR 0
+#define PNL_BOUNDARY 1
+
+/* counters (pnl_get_counters), names after the reference's PLogger values NA:1834-1838 */
+enum pnl_counter {
+    PNL_C_NUM_CELL_PAIRS = 0,          /* pairs visited (c1 <= c2)                       */
+    PNL_C_NUM_ASSEMBLED_CELL_PAIRS,    /* pairs with panel != IGNORED                    */
+    PNL_C_NUM_INTEGRATIONS,            /* kernel evaluations, interior                   */
+    PNL_C_NUM_BOUNDARY_PAIRS,
+    PNL_C_NUM_BOUNDARY_INTEGRATIONS,
+    PNL_C_ORDER_OVERFLOW,              /* pairs whose order exceeded the tables (error)  */
+    PNL_C_RESERVED6, PNL_C_RESERVED7,
+    PNL_C_HIST0 = 8                    /* [8+q]: distant pairs of order q, q < 120; [128..130]: vertex/edge/face */
+};
+#define PNL_NUM_COUNTERS 131
+
+/* ---- lifetime ---------------------------------------------------------------- */
+int pnl_create(int device_id, pnl_context **ctx);
+void pnl_destroy(pnl_context *ctx);
+const char *pnl_error_string(pnl_context *ctx);
+const char *pnl_version(void);
+/* use a caller-owned HIP stream (hipStream_t) for all later work; NULL = the context's own stream */
+int pnl_set_stream(pnl_context *ctx, void *hip_stream);
+int pnl_synchronize(pnl_context *ctx);
+
+/* ---- problem description (replaces setMesh1/2 + precomputeSimplices, NO:111-191) ---------- */
+/* vertices[nv][dim], cells[nc][dim+1], vol[nc], h[nc] (mesh.volVector / hVector), H0 = diam/sqrt(8) */
+int pnl_upload_mesh(pnl_context *ctx, int dim, int nv, const double *vertices_host, int nc, const int32_t *cells_host,
+                    const double *vol_host, const double *h_host, double H0);
+/* dofs[nc][dpe] (negative = boundary DoF, dm.dofs), dof_perm_table[(dim+1)!][dpe]
+ * (precomputedDoFPermutations, NO:66-109) */
+int pnl_upload_dofmap(pnl_context *ctx, int dpe, int dofs_per_vertex, int dofs_per_edge, int num_dofs,
+                      const int32_t *dofs_host, const int32_t *dof_perm_table_host);
+/* which = PNL_INTERIOR (gamma) or PNL_BOUNDARY (Gauss-theorem boundary kernel, KC:1982-2027) */
+int pnl_set_kernel(pnl_context *ctx, int which, const pnl_kernel *kernel);
+int pnl_set_order_formula(pnl_context *ctx, int which, const pnl_order_formula *formula);
+/* Distant rules for orders 0..qmax (addQuadRule NO:549-600, addQuadRule_boundary NO:988-1020):
+ * off[qmax+2], bary[total][3], w[total], phi[total][dpe]; facet rule foff[qmax+2], fbary[ftotal][2], fw[ftotal] */
+int pnl_upload_distant_rules(pnl_context *ctx, int qmax, const int32_t *off_host, const double *bary_host,
+                             const double *w_host, const double *phi_host, const int32_t *foff_host,
+                             const double *fbary_host, const double *fw_host);
+/* Singular rules (getNearQuadRule FL2:644-813, FL2:1255-1314, FL1:255-330, :672-712):
+ * panel = -1 vertex, -2 edge, -3 face; nodes[ncoord][M] (ncoord = 2(dim+1) interior, 2dim+1 boundary),
+ * w[M], psi[rows][M], fac = multiplier of vol1*vol2 (4 / -2 in 2D, 1 in 1D) */
+int pnl_upload_singular_rule(pnl_context *ctx, int which, int panel, int M, int rows, const double *nodes_host,
+                             const double *w_host, const double *psi_host, double fac);
+/* boundary facets bcells[nb][dim] (mesh.get_surface_mesh().cells, oriented as in their cell) */
+int pnl_upload_boundary(pnl_context *ctx, int nb, const int32_t *bcells_host);
+
+/* ---- the hot path --------------------------------------------------------------------------- */
+/* nonlocalBuilder.getDense (NA:1262-1473): accumulates the operator into A_dev[num_dofs][ldA]
+ * (caller zeroes it).  Cell pairs (c1,c2), c1<=c2, with c1 in [cell_begin, cell_end) are assembled
+ * (the reference's MPI split NA:1280-1285); zero_exterior adds the Omega x Omega^c term for the
+ * same cells.  flags: PNL_FLAG_* below. */
+#define PNL_FLAG_NO_MIRROR 1   /* leave cross contributions in A'[I,J] only (operator = A' + A'^T), for sharded matvec */
+int pnl_assemble_dense(pnl_context *ctx, double *A_dev, int64_t ldA, int zero_exterior, int cell_begin, int cell_end,
+                       int flags);
+/* Like pnl_assemble_dense but with an explicit work list of block-tile pairs for the distant pairs
+ * (multi-GPU balancing): tiles[2*i] <= tiles[2*i+1] are cell-block indices, block size pnl_tile_cells().
+ * Touching pairs, the Omega x Omega^c term and nothing else are restricted to c1 in [cell_begin, cell_end). */
+int pnl_tile_cells(pnl_context *ctx);
+int pnl_assemble_dense_tiles(pnl_context *ctx, double *A_dev, int64_t ldA, int zero_exterior, int ntiles,
+                             const int32_t *tiles_host, int cell_begin, int cell_end, int flags);
+/* counters of the last assemble call (synchronises the stream) */
+int pnl_get_counters(pnl_context *ctx, int64_t *out, int n);
+/* device time of the last assemble call per phase in milliseconds (HIP events on the context's stream):
+ * [0] distant tiles, [1] singular pairs, [2] boundary, [3] scatter+mirror, [4] total */
+int pnl_get_phase_ms(pnl_context *ctx, float *out, int n);
+
+/* ---- adjacent solve path: Dense_LinearOperator.matvec (dgemv, DenseLinearOperator_{SCALAR}.pxi:14-18)
+ *      and cg_solver + jacobi (base/PyNucleus_base/solvers.pyx:363-444, 229-245) ------------------- */
+/* y = A x (n x n, row-major, leading dimension ldA); symmetric_half: y = (A + A^T) x for PNL_FLAG_NO_MIRROR storage */
+int pnl_gemv(pnl_context *ctx, const double *A_dev, int64_t ldA, int n, const double *x_dev, double *y_dev,
+             int symmetric_half);
+/* Jacobi-preconditioned CG on A x = b; x_dev holds the initial guess and the result.
+ * Stops when ||r||_2 <= tol (absolute, like the reference's default) or after maxiter; returns iterations in
+ * *iters and the final residual norm in *residual. */
+int pnl_cg_jacobi(pnl_context *ctx, const double *A_dev, int64_t ldA, int n, const double *b_dev, double *x_dev,
+                  double tol, int maxiter, int *iters, double *residual);
+/* 1/diag(A) into dinv_dev (jacobi_solver.setup, solvers.pyx:233-237) */
+int pnl_inv_diagonal(pnl_context *ctx, const double *A_dev, int64_t ldA, int n, double *dinv_dev);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

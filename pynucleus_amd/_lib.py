@@ -1,0 +1,220 @@
+"""ctypes binding of libpnl_hip.so (the C ABI in include/pnl_hip.h).
+
+The product path has no CPU fallback: if the HIP library is missing or cannot be
+loaded, importing a GPU entry point raises.  Build it with
+``python -c "import __graft_entry__ as g; g.build()"`` or ``make -C pynucleus_amd/csrc``.
+"""
+import ctypes as C
+import os
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libpnl_hip.so')
+
+PNL_OK = 0
+PNL_ERR_INVALID = -1
+PNL_ERR_UNSUPPORTED = -2
+PNL_ERR_HIP = -3
+PNL_ERR_STATE = -4
+PNL_ERR_ORDER = -5
+PNL_INTERIOR = 0
+PNL_BOUNDARY = 1
+PNL_FLAG_NO_MIRROR = 1
+PNL_NUM_COUNTERS = 131
+
+# every symbol include/pnl_hip.h declares (checked by tests/test_abi.py)
+EXPORTS = ['pnl_create', 'pnl_destroy', 'pnl_error_string', 'pnl_version', 'pnl_set_stream', 'pnl_synchronize',
+           'pnl_upload_mesh', 'pnl_upload_dofmap', 'pnl_set_kernel', 'pnl_set_order_formula', 'pnl_upload_distant_rules',
+           'pnl_upload_singular_rule', 'pnl_upload_boundary', 'pnl_assemble_dense', 'pnl_tile_cells',
+           'pnl_assemble_dense_tiles', 'pnl_get_counters', 'pnl_get_phase_ms', 'pnl_gemv', 'pnl_cg_jacobi',
+           'pnl_inv_diagonal']
+
+
+class pnl_kernel(C.Structure):
+    _fields_ = [('ktype', C.c_int32), ('pad', C.c_int32), ('exponent', C.c_double), ('scale', C.c_double),
+                ('horizon2', C.c_double)]
+
+
+class pnl_order_formula(C.Structure):
+    _fields_ = [('c0', C.c_double), ('a', C.c_double), ('b', C.c_double), ('e', C.c_double), ('den0', C.c_double),
+                ('clip_num', C.c_int32), ('pad', C.c_int32)]
+
+
+class PnlError(RuntimeError):
+    pass
+
+
+_LIB = None
+
+
+def load():
+    """dlopen libpnl_hip.so and declare the prototypes; raises if the library is not built"""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(LIB_PATH):
+        raise PnlError('{} is missing: the HIP extension has not been built (run __graft_entry__.build()); '
+                       'there is no CPU fallback for the assembly path'.format(LIB_PATH))
+    L = C.CDLL(LIB_PATH)
+    vp, i32, i64, dbl = C.c_void_p, C.c_int, C.c_int64, C.c_double
+    L.pnl_create.argtypes = [i32, C.POINTER(vp)]
+    L.pnl_destroy.argtypes = [vp]
+    L.pnl_destroy.restype = None
+    L.pnl_error_string.argtypes = [vp]
+    L.pnl_error_string.restype = C.c_char_p
+    L.pnl_version.restype = C.c_char_p
+    L.pnl_set_stream.argtypes = [vp, vp]
+    L.pnl_synchronize.argtypes = [vp]
+    L.pnl_upload_mesh.argtypes = [vp, i32, i32, vp, i32, vp, vp, vp, dbl]
+    L.pnl_upload_dofmap.argtypes = [vp, i32, i32, i32, i32, vp, vp]
+    L.pnl_set_kernel.argtypes = [vp, i32, C.POINTER(pnl_kernel)]
+    L.pnl_set_order_formula.argtypes = [vp, i32, C.POINTER(pnl_order_formula)]
+    L.pnl_upload_distant_rules.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp]
+    L.pnl_upload_singular_rule.argtypes = [vp, i32, i32, i32, i32, vp, vp, vp, dbl]
+    L.pnl_upload_boundary.argtypes = [vp, i32, vp]
+    L.pnl_assemble_dense.argtypes = [vp, vp, i64, i32, i32, i32, i32]
+    L.pnl_tile_cells.argtypes = [vp]
+    L.pnl_assemble_dense_tiles.argtypes = [vp, vp, i64, i32, i32, vp, i32, i32, i32]
+    L.pnl_get_counters.argtypes = [vp, vp, i32]
+    L.pnl_get_phase_ms.argtypes = [vp, vp, i32]
+    L.pnl_gemv.argtypes = [vp, vp, i64, i32, vp, vp, i32]
+    L.pnl_cg_jacobi.argtypes = [vp, vp, i64, i32, vp, vp, dbl, i32, C.POINTER(C.c_int), C.POINTER(C.c_double)]
+    L.pnl_inv_diagonal.argtypes = [vp, vp, i64, i32, vp]
+    for name in EXPORTS:
+        f = getattr(L, name)
+        if name not in ('pnl_destroy', 'pnl_error_string', 'pnl_version'):
+            f.restype = C.c_int
+    _LIB = L
+    return L
+
+
+def _hp(a, dtype):
+    a = np.ascontiguousarray(a, dtype=dtype)
+    return a, a.ctypes.data
+
+
+class Context:
+    """One pnl_context = one GPU + one HIP stream, single caller (like a reference builder object)."""
+
+    def __init__(self, device=0):
+        self.L = load()
+        h = C.c_void_p()
+        rc = self.L.pnl_create(int(device), C.byref(h))
+        if rc != PNL_OK:
+            raise PnlError('pnl_create(device={}) failed with status {} (is a GPU visible?)'.format(device, rc))
+        self.h = h
+        self.device = int(device)
+
+    def close(self):
+        if getattr(self, 'h', None):
+            self.L.pnl_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def check(self, rc):
+        if rc == PNL_OK:
+            return
+        msg = self.L.pnl_error_string(self.h).decode()
+        if rc == PNL_ERR_UNSUPPORTED:
+            raise NotImplementedError(msg)
+        if rc == PNL_ERR_INVALID:
+            raise AssertionError(msg)
+        raise PnlError('status {}: {}'.format(rc, msg))
+
+    # -- uploads ---------------------------------------------------------
+    def upload_tables(self, T):
+        """push a nonlocalTables object (mesh, DoF map, kernel, rules) to the GPU"""
+        L, h = self.L, self.h
+        dm, mesh = T.dm, T.dm.mesh
+        v, pv = _hp(mesh.vertices, np.float64)
+        c, pc = _hp(mesh.cells, np.int32)
+        vol, pvol = _hp(mesh.volVector, np.float64)
+        hh, ph = _hp(mesh.hVector, np.float64)
+        self.check(L.pnl_upload_mesh(h, T.dim, mesh.num_vertices, pv, mesh.num_cells, pc, pvol, ph, float(T.H0)))
+        d, pd = _hp(dm.dofs, np.int32)
+        pt, ppt = _hp(T.dof_perm_table, np.int32)
+        self.check(L.pnl_upload_dofmap(h, T.dpe, dm.dofs_per_vertex, dm.dofs_per_edge, dm.num_dofs, pd, ppt))
+        self._set_kernel(PNL_INTERIOR, T.kernel, T.qo)
+        off, poff = _hp(T.dist_off, np.int32)
+        b, pb = _hp(T.dist_bary, np.float64)
+        w, pw = _hp(T.dist_w, np.float64)
+        phi, pphi = _hp(T.dist_phi, np.float64)
+        fo, pfo = _hp(T.bfacet_off, np.int32)
+        fb, pfb = _hp(T.bfacet_bary, np.float64)
+        fw, pfw = _hp(T.bfacet_w, np.float64)
+        self.check(L.pnl_upload_distant_rules(h, T.qcap, poff, pb, pw, pphi, pfo, pfb, pfw))
+        for panel, r in T.singular.items():
+            n, pn = _hp(r.nodes, np.float64)
+            ww, pww = _hp(r.weights, np.float64)
+            ps, pps = _hp(r.psi, np.float64)
+            self.check(L.pnl_upload_singular_rule(h, PNL_INTERIOR, panel, r.num_nodes, r.rows, pn, pww, pps, float(T.sing_fac)))
+        if T.zeroExterior:
+            bc, pbc = _hp(T.bcells, np.int32)
+            self.check(L.pnl_upload_boundary(h, bc.shape[0], pbc))
+            self._set_kernel(PNL_BOUNDARY, T.boundaryKernel, T.bqo)
+            for panel, r in T.bsingular.items():
+                n, pn = _hp(r.nodes, np.float64)
+                ww, pww = _hp(r.weights, np.float64)
+                ps, pps = _hp(r.psi, np.float64)
+                self.check(L.pnl_upload_singular_rule(h, PNL_BOUNDARY, panel, r.num_nodes, r.rows, pn, pww, pps, float(T.bsing_fac)))
+
+    def _set_kernel(self, which, kernel, formula):
+        p = kernel.device_params()
+        k = pnl_kernel(p['ktype'], 0, p['exponent'], p['scale'], p['horizon2'])
+        self.check(self.L.pnl_set_kernel(self.h, which, C.byref(k)))
+        f = pnl_order_formula(formula.c0, formula.a, formula.b, formula.e, formula.den0, int(formula.clip_num), 0)
+        self.check(self.L.pnl_set_order_formula(self.h, which, C.byref(f)))
+
+    # -- hot path --------------------------------------------------------
+    def set_stream(self, stream_ptr):
+        self.check(self.L.pnl_set_stream(self.h, C.c_void_p(stream_ptr)))
+
+    def synchronize(self):
+        self.check(self.L.pnl_synchronize(self.h))
+
+    def assemble_dense(self, A_ptr, ldA, zero_exterior, cell_begin, cell_end, flags=0):
+        self.check(self.L.pnl_assemble_dense(self.h, C.c_void_p(A_ptr), int(ldA), int(bool(zero_exterior)), int(cell_begin),
+                                             int(cell_end), int(flags)))
+
+    def tile_cells(self):
+        rc = self.L.pnl_tile_cells(self.h)
+        if rc <= 0:
+            self.check(rc)
+        return rc
+
+    def assemble_dense_tiles(self, A_ptr, ldA, zero_exterior, tiles, cell_begin, cell_end, flags=0):
+        t, pt = _hp(tiles, np.int32)
+        self.check(self.L.pnl_assemble_dense_tiles(self.h, C.c_void_p(A_ptr), int(ldA), int(bool(zero_exterior)), t.shape[0], pt,
+                                                   int(cell_begin), int(cell_end), int(flags)))
+
+    def counters(self):
+        out = np.zeros(PNL_NUM_COUNTERS, dtype=np.int64)
+        self.check(self.L.pnl_get_counters(self.h, out.ctypes.data, PNL_NUM_COUNTERS))
+        hist = {q: int(out[8+q]) for q in range(120) if out[8+q]}
+        sing = {-1-k: int(out[128+k]) for k in range(3)}
+        return dict(numCellPairs=int(out[0]), numAssembledCellPairs=int(out[1]), numIntegrations=int(out[2]),
+                    numBoundaryPairs=int(out[3]), numBoundaryIntegrations=int(out[4]), orders=hist, singular=sing)
+
+    def phase_ms(self):
+        out = np.zeros(5, dtype=np.float32)
+        self.check(self.L.pnl_get_phase_ms(self.h, out.ctypes.data, 5))
+        return dict(tiles=float(out[0]), singular=float(out[1]), boundary=float(out[2]), scatter_mirror=float(out[3]),
+                    total=float(out[4]))
+
+    def gemv(self, A_ptr, ldA, n, x_ptr, y_ptr, symmetric_half=False):
+        self.check(self.L.pnl_gemv(self.h, C.c_void_p(A_ptr), int(ldA), int(n), C.c_void_p(x_ptr), C.c_void_p(y_ptr),
+                                   int(symmetric_half)))
+
+    def cg_jacobi(self, A_ptr, ldA, n, b_ptr, x_ptr, tol, maxiter):
+        it, res = C.c_int(0), C.c_double(0.)
+        self.check(self.L.pnl_cg_jacobi(self.h, C.c_void_p(A_ptr), int(ldA), int(n), C.c_void_p(b_ptr), C.c_void_p(x_ptr),
+                                        float(tol), int(maxiter), C.byref(it), C.byref(res)))
+        return it.value, res.value
+
+    def inv_diagonal(self, A_ptr, ldA, n, out_ptr):
+        self.check(self.L.pnl_inv_diagonal(self.h, C.c_void_p(A_ptr), int(ldA), int(n), C.c_void_p(out_ptr)))

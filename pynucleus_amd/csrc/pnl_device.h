@@ -1,0 +1,58 @@
+// Device-side problem description shared by all kernels of libpnl_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define PNL_NTHREADS 256
+#define PNL_MAXQ 120            // nonlocalOperator.pyx:107 MAX_PANEL
+#define PNL_NCOUNTERS 131
+
+struct DevKernel {
+    int ktype;                  // 0 fractional, 1 indicator, 2 peridynamic
+    int fast;                   // 1: fractional, exponent == -1.5, no horizon (s = 1/2 in 2D)
+    double exponent, scale, horizon2;
+};
+
+struct DevFormula {
+    double c0, a, b, e, den0;
+    int clip;
+    int pad;
+};
+
+struct DevProblem {
+    int dim, dpe, nc, ncp, N, dpv, dped, nb;
+    double H0;
+    // SoA cell data, padded to ncp (multiple of the tile size)
+    const double *cellv;        // [(dim+1)*dim][ncp] vertex coordinates of each cell
+    const double *ccen;         // [dim][ncp] cell centres
+    const double *cvol, *ch;    // [ncp]
+    const int *cvid;            // [dim+1][ncp] vertex ids (-1-l for padding cells)
+    const int *cdof;            // [dpe][ncp] global DoF ids (negative = boundary / padding)
+    const short *cslot;         // [dpe][ncp] slot of the DoF in its block's unique-DoF list (-1 if none)
+    const int *blk_ndof;        // [nblocks]
+    const int *blk_dofs;        // [nblocks][blk_stride]
+    int blk_stride, nblocks;
+    const int *perm_table;      // [(dim+1)!][dpe]
+    DevKernel k, bk;
+    DevFormula qo, bqo;
+    // distant rules
+    int qmax, pad0;
+    const int *off;             // [qmax+2]
+    const double *bary;         // [total][3]
+    const double *w;            // [total]
+    const double *phi;          // [total][dpe]
+    const int *foff;            // facet rules
+    const double *fbary;        // [ftotal][2]
+    const double *fw;
+    // singular rules (slot 0 vertex, 1 edge, 2 face)
+    int sM[3], sRows[3];
+    const double *sNodes[3], *sW[3], *sPsi[3];
+    double sFac;
+    int bM[2];
+    const double *bNodes[2], *bW[2], *bPhi[2];
+    double bFac;
+    // boundary facets
+    const int *bvid;            // [dim][nb]
+    const double *bv;           // [dim*dim][nb] facet vertex coordinates
+    unsigned long long *counters;
+};

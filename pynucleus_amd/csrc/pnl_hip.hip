@@ -1,0 +1,815 @@
+// libpnl_hip.so -- host side of the C ABI declared in include/pnl_hip.h (gfx950 only).
+//
+// Owns the HBM copies of mesh / DoF map / quadrature tables (flattened to SoA), derives the
+// work lists (tiles, touching cell pairs, touching cell/facet pairs) and launches the kernels of
+// pnl_kernels.h on one HIP stream.  No Python or torch types cross this boundary.
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "pnl_hip.h"
+#include "pnl_kernels.h"
+
+namespace {
+
+constexpr int TILE_P1 = 64;     // cells per block for dpe <= 3
+constexpr int TILE_P2 = 32;     // cells per block for dpe == 6 (bigger LDS sub-block per cell)
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+    ~DevBuf() { release(); }
+    void release() { if (p) { (void)hipFree(p); p = nullptr; bytes = 0; } }
+};
+
+}  // namespace
+
+struct pnl_context {
+    int device = 0;
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    std::string err;
+    // host copies
+    int dim = 0, nv = 0, nc = 0, dpe = 0, dpv = 0, dped = 0, N = 0, nb = 0, qmax = -1;
+    double H0 = 0.;
+    std::vector<double> vertices, vol, h;
+    std::vector<int32_t> cells, dofs, perm_table, bcells;
+    pnl_kernel kern[2];
+    pnl_order_formula form[2];
+    bool have_mesh = false, have_dofs = false, have_kernel[2] = {false, false}, have_form[2] = {false, false},
+         have_rules = false, have_boundary = false;
+    bool have_sing[2][3] = {{false, false, false}, {false, false, false}};
+    bool dirty = true;
+    // device
+    DevProblem P;
+    DevBuf b_cellv, b_ccen, b_cvol, b_ch, b_cvid, b_cdof, b_cslot, b_blk_ndof, b_blk_dofs, b_perm, b_off, b_bary, b_w, b_phi,
+        b_foff, b_fbary, b_fw, b_sn[3], b_sw[3], b_sp[3], b_bn[2], b_bw[2], b_bp[2], b_bvid, b_bv, b_counters, b_D, b_tiles,
+        b_spairs[3], b_bpairs[2], b_vec[6], b_scal;
+    int tile = TILE_P1, nblocks = 0, ncp = 0, nU = 0;
+    int n_spairs[3] = {0, 0, 0}, n_bpairs[2] = {0, 0};
+    std::vector<int2> spairs_host[3];
+    size_t tiles_cap = 0;
+    hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    bool ev_valid = false;
+    unsigned long long visited_pairs = 0;
+    bool tile_cell_filter = true;   // apply [cell_begin, cell_end) to the a-cells of the tiles too
+};
+
+namespace {
+
+int fail(pnl_context *ctx, int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    if (ctx) ctx->err = buf;
+    return code;
+}
+
+#define HIPCHK(ctx, call)                                                                            \
+    do {                                                                                             \
+        hipError_t e_ = (call);                                                                      \
+        if (e_ != hipSuccess) return fail(ctx, PNL_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); \
+    } while (0)
+
+template <class T>
+int upload(pnl_context *ctx, DevBuf &b, const T *src, size_t n) {
+    const size_t bytes = std::max<size_t>(n*sizeof(T), 16);
+    if (b.bytes < bytes) {
+        b.release();
+        HIPCHK(ctx, hipMalloc(&b.p, bytes));
+        b.bytes = bytes;
+    }
+    if (n) HIPCHK(ctx, hipMemcpyAsync(b.p, src, n*sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+    // host vectors passed here may be temporaries: make the copy synchronous
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return PNL_OK;
+}
+
+int ensure(pnl_context *ctx, DevBuf &b, size_t bytes) {
+    bytes = std::max<size_t>(bytes, 16);
+    if (b.bytes < bytes) {
+        b.release();
+        HIPCHK(ctx, hipMalloc(&b.p, bytes));
+        b.bytes = bytes;
+    }
+    return PNL_OK;
+}
+
+DevKernel to_dev(const pnl_kernel &k, int dim) {
+    DevKernel d;
+    d.ktype = k.ktype;
+    d.exponent = k.exponent;
+    d.scale = k.scale;
+    d.horizon2 = k.horizon2;
+    d.fast = (k.ktype == PNL_FRACTIONAL && k.exponent == -1.5 && std::isinf(k.horizon2) && dim == 2) ? 1 : 0;
+    return d;
+}
+
+DevFormula to_dev(const pnl_order_formula &f) {
+    DevFormula d;
+    d.c0 = f.c0; d.a = f.a; d.b = f.b; d.e = f.e; d.den0 = f.den0; d.clip = f.clip_num; d.pad = 0;
+    return d;
+}
+
+// Build everything derived from mesh + DoF map: padded SoA cell arrays, per-block unique DoF lists,
+// touching cell pairs (NO:311-323 shared-vertex test, done once through the vertex->cell adjacency),
+// touching cell/facet pairs.
+int finalize(pnl_context *ctx) {
+    if (!ctx->dirty) return PNL_OK;
+    if (!ctx->have_mesh || !ctx->have_dofs) return fail(ctx, PNL_ERR_STATE, "mesh and DoF map must be uploaded first");
+    const int dim = ctx->dim, nV = dim+1, nc = ctx->nc, dpe = ctx->dpe;
+    if (!((dim == 2 && (dpe == 3 || dpe == 6)) || (dim == 1 && dpe == 2)))
+        return fail(ctx, PNL_ERR_UNSUPPORTED, "unsupported (dim=%d, dofs_per_element=%d)", dim, dpe);
+    const int T = ctx->tile = (dpe == 6) ? TILE_P2 : TILE_P1;
+    const int nblocks = ctx->nblocks = (nc+T-1)/T;
+    const int ncp = ctx->ncp = nblocks*T;
+    const int NC = nV*dim;
+    std::vector<double> cellv((size_t)NC*ncp, 0.), ccen((size_t)dim*ncp, 0.), cvol(ncp, 0.), ch(ncp, 1.);
+    std::vector<int32_t> cvid((size_t)nV*ncp), cdof((size_t)dpe*ncp, -1);
+    for (int c = 0; c < ncp; c++) {
+        for (int k = 0; k < nV; k++) cvid[(size_t)k*ncp+c] = -1-k;
+        if (c >= nc) continue;
+        double cen[2] = {0., 0.};
+        for (int k = 0; k < nV; k++) {
+            const int v = ctx->cells[(size_t)c*nV+k];
+            if (v < 0 || v >= ctx->nv) return fail(ctx, PNL_ERR_INVALID, "cell %d references vertex %d", c, v);
+            cvid[(size_t)k*ncp+c] = v;
+            for (int d = 0; d < dim; d++) {
+                const double x = ctx->vertices[(size_t)v*dim+d];
+                cellv[(size_t)(k*dim+d)*ncp+c] = x;
+                cen[d] += x;
+            }
+        }
+        const double fac = 1./nV;                    // NO:116-126
+        for (int d = 0; d < dim; d++) ccen[(size_t)d*ncp+c] = cen[d]*fac;
+        cvol[c] = ctx->vol[c];
+        ch[c] = ctx->h[c];
+        for (int k = 0; k < dpe; k++) {
+            const int g = ctx->dofs[(size_t)c*dpe+k];
+            if (g >= ctx->N) return fail(ctx, PNL_ERR_INVALID, "DoF id %d >= num_dofs %d", g, ctx->N);
+            cdof[(size_t)k*ncp+c] = g;
+        }
+    }
+    // unique DoFs per block
+    std::vector<std::vector<int>> lists(nblocks);
+    int nU = 1;
+    for (int b = 0; b < nblocks; b++) {
+        auto &L = lists[b];
+        for (int c = b*T; c < std::min(nc, (b+1)*T); c++)
+            for (int k = 0; k < dpe; k++) {
+                const int g = ctx->dofs[(size_t)c*dpe+k];
+                if (g >= 0) L.push_back(g);
+            }
+        std::sort(L.begin(), L.end());
+        L.erase(std::unique(L.begin(), L.end()), L.end());
+        nU = std::max<int>(nU, (int)L.size());
+    }
+    ctx->nU = nU;
+    std::vector<int32_t> blk_ndof(nblocks), blk_dofs((size_t)nblocks*nU, 0);
+    std::vector<int16_t> cslot((size_t)dpe*ncp, -1);
+    for (int b = 0; b < nblocks; b++) {
+        auto &L = lists[b];
+        blk_ndof[b] = (int)L.size();
+        std::copy(L.begin(), L.end(), blk_dofs.begin()+(size_t)b*nU);
+        for (int c = b*T; c < std::min(nc, (b+1)*T); c++)
+            for (int k = 0; k < dpe; k++) {
+                const int g = ctx->dofs[(size_t)c*dpe+k];
+                if (g >= 0) cslot[(size_t)k*ncp+c] = (int16_t)(std::lower_bound(L.begin(), L.end(), g)-L.begin());
+            }
+    }
+    // touching cell pairs via vertex -> cells adjacency
+    std::vector<int> vptr(ctx->nv+1, 0);
+    for (int c = 0; c < nc; c++)
+        for (int k = 0; k < nV; k++) vptr[ctx->cells[(size_t)c*nV+k]+1]++;
+    for (int v = 0; v < ctx->nv; v++) vptr[v+1] += vptr[v];
+    std::vector<int> vcells(vptr[ctx->nv]), fill(vptr.begin(), vptr.end()-1);
+    for (int c = 0; c < nc; c++)
+        for (int k = 0; k < nV; k++) vcells[fill[ctx->cells[(size_t)c*nV+k]]++] = c;
+    for (int s = 0; s < 3; s++) ctx->spairs_host[s].clear();
+    {
+        std::vector<int> nbr;
+        for (int c1 = 0; c1 < nc; c1++) {
+            nbr.clear();
+            for (int k = 0; k < nV; k++) {
+                const int v = ctx->cells[(size_t)c1*nV+k];
+                for (int t = vptr[v]; t < vptr[v+1]; t++)
+                    if (vcells[t] >= c1) nbr.push_back(vcells[t]);
+            }
+            std::sort(nbr.begin(), nbr.end());
+            for (size_t t = 0; t < nbr.size();) {
+                size_t u = t;
+                while (u < nbr.size() && nbr[u] == nbr[t]) u++;
+                const int common = (nbr[t] == c1) ? nV : (int)(u-t);
+                if (common < 1 || common > nV) return fail(ctx, PNL_ERR_INVALID, "degenerate cell pair (%d,%d)", c1, nbr[t]);
+                ctx->spairs_host[common-1].push_back(make_int2(c1, nbr[t]));
+                t = u;
+            }
+        }
+    }
+    int rc;
+    for (int s = 0; s < 3; s++) {
+        ctx->n_spairs[s] = (int)ctx->spairs_host[s].size();
+        if ((rc = upload(ctx, ctx->b_spairs[s], ctx->spairs_host[s].data(), ctx->spairs_host[s].size()))) return rc;
+    }
+    // boundary facets
+    ctx->n_bpairs[0] = ctx->n_bpairs[1] = 0;
+    if (ctx->have_boundary) {
+        const int nF = dim, nb = ctx->nb;
+        std::vector<int32_t> bvid((size_t)nF*nb);
+        std::vector<double> bv((size_t)nF*dim*nb);
+        std::vector<int2> bp[2];
+        for (int f = 0; f < nb; f++) {
+            for (int k = 0; k < nF; k++) {
+                const int v = ctx->bcells[(size_t)f*nF+k];
+                if (v < 0 || v >= ctx->nv) return fail(ctx, PNL_ERR_INVALID, "facet %d references vertex %d", f, v);
+                bvid[(size_t)k*nb+f] = v;
+                for (int d = 0; d < dim; d++) bv[(size_t)(k*dim+d)*nb+f] = ctx->vertices[(size_t)v*dim+d];
+            }
+        }
+        {
+            std::vector<int> nbr;
+            for (int f = 0; f < nb; f++) {
+                nbr.clear();
+                for (int k = 0; k < nF; k++) {
+                    const int v = ctx->bcells[(size_t)f*nF+k];
+                    for (int t = vptr[v]; t < vptr[v+1]; t++) nbr.push_back(vcells[t]);
+                }
+                std::sort(nbr.begin(), nbr.end());
+                for (size_t t = 0; t < nbr.size();) {
+                    size_t u = t;
+                    while (u < nbr.size() && nbr[u] == nbr[t]) u++;
+                    const int common = (int)(u-t);
+                    if (common > nF) return fail(ctx, PNL_ERR_INVALID, "degenerate cell/facet pair");
+                    bp[common-1].push_back(make_int2(nbr[t], f));
+                    t = u;
+                }
+            }
+        }
+        for (int s = 0; s < 2; s++) {
+            ctx->n_bpairs[s] = (int)bp[s].size();
+            if ((rc = upload(ctx, ctx->b_bpairs[s], bp[s].data(), bp[s].size()))) return rc;
+        }
+        if ((rc = upload(ctx, ctx->b_bvid, bvid.data(), bvid.size()))) return rc;
+        if ((rc = upload(ctx, ctx->b_bv, bv.data(), bv.size()))) return rc;
+    }
+    if ((rc = upload(ctx, ctx->b_cellv, cellv.data(), cellv.size()))) return rc;
+    if ((rc = upload(ctx, ctx->b_ccen, ccen.data(), ccen.size()))) return rc;
+    if ((rc = upload(ctx, ctx->b_cvol, cvol.data(), cvol.size()))) return rc;
+    if ((rc = upload(ctx, ctx->b_ch, ch.data(), ch.size()))) return rc;
+    if ((rc = upload(ctx, ctx->b_cvid, cvid.data(), cvid.size()))) return rc;
+    if ((rc = upload(ctx, ctx->b_cdof, cdof.data(), cdof.size()))) return rc;
+    if ((rc = upload(ctx, ctx->b_cslot, cslot.data(), cslot.size()))) return rc;
+    if ((rc = upload(ctx, ctx->b_blk_ndof, blk_ndof.data(), blk_ndof.size()))) return rc;
+    if ((rc = upload(ctx, ctx->b_blk_dofs, blk_dofs.data(), blk_dofs.size()))) return rc;
+    if ((rc = upload(ctx, ctx->b_perm, ctx->perm_table.data(), ctx->perm_table.size()))) return rc;
+    if ((rc = ensure(ctx, ctx->b_counters, sizeof(unsigned long long)*PNL_NCOUNTERS))) return rc;
+    if ((rc = ensure(ctx, ctx->b_D, sizeof(double)*(size_t)ncp*(dpe*(dpe+1)/2)))) return rc;
+
+    DevProblem &P = ctx->P;
+    P.dim = dim; P.dpe = dpe; P.nc = nc; P.ncp = ncp; P.N = ctx->N; P.dpv = ctx->dpv; P.dped = ctx->dped; P.nb = ctx->nb;
+    P.H0 = ctx->H0;
+    P.cellv = (const double*)ctx->b_cellv.p; P.ccen = (const double*)ctx->b_ccen.p;
+    P.cvol = (const double*)ctx->b_cvol.p; P.ch = (const double*)ctx->b_ch.p;
+    P.cvid = (const int*)ctx->b_cvid.p; P.cdof = (const int*)ctx->b_cdof.p; P.cslot = (const short*)ctx->b_cslot.p;
+    P.blk_ndof = (const int*)ctx->b_blk_ndof.p; P.blk_dofs = (const int*)ctx->b_blk_dofs.p;
+    P.blk_stride = nU; P.nblocks = nblocks;
+    P.perm_table = (const int*)ctx->b_perm.p;
+    P.bvid = (const int*)ctx->b_bvid.p; P.bv = (const double*)ctx->b_bv.p;
+    P.counters = (unsigned long long*)ctx->b_counters.p;
+    ctx->dirty = false;
+    return PNL_OK;
+}
+
+void refresh_tables(pnl_context *ctx) {
+    DevProblem &P = ctx->P;
+    P.k = to_dev(ctx->kern[0], ctx->dim);
+    P.bk = to_dev(ctx->kern[1], ctx->dim);
+    P.qo = to_dev(ctx->form[0]);
+    P.bqo = to_dev(ctx->form[1]);
+    P.qmax = ctx->qmax;
+    P.off = (const int*)ctx->b_off.p; P.bary = (const double*)ctx->b_bary.p; P.w = (const double*)ctx->b_w.p;
+    P.phi = (const double*)ctx->b_phi.p; P.foff = (const int*)ctx->b_foff.p; P.fbary = (const double*)ctx->b_fbary.p;
+    P.fw = (const double*)ctx->b_fw.p;
+    for (int s = 0; s < 3; s++) {
+        P.sNodes[s] = (const double*)ctx->b_sn[s].p; P.sW[s] = (const double*)ctx->b_sw[s].p; P.sPsi[s] = (const double*)ctx->b_sp[s].p;
+    }
+    for (int s = 0; s < 2; s++) {
+        P.bNodes[s] = (const double*)ctx->b_bn[s].p; P.bW[s] = (const double*)ctx->b_bw[s].p; P.bPhi[s] = (const double*)ctx->b_bp[s].p;
+    }
+}
+
+template <int DIM, int DPE, int TILE, int KT>
+int launch_tiles(pnl_context *ctx, int ntiles, double *A, int64_t ldA, int cell_begin, int cell_end) {
+    using S = TileSmem<DIM, DPE, TILE>;
+    const int acc_stride = ctx->nU;
+    const size_t lds = S::fixed_bytes+sizeof(double)*(size_t)ctx->nU*acc_stride;
+    if (lds > 160*1024)
+        return fail(ctx, PNL_ERR_UNSUPPORTED, "a block of %d cells touches %d DoFs: LDS sub-block of %zu bytes exceeds 160 KiB "
+                    "(cells must be numbered with spatial locality)", TILE, ctx->nU, lds);
+    auto kfun = k_tile_distant<DIM, DPE, TILE, KT>;
+    HIPCHK(ctx, hipFuncSetAttribute((const void*)kfun, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kfun, dim3(ntiles), dim3(PNL_NTHREADS), lds, ctx->stream, ctx->P, (const int2*)ctx->b_tiles.p, A,
+                       (long long)ldA, (double*)ctx->b_D.p, cell_begin, cell_end, acc_stride);
+    HIPCHK(ctx, hipGetLastError());
+    return PNL_OK;
+}
+
+template <int DIM, int DPE, int KT>
+int launch_singular(pnl_context *ctx, double *A, int64_t ldA, int cell_begin, int cell_end) {
+    for (int s = 0; s < DIM+1; s++) {
+        const int np = ctx->n_spairs[s];
+        if (!np) continue;
+        if (!ctx->have_sing[0][s]) return fail(ctx, PNL_ERR_STATE, "singular rule for %d common vertices not uploaded", s+1);
+        const int grid = (np+3)/4;
+        const int2 *pairs = (const int2*)ctx->b_spairs[s].p;
+        if (s == 0) hipLaunchKernelGGL((k_singular_pairs<DIM, DPE, 0, KT>), dim3(grid), dim3(PNL_NTHREADS), 0, ctx->stream, ctx->P, pairs, np, A, (long long)ldA, cell_begin, cell_end);
+        else if (s == 1) hipLaunchKernelGGL((k_singular_pairs<DIM, DPE, 1, KT>), dim3(grid), dim3(PNL_NTHREADS), 0, ctx->stream, ctx->P, pairs, np, A, (long long)ldA, cell_begin, cell_end);
+        else if (DIM == 2) hipLaunchKernelGGL((k_singular_pairs<DIM, DPE, (DIM == 2 ? 2 : 1), KT>), dim3(grid), dim3(PNL_NTHREADS), 0, ctx->stream, ctx->P, pairs, np, A, (long long)ldA, cell_begin, cell_end);
+        HIPCHK(ctx, hipGetLastError());
+    }
+    return PNL_OK;
+}
+
+template <int DIM, int DPE, int KT>
+int launch_boundary(pnl_context *ctx, int cell_begin, int cell_end) {
+    if (ctx->nb == 0) return PNL_OK;
+    const int ncell = cell_end-cell_begin;
+    const int gx = (ncell+PNL_NTHREADS-1)/PNL_NTHREADS;
+    // enough chunks to fill the chip a few times over
+    int chunks = std::max(1, std::min(ctx->nb, (256*8+gx-1)/gx));
+    const int per = (ctx->nb+chunks-1)/chunks;
+    chunks = (ctx->nb+per-1)/per;
+    hipLaunchKernelGGL((k_boundary_distant<DIM, DPE, KT>), dim3(gx, chunks), dim3(PNL_NTHREADS), 0, ctx->stream, ctx->P,
+                       (double*)ctx->b_D.p, cell_begin, cell_end, per);
+    HIPCHK(ctx, hipGetLastError());
+    for (int s = 0; s < DIM; s++) {
+        const int np = ctx->n_bpairs[s];
+        if (!np) continue;
+        if (!ctx->have_sing[1][s]) return fail(ctx, PNL_ERR_STATE, "boundary singular rule for %d common vertices not uploaded", s+1);
+        const int grid = (np+3)/4;
+        const int2 *pairs = (const int2*)ctx->b_bpairs[s].p;
+        if (s == 0) hipLaunchKernelGGL((k_boundary_singular<DIM, DPE, 0, KT>), dim3(grid), dim3(PNL_NTHREADS), 0, ctx->stream, ctx->P, pairs, np, (double*)ctx->b_D.p, cell_begin, cell_end);
+        else hipLaunchKernelGGL((k_boundary_singular<DIM, DPE, (DIM == 2 ? 1 : 0), KT>), dim3(grid), dim3(PNL_NTHREADS), 0, ctx->stream, ctx->P, pairs, np, (double*)ctx->b_D.p, cell_begin, cell_end);
+        HIPCHK(ctx, hipGetLastError());
+    }
+    return PNL_OK;
+}
+
+template <int DIM, int DPE, int TILE>
+int assemble_impl(pnl_context *ctx, double *A, int64_t ldA, int zero_exterior, int ntiles, int cell_begin, int cell_end, int flags) {
+    int rc;
+    const int kt = ctx->P.k.fast ? 1 : 0, bkt = 0;
+    (void)bkt;
+    HIPCHK(ctx, hipMemsetAsync(ctx->b_counters.p, 0, sizeof(unsigned long long)*PNL_NCOUNTERS, ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(ctx->b_D.p, 0, sizeof(double)*(size_t)ctx->ncp*(DPE*(DPE+1)/2), ctx->stream));
+    HIPCHK(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
+    if (ntiles > 0) {
+        const int tb0 = ctx->tile_cell_filter ? cell_begin : 0, tb1 = ctx->tile_cell_filter ? cell_end : ctx->nc;
+        rc = kt ? launch_tiles<DIM, DPE, TILE, 1>(ctx, ntiles, A, ldA, tb0, tb1)
+                : launch_tiles<DIM, DPE, TILE, 0>(ctx, ntiles, A, ldA, tb0, tb1);
+        if (rc) return rc;
+    }
+    HIPCHK(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
+    // mirror the cross part before the symmetric contributions are added on both sides
+    if (!(flags & PNL_FLAG_NO_MIRROR)) {
+        const long long nb = (ctx->N+31)/32;
+        hipLaunchKernelGGL(k_mirror, dim3((unsigned)(nb*(nb+1)/2)), dim3(PNL_NTHREADS), 0, ctx->stream, A, (long long)ldA, ctx->N);
+        HIPCHK(ctx, hipGetLastError());
+    }
+    HIPCHK(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
+    rc = kt ? launch_singular<DIM, DPE, 1>(ctx, A, ldA, cell_begin, cell_end) : launch_singular<DIM, DPE, 0>(ctx, A, ldA, cell_begin, cell_end);
+    if (rc) return rc;
+    HIPCHK(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
+    if (zero_exterior) {
+        if (!ctx->have_boundary || !ctx->have_kernel[1] || !ctx->have_form[1])
+            return fail(ctx, PNL_ERR_STATE, "zero_exterior needs boundary facets, boundary kernel and order formula");
+        if ((rc = launch_boundary<DIM, DPE, 0>(ctx, cell_begin, cell_end))) return rc;
+    }
+    HIPCHK(ctx, hipEventRecord(ctx->ev[4], ctx->stream));
+    {
+        const long long nt = (long long)ctx->nc*DPE*DPE;
+        hipLaunchKernelGGL((k_scatter_diag<DPE>), dim3((unsigned)((nt+PNL_NTHREADS-1)/PNL_NTHREADS)), dim3(PNL_NTHREADS), 0,
+                           ctx->stream, ctx->P, (const double*)ctx->b_D.p, A, (long long)ldA);
+        HIPCHK(ctx, hipGetLastError());
+    }
+    HIPCHK(ctx, hipEventRecord(ctx->ev[5], ctx->stream));
+    ctx->ev_valid = true;
+    return PNL_OK;
+}
+
+int check_ready(pnl_context *ctx) {
+    if (!ctx->have_kernel[0] || !ctx->have_form[0] || !ctx->have_rules)
+        return fail(ctx, PNL_ERR_STATE, "kernel, order formula and distant rules must be set before assembling");
+    return PNL_OK;
+}
+
+int dispatch(pnl_context *ctx, double *A, int64_t ldA, int zero_exterior, int ntiles, int cell_begin, int cell_end, int flags) {
+    refresh_tables(ctx);
+    if (ctx->dim == 2 && ctx->dpe == 3) return assemble_impl<2, 3, TILE_P1>(ctx, A, ldA, zero_exterior, ntiles, cell_begin, cell_end, flags);
+    if (ctx->dim == 2 && ctx->dpe == 6) return assemble_impl<2, 6, TILE_P2>(ctx, A, ldA, zero_exterior, ntiles, cell_begin, cell_end, flags);
+    if (ctx->dim == 1 && ctx->dpe == 2) return assemble_impl<1, 2, TILE_P1>(ctx, A, ldA, zero_exterior, ntiles, cell_begin, cell_end, flags);
+    return fail(ctx, PNL_ERR_UNSUPPORTED, "unsupported (dim=%d, dofs_per_element=%d)", ctx->dim, ctx->dpe);
+}
+
+// ---- GEMV / CG kernels ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(PNL_NTHREADS)
+k_gemv(const double *__restrict__ A, long long ldA, int n, const double *__restrict__ x, double *__restrict__ y) {
+    // one wave per row; 16 B per lane per load
+    const int lane = threadIdx.x & 63;
+    const int row = (blockIdx.x*PNL_NTHREADS+threadIdx.x) >> 6;
+    if (row >= n) return;
+    const double *__restrict__ a = A+(long long)row*ldA;
+    double s0 = 0., s1 = 0.;
+    const bool aligned = (((uintptr_t)a) & 15) == 0;
+    if (aligned) {
+        const int n2 = n >> 1;
+        const double2 *a2 = (const double2*)a;
+        const double2 *x2 = (const double2*)x;
+        for (int j = lane; j < n2; j += 64) {
+            const double2 av = a2[j], xv = x2[j];
+            s0 = __builtin_fma(av.x, xv.x, s0);
+            s1 = __builtin_fma(av.y, xv.y, s1);
+        }
+        if ((n & 1) && lane == 0) s0 = __builtin_fma(a[n-1], x[n-1], s0);
+    } else {
+        for (int j = lane; j < n; j += 64) s0 = __builtin_fma(a[j], x[j], s0);
+    }
+    const double s = wave_sum(s0+s1);
+    if (lane == 0) y[row] = s;
+}
+
+// y += (A^T) x contribution for the one-sided storage: each wave takes a row I and adds A[I,J] x_I to y_J
+__global__ void __launch_bounds__(PNL_NTHREADS)
+k_gemv_t_add(const double *__restrict__ A, long long ldA, int n, const double *__restrict__ x, double *__restrict__ y,
+             int rows_per_block) {
+    // block handles rows [r0, r1): lane-owned column sums, then one atomic per column
+    const int r0 = blockIdx.y*rows_per_block, r1 = min(n, r0+rows_per_block);
+    const int j = blockIdx.x*PNL_NTHREADS+threadIdx.x;
+    if (j >= n) return;
+    double s = 0.;
+    for (int r = r0; r < r1; r++) s = __builtin_fma(A[(long long)r*ldA+j], x[r], s);
+    if (s != 0.) atomic_add_f64(&y[j], s);
+}
+
+__global__ void __launch_bounds__(PNL_NTHREADS) k_dot(const double *__restrict__ a, const double *__restrict__ b, int n, double *out) {
+    double s = 0.;
+    for (int i = blockIdx.x*PNL_NTHREADS+threadIdx.x; i < n; i += gridDim.x*PNL_NTHREADS) s = __builtin_fma(a[i], b[i], s);
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) atomic_add_f64(out, s);
+}
+
+__global__ void __launch_bounds__(PNL_NTHREADS) k_diag_inv(const double *__restrict__ A, long long ldA, int n, double *__restrict__ dinv) {
+    const int i = blockIdx.x*PNL_NTHREADS+threadIdx.x;
+    if (i < n) dinv[i] = 1./A[(long long)i*ldA+i];
+}
+
+// r = b - Ax given Ax in t ; z = dinv*r ; p = z
+__global__ void __launch_bounds__(PNL_NTHREADS)
+k_cg_init(const double *__restrict__ b, const double *__restrict__ Ax, const double *__restrict__ dinv, int n, double *r, double *p) {
+    const int i = blockIdx.x*PNL_NTHREADS+threadIdx.x;
+    if (i < n) { const double ri = b[i]-Ax[i]; r[i] = ri; p[i] = dinv[i]*ri; }
+}
+
+// x += alpha p ; r -= alpha Ap ; z = dinv r   (alpha = scal[0]/scal[1])
+__global__ void __launch_bounds__(PNL_NTHREADS)
+k_cg_update(const double *__restrict__ scal, const double *__restrict__ p, const double *__restrict__ Ap,
+            const double *__restrict__ dinv, int n, double *x, double *r, double *z) {
+    const int i = blockIdx.x*PNL_NTHREADS+threadIdx.x;
+    const double alpha = scal[0]/scal[1];
+    if (i < n) {
+        x[i] = __builtin_fma(alpha, p[i], x[i]);
+        const double ri = __builtin_fma(-alpha, Ap[i], r[i]);
+        r[i] = ri;
+        z[i] = dinv[i]*ri;
+    }
+}
+
+// p = z + (beta/betaOld) p   (beta = scal[2], betaOld = scal[0])
+__global__ void __launch_bounds__(PNL_NTHREADS)
+k_cg_dir(const double *__restrict__ scal, const double *__restrict__ z, int n, double *p) {
+    const int i = blockIdx.x*PNL_NTHREADS+threadIdx.x;
+    const double t = scal[2]/scal[0];
+    if (i < n) p[i] = __builtin_fma(t, p[i], z[i]);
+}
+
+}  // namespace
+
+// =================================================================================================
+extern "C" {
+
+const char *pnl_version(void) { return "pnl_hip 0.1 (gfx950)"; }
+
+int pnl_create(int device_id, pnl_context **out) {
+    if (!out) return PNL_ERR_INVALID;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return PNL_ERR_HIP;
+    if (device_id < 0 || device_id >= ndev) return PNL_ERR_INVALID;
+    if (hipSetDevice(device_id) != hipSuccess) return PNL_ERR_HIP;
+    pnl_context *ctx = new pnl_context();
+    ctx->device = device_id;
+    if (hipStreamCreate(&ctx->own_stream) != hipSuccess) { delete ctx; return PNL_ERR_HIP; }
+    ctx->stream = ctx->own_stream;
+    for (auto &e : ctx->ev)
+        if (hipEventCreate(&e) != hipSuccess) { delete ctx; return PNL_ERR_HIP; }
+    std::memset(&ctx->P, 0, sizeof(ctx->P));
+    std::memset(ctx->kern, 0, sizeof(ctx->kern));
+    std::memset(ctx->form, 0, sizeof(ctx->form));
+    *out = ctx;
+    return PNL_OK;
+}
+
+void pnl_destroy(pnl_context *ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto &e : ctx->ev)
+        if (e) (void)hipEventDestroy(e);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+}
+
+const char *pnl_error_string(pnl_context *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int pnl_set_stream(pnl_context *ctx, void *hip_stream) {
+    if (!ctx) return PNL_ERR_INVALID;
+    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    return PNL_OK;
+}
+
+int pnl_synchronize(pnl_context *ctx) {
+    if (!ctx) return PNL_ERR_INVALID;
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return PNL_OK;
+}
+
+int pnl_upload_mesh(pnl_context *ctx, int dim, int nv, const double *vertices, int nc, const int32_t *cells,
+                    const double *vol, const double *h, double H0) {
+    if (!ctx) return PNL_ERR_INVALID;
+    if (dim != 1 && dim != 2) return fail(ctx, PNL_ERR_UNSUPPORTED, "dim=%d is not implemented", dim);
+    if (nv <= 0 || nc <= 0 || !vertices || !cells || !vol || !h || !(H0 > 0.)) return fail(ctx, PNL_ERR_INVALID, "bad mesh arguments");
+    ctx->dim = dim; ctx->nv = nv; ctx->nc = nc; ctx->H0 = H0;
+    ctx->vertices.assign(vertices, vertices+(size_t)nv*dim);
+    ctx->cells.assign(cells, cells+(size_t)nc*(dim+1));
+    ctx->vol.assign(vol, vol+nc);
+    ctx->h.assign(h, h+nc);
+    ctx->have_mesh = true;
+    ctx->dirty = true;
+    return PNL_OK;
+}
+
+int pnl_upload_dofmap(pnl_context *ctx, int dpe, int dofs_per_vertex, int dofs_per_edge, int num_dofs, const int32_t *dofs,
+                      const int32_t *perm_table) {
+    if (!ctx) return PNL_ERR_INVALID;
+    if (!ctx->have_mesh) return fail(ctx, PNL_ERR_STATE, "upload the mesh first");
+    if (dpe <= 0 || num_dofs <= 0 || !dofs || !perm_table) return fail(ctx, PNL_ERR_INVALID, "bad DoF map arguments");
+    // NA:941: the local matrix must fit the mask type (256 bits in the reference)
+    if ((2*dpe)*(2*dpe+1)/2 > 256) return fail(ctx, PNL_ERR_INVALID, "local matrix has more than 256 entries");
+    ctx->dpe = dpe; ctx->dpv = dofs_per_vertex; ctx->dped = dofs_per_edge; ctx->N = num_dofs;
+    ctx->dofs.assign(dofs, dofs+(size_t)ctx->nc*dpe);
+    int nperm = 1;
+    for (int k = 2; k <= ctx->dim+1; k++) nperm *= k;
+    ctx->perm_table.assign(perm_table, perm_table+(size_t)nperm*dpe);
+    ctx->have_dofs = true;
+    ctx->dirty = true;
+    return PNL_OK;
+}
+
+int pnl_set_kernel(pnl_context *ctx, int which, const pnl_kernel *k) {
+    if (!ctx || !k || which < 0 || which > 1) return fail(ctx, PNL_ERR_INVALID, "bad kernel arguments");
+    if (k->ktype < 0 || k->ktype > 2) return fail(ctx, PNL_ERR_UNSUPPORTED, "kernel type %d is not implemented", k->ktype);
+    if (!std::isinf(k->horizon2) && which == PNL_INTERIOR)
+        return fail(ctx, PNL_ERR_UNSUPPORTED, "finite-horizon kernels (cut elements) are not implemented on the GPU path yet");
+    ctx->kern[which] = *k;
+    ctx->have_kernel[which] = true;
+    return PNL_OK;
+}
+
+int pnl_set_order_formula(pnl_context *ctx, int which, const pnl_order_formula *f) {
+    if (!ctx || !f || which < 0 || which > 1) return fail(ctx, PNL_ERR_INVALID, "bad order-formula arguments");
+    ctx->form[which] = *f;
+    ctx->have_form[which] = true;
+    return PNL_OK;
+}
+
+int pnl_upload_distant_rules(pnl_context *ctx, int qmax, const int32_t *off, const double *bary, const double *w,
+                             const double *phi, const int32_t *foff, const double *fbary, const double *fw) {
+    if (!ctx) return PNL_ERR_INVALID;
+    if (!ctx->have_dofs) return fail(ctx, PNL_ERR_STATE, "upload the DoF map first");
+    if (qmax < 2 || qmax > PNL_MAXQ || !off || !bary || !w || !phi || !foff || !fbary || !fw)
+        return fail(ctx, PNL_ERR_INVALID, "bad rule arguments (2 <= qmax <= %d)", PNL_MAXQ);
+    const int total = off[qmax+1], ftotal = foff[qmax+1];
+    int rc;
+    if ((rc = upload(ctx, ctx->b_off, off, (size_t)qmax+2))) return rc;
+    if ((rc = upload(ctx, ctx->b_bary, bary, (size_t)total*3))) return rc;
+    if ((rc = upload(ctx, ctx->b_w, w, (size_t)total))) return rc;
+    if ((rc = upload(ctx, ctx->b_phi, phi, (size_t)total*ctx->dpe))) return rc;
+    if ((rc = upload(ctx, ctx->b_foff, foff, (size_t)qmax+2))) return rc;
+    if ((rc = upload(ctx, ctx->b_fbary, fbary, (size_t)ftotal*2))) return rc;
+    if ((rc = upload(ctx, ctx->b_fw, fw, (size_t)ftotal))) return rc;
+    ctx->qmax = qmax;
+    ctx->have_rules = true;
+    return PNL_OK;
+}
+
+int pnl_upload_singular_rule(pnl_context *ctx, int which, int panel, int M, int rows, const double *nodes, const double *w,
+                             const double *psi, double facv) {
+    if (!ctx) return PNL_ERR_INVALID;
+    if (!ctx->have_dofs) return fail(ctx, PNL_ERR_STATE, "upload the DoF map first");
+    const int slot = -panel-1;
+    const int nslots = which == PNL_INTERIOR ? ctx->dim+1 : ctx->dim;
+    if (which < 0 || which > 1 || slot < 0 || slot >= nslots || M <= 0 || rows <= 0 || !nodes || !w || !psi)
+        return fail(ctx, PNL_ERR_INVALID, "bad singular-rule arguments");
+    const int dim = ctx->dim, dpe = ctx->dpe, dpv = ctx->dpv, dped = ctx->dped, nV = dim+1;
+    int rc;
+    if (which == PNL_INTERIOR) {
+        const int common = slot+1;
+        const int expect = common == nV ? dpe : (common == 1 ? 2*dpe-dpv : 2*dpe-2*dpv-dped);
+        if (rows != expect) return fail(ctx, PNL_ERR_INVALID, "singular rule has %d rows, expected %d", rows, expect);
+        if ((rc = upload(ctx, ctx->b_sn[slot], nodes, (size_t)2*nV*M))) return rc;
+        if ((rc = upload(ctx, ctx->b_sw[slot], w, (size_t)M))) return rc;
+        if ((rc = upload(ctx, ctx->b_sp[slot], psi, (size_t)rows*M))) return rc;
+        ctx->P.sM[slot] = M; ctx->P.sRows[slot] = rows; ctx->P.sFac = facv;
+    } else {
+        if (rows != dpe) return fail(ctx, PNL_ERR_INVALID, "boundary singular rule has %d rows, expected %d", rows, dpe);
+        if ((rc = upload(ctx, ctx->b_bn[slot], nodes, (size_t)(nV+dim)*M))) return rc;
+        if ((rc = upload(ctx, ctx->b_bw[slot], w, (size_t)M))) return rc;
+        if ((rc = upload(ctx, ctx->b_bp[slot], psi, (size_t)rows*M))) return rc;
+        ctx->P.bM[slot] = M; ctx->P.bFac = facv;
+    }
+    ctx->have_sing[which][slot] = true;
+    return PNL_OK;
+}
+
+int pnl_upload_boundary(pnl_context *ctx, int nb, const int32_t *bcells) {
+    if (!ctx) return PNL_ERR_INVALID;
+    if (!ctx->have_mesh) return fail(ctx, PNL_ERR_STATE, "upload the mesh first");
+    if (nb < 0 || (nb > 0 && !bcells)) return fail(ctx, PNL_ERR_INVALID, "bad boundary arguments");
+    ctx->nb = nb;
+    ctx->bcells.assign(bcells, bcells+(size_t)nb*ctx->dim);
+    ctx->have_boundary = true;
+    ctx->dirty = true;
+    return PNL_OK;
+}
+
+int pnl_tile_cells(pnl_context *ctx) {
+    if (!ctx) return PNL_ERR_INVALID;
+    int rc = finalize(ctx);
+    return rc ? rc : ctx->tile;
+}
+
+static int make_tiles(pnl_context *ctx, std::vector<int2> &tiles, int cell_begin, int cell_end) {
+    const int T = ctx->tile, nbk = ctx->nblocks;
+    const int a0 = cell_begin/T, a1 = (cell_end+T-1)/T;
+    // heavy (near-diagonal) tiles first
+    for (int d = 0; d < nbk; d++)
+        for (int a = a0; a < a1 && a+d < nbk; a++) tiles.push_back(make_int2(a, a+d));
+    return PNL_OK;
+}
+
+int pnl_assemble_dense(pnl_context *ctx, double *A, int64_t ldA, int zero_exterior, int cell_begin, int cell_end, int flags) {
+    if (!ctx) return PNL_ERR_INVALID;
+    int rc;
+    if ((rc = check_ready(ctx))) return rc;
+    if ((rc = finalize(ctx))) return rc;
+    if (!A || ldA < ctx->N) return fail(ctx, PNL_ERR_INVALID, "bad output matrix (ldA=%lld, num_dofs=%d)", (long long)ldA, ctx->N);
+    if (cell_begin < 0 || cell_end > ctx->nc || cell_begin > cell_end) return fail(ctx, PNL_ERR_INVALID, "bad cell range");
+    std::vector<int2> tiles;
+    if (cell_end > cell_begin) make_tiles(ctx, tiles, cell_begin, cell_end);
+    if ((rc = upload(ctx, ctx->b_tiles, tiles.data(), tiles.size()))) return rc;
+    // pairs visited by the reference loop: c1 in [begin,end), c2 in [c1, nc)
+    unsigned long long visited = 0;
+    for (long long c = cell_begin; c < cell_end; c++) visited += (unsigned long long)(ctx->nc-c);
+    ctx->visited_pairs = visited;
+    return dispatch(ctx, A, ldA, zero_exterior, (int)tiles.size(), cell_begin, cell_end, flags);
+}
+
+int pnl_assemble_dense_tiles(pnl_context *ctx, double *A, int64_t ldA, int zero_exterior, int ntiles, const int32_t *tiles_host,
+                             int cell_begin, int cell_end, int flags) {
+    if (!ctx) return PNL_ERR_INVALID;
+    int rc;
+    if ((rc = check_ready(ctx))) return rc;
+    if ((rc = finalize(ctx))) return rc;
+    if (!A || ldA < ctx->N || ntiles < 0 || (ntiles && !tiles_host)) return fail(ctx, PNL_ERR_INVALID, "bad arguments");
+    if (cell_begin < 0 || cell_end > ctx->nc || cell_begin > cell_end) return fail(ctx, PNL_ERR_INVALID, "bad cell range");
+    std::vector<int2> tiles(ntiles);
+    for (int i = 0; i < ntiles; i++) {
+        tiles[i] = make_int2(tiles_host[2*i], tiles_host[2*i+1]);
+        if (tiles[i].x < 0 || tiles[i].y >= ctx->nblocks || tiles[i].x > tiles[i].y) return fail(ctx, PNL_ERR_INVALID, "bad tile %d", i);
+    }
+    if ((rc = upload(ctx, ctx->b_tiles, tiles.data(), tiles.size()))) return rc;
+    ctx->visited_pairs = 0;
+    ctx->tile_cell_filter = false;
+    rc = dispatch(ctx, A, ldA, zero_exterior, ntiles, cell_begin, cell_end, flags);
+    ctx->tile_cell_filter = true;
+    return rc;
+}
+
+int pnl_inv_diagonal(pnl_context *ctx, const double *A, int64_t ldA, int n, double *dinv) {
+    if (!ctx || !A || !dinv || n <= 0 || ldA < n) return fail(ctx, PNL_ERR_INVALID, "bad arguments");
+    hipLaunchKernelGGL(k_diag_inv, dim3((n+PNL_NTHREADS-1)/PNL_NTHREADS), dim3(PNL_NTHREADS), 0, ctx->stream, A, (long long)ldA, n, dinv);
+    HIPCHK(ctx, hipGetLastError());
+    return PNL_OK;
+}
+
+int pnl_get_counters(pnl_context *ctx, int64_t *out, int n) {
+    if (!ctx || !out || n <= 0) return PNL_ERR_INVALID;
+    if (!ctx->b_counters.p) return fail(ctx, PNL_ERR_STATE, "nothing assembled yet");
+    unsigned long long tmp[PNL_NCOUNTERS];
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, hipMemcpy(tmp, ctx->b_counters.p, sizeof(tmp), hipMemcpyDeviceToHost));
+    tmp[0] = ctx->visited_pairs;
+    for (int i = 0; i < n && i < PNL_NCOUNTERS; i++) out[i] = (int64_t)tmp[i];
+    if (tmp[5]) return fail(ctx, PNL_ERR_ORDER, "%llu pairs need a quadrature order beyond the uploaded tables (qmax=%d)", tmp[5], ctx->qmax);
+    return PNL_OK;
+}
+
+int pnl_get_phase_ms(pnl_context *ctx, float *out, int n) {
+    if (!ctx || !out || n <= 0) return PNL_ERR_INVALID;
+    if (!ctx->ev_valid) return fail(ctx, PNL_ERR_STATE, "nothing assembled yet");
+    HIPCHK(ctx, hipEventSynchronize(ctx->ev[5]));
+    float t[5] = {0, 0, 0, 0, 0}, tmp;
+    HIPCHK(ctx, hipEventElapsedTime(&t[0], ctx->ev[0], ctx->ev[1]));      // tiles
+    HIPCHK(ctx, hipEventElapsedTime(&tmp, ctx->ev[1], ctx->ev[2]));       // mirror
+    HIPCHK(ctx, hipEventElapsedTime(&t[1], ctx->ev[2], ctx->ev[3]));      // singular
+    HIPCHK(ctx, hipEventElapsedTime(&t[2], ctx->ev[3], ctx->ev[4]));      // boundary
+    HIPCHK(ctx, hipEventElapsedTime(&t[3], ctx->ev[4], ctx->ev[5]));      // diagonal scatter
+    t[3] += tmp;
+    HIPCHK(ctx, hipEventElapsedTime(&t[4], ctx->ev[0], ctx->ev[5]));
+    for (int i = 0; i < n && i < 5; i++) out[i] = t[i];
+    return PNL_OK;
+}
+
+int pnl_gemv(pnl_context *ctx, const double *A, int64_t ldA, int n, const double *x, double *y, int symmetric_half) {
+    if (!ctx || !A || !x || !y || n <= 0 || ldA < n) return fail(ctx, PNL_ERR_INVALID, "bad gemv arguments");
+    hipLaunchKernelGGL(k_gemv, dim3((n+3)/4), dim3(PNL_NTHREADS), 0, ctx->stream, A, (long long)ldA, n, x, y);
+    HIPCHK(ctx, hipGetLastError());
+    if (symmetric_half) {
+        const int rows = 128;
+        hipLaunchKernelGGL(k_gemv_t_add, dim3((n+PNL_NTHREADS-1)/PNL_NTHREADS, (n+rows-1)/rows), dim3(PNL_NTHREADS), 0, ctx->stream,
+                           A, (long long)ldA, n, x, y, rows);
+        HIPCHK(ctx, hipGetLastError());
+    }
+    return PNL_OK;
+}
+
+int pnl_cg_jacobi(pnl_context *ctx, const double *A, int64_t ldA, int n, const double *b, double *x, double tol, int maxiter,
+                  int *iters, double *residual) {
+    if (!ctx || !A || !b || !x || n <= 0 || ldA < n || maxiter < 0) return fail(ctx, PNL_ERR_INVALID, "bad cg arguments");
+    int rc;
+    for (int i = 0; i < 5; i++)
+        if ((rc = ensure(ctx, ctx->b_vec[i], sizeof(double)*n))) return rc;
+    if ((rc = ensure(ctx, ctx->b_scal, sizeof(double)*4))) return rc;
+    double *r = (double*)ctx->b_vec[0].p, *p = (double*)ctx->b_vec[1].p, *Ap = (double*)ctx->b_vec[2].p,
+           *z = (double*)ctx->b_vec[3].p, *dinv = (double*)ctx->b_vec[4].p, *scal = (double*)ctx->b_scal.p;
+    const int gv = (n+PNL_NTHREADS-1)/PNL_NTHREADS, gd = std::min(gv, 1024);
+    hipStream_t st = ctx->stream;
+    auto dot = [&](const double *u, const double *v, int slot) {
+        (void)hipMemsetAsync(scal+slot, 0, sizeof(double), st);
+        hipLaunchKernelGGL(k_dot, dim3(gd), dim3(PNL_NTHREADS), 0, st, u, v, n, scal+slot);
+    };
+    double hs[4];
+    // solvers.pyx:363-444 with the Jacobi preconditioner (:229-245); convergence in the preconditioner norm
+    hipLaunchKernelGGL(k_diag_inv, dim3(gv), dim3(PNL_NTHREADS), 0, st, A, (long long)ldA, n, dinv);
+    hipLaunchKernelGGL(k_gemv, dim3((n+3)/4), dim3(PNL_NTHREADS), 0, st, A, (long long)ldA, n, (const double*)x, Ap);
+    hipLaunchKernelGGL(k_cg_init, dim3(gv), dim3(PNL_NTHREADS), 0, st, b, (const double*)Ap, (const double*)dinv, n, r, p);
+    dot(r, p, 0);                                                // betaOld = r . Br
+    HIPCHK(ctx, hipMemcpyAsync(hs, scal, sizeof(double), hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipStreamSynchronize(st));
+    double conv = std::sqrt(hs[0]);
+    int it = 0, k = 0;
+    if (conv > tol) {
+        for (it = 0; it < maxiter; it++) {
+            hipLaunchKernelGGL(k_gemv, dim3((n+3)/4), dim3(PNL_NTHREADS), 0, st, A, (long long)ldA, n, (const double*)p, Ap);
+            dot(p, Ap, 1);
+            hipLaunchKernelGGL(k_cg_update, dim3(gv), dim3(PNL_NTHREADS), 0, st, (const double*)scal, (const double*)p,
+                               (const double*)Ap, (const double*)dinv, n, x, r, z);
+            if (k == 50) {
+                // recalculate the residual to limit rounding drift (solvers.pyx:412-415)
+                hipLaunchKernelGGL(k_gemv, dim3((n+3)/4), dim3(PNL_NTHREADS), 0, st, A, (long long)ldA, n, (const double*)x, Ap);
+                hipLaunchKernelGGL(k_cg_init, dim3(gv), dim3(PNL_NTHREADS), 0, st, b, (const double*)Ap, (const double*)dinv, n, r, z);
+                k = 0;
+            }
+            dot(r, z, 2);                                        // beta = r . Br
+            HIPCHK(ctx, hipMemcpyAsync(hs, scal, 3*sizeof(double), hipMemcpyDeviceToHost, st));
+            HIPCHK(ctx, hipStreamSynchronize(st));
+            conv = std::sqrt(hs[2]);
+            if (conv <= tol) break;
+            hipLaunchKernelGGL(k_cg_dir, dim3(gv), dim3(PNL_NTHREADS), 0, st, (const double*)scal, (const double*)z, n, p);
+            // betaOld = beta
+            HIPCHK(ctx, hipMemcpyAsync(scal, scal+2, sizeof(double), hipMemcpyDeviceToDevice, st));
+            k++;
+        }
+    }
+    HIPCHK(ctx, hipGetLastError());
+    if (iters) *iters = it;
+    if (residual) *residual = conv;
+    return PNL_OK;
+}
+
+}  // extern "C"
