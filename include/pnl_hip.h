@@ -130,7 +130,8 @@ int pnl_assemble_dense_tiles(pnl_context *ctx, double *A_dev, int64_t ldA, int z
 /* counters of the last assemble call (synchronises the stream) */
 int pnl_get_counters(pnl_context *ctx, int64_t *out, int n);
 /* device time of the last assemble call per phase in milliseconds (HIP events on the context's stream):
- * [0] distant tiles, [1] singular pairs, [2] boundary, [3] scatter+mirror, [4] total */
+ * [0] tile kernel (distant pairs, one per lane), [1] work-list kernel (distant pairs, one per wave),
+ * [2] singular pairs, [3] boundary term, [4] mirror + diagonal scatter, [5] total */
 int pnl_get_phase_ms(pnl_context *ctx, float *out, int n);
 
 /* ---- adjacent solve path: Dense_LinearOperator.matvec (dgemv, DenseLinearOperator_{SCALAR}.pxi:14-18)

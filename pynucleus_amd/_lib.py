@@ -201,10 +201,10 @@ class Context:
                     numBoundaryPairs=int(out[3]), numBoundaryIntegrations=int(out[4]), orders=hist, singular=sing)
 
     def phase_ms(self):
-        out = np.zeros(5, dtype=np.float32)
-        self.check(self.L.pnl_get_phase_ms(self.h, out.ctypes.data, 5))
-        return dict(tiles=float(out[0]), singular=float(out[1]), boundary=float(out[2]), scatter_mirror=float(out[3]),
-                    total=float(out[4]))
+        out = np.zeros(6, dtype=np.float32)
+        self.check(self.L.pnl_get_phase_ms(self.h, out.ctypes.data, 6))
+        return dict(tiles=float(out[0]), worklist=float(out[1]), singular=float(out[2]), boundary=float(out[3]),
+                    scatter_mirror=float(out[4]), total=float(out[5]))
 
     def gemv(self, A_ptr, ldA, n, x_ptr, y_ptr, symmetric_half=False):
         self.check(self.L.pnl_gemv(self.h, C.c_void_p(A_ptr), int(ldA), int(n), C.c_void_p(x_ptr), C.c_void_p(y_ptr),

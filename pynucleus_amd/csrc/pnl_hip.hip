@@ -47,14 +47,18 @@ struct pnl_context {
     DevProblem P;
     DevBuf b_cellv, b_ccen, b_cvol, b_ch, b_cvid, b_cdof, b_cslot, b_blk_ndof, b_blk_dofs, b_perm, b_off, b_bary, b_w, b_phi,
         b_foff, b_fbary, b_fw, b_sn[3], b_sw[3], b_sp[3], b_bn[2], b_bw[2], b_bp[2], b_bvid, b_bv, b_counters, b_D, b_tiles,
-        b_spairs[3], b_bpairs[2], b_vec[6], b_scal;
+        b_spairs[3], b_bpairs[2], b_vec[6], b_scal, b_wl, b_wlcount;
+    unsigned wl_cap = 0;
     int tile = TILE_P1, nblocks = 0, ncp = 0, nU = 0;
     int n_spairs[3] = {0, 0, 0}, n_bpairs[2] = {0, 0};
     std::vector<int2> spairs_host[3];
+    std::vector<int2> tiles_cached;   // tile list currently resident in b_tiles
     size_t tiles_cap = 0;
-    hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     bool ev_valid = false;
     unsigned long long visited_pairs = 0;
+    bool tiles_launched = false;
+    int ablate = 0;                 // debug: PNL_ABLATE env bits (1 no LDS accumulate, 2 no evaluation)
     bool tile_cell_filter = true;   // apply [cell_begin, cell_end) to the a-cells of the tiles too
 };
 
@@ -308,13 +312,33 @@ int launch_tiles(pnl_context *ctx, int ntiles, double *A, int64_t ldA, int cell_
     using S = TileSmem<DIM, DPE, TILE>;
     const int acc_stride = ctx->nU;
     const size_t lds = S::fixed_bytes+sizeof(double)*(size_t)ctx->nU*acc_stride;
+    if (getenv("PNL_VERBOSE")) fprintf(stderr, "[pnl] tiles=%d nU=%d lds=%zu bytes\n", ntiles, ctx->nU, lds);
     if (lds > 160*1024)
         return fail(ctx, PNL_ERR_UNSUPPORTED, "a block of %d cells touches %d DoFs: LDS sub-block of %zu bytes exceeds 160 KiB "
                     "(cells must be numbered with spatial locality)", TILE, ctx->nU, lds);
+    // work list for the orders that are integrated one pair per wave; sized generously, overflow is detected
+    {
+        const double pairs = (double)ntiles*TILE*TILE;
+        const size_t want = (size_t)std::min<double>(std::max<double>(pairs*0.05, 1<<20), 400e6);
+        if (ctx->wl_cap < want) {
+            int rc;
+            if ((rc = ensure(ctx, ctx->b_wl, want*sizeof(int4)))) return rc;
+            ctx->wl_cap = (unsigned)want;
+        }
+        int rc;
+        if ((rc = ensure(ctx, ctx->b_wlcount, sizeof(unsigned)))) return rc;
+        HIPCHK(ctx, hipMemsetAsync(ctx->b_wlcount.p, 0, sizeof(unsigned), ctx->stream));
+    }
     auto kfun = k_tile_distant<DIM, DPE, TILE, KT>;
     HIPCHK(ctx, hipFuncSetAttribute((const void*)kfun, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kfun, dim3(ntiles), dim3(PNL_NTHREADS), lds, ctx->stream, ctx->P, (const int2*)ctx->b_tiles.p, A,
-                       (long long)ldA, (double*)ctx->b_D.p, cell_begin, cell_end, acc_stride);
+                       (long long)ldA, (double*)ctx->b_D.p, cell_begin, cell_end, acc_stride, (int4*)ctx->b_wl.p,
+                       (unsigned*)ctx->b_wlcount.p, ctx->wl_cap, ctx->ablate);
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipEventRecord(ctx->ev[6], ctx->stream));
+    hipLaunchKernelGGL((k_worklist_pairs<DIM, DPE, KT>), dim3(256*8), dim3(PNL_NTHREADS), 0, ctx->stream, ctx->P,
+                       (const int4*)ctx->b_wl.p, (const unsigned*)ctx->b_wlcount.p, ctx->wl_cap, A, (long long)ldA,
+                       (double*)ctx->b_D.p);
     HIPCHK(ctx, hipGetLastError());
     return PNL_OK;
 }
@@ -368,6 +392,7 @@ int assemble_impl(pnl_context *ctx, double *A, int64_t ldA, int zero_exterior, i
     HIPCHK(ctx, hipMemsetAsync(ctx->b_counters.p, 0, sizeof(unsigned long long)*PNL_NCOUNTERS, ctx->stream));
     HIPCHK(ctx, hipMemsetAsync(ctx->b_D.p, 0, sizeof(double)*(size_t)ctx->ncp*(DPE*(DPE+1)/2), ctx->stream));
     HIPCHK(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
+    ctx->tiles_launched = ntiles > 0;
     if (ntiles > 0) {
         const int tb0 = ctx->tile_cell_filter ? cell_begin : 0, tb1 = ctx->tile_cell_filter ? cell_end : ctx->nc;
         rc = kt ? launch_tiles<DIM, DPE, TILE, 1>(ctx, ntiles, A, ldA, tb0, tb1)
@@ -518,6 +543,7 @@ int pnl_create(int device_id, pnl_context **out) {
     for (auto &e : ctx->ev)
         if (hipEventCreate(&e) != hipSuccess) { delete ctx; return PNL_ERR_HIP; }
     std::memset(&ctx->P, 0, sizeof(ctx->P));
+    if (const char *e = getenv("PNL_ABLATE")) ctx->ablate = atoi(e);
     std::memset(ctx->kern, 0, sizeof(ctx->kern));
     std::memset(ctx->form, 0, sizeof(ctx->form));
     *out = ctx;
@@ -663,6 +689,17 @@ int pnl_tile_cells(pnl_context *ctx) {
     return rc ? rc : ctx->tile;
 }
 
+static int upload_tiles(pnl_context *ctx, std::vector<int2> &tiles) {
+    // repeated assemblies of the same work list keep it resident
+    if (tiles.size() == ctx->tiles_cached.size() && ctx->b_tiles.p &&
+        (tiles.empty() || std::memcmp(tiles.data(), ctx->tiles_cached.data(), tiles.size()*sizeof(int2)) == 0))
+        return PNL_OK;
+    int rc = upload(ctx, ctx->b_tiles, tiles.data(), tiles.size());
+    if (rc) return rc;
+    ctx->tiles_cached = tiles;
+    return PNL_OK;
+}
+
 static int make_tiles(pnl_context *ctx, std::vector<int2> &tiles, int cell_begin, int cell_end) {
     const int T = ctx->tile, nbk = ctx->nblocks;
     const int a0 = cell_begin/T, a1 = (cell_end+T-1)/T;
@@ -681,7 +718,7 @@ int pnl_assemble_dense(pnl_context *ctx, double *A, int64_t ldA, int zero_exteri
     if (cell_begin < 0 || cell_end > ctx->nc || cell_begin > cell_end) return fail(ctx, PNL_ERR_INVALID, "bad cell range");
     std::vector<int2> tiles;
     if (cell_end > cell_begin) make_tiles(ctx, tiles, cell_begin, cell_end);
-    if ((rc = upload(ctx, ctx->b_tiles, tiles.data(), tiles.size()))) return rc;
+    if ((rc = upload_tiles(ctx, tiles))) return rc;
     // pairs visited by the reference loop: c1 in [begin,end), c2 in [c1, nc)
     unsigned long long visited = 0;
     for (long long c = cell_begin; c < cell_end; c++) visited += (unsigned long long)(ctx->nc-c);
@@ -702,7 +739,7 @@ int pnl_assemble_dense_tiles(pnl_context *ctx, double *A, int64_t ldA, int zero_
         tiles[i] = make_int2(tiles_host[2*i], tiles_host[2*i+1]);
         if (tiles[i].x < 0 || tiles[i].y >= ctx->nblocks || tiles[i].x > tiles[i].y) return fail(ctx, PNL_ERR_INVALID, "bad tile %d", i);
     }
-    if ((rc = upload(ctx, ctx->b_tiles, tiles.data(), tiles.size()))) return rc;
+    if ((rc = upload_tiles(ctx, tiles))) return rc;
     ctx->visited_pairs = 0;
     ctx->tile_cell_filter = false;
     rc = dispatch(ctx, A, ldA, zero_exterior, ntiles, cell_begin, cell_end, flags);
@@ -724,6 +761,11 @@ int pnl_get_counters(pnl_context *ctx, int64_t *out, int n) {
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     HIPCHK(ctx, hipMemcpy(tmp, ctx->b_counters.p, sizeof(tmp), hipMemcpyDeviceToHost));
     tmp[0] = ctx->visited_pairs;
+    if (ctx->b_wlcount.p) {
+        unsigned wl = 0;
+        HIPCHK(ctx, hipMemcpy(&wl, ctx->b_wlcount.p, sizeof(wl), hipMemcpyDeviceToHost));
+        if (wl > ctx->wl_cap) return fail(ctx, PNL_ERR_STATE, "work list overflow: %u entries needed, capacity %u", wl, ctx->wl_cap);
+    }
     for (int i = 0; i < n && i < PNL_NCOUNTERS; i++) out[i] = (int64_t)tmp[i];
     if (tmp[5]) return fail(ctx, PNL_ERR_ORDER, "%llu pairs need a quadrature order beyond the uploaded tables (qmax=%d)", tmp[5], ctx->qmax);
     return PNL_OK;
@@ -733,15 +775,18 @@ int pnl_get_phase_ms(pnl_context *ctx, float *out, int n) {
     if (!ctx || !out || n <= 0) return PNL_ERR_INVALID;
     if (!ctx->ev_valid) return fail(ctx, PNL_ERR_STATE, "nothing assembled yet");
     HIPCHK(ctx, hipEventSynchronize(ctx->ev[5]));
-    float t[5] = {0, 0, 0, 0, 0}, tmp;
-    HIPCHK(ctx, hipEventElapsedTime(&t[0], ctx->ev[0], ctx->ev[1]));      // tiles
+    float t[6] = {0, 0, 0, 0, 0, 0}, tmp;
+    if (ctx->tiles_launched) {
+        HIPCHK(ctx, hipEventElapsedTime(&t[0], ctx->ev[0], ctx->ev[6]));  // tile kernel
+        HIPCHK(ctx, hipEventElapsedTime(&t[1], ctx->ev[6], ctx->ev[1]));  // work-list kernel
+    }
     HIPCHK(ctx, hipEventElapsedTime(&tmp, ctx->ev[1], ctx->ev[2]));       // mirror
-    HIPCHK(ctx, hipEventElapsedTime(&t[1], ctx->ev[2], ctx->ev[3]));      // singular
-    HIPCHK(ctx, hipEventElapsedTime(&t[2], ctx->ev[3], ctx->ev[4]));      // boundary
-    HIPCHK(ctx, hipEventElapsedTime(&t[3], ctx->ev[4], ctx->ev[5]));      // diagonal scatter
-    t[3] += tmp;
-    HIPCHK(ctx, hipEventElapsedTime(&t[4], ctx->ev[0], ctx->ev[5]));
-    for (int i = 0; i < n && i < 5; i++) out[i] = t[i];
+    HIPCHK(ctx, hipEventElapsedTime(&t[2], ctx->ev[2], ctx->ev[3]));      // singular
+    HIPCHK(ctx, hipEventElapsedTime(&t[3], ctx->ev[3], ctx->ev[4]));      // boundary
+    HIPCHK(ctx, hipEventElapsedTime(&t[4], ctx->ev[4], ctx->ev[5]));      // diagonal scatter
+    t[4] += tmp;
+    HIPCHK(ctx, hipEventElapsedTime(&t[5], ctx->ev[0], ctx->ev[5]));
+    for (int i = 0; i < n && i < 6; i++) out[i] = t[i];
     return PNL_OK;
 }
 

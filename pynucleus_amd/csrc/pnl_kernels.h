@@ -27,7 +27,7 @@ __device__ __forceinline__ double kern_eval(const DevKernel &k, double d2) {
         r = r*__builtin_fma(-h*r, r, 1.5);              // Newton, quadratic convergence
         r = r*__builtin_fma(-h*r, r, 1.5);
         r = r*__builtin_fma(-h*r, r, 1.5);
-        return k.scale*(r*r*r);
+        return (r*r)*(r*k.scale);
     } else {
         if (!(d2 <= k.horizon2)) return 0.;
         if (k.ktype == 0) return k.scale*pow(d2, k.exponent);
@@ -46,6 +46,25 @@ __device__ __forceinline__ int quad_order(const DevFormula &F, double H0, double
     double p1 = ceil((F.c0 + F.a*L2 + F.b*Lm - F.e*n2)/(fmax(logdh1, 0.) + F.den0));
     double p2 = ceil((F.c0 + F.a*L1 + F.b*Lm - F.e*n1)/(fmax(logdh2, 0.) + F.den0));
     int q1 = (int)fmax(p1, 2.), q2 = (int)fmax(p2, 2.);
+    return q1 > q2 ? q1 : q2;
+}
+
+// Same order, decided in fp32 where that is safe: the fp32 value of the ceil() argument is off by < 1e-4, so
+// whenever it is further than 1e-3 from an integer the fp64 formula gives the same ceil; otherwise (rare) the
+// exact formula above is evaluated.  lh = ln(h), L = |ln(h/H0)| per cell are staged once per tile.
+__device__ __forceinline__ int quad_order_fast(const DevFormula &F, double H0, double h1, double h2, float lh1, float lh2,
+                                               float L1, float L2, double d2) {
+    const float ld = 0.5f*0.69314718056f*__builtin_amdgcn_logf((float)d2);
+    const float logdh1 = ld-lh1, logdh2 = ld-lh2;
+    const float Lm = fmaxf(L1, L2);
+    const float n1 = F.clip ? fmaxf(logdh1, 0.f) : logdh1, n2 = F.clip ? fmaxf(logdh2, 0.f) : logdh2;
+    const float c0 = (float)F.c0, a = (float)F.a, b = (float)F.b, e = (float)F.e, den0 = (float)F.den0;
+    const float a1 = (c0+a*L2+b*Lm-e*n2)*__builtin_amdgcn_rcpf(fmaxf(logdh1, 0.f)+den0);
+    const float a2 = (c0+a*L1+b*Lm-e*n1)*__builtin_amdgcn_rcpf(fmaxf(logdh2, 0.f)+den0);
+    const float r1 = rintf(a1), r2 = rintf(a2);
+    const bool risky = (a1 > 1.5f && fabsf(a1-r1) < 1e-3f) || (a2 > 1.5f && fabsf(a2-r2) < 1e-3f) || !(a1 == a1) || !(a2 == a2);
+    if (risky) return quad_order(F, H0, h1, h2, sqrt(d2));
+    const int q1 = (int)fmaxf(ceilf(a1), 2.f), q2 = (int)fmaxf(ceilf(a2), 2.f);
     return q1 > q2 ? q1 : q2;
 }
 
@@ -155,7 +174,7 @@ __device__ __forceinline__ void eval_distant_fixed(const DevProblem &P, int off,
             y[j][d] = s;
         }
     }
-#pragma unroll
+#pragma unroll 1
     for (int i = 0; i < N; i++) {
         double x[DIM];
 #pragma unroll
@@ -220,8 +239,11 @@ struct TileSmem {
     static constexpr int o_vid = 0;                        // [2][NV][TILE]
     static constexpr int o_cnt = o_vid+2*NV*TILE;          // [PNL_MAXQ+2]
     static constexpr int o_cur = o_cnt+PNL_MAXQ+2;         // [PNL_MAXQ+2]
-    static constexpr int o_misc = o_cur+PNL_MAXQ+2;        // [4]: qlo, qhi, evals lo/hi
-    static constexpr int n_int = o_misc+4;
+    static constexpr int o_misc = o_cur+PNL_MAXQ+2;        // [4]: list length, work-list base, #eligible buckets
+    static constexpr int o_el = o_misc+4;                  // [2][16]: order and list end of the populated eligible buckets
+    static constexpr int o_lh = o_el+32;                   // float [2][2][TILE]: ln h, |ln(h/H0)|
+    static constexpr int o_q = o_lh+4*TILE;                // unsigned char [TILE*TILE] order of each pair
+    static constexpr int n_int = o_q+TILE*TILE/4;
     // shorts after the ints
     static constexpr int o_slot = 0;                       // [2][DPE][TILE]
     static constexpr int o_list = o_slot+2*DPE*TILE;       // [TILE*TILE]
@@ -229,10 +251,18 @@ struct TileSmem {
     static constexpr size_t fixed_bytes = sizeof(double)*n_dbl+sizeof(int)*n_int+sizeof(short)*((n_short+3)/4*4);
 };
 
+// number of points of a distant rule the tile kernel integrates one pair per lane (fully unrolled);
+// every other order goes to the global work list and is integrated one pair per wave.
+__device__ __forceinline__ bool tile_eligible(int n) { return n == 2 || n == 3 || n == 4 || n == 6 || n == 7; }
+
+#ifndef PNL_TILE_WAVES
+#define PNL_TILE_WAVES 2      // waves per SIMD the tile kernel is register-limited to (measured: 2 beats 3 and 4)
+#endif
 template <int DIM, int DPE, int TILE, int KT>
-__global__ void __launch_bounds__(PNL_NTHREADS)
+__global__ void __launch_bounds__(PNL_NTHREADS, PNL_TILE_WAVES)
 k_tile_distant(const DevProblem P, const int2 *__restrict__ tiles, double *__restrict__ A, long long ldA,
-               double *__restrict__ Dglob, int cell_begin, int cell_end, int acc_stride) {
+               double *__restrict__ Dglob, int cell_begin, int cell_end, int acc_stride, int4 *__restrict__ worklist,
+               unsigned *__restrict__ wl_count, unsigned wl_cap, int ablate) {
     using S = TileSmem<DIM, DPE, TILE>;
     constexpr int NV = S::NV, NC = S::NC, ND = S::ND;
     constexpr int PAIRS = TILE*TILE, PER_THREAD = PAIRS/PNL_NTHREADS;
@@ -242,9 +272,11 @@ k_tile_distant(const DevProblem P, const int2 *__restrict__ tiles, double *__res
     short *s_short = (short*)(s_int+S::n_int);
     double *s_acc = (double*)(s_short+(S::n_short+3)/4*4);   // [nA][acc_stride]
     double *s_v = s_dbl+S::o_v, *s_cen = s_dbl+S::o_cen, *s_vol = s_dbl+S::o_vol, *s_h = s_dbl+S::o_h, *s_D = s_dbl+S::o_D;
-    int *s_vid = s_int+S::o_vid, *s_cnt = s_int+S::o_cnt, *s_cur = s_int+S::o_cur, *s_misc = s_int+S::o_misc;
+    int *s_vid = s_int+S::o_vid, *s_cnt = s_int+S::o_cnt, *s_cur = s_int+S::o_cur, *s_misc = s_int+S::o_misc, *s_el = s_int+S::o_el;
     short *s_slot = s_short+S::o_slot;
     unsigned short *s_list = (unsigned short*)(s_short+S::o_list);
+    float *s_lh = (float*)(s_int+S::o_lh);
+    unsigned char *s_q = (unsigned char*)(s_int+S::o_q);
 
     const int tid = threadIdx.x;
     const int2 tl = tiles[blockIdx.x];
@@ -260,7 +292,10 @@ k_tile_distant(const DevProblem P, const int2 *__restrict__ tiles, double *__res
 #pragma unroll
         for (int d = 0; d < DIM; d++) s_cen[(side*DIM+d)*TILE+l] = P.ccen[(size_t)d*P.ncp+c];
         s_vol[side*TILE+l] = P.cvol[c];
-        s_h[side*TILE+l] = P.ch[c];
+        const double hc = P.ch[c];
+        s_h[side*TILE+l] = hc;
+        s_lh[(side*2+0)*TILE+l] = (float)log(hc);
+        s_lh[(side*2+1)*TILE+l] = (float)fabs(log(hc/P.H0));
 #pragma unroll
         for (int k = 0; k < NV; k++) s_vid[(side*NV+k)*TILE+l] = P.cvid[(size_t)k*P.ncp+c];
 #pragma unroll
@@ -269,15 +304,13 @@ k_tile_distant(const DevProblem P, const int2 *__restrict__ tiles, double *__res
     for (int t = tid; t < nA*acc_stride; t += PNL_NTHREADS) s_acc[t] = 0.;
     for (int t = tid; t < 2*TILE*ND; t += PNL_NTHREADS) s_D[t] = 0.;
     for (int t = tid; t < 2*(PNL_MAXQ+2); t += PNL_NTHREADS) s_cnt[t] = 0;      // s_cnt and s_cur are adjacent
-    if (tid == 0) { s_misc[0] = PNL_MAXQ+1; s_misc[1] = 0; }
     __syncthreads();
 
     // ---- classification ------------------------------------------------------------------------
     // pair p -> (i, j) along wrapped diagonals: consecutive lanes get distinct a-cells AND distinct
     // b-cells, so the per-cell LDS accumulators below see (almost) no same-address conflicts.
-    unsigned char qreg[PER_THREAD];
     int overflow = 0;
-#pragma unroll
+#pragma unroll 1
     for (int it = 0; it < PER_THREAD; it++) {
         const int p = it*PNL_NTHREADS+tid;
         const int j = p%TILE, i = (p/TILE+j)%TILE;
@@ -304,88 +337,125 @@ k_tile_distant(const DevProblem P, const int2 *__restrict__ tiles, double *__res
                     const double t = s_cen[(0*DIM+d)*TILE+i]-s_cen[(1*DIM+d)*TILE+j];
                     d2 += t*t;
                 }
-                q = quad_order(P.qo, P.H0, s_h[i], s_h[TILE+j], sqrt(d2));
+                q = quad_order_fast(P.qo, P.H0, s_h[i], s_h[TILE+j], s_lh[i], s_lh[2*TILE+j], s_lh[TILE+i], s_lh[3*TILE+j], d2);
                 if (q > P.qmax || q > PNL_MAXQ) { overflow++; q = 0; }
-                else if (!(d2 >= 0.)) q = 0;
             }
         }
-        qreg[it] = (unsigned char)q;
+        s_q[p] = (unsigned char)q;
         if (q) atomicAdd(&s_cnt[q], 1);
     }
     if (overflow) atomicAdd(&P.counters[5], (unsigned long long)overflow);
     __syncthreads();
     if (tid == 0) {
-        // exclusive prefix over the orders; remember the populated range
-        int run = 0, qlo = PNL_MAXQ+1, qhi = 0;
+        // exclusive prefixes over the orders: tile-eligible orders index the LDS list, the others a slice of
+        // the global work list reserved with one atomic
+        int run = 0, far = 0, nel = 0;
         unsigned long long evals = 0;
-        for (int q = 0; q <= PNL_MAXQ; q++) {
+        for (int q = 2; q <= P.qmax; q++) {
             const int cq = s_cnt[q];
-            s_cur[q] = run;
-            if (cq) {
-                if (q < qlo) qlo = q;
-                qhi = q;
-                const unsigned long long n = (unsigned long long)(P.off[q+1]-P.off[q]);
-                evals += n*n*cq;
-                atomicAdd(&P.counters[8+q], (unsigned long long)cq);
-            }
-            run += cq;
+            if (!cq) continue;
+            const int n = P.off[q+1]-P.off[q];
+            if (tile_eligible(n) && nel < 16) { s_cur[q] = run; run += cq; s_el[nel] = q; s_el[16+nel] = run; nel++; }
+            else { s_cur[q] = far; far += cq; s_cnt[q] = -cq; }
+            evals += (unsigned long long)n*n*cq;
+            atomicAdd(&P.counters[8+q], (unsigned long long)cq);
         }
-        s_cur[PNL_MAXQ+1] = run;
-        s_misc[0] = qlo; s_misc[1] = qhi;
-        if (run) {
-            atomicAdd(&P.counters[1], (unsigned long long)run);
+        s_misc[0] = run;
+        s_misc[2] = nel;
+        unsigned base = 0;
+        if (far) base = atomicAdd(wl_count, (unsigned)far);
+        s_misc[1] = (int)base;
+        if (run+far) {
+            atomicAdd(&P.counters[1], (unsigned long long)(run+far));
             atomicAdd(&P.counters[2], evals);
         }
     }
     __syncthreads();
-#pragma unroll
-    for (int it = 0; it < PER_THREAD; it++) {
-        const int q = qreg[it];
-        if (q) {
-            const int pos = atomicAdd(&s_cur[q], 1);
-            s_list[pos] = (unsigned short)(it*PNL_NTHREADS+tid);
+    {
+        const unsigned base = (unsigned)s_misc[1];
+#pragma unroll 1
+        for (int it = 0; it < PER_THREAD; it++) {
+            const int p = it*PNL_NTHREADS+tid;
+            const int q = s_q[p];
+            if (q) {
+                const int pos = atomicAdd(&s_cur[q], 1);
+                if (s_cnt[q] > 0) s_list[pos] = (unsigned short)p;
+                else {
+                    const unsigned g = base+(unsigned)pos;
+                    const int j = p%TILE, i = (p/TILE+j)%TILE;
+                    if (g < wl_cap) worklist[g] = make_int4(ta*TILE+i, tb*TILE+j, q, 0);
+                }
+            }
         }
     }
     __syncthreads();
-    // after the fill s_cur[q] = end of bucket q; its start is end - count
+    // after the fill s_cur[q] = end of bucket q in the LDS list (for eligible q)
 
-    // ---- evaluation, one order (= one trip count) at a time ---------------------------------------
-    const int qlo = __builtin_amdgcn_readfirstlane(s_misc[0]), qhi = __builtin_amdgcn_readfirstlane(s_misc[1]);
-    for (int q = qlo; q <= qhi; q++) {
-        const int cq = __builtin_amdgcn_readfirstlane(s_cnt[q]);
-        if (cq == 0) continue;
-        const int end = __builtin_amdgcn_readfirstlane(s_cur[q]);
-        const int off = __builtin_amdgcn_readfirstlane(P.off[q]);
-        const int n = __builtin_amdgcn_readfirstlane(P.off[q+1])-off;
-        for (int idx = end-cq+tid; idx < end; idx += PNL_NTHREADS) {
-            const int p = s_list[idx];
-            const int j = p%TILE, i = (p/TILE+j)%TILE;
-            double av[NC], bv[NC];
+    // ---- evaluation: waves take 64-pair chunks of the order-sorted list; inside a chunk the (at most few)
+    //      orders present run one after the other so that every lane of a pass has the same trip count ----
+    const int total = __builtin_amdgcn_readfirstlane(s_misc[0]);
+    const int nel = __builtin_amdgcn_readfirstlane(s_misc[2]);
+    const int wave = tid >> 6, lane = tid & 63;
+    if (!(ablate & 2))
+    for (int c0 = wave*64; c0 < total; c0 += PNL_NTHREADS) {
+        const int idx = c0+lane;
+        const bool act = idx < total;
+        const int p = act ? s_list[idx] : 0;
+        const int j = p%TILE, i = (p/TILE+j)%TILE;
+        // order of this entry: first q whose bucket end exceeds idx
+        int myq = 0;
+        if (act)
+            for (int k = nel-1; k >= 0; k--)
+                if (idx < s_el[16+k]) myq = s_el[k];
+        double av[NC], bv[NC];
 #pragma unroll
-            for (int k = 0; k < NC; k++) { av[k] = s_v[(0*NC+k)*TILE+i]; bv[k] = s_v[(1*NC+k)*TILE+j]; }
-            PairAcc<DIM, DPE> R;
-            R.clear();
-            if (DPE <= 3 && n == 3) eval_distant_fixed<DIM, DPE, KT, 3>(P, off, av, bv, R);
-            else if (DPE <= 3 && n == 6) eval_distant_fixed<DIM, DPE, KT, 6>(P, off, av, bv, R);
-            else if (DPE <= 3 && n == 7) eval_distant_fixed<DIM, DPE, KT, 7>(P, off, av, bv, R);
-            else eval_distant_generic<DIM, DPE, KT>(P, off, n, av, bv, R);
-            // NA:1405-1410: symmetric cell pairs count twice
-            const double vv = 2.*s_vol[i]*s_vol[TILE+j];
-            int e = 0;
+        for (int k = 0; k < NC; k++) { av[k] = s_v[(0*NC+k)*TILE+i]; bv[k] = s_v[(1*NC+k)*TILE+j]; }
+        PairAcc<DIM, DPE> R;
+        R.clear();
+        unsigned long long todo = __ballot(act);
+        while (todo) {
+            const int src = __ffsll((long long)todo)-1;
+            const int q = __shfl(myq, src, 64);
+            const bool mine = act && (myq == q);
+            todo &= ~__ballot(mine);
+            const int off = __builtin_amdgcn_readfirstlane(P.off[q]);
+            const int n = __builtin_amdgcn_readfirstlane(P.off[q+1])-off;
+            if (mine) {
+                if (n == 3) eval_distant_fixed<DIM, DPE, KT, 3>(P, off, av, bv, R);
+                else if (n == 6) eval_distant_fixed<DIM, DPE, KT, 6>(P, off, av, bv, R);
+                else if (n == 7) eval_distant_fixed<DIM, DPE, KT, 7>(P, off, av, bv, R);
+                else if (n == 2) eval_distant_fixed<DIM, DPE, KT, 2>(P, off, av, bv, R);
+                else eval_distant_fixed<DIM, DPE, KT, 4>(P, off, av, bv, R);
+            }
+        }
+        if (!act) continue;
+        // NA:1405-1410: symmetric cell pairs count twice
+        const double vv = 2.*s_vol[i]*s_vol[TILE+j];
+        if (ablate & 1) {
+            double keep = 0.;
 #pragma unroll
-            for (int a = 0; a < DPE; a++) {
-                const int sa = s_slot[(0*DPE+a)*TILE+i];
+            for (int a = 0; a < DPE; a++)
 #pragma unroll
-                for (int b = 0; b < DPE; b++) {
-                    const int sb = s_slot[(1*DPE+b)*TILE+j];
-                    if (sa >= 0 && sb >= 0) lds_add_f64(&s_acc[sa*acc_stride+sb], -vv*R.G[a][b]);
-                }
+                for (int b = 0; b < DPE; b++) keep += R.G[a][b];
 #pragma unroll
-                for (int b = a; b < DPE; b++) {
-                    lds_add_f64(&s_D[(0*TILE+i)*ND+e], vv*R.S1[e]);
-                    lds_add_f64(&s_D[(1*TILE+j)*ND+e], vv*R.S2[e]);
-                    e++;
-                }
+            for (int e2 = 0; e2 < ND; e2++) keep += R.S1[e2]+R.S2[e2];
+            if (keep == 1.2345e300) s_D[0] = keep*vv;
+            continue;
+        }
+        int e = 0;
+#pragma unroll
+        for (int a = 0; a < DPE; a++) {
+            const int sa = s_slot[(0*DPE+a)*TILE+i];
+#pragma unroll
+            for (int b = 0; b < DPE; b++) {
+                const int sb = s_slot[(1*DPE+b)*TILE+j];
+                if (sa >= 0 && sb >= 0) lds_add_f64(&s_acc[sa*acc_stride+sb], -vv*R.G[a][b]);
+            }
+#pragma unroll
+            for (int b = a; b < DPE; b++) {
+                lds_add_f64(&s_D[(0*TILE+i)*ND+e], vv*R.S1[e]);
+                lds_add_f64(&s_D[(1*TILE+j)*ND+e], vv*R.S2[e]);
+                e++;
             }
         }
     }
@@ -394,6 +464,7 @@ k_tile_distant(const DevProblem P, const int2 *__restrict__ tiles, double *__res
     // ---- flush: sub-block of A' (rows = DoFs of block a, cols = DoFs of block b) and diagonal blocks ----
     const int *__restrict__ dofA = P.blk_dofs+(size_t)ta*P.blk_stride;
     const int *__restrict__ dofB = P.blk_dofs+(size_t)tb*P.blk_stride;
+    if (ablate & 4) return;
     for (int t = tid; t < nA*nB; t += PNL_NTHREADS) {
         const int r = t/nB, c = t-r*nB;
         const double v = s_acc[r*acc_stride+c];
@@ -415,6 +486,89 @@ __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
     return v;
+}
+
+// Distant pairs of the orders the tile kernel does not unroll (NO:722-789): one wave per pair, lanes over
+// the n*n point pairs of the tensor rule, butterfly reduction of the local matrix, atomic scatter.
+// A' receives the cross block on the (c1-DoF, c2-DoF) side only, like the tile kernel.
+template <int DIM, int DPE, int KT>
+__global__ void __launch_bounds__(PNL_NTHREADS)
+k_worklist_pairs(const DevProblem P, const int4 *__restrict__ worklist, const unsigned *__restrict__ wl_count, unsigned wl_cap,
+                 double *__restrict__ A, long long ldA, double *__restrict__ Dglob) {
+    constexpr int NV = DIM+1, NC = NV*DIM, ND = DPE*(DPE+1)/2, NG = DPE*DPE, NACC = NG+2*ND;
+    const int lane = threadIdx.x & 63;
+    const unsigned nwaves = gridDim.x*(PNL_NTHREADS/64);
+    const unsigned count = min(*wl_count, wl_cap);
+    for (unsigned item = (blockIdx.x*PNL_NTHREADS+threadIdx.x) >> 6; item < count; item += nwaves) {
+        const int4 ent = worklist[item];
+        const int c1 = __builtin_amdgcn_readfirstlane(ent.x), c2 = __builtin_amdgcn_readfirstlane(ent.y);
+        const int q = __builtin_amdgcn_readfirstlane(ent.z);
+        const int off = P.off[q], n = P.off[q+1]-off, nn = n*n;
+        const double *__restrict__ bary = P.bary+3*(size_t)off;
+        const double *__restrict__ w = P.w+off;
+        const double *__restrict__ phi = P.phi+(size_t)off*DPE;
+        double av[NC], bv[NC];
+#pragma unroll
+        for (int k = 0; k < NC; k++) { av[k] = P.cellv[(size_t)k*P.ncp+c1]; bv[k] = P.cellv[(size_t)k*P.ncp+c2]; }
+        double acc[NACC];
+#pragma unroll
+        for (int e = 0; e < NACC; e++) acc[e] = 0.;
+        const int di = 64/n, dj = 64-di*n;
+        int i = lane/n, j = lane-i*n;
+        for (int k = lane; k < nn; k += 64) {
+            double d2 = 0.;
+#pragma unroll
+            for (int d = 0; d < DIM; d++) {
+                double x = 0., y = 0.;
+#pragma unroll
+                for (int m = 0; m < NV; m++) {
+                    x = __builtin_fma(bary[3*i+m], av[m*DIM+d], x);
+                    y = __builtin_fma(bary[3*j+m], bv[m*DIM+d], y);
+                }
+                d2 = __builtin_fma(x-y, x-y, d2);
+            }
+            const double K = (w[i]*w[j])*kern_eval<KT>(P.k, d2);
+            double pa[DPE], pb[DPE];
+#pragma unroll
+            for (int a = 0; a < DPE; a++) { pa[a] = phi[i*DPE+a]; pb[a] = phi[j*DPE+a]; }
+            int e = 0;
+#pragma unroll
+            for (int a = 0; a < DPE; a++) {
+                const double ka = K*pa[a];
+#pragma unroll
+                for (int b = 0; b < DPE; b++) acc[a*DPE+b] = __builtin_fma(ka, pb[b], acc[a*DPE+b]);
+                const double kb = K*pb[a];
+#pragma unroll
+                for (int b = a; b < DPE; b++) {
+                    acc[NG+e] = __builtin_fma(ka, pa[b], acc[NG+e]);
+                    acc[NG+ND+e] = __builtin_fma(kb, pb[b], acc[NG+ND+e]);
+                    e++;
+                }
+            }
+            i += di; j += dj;
+            if (j >= n) { j -= n; i++; }
+        }
+        // reduce; lane (e mod 64) keeps entry e (two per lane at most: NACC <= 128)
+        double mine0 = 0., mine1 = 0.;
+#pragma unroll
+        for (int e = 0; e < NACC; e++) {
+            const double s = wave_sum(acc[e]);
+            if (e < 64) mine0 = (lane == e) ? s : mine0;
+            else mine1 = (lane == e-64) ? s : mine1;
+        }
+        const double vv = 2.*P.cvol[c1]*P.cvol[c2];
+#pragma unroll
+        for (int rep = 0; rep < (NACC+63)/64; rep++) {
+            const int e = lane+64*rep;
+            const double val = rep ? mine1 : mine0;
+            if (e < NG) {
+                const int a = e/DPE, b = e-a*DPE;
+                const int I = P.cdof[(size_t)a*P.ncp+c1], J = P.cdof[(size_t)b*P.ncp+c2];
+                if (I >= 0 && J >= 0) atomic_add_f64(&A[(long long)I*ldA+J], -vv*val);
+            } else if (e < NG+ND) atomic_add_f64(&Dglob[(size_t)c1*ND+(e-NG)], vv*val);
+            else if (e < NACC) atomic_add_f64(&Dglob[(size_t)c2*ND+(e-NG-ND)], vv*val);
+        }
+    }
 }
 
 __device__ __forceinline__ int perm_rank(const int *perm, int n) {
