@@ -77,7 +77,8 @@ def main():
     A = torch.zeros((N, N), dtype=torch.float64, device=dev)
     if world > 1:
         tiles = builder.tiles_for_rank(rank, world)
-        c0, c1 = int(np.ceil(nc*rank/world)), int(np.ceil(nc*(rank+1)/world))
+        from pynucleus_amd.builder import cell_range_of_rank
+        c0, c1 = cell_range_of_rank(nc, rank, world)
 
     def step():
         A.zero_()

@@ -25,6 +25,26 @@ class FakePLogger:
         self.timings[key] = self.timings.get(key, 0.)+seconds
 
 
+def tile_cells(dpe):
+    """cells per block of the GPU tile kernel (mirrors TILE_P1 / TILE_P2 in csrc/pnl_hip.hip)"""
+    return 32 if dpe == 6 else 64
+
+
+def upper_tiles(num_cells, T):
+    """all block-tile pairs (ta <= tb), heavy near-diagonal ones first"""
+    nb = (num_cells+T-1)//T
+    return np.array([(a, a+d) for d in range(nb) for a in range(nb-d)], dtype=np.int32).reshape(-1, 2)
+
+
+def tiles_of_rank(num_cells, T, rank, size):
+    return np.ascontiguousarray(upper_tiles(num_cells, T)[rank::size])
+
+
+def cell_range_of_rank(num_cells, rank, size):
+    """the reference's MPI split of cellNo1 (NA:1280-1285)"""
+    return int(np.ceil(num_cells*rank/size)), int(np.ceil(num_cells*(rank+1)/size))
+
+
 class nonlocalBuilder:
     def __init__(self, dm, kernel, params={}, zeroExterior=True, comm=None, PLogger=None, dm2=None, device=None, **kwargs):
         if 'boundary' in kwargs:
@@ -97,8 +117,7 @@ class nonlocalBuilder:
             ctx.assemble_dense(A.data_ptr(), A.stride(0), self.zeroExterior, 0, nc)
         else:
             tiles = self.tiles_for_rank(rank, size)
-            start = int(np.ceil(nc*rank/size))
-            end = int(np.ceil(nc*(rank+1)/size))
+            start, end = cell_range_of_rank(nc, rank, size)
             ctx.assemble_dense_tiles(A.data_ptr(), A.stride(0), self.zeroExterior, tiles, start, end)
         cnt = ctx.counters()
         ms = ctx.phase_ms()
@@ -116,11 +135,10 @@ class nonlocalBuilder:
     def tiles_for_rank(self, rank, size):
         """block-tile pairs (ta <= tb) of the upper block triangle owned by `rank`: the list is ordered by
         block distance (heavy near-diagonal tiles first) and dealt round-robin."""
-        ctx = self.context()
-        T = ctx.tile_cells()
-        nb = (self.mesh.num_cells+T-1)//T
-        tiles = np.array([(a, a+d) for d in range(nb) for a in range(nb-d)], dtype=np.int32)
-        return np.ascontiguousarray(tiles[rank::size])
+        T = tile_cells(self.dm.dofs_per_element)
+        if self._ctx is not None:
+            assert self._ctx.tile_cells() == T
+        return tiles_of_rank(self.mesh.num_cells, T, rank, size)
 
     def getDiagonal(self):
         raise NotImplementedError('getDiagonal: assemble the dense operator and take .diagonal')

@@ -350,3 +350,20 @@ def interval(noRef=0, a=-1., b=1.):
     for _ in range(noRef):
         mesh = mesh.refine()
     return mesh
+
+
+def driverMesh(domain, noRef):
+    """Mesh of the reference's runFractional driver for `--domain domain --noRef noRef`: the factory mesh is
+    refined until a P1 space with PHYSICAL boundary has a DoF (nonlocalProblems.py:209-212) and then noRef
+    more times by the level hierarchy (discretizedProblems.py:386-409, helpers.py:381-411)."""
+    if domain == 'interval':
+        mesh = simpleInterval(-1., 1.)
+    elif domain == 'disc':
+        mesh = uniform_disc(1.)
+    else:
+        raise NotImplementedError(domain)
+    while mesh.num_vertices-mesh.boundaryVertices.shape[0] == 0:
+        mesh = mesh.refine()
+    for _ in range(noRef):
+        mesh = mesh.refine()
+    return mesh

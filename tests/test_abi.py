@@ -1,0 +1,56 @@
+"""The C-ABI library loads and exports every symbol include/pnl_hip.h declares; host-side error paths that do
+not need a GPU behave as documented.  No compute calls here (CPU-only container)."""
+import ctypes
+import os
+import re
+import pytest
+from pynucleus_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    txt = open(os.path.join(ROOT, 'include', 'pnl_hip.h')).read()
+    txt = re.sub(r'/\*.*?\*/', '', txt, flags=re.S)
+    return sorted(set(re.findall(r'\b(pnl_[a-z_0-9]+)\s*\(', txt)))
+
+
+def test_header_and_binding_agree():
+    assert sorted(_lib.EXPORTS) == declared_symbols()
+
+
+def test_library_exports_every_declared_symbol():
+    assert os.path.exists(_lib.LIB_PATH), 'build the HIP library first (__graft_entry__.build())'
+    L = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared_symbols():
+        assert hasattr(L, name), name
+    assert b'gfx950' in _lib.load().pnl_version()
+
+
+def test_create_without_gpu_fails_loudly():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip('a GPU is visible')
+    with pytest.raises(_lib.PnlError):
+        _lib.Context(0)
+
+
+def test_builder_has_no_cpu_fallback():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip('a GPU is visible')
+    from pynucleus_amd import disc, P1_DoFMap, PHYSICAL, getFractionalKernel
+    from pynucleus_amd.builder import nonlocalBuilder
+    mesh = disc(1)
+    b = nonlocalBuilder(P1_DoFMap(mesh, PHYSICAL), getFractionalKernel(2, 0.5))
+    with pytest.raises(_lib.PnlError):
+        b.getDense()
+
+
+def test_product_does_not_import_oracle():
+    pkg = os.path.join(ROOT, 'pynucleus_amd')
+    for dirpath, _, files in os.walk(pkg):
+        for fn in files:
+            if fn.endswith(('.py', '.hip', '.h')):
+                src = open(os.path.join(dirpath, fn)).read()
+                assert 'import oracle' not in src and 'from oracle' not in src and 'nl_oracle' not in src, fn

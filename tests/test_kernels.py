@@ -1,0 +1,78 @@
+"""Kernel known-answer tests: the closed forms of the reference's tests/test_kernels.py:536-669
+(points :540-551, constants :591-608, asserts :610-660)."""
+import numpy as np
+import pytest
+from math import gamma, pi, sqrt
+from numpy.linalg import norm
+from pynucleus_amd import getFractionalKernel, getKernel, getIntegrableKernel, INDICATOR, PERIDYNAMIC
+
+POINTS = {1: [(np.array([-0.1]), np.array([0.1])), (np.array([0.1]), np.array([-0.1])), (np.array([-0.1]), np.array([0.5]))],
+          2: [(np.array([-0.1, 0.1]), np.array([0.1, 0.2])), (np.array([0.1, 0.1]), np.array([-0.1, 0.2])),
+              (np.array([-0.1, 0.1]), np.array([0.5, 0.2]))]}
+
+
+def const(dim, s, horizon, normalized):
+    if not normalized:
+        return 0.5
+    if dim == 1:
+        if horizon < np.inf:
+            return (2.-2*s)*pow(horizon**2, s-1.)*0.5
+        return 2.0**(2.0*s)*s*gamma(s+0.5)/sqrt(pi)/gamma(1.0-s)*0.5
+    if horizon < np.inf:
+        return (2.-2*s)*pow(horizon**2, s-1.)*2./pi*0.5
+    return 2.0**(2.0*s)*s*gamma(s+1.0)/pi/gamma(1.-s)*0.5
+
+
+@pytest.mark.parametrize('dim', [1, 2])
+@pytest.mark.parametrize('s', [0.25, 0.5, 0.75])
+@pytest.mark.parametrize('horizon', [np.inf, 0.5])
+@pytest.mark.parametrize('normalized', [True, False])
+def test_fractional_kernel(dim, s, horizon, normalized):
+    kernel = getFractionalKernel(dim, s, horizon, normalized=normalized)
+    bk = kernel.getBoundaryKernel()
+    inf_kernel = getFractionalKernel(dim, s, np.inf, normalized=normalized)
+    c = const(dim, s, horizon, normalized)
+    cinf = const(dim, s, np.inf, normalized)
+    for x, y in POINTS[dim]:
+        refInf = c/norm(x-y)**(dim+2*s)
+        ref = refInf if norm(x-y) < horizon else 0.
+        assert np.isclose(kernel(x, y), ref)
+        assert np.isclose(inf_kernel(x, y), cinf/norm(x-y)**(dim+2*s))
+        # boundary kernel = Gamma(x,y) |x-y| / s   (tests/test_kernels.py:657-660)
+        assert np.isclose(bk(x, y), ref*norm(x-y)/s)
+
+
+def test_scaling_s_half_2d():
+    k = getFractionalKernel(2, 0.5)
+    assert np.isclose(k.scalingValue, 1/(4*pi))
+    assert np.isclose(k.getBoundaryKernel().scalingValue, 1/(2*pi))
+    assert k.singularityValue == -3. and k.getBoundaryKernel().singularityValue == -2.
+    p = k.device_params()
+    assert p['exponent'] == -1.5 and np.isinf(p['horizon2'])
+
+
+def test_integrable_kernels():
+    k = getIntegrableKernel(2, INDICATOR, 0.5)
+    assert np.isclose(k(np.zeros(2), np.array([0.3, 0.])), 8./pi/0.5**4/2.)
+    assert k(np.zeros(2), np.array([0.6, 0.])) == 0.
+    k = getKernel(1, kernel='inverseDistance', horizon=0.5)
+    assert k.kernelType == PERIDYNAMIC
+    assert np.isclose(k(np.zeros(1), np.array([0.25])), 2./0.5**2/2./0.25)
+
+
+def test_divergence_identity():
+    """div_y( Gamma_b(x,y) (x-y)/|x-y| ) = 2 gamma(x,y)  (tests/test_kernels.py:662-669), by finite differences"""
+    for dim in (1, 2):
+        for s in (0.25, 0.75):
+            k = getFractionalKernel(dim, s)
+            bk = k.getBoundaryKernel()
+            x, y = POINTS[dim][2]
+            eps = 1e-6
+            div = 0.
+            for d in range(dim):
+                e = np.zeros(dim)
+                e[d] = eps
+                fp = bk(x, y+e)*(x-(y+e))[d]/norm(x-(y+e))
+                fm = bk(x, y-e)*(x-(y-e))[d]/norm(x-(y-e))
+                div += (fp-fm)/(2*eps)
+            assert np.isclose(div, 2*k(x, y), rtol=1e-6)
