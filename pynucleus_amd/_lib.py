@@ -198,7 +198,7 @@ class Context:
         hist = {q: int(out[8+q]) for q in range(120) if out[8+q]}
         sing = {-1-k: int(out[128+k]) for k in range(3)}
         return dict(numCellPairs=int(out[0]), numAssembledCellPairs=int(out[1]), numIntegrations=int(out[2]),
-                    numBoundaryPairs=int(out[3]), numBoundaryIntegrations=int(out[4]), orders=hist, singular=sing)
+                    numBoundaryPairs=int(out[3]), numBoundaryIntegrations=int(out[4]), orders=hist, singular=sing, debug6=int(out[6]))
 
     def phase_ms(self):
         out = np.zeros(6, dtype=np.float32)

@@ -34,6 +34,7 @@ struct DevProblem {
     int blk_stride, nblocks;
     const int *perm_table;      // [(dim+1)!][dpe]
     DevKernel k, bk;
+    DevKernel bkn;              // boundary kernel with the 1/|x-y| of the normal factor folded in (2D)
     DevFormula qo, bqo;
     // distant rules
     int qmax, pad0;
@@ -44,6 +45,10 @@ struct DevProblem {
     const int *foff;            // facet rules
     const double *fbary;        // [ftotal][2]
     const double *fw;
+    // rules the tile kernel integrates one pair per lane, packed for one coalesced copy into LDS
+    const int *tt_n, *tt_off;   // [PNL_MAXQ+2]
+    const double *tt_tab;       // [tt_npts][4+dpe]: bary[3], w, phi[dpe]
+    int tt_npts, pad1;
     // singular rules (slot 0 vertex, 1 edge, 2 face)
     int sM[3], sRows[3];
     const double *sNodes[3], *sW[3], *sPsi[3];

@@ -47,7 +47,7 @@ struct pnl_context {
     DevProblem P;
     DevBuf b_cellv, b_ccen, b_cvol, b_ch, b_cvid, b_cdof, b_cslot, b_blk_ndof, b_blk_dofs, b_perm, b_off, b_bary, b_w, b_phi,
         b_foff, b_fbary, b_fw, b_sn[3], b_sw[3], b_sp[3], b_bn[2], b_bw[2], b_bp[2], b_bvid, b_bv, b_counters, b_D, b_tiles,
-        b_spairs[3], b_bpairs[2], b_vec[6], b_scal, b_wl, b_wlcount;
+        b_spairs[3], b_bpairs[2], b_vec[6], b_scal, b_wl, b_wlcount, b_ttn, b_ttoff, b_tttab;
     unsigned wl_cap = 0;
     int tile = TILE_P1, nblocks = 0, ncp = 0, nU = 0;
     int n_spairs[3] = {0, 0, 0}, n_bpairs[2] = {0, 0};
@@ -293,12 +293,20 @@ void refresh_tables(pnl_context *ctx) {
     DevProblem &P = ctx->P;
     P.k = to_dev(ctx->kern[0], ctx->dim);
     P.bk = to_dev(ctx->kern[1], ctx->dim);
+    {
+        // n.(y-x)/|y-x| * Gamma_b(|x-y|^2): fold the normalisation into the exponent (fractional kernels only)
+        pnl_kernel kn = ctx->kern[1];
+        if (ctx->dim == 2 && kn.ktype == PNL_FRACTIONAL) kn.exponent -= 0.5;
+        P.bkn = to_dev(kn, ctx->dim);
+        if (ctx->dim == 2 && kn.ktype != PNL_FRACTIONAL) P.bkn.fast = 0;
+    }
     P.qo = to_dev(ctx->form[0]);
     P.bqo = to_dev(ctx->form[1]);
     P.qmax = ctx->qmax;
     P.off = (const int*)ctx->b_off.p; P.bary = (const double*)ctx->b_bary.p; P.w = (const double*)ctx->b_w.p;
     P.phi = (const double*)ctx->b_phi.p; P.foff = (const int*)ctx->b_foff.p; P.fbary = (const double*)ctx->b_fbary.p;
     P.fw = (const double*)ctx->b_fw.p;
+    P.tt_n = (const int*)ctx->b_ttn.p; P.tt_off = (const int*)ctx->b_ttoff.p; P.tt_tab = (const double*)ctx->b_tttab.p;
     for (int s = 0; s < 3; s++) {
         P.sNodes[s] = (const double*)ctx->b_sn[s].p; P.sW[s] = (const double*)ctx->b_sw[s].p; P.sPsi[s] = (const double*)ctx->b_sp[s].p;
     }
@@ -312,14 +320,19 @@ int launch_tiles(pnl_context *ctx, int ntiles, double *A, int64_t ldA, int cell_
     using S = TileSmem<DIM, DPE, TILE>;
     const int acc_stride = ctx->nU;
     const size_t lds = S::fixed_bytes+sizeof(double)*(size_t)ctx->nU*acc_stride;
-    if (getenv("PNL_VERBOSE")) fprintf(stderr, "[pnl] tiles=%d nU=%d lds=%zu bytes\n", ntiles, ctx->nU, lds);
+    if (getenv("PNL_VERBOSE")) {
+        int nblk = -1;
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nblk, (const void*)k_tile_distant<DIM, DPE, TILE, KT>, PNL_NTHREADS, lds);
+        fprintf(stderr, "[pnl] tiles=%d nU=%d lds=%zu bytes, occupancy API: %d blocks/CU\n", ntiles, ctx->nU, lds, nblk);
+    }
     if (lds > 160*1024)
         return fail(ctx, PNL_ERR_UNSUPPORTED, "a block of %d cells touches %d DoFs: LDS sub-block of %zu bytes exceeds 160 KiB "
                     "(cells must be numbered with spatial locality)", TILE, ctx->nU, lds);
     // work list for the orders that are integrated one pair per wave; sized generously, overflow is detected
     {
         const double pairs = (double)ntiles*TILE*TILE;
-        const size_t want = (size_t)std::min<double>(std::max<double>(pairs*0.05, 1<<20), 400e6);
+        const double frac = getenv("PNL_WL_FRAC") ? atof(getenv("PNL_WL_FRAC")) : 0.05;
+        const size_t want = (size_t)std::min<double>(std::max<double>(pairs*frac, 1<<20), 400e6);
         if (ctx->wl_cap < want) {
             int rc;
             if ((rc = ensure(ctx, ctx->b_wl, want*sizeof(int4)))) return rc;
@@ -331,14 +344,41 @@ int launch_tiles(pnl_context *ctx, int ntiles, double *A, int64_t ldA, int cell_
     }
     auto kfun = k_tile_distant<DIM, DPE, TILE, KT>;
     HIPCHK(ctx, hipFuncSetAttribute((const void*)kfun, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kfun, dim3(ntiles), dim3(PNL_NTHREADS), lds, ctx->stream, ctx->P, (const int2*)ctx->b_tiles.p, A,
+    int per_cu = 2;
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)kfun, PNL_NTHREADS, lds);
+    const int grid_mult = getenv("PNL_GRID_MULT") ? atoi(getenv("PNL_GRID_MULT")) : 1;
+    const int grid = std::min(ntiles, 256*std::max(per_cu, 1)*std::max(grid_mult, 1));
+    hipLaunchKernelGGL(kfun, dim3(grid), dim3(PNL_NTHREADS), lds, ctx->stream, ctx->P, (const int2*)ctx->b_tiles.p, A,
                        (long long)ldA, (double*)ctx->b_D.p, cell_begin, cell_end, acc_stride, (int4*)ctx->b_wl.p,
-                       (unsigned*)ctx->b_wlcount.p, ctx->wl_cap, ctx->ablate);
+                       (unsigned*)ctx->b_wlcount.p, ctx->wl_cap, ctx->ablate, ntiles);
     HIPCHK(ctx, hipGetLastError());
     HIPCHK(ctx, hipEventRecord(ctx->ev[6], ctx->stream));
     hipLaunchKernelGGL((k_worklist_pairs<DIM, DPE, KT>), dim3(256*8), dim3(PNL_NTHREADS), 0, ctx->stream, ctx->P,
                        (const int4*)ctx->b_wl.p, (const unsigned*)ctx->b_wlcount.p, ctx->wl_cap, A, (long long)ldA,
                        (double*)ctx->b_D.p);
+    HIPCHK(ctx, hipGetLastError());
+    return PNL_OK;
+}
+
+template <int DIM, int DPE, int SLOT, int KT>
+int launch_singular_slot(pnl_context *ctx, int np, double *A, int64_t ldA, int cell_begin, int cell_end) {
+    constexpr int NV = DIM+1;
+    const int2 *pairs = (const int2*)ctx->b_spairs[SLOT].p;
+    const int M = ctx->P.sM[SLOT], rows = ctx->P.sRows[SLOT];
+    const size_t lds = sizeof(double)*(size_t)(2*NV+1+rows)*M;
+    const int waves_per_block = PNL_SING_THREADS/64;
+    if (lds <= 150*1024) {
+        auto kfun = k_singular_pairs<DIM, DPE, SLOT, KT, true>;
+        HIPCHK(ctx, hipFuncSetAttribute((const void*)kfun, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        const int per_cu = std::max(1, (int)((160*1024)/std::max<size_t>(lds, 1)));
+        const int grid = std::min((np+waves_per_block-1)/waves_per_block, 256*std::min(per_cu, 4));
+        hipLaunchKernelGGL(kfun, dim3(grid), dim3(PNL_SING_THREADS), lds, ctx->stream, ctx->P, pairs, np, A, (long long)ldA,
+                           cell_begin, cell_end);
+    } else {
+        const int grid = std::min((np+waves_per_block-1)/waves_per_block, 256*4);
+        hipLaunchKernelGGL((k_singular_pairs<DIM, DPE, SLOT, KT, false>), dim3(grid), dim3(PNL_SING_THREADS), 0, ctx->stream,
+                           ctx->P, pairs, np, A, (long long)ldA, cell_begin, cell_end);
+    }
     HIPCHK(ctx, hipGetLastError());
     return PNL_OK;
 }
@@ -349,12 +389,11 @@ int launch_singular(pnl_context *ctx, double *A, int64_t ldA, int cell_begin, in
         const int np = ctx->n_spairs[s];
         if (!np) continue;
         if (!ctx->have_sing[0][s]) return fail(ctx, PNL_ERR_STATE, "singular rule for %d common vertices not uploaded", s+1);
-        const int grid = (np+3)/4;
-        const int2 *pairs = (const int2*)ctx->b_spairs[s].p;
-        if (s == 0) hipLaunchKernelGGL((k_singular_pairs<DIM, DPE, 0, KT>), dim3(grid), dim3(PNL_NTHREADS), 0, ctx->stream, ctx->P, pairs, np, A, (long long)ldA, cell_begin, cell_end);
-        else if (s == 1) hipLaunchKernelGGL((k_singular_pairs<DIM, DPE, 1, KT>), dim3(grid), dim3(PNL_NTHREADS), 0, ctx->stream, ctx->P, pairs, np, A, (long long)ldA, cell_begin, cell_end);
-        else if (DIM == 2) hipLaunchKernelGGL((k_singular_pairs<DIM, DPE, (DIM == 2 ? 2 : 1), KT>), dim3(grid), dim3(PNL_NTHREADS), 0, ctx->stream, ctx->P, pairs, np, A, (long long)ldA, cell_begin, cell_end);
-        HIPCHK(ctx, hipGetLastError());
+        int rc;
+        if (s == 0) rc = launch_singular_slot<DIM, DPE, 0, KT>(ctx, np, A, ldA, cell_begin, cell_end);
+        else if (s == 1) rc = launch_singular_slot<DIM, DPE, 1, KT>(ctx, np, A, ldA, cell_begin, cell_end);
+        else rc = launch_singular_slot<DIM, DPE, (DIM == 2 ? 2 : 1), KT>(ctx, np, A, ldA, cell_begin, cell_end);
+        if (rc) return rc;
     }
     return PNL_OK;
 }
@@ -364,12 +403,15 @@ int launch_boundary(pnl_context *ctx, int cell_begin, int cell_end) {
     if (ctx->nb == 0) return PNL_OK;
     const int ncell = cell_end-cell_begin;
     const int gx = (ncell+PNL_NTHREADS-1)/PNL_NTHREADS;
-    // enough chunks to fill the chip a few times over
-    int chunks = std::max(1, std::min(ctx->nb, (256*8+gx-1)/gx));
-    const int per = (ctx->nb+chunks-1)/chunks;
-    chunks = (ctx->nb+per-1)/per;
-    hipLaunchKernelGGL((k_boundary_distant<DIM, DPE, KT>), dim3(gx, chunks), dim3(PNL_NTHREADS), 0, ctx->stream, ctx->P,
-                       (double*)ctx->b_D.p, cell_begin, cell_end, per);
+    // small facet chunks: many waves in flight hide the latency of the per-facet dependent chain
+    const int per = 4;
+    const int chunks = (ctx->nb+per-1)/per;
+    if (ctx->P.bkn.fast)
+        hipLaunchKernelGGL((k_boundary_distant<DIM, DPE, 1>), dim3(gx, chunks), dim3(PNL_NTHREADS), 0, ctx->stream, ctx->P,
+                           (double*)ctx->b_D.p, cell_begin, cell_end, per);
+    else
+        hipLaunchKernelGGL((k_boundary_distant<DIM, DPE, 0>), dim3(gx, chunks), dim3(PNL_NTHREADS), 0, ctx->stream, ctx->P,
+                           (double*)ctx->b_D.p, cell_begin, cell_end, per);
     HIPCHK(ctx, hipGetLastError());
     for (int s = 0; s < DIM; s++) {
         const int np = ctx->n_bpairs[s];
@@ -377,8 +419,11 @@ int launch_boundary(pnl_context *ctx, int cell_begin, int cell_end) {
         if (!ctx->have_sing[1][s]) return fail(ctx, PNL_ERR_STATE, "boundary singular rule for %d common vertices not uploaded", s+1);
         const int grid = (np+3)/4;
         const int2 *pairs = (const int2*)ctx->b_bpairs[s].p;
-        if (s == 0) hipLaunchKernelGGL((k_boundary_singular<DIM, DPE, 0, KT>), dim3(grid), dim3(PNL_NTHREADS), 0, ctx->stream, ctx->P, pairs, np, (double*)ctx->b_D.p, cell_begin, cell_end);
-        else hipLaunchKernelGGL((k_boundary_singular<DIM, DPE, (DIM == 2 ? 1 : 0), KT>), dim3(grid), dim3(PNL_NTHREADS), 0, ctx->stream, ctx->P, pairs, np, (double*)ctx->b_D.p, cell_begin, cell_end);
+        const bool fast = ctx->P.bkn.fast;
+        if (s == 0 && fast) hipLaunchKernelGGL((k_boundary_singular<DIM, DPE, 0, 1>), dim3(grid), dim3(PNL_NTHREADS), 0, ctx->stream, ctx->P, pairs, np, (double*)ctx->b_D.p, cell_begin, cell_end);
+        else if (s == 0) hipLaunchKernelGGL((k_boundary_singular<DIM, DPE, 0, 0>), dim3(grid), dim3(PNL_NTHREADS), 0, ctx->stream, ctx->P, pairs, np, (double*)ctx->b_D.p, cell_begin, cell_end);
+        else if (fast) hipLaunchKernelGGL((k_boundary_singular<DIM, DPE, (DIM == 2 ? 1 : 0), 1>), dim3(grid), dim3(PNL_NTHREADS), 0, ctx->stream, ctx->P, pairs, np, (double*)ctx->b_D.p, cell_begin, cell_end);
+        else hipLaunchKernelGGL((k_boundary_singular<DIM, DPE, (DIM == 2 ? 1 : 0), 0>), dim3(grid), dim3(PNL_NTHREADS), 0, ctx->stream, ctx->P, pairs, np, (double*)ctx->b_D.p, cell_begin, cell_end);
         HIPCHK(ctx, hipGetLastError());
     }
     return PNL_OK;
@@ -638,6 +683,32 @@ int pnl_upload_distant_rules(pnl_context *ctx, int qmax, const int32_t *off, con
     if ((rc = upload(ctx, ctx->b_foff, foff, (size_t)qmax+2))) return rc;
     if ((rc = upload(ctx, ctx->b_fbary, fbary, (size_t)ftotal*2))) return rc;
     if ((rc = upload(ctx, ctx->b_fw, fw, (size_t)ftotal))) return rc;
+    // pack the orders with 2, 3, 4, 6 or 7 points (the unrolled lane-per-pair variants) for the tile kernel's LDS copy
+    {
+        const int dpe = ctx->dpe, st = 4+dpe;
+        std::vector<int32_t> tn(PNL_MAXQ+2, 0), to(PNL_MAXQ+2, 0);
+        std::vector<double> tab;
+        int npts = 0, nb = 0;
+        // the tile kernel unrolls exactly two point counts: 3 and 6 on triangles, 2 and 3 on intervals
+        const int nA = ctx->dim == 2 ? 3 : 2, nB = ctx->dim == 2 ? 6 : 3;
+        for (int q = 2; q <= qmax && q < 18; q++) {
+            const int n = off[q+1]-off[q];
+            const bool ok = (n == nA || n == nB);
+            if (!ok || nb >= 16 || npts+n > 96) continue;
+            tn[q] = n; to[q] = npts;
+            for (int i = 0; i < n; i++) {
+                const size_t p = (size_t)off[q]+i;
+                tab.push_back(bary[3*p]); tab.push_back(bary[3*p+1]); tab.push_back(bary[3*p+2]); tab.push_back(w[p]);
+                for (int a = 0; a < dpe; a++) tab.push_back(phi[p*dpe+a]);
+            }
+            npts += n; nb++;
+            (void)st;
+        }
+        if ((rc = upload(ctx, ctx->b_ttn, tn.data(), tn.size()))) return rc;
+        if ((rc = upload(ctx, ctx->b_ttoff, to.data(), to.size()))) return rc;
+        if ((rc = upload(ctx, ctx->b_tttab, tab.data(), tab.size()))) return rc;
+        ctx->P.tt_npts = npts;
+    }
     ctx->qmax = qmax;
     ctx->have_rules = true;
     return PNL_OK;

@@ -24,10 +24,9 @@ __device__ __forceinline__ double kern_eval(const DevKernel &k, double d2) {
         // s = 1/2 in 2D: C * d2^(-3/2)
         double r = __builtin_amdgcn_rsq(d2);            // ~2^-26 relative
         double h = 0.5*d2;
-        r = r*__builtin_fma(-h*r, r, 1.5);              // Newton, quadratic convergence
+        r = r*__builtin_fma(-h*r, r, 1.5);              // Newton: v_rsq_f64 (~2^-23) -> ~2^-45 -> full fp64
         r = r*__builtin_fma(-h*r, r, 1.5);
-        r = r*__builtin_fma(-h*r, r, 1.5);
-        return (r*r)*(r*k.scale);
+        return (r*r)*r;                                  // scale is applied once per pair (kern_scale)
     } else {
         if (!(d2 <= k.horizon2)) return 0.;
         if (k.ktype == 0) return k.scale*pow(d2, k.exponent);
@@ -35,6 +34,9 @@ __device__ __forceinline__ double kern_eval(const DevKernel &k, double d2) {
         return k.scale/sqrt(d2);
     }
 }
+
+template <int KT>
+__device__ __forceinline__ double kern_scale(const DevKernel &k) { return KT == 1 ? k.scale : 1.; }
 
 // distant quadrature order  (FL2:622-642, :1226-1243, FL1:234-253, :646-660)
 __device__ __forceinline__ int quad_order(const DevFormula &F, double H0, double h1, double h2, double d) {
@@ -49,11 +51,23 @@ __device__ __forceinline__ int quad_order(const DevFormula &F, double H0, double
     return q1 > q2 ? q1 : q2;
 }
 
-// Same order, decided in fp32 where that is safe: the fp32 value of the ceil() argument is off by < 1e-4, so
-// whenever it is further than 1e-3 from an integer the fp64 formula gives the same ceil; otherwise (rare) the
-// exact formula above is evaluated.  lh = ln(h), L = |ln(h/H0)| per cell are staged once per tile.
-__device__ __forceinline__ int quad_order_fast(const DevFormula &F, double H0, double h1, double h2, float lh1, float lh2,
-                                               float L1, float L2, double d2) {
+// Same order, decided in fp32 where that is safe: the fp32 value of the ceil() argument is off by < 2e-5 (v_log_f32 /
+// v_rcp_f32 are 1 ulp, the operands are O(10)), so whenever it is further than 2e-4 from an integer the fp64 formula
+// gives the same ceil; otherwise (0.03 % of the pairs) the exact fp64 formula decides.  lh = ln h and L = |ln(h/H0)| per
+// cell are staged once per tile in fp32, Ld = |ln(h/H0)| in fp64 for the exact path.
+__device__ __forceinline__ int quad_order_exact(const DevFormula &F, double h1, double h2, double Ld1, double Ld2, double d) {
+    const double logdh1 = log(d/h1), logdh2 = log(d/h2);
+    const double Lm = fmax(Ld1, Ld2);
+    double n1 = logdh1, n2 = logdh2;
+    if (F.clip) { n1 = fmax(logdh1, 0.); n2 = fmax(logdh2, 0.); }
+    const double p1 = ceil((F.c0 + F.a*Ld2 + F.b*Lm - F.e*n2)/(fmax(logdh1, 0.) + F.den0));
+    const double p2 = ceil((F.c0 + F.a*Ld1 + F.b*Lm - F.e*n1)/(fmax(logdh2, 0.) + F.den0));
+    const int q1 = (int)fmax(p1, 2.), q2 = (int)fmax(p2, 2.);
+    return q1 > q2 ? q1 : q2;
+}
+
+__device__ __forceinline__ int quad_order_fast(const DevFormula &F, double h1, double h2, float lh1, float lh2,
+                                               float L1, float L2, double Ld1, double Ld2, double d2) {
     const float ld = 0.5f*0.69314718056f*__builtin_amdgcn_logf((float)d2);
     const float logdh1 = ld-lh1, logdh2 = ld-lh2;
     const float Lm = fmaxf(L1, L2);
@@ -62,8 +76,8 @@ __device__ __forceinline__ int quad_order_fast(const DevFormula &F, double H0, d
     const float a1 = (c0+a*L2+b*Lm-e*n2)*__builtin_amdgcn_rcpf(fmaxf(logdh1, 0.f)+den0);
     const float a2 = (c0+a*L1+b*Lm-e*n1)*__builtin_amdgcn_rcpf(fmaxf(logdh2, 0.f)+den0);
     const float r1 = rintf(a1), r2 = rintf(a2);
-    const bool risky = (a1 > 1.5f && fabsf(a1-r1) < 1e-3f) || (a2 > 1.5f && fabsf(a2-r2) < 1e-3f) || !(a1 == a1) || !(a2 == a2);
-    if (risky) return quad_order(F, H0, h1, h2, sqrt(d2));
+    const bool risky = (a1 > 1.5f && fabsf(a1-r1) < 2e-4f) || (a2 > 1.5f && fabsf(a2-r2) < 2e-4f) || !(a1 == a1) || !(a2 == a2);
+    if (risky) return quad_order_exact(F, h1, h2, Ld1, Ld2, sqrt(d2));
     const int q1 = (int)fmaxf(ceilf(a1), 2.f), q2 = (int)fmaxf(ceilf(a2), 2.f);
     return q1 > q2 ? q1 : q2;
 }
@@ -154,14 +168,12 @@ __device__ __forceinline__ void eval_distant_generic(const DevProblem &P, int of
     }
 }
 
-// compile-time number of points: y_j and the column sums stay in registers
+// compile-time number of points: y_j and the column sums stay in registers.  The rule comes from the tile's LDS copy
+// (layout per point: bary[3], w, phi[DPE]); all lanes read the same address, so every read is an LDS broadcast.
 template <int DIM, int DPE, int KT, int N>
-__device__ __forceinline__ void eval_distant_fixed(const DevProblem &P, int off, const double *av, const double *bv,
-                                                   PairAcc<DIM, DPE> &R) {
-    constexpr int NV = DIM+1;
-    const double *__restrict__ bary = P.bary+3*(size_t)off;
-    const double *__restrict__ w = P.w+off;
-    const double *__restrict__ phi = P.phi+(size_t)off*DPE;
+__device__ __forceinline__ void eval_distant_fixed(const DevProblem &P, const double *__restrict__ tab, const double *av,
+                                                   const double *bv, PairAcc<DIM, DPE> &R) {
+    constexpr int NV = DIM+1, ST = 4+DPE;
     double y[N][DIM], c[N];
 #pragma unroll
     for (int j = 0; j < N; j++) {
@@ -170,7 +182,7 @@ __device__ __forceinline__ void eval_distant_fixed(const DevProblem &P, int off,
         for (int d = 0; d < DIM; d++) {
             double s = 0.;
 #pragma unroll
-            for (int k = 0; k < NV; k++) s = __builtin_fma(bary[3*j+k], bv[k*DIM+d], s);
+            for (int k = 0; k < NV; k++) s = __builtin_fma(tab[j*ST+k], bv[k*DIM+d], s);
             y[j][d] = s;
         }
     }
@@ -181,10 +193,10 @@ __device__ __forceinline__ void eval_distant_fixed(const DevProblem &P, int off,
         for (int d = 0; d < DIM; d++) {
             double s = 0.;
 #pragma unroll
-            for (int k = 0; k < NV; k++) s = __builtin_fma(bary[3*i+k], av[k*DIM+d], s);
+            for (int k = 0; k < NV; k++) s = __builtin_fma(tab[i*ST+k], av[k*DIM+d], s);
             x[d] = s;
         }
-        const double wi = w[i];
+        const double wi = tab[i*ST+3];
         double r = 0., u[DPE];
 #pragma unroll
         for (int b = 0; b < DPE; b++) u[b] = 0.;
@@ -193,21 +205,21 @@ __device__ __forceinline__ void eval_distant_fixed(const DevProblem &P, int off,
             double d2 = 0.;
 #pragma unroll
             for (int d = 0; d < DIM; d++) { double t = x[d]-y[j][d]; d2 = __builtin_fma(t, t, d2); }
-            const double K = (wi*w[j])*kern_eval<KT>(P.k, d2);
+            const double K = (wi*tab[j*ST+3])*kern_eval<KT>(P.k, d2);
             r += K;
             c[j] += K;
 #pragma unroll
-            for (int b = 0; b < DPE; b++) u[b] = __builtin_fma(K, phi[j*DPE+b], u[b]);
+            for (int b = 0; b < DPE; b++) u[b] = __builtin_fma(K, tab[j*ST+4+b], u[b]);
         }
         int e = 0;
 #pragma unroll
         for (int a = 0; a < DPE; a++) {
-            const double pa = phi[i*DPE+a];
+            const double pa = tab[i*ST+4+a];
 #pragma unroll
             for (int b = 0; b < DPE; b++) R.G[a][b] = __builtin_fma(pa, u[b], R.G[a][b]);
             const double pr = pa*r;
 #pragma unroll
-            for (int b = a; b < DPE; b++) { R.S1[e] = __builtin_fma(pr, phi[i*DPE+b], R.S1[e]); e++; }
+            for (int b = a; b < DPE; b++) { R.S1[e] = __builtin_fma(pr, tab[i*ST+4+b], R.S1[e]); e++; }
         }
     }
 #pragma unroll
@@ -215,9 +227,9 @@ __device__ __forceinline__ void eval_distant_fixed(const DevProblem &P, int off,
         int e = 0;
 #pragma unroll
         for (int a = 0; a < DPE; a++) {
-            const double pc = phi[j*DPE+a]*c[j];
+            const double pc = tab[j*ST+4+a]*c[j];
 #pragma unroll
-            for (int b = a; b < DPE; b++) { R.S2[e] = __builtin_fma(pc, phi[j*DPE+b], R.S2[e]); e++; }
+            for (int b = a; b < DPE; b++) { R.S2[e] = __builtin_fma(pc, tab[j*ST+4+b], R.S2[e]); e++; }
         }
     }
 }
@@ -225,6 +237,7 @@ __device__ __forceinline__ void eval_distant_fixed(const DevProblem &P, int off,
 // ---------------------------------------------------------------------------------------------
 // Tile kernel: classification (NO:280-378 vertex test, NO:493-540 + FL2:622-642 order) and distant
 // evaluation for one TILE x TILE block of cell pairs.
+#define PNL_TT_MAXPTS 96
 template <int DIM, int DPE, int TILE>
 struct TileSmem {
     static constexpr int NV = DIM+1, NC = NV*DIM, ND = DPE*(DPE+1)/2;
@@ -234,7 +247,9 @@ struct TileSmem {
     static constexpr int o_vol = o_cen+2*DIM*TILE;         // [2][TILE]
     static constexpr int o_h = o_vol+2*TILE;               // [2][TILE]
     static constexpr int o_D = o_h+2*TILE;                 // [2][TILE][ND]
-    static constexpr int n_dbl = o_D+2*TILE*ND;
+    static constexpr int o_Ld = o_D+2*TILE*ND;             // [2][TILE] |ln(h/H0)| in fp64
+    static constexpr int o_tt = o_Ld+2*TILE;               // [PNL_TT_MAXPTS][4+DPE] rules integrated one pair per lane
+    static constexpr int n_dbl = o_tt+PNL_TT_MAXPTS*(4+DPE);
     // ints after the doubles
     static constexpr int o_vid = 0;                        // [2][NV][TILE]
     static constexpr int o_cnt = o_vid+2*NV*TILE;          // [PNL_MAXQ+2]
@@ -242,18 +257,44 @@ struct TileSmem {
     static constexpr int o_misc = o_cur+PNL_MAXQ+2;        // [4]: list length, work-list base, #eligible buckets
     static constexpr int o_el = o_misc+4;                  // [2][16]: order and list end of the populated eligible buckets
     static constexpr int o_lh = o_el+32;                   // float [2][2][TILE]: ln h, |ln(h/H0)|
-    static constexpr int o_q = o_lh+4*TILE;                // unsigned char [TILE*TILE] order of each pair
-    static constexpr int n_int = o_q+TILE*TILE/4;
+    static constexpr int o_ttn = o_lh+4*TILE;          // [PNL_MAXQ+2] points of order q if the tile kernel integrates it, else 0
+    static constexpr int o_tto = o_ttn+PNL_MAXQ+2;         // [PNL_MAXQ+2] its offset (points) in the table blob
+    static constexpr int n_int = o_tto+PNL_MAXQ+2;
     // shorts after the ints
     static constexpr int o_slot = 0;                       // [2][DPE][TILE]
-    static constexpr int o_list = o_slot+2*DPE*TILE;       // [TILE*TILE]
-    static constexpr int n_short = o_list+TILE*TILE;
+    static constexpr int o_list = o_slot+2*DPE*TILE;       // [TILE*TILE] list A (16 bit) + [TILE*TILE] list B / far list (32 bit)
+    static constexpr int n_short = o_list+3*TILE*TILE;
     static constexpr size_t fixed_bytes = sizeof(double)*n_dbl+sizeof(int)*n_int+sizeof(short)*((n_short+3)/4*4);
 };
 
+// Wave-aggregated bucket counter: lanes with the same key q (> 0) are handed consecutive positions from ONE LDS atomic
+// per distinct key instead of one atomic per lane (most lanes of a wave share the key).
+__device__ __forceinline__ int wave_bucket_add(int *counters, int q, bool fetch) {
+    int pos = 0;
+    unsigned long long todo = __ballot(q > 0);
+    const unsigned long long lt = (1ull << (threadIdx.x & 63))-1ull;
+    while (todo) {
+        const int leader = __ffsll((long long)todo)-1;
+        const int qL = __builtin_amdgcn_readlane(q, leader);
+        const unsigned long long same = __ballot(q == qL);
+        int base = 0;
+        if ((int)(threadIdx.x & 63) == leader) base = atomicAdd(&counters[qL], __popcll(same));
+        if (fetch) {
+            base = __builtin_amdgcn_readlane(base, leader);
+            if (q == qL) pos = base+__popcll(same & lt);
+        }
+        todo &= ~same;
+    }
+    return pos;
+}
+
 // number of points of a distant rule the tile kernel integrates one pair per lane (fully unrolled);
 // every other order goes to the global work list and is integrated one pair per wave.
+#ifdef PNL_ONLY_N3
+__device__ __forceinline__ bool tile_eligible(int n) { return n == 3; }
+#else
 __device__ __forceinline__ bool tile_eligible(int n) { return n == 2 || n == 3 || n == 4 || n == 6 || n == 7; }
+#endif
 
 #ifndef PNL_TILE_WAVES
 #define PNL_TILE_WAVES 2      // waves per SIMD the tile kernel is register-limited to (measured: 2 beats 3 and 4)
@@ -262,7 +303,7 @@ template <int DIM, int DPE, int TILE, int KT>
 __global__ void __launch_bounds__(PNL_NTHREADS, PNL_TILE_WAVES)
 k_tile_distant(const DevProblem P, const int2 *__restrict__ tiles, double *__restrict__ A, long long ldA,
                double *__restrict__ Dglob, int cell_begin, int cell_end, int acc_stride, int4 *__restrict__ worklist,
-               unsigned *__restrict__ wl_count, unsigned wl_cap, int ablate) {
+               unsigned *__restrict__ wl_count, unsigned wl_cap, int ablate, int ntiles) {
     using S = TileSmem<DIM, DPE, TILE>;
     constexpr int NV = S::NV, NC = S::NC, ND = S::ND;
     constexpr int PAIRS = TILE*TILE, PER_THREAD = PAIRS/PNL_NTHREADS;
@@ -276,10 +317,14 @@ k_tile_distant(const DevProblem P, const int2 *__restrict__ tiles, double *__res
     short *s_slot = s_short+S::o_slot;
     unsigned short *s_list = (unsigned short*)(s_short+S::o_list);
     float *s_lh = (float*)(s_int+S::o_lh);
-    unsigned char *s_q = (unsigned char*)(s_int+S::o_q);
+    int *s_ttn = s_int+S::o_ttn, *s_tto = s_int+S::o_tto;
+    double *s_tt = s_dbl+S::o_tt, *s_Ld = s_dbl+S::o_Ld;
 
     const int tid = threadIdx.x;
-    const int2 tl = tiles[blockIdx.x];
+    // persistent workgroups: each one walks the tile list with stride gridDim.x (heavy tiles come first in the list)
+#pragma unroll 1
+    for (int tile_idx = blockIdx.x; tile_idx < ntiles; tile_idx += gridDim.x) {
+    const int2 tl = tiles[tile_idx];
     const int ta = tl.x, tb = tl.y;
     const int nA = P.blk_ndof[ta], nB = P.blk_ndof[tb];
 
@@ -294,30 +339,41 @@ k_tile_distant(const DevProblem P, const int2 *__restrict__ tiles, double *__res
         s_vol[side*TILE+l] = P.cvol[c];
         const double hc = P.ch[c];
         s_h[side*TILE+l] = hc;
+        const double Ld = fabs(log(hc/P.H0));
+        s_Ld[side*TILE+l] = Ld;
         s_lh[(side*2+0)*TILE+l] = (float)log(hc);
-        s_lh[(side*2+1)*TILE+l] = (float)fabs(log(hc/P.H0));
+        s_lh[(side*2+1)*TILE+l] = (float)Ld;
 #pragma unroll
         for (int k = 0; k < NV; k++) s_vid[(side*NV+k)*TILE+l] = P.cvid[(size_t)k*P.ncp+c];
 #pragma unroll
         for (int k = 0; k < DPE; k++) s_slot[(side*DPE+k)*TILE+l] = P.cslot[(size_t)k*P.ncp+c];
     }
+    for (int t = tid; t < PNL_MAXQ+2; t += PNL_NTHREADS) { s_ttn[t] = P.tt_n[t]; s_tto[t] = P.tt_off[t]; }
+    for (int t = tid; t < P.tt_npts*(4+DPE); t += PNL_NTHREADS) s_tt[t] = P.tt_tab[t];
     for (int t = tid; t < nA*acc_stride; t += PNL_NTHREADS) s_acc[t] = 0.;
     for (int t = tid; t < 2*TILE*ND; t += PNL_NTHREADS) s_D[t] = 0.;
-    for (int t = tid; t < 2*(PNL_MAXQ+2); t += PNL_NTHREADS) s_cnt[t] = 0;      // s_cnt and s_cur are adjacent
+    for (int t = tid; t < 2*(PNL_MAXQ+2)+4; t += PNL_NTHREADS) s_cnt[t] = 0;    // s_cnt, s_cur and s_misc are adjacent
     __syncthreads();
 
     // ---- classification ------------------------------------------------------------------------
     // pair p -> (i, j) along wrapped diagonals: consecutive lanes get distinct a-cells AND distinct
     // b-cells, so the per-cell LDS accumulators below see (almost) no same-address conflicts.
+    // Pairs whose order has NA points (the far-field order 2) go to list A, those with NB points to list B,
+    // everything else to the global work list.  No sorting, no prefix sums: one barrier.
+    constexpr int NA = (DIM == 2) ? 3 : 2, NB = (DIM == 2) ? 6 : 3;
+    // list B grows from the front of s_l32, the far list (pairs for the global work list) from its back
+    int *s_l32 = (int*)(s_list+PAIRS+((((size_t)(s_list+PAIRS)) & 2) ? 1 : 0));
     int overflow = 0;
-#pragma unroll 1
+    const int lane = tid & 63;
+    const unsigned long long lt = (1ull << lane)-1ull;
+#pragma unroll 2
     for (int it = 0; it < PER_THREAD; it++) {
         const int p = it*PNL_NTHREADS+tid;
         const int j = p%TILE, i = (p/TILE+j)%TILE;
         int q = 0;
         const int va0 = s_vid[(0*NV+0)*TILE+i], vb0 = s_vid[(1*NV+0)*TILE+j];
         const int ca = ta*TILE+i;
-        bool ok = (va0 >= 0) && (vb0 >= 0) && (ta < tb || i < j) && (ca >= cell_begin) && (ca < cell_end);
+        bool ok = (va0 >= 0) && (vb0 >= 0) && (ta < tb || i < j) && (ca >= cell_begin) && (ca < cell_end) && !(ablate & 8);
         if (ok) {
             // NA:138-150: skip pairs with boundary DoFs only;  NO:311-323: shared vertices -> singular pair
             bool any_dof = false, shared = false;
@@ -337,125 +393,122 @@ k_tile_distant(const DevProblem P, const int2 *__restrict__ tiles, double *__res
                     const double t = s_cen[(0*DIM+d)*TILE+i]-s_cen[(1*DIM+d)*TILE+j];
                     d2 += t*t;
                 }
-                q = quad_order_fast(P.qo, P.H0, s_h[i], s_h[TILE+j], s_lh[i], s_lh[2*TILE+j], s_lh[TILE+i], s_lh[3*TILE+j], d2);
+                if (ablate & 16) q = 2;
+                else q = quad_order_fast(P.qo, s_h[i], s_h[TILE+j], s_lh[i], s_lh[2*TILE+j], s_lh[TILE+i], s_lh[3*TILE+j],
+                                         s_Ld[i], s_Ld[TILE+j], d2);
                 if (q > P.qmax || q > PNL_MAXQ) { overflow++; q = 0; }
             }
         }
-        s_q[p] = (unsigned char)q;
-        if (q) atomicAdd(&s_cnt[q], 1);
+        wave_bucket_add(s_cnt, q, false);                       // statistics only
+        const int nq = q ? s_ttn[q] : 0;
+        const int cls = !q ? 0 : ((nq == NA && q < 18) ? 1 : ((nq == NB && q < 18) ? 2 : 3));
+        const unsigned short ent = (unsigned short)(p | ((q-2) << 12));
+        // one returning atomic per class and wave
+        const unsigned long long mA = __ballot(cls == 1), mB = __ballot(cls == 2), mF = __ballot(cls == 3);
+        if (mA) {
+            int base = 0;
+            const int leader = __ffsll((long long)mA)-1;
+            if (lane == leader) base = atomicAdd(&s_misc[0], __popcll(mA));
+            base = __builtin_amdgcn_readlane(base, leader);
+            if (cls == 1) s_list[base+__popcll(mA & lt)] = ent;
+        }
+        if (mB) {
+            int base = 0;
+            const int leader = __ffsll((long long)mB)-1;
+            if (lane == leader) base = atomicAdd(&s_misc[1], __popcll(mB));
+            base = __builtin_amdgcn_readlane(base, leader);
+            if (cls == 2) s_l32[base+__popcll(mB & lt)] = ent;
+        }
+        if (mF) {
+            int base = 0;
+            const int leader = __ffsll((long long)mF)-1;
+            if (lane == leader) base = atomicAdd(&s_misc[2], __popcll(mF));
+            base = __builtin_amdgcn_readlane(base, leader);
+            if (cls == 3) s_l32[PAIRS-1-(base+__popcll(mF & lt))] = p | (q << 12);
+        }
     }
     if (overflow) atomicAdd(&P.counters[5], (unsigned long long)overflow);
     __syncthreads();
-    if (tid == 0) {
-        // exclusive prefixes over the orders: tile-eligible orders index the LDS list, the others a slice of
-        // the global work list reserved with one atomic
-        int run = 0, far = 0, nel = 0;
-        unsigned long long evals = 0;
-        for (int q = 2; q <= P.qmax; q++) {
-            const int cq = s_cnt[q];
-            if (!cq) continue;
-            const int n = P.off[q+1]-P.off[q];
-            if (tile_eligible(n) && nel < 16) { s_cur[q] = run; run += cq; s_el[nel] = q; s_el[16+nel] = run; nel++; }
-            else { s_cur[q] = far; far += cq; s_cnt[q] = -cq; }
-            evals += (unsigned long long)n*n*cq;
-            atomicAdd(&P.counters[8+q], (unsigned long long)cq);
-        }
-        s_misc[0] = run;
-        s_misc[2] = nel;
-        unsigned base = 0;
-        if (far) base = atomicAdd(wl_count, (unsigned)far);
-        s_misc[1] = (int)base;
-        if (run+far) {
-            atomicAdd(&P.counters[1], (unsigned long long)(run+far));
-            atomicAdd(&P.counters[2], evals);
-        }
-    }
-    __syncthreads();
     {
-        const unsigned base = (unsigned)s_misc[1];
-#pragma unroll 1
-        for (int it = 0; it < PER_THREAD; it++) {
-            const int p = it*PNL_NTHREADS+tid;
-            const int q = s_q[p];
-            if (q) {
-                const int pos = atomicAdd(&s_cur[q], 1);
-                if (s_cnt[q] > 0) s_list[pos] = (unsigned short)p;
-                else {
-                    const unsigned g = base+(unsigned)pos;
-                    const int j = p%TILE, i = (p/TILE+j)%TILE;
-                    if (g < wl_cap) worklist[g] = make_int4(ta*TILE+i, tb*TILE+j, q, 0);
-                }
+        // far pairs: one reservation in the global work list per tile, then a coalesced copy
+        const int nF = s_misc[2];
+        if (nF) {
+            if (tid == 0) s_misc[3] = (int)atomicAdd(wl_count, (unsigned)nF);
+            __syncthreads();
+            const unsigned base = (unsigned)s_misc[3];
+            for (int t = tid; t < nF; t += PNL_NTHREADS) {
+                const int ent = s_l32[PAIRS-1-t];
+                const int p = ent & 4095, q = ent >> 12;
+                const int j = p%TILE, i = (p/TILE+j)%TILE;
+                const int off = P.off[q];
+                if (base+t < wl_cap) worklist[base+t] = make_int4(ta*TILE+i, tb*TILE+j, off, P.off[q+1]-off);
             }
         }
     }
-    __syncthreads();
-    // after the fill s_cur[q] = end of bucket q in the LDS list (for eligible q)
+    // statistics: one thread per order
+    for (int q = 2+tid; q <= P.qmax; q += PNL_NTHREADS) {
+        const int cq = s_cnt[q];
+        if (cq) {
+            const int ne = s_ttn[q];
+            const unsigned long long n = (unsigned long long)(ne ? ne : P.off[q+1]-P.off[q]);
+            atomicAdd(&P.counters[8+q], (unsigned long long)cq);
+            atomicAdd(&P.counters[1], (unsigned long long)cq);
+            atomicAdd(&P.counters[2], n*n*cq);
+        }
+    }
 
-    // ---- evaluation: waves take 64-pair chunks of the order-sorted list; inside a chunk the (at most few)
-    //      orders present run one after the other so that every lane of a pass has the same trip count ----
-    const int total = __builtin_amdgcn_readfirstlane(s_misc[0]);
-    const int nel = __builtin_amdgcn_readfirstlane(s_misc[2]);
-    const int wave = tid >> 6, lane = tid & 63;
+    // ---- evaluation: waves take 64-pair chunks of list A, then of list B ---------------------------------------
+    const int wave = tid >> 6;
     if (!(ablate & 2))
-    for (int c0 = wave*64; c0 < total; c0 += PNL_NTHREADS) {
-        const int idx = c0+lane;
-        const bool act = idx < total;
-        const int p = act ? s_list[idx] : 0;
-        const int j = p%TILE, i = (p/TILE+j)%TILE;
-        // order of this entry: first q whose bucket end exceeds idx
-        int myq = 0;
-        if (act)
-            for (int k = nel-1; k >= 0; k--)
-                if (idx < s_el[16+k]) myq = s_el[k];
-        double av[NC], bv[NC];
+#pragma unroll 1
+    for (int pass = 0; pass < 2; pass++) {
+        const int total = __builtin_amdgcn_readfirstlane(s_misc[pass]);
+#pragma unroll 1
+        for (int c0 = wave*64; c0 < total; c0 += PNL_NTHREADS) {
+            const int idx = c0+lane;
+            const bool act = idx < total;
+            const int ent = act ? (pass ? s_l32[idx] : (int)s_list[idx]) : 0;
+            const int p = ent & 4095, q = (ent >> 12)+2;
+            const int j = p%TILE, i = (p/TILE+j)%TILE;
+            const double *tab = s_tt+s_tto[q]*(4+DPE);
+            double av[NC], bv[NC];
 #pragma unroll
-        for (int k = 0; k < NC; k++) { av[k] = s_v[(0*NC+k)*TILE+i]; bv[k] = s_v[(1*NC+k)*TILE+j]; }
-        PairAcc<DIM, DPE> R;
-        R.clear();
-        unsigned long long todo = __ballot(act);
-        while (todo) {
-            const int src = __ffsll((long long)todo)-1;
-            const int q = __shfl(myq, src, 64);
-            const bool mine = act && (myq == q);
-            todo &= ~__ballot(mine);
-            const int off = __builtin_amdgcn_readfirstlane(P.off[q]);
-            const int n = __builtin_amdgcn_readfirstlane(P.off[q+1])-off;
-            if (mine) {
-                if (n == 3) eval_distant_fixed<DIM, DPE, KT, 3>(P, off, av, bv, R);
-                else if (n == 6) eval_distant_fixed<DIM, DPE, KT, 6>(P, off, av, bv, R);
-                else if (n == 7) eval_distant_fixed<DIM, DPE, KT, 7>(P, off, av, bv, R);
-                else if (n == 2) eval_distant_fixed<DIM, DPE, KT, 2>(P, off, av, bv, R);
-                else eval_distant_fixed<DIM, DPE, KT, 4>(P, off, av, bv, R);
+            for (int k = 0; k < NC; k++) { av[k] = s_v[(0*NC+k)*TILE+i]; bv[k] = s_v[(1*NC+k)*TILE+j]; }
+            PairAcc<DIM, DPE> R;
+            R.clear();
+            if (act) {
+                if (pass == 0) eval_distant_fixed<DIM, DPE, KT, NA>(P, tab, av, bv, R);
+                else eval_distant_fixed<DIM, DPE, KT, NB>(P, tab, av, bv, R);
             }
-        }
-        if (!act) continue;
-        // NA:1405-1410: symmetric cell pairs count twice
-        const double vv = 2.*s_vol[i]*s_vol[TILE+j];
-        if (ablate & 1) {
-            double keep = 0.;
+            if (!act) continue;
+            // NA:1405-1410: symmetric cell pairs count twice
+            const double vv = 2.*s_vol[i]*s_vol[TILE+j]*kern_scale<KT>(P.k);
+            if (ablate & 1) {
+                double keep = 0.;
 #pragma unroll
-            for (int a = 0; a < DPE; a++)
+                for (int a = 0; a < DPE; a++)
 #pragma unroll
-                for (int b = 0; b < DPE; b++) keep += R.G[a][b];
+                    for (int b = 0; b < DPE; b++) keep += R.G[a][b];
 #pragma unroll
-            for (int e2 = 0; e2 < ND; e2++) keep += R.S1[e2]+R.S2[e2];
-            if (keep == 1.2345e300) s_D[0] = keep*vv;
-            continue;
-        }
-        int e = 0;
-#pragma unroll
-        for (int a = 0; a < DPE; a++) {
-            const int sa = s_slot[(0*DPE+a)*TILE+i];
-#pragma unroll
-            for (int b = 0; b < DPE; b++) {
-                const int sb = s_slot[(1*DPE+b)*TILE+j];
-                if (sa >= 0 && sb >= 0) lds_add_f64(&s_acc[sa*acc_stride+sb], -vv*R.G[a][b]);
+                for (int e2 = 0; e2 < ND; e2++) keep += R.S1[e2]+R.S2[e2];
+                if (keep == 1.2345e300) s_D[0] = keep*vv;
+                continue;
             }
+            int e = 0;
 #pragma unroll
-            for (int b = a; b < DPE; b++) {
-                lds_add_f64(&s_D[(0*TILE+i)*ND+e], vv*R.S1[e]);
-                lds_add_f64(&s_D[(1*TILE+j)*ND+e], vv*R.S2[e]);
-                e++;
+            for (int a = 0; a < DPE; a++) {
+                const int sa = s_slot[(0*DPE+a)*TILE+i];
+#pragma unroll
+                for (int b = 0; b < DPE; b++) {
+                    const int sb = s_slot[(1*DPE+b)*TILE+j];
+                    if (sa >= 0 && sb >= 0) lds_add_f64(&s_acc[sa*acc_stride+sb], -vv*R.G[a][b]);
+                }
+#pragma unroll
+                for (int b = a; b < DPE; b++) {
+                    lds_add_f64(&s_D[(0*TILE+i)*ND+e], vv*R.S1[e]);
+                    lds_add_f64(&s_D[(1*TILE+j)*ND+e], vv*R.S2[e]);
+                    e++;
+                }
             }
         }
     }
@@ -464,7 +517,7 @@ k_tile_distant(const DevProblem P, const int2 *__restrict__ tiles, double *__res
     // ---- flush: sub-block of A' (rows = DoFs of block a, cols = DoFs of block b) and diagonal blocks ----
     const int *__restrict__ dofA = P.blk_dofs+(size_t)ta*P.blk_stride;
     const int *__restrict__ dofB = P.blk_dofs+(size_t)tb*P.blk_stride;
-    if (ablate & 4) return;
+    if (!(ablate & 4)) {
     for (int t = tid; t < nA*nB; t += PNL_NTHREADS) {
         const int r = t/nB, c = t-r*nB;
         const double v = s_acc[r*acc_stride+c];
@@ -478,19 +531,49 @@ k_tile_distant(const DevProblem P, const int2 *__restrict__ tiles, double *__res
             atomic_add_f64(&Dglob[(size_t)c*ND+rem%ND], v);
         }
     }
+    }
+    __syncthreads();
+    }   // tile loop
 }
 
 // ---------------------------------------------------------------------------------------------
-// wave-wide sum (butterfly), result in every lane
+// wave-wide sum with DPP row shifts / broadcasts (no LDS traffic); result in every lane
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_add(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xf, false);
+    return v+__hiloint2double(hi, lo);
+}
 __device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    v = dpp_add<0x111, 0xf>(v);      // row_shr:1
+    v = dpp_add<0x112, 0xf>(v);      // row_shr:2
+    v = dpp_add<0x114, 0xf>(v);      // row_shr:4
+    v = dpp_add<0x118, 0xf>(v);      // row_shr:8  -> lane 15 of every row holds the row sum
+    v = dpp_add<0x142, 0xa>(v);      // row_bcast:15 into rows 1 and 3
+    v = dpp_add<0x143, 0xc>(v);      // row_bcast:31 into rows 2 and 3 -> lane 63 holds the total
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+    return __hiloint2double(hi, lo);
+}
+
+// sum over the 16 lanes of a DPP row, result in every lane of the row
+template <int CTRL>
+__device__ __forceinline__ double dpp_row_add(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+    return v+__hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double row16_sum(double v) {
+    v = dpp_row_add<0xB1>(v);        // quad_perm [1,0,3,2]
+    v = dpp_row_add<0x4E>(v);        // quad_perm [2,3,0,1]
+    v = dpp_row_add<0x141>(v);       // row_half_mirror
+    v = dpp_row_add<0x140>(v);       // row_mirror
     return v;
 }
 
-// Distant pairs of the orders the tile kernel does not unroll (NO:722-789): one wave per pair, lanes over
-// the n*n point pairs of the tensor rule, butterfly reduction of the local matrix, atomic scatter.
-// A' receives the cross block on the (c1-DoF, c2-DoF) side only, like the tile kernel.
+// Distant pairs of the orders the tile kernel does not unroll (NO:722-789): one wave per pair, lanes over the n*n
+// point pairs of the tensor rule, DPP reduction of the local matrix, atomic scatter.  A' receives the cross block on
+// the (c1-DoF, c2-DoF) side only, like the tile kernel.  Work-list entry: (c1, c2, rule offset, n).
 template <int DIM, int DPE, int KT>
 __global__ void __launch_bounds__(PNL_NTHREADS)
 k_worklist_pairs(const DevProblem P, const int4 *__restrict__ worklist, const unsigned *__restrict__ wl_count, unsigned wl_cap,
@@ -499,11 +582,13 @@ k_worklist_pairs(const DevProblem P, const int4 *__restrict__ worklist, const un
     const int lane = threadIdx.x & 63;
     const unsigned nwaves = gridDim.x*(PNL_NTHREADS/64);
     const unsigned count = min(*wl_count, wl_cap);
-    for (unsigned item = (blockIdx.x*PNL_NTHREADS+threadIdx.x) >> 6; item < count; item += nwaves) {
-        const int4 ent = worklist[item];
+    unsigned item = (blockIdx.x*PNL_NTHREADS+threadIdx.x) >> 6;
+    int4 ent = item < count ? worklist[item] : make_int4(0, 0, 0, 0);
+    for (; item < count; item += nwaves) {
         const int c1 = __builtin_amdgcn_readfirstlane(ent.x), c2 = __builtin_amdgcn_readfirstlane(ent.y);
-        const int q = __builtin_amdgcn_readfirstlane(ent.z);
-        const int off = P.off[q], n = P.off[q+1]-off, nn = n*n;
+        const int off = __builtin_amdgcn_readfirstlane(ent.z), n = __builtin_amdgcn_readfirstlane(ent.w), nn = n*n;
+        // prefetch the next entry while this one is integrated
+        if (item+nwaves < count) ent = worklist[item+nwaves];
         const double *__restrict__ bary = P.bary+3*(size_t)off;
         const double *__restrict__ w = P.w+off;
         const double *__restrict__ phi = P.phi+(size_t)off*DPE;
@@ -556,7 +641,7 @@ k_worklist_pairs(const DevProblem P, const int4 *__restrict__ worklist, const un
             if (e < 64) mine0 = (lane == e) ? s : mine0;
             else mine1 = (lane == e-64) ? s : mine1;
         }
-        const double vv = 2.*P.cvol[c1]*P.cvol[c2];
+        const double vv = 2.*P.cvol[c1]*P.cvol[c2]*kern_scale<KT>(P.k);
 #pragma unroll
         for (int rep = 0; rep < (NACC+63)/64; rep++) {
             const int e = lane+64*rep;
@@ -585,8 +670,11 @@ __device__ __forceinline__ int perm_rank(const int *perm, int n) {
 // Singular pairs: FL2:823-891 / FL1:349-407 with the permutations of NO:280-378 and the symmetric
 // scatter NA:204-221.  One wave per pair; SLOT 0 common vertex, 1 common edge, 2 common face.
 // ROWS is the number of merged local DoFs (rows of PSI).
-template <int DIM, int DPE, int SLOT, int KT>
-__global__ void __launch_bounds__(PNL_NTHREADS)
+// STAGE: the rule tables (nodes, weights, PSI) are copied into LDS once per workgroup and shared by all of its
+// waves over a grid-stride loop of pairs; otherwise (tables too large for LDS) they are read from L2.
+#define PNL_SING_THREADS 512
+template <int DIM, int DPE, int SLOT, int KT, bool STAGE>
+__global__ void __launch_bounds__(PNL_SING_THREADS)
 k_singular_pairs(const DevProblem P, const int2 *__restrict__ pairs, int npairs, double *__restrict__ A, long long ldA,
                  int cell_begin, int cell_end) {
     constexpr int NV = DIM+1;
@@ -594,12 +682,24 @@ k_singular_pairs(const DevProblem P, const int2 *__restrict__ pairs, int npairs,
     constexpr int COMMON = SLOT+1;
     constexpr int ROWS = (COMMON == NV) ? DPE : (COMMON == 1 ? 2*DPE-DPV : 2*DPE-2*DPV-DPED);
     constexpr int NE = ROWS*(ROWS+1)/2;
+    extern __shared__ double s_tab[];
     const int lane = threadIdx.x & 63;
-    const int wid = (blockIdx.x*PNL_NTHREADS+threadIdx.x) >> 6;
-    if (wid >= npairs) return;
+    const int M = P.sM[SLOT];
+    const double *__restrict__ nodes = P.sNodes[SLOT];
+    const double *__restrict__ w = P.sW[SLOT];
+    const double *__restrict__ psi = P.sPsi[SLOT];
+    if (STAGE) {
+        for (int t = threadIdx.x; t < 2*NV*M; t += PNL_SING_THREADS) s_tab[t] = P.sNodes[SLOT][t];
+        for (int t = threadIdx.x; t < M; t += PNL_SING_THREADS) s_tab[2*NV*M+t] = P.sW[SLOT][t];
+        for (int t = threadIdx.x; t < ROWS*M; t += PNL_SING_THREADS) s_tab[(2*NV+1)*M+t] = P.sPsi[SLOT][t];
+        __syncthreads();
+        nodes = s_tab; w = s_tab+2*NV*M; psi = s_tab+(2*NV+1)*M;
+    }
+    const int nwaves = gridDim.x*(PNL_SING_THREADS/64);
+    for (int wid = (blockIdx.x*PNL_SING_THREADS+threadIdx.x) >> 6; wid < npairs; wid += nwaves) {
     const int2 pr = pairs[wid];
-    const int c1 = pr.x, c2 = pr.y;
-    if (c1 < cell_begin || c1 >= cell_end) return;
+    const int c1 = __builtin_amdgcn_readfirstlane(pr.x), c2 = __builtin_amdgcn_readfirstlane(pr.y);
+    if (c1 < cell_begin || c1 >= cell_end) continue;
     // NA:138-150
     int ld[2*DPE];
     bool any = false;
@@ -609,7 +709,7 @@ k_singular_pairs(const DevProblem P, const int2 *__restrict__ pairs, int npairs,
         ld[DPE+k] = P.cdof[(size_t)k*P.ncp+c2];
         any = any || ld[k] >= 0 || ld[DPE+k] >= 0;
     }
-    if (!any) return;
+    if (!any) continue;
     // vertex permutations, shared vertices first (NO:311-346)
     int perm1[NV], perm2[NV], perm[2*DPE];
 #pragma unroll
@@ -618,11 +718,16 @@ k_singular_pairs(const DevProblem P, const int2 *__restrict__ pairs, int npairs,
     for (int k = 0; k < 2*DPE; k++) perm[k] = k;
     if (c1 != c2) {
         int mask1 = 0, mask2 = 0, common = 0;
+        int vid1[NV], vid2[NV];
+#pragma unroll
+        for (int a = 0; a < NV; a++) { vid1[a] = P.cvid[(size_t)a*P.ncp+c1]; vid2[a] = P.cvid[(size_t)a*P.ncp+c2]; }
+#pragma unroll
         for (int a = 0; a < NV; a++) {
-            const int v1 = P.cvid[(size_t)a*P.ncp+c1];
+            const int v1 = vid1[a];
+#pragma unroll
             for (int b = 0; b < NV; b++) {
                 if (mask2 & (1 << b)) continue;
-                if (v1 == P.cvid[(size_t)b*P.ncp+c2]) {
+                if (v1 == vid2[b]) {
                     perm1[common] = a; perm2[common] = b;
                     mask1 += (1 << a); mask2 += (1 << b);
                     common++;
@@ -660,10 +765,6 @@ k_singular_pairs(const DevProblem P, const int2 *__restrict__ pairs, int npairs,
             }
             s1[k][d] = a; s2[k][d] = b;
         }
-    const int M = P.sM[SLOT];
-    const double *__restrict__ nodes = P.sNodes[SLOT];
-    const double *__restrict__ w = P.sW[SLOT];
-    const double *__restrict__ psi = P.sPsi[SLOT];
     double acc[NE];
 #pragma unroll
     for (int e = 0; e < NE; e++) acc[e] = 0.;
@@ -691,10 +792,10 @@ k_singular_pairs(const DevProblem P, const int2 *__restrict__ pairs, int npairs,
             for (int J = I; J < ROWS; J++) { acc[e] = __builtin_fma(tI, ps[J], acc[e]); e++; }
         }
     }
-    const double vol = P.sFac*P.cvol[c1]*P.cvol[c2]*(c1 == c2 ? 1. : 2.);
-    // reduce and let lane e scatter entry e
-    double mine = 0.;
-    int myI = 0, myJ = 0;
+    const double vol = P.sFac*P.cvol[c1]*P.cvol[c2]*(c1 == c2 ? 1. : 2.)*kern_scale<KT>(P.k);
+    // reduce; lane (e mod 64) scatters entry e (NE <= 66 < 128: at most two entries per lane)
+    double mine[2] = {0., 0.};
+    int myI[2] = {0, 0}, myJ[2] = {0, 0};
     {
         int e = 0;
 #pragma unroll
@@ -702,25 +803,27 @@ k_singular_pairs(const DevProblem P, const int2 *__restrict__ pairs, int npairs,
 #pragma unroll
             for (int J = I; J < ROWS; J++) {
                 const double s = wave_sum(acc[e]);
-                if (lane == e) { mine = s; myI = I; myJ = J; }
+                if (lane == (e & 63)) { mine[e >> 6] = s; myI[e >> 6] = I; myJ[e >> 6] = J; }
                 e++;
             }
     }
-    if (lane < NE) {
+#pragma unroll
+    for (int rep = 0; rep < (NE+63)/64; rep++) {
+        if (lane+64*rep >= NE) continue;
         int gi = -1, gj = -1;
 #pragma unroll
         for (int k = 0; k < 2*DPE; k++) {
             // perm[] and ld[] with runtime indices -> selects
-            int pk = perm[k];
+            const int pk = perm[k];
             int g = -1;
 #pragma unroll
             for (int m = 0; m < 2*DPE; m++) g = (pk == m) ? ld[m] : g;
-            gi = (myI == k) ? g : gi;
-            gj = (myJ == k) ? g : gj;
+            gi = (myI[rep] == k) ? g : gi;
+            gj = (myJ[rep] == k) ? g : gj;
         }
-        const double v = mine*vol;
+        const double v = mine[rep]*vol;
         if (gi >= 0 && gj >= 0) {
-            if (myI == myJ) atomic_add_f64(&A[(long long)gi*ldA+gi], v);
+            if (myI[rep] == myJ[rep]) atomic_add_f64(&A[(long long)gi*ldA+gi], v);
             else {
                 atomic_add_f64(&A[(long long)gi*ldA+gj], v);
                 atomic_add_f64(&A[(long long)gj*ldA+gi], v);
@@ -732,11 +835,14 @@ k_singular_pairs(const DevProblem P, const int2 *__restrict__ pairs, int npairs,
         atomicAdd(&P.counters[2], (unsigned long long)M);
         atomicAdd(&P.counters[128+SLOT], 1ull);
     }
+    }   // grid-stride loop over pairs
 }
 
 // ---------------------------------------------------------------------------------------------
-// Omega x Omega^c, distant part: one thread per cell, loops over a chunk of boundary facets
+// Omega x Omega^c, distant part: one thread per cell, loops over a small chunk of boundary facets
 // (NA:1430-1448 loop, NO:1022-1108 eval_distant_boundary, order FL2:1226-1243 / FL1:646-660).
+// The reference multiplies the boundary kernel Gamma_b(|x-y|) by n.(y-x)/|y-x|; here the 1/|y-x| is folded
+// into the kernel exponent (P.bkn = Gamma_b with exponent - 1/2), so one rsqrt-type evaluation does both.
 template <int DIM, int DPE, int KT>
 __global__ void __launch_bounds__(PNL_NTHREADS)
 k_boundary_distant(const DevProblem P, double *__restrict__ Dglob, int cell_begin, int cell_end, int facets_per_chunk) {
@@ -753,6 +859,8 @@ k_boundary_distant(const DevProblem P, double *__restrict__ Dglob, int cell_begi
 #pragma unroll
     for (int k = 0; k < NV; k++) vid[k] = P.cvid[(size_t)k*P.ncp+cc];
     const double h1 = P.ch[cc], vol1 = P.cvol[cc];
+    const double Ld1 = fabs(log(h1/P.H0));
+    const float lh1 = (float)log(h1), L1 = (float)Ld1;
     double D[ND];
 #pragma unroll
     for (int e = 0; e < ND; e++) D[e] = 0.;
@@ -775,6 +883,7 @@ k_boundary_distant(const DevProblem P, double *__restrict__ Dglob, int cell_begi
 #pragma unroll
             for (int k = 0; k < NF; k++) s += fv[k*DIM+d];
             fc[d] = s*(1./NF);
+            nrm[d] = 0.;
         }
         if (DIM == 2) {
             nrm[0] = fv[1*DIM+1]-fv[0*DIM+1];
@@ -793,7 +902,9 @@ k_boundary_distant(const DevProblem P, double *__restrict__ Dglob, int cell_begi
         double dc2 = 0.;
 #pragma unroll
         for (int d = 0; d < DIM; d++) dc2 += (cen[d]-fc[d])*(cen[d]-fc[d]);
-        const int q = quad_order(P.bqo, P.H0, h1, vol2, sqrt(dc2));
+        const double Ld2 = fabs(log(vol2/P.H0));
+        const float lh2 = (float)log(vol2), L2 = (float)Ld2;
+        const int q = quad_order_fast(P.bqo, h1, vol2, lh1, lh2, L1, L2, Ld1, Ld2, dc2);
         if (q > P.qmax || q > PNL_MAXQ) { overflow++; continue; }
         const int off = P.off[q], n = P.off[q+1]-off;
         const int foff = P.foff[q], nf = P.foff[q+1]-foff;
@@ -804,7 +915,7 @@ k_boundary_distant(const DevProblem P, double *__restrict__ Dglob, int cell_begi
         const double *__restrict__ fw = P.fw+foff;
         npairs++;
         nevals += (unsigned long long)n*nf;
-        const double vol = vol1*vol2;
+        const double vol = vol1*vol2*kern_scale<KT>(P.bkn);
         for (int k = 0; k < n; k++) {
             double x[DIM];
 #pragma unroll
@@ -826,8 +937,8 @@ k_boundary_distant(const DevProblem P, double *__restrict__ Dglob, int cell_begi
                     d2 = __builtin_fma(wv, wv, d2);
                     if (DIM == 2) nw = __builtin_fma(nrm[d], wv, nw);
                 }
-                if (DIM == 2) nw *= 1./sqrt(d2); else nw = 1.;
-                r = __builtin_fma(fw[m]*nw, kern_eval<KT>(P.bk, d2), r);
+                if (DIM != 2) nw = 1.;
+                r = __builtin_fma(fw[m]*nw, kern_eval<KT>(P.bkn, d2), r);
             }
             r *= w[k]*vol;
             int e = 0;
@@ -860,7 +971,7 @@ k_boundary_singular(const DevProblem P, const int2 *__restrict__ pairs, int npai
     const int lane = threadIdx.x & 63;
     const int wid = (blockIdx.x*PNL_NTHREADS+threadIdx.x) >> 6;
     if (wid >= npairs) return;
-    const int c1 = pairs[wid].x, f = pairs[wid].y;
+    const int c1 = __builtin_amdgcn_readfirstlane(pairs[wid].x), f = __builtin_amdgcn_readfirstlane(pairs[wid].y);
     if (c1 < cell_begin || c1 >= cell_end) return;
     int perm1[NV], perm2[NF], perm[DPE];
 #pragma unroll
@@ -939,8 +1050,8 @@ k_boundary_singular(const DevProblem P, const int2 *__restrict__ pairs, int npai
             d2 = __builtin_fma(wv, wv, d2);
             if (DIM == 2) nw = __builtin_fma(nrm[d], wv, nw);
         }
-        if (DIM == 2) nw *= 1./sqrt(d2); else nw = 1.;
-        const double t = w[m]*nw*kern_eval<KT>(P.bk, d2);
+        if (DIM != 2) nw = 1.;
+        const double t = w[m]*nw*kern_eval<KT>(P.bkn, d2);
         double ps[DPE];
 #pragma unroll
         for (int r = 0; r < DPE; r++) ps[r] = PHI[(size_t)r*M+m];
@@ -952,7 +1063,7 @@ k_boundary_singular(const DevProblem P, const int2 *__restrict__ pairs, int npai
             for (int J = I; J < DPE; J++) { acc[e] = __builtin_fma(tI, ps[J], acc[e]); e++; }
         }
     }
-    const double vol = (DIM == 2) ? P.bFac*P.cvol[c1]*vol2 : P.bFac*P.cvol[c1];
+    const double vol = ((DIM == 2) ? P.bFac*P.cvol[c1]*vol2 : P.bFac*P.cvol[c1])*kern_scale<KT>(P.bkn);
     double mine = 0.;
     int myI = 0, myJ = 0;
     {
