@@ -78,3 +78,51 @@ def test_gemv_and_cg():
     uref = np.linalg.solve(Aref, np.asarray(b))
     assert res <= 1e-10 and its < 2000
     assert np.abs(u-uref).max() <= 1e-7*np.abs(uref).max()
+
+
+def _dist_worker(rank, world, port, out):
+    import os
+    import torch
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.cuda.set_device(0)                       # one-GPU box: both ranks share the card, collectives over gloo
+    from pynucleus_amd import disc, P1_DoFMap, PHYSICAL, getFractionalKernel
+    from pynucleus_amd.builder import nonlocalBuilder
+    from oracle.oracle import OracleProblem
+    mesh = disc(4)
+    dm = P1_DoFMap(mesh, PHYSICAL)
+    b = nonlocalBuilder(dm, getFractionalKernel(2, 0.5), {'target_order': 0.5}, zeroExterior=True, comm=True)
+    op = b.getDense(distributed=True)
+    x = np.linspace(-1., 1., dm.num_dofs)
+    y = op.matvec(x)
+    Aref = OracleProblem(b.tables).get_dense()[0]
+    yref = Aref@x
+    e1 = float(np.abs(y-yref).max()/np.abs(yref).max())
+    full = b.getDense()                            # all-reduced like the reference (NA:1449-1450)
+    e2 = float(np.abs(full.toarray()-Aref).max()/np.abs(Aref).max())
+    pairs = torch.tensor([op.info['counters']['numAssembledCellPairs']], dtype=torch.float64)
+    dist.all_reduce(pairs)
+    if rank == 0:
+        out.put((e1, e2, float(pairs.item()), mesh.num_cells))
+    dist.destroy_process_group()
+
+
+def test_two_ranks_share_the_pairs():
+    """world size 2 (gloo, both ranks on the one GPU of the box): the tile deal + cell-range split assemble every pair
+    exactly once, the distributed operator's matvec and the all-reduced matrix match the oracle"""
+    import os
+    import torch.multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    out = ctx.Queue()
+    port = 29600+os.getpid() % 2000
+    procs = [ctx.Process(target=_dist_worker, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    e1, e2, pairs, nc = out.get(timeout=300)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert pairs == nc*(nc+1)//2
+    assert e1 < 1e-11 and e2 < TOL
