@@ -127,7 +127,7 @@ def main():
 
     # ---- roofline of the dominant kernel (k_tile_distant): algorithmic flops / its own event-timed duration ----
     T = builder.tables
-    tile_orders = {q: c for q, c in cnt['orders'].items() if T.num_points(q) in (3, 6) and q < 18}
+    tile_orders = {q: c for q, c in cnt['orders'].items() if T.num_points(q) in (3, 6) and q < 18}   # the two unrolled rules
     flops_tile = algorithmic_flops(tile_orders, T.num_points)
     tile_s = 1e-3*float(np.mean(tile_ms))
     achieved = flops_tile/tile_s/1e12 if tile_s > 0 else 0.

@@ -318,8 +318,8 @@ void refresh_tables(pnl_context *ctx) {
 template <int DIM, int DPE, int TILE, int KT>
 int launch_tiles(pnl_context *ctx, int ntiles, double *A, int64_t ldA, int cell_begin, int cell_end) {
     using S = TileSmem<DIM, DPE, TILE>;
-    const int acc_stride = ctx->nU;
-    const size_t lds = S::fixed_bytes+sizeof(double)*(size_t)ctx->nU*acc_stride;
+    const int acc_stride = ctx->nU+1;            // +1: trash column / row for boundary DoFs
+    const size_t lds = S::fixed_bytes+sizeof(double)*(size_t)(ctx->nU+1)*acc_stride;
     if (getenv("PNL_VERBOSE")) {
         int nblk = -1;
         (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nblk, (const void*)k_tile_distant<DIM, DPE, TILE, KT>, PNL_NTHREADS, lds);

@@ -238,6 +238,15 @@ __device__ __forceinline__ void eval_distant_fixed(const DevProblem &P, const do
 // Tile kernel: classification (NO:280-378 vertex test, NO:493-540 + FL2:622-642 order) and distant
 // evaluation for one TILE x TILE block of cell pairs.
 #define PNL_TT_MAXPTS 96
+// Orders with at most PNL_NC_MAX points that are not unrolled could also be integrated one pair per lane inside the tile
+// (list C, generic trip count).  Measured on MI355X (noRef 6): tile kernel 13.1 -> 23.2 ms for 3 ms saved in the work-list
+// kernel, so it is disabled; such orders go to the global work list (one pair per wave).
+#define PNL_NC_MAX 0
+// lanes walk the tile along generalised diagonals i = (s + m*j) mod TILE (m odd): distinct a- and b-cells per lane, and
+// neighbouring b-cells are paired with non-neighbouring a-cells, which keeps same-address LDS atomics rare
+#ifndef PNL_DIAG_MULT
+#define PNL_DIAG_MULT 21
+#endif
 template <int DIM, int DPE, int TILE>
 struct TileSmem {
     static constexpr int NV = DIM+1, NC = NV*DIM, ND = DPE*(DPE+1)/2;
@@ -263,7 +272,8 @@ struct TileSmem {
     // shorts after the ints
     static constexpr int o_slot = 0;                       // [2][DPE][TILE]
     static constexpr int o_list = o_slot+2*DPE*TILE;       // [TILE*TILE] list A (16 bit) + [TILE*TILE] list B / far list (32 bit)
-    static constexpr int n_short = o_list+3*TILE*TILE;
+                                                           // + [TILE*TILE] list C (32 bit)
+    static constexpr int n_short = o_list+(PNL_NC_MAX > 0 ? 5 : 3)*TILE*TILE+2;
     static constexpr size_t fixed_bytes = sizeof(double)*n_dbl+sizeof(int)*n_int+sizeof(short)*((n_short+3)/4*4);
 };
 
@@ -346,11 +356,15 @@ k_tile_distant(const DevProblem P, const int2 *__restrict__ tiles, double *__res
 #pragma unroll
         for (int k = 0; k < NV; k++) s_vid[(side*NV+k)*TILE+l] = P.cvid[(size_t)k*P.ncp+c];
 #pragma unroll
-        for (int k = 0; k < DPE; k++) s_slot[(side*DPE+k)*TILE+l] = P.cslot[(size_t)k*P.ncp+c];
+        for (int k = 0; k < DPE; k++) {
+            // boundary DoFs (no slot) are sent to a trash row / column of the LDS sub-block: no branches in the hot loop
+            const short sl = P.cslot[(size_t)k*P.ncp+c];
+            s_slot[(side*DPE+k)*TILE+l] = sl >= 0 ? sl : (short)(side ? nB : nA);
+        }
     }
     for (int t = tid; t < PNL_MAXQ+2; t += PNL_NTHREADS) { s_ttn[t] = P.tt_n[t]; s_tto[t] = P.tt_off[t]; }
     for (int t = tid; t < P.tt_npts*(4+DPE); t += PNL_NTHREADS) s_tt[t] = P.tt_tab[t];
-    for (int t = tid; t < nA*acc_stride; t += PNL_NTHREADS) s_acc[t] = 0.;
+    for (int t = tid; t < (nA+1)*acc_stride; t += PNL_NTHREADS) s_acc[t] = 0.;
     for (int t = tid; t < 2*TILE*ND; t += PNL_NTHREADS) s_D[t] = 0.;
     for (int t = tid; t < 2*(PNL_MAXQ+2)+4; t += PNL_NTHREADS) s_cnt[t] = 0;    // s_cnt, s_cur and s_misc are adjacent
     __syncthreads();
@@ -363,13 +377,14 @@ k_tile_distant(const DevProblem P, const int2 *__restrict__ tiles, double *__res
     constexpr int NA = (DIM == 2) ? 3 : 2, NB = (DIM == 2) ? 6 : 3;
     // list B grows from the front of s_l32, the far list (pairs for the global work list) from its back
     int *s_l32 = (int*)(s_list+PAIRS+((((size_t)(s_list+PAIRS)) & 2) ? 1 : 0));
+    int *s_lC = s_l32+PAIRS;     // list C: other orders with at most PNL_NC_MAX points, integrated one pair per lane too
     int overflow = 0;
     const int lane = tid & 63;
     const unsigned long long lt = (1ull << lane)-1ull;
 #pragma unroll 2
     for (int it = 0; it < PER_THREAD; it++) {
         const int p = it*PNL_NTHREADS+tid;
-        const int j = p%TILE, i = (p/TILE+j)%TILE;
+        const int j = p%TILE, i = (p/TILE+PNL_DIAG_MULT*j)%TILE;
         int q = 0;
         const int va0 = s_vid[(0*NV+0)*TILE+i], vb0 = s_vid[(1*NV+0)*TILE+j];
         const int ca = ta*TILE+i;
@@ -379,7 +394,7 @@ k_tile_distant(const DevProblem P, const int2 *__restrict__ tiles, double *__res
             bool any_dof = false, shared = false;
 #pragma unroll
             for (int k = 0; k < DPE; k++)
-                any_dof = any_dof || (s_slot[(0*DPE+k)*TILE+i] >= 0) || (s_slot[(1*DPE+k)*TILE+j] >= 0);
+                any_dof = any_dof || (s_slot[(0*DPE+k)*TILE+i] < nA) || (s_slot[(1*DPE+k)*TILE+j] < nB);
 #pragma unroll
             for (int k = 0; k < NV; k++) {
                 const int va = s_vid[(0*NV+k)*TILE+i];
@@ -401,10 +416,18 @@ k_tile_distant(const DevProblem P, const int2 *__restrict__ tiles, double *__res
         }
         wave_bucket_add(s_cnt, q, false);                       // statistics only
         const int nq = q ? s_ttn[q] : 0;
-        const int cls = !q ? 0 : ((nq == NA && q < 18) ? 1 : ((nq == NB && q < 18) ? 2 : 3));
+        int cls = !q ? 0 : ((nq == NA && q < 18) ? 1 : ((nq == NB && q < 18) ? 2 : 4));
+        if (PNL_NC_MAX > 0 && cls == 4 && P.off[q+1]-P.off[q] <= PNL_NC_MAX) cls = 3;
         const unsigned short ent = (unsigned short)(p | ((q-2) << 12));
         // one returning atomic per class and wave
-        const unsigned long long mA = __ballot(cls == 1), mB = __ballot(cls == 2), mF = __ballot(cls == 3);
+        const unsigned long long mA = __ballot(cls == 1), mB = __ballot(cls == 2), mC = __ballot(cls == 3), mF = __ballot(cls == 4);
+        if (mC) {
+            int base = 0;
+            const int leader = __ffsll((long long)mC)-1;
+            if (lane == leader) base = atomicAdd(&s_misc[3], __popcll(mC));
+            base = __builtin_amdgcn_readlane(base, leader);
+            if (cls == 3) s_lC[base+__popcll(mC & lt)] = p | (q << 12);
+        }
         if (mA) {
             int base = 0;
             const int leader = __ffsll((long long)mA)-1;
@@ -424,7 +447,7 @@ k_tile_distant(const DevProblem P, const int2 *__restrict__ tiles, double *__res
             const int leader = __ffsll((long long)mF)-1;
             if (lane == leader) base = atomicAdd(&s_misc[2], __popcll(mF));
             base = __builtin_amdgcn_readlane(base, leader);
-            if (cls == 3) s_l32[PAIRS-1-(base+__popcll(mF & lt))] = p | (q << 12);
+            if (cls == 4) s_l32[PAIRS-1-(base+__popcll(mF & lt))] = p | (q << 12);
         }
     }
     if (overflow) atomicAdd(&P.counters[5], (unsigned long long)overflow);
@@ -433,13 +456,13 @@ k_tile_distant(const DevProblem P, const int2 *__restrict__ tiles, double *__res
         // far pairs: one reservation in the global work list per tile, then a coalesced copy
         const int nF = s_misc[2];
         if (nF) {
-            if (tid == 0) s_misc[3] = (int)atomicAdd(wl_count, (unsigned)nF);
+            if (tid == 0) s_cur[0] = (int)atomicAdd(wl_count, (unsigned)nF);
             __syncthreads();
-            const unsigned base = (unsigned)s_misc[3];
+            const unsigned base = (unsigned)s_cur[0];
             for (int t = tid; t < nF; t += PNL_NTHREADS) {
                 const int ent = s_l32[PAIRS-1-t];
                 const int p = ent & 4095, q = ent >> 12;
-                const int j = p%TILE, i = (p/TILE+j)%TILE;
+                const int j = p%TILE, i = (p/TILE+PNL_DIAG_MULT*j)%TILE;
                 const int off = P.off[q];
                 if (base+t < wl_cap) worklist[base+t] = make_int4(ta*TILE+i, tb*TILE+j, off, P.off[q+1]-off);
             }
@@ -461,22 +484,26 @@ k_tile_distant(const DevProblem P, const int2 *__restrict__ tiles, double *__res
     const int wave = tid >> 6;
     if (!(ablate & 2))
 #pragma unroll 1
-    for (int pass = 0; pass < 2; pass++) {
-        const int total = __builtin_amdgcn_readfirstlane(s_misc[pass]);
+    for (int pass = 0; pass < (PNL_NC_MAX > 0 ? 3 : 2); pass++) {
+        const int total = __builtin_amdgcn_readfirstlane(s_misc[pass == 2 ? 3 : pass]);
 #pragma unroll 1
         for (int c0 = wave*64; c0 < total; c0 += PNL_NTHREADS) {
             const int idx = c0+lane;
             const bool act = idx < total;
-            const int ent = act ? (pass ? s_l32[idx] : (int)s_list[idx]) : 0;
-            const int p = ent & 4095, q = (ent >> 12)+2;
-            const int j = p%TILE, i = (p/TILE+j)%TILE;
+            const int ent = act ? (pass == 0 ? (int)s_list[idx] : (pass == 1 ? s_l32[idx] : s_lC[idx])) : 0;
+            const int p = ent & 4095, q = (ent >> 12)+(pass == 2 ? 0 : 2);
+            const int j = p%TILE, i = (p/TILE+PNL_DIAG_MULT*j)%TILE;
             const double *tab = s_tt+s_tto[q]*(4+DPE);
             double av[NC], bv[NC];
 #pragma unroll
             for (int k = 0; k < NC; k++) { av[k] = s_v[(0*NC+k)*TILE+i]; bv[k] = s_v[(1*NC+k)*TILE+j]; }
             PairAcc<DIM, DPE> R;
             R.clear();
-            if (act) {
+            if (pass == 2) {
+                // per-lane order: every lane runs its own trip count, the wave the longest one
+                const int off = act ? P.off[q] : 0, n = act ? P.off[q+1]-off : 0;
+                eval_distant_generic<DIM, DPE, KT>(P, off, n, av, bv, R);
+            } else if (act) {
                 if (pass == 0) eval_distant_fixed<DIM, DPE, KT, NA>(P, tab, av, bv, R);
                 else eval_distant_fixed<DIM, DPE, KT, NB>(P, tab, av, bv, R);
             }
@@ -501,12 +528,14 @@ k_tile_distant(const DevProblem P, const int2 *__restrict__ tiles, double *__res
 #pragma unroll
                 for (int b = 0; b < DPE; b++) {
                     const int sb = s_slot[(1*DPE+b)*TILE+j];
-                    if (sa >= 0 && sb >= 0) lds_add_f64(&s_acc[sa*acc_stride+sb], -vv*R.G[a][b]);
+                    lds_add_f64(&s_acc[sa*acc_stride+sb], -vv*R.G[a][b]);
                 }
 #pragma unroll
                 for (int b = a; b < DPE; b++) {
-                    lds_add_f64(&s_D[(0*TILE+i)*ND+e], vv*R.S1[e]);
-                    lds_add_f64(&s_D[(1*TILE+j)*ND+e], vv*R.S2[e]);
+                    if (!(ablate & 64)) {
+                        lds_add_f64(&s_D[(0*TILE+i)*ND+e], vv*R.S1[e]);
+                        lds_add_f64(&s_D[(1*TILE+j)*ND+e], vv*R.S2[e]);
+                    } else if (R.S1[e]+R.S2[e] == 1.2345e300) s_D[0] = 1.;
                     e++;
                 }
             }
