@@ -47,7 +47,7 @@ struct pnl_context {
     DevProblem P;
     DevBuf b_cellv, b_ccen, b_cvol, b_ch, b_cvid, b_cdof, b_cslot, b_blk_ndof, b_blk_dofs, b_perm, b_off, b_bary, b_w, b_phi,
         b_foff, b_fbary, b_fw, b_sn[3], b_sw[3], b_sp[3], b_bn[2], b_bw[2], b_bp[2], b_bvid, b_bv, b_counters, b_D, b_tiles,
-        b_spairs[3], b_bpairs[2], b_vec[6], b_scal, b_wl, b_wlcount, b_ttn, b_ttoff, b_tttab;
+        b_spairs[3], b_bpairs[2], b_vec[6], b_scal, b_wl, b_wlcount, b_ttn, b_ttoff, b_tttab, b_wlsorted, b_wlaux;
     unsigned wl_cap = 0;
     int tile = TILE_P1, nblocks = 0, ncp = 0, nU = 0;
     int n_spairs[3] = {0, 0, 0}, n_bpairs[2] = {0, 0};
@@ -353,10 +353,28 @@ int launch_tiles(pnl_context *ctx, int ntiles, double *A, int64_t ldA, int cell_
                        (unsigned*)ctx->b_wlcount.p, ctx->wl_cap, ctx->ablate, ntiles);
     HIPCHK(ctx, hipGetLastError());
     HIPCHK(ctx, hipEventRecord(ctx->ev[6], ctx->stream));
-    hipLaunchKernelGGL((k_worklist_pairs<DIM, DPE, KT>), dim3(256*8), dim3(PNL_NTHREADS), 0, ctx->stream, ctx->P,
-                       (const int4*)ctx->b_wl.p, (const unsigned*)ctx->b_wlcount.p, ctx->wl_cap, A, (long long)ldA,
-                       (double*)ctx->b_D.p);
-    HIPCHK(ctx, hipGetLastError());
+    {
+        // counting sort of the work list by order, then the sorted evaluation
+        int rc;
+        if ((rc = ensure(ctx, ctx->b_wlsorted, (size_t)ctx->wl_cap*sizeof(int4)))) return rc;
+        if ((rc = ensure(ctx, ctx->b_wlaux, sizeof(unsigned)*(4*(PNL_WL_BINS+1))))) return rc;
+        unsigned *hist = (unsigned*)ctx->b_wlaux.p, *offs = hist+(PNL_WL_BINS+1), *coff = offs+(PNL_WL_BINS+1), *cursor = coff+(PNL_WL_BINS+1);
+        HIPCHK(ctx, hipMemsetAsync(hist, 0, sizeof(unsigned)*(PNL_WL_BINS+1), ctx->stream));
+        const int4 *wl = (const int4*)ctx->b_wl.p;
+        const unsigned *wlc = (const unsigned*)ctx->b_wlcount.p;
+        hipLaunchKernelGGL(k_wl_hist, dim3(512), dim3(PNL_NTHREADS), 0, ctx->stream, wl, wlc, ctx->wl_cap, hist);
+        hipLaunchKernelGGL(k_wl_scan, dim3(1), dim3(64), 0, ctx->stream, (const unsigned*)hist, offs, coff, cursor);
+        hipLaunchKernelGGL(k_wl_scatter, dim3(512), dim3(PNL_NTHREADS), 0, ctx->stream, wl, wlc, ctx->wl_cap, (const unsigned*)offs, cursor,
+                           (int4*)ctx->b_wlsorted.p);
+        const int st = 4+DPE;
+        const int tab_max = (60*1024)/(st*(int)sizeof(double));
+        const size_t lds = (size_t)tab_max*st*sizeof(double);
+        auto wfun = k_worklist_sorted<DIM, DPE, KT>;
+        HIPCHK(ctx, hipFuncSetAttribute((const void*)wfun, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(wfun, dim3(256*2), dim3(PNL_NTHREADS), lds, ctx->stream, ctx->P, (const int4*)ctx->b_wlsorted.p,
+                           (const unsigned*)offs, (const unsigned*)coff, A, (long long)ldA, (double*)ctx->b_D.p, tab_max);
+        HIPCHK(ctx, hipGetLastError());
+    }
     return PNL_OK;
 }
 
@@ -404,7 +422,7 @@ int launch_boundary(pnl_context *ctx, int cell_begin, int cell_end) {
     const int ncell = cell_end-cell_begin;
     const int gx = (ncell+PNL_NTHREADS-1)/PNL_NTHREADS;
     // small facet chunks: many waves in flight hide the latency of the per-facet dependent chain
-    const int per = 4;
+    const int per = getenv("PNL_BND_PER") ? atoi(getenv("PNL_BND_PER")) : 8;
     const int chunks = (ctx->nb+per-1)/per;
     if (ctx->P.bkn.fast)
         hipLaunchKernelGGL((k_boundary_distant<DIM, DPE, 1>), dim3(gx, chunks), dim3(PNL_NTHREADS), 0, ctx->stream, ctx->P,

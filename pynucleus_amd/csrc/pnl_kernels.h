@@ -331,6 +331,9 @@ k_tile_distant(const DevProblem P, const int2 *__restrict__ tiles, double *__res
     double *s_tt = s_dbl+S::o_tt, *s_Ld = s_dbl+S::o_Ld;
 
     const int tid = threadIdx.x;
+    // statistics of order q = 2 + tid (+256) are kept in registers over all tiles of this workgroup: hot counters
+    // see one atomic per workgroup, not one per tile
+    unsigned long long st_cnt[(PNL_MAXQ+PNL_NTHREADS)/PNL_NTHREADS] = {0}, st_ev[(PNL_MAXQ+PNL_NTHREADS)/PNL_NTHREADS] = {0};
     // persistent workgroups: each one walks the tile list with stride gridDim.x (heavy tiles come first in the list)
 #pragma unroll 1
     for (int tile_idx = blockIdx.x; tile_idx < ntiles; tile_idx += gridDim.x) {
@@ -464,19 +467,22 @@ k_tile_distant(const DevProblem P, const int2 *__restrict__ tiles, double *__res
                 const int p = ent & 4095, q = ent >> 12;
                 const int j = p%TILE, i = (p/TILE+PNL_DIAG_MULT*j)%TILE;
                 const int off = P.off[q];
-                if (base+t < wl_cap) worklist[base+t] = make_int4(ta*TILE+i, tb*TILE+j, off, P.off[q+1]-off);
+                if (base+t < wl_cap) worklist[base+t] = make_int4(ta*TILE+i, tb*TILE+j, off, (P.off[q+1]-off) | (q << 16));
             }
         }
     }
     // statistics: one thread per order
-    for (int q = 2+tid; q <= P.qmax; q += PNL_NTHREADS) {
-        const int cq = s_cnt[q];
-        if (cq) {
-            const int ne = s_ttn[q];
-            const unsigned long long n = (unsigned long long)(ne ? ne : P.off[q+1]-P.off[q]);
-            atomicAdd(&P.counters[8+q], (unsigned long long)cq);
-            atomicAdd(&P.counters[1], (unsigned long long)cq);
-            atomicAdd(&P.counters[2], n*n*cq);
+#pragma unroll
+    for (int r = 0; r < (PNL_MAXQ+PNL_NTHREADS)/PNL_NTHREADS; r++) {
+        const int q = 2+tid+r*PNL_NTHREADS;
+        if (q <= P.qmax) {
+            const int cq = s_cnt[q];
+            if (cq) {
+                const int ne = s_ttn[q];
+                const unsigned long long n = (unsigned long long)(ne ? ne : P.off[q+1]-P.off[q]);
+                st_cnt[r] += (unsigned long long)cq;
+                st_ev[r] += n*n*cq;
+            }
         }
     }
 
@@ -563,6 +569,15 @@ k_tile_distant(const DevProblem P, const int2 *__restrict__ tiles, double *__res
     }
     __syncthreads();
     }   // tile loop
+#pragma unroll
+    for (int r = 0; r < (PNL_MAXQ+PNL_NTHREADS)/PNL_NTHREADS; r++) {
+        const int q = 2+tid+r*PNL_NTHREADS;
+        if (st_cnt[r]) {
+            atomicAdd(&P.counters[8+q], st_cnt[r]);
+            atomicAdd(&P.counters[1], st_cnt[r]);
+            atomicAdd(&P.counters[2], st_ev[r]);
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -600,87 +615,169 @@ __device__ __forceinline__ double row16_sum(double v) {
     return v;
 }
 
-// Distant pairs of the orders the tile kernel does not unroll (NO:722-789): one wave per pair, lanes over the n*n
-// point pairs of the tensor rule, DPP reduction of the local matrix, atomic scatter.  A' receives the cross block on
-// the (c1-DoF, c2-DoF) side only, like the tile kernel.  Work-list entry: (c1, c2, rule offset, n).
+// ---- work list of the orders the tile kernel does not unroll -------------------------------------------------------
+// entry = (c1, c2, rule offset, n | order << 16).  The list is counting-sorted by order so that a workgroup integrates
+// pairs of ONE order at a time: the rule is staged in LDS once and all 16 pairs of a chunk run the same trip count.
+#define PNL_WL_BINS 128
+__global__ void __launch_bounds__(PNL_NTHREADS)
+k_wl_hist(const int4 *__restrict__ wl, const unsigned *__restrict__ wl_count, unsigned wl_cap, unsigned *__restrict__ hist) {
+    __shared__ unsigned h[PNL_WL_BINS];
+    if (threadIdx.x < PNL_WL_BINS) h[threadIdx.x] = 0;
+    __syncthreads();
+    const unsigned count = min(*wl_count, wl_cap);
+    for (unsigned i = blockIdx.x*PNL_NTHREADS+threadIdx.x; i < count; i += gridDim.x*PNL_NTHREADS)
+        atomicAdd(&h[(wl[i].w >> 16) & (PNL_WL_BINS-1)], 1u);
+    __syncthreads();
+    if (threadIdx.x < PNL_WL_BINS && h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], h[threadIdx.x]);
+}
+
+// offs[q] = first sorted position of order q, chunk_off[q] = first 16-pair chunk of order q; both have PNL_WL_BINS+1 entries
+__global__ void k_wl_scan(const unsigned *__restrict__ hist, unsigned *__restrict__ offs, unsigned *__restrict__ chunk_off,
+                          unsigned *__restrict__ cursor) {
+    if (threadIdx.x == 0) {
+        unsigned run = 0, crun = 0;
+        for (int q = 0; q < PNL_WL_BINS; q++) {
+            offs[q] = run; chunk_off[q] = crun; cursor[q] = 0;
+            run += hist[q]; crun += (hist[q]+15)/16;
+        }
+        offs[PNL_WL_BINS] = run; chunk_off[PNL_WL_BINS] = crun;
+    }
+}
+
+__global__ void __launch_bounds__(PNL_NTHREADS)
+k_wl_scatter(const int4 *__restrict__ wl, const unsigned *__restrict__ wl_count, unsigned wl_cap, const unsigned *__restrict__ offs,
+             unsigned *__restrict__ cursor, int4 *__restrict__ sorted) {
+    __shared__ unsigned h[PNL_WL_BINS], base[PNL_WL_BINS];
+    const unsigned count = min(*wl_count, wl_cap);
+    const unsigned per = (count+gridDim.x-1)/gridDim.x;
+    const unsigned i0 = blockIdx.x*per, i1 = min(count, i0+per);
+    if (threadIdx.x < PNL_WL_BINS) h[threadIdx.x] = 0;
+    __syncthreads();
+    for (unsigned i = i0+threadIdx.x; i < i1; i += PNL_NTHREADS) atomicAdd(&h[(wl[i].w >> 16) & (PNL_WL_BINS-1)], 1u);
+    __syncthreads();
+    if (threadIdx.x < PNL_WL_BINS) {
+        base[threadIdx.x] = h[threadIdx.x] ? offs[threadIdx.x]+atomicAdd(&cursor[threadIdx.x], h[threadIdx.x]) : 0;
+        h[threadIdx.x] = 0;
+    }
+    __syncthreads();
+    for (unsigned i = i0+threadIdx.x; i < i1; i += PNL_NTHREADS) {
+        const int4 e = wl[i];
+        const int q = (e.w >> 16) & (PNL_WL_BINS-1);
+        sorted[base[q]+atomicAdd(&h[q], 1u)] = e;
+    }
+}
+
+// Distant pairs from the sorted work list (NO:722-789): a workgroup takes chunks of 16 pairs of one order, one DPP row
+// (16 lanes) per pair, lanes over the n*n point pairs of the tensor rule read from the LDS copy of the rule, row-wise
+// DPP reduction of the local matrix, atomic scatter.  A' receives the cross block on the (c1-DoF, c2-DoF) side only.
 template <int DIM, int DPE, int KT>
 __global__ void __launch_bounds__(PNL_NTHREADS)
-k_worklist_pairs(const DevProblem P, const int4 *__restrict__ worklist, const unsigned *__restrict__ wl_count, unsigned wl_cap,
-                 double *__restrict__ A, long long ldA, double *__restrict__ Dglob) {
-    constexpr int NV = DIM+1, NC = NV*DIM, ND = DPE*(DPE+1)/2, NG = DPE*DPE, NACC = NG+2*ND;
-    const int lane = threadIdx.x & 63;
-    const unsigned nwaves = gridDim.x*(PNL_NTHREADS/64);
-    const unsigned count = min(*wl_count, wl_cap);
-    unsigned item = (blockIdx.x*PNL_NTHREADS+threadIdx.x) >> 6;
-    int4 ent = item < count ? worklist[item] : make_int4(0, 0, 0, 0);
-    for (; item < count; item += nwaves) {
-        const int c1 = __builtin_amdgcn_readfirstlane(ent.x), c2 = __builtin_amdgcn_readfirstlane(ent.y);
-        const int off = __builtin_amdgcn_readfirstlane(ent.z), n = __builtin_amdgcn_readfirstlane(ent.w), nn = n*n;
-        // prefetch the next entry while this one is integrated
-        if (item+nwaves < count) ent = worklist[item+nwaves];
-        const double *__restrict__ bary = P.bary+3*(size_t)off;
-        const double *__restrict__ w = P.w+off;
-        const double *__restrict__ phi = P.phi+(size_t)off*DPE;
+k_worklist_sorted(const DevProblem P, const int4 *__restrict__ sorted, const unsigned *__restrict__ offs,
+                  const unsigned *__restrict__ chunk_off, double *__restrict__ A, long long ldA, double *__restrict__ Dglob,
+                  int tab_max_pts) {
+    constexpr int NV = DIM+1, NC = NV*DIM, ND = DPE*(DPE+1)/2, NG = DPE*DPE, NACC = NG+2*ND, NREP = (NACC+15)/16, ST = 4+DPE;
+    extern __shared__ double s_rule[];           // [tab_max_pts][ST]: bary[3], w, phi[DPE]
+    __shared__ unsigned s_coff[PNL_WL_BINS+1];
+    const int tid = threadIdx.x, sub = tid & 15, g = tid >> 4;
+    for (int t = tid; t <= PNL_WL_BINS; t += PNL_NTHREADS) s_coff[t] = chunk_off[t];
+    __syncthreads();
+    const unsigned nchunks = s_coff[PNL_WL_BINS];
+    int staged_q = -1;
+    for (unsigned chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+        // order of this chunk: last q with chunk_off[q] <= chunk
+        int lo = 0, hi = PNL_WL_BINS-1;
+        while (lo < hi) {
+            const int mid = (lo+hi+1) >> 1;
+            if (s_coff[mid] <= chunk) lo = mid; else hi = mid-1;
+        }
+        const int q = lo;
+        const unsigned first = offs[q]+16u*(chunk-s_coff[q]);
+        const int cnt = (int)min(16u, offs[q+1]-first);
+        const int4 e0 = sorted[first];
+        const int off = e0.z, n = e0.w & 0xffff, nn = n*n;
+        const bool in_lds = n <= tab_max_pts;
+        if (q != staged_q) {
+            __syncthreads();
+            if (in_lds)
+                for (int t = tid; t < n*ST; t += PNL_NTHREADS) {
+                    const int pt = t/ST, k = t-pt*ST;
+                    s_rule[t] = k < 3 ? P.bary[3*(size_t)(off+pt)+k] : (k == 3 ? P.w[off+pt] : P.phi[(size_t)(off+pt)*DPE+k-4]);
+                }
+            __syncthreads();
+            staged_q = q;
+        }
+        const bool valid = g < cnt;
+        const int4 ent = valid ? sorted[first+g] : e0;
+        const int c1 = ent.x, c2 = ent.y;
         double av[NC], bv[NC];
 #pragma unroll
         for (int k = 0; k < NC; k++) { av[k] = P.cellv[(size_t)k*P.ncp+c1]; bv[k] = P.cellv[(size_t)k*P.ncp+c2]; }
         double acc[NACC];
 #pragma unroll
         for (int e = 0; e < NACC; e++) acc[e] = 0.;
-        const int di = 64/n, dj = 64-di*n;
-        int i = lane/n, j = lane-i*n;
-        for (int k = lane; k < nn; k += 64) {
+        const float rn = 1.f/(float)n;
+        for (int k = sub; k < nn; k += 16) {
+            const int i = (int)(((float)k+0.5f)*rn), j = k-i*n;
+            double ti[ST], tj[ST];
+            if (in_lds) {
+#pragma unroll
+                for (int m = 0; m < ST; m++) { ti[m] = s_rule[i*ST+m]; tj[m] = s_rule[j*ST+m]; }
+            } else {
+#pragma unroll
+                for (int m = 0; m < 3; m++) { ti[m] = P.bary[3*(size_t)(off+i)+m]; tj[m] = P.bary[3*(size_t)(off+j)+m]; }
+                ti[3] = P.w[off+i]; tj[3] = P.w[off+j];
+#pragma unroll
+                for (int m = 0; m < DPE; m++) { ti[4+m] = P.phi[(size_t)(off+i)*DPE+m]; tj[4+m] = P.phi[(size_t)(off+j)*DPE+m]; }
+            }
             double d2 = 0.;
 #pragma unroll
             for (int d = 0; d < DIM; d++) {
                 double x = 0., y = 0.;
 #pragma unroll
                 for (int m = 0; m < NV; m++) {
-                    x = __builtin_fma(bary[3*i+m], av[m*DIM+d], x);
-                    y = __builtin_fma(bary[3*j+m], bv[m*DIM+d], y);
+                    x = __builtin_fma(ti[m], av[m*DIM+d], x);
+                    y = __builtin_fma(tj[m], bv[m*DIM+d], y);
                 }
                 d2 = __builtin_fma(x-y, x-y, d2);
             }
-            const double K = (w[i]*w[j])*kern_eval<KT>(P.k, d2);
-            double pa[DPE], pb[DPE];
-#pragma unroll
-            for (int a = 0; a < DPE; a++) { pa[a] = phi[i*DPE+a]; pb[a] = phi[j*DPE+a]; }
+            const double K = (ti[3]*tj[3])*kern_eval<KT>(P.k, d2);
             int e = 0;
 #pragma unroll
             for (int a = 0; a < DPE; a++) {
-                const double ka = K*pa[a];
+                const double ka = K*ti[4+a];
 #pragma unroll
-                for (int b = 0; b < DPE; b++) acc[a*DPE+b] = __builtin_fma(ka, pb[b], acc[a*DPE+b]);
-                const double kb = K*pb[a];
+                for (int b = 0; b < DPE; b++) acc[a*DPE+b] = __builtin_fma(ka, tj[4+b], acc[a*DPE+b]);
+                const double kb = K*tj[4+a];
 #pragma unroll
                 for (int b = a; b < DPE; b++) {
-                    acc[NG+e] = __builtin_fma(ka, pa[b], acc[NG+e]);
-                    acc[NG+ND+e] = __builtin_fma(kb, pb[b], acc[NG+ND+e]);
+                    acc[NG+e] = __builtin_fma(ka, ti[4+b], acc[NG+e]);
+                    acc[NG+ND+e] = __builtin_fma(kb, tj[4+b], acc[NG+ND+e]);
                     e++;
                 }
             }
-            i += di; j += dj;
-            if (j >= n) { j -= n; i++; }
         }
-        // reduce; lane (e mod 64) keeps entry e (two per lane at most: NACC <= 128)
-        double mine0 = 0., mine1 = 0.;
+        // row-wise reduction; lane (e mod 16) of the row keeps entry e
+        double mine[NREP];
+#pragma unroll
+        for (int r = 0; r < NREP; r++) mine[r] = 0.;
 #pragma unroll
         for (int e = 0; e < NACC; e++) {
-            const double s = wave_sum(acc[e]);
-            if (e < 64) mine0 = (lane == e) ? s : mine0;
-            else mine1 = (lane == e-64) ? s : mine1;
+            const double s = row16_sum(acc[e]);
+            mine[e/16] = (sub == (e & 15)) ? s : mine[e/16];
         }
-        const double vv = 2.*P.cvol[c1]*P.cvol[c2]*kern_scale<KT>(P.k);
+        if (valid) {
+            const double vv = 2.*P.cvol[c1]*P.cvol[c2]*kern_scale<KT>(P.k);
 #pragma unroll
-        for (int rep = 0; rep < (NACC+63)/64; rep++) {
-            const int e = lane+64*rep;
-            const double val = rep ? mine1 : mine0;
-            if (e < NG) {
-                const int a = e/DPE, b = e-a*DPE;
-                const int I = P.cdof[(size_t)a*P.ncp+c1], J = P.cdof[(size_t)b*P.ncp+c2];
-                if (I >= 0 && J >= 0) atomic_add_f64(&A[(long long)I*ldA+J], -vv*val);
-            } else if (e < NG+ND) atomic_add_f64(&Dglob[(size_t)c1*ND+(e-NG)], vv*val);
-            else if (e < NACC) atomic_add_f64(&Dglob[(size_t)c2*ND+(e-NG-ND)], vv*val);
+            for (int rep = 0; rep < NREP; rep++) {
+                const int e = sub+16*rep;
+                const double val = mine[rep];
+                if (e < NG) {
+                    const int a = e/DPE, b = e-a*DPE;
+                    const int I = P.cdof[(size_t)a*P.ncp+c1], J = P.cdof[(size_t)b*P.ncp+c2];
+                    if (I >= 0 && J >= 0) atomic_add_f64(&A[(long long)I*ldA+J], -vv*val);
+                } else if (e < NG+ND) atomic_add_f64(&Dglob[(size_t)c1*ND+(e-NG)], vv*val);
+                else if (e < NACC) atomic_add_f64(&Dglob[(size_t)c2*ND+(e-NG-ND)], vv*val);
+            }
         }
     }
 }
@@ -725,6 +822,7 @@ k_singular_pairs(const DevProblem P, const int2 *__restrict__ pairs, int npairs,
         nodes = s_tab; w = s_tab+2*NV*M; psi = s_tab+(2*NV+1)*M;
     }
     const int nwaves = gridDim.x*(PNL_SING_THREADS/64);
+    unsigned long long done = 0;        // statistics are accumulated per wave: one atomic per wave, not per pair
     for (int wid = (blockIdx.x*PNL_SING_THREADS+threadIdx.x) >> 6; wid < npairs; wid += nwaves) {
     const int2 pr = pairs[wid];
     const int c1 = __builtin_amdgcn_readfirstlane(pr.x), c2 = __builtin_amdgcn_readfirstlane(pr.y);
@@ -859,12 +957,13 @@ k_singular_pairs(const DevProblem P, const int2 *__restrict__ pairs, int npairs,
             }
         }
     }
-    if (lane == 0) {
-        atomicAdd(&P.counters[1], 1ull);
-        atomicAdd(&P.counters[2], (unsigned long long)M);
-        atomicAdd(&P.counters[128+SLOT], 1ull);
-    }
+    done++;
     }   // grid-stride loop over pairs
+    if (lane == 0 && done) {
+        atomicAdd(&P.counters[1], done);
+        atomicAdd(&P.counters[2], done*(unsigned long long)M);
+        atomicAdd(&P.counters[128+SLOT], done);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -983,11 +1082,15 @@ k_boundary_distant(const DevProblem P, double *__restrict__ Dglob, int cell_begi
 #pragma unroll
         for (int e = 0; e < ND; e++)
             if (D[e] != 0.) atomic_add_f64(&Dglob[(size_t)c*ND+e], D[e]);
-        if (npairs) {
-            atomicAdd(&P.counters[3], npairs);
-            atomicAdd(&P.counters[4], nevals);
-        }
         if (overflow) atomicAdd(&P.counters[5], (unsigned long long)overflow);
+    }
+    {
+        // statistics: one atomic per wave
+        const double sp = wave_sum((double)npairs), se = wave_sum((double)nevals);
+        if ((threadIdx.x & 63) == 0 && sp > 0.) {
+            atomicAdd(&P.counters[3], (unsigned long long)sp);
+            atomicAdd(&P.counters[4], (unsigned long long)se);
+        }
     }
 }
 
