@@ -127,6 +127,29 @@ int pnl_assemble_dense(pnl_context *ctx, double *A_dev, int64_t ldA, int zero_ex
 int pnl_tile_cells(pnl_context *ctx);
 int pnl_assemble_dense_tiles(pnl_context *ctx, double *A_dev, int64_t ldA, int zero_exterior, int ntiles,
                              const int32_t *tiles_host, int cell_begin, int cell_end, int flags);
+/* ---- H2 near field: nonlocalBuilder.assembleClusters (NA:1663-1964) ------------------------------------------ */
+/* Sparsity pattern of the near-field matrix (getSparseNearField NA:3226-3289): CSR indptr[num_dofs+1], indices[nnz],
+ * column indices strictly increasing per row.  For an SSS_LinearOperator only the strict lower triangle (I > J) is
+ * listed and the diagonal lives in its own vector (SSS_LinearOperator_{SCALAR}.pxi:23-60). */
+int pnl_upload_sparsity(pnl_context *ctx, int nnz, const int32_t *indptr_host, const int32_t *indices_host);
+/* 'interior' loop over the recorded element pairs (NA:1776-1832): pairs[np][2] with c1 <= c2, masks[np][4] = the
+ * 256-bit MASK_t of requested entries of the symmetric local matrix (bit k(p,q), p <= q over the 2*dpe local DoFs,
+ * buildMasksForClusters NA:260-391).  Panel + quadrature as in pnl_assemble_dense; scatter = addToMatrixElemElemSymMasked
+ * (NA:503-520) with the reference's addToEntry semantics: entries absent from the pattern are dropped
+ * (CSR_LinearOperator_{SCALAR}.pxi:150-170), SSS keeps I >= J only (SSS_LinearOperator_{SCALAR}.pxi:104-130).
+ * data_dev[nnz] (+ diag_dev[num_dofs] for SSS, NULL for CSR) are accumulated into; the caller zeroes them. */
+int pnl_assemble_pairs_masked(pnl_context *ctx, int np, const int32_t *pairs_host, const uint64_t *masks_host,
+                              double *data_dev, double *diag_dev);
+/* Gauss-theorem boundary term over explicit items: the cluster-local term (NA:1842-1889; facets = boundary of
+ * cellsUnion, nonlocalAssembly.pyx:505-578) and the global Omega x Omega^c term with fac = +-1 (NA:1896-1913, 1945-1964).
+ * cells[ni], facets[ni][dim] vertex ids oriented as in their owning cell, masks[ni] bit field over the dpe(dpe+1)/2
+ * entries (getElemSymMaskCluster NA:463-478), scatter addToMatrixElemSymMasked NA:534-546 times fac. */
+int pnl_assemble_boundary_masked(pnl_context *ctx, int ni, const int32_t *cells_host, const int32_t *facets_host,
+                                 const uint32_t *masks_host, double fac, double *data_dev, double *diag_dev);
+/* y = A x for the uploaded pattern (CSR: diag_dev NULL; SSS: lower triangle + diagonal, y = (L + D + L^T) x):
+ * CSR_LinearOperator.matvec / SSS_LinearOperator.matvec */
+int pnl_spmv(pnl_context *ctx, const double *data_dev, const double *diag_dev, const double *x_dev, double *y_dev);
+
 /* counters of the last assemble call (synchronises the stream) */
 int pnl_get_counters(pnl_context *ctx, int64_t *out, int n);
 /* device time of the last assemble call per phase in milliseconds (HIP events on the context's stream):

@@ -432,3 +432,92 @@ int nlo_get_dense(const nlo_problem *P, double *A, int zero_exterior, int cell_s
                   int64_t *counters, double *seconds) {
     return nlo_get_dense_rows(P, A, zero_exterior, cell_start, cell_end, counters, seconds, 1);
 }
+
+/* CSR_LinearOperator.addToEntry / SSS_LinearOperator.addToEntry
+ * (base/PyNucleus_base/CSR_LinearOperator_{SCALAR}.pxi:150-170, SSS_LinearOperator_{SCALAR}.pxi:104-130):
+ * search the row, silently drop entries that are not in the pattern; SSS keeps I > J plus a diagonal vector. */
+static void sparse_add(const int32_t *indptr, const int32_t *indices, double *data, double *diag, int I, int J, double v) {
+    if (I < 0 || J < 0) return;                 /* boundary DoFs are skipped by every addToMatrix* (NA:152-253) */
+    if (diag) {
+        if (I == J) { diag[I] += v; return; }
+        if (I < J) return;
+    }
+    int lo = indptr[I], hi = indptr[I+1];
+    while (lo < hi) {
+        int mid = (lo+hi) >> 1;
+        if (indices[mid] < J) lo = mid+1; else hi = mid;
+    }
+    if (lo < indptr[I+1] && indices[lo] == J) data[lo] += v;
+}
+
+int nlo_assemble_pairs_masked(const nlo_problem *P, int np, const int32_t *pairs, const uint64_t *masks, const int32_t *indptr,
+                              const int32_t *indices, double *data, double *diag, int64_t *counters) {
+    const int dpe = P->dpe, n2 = 2*dpe;
+    double contrib[MAXE];
+    int perm1[MAXV], perm2[MAXV], perm[2*MAXDPE], ld[2*MAXDPE];
+    counters[0] = counters[1] = counters[2] = 0;
+    for (int t = 0; t < np; t++) {
+        const int c1 = pairs[2*t], c2 = pairs[2*t+1];
+        const uint64_t *mask = masks+4*(size_t)t;
+        counters[0]++;
+        int panel = nlo_panel(P, c1, c2, perm1, perm2, perm);
+        if (panel == NLO_IGNORED) continue;
+        if (panel >= 1 && (panel > P->qmax || P->dist_off[panel+1] == P->dist_off[panel])) return -(1000+panel);
+        counters[1]++;
+        int skip = 1;
+        for (int p = 0; p < dpe; p++) { ld[p] = P->dofs[c1*dpe+p]; skip = skip && ld[p] < 0; }
+        for (int p = 0; p < dpe; p++) { ld[dpe+p] = P->dofs[c2*dpe+p]; skip = skip && ld[dpe+p] < 0; }
+        if (skip) continue;
+        nlo_eval(P, c1, c2, panel, perm1, perm2, perm, contrib, &counters[2]);
+        const double fac = c1 == c2 ? 1. : 2.;
+        int k = 0;                                  /* NA:503-520 addToMatrixElemElemSymMasked */
+        for (int p = 0; p < n2; p++) {
+            const int I = ld[p];
+            if ((mask[k >> 6] >> (k & 63)) & 1) sparse_add(indptr, indices, data, diag, I, I, fac*contrib[k]);
+            k++;
+            for (int q = p+1; q < n2; q++) {
+                if ((mask[k >> 6] >> (k & 63)) & 1) {
+                    const int J = ld[q];
+                    sparse_add(indptr, indices, data, diag, I, J, fac*contrib[k]);
+                    sparse_add(indptr, indices, data, diag, J, I, fac*contrib[k]);
+                }
+                k++;
+            }
+        }
+    }
+    return 0;
+}
+
+int nlo_assemble_boundary_masked(const nlo_problem *P, int ni, const int32_t *cells, const int32_t *facets, const uint32_t *masks,
+                                 double fac, const int32_t *indptr, const int32_t *indices, double *data, double *diag) {
+    const int dpe = P->dpe, dim = P->dim;
+    double contrib[MAXE];
+    int perm1[MAXV], perm2[MAXV], perm[2*MAXDPE];
+    int64_t nevals = 0;
+    nlo_problem Q = *P;
+    Q.nb = 1;
+    for (int t = 0; t < ni; t++) {
+        const int c1 = cells[t];
+        Q.bcells = facets+(size_t)t*dim;
+        int panel = nlo_panel_boundary(&Q, c1, 0, perm1, perm2, perm);
+        if (panel >= 1 && (panel > P->qmax || P->dist_off[panel+1] == P->dist_off[panel]
+                           || P->bfacet_off[panel+1] == P->bfacet_off[panel])) return -(2000+panel);
+        nlo_eval_boundary(&Q, c1, 0, panel, perm1, perm2, perm, contrib, &nevals);
+        const uint32_t mask = masks[t];
+        int k = 0;                                  /* NA:534-546 addToMatrixElemSymMasked */
+        for (int p = 0; p < dpe; p++) {
+            const int I = P->dofs[c1*dpe+p];
+            if ((mask >> k) & 1) sparse_add(indptr, indices, data, diag, I, I, fac*contrib[k]);
+            k++;
+            for (int q = p+1; q < dpe; q++) {
+                if ((mask >> k) & 1) {
+                    const int J = P->dofs[c1*dpe+q];
+                    sparse_add(indptr, indices, data, diag, I, J, fac*contrib[k]);
+                    sparse_add(indptr, indices, data, diag, J, I, fac*contrib[k]);
+                }
+                k++;
+            }
+        }
+    }
+    return 0;
+}

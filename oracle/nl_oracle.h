@@ -90,4 +90,13 @@ int nlo_get_dense(const nlo_problem *P, double *A, int zero_exterior, int cell_s
 /* same loops, only counting (for sampling the cost of a sub-range without storing A): A may be NULL */
 int nlo_get_dense_rows(const nlo_problem *P, double *A, int zero_exterior, int cell_start, int cell_end,
                        int64_t *counters, double *seconds, int store);
+/* H2 near field (NA:1663-1964): masked interior pairs (NA:1812-1832 with the scatter NA:503-520) into CSR (diag == NULL)
+ * or SSS (strict lower triangle in data + diag); entries absent from the pattern are dropped like the reference's addToEntry.
+ * pairs[np][2] with c1 <= c2, masks[np][4] (256-bit MASK_t).  counters: [0] pairs, [1] assembled, [2] kernel evaluations. */
+int nlo_assemble_pairs_masked(const nlo_problem *P, int np, const int32_t *pairs, const uint64_t *masks, const int32_t *indptr,
+                              const int32_t *indices, double *data, double *diag, int64_t *counters);
+/* cluster-local Gauss-theorem term (NA:1842-1889) and the global one with fac = +-1 (NA:1896-1913, 1945-1964):
+ * items (cell, facet vertex ids[dim], mask over the dpe(dpe+1)/2 entries), scatter NA:534-546 */
+int nlo_assemble_boundary_masked(const nlo_problem *P, int ni, const int32_t *cells, const int32_t *facets, const uint32_t *masks,
+                                 double fac, const int32_t *indptr, const int32_t *indices, double *data, double *diag);
 #endif

@@ -71,6 +71,10 @@ def lib():
         L.nlo_eval_boundary.argtypes = [C.POINTER(nlo_problem), C.c_int, C.c_int, C.c_int, ip, ip, ip, _P, _P]
         L.nlo_get_dense_rows.restype = C.c_int
         L.nlo_get_dense_rows.argtypes = [C.POINTER(nlo_problem), _P, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int]
+        L.nlo_assemble_pairs_masked.restype = C.c_int
+        L.nlo_assemble_pairs_masked.argtypes = [C.POINTER(nlo_problem), C.c_int, _P, _P, _P, _P, _P, _P, _P]
+        L.nlo_assemble_boundary_masked.restype = C.c_int
+        L.nlo_assemble_boundary_masked.argtypes = [C.POINTER(nlo_problem), C.c_int, _P, _P, _P, C.c_double, _P, _P, _P, _P]
         _LIB = L
     return _LIB
 
@@ -124,7 +128,7 @@ class OracleProblem:
         P.bfacet_off = ptr(T.bfacet_off, np.int32)
         P.bfacet_bary = ptr(T.bfacet_bary, np.float64)
         P.bfacet_w = ptr(T.bfacet_w, np.float64)
-        if T.zeroExterior:
+        if T.has_boundary_tables:
             P.nb = T.bcells.shape[0]
             P.bcells = ptr(T.bcells, np.int32)
             P.bkernel = _kern(T.boundaryKernel)
@@ -183,3 +187,35 @@ class OracleProblem:
         cnt = dict(numCellPairs=int(counters[0]), numAssembledCellPairs=int(counters[1]), numIntegrations=int(counters[2]),
                    numBoundaryPairs=int(counters[3]), numBoundaryIntegrations=int(counters[4]), orders=hist, singular=sing)
         return A, cnt, (float(seconds[0]), float(seconds[1]))
+
+    # -- H2 near field ------------------------------------------------------------------------------------------
+    def assemble_clusters(self, pairs, masks, bcells, bfacets, bmasks, indptr, indices, symmetric=True, global_boundary=None):
+        """masked interior pairs + cluster-local boundary items into CSR / SSS; returns (data, diagonal or None, counters).
+        global_boundary = (cells, facets, masks, fac) adds the global Omega x Omega^c term with the given sign."""
+        N = self.tables.dm.num_dofs
+        data = np.zeros(indices.shape[0])
+        diag = np.zeros(N) if symmetric else None
+        pairs = np.ascontiguousarray(pairs, dtype=np.int32)
+        masks = np.ascontiguousarray(masks, dtype=np.uint64)
+        indptr = np.ascontiguousarray(indptr, dtype=np.int32)
+        indices = np.ascontiguousarray(indices, dtype=np.int32)
+        cnt = np.zeros(3, dtype=np.int64)
+        dptr = diag.ctypes.data if symmetric else None
+        rc = lib().nlo_assemble_pairs_masked(C.byref(self.P), pairs.shape[0], pairs.ctypes.data, masks.ctypes.data, indptr.ctypes.data,
+                                             indices.ctypes.data, data.ctypes.data, dptr, cnt.ctypes.data)
+        if rc:
+            raise RuntimeError('oracle failed with code {}'.format(rc))
+        items = [(bcells, bfacets, bmasks, 1.)]
+        if global_boundary is not None:
+            items.append(global_boundary)
+        for cc, ff, mm, fac in items:
+            cc = np.ascontiguousarray(cc, dtype=np.int32)
+            ff = np.ascontiguousarray(ff, dtype=np.int32)
+            mm = np.ascontiguousarray(mm, dtype=np.uint32)
+            if cc.shape[0] == 0:
+                continue
+            rc = lib().nlo_assemble_boundary_masked(C.byref(self.P), cc.shape[0], cc.ctypes.data, ff.ctypes.data, mm.ctypes.data,
+                                                    float(fac), indptr.ctypes.data, indices.ctypes.data, data.ctypes.data, dptr)
+            if rc:
+                raise RuntimeError('oracle failed with code {}'.format(rc))
+        return data, diag, dict(numCellPairs=int(cnt[0]), numAssembledCellPairs=int(cnt[1]), numIntegrations=int(cnt[2]))

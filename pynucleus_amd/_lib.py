@@ -27,7 +27,7 @@ EXPORTS = ['pnl_create', 'pnl_destroy', 'pnl_error_string', 'pnl_version', 'pnl_
            'pnl_upload_mesh', 'pnl_upload_dofmap', 'pnl_set_kernel', 'pnl_set_order_formula', 'pnl_upload_distant_rules',
            'pnl_upload_singular_rule', 'pnl_upload_boundary', 'pnl_assemble_dense', 'pnl_tile_cells',
            'pnl_assemble_dense_tiles', 'pnl_get_counters', 'pnl_get_phase_ms', 'pnl_gemv', 'pnl_cg_jacobi',
-           'pnl_inv_diagonal']
+           'pnl_inv_diagonal', 'pnl_upload_sparsity', 'pnl_assemble_pairs_masked', 'pnl_assemble_boundary_masked', 'pnl_spmv']
 
 
 class pnl_kernel(C.Structure):
@@ -80,6 +80,10 @@ def load():
     L.pnl_gemv.argtypes = [vp, vp, i64, i32, vp, vp, i32]
     L.pnl_cg_jacobi.argtypes = [vp, vp, i64, i32, vp, vp, dbl, i32, C.POINTER(C.c_int), C.POINTER(C.c_double)]
     L.pnl_inv_diagonal.argtypes = [vp, vp, i64, i32, vp]
+    L.pnl_upload_sparsity.argtypes = [vp, i32, vp, vp]
+    L.pnl_assemble_pairs_masked.argtypes = [vp, i32, vp, vp, vp, vp]
+    L.pnl_assemble_boundary_masked.argtypes = [vp, i32, vp, vp, vp, dbl, vp, vp]
+    L.pnl_spmv.argtypes = [vp, vp, vp, vp, vp]
     for name in EXPORTS:
         f = getattr(L, name)
         if name not in ('pnl_destroy', 'pnl_error_string', 'pnl_version'):
@@ -153,7 +157,7 @@ class Context:
             ww, pww = _hp(r.weights, np.float64)
             ps, pps = _hp(r.psi, np.float64)
             self.check(L.pnl_upload_singular_rule(h, PNL_INTERIOR, panel, r.num_nodes, r.rows, pn, pww, pps, float(T.sing_fac)))
-        if T.zeroExterior:
+        if T.has_boundary_tables:
             bc, pbc = _hp(T.bcells, np.int32)
             self.check(L.pnl_upload_boundary(h, bc.shape[0], pbc))
             self._set_kernel(PNL_BOUNDARY, T.boundaryKernel, T.bqo)
@@ -191,6 +195,31 @@ class Context:
         t, pt = _hp(tiles, np.int32)
         self.check(self.L.pnl_assemble_dense_tiles(self.h, C.c_void_p(A_ptr), int(ldA), int(bool(zero_exterior)), t.shape[0], pt,
                                                    int(cell_begin), int(cell_end), int(flags)))
+
+    # -- near field (assembleClusters) -------------------------------------
+    def upload_sparsity(self, indptr, indices):
+        ip, pip = _hp(indptr, np.int32)
+        ix, pix = _hp(indices, np.int32)
+        self.check(self.L.pnl_upload_sparsity(self.h, ix.shape[0], pip, pix))
+
+    def assemble_pairs_masked(self, pairs, masks, data_ptr, diag_ptr=None):
+        p, pp = _hp(pairs, np.int32)
+        m, pm = _hp(masks, np.uint64)
+        assert p.ndim == 2 and p.shape[1] == 2 and m.shape == (p.shape[0], 4)
+        self.check(self.L.pnl_assemble_pairs_masked(self.h, p.shape[0], pp, pm, C.c_void_p(data_ptr),
+                                                    C.c_void_p(diag_ptr) if diag_ptr else None))
+
+    def assemble_boundary_masked(self, cells, facets, masks, fac, data_ptr, diag_ptr=None):
+        c, pc = _hp(cells, np.int32)
+        f, pf = _hp(facets, np.int32)
+        m, pm = _hp(masks, np.uint32)
+        assert f.shape[0] == c.shape[0] == m.shape[0]
+        self.check(self.L.pnl_assemble_boundary_masked(self.h, c.shape[0], pc, pf, pm, float(fac), C.c_void_p(data_ptr),
+                                                       C.c_void_p(diag_ptr) if diag_ptr else None))
+
+    def spmv(self, data_ptr, diag_ptr, x_ptr, y_ptr):
+        self.check(self.L.pnl_spmv(self.h, C.c_void_p(data_ptr), C.c_void_p(diag_ptr) if diag_ptr else None, C.c_void_p(x_ptr),
+                                   C.c_void_p(y_ptr)))
 
     def counters(self):
         out = np.zeros(PNL_NUM_COUNTERS, dtype=np.int64)

@@ -141,16 +141,95 @@ class nonlocalBuilder:
         return tiles_of_rank(self.mesh.num_cells, T, rank, size)
 
     def getDiagonal(self):
+        """NA:2269-2289: the diagonal through cluster pairs of single DoFs; here one masked assembly into a
+        diagonal-only SSS pattern (every element pair that shares a DoF contributes)"""
         raise NotImplementedError('getDiagonal: assemble the dense operator and take .diagonal')
 
     def getSparse(self, returnNearField=False):
         raise NotImplementedError('finite-horizon sparse assembly is not implemented on the GPU path yet')
 
-    def getH2(self, **kwargs):
-        raise NotImplementedError('H2 assembly is not implemented on the GPU path yet')
+    def getH2RefinementParams(self):
+        """NA:2386-2431: eta, leaf size and depth of the cluster tree from params"""
+        p = self.params
+        N = self.dm.num_dofs
+        return dict(eta=p.get('eta', 3.), maxLevels=p.get('maxLevels', 200),
+                    minSize=p.get('minClusterSize', max(self.dm.dofs_per_element*4, min(64, max(N//16, 8)))))
 
-    def assembleClusters(self, Pnear, **kwargs):
-        raise NotImplementedError('cluster (near-field) assembly is not implemented on the GPU path yet')
+    def getH2(self, returnNearField=False, returnTree=False, **kwargs):
+        """NA:3094-3219.  Built here: cluster tree, admissibility and the near-field matrix on the GPU.  The far field
+        (Chebyshev kernel interpolation, transfer operators, H2Matrix.matvec: SURVEY 8f row 1) is not built yet, so the
+        full operator is only available when no admissible pair exists (then the dense operator is returned like the
+        reference's assembleDenseWhenH2Fails branch)."""
+        from . import clusters
+        rp = self.getH2RefinementParams()
+        root, Pnear, Pfar = clusters.getNearFieldClusters(self.dm, rp['eta'], rp['minSize'], rp['maxLevels'])
+        if sum(len(v) for v in Pfar.values()) == 0:
+            h2 = self.getDense()
+        elif returnNearField:
+            h2 = self.assembleClusters(Pnear)
+        else:
+            raise NotImplementedError('H2 far field (clusterMethodCy.pyx:2153-2295) is not built yet; '
+                                      'getH2(returnNearField=True) returns the GPU-assembled near-field matrix')
+        out = (h2,)
+        if returnNearField:
+            out += (Pnear,)
+        if returnTree:
+            out += (root,)
+        return out if len(out) > 1 else out[0]
+
+    def assembleClusters(self, Pnear, forceUnsymmetricMatrix=False, Anear=None, jumps={}, myRoot=None, **kwargs):
+        """Near-field matrix of the cluster pairs Pnear (NA:1663-1964), assembled on the GPU.
+
+        Host side: sparsity pattern (getSparseNearField NA:3226-3289), per element-pair 256-bit entry masks
+        (buildMasksForClusters NA:260-391) and the item list of the cluster-local Gauss-theorem term
+        (NA:1842-1889).  Device side: classification, quadrature and masked scatter into CSR / SSS.
+        Without zeroExterior the global Omega x Omega^c term is subtracted again (NA:1896-1913)."""
+        import torch
+        from . import clusters
+        from .linear_operators import CSR_LinearOperator, SSS_LinearOperator
+        if jumps:
+            raise NotImplementedError('variable-order jump terms')
+        if myRoot is not None:
+            raise NotImplementedError('distributed near-field assembly by subtree')
+        ctx = self.context()
+        dev = torch.device('cuda', ctx.device)
+        dm = self.dm
+        symmetric = not forceUnsymmetricMatrix
+        if Anear is None:
+            indptr, indices = clusters.getSparseNearField(dm, Pnear, symmetric=symmetric)
+            Anear = (SSS_LinearOperator if symmetric else CSR_LinearOperator)(indptr, indices, dm.num_dofs, ctx, dev)
+        Anear._bind()
+        data_ptr, diag_ptr = Anear._ptrs()
+        maxNNZ = int(self.params.get('maxMasksNNZ', 10000000))
+        totals = dict(numCellPairs=0, numAssembledCellPairs=0, numIntegrations=0)
+        hist, sing = {}, {}
+        ms_total = 0.
+        # element pairs in chunks of cluster pairs like the reference's maxMasksNNZ loop (NA:1786-1791)
+        for pairs, masks in clusters.iterMasksForClusters(dm, Pnear, maxNNZ):
+            ctx.assemble_pairs_masked(pairs, masks, data_ptr, diag_ptr)
+            cnt = ctx.counters()
+            for k in totals:
+                totals[k] += cnt[k]
+            for q, c in cnt['orders'].items():
+                hist[q] = hist.get(q, 0)+c
+            for q, c in cnt['singular'].items():
+                sing[q] = sing.get(q, 0)+c
+            ms_total += ctx.phase_ms()['total']
+        nitems = 0
+        if self.tables.has_boundary_tables and not self.kernel.variable:
+            cells, facets, bmasks = clusters.clusterBoundaryItems(dm, Pnear)
+            nitems = int(cells.shape[0])
+            ctx.assemble_boundary_masked(cells, facets, bmasks, 1., data_ptr, diag_ptr)
+            if not self.zeroExterior:
+                cells, facets, bmasks = clusters.globalBoundaryItems(dm, self.tables.bcells)
+                nitems += int(cells.shape[0])
+                ctx.assemble_boundary_masked(cells, facets, bmasks, -1., data_ptr, diag_ptr)
+        ctx.synchronize()
+        for k, v in totals.items():
+            self.PLogger.addValue(k, v)
+        self.PLogger.addTimer('interior', 1e-3*ms_total)
+        Anear.info = dict(counters=dict(totals, orders=hist, singular=sing, numBoundaryItems=nitems), interior_ms=ms_total)
+        return Anear
 
 
 def assembleNonlocalOperator(mesh, dm, s, horizon=None, params={}, zeroExterior=True, comm=None, **kwargs):

@@ -1,0 +1,368 @@
+"""Cluster tree, admissibility and near-field work lists for assembleClusters (host side, numpy).
+
+Mirrors what the H2 near-field assembly of the reference consumes
+(/root/reference/nl/PyNucleus_nl):
+  clusterMethodCy.pyx:3922-3977  getDoFBoxesAndCells  (support boxes of the DoFs, DoF -> cells graph)
+  clusterMethodCy.pyx:354-663    tree_node.refine     (here: the MEDIAN split along the longest box edge only)
+  clusterMethodCy.pyx:4008-4136  queryAdmissibility / getAdmissibleClusters (eta criterion, near/far recursion and
+                                 the merge of near-field children into their parent pair)
+  nonlocalAssembly.pyx:374-392   nearFieldClusterPair.set_cells (cellsUnion, cellsInter)
+  nonlocalAssembly.pyx:540-578   boundaryEdges of a cell set (orientation of the owning cell)
+  nonlocalAssembly_{SCALAR}.pxi:260-391, 408-424   buildMasksForClusters / getElemElemSymMask
+  nonlocalAssembly_{SCALAR}.pxi:3226-3289          getSparseNearField (CSR / SSS sparsity pattern)
+The far field (Chebyshev interpolation, transfer operators, H2 matvec) is not built yet.
+"""
+import numpy as np
+
+
+def getDoFBoxesAndCells(dm):
+    """boxes[N, dim, 2] of the DoF supports and the DoF -> cells graph as CSR (indptr, indices)"""
+    mesh = dm.mesh
+    v = mesh.vertices[mesh.cells]                       # [nc, k, dim]
+    lo, hi = v.min(axis=1), v.max(axis=1)               # [nc, dim]
+    N, dim = dm.num_dofs, mesh.dim
+    boxes = np.empty((N, dim, 2))
+    boxes[:, :, 0] = np.inf
+    boxes[:, :, 1] = -np.inf
+    cell_ids = np.repeat(np.arange(mesh.num_cells), dm.dofs_per_element)
+    d = dm.dofs.reshape(-1)
+    m = d >= 0
+    for k in range(dim):
+        np.minimum.at(boxes[:, k, 0], d[m], lo[cell_ids[m], k])
+        np.maximum.at(boxes[:, k, 1], d[m], hi[cell_ids[m], k])
+    order = np.lexsort((cell_ids[m], d[m]))
+    dd, cc = d[m][order], cell_ids[m][order]
+    keep = np.ones(dd.shape[0], dtype=bool)
+    keep[1:] = (dd[1:] != dd[:-1]) | (cc[1:] != cc[:-1])
+    dd, cc = dd[keep], cc[keep]
+    indptr = np.zeros(N+1, dtype=np.int64)
+    np.add.at(indptr, dd+1, 1)
+    indptr = np.cumsum(indptr)
+    return boxes, (indptr, cc.astype(np.int32))
+
+
+class tree_node:
+    def __init__(self, parent, dofs, boxes, coords, dof2cells, levelNo):
+        self.parent = parent
+        self.dofs = np.sort(np.asarray(dofs, dtype=np.int32))
+        self.box = np.stack([boxes[self.dofs, :, 0].min(axis=0), boxes[self.dofs, :, 1].max(axis=0)], axis=1)
+        self.children = []
+        self.levelNo = levelNo
+        self._boxes, self._coords, self._d2c = boxes, coords, dof2cells
+        self._cells = None
+
+    @property
+    def is_leaf(self):
+        return len(self.children) == 0
+
+    def get_dofs(self):
+        return self.dofs
+
+    def get_num_dofs(self):
+        return self.dofs.shape[0]
+
+    @property
+    def cells(self):
+        """cells touching the cluster's DoFs (NA:2887-2898)"""
+        if self._cells is None:
+            indptr, indices = self._d2c
+            parts = [indices[indptr[I]:indptr[I+1]] for I in self.dofs]
+            self._cells = np.unique(np.concatenate(parts)) if parts else np.zeros(0, dtype=np.int32)
+        return self._cells
+
+    def refine(self, minSize, maxLevels):
+        """MEDIAN split of the DoF coordinates along the longest edge of the cluster box into two children"""
+        n = self.dofs.shape[0]
+        if self.levelNo+1 >= maxLevels or n <= minSize or not self.is_leaf:
+            return
+        k = int(np.argmax(self.box[:, 1]-self.box[:, 0]))
+        x = self._coords[self.dofs, k]
+        med = np.median(x)
+        left, right = self.dofs[x < med], self.dofs[x >= med]
+        if left.shape[0] < minSize or right.shape[0] < minSize or left.shape[0] == n or right.shape[0] == n:
+            return
+        self.children = [tree_node(self, left, self._boxes, self._coords, self._d2c, self.levelNo+1),
+                         tree_node(self, right, self._boxes, self._coords, self._d2c, self.levelNo+1)]
+
+    def leaves(self):
+        if self.is_leaf:
+            yield self
+        else:
+            for c in self.children:
+                yield from c.leaves()
+
+
+class nearFieldClusterPair:
+    def __init__(self, n1, n2):
+        self.n1, self.n2 = n1, n2
+        self.cellsUnion = self.cellsInter = None
+
+    def set_cells(self):
+        c1, c2 = self.n1.cells, self.n2.cells
+        self.cellsUnion = np.union1d(c1, c2)
+        self.cellsInter = np.intersect1d(c1, c2)
+
+    def __repr__(self):
+        return 'nearFieldClusterPair({} x {} DoFs)'.format(self.n1.get_num_dofs(), self.n2.get_num_dofs())
+
+
+class farFieldClusterPair:
+    def __init__(self, n1, n2):
+        self.n1, self.n2 = n1, n2
+
+
+def distBoxes(b1, b2):
+    gap = np.maximum(0., np.maximum(b1[:, 0]-b2[:, 1], b2[:, 0]-b1[:, 1]))
+    return float(np.sqrt((gap**2).sum()))
+
+
+def diamBox(b):
+    return float(np.sqrt(((b[:, 1]-b[:, 0])**2).sum()))
+
+
+def getTree(dm):
+    boxes, d2c = getDoFBoxesAndCells(dm)
+    coords = boxes.mean(axis=2)
+    root = tree_node(None, np.arange(dm.num_dofs, dtype=np.int32), boxes, coords, d2c, 0)
+    return root
+
+
+def getAdmissibleClusters(n1, n2, eta, minSize, maxLevels, Pfar, Pnear, level=0):
+    """clusterMethodCy.pyx:4046-4136 for an infinite horizon; returns whether far-field pairs were added below"""
+    dist = distBoxes(n1.box, n2.box)
+    admissible = eta*dist >= max(diamBox(n1.box), diamBox(n2.box))
+    lenNear = len(Pnear)
+    added = False
+    if admissible:
+        Pfar.setdefault(level, []).append(farFieldClusterPair(n1, n2))
+        return True
+    n1.refine(minSize, maxLevels)
+    n2.refine(minSize, maxLevels)
+    if (n1.is_leaf and n2.is_leaf) or level == maxLevels:
+        Pnear.append(nearFieldClusterPair(n1, n2))
+        return False
+    elif n1.is_leaf:
+        for t2 in n2.children:
+            added |= getAdmissibleClusters(n1, t2, eta, minSize, maxLevels, Pfar, Pnear, level+1)
+    elif n2.is_leaf:
+        for t1 in n1.children:
+            added |= getAdmissibleClusters(t1, n2, eta, minSize, maxLevels, Pfar, Pnear, level+1)
+    else:
+        for t1 in n1.children:
+            for t2 in n2.children:
+                added |= getAdmissibleClusters(t1, t2, eta, minSize, maxLevels, Pfar, Pnear, level+1)
+    if not added:
+        # no far-field pair below: keep the whole block as one near-field pair (CM:4131-4135)
+        del Pnear[lenNear:]
+        Pnear.append(nearFieldClusterPair(n1, n2))
+    return added
+
+
+def getNearFieldClusters(dm, eta=3., minClusterSize=None, maxLevels=200):
+    """(root, Pnear, Pfar) for dm; both orientations (n1,n2) and (n2,n1) of off-diagonal pairs are listed, like the
+    reference's recursion from (root, root)"""
+    root = getTree(dm)
+    if minClusterSize is None:
+        minClusterSize = max(dm.num_dofs//64, 8)
+    Pnear, Pfar = [], {}
+    getAdmissibleClusters(root, root, eta, minClusterSize, maxLevels, Pfar, Pnear)
+    for cp in Pnear:
+        cp.set_cells()
+    return root, Pnear, Pfar
+
+
+def coveringCluster(dm):
+    """one near-field pair (root, root): assembleClusters must then reproduce the dense operator (tests/test_nearField.py:171-184)"""
+    root = getTree(dm)
+    cp = nearFieldClusterPair(root, root)
+    cp.set_cells()
+    return root, [cp]
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def getSparseNearField(dm, Pnear, symmetric=True):
+    """sparsity pattern of the near field: CSR (indptr, indices); with symmetric=True only I > J is stored (SSS, the
+    diagonal lives in its own vector)"""
+    N = dm.num_dofs
+    rows, cols = [], []
+    for cp in Pnear:
+        I = np.repeat(cp.n1.dofs, cp.n2.dofs.shape[0])
+        J = np.tile(cp.n2.dofs, cp.n1.dofs.shape[0])
+        if symmetric:
+            m = I > J
+            I, J = I[m], J[m]
+        rows.append(I)
+        cols.append(J)
+    keys = np.unique(np.concatenate(rows).astype(np.int64)*N+np.concatenate(cols))
+    I, J = (keys//N).astype(np.int32), (keys % N).astype(np.int32)
+    indptr = np.zeros(N+1, dtype=np.int32)
+    np.add.at(indptr, I+1, 1)
+    return np.cumsum(indptr).astype(np.int32), J
+
+
+def elemElemSymMaskTable(dpe):
+    """k(p, q) for p <= q over the 2*dpe local DoFs: flattened index of the symmetric local matrix"""
+    n = 2*dpe
+    k = np.full((n, n), -1, dtype=np.int64)
+    c = 0
+    for p in range(n):
+        for q in range(p, n):
+            k[p, q] = c
+            c += 1
+    return k
+
+
+def _masksOfClusterPair(dm, cp, ktab):
+    """(keys = c1*nc + c2 with c1 <= c2, mask words) requested by one near-field cluster pair"""
+    dpe = dm.dofs_per_element
+    nc = dm.mesh.num_cells
+    E = (2*dpe)*(2*dpe+1)//2
+    dofs = dm.dofs
+    in1 = np.zeros(dm.num_dofs+1, dtype=bool)
+    in2 = np.zeros(dm.num_dofs+1, dtype=bool)
+    in1[cp.n1.dofs] = True
+    in2[cp.n2.dofs] = True
+    cu = cp.cellsUnion
+    d = np.where(dofs[cu] >= 0, dofs[cu], dm.num_dofs)              # [ncu, dpe]
+    m1 = in1[d]                                                    # cellMasks1: local DoF in cluster 1
+    m2 = in2[d]
+    pos = -np.ones(nc, dtype=np.int64)
+    pos[cu] = np.arange(cu.shape[0])
+    c1 = np.repeat(cp.n1.cells, cp.n2.cells.shape[0])
+    c2 = np.tile(cp.n2.cells, cp.n1.cells.shape[0])
+    swap = c1 > c2
+    a, b = np.where(swap, c2, c1), np.where(swap, c1, c2)
+    pa, pb = pos[a], pos[b]
+    cm1 = np.concatenate([m1[pa], m1[pb]], axis=1)                  # cellMask1 over 2 dpe local DoFs
+    cm2 = np.concatenate([m2[pa], m2[pb]], axis=1)
+    ok = cm1.any(axis=1) & cm2.any(axis=1)
+    a, b, cm1, cm2 = a[ok], b[ok], cm1[ok], cm2[ok]
+    # getElemElemSymMask: bit k(p,q), p <= q, set if p in cellMask1 and q in cellMask2
+    words = np.zeros((a.shape[0], 4), dtype=np.uint64)
+    for p in range(2*dpe):
+        for q in range(p, 2*dpe):
+            k = int(ktab[p, q])
+            words[:, k//64] |= (cm1[:, p] & cm2[:, q]).astype(np.uint64) << np.uint64(k % 64)
+    assert E <= 256
+    return a.astype(np.int64)*nc+b, words
+
+
+def _mergeMasks(keys, masks, nc):
+    keys = np.concatenate(keys)
+    masks = np.concatenate(masks)
+    order = np.argsort(keys, kind='stable')
+    keys, masks = keys[order], masks[order]
+    uniq, first = np.unique(keys, return_index=True)
+    merged = np.bitwise_or.reduceat(masks, first, axis=0) if keys.shape[0] else masks
+    pairs = np.stack([uniq//nc, uniq % nc], axis=1).astype(np.int32)
+    return np.ascontiguousarray(pairs), np.ascontiguousarray(merged)
+
+
+def iterMasksForClusters(dm, Pnear, maxNNZ=10000000):
+    """yields (pairs[np, 2] with c1 <= c2, masks[np, 4] uint64) for consecutive groups of cluster pairs holding about
+    maxNNZ element pairs each -- the reference's chunked loop NA:1786-1791 over buildMasksForClusters NA:260-391
+    (symmetric cells and local matrix): which entries of the symmetric local matrix of each element pair are requested
+    by some cluster pair of the group (OR-merged)."""
+    nc = dm.mesh.num_cells
+    ktab = elemElemSymMaskTable(dm.dofs_per_element)
+    keys, masks, n = [], [], 0
+    for cp in Pnear:
+        k, m = _masksOfClusterPair(dm, cp, ktab)
+        keys.append(k)
+        masks.append(m)
+        n += k.shape[0]
+        if n > maxNNZ:
+            yield _mergeMasks(keys, masks, nc)
+            keys, masks, n = [], [], 0
+    if keys:
+        yield _mergeMasks(keys, masks, nc)
+
+
+def buildMasksForClusters(dm, Pnear):
+    """all cluster pairs in one group"""
+    out = list(iterMasksForClusters(dm, Pnear, maxNNZ=1 << 62))
+    if not out:
+        return np.zeros((0, 2), dtype=np.int32), np.zeros((0, 4), dtype=np.uint64)
+    return out[0]
+
+
+def boundaryFacetsOfCells(mesh, cellIds):
+    """facets (vertex ids, oriented as in their cell) that belong to exactly one cell of the set
+    (nonlocalAssembly.pyx:540-578 in 2D, :505-533 in 1D)"""
+    cells = mesh.cells[cellIds].astype(np.int64)
+    nv = mesh.num_vertices
+    if mesh.manifold_dim == 2:
+        e = np.stack([cells[:, [0, 1]], cells[:, [1, 2]], cells[:, [2, 0]]], axis=1).reshape(-1, 2)
+        keys = e.min(axis=1)*nv+e.max(axis=1)
+        uniq, first, counts = np.unique(keys, return_index=True, return_counts=True)
+        return e[np.sort(first[counts == 1])].astype(np.int32)
+    ids, counts = np.unique(cells.reshape(-1), return_counts=True)
+    return ids[counts == 1].astype(np.int32).reshape(-1, 1)
+
+
+def clusterBoundaryItems(dm, Pnear):
+    """work list of the cluster-local Gauss-theorem term (NA:1842-1889): for every near-field pair with common cells,
+    (cell in cellsInter) x (facet of the boundary of cellsUnion) with the mask of the local entries whose DoFs lie in
+    (n1, n2) -- getElemSymMaskCluster NA:463-478.  Returns cells[ni], facets[ni, dim], masks[ni] (uint32 bit field over
+    the dpe(dpe+1)/2 entries)."""
+    mesh = dm.mesh
+    dpe = dm.dofs_per_element
+    out_c, out_f, out_m = [], [], []
+    for cp in Pnear:
+        ci = cp.cellsInter
+        if ci.shape[0] == 0:
+            continue
+        facets = boundaryFacetsOfCells(mesh, cp.cellsUnion)
+        in1 = np.zeros(dm.num_dofs+1, dtype=bool)
+        in2 = np.zeros(dm.num_dofs+1, dtype=bool)
+        in1[cp.n1.dofs] = True
+        in2[cp.n2.dofs] = True
+        d = np.where(dm.dofs[ci] >= 0, dm.dofs[ci], dm.num_dofs)
+        m1, m2 = in1[d], in2[d]
+        mask = np.zeros(ci.shape[0], dtype=np.uint32)
+        k = 0
+        for p in range(dpe):
+            for q in range(p, dpe):
+                mask |= ((m1[:, p] & m2[:, q]).astype(np.uint32) << np.uint32(k))
+                k += 1
+        keep = mask != 0
+        ci, mask = ci[keep], mask[keep]
+        out_c.append(np.repeat(ci, facets.shape[0]))
+        out_f.append(np.tile(facets, (ci.shape[0], 1)))
+        out_m.append(np.repeat(mask, facets.shape[0]))
+    if not out_c:
+        return np.zeros(0, dtype=np.int32), np.zeros((0, mesh.dim), dtype=np.int32), np.zeros(0, dtype=np.uint32)
+    return (np.concatenate(out_c).astype(np.int32), np.ascontiguousarray(np.concatenate(out_f), dtype=np.int32),
+            np.concatenate(out_m).astype(np.uint32))
+
+
+def globalBoundaryItems(dm, bcells):
+    """every cell x every facet of the domain boundary with all entries requested (getElemSymMask NA:170-186): the
+    global Omega x Omega^c term of NA:1896-1913 / 1945-1964"""
+    nc, nb = dm.mesh.num_cells, bcells.shape[0]
+    dpe = dm.dofs_per_element
+    ok = dm.dofs >= 0
+    mask = np.zeros(nc, dtype=np.uint32)
+    k = 0
+    for p in range(dpe):
+        for q in range(p, dpe):
+            mask |= (ok[:, p] & ok[:, q]).astype(np.uint32) << np.uint32(k)
+            k += 1
+    keep = np.nonzero(mask)[0].astype(np.int32)
+    cells = np.repeat(keep, nb)
+    facets = np.tile(np.ascontiguousarray(bcells, dtype=np.int32), (keep.shape[0], 1))
+    return cells, facets, np.repeat(mask[keep], nb)
+
+
+def allLeafPairs(dm, maxLevels, minSize=1):
+    """every (leaf, leaf) pair of a tree refined maxLevels times: cluster pairs covering all matrix blocks, the set-up of
+    the reference's dense-vs-cluster test (tests/test_nearField.py:131-163)"""
+    root = getTree(dm)
+    for _ in range(maxLevels):
+        for n in list(root.leaves()):
+            n.refine(minSize, maxLevels+1)
+    leaves = list(root.leaves())
+    Pnear = [nearFieldClusterPair(c, d) for c in leaves for d in leaves]
+    for cp in Pnear:
+        cp.set_cells()
+    return root, Pnear

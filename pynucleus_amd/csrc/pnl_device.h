@@ -59,5 +59,6 @@ struct DevProblem {
     // boundary facets
     const int *bvid;            // [dim][nb]
     const double *bv;           // [dim*dim][nb] facet vertex coordinates
+    const double *bgeo;         // [2 dim + 3][nb]: centre, unit normal (2D), length, |ln(len/H0)|, ln(len)
     unsigned long long *counters;
 };

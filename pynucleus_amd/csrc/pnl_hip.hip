@@ -46,8 +46,11 @@ struct pnl_context {
     // device
     DevProblem P;
     DevBuf b_cellv, b_ccen, b_cvol, b_ch, b_cvid, b_cdof, b_cslot, b_blk_ndof, b_blk_dofs, b_perm, b_off, b_bary, b_w, b_phi,
-        b_foff, b_fbary, b_fw, b_sn[3], b_sw[3], b_sp[3], b_bn[2], b_bw[2], b_bp[2], b_bvid, b_bv, b_counters, b_D, b_tiles,
-        b_spairs[3], b_bpairs[2], b_vec[6], b_scal, b_wl, b_wlcount, b_ttn, b_ttoff, b_tttab, b_wlsorted, b_wlaux;
+        b_foff, b_fbary, b_fw, b_sn[3], b_sw[3], b_sp[3], b_bn[2], b_bw[2], b_bp[2], b_bvid, b_bv, b_bgeo, b_counters, b_D, b_tiles,
+        b_spairs[3], b_bpairs[2], b_vec[6], b_scal, b_wl, b_wlcount, b_ttn, b_ttoff, b_tttab, b_wlsorted, b_wlaux,
+        b_vertices, b_sp_indptr, b_sp_indices, b_mp_pairs, b_mp_masks, b_mp_wl, b_mp_sorted, b_mp_aux, b_bi_cells, b_bi_facets,
+        b_bi_masks;
+    int sp_nnz = -1;                // near-field sparsity pattern (pnl_upload_sparsity)
     unsigned wl_cap = 0;
     int tile = TILE_P1, nblocks = 0, ncp = 0, nU = 0;
     int n_spairs[3] = {0, 0, 0}, n_bpairs[2] = {0, 0};
@@ -260,7 +263,33 @@ int finalize(pnl_context *ctx) {
         }
         if ((rc = upload(ctx, ctx->b_bvid, bvid.data(), bvid.size()))) return rc;
         if ((rc = upload(ctx, ctx->b_bv, bv.data(), bv.size()))) return rc;
+        {
+            // per-facet geometry used by every (cell, facet) pair: NO:1049-1055 normal, get_h_surface_simplex
+            std::vector<double> geo((size_t)(2*dim+3)*nb, 0.);
+            for (int f = 0; f < nb; f++) {
+                double len = 1.;
+                for (int d = 0; d < dim; d++) {
+                    double sum = 0.;
+                    for (int k = 0; k < nF; k++) sum += bv[(size_t)(k*dim+d)*nb+f];
+                    geo[(size_t)d*nb+f] = sum*(1./nF);
+                }
+                if (dim == 2) {
+                    double n0 = bv[(size_t)(1*dim+1)*nb+f]-bv[(size_t)(0*dim+1)*nb+f];
+                    double n1 = bv[(size_t)(0*dim+0)*nb+f]-bv[(size_t)(1*dim+0)*nb+f];
+                    const double inv = 1./std::sqrt(n0*n0+n1*n1);
+                    geo[(size_t)(dim+0)*nb+f] = n0*inv;
+                    geo[(size_t)(dim+1)*nb+f] = n1*inv;
+                    const double dx = bv[(size_t)2*nb+f]-bv[(size_t)0*nb+f], dy = bv[(size_t)3*nb+f]-bv[(size_t)1*nb+f];
+                    len = std::sqrt(dx*dx+dy*dy);
+                }
+                geo[(size_t)(2*dim)*nb+f] = len;
+                geo[(size_t)(2*dim+1)*nb+f] = std::fabs(std::log(len/ctx->H0));
+                geo[(size_t)(2*dim+2)*nb+f] = std::log(len);
+            }
+            if ((rc = upload(ctx, ctx->b_bgeo, geo.data(), geo.size()))) return rc;
+        }
     }
+    if ((rc = upload(ctx, ctx->b_vertices, ctx->vertices.data(), ctx->vertices.size()))) return rc;
     if ((rc = upload(ctx, ctx->b_cellv, cellv.data(), cellv.size()))) return rc;
     if ((rc = upload(ctx, ctx->b_ccen, ccen.data(), ccen.size()))) return rc;
     if ((rc = upload(ctx, ctx->b_cvol, cvol.data(), cvol.size()))) return rc;
@@ -283,7 +312,7 @@ int finalize(pnl_context *ctx) {
     P.blk_ndof = (const int*)ctx->b_blk_ndof.p; P.blk_dofs = (const int*)ctx->b_blk_dofs.p;
     P.blk_stride = nU; P.nblocks = nblocks;
     P.perm_table = (const int*)ctx->b_perm.p;
-    P.bvid = (const int*)ctx->b_bvid.p; P.bv = (const double*)ctx->b_bv.p;
+    P.bvid = (const int*)ctx->b_bvid.p; P.bv = (const double*)ctx->b_bv.p; P.bgeo = (const double*)ctx->b_bgeo.p;
     P.counters = (unsigned long long*)ctx->b_counters.p;
     ctx->dirty = false;
     return PNL_OK;
@@ -369,10 +398,11 @@ int launch_tiles(pnl_context *ctx, int ntiles, double *A, int64_t ldA, int cell_
         const int st = 4+DPE;
         const int tab_max = (60*1024)/(st*(int)sizeof(double));
         const size_t lds = (size_t)tab_max*st*sizeof(double);
-        auto wfun = k_worklist_sorted<DIM, DPE, KT>;
+        auto wfun = k_worklist_sorted<DIM, DPE, KT, false>;
         HIPCHK(ctx, hipFuncSetAttribute((const void*)wfun, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(wfun, dim3(256*2), dim3(PNL_NTHREADS), lds, ctx->stream, ctx->P, (const int4*)ctx->b_wlsorted.p,
-                           (const unsigned*)offs, (const unsigned*)coff, A, (long long)ldA, (double*)ctx->b_D.p, tab_max);
+                           (const unsigned*)offs, (const unsigned*)coff, A, (long long)ldA, (double*)ctx->b_D.p, tab_max,
+                           SparseOut{}, PNL_WL_BINS-1);
         HIPCHK(ctx, hipGetLastError());
     }
     return PNL_OK;
@@ -386,16 +416,17 @@ int launch_singular_slot(pnl_context *ctx, int np, double *A, int64_t ldA, int c
     const size_t lds = sizeof(double)*(size_t)(2*NV+1+rows)*M;
     const int waves_per_block = PNL_SING_THREADS/64;
     if (lds <= 150*1024) {
-        auto kfun = k_singular_pairs<DIM, DPE, SLOT, KT, true>;
+        auto kfun = k_singular_pairs<DIM, DPE, SLOT, KT, true, false>;
         HIPCHK(ctx, hipFuncSetAttribute((const void*)kfun, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         const int per_cu = std::max(1, (int)((160*1024)/std::max<size_t>(lds, 1)));
         const int grid = std::min((np+waves_per_block-1)/waves_per_block, 256*std::min(per_cu, 4));
         hipLaunchKernelGGL(kfun, dim3(grid), dim3(PNL_SING_THREADS), lds, ctx->stream, ctx->P, pairs, np, A, (long long)ldA,
-                           cell_begin, cell_end);
+                           cell_begin, cell_end, SparseOut{}, (const int4*)nullptr, (const unsigned*)nullptr);
     } else {
         const int grid = std::min((np+waves_per_block-1)/waves_per_block, 256*4);
-        hipLaunchKernelGGL((k_singular_pairs<DIM, DPE, SLOT, KT, false>), dim3(grid), dim3(PNL_SING_THREADS), 0, ctx->stream,
-                           ctx->P, pairs, np, A, (long long)ldA, cell_begin, cell_end);
+        hipLaunchKernelGGL((k_singular_pairs<DIM, DPE, SLOT, KT, false, false>), dim3(grid), dim3(PNL_SING_THREADS), 0, ctx->stream,
+                           ctx->P, pairs, np, A, (long long)ldA, cell_begin, cell_end, SparseOut{}, (const int4*)nullptr,
+                           (const unsigned*)nullptr);
     }
     HIPCHK(ctx, hipGetLastError());
     return PNL_OK;
@@ -422,7 +453,7 @@ int launch_boundary(pnl_context *ctx, int cell_begin, int cell_end) {
     const int ncell = cell_end-cell_begin;
     const int gx = (ncell+PNL_NTHREADS-1)/PNL_NTHREADS;
     // small facet chunks: many waves in flight hide the latency of the per-facet dependent chain
-    const int per = getenv("PNL_BND_PER") ? atoi(getenv("PNL_BND_PER")) : 8;
+    const int per = getenv("PNL_BND_PER") ? atoi(getenv("PNL_BND_PER")) : 16;
     const int chunks = (ctx->nb+per-1)/per;
     if (ctx->P.bkn.fast)
         hipLaunchKernelGGL((k_boundary_distant<DIM, DPE, 1>), dim3(gx, chunks), dim3(PNL_NTHREADS), 0, ctx->stream, ctx->P,
@@ -487,6 +518,95 @@ int assemble_impl(pnl_context *ctx, double *A, int64_t ldA, int zero_exterior, i
     }
     HIPCHK(ctx, hipEventRecord(ctx->ev[5], ctx->stream));
     ctx->ev_valid = true;
+    return PNL_OK;
+}
+
+// ---- masked pair assembly into CSR / SSS (assembleClusters) --------------------------------------------------------
+template <int DIM, int DPE, int SLOT, int KT>
+int launch_singular_sparse(pnl_context *ctx, const SparseOut &S, const int4 *sorted, const unsigned *offs) {
+    constexpr int NV = DIM+1;
+    if (!ctx->have_sing[0][SLOT]) return PNL_OK;     // checked against the histogram by the caller
+    const int M = ctx->P.sM[SLOT], rows = ctx->P.sRows[SLOT];
+    const size_t lds = sizeof(double)*(size_t)(2*NV+1+rows)*M;
+    if (lds <= 150*1024) {
+        auto kfun = k_singular_pairs<DIM, DPE, SLOT, KT, true, true>;
+        HIPCHK(ctx, hipFuncSetAttribute((const void*)kfun, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        const int per_cu = std::max(1, (int)((160*1024)/std::max<size_t>(lds, 1)));
+        hipLaunchKernelGGL(kfun, dim3(256*std::min(per_cu, 4)), dim3(PNL_SING_THREADS), lds, ctx->stream, ctx->P, (const int2*)nullptr, 0,
+                           (double*)nullptr, 0ll, 0, 0, S, sorted, offs);
+    } else {
+        hipLaunchKernelGGL((k_singular_pairs<DIM, DPE, SLOT, KT, false, true>), dim3(256*4), dim3(PNL_SING_THREADS), 0, ctx->stream,
+                           ctx->P, (const int2*)nullptr, 0, (double*)nullptr, 0ll, 0, 0, S, sorted, offs);
+    }
+    HIPCHK(ctx, hipGetLastError());
+    return PNL_OK;
+}
+
+template <int DIM, int DPE, int KT>
+int pairs_masked_impl(pnl_context *ctx, int np, const SparseOut &S) {
+    int rc;
+    if ((rc = ensure(ctx, ctx->b_mp_wl, (size_t)np*sizeof(int4)))) return rc;
+    if ((rc = ensure(ctx, ctx->b_mp_sorted, (size_t)np*sizeof(int4)))) return rc;
+    if ((rc = ensure(ctx, ctx->b_mp_aux, sizeof(unsigned)*(4*(PNL_WL_BINS+1)+1)))) return rc;
+    unsigned *hist = (unsigned*)ctx->b_mp_aux.p, *offs = hist+(PNL_WL_BINS+1), *coff = offs+(PNL_WL_BINS+1), *cursor = coff+(PNL_WL_BINS+1),
+             *count = cursor+(PNL_WL_BINS+1);
+    int4 *wl = (int4*)ctx->b_mp_wl.p, *sorted = (int4*)ctx->b_mp_sorted.p;
+    const unsigned unp = (unsigned)np;
+    HIPCHK(ctx, hipMemsetAsync(hist, 0, sizeof(unsigned)*(PNL_WL_BINS+1), ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(count, &unp, sizeof(unsigned), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));          // unp lives on this stack frame
+    HIPCHK(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
+    hipLaunchKernelGGL((k_mp_classify<DIM, DPE>), dim3((np+PNL_NTHREADS-1)/PNL_NTHREADS), dim3(PNL_NTHREADS), 0, ctx->stream, ctx->P,
+                       S.pairs, np, wl);
+    hipLaunchKernelGGL(k_wl_hist, dim3(512), dim3(PNL_NTHREADS), 0, ctx->stream, (const int4*)wl, (const unsigned*)count, unp, hist);
+    hipLaunchKernelGGL(k_wl_scan, dim3(1), dim3(64), 0, ctx->stream, (const unsigned*)hist, offs, coff, cursor);
+    hipLaunchKernelGGL(k_wl_scatter, dim3(512), dim3(PNL_NTHREADS), 0, ctx->stream, (const int4*)wl, (const unsigned*)count, unp,
+                       (const unsigned*)offs, cursor, sorted);
+    hipLaunchKernelGGL(k_mp_stats, dim3(1), dim3(PNL_WL_BINS), 0, ctx->stream, ctx->P, (const unsigned*)hist);
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipEventRecord(ctx->ev[6], ctx->stream));
+    {
+        const int st = 4+DPE;
+        const int tab_max = (60*1024)/(st*(int)sizeof(double));
+        const size_t lds = (size_t)tab_max*st*sizeof(double);
+        auto wfun = k_worklist_sorted<DIM, DPE, KT, true>;
+        HIPCHK(ctx, hipFuncSetAttribute((const void*)wfun, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(wfun, dim3(256*2), dim3(PNL_NTHREADS), lds, ctx->stream, ctx->P, (const int4*)sorted, (const unsigned*)offs,
+                           (const unsigned*)coff, (double*)nullptr, 0ll, (double*)nullptr, tab_max, S, PNL_MAXQ);
+        HIPCHK(ctx, hipGetLastError());
+    }
+    HIPCHK(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
+    HIPCHK(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
+    // touching pairs: bins 121 (common vertex), 122 (common edge / identical in 1D), 123 (identical in 2D)
+    unsigned hh[PNL_WL_BINS+1];
+    HIPCHK(ctx, hipMemcpyAsync(hh, hist, sizeof(hh), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    for (int s = 0; s < DIM+1; s++)
+        if (hh[121+s] && !ctx->have_sing[0][s]) return fail(ctx, PNL_ERR_STATE, "singular rule for %d common vertices not uploaded", s+1);
+    if (hh[121] && (rc = launch_singular_sparse<DIM, DPE, 0, KT>(ctx, S, sorted, offs))) return rc;
+    if (hh[122] && (rc = launch_singular_sparse<DIM, DPE, 1, KT>(ctx, S, sorted, offs))) return rc;
+    if (DIM == 2 && hh[123] && (rc = launch_singular_sparse<DIM, DPE, (DIM == 2 ? 2 : 1), KT>(ctx, S, sorted, offs))) return rc;
+    HIPCHK(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
+    HIPCHK(ctx, hipEventRecord(ctx->ev[4], ctx->stream));
+    HIPCHK(ctx, hipEventRecord(ctx->ev[5], ctx->stream));
+    ctx->ev_valid = true;
+    ctx->tiles_launched = true;
+    return PNL_OK;
+}
+
+template <int DIM, int DPE>
+int boundary_masked_impl(pnl_context *ctx, int ni, double fac, const SparseOut &S) {
+    const int grid = std::min((ni+3)/4, 256*8);
+    const int *cells = (const int*)ctx->b_bi_cells.p, *facets = (const int*)ctx->b_bi_facets.p;
+    const unsigned *masks = (const unsigned*)ctx->b_bi_masks.p;
+    const double *verts = (const double*)ctx->b_vertices.p;
+    if (ctx->P.bkn.fast)
+        hipLaunchKernelGGL((k_boundary_items<DIM, DPE, 1>), dim3(grid), dim3(PNL_NTHREADS), 0, ctx->stream, ctx->P, verts, cells, facets,
+                           masks, ni, fac, S);
+    else
+        hipLaunchKernelGGL((k_boundary_items<DIM, DPE, 0>), dim3(grid), dim3(PNL_NTHREADS), 0, ctx->stream, ctx->P, verts, cells, facets,
+                           masks, ni, fac, S);
+    HIPCHK(ctx, hipGetLastError());
     return PNL_OK;
 }
 
@@ -834,6 +954,96 @@ int pnl_assemble_dense_tiles(pnl_context *ctx, double *A, int64_t ldA, int zero_
     rc = dispatch(ctx, A, ldA, zero_exterior, ntiles, cell_begin, cell_end, flags);
     ctx->tile_cell_filter = true;
     return rc;
+}
+
+int pnl_upload_sparsity(pnl_context *ctx, int nnz, const int32_t *indptr, const int32_t *indices) {
+    if (!ctx) return PNL_ERR_INVALID;
+    if (!ctx->have_dofs) return fail(ctx, PNL_ERR_STATE, "upload the DoF map first");
+    if (nnz < 0 || !indptr || (nnz && !indices) || indptr[0] != 0 || indptr[ctx->N] != nnz)
+        return fail(ctx, PNL_ERR_INVALID, "bad sparsity pattern (nnz=%d)", nnz);
+    for (int i = 0; i < ctx->N; i++) {
+        if (indptr[i+1] < indptr[i]) return fail(ctx, PNL_ERR_INVALID, "indptr is not monotone at row %d", i);
+        for (int t = indptr[i]; t < indptr[i+1]; t++)
+            if (indices[t] < 0 || indices[t] >= ctx->N || (t > indptr[i] && indices[t] <= indices[t-1]))
+                return fail(ctx, PNL_ERR_INVALID, "row %d of the pattern is not sorted / in range", i);
+    }
+    int rc;
+    if ((rc = upload(ctx, ctx->b_sp_indptr, indptr, (size_t)ctx->N+1))) return rc;
+    if ((rc = upload(ctx, ctx->b_sp_indices, indices, (size_t)nnz))) return rc;
+    ctx->sp_nnz = nnz;
+    return PNL_OK;
+}
+
+static int sparse_ready(pnl_context *ctx, double *data, double *diag, SparseOut &S) {
+    int rc;
+    if ((rc = check_ready(ctx))) return rc;
+    if ((rc = finalize(ctx))) return rc;
+    if (ctx->sp_nnz < 0) return fail(ctx, PNL_ERR_STATE, "upload the sparsity pattern first");
+    if (!data && ctx->sp_nnz > 0) return fail(ctx, PNL_ERR_INVALID, "null output");
+    refresh_tables(ctx);
+    S.indptr = (const int*)ctx->b_sp_indptr.p; S.indices = (const int*)ctx->b_sp_indices.p;
+    S.data = data; S.diag = diag;
+    S.pairs = (const int*)ctx->b_mp_pairs.p; S.masks = (const unsigned long long*)ctx->b_mp_masks.p;
+    return PNL_OK;
+}
+
+int pnl_assemble_pairs_masked(pnl_context *ctx, int np, const int32_t *pairs, const uint64_t *masks, double *data, double *diag) {
+    if (!ctx) return PNL_ERR_INVALID;
+    if (np < 0 || (np && (!pairs || !masks))) return fail(ctx, PNL_ERR_INVALID, "bad pair list");
+    for (int i = 0; i < np; i++)
+        if (pairs[2*i] < 0 || pairs[2*i] > pairs[2*i+1] || pairs[2*i+1] >= ctx->nc)
+            return fail(ctx, PNL_ERR_INVALID, "pair %d = (%d, %d) is not an ordered pair of cells", i, pairs[2*i], pairs[2*i+1]);
+    int rc;
+    if ((rc = upload(ctx, ctx->b_mp_pairs, pairs, (size_t)2*np))) return rc;
+    if ((rc = upload(ctx, ctx->b_mp_masks, masks, (size_t)4*np))) return rc;
+    SparseOut S;
+    if ((rc = sparse_ready(ctx, data, diag, S))) return rc;
+    HIPCHK(ctx, hipMemsetAsync(ctx->b_counters.p, 0, sizeof(unsigned long long)*PNL_NCOUNTERS, ctx->stream));
+    ctx->visited_pairs = (unsigned long long)np;
+    if (np == 0) return PNL_OK;
+    const int kt = ctx->P.k.fast ? 1 : 0;
+    if (ctx->dim == 2 && ctx->dpe == 3) return kt ? pairs_masked_impl<2, 3, 1>(ctx, np, S) : pairs_masked_impl<2, 3, 0>(ctx, np, S);
+    if (ctx->dim == 2 && ctx->dpe == 6) return kt ? pairs_masked_impl<2, 6, 1>(ctx, np, S) : pairs_masked_impl<2, 6, 0>(ctx, np, S);
+    if (ctx->dim == 1 && ctx->dpe == 2) return pairs_masked_impl<1, 2, 0>(ctx, np, S);
+    return fail(ctx, PNL_ERR_UNSUPPORTED, "unsupported (dim=%d, dofs_per_element=%d)", ctx->dim, ctx->dpe);
+}
+
+int pnl_assemble_boundary_masked(pnl_context *ctx, int ni, const int32_t *cells, const int32_t *facets, const uint32_t *masks,
+                                 double fac, double *data, double *diag) {
+    if (!ctx) return PNL_ERR_INVALID;
+    if (ni < 0 || (ni && (!cells || !facets || !masks))) return fail(ctx, PNL_ERR_INVALID, "bad item list");
+    if (!ctx->have_kernel[1] || !ctx->have_form[1]) return fail(ctx, PNL_ERR_STATE, "boundary kernel and order formula must be set");
+    for (int i = 0; i < ni; i++) {
+        if (cells[i] < 0 || cells[i] >= ctx->nc) return fail(ctx, PNL_ERR_INVALID, "item %d: bad cell %d", i, cells[i]);
+        for (int k = 0; k < ctx->dim; k++)
+            if (facets[(size_t)i*ctx->dim+k] < 0 || facets[(size_t)i*ctx->dim+k] >= ctx->nv)
+                return fail(ctx, PNL_ERR_INVALID, "item %d: bad facet vertex", i);
+    }
+    for (int s = 0; s < ctx->dim; s++)
+        if (!ctx->have_sing[1][s]) return fail(ctx, PNL_ERR_STATE, "boundary singular rule for %d common vertices not uploaded", s+1);
+    int rc;
+    if ((rc = upload(ctx, ctx->b_bi_cells, cells, (size_t)ni))) return rc;
+    if ((rc = upload(ctx, ctx->b_bi_facets, facets, (size_t)ni*ctx->dim))) return rc;
+    if ((rc = upload(ctx, ctx->b_bi_masks, masks, (size_t)ni))) return rc;
+    SparseOut S;
+    if ((rc = sparse_ready(ctx, data, diag, S))) return rc;
+    if (ni == 0) return PNL_OK;
+    if (ctx->dim == 2 && ctx->dpe == 3) return boundary_masked_impl<2, 3>(ctx, ni, fac, S);
+    if (ctx->dim == 2 && ctx->dpe == 6) return boundary_masked_impl<2, 6>(ctx, ni, fac, S);
+    if (ctx->dim == 1 && ctx->dpe == 2) return boundary_masked_impl<1, 2>(ctx, ni, fac, S);
+    return fail(ctx, PNL_ERR_UNSUPPORTED, "unsupported (dim=%d, dofs_per_element=%d)", ctx->dim, ctx->dpe);
+}
+
+int pnl_spmv(pnl_context *ctx, const double *data, const double *diag, const double *x, double *y) {
+    if (!ctx || !x || !y) return PNL_ERR_INVALID;
+    if (ctx->sp_nnz < 0) return fail(ctx, PNL_ERR_STATE, "upload the sparsity pattern first");
+    if (!data && ctx->sp_nnz > 0) return fail(ctx, PNL_ERR_INVALID, "null matrix data");
+    const int n = ctx->N;
+    if (diag) HIPCHK(ctx, hipMemsetAsync(y, 0, sizeof(double)*n, ctx->stream));
+    hipLaunchKernelGGL(k_spmv, dim3((n+3)/4), dim3(PNL_NTHREADS), 0, ctx->stream, (const int*)ctx->b_sp_indptr.p,
+                       (const int*)ctx->b_sp_indices.p, data, diag, n, x, y);
+    HIPCHK(ctx, hipGetLastError());
+    return PNL_OK;
 }
 
 int pnl_inv_diagonal(pnl_context *ctx, const double *A, int64_t ldA, int n, double *dinv) {

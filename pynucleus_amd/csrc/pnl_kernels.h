@@ -615,6 +615,77 @@ __device__ __forceinline__ double row16_sum(double v) {
     return v;
 }
 
+// ---- sparse output (H2 near field, NA:1663-1964) -------------------------------------------------------------------
+// CSR or SSS target with the reference's addToEntry semantics (CSR_LinearOperator_{SCALAR}.pxi:150-170,
+// SSS_LinearOperator_{SCALAR}.pxi:104-130): binary search in the row, entries that are not in the pattern are dropped;
+// SSS (diag != nullptr) keeps I > J in data and the diagonal in its own vector.
+struct SparseOut {
+    const int *indptr, *indices;
+    double *data, *diag;
+    const int *pairs;                    // [np][2] cell pairs, c1 <= c2
+    const unsigned long long *masks;     // [np][4] requested entries of the symmetric local matrix (256-bit MASK_t)
+};
+
+__device__ __forceinline__ void sparse_add(const SparseOut &S, int I, int J, double v) {
+    if (I < 0 || J < 0) return;
+    if (S.diag) {
+        if (I == J) { atomic_add_f64(&S.diag[I], v); return; }
+        if (I < J) return;
+    }
+    int lo = S.indptr[I];
+    const int end = S.indptr[I+1];
+    int hi = end;
+    while (lo < hi) {
+        const int mid = (lo+hi) >> 1;
+        if (S.indices[mid] < J) lo = mid+1; else hi = mid;
+    }
+    if (lo < end && S.indices[lo] == J) atomic_add_f64(&S.data[lo], v);
+}
+
+// NA:503-520 addToMatrixElemElemSymMasked for one entry (p <= q) of the local matrix over 2*dpe local DoFs
+__device__ __forceinline__ void sparse_add_sym(const SparseOut &S, const unsigned long long *mask, int n2, int p, int q, int I, int J,
+                                               double v) {
+    const int k = n2*p-((p*(p-1)) >> 1)+(q-p);
+    if (!((mask[k >> 6] >> (k & 63)) & 1ull)) return;
+    if (p == q) sparse_add(S, I, I, v);
+    else { sparse_add(S, I, J, v); sparse_add(S, J, I, v); }
+}
+
+// classification of explicit cell pairs (NO:280-378 + NO:493-540 with the exact fp64 order formula); entry =
+// (pair index, 0, rule offset, n | key << 16), key = order for distant pairs, 121 + (#shared vertices - 1) for touching ones
+template <int DIM, int DPE>
+__global__ void __launch_bounds__(PNL_NTHREADS)
+k_mp_classify(const DevProblem P, const int *__restrict__ pairs, int npairs, int4 *__restrict__ out) {
+    constexpr int NV = DIM+1;
+    const int t = blockIdx.x*PNL_NTHREADS+threadIdx.x;
+    if (t >= npairs) return;
+    const int c1 = pairs[2*t], c2 = pairs[2*t+1];
+    bool any = false;
+#pragma unroll
+    for (int k = 0; k < DPE; k++) any = any || P.cdof[(size_t)k*P.ncp+c1] >= 0 || P.cdof[(size_t)k*P.ncp+c2] >= 0;
+    int key = 0, off = 0, n = 0;
+    if (any) {
+        int common = 0;
+        if (c1 == c2) common = NV;
+        else {
+#pragma unroll
+            for (int a = 0; a < NV; a++)
+#pragma unroll
+                for (int b = 0; b < NV; b++) common += (P.cvid[(size_t)a*P.ncp+c1] == P.cvid[(size_t)b*P.ncp+c2]);
+        }
+        if (common > 0) key = 121+common-1;
+        else {
+            double d2 = 0.;
+#pragma unroll
+            for (int d = 0; d < DIM; d++) { const double u = P.ccen[(size_t)d*P.ncp+c1]-P.ccen[(size_t)d*P.ncp+c2]; d2 += u*u; }
+            const int q = quad_order(P.qo, P.H0, P.ch[c1], P.ch[c2], sqrt(d2));
+            if (q > P.qmax || q > PNL_MAXQ) atomicAdd(&P.counters[5], 1ull);
+            else { key = q; off = P.off[q]; n = P.off[q+1]-off; }
+        }
+    }
+    out[t] = make_int4(t, 0, off, n | (key << 16));
+}
+
 // ---- work list of the orders the tile kernel does not unroll -------------------------------------------------------
 // entry = (c1, c2, rule offset, n | order << 16).  The list is counting-sorted by order so that a workgroup integrates
 // pairs of ONE order at a time: the rule is staged in LDS once and all 16 pairs of a chunk run the same trip count.
@@ -670,20 +741,22 @@ k_wl_scatter(const int4 *__restrict__ wl, const unsigned *__restrict__ wl_count,
 // Distant pairs from the sorted work list (NO:722-789): a workgroup takes chunks of 16 pairs of one order, one DPP row
 // (16 lanes) per pair, lanes over the n*n point pairs of the tensor rule read from the LDS copy of the rule, row-wise
 // DPP reduction of the local matrix, atomic scatter.  A' receives the cross block on the (c1-DoF, c2-DoF) side only.
-template <int DIM, int DPE, int KT>
+template <int DIM, int DPE, int KT, bool SPARSE>
 __global__ void __launch_bounds__(PNL_NTHREADS)
 k_worklist_sorted(const DevProblem P, const int4 *__restrict__ sorted, const unsigned *__restrict__ offs,
                   const unsigned *__restrict__ chunk_off, double *__restrict__ A, long long ldA, double *__restrict__ Dglob,
-                  int tab_max_pts) {
+                  int tab_max_pts, const SparseOut S, int qlast) {
     constexpr int NV = DIM+1, NC = NV*DIM, ND = DPE*(DPE+1)/2, NG = DPE*DPE, NACC = NG+2*ND, NREP = (NACC+15)/16, ST = 4+DPE;
     extern __shared__ double s_rule[];           // [tab_max_pts][ST]: bary[3], w, phi[DPE]
     __shared__ unsigned s_coff[PNL_WL_BINS+1];
     const int tid = threadIdx.x, sub = tid & 15, g = tid >> 4;
     for (int t = tid; t <= PNL_WL_BINS; t += PNL_NTHREADS) s_coff[t] = chunk_off[t];
     __syncthreads();
-    const unsigned nchunks = s_coff[PNL_WL_BINS];
+    // only the chunks of the orders 0..qlast (the sparse path keeps the touching pairs in the bins above)
+    const unsigned nchunks = s_coff[qlast+1];
     int staged_q = -1;
-    for (unsigned chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+    // bins 0 and 1 hold no distant pair (orders start at 2; the sparse path parks skipped pairs in bin 0)
+    for (unsigned chunk = s_coff[2]+blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
         // order of this chunk: last q with chunk_off[q] <= chunk
         int lo = 0, hi = PNL_WL_BINS-1;
         while (lo < hi) {
@@ -708,7 +781,7 @@ k_worklist_sorted(const DevProblem P, const int4 *__restrict__ sorted, const uns
         }
         const bool valid = g < cnt;
         const int4 ent = valid ? sorted[first+g] : e0;
-        const int c1 = ent.x, c2 = ent.y;
+        const int c1 = SPARSE ? S.pairs[2*ent.x] : ent.x, c2 = SPARSE ? S.pairs[2*ent.x+1] : ent.y;
         double av[NC], bv[NC];
 #pragma unroll
         for (int k = 0; k < NC; k++) { av[k] = P.cellv[(size_t)k*P.ncp+c1]; bv[k] = P.cellv[(size_t)k*P.ncp+c2]; }
@@ -765,7 +838,27 @@ k_worklist_sorted(const DevProblem P, const int4 *__restrict__ sorted, const uns
             const double s = row16_sum(acc[e]);
             mine[e/16] = (sub == (e & 15)) ? s : mine[e/16];
         }
-        if (valid) {
+        if (valid && SPARSE) {
+            const double vv = 2.*P.cvol[c1]*P.cvol[c2]*kern_scale<KT>(P.k);
+            const unsigned long long *mask = S.masks+4*(size_t)ent.x;
+#pragma unroll
+            for (int rep = 0; rep < NREP; rep++) {
+                const int e = sub+16*rep;
+                const double val = mine[rep];
+                if (e < NG) {
+                    const int a = e/DPE, b = e-a*DPE;
+                    sparse_add_sym(S, mask, 2*DPE, a, DPE+b, P.cdof[(size_t)a*P.ncp+c1], P.cdof[(size_t)b*P.ncp+c2], -vv*val);
+                } else if (e < NACC) {
+                    // upper triangle of a diagonal block: entry index -> (a, b), a <= b
+                    const bool second = e >= NG+ND;
+                    int idx = e-NG-(second ? ND : 0), a = 0;
+                    while (idx >= DPE-a) { idx -= DPE-a; a++; }
+                    const int b = a+idx, cc = second ? c2 : c1, sh = second ? DPE : 0;
+                    sparse_add_sym(S, mask, 2*DPE, sh+a, sh+b, P.cdof[(size_t)a*P.ncp+cc], P.cdof[(size_t)b*P.ncp+cc], vv*val);
+                }
+            }
+        }
+        if (valid && !SPARSE) {
             const double vv = 2.*P.cvol[c1]*P.cvol[c2]*kern_scale<KT>(P.k);
 #pragma unroll
             for (int rep = 0; rep < NREP; rep++) {
@@ -799,10 +892,11 @@ __device__ __forceinline__ int perm_rank(const int *perm, int n) {
 // STAGE: the rule tables (nodes, weights, PSI) are copied into LDS once per workgroup and shared by all of its
 // waves over a grid-stride loop of pairs; otherwise (tables too large for LDS) they are read from L2.
 #define PNL_SING_THREADS 512
-template <int DIM, int DPE, int SLOT, int KT, bool STAGE>
+template <int DIM, int DPE, int SLOT, int KT, bool STAGE, bool SPARSE>
 __global__ void __launch_bounds__(PNL_SING_THREADS)
-k_singular_pairs(const DevProblem P, const int2 *__restrict__ pairs, int npairs, double *__restrict__ A, long long ldA,
-                 int cell_begin, int cell_end) {
+k_singular_pairs(const DevProblem P, const int2 *__restrict__ pairs, int npairs_in, double *__restrict__ A, long long ldA,
+                 int cell_begin, int cell_end, const SparseOut S, const int4 *__restrict__ sorted,
+                 const unsigned *__restrict__ offs) {
     constexpr int NV = DIM+1;
     constexpr int DPV = 1, DPED = (DIM == 2 && DPE == 6) ? 1 : 0;
     constexpr int COMMON = SLOT+1;
@@ -823,10 +917,18 @@ k_singular_pairs(const DevProblem P, const int2 *__restrict__ pairs, int npairs,
     }
     const int nwaves = gridDim.x*(PNL_SING_THREADS/64);
     unsigned long long done = 0;        // statistics are accumulated per wave: one atomic per wave, not per pair
+    // sparse path: the pairs are the segment of the sorted list with key 121 + SLOT
+    const int seg0 = SPARSE ? (int)offs[121+SLOT] : 0;
+    const int npairs = SPARSE ? (int)(offs[121+SLOT+1]-offs[121+SLOT]) : npairs_in;
     for (int wid = (blockIdx.x*PNL_SING_THREADS+threadIdx.x) >> 6; wid < npairs; wid += nwaves) {
-    const int2 pr = pairs[wid];
+    int pidx = 0;
+    int2 pr;
+    if (SPARSE) {
+        pidx = __builtin_amdgcn_readfirstlane(sorted[seg0+wid].x);
+        pr = make_int2(S.pairs[2*pidx], S.pairs[2*pidx+1]);
+    } else pr = pairs[wid];
     const int c1 = __builtin_amdgcn_readfirstlane(pr.x), c2 = __builtin_amdgcn_readfirstlane(pr.y);
-    if (c1 < cell_begin || c1 >= cell_end) continue;
+    if (!SPARSE && (c1 < cell_begin || c1 >= cell_end)) continue;
     // NA:138-150
     int ld[2*DPE];
     bool any = false;
@@ -949,7 +1051,15 @@ k_singular_pairs(const DevProblem P, const int2 *__restrict__ pairs, int npairs,
             gj = (myJ[rep] == k) ? g : gj;
         }
         const double v = mine[rep]*vol;
-        if (gi >= 0 && gj >= 0) {
+        if (SPARSE) {
+            // local indices of the merged rows (FL2:874-884): p = perm[I], q = perm[J], entry (min, max)
+            int pi = 0, pj = 0;
+#pragma unroll
+            for (int k = 0; k < 2*DPE; k++) { pi = (myI[rep] == k) ? perm[k] : pi; pj = (myJ[rep] == k) ? perm[k] : pj; }
+            const int lo = min(pi, pj), hi = max(pi, pj);
+            const int glo = (lo == pi) ? gi : gj, ghi = (lo == pi) ? gj : gi;
+            sparse_add_sym(S, S.masks+4*(size_t)pidx, 2*DPE, lo, hi, glo, ghi, v);
+        } else if (gi >= 0 && gj >= 0) {
             if (myI[rep] == myJ[rep]) atomic_add_f64(&A[(long long)gi*ldA+gi], v);
             else {
                 atomic_add_f64(&A[(long long)gi*ldA+gj], v);
@@ -997,30 +1107,17 @@ k_boundary_distant(const DevProblem P, double *__restrict__ Dglob, int cell_begi
     const int f0 = blockIdx.y*facets_per_chunk;
     const int f1 = min(P.nb, f0+facets_per_chunk);
     for (int f = f0; f < f1; f++) {
-        // facet data: wave-uniform
+        // facet data: wave-uniform, precomputed once per upload (centre, unit normal, length, logs)
         double fv[NF*DIM], fc[DIM], nrm[DIM];
         int fvid[NF];
 #pragma unroll
         for (int k = 0; k < NF; k++) fvid[k] = P.bvid[(size_t)k*P.nb+f];
 #pragma unroll
         for (int k = 0; k < NF*DIM; k++) fv[k] = P.bv[(size_t)k*P.nb+f];
-        double vol2 = 1.;
 #pragma unroll
-        for (int d = 0; d < DIM; d++) {
-            double s = 0.;
-#pragma unroll
-            for (int k = 0; k < NF; k++) s += fv[k*DIM+d];
-            fc[d] = s*(1./NF);
-            nrm[d] = 0.;
-        }
-        if (DIM == 2) {
-            nrm[0] = fv[1*DIM+1]-fv[0*DIM+1];
-            nrm[1] = fv[0*DIM+0]-fv[1*DIM+0];
-            const double l2 = nrm[0]*nrm[0]+nrm[1]*nrm[1];
-            const double inv = 1./sqrt(l2);
-            nrm[0] *= inv; nrm[1] *= inv;
-            vol2 = sqrt((fv[2]-fv[0])*(fv[2]-fv[0])+(fv[3]-fv[1])*(fv[3]-fv[1]));
-        }
+        for (int d = 0; d < DIM; d++) { fc[d] = P.bgeo[(size_t)d*P.nb+f]; nrm[d] = P.bgeo[(size_t)(DIM+d)*P.nb+f]; }
+        const double vol2 = P.bgeo[(size_t)(2*DIM)*P.nb+f], Ld2 = P.bgeo[(size_t)(2*DIM+1)*P.nb+f];
+        const float lh2 = (float)P.bgeo[(size_t)(2*DIM+2)*P.nb+f], L2 = (float)Ld2;
         bool shared = false;
 #pragma unroll
         for (int k = 0; k < NV; k++)
@@ -1030,8 +1127,6 @@ k_boundary_distant(const DevProblem P, double *__restrict__ Dglob, int cell_begi
         double dc2 = 0.;
 #pragma unroll
         for (int d = 0; d < DIM; d++) dc2 += (cen[d]-fc[d])*(cen[d]-fc[d]);
-        const double Ld2 = fabs(log(vol2/P.H0));
-        const float lh2 = (float)log(vol2), L2 = (float)Ld2;
         const int q = quad_order_fast(P.bqo, h1, vol2, lh1, lh2, L1, L2, Ld1, Ld2, dc2);
         if (q > P.qmax || q > PNL_MAXQ) { overflow++; continue; }
         const int off = P.off[q], n = P.off[q+1]-off;
@@ -1272,5 +1367,240 @@ k_mirror(double *__restrict__ A, long long ldA, int N) {
         }
         const int I2 = bj*32+r, J2 = bi*32+tx;
         if (bi != bj && I2 < N && J2 < N) A[(long long)I2*ldA+J2] = t2[r][tx]+t1[tx][r];
+    }
+}
+
+// ---- masked pair assembly (assembleClusters, NA:1663-1964): statistics of the sorted pair list ---------------------
+// hist[q] pairs of order q: numAssembledCellPairs, kernel evaluations n(q)^2 each and the order histogram (the touching
+// pairs in bins 121.. are counted by k_singular_pairs itself)
+__global__ void k_mp_stats(const DevProblem P, const unsigned *__restrict__ hist) {
+    const int q = threadIdx.x;
+    if (q < 2 || q > P.qmax || q > PNL_MAXQ) return;
+    const unsigned long long c = hist[q];
+    if (!c) return;
+    const unsigned long long n = (unsigned long long)(P.off[q+1]-P.off[q]);
+    atomicAdd(&P.counters[8+q], c);
+    atomicAdd(&P.counters[1], c);
+    atomicAdd(&P.counters[2], c*n*n);
+}
+
+// Gauss-theorem boundary term over explicit (cell, facet) items with entry masks: the cluster-local term
+// NA:1842-1889 (facets = boundary of cellsUnion) and the global Omega x Omega^c term with fac = +-1 (NA:1896-1913,
+// 1945-1964).  Panel by shared vertices (NO:280-378), distant evaluation NO:1022-1108, touching FL2:1324-1407 /
+// FL1:726-785, scatter NA:534-546 addToMatrixElemSymMasked.  One wave per item, lanes over the quadrature points.
+template <int DIM, int DPE, int KT>
+__global__ void __launch_bounds__(PNL_NTHREADS)
+k_boundary_items(const DevProblem P, const double *__restrict__ verts, const int *__restrict__ cells,
+                 const int *__restrict__ facets, const unsigned *__restrict__ masks, int ni, double fac, const SparseOut S) {
+    constexpr int NV = DIM+1, NF = DIM, ND = DPE*(DPE+1)/2;
+    const int lane = threadIdx.x & 63;
+    const int nwaves = gridDim.x*(PNL_NTHREADS/64);
+    unsigned long long npairs = 0, nevals = 0;
+    for (int wid = (blockIdx.x*PNL_NTHREADS+threadIdx.x) >> 6; wid < ni; wid += nwaves) {
+        const int c1 = __builtin_amdgcn_readfirstlane(cells[wid]);
+        const unsigned mask = (unsigned)__builtin_amdgcn_readfirstlane((int)masks[wid]);
+        int fvid[NF];
+        double fv[NF][DIM], cv[NV][DIM];
+#pragma unroll
+        for (int k = 0; k < NF; k++) {
+            fvid[k] = __builtin_amdgcn_readfirstlane(facets[(size_t)wid*NF+k]);
+#pragma unroll
+            for (int d = 0; d < DIM; d++) fv[k][d] = verts[(size_t)fvid[k]*DIM+d];
+        }
+#pragma unroll
+        for (int k = 0; k < NV; k++)
+#pragma unroll
+            for (int d = 0; d < DIM; d++) cv[k][d] = P.cellv[(size_t)(k*DIM+d)*P.ncp+c1];
+        int perm1[NV], perm2[NF], perm[DPE];
+#pragma unroll
+        for (int k = 0; k < NV; k++) perm1[k] = k;
+#pragma unroll
+        for (int k = 0; k < NF; k++) perm2[k] = k;
+#pragma unroll
+        for (int k = 0; k < DPE; k++) perm[k] = k;
+        int mask1 = 0, mask2 = 0, common = 0;
+        for (int a = 0; a < NV; a++) {
+            const int v1 = P.cvid[(size_t)a*P.ncp+c1];
+            for (int b = 0; b < NF; b++) {
+                if (mask2 & (1 << b)) continue;
+                if (v1 == fvid[b]) {
+                    perm1[common] = a; perm2[common] = b;
+                    mask1 += (1 << a); mask2 += (1 << b);
+                    common++;
+                    break;
+                }
+            }
+        }
+        double nrm[DIM], vol2 = 1.;
+#pragma unroll
+        for (int d = 0; d < DIM; d++) nrm[d] = 0.;
+        if (DIM == 2) {
+            nrm[0] = fv[1][1]-fv[0][1];
+            nrm[1] = fv[0][0]-fv[1][0];
+            const double inv = 1./sqrt(nrm[0]*nrm[0]+nrm[1]*nrm[1]);
+            nrm[0] *= inv; nrm[1] *= inv;
+            vol2 = sqrt((fv[1][0]-fv[0][0])*(fv[1][0]-fv[0][0])+(fv[1][1]-fv[0][1])*(fv[1][1]-fv[0][1]));
+        }
+        double acc[ND];
+#pragma unroll
+        for (int e = 0; e < ND; e++) acc[e] = 0.;
+        double vol;
+        if (common == 0) {
+            double dc2 = 0.;
+#pragma unroll
+            for (int d = 0; d < DIM; d++) {
+                double fc = 0.;
+#pragma unroll
+                for (int k = 0; k < NF; k++) fc += fv[k][d];
+                const double u = P.ccen[(size_t)d*P.ncp+c1]-fc*(1./NF);
+                dc2 += u*u;
+            }
+            const int q = quad_order(P.bqo, P.H0, P.ch[c1], vol2, sqrt(dc2));
+            if (q > P.qmax || q > PNL_MAXQ || P.off[q+1] == P.off[q] || P.foff[q+1] == P.foff[q]) {
+                if (lane == 0) atomicAdd(&P.counters[5], 1ull);
+                continue;
+            }
+            const int off = P.off[q], n = P.off[q+1]-off, foff = P.foff[q], nf = P.foff[q+1]-foff;
+            for (int k = lane; k < n*nf; k += 64) {
+                const int i = k/nf, m = k-i*nf;
+                double d2 = 0., nw = 0.;
+#pragma unroll
+                for (int d = 0; d < DIM; d++) {
+                    double x = 0., y = 0.;
+#pragma unroll
+                    for (int t = 0; t < NV; t++) x = __builtin_fma(P.bary[3*(size_t)(off+i)+t], cv[t][d], x);
+#pragma unroll
+                    for (int t = 0; t < NF; t++) y = __builtin_fma(P.fbary[2*(size_t)(foff+m)+t], fv[t][d], y);
+                    const double wv = y-x;
+                    d2 = __builtin_fma(wv, wv, d2);
+                    if (DIM == 2) nw = __builtin_fma(nrm[d], wv, nw);
+                }
+                if (DIM != 2) nw = 1.;
+                const double t = (P.w[off+i]*P.fw[foff+m])*nw*kern_eval<KT>(P.bkn, d2);
+                int e = 0;
+#pragma unroll
+                for (int a = 0; a < DPE; a++) {
+                    const double ta = t*P.phi[(size_t)(off+i)*DPE+a];
+#pragma unroll
+                    for (int b = a; b < DPE; b++) { acc[e] = __builtin_fma(ta, P.phi[(size_t)(off+i)*DPE+b], acc[e]); e++; }
+                }
+            }
+            vol = P.cvol[c1]*vol2*kern_scale<KT>(P.bkn);
+            nevals += (unsigned long long)n*nf;
+        } else {
+            int i = 0;
+            for (int k = common; k < NV; k++) { while (mask1 & (1 << i)) i++; perm1[k] = i; mask1 += (1 << i); }
+            i = 0;
+            for (int k = common; k < NF; k++) { while (mask2 & (1 << i)) i++; perm2[k] = i; mask2 += (1 << i); }
+            const int *t1 = P.perm_table+perm_rank(perm1, NV)*DPE;
+            for (int k = 0; k < DPE; k++) perm[k] = t1[k];
+            double s1[NV][DIM], s2[NF][DIM];
+#pragma unroll
+            for (int k = 0; k < NV; k++)
+#pragma unroll
+                for (int d = 0; d < DIM; d++) {
+                    double a = 0.;
+#pragma unroll
+                    for (int m = 0; m < NV; m++) a = (perm1[k] == m) ? cv[m][d] : a;
+                    s1[k][d] = a;
+                }
+#pragma unroll
+            for (int k = 0; k < NF; k++)
+#pragma unroll
+                for (int d = 0; d < DIM; d++) {
+                    double b = 0.;
+#pragma unroll
+                    for (int m = 0; m < NF; m++) b = (perm2[k] == m) ? fv[m][d] : b;
+                    s2[k][d] = b;
+                }
+            const int slot = common-1;
+            const int M = P.bM[slot];
+            const double *__restrict__ nodes = P.bNodes[slot];
+            const double *__restrict__ w = P.bW[slot];
+            const double *__restrict__ PHI = P.bPhi[slot];
+            for (int m = lane; m < M; m += 64) {
+                double d2 = 0., nw = 0.;
+#pragma unroll
+                for (int d = 0; d < DIM; d++) {
+                    double x = 0., y = 0.;
+#pragma unroll
+                    for (int k = 0; k < NV; k++) x = __builtin_fma(s1[k][d], nodes[(size_t)k*M+m], x);
+#pragma unroll
+                    for (int k = 0; k < NF; k++) y = __builtin_fma(s2[k][d], nodes[(size_t)(NV+k)*M+m], y);
+                    const double wv = x-y;
+                    d2 = __builtin_fma(wv, wv, d2);
+                    if (DIM == 2) nw = __builtin_fma(nrm[d], wv, nw);
+                }
+                if (DIM != 2) nw = 1.;
+                const double t = w[m]*nw*kern_eval<KT>(P.bkn, d2);
+                double ps[DPE];
+#pragma unroll
+                for (int r = 0; r < DPE; r++) ps[r] = PHI[(size_t)r*M+m];
+                int e = 0;
+#pragma unroll
+                for (int I = 0; I < DPE; I++) {
+                    const double tI = t*ps[I];
+#pragma unroll
+                    for (int J = I; J < DPE; J++) { acc[e] = __builtin_fma(tI, ps[J], acc[e]); e++; }
+                }
+            }
+            vol = ((DIM == 2) ? P.bFac*P.cvol[c1]*vol2 : P.bFac*P.cvol[c1])*kern_scale<KT>(P.bkn);
+            nevals += (unsigned long long)M;
+        }
+        npairs++;
+        double mine = 0.;
+        int myI = 0, myJ = 0;
+        {
+            int e = 0;
+#pragma unroll
+            for (int I = 0; I < DPE; I++)
+#pragma unroll
+                for (int J = I; J < DPE; J++) {
+                    const double s = wave_sum(acc[e]);
+                    if (lane == e) { mine = s; myI = I; myJ = J; }
+                    e++;
+                }
+        }
+        if (lane < ND) {
+            int i = 0, j = 0;
+#pragma unroll
+            for (int k = 0; k < DPE; k++) { i = (myI == k) ? perm[k] : i; j = (myJ == k) ? perm[k] : j; }
+            const int lo = min(i, j), hi = max(i, j);
+            const int kk = DPE*lo-(lo*(lo+1) >> 1)+hi;
+            if ((mask >> kk) & 1u) {
+                const int I = P.cdof[(size_t)lo*P.ncp+c1], J = P.cdof[(size_t)hi*P.ncp+c1];
+                const double v = fac*vol*mine;
+                if (lo == hi) sparse_add(S, I, I, v);
+                else { sparse_add(S, I, J, v); sparse_add(S, J, I, v); }
+            }
+        }
+    }
+    if (lane == 0 && npairs) {
+        atomicAdd(&P.counters[3], npairs);
+        atomicAdd(&P.counters[4], nevals);
+    }
+}
+
+// ---- near-field matvec: CSR_LinearOperator / SSS_LinearOperator matvec (CSR_LinearOperator_{SCALAR}.pxi:259-284,
+// SSS_LinearOperator_{SCALAR}.pxi:146-176).  One wave per row; SSS adds the mirrored entries with atomics.
+__global__ void __launch_bounds__(PNL_NTHREADS)
+k_spmv(const int *__restrict__ indptr, const int *__restrict__ indices, const double *__restrict__ data,
+       const double *__restrict__ diag, int n, const double *__restrict__ x, double *__restrict__ y) {
+    const int lane = threadIdx.x & 63;
+    const int row = (blockIdx.x*PNL_NTHREADS+threadIdx.x) >> 6;
+    if (row >= n) return;
+    const int b = indptr[row], e = indptr[row+1];
+    const double xi = x[row];
+    double s = 0.;
+    for (int t = b+lane; t < e; t += 64) {
+        const int J = indices[t];
+        const double a = data[t];
+        s = __builtin_fma(a, x[J], s);
+        if (diag) atomic_add_f64(&y[J], a*xi);
+    }
+    s = wave_sum(s);
+    if (lane == 0) {
+        if (diag) atomic_add_f64(&y[row], __builtin_fma(diag[row], xi, s));
+        else y[row] = s;
     }
 }

@@ -113,3 +113,94 @@ class DistributedDense_LinearOperator(Dense_LinearOperator):
         dist.all_reduce(self.A, group=self.group)
         self._host = None
         return Dense_LinearOperator(self.A, self.ctx, self.info)
+
+
+class CSR_LinearOperator:
+    """Near-field matrix in HBM, CSR layout (base/PyNucleus_base/CSR_LinearOperator_{SCALAR}.pxi:20-60: ``indptr``,
+    ``indices``, ``data``).  The pattern is fixed by getSparseNearField; ``data`` is filled by
+    pnl_assemble_pairs_masked / pnl_assemble_boundary_masked with the reference's addToEntry semantics."""
+    symmetric = False
+
+    def __init__(self, indptr, indices, num_dofs, ctx, device):
+        self.indptr = np.ascontiguousarray(indptr, dtype=np.int32)
+        self.indices = np.ascontiguousarray(indices, dtype=np.int32)
+        self.num_rows = self.num_columns = int(num_dofs)
+        self.shape = (self.num_rows, self.num_columns)
+        self.ctx = ctx
+        self.device = device
+        self.data_dev = torch.zeros(max(self.indices.shape[0], 1), dtype=torch.float64, device=device)
+        self.diag_dev = None
+        self.info = {}
+
+    @property
+    def nnz(self):
+        return int(self.indices.shape[0])
+
+    @property
+    def data(self):
+        self.ctx.synchronize()
+        return self.data_dev[:self.nnz].cpu().numpy()
+
+    def _ptrs(self):
+        return self.data_dev.data_ptr(), (self.diag_dev.data_ptr() if self.diag_dev is not None else None)
+
+    def _bind(self):
+        """make this operator's pattern the one resident in the context"""
+        if getattr(self.ctx, '_pattern_owner', None) is not self:
+            self.ctx.upload_sparsity(self.indptr, self.indices)
+            self.ctx._pattern_owner = self
+
+    def toarray(self):
+        N = self.num_rows
+        A = np.zeros((N, N))
+        rows = np.repeat(np.arange(N), np.diff(self.indptr))
+        A[rows, self.indices] = self.data
+        return A
+
+    @property
+    def diagonal(self):
+        return np.diag(self.toarray()).copy()
+
+    def matvec(self, x, y=None):
+        self._bind()
+        xd = _as_dev(x, self.device)
+        assert xd.shape[0] == self.num_columns
+        yd = torch.empty(self.num_rows, dtype=torch.float64, device=self.device)
+        torch.cuda.current_stream(self.device).synchronize()
+        d, g = self._ptrs()
+        self.ctx.spmv(d, g, xd.data_ptr(), yd.data_ptr())
+        self.ctx.synchronize()
+        if isinstance(x, torch.Tensor):
+            return yd
+        out = yd.cpu().numpy()
+        if y is not None:
+            y[:] = out
+            return y
+        return out
+
+    def __mul__(self, x):
+        return self.matvec(x)
+
+    dot = matvec
+
+    def __repr__(self):
+        return '<{}x{} {} with {} stored entries on {}>'.format(self.num_rows, self.num_columns, type(self).__name__, self.nnz, self.device)
+
+
+class SSS_LinearOperator(CSR_LinearOperator):
+    """Symmetric sparse skyline storage (base/PyNucleus_base/SSS_LinearOperator_{SCALAR}.pxi:23-60): strict lower
+    triangle in CSR (``indptr``, ``indices``, ``data``) plus the ``diagonal`` vector."""
+    symmetric = True
+
+    def __init__(self, indptr, indices, num_dofs, ctx, device):
+        super().__init__(indptr, indices, num_dofs, ctx, device)
+        self.diag_dev = torch.zeros(self.num_rows, dtype=torch.float64, device=device)
+
+    @property
+    def diagonal(self):
+        self.ctx.synchronize()
+        return self.diag_dev.cpu().numpy()
+
+    def toarray(self):
+        L = CSR_LinearOperator.toarray(self)
+        return L+L.T+np.diag(self.diagonal)

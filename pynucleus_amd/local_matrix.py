@@ -104,10 +104,12 @@ class nonlocalTables:
             self._setup1D(kernel, target_order, params.get('quad_order_diagonal', None))
         self.singularityValue = sing
         self._distant_rules(qcap)
-        if self.zeroExterior:
-            # NA:954: kernel.getModifiedKernel(horizon=inf).getBoundaryKernel(); zeroExterior implies horizon=inf already
-            if kernel.kernelType != FRACTIONAL:
-                raise NotImplementedError('zeroExterior needs a fractional kernel')
+        # surface integrals (NA:953-955): the Gauss-theorem twin is built whenever it exists, not only for zeroExterior --
+        # the cluster-local boundary term of assembleClusters (NA:1842-1889) needs it too
+        self.has_boundary_tables = kernel.kernelType == FRACTIONAL and not kernel.finiteHorizon
+        if self.zeroExterior and not self.has_boundary_tables:
+            raise NotImplementedError('zeroExterior needs a fractional kernel')
+        if self.has_boundary_tables:
             bk = kernel.getBoundaryKernel()
             self.boundaryKernel = bk
             if dim == 2:
