@@ -45,7 +45,7 @@ struct pnl_context {
     bool dirty = true;
     // device
     DevProblem P;
-    DevBuf b_cellv, b_ccen, b_cvol, b_ch, b_cvid, b_cdof, b_cslot, b_blk_ndof, b_blk_dofs, b_perm, b_off, b_bary, b_w, b_phi,
+    DevBuf b_cellv, b_ccen, b_cvol, b_ch, b_clog, b_cvid, b_cdof, b_cslot, b_blk_ndof, b_blk_dofs, b_perm, b_off, b_bary, b_w, b_phi,
         b_foff, b_fbary, b_fw, b_sn[3], b_sw[3], b_sp[3], b_bn[2], b_bw[2], b_bp[2], b_bvid, b_bv, b_bgeo, b_counters, b_D, b_tiles,
         b_spairs[3], b_bpairs[2], b_vec[6], b_scal, b_wl, b_wlcount, b_ttn, b_ttoff, b_tttab, b_wlsorted, b_wlaux,
         b_vertices, b_sp_indptr, b_sp_indices, b_mp_pairs, b_mp_masks, b_mp_wl, b_mp_sorted, b_mp_aux, b_bi_cells, b_bi_facets,
@@ -63,6 +63,7 @@ struct pnl_context {
     bool tiles_launched = false;
     int ablate = 0;                 // debug: PNL_ABLATE env bits (1 no LDS accumulate, 2 no evaluation)
     bool tile_cell_filter = true;   // apply [cell_begin, cell_end) to the a-cells of the tiles too
+    bool wl_lane = true;            // debug: PNL_WL_LANE=0 sends every work-list order to the 16-lanes-per-pair kernel
 };
 
 namespace {
@@ -294,6 +295,11 @@ int finalize(pnl_context *ctx) {
     if ((rc = upload(ctx, ctx->b_ccen, ccen.data(), ccen.size()))) return rc;
     if ((rc = upload(ctx, ctx->b_cvol, cvol.data(), cvol.size()))) return rc;
     if ((rc = upload(ctx, ctx->b_ch, ch.data(), ch.size()))) return rc;
+    {
+        std::vector<double> clog((size_t)2*ncp, 0.);
+        for (int c = 0; c < ncp; c++) { clog[c] = std::log(ch[c]); clog[(size_t)ncp+c] = std::fabs(std::log(ch[c]/ctx->H0)); }
+        if ((rc = upload(ctx, ctx->b_clog, clog.data(), clog.size()))) return rc;
+    }
     if ((rc = upload(ctx, ctx->b_cvid, cvid.data(), cvid.size()))) return rc;
     if ((rc = upload(ctx, ctx->b_cdof, cdof.data(), cdof.size()))) return rc;
     if ((rc = upload(ctx, ctx->b_cslot, cslot.data(), cslot.size()))) return rc;
@@ -307,7 +313,7 @@ int finalize(pnl_context *ctx) {
     P.dim = dim; P.dpe = dpe; P.nc = nc; P.ncp = ncp; P.N = ctx->N; P.dpv = ctx->dpv; P.dped = ctx->dped; P.nb = ctx->nb;
     P.H0 = ctx->H0;
     P.cellv = (const double*)ctx->b_cellv.p; P.ccen = (const double*)ctx->b_ccen.p;
-    P.cvol = (const double*)ctx->b_cvol.p; P.ch = (const double*)ctx->b_ch.p;
+    P.cvol = (const double*)ctx->b_cvol.p; P.ch = (const double*)ctx->b_ch.p; P.clog = (const double*)ctx->b_clog.p;
     P.cvid = (const int*)ctx->b_cvid.p; P.cdof = (const int*)ctx->b_cdof.p; P.cslot = (const short*)ctx->b_cslot.p;
     P.blk_ndof = (const int*)ctx->b_blk_ndof.p; P.blk_dofs = (const int*)ctx->b_blk_dofs.p;
     P.blk_stride = nU; P.nblocks = nblocks;
@@ -400,9 +406,14 @@ int launch_tiles(pnl_context *ctx, int ntiles, double *A, int64_t ldA, int cell_
         const size_t lds = (size_t)tab_max*st*sizeof(double);
         auto wfun = k_worklist_sorted<DIM, DPE, KT, false>;
         HIPCHK(ctx, hipFuncSetAttribute((const void*)wfun, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        const int nmin = ctx->wl_lane ? PNL_WL_LANE_MAXPTS+1 : 0;
+        if (ctx->wl_lane)
+            hipLaunchKernelGGL((k_worklist_lane<DIM, DPE, KT, false>), dim3(256*4), dim3(PNL_NTHREADS), 0, ctx->stream, ctx->P,
+                               (const int4*)ctx->b_wlsorted.p, (const unsigned*)offs, A, (long long)ldA, (double*)ctx->b_D.p, SparseOut{},
+                               getenv("PNL_WL_DBG") ? atoi(getenv("PNL_WL_DBG")) : 0);
         hipLaunchKernelGGL(wfun, dim3(256*2), dim3(PNL_NTHREADS), lds, ctx->stream, ctx->P, (const int4*)ctx->b_wlsorted.p,
                            (const unsigned*)offs, (const unsigned*)coff, A, (long long)ldA, (double*)ctx->b_D.p, tab_max,
-                           SparseOut{}, PNL_WL_BINS-1);
+                           SparseOut{}, PNL_WL_BINS-1, nmin);
         HIPCHK(ctx, hipGetLastError());
     }
     return PNL_OK;
@@ -571,8 +582,12 @@ int pairs_masked_impl(pnl_context *ctx, int np, const SparseOut &S) {
         const size_t lds = (size_t)tab_max*st*sizeof(double);
         auto wfun = k_worklist_sorted<DIM, DPE, KT, true>;
         HIPCHK(ctx, hipFuncSetAttribute((const void*)wfun, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        const int nmin = ctx->wl_lane ? PNL_WL_LANE_MAXPTS+1 : 0;
+        if (ctx->wl_lane)
+            hipLaunchKernelGGL((k_worklist_lane<DIM, DPE, KT, true>), dim3(256*4), dim3(PNL_NTHREADS), 0, ctx->stream, ctx->P,
+                               (const int4*)sorted, (const unsigned*)offs, (double*)nullptr, 0ll, (double*)nullptr, S, 0);
         hipLaunchKernelGGL(wfun, dim3(256*2), dim3(PNL_NTHREADS), lds, ctx->stream, ctx->P, (const int4*)sorted, (const unsigned*)offs,
-                           (const unsigned*)coff, (double*)nullptr, 0ll, (double*)nullptr, tab_max, S, PNL_MAXQ);
+                           (const unsigned*)coff, (double*)nullptr, 0ll, (double*)nullptr, tab_max, S, PNL_MAXQ, nmin);
         HIPCHK(ctx, hipGetLastError());
     }
     HIPCHK(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
@@ -727,6 +742,7 @@ int pnl_create(int device_id, pnl_context **out) {
         if (hipEventCreate(&e) != hipSuccess) { delete ctx; return PNL_ERR_HIP; }
     std::memset(&ctx->P, 0, sizeof(ctx->P));
     if (const char *e = getenv("PNL_ABLATE")) ctx->ablate = atoi(e);
+    if (const char *e = getenv("PNL_WL_LANE")) ctx->wl_lane = atoi(e) != 0;
     std::memset(ctx->kern, 0, sizeof(ctx->kern));
     std::memset(ctx->form, 0, sizeof(ctx->form));
     *out = ctx;
@@ -827,12 +843,13 @@ int pnl_upload_distant_rules(pnl_context *ctx, int qmax, const int32_t *off, con
         std::vector<int32_t> tn(PNL_MAXQ+2, 0), to(PNL_MAXQ+2, 0);
         std::vector<double> tab;
         int npts = 0, nb = 0;
-        // the tile kernel unrolls exactly two point counts: 3 and 6 on triangles, 2 and 3 on intervals
+        // the tile kernel unrolls exactly two point counts (3 and 6 on triangles, 2 and 3 on intervals) and integrates the
+        // other orders with at most PNL_GEN_MAXPTS points through a generic loop (list C)
         const int nA = ctx->dim == 2 ? 3 : 2, nB = ctx->dim == 2 ? 6 : 3;
         for (int q = 2; q <= qmax && q < 18; q++) {
             const int n = off[q+1]-off[q];
-            const bool ok = (n == nA || n == nB);
-            if (!ok || nb >= 16 || npts+n > 96) continue;
+            const bool ok = (n == nA || n == nB || (n > 0 && n <= PNL_GEN_MAXPTS));
+            if (!ok || npts+n > PNL_TT_MAXPTS) continue;
             tn[q] = n; to[q] = npts;
             for (int i = 0; i < n; i++) {
                 const size_t p = (size_t)off[q]+i;

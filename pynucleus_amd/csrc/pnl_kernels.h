@@ -234,14 +234,75 @@ __device__ __forceinline__ void eval_distant_fixed(const DevProblem &P, const do
     }
 }
 
+// runtime number of points n, the same for all lanes of the wave; the rule is read from an LDS copy (layout per point:
+// bary[3], w, phi[DPE], stride stp) with wave-uniform addresses, i.e. broadcast reads.  x_i, the row sums and u_b are kept
+// per i; S2 is accumulated directly per point pair (no per-lane column sums of runtime length).
+template <int DIM, int DPE, int KT>
+__device__ __forceinline__ void eval_distant_lds(const DevProblem &P, const double *__restrict__ tab, int stp, int n, const double *av,
+                                                 const double *bv, PairAcc<DIM, DPE> &R) {
+    constexpr int NV = DIM+1;
+#pragma unroll 1
+    for (int i = 0; i < n; i++) {
+        const double *__restrict__ ti = tab+i*stp;
+        double x[DIM];
+#pragma unroll
+        for (int d = 0; d < DIM; d++) {
+            double sx = 0.;
+#pragma unroll
+            for (int k = 0; k < NV; k++) sx = __builtin_fma(ti[k], av[k*DIM+d], sx);
+            x[d] = sx;
+        }
+        const double wi = ti[3];
+        double r = 0., u[DPE];
+#pragma unroll
+        for (int b = 0; b < DPE; b++) u[b] = 0.;
+#pragma unroll 2
+        for (int j = 0; j < n; j++) {
+            const double *__restrict__ tj = tab+j*stp;
+            double d2 = 0.;
+#pragma unroll
+            for (int d = 0; d < DIM; d++) {
+                double sy = 0.;
+#pragma unroll
+                for (int k = 0; k < NV; k++) sy = __builtin_fma(tj[k], bv[k*DIM+d], sy);
+                const double t = x[d]-sy;
+                d2 = __builtin_fma(t, t, d2);
+            }
+            const double K = (wi*tj[3])*kern_eval<KT>(P.k, d2);
+            r += K;
+            double t[DPE];
+#pragma unroll
+            for (int b = 0; b < DPE; b++) { t[b] = K*tj[4+b]; u[b] += t[b]; }
+            int e = 0;
+#pragma unroll
+            for (int a = 0; a < DPE; a++)
+#pragma unroll
+                for (int b = a; b < DPE; b++) { R.S2[e] = __builtin_fma(t[a], tj[4+b], R.S2[e]); e++; }
+        }
+        int e = 0;
+#pragma unroll
+        for (int a = 0; a < DPE; a++) {
+            const double pa = ti[4+a];
+#pragma unroll
+            for (int b = 0; b < DPE; b++) R.G[a][b] = __builtin_fma(pa, u[b], R.G[a][b]);
+            const double pr = pa*r;
+#pragma unroll
+            for (int b = a; b < DPE; b++) { R.S1[e] = __builtin_fma(pr, ti[4+b], R.S1[e]); e++; }
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Tile kernel: classification (NO:280-378 vertex test, NO:493-540 + FL2:622-642 order) and distant
 // evaluation for one TILE x TILE block of cell pairs.
 #define PNL_TT_MAXPTS 96
-// Orders with at most PNL_NC_MAX points that are not unrolled could also be integrated one pair per lane inside the tile
-// (list C, generic trip count).  Measured on MI355X (noRef 6): tile kernel 13.1 -> 23.2 ms for 3 ms saved in the work-list
-// kernel, so it is disabled; such orders go to the global work list (one pair per wave).
-#define PNL_NC_MAX 0
+#define PNL_GEN_MAXPTS 16      // other orders with at most this many points are integrated in the tile kernel too (list C)
+#define PNL_GEN_MAXCHUNKS 128
+// Pairs whose order is not one of the two unrolled point counts but has at most PNL_GEN_MAXPTS points (orders 5-8 on
+// triangles, 92 % of the remaining pairs) stay in the tile as list C: it is counting-sorted by order in LDS so that a wave
+// runs 64 pairs of ONE order (same trip counts), one pair per lane, and their local matrices go through the same LDS
+// sub-block as lists A and B.  (Unsorted, per-lane trip counts: 13.1 -> 23.2 ms; through the global work list with global
+// atomics per pair: 3.8 ms of which 2.5 ms are the atomics.)  Only higher orders go to the global work list.
 // lanes walk the tile along generalised diagonals i = (s + m*j) mod TILE (m odd): distinct a- and b-cells per lane, and
 // neighbouring b-cells are paired with non-neighbouring a-cells, which keeps same-address LDS atomics rare
 #ifndef PNL_DIAG_MULT
@@ -268,12 +329,13 @@ struct TileSmem {
     static constexpr int o_lh = o_el+32;                   // float [2][2][TILE]: ln h, |ln(h/H0)|
     static constexpr int o_ttn = o_lh+4*TILE;          // [PNL_MAXQ+2] points of order q if the tile kernel integrates it, else 0
     static constexpr int o_tto = o_ttn+PNL_MAXQ+2;         // [PNL_MAXQ+2] its offset (points) in the table blob
-    static constexpr int n_int = o_tto+PNL_MAXQ+2;
+    static constexpr int o_chunk = o_tto+PNL_MAXQ+2;       // [PNL_GEN_MAXCHUNKS] list C chunks: order << 20 | start << 7 | count-1
+    static constexpr int n_int = o_chunk+PNL_GEN_MAXCHUNKS;
     // shorts after the ints
     static constexpr int o_slot = 0;                       // [2][DPE][TILE]
-    static constexpr int o_list = o_slot+2*DPE*TILE;       // [TILE*TILE] list A (16 bit) + [TILE*TILE] list B / far list (32 bit)
-                                                           // + [TILE*TILE] list C (32 bit)
-    static constexpr int n_short = o_list+(PNL_NC_MAX > 0 ? 5 : 3)*TILE*TILE+2;
+    static constexpr int o_list = o_slot+2*DPE*TILE;       // [TILE*TILE] 16 bit: list A from the front, list C from the back;
+                                                           // [TILE*TILE] 32 bit: list B from the front, far list from the back
+    static constexpr int n_short = o_list+3*TILE*TILE+2;
     static constexpr size_t fixed_bytes = sizeof(double)*n_dbl+sizeof(int)*n_int+sizeof(short)*((n_short+3)/4*4);
 };
 
@@ -331,9 +393,13 @@ k_tile_distant(const DevProblem P, const int2 *__restrict__ tiles, double *__res
     double *s_tt = s_dbl+S::o_tt, *s_Ld = s_dbl+S::o_Ld;
 
     const int tid = threadIdx.x;
+    int *s_chunk = s_int+S::o_chunk;
     // statistics of order q = 2 + tid (+256) are kept in registers over all tiles of this workgroup: hot counters
     // see one atomic per workgroup, not one per tile
     unsigned long long st_cnt[(PNL_MAXQ+PNL_NTHREADS)/PNL_NTHREADS] = {0}, st_ev[(PNL_MAXQ+PNL_NTHREADS)/PNL_NTHREADS] = {0};
+    // rules integrated inside the tile (the two unrolled point counts and the generic ones): staged once per workgroup
+    for (int t = tid; t < PNL_MAXQ+2; t += PNL_NTHREADS) { s_ttn[t] = P.tt_n[t]; s_tto[t] = P.tt_off[t]; }
+    for (int t = tid; t < P.tt_npts*(4+DPE); t += PNL_NTHREADS) s_tt[t] = P.tt_tab[t];
     // persistent workgroups: each one walks the tile list with stride gridDim.x (heavy tiles come first in the list)
 #pragma unroll 1
     for (int tile_idx = blockIdx.x; tile_idx < ntiles; tile_idx += gridDim.x) {
@@ -350,11 +416,11 @@ k_tile_distant(const DevProblem P, const int2 *__restrict__ tiles, double *__res
 #pragma unroll
         for (int d = 0; d < DIM; d++) s_cen[(side*DIM+d)*TILE+l] = P.ccen[(size_t)d*P.ncp+c];
         s_vol[side*TILE+l] = P.cvol[c];
-        const double hc = P.ch[c];
-        s_h[side*TILE+l] = hc;
-        const double Ld = fabs(log(hc/P.H0));
+        s_h[side*TILE+l] = P.ch[c];
+        // ln h and |ln(h/H0)| per cell are precomputed on the host (finalize)
+        const double lh = P.clog[c], Ld = P.clog[(size_t)P.ncp+c];
         s_Ld[side*TILE+l] = Ld;
-        s_lh[(side*2+0)*TILE+l] = (float)log(hc);
+        s_lh[(side*2+0)*TILE+l] = (float)lh;
         s_lh[(side*2+1)*TILE+l] = (float)Ld;
 #pragma unroll
         for (int k = 0; k < NV; k++) s_vid[(side*NV+k)*TILE+l] = P.cvid[(size_t)k*P.ncp+c];
@@ -365,8 +431,6 @@ k_tile_distant(const DevProblem P, const int2 *__restrict__ tiles, double *__res
             s_slot[(side*DPE+k)*TILE+l] = sl >= 0 ? sl : (short)(side ? nB : nA);
         }
     }
-    for (int t = tid; t < PNL_MAXQ+2; t += PNL_NTHREADS) { s_ttn[t] = P.tt_n[t]; s_tto[t] = P.tt_off[t]; }
-    for (int t = tid; t < P.tt_npts*(4+DPE); t += PNL_NTHREADS) s_tt[t] = P.tt_tab[t];
     for (int t = tid; t < (nA+1)*acc_stride; t += PNL_NTHREADS) s_acc[t] = 0.;
     for (int t = tid; t < 2*TILE*ND; t += PNL_NTHREADS) s_D[t] = 0.;
     for (int t = tid; t < 2*(PNL_MAXQ+2)+4; t += PNL_NTHREADS) s_cnt[t] = 0;    // s_cnt, s_cur and s_misc are adjacent
@@ -375,12 +439,12 @@ k_tile_distant(const DevProblem P, const int2 *__restrict__ tiles, double *__res
     // ---- classification ------------------------------------------------------------------------
     // pair p -> (i, j) along wrapped diagonals: consecutive lanes get distinct a-cells AND distinct
     // b-cells, so the per-cell LDS accumulators below see (almost) no same-address conflicts.
-    // Pairs whose order has NA points (the far-field order 2) go to list A, those with NB points to list B,
-    // everything else to the global work list.  No sorting, no prefix sums: one barrier.
+    // Pairs whose order has NA points (the far-field order 2) go to list A, those with NB points to list B, other orders
+    // packed into the tile's rule table to list C, everything else to the global work list.  One barrier.
     constexpr int NA = (DIM == 2) ? 3 : 2, NB = (DIM == 2) ? 6 : 3;
-    // list B grows from the front of s_l32, the far list (pairs for the global work list) from its back
+    // list A grows from the front of s_list, list C from its back; list B from the front of s_l32, the far list (pairs for
+    // the global work list) from its back
     int *s_l32 = (int*)(s_list+PAIRS+((((size_t)(s_list+PAIRS)) & 2) ? 1 : 0));
-    int *s_lC = s_l32+PAIRS;     // list C: other orders with at most PNL_NC_MAX points, integrated one pair per lane too
     int overflow = 0;
     const int lane = tid & 63;
     const unsigned long long lt = (1ull << lane)-1ull;
@@ -419,8 +483,7 @@ k_tile_distant(const DevProblem P, const int2 *__restrict__ tiles, double *__res
         }
         wave_bucket_add(s_cnt, q, false);                       // statistics only
         const int nq = q ? s_ttn[q] : 0;
-        int cls = !q ? 0 : ((nq == NA && q < 18) ? 1 : ((nq == NB && q < 18) ? 2 : 4));
-        if (PNL_NC_MAX > 0 && cls == 4 && P.off[q+1]-P.off[q] <= PNL_NC_MAX) cls = 3;
+        const int cls = !q ? 0 : (nq == NA ? 1 : (nq == NB ? 2 : (nq > 0 ? 3 : 4)));
         const unsigned short ent = (unsigned short)(p | ((q-2) << 12));
         // one returning atomic per class and wave
         const unsigned long long mA = __ballot(cls == 1), mB = __ballot(cls == 2), mC = __ballot(cls == 3), mF = __ballot(cls == 4);
@@ -429,7 +492,7 @@ k_tile_distant(const DevProblem P, const int2 *__restrict__ tiles, double *__res
             const int leader = __ffsll((long long)mC)-1;
             if (lane == leader) base = atomicAdd(&s_misc[3], __popcll(mC));
             base = __builtin_amdgcn_readlane(base, leader);
-            if (cls == 3) s_lC[base+__popcll(mC & lt)] = p | (q << 12);
+            if (cls == 3) s_list[PAIRS-1-(base+__popcll(mC & lt))] = ent;
         }
         if (mA) {
             int base = 0;
@@ -488,16 +551,50 @@ k_tile_distant(const DevProblem P, const int2 *__restrict__ tiles, double *__res
 
     // ---- evaluation: waves take 64-pair chunks of list A, then of list B ---------------------------------------
     const int wave = tid >> 6;
+    // local matrix of pair (i, j) -> LDS sub-block of A' and the per-cell diagonal blocks
+    auto accumulate = [&](const PairAcc<DIM, DPE> &R, int i, int j) {
+        // NA:1405-1410: symmetric cell pairs count twice
+        const double vv = 2.*s_vol[i]*s_vol[TILE+j]*kern_scale<KT>(P.k);
+        if (ablate & 1) {
+            double keep = 0.;
+#pragma unroll
+            for (int a = 0; a < DPE; a++)
+#pragma unroll
+                for (int b = 0; b < DPE; b++) keep += R.G[a][b];
+#pragma unroll
+            for (int e2 = 0; e2 < ND; e2++) keep += R.S1[e2]+R.S2[e2];
+            if (keep == 1.2345e300) s_D[0] = keep*vv;
+            return;
+        }
+        int e = 0;
+#pragma unroll
+        for (int a = 0; a < DPE; a++) {
+            const int sa = s_slot[(0*DPE+a)*TILE+i];
+#pragma unroll
+            for (int b = 0; b < DPE; b++) {
+                const int sb = s_slot[(1*DPE+b)*TILE+j];
+                lds_add_f64(&s_acc[sa*acc_stride+sb], -vv*R.G[a][b]);
+            }
+#pragma unroll
+            for (int b = a; b < DPE; b++) {
+                if (!(ablate & 64)) {
+                    lds_add_f64(&s_D[(0*TILE+i)*ND+e], vv*R.S1[e]);
+                    lds_add_f64(&s_D[(1*TILE+j)*ND+e], vv*R.S2[e]);
+                } else if (R.S1[e]+R.S2[e] == 1.2345e300) s_D[0] = 1.;
+                e++;
+            }
+        }
+    };
     if (!(ablate & 2))
 #pragma unroll 1
-    for (int pass = 0; pass < (PNL_NC_MAX > 0 ? 3 : 2); pass++) {
-        const int total = __builtin_amdgcn_readfirstlane(s_misc[pass == 2 ? 3 : pass]);
+    for (int pass = 0; pass < 2; pass++) {
+        const int total = __builtin_amdgcn_readfirstlane(s_misc[pass]);
 #pragma unroll 1
         for (int c0 = wave*64; c0 < total; c0 += PNL_NTHREADS) {
             const int idx = c0+lane;
             const bool act = idx < total;
-            const int ent = act ? (pass == 0 ? (int)s_list[idx] : (pass == 1 ? s_l32[idx] : s_lC[idx])) : 0;
-            const int p = ent & 4095, q = (ent >> 12)+(pass == 2 ? 0 : 2);
+            const int ent = act ? (pass == 0 ? (int)s_list[idx] : s_l32[idx]) : 0;
+            const int p = ent & 4095, q = (ent >> 12)+2;
             const int j = p%TILE, i = (p/TILE+PNL_DIAG_MULT*j)%TILE;
             const double *tab = s_tt+s_tto[q]*(4+DPE);
             double av[NC], bv[NC];
@@ -505,46 +602,49 @@ k_tile_distant(const DevProblem P, const int2 *__restrict__ tiles, double *__res
             for (int k = 0; k < NC; k++) { av[k] = s_v[(0*NC+k)*TILE+i]; bv[k] = s_v[(1*NC+k)*TILE+j]; }
             PairAcc<DIM, DPE> R;
             R.clear();
-            if (pass == 2) {
-                // per-lane order: every lane runs its own trip count, the wave the longest one
-                const int off = act ? P.off[q] : 0, n = act ? P.off[q+1]-off : 0;
-                eval_distant_generic<DIM, DPE, KT>(P, off, n, av, bv, R);
-            } else if (act) {
-                if (pass == 0) eval_distant_fixed<DIM, DPE, KT, NA>(P, tab, av, bv, R);
-                else eval_distant_fixed<DIM, DPE, KT, NB>(P, tab, av, bv, R);
-            }
             if (!act) continue;
-            // NA:1405-1410: symmetric cell pairs count twice
-            const double vv = 2.*s_vol[i]*s_vol[TILE+j]*kern_scale<KT>(P.k);
-            if (ablate & 1) {
-                double keep = 0.;
-#pragma unroll
-                for (int a = 0; a < DPE; a++)
-#pragma unroll
-                    for (int b = 0; b < DPE; b++) keep += R.G[a][b];
-#pragma unroll
-                for (int e2 = 0; e2 < ND; e2++) keep += R.S1[e2]+R.S2[e2];
-                if (keep == 1.2345e300) s_D[0] = keep*vv;
-                continue;
+            if (pass == 0) eval_distant_fixed<DIM, DPE, KT, NA>(P, tab, av, bv, R);
+            else eval_distant_fixed<DIM, DPE, KT, NB>(P, tab, av, bv, R);
+            accumulate(R, i, j);
+        }
+    }
+    // ---- list C: counting sort by order into the (now free) storage of list B, then 64 pairs of one order per wave ----
+    const int nC = s_misc[3];
+    if (nC && !(ablate & 2)) {
+        __syncthreads();
+        if (tid == 0) {
+            int run = 0, nch = 0;
+            for (int q = 2; q < 18 && q <= P.qmax; q++) {
+                const int nq = s_ttn[q], c = s_cnt[q];
+                if (!c || nq == 0 || nq == NA || nq == NB) continue;
+                s_cur[q] = run;
+                for (int st = 0; st < c && nch < PNL_GEN_MAXCHUNKS; st += 64) s_chunk[nch++] = (q << 20) | ((run+st) << 7) | (min(64, c-st)-1);
+                run += c;
             }
-            int e = 0;
+            s_misc[0] = nch;
+        }
+        __syncthreads();
+        for (int t = tid; t < nC; t += PNL_NTHREADS) {
+            const int ent = s_list[PAIRS-1-t];
+            const int q = (ent >> 12)+2;
+            s_l32[atomicAdd(&s_cur[q], 1)] = ent & 4095;
+        }
+        __syncthreads();
+        const int nch = __builtin_amdgcn_readfirstlane(s_misc[0]);
+#pragma unroll 1
+        for (int ch = wave; ch < nch; ch += PNL_NTHREADS/64) {
+            const int desc = __builtin_amdgcn_readfirstlane(s_chunk[ch]);
+            const int q = desc >> 20, start = (desc >> 7) & 8191, cnt = (desc & 127)+1;
+            const bool act = lane < cnt;
+            const int p = s_l32[start+(act ? lane : 0)];
+            const int j = p%TILE, i = (p/TILE+PNL_DIAG_MULT*j)%TILE;
+            double av[NC], bv[NC];
 #pragma unroll
-            for (int a = 0; a < DPE; a++) {
-                const int sa = s_slot[(0*DPE+a)*TILE+i];
-#pragma unroll
-                for (int b = 0; b < DPE; b++) {
-                    const int sb = s_slot[(1*DPE+b)*TILE+j];
-                    lds_add_f64(&s_acc[sa*acc_stride+sb], -vv*R.G[a][b]);
-                }
-#pragma unroll
-                for (int b = a; b < DPE; b++) {
-                    if (!(ablate & 64)) {
-                        lds_add_f64(&s_D[(0*TILE+i)*ND+e], vv*R.S1[e]);
-                        lds_add_f64(&s_D[(1*TILE+j)*ND+e], vv*R.S2[e]);
-                    } else if (R.S1[e]+R.S2[e] == 1.2345e300) s_D[0] = 1.;
-                    e++;
-                }
-            }
+            for (int k = 0; k < NC; k++) { av[k] = s_v[(0*NC+k)*TILE+i]; bv[k] = s_v[(1*NC+k)*TILE+j]; }
+            PairAcc<DIM, DPE> R;
+            R.clear();
+            eval_distant_lds<DIM, DPE, KT>(P, s_tt+s_tto[q]*(4+DPE), 4+DPE, s_ttn[q], av, bv, R);
+            if (act) accumulate(R, i, j);
         }
     }
     __syncthreads();
@@ -738,25 +838,33 @@ k_wl_scatter(const int4 *__restrict__ wl, const unsigned *__restrict__ wl_count,
     }
 }
 
-// Distant pairs from the sorted work list (NO:722-789): a workgroup takes chunks of 16 pairs of one order, one DPP row
-// (16 lanes) per pair, lanes over the n*n point pairs of the tensor rule read from the LDS copy of the rule, row-wise
-// DPP reduction of the local matrix, atomic scatter.  A' receives the cross block on the (c1-DoF, c2-DoF) side only.
+// Distant pairs of the high orders from the sorted work list (NO:722-789; few pairs, thousands of point pairs each): a
+// workgroup takes chunks of 16 pairs of one order, one DPP row (16 lanes) per pair; the lanes split the rows of the tensor
+// rule (read from the LDS copy of the rule), row-wise DPP reduction of the local matrix, atomic scatter.  A' receives the cross block on the (c1-DoF, c2-DoF) side only.
 template <int DIM, int DPE, int KT, bool SPARSE>
 __global__ void __launch_bounds__(PNL_NTHREADS)
 k_worklist_sorted(const DevProblem P, const int4 *__restrict__ sorted, const unsigned *__restrict__ offs,
                   const unsigned *__restrict__ chunk_off, double *__restrict__ A, long long ldA, double *__restrict__ Dglob,
-                  int tab_max_pts, const SparseOut S, int qlast) {
-    constexpr int NV = DIM+1, NC = NV*DIM, ND = DPE*(DPE+1)/2, NG = DPE*DPE, NACC = NG+2*ND, NREP = (NACC+15)/16, ST = 4+DPE;
+                  int tab_max_pts, const SparseOut S, int qlast, int nmin) {
+    constexpr int NV = DIM+1, NC = NV*DIM, ND = DPE*(DPE+1)/2, NG = DPE*DPE, NACC = NG+2*ND, LPP = 16, PPC = PNL_NTHREADS/LPP, NREP = (NACC+LPP-1)/LPP, ST = 4+DPE;   // LPP lanes per pair
     extern __shared__ double s_rule[];           // [tab_max_pts][ST]: bary[3], w, phi[DPE]
     __shared__ unsigned s_coff[PNL_WL_BINS+1];
-    const int tid = threadIdx.x, sub = tid & 15, g = tid >> 4;
-    for (int t = tid; t <= PNL_WL_BINS; t += PNL_NTHREADS) s_coff[t] = chunk_off[t];
+    const int tid = threadIdx.x, sub = tid & (LPP-1), g = tid/LPP;
+    // chunks of PPC pairs over the orders this kernel owns: 2 <= q <= qlast (the sparse path keeps skipped pairs in bin 0 and
+    // the touching pairs in the bins above qlast) with at least nmin points (the smaller rules go to k_worklist_lane)
+    if (tid == 0) {
+        unsigned run = 0;
+        for (int q = 0; q < PNL_WL_BINS; q++) {
+            s_coff[q] = run;
+            const int nq = (q >= 2 && q <= P.qmax && q <= PNL_MAXQ && q <= qlast) ? P.off[q+1]-P.off[q] : 0;
+            if (nq > 0 && nq >= nmin) run += (offs[q+1]-offs[q]+PPC-1u)/PPC;
+        }
+        s_coff[PNL_WL_BINS] = run;
+    }
     __syncthreads();
-    // only the chunks of the orders 0..qlast (the sparse path keeps the touching pairs in the bins above)
-    const unsigned nchunks = s_coff[qlast+1];
+    const unsigned nchunks = s_coff[PNL_WL_BINS];
     int staged_q = -1;
-    // bins 0 and 1 hold no distant pair (orders start at 2; the sparse path parks skipped pairs in bin 0)
-    for (unsigned chunk = s_coff[2]+blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+    for (unsigned chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
         // order of this chunk: last q with chunk_off[q] <= chunk
         int lo = 0, hi = PNL_WL_BINS-1;
         while (lo < hi) {
@@ -764,8 +872,8 @@ k_worklist_sorted(const DevProblem P, const int4 *__restrict__ sorted, const uns
             if (s_coff[mid] <= chunk) lo = mid; else hi = mid-1;
         }
         const int q = lo;
-        const unsigned first = offs[q]+16u*(chunk-s_coff[q]);
-        const int cnt = (int)min(16u, offs[q+1]-first);
+        const unsigned first = offs[q]+(unsigned)PPC*(chunk-s_coff[q]);
+        const int cnt = (int)min((unsigned)PPC, offs[q+1]-first);
         const int4 e0 = sorted[first];
         const int off = e0.z, n = e0.w & 0xffff, nn = n*n;
         const bool in_lds = n <= tab_max_pts;
@@ -785,50 +893,85 @@ k_worklist_sorted(const DevProblem P, const int4 *__restrict__ sorted, const uns
         double av[NC], bv[NC];
 #pragma unroll
         for (int k = 0; k < NC; k++) { av[k] = P.cellv[(size_t)k*P.ncp+c1]; bv[k] = P.cellv[(size_t)k*P.ncp+c2]; }
-        double acc[NACC];
-#pragma unroll
-        for (int e = 0; e < NACC; e++) acc[e] = 0.;
-        const float rn = 1.f/(float)n;
-        for (int k = sub; k < nn; k += 16) {
-            const int i = (int)(((float)k+0.5f)*rn), j = k-i*n;
-            double ti[ST], tj[ST];
+        // the LPP lanes of a pair split the rows i of the tensor rule; each lane runs the factorised accumulation of
+        // eval_distant_lds over its rows and all columns j (column data are broadcast reads)
+        PairAcc<DIM, DPE> R;
+        R.clear();
+#pragma unroll 1
+        for (int i = sub; i < n; i += LPP) {
+            double ti[ST];
             if (in_lds) {
 #pragma unroll
-                for (int m = 0; m < ST; m++) { ti[m] = s_rule[i*ST+m]; tj[m] = s_rule[j*ST+m]; }
+                for (int m = 0; m < ST; m++) ti[m] = s_rule[i*ST+m];
             } else {
 #pragma unroll
-                for (int m = 0; m < 3; m++) { ti[m] = P.bary[3*(size_t)(off+i)+m]; tj[m] = P.bary[3*(size_t)(off+j)+m]; }
-                ti[3] = P.w[off+i]; tj[3] = P.w[off+j];
+                for (int m = 0; m < 3; m++) ti[m] = P.bary[3*(size_t)(off+i)+m];
+                ti[3] = P.w[off+i];
 #pragma unroll
-                for (int m = 0; m < DPE; m++) { ti[4+m] = P.phi[(size_t)(off+i)*DPE+m]; tj[4+m] = P.phi[(size_t)(off+j)*DPE+m]; }
+                for (int m = 0; m < DPE; m++) ti[4+m] = P.phi[(size_t)(off+i)*DPE+m];
             }
-            double d2 = 0.;
+            double x[DIM];
 #pragma unroll
             for (int d = 0; d < DIM; d++) {
-                double x = 0., y = 0.;
+                double sx = 0.;
 #pragma unroll
-                for (int m = 0; m < NV; m++) {
-                    x = __builtin_fma(ti[m], av[m*DIM+d], x);
-                    y = __builtin_fma(tj[m], bv[m*DIM+d], y);
-                }
-                d2 = __builtin_fma(x-y, x-y, d2);
+                for (int m = 0; m < NV; m++) sx = __builtin_fma(ti[m], av[m*DIM+d], sx);
+                x[d] = sx;
             }
-            const double K = (ti[3]*tj[3])*kern_eval<KT>(P.k, d2);
+            double r = 0., u[DPE];
+#pragma unroll
+            for (int b = 0; b < DPE; b++) u[b] = 0.;
+#pragma unroll 2
+            for (int j = 0; j < n; j++) {
+                double tj[ST];
+                if (in_lds) {
+#pragma unroll
+                    for (int m = 0; m < ST; m++) tj[m] = s_rule[j*ST+m];
+                } else {
+#pragma unroll
+                    for (int m = 0; m < 3; m++) tj[m] = P.bary[3*(size_t)(off+j)+m];
+                    tj[3] = P.w[off+j];
+#pragma unroll
+                    for (int m = 0; m < DPE; m++) tj[4+m] = P.phi[(size_t)(off+j)*DPE+m];
+                }
+                double d2 = 0.;
+#pragma unroll
+                for (int d = 0; d < DIM; d++) {
+                    double sy = 0.;
+#pragma unroll
+                    for (int m = 0; m < NV; m++) sy = __builtin_fma(tj[m], bv[m*DIM+d], sy);
+                    const double t = x[d]-sy;
+                    d2 = __builtin_fma(t, t, d2);
+                }
+                const double K = (ti[3]*tj[3])*kern_eval<KT>(P.k, d2);
+                r += K;
+                double t[DPE];
+#pragma unroll
+                for (int b = 0; b < DPE; b++) { t[b] = K*tj[4+b]; u[b] += t[b]; }
+                int e = 0;
+#pragma unroll
+                for (int a = 0; a < DPE; a++)
+#pragma unroll
+                    for (int b = a; b < DPE; b++) { R.S2[e] = __builtin_fma(t[a], tj[4+b], R.S2[e]); e++; }
+            }
             int e = 0;
 #pragma unroll
             for (int a = 0; a < DPE; a++) {
-                const double ka = K*ti[4+a];
+                const double pa = ti[4+a];
 #pragma unroll
-                for (int b = 0; b < DPE; b++) acc[a*DPE+b] = __builtin_fma(ka, tj[4+b], acc[a*DPE+b]);
-                const double kb = K*tj[4+a];
+                for (int b = 0; b < DPE; b++) R.G[a][b] = __builtin_fma(pa, u[b], R.G[a][b]);
+                const double pr = pa*r;
 #pragma unroll
-                for (int b = a; b < DPE; b++) {
-                    acc[NG+e] = __builtin_fma(ka, ti[4+b], acc[NG+e]);
-                    acc[NG+ND+e] = __builtin_fma(kb, tj[4+b], acc[NG+ND+e]);
-                    e++;
-                }
+                for (int b = a; b < DPE; b++) { R.S1[e] = __builtin_fma(pr, ti[4+b], R.S1[e]); e++; }
             }
         }
+        double acc[NACC];
+#pragma unroll
+        for (int a = 0; a < DPE; a++)
+#pragma unroll
+            for (int b = 0; b < DPE; b++) acc[a*DPE+b] = R.G[a][b];
+#pragma unroll
+        for (int e = 0; e < ND; e++) { acc[NG+e] = R.S1[e]; acc[NG+ND+e] = R.S2[e]; }
         // row-wise reduction; lane (e mod 16) of the row keeps entry e
         double mine[NREP];
 #pragma unroll
@@ -836,14 +979,14 @@ k_worklist_sorted(const DevProblem P, const int4 *__restrict__ sorted, const uns
 #pragma unroll
         for (int e = 0; e < NACC; e++) {
             const double s = row16_sum(acc[e]);
-            mine[e/16] = (sub == (e & 15)) ? s : mine[e/16];
+            mine[e/LPP] = (sub == (e & (LPP-1))) ? s : mine[e/LPP];
         }
         if (valid && SPARSE) {
             const double vv = 2.*P.cvol[c1]*P.cvol[c2]*kern_scale<KT>(P.k);
             const unsigned long long *mask = S.masks+4*(size_t)ent.x;
 #pragma unroll
             for (int rep = 0; rep < NREP; rep++) {
-                const int e = sub+16*rep;
+                const int e = sub+LPP*rep;
                 const double val = mine[rep];
                 if (e < NG) {
                     const int a = e/DPE, b = e-a*DPE;
@@ -862,7 +1005,7 @@ k_worklist_sorted(const DevProblem P, const int4 *__restrict__ sorted, const uns
             const double vv = 2.*P.cvol[c1]*P.cvol[c2]*kern_scale<KT>(P.k);
 #pragma unroll
             for (int rep = 0; rep < NREP; rep++) {
-                const int e = sub+16*rep;
+                const int e = sub+LPP*rep;
                 const double val = mine[rep];
                 if (e < NG) {
                     const int a = e/DPE, b = e-a*DPE;
@@ -870,6 +1013,97 @@ k_worklist_sorted(const DevProblem P, const int4 *__restrict__ sorted, const uns
                     if (I >= 0 && J >= 0) atomic_add_f64(&A[(long long)I*ldA+J], -vv*val);
                 } else if (e < NG+ND) atomic_add_f64(&Dglob[(size_t)c1*ND+(e-NG)], vv*val);
                 else if (e < NACC) atomic_add_f64(&Dglob[(size_t)c2*ND+(e-NG-ND)], vv*val);
+            }
+        }
+    }
+}
+
+// Distant pairs of the orders with at most PNL_WL_LANE_MAXPTS points, ONE PAIR PER LANE (NO:722-789): the list is sorted by
+// order, so all 64 pairs of a wave's chunk run the same trip counts (no divergence) and read the rule from the wave's own
+// LDS copy with broadcast reads; the factorised accumulation of eval_distant_fixed is used (x_i, row sums and u_b per i,
+// S2 directly per point pair), no cross-lane reduction.  Orders with more points (few pairs, thousands of point pairs each)
+// go to k_worklist_sorted, which spreads one pair over 16 lanes.
+#define PNL_WL_LANE_MAXPTS 40
+template <int DIM, int DPE, int KT, bool SPARSE>
+__global__ void __launch_bounds__(PNL_NTHREADS)
+k_worklist_lane(const DevProblem P, const int4 *__restrict__ sorted, const unsigned *__restrict__ offs, double *__restrict__ A,
+                long long ldA, double *__restrict__ Dglob, const SparseOut S, int dbg) {
+    constexpr int NV = DIM+1, NC = NV*DIM, ND = DPE*(DPE+1)/2, ST = 4+DPE, STP = (ST+1) & ~1;
+    __shared__ unsigned s_coff[PNL_WL_BINS+1];
+    __shared__ double s_rule_all[PNL_NTHREADS/64][PNL_WL_LANE_MAXPTS*STP];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) {
+        unsigned run = 0;
+        for (int q = 0; q < PNL_WL_BINS; q++) {
+            s_coff[q] = run;
+            const int n = (q >= 2 && q <= P.qmax && q <= PNL_MAXQ) ? P.off[q+1]-P.off[q] : 0;
+            if (n > 0 && n <= PNL_WL_LANE_MAXPTS) run += (offs[q+1]-offs[q]+63u)/64u;
+        }
+        s_coff[PNL_WL_BINS] = run;
+    }
+    __syncthreads();
+    const unsigned nchunks = s_coff[PNL_WL_BINS];
+    double *s_rule = s_rule_all[wave];
+    int staged_q = -1;
+    const unsigned nw = gridDim.x*(PNL_NTHREADS/64);
+    for (unsigned chunk = blockIdx.x*(PNL_NTHREADS/64)+wave; chunk < nchunks; chunk += nw) {
+        int lo = 0, hi = PNL_WL_BINS-1;
+        while (lo < hi) {
+            const int mid = (lo+hi+1) >> 1;
+            if (s_coff[mid] <= chunk) lo = mid; else hi = mid-1;
+        }
+        const int q = __builtin_amdgcn_readfirstlane(lo);
+        const unsigned first = offs[q]+64u*(chunk-s_coff[q]);
+        const int cnt = (int)min(64u, offs[q+1]-first);
+        const int off = P.off[q], n = P.off[q+1]-off;
+        if (q != staged_q) {
+            for (int t = lane; t < n*STP; t += 64) {
+                const int pt = t/STP, k = t-pt*STP;
+                s_rule[t] = k < 3 ? P.bary[3*(size_t)(off+pt)+k] : (k == 3 ? P.w[off+pt] : (k < ST ? P.phi[(size_t)(off+pt)*DPE+k-4] : 0.));
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            staged_q = q;
+        }
+        const bool valid = lane < cnt;
+        const int4 ent = sorted[first+(valid ? lane : 0)];
+        const int c1 = SPARSE ? S.pairs[2*(size_t)ent.x] : ent.x, c2 = SPARSE ? S.pairs[2*(size_t)ent.x+1] : ent.y;
+        double av[NC], bv[NC];
+#pragma unroll
+        for (int k = 0; k < NC; k++) { av[k] = P.cellv[(size_t)k*P.ncp+c1]; bv[k] = P.cellv[(size_t)k*P.ncp+c2]; }
+        PairAcc<DIM, DPE> R;
+        R.clear();
+        eval_distant_lds<DIM, DPE, KT>(P, s_rule, STP, (dbg & 4) ? 1 : n, av, bv, R);
+        if (!valid) continue;
+        const double vv = 2.*P.cvol[c1]*P.cvol[c2]*kern_scale<KT>(P.k);
+        int ld1[DPE], ld2[DPE];
+#pragma unroll
+        for (int a = 0; a < DPE; a++) { ld1[a] = P.cdof[(size_t)a*P.ncp+c1]; ld2[a] = P.cdof[(size_t)a*P.ncp+c2]; }
+        if (SPARSE) {
+            const unsigned long long *mask = S.masks+4*(size_t)ent.x;
+            int e = 0;
+#pragma unroll
+            for (int a = 0; a < DPE; a++) {
+#pragma unroll
+                for (int b = 0; b < DPE; b++) sparse_add_sym(S, mask, 2*DPE, a, DPE+b, ld1[a], ld2[b], -vv*R.G[a][b]);
+#pragma unroll
+                for (int b = a; b < DPE; b++) {
+                    sparse_add_sym(S, mask, 2*DPE, a, b, ld1[a], ld1[b], vv*R.S1[e]);
+                    sparse_add_sym(S, mask, 2*DPE, DPE+a, DPE+b, ld2[a], ld2[b], vv*R.S2[e]);
+                    e++;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int a = 0; a < DPE; a++)
+#pragma unroll
+                for (int b = 0; b < DPE; b++)
+                    if (ld1[a] >= 0 && ld2[b] >= 0 && !(dbg & 1)) atomic_add_f64(&A[(long long)ld1[a]*ldA+ld2[b]], -vv*R.G[a][b]);
+            if (!(dbg & 2))
+#pragma unroll
+            for (int e = 0; e < ND; e++) {
+                atomic_add_f64(&Dglob[(size_t)c1*ND+e], vv*R.S1[e]);
+                atomic_add_f64(&Dglob[(size_t)c2*ND+e], vv*R.S2[e]);
             }
         }
     }
