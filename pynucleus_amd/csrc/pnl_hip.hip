@@ -55,8 +55,15 @@ struct pnl_context {
     int tile = TILE_P1, nblocks = 0, ncp = 0, nU = 0;
     int n_spairs[3] = {0, 0, 0}, n_bpairs[2] = {0, 0};
     std::vector<int2> spairs_host[3];
-    std::vector<int2> tiles_cached;   // tile list currently resident in b_tiles
+    std::vector<int2> tiles_cached;   // tile list (as given by the caller) currently resident in b_tiles
     size_t tiles_cap = 0;
+    // b_tiles holds the mixed tiles first, then the uniform ones (all pairs distant with the lowest order)
+    int n_mixed = 0, n_pure = 0, tiles_cb = -1, tiles_ce = -1;
+    pnl_order_formula tiles_form;
+    bool tiles_filter = true;
+    bool use_pure = true;             // debug: PNL_PURE=0 sends every tile through the general kernel
+    struct BlockAgg { double cx, cy, rad, hmax, Lmin, Lmax; bool full; };
+    std::vector<BlockAgg> blocks;
     hipEvent_t ev[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     bool ev_valid = false;
     unsigned long long visited_pairs = 0;
@@ -299,6 +306,25 @@ int finalize(pnl_context *ctx) {
         std::vector<double> clog((size_t)2*ncp, 0.);
         for (int c = 0; c < ncp; c++) { clog[c] = std::log(ch[c]); clog[(size_t)ncp+c] = std::fabs(std::log(ch[c]/ctx->H0)); }
         if ((rc = upload(ctx, ctx->b_clog, clog.data(), clog.size()))) return rc;
+        // per-block aggregates for the host-side tile classification (uniform tiles)
+        ctx->blocks.assign(nblocks, pnl_context::BlockAgg{0., 0., 0., 0., 0., 0., false});
+        for (int b = 0; b < nblocks; b++) {
+            auto &B = ctx->blocks[b];
+            const int c0 = b*T, c1 = std::min(nc, (b+1)*T);
+            B.full = (c1-c0 == T);
+            double sx = 0., sy = 0.;
+            for (int c = c0; c < c1; c++) { sx += ccen[c]; if (dim == 2) sy += ccen[(size_t)ncp+c]; }
+            B.cx = sx/(c1-c0); B.cy = sy/(c1-c0);
+            B.rad = 0.; B.hmax = 0.; B.Lmin = 1e300; B.Lmax = -1e300;
+            for (int c = c0; c < c1; c++) {
+                const double dx = ccen[c]-B.cx, dy = dim == 2 ? ccen[(size_t)ncp+c]-B.cy : 0.;
+                B.rad = std::max(B.rad, std::sqrt(dx*dx+dy*dy));
+                B.hmax = std::max(B.hmax, ch[c]);
+                B.Lmin = std::min(B.Lmin, clog[(size_t)ncp+c]);
+                B.Lmax = std::max(B.Lmax, clog[(size_t)ncp+c]);
+            }
+        }
+        ctx->tiles_cached.clear(); ctx->tiles_cb = -1;
     }
     if ((rc = upload(ctx, ctx->b_cvid, cvid.data(), cvid.size()))) return rc;
     if ((rc = upload(ctx, ctx->b_cdof, cdof.data(), cdof.size()))) return rc;
@@ -350,10 +376,45 @@ void refresh_tables(pnl_context *ctx) {
     }
 }
 
+// row stride of the LDS sub-block: nU + 1 columns (+1: trash column / row for boundary DoFs); PNL_ACC_PAD=m rounds it up
+// to 1 mod m so that consecutive rows start in different LDS banks
+int acc_stride_of(int nU) {
+    int st = nU+1;
+    const int m = getenv("PNL_ACC_PAD") ? atoi(getenv("PNL_ACC_PAD")) : 0;
+    if (m > 1) while (st % m != 1) st++;
+    return st;
+}
+
+template <int DIM, int DPE, int KT>
+int launch_pure(pnl_context *ctx, double *A, int64_t ldA) {
+    if (ctx->n_pure == 0) return PNL_OK;
+    constexpr int NP = DIM == 2 ? 3 : 2, ND = DPE*(DPE+1)/2;
+    const int acc_stride = acc_stride_of(ctx->nU);
+    const size_t lds = sizeof(double)*(64*NP*DIM+64+2*64*ND+NP*(4+DPE))+sizeof(int)*(64*DPE+64)
+                       +sizeof(double)*(size_t)(ctx->nU+1)*acc_stride;
+    auto kfun = k_tile_pure<DIM, DPE, KT>;
+    HIPCHK(ctx, hipFuncSetAttribute((const void*)kfun, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    int per_cu = 2;
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)kfun, PNL_NTHREADS, lds);
+    if (getenv("PNL_VERBOSE")) fprintf(stderr, "[pnl] uniform tiles=%d of %d, lds=%zu bytes, occupancy API: %d blocks/CU\n", ctx->n_pure,
+                                       ctx->n_pure+ctx->n_mixed, lds, per_cu);
+    const int grid = std::min(ctx->n_pure, 256*std::max(per_cu, 1));
+    hipLaunchKernelGGL(kfun, dim3(grid), dim3(PNL_NTHREADS), lds, ctx->stream, ctx->P, (const int2*)ctx->b_tiles.p+ctx->n_mixed,
+                       ctx->n_pure, A, (long long)ldA, (double*)ctx->b_D.p, acc_stride, 2);
+    HIPCHK(ctx, hipGetLastError());
+    return PNL_OK;
+}
+
 template <int DIM, int DPE, int TILE, int KT>
-int launch_tiles(pnl_context *ctx, int ntiles, double *A, int64_t ldA, int cell_begin, int cell_end) {
+int launch_tiles(pnl_context *ctx, int ntiles_all, double *A, int64_t ldA, int cell_begin, int cell_end) {
     using S = TileSmem<DIM, DPE, TILE>;
-    const int acc_stride = ctx->nU+1;            // +1: trash column / row for boundary DoFs
+    if (TILE == 64 && DPE <= 3) {
+        int rc = launch_pure<DIM, (DPE <= 3 ? DPE : 3), KT>(ctx, A, ldA);
+        if (rc) return rc;
+    }
+    const int ntiles = ctx->n_mixed;
+    (void)ntiles_all;
+    const int acc_stride = acc_stride_of(ctx->nU);
     const size_t lds = S::fixed_bytes+sizeof(double)*(size_t)(ctx->nU+1)*acc_stride;
     if (getenv("PNL_VERBOSE")) {
         int nblk = -1;
@@ -383,9 +444,10 @@ int launch_tiles(pnl_context *ctx, int ntiles, double *A, int64_t ldA, int cell_
     (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)kfun, PNL_NTHREADS, lds);
     const int grid_mult = getenv("PNL_GRID_MULT") ? atoi(getenv("PNL_GRID_MULT")) : 1;
     const int grid = std::min(ntiles, 256*std::max(per_cu, 1)*std::max(grid_mult, 1));
-    hipLaunchKernelGGL(kfun, dim3(grid), dim3(PNL_NTHREADS), lds, ctx->stream, ctx->P, (const int2*)ctx->b_tiles.p, A,
-                       (long long)ldA, (double*)ctx->b_D.p, cell_begin, cell_end, acc_stride, (int4*)ctx->b_wl.p,
-                       (unsigned*)ctx->b_wlcount.p, ctx->wl_cap, ctx->ablate, ntiles);
+    if (grid > 0)
+        hipLaunchKernelGGL(kfun, dim3(grid), dim3(PNL_NTHREADS), lds, ctx->stream, ctx->P, (const int2*)ctx->b_tiles.p, A,
+                           (long long)ldA, (double*)ctx->b_D.p, cell_begin, cell_end, acc_stride, (int4*)ctx->b_wl.p,
+                           (unsigned*)ctx->b_wlcount.p, ctx->wl_cap, ctx->ablate, ntiles);
     HIPCHK(ctx, hipGetLastError());
     HIPCHK(ctx, hipEventRecord(ctx->ev[6], ctx->stream));
     {
@@ -743,6 +805,7 @@ int pnl_create(int device_id, pnl_context **out) {
     std::memset(&ctx->P, 0, sizeof(ctx->P));
     if (const char *e = getenv("PNL_ABLATE")) ctx->ablate = atoi(e);
     if (const char *e = getenv("PNL_WL_LANE")) ctx->wl_lane = atoi(e) != 0;
+    if (const char *e = getenv("PNL_PURE")) ctx->use_pure = atoi(e) != 0;
     std::memset(ctx->kern, 0, sizeof(ctx->kern));
     std::memset(ctx->form, 0, sizeof(ctx->form));
     *out = ctx;
@@ -915,14 +978,53 @@ int pnl_tile_cells(pnl_context *ctx) {
     return rc ? rc : ctx->tile;
 }
 
-static int upload_tiles(pnl_context *ctx, std::vector<int2> &tiles) {
+// Is every cell pair of the tile (block a, block b) a distant pair of order 2?  Conservative bound on the order formula
+// (FL2:622-642 / FL1:234-253): with d >= dmin = |centre_a - centre_b| - rad_a - rad_b (distance of cell centres),
+// h <= hmax and L = |ln(h/H0)| in [Lmin, Lmax] per block,
+//   (c0 + a L_other + b Lmax - e ln(d/h_other)) / (max(ln(d/h_self), 0) + den0)  <=  num_max / den_min,
+// and ceil(.) <= 2 for both roles makes the order max(., 2) = 2 exactly.  dmin > hmax_a + hmax_b also rules out shared
+// vertices (a vertex is closer than 2/3 h to its cell's centre).  Anything not provably uniform goes to the general kernel.
+static bool tile_is_uniform(const pnl_context *ctx, const pnl_order_formula &F, int ta, int tb) {
+    if (ta == tb) return false;
+    const auto &A = ctx->blocks[ta], &B = ctx->blocks[tb];
+    if (!A.full || !B.full || !(F.e >= 0.) || !(F.den0 > 0.)) return false;
+    const double dx = A.cx-B.cx, dy = A.cy-B.cy;
+    const double dmin = std::sqrt(dx*dx+dy*dy)-A.rad-B.rad;
+    if (!(dmin > A.hmax+B.hmax)) return false;
+    auto bound = [&](const pnl_context::BlockAgg &S, const pnl_context::BlockAgg &O) {
+        const double l_self = std::log(dmin/S.hmax), n_other = std::log(dmin/O.hmax);      // both > 0
+        const double aL = std::max(F.a*O.Lmin, F.a*O.Lmax);
+        const double bL = std::max(F.b*std::max(S.Lmin, O.Lmin), F.b*std::max(S.Lmax, O.Lmax));
+        const double num = F.c0+aL+bL-F.e*n_other, den = l_self+F.den0;
+        return num <= 2.*den*(1.-1e-9)-1e-9;
+    };
+    return bound(A, B) && bound(B, A);
+}
+
+static int upload_tiles(pnl_context *ctx, std::vector<int2> &tiles, int cell_begin, int cell_end) {
     // repeated assemblies of the same work list keep it resident
-    if (tiles.size() == ctx->tiles_cached.size() && ctx->b_tiles.p &&
+    const pnl_order_formula &F = ctx->form[0];
+    if (tiles.size() == ctx->tiles_cached.size() && ctx->b_tiles.p && ctx->tiles_cb == cell_begin && ctx->tiles_ce == cell_end &&
+        std::memcmp(&F, &ctx->tiles_form, sizeof(F)) == 0 && ctx->tiles_filter == ctx->tile_cell_filter &&
         (tiles.empty() || std::memcmp(tiles.data(), ctx->tiles_cached.data(), tiles.size()*sizeof(int2)) == 0))
         return PNL_OK;
-    int rc = upload(ctx, ctx->b_tiles, tiles.data(), tiles.size());
+    const int T = ctx->tile;
+    const bool filter = ctx->tile_cell_filter;
+    const bool allow = ctx->use_pure && T == 64 && (ctx->dpe == 3 || ctx->dpe == 2) && ctx->qmax >= 2;
+    std::vector<int2> mixed, pure;
+    for (const int2 &t : tiles) {
+        bool u = allow && tile_is_uniform(ctx, F, t.x, t.y);
+        // the cell range of the MPI-style split applies to the a-cells: only blocks entirely inside qualify
+        if (u && filter && !(t.x*T >= cell_begin && (t.x+1)*T <= cell_end)) u = false;
+        (u ? pure : mixed).push_back(t);
+    }
+    std::vector<int2> all(mixed);
+    all.insert(all.end(), pure.begin(), pure.end());
+    int rc = upload(ctx, ctx->b_tiles, all.data(), all.size());
     if (rc) return rc;
-    ctx->tiles_cached = tiles;
+    ctx->n_mixed = (int)mixed.size(); ctx->n_pure = (int)pure.size();
+    ctx->tiles_cached = tiles; ctx->tiles_cb = cell_begin; ctx->tiles_ce = cell_end; ctx->tiles_form = F;
+    ctx->tiles_filter = ctx->tile_cell_filter;
     return PNL_OK;
 }
 
@@ -944,7 +1046,7 @@ int pnl_assemble_dense(pnl_context *ctx, double *A, int64_t ldA, int zero_exteri
     if (cell_begin < 0 || cell_end > ctx->nc || cell_begin > cell_end) return fail(ctx, PNL_ERR_INVALID, "bad cell range");
     std::vector<int2> tiles;
     if (cell_end > cell_begin) make_tiles(ctx, tiles, cell_begin, cell_end);
-    if ((rc = upload_tiles(ctx, tiles))) return rc;
+    if ((rc = upload_tiles(ctx, tiles, cell_begin, cell_end))) return rc;
     // pairs visited by the reference loop: c1 in [begin,end), c2 in [c1, nc)
     unsigned long long visited = 0;
     for (long long c = cell_begin; c < cell_end; c++) visited += (unsigned long long)(ctx->nc-c);
@@ -965,9 +1067,9 @@ int pnl_assemble_dense_tiles(pnl_context *ctx, double *A, int64_t ldA, int zero_
         tiles[i] = make_int2(tiles_host[2*i], tiles_host[2*i+1]);
         if (tiles[i].x < 0 || tiles[i].y >= ctx->nblocks || tiles[i].x > tiles[i].y) return fail(ctx, PNL_ERR_INVALID, "bad tile %d", i);
     }
-    if ((rc = upload_tiles(ctx, tiles))) return rc;
-    ctx->visited_pairs = 0;
     ctx->tile_cell_filter = false;
+    if ((rc = upload_tiles(ctx, tiles, cell_begin, cell_end))) { ctx->tile_cell_filter = true; return rc; }
+    ctx->visited_pairs = 0;
     rc = dispatch(ctx, A, ldA, zero_exterior, ntiles, cell_begin, cell_end, flags);
     ctx->tile_cell_filter = true;
     return rc;

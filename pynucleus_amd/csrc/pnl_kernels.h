@@ -715,6 +715,220 @@ __device__ __forceinline__ double row16_sum(double v) {
     return v;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Uniform tiles: every one of the 64 x 64 cell pairs of the tile is a distant pair of the lowest order (host-side
+// conservative bound on the order formula over the two blocks, see classify_tiles in pnl_hip.hip) -- two thirds of all
+// pairs at noRef 6, more on finer meshes.  No classification, no lists: lane = cell i of block a, the four waves split the
+// cells j of block b, so everything that depends on j alone (its quadrature points, volume, DoF slots) is a broadcast LDS
+// read, the points of cell i and the row sums that feed its diagonal block stay in registers for the whole tile, and the
+// column sums are reduced over the wave with DPP.  Same numbers as eval_distant_fixed (NO:722-789), same LDS sub-block.
+template <int DIM, int DPE, int KT>
+__global__ void __launch_bounds__(PNL_NTHREADS, 3)
+k_tile_pure(const DevProblem P, const int2 *__restrict__ tiles, int ntiles, double *__restrict__ A, long long ldA,
+            double *__restrict__ Dglob, int acc_stride, int q_uniform) {
+    constexpr int TILE = 64, NV = DIM+1, NC = NV*DIM, ND = DPE*(DPE+1)/2, NP = (DIM == 2) ? 3 : 2, ST = 4+DPE;
+    constexpr int JW = TILE/(PNL_NTHREADS/64);          // cells j per wave
+    extern __shared__ double smem[];
+    double *s_y = smem;                                 // [TILE][NP*DIM] quadrature points of the b-cells
+    double *s_volb = s_y+TILE*NP*DIM;                   // [TILE]
+    double *s_Da = s_volb+TILE;                         // [TILE][ND]
+    double *s_Db = s_Da+TILE*ND;                        // [TILE][ND]
+    double *s_rule = s_Db+TILE*ND;                      // [NP][ST]
+    int *s_slotb = (int*)(s_rule+NP*ST);                // [TILE][DPE] (+ [TILE] has-DoF flags)
+    int *s_hb = s_slotb+TILE*DPE;
+    double *s_acc = (double*)(s_hb+TILE);               // [nA+1][acc_stride]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    {
+        const int off = P.off[q_uniform];
+        for (int t = tid; t < NP*ST; t += PNL_NTHREADS) {
+            const int pt = t/ST, k = t-pt*ST;
+            s_rule[t] = k < 3 ? P.bary[3*(size_t)(off+pt)+k] : (k == 3 ? P.w[off+pt] : P.phi[(size_t)(off+pt)*DPE+k-4]);
+        }
+    }
+    __syncthreads();
+    // rule in registers: weights products, shape functions at the points
+    double ww[NP][NP], ph[NP][DPE], bary[NP][NV];
+#pragma unroll
+    for (int i = 0; i < NP; i++) {
+#pragma unroll
+        for (int j = 0; j < NP; j++) ww[i][j] = s_rule[i*ST+3]*s_rule[j*ST+3];
+#pragma unroll
+        for (int a = 0; a < DPE; a++) ph[i][a] = s_rule[i*ST+4+a];
+#pragma unroll
+        for (int k = 0; k < NV; k++) bary[i][k] = s_rule[i*ST+k];
+    }
+    const double scale2 = 2.*kern_scale<KT>(P.k);
+    unsigned long long npairs = 0;
+#pragma unroll 1
+    for (int tile_idx = blockIdx.x; tile_idx < ntiles; tile_idx += gridDim.x) {
+        const int2 tl = tiles[tile_idx];
+        const int ta = tl.x, tb = tl.y;
+        const int nA = P.blk_ndof[ta], nB = P.blk_ndof[tb];
+        __syncthreads();                                 // the previous tile's flush is done with the LDS buffers
+        if (tid < TILE) {
+            const int c = tb*TILE+tid;
+            double bv[NC];
+#pragma unroll
+            for (int k = 0; k < NC; k++) bv[k] = P.cellv[(size_t)k*P.ncp+c];
+#pragma unroll
+            for (int jp = 0; jp < NP; jp++)
+#pragma unroll
+                for (int d = 0; d < DIM; d++) {
+                    double sy = 0.;
+#pragma unroll
+                    for (int k = 0; k < NV; k++) sy = __builtin_fma(bary[jp][k], bv[k*DIM+d], sy);
+                    s_y[tid*NP*DIM+jp*DIM+d] = sy;
+                }
+            s_volb[tid] = P.cvol[c];
+            int any = 0;
+#pragma unroll
+            for (int k = 0; k < DPE; k++) {
+                const int sl = P.cslot[(size_t)k*P.ncp+c];
+                s_slotb[tid*DPE+k] = sl >= 0 ? sl : nB;
+                any |= (sl >= 0);
+            }
+            s_hb[tid] = any;
+        }
+        for (int t = tid; t < (nA+1)*acc_stride; t += PNL_NTHREADS) s_acc[t] = 0.;
+        for (int t = tid; t < 2*TILE*ND; t += PNL_NTHREADS) s_Da[t] = 0.;
+        // a side: lane = cell i
+        const int ca = ta*TILE+lane;
+        double x[NP][DIM];
+        {
+            double av[NC];
+#pragma unroll
+            for (int k = 0; k < NC; k++) av[k] = P.cellv[(size_t)k*P.ncp+ca];
+#pragma unroll
+            for (int ip = 0; ip < NP; ip++)
+#pragma unroll
+                for (int d = 0; d < DIM; d++) {
+                    double sx = 0.;
+#pragma unroll
+                    for (int k = 0; k < NV; k++) sx = __builtin_fma(bary[ip][k], av[k*DIM+d], sx);
+                    x[ip][d] = sx;
+                }
+        }
+        int sa[DPE];
+        bool ha = false;
+#pragma unroll
+        for (int k = 0; k < DPE; k++) {
+            const int sl = P.cslot[(size_t)k*P.ncp+ca];
+            sa[k] = (sl >= 0 ? sl : nA)*acc_stride;
+            ha = ha || sl >= 0;
+        }
+        const double vola = P.cvol[ca];
+        double rr[NP];                                   // sum_j vol_j * (row sums of K): feeds the diagonal block of cell i
+#pragma unroll
+        for (int ip = 0; ip < NP; ip++) rr[ip] = 0.;
+        __syncthreads();
+#pragma unroll 1
+        for (int jj = 0; jj < JW; jj++) {
+            const int j = wave*JW+jj;
+            double y[NP][DIM];
+#pragma unroll
+            for (int jp = 0; jp < NP; jp++)
+#pragma unroll
+                for (int d = 0; d < DIM; d++) y[jp][d] = s_y[j*NP*DIM+jp*DIM+d];
+            const bool valid = ha || (s_hb[j] != 0);     // NA:138-150: pairs with boundary DoFs only are skipped
+            npairs += (unsigned long long)__popcll(__ballot(valid));
+            const double volb = valid ? s_volb[j] : 0.;
+            double c[NP], G[DPE][DPE];
+#pragma unroll
+            for (int jp = 0; jp < NP; jp++) c[jp] = 0.;
+#pragma unroll
+            for (int a = 0; a < DPE; a++)
+#pragma unroll
+                for (int b = 0; b < DPE; b++) G[a][b] = 0.;
+#pragma unroll
+            for (int ip = 0; ip < NP; ip++) {
+                double r = 0., u[DPE];
+#pragma unroll
+                for (int b = 0; b < DPE; b++) u[b] = 0.;
+#pragma unroll
+                for (int jp = 0; jp < NP; jp++) {
+                    double d2 = 0.;
+#pragma unroll
+                    for (int d = 0; d < DIM; d++) { const double t = x[ip][d]-y[jp][d]; d2 = __builtin_fma(t, t, d2); }
+                    const double K = ww[ip][jp]*kern_eval<KT>(P.k, d2);
+                    r += K;
+                    c[jp] += K;
+#pragma unroll
+                    for (int b = 0; b < DPE; b++) u[b] = __builtin_fma(K, ph[jp][b], u[b]);
+                }
+                rr[ip] = __builtin_fma(volb, r, rr[ip]);
+#pragma unroll
+                for (int a = 0; a < DPE; a++)
+#pragma unroll
+                    for (int b = 0; b < DPE; b++) G[a][b] = __builtin_fma(ph[ip][a], u[b], G[a][b]);
+            }
+            // cross block -> LDS sub-block of A'
+            const double vv = scale2*vola*volb;
+#pragma unroll
+            for (int b = 0; b < DPE; b++) {
+                const int sb = s_slotb[j*DPE+b];
+#pragma unroll
+                for (int a = 0; a < DPE; a++) lds_add_f64(&s_acc[sa[a]+sb], -vv*G[a][b]);
+            }
+            // diagonal block of cell j: column sums over all cells i of the wave
+            const double wa = valid ? vola : 0.;
+            double cw[NP];
+#pragma unroll
+            for (int jp = 0; jp < NP; jp++) cw[jp] = wave_sum(wa*c[jp]);
+            if (lane < ND) {
+                int a = 0, idx = lane;
+                while (idx >= DPE-a) { idx -= DPE-a; a++; }
+                const int b = a+idx;
+                double s2 = 0.;
+#pragma unroll
+                for (int jp = 0; jp < NP; jp++) {
+                    double pa = 0., pb = 0.;
+#pragma unroll
+                    for (int k = 0; k < DPE; k++) { pa = (a == k) ? ph[jp][k] : pa; pb = (b == k) ? ph[jp][k] : pb; }
+                    s2 = __builtin_fma(pa*pb, cw[jp], s2);
+                }
+                s_Db[j*ND+lane] = scale2*s_volb[j]*s2;       // this wave owns cell j: plain store
+            }
+        }
+        // diagonal block of cell i from the accumulated row sums (the four waves hold partial sums over their j's)
+        {
+            int e = 0;
+#pragma unroll
+            for (int a = 0; a < DPE; a++)
+#pragma unroll
+                for (int b = a; b < DPE; b++) {
+                    double s1 = 0.;
+#pragma unroll
+                    for (int ip = 0; ip < NP; ip++) s1 = __builtin_fma(ph[ip][a]*ph[ip][b], rr[ip], s1);
+                    lds_add_f64(&s_Da[lane*ND+e], scale2*vola*s1);
+                    e++;
+                }
+        }
+        __syncthreads();
+        // ---- flush ----
+        const int *__restrict__ dofA = P.blk_dofs+(size_t)ta*P.blk_stride;
+        const int *__restrict__ dofB = P.blk_dofs+(size_t)tb*P.blk_stride;
+        for (int t = tid; t < nA*nB; t += PNL_NTHREADS) {
+            const int r = t/nB, cc = t-r*nB;
+            const double v = s_acc[r*acc_stride+cc];
+            if (v != 0.) atomic_add_f64(&A[(long long)dofA[r]*ldA+dofB[cc]], v);
+        }
+        for (int t = tid; t < 2*TILE*ND; t += PNL_NTHREADS) {
+            const double v = s_Da[t];
+            if (v != 0.) {
+                const int side = t/(TILE*ND), rem = t-side*TILE*ND;
+                const int cc = (side ? tb : ta)*TILE+rem/ND;
+                atomic_add_f64(&Dglob[(size_t)cc*ND+rem%ND], v);
+            }
+        }
+    }
+    // statistics: every lane of a wave holds the same count
+    if (lane == 0 && npairs) {
+        atomicAdd(&P.counters[8+q_uniform], npairs);
+        atomicAdd(&P.counters[1], npairs);
+        atomicAdd(&P.counters[2], npairs*(unsigned long long)(NP*NP));
+    }
+}
+
 // ---- sparse output (H2 near field, NA:1663-1964) -------------------------------------------------------------------
 // CSR or SSS target with the reference's addToEntry semantics (CSR_LinearOperator_{SCALAR}.pxi:150-170,
 // SSS_LinearOperator_{SCALAR}.pxi:104-130): binary search in the row, entries that are not in the pattern are dropped;
