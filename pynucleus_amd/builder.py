@@ -141,9 +141,39 @@ class nonlocalBuilder:
         return tiles_of_rank(self.mesh.num_cells, T, rank, size)
 
     def getDiagonal(self):
-        """NA:2269-2289: the diagonal through cluster pairs of single DoFs; here one masked assembly into a
-        diagonal-only SSS pattern (every element pair that shares a DoF contributes)"""
-        raise NotImplementedError('getDiagonal: assemble the dense operator and take .diagonal')
+        """NA:2269-2289 / getDiagonalCluster NA:2291-2309: the diagonal through the cluster pairs ({I}, {I}) -- element
+        pairs inside the support of phi_I plus the Gauss-theorem term over the boundary of the support.  One masked
+        assembly on the GPU into a diagonal-only SSS pattern; returns the diagonal as a numpy vector wrapped like the
+        reference's diagonalOperator (``.data``, ``.diagonal``)."""
+        from . import clusters
+        from .linear_operators import diagonalOperator
+        Pnear = clusters.singleDoFClusters(self.dm)
+        Anear = self.assembleClusters(Pnear, _globalBoundary=False, _clusterBoundary=self.zeroExterior)
+        return diagonalOperator(Anear.diagonal)
+
+    def getEntry(self, I, J):
+        """NA:1538-1661: the entry A[I, J] alone: element pairs of (supp phi_I u supp phi_J)^2 and, with zeroExterior,
+        the Gauss-theorem term over the boundary of that union, assembled on the GPU into a one-entry pattern."""
+        import torch
+        from . import clusters
+        from .linear_operators import CSR_LinearOperator
+        assert not self.kernel.finiteHorizon
+        dm = self.dm
+        _, d2c = clusters.getDoFBoxesAndCells(dm)
+        if I == J:
+            n = clusters.dofClusterNode(dm, [I], d2c)
+            Pnear = [clusters.nearFieldClusterPair(n, n)]
+        else:
+            n1, n2 = clusters.dofClusterNode(dm, [I], d2c), clusters.dofClusterNode(dm, [J], d2c)
+            Pnear = [clusters.nearFieldClusterPair(n1, n2), clusters.nearFieldClusterPair(n2, n1)]
+        for cp in Pnear:
+            cp.set_cells()
+        ctx = self.context()
+        indptr = np.zeros(dm.num_dofs+1, dtype=np.int32)
+        indptr[I+1:] = 1
+        A = CSR_LinearOperator(indptr, np.array([J], dtype=np.int32), dm.num_dofs, ctx, torch.device('cuda', ctx.device))
+        self.assembleClusters(Pnear, Anear=A, _globalBoundary=False, _clusterBoundary=self.zeroExterior)
+        return float(A.data[0])
 
     def getSparse(self, returnNearField=False):
         raise NotImplementedError('finite-horizon sparse assembly is not implemented on the GPU path yet')
@@ -163,8 +193,16 @@ class nonlocalBuilder:
         from . import clusters
         rp = self.getH2RefinementParams()
         root, Pnear, Pfar = clusters.getNearFieldClusters(self.dm, rp['eta'], rp['minSize'], rp['maxLevels'])
+        rank, size = self._rank_size()
         if sum(len(v) for v in Pfar.values()) == 0:
             h2 = self.getDense()
+        elif returnNearField and size > 1:
+            # row-sharded near field: this rank's cluster pairs into its own unsymmetric CSR, matvec = local SpMV +
+            # all-reduce of the N-vector (DistributedH2Matrix_globalData, clusterMethodCy.pyx:3127-3154)
+            from .linear_operators import DistributedSparse_LinearOperator
+            mine = clusters.partitionClusterPairs(Pnear, size)[rank]
+            local = self.assembleClusters([Pnear[k] for k in mine], forceUnsymmetricMatrix=True, _symmetrizeMasks=True)
+            h2 = DistributedSparse_LinearOperator(local, None if self.comm is True else self.comm)
         elif returnNearField:
             h2 = self.assembleClusters(Pnear)
         else:
@@ -177,7 +215,8 @@ class nonlocalBuilder:
             out += (root,)
         return out if len(out) > 1 else out[0]
 
-    def assembleClusters(self, Pnear, forceUnsymmetricMatrix=False, Anear=None, jumps={}, myRoot=None, **kwargs):
+    def assembleClusters(self, Pnear, forceUnsymmetricMatrix=False, Anear=None, jumps={}, myRoot=None, _clusterBoundary=True,
+                         _globalBoundary=True, _symmetrizeMasks=False, **kwargs):
         """Near-field matrix of the cluster pairs Pnear (NA:1663-1964), assembled on the GPU.
 
         Host side: sparsity pattern (getSparseNearField NA:3226-3289), per element-pair 256-bit entry masks
@@ -205,7 +244,7 @@ class nonlocalBuilder:
         hist, sing = {}, {}
         ms_total = 0.
         # element pairs in chunks of cluster pairs like the reference's maxMasksNNZ loop (NA:1786-1791)
-        for pairs, masks in clusters.iterMasksForClusters(dm, Pnear, maxNNZ):
+        for pairs, masks in clusters.iterMasksForClusters(dm, Pnear, maxNNZ, symmetrize=_symmetrizeMasks):
             ctx.assemble_pairs_masked(pairs, masks, data_ptr, diag_ptr)
             cnt = ctx.counters()
             for k in totals:
@@ -216,11 +255,11 @@ class nonlocalBuilder:
                 sing[q] = sing.get(q, 0)+c
             ms_total += ctx.phase_ms()['total']
         nitems = 0
-        if self.tables.has_boundary_tables and not self.kernel.variable:
-            cells, facets, bmasks = clusters.clusterBoundaryItems(dm, Pnear)
+        if self.tables.has_boundary_tables and not self.kernel.variable and _clusterBoundary:
+            cells, facets, bmasks = clusters.clusterBoundaryItems(dm, Pnear, symmetrize=_symmetrizeMasks)
             nitems = int(cells.shape[0])
             ctx.assemble_boundary_masked(cells, facets, bmasks, 1., data_ptr, diag_ptr)
-            if not self.zeroExterior:
+            if not self.zeroExterior and _globalBoundary:
                 cells, facets, bmasks = clusters.globalBoundaryItems(dm, self.tables.bcells)
                 nitems += int(cells.shape[0])
                 ctx.assemble_boundary_masked(cells, facets, bmasks, -1., data_ptr, diag_ptr)

@@ -212,8 +212,9 @@ def elemElemSymMaskTable(dpe):
     return k
 
 
-def _masksOfClusterPair(dm, cp, ktab):
-    """(keys = c1*nc + c2 with c1 <= c2, mask words) requested by one near-field cluster pair"""
+def _masksOfClusterPair(dm, cp, ktab, symmetrize=False):
+    """(keys = c1*nc + c2 with c1 <= c2, mask words) requested by one near-field cluster pair; symmetrize also requests
+    the entries of the transposed pair (n2, n1) -- see partitionClusterPairs"""
     dpe = dm.dofs_per_element
     nc = dm.mesh.num_cells
     E = (2*dpe)*(2*dpe+1)//2
@@ -242,7 +243,10 @@ def _masksOfClusterPair(dm, cp, ktab):
     for p in range(2*dpe):
         for q in range(p, 2*dpe):
             k = int(ktab[p, q])
-            words[:, k//64] |= (cm1[:, p] & cm2[:, q]).astype(np.uint64) << np.uint64(k % 64)
+            bit = cm1[:, p] & cm2[:, q]
+            if symmetrize:
+                bit = bit | (cm2[:, p] & cm1[:, q])
+            words[:, k//64] |= bit.astype(np.uint64) << np.uint64(k % 64)
     assert E <= 256
     return a.astype(np.int64)*nc+b, words
 
@@ -258,7 +262,7 @@ def _mergeMasks(keys, masks, nc):
     return np.ascontiguousarray(pairs), np.ascontiguousarray(merged)
 
 
-def iterMasksForClusters(dm, Pnear, maxNNZ=10000000):
+def iterMasksForClusters(dm, Pnear, maxNNZ=10000000, symmetrize=False):
     """yields (pairs[np, 2] with c1 <= c2, masks[np, 4] uint64) for consecutive groups of cluster pairs holding about
     maxNNZ element pairs each -- the reference's chunked loop NA:1786-1791 over buildMasksForClusters NA:260-391
     (symmetric cells and local matrix): which entries of the symmetric local matrix of each element pair are requested
@@ -267,7 +271,7 @@ def iterMasksForClusters(dm, Pnear, maxNNZ=10000000):
     ktab = elemElemSymMaskTable(dm.dofs_per_element)
     keys, masks, n = [], [], 0
     for cp in Pnear:
-        k, m = _masksOfClusterPair(dm, cp, ktab)
+        k, m = _masksOfClusterPair(dm, cp, ktab, symmetrize)
         keys.append(k)
         masks.append(m)
         n += k.shape[0]
@@ -278,9 +282,9 @@ def iterMasksForClusters(dm, Pnear, maxNNZ=10000000):
         yield _mergeMasks(keys, masks, nc)
 
 
-def buildMasksForClusters(dm, Pnear):
+def buildMasksForClusters(dm, Pnear, symmetrize=False):
     """all cluster pairs in one group"""
-    out = list(iterMasksForClusters(dm, Pnear, maxNNZ=1 << 62))
+    out = list(iterMasksForClusters(dm, Pnear, maxNNZ=1 << 62, symmetrize=symmetrize))
     if not out:
         return np.zeros((0, 2), dtype=np.int32), np.zeros((0, 4), dtype=np.uint64)
     return out[0]
@@ -300,7 +304,7 @@ def boundaryFacetsOfCells(mesh, cellIds):
     return ids[counts == 1].astype(np.int32).reshape(-1, 1)
 
 
-def clusterBoundaryItems(dm, Pnear):
+def clusterBoundaryItems(dm, Pnear, symmetrize=False):
     """work list of the cluster-local Gauss-theorem term (NA:1842-1889): for every near-field pair with common cells,
     (cell in cellsInter) x (facet of the boundary of cellsUnion) with the mask of the local entries whose DoFs lie in
     (n1, n2) -- getElemSymMaskCluster NA:463-478.  Returns cells[ni], facets[ni, dim], masks[ni] (uint32 bit field over
@@ -308,10 +312,13 @@ def clusterBoundaryItems(dm, Pnear):
     mesh = dm.mesh
     dpe = dm.dofs_per_element
     out_c, out_f, out_m = [], [], []
+    # items are not OR-merged like the element pairs: symmetrise only the pairs whose transposed pair is not in the list
+    have = {(id(cp.n1), id(cp.n2)) for cp in Pnear}
     for cp in Pnear:
         ci = cp.cellsInter
         if ci.shape[0] == 0:
             continue
+        sym = symmetrize and (id(cp.n2), id(cp.n1)) not in have
         facets = boundaryFacetsOfCells(mesh, cp.cellsUnion)
         in1 = np.zeros(dm.num_dofs+1, dtype=bool)
         in2 = np.zeros(dm.num_dofs+1, dtype=bool)
@@ -323,7 +330,10 @@ def clusterBoundaryItems(dm, Pnear):
         k = 0
         for p in range(dpe):
             for q in range(p, dpe):
-                mask |= ((m1[:, p] & m2[:, q]).astype(np.uint32) << np.uint32(k))
+                bit = m1[:, p] & m2[:, q]
+                if sym:
+                    bit = bit | (m2[:, p] & m1[:, q])
+                mask |= (bit.astype(np.uint32) << np.uint32(k))
                 k += 1
         keep = mask != 0
         ci, mask = ci[keep], mask[keep]
@@ -366,3 +376,61 @@ def allLeafPairs(dm, maxLevels, minSize=1):
     for cp in Pnear:
         cp.set_cells()
     return root, Pnear
+
+
+def dofClusterNode(dm, dofs, d2c=None):
+    """a tree node holding the given DoFs and the cells of their supports, without boxes (getEntryCluster NA:2317-2360)"""
+    n = tree_node.__new__(tree_node)
+    n.parent, n.children, n.levelNo = None, [], 0
+    n.dofs = np.sort(np.asarray(dofs, dtype=np.int32))
+    n.box = None
+    if d2c is None:
+        _, d2c = getDoFBoxesAndCells(dm)
+    n._boxes = n._coords = None
+    n._d2c = d2c
+    n._cells = None
+    return n
+
+
+def singleDoFClusters(dm):
+    """[({I}, {I}) for every DoF I]: the cluster pairs of getDiagonalCluster (NA:2291-2309)"""
+    _, d2c = getDoFBoxesAndCells(dm)
+    out = []
+    for I in range(dm.num_dofs):
+        n = dofClusterNode(dm, [I], d2c)
+        cp = nearFieldClusterPair(n, n)
+        cp.set_cells()
+        out.append(cp)
+    return out
+
+
+def partitionClusterPairs(Pnear, size):
+    """Row-sharding of the near field over `size` ranks (the reference hangs one subtree per rank under the
+    root, clusterMethodCy.pyx:1854-1896, and assembles the pairs whose row cluster n1 descends from it, NA:3247-3260):
+    the cluster pairs are grouped by their row cluster n1, the groups are kept in tree order and cut into `size`
+    contiguous parts of about equal work (|cells(n1)| * |cells(n2)| element pairs).  Returns a list of index arrays.
+
+    A rank stores only the blocks n1 x n2 of its pairs (unsymmetric CSR).  The symmetric masked scatter writes an entry
+    and its mirror image; the mirror image of a block entry lies in the block n2 x n1, which another rank may own, where
+    it is dropped by the pattern (addToEntry semantics).  Each rank therefore builds its masks with symmetrize=True:
+    an entry (p, q), p <= q, of an element pair is requested if (p in n1, q in n2) OR (p in n2, q in n1); the pattern
+    keeps exactly the writes into the rank's own blocks, so every block is complete and the operator is the sum of
+    the rank-local matrices."""
+    order, seen = [], {}
+    for k, cp in enumerate(Pnear):
+        key = id(cp.n1)
+        if key not in seen:
+            seen[key] = len(order)
+            order.append((int(cp.n1.dofs[0]) if cp.n1.dofs.shape[0] else 0, key))
+    # tree order of the row clusters = order of first appearance in the recursion, which walks the tree depth first
+    weight = np.zeros(len(order))
+    group = np.zeros(len(Pnear), dtype=np.int64)
+    for k, cp in enumerate(Pnear):
+        g = seen[id(cp.n1)]
+        group[k] = g
+        weight[g] += float(cp.n1.cells.shape[0])*float(cp.n2.cells.shape[0])
+    cum = np.cumsum(weight)
+    total = cum[-1] if cum.shape[0] else 0.
+    owner_of_group = np.minimum((cum-0.5*weight)/max(total, 1e-300)*size, size-1).astype(np.int64)
+    owner = owner_of_group[group]
+    return [np.nonzero(owner == r)[0] for r in range(size)]

@@ -204,3 +204,74 @@ class SSS_LinearOperator(CSR_LinearOperator):
     def toarray(self):
         L = CSR_LinearOperator.toarray(self)
         return L+L.T+np.diag(self.diagonal)
+
+
+class diagonalOperator:
+    """base/PyNucleus_base/linear_operators.pyx diagonalOperator: ``data`` = the diagonal; matvec scales"""
+
+    def __init__(self, diag):
+        self.data = np.ascontiguousarray(diag, dtype=np.float64)
+        self.num_rows = self.num_columns = self.data.shape[0]
+        self.shape = (self.num_rows, self.num_columns)
+
+    @property
+    def diagonal(self):
+        return self.data
+
+    def matvec(self, x, y=None):
+        out = self.data*np.asarray(x)
+        if y is not None:
+            y[:] = out
+            return y
+        return out
+
+    __mul__ = matvec
+
+    def toarray(self):
+        return np.diag(self.data)
+
+
+class DistributedSparse_LinearOperator:
+    """Row-sharded near field: every rank holds the CSR blocks of its cluster pairs; A = sum over ranks.  matvec follows
+    the reference's DistributedH2Matrix_globalData (clusterMethodCy.pyx:3127-3154): Bcast(x), local product, Allreduce(y)
+    -- an N-vector over RCCL (or gloo), never the matrix."""
+
+    def __init__(self, local, comm_group=None):
+        self.local = local
+        self.group = comm_group
+        self.num_rows, self.num_columns = local.num_rows, local.num_columns
+        self.shape = local.shape
+        self.info = local.info
+
+    def matvec(self, x, y=None):
+        import torch.distributed as dist
+        dev = self.local.device
+        xd = _as_dev(x, dev)
+        backend = dist.get_backend(self.group)
+        if backend == 'gloo':
+            xh = xd.cpu()
+            dist.broadcast(xh, src=0, group=self.group)
+            yh = self.local.matvec(xh.to(dev)).cpu()
+            dist.all_reduce(yh, group=self.group)
+            yd = yh.to(dev)
+        else:
+            dist.broadcast(xd, src=0, group=self.group)
+            yd = self.local.matvec(xd)
+            dist.all_reduce(yd, group=self.group)
+        if isinstance(x, torch.Tensor):
+            return yd
+        out = yd.cpu().numpy()
+        if y is not None:
+            y[:] = out
+            return y
+        return out
+
+    __mul__ = matvec
+    dot = matvec
+
+    def toarray(self):
+        """the full matrix (all-reduce of the dense images; tests only)"""
+        import torch.distributed as dist
+        A = torch.from_numpy(self.local.toarray())
+        dist.all_reduce(A, group=self.group)
+        return A.numpy()

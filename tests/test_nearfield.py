@@ -15,13 +15,13 @@ def _setup(noRef=2, s=0.75, element='P1', zeroExterior=True, domain='disc'):
     return dm, kernel, nonlocalTables(dm, kernel, {}, zeroExterior)
 
 
-def _oracle_near(tables, Pnear, symmetric=True):
+def _oracle_near(tables, Pnear, symmetric=True, symmetrize=False):
     from pynucleus_amd import clusters
     from oracle.oracle import OracleProblem
     dm = tables.dm
     indptr, indices = clusters.getSparseNearField(dm, Pnear, symmetric=symmetric)
-    pairs, masks = clusters.buildMasksForClusters(dm, Pnear)
-    bc, bf, bm = clusters.clusterBoundaryItems(dm, Pnear)
+    pairs, masks = clusters.buildMasksForClusters(dm, Pnear, symmetrize=symmetrize)
+    bc, bf, bm = clusters.clusterBoundaryItems(dm, Pnear, symmetrize=symmetrize)
     gb = None
     if not tables.zeroExterior:
         c, f, m = clusters.globalBoundaryItems(dm, tables.bcells)
@@ -108,6 +108,27 @@ def test_oracle_regional_no_exterior():
     assert np.abs(Anear-Adense).max() <= 1e-11*np.abs(Adense).max()
 
 
+@pytest.mark.parametrize('zeroExterior', [True, False])
+def test_oracle_row_sharded_near_field_sums_to_full(zeroExterior):
+    """cluster pairs row-partitioned over ranks, rank-local unsymmetric CSR with symmetrised masks; the sum of
+    the rank-local matrices is the near-field matrix"""
+    from pynucleus_amd import clusters
+    dm, kernel, T = _setup(3, 0.75, zeroExterior=zeroExterior)
+    root, Pnear, Pfar = clusters.getNearFieldClusters(dm, eta=3., minClusterSize=8)
+    indptr, indices, data, diag, cnt = _oracle_near(T, Pnear, symmetric=False)
+    full = _to_dense(dm.num_dofs, indptr, indices, data, None)
+    for size in (2, 3):
+        parts = clusters.partitionClusterPairs(Pnear, size)
+        assert sorted(np.concatenate(parts).tolist()) == list(range(len(Pnear)))
+        w = [sum(Pnear[k].n1.cells.shape[0]*Pnear[k].n2.cells.shape[0] for k in p) for p in parts]
+        assert min(w) > 0.5*max(w)
+        acc = np.zeros_like(full)
+        for p in parts:
+            ip, ix, d, _, _ = _oracle_near(T, [Pnear[k] for k in p], symmetric=False, symmetrize=True)
+            acc += _to_dense(dm.num_dofs, ip, ix, d, None)
+        assert np.abs(acc-full).max() <= 1e-12*np.abs(full).max()
+
+
 # ---- GPU -------------------------------------------------------------------------------------------------------------
 def _gpu_builder(noRef, s, element='P1', zeroExterior=True, domain='disc', params=None):
     from pynucleus_amd import disc, interval, PHYSICAL, dofmapFactory, getFractionalKernel
@@ -182,3 +203,72 @@ def test_getH2_returns_near_field():
     assert Anear.nnz > 0 and len(Pnear) > 0
     with pytest.raises(NotImplementedError):
         b.getH2()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('zeroExterior', [True, False])
+def test_gpu_getDiagonal_getEntry(zeroExterior):
+    """getDiagonal / getEntry (NA:2269-2289, 1538-1661) against the dense operator: same tolerance as the reference's
+    tests/test_fracLapl.py:103-111 (rtol 2e-3), and exactly against the oracle's cluster assembly"""
+    from pynucleus_amd import clusters
+    b = _gpu_builder(3, 0.75, zeroExterior=zeroExterior)
+    dm = b.dm
+    d = b.getDiagonal().diagonal
+    if zeroExterior:
+        Pnear = clusters.singleDoFClusters(dm)
+        indptr, indices, data, diag, cnt = _oracle_near(b.tables, Pnear)
+        assert np.abs(d-diag).max() <= 1e-11*np.abs(diag).max()
+        Adense = b.getDense().toarray()
+        assert np.allclose(d, np.diag(Adense), rtol=2e-3)
+        for I, J in [(0, 0), (5, 5), (3, 4), (10, 90), (dm.num_dofs-1, 0)]:
+            e = b.getEntry(I, J)
+            assert abs(e-Adense[I, J]) <= 2e-3*abs(Adense[I, J])+1e-6, (I, J, e, Adense[I, J])
+    else:
+        # no exterior term at all (NA:1599: only (supp)^2): strictly smaller than the zeroExterior diagonal
+        b2 = _gpu_builder(3, 0.75, zeroExterior=True)
+        assert (d < b2.getDiagonal().diagonal).all() and (d > 0).all()
+
+
+def _dist_near_worker(rank, world, port, out):
+    import os
+    import torch
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.cuda.set_device(0)                       # one-GPU box: both ranks share the card, collectives over gloo
+    from pynucleus_amd import disc, P1_DoFMap, PHYSICAL, getFractionalKernel, clusters
+    from pynucleus_amd.builder import nonlocalBuilder
+    mesh = disc(3)
+    dm = P1_DoFMap(mesh, PHYSICAL)
+    b = nonlocalBuilder(dm, getFractionalKernel(2, 0.75), {'eta': 3., 'minClusterSize': 8}, zeroExterior=True, comm=True)
+    op, Pnear = b.getH2(returnNearField=True)
+    x = np.linspace(-1., 1., dm.num_dofs)
+    y = op.matvec(x)
+    indptr, indices, data, diag, cnt = _oracle_near(b.tables, Pnear, symmetric=False)
+    Aref = _to_dense(dm.num_dofs, indptr, indices, data, None)
+    e1 = float(np.abs(y-Aref@x).max()/np.abs(Aref@x).max())
+    e2 = float(np.abs(op.toarray()-Aref).max()/np.abs(Aref).max())
+    if rank == 0:
+        out.put((e1, e2, op.local.nnz, indices.shape[0]))
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_two_ranks_row_sharded_near_field():
+    """BASELINE configs[3] at world size 2 (gloo, both ranks on the one GPU of the box): rank-local near-field blocks,
+    matvec = local SpMV + all-reduce of the N-vector"""
+    import os
+    import torch.multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    out = ctx.Queue()
+    port = 29700+os.getpid() % 2000
+    procs = [ctx.Process(target=_dist_near_worker, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    e1, e2, nnz_local, nnz_full = out.get(timeout=300)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert 0 < nnz_local < nnz_full
+    assert e1 < 1e-11 and e2 < 1e-11
