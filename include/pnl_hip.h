@@ -97,6 +97,15 @@ int pnl_upload_mesh(pnl_context *ctx, int dim, int nv, const double *vertices_ho
  * (precomputedDoFPermutations, NO:66-109) */
 int pnl_upload_dofmap(pnl_context *ctx, int dpe, int dofs_per_vertex, int dofs_per_edge, int num_dofs,
                       const int32_t *dofs_host, const int32_t *dof_perm_table_host);
+/* Variable fractional order that is piecewise constant per element pair (Kernel.evalParams at the two cell centres,
+ * NO:509-513, kernelsCy.pyx:1852-1867; order functions fractionalOrders.pyx:203-336, 826-882): the order takes nclasses
+ * distinct values.  cell_labels[nc] / facet_labels[nb] (boundary facets, may be NULL without zeroExterior) are the labels
+ * of the centres, cls_of[num_labels][num_labels] the class of a label pair.  After this call pnl_select_class(k) makes
+ * pnl_set_kernel / pnl_set_order_formula / pnl_upload_singular_rule act on class k (kernel parameters, order formula and
+ * the near rules keyed by the class's singularity, FL2:664/688).  nclasses = 1, num_labels = 0 restores a constant order. */
+int pnl_set_classes(pnl_context *ctx, int nclasses, int num_labels, const int32_t *cell_labels_host,
+                    const int32_t *facet_labels_host, const int32_t *cls_of_host);
+int pnl_select_class(pnl_context *ctx, int k);
 /* which = PNL_INTERIOR (gamma) or PNL_BOUNDARY (Gauss-theorem boundary kernel, KC:1982-2027) */
 int pnl_set_kernel(pnl_context *ctx, int which, const pnl_kernel *kernel);
 int pnl_set_order_formula(pnl_context *ctx, int which, const pnl_order_formula *formula);

@@ -47,6 +47,17 @@ static int perm_rank(const int *perm, int n) {
     return index;
 }
 
+/* Kernel.evalParams for a piecewise-constant variable order (kernelsCy.pyx:1852-1867 with the order functions of
+ * fractionalOrders.pyx:285-336, 826-882): the parameters of the pair are those of the class of the two labels */
+static const nlo_problem *class_of_cells(const nlo_problem *P, int c1, int c2) {
+    if (!P->nclasses) return P;
+    return &P->classes[P->cls_of[P->cell_labels[c1]*P->num_labels+P->cell_labels[c2]]];
+}
+static const nlo_problem *class_of_cell_facet(const nlo_problem *P, int c1, int b) {
+    if (!P->nclasses) return P;
+    return &P->classes[P->cls_of[P->cell_labels[c1]*P->num_labels+P->facet_labels[b]]];
+}
+
 static void simplex_of(const nlo_problem *P, int c, double s[MAXV][2], double center[2]) {
     int nV = P->dim+1;
     center[0] = center[1] = 0.;
@@ -100,7 +111,7 @@ int nlo_panel(const nlo_problem *P, int c1, int c2, int *perm1, int *perm2, int 
         simplex_of(P, c2, s2, ce2);
         double d2 = 0.;
         for (int j = 0; j < P->dim; j++) d2 += (ce1[j]-ce2[j])*(ce1[j]-ce2[j]);
-        return quad_order(&P->qo, P->H0, P->h[c1], P->h[c2], sqrt(d2));
+        return quad_order(&class_of_cells(P, c1, c2)->qo, P->H0, P->h[c1], P->h[c2], sqrt(d2));
     }
     int i = 0;
     for (int k = common; k < nV; k++) { while (mask1 & (1 << i)) i++; perm1[k] = i; mask1 += (1 << i); }
@@ -164,8 +175,9 @@ static void eval_distant(const nlo_problem *P, double s1[MAXV][2], double s2[MAX
 }
 
 /* NO:722-789 (uncut distant pairs) and FL2:823-891 / FL1:349-407 (singular pairs) */
-void nlo_eval(const nlo_problem *P, int c1, int c2, int panel, const int *perm1, const int *perm2, const int *perm,
+void nlo_eval(const nlo_problem *P0, int c1, int c2, int panel, const int *perm1, const int *perm2, const int *perm,
               double *contrib, int64_t *nevals) {
+    const nlo_problem *P = class_of_cells(P0, c1, c2);
     const int dim = P->dim, nV = dim+1, dpe = P->dpe;
     const int E = (2*dpe)*(2*dpe+1)/2;
     double s1[MAXV][2], s2[MAXV][2], ce[2];
@@ -250,7 +262,7 @@ int nlo_panel_boundary(const nlo_problem *P, int c1, int b, int *perm1, int *per
         double d2 = 0.;
         for (int j = 0; j < P->dim; j++) d2 += (ce1[j]-ce2[j])*(ce1[j]-ce2[j]);
         /* h2 = get_h_surface_simplex: edge length in 2D, 1 in 1D (nonlocalOperator.pyx:121-122,164-171) */
-        return quad_order(&P->bqo, P->H0, P->h[c1], vol2, sqrt(d2));
+        return quad_order(&class_of_cell_facet(P, c1, b)->bqo, P->H0, P->h[c1], vol2, sqrt(d2));
     }
     int i = 0;
     for (int k = common; k < nV; k++) { while (mask1 & (1 << i)) i++; perm1[k] = i; mask1 += (1 << i); }
@@ -262,8 +274,9 @@ int nlo_panel_boundary(const nlo_problem *P, int c1, int b, int *perm1, int *per
 }
 
 /* NO:1022-1108 eval_distant_boundary, FL2:1324-1407, FL1:726-785 */
-void nlo_eval_boundary(const nlo_problem *P, int c1, int b, int panel, const int *perm1, const int *perm2, const int *perm,
+void nlo_eval_boundary(const nlo_problem *P0, int c1, int b, int panel, const int *perm1, const int *perm2, const int *perm,
                        double *contrib, int64_t *nevals) {
+    const nlo_problem *P = class_of_cell_facet(P0, c1, b);
     const int dim = P->dim, nV = dim+1, nF = dim, dpe = P->dpe;
     const int E = dpe*(dpe+1)/2;
     double s1[MAXV][2], s2[MAXV][2], ce[2], vol2, nrm[2] = {0., 0.};
@@ -399,7 +412,7 @@ int nlo_get_dense_rows(const nlo_problem *P, double *A, int zero_exterior, int c
                 double s1[MAXV][2], s2[MAXV][2], ce[2];
                 simplex_of(P, c1, s1, ce);
                 simplex_of(P, c2, s2, ce);
-                eval_distant(P, s1, s2, P->vol[c1]*P->vol[c2], panel, psi_cache[panel], scratch, contrib);
+                eval_distant(class_of_cells(P, c1, c2), s1, s2, P->vol[c1]*P->vol[c2], panel, psi_cache[panel], scratch, contrib);
                 int n = P->dist_off[panel+1]-P->dist_off[panel];
                 counters[2] += (int64_t)n*n;
             } else
@@ -455,6 +468,7 @@ int nlo_assemble_pairs_masked(const nlo_problem *P, int np, const int32_t *pairs
     const int dpe = P->dpe, n2 = 2*dpe;
     double contrib[MAXE];
     int perm1[MAXV], perm2[MAXV], perm[2*MAXDPE], ld[2*MAXDPE];
+    if (P->nclasses) return -3;                 /* variable orders need the jump terms NA:1966-2156: not restated */
     counters[0] = counters[1] = counters[2] = 0;
     for (int t = 0; t < np; t++) {
         const int c1 = pairs[2*t], c2 = pairs[2*t+1];

@@ -32,7 +32,7 @@ typedef struct {
     double horizon2;            /* inf = no truncation */
 } nlo_kernel;
 
-typedef struct {
+typedef struct nlo_problem_s {
     int32_t dim, dpe, nc, nv, num_dofs, dofs_per_vertex, dofs_per_edge, pad0;
     const double *vertices;       /* [nv][dim] */
     const int32_t *cells;         /* [nc][dim+1] */
@@ -71,6 +71,14 @@ typedef struct {
     const double *bsing_w[2];
     const double *bsing_phi[2];   /* [dpe][M] */
     double bsing_fac;             /* -2 in 2D (FL2:1375), +1 in 1D */
+
+    /* variable order, piecewise constant per element pair (NO:509-513 evalParams at the two centres, FL2:664/688 near
+     * rules keyed by the pair's singularity): nclasses == 0 for a constant order; otherwise classes[k] holds the
+     * kernel / order formula / singular rules of the k-th distinct order value and a pair (c1, c2) belongs to class
+     * cls_of[cell_labels[c1]*num_labels + cell_labels[c2]] (cell/facet pairs: facet_labels[b] for the second index) */
+    int32_t nclasses, num_labels;
+    const struct nlo_problem_s *classes;
+    const int32_t *cell_labels, *facet_labels, *cls_of;
 } nlo_problem;
 
 /* counters[0] pairs visited, [1] pairs assembled (panel != IGNORED, not all-boundary),

@@ -45,7 +45,9 @@ class nlo_problem(C.Structure):
                 ('bkernel', nlo_kernel), ('bqo', nlo_order_formula),
                 ('bfacet_off', _P), ('bfacet_bary', _P), ('bfacet_w', _P),
                 ('bsing_M', C.c_int32*2), ('bpad', C.c_int32*2),
-                ('bsing_nodes', _P*2), ('bsing_w', _P*2), ('bsing_phi', _P*2), ('bsing_fac', C.c_double)]
+                ('bsing_nodes', _P*2), ('bsing_w', _P*2), ('bsing_phi', _P*2), ('bsing_fac', C.c_double),
+                ('nclasses', C.c_int32), ('num_labels', C.c_int32), ('classes', _P), ('cell_labels', _P), ('facet_labels', _P),
+                ('cls_of', _P)]
 
 
 def build():
@@ -95,6 +97,23 @@ class OracleProblem:
         T = self.tables = tables
         dm, mesh = T.dm, T.dm.mesh
         self._keep = []
+        if getattr(T, 'classes', None):
+            # variable order: one full problem description per class, the top-level one carries the labels
+            self._class_problems = [OracleProblem(c) for c in T.classes]
+            arr = (nlo_problem*len(self._class_problems))(*[op.P for op in self._class_problems])
+            self._keep.append(arr)
+            base = self._class_problems[0]
+            P = self.P = nlo_problem.from_buffer_copy(base.P)
+            self._keep.append(base)
+            P.nclasses, P.num_labels = len(self._class_problems), T.num_labels
+            P.classes = C.cast(arr, C.c_void_p)
+            for name, a in (('cell_labels', T.cell_labels), ('facet_labels', T.facet_labels), ('cls_of', T.cls_of)):
+                a = np.ascontiguousarray(a, dtype=np.int32)
+                self._keep.append(a)
+                setattr(P, name, a.ctypes.data)
+            self.E = base.E
+            self.nV = base.nV
+            return
 
         def ptr(a, dtype):
             a = np.ascontiguousarray(a, dtype=dtype)

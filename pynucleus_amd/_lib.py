@@ -27,7 +27,7 @@ EXPORTS = ['pnl_create', 'pnl_destroy', 'pnl_error_string', 'pnl_version', 'pnl_
            'pnl_upload_mesh', 'pnl_upload_dofmap', 'pnl_set_kernel', 'pnl_set_order_formula', 'pnl_upload_distant_rules',
            'pnl_upload_singular_rule', 'pnl_upload_boundary', 'pnl_assemble_dense', 'pnl_tile_cells',
            'pnl_assemble_dense_tiles', 'pnl_get_counters', 'pnl_get_phase_ms', 'pnl_gemv', 'pnl_cg_jacobi',
-           'pnl_inv_diagonal', 'pnl_upload_sparsity', 'pnl_assemble_pairs_masked', 'pnl_assemble_boundary_masked', 'pnl_spmv']
+           'pnl_inv_diagonal', 'pnl_set_classes', 'pnl_select_class', 'pnl_upload_sparsity', 'pnl_assemble_pairs_masked', 'pnl_assemble_boundary_masked', 'pnl_spmv']
 
 
 class pnl_kernel(C.Structure):
@@ -81,6 +81,8 @@ def load():
     L.pnl_cg_jacobi.argtypes = [vp, vp, i64, i32, vp, vp, dbl, i32, C.POINTER(C.c_int), C.POINTER(C.c_double)]
     L.pnl_inv_diagonal.argtypes = [vp, vp, i64, i32, vp]
     L.pnl_upload_sparsity.argtypes = [vp, i32, vp, vp]
+    L.pnl_set_classes.argtypes = [vp, i32, i32, vp, vp, vp]
+    L.pnl_select_class.argtypes = [vp, i32]
     L.pnl_assemble_pairs_masked.argtypes = [vp, i32, vp, vp, vp, vp]
     L.pnl_assemble_boundary_masked.argtypes = [vp, i32, vp, vp, vp, dbl, vp, vp]
     L.pnl_spmv.argtypes = [vp, vp, vp, vp, vp]
@@ -143,7 +145,6 @@ class Context:
         d, pd = _hp(dm.dofs, np.int32)
         pt, ppt = _hp(T.dof_perm_table, np.int32)
         self.check(L.pnl_upload_dofmap(h, T.dpe, dm.dofs_per_vertex, dm.dofs_per_edge, dm.num_dofs, pd, ppt))
-        self._set_kernel(PNL_INTERIOR, T.kernel, T.qo)
         off, poff = _hp(T.dist_off, np.int32)
         b, pb = _hp(T.dist_bary, np.float64)
         w, pw = _hp(T.dist_w, np.float64)
@@ -152,20 +153,34 @@ class Context:
         fb, pfb = _hp(T.bfacet_bary, np.float64)
         fw, pfw = _hp(T.bfacet_w, np.float64)
         self.check(L.pnl_upload_distant_rules(h, T.qcap, poff, pb, pw, pphi, pfo, pfb, pfw))
-        for panel, r in T.singular.items():
-            n, pn = _hp(r.nodes, np.float64)
-            ww, pww = _hp(r.weights, np.float64)
-            ps, pps = _hp(r.psi, np.float64)
-            self.check(L.pnl_upload_singular_rule(h, PNL_INTERIOR, panel, r.num_nodes, r.rows, pn, pww, pps, float(T.sing_fac)))
         if T.has_boundary_tables:
             bc, pbc = _hp(T.bcells, np.int32)
             self.check(L.pnl_upload_boundary(h, bc.shape[0], pbc))
-            self._set_kernel(PNL_BOUNDARY, T.boundaryKernel, T.bqo)
-            for panel, r in T.bsingular.items():
+        classes = getattr(T, 'classes', None)
+        if classes:
+            cl, pcl = _hp(T.cell_labels, np.int32)
+            fl, pfl = _hp(T.facet_labels, np.int32)
+            co, pco = _hp(T.cls_of, np.int32)
+            self.check(L.pnl_set_classes(h, len(classes), T.num_labels, pcl, pfl if fl.shape[0] else None, pco))
+        else:
+            self.check(L.pnl_set_classes(h, 1, 0, None, None, None))
+            classes = [T]
+        for k, Tk in enumerate(classes):
+            self.check(L.pnl_select_class(h, k))
+            self._set_kernel(PNL_INTERIOR, Tk.kernel, Tk.qo)
+            for panel, r in Tk.singular.items():
                 n, pn = _hp(r.nodes, np.float64)
                 ww, pww = _hp(r.weights, np.float64)
                 ps, pps = _hp(r.psi, np.float64)
-                self.check(L.pnl_upload_singular_rule(h, PNL_BOUNDARY, panel, r.num_nodes, r.rows, pn, pww, pps, float(T.bsing_fac)))
+                self.check(L.pnl_upload_singular_rule(h, PNL_INTERIOR, panel, r.num_nodes, r.rows, pn, pww, pps, float(Tk.sing_fac)))
+            if T.has_boundary_tables:
+                self._set_kernel(PNL_BOUNDARY, Tk.boundaryKernel, Tk.bqo)
+                for panel, r in Tk.bsingular.items():
+                    n, pn = _hp(r.nodes, np.float64)
+                    ww, pww = _hp(r.weights, np.float64)
+                    ps, pps = _hp(r.psi, np.float64)
+                    self.check(L.pnl_upload_singular_rule(h, PNL_BOUNDARY, panel, r.num_nodes, r.rows, pn, pww, pps, float(Tk.bsing_fac)))
+        self.check(L.pnl_select_class(h, 0))
 
     def _set_kernel(self, which, kernel, formula):
         p = kernel.device_params()

@@ -61,5 +61,9 @@ struct DevProblem {
     const int *bvid;            // [dim][nb]
     const double *bv;           // [dim*dim][nb] facet vertex coordinates
     const double *bgeo;         // [2 dim + 3][nb]: centre, unit normal (2D), length, |ln(len/H0)|, ln(len)
+    // variable order, piecewise constant per element pair: labels of cells / boundary facets, class of a label pair and
+    // the class this launch assembles (-1: constant order, no filter)
+    const int *clabel, *blabel, *cls_of;
+    int nlab, cur_class;
     unsigned long long *counters;
 };

@@ -37,23 +37,36 @@ struct pnl_context {
     double H0 = 0.;
     std::vector<double> vertices, vol, h;
     std::vector<int32_t> cells, dofs, perm_table, bcells;
-    pnl_kernel kern[2];
-    pnl_order_formula form[2];
-    bool have_mesh = false, have_dofs = false, have_kernel[2] = {false, false}, have_form[2] = {false, false},
-         have_rules = false, have_boundary = false;
-    bool have_sing[2][3] = {{false, false, false}, {false, false, false}};
+    // per order class (one class for a constant order; pnl_set_classes for a piecewise-constant variable order): kernel,
+    // order formula, singular rules and the touching pairs that belong to the class
+    struct ClassData {
+        pnl_kernel kern[2];
+        pnl_order_formula form[2];
+        bool have_kernel[2] = {false, false}, have_form[2] = {false, false};
+        bool have_sing[2][3] = {{false, false, false}, {false, false, false}};
+        DevBuf b_sn[3], b_sw[3], b_sp[3], b_bn[2], b_bw[2], b_bp[2], b_spairs[3], b_bpairs[2];
+        int sM[3] = {0, 0, 0}, sRows[3] = {0, 0, 0}, bM[2] = {0, 0};
+        double sFac = 0., bFac = 0.;
+        int n_spairs[3] = {0, 0, 0}, n_bpairs[2] = {0, 0};
+        ClassData() { std::memset(kern, 0, sizeof(kern)); std::memset(form, 0, sizeof(form)); }
+    };
+    std::vector<ClassData*> cls;
+    int cur = 0;                      // class the setters and launchers currently act on
+    ClassData &C() { return *cls[cur]; }
+    int nlab = 0;                     // labels of the variable order (0: constant order)
+    std::vector<int32_t> cell_labels, facet_labels, cls_of;
+    bool have_mesh = false, have_dofs = false, have_rules = false, have_boundary = false;
     bool dirty = true;
     // device
     DevProblem P;
     DevBuf b_cellv, b_ccen, b_cvol, b_ch, b_clog, b_cvid, b_cdof, b_cslot, b_blk_ndof, b_blk_dofs, b_perm, b_off, b_bary, b_w, b_phi,
-        b_foff, b_fbary, b_fw, b_sn[3], b_sw[3], b_sp[3], b_bn[2], b_bw[2], b_bp[2], b_bvid, b_bv, b_bgeo, b_counters, b_D, b_tiles,
-        b_spairs[3], b_bpairs[2], b_vec[6], b_scal, b_wl, b_wlcount, b_ttn, b_ttoff, b_tttab, b_wlsorted, b_wlaux,
+        b_foff, b_fbary, b_fw, b_bvid, b_bv, b_bgeo, b_counters, b_D, b_tiles,
+        b_vec[6], b_clabel, b_blabel, b_clsof, b_scal, b_wl, b_wlcount, b_ttn, b_ttoff, b_tttab, b_wlsorted, b_wlaux,
         b_vertices, b_sp_indptr, b_sp_indices, b_mp_pairs, b_mp_masks, b_mp_wl, b_mp_sorted, b_mp_aux, b_bi_cells, b_bi_facets,
         b_bi_masks;
     int sp_nnz = -1;                // near-field sparsity pattern (pnl_upload_sparsity)
     unsigned wl_cap = 0;
     int tile = TILE_P1, nblocks = 0, ncp = 0, nU = 0;
-    int n_spairs[3] = {0, 0, 0}, n_bpairs[2] = {0, 0};
     std::vector<int2> spairs_host[3];
     std::vector<int2> tiles_cached;   // tile list (as given by the caller) currently resident in b_tiles
     size_t tiles_cap = 0;
@@ -227,13 +240,23 @@ int finalize(pnl_context *ctx) {
         }
     }
     int rc;
-    for (int s = 0; s < 3; s++) {
-        ctx->n_spairs[s] = (int)ctx->spairs_host[s].size();
-        if ((rc = upload(ctx, ctx->b_spairs[s], ctx->spairs_host[s].data(), ctx->spairs_host[s].size()))) return rc;
-    }
+    const int ncls = (int)ctx->cls.size(), nlab = ctx->nlab;
+    if (nlab > 0 && (int)ctx->cell_labels.size() != nc) return fail(ctx, PNL_ERR_STATE, "cell labels do not match the mesh");
+    // class of a cell pair / cell-facet pair (Kernel.evalParams at the two centres, NO:509-513)
+    auto class_cc = [&](int c1, int c2) { return nlab ? ctx->cls_of[(size_t)ctx->cell_labels[c1]*nlab+ctx->cell_labels[c2]] : 0; };
+    auto class_cf = [&](int c1, int f) { return nlab ? ctx->cls_of[(size_t)ctx->cell_labels[c1]*nlab+ctx->facet_labels[f]] : 0; };
+    for (int s = 0; s < 3; s++)
+        for (int k = 0; k < ncls; k++) {
+            std::vector<int2> mine;
+            for (const int2 &pr : ctx->spairs_host[s])
+                if (class_cc(pr.x, pr.y) == k) mine.push_back(pr);
+            ctx->cls[k]->n_spairs[s] = (int)mine.size();
+            if ((rc = upload(ctx, ctx->cls[k]->b_spairs[s], mine.data(), mine.size()))) return rc;
+        }
     // boundary facets
-    ctx->n_bpairs[0] = ctx->n_bpairs[1] = 0;
+    for (int k = 0; k < ncls; k++) ctx->cls[k]->n_bpairs[0] = ctx->cls[k]->n_bpairs[1] = 0;
     if (ctx->have_boundary) {
+        if (nlab > 0 && (int)ctx->facet_labels.size() != ctx->nb) return fail(ctx, PNL_ERR_STATE, "facet labels do not match the boundary");
         const int nF = dim, nb = ctx->nb;
         std::vector<int32_t> bvid((size_t)nF*nb);
         std::vector<double> bv((size_t)nF*dim*nb);
@@ -265,10 +288,15 @@ int finalize(pnl_context *ctx) {
                 }
             }
         }
-        for (int s = 0; s < 2; s++) {
-            ctx->n_bpairs[s] = (int)bp[s].size();
-            if ((rc = upload(ctx, ctx->b_bpairs[s], bp[s].data(), bp[s].size()))) return rc;
-        }
+        for (int s = 0; s < 2; s++)
+            for (int k = 0; k < ncls; k++) {
+                std::vector<int2> mine;
+                for (const int2 &pr : bp[s])
+                    if (class_cf(pr.x, pr.y) == k) mine.push_back(pr);
+                ctx->cls[k]->n_bpairs[s] = (int)mine.size();
+                if ((rc = upload(ctx, ctx->cls[k]->b_bpairs[s], mine.data(), mine.size()))) return rc;
+            }
+        if (nlab > 0 && (rc = upload(ctx, ctx->b_blabel, ctx->facet_labels.data(), ctx->facet_labels.size()))) return rc;
         if ((rc = upload(ctx, ctx->b_bvid, bvid.data(), bvid.size()))) return rc;
         if ((rc = upload(ctx, ctx->b_bv, bv.data(), bv.size()))) return rc;
         {
@@ -298,6 +326,12 @@ int finalize(pnl_context *ctx) {
         }
     }
     if ((rc = upload(ctx, ctx->b_vertices, ctx->vertices.data(), ctx->vertices.size()))) return rc;
+    if (nlab > 0) {
+        std::vector<int32_t> cl(ncp, 0);
+        std::copy(ctx->cell_labels.begin(), ctx->cell_labels.end(), cl.begin());
+        if ((rc = upload(ctx, ctx->b_clabel, cl.data(), cl.size()))) return rc;
+        if ((rc = upload(ctx, ctx->b_clsof, ctx->cls_of.data(), ctx->cls_of.size()))) return rc;
+    }
     if ((rc = upload(ctx, ctx->b_cellv, cellv.data(), cellv.size()))) return rc;
     if ((rc = upload(ctx, ctx->b_ccen, ccen.data(), ccen.size()))) return rc;
     if ((rc = upload(ctx, ctx->b_cvol, cvol.data(), cvol.size()))) return rc;
@@ -346,34 +380,40 @@ int finalize(pnl_context *ctx) {
     P.perm_table = (const int*)ctx->b_perm.p;
     P.bvid = (const int*)ctx->b_bvid.p; P.bv = (const double*)ctx->b_bv.p; P.bgeo = (const double*)ctx->b_bgeo.p;
     P.counters = (unsigned long long*)ctx->b_counters.p;
+    P.nlab = nlab; P.cur_class = -1;
+    P.clabel = (const int*)ctx->b_clabel.p; P.blabel = (const int*)ctx->b_blabel.p; P.cls_of = (const int*)ctx->b_clsof.p;
     ctx->dirty = false;
     return PNL_OK;
 }
 
 void refresh_tables(pnl_context *ctx) {
     DevProblem &P = ctx->P;
-    P.k = to_dev(ctx->kern[0], ctx->dim);
-    P.bk = to_dev(ctx->kern[1], ctx->dim);
+    P.k = to_dev(ctx->C().kern[0], ctx->dim);
+    P.bk = to_dev(ctx->C().kern[1], ctx->dim);
     {
         // n.(y-x)/|y-x| * Gamma_b(|x-y|^2): fold the normalisation into the exponent (fractional kernels only)
-        pnl_kernel kn = ctx->kern[1];
+        pnl_kernel kn = ctx->C().kern[1];
         if (ctx->dim == 2 && kn.ktype == PNL_FRACTIONAL) kn.exponent -= 0.5;
         P.bkn = to_dev(kn, ctx->dim);
         if (ctx->dim == 2 && kn.ktype != PNL_FRACTIONAL) P.bkn.fast = 0;
     }
-    P.qo = to_dev(ctx->form[0]);
-    P.bqo = to_dev(ctx->form[1]);
+    P.qo = to_dev(ctx->C().form[0]);
+    P.bqo = to_dev(ctx->C().form[1]);
     P.qmax = ctx->qmax;
     P.off = (const int*)ctx->b_off.p; P.bary = (const double*)ctx->b_bary.p; P.w = (const double*)ctx->b_w.p;
     P.phi = (const double*)ctx->b_phi.p; P.foff = (const int*)ctx->b_foff.p; P.fbary = (const double*)ctx->b_fbary.p;
     P.fw = (const double*)ctx->b_fw.p;
     P.tt_n = (const int*)ctx->b_ttn.p; P.tt_off = (const int*)ctx->b_ttoff.p; P.tt_tab = (const double*)ctx->b_tttab.p;
     for (int s = 0; s < 3; s++) {
-        P.sNodes[s] = (const double*)ctx->b_sn[s].p; P.sW[s] = (const double*)ctx->b_sw[s].p; P.sPsi[s] = (const double*)ctx->b_sp[s].p;
+        P.sNodes[s] = (const double*)ctx->C().b_sn[s].p; P.sW[s] = (const double*)ctx->C().b_sw[s].p; P.sPsi[s] = (const double*)ctx->C().b_sp[s].p;
     }
     for (int s = 0; s < 2; s++) {
-        P.bNodes[s] = (const double*)ctx->b_bn[s].p; P.bW[s] = (const double*)ctx->b_bw[s].p; P.bPhi[s] = (const double*)ctx->b_bp[s].p;
+        P.bNodes[s] = (const double*)ctx->C().b_bn[s].p; P.bW[s] = (const double*)ctx->C().b_bw[s].p; P.bPhi[s] = (const double*)ctx->C().b_bp[s].p;
     }
+    for (int s = 0; s < 3; s++) { P.sM[s] = ctx->C().sM[s]; P.sRows[s] = ctx->C().sRows[s]; }
+    for (int s = 0; s < 2; s++) P.bM[s] = ctx->C().bM[s];
+    P.sFac = ctx->C().sFac; P.bFac = ctx->C().bFac;
+    P.cur_class = ctx->nlab > 0 ? ctx->cur : -1;
 }
 
 // row stride of the LDS sub-block: nU + 1 columns (+1: trash column / row for boundary DoFs); PNL_ACC_PAD=m rounds it up
@@ -484,7 +524,7 @@ int launch_tiles(pnl_context *ctx, int ntiles_all, double *A, int64_t ldA, int c
 template <int DIM, int DPE, int SLOT, int KT>
 int launch_singular_slot(pnl_context *ctx, int np, double *A, int64_t ldA, int cell_begin, int cell_end) {
     constexpr int NV = DIM+1;
-    const int2 *pairs = (const int2*)ctx->b_spairs[SLOT].p;
+    const int2 *pairs = (const int2*)ctx->C().b_spairs[SLOT].p;
     const int M = ctx->P.sM[SLOT], rows = ctx->P.sRows[SLOT];
     const size_t lds = sizeof(double)*(size_t)(2*NV+1+rows)*M;
     const int waves_per_block = PNL_SING_THREADS/64;
@@ -508,9 +548,9 @@ int launch_singular_slot(pnl_context *ctx, int np, double *A, int64_t ldA, int c
 template <int DIM, int DPE, int KT>
 int launch_singular(pnl_context *ctx, double *A, int64_t ldA, int cell_begin, int cell_end) {
     for (int s = 0; s < DIM+1; s++) {
-        const int np = ctx->n_spairs[s];
+        const int np = ctx->C().n_spairs[s];
         if (!np) continue;
-        if (!ctx->have_sing[0][s]) return fail(ctx, PNL_ERR_STATE, "singular rule for %d common vertices not uploaded", s+1);
+        if (!ctx->C().have_sing[0][s]) return fail(ctx, PNL_ERR_STATE, "singular rule for %d common vertices not uploaded", s+1);
         int rc;
         if (s == 0) rc = launch_singular_slot<DIM, DPE, 0, KT>(ctx, np, A, ldA, cell_begin, cell_end);
         else if (s == 1) rc = launch_singular_slot<DIM, DPE, 1, KT>(ctx, np, A, ldA, cell_begin, cell_end);
@@ -536,11 +576,11 @@ int launch_boundary(pnl_context *ctx, int cell_begin, int cell_end) {
                            (double*)ctx->b_D.p, cell_begin, cell_end, per);
     HIPCHK(ctx, hipGetLastError());
     for (int s = 0; s < DIM; s++) {
-        const int np = ctx->n_bpairs[s];
+        const int np = ctx->C().n_bpairs[s];
         if (!np) continue;
-        if (!ctx->have_sing[1][s]) return fail(ctx, PNL_ERR_STATE, "boundary singular rule for %d common vertices not uploaded", s+1);
+        if (!ctx->C().have_sing[1][s]) return fail(ctx, PNL_ERR_STATE, "boundary singular rule for %d common vertices not uploaded", s+1);
         const int grid = (np+3)/4;
-        const int2 *pairs = (const int2*)ctx->b_bpairs[s].p;
+        const int2 *pairs = (const int2*)ctx->C().b_bpairs[s].p;
         const bool fast = ctx->P.bkn.fast;
         if (s == 0 && fast) hipLaunchKernelGGL((k_boundary_singular<DIM, DPE, 0, 1>), dim3(grid), dim3(PNL_NTHREADS), 0, ctx->stream, ctx->P, pairs, np, (double*)ctx->b_D.p, cell_begin, cell_end);
         else if (s == 0) hipLaunchKernelGGL((k_boundary_singular<DIM, DPE, 0, 0>), dim3(grid), dim3(PNL_NTHREADS), 0, ctx->stream, ctx->P, pairs, np, (double*)ctx->b_D.p, cell_begin, cell_end);
@@ -554,18 +594,22 @@ int launch_boundary(pnl_context *ctx, int cell_begin, int cell_end) {
 template <int DIM, int DPE, int TILE>
 int assemble_impl(pnl_context *ctx, double *A, int64_t ldA, int zero_exterior, int ntiles, int cell_begin, int cell_end, int flags) {
     int rc;
-    const int kt = ctx->P.k.fast ? 1 : 0, bkt = 0;
-    (void)bkt;
+    const int ncls = (int)ctx->cls.size();
     HIPCHK(ctx, hipMemsetAsync(ctx->b_counters.p, 0, sizeof(unsigned long long)*PNL_NCOUNTERS, ctx->stream));
     HIPCHK(ctx, hipMemsetAsync(ctx->b_D.p, 0, sizeof(double)*(size_t)ctx->ncp*(DPE*(DPE+1)/2), ctx->stream));
     HIPCHK(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
     ctx->tiles_launched = ntiles > 0;
-    if (ntiles > 0) {
-        const int tb0 = ctx->tile_cell_filter ? cell_begin : 0, tb1 = ctx->tile_cell_filter ? cell_end : ctx->nc;
-        rc = kt ? launch_tiles<DIM, DPE, TILE, 1>(ctx, ntiles, A, ldA, tb0, tb1)
-                : launch_tiles<DIM, DPE, TILE, 0>(ctx, ntiles, A, ldA, tb0, tb1);
-        if (rc) return rc;
-    }
+    // a piecewise-constant variable order is assembled class by class: every pass sees the kernel, order formula and
+    // singular rules of one order value and skips the pairs of the other classes in its classification
+    if (ntiles > 0)
+        for (int k = 0; k < ncls; k++) {
+            ctx->cur = k;
+            refresh_tables(ctx);
+            const int tb0 = ctx->tile_cell_filter ? cell_begin : 0, tb1 = ctx->tile_cell_filter ? cell_end : ctx->nc;
+            rc = ctx->P.k.fast ? launch_tiles<DIM, DPE, TILE, 1>(ctx, ntiles, A, ldA, tb0, tb1)
+                               : launch_tiles<DIM, DPE, TILE, 0>(ctx, ntiles, A, ldA, tb0, tb1);
+            if (rc) { ctx->cur = 0; return rc; }
+        }
     HIPCHK(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
     // mirror the cross part before the symmetric contributions are added on both sides
     if (!(flags & PNL_FLAG_NO_MIRROR)) {
@@ -574,14 +618,25 @@ int assemble_impl(pnl_context *ctx, double *A, int64_t ldA, int zero_exterior, i
         HIPCHK(ctx, hipGetLastError());
     }
     HIPCHK(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
-    rc = kt ? launch_singular<DIM, DPE, 1>(ctx, A, ldA, cell_begin, cell_end) : launch_singular<DIM, DPE, 0>(ctx, A, ldA, cell_begin, cell_end);
-    if (rc) return rc;
-    HIPCHK(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
-    if (zero_exterior) {
-        if (!ctx->have_boundary || !ctx->have_kernel[1] || !ctx->have_form[1])
-            return fail(ctx, PNL_ERR_STATE, "zero_exterior needs boundary facets, boundary kernel and order formula");
-        if ((rc = launch_boundary<DIM, DPE, 0>(ctx, cell_begin, cell_end))) return rc;
+    for (int k = 0; k < ncls; k++) {
+        ctx->cur = k;
+        refresh_tables(ctx);
+        rc = ctx->P.k.fast ? launch_singular<DIM, DPE, 1>(ctx, A, ldA, cell_begin, cell_end)
+                           : launch_singular<DIM, DPE, 0>(ctx, A, ldA, cell_begin, cell_end);
+        if (rc) { ctx->cur = 0; return rc; }
     }
+    HIPCHK(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
+    if (zero_exterior)
+        for (int k = 0; k < ncls; k++) {
+            ctx->cur = k;
+            refresh_tables(ctx);
+            if (!ctx->have_boundary || !ctx->C().have_kernel[1] || !ctx->C().have_form[1]) {
+                ctx->cur = 0;
+                return fail(ctx, PNL_ERR_STATE, "zero_exterior needs boundary facets, boundary kernel and order formula");
+            }
+            if ((rc = launch_boundary<DIM, DPE, 0>(ctx, cell_begin, cell_end))) { ctx->cur = 0; return rc; }
+        }
+    ctx->cur = 0;
     HIPCHK(ctx, hipEventRecord(ctx->ev[4], ctx->stream));
     {
         const long long nt = (long long)ctx->nc*DPE*DPE;
@@ -598,7 +653,7 @@ int assemble_impl(pnl_context *ctx, double *A, int64_t ldA, int zero_exterior, i
 template <int DIM, int DPE, int SLOT, int KT>
 int launch_singular_sparse(pnl_context *ctx, const SparseOut &S, const int4 *sorted, const unsigned *offs) {
     constexpr int NV = DIM+1;
-    if (!ctx->have_sing[0][SLOT]) return PNL_OK;     // checked against the histogram by the caller
+    if (!ctx->C().have_sing[0][SLOT]) return PNL_OK;     // checked against the histogram by the caller
     const int M = ctx->P.sM[SLOT], rows = ctx->P.sRows[SLOT];
     const size_t lds = sizeof(double)*(size_t)(2*NV+1+rows)*M;
     if (lds <= 150*1024) {
@@ -659,7 +714,7 @@ int pairs_masked_impl(pnl_context *ctx, int np, const SparseOut &S) {
     HIPCHK(ctx, hipMemcpyAsync(hh, hist, sizeof(hh), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     for (int s = 0; s < DIM+1; s++)
-        if (hh[121+s] && !ctx->have_sing[0][s]) return fail(ctx, PNL_ERR_STATE, "singular rule for %d common vertices not uploaded", s+1);
+        if (hh[121+s] && !ctx->C().have_sing[0][s]) return fail(ctx, PNL_ERR_STATE, "singular rule for %d common vertices not uploaded", s+1);
     if (hh[121] && (rc = launch_singular_sparse<DIM, DPE, 0, KT>(ctx, S, sorted, offs))) return rc;
     if (hh[122] && (rc = launch_singular_sparse<DIM, DPE, 1, KT>(ctx, S, sorted, offs))) return rc;
     if (DIM == 2 && hh[123] && (rc = launch_singular_sparse<DIM, DPE, (DIM == 2 ? 2 : 1), KT>(ctx, S, sorted, offs))) return rc;
@@ -688,8 +743,9 @@ int boundary_masked_impl(pnl_context *ctx, int ni, double fac, const SparseOut &
 }
 
 int check_ready(pnl_context *ctx) {
-    if (!ctx->have_kernel[0] || !ctx->have_form[0] || !ctx->have_rules)
-        return fail(ctx, PNL_ERR_STATE, "kernel, order formula and distant rules must be set before assembling");
+    for (auto *c : ctx->cls)
+        if (!c->have_kernel[0] || !c->have_form[0] || !ctx->have_rules)
+            return fail(ctx, PNL_ERR_STATE, "kernel, order formula and distant rules must be set (for every class) before assembling");
     return PNL_OK;
 }
 
@@ -806,8 +862,7 @@ int pnl_create(int device_id, pnl_context **out) {
     if (const char *e = getenv("PNL_ABLATE")) ctx->ablate = atoi(e);
     if (const char *e = getenv("PNL_WL_LANE")) ctx->wl_lane = atoi(e) != 0;
     if (const char *e = getenv("PNL_PURE")) ctx->use_pure = atoi(e) != 0;
-    std::memset(ctx->kern, 0, sizeof(ctx->kern));
-    std::memset(ctx->form, 0, sizeof(ctx->form));
+    ctx->cls.push_back(new pnl_context::ClassData());
     *out = ctx;
     return PNL_OK;
 }
@@ -819,6 +874,7 @@ void pnl_destroy(pnl_context *ctx) {
     for (auto &e : ctx->ev)
         if (e) (void)hipEventDestroy(e);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    for (auto *c : ctx->cls) delete c;
     delete ctx;
 }
 
@@ -868,20 +924,54 @@ int pnl_upload_dofmap(pnl_context *ctx, int dpe, int dofs_per_vertex, int dofs_p
     return PNL_OK;
 }
 
+int pnl_set_classes(pnl_context *ctx, int nclasses, int num_labels, const int32_t *cell_labels, const int32_t *facet_labels,
+                    const int32_t *cls_of) {
+    if (!ctx) return PNL_ERR_INVALID;
+    if (!ctx->have_mesh) return fail(ctx, PNL_ERR_STATE, "upload the mesh first");
+    if (nclasses < 1 || nclasses > 64 || num_labels < 0 || (num_labels > 0 && (!cell_labels || !cls_of)))
+        return fail(ctx, PNL_ERR_INVALID, "bad class arguments");
+    for (int i = 0; i < num_labels*num_labels; i++)
+        if (cls_of[i] < 0 || cls_of[i] >= nclasses) return fail(ctx, PNL_ERR_INVALID, "class table entry %d out of range", i);
+    for (int c = 0; num_labels > 0 && c < ctx->nc; c++)
+        if (cell_labels[c] < 0 || cell_labels[c] >= num_labels) return fail(ctx, PNL_ERR_INVALID, "label of cell %d out of range", c);
+    for (auto *c : ctx->cls) delete c;
+    ctx->cls.clear();
+    for (int k = 0; k < nclasses; k++) ctx->cls.push_back(new pnl_context::ClassData());
+    ctx->cur = 0;
+    ctx->nlab = num_labels;
+    ctx->cell_labels.assign(cell_labels, cell_labels+(num_labels > 0 ? ctx->nc : 0));
+    ctx->cls_of.assign(cls_of, cls_of+(size_t)num_labels*num_labels);
+    ctx->facet_labels.clear();
+    if (num_labels > 0 && facet_labels && ctx->have_boundary) {
+        for (int f = 0; f < ctx->nb; f++)
+            if (facet_labels[f] < 0 || facet_labels[f] >= num_labels) return fail(ctx, PNL_ERR_INVALID, "label of facet %d out of range", f);
+        ctx->facet_labels.assign(facet_labels, facet_labels+ctx->nb);
+    }
+    ctx->dirty = true;
+    return PNL_OK;
+}
+
+int pnl_select_class(pnl_context *ctx, int k) {
+    if (!ctx) return PNL_ERR_INVALID;
+    if (k < 0 || k >= (int)ctx->cls.size()) return fail(ctx, PNL_ERR_INVALID, "class %d out of range", k);
+    ctx->cur = k;
+    return PNL_OK;
+}
+
 int pnl_set_kernel(pnl_context *ctx, int which, const pnl_kernel *k) {
     if (!ctx || !k || which < 0 || which > 1) return fail(ctx, PNL_ERR_INVALID, "bad kernel arguments");
     if (k->ktype < 0 || k->ktype > 2) return fail(ctx, PNL_ERR_UNSUPPORTED, "kernel type %d is not implemented", k->ktype);
     if (!std::isinf(k->horizon2) && which == PNL_INTERIOR)
         return fail(ctx, PNL_ERR_UNSUPPORTED, "finite-horizon kernels (cut elements) are not implemented on the GPU path yet");
-    ctx->kern[which] = *k;
-    ctx->have_kernel[which] = true;
+    ctx->C().kern[which] = *k;
+    ctx->C().have_kernel[which] = true;
     return PNL_OK;
 }
 
 int pnl_set_order_formula(pnl_context *ctx, int which, const pnl_order_formula *f) {
     if (!ctx || !f || which < 0 || which > 1) return fail(ctx, PNL_ERR_INVALID, "bad order-formula arguments");
-    ctx->form[which] = *f;
-    ctx->have_form[which] = true;
+    ctx->C().form[which] = *f;
+    ctx->C().have_form[which] = true;
     return PNL_OK;
 }
 
@@ -946,18 +1036,18 @@ int pnl_upload_singular_rule(pnl_context *ctx, int which, int panel, int M, int 
         const int common = slot+1;
         const int expect = common == nV ? dpe : (common == 1 ? 2*dpe-dpv : 2*dpe-2*dpv-dped);
         if (rows != expect) return fail(ctx, PNL_ERR_INVALID, "singular rule has %d rows, expected %d", rows, expect);
-        if ((rc = upload(ctx, ctx->b_sn[slot], nodes, (size_t)2*nV*M))) return rc;
-        if ((rc = upload(ctx, ctx->b_sw[slot], w, (size_t)M))) return rc;
-        if ((rc = upload(ctx, ctx->b_sp[slot], psi, (size_t)rows*M))) return rc;
-        ctx->P.sM[slot] = M; ctx->P.sRows[slot] = rows; ctx->P.sFac = facv;
+        if ((rc = upload(ctx, ctx->C().b_sn[slot], nodes, (size_t)2*nV*M))) return rc;
+        if ((rc = upload(ctx, ctx->C().b_sw[slot], w, (size_t)M))) return rc;
+        if ((rc = upload(ctx, ctx->C().b_sp[slot], psi, (size_t)rows*M))) return rc;
+        ctx->C().sM[slot] = M; ctx->C().sRows[slot] = rows; ctx->C().sFac = facv;
     } else {
         if (rows != dpe) return fail(ctx, PNL_ERR_INVALID, "boundary singular rule has %d rows, expected %d", rows, dpe);
-        if ((rc = upload(ctx, ctx->b_bn[slot], nodes, (size_t)(nV+dim)*M))) return rc;
-        if ((rc = upload(ctx, ctx->b_bw[slot], w, (size_t)M))) return rc;
-        if ((rc = upload(ctx, ctx->b_bp[slot], psi, (size_t)rows*M))) return rc;
-        ctx->P.bM[slot] = M; ctx->P.bFac = facv;
+        if ((rc = upload(ctx, ctx->C().b_bn[slot], nodes, (size_t)(nV+dim)*M))) return rc;
+        if ((rc = upload(ctx, ctx->C().b_bw[slot], w, (size_t)M))) return rc;
+        if ((rc = upload(ctx, ctx->C().b_bp[slot], psi, (size_t)rows*M))) return rc;
+        ctx->C().bM[slot] = M; ctx->C().bFac = facv;
     }
-    ctx->have_sing[which][slot] = true;
+    ctx->C().have_sing[which][slot] = true;
     return PNL_OK;
 }
 
@@ -1003,14 +1093,14 @@ static bool tile_is_uniform(const pnl_context *ctx, const pnl_order_formula &F, 
 
 static int upload_tiles(pnl_context *ctx, std::vector<int2> &tiles, int cell_begin, int cell_end) {
     // repeated assemblies of the same work list keep it resident
-    const pnl_order_formula &F = ctx->form[0];
+    const pnl_order_formula &F = ctx->C().form[0];
     if (tiles.size() == ctx->tiles_cached.size() && ctx->b_tiles.p && ctx->tiles_cb == cell_begin && ctx->tiles_ce == cell_end &&
         std::memcmp(&F, &ctx->tiles_form, sizeof(F)) == 0 && ctx->tiles_filter == ctx->tile_cell_filter &&
         (tiles.empty() || std::memcmp(tiles.data(), ctx->tiles_cached.data(), tiles.size()*sizeof(int2)) == 0))
         return PNL_OK;
     const int T = ctx->tile;
     const bool filter = ctx->tile_cell_filter;
-    const bool allow = ctx->use_pure && T == 64 && (ctx->dpe == 3 || ctx->dpe == 2) && ctx->qmax >= 2;
+    const bool allow = ctx->use_pure && T == 64 && (ctx->dpe == 3 || ctx->dpe == 2) && ctx->qmax >= 2 && ctx->nlab == 0;
     std::vector<int2> mixed, pure;
     for (const int2 &t : tiles) {
         bool u = allow && tile_is_uniform(ctx, F, t.x, t.y);
@@ -1115,6 +1205,7 @@ int pnl_assemble_pairs_masked(pnl_context *ctx, int np, const int32_t *pairs, co
     int rc;
     if ((rc = upload(ctx, ctx->b_mp_pairs, pairs, (size_t)2*np))) return rc;
     if ((rc = upload(ctx, ctx->b_mp_masks, masks, (size_t)4*np))) return rc;
+    if (ctx->nlab > 0) return fail(ctx, PNL_ERR_UNSUPPORTED, "cluster assembly with a variable order needs the jump terms (NA:1966-2156)");
     SparseOut S;
     if ((rc = sparse_ready(ctx, data, diag, S))) return rc;
     HIPCHK(ctx, hipMemsetAsync(ctx->b_counters.p, 0, sizeof(unsigned long long)*PNL_NCOUNTERS, ctx->stream));
@@ -1131,7 +1222,7 @@ int pnl_assemble_boundary_masked(pnl_context *ctx, int ni, const int32_t *cells,
                                  double fac, double *data, double *diag) {
     if (!ctx) return PNL_ERR_INVALID;
     if (ni < 0 || (ni && (!cells || !facets || !masks))) return fail(ctx, PNL_ERR_INVALID, "bad item list");
-    if (!ctx->have_kernel[1] || !ctx->have_form[1]) return fail(ctx, PNL_ERR_STATE, "boundary kernel and order formula must be set");
+    if (!ctx->C().have_kernel[1] || !ctx->C().have_form[1]) return fail(ctx, PNL_ERR_STATE, "boundary kernel and order formula must be set");
     for (int i = 0; i < ni; i++) {
         if (cells[i] < 0 || cells[i] >= ctx->nc) return fail(ctx, PNL_ERR_INVALID, "item %d: bad cell %d", i, cells[i]);
         for (int k = 0; k < ctx->dim; k++)
@@ -1139,7 +1230,7 @@ int pnl_assemble_boundary_masked(pnl_context *ctx, int ni, const int32_t *cells,
                 return fail(ctx, PNL_ERR_INVALID, "item %d: bad facet vertex", i);
     }
     for (int s = 0; s < ctx->dim; s++)
-        if (!ctx->have_sing[1][s]) return fail(ctx, PNL_ERR_STATE, "boundary singular rule for %d common vertices not uploaded", s+1);
+        if (!ctx->C().have_sing[1][s]) return fail(ctx, PNL_ERR_STATE, "boundary singular rule for %d common vertices not uploaded", s+1);
     int rc;
     if ((rc = upload(ctx, ctx->b_bi_cells, cells, (size_t)ni))) return rc;
     if ((rc = upload(ctx, ctx->b_bi_facets, facets, (size_t)ni*ctx->dim))) return rc;

@@ -456,6 +456,8 @@ k_tile_distant(const DevProblem P, const int2 *__restrict__ tiles, double *__res
         const int va0 = s_vid[(0*NV+0)*TILE+i], vb0 = s_vid[(1*NV+0)*TILE+j];
         const int ca = ta*TILE+i;
         bool ok = (va0 >= 0) && (vb0 >= 0) && (ta < tb || i < j) && (ca >= cell_begin) && (ca < cell_end) && !(ablate & 8);
+        // variable order: this launch assembles the pairs of one order class only
+        if (P.cur_class >= 0 && ok) ok = P.cls_of[P.clabel[ca]*P.nlab+P.clabel[tb*TILE+j]] == P.cur_class;
         if (ok) {
             // NA:138-150: skip pairs with boundary DoFs only;  NO:311-323: shared vertices -> singular pair
             bool any_dof = false, shared = false;
@@ -1572,6 +1574,7 @@ k_boundary_distant(const DevProblem P, double *__restrict__ Dglob, int cell_begi
 #pragma unroll
             for (int m = 0; m < NF; m++) shared = shared || (vid[k] == fvid[m]);
         if (!active || shared) continue;
+        if (P.cur_class >= 0 && P.cls_of[P.clabel[cc]*P.nlab+P.blabel[f]] != P.cur_class) continue;
         double dc2 = 0.;
 #pragma unroll
         for (int d = 0; d < DIM; d++) dc2 += (cen[d]-fc[d])*(cen[d]-fc[d]);

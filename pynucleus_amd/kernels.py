@@ -229,21 +229,57 @@ class FractionalKernel(Kernel):
                  derivative=0, tempered=0., max_horizon=np.nan, manifold=False, normalized=True):
         if derivative != 0 or tempered != 0. or manifold:
             raise NotImplementedError('derivative / tempered / manifold fractional kernels')
-        if not isinstance(s, constFractionalOrder):
-            raise NotImplementedError('variable fractional orders')
+        from .fractionalOrders import variableFractionalOrder
         self.s = s
-        self.sValue = s.value
         self.derivative = derivative
         self.temperedValue = tempered
         self.manifold = manifold
         self.normalized = normalized
-        # kernelsCy.pyx:1622-1634
-        if not boundary:
-            self.singularityValue = -dim-2*self.sValue
+        variableOrder = isinstance(s, variableFractionalOrder)
+        if variableOrder:
+            # kernelsCy.pyx:1603-1621: parameters are set per element pair by evalParams
+            if not piecewise:
+                raise NotImplementedError('variable orders that are not piecewise constant per element pair')
+            self.sValue = np.nan
+            self.singularityValue = np.nan
+            shift = 0. if not boundary else 1.
+            self.min_singularity = shift-dim-2*s.min
+            self.max_singularity = shift-dim-2*s.max
+            self._scalingFun = scaling
+            scaling = constantTwoPoint(np.nan)
         else:
-            self.singularityValue = 1.-dim-2*self.sValue
-        self.min_singularity = self.max_singularity = self.singularityValue
+            if not isinstance(s, constFractionalOrder):
+                raise NotImplementedError('fractional order {}'.format(s))
+            self.sValue = s.value
+            # kernelsCy.pyx:1622-1634
+            if not boundary:
+                self.singularityValue = -dim-2*self.sValue
+            else:
+                self.singularityValue = 1.-dim-2*self.sValue
+            self.min_singularity = self.max_singularity = self.singularityValue
         super().__init__(dim, FRACTIONAL, horizon, interaction, scaling, phi, piecewise, boundary, 1, max_horizon)
+        if variableOrder:
+            self.variable = self.variableOrder = self.variableSingularity = self.variableScaling = True
+            self.symmetric = bool(s.symmetric)
+
+    def evalParams(self, x, y):
+        """kernelsCy.pyx:1852-1867 (piecewise): order, singularity and scaling of the element pair with centres x, y"""
+        if not self.variable:
+            return
+        sv = self.s(x, y)
+        self.sValue = sv
+        self.singularityValue = (1. if self.boundary else 0.)-self.dim-2*sv
+        C = constantFractionalLaplacianScaling(self.dim, sv, self.horizonValue).value if self.normalized else 0.5
+        self.scalingValue = C/sv if self.boundary else C
+
+    def constantOrderKernel(self, sv):
+        """the constant-order kernel an element pair with s(x, y) = sv sees after evalParams (same family, same boundary flag)"""
+        k = getFractionalKernel(self.dim, float(sv), self.horizon, self.interaction, None, self.normalized, self.piecewise, None,
+                                self.boundary)
+        # the near-field quadrature orders are chosen from the extreme singularities of the VARIABLE kernel
+        # (fractionalLaplacian2D.pyx:606, 1210; fractionalLaplacian1D.pyx:218-219, 629-630)
+        k.min_singularity, k.max_singularity = self.min_singularity, self.max_singularity
+        return k
 
     def getModifiedKernel(self, s=None, horizon=None, scaling=None):
         s = self.s if s is None else s
@@ -262,6 +298,9 @@ class FractionalKernel(Kernel):
     def getBoundaryKernel(self):
         """Kernel obtained by eliminating the exterior via Gauss' theorem:
         Gamma_b = (C/s) |x-y|^{-(d-1)-2s}."""
+        if self.variable:
+            return FractionalKernel(self.dim, self.s, self.horizon, None, None, phi=None, piecewise=self.piecewise, boundary=True,
+                                    normalized=self.normalized)
         return FractionalKernel(self.dim, self.s, self.horizon, None, self.scalingPrePhi,
                                 phi=constantTwoPoint(1./self.sValue), piecewise=self.piecewise, boundary=True,
                                 normalized=self.normalized)
@@ -271,7 +310,8 @@ class FractionalKernel(Kernel):
 
 
 def _getFractionalOrder(s):
-    if isinstance(s, constFractionalOrder):
+    from .fractionalOrders import variableFractionalOrder
+    if isinstance(s, (constFractionalOrder, variableFractionalOrder)):
         return s
     if isinstance(s, (float, int, np.floating)):
         return constFractionalOrder(float(s))
@@ -301,6 +341,11 @@ def getFractionalKernel(dim, s, horizon=None, interaction=None, scaling=None, no
     sFun = _getFractionalOrder(s)
     horizonFun = _getHorizon(horizon)
     interaction = _getInteraction(interaction, horizonFun)
+    from .fractionalOrders import variableFractionalOrder
+    if isinstance(sFun, variableFractionalOrder):
+        # variableFractionalLaplacianScaling (kernelNormalization.pyx:329-364) is evaluated per element pair in evalParams
+        return FractionalKernel(dim, sFun, horizonFun, interaction, None, None, piecewise, boundary, derivative, tempered,
+                                max_horizon, manifold, normalized)
     if scaling is None:
         if normalized:
             scaling = constantFractionalLaplacianScaling(dim, sFun.value, horizonFun.value, tempered)

@@ -86,8 +86,13 @@ class nonlocalTables:
         self.dim = dim = mesh.dim
         assert mesh.manifold_dim == dim and dim in (1, 2)
         assert kernel.dim == dim, 'Kernel dimension must match dm.mesh dimension'
-        if not kernel.symmetric or kernel.variable:
-            raise NotImplementedError('non-symmetric / variable kernels')
+        if not kernel.symmetric:
+            raise NotImplementedError('non-symmetric kernels (local matrices with (2 dpe)^2 entries, NA:1411-1428)')
+        self.variable = bool(kernel.variable)
+        if self.variable:
+            self._setup_variable(dm, kernel, params, zeroExterior, qcap)
+            return
+        self.classes = None
         self.dpe = dm.dofs_per_element
         self.num_dofs = dm.num_dofs
         self.hmin = mesh.hmin
@@ -111,12 +116,49 @@ class nonlocalTables:
             raise NotImplementedError('zeroExterior needs a fractional kernel')
         if self.has_boundary_tables:
             bk = kernel.getBoundaryKernel()
+            if (kernel.min_singularity, kernel.max_singularity) != (sing, sing):
+                # class table of a variable-order kernel: the boundary twin inherits the range of singularities too
+                bk.min_singularity, bk.max_singularity = kernel.min_singularity+1., kernel.max_singularity+1.
             self.boundaryKernel = bk
             if dim == 2:
                 self._setup2D_boundary(bk, target_order, params.get('quad_order_diagonal', None))
             else:
                 self._setup1D_boundary(bk, target_order, params.get('quad_order_diagonal', None))
             self._boundary_mesh()
+
+    # ------------------------------------------------------------------
+    def _setup_variable(self, dm, kernel, params, zeroExterior, qcap):
+        """Variable order, piecewise constant per element pair (NO:509-513: evalParams at the two cell centres before the
+        panel is chosen; FL2:664, 688: near rules keyed by the singularity of the pair).  The order takes finitely many
+        values: every distinct value is a CLASS with the tables of the corresponding constant-order kernel (whose
+        near-field quadrature orders use the extreme singularities of the variable kernel); cells and boundary facets
+        carry the label of their centre and cls_of[label1, label2] names the class of a pair."""
+        sFun = kernel.s
+        mesh = dm.mesh
+        vals = np.unique(sFun.sVals)
+        self.class_s = vals
+        self.cls_of = np.searchsorted(vals, sFun.sVals).astype(np.int32)          # [L, L]
+        self.num_labels = int(sFun.numLabels)
+        centers = mesh.vertices[mesh.cells].mean(axis=1)
+        self.cell_labels = np.ascontiguousarray(sFun.labels(centers), dtype=np.int32)
+        assert self.cell_labels.min() >= 0 and self.cell_labels.max() < self.num_labels
+        self.classes = [nonlocalTables(dm, kernel.constantOrderKernel(sv), params, zeroExterior, qcap) for sv in vals]
+        c0 = self.classes[0]
+        for name in ('dm', 'dim', 'dpe', 'num_dofs', 'hmin', 'H0', 'dof_perm_table', 'qcap', 'zeroExterior', 'has_boundary_tables',
+                     'dist_off', 'dist_bary', 'dist_w', 'dist_phi', 'bfacet_off', 'bfacet_bary', 'bfacet_w', 'target_order',
+                     'quad_order_diagonal', 'quad_order_diagonalV'):
+            setattr(self, name, getattr(c0, name))
+        self.kernel = kernel
+        self.singular = c0.singular
+        if self.has_boundary_tables:
+            self.bcells = c0.bcells
+            fc = mesh.vertices[self.bcells].mean(axis=1)
+            self.facet_labels = np.ascontiguousarray(sFun.labels(fc), dtype=np.int32)
+        else:
+            self.facet_labels = np.zeros(0, dtype=np.int32)
+
+    def class_of_pair(self, c1, c2):
+        return int(self.cls_of[self.cell_labels[c1], self.cell_labels[c2]])
 
     # ------------------------------------------------------------------
     def _psi_tables(self, rules):

@@ -65,6 +65,35 @@ def test_disc_P2_dense(noRef, s):
     _compare(_build('disc', noRef, s, element='P2'))
 
 
+def _build_variable(domain, noRef, sFun, element='P1', zeroExterior=True):
+    from pynucleus_amd import disc, interval, PHYSICAL, dofmapFactory, getFractionalKernel
+    from pynucleus_amd.builder import nonlocalBuilder
+    mesh = disc(noRef) if domain == 'disc' else interval(noRef)
+    dm = dofmapFactory(element, mesh, PHYSICAL)
+    return nonlocalBuilder(dm, getFractionalKernel(mesh.dim, sFun), {}, zeroExterior=zeroExterior)
+
+
+@pytest.mark.parametrize('case', ['leftRight_P1', 'layers_P1', 'leftRight_P2', 'varconst_1d', 'leftRight_1d', 'leftRight_noext'])
+def test_variable_order_dense(case):
+    """a16: piecewise-constant variable order (evalParams per element pair, near rules per singularity): the GPU assembles
+    class by class, the oracle looks the class up per pair; BASELINE configs[4] uses P2 with such an order"""
+    from pynucleus_amd.fractionalOrders import leftRightFractionalOrder, layersFractionalOrder, variableConstFractionalOrder
+    if case == 'leftRight_P1':
+        b = _build_variable('disc', 3, leftRightFractionalOrder(0.25, 0.75))
+    elif case == 'layers_P1':
+        orders = np.array([[0.3, 0.4, 0.5], [0.4, 0.5, 0.6], [0.5, 0.6, 0.7]])
+        b = _build_variable('disc', 3, layersFractionalOrder(2, np.array([-1., -0.3, 0.3, 1.]), orders))
+    elif case == 'leftRight_P2':
+        b = _build_variable('disc', 2, leftRightFractionalOrder(0.25, 0.75), element='P2')
+    elif case == 'varconst_1d':
+        b = _build_variable('interval', 5, variableConstFractionalOrder(0.75))
+    elif case == 'leftRight_1d':
+        b = _build_variable('interval', 5, leftRightFractionalOrder(0.3, 0.6))
+    else:
+        b = _build_variable('disc', 3, leftRightFractionalOrder(0.5, 0.75), zeroExterior=False)
+    _compare(b)
+
+
 def test_gemv_and_cg():
     builder = _build('disc', 4, 0.5, params={'target_order': 0.5})
     A, Aref = _compare(builder)
