@@ -75,7 +75,8 @@ enum pnl_counter {
     PNL_C_NUM_BOUNDARY_PAIRS,
     PNL_C_NUM_BOUNDARY_INTEGRATIONS,
     PNL_C_ORDER_OVERFLOW,              /* pairs whose order exceeded the tables (error)  */
-    PNL_C_RESERVED6, PNL_C_RESERVED7,
+    PNL_C_UNIFORM_TILE_PAIRS,          /* pairs integrated by the uniform-tile kernel (subset of assembled) */
+    PNL_C_RESERVED7,
     PNL_C_HIST0 = 8                    /* [8+q]: distant pairs of order q, q < 120; [128..130]: vertex/edge/face */
 };
 #define PNL_NUM_COUNTERS 131
@@ -162,8 +163,8 @@ int pnl_spmv(pnl_context *ctx, const double *data_dev, const double *diag_dev, c
 /* counters of the last assemble call (synchronises the stream) */
 int pnl_get_counters(pnl_context *ctx, int64_t *out, int n);
 /* device time of the last assemble call per phase in milliseconds (HIP events on the context's stream):
- * [0] tile kernel (distant pairs, one per lane), [1] work-list kernel (distant pairs, one per wave),
- * [2] singular pairs, [3] boundary term, [4] mirror + diagonal scatter, [5] total */
+ * [0] general tile kernel (distant pairs, one per lane), [1] work-list kernels (high orders),
+ * [2] singular pairs, [3] boundary term, [4] mirror + diagonal scatter, [5] total, [6] uniform-tile kernel */
 int pnl_get_phase_ms(pnl_context *ctx, float *out, int n);
 
 /* ---- adjacent solve path: Dense_LinearOperator.matvec (dgemv, DenseLinearOperator_{SCALAR}.pxi:14-18)

@@ -242,13 +242,14 @@ class Context:
         hist = {q: int(out[8+q]) for q in range(120) if out[8+q]}
         sing = {-1-k: int(out[128+k]) for k in range(3)}
         return dict(numCellPairs=int(out[0]), numAssembledCellPairs=int(out[1]), numIntegrations=int(out[2]),
-                    numBoundaryPairs=int(out[3]), numBoundaryIntegrations=int(out[4]), orders=hist, singular=sing, debug6=int(out[6]))
+                    numBoundaryPairs=int(out[3]), numBoundaryIntegrations=int(out[4]), orders=hist, singular=sing,
+                    uniformTilePairs=int(out[6]))
 
     def phase_ms(self):
-        out = np.zeros(6, dtype=np.float32)
-        self.check(self.L.pnl_get_phase_ms(self.h, out.ctypes.data, 6))
-        return dict(tiles=float(out[0]), worklist=float(out[1]), singular=float(out[2]), boundary=float(out[3]),
-                    scatter_mirror=float(out[4]), total=float(out[5]))
+        out = np.zeros(7, dtype=np.float32)
+        self.check(self.L.pnl_get_phase_ms(self.h, out.ctypes.data, 7))
+        return dict(tiles=float(out[0]), tiles_uniform=float(out[6]), worklist=float(out[1]), singular=float(out[2]),
+                    boundary=float(out[3]), scatter_mirror=float(out[4]), total=float(out[5]))
 
     def gemv(self, A_ptr, ldA, n, x_ptr, y_ptr, symmetric_half=False):
         self.check(self.L.pnl_gemv(self.h, C.c_void_p(A_ptr), int(ldA), int(n), C.c_void_p(x_ptr), C.c_void_p(y_ptr),

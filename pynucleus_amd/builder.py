@@ -123,7 +123,7 @@ class nonlocalBuilder:
         ms = ctx.phase_ms()
         for k in ('numCellPairs', 'numAssembledCellPairs', 'numIntegrations'):
             self.PLogger.addValue(k, cnt[k])
-        self.PLogger.addTimer('interior', 1e-3*(ms['tiles']+ms['worklist']+ms['singular']))
+        self.PLogger.addTimer('interior', 1e-3*(ms['tiles']+ms['tiles_uniform']+ms['worklist']+ms['singular']))
         self.PLogger.addTimer('zeroExterior', 1e-3*ms['boundary'])
         info = dict(counters=cnt, phase_ms=ms)
         if size == 1:

@@ -77,7 +77,8 @@ struct pnl_context {
     bool use_pure = true;             // debug: PNL_PURE=0 sends every tile through the general kernel
     struct BlockAgg { double cx, cy, rad, hmax, Lmin, Lmax; bool full; };
     std::vector<BlockAgg> blocks;
-    hipEvent_t ev[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    bool pure_launched = false;
     bool ev_valid = false;
     unsigned long long visited_pairs = 0;
     bool tiles_launched = false;
@@ -448,9 +449,13 @@ int launch_pure(pnl_context *ctx, double *A, int64_t ldA) {
 template <int DIM, int DPE, int TILE, int KT>
 int launch_tiles(pnl_context *ctx, int ntiles_all, double *A, int64_t ldA, int cell_begin, int cell_end) {
     using S = TileSmem<DIM, DPE, TILE>;
+    HIPCHK(ctx, hipEventRecord(ctx->ev[7], ctx->stream));
+    ctx->pure_launched = false;
     if (TILE == 64 && DPE <= 3) {
         int rc = launch_pure<DIM, (DPE <= 3 ? DPE : 3), KT>(ctx, A, ldA);
         if (rc) return rc;
+        ctx->pure_launched = ctx->n_pure > 0;
+        HIPCHK(ctx, hipEventRecord(ctx->ev[7], ctx->stream));
     }
     const int ntiles = ctx->n_mixed;
     (void)ntiles_all;
@@ -1284,10 +1289,14 @@ int pnl_get_phase_ms(pnl_context *ctx, float *out, int n) {
     if (!ctx || !out || n <= 0) return PNL_ERR_INVALID;
     if (!ctx->ev_valid) return fail(ctx, PNL_ERR_STATE, "nothing assembled yet");
     HIPCHK(ctx, hipEventSynchronize(ctx->ev[5]));
-    float t[6] = {0, 0, 0, 0, 0, 0}, tmp;
+    float t[7] = {0, 0, 0, 0, 0, 0, 0}, tmp;
     if (ctx->tiles_launched) {
-        HIPCHK(ctx, hipEventElapsedTime(&t[0], ctx->ev[0], ctx->ev[6]));  // tile kernel
-        HIPCHK(ctx, hipEventElapsedTime(&t[1], ctx->ev[6], ctx->ev[1]));  // work-list kernel
+        HIPCHK(ctx, hipEventElapsedTime(&t[0], ctx->ev[0], ctx->ev[6]));  // tile kernels (uniform + general; last class)
+        HIPCHK(ctx, hipEventElapsedTime(&t[1], ctx->ev[6], ctx->ev[1]));  // work-list kernels
+        if (ctx->pure_launched && ctx->cls.size() == 1) {
+            HIPCHK(ctx, hipEventElapsedTime(&t[6], ctx->ev[0], ctx->ev[7]));   // uniform-tile kernel alone
+            t[0] -= t[6];
+        }
     }
     HIPCHK(ctx, hipEventElapsedTime(&tmp, ctx->ev[1], ctx->ev[2]));       // mirror
     HIPCHK(ctx, hipEventElapsedTime(&t[2], ctx->ev[2], ctx->ev[3]));      // singular
@@ -1295,7 +1304,7 @@ int pnl_get_phase_ms(pnl_context *ctx, float *out, int n) {
     HIPCHK(ctx, hipEventElapsedTime(&t[4], ctx->ev[4], ctx->ev[5]));      // diagonal scatter
     t[4] += tmp;
     HIPCHK(ctx, hipEventElapsedTime(&t[5], ctx->ev[0], ctx->ev[5]));
-    for (int i = 0; i < n && i < 6; i++) out[i] = t[i];
+    for (int i = 0; i < n && i < 7; i++) out[i] = t[i];
     return PNL_OK;
 }
 

@@ -1,0 +1,65 @@
+#!/usr/bin/env python3
+"""Turn one tools/profile_round.sh output directory (gpurun_out/<tag>) into the tracked artefacts under profiles/:
+  <tag>_bench_noRef<N>.json            the bench line
+  <tag>_bench_noRef<N>_kernel_stats.csv rocprofv3 --kernel-trace --stats of the same command
+  <tag>_pmc_summary_noRef<N>.json      mean counter value per dispatch and kernel (separate --pmc passes)
+  pmc_traffic.json                     HBM bytes per launch of the tile kernels, corrected as MI355X_MICROARCH.md prescribes
+usage: tools/collect_profiles.py <tag> <noRef>"""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+tag, noRef = sys.argv[1], sys.argv[2]
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src = os.path.join(root, 'gpurun_out', tag)
+dst = os.path.join(root, 'profiles')
+shutil.copy(os.path.join(src, 'bench_noRef{}.json'.format(noRef)), os.path.join(dst, '{}_bench_noRef{}.json'.format(tag, noRef)))
+stats = glob.glob(os.path.join(src, 'stats', '*', '*kernel_stats.csv'))
+if stats:
+    shutil.copy(stats[0], os.path.join(dst, '{}_bench_noRef{}_kernel_stats.csv'.format(tag, noRef)))
+
+
+def short(name):
+    n = name.split('(')[0].split('<')[0].split()[-1]
+    return n
+
+
+summary = collections.defaultdict(dict)
+for d in ('pmc_fetch', 'pmc_write', 'pmc_tcc'):
+    for fn in glob.glob(os.path.join(src, d, '*', '*counter_collection.csv')):
+        agg = collections.defaultdict(lambda: collections.defaultdict(float))
+        calls = collections.defaultdict(set)
+        for r in csv.DictReader(open(fn)):
+            k = short(r['Kernel_Name'])
+            if k.startswith('at::') or 'rocclr' in k or 'vectorized' in k:
+                continue
+            agg[k][r['Counter_Name']] += float(r['Counter_Value'])
+            calls[k].add(r['Dispatch_Id'])
+        for k in agg:
+            for c, v in agg[k].items():
+                summary[k][c] = v/max(1, len(calls[k]))
+with open(os.path.join(dst, '{}_pmc_summary_noRef{}.json'.format(tag, noRef)), 'w') as f:
+    json.dump(summary, f, indent=1, sort_keys=True)
+
+traffic_fn = os.path.join(dst, 'pmc_traffic.json')
+rec = {}
+if os.path.exists(traffic_fn):
+    rec = json.load(open(traffic_fn))
+rec['comment'] = ('HBM traffic per launch of the tile kernels from rocprofv3 --pmc passes of bench.py (tools/profile_round.sh): '
+                  'FETCH_SIZE and WRITE_SIZE in separate passes (KB units x 1024).  FETCH_SIZE doubled per MI355X_MICROARCH.md '
+                  '(gfx950 reports half of wide coalesced reads); WRITE_SIZE is dominated by 8-byte fp64 atomics.  '
+                  'Raw values: profiles/<tag>_pmc_summary_noRef<N>.json.')
+entry = {'tag': tag}
+for k in ('k_tile_distant', 'k_tile_pure'):
+    if k in summary and 'FETCH_SIZE' in summary[k] and 'WRITE_SIZE' in summary[k]:
+        entry[k+'_hbm_bytes_per_launch'] = int(1024*(2*summary[k]['FETCH_SIZE']+summary[k]['WRITE_SIZE']))
+        entry[k+'_fetch_size_kb'] = summary[k]['FETCH_SIZE']
+        entry[k+'_write_size_kb'] = summary[k]['WRITE_SIZE']
+rec['noRef{}'.format(noRef)] = entry
+with open(traffic_fn, 'w') as f:
+    json.dump(rec, f, indent=1)
+print(json.dumps(entry, indent=1))

@@ -33,5 +33,5 @@ for noRef in [int(a) for a in sys.argv[1].split(',')]:
         print('noRef {} N {} nc {} rep {}: wall {:.2f} ms, phases {} -> {:.3e} pairs/s (device total)'.format(
             noRef, N, nc, rep, 1e3*(t4-t3), {k: round(v, 3) for k, v in ms.items()}, pairs/(1e-3*ms['total'])), flush=True)
     print('   setup: tables {:.2f}s, upload {:.2f}s; evals {} ({:.1f}/pair), orders {}'.format(
-        t1-t0, t2-t1, cnt['numIntegrations'], cnt['numIntegrations']/pairs, dict(list(cnt['orders'].items())[:8])), 'debug6', cnt.get('debug6'), flush=True)
+        t1-t0, t2-t1, cnt['numIntegrations'], cnt['numIntegrations']/pairs, dict(list(cnt['orders'].items())[:8])), 'uniform-tile pairs', cnt.get('uniformTilePairs'), flush=True)
     del A
