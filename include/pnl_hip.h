@@ -46,10 +46,12 @@ enum pnl_kernel_type { PNL_FRACTIONAL = 0, PNL_INDICATOR = 1, PNL_PERIDYNAMIC = 
 
 /* gamma(x,y) = scale * (|x-y|^2)^exponent inside |x-y|^2 <= horizon2 (inf: everywhere).
  * Replaces the opaque c_kernel_params block + kernelFun pointer (kernel_params.pxi:8-30,
- * kernelsCy.pyx:75-294). */
+ * kernelsCy.pyx:75-294).  interaction (finite horizon only): how element pairs cut by the horizon are integrated,
+ * 1 = ball2_retriangulation (interactionDomains.pyx:395-822, 866-980), 2 = ball2_barycenter (:340-392, 982-1067).
+ * Finite-horizon kernels are assembled from an explicit pair list (pnl_assemble_pairs_masked = getSparse NA:1062-1260). */
 typedef struct {
     int32_t ktype;
-    int32_t pad;
+    int32_t interaction;
     double exponent;
     double scale;
     double horizon2;

@@ -72,6 +72,11 @@ static void simplex_of(const nlo_problem *P, int c, double s[MAXV][2], double ce
     for (int l = 0; l < P->dim; l++) center[l] *= fac;
 }
 
+#define NLO_INTERACT 0
+#define NLO_REMOTE 1
+#define NLO_CUT 2
+static int rel_position(const nlo_problem *P, double s1[MAXV][2], int n1, double s2[MAXV][2], int n2);
+
 /* FL2:622-642, FL1:234-253, boundary FL2:1226-1243, FL1:646-660 */
 static int quad_order(const nlo_order_formula *F, double H0, double h1, double h2, double d) {
     double logdh1 = log(d/h1), logdh2 = log(d/h2);
@@ -109,6 +114,7 @@ int nlo_panel(const nlo_problem *P, int c1, int c2, int *perm1, int *perm2, int 
         double s1[MAXV][2], s2[MAXV][2], ce1[2], ce2[2];
         simplex_of(P, c1, s1, ce1);
         simplex_of(P, c2, s2, ce2);
+        if (rel_position(P, s1, nV, s2, nV) == NLO_REMOTE) return NLO_IGNORED;     /* NO:515-517 */
         double d2 = 0.;
         for (int j = 0; j < P->dim; j++) d2 += (ce1[j]-ce2[j])*(ce1[j]-ce2[j]);
         return quad_order(&class_of_cells(P, c1, c2)->qo, P->H0, P->h[c1], P->h[c2], sqrt(d2));
@@ -128,6 +134,348 @@ int nlo_panel(const nlo_problem *P, int c1, int c2, int *perm1, int *perm2, int 
         for (int k = nV*dpv+dped; k < dpe; k++) perm[dpe+k-2*dpv-dped] = dpe+t2[k];
     }
     return -common;
+}
+
+
+/* ---- finite horizon (interactionDomains.pyx) ------------------------------------------------------------------
+ * RELATIVE_POSITION of two simplices for the l2 ball: ball2_retriangulation.getRelativePosition :875-898 and
+ * ball2_barycenter.getRelativePosition :990-1013 (the same vertex-distance test). */
+static int rel_position(const nlo_problem *P, double s1[MAXV][2], int n1, double s2[MAXV][2], int n2) {
+    const double h2 = P->kernel.horizon2;
+    if (isinf(h2)) return NLO_INTERACT;         /* fullSpace :834 */
+    double dmin2 = INFINITY, dmax2 = 0.;
+    for (int i = 0; i < n1; i++)
+        for (int k = 0; k < n2; k++) {
+            double d2 = 0.;
+            for (int j = 0; j < P->dim; j++) d2 += (s1[i][j]-s2[k][j])*(s1[i][j]-s2[k][j]);
+            if (d2 < dmin2) dmin2 = d2;
+            if (d2 > dmax2) dmax2 = d2;
+        }
+    if (dmin2 >= h2) return NLO_REMOTE;
+    if (dmax2 <= h2) return NLO_INTERACT;
+    return NLO_CUT;
+}
+
+typedef struct { int n; double A[3][3][3], b[3][3], vol[3]; } subs_t;
+
+static int is_inside(const nlo_problem *P, const double *x, const double *y) {   /* :900-909 */
+    double d2 = 0.;
+    for (int j = 0; j < P->dim; j++) d2 += (x[j]-y[j])*(x[j]-y[j]);
+    return d2 <= P->kernel.horizon2;
+}
+
+/* ball2_retriangulation.findIntersections :911-938 */
+static int find_intersections(const nlo_problem *P, const double *x, double simplex[MAXV][2], int start, int end, double *out) {
+    double nn = 0., p = 0., q = 0.;
+    for (int k = 0; k < P->dim; k++) {
+        double A = simplex[end][k]-simplex[start][k], B = simplex[start][k]-x[k];
+        nn += A*A; p += A*B; q += B*B;
+    }
+    nn = 1./nn;
+    p *= 2.*nn;
+    q = (q-P->kernel.horizon2)*nn;
+    double A = -p*0.5, B = sqrt(A*A-q), c;
+    int num = 0;
+    c = A-B;
+    if (c >= 0 && c <= 1) out[num++] = c;
+    c = A+B;
+    if (c >= 0 && c <= 1) out[num++] = c;
+    return num;
+}
+
+static void subs_identity(subs_t *S, int nv) {
+    memset(S, 0, sizeof(*S));
+    for (int k = 0; k < nv; k++) S->A[0][k][k] = 1.;
+    S->vol[0] = 1.;
+    S->n = 1;
+}
+
+/* startLoopSubSimplices_Simplex: retriangulationDomain :406-567 (2D; the 1D interval branch :425-446 with
+ * nextSubSimplex_Simplex :71-87), barycenterDomain :358-374 */
+static void subs_simplex(const nlo_problem *P, double s1[MAXV][2], double s2[MAXV][2], subs_t *S) {
+    const int dim = P->dim, nV = dim+1;
+    memset(S, 0, sizeof(*S));
+    if (P->kernel.interaction == 2) {
+        double bary[2] = {0., 0.};
+        for (int v = 0; v < nV; v++) for (int j = 0; j < dim; j++) bary[j] += s2[v][j];
+        for (int j = 0; j < dim; j++) bary[j] /= nV;
+        for (int v = 0; v < nV; v++)
+            if (is_inside(P, s1[v], bary)) { subs_identity(S, nV); return; }
+        return;
+    }
+    if (dim == 1) {
+        const double horizon = sqrt(P->kernel.horizon2);
+        const int lr = s1[0][0] < s2[0][0];
+        const double vol1 = fabs(s1[0][0]-s1[1][0]), inv = 1./vol1;
+        double iv[4];
+        int it, itEnd;
+        iv[0] = s1[0][0]*inv; iv[3] = s1[1][0]*inv;
+        if (lr) {
+            iv[1] = fmax(s1[0][0], s2[0][0]-horizon)*inv;
+            iv[2] = fmin(s1[1][0], s2[1][0]-horizon)*inv;
+            it = 1; itEnd = 3;
+        } else {
+            iv[1] = fmax(s1[0][0], s2[0][0]+horizon)*inv;
+            iv[2] = fmin(s1[1][0], s2[1][0]+horizon)*inv;
+            it = 0; itEnd = 2;
+        }
+        for (; it < itEnd; it++) {
+            const double l = iv[it], r = iv[it+1];
+            if (r-l <= 0) continue;
+            const int m = S->n++;
+            S->A[m][0][0] = r-l; S->A[m][1][1] = r-l;
+            S->b[m][0] = iv[3]-r; S->b[m][1] = l-iv[0];
+            S->vol[m] = r-l;
+        }
+        return;
+    }
+    int insideIJ[3][3], insideI[3], numInside = 0;
+    for (int i = 0; i < 3; i++) {
+        int any = 0;
+        for (int k = 0; k < 3; k++) { insideIJ[i][k] = is_inside(P, s1[i], s2[k]); any |= insideIJ[i][k]; }
+        insideI[i] = any;
+        numInside += any;
+    }
+    double isec[2];
+    if (numInside == 0) return;                 /* the reference raises NotImplementedError; CUT implies numInside >= 1 */
+    if (numInside == 1) {
+        int inside = 0;
+        while (!insideI[inside]) inside++;
+        const int o1 = (inside+1)%3, o2 = (inside+2)%3;
+        double c1 = 0., c2 = 0.;
+        for (int j = 0; j < 3; j++)
+            if (insideIJ[inside][j]) {
+                find_intersections(P, s2[j], s1, inside, o1, isec);
+                c1 = fmax(c1, isec[0]);
+                find_intersections(P, s2[j], s1, inside, o2, isec);
+                c2 = fmax(c2, isec[0]);
+            }
+        if (c1*c2 > 0) {
+            S->A[0][inside][inside] = c1+c2;
+            S->A[0][inside][o1] = c2;
+            S->A[0][inside][o2] = c1;
+            S->A[0][o1][o1] = c1;
+            S->A[0][o2][o2] = c2;
+            S->b[0][inside] = 1-c1-c2;
+            S->vol[0] = c1*c2;
+            S->n = 1;
+        }
+        return;
+    }
+    if (numInside == 2) {
+        int outside = 0;
+        while (insideI[outside]) outside++;
+        const int i1 = (outside+1)%3, i2 = (outside+2)%3;
+        double c1 = 1., c2 = 1.;
+        for (int j = 0; j < 3; j++) {
+            if (insideIJ[i1][j]) { find_intersections(P, s2[j], s1, outside, i1, isec); c1 = fmin(c1, isec[0]); }
+            if (insideIJ[i2][j]) { find_intersections(P, s2[j], s1, outside, i2, isec); c2 = fmin(c2, isec[0]); }
+        }
+        /* :509-516, literally (simplex2 coordinates, d2 without the square) */
+        double d1 = 0., d2 = 0.;
+        for (int k = 0; k < 2; k++) {
+            const double t = s2[outside][k]+c1*(s2[i1][k]-s2[outside][k])-s2[i2][k];
+            d1 += t*t;
+            d2 += s2[outside][k]+c2*(s2[i2][k]-s2[outside][k])-s2[i1][k];
+        }
+        if (d1 < d2) {
+            if (1-c1 > 0) {
+                const int m = S->n++;
+                S->A[m][outside][outside] = 1-c1;
+                S->A[m][i1][i1] = 1-c1;
+                S->A[m][i1][i2] = -c1;
+                S->A[m][i2][i2] = 1.;
+                S->b[m][i1] = c1;
+                S->vol[m] = 1-c1;
+            }
+            if (c1*(1-c2) > 0.) {
+                const int m = S->n++;
+                S->A[m][outside][outside] = 1-c2;
+                S->A[m][i2][i2] = 1;
+                S->A[m][i2][outside] = c2;
+                S->A[m][outside][i1] = 1-c1;
+                S->A[m][i1][i1] = c1;
+                S->vol[m] = c1*(1-c2);
+            }
+        } else {
+            if (1-c2 > 0) {
+                const int m = S->n++;
+                S->A[m][outside][outside] = 1-c2;
+                S->A[m][i2][i2] = 1-c2;
+                S->A[m][i2][i1] = -c2;
+                S->A[m][i1][i1] = 1.;
+                S->b[m][i2] = c2;
+                S->vol[m] = 1-c2;
+            }
+            if (c2*(1-c1) > 0.) {
+                const int m = S->n++;
+                S->A[m][outside][outside] = 1-c1;
+                S->A[m][i1][i1] = 1;
+                S->A[m][i1][outside] = c1;
+                S->A[m][outside][i2] = 1-c2;
+                S->A[m][i2][i2] = c2;
+                S->vol[m] = c2*(1-c1);
+            }
+        }
+        return;
+    }
+    subs_identity(S, 3);
+}
+
+/* startLoopSubSimplices_Node: retriangulationDomain :570-822 (no special points for the l2 ball: specialOffsets is empty,
+ * :43), barycenterDomain :376-392 */
+static void subs_node(const nlo_problem *P, const double *x, double s2[MAXV][2], subs_t *S) {
+    const int dim = P->dim, nV = dim+1;
+    memset(S, 0, sizeof(*S));
+    if (P->kernel.interaction == 2) {
+        double bary[2] = {0., 0.};
+        for (int v = 0; v < nV; v++) for (int j = 0; j < dim; j++) bary[j] += s2[v][j];
+        for (int j = 0; j < dim; j++) bary[j] /= nV;
+        if (is_inside(P, x, bary)) subs_identity(S, nV);
+        return;
+    }
+    int ind[3] = {0, 0, 0}, numInside = 0;
+    for (int j = 0; j < nV; j++) { ind[j] = is_inside(P, x, s2[j]); numInside += ind[j]; }
+    double isec[2];
+    if (dim == 1) {
+        if (numInside == 0) {
+            if (find_intersections(P, x, s2, 0, 1, isec) == 2) {
+                S->A[0][0][0] = 1-isec[0]; S->A[0][1][0] = isec[0];
+                S->A[0][1][1] = isec[1]; S->A[0][0][1] = 1.-isec[1];
+                S->vol[0] = isec[1]-isec[0];
+                S->n = 1;
+            }
+        } else if (numInside == 1) {
+            int inside = 0;
+            while (!ind[inside]) inside++;
+            const int outside = (inside+1)%2;
+            find_intersections(P, x, s2, inside, outside, isec);
+            S->A[0][inside][inside] = 1.;
+            S->A[0][outside][outside] = isec[0];
+            S->A[0][inside][outside] = 1.-isec[0];
+            S->vol[0] = isec[0];
+            S->n = 1;
+        } else subs_identity(S, 2);
+        return;
+    }
+    if (numInside == 0) return;                 /* "There can be a nonzero intersection, but we ignore it" :664 */
+    if (numInside == 1) {
+        int inside = 0;
+        while (!ind[inside]) inside++;
+        const int o1 = (inside+1)%3, o2 = (inside+2)%3;
+        find_intersections(P, x, s2, inside, o1, isec);
+        const double c1 = isec[0];
+        find_intersections(P, x, s2, inside, o2, isec);
+        const double c2 = isec[0];
+        const int num = find_intersections(P, x, s2, o1, o2, isec);
+        if (num == 0) {
+            S->A[0][inside][inside] = 1; S->A[0][inside][o1] = 1-c1; S->A[0][o1][o1] = c1;
+            S->A[0][o2][o2] = c2; S->A[0][inside][o2] = 1-c2;
+            S->vol[0] = c1*c2;
+            S->n = 1;
+        } else if (num == 2) {
+            S->A[0][inside][inside] = 1; S->A[0][o1][o1] = c1; S->A[0][inside][o1] = 1-c1;
+            S->A[0][o2][o2] = isec[0]; S->A[0][o1][o2] = 1-isec[0];
+            S->vol[0] = c1*isec[0];
+            S->A[1][inside][inside] = 1; S->A[1][o1][o1] = 1-isec[0]; S->A[1][o2][o1] = isec[0];
+            S->A[1][o1][o2] = 1-isec[1]; S->A[1][o2][o2] = isec[1];
+            S->vol[1] = isec[1]-isec[0];
+            S->A[2][inside][inside] = 1; S->A[2][o1][o1] = 1-isec[1]; S->A[2][o2][o1] = isec[1];
+            S->A[2][o2][o2] = c2; S->A[2][inside][o2] = 1-c2;
+            S->vol[2] = c2*(1-isec[1]);
+            S->n = 3;
+        } else {
+            S->A[0][inside][inside] = 1; S->A[0][o1][o1] = c1; S->A[0][inside][o1] = 1-c1;
+            S->A[0][o2][o2] = isec[0]; S->A[0][o1][o2] = 1-isec[0];
+            S->vol[0] = c1*isec[0];
+            S->A[1][inside][inside] = 1; S->A[1][o1][o1] = 1-isec[0]; S->A[1][o2][o1] = isec[0];
+            S->A[1][o2][o2] = c2; S->A[1][inside][o2] = 1-c2;
+            S->vol[1] = c2*(1-isec[0]);
+            S->n = 2;
+        }
+        return;
+    }
+    if (numInside == 2) {
+        int outside = 0;
+        while (ind[outside]) outside++;
+        const int i1 = (outside+1)%3, i2 = (outside+2)%3;
+        find_intersections(P, x, s2, outside, i1, isec);
+        const double c1 = isec[0];
+        find_intersections(P, x, s2, outside, i2, isec);
+        const double c2 = isec[0];
+        double d1 = 0., d2 = 0.;
+        for (int k = 0; k < 2; k++) {
+            const double t1 = s2[i2][k]-(c1*s2[i1][k]+(1-c1)*s2[outside][k]);
+            const double t2 = s2[i1][k]-(c2*s2[i2][k]+(1-c2)*s2[outside][k]);
+            d1 += t1*t1; d2 += t2*t2;
+        }
+        if (d1 < d2) {
+            S->A[0][i2][i2] = 1; S->A[0][outside][outside] = 1-c2; S->A[0][i2][outside] = c2;
+            S->A[0][i1][i1] = c1; S->A[0][outside][i1] = 1-c1;
+            S->vol[0] = c1*(1-c2);
+            S->A[1][i1][i1] = 1; S->A[1][i2][i2] = 1; S->A[1][outside][outside] = 1-c1; S->A[1][i1][outside] = c1;
+            S->vol[1] = 1-c1;
+        } else {
+            S->A[0][i1][i1] = 1; S->A[0][i2][i2] = c2; S->A[0][outside][i2] = 1-c2;
+            S->A[0][outside][outside] = 1-c1; S->A[0][i1][outside] = c1;
+            S->vol[0] = c2*(1-c1);
+            S->A[1][i1][i1] = 1; S->A[1][i2][i2] = 1; S->A[1][outside][outside] = 1-c2; S->A[1][i2][outside] = c2;
+            S->vol[1] = 1-c2;
+        }
+        S->n = 2;
+        return;
+    }
+    subs_identity(S, 3);
+}
+
+/* local shape functions at barycentric coordinates (fem/PyNucleus_fem/DoFMaps.pyx:1854-2025): P1, P2 on triangles */
+static void shape_eval(const nlo_problem *P, const double *lam, double *phi) {
+    if (P->dpe == P->dim+1) { for (int k = 0; k < P->dpe; k++) phi[k] = lam[k]; return; }
+    phi[0] = lam[0]*(2*lam[0]-1); phi[1] = lam[1]*(2*lam[1]-1); phi[2] = lam[2]*(2*lam[2]-1);
+    phi[3] = 4*lam[0]*lam[1]; phi[4] = 4*lam[1]*lam[2]; phi[5] = 4*lam[0]*lam[2];
+}
+
+/* NO:790-847 eval_distant, cut branch: sub-simplices of simplex1, per quadrature node sub-simplices of simplex2 */
+static void eval_distant_cut(const nlo_problem *P, double s1[MAXV][2], double s2[MAXV][2], double vol, int order, double *contrib,
+                             int64_t *nevals) {
+    const int dim = P->dim, nV = dim+1, dpe = P->dpe;
+    const int off = P->dist_off[order], n = P->dist_off[order+1]-off;
+    const double *bary = P->dist_bary+3*off, *w = P->dist_w+off;
+    const int E = (2*dpe)*(2*dpe+1)/2;
+    for (int k = 0; k < E; k++) contrib[k] = 0.;
+    subs_t S1, S2;
+    subs_simplex(P, s1, s2, &S1);
+    for (int a = 0; a < S1.n; a++)
+        for (int i = 0; i < n; i++) {
+            double lx[3] = {0., 0., 0.}, x[2] = {0., 0.}, psi[2*MAXDPE];
+            for (int k = 0; k < nV; k++) {
+                lx[k] = S1.b[a][k];
+                for (int j = 0; j < nV; j++) lx[k] += S1.A[a][k][j]*bary[3*i+j];
+            }
+            for (int k = 0; k < nV; k++) for (int m = 0; m < dim; m++) x[m] += lx[k]*s1[k][m];
+            shape_eval(P, lx, psi);
+            subs_node(P, x, s2, &S2);
+            for (int b = 0; b < S2.n; b++)
+                for (int j = 0; j < n; j++) {
+                    double ly[3] = {0., 0., 0.}, y[2] = {0., 0.};
+                    for (int k = 0; k < nV; k++) for (int jj = 0; jj < nV; jj++) ly[k] += S2.A[b][k][jj]*bary[3*j+jj];
+                    for (int k = 0; k < nV; k++) for (int m = 0; m < dim; m++) y[m] += ly[k]*s2[k][m];
+                    shape_eval(P, ly, psi+dpe);
+                    double d2 = 0.;
+                    for (int m = 0; m < dim; m++) d2 += (x[m]-y[m])*(x[m]-y[m]);
+                    double val = w[i]*w[j]*kernel_eval(&P->kernel, d2);
+                    val *= S1.vol[a]*S2.vol[b]*vol;
+                    (*nevals)++;
+                    int k = 0;
+                    for (int I = 0; I < 2*dpe; I++) {
+                        const double pI = I < dpe ? psi[I] : -psi[I];
+                        for (int J = I; J < 2*dpe; J++) {
+                            const double pJ = J < dpe ? psi[J] : -psi[J];
+                            contrib[k++] += val*pI*pJ;
+                        }
+                    }
+                }
+        }
 }
 
 /* NO:549-600 addQuadRule: PSI[2 dpe][n*n], rows 0..dpe-1 = phi_I(x_i), rows dpe.. = -phi_I(y_j), k = i*n+j */
@@ -184,6 +532,10 @@ void nlo_eval(const nlo_problem *P0, int c1, int c2, int panel, const int *perm1
     simplex_of(P, c1, s1, ce);
     simplex_of(P, c2, s2, ce);
     for (int k = 0; k < E; k++) contrib[k] = 0.;
+    if (panel >= 1 && rel_position(P, s1, nV, s2, nV) == NLO_CUT) {
+        eval_distant_cut(P, s1, s2, P->vol[c1]*P->vol[c2], panel, contrib, nevals);
+        return;
+    }
     if (panel >= 1) {
         const int off = P->dist_off[panel], n = P->dist_off[panel+1]-off;
         double *PSI = build_distant_psi(P, panel);
@@ -407,7 +759,9 @@ int nlo_get_dense_rows(const nlo_problem *P, double *A, int zero_exterior, int c
             if (panel >= 1 && (panel > P->qmax || P->dist_off[panel+1] == P->dist_off[panel])) return -(1000+panel);
             counters[1]++;
             if (panel >= 1) counters[8+panel]++; else counters[8+NLO_MAX_ORDER+(-panel-1)]++;
-            if (panel >= 1) {
+            if (panel >= 1 && !isinf(P->kernel.horizon2)) {
+                nlo_eval(P, c1, c2, panel, perm1, perm2, perm, contrib, &counters[2]);
+            } else if (panel >= 1) {
                 if (!psi_cache[panel]) psi_cache[panel] = build_distant_psi(P, panel);
                 double s1[MAXV][2], s2[MAXV][2], ce[2];
                 simplex_of(P, c1, s1, ce);

@@ -26,7 +26,7 @@ typedef struct {
 
 typedef struct {
     int32_t ktype;              /* 0 fractional, 1 indicator, 2 peridynamic */
-    int32_t pad;
+    int32_t interaction;        /* finite horizon only: 1 ball2_retriangulation, 2 ball2_barycenter (interactionDomains.pyx) */
     double exponent;            /* power of |x-y|^2 */
     double scale;
     double horizon2;            /* inf = no truncation */

@@ -24,7 +24,7 @@ class nlo_order_formula(C.Structure):
 
 
 class nlo_kernel(C.Structure):
-    _fields_ = [('ktype', C.c_int32), ('pad', C.c_int32), ('exponent', C.c_double), ('scale', C.c_double),
+    _fields_ = [('ktype', C.c_int32), ('interaction', C.c_int32), ('exponent', C.c_double), ('scale', C.c_double),
                 ('horizon2', C.c_double)]
 
 
@@ -83,7 +83,7 @@ def lib():
 
 def _kern(k):
     p = k.device_params()
-    return nlo_kernel(p['ktype'], 0, p['exponent'], p['scale'], p['horizon2'])
+    return nlo_kernel(p['ktype'], p.get('interaction', 0), p['exponent'], p['scale'], p['horizon2'])
 
 
 def _qo(f):

@@ -31,7 +31,7 @@ EXPORTS = ['pnl_create', 'pnl_destroy', 'pnl_error_string', 'pnl_version', 'pnl_
 
 
 class pnl_kernel(C.Structure):
-    _fields_ = [('ktype', C.c_int32), ('pad', C.c_int32), ('exponent', C.c_double), ('scale', C.c_double),
+    _fields_ = [('ktype', C.c_int32), ('interaction', C.c_int32), ('exponent', C.c_double), ('scale', C.c_double),
                 ('horizon2', C.c_double)]
 
 
@@ -184,7 +184,7 @@ class Context:
 
     def _set_kernel(self, which, kernel, formula):
         p = kernel.device_params()
-        k = pnl_kernel(p['ktype'], 0, p['exponent'], p['scale'], p['horizon2'])
+        k = pnl_kernel(p['ktype'], p.get('interaction', 0), p['exponent'], p['scale'], p['horizon2'])
         self.check(self.L.pnl_set_kernel(self.h, which, C.byref(k)))
         f = pnl_order_formula(formula.c0, formula.a, formula.b, formula.e, formula.den0, int(formula.clip_num), 0)
         self.check(self.L.pnl_set_order_formula(self.h, which, C.byref(f)))

@@ -105,6 +105,13 @@ class nonlocalBuilder:
         separate and all-reduces the N-vector in matvec instead."""
         import torch
         from .linear_operators import Dense_LinearOperator, DistributedDense_LinearOperator
+        if self.kernel.finiteHorizon:
+            # the reference's all-pairs loop visits every pair and ignores the REMOTE ones; the same matrix is obtained from
+            # the pairs within the horizon (getSparse), stored densely
+            ctx = self.context()
+            S = self.getSparse()
+            A = torch.from_numpy(S.toarray()).to(torch.device('cuda', ctx.device))
+            return Dense_LinearOperator(A, ctx, S.info)
         ctx = self.context()
         dev = torch.device('cuda', ctx.device)
         N = self.dm.num_dofs
@@ -175,8 +182,79 @@ class nonlocalBuilder:
         self.assembleClusters(Pnear, Anear=A, _globalBoundary=False, _clusterBoundary=self.zeroExterior)
         return float(A.data[0])
 
+    def interactingCellPairs(self):
+        """all ordered cell pairs c1 <= c2 that the horizon does not separate for sure: |centre1 - centre2| <= delta + r1 + r2
+        with r = largest vertex distance from the centre.  A superset of the pairs getRelativePosition does not call
+        REMOTE; the reference enumerates a superset too (cells of covering cluster pairs, NA:1150-1170, CM:4139-4194) and
+        the device drops the REMOTE ones in its classification (NO:515-517), so the assembled entries are the same."""
+        from scipy.spatial import cKDTree
+        mesh = self.mesh
+        v = mesh.vertices[mesh.cells]
+        cen = v.mean(axis=1)
+        rad = np.sqrt(((v-cen[:, None, :])**2).sum(axis=2)).max(axis=1)
+        delta = self.kernel.horizonValue
+        tree = cKDTree(cen)
+        pr = tree.query_pairs(delta+2.*rad.max(), output_type='ndarray')
+        if pr.shape[0]:
+            d = np.sqrt(((cen[pr[:, 0]]-cen[pr[:, 1]])**2).sum(axis=1))
+            pr = pr[d <= delta+rad[pr[:, 0]]+rad[pr[:, 1]]]
+        lo, hi = np.minimum(pr[:, 0], pr[:, 1]), np.maximum(pr[:, 0], pr[:, 1])
+        diag = np.arange(mesh.num_cells)
+        pairs = np.stack([np.concatenate([diag, lo]), np.concatenate([diag, hi])], axis=1)
+        order = np.lexsort((pairs[:, 1], pairs[:, 0]))
+        return np.ascontiguousarray(pairs[order], dtype=np.int32)
+
     def getSparse(self, returnNearField=False):
-        raise NotImplementedError('finite-horizon sparse assembly is not implemented on the GPU path yet')
+        """Finite-horizon operator as a sparse matrix (NA:1062-1260): every element pair within the horizon is classified
+        (REMOTE / INTERACT / CUT, getRelativePosition), integrated (cut pairs through the sub-simplex loops NO:790-847) and
+        scattered without masks into the sparsity pattern of all DoF pairs that share such an element pair.  Symmetric
+        storage (SSS) unless params['forceUnsymmetric']."""
+        import torch
+        import scipy.sparse as sp
+        from .linear_operators import CSR_LinearOperator, SSS_LinearOperator
+        if not self.kernel.finiteHorizon:
+            raise NotImplementedError('getSparse needs a finite horizon; use getDense / getH2 for horizon = inf')
+        ctx = self.context()
+        dev = torch.device('cuda', ctx.device)
+        dm = self.dm
+        N, nc, dpe = dm.num_dofs, self.mesh.num_cells, dm.dofs_per_element
+        pairs = self.interactingCellPairs()
+        # sparsity pattern: DoFs I, J coupled through an element pair (c1, c2): G = C^T (P + P^T) C
+        rows = np.repeat(np.arange(nc), dpe)
+        d = dm.dofs.reshape(-1)
+        m = d >= 0
+        C = sp.csr_matrix((np.ones(int(m.sum()), dtype=np.int8), (rows[m], d[m])), shape=(nc, N))
+        Pm = sp.csr_matrix((np.ones(pairs.shape[0], dtype=np.int8), (pairs[:, 0], pairs[:, 1])), shape=(nc, nc))
+        G = (C.T.astype(np.int32) @ ((Pm+Pm.T).astype(np.int32) @ C.astype(np.int32))).tocsr()
+        G.sort_indices()
+        symmetric = not self.params.get('forceUnsymmetric', False)
+        if symmetric:
+            G = sp.tril(G, k=-1, format='csr')
+            G.sort_indices()
+        indptr, indices = G.indptr.astype(np.int32), G.indices.astype(np.int32)
+        A = (SSS_LinearOperator if symmetric else CSR_LinearOperator)(indptr, indices, N, ctx, dev)
+        A._bind()
+        data_ptr, diag_ptr = A._ptrs()
+        E = (2*dpe)*(2*dpe+1)//2
+        full = np.zeros(4, dtype=np.uint64)
+        for k in range(E):
+            full[k//64] |= np.uint64(1) << np.uint64(k % 64)
+        maxNNZ = int(self.params.get('maxMasksNNZ', 10000000))
+        totals = dict(numCellPairs=0, numAssembledCellPairs=0, numIntegrations=0)
+        ms_total = 0.
+        for s0 in range(0, pairs.shape[0], maxNNZ):
+            chunk = pairs[s0:s0+maxNNZ]
+            ctx.assemble_pairs_masked(chunk, np.tile(full, (chunk.shape[0], 1)), data_ptr, diag_ptr)
+            cnt = ctx.counters()
+            for k in totals:
+                totals[k] += cnt[k]
+            ms_total += ctx.phase_ms()['total']
+        ctx.synchronize()
+        for k, v in totals.items():
+            self.PLogger.addValue(k, v)
+        self.PLogger.addTimer('interior - compute', 1e-3*ms_total)
+        A.info = dict(counters=totals, interior_ms=ms_total, num_candidate_pairs=int(pairs.shape[0]))
+        return (A, pairs) if returnNearField else A
 
     def getH2RefinementParams(self):
         """NA:2386-2431: eta, leaf size and depth of the cluster tree from params"""

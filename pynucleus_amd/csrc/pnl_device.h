@@ -11,6 +11,7 @@ struct DevKernel {
     int ktype;                  // 0 fractional, 1 indicator, 2 peridynamic
     int fast;                   // 1: fractional, exponent == -1.5, no horizon (s = 1/2 in 2D)
     double exponent, scale, horizon2;
+    int interaction, pad;       // finite horizon: 1 ball2_retriangulation, 2 ball2_barycenter
 };
 
 struct DevFormula {

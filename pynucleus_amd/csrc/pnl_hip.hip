@@ -135,6 +135,7 @@ DevKernel to_dev(const pnl_kernel &k, int dim) {
     d.exponent = k.exponent;
     d.scale = k.scale;
     d.horizon2 = k.horizon2;
+    d.interaction = k.interaction; d.pad = 0;
     d.fast = (k.ktype == PNL_FRACTIONAL && k.exponent == -1.5 && std::isinf(k.horizon2) && dim == 2) ? 1 : 0;
     return d;
 }
@@ -755,6 +756,10 @@ int check_ready(pnl_context *ctx) {
 }
 
 int dispatch(pnl_context *ctx, double *A, int64_t ldA, int zero_exterior, int ntiles, int cell_begin, int cell_end, int flags) {
+    for (auto *c : ctx->cls)
+        if (!std::isinf(c->kern[0].horizon2))
+            return fail(ctx, PNL_ERR_UNSUPPORTED, "finite-horizon kernels are assembled from an explicit pair list (pnl_assemble_pairs_masked, "
+                        "nonlocalBuilder.getSparse): the all-pairs dense loop has no REMOTE / CUT handling");
     refresh_tables(ctx);
     if (ctx->dim == 2 && ctx->dpe == 3) return assemble_impl<2, 3, TILE_P1>(ctx, A, ldA, zero_exterior, ntiles, cell_begin, cell_end, flags);
     if (ctx->dim == 2 && ctx->dpe == 6) return assemble_impl<2, 6, TILE_P2>(ctx, A, ldA, zero_exterior, ntiles, cell_begin, cell_end, flags);
@@ -966,8 +971,9 @@ int pnl_select_class(pnl_context *ctx, int k) {
 int pnl_set_kernel(pnl_context *ctx, int which, const pnl_kernel *k) {
     if (!ctx || !k || which < 0 || which > 1) return fail(ctx, PNL_ERR_INVALID, "bad kernel arguments");
     if (k->ktype < 0 || k->ktype > 2) return fail(ctx, PNL_ERR_UNSUPPORTED, "kernel type %d is not implemented", k->ktype);
-    if (!std::isinf(k->horizon2) && which == PNL_INTERIOR)
-        return fail(ctx, PNL_ERR_UNSUPPORTED, "finite-horizon kernels (cut elements) are not implemented on the GPU path yet");
+    if (!std::isinf(k->horizon2) && (k->interaction < 1 || k->interaction > 2 || !(k->horizon2 > 0.)))
+        return fail(ctx, PNL_ERR_UNSUPPORTED, "finite horizon: interaction %d is not implemented (1 ball2_retriangulation, 2 ball2_barycenter)",
+                    k->interaction);
     ctx->C().kern[which] = *k;
     ctx->C().have_kernel[which] = true;
     return PNL_OK;
@@ -1211,6 +1217,8 @@ int pnl_assemble_pairs_masked(pnl_context *ctx, int np, const int32_t *pairs, co
     if ((rc = upload(ctx, ctx->b_mp_pairs, pairs, (size_t)2*np))) return rc;
     if ((rc = upload(ctx, ctx->b_mp_masks, masks, (size_t)4*np))) return rc;
     if (ctx->nlab > 0) return fail(ctx, PNL_ERR_UNSUPPORTED, "cluster assembly with a variable order needs the jump terms (NA:1966-2156)");
+    if (!std::isinf(ctx->C().kern[0].horizon2) && ctx->qmax > PNL_CUT_SHIFT)
+        return fail(ctx, PNL_ERR_UNSUPPORTED, "finite horizon: upload distant rules up to order %d at most", PNL_CUT_SHIFT);
     SparseOut S;
     if ((rc = sparse_ready(ctx, data, diag, S))) return rc;
     HIPCHK(ctx, hipMemsetAsync(ctx->b_counters.p, 0, sizeof(unsigned long long)*PNL_NCOUNTERS, ctx->stream));

@@ -932,6 +932,511 @@ k_tile_pure(const DevProblem P, const int2 *__restrict__ tiles, int ntiles, doub
     }
 }
 
+#define PNL_WL_LANE_MAXPTS 40
+// ---------------------------------------------------------------------------------------------
+// Finite horizon, l2 ball (interactionDomains.pyx): relative position of two simplices by their vertex distances
+// (ball2_retriangulation.getRelativePosition :875-898 = ball2_barycenter :990-1013) and the evaluation of pairs that
+// the horizon CUTS (eval_distant NO:790-847): sub-simplices of simplex1 (startLoopSubSimplices_Simplex, :406-567), and
+// for every quadrature node x of them the sub-simplices of simplex2 inside the ball around x
+// (startLoopSubSimplices_Node, :570-822).  A sub-simplex is kept as the barycentric coordinates of its vertices in a
+// frame ROTATED so that the distinguished vertex (the only one inside / the only one outside) is vertex 0 -- the
+// reference's index arithmetic (inside+1)%3, (inside+2)%3 is exactly that rotation -- which keeps every array index
+// static; the rotation is undone on the barycentric coordinates of each quadrature point.
+#define PNL_CUT_SHIFT 60        // sorted-list bin of a cut pair = order + PNL_CUT_SHIFT (orders <= 60)
+#define PNL_INTERACT 0
+#define PNL_REMOTE 1
+#define PNL_CUT 2
+
+template <int DIM>
+__device__ __forceinline__ int rel_position(double h2, const double *av, const double *bv) {
+    // no FMA contraction in the geometric predicates: symmetric meshes produce exact ties (d1 == d2, |x-y|^2 == horizon^2)
+    // and the branch taken must be the one plain IEEE evaluation takes
+#pragma clang fp contract(off)
+    constexpr int NV = DIM+1;
+    double dmin2 = 1e300, dmax2 = 0.;
+#pragma unroll
+    for (int i = 0; i < NV; i++)
+#pragma unroll
+        for (int k = 0; k < NV; k++) {
+            double d2 = 0.;
+#pragma unroll
+            for (int d = 0; d < DIM; d++) { const double t = av[i*DIM+d]-bv[k*DIM+d]; d2 += t*t; }
+            dmin2 = fmin(dmin2, d2);
+            dmax2 = fmax(dmax2, d2);
+        }
+    if (dmin2 >= h2) return PNL_REMOTE;
+    if (dmax2 <= h2) return PNL_INTERACT;
+    return PNL_CUT;
+}
+
+// ball2_retriangulation.findIntersections :911-938 on the segment p0 -> p1; returns the count, t[0] <= t[1]
+template <int DIM>
+__device__ __forceinline__ int find_intersections(double h2, const double *x, const double *p0, const double *p1, double *t) {
+    // no FMA contraction in the geometric predicates: symmetric meshes produce exact ties (d1 == d2, |x-y|^2 == horizon^2)
+    // and the branch taken must be the one plain IEEE evaluation takes
+#pragma clang fp contract(off)
+    double nn = 0., p = 0., q = 0.;
+#pragma unroll
+    for (int k = 0; k < DIM; k++) {
+        const double A = p1[k]-p0[k], B = p0[k]-x[k];
+        nn += A*A; p += A*B; q += B*B;
+    }
+    nn = 1./nn;
+    p *= 2.*nn;
+    q = (q-h2)*nn;
+    const double A = -p*0.5, B = sqrt(A*A-q);
+    int num = 0;
+    double c = A-B;
+    t[0] = t[1] = 0.;
+    if (c >= 0 && c <= 1) t[num++] = c;
+    c = A+B;
+    if (c >= 0 && c <= 1) t[num++] = c;
+    return num;
+}
+
+template <int DIM>
+struct SubSimplices {
+    static constexpr int NV = DIM+1;
+    int n, rot;                 // number of sub-simplices; rotation of the frame the cases are written in
+    // barycentric transform of the reference: node -> b + A node (A[s][k][j]: coordinate k from coordinate j), first in
+    // the rotated frame, after unrotate() in the frame of the parent simplex
+    double A[3][NV][NV], b[3][NV];
+    double vol[3];
+    __device__ __forceinline__ void clear() {
+        n = 0; rot = 0;
+#pragma unroll
+        for (int s = 0; s < 3; s++) {
+            vol[s] = 0.;
+#pragma unroll
+            for (int k = 0; k < NV; k++) {
+                b[s][k] = 0.;
+#pragma unroll
+                for (int j = 0; j < NV; j++) A[s][k][j] = 0.;
+            }
+        }
+    }
+    __device__ __forceinline__ void identity() {
+        clear();
+#pragma unroll
+        for (int k = 0; k < NV; k++) A[0][k][k] = 1.;
+        vol[0] = 1.;
+        n = 1;
+    }
+    // rotated frame -> parent frame: entry (k, j) of the parent frame is entry ((k-rot)%NV, (j-rot)%NV) of the rotated one
+    __device__ __forceinline__ void unrotate() {
+        if (rot == 0) return;
+#pragma unroll
+        for (int s = 0; s < 3; s++) {
+            double Ao[NV][NV], bo[NV];
+#pragma unroll
+            for (int k = 0; k < NV; k++) {
+                double bv = 0.;
+#pragma unroll
+                for (int r = 1; r < NV; r++) bv = (rot == r) ? b[s][(k+NV-r)%NV] : bv;
+                bo[k] = bv;
+#pragma unroll
+                for (int j = 0; j < NV; j++) {
+                    double av = 0.;
+#pragma unroll
+                    for (int r = 1; r < NV; r++) av = (rot == r) ? A[s][(k+NV-r)%NV][(j+NV-r)%NV] : av;
+                    Ao[k][j] = av;
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < NV; k++) {
+                b[s][k] = bo[k];
+#pragma unroll
+                for (int j = 0; j < NV; j++) A[s][k][j] = Ao[k][j];
+            }
+        }
+    }
+};
+
+// vertex (k + rot) % NV of a simplex, without dynamic register indexing
+template <int DIM>
+__device__ __forceinline__ void rotated_vertex(const double *v, int rot, int k, double *out) {
+    constexpr int NV = DIM+1;
+#pragma unroll
+    for (int d = 0; d < DIM; d++) {
+        double r = 0.;
+#pragma unroll
+        for (int m = 0; m < NV; m++) r = (((k+rot)%NV) == m) ? v[m*DIM+d] : r;
+        out[d] = r;
+    }
+}
+
+// startLoopSubSimplices_Node: sub-simplices of simplex bv inside the ball around x
+template <int DIM>
+__device__ __forceinline__ void subs_node(const DevKernel &K, const double *x, const double *bv, SubSimplices<DIM> &S) {
+    // no FMA contraction in the geometric code: symmetric meshes produce exact ties (d1 == d2, |x-y|^2 == horizon^2) and the
+    // branch taken must be the one the plain IEEE evaluation of the same expressions takes
+#pragma clang fp contract(off)
+    constexpr int NV = DIM+1;
+    const double h2 = K.horizon2;
+    S.clear();
+    if (K.interaction == 2) {                           // barycenterDomain :376-392
+        double c[DIM], d2 = 0.;
+#pragma unroll
+        for (int d = 0; d < DIM; d++) {
+            double s = 0.;
+#pragma unroll
+            for (int m = 0; m < NV; m++) s += bv[m*DIM+d];
+            c[d] = s/NV;
+        }
+#pragma unroll
+        for (int d = 0; d < DIM; d++) d2 += (x[d]-c[d])*(x[d]-c[d]);
+        if (d2 <= h2) S.identity();
+        return;
+    }
+    int ind[NV], numInside = 0;
+#pragma unroll
+    for (int m = 0; m < NV; m++) {
+        double d2 = 0.;
+#pragma unroll
+        for (int d = 0; d < DIM; d++) d2 += (x[d]-bv[m*DIM+d])*(x[d]-bv[m*DIM+d]);
+        ind[m] = d2 <= h2;
+        numInside += ind[m];
+    }
+    if (numInside == NV) { S.identity(); return; }
+    double t[2], p0[DIM], p1[DIM], p2[DIM];
+    if (DIM == 1) {
+        if (numInside == 0) {
+            if (find_intersections<DIM>(h2, x, bv, bv+DIM, t) == 2) {
+                S.A[0][0][0] = 1.-t[0]; S.A[0][1 % NV][0] = t[0];
+                S.A[0][1 % NV][1 % NV] = t[1]; S.A[0][0][1 % NV] = 1.-t[1];
+                S.vol[0] = t[1]-t[0];
+                S.n = 1;
+            }
+        } else {
+            S.rot = ind[0] ? 0 : 1;                      // inside vertex -> 0
+            rotated_vertex<DIM>(bv, S.rot, 0, p0);
+            rotated_vertex<DIM>(bv, S.rot, 1, p1);
+            find_intersections<DIM>(h2, x, p0, p1, t);
+            S.A[0][0][0] = 1.; S.A[0][1 % NV][1 % NV] = t[0]; S.A[0][0][1 % NV] = 1.-t[0];
+            S.vol[0] = t[0];
+            S.n = 1;
+            S.unrotate();
+        }
+        return;
+    }
+    if (numInside == 0) return;                         // ":664 There can be a nonzero intersection, but we ignore it"
+    constexpr int I1 = 1 % NV, I2 = 2 % NV;            // keeps the 1D instantiation in bounds (this code is 2D only)
+    if (numInside == 1) {
+        S.rot = ind[0] ? 0 : (ind[I1] ? 1 : 2);
+        rotated_vertex<DIM>(bv, S.rot, 0, p0);
+        rotated_vertex<DIM>(bv, S.rot, 1, p1);
+        rotated_vertex<DIM>(bv, S.rot, 2, p2);
+        find_intersections<DIM>(h2, x, p0, p1, t);
+        const double c1 = t[0];
+        find_intersections<DIM>(h2, x, p0, p2, t);
+        const double c2 = t[0];
+        const int num = find_intersections<DIM>(h2, x, p1, p2, t);
+        if (num == 0) {
+            S.A[0][0][0] = 1.; S.A[0][0][I1] = 1.-c1; S.A[0][I1][I1] = c1; S.A[0][I2][I2] = c2; S.A[0][0][I2] = 1.-c2;
+            S.vol[0] = c1*c2;
+            S.n = 1;
+        } else if (num == 2) {
+            S.A[0][0][0] = 1.; S.A[0][I1][I1] = c1; S.A[0][0][I1] = 1.-c1; S.A[0][I2][I2] = t[0]; S.A[0][I1][I2] = 1.-t[0];
+            S.vol[0] = c1*t[0];
+            S.A[1][0][0] = 1.; S.A[1][I1][I1] = 1.-t[0]; S.A[1][I2][I1] = t[0]; S.A[1][I1][I2] = 1.-t[1]; S.A[1][I2][I2] = t[1];
+            S.vol[1] = t[1]-t[0];
+            S.A[2][0][0] = 1.; S.A[2][I1][I1] = 1.-t[1]; S.A[2][I2][I1] = t[1]; S.A[2][I2][I2] = c2; S.A[2][0][I2] = 1.-c2;
+            S.vol[2] = c2*(1.-t[1]);
+            S.n = 3;
+        } else {
+            S.A[0][0][0] = 1.; S.A[0][I1][I1] = c1; S.A[0][0][I1] = 1.-c1; S.A[0][I2][I2] = t[0]; S.A[0][I1][I2] = 1.-t[0];
+            S.vol[0] = c1*t[0];
+            S.A[1][0][0] = 1.; S.A[1][I1][I1] = 1.-t[0]; S.A[1][I2][I1] = t[0]; S.A[1][I2][I2] = c2; S.A[1][0][I2] = 1.-c2;
+            S.vol[1] = c2*(1.-t[0]);
+            S.n = 2;
+        }
+        S.unrotate();
+        return;
+    }
+    // two vertices inside: outside vertex -> 0
+    S.rot = !ind[0] ? 0 : (!ind[I1] ? 1 : 2);
+    rotated_vertex<DIM>(bv, S.rot, 0, p0);
+    rotated_vertex<DIM>(bv, S.rot, 1, p1);
+    rotated_vertex<DIM>(bv, S.rot, 2, p2);
+    find_intersections<DIM>(h2, x, p0, p1, t);
+    const double c1 = t[0];
+    find_intersections<DIM>(h2, x, p0, p2, t);
+    const double c2 = t[0];
+    double d1 = 0., d2 = 0.;
+#pragma unroll
+    for (int k = 0; k < DIM; k++) {
+        d1 += (p2[k]-(c1*p1[k]+(1.-c1)*p0[k]))*(p2[k]-(c1*p1[k]+(1.-c1)*p0[k]));
+        d2 += (p1[k]-(c2*p2[k]+(1.-c2)*p0[k]))*(p1[k]-(c2*p2[k]+(1.-c2)*p0[k]));
+    }
+    if (d1 < d2) {
+        S.A[0][I2][I2] = 1.; S.A[0][0][0] = 1.-c2; S.A[0][I2][0] = c2; S.A[0][I1][I1] = c1; S.A[0][0][I1] = 1.-c1;
+        S.vol[0] = c1*(1.-c2);
+        S.A[1][I1][I1] = 1.; S.A[1][I2][I2] = 1.; S.A[1][0][0] = 1.-c1; S.A[1][I1][0] = c1;
+        S.vol[1] = 1.-c1;
+    } else {
+        S.A[0][I1][I1] = 1.; S.A[0][I2][I2] = c2; S.A[0][0][I2] = 1.-c2; S.A[0][0][0] = 1.-c1; S.A[0][I1][0] = c1;
+        S.vol[0] = c2*(1.-c1);
+        S.A[1][I1][I1] = 1.; S.A[1][I2][I2] = 1.; S.A[1][0][0] = 1.-c2; S.A[1][I2][0] = c2;
+        S.vol[1] = 1.-c2;
+    }
+    S.n = 2;
+    S.unrotate();
+}
+
+// startLoopSubSimplices_Simplex: sub-simplices of simplex av that can interact with simplex bv
+template <int DIM>
+__device__ __forceinline__ void subs_simplex(const DevKernel &K, const double *av, const double *bv, SubSimplices<DIM> &S) {
+#pragma clang fp contract(off)
+    constexpr int NV = DIM+1;
+    const double h2 = K.horizon2;
+    S.clear();
+    if (K.interaction == 2) {                           // barycenterDomain :358-374
+        double c[DIM];
+#pragma unroll
+        for (int d = 0; d < DIM; d++) {
+            double s = 0.;
+#pragma unroll
+            for (int m = 0; m < NV; m++) s += bv[m*DIM+d];
+            c[d] = s/NV;
+        }
+        bool any = false;
+#pragma unroll
+        for (int m = 0; m < NV; m++) {
+            double d2 = 0.;
+#pragma unroll
+            for (int d = 0; d < DIM; d++) d2 += (av[m*DIM+d]-c[d])*(av[m*DIM+d]-c[d]);
+            any = any || d2 <= h2;
+        }
+        if (any) S.identity();
+        return;
+    }
+    if (DIM == 1) {
+        // :425-446 with nextSubSimplex_Simplex :71-87: up to two sub-intervals [l, r] of simplex1 (in units of its length)
+        const double horizon = sqrt(h2);
+        const bool lr = av[0] < bv[0];
+        const double inv = 1./fabs(av[0]-av[1 % (NV*DIM)]);
+        double iv[4];
+        iv[0] = av[0]*inv; iv[3] = av[1 % (NV*DIM)]*inv;
+        iv[1] = (lr ? fmax(av[0], bv[0]-horizon) : fmax(av[0], bv[0]+horizon))*inv;
+        iv[2] = (lr ? fmin(av[1 % (NV*DIM)], bv[1 % (NV*DIM)]-horizon) : fmin(av[1 % (NV*DIM)], bv[1 % (NV*DIM)]+horizon))*inv;
+        const int it0 = lr ? 1 : 0;
+#pragma unroll
+        for (int it = 0; it < 3; it++) {
+            if (it < it0 || it >= it0+2) continue;
+            const double l = iv[it], r = iv[it+1];
+            if (r-l <= 0) continue;
+            const int m = S.n++;
+#pragma unroll
+            for (int s = 0; s < 3; s++)
+                if (s == m) {
+                    S.A[s][0][0] = r-l; S.A[s][1 % NV][1 % NV] = r-l;
+                    S.b[s][0] = iv[3]-r; S.b[s][1 % NV] = l-iv[0];
+                    S.vol[s] = r-l;
+                }
+        }
+        return;
+    }
+    constexpr int I1 = 1 % NV, I2 = 2 % NV;
+    bool in[3][3], inI[3];
+    int numInside = 0;
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        bool any = false;
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            double d2 = 0.;
+#pragma unroll
+            for (int d = 0; d < DIM; d++) d2 += (av[(i % NV)*DIM+d]-bv[(k % NV)*DIM+d])*(av[(i % NV)*DIM+d]-bv[(k % NV)*DIM+d]);
+            in[i][k] = d2 <= h2;
+            any = any || in[i][k];
+        }
+        inI[i] = any;
+        numInside += any;
+    }
+    if (numInside == 0) return;
+    if (numInside == 3) { S.identity(); return; }
+    double t[2], p0[DIM], p1[DIM], p2[DIM];
+    if (numInside == 1) {
+        S.rot = inI[0] ? 0 : (inI[1] ? 1 : 2);
+        rotated_vertex<DIM>(av, S.rot, 0, p0);
+        rotated_vertex<DIM>(av, S.rot, 1, p1);
+        rotated_vertex<DIM>(av, S.rot, 2, p2);
+        double c1 = 0., c2 = 0.;
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            bool f = false;
+#pragma unroll
+            for (int i = 0; i < 3; i++) f = (i == S.rot) ? in[i][j] : f;
+            if (f) {
+                find_intersections<DIM>(h2, bv+(j % NV)*DIM, p0, p1, t);
+                c1 = fmax(c1, t[0]);
+                find_intersections<DIM>(h2, bv+(j % NV)*DIM, p0, p2, t);
+                c2 = fmax(c2, t[0]);
+            }
+        }
+        if (c1*c2 > 0) {
+            S.A[0][0][0] = c1+c2; S.A[0][0][I1] = c2; S.A[0][0][I2] = c1; S.A[0][I1][I1] = c1; S.A[0][I2][I2] = c2;
+            S.b[0][0] = 1.-c1-c2;
+            S.vol[0] = c1*c2;
+            S.n = 1;
+            S.unrotate();
+        }
+        return;
+    }
+    S.rot = !inI[0] ? 0 : (!inI[1] ? 1 : 2);
+    rotated_vertex<DIM>(av, S.rot, 0, p0);
+    rotated_vertex<DIM>(av, S.rot, 1, p1);
+    rotated_vertex<DIM>(av, S.rot, 2, p2);
+    double c1 = 1., c2 = 1.;
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        bool f1 = false, f2 = false;
+#pragma unroll
+        for (int i = 0; i < 3; i++) { f1 = (i == (S.rot+1)%3) ? in[i][j] : f1; f2 = (i == (S.rot+2)%3) ? in[i][j] : f2; }
+        if (f1) { find_intersections<DIM>(h2, bv+(j % NV)*DIM, p0, p1, t); c1 = fmin(c1, t[0]); }
+        if (f2) { find_intersections<DIM>(h2, bv+(j % NV)*DIM, p0, p2, t); c2 = fmin(c2, t[0]); }
+    }
+    // :509-516 literally: rows outside / inside1 / inside2 of SIMPLEX2, the second sum without the square
+    double q0[DIM], q1[DIM], q2[DIM], d1 = 0., d2 = 0.;
+    rotated_vertex<DIM>(bv, S.rot, 0, q0);
+    rotated_vertex<DIM>(bv, S.rot, 1, q1);
+    rotated_vertex<DIM>(bv, S.rot, 2, q2);
+#pragma unroll
+    for (int k = 0; k < DIM; k++) {
+        d1 += (q0[k]+c1*(q1[k]-q0[k])-q2[k])*(q0[k]+c1*(q1[k]-q0[k])-q2[k]);
+        d2 += q0[k]+c2*(q2[k]-q0[k])-q1[k];
+    }
+    // the second sub-simplex goes to slot S.n, which is 0 or 1: write both candidates with selects
+    if (d1 < d2) {
+        if (1.-c1 > 0) {
+            S.A[0][0][0] = 1.-c1; S.A[0][I1][I1] = 1.-c1; S.A[0][I1][I2] = -c1; S.A[0][I2][I2] = 1.; S.b[0][I1] = c1;
+            S.vol[0] = 1.-c1;
+            S.n = 1;
+        }
+        if (c1*(1.-c2) > 0.) {
+            const int m = S.n++;
+#pragma unroll
+            for (int s = 0; s < 2; s++)
+                if (s == m) {
+#pragma unroll
+                    for (int k = 0; k < NV; k++) { S.b[s][k] = 0.; for (int j = 0; j < NV; j++) S.A[s][k][j] = 0.; }
+                    S.A[s][0][0] = 1.-c2; S.A[s][I2][I2] = 1.; S.A[s][I2][0] = c2; S.A[s][0][I1] = 1.-c1; S.A[s][I1][I1] = c1;
+                    S.vol[s] = c1*(1.-c2);
+                }
+        }
+    } else {
+        if (1.-c2 > 0) {
+            S.A[0][0][0] = 1.-c2; S.A[0][I2][I2] = 1.-c2; S.A[0][I2][I1] = -c2; S.A[0][I1][I1] = 1.; S.b[0][I2] = c2;
+            S.vol[0] = 1.-c2;
+            S.n = 1;
+        }
+        if (c2*(1.-c1) > 0.) {
+            const int m = S.n++;
+#pragma unroll
+            for (int s = 0; s < 2; s++)
+                if (s == m) {
+#pragma unroll
+                    for (int k = 0; k < NV; k++) { S.b[s][k] = 0.; for (int j = 0; j < NV; j++) S.A[s][k][j] = 0.; }
+                    S.A[s][0][0] = 1.-c1; S.A[s][I1][I1] = 1.; S.A[s][I1][0] = c1; S.A[s][0][I2] = 1.-c2; S.A[s][I2][I2] = c2;
+                    S.vol[s] = c2*(1.-c1);
+                }
+        }
+    }
+    S.unrotate();
+}
+
+// local shape functions at barycentric coordinates (DoFMaps.pyx:1854-2025): P1 (DPE = DIM+1), P2 on triangles (DPE = 6)
+template <int DIM, int DPE>
+__device__ __forceinline__ void shape_eval(const double *lam, double *phi) {
+    if (DPE == DIM+1) {
+#pragma unroll
+        for (int k = 0; k < DPE; k++) phi[k] = lam[k];
+    } else {
+        phi[0] = lam[0]*(2.*lam[0]-1.); phi[1] = lam[1]*(2.*lam[1]-1.); phi[2 % DPE] = lam[2 % (DIM+1)]*(2.*lam[2 % (DIM+1)]-1.);
+        phi[3 % DPE] = 4.*lam[0]*lam[1]; phi[4 % DPE] = 4.*lam[1]*lam[2 % (DIM+1)]; phi[5 % DPE] = 4.*lam[0]*lam[2 % (DIM+1)];
+    }
+}
+
+// barycentric coordinates (parent frame) and global point of quadrature node mu on sub-simplex s, in the reference's order of
+// operations: lam = b + A mu (transformQuadratureRule.compute, quadrature.pyx:197-206), pt = sum_k lam_k v_k (Q:76-87)
+template <int DIM>
+__device__ __forceinline__ void sub_point(const SubSimplices<DIM> &S, int s, const double *mu, const double *v, double *lam, double *pt) {
+#pragma clang fp contract(off)
+    constexpr int NV = DIM+1;
+#pragma unroll
+    for (int k = 0; k < NV; k++) {
+        double a = 0.;
+#pragma unroll
+        for (int ss = 0; ss < 3; ss++)
+            if (ss == s) {
+                a = S.b[ss][k];
+#pragma unroll
+                for (int j = 0; j < NV; j++) a += S.A[ss][k][j]*mu[j];
+            }
+        lam[k] = a;
+    }
+#pragma unroll
+    for (int d = 0; d < DIM; d++) {
+        double a = 0.;
+#pragma unroll
+        for (int k = 0; k < NV; k++) a += lam[k]*v[k*DIM+d];
+        pt[d] = a;
+    }
+}
+
+// NO:790-847, cut branch, one pair per lane; tab = LDS copy of the rule of the pair's order (bary[3], w, ...; stride stp)
+template <int DIM, int DPE>
+__device__ __forceinline__ unsigned eval_distant_cut(const DevProblem &P, const double *__restrict__ tab, int stp, int n, const double *av,
+                                                     const double *bv, PairAcc<DIM, DPE> &R) {
+    constexpr int NV = DIM+1;
+    SubSimplices<DIM> S1, S2;
+    subs_simplex<DIM>(P.k, av, bv, S1);
+    unsigned nevals = 0;
+#pragma unroll 1
+    for (int a = 0; a < S1.n; a++)
+#pragma unroll 1
+        for (int i = 0; i < n; i++) {
+            double mu[NV], lx[NV], x[DIM], px[DPE];
+#pragma unroll
+            for (int k = 0; k < NV; k++) mu[k] = tab[i*stp+k];
+            sub_point<DIM>(S1, a, mu, av, lx, x);
+            shape_eval<DIM, DPE>(lx, px);
+            const double wi = tab[i*stp+3]*(a == 0 ? S1.vol[0] : S1.vol[1]);
+            subs_node<DIM>(P.k, x, bv, S2);
+#pragma unroll 1
+            for (int b = 0; b < S2.n; b++) {
+                const double wb = wi*(b == 0 ? S2.vol[0] : (b == 1 ? S2.vol[1] : S2.vol[2]));
+#pragma unroll 1
+                for (int j = 0; j < n; j++) {
+                    double nu[NV], ly[NV], y[DIM], py[DPE];
+#pragma unroll
+                    for (int k = 0; k < NV; k++) nu[k] = tab[j*stp+k];
+                    sub_point<DIM>(S2, b, nu, bv, ly, y);
+                    shape_eval<DIM, DPE>(ly, py);
+                    double d2 = 0.;
+#pragma unroll
+                    for (int d = 0; d < DIM; d++) { const double t = x[d]-y[d]; d2 = __builtin_fma(t, t, d2); }
+                    const double K = wb*tab[j*stp+3]*kern_eval<0>(P.k, d2);
+                    nevals++;
+                    int e = 0;
+#pragma unroll
+                    for (int aa = 0; aa < DPE; aa++) {
+                        const double kx = K*px[aa], ky = K*py[aa];
+#pragma unroll
+                        for (int bb = 0; bb < DPE; bb++) R.G[aa][bb] = __builtin_fma(kx, py[bb], R.G[aa][bb]);
+#pragma unroll
+                        for (int bb = aa; bb < DPE; bb++) {
+                            R.S1[e] = __builtin_fma(kx, px[bb], R.S1[e]);
+                            R.S2[e] = __builtin_fma(ky, py[bb], R.S2[e]);
+                            e++;
+                        }
+                    }
+                }
+            }
+        }
+    return nevals;
+}
+
 // ---- sparse output (H2 near field, NA:1663-1964) -------------------------------------------------------------------
 // CSR or SSS target with the reference's addToEntry semantics (CSR_LinearOperator_{SCALAR}.pxi:150-170,
 // SSS_LinearOperator_{SCALAR}.pxi:104-130): binary search in the row, entries that are not in the pattern are dropped;
@@ -992,12 +1497,23 @@ k_mp_classify(const DevProblem P, const int *__restrict__ pairs, int npairs, int
         }
         if (common > 0) key = 121+common-1;
         else {
-            double d2 = 0.;
+            // finite horizon: REMOTE pairs are ignored (NO:515-517), pairs CUT by the horizon go to their own bins
+            int rel = PNL_INTERACT;
+            if (P.k.horizon2 < 1e300) {
+                double av[NV*DIM], bv[NV*DIM];
 #pragma unroll
-            for (int d = 0; d < DIM; d++) { const double u = P.ccen[(size_t)d*P.ncp+c1]-P.ccen[(size_t)d*P.ncp+c2]; d2 += u*u; }
-            const int q = quad_order(P.qo, P.H0, P.ch[c1], P.ch[c2], sqrt(d2));
-            if (q > P.qmax || q > PNL_MAXQ) atomicAdd(&P.counters[5], 1ull);
-            else { key = q; off = P.off[q]; n = P.off[q+1]-off; }
+                for (int k = 0; k < NV*DIM; k++) { av[k] = P.cellv[(size_t)k*P.ncp+c1]; bv[k] = P.cellv[(size_t)k*P.ncp+c2]; }
+                rel = rel_position<DIM>(P.k.horizon2, av, bv);
+            }
+            if (rel != PNL_REMOTE) {
+                double d2 = 0.;
+#pragma unroll
+                for (int d = 0; d < DIM; d++) { const double u = P.ccen[(size_t)d*P.ncp+c1]-P.ccen[(size_t)d*P.ncp+c2]; d2 += u*u; }
+                const int q = quad_order(P.qo, P.H0, P.ch[c1], P.ch[c2], sqrt(d2));
+                if (q > P.qmax || q > PNL_MAXQ || (rel == PNL_CUT && (q > PNL_CUT_SHIFT || P.off[q+1]-P.off[q] > PNL_WL_LANE_MAXPTS)))
+                    atomicAdd(&P.counters[5], 1ull);
+                else { key = q+(rel == PNL_CUT ? PNL_CUT_SHIFT : 0); off = P.off[q]; n = P.off[q+1]-off; }
+            }
         }
     }
     out[t] = make_int4(t, 0, off, n | (key << 16));
@@ -1240,7 +1756,6 @@ k_worklist_sorted(const DevProblem P, const int4 *__restrict__ sorted, const uns
 // LDS copy with broadcast reads; the factorised accumulation of eval_distant_fixed is used (x_i, row sums and u_b per i,
 // S2 directly per point pair), no cross-lane reduction.  Orders with more points (few pairs, thousands of point pairs each)
 // go to k_worklist_sorted, which spreads one pair over 16 lanes.
-#define PNL_WL_LANE_MAXPTS 40
 template <int DIM, int DPE, int KT, bool SPARSE>
 __global__ void __launch_bounds__(PNL_NTHREADS)
 k_worklist_lane(const DevProblem P, const int4 *__restrict__ sorted, const unsigned *__restrict__ offs, double *__restrict__ A,
@@ -1251,10 +1766,14 @@ k_worklist_lane(const DevProblem P, const int4 *__restrict__ sorted, const unsig
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid == 0) {
         unsigned run = 0;
-        for (int q = 0; q < PNL_WL_BINS; q++) {
-            s_coff[q] = run;
-            const int n = (q >= 2 && q <= P.qmax && q <= PNL_MAXQ) ? P.off[q+1]-P.off[q] : 0;
-            if (n > 0 && n <= PNL_WL_LANE_MAXPTS) run += (offs[q+1]-offs[q]+63u)/64u;
+        const bool finite = SPARSE && P.k.horizon2 < 1e300;
+        for (int bin = 0; bin < PNL_WL_BINS; bin++) {
+            s_coff[bin] = run;
+            // bins above PNL_CUT_SHIFT+1 hold the pairs of order bin - PNL_CUT_SHIFT that a finite horizon cuts
+            const int q = (finite && bin >= PNL_CUT_SHIFT+2 && bin <= 2*PNL_CUT_SHIFT) ? bin-PNL_CUT_SHIFT : bin;
+            const bool own = finite ? bin <= 2*PNL_CUT_SHIFT : true;
+            const int n = (own && q >= 2 && q <= P.qmax && q <= PNL_MAXQ) ? P.off[q+1]-P.off[q] : 0;
+            if (n > 0 && n <= PNL_WL_LANE_MAXPTS) run += (offs[bin+1]-offs[bin]+63u)/64u;
         }
         s_coff[PNL_WL_BINS] = run;
     }
@@ -1269,9 +1788,11 @@ k_worklist_lane(const DevProblem P, const int4 *__restrict__ sorted, const unsig
             const int mid = (lo+hi+1) >> 1;
             if (s_coff[mid] <= chunk) lo = mid; else hi = mid-1;
         }
-        const int q = __builtin_amdgcn_readfirstlane(lo);
-        const unsigned first = offs[q]+64u*(chunk-s_coff[q]);
-        const int cnt = (int)min(64u, offs[q+1]-first);
+        const int bin = __builtin_amdgcn_readfirstlane(lo);
+        const bool cut = SPARSE && P.k.horizon2 < 1e300 && bin >= PNL_CUT_SHIFT+2;
+        const int q = cut ? bin-PNL_CUT_SHIFT : bin;
+        const unsigned first = offs[bin]+64u*(chunk-s_coff[bin]);
+        const int cnt = (int)min(64u, offs[bin+1]-first);
         const int off = P.off[q], n = P.off[q+1]-off;
         if (q != staged_q) {
             for (int t = lane; t < n*STP; t += 64) {
@@ -1290,7 +1811,12 @@ k_worklist_lane(const DevProblem P, const int4 *__restrict__ sorted, const unsig
         for (int k = 0; k < NC; k++) { av[k] = P.cellv[(size_t)k*P.ncp+c1]; bv[k] = P.cellv[(size_t)k*P.ncp+c2]; }
         PairAcc<DIM, DPE> R;
         R.clear();
-        eval_distant_lds<DIM, DPE, KT>(P, s_rule, STP, (dbg & 4) ? 1 : n, av, bv, R);
+        if (SPARSE && cut) {
+            const unsigned ne = valid ? eval_distant_cut<DIM, DPE>(P, s_rule, STP, n, av, bv, R) : 0u;
+            const double tot = wave_sum((double)ne);
+            if (lane == 0 && tot > 0.) atomicAdd(&P.counters[2], (unsigned long long)tot);
+        } else
+            eval_distant_lds<DIM, DPE, KT>(P, s_rule, STP, (dbg & 4) ? 1 : n, av, bv, R);
         if (!valid) continue;
         const double vv = 2.*P.cvol[c1]*P.cvol[c2]*kern_scale<KT>(P.k);
         int ld1[DPE], ld2[DPE];
@@ -1829,11 +2355,13 @@ __global__ void k_mp_stats(const DevProblem P, const unsigned *__restrict__ hist
     const int q = threadIdx.x;
     if (q < 2 || q > P.qmax || q > PNL_MAXQ) return;
     const unsigned long long c = hist[q];
-    if (!c) return;
+    // pairs cut by a finite horizon sit in bin q + PNL_CUT_SHIFT; their kernel evaluations are counted by the kernel
+    const unsigned long long ccut = (P.k.horizon2 < 1e300 && q+PNL_CUT_SHIFT < PNL_WL_BINS && q <= PNL_CUT_SHIFT) ? hist[q+PNL_CUT_SHIFT] : 0ull;
+    if (!c && !ccut) return;
     const unsigned long long n = (unsigned long long)(P.off[q+1]-P.off[q]);
-    atomicAdd(&P.counters[8+q], c);
-    atomicAdd(&P.counters[1], c);
-    atomicAdd(&P.counters[2], c*n*n);
+    atomicAdd(&P.counters[8+q], c+ccut);
+    atomicAdd(&P.counters[1], c+ccut);
+    if (c) atomicAdd(&P.counters[2], c*n*n);
 }
 
 // Gauss-theorem boundary term over explicit (cell, facet) items with entry masks: the cluster-local term

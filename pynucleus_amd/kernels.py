@@ -130,6 +130,8 @@ class interactionDomain:
 
 
 class fullSpace(interactionDomain):
+    device_id = 0
+
     def __init__(self):
         super().__init__(np.inf)
 
@@ -139,10 +141,20 @@ class fullSpace(interactionDomain):
 
 class ball2_retriangulation(interactionDomain):
     """l2 ball |x-y| <= horizon; elements cut by the horizon are re-triangulated
-    (interactionDomains.pyx:866-1100)."""
+    (interactionDomains.pyx:395-822, 866-980)."""
+    device_id = 1
 
     def __repr__(self):
         return 'ball2({})'.format(self.horizon)
+
+
+class ball2_barycenter(interactionDomain):
+    """l2 ball; a cut element interacts entirely or not at all, decided by its barycentre
+    (interactionDomains.pyx:340-392, 982-1067)."""
+    device_id = 2
+
+    def __repr__(self):
+        return 'ball2_barycenter({})'.format(self.horizon)
 
 
 class Kernel:
@@ -200,7 +212,8 @@ class Kernel:
         """POD block handed to pnl_set_kernel: (type, dim, exponent, scale, horizon^2)."""
         h2 = self.horizonValue**2 if self.finiteHorizon else np.inf
         return dict(ktype=int(self.kernelType), dim=self.dim, exponent=float(self.exponent),
-                    scale=float(self.scalingValue), horizon2=float(h2), boundary=bool(self.boundary))
+                    scale=float(self.scalingValue), horizon2=float(h2), boundary=bool(self.boundary),
+                    interaction=int(getattr(self.interaction, 'device_id', 0)) if self.finiteHorizon else 0)
 
     def __call__(self, x, y):
         x = np.atleast_1d(np.asarray(x, dtype=float))
@@ -333,6 +346,8 @@ def _getInteraction(interaction, horizon):
         return fullSpace()
     if interaction is None or interaction == 'ball2':
         return ball2_retriangulation(horizon.value)
+    if interaction == 'ball2_barycenter':
+        return ball2_barycenter(horizon.value)
     raise NotImplementedError('Interaction: {}'.format(interaction))
 
 
