@@ -9,9 +9,9 @@
 
 struct DevKernel {
     int ktype;                  // 0 fractional, 1 indicator, 2 peridynamic
-    int fast;                   // 1: fractional, exponent == -1.5, no horizon (s = 1/2 in 2D)
+    int fast;                   // 1: fractional, exponent == -qm/4 with an integer qm, no horizon (s = 1/4, 1/2, 3/4 in 1D / 2D)
     double exponent, scale, horizon2;
-    int interaction, pad;       // finite horizon: 1 ball2_retriangulation, 2 ball2_barycenter
+    int interaction, qm;        // finite horizon: 1 ball2_retriangulation, 2 ball2_barycenter; qm: see fast
 };
 
 struct DevFormula {

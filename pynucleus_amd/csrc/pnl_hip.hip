@@ -135,8 +135,13 @@ DevKernel to_dev(const pnl_kernel &k, int dim) {
     d.exponent = k.exponent;
     d.scale = k.scale;
     d.horizon2 = k.horizon2;
-    d.interaction = k.interaction; d.pad = 0;
-    d.fast = (k.ktype == PNL_FRACTIONAL && k.exponent == -1.5 && std::isinf(k.horizon2) && dim == 2) ? 1 : 0;
+    d.interaction = k.interaction;
+    // quarter-integer exponents get the rsqrt-based evaluation
+    const double m4 = -4.*k.exponent;
+    const int qm = (int)std::lround(m4);
+    (void)dim;
+    d.qm = qm;
+    d.fast = (k.ktype == PNL_FRACTIONAL && std::isinf(k.horizon2) && qm >= 1 && qm <= 32 && std::fabs(m4-qm) < 1e-13) ? 1 : 0;
     return d;
 }
 

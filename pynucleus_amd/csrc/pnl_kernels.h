@@ -21,12 +21,31 @@
 template <int KT>
 __device__ __forceinline__ double kern_eval(const DevKernel &k, double d2) {
     if (KT == 1) {
-        // s = 1/2 in 2D: C * d2^(-3/2)
-        double r = __builtin_amdgcn_rsq(d2);            // ~2^-26 relative
-        double h = 0.5*d2;
-        r = r*__builtin_fma(-h*r, r, 1.5);              // Newton: v_rsq_f64 (~2^-23) -> ~2^-45 -> full fp64
+        // exponent = -qm/4 (s a multiple of 1/4 in 1D / 2D): d2^(-1/2) from v_rsq_f64 (~2^-23 relative) + 2 Newton steps, for
+        // odd qm one more refined rsqrt gives d2^(-1/4); then an integer power.  A few ulp instead of libm's pow at 1/7 of the
+        // cost.  The scale is applied once per pair (kern_scale); qm is wave-uniform, the branches are scalar.
+        double r = __builtin_amdgcn_rsq(d2);
+        const double h = 0.5*d2;
         r = r*__builtin_fma(-h*r, r, 1.5);
-        return (r*r)*r;                                  // scale is applied once per pair (kern_scale)
+        r = r*__builtin_fma(-h*r, r, 1.5);
+        int p = k.qm;
+        if (p == 6) return (r*r)*r;                      // s = 1/2 in 2D
+        double base = r;
+        if (p & 1) {
+            double t = __builtin_amdgcn_rsq(r);
+            const double hr = 0.5*r;
+            t = t*__builtin_fma(-hr*t, t, 1.5);
+            t = t*__builtin_fma(-hr*t, t, 1.5);
+            base = r*t;                                  // d2^(-1/4)
+        } else p >>= 1;
+        double res = (p & 1) ? base : 1.;
+        p >>= 1;
+        while (p) {
+            base *= base;
+            if (p & 1) res *= base;
+            p >>= 1;
+        }
+        return res;
     } else {
         if (!(d2 <= k.horizon2)) return 0.;
         if (k.ktype == 0) return k.scale*pow(d2, k.exponent);

@@ -43,7 +43,7 @@ elif what == 'c4':
     noRef = size or 6
     mesh = disc(noRef)
     dm = P1_DoFMap(mesh, PHYSICAL)
-    b = nonlocalBuilder(dm, getFractionalKernel(2, 0.75), {'target_order': 0.5, 'eta': 3.}, zeroExterior=True)
+    b = nonlocalBuilder(dm, getFractionalKernel(2, float(__import__('os').environ.get('PNL_S', '0.75'))), {'target_order': 0.5, 'eta': 3.}, zeroExterior=True)
     t0 = time.time()
     rp = b.getH2RefinementParams()
     root, Pnear, Pfar = clusters.getNearFieldClusters(dm, rp['eta'], rp['minSize'], rp['maxLevels'])
