@@ -158,6 +158,33 @@ int pnl_assemble_pairs_masked(pnl_context *ctx, int np, const int32_t *pairs_hos
  * entries (getElemSymMaskCluster NA:463-478), scatter addToMatrixElemSymMasked NA:534-546 times fac. */
 int pnl_assemble_boundary_masked(pnl_context *ctx, int ni, const int32_t *cells_host, const int32_t *facets_host,
                                  const uint32_t *masks_host, double fac, double *data_dev, double *diag_dev);
+/* Tiled near-field assembly: the same operator as pnl_assemble_pairs_masked + pnl_assemble_boundary_masked over all
+ * cluster pairs (assembleClusters NA:1663-1964), organised for the GPU instead of element pair by element pair.  The host
+ * (clusters.nearFieldPlan) lists, per UNORDERED near-field cluster pair {n1, n2} (pair_nodes; nodes = sorted DoF lists
+ * node_off / node_dofs): tiles (64-cell chunk of n1.cells) x (chunk of n2.cells) -- chunk tables: cells (-1 = padding),
+ * the chunk's DoFs that belong to the node and the slot of every local DoF in that list --; a slot in the diagonal-block
+ * buffer for every cell of cellsInter (d_cell, d_pair; tile_dslotA/B give the slot of a tile's cells or -1); the
+ * touching element pairs (sing_items[common vertices - 1] = (pair, c1 <= c2)); the facets of the boundary of cellsUnion
+ * (pair_foff, fvid) and the touching (cell, facet) items of the cluster-local Gauss-theorem term (bt_slot, bt_cell,
+ * bt_facet).  tile_flags bit 0: n1 == n2.  No masks cross the boundary: an entry of a local matrix is kept iff its DoF pair
+ * {I, J} belongs to the cluster pair ((I in n1, J in n2) or (I in n2, J in n1)), and is written at (I, J) and (J, I) with the
+ * addToEntry semantics of the uploaded pattern.  Constant order, infinite horizon.  cluster_boundary = 0 skips the
+ * Gauss-theorem term. */
+typedef struct {
+    int32_t npairs, nnodes, nchunks, chunk_stride, ntiles, num_dslots, nfacets, tile;
+    const int32_t *pair_nodes, *node_off, *node_dofs;
+    const int32_t *chunk_cells, *chunk_ndof, *chunk_dofs;
+    const int16_t *chunk_slot;
+    const int32_t *tile_chunkA, *tile_chunkB, *tile_pair, *tile_flags, *tile_dslotA, *tile_dslotB;
+    const int32_t *d_cell, *d_pair;
+    int32_t n_sing[3];
+    int32_t n_btouch;
+    const int32_t *sing_items[3];
+    const int32_t *pair_foff, *fvid;
+    const int32_t *bt_slot, *bt_cell, *bt_facet;
+} pnl_cluster_plan;
+int pnl_assemble_clusters_tiled(pnl_context *ctx, const pnl_cluster_plan *plan, int cluster_boundary, double *data_dev,
+                                double *diag_dev);
 /* y = A x for the uploaded pattern (CSR: diag_dev NULL; SSS: lower triangle + diagonal, y = (L + D + L^T) x):
  * CSR_LinearOperator.matvec / SSS_LinearOperator.matvec */
 int pnl_spmv(pnl_context *ctx, const double *data_dev, const double *diag_dev, const double *x_dev, double *y_dev);

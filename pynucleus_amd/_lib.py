@@ -27,7 +27,7 @@ EXPORTS = ['pnl_create', 'pnl_destroy', 'pnl_error_string', 'pnl_version', 'pnl_
            'pnl_upload_mesh', 'pnl_upload_dofmap', 'pnl_set_kernel', 'pnl_set_order_formula', 'pnl_upload_distant_rules',
            'pnl_upload_singular_rule', 'pnl_upload_boundary', 'pnl_assemble_dense', 'pnl_tile_cells',
            'pnl_assemble_dense_tiles', 'pnl_get_counters', 'pnl_get_phase_ms', 'pnl_gemv', 'pnl_cg_jacobi',
-           'pnl_inv_diagonal', 'pnl_set_classes', 'pnl_select_class', 'pnl_upload_sparsity', 'pnl_assemble_pairs_masked', 'pnl_assemble_boundary_masked', 'pnl_spmv']
+           'pnl_inv_diagonal', 'pnl_set_classes', 'pnl_select_class', 'pnl_upload_sparsity', 'pnl_assemble_pairs_masked', 'pnl_assemble_boundary_masked', 'pnl_assemble_clusters_tiled', 'pnl_spmv']
 
 
 class pnl_kernel(C.Structure):
@@ -38,6 +38,15 @@ class pnl_kernel(C.Structure):
 class pnl_order_formula(C.Structure):
     _fields_ = [('c0', C.c_double), ('a', C.c_double), ('b', C.c_double), ('e', C.c_double), ('den0', C.c_double),
                 ('clip_num', C.c_int32), ('pad', C.c_int32)]
+
+
+class pnl_cluster_plan(C.Structure):
+    _fields_ = ([(n, C.c_int32) for n in ('npairs', 'nnodes', 'nchunks', 'chunk_stride', 'ntiles', 'num_dslots', 'nfacets', 'tile')] +
+                [(n, C.c_void_p) for n in ('pair_nodes', 'node_off', 'node_dofs', 'chunk_cells', 'chunk_ndof', 'chunk_dofs', 'chunk_slot',
+                                           'tile_chunkA', 'tile_chunkB', 'tile_pair', 'tile_flags', 'tile_dslotA', 'tile_dslotB',
+                                           'd_cell', 'd_pair')] +
+                [('n_sing', C.c_int32*3), ('n_btouch', C.c_int32), ('sing_items', C.c_void_p*3)] +
+                [(n, C.c_void_p) for n in ('pair_foff', 'fvid', 'bt_slot', 'bt_cell', 'bt_facet')])
 
 
 class PnlError(RuntimeError):
@@ -86,6 +95,7 @@ def load():
     L.pnl_assemble_pairs_masked.argtypes = [vp, i32, vp, vp, vp, vp]
     L.pnl_assemble_boundary_masked.argtypes = [vp, i32, vp, vp, vp, dbl, vp, vp]
     L.pnl_spmv.argtypes = [vp, vp, vp, vp, vp]
+    L.pnl_assemble_clusters_tiled.argtypes = [vp, C.POINTER(pnl_cluster_plan), i32, vp, vp]
     for name in EXPORTS:
         f = getattr(L, name)
         if name not in ('pnl_destroy', 'pnl_error_string', 'pnl_version'):
@@ -231,6 +241,31 @@ class Context:
         assert f.shape[0] == c.shape[0] == m.shape[0]
         self.check(self.L.pnl_assemble_boundary_masked(self.h, c.shape[0], pc, pf, pm, float(fac), C.c_void_p(data_ptr),
                                                        C.c_void_p(diag_ptr) if diag_ptr else None))
+
+    def assemble_clusters_tiled(self, plan, cluster_boundary, data_ptr, diag_ptr=None):
+        """plan: clusters.nearFieldPlan"""
+        keep = []
+
+        def ptr(a, dt):
+            a = np.ascontiguousarray(a, dtype=dt)
+            keep.append(a)
+            return a.ctypes.data
+
+        P = pnl_cluster_plan()
+        P.npairs, P.nnodes, P.nchunks = plan.num_pairs, len(plan.nodes), plan.chunk_cells.shape[0]
+        P.chunk_stride, P.ntiles, P.num_dslots = plan.nU, plan.tile_chunkA.shape[0], plan.num_dslots
+        P.nfacets, P.tile = plan.fvid.shape[0], plan.tile
+        for name in ('pair_nodes', 'node_off', 'node_dofs', 'chunk_cells', 'chunk_ndof', 'chunk_dofs', 'tile_chunkA', 'tile_chunkB',
+                     'tile_pair', 'tile_flags', 'tile_dslotA', 'tile_dslotB', 'd_cell', 'd_pair', 'pair_foff', 'fvid', 'bt_slot',
+                     'bt_cell', 'bt_facet'):
+            setattr(P, name, ptr(getattr(plan, name), np.int32))
+        P.chunk_slot = ptr(plan.chunk_slot, np.int16)
+        for s in range(3):
+            P.n_sing[s] = plan.sing_items[s].shape[0]
+            P.sing_items[s] = ptr(plan.sing_items[s], np.int32)
+        P.n_btouch = plan.bt_cell.shape[0]
+        self.check(self.L.pnl_assemble_clusters_tiled(self.h, C.byref(P), int(bool(cluster_boundary)), C.c_void_p(data_ptr),
+                                                      C.c_void_p(diag_ptr) if diag_ptr else None))
 
     def spmv(self, data_ptr, diag_ptr, x_ptr, y_ptr):
         self.check(self.L.pnl_spmv(self.h, C.c_void_p(data_ptr), C.c_void_p(diag_ptr) if diag_ptr else None, C.c_void_p(x_ptr),

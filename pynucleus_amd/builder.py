@@ -317,6 +317,24 @@ class nonlocalBuilder:
             Anear = (SSS_LinearOperator if symmetric else CSR_LinearOperator)(indptr, indices, dm.num_dofs, ctx, dev)
         Anear._bind()
         data_ptr, diag_ptr = Anear._ptrs()
+        mode = self.params.get('nearFieldAssembly', 'tiles' if 'maxMasksNNZ' not in self.params else 'masks')
+        if mode == 'tiles' and not self.kernel.variable and not self.kernel.finiteHorizon:
+            # the GPU's own decomposition: cluster-pair tiles with LDS sub-blocks, no masks (clusters.nearFieldPlan)
+            plan = clusters.nearFieldPlan(dm, Pnear, tile=ctx.tile_cells())
+            use_bnd = bool(self.tables.has_boundary_tables and _clusterBoundary)
+            ctx.assemble_clusters_tiled(plan, use_bnd, data_ptr, diag_ptr)
+            cnt = ctx.counters()
+            ms = ctx.phase_ms()
+            nitems = plan.bt_cell.shape[0]
+            if use_bnd and not self.zeroExterior and _globalBoundary:
+                cells, facets, bmasks = clusters.globalBoundaryItems(dm, self.tables.bcells)
+                nitems += int(cells.shape[0])
+                ctx.assemble_boundary_masked(cells, facets, bmasks, -1., data_ptr, diag_ptr)
+            ctx.synchronize()
+            self.PLogger.addTimer('interior', 1e-3*ms['total'])
+            Anear.info = dict(counters=dict(cnt, numBoundaryItems=nitems, numTiles=int(plan.tile_chunkA.shape[0])), interior_ms=ms['total'],
+                              phase_ms=ms, mode='tiles')
+            return Anear
         maxNNZ = int(self.params.get('maxMasksNNZ', 10000000))
         totals = dict(numCellPairs=0, numAssembledCellPairs=0, numIntegrations=0)
         hist, sing = {}, {}

@@ -434,3 +434,217 @@ def partitionClusterPairs(Pnear, size):
     owner_of_group = np.minimum((cum-0.5*weight)/max(total, 1e-300)*size, size-1).astype(np.int64)
     owner = owner_of_group[group]
     return [np.nonzero(owner == r)[0] for r in range(size)]
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+class nearFieldPlan:
+    """Work lists of the tiled near-field assembly (the GPU's own decomposition of assembleClusters, NA:1663-1964).
+
+    The reference records per element pair a 256-bit mask of requested entries (buildMasksForClusters NA:260-391) and
+    scatters entry by entry.  Here every UNORDERED cluster pair {n1, n2} is processed once as a set of tiles
+
+        (64-cell chunk of n1.cells) x (64-cell chunk of n2.cells)
+
+    that accumulate the cross blocks of their ordered element pairs (X in n1.cells, Y in n2.cells) in an LDS sub-block
+    whose rows / columns are the chunk's DoFs that belong to n1 / n2; a sub-block entry (I, J) is then written to the
+    near-field matrix at (I, J) and (J, I).  An element pair with both cells in both cell sets is evaluated in both orders
+    (each order feeds different entries); for n1 == n2 the unordered pairs are evaluated once and the symmetric write does
+    the rest.  Contributions to the diagonal block of a cell X (both DoFs on X) are needed for X in cellsInter only and
+    are summed per (cluster pair, cell) in a buffer D: an ordered pair (X, Y) adds X's part if X is in cellsInter, and Y's
+    part if Y is in cellsInter and the pair (Y, X) is not enumerated itself (X not in n2.cells); the cluster-local
+    Gauss-theorem term (NA:1842-1889) goes to the same buffer.  D is scattered at the end to the DoF pairs {I, J} of the
+    cell that belong to {n1, n2}.  Element pairs that touch (singular rules) are listed per cluster pair and scattered
+    entry-wise under the same membership rule -- that rule is all that is left of the masks."""
+
+    def __init__(self, dm, Pnear, tile=64, maxChunkDofs=None):
+        mesh = dm.mesh
+        dpe = dm.dofs_per_element
+        if maxChunkDofs is None:
+            maxChunkDofs = 56 if dpe <= 3 else 96           # keeps two workgroups of the tile kernel per CU (LDS)
+        nc = mesh.num_cells
+        N = dm.num_dofs
+        self.dm, self.tile = dm, tile
+        # ---- distinct nodes, unordered pairs --------------------------------------------------------------------------
+        nodes, nid = [], {}
+        for cp in Pnear:
+            for n in (cp.n1, cp.n2):
+                if id(n) not in nid:
+                    nid[id(n)] = len(nodes)
+                    nodes.append(n)
+        seen, pairs = set(), []
+        for cp in Pnear:
+            a, b = nid[id(cp.n1)], nid[id(cp.n2)]
+            key = (min(a, b), max(a, b))
+            if key in seen:
+                continue
+            seen.add(key)
+            pairs.append((a, b, cp))
+        self.nodes = nodes
+        self.pair_nodes = np.array([(a, b) for a, b, _ in pairs], dtype=np.int32).reshape(-1, 2)
+        self.node_off = np.zeros(len(nodes)+1, dtype=np.int32)
+        self.node_off[1:] = np.cumsum([n.dofs.shape[0] for n in nodes])
+        self.node_dofs = np.concatenate([n.dofs for n in nodes]).astype(np.int32) if nodes else np.zeros(0, dtype=np.int32)
+        # ---- chunks of every node's cell list ---------------------------------------------------------------------------
+        dofs = dm.dofs
+        chunk_cells, chunk_ndof, chunk_dofl, chunk_slot = [], [], [], []
+        self.node_chunk_off = np.zeros(len(nodes)+1, dtype=np.int32)
+        cen = mesh.vertices[mesh.cells].mean(axis=1)
+        lo, ext = cen.min(axis=0), np.maximum(cen.max(axis=0)-cen.min(axis=0), 1e-300)
+        g = np.minimum(((cen-lo)/ext*65535.).astype(np.uint64), np.uint64(65535))
+        morton = np.zeros(nc, dtype=np.uint64)
+        for bit in range(16):
+            for d in range(mesh.dim):
+                morton |= ((g[:, d] >> np.uint64(bit)) & np.uint64(1)) << np.uint64(mesh.dim*bit+d)
+        for i, n in enumerate(nodes):
+            # chunks of spatially compact cells (Morton order of the centres) share more DoFs: smaller LDS sub-blocks
+            cells = n.cells[np.argsort(morton[n.cells], kind='stable')]
+            member = np.zeros(N+1, dtype=bool)
+            member[n.dofs] = True
+            # a chunk closes at `tile` cells or when one more cell would bring it above maxChunkDofs distinct DoFs (LDS budget)
+            dall = dofs[cells]
+            okall = (dall >= 0) & member[np.where(dall >= 0, dall, N)]
+            s0 = 0
+            while s0 < cells.shape[0]:
+                s1 = min(s0+tile, cells.shape[0])
+                while True:
+                    cc = cells[s0:s1]
+                    d, ok = dall[s0:s1], okall[s0:s1]
+                    u = np.unique(d[ok])
+                    if u.shape[0] <= maxChunkDofs or s1-s0 <= 1:
+                        break
+                    s1 = s0+max(1, (s1-s0)*maxChunkDofs//u.shape[0])
+                slot = np.full((tile, dpe), -1, dtype=np.int16)
+                slot[:cc.shape[0]][ok] = np.searchsorted(u, d[ok]).astype(np.int16)
+                pad = np.full(tile, -1, dtype=np.int32)
+                pad[:cc.shape[0]] = cc
+                chunk_cells.append(pad)
+                chunk_ndof.append(u.shape[0])
+                chunk_dofl.append(u.astype(np.int32))
+                chunk_slot.append(slot.T.copy())                        # [dpe, tile]
+                s0 = s1
+            self.node_chunk_off[i+1] = len(chunk_cells)
+        self.nU = max(chunk_ndof) if chunk_ndof else 1
+        nchunks = len(chunk_cells)
+        self.chunk_cells = np.array(chunk_cells, dtype=np.int32).reshape(nchunks, tile)
+        self.chunk_ndof = np.array(chunk_ndof, dtype=np.int32)
+        self.chunk_dofs = np.zeros((nchunks, self.nU), dtype=np.int32)
+        for k, u in enumerate(chunk_dofl):
+            self.chunk_dofs[k, :u.shape[0]] = u
+        self.chunk_slot = np.array(chunk_slot, dtype=np.int16).reshape(nchunks, dpe, tile)
+        # ---- per pair: diagonal-block buffer slots, tiles, touching element pairs, boundary items --------------------------
+        adj = _cellAdjacency(mesh)
+        tA, tB, tP, tF, dsA, dsB = [], [], [], [], [], []
+        sing = [[], [], []]                                               # by number of shared vertices - 1: (k, c1, c2)
+        bt_slot, bt_cell, bt_facet = [], [], []
+        pair_facets = []
+        self.pair_foff = np.zeros(len(pairs)+1, dtype=np.int32)
+        self.pair_dbase = np.zeros(len(pairs)+1, dtype=np.int64)
+        d_cell, d_pair = [], []
+        nV = mesh.dim+1
+        for k, (a, b, cp) in enumerate(pairs):
+            n1, n2 = nodes[a], nodes[b]
+            sym = a == b
+            inter = np.intersect1d(n1.cells, n2.cells)
+            dbase = int(self.pair_dbase[k])
+            self.pair_dbase[k+1] = dbase+inter.shape[0]
+            d_cell.append(inter)
+            d_pair.append(np.full(inter.shape[0], k, dtype=np.int32))
+            pos = np.full(nc, -1, dtype=np.int64)
+            pos[inter] = dbase+np.arange(inter.shape[0])
+            ca = np.arange(self.node_chunk_off[a], self.node_chunk_off[a+1])
+            cb = np.arange(self.node_chunk_off[b], self.node_chunk_off[b+1])
+            A, B = np.meshgrid(ca, cb, indexing='ij')
+            A, B = A.reshape(-1), B.reshape(-1)
+            if sym:
+                keep = A <= B
+                A, B = A[keep], B[keep]
+            tA.append(A)
+            tB.append(B)
+            tP.append(np.full(A.shape[0], k, dtype=np.int32))
+            tF.append(np.full(A.shape[0], 1 if sym else 0, dtype=np.int32))
+            cellsA, cellsB = self.chunk_cells[A], self.chunk_cells[B]
+            dsA.append(np.where(cellsA >= 0, pos[np.maximum(cellsA, 0)], -1))
+            dsB.append(np.where(cellsB >= 0, pos[np.maximum(cellsB, 0)], -1))
+            # touching element pairs {X, Y}, X in n1.cells, Y in n2.cells (folded, unique)
+            in2 = np.zeros(nc, dtype=bool)
+            in2[n2.cells] = True
+            ptr, idx = adj
+            cnt = ptr[n1.cells+1]-ptr[n1.cells]
+            X = np.repeat(n1.cells, cnt)
+            Y = np.concatenate([idx[ptr[c]:ptr[c+1]] for c in n1.cells]) if n1.cells.shape[0] else np.zeros(0, dtype=np.int64)
+            m = in2[Y]
+            X, Y = X[m], Y[m]
+            lo, hi = np.minimum(X, Y), np.maximum(X, Y)
+            key = np.unique(lo.astype(np.int64)*nc+hi)
+            lo, hi = (key//nc).astype(np.int32), (key % nc).astype(np.int32)
+            common = (mesh.cells[lo][:, :, None] == mesh.cells[hi][:, None, :]).sum(axis=(1, 2))
+            common = np.where(lo == hi, nV, common)
+            for c in range(1, nV+1):
+                mm = common == c
+                if mm.any():
+                    sing[c-1].append(np.stack([np.full(int(mm.sum()), k, dtype=np.int32), lo[mm], hi[mm]], axis=1))
+            # cluster-local Gauss-theorem term: cells of cellsInter x boundary facets of cellsUnion; the device loops over the
+            # facets per cell and skips the touching (cell, facet) pairs, which are listed here
+            self.pair_foff[k+1] = self.pair_foff[k]
+            if inter.shape[0]:
+                union = np.union1d(n1.cells, n2.cells)
+                facets = boundaryFacetsOfCells(mesh, union)
+                pair_facets.append(facets)
+                self.pair_foff[k+1] += facets.shape[0]
+                cv = mesh.cells[inter]                                  # [m, nV]
+                cand = np.nonzero(np.isin(cv, facets).any(axis=1))[0]
+                if cand.shape[0]:
+                    touch = (cv[cand][:, None, :, None] == facets[None, :, None, :]).any(axis=(2, 3))   # [ncand, nf]
+                    ci, fi = np.nonzero(touch)
+                    bt_slot.append(pos[inter[cand[ci]]])
+                    bt_cell.append(inter[cand[ci]])
+                    bt_facet.append(facets[fi])
+        cat = lambda L, dt, shape=None: (np.concatenate(L).astype(dt) if L else np.zeros((0,)+(shape or ()), dtype=dt))
+        self.tile_chunkA, self.tile_chunkB = cat(tA, np.int32), cat(tB, np.int32)
+        self.tile_pair, self.tile_flags = cat(tP, np.int32), cat(tF, np.int32)
+        self.tile_dslotA = cat(dsA, np.int32, (tile,)).reshape(-1, tile)
+        self.tile_dslotB = cat(dsB, np.int32, (tile,)).reshape(-1, tile)
+        self.sing_items = [cat(s, np.int32, (3,)).reshape(-1, 3) for s in sing]
+        self.d_cell, self.d_pair = cat(d_cell, np.int32), cat(d_pair, np.int32)
+        self.num_dslots = int(self.pair_dbase[-1])
+        self.fvid = cat(pair_facets, np.int32, (mesh.dim,)).reshape(-1, mesh.dim)
+        self.bt_slot, self.bt_cell = cat(bt_slot, np.int32), cat(bt_cell, np.int32)
+        self.bt_facet = cat(bt_facet, np.int32, (mesh.dim,)).reshape(-1, mesh.dim)
+        # heavy tiles (more real cells) first
+        if self.tile_chunkA.shape[0]:
+            w = (self.chunk_cells[self.tile_chunkA] >= 0).sum(axis=1)*(self.chunk_cells[self.tile_chunkB] >= 0).sum(axis=1)
+            order = np.argsort(-w, kind='stable')
+            for name in ('tile_chunkA', 'tile_chunkB', 'tile_pair', 'tile_flags', 'tile_dslotA', 'tile_dslotB'):
+                setattr(self, name, np.ascontiguousarray(getattr(self, name)[order]))
+
+    @property
+    def num_pairs(self):
+        return self.pair_nodes.shape[0]
+
+
+def _cellAdjacency(mesh):
+    """CSR (ptr, idx) of the cells sharing at least one vertex with a cell (the cell itself included)"""
+    nc, nV = mesh.num_cells, mesh.cells.shape[1]
+    v = mesh.cells.reshape(-1)
+    c = np.repeat(np.arange(nc), nV)
+    order = np.argsort(v, kind='stable')
+    v, c = v[order], c[order]
+    vptr = np.zeros(mesh.num_vertices+1, dtype=np.int64)
+    np.add.at(vptr, v+1, 1)
+    vptr = np.cumsum(vptr)
+    out_c, out_n = [], []
+    deg = vptr[1:]-vptr[:-1]
+    # pairs (cell, neighbour) through every shared vertex
+    for d in np.unique(deg):
+        vs = np.nonzero(deg == d)[0]
+        if d == 0:
+            continue
+        block = c[(vptr[vs][:, None]+np.arange(d)[None, :])]           # [nvs, d]
+        out_c.append(np.repeat(block, d, axis=1).reshape(-1))
+        out_n.append(np.tile(block, (1, d)).reshape(-1))
+    cc, nn = np.concatenate(out_c), np.concatenate(out_n)
+    key = np.unique(cc.astype(np.int64)*nc+nn)
+    cc, nn = key//nc, key % nc
+    ptr = np.zeros(nc+1, dtype=np.int64)
+    np.add.at(ptr, cc+1, 1)
+    return np.cumsum(ptr), nn.astype(np.int64)

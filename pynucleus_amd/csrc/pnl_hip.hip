@@ -63,7 +63,7 @@ struct pnl_context {
         b_foff, b_fbary, b_fw, b_bvid, b_bv, b_bgeo, b_counters, b_D, b_tiles,
         b_vec[6], b_clabel, b_blabel, b_clsof, b_scal, b_wl, b_wlcount, b_ttn, b_ttoff, b_tttab, b_wlsorted, b_wlaux,
         b_vertices, b_sp_indptr, b_sp_indices, b_mp_pairs, b_mp_masks, b_mp_wl, b_mp_sorted, b_mp_aux, b_bi_cells, b_bi_facets,
-        b_bi_masks;
+        b_bi_masks, b_cp[28], b_cpD, b_wlds, b_wlpair;
     int sp_nnz = -1;                // near-field sparsity pattern (pnl_upload_sparsity)
     unsigned wl_cap = 0;
     int tile = TILE_P1, nblocks = 0, ncp = 0, nU = 0;
@@ -469,7 +469,7 @@ int launch_tiles(pnl_context *ctx, int ntiles_all, double *A, int64_t ldA, int c
     const size_t lds = S::fixed_bytes+sizeof(double)*(size_t)(ctx->nU+1)*acc_stride;
     if (getenv("PNL_VERBOSE")) {
         int nblk = -1;
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nblk, (const void*)k_tile_distant<DIM, DPE, TILE, KT>, PNL_NTHREADS, lds);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nblk, (const void*)k_tile_distant<DIM, DPE, TILE, KT, false>, PNL_NTHREADS, lds);
         fprintf(stderr, "[pnl] tiles=%d nU=%d lds=%zu bytes, occupancy API: %d blocks/CU\n", ntiles, ctx->nU, lds, nblk);
     }
     if (lds > 160*1024)
@@ -489,7 +489,7 @@ int launch_tiles(pnl_context *ctx, int ntiles_all, double *A, int64_t ldA, int c
         if ((rc = ensure(ctx, ctx->b_wlcount, sizeof(unsigned)))) return rc;
         HIPCHK(ctx, hipMemsetAsync(ctx->b_wlcount.p, 0, sizeof(unsigned), ctx->stream));
     }
-    auto kfun = k_tile_distant<DIM, DPE, TILE, KT>;
+    auto kfun = k_tile_distant<DIM, DPE, TILE, KT, false>;
     HIPCHK(ctx, hipFuncSetAttribute((const void*)kfun, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     int per_cu = 2;
     (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)kfun, PNL_NTHREADS, lds);
@@ -498,7 +498,7 @@ int launch_tiles(pnl_context *ctx, int ntiles_all, double *A, int64_t ldA, int c
     if (grid > 0)
         hipLaunchKernelGGL(kfun, dim3(grid), dim3(PNL_NTHREADS), lds, ctx->stream, ctx->P, (const int2*)ctx->b_tiles.p, A,
                            (long long)ldA, (double*)ctx->b_D.p, cell_begin, cell_end, acc_stride, (int4*)ctx->b_wl.p,
-                           (unsigned*)ctx->b_wlcount.p, ctx->wl_cap, ctx->ablate, ntiles);
+                           (unsigned*)ctx->b_wlcount.p, ctx->wl_cap, ctx->ablate, ntiles, ClusterTiles{});
     HIPCHK(ctx, hipGetLastError());
     HIPCHK(ctx, hipEventRecord(ctx->ev[6], ctx->stream));
     {
@@ -523,10 +523,10 @@ int launch_tiles(pnl_context *ctx, int ntiles_all, double *A, int64_t ldA, int c
         if (ctx->wl_lane)
             hipLaunchKernelGGL((k_worklist_lane<DIM, DPE, KT, false>), dim3(256*4), dim3(PNL_NTHREADS), 0, ctx->stream, ctx->P,
                                (const int4*)ctx->b_wlsorted.p, (const unsigned*)offs, A, (long long)ldA, (double*)ctx->b_D.p, SparseOut{},
-                               getenv("PNL_WL_DBG") ? atoi(getenv("PNL_WL_DBG")) : 0);
+                               getenv("PNL_WL_DBG") ? atoi(getenv("PNL_WL_DBG")) : 0, ClusterTiles{});
         hipLaunchKernelGGL(wfun, dim3(256*2), dim3(PNL_NTHREADS), lds, ctx->stream, ctx->P, (const int4*)ctx->b_wlsorted.p,
                            (const unsigned*)offs, (const unsigned*)coff, A, (long long)ldA, (double*)ctx->b_D.p, tab_max,
-                           SparseOut{}, PNL_WL_BINS-1, nmin);
+                           SparseOut{}, PNL_WL_BINS-1, nmin, ClusterTiles{});
         HIPCHK(ctx, hipGetLastError());
     }
     return PNL_OK;
@@ -545,12 +545,12 @@ int launch_singular_slot(pnl_context *ctx, int np, double *A, int64_t ldA, int c
         const int per_cu = std::max(1, (int)((160*1024)/std::max<size_t>(lds, 1)));
         const int grid = std::min((np+waves_per_block-1)/waves_per_block, 256*std::min(per_cu, 4));
         hipLaunchKernelGGL(kfun, dim3(grid), dim3(PNL_SING_THREADS), lds, ctx->stream, ctx->P, pairs, np, A, (long long)ldA,
-                           cell_begin, cell_end, SparseOut{}, (const int4*)nullptr, (const unsigned*)nullptr);
+                           cell_begin, cell_end, SparseOut{}, (const int4*)nullptr, (const unsigned*)nullptr, ClusterTiles{});
     } else {
         const int grid = std::min((np+waves_per_block-1)/waves_per_block, 256*4);
         hipLaunchKernelGGL((k_singular_pairs<DIM, DPE, SLOT, KT, false, false>), dim3(grid), dim3(PNL_SING_THREADS), 0, ctx->stream,
                            ctx->P, pairs, np, A, (long long)ldA, cell_begin, cell_end, SparseOut{}, (const int4*)nullptr,
-                           (const unsigned*)nullptr);
+                           (const unsigned*)nullptr, ClusterTiles{});
     }
     HIPCHK(ctx, hipGetLastError());
     return PNL_OK;
@@ -672,10 +672,10 @@ int launch_singular_sparse(pnl_context *ctx, const SparseOut &S, const int4 *sor
         HIPCHK(ctx, hipFuncSetAttribute((const void*)kfun, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         const int per_cu = std::max(1, (int)((160*1024)/std::max<size_t>(lds, 1)));
         hipLaunchKernelGGL(kfun, dim3(256*std::min(per_cu, 4)), dim3(PNL_SING_THREADS), lds, ctx->stream, ctx->P, (const int2*)nullptr, 0,
-                           (double*)nullptr, 0ll, 0, 0, S, sorted, offs);
+                           (double*)nullptr, 0ll, 0, 0, S, sorted, offs, ClusterTiles{});
     } else {
         hipLaunchKernelGGL((k_singular_pairs<DIM, DPE, SLOT, KT, false, true>), dim3(256*4), dim3(PNL_SING_THREADS), 0, ctx->stream,
-                           ctx->P, (const int2*)nullptr, 0, (double*)nullptr, 0ll, 0, 0, S, sorted, offs);
+                           ctx->P, (const int2*)nullptr, 0, (double*)nullptr, 0ll, 0, 0, S, sorted, offs, ClusterTiles{});
     }
     HIPCHK(ctx, hipGetLastError());
     return PNL_OK;
@@ -713,9 +713,9 @@ int pairs_masked_impl(pnl_context *ctx, int np, const SparseOut &S) {
         const int nmin = ctx->wl_lane ? PNL_WL_LANE_MAXPTS+1 : 0;
         if (ctx->wl_lane)
             hipLaunchKernelGGL((k_worklist_lane<DIM, DPE, KT, true>), dim3(256*4), dim3(PNL_NTHREADS), 0, ctx->stream, ctx->P,
-                               (const int4*)sorted, (const unsigned*)offs, (double*)nullptr, 0ll, (double*)nullptr, S, 0);
+                               (const int4*)sorted, (const unsigned*)offs, (double*)nullptr, 0ll, (double*)nullptr, S, 0, ClusterTiles{});
         hipLaunchKernelGGL(wfun, dim3(256*2), dim3(PNL_NTHREADS), lds, ctx->stream, ctx->P, (const int4*)sorted, (const unsigned*)offs,
-                           (const unsigned*)coff, (double*)nullptr, 0ll, (double*)nullptr, tab_max, S, PNL_MAXQ, nmin);
+                           (const unsigned*)coff, (double*)nullptr, 0ll, (double*)nullptr, tab_max, S, PNL_MAXQ, nmin, ClusterTiles{});
         HIPCHK(ctx, hipGetLastError());
     }
     HIPCHK(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
@@ -745,11 +745,151 @@ int boundary_masked_impl(pnl_context *ctx, int ni, double fac, const SparseOut &
     const double *verts = (const double*)ctx->b_vertices.p;
     if (ctx->P.bkn.fast)
         hipLaunchKernelGGL((k_boundary_items<DIM, DPE, 1>), dim3(grid), dim3(PNL_NTHREADS), 0, ctx->stream, ctx->P, verts, cells, facets,
-                           masks, ni, fac, S);
+                           masks, ni, fac, S, (double*)nullptr);
     else
         hipLaunchKernelGGL((k_boundary_items<DIM, DPE, 0>), dim3(grid), dim3(PNL_NTHREADS), 0, ctx->stream, ctx->P, verts, cells, facets,
-                           masks, ni, fac, S);
+                           masks, ni, fac, S, (double*)nullptr);
     HIPCHK(ctx, hipGetLastError());
+    return PNL_OK;
+}
+
+
+// ---- tiled near-field assembly -------------------------------------------------------------------------------------------
+template <int DIM, int DPE, int TILE, int KT>
+int clusters_tiled_impl(pnl_context *ctx, const pnl_cluster_plan *pl, ClusterTiles CT, int cluster_boundary, const int *d_cell,
+                        const int *d_pair, const int2 *sing_dev[3], const int *sing_pair_dev[3], const int *pair_foff, const int *fvid,
+                        const double *fgeo, int maxf, const int *bt_cell, const int *bt_facet, const unsigned *bt_slot) {
+    using S = TileSmem<DIM, DPE, TILE>;
+    constexpr int ND = DPE*(DPE+1)/2;
+    int rc;
+    const int acc_stride = pl->chunk_stride+1;
+    const size_t lds = S::fixed_bytes+sizeof(double)*(size_t)(pl->chunk_stride+1)*acc_stride;
+    if (lds > 160*1024) return fail(ctx, PNL_ERR_UNSUPPORTED, "cluster chunk with %d DoFs: LDS sub-block of %zu bytes exceeds 160 KiB", pl->chunk_stride, lds);
+    HIPCHK(ctx, hipMemsetAsync(ctx->b_counters.p, 0, sizeof(unsigned long long)*PNL_NCOUNTERS, ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(CT.D, 0, sizeof(double)*(size_t)std::max(pl->num_dslots, 1)*ND, ctx->stream));
+    HIPCHK(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
+    HIPCHK(ctx, hipEventRecord(ctx->ev[7], ctx->stream));
+    ctx->pure_launched = false;
+    // work list of the orders the tiles do not integrate themselves
+    {
+        const double pairs = (double)pl->ntiles*TILE*TILE;
+        const size_t want = (size_t)std::min<double>(std::max<double>(pairs*0.25, 1<<20), 400e6);
+        if (ctx->wl_cap < want) {
+            if ((rc = ensure(ctx, ctx->b_wl, want*sizeof(int4)))) return rc;
+            ctx->wl_cap = (unsigned)want;
+        }
+        if ((rc = ensure(ctx, ctx->b_wlds, (size_t)ctx->wl_cap*sizeof(int2)))) return rc;
+        if ((rc = ensure(ctx, ctx->b_wlpair, (size_t)ctx->wl_cap*sizeof(int)))) return rc;
+        if ((rc = ensure(ctx, ctx->b_wlcount, sizeof(unsigned)))) return rc;
+        HIPCHK(ctx, hipMemsetAsync(ctx->b_wlcount.p, 0, sizeof(unsigned), ctx->stream));
+        CT.wl_ds = (int2*)ctx->b_wlds.p; CT.wl_pair = (int*)ctx->b_wlpair.p;
+    }
+    if (pl->ntiles > 0) {
+        auto kfun = k_tile_distant<DIM, DPE, TILE, KT, true>;
+        HIPCHK(ctx, hipFuncSetAttribute((const void*)kfun, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        int per_cu = 2;
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)kfun, PNL_NTHREADS, lds);
+        if (getenv("PNL_VERBOSE")) fprintf(stderr, "[pnl] cluster tiles=%d nU=%d lds=%zu bytes, occupancy API: %d blocks/CU\n", pl->ntiles,
+                                           pl->chunk_stride, lds, per_cu);
+        const int grid = std::min(pl->ntiles, 256*std::max(per_cu, 1));
+        hipLaunchKernelGGL(kfun, dim3(grid), dim3(PNL_NTHREADS), lds, ctx->stream, ctx->P, (const int2*)nullptr, (double*)nullptr, 0ll,
+                           (double*)nullptr, 0, ctx->nc, acc_stride, (int4*)ctx->b_wl.p, (unsigned*)ctx->b_wlcount.p, ctx->wl_cap, 0,
+                           pl->ntiles, CT);
+        HIPCHK(ctx, hipGetLastError());
+    }
+    HIPCHK(ctx, hipEventRecord(ctx->ev[6], ctx->stream));
+    {
+        if ((rc = ensure(ctx, ctx->b_wlsorted, (size_t)ctx->wl_cap*sizeof(int4)))) return rc;
+        if ((rc = ensure(ctx, ctx->b_wlaux, sizeof(unsigned)*(4*(PNL_WL_BINS+1))))) return rc;
+        unsigned *hist = (unsigned*)ctx->b_wlaux.p, *offs = hist+(PNL_WL_BINS+1), *coff = offs+(PNL_WL_BINS+1), *cursor = coff+(PNL_WL_BINS+1);
+        HIPCHK(ctx, hipMemsetAsync(hist, 0, sizeof(unsigned)*(PNL_WL_BINS+1), ctx->stream));
+        const int4 *wl = (const int4*)ctx->b_wl.p;
+        const unsigned *wlc = (const unsigned*)ctx->b_wlcount.p;
+        hipLaunchKernelGGL(k_wl_hist, dim3(512), dim3(PNL_NTHREADS), 0, ctx->stream, wl, wlc, ctx->wl_cap, hist);
+        hipLaunchKernelGGL(k_wl_scan, dim3(1), dim3(64), 0, ctx->stream, (const unsigned*)hist, offs, coff, cursor);
+        hipLaunchKernelGGL(k_wl_scatter, dim3(512), dim3(PNL_NTHREADS), 0, ctx->stream, wl, wlc, ctx->wl_cap, (const unsigned*)offs, cursor,
+                           (int4*)ctx->b_wlsorted.p);
+        const int st = 4+DPE;
+        const int tab_max = (60*1024)/(st*(int)sizeof(double));
+        const size_t wlds = (size_t)tab_max*st*sizeof(double);
+        auto wfun = k_worklist_sorted<DIM, DPE, KT, false>;
+        HIPCHK(ctx, hipFuncSetAttribute((const void*)wfun, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wlds));
+        hipLaunchKernelGGL((k_worklist_lane<DIM, DPE, KT, false>), dim3(256*4), dim3(PNL_NTHREADS), 0, ctx->stream, ctx->P,
+                           (const int4*)ctx->b_wlsorted.p, (const unsigned*)offs, (double*)nullptr, 0ll, (double*)nullptr, SparseOut{}, 0, CT);
+        hipLaunchKernelGGL(wfun, dim3(256*2), dim3(PNL_NTHREADS), wlds, ctx->stream, ctx->P, (const int4*)ctx->b_wlsorted.p,
+                           (const unsigned*)offs, (const unsigned*)coff, (double*)nullptr, 0ll, (double*)nullptr, tab_max, SparseOut{},
+                           PNL_WL_BINS-1, PNL_WL_LANE_MAXPTS+1, CT);
+        HIPCHK(ctx, hipGetLastError());
+    }
+    HIPCHK(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
+    HIPCHK(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
+    // touching element pairs
+    for (int s = 0; s < DIM+1; s++) {
+        const int np = pl->n_sing[s];
+        if (!np) continue;
+        if (!ctx->C().have_sing[0][s]) return fail(ctx, PNL_ERR_STATE, "singular rule for %d common vertices not uploaded", s+1);
+        ClusterTiles C2 = CT;
+        C2.sing_pair = sing_pair_dev[s];
+        const int M = ctx->P.sM[s], rows = ctx->P.sRows[s];
+        const size_t slds = sizeof(double)*(size_t)(2*(DIM+1)+1+rows)*M;
+        const int wpb = PNL_SING_THREADS/64;
+        const bool stage = slds <= 150*1024;
+        const int per_cu = stage ? std::max(1, (int)((160*1024)/std::max<size_t>(slds, 1))) : 4;
+        const int grid = std::min((np+wpb-1)/wpb, 256*std::min(per_cu, 4));
+#define PNL_LAUNCH_SING(SLOT)                                                                                                          \
+        if (stage) {                                                                                                                   \
+            auto kf = k_singular_pairs<DIM, DPE, SLOT, KT, true, false>;                                                               \
+            HIPCHK(ctx, hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)slds));                 \
+            hipLaunchKernelGGL(kf, dim3(grid), dim3(PNL_SING_THREADS), slds, ctx->stream, ctx->P, sing_dev[s], np, (double*)nullptr, 0ll, \
+                               0, ctx->nc, SparseOut{}, (const int4*)nullptr, (const unsigned*)nullptr, C2);                          \
+        } else                                                                                                                         \
+            hipLaunchKernelGGL((k_singular_pairs<DIM, DPE, SLOT, KT, false, false>), dim3(grid), dim3(PNL_SING_THREADS), 0, ctx->stream, \
+                               ctx->P, sing_dev[s], np, (double*)nullptr, 0ll, 0, ctx->nc, SparseOut{}, (const int4*)nullptr,          \
+                               (const unsigned*)nullptr, C2);
+        if (s == 0) { PNL_LAUNCH_SING(0) }
+        else if (s == 1) { PNL_LAUNCH_SING(1) }
+        else { PNL_LAUNCH_SING((DIM == 2 ? 2 : 1)) }
+#undef PNL_LAUNCH_SING
+        HIPCHK(ctx, hipGetLastError());
+    }
+    HIPCHK(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
+    // cluster-local Gauss-theorem term into the diagonal-block buffer
+    if (cluster_boundary && pl->num_dslots > 0 && pl->nfacets > 0) {
+        if (!ctx->C().have_kernel[1] || !ctx->C().have_form[1]) return fail(ctx, PNL_ERR_STATE, "boundary kernel and order formula must be set");
+        // few cells (those of cellsInter), many facets each: small facet chunks give the parallelism
+        const int per = getenv("PNL_CB_PER") ? atoi(getenv("PNL_CB_PER")) : 2;
+        const dim3 grid((pl->num_dslots+PNL_NTHREADS-1)/PNL_NTHREADS, (maxf+per-1)/per);
+        const double *verts = (const double*)ctx->b_vertices.p;
+        if (ctx->P.bkn.fast)
+            hipLaunchKernelGGL((k_cluster_boundary<DIM, DPE, 1>), grid, dim3(PNL_NTHREADS), 0, ctx->stream, ctx->P, verts, d_cell, d_pair,
+                               pl->num_dslots, pair_foff, fvid, fgeo, pl->nfacets, CT.D, per);
+        else
+            hipLaunchKernelGGL((k_cluster_boundary<DIM, DPE, 0>), grid, dim3(PNL_NTHREADS), 0, ctx->stream, ctx->P, verts, d_cell, d_pair,
+                               pl->num_dslots, pair_foff, fvid, fgeo, pl->nfacets, CT.D, per);
+        HIPCHK(ctx, hipGetLastError());
+        if (pl->n_btouch > 0) {
+            for (int s = 0; s < DIM; s++)
+                if (!ctx->C().have_sing[1][s]) return fail(ctx, PNL_ERR_STATE, "boundary singular rule for %d common vertices not uploaded", s+1);
+            const int g2 = std::min((pl->n_btouch+3)/4, 256*8);
+            if (ctx->P.bkn.fast)
+                hipLaunchKernelGGL((k_boundary_items<DIM, DPE, 1>), dim3(g2), dim3(PNL_NTHREADS), 0, ctx->stream, ctx->P, verts, bt_cell,
+                                   bt_facet, bt_slot, pl->n_btouch, 1., SparseOut{}, CT.D);
+            else
+                hipLaunchKernelGGL((k_boundary_items<DIM, DPE, 0>), dim3(g2), dim3(PNL_NTHREADS), 0, ctx->stream, ctx->P, verts, bt_cell,
+                                   bt_facet, bt_slot, pl->n_btouch, 1., SparseOut{}, CT.D);
+            HIPCHK(ctx, hipGetLastError());
+        }
+    }
+    HIPCHK(ctx, hipEventRecord(ctx->ev[4], ctx->stream));
+    if (pl->num_dslots > 0) {
+        const long long nt = (long long)pl->num_dslots*DPE*DPE;
+        hipLaunchKernelGGL((k_cluster_scatter_diag<DPE>), dim3((unsigned)((nt+PNL_NTHREADS-1)/PNL_NTHREADS)), dim3(PNL_NTHREADS), 0,
+                           ctx->stream, ctx->P, CT, d_cell, d_pair, pl->num_dslots);
+        HIPCHK(ctx, hipGetLastError());
+    }
+    HIPCHK(ctx, hipEventRecord(ctx->ev[5], ctx->stream));
+    ctx->ev_valid = true;
+    ctx->tiles_launched = true;
     return PNL_OK;
 }
 
@@ -1260,6 +1400,121 @@ int pnl_assemble_boundary_masked(pnl_context *ctx, int ni, const int32_t *cells,
     if (ctx->dim == 2 && ctx->dpe == 6) return boundary_masked_impl<2, 6>(ctx, ni, fac, S);
     if (ctx->dim == 1 && ctx->dpe == 2) return boundary_masked_impl<1, 2>(ctx, ni, fac, S);
     return fail(ctx, PNL_ERR_UNSUPPORTED, "unsupported (dim=%d, dofs_per_element=%d)", ctx->dim, ctx->dpe);
+}
+
+int pnl_assemble_clusters_tiled(pnl_context *ctx, const pnl_cluster_plan *pl, int cluster_boundary, double *data, double *diag) {
+    if (!ctx || !pl) return PNL_ERR_INVALID;
+    if (ctx->nlab > 0) return fail(ctx, PNL_ERR_UNSUPPORTED, "cluster assembly with a variable order needs the jump terms (NA:1966-2156)");
+    if (!std::isinf(ctx->C().kern[0].horizon2)) return fail(ctx, PNL_ERR_UNSUPPORTED, "tiled cluster assembly: infinite horizon only");
+    int rc;
+    SparseOut S;
+    if ((rc = sparse_ready(ctx, data, diag, S))) return rc;
+    if (pl->tile != ctx->tile) return fail(ctx, PNL_ERR_INVALID, "plan built for tiles of %d cells, the kernels use %d", pl->tile, ctx->tile);
+    if (pl->npairs < 0 || pl->ntiles < 0 || pl->num_dslots < 0 || pl->chunk_stride < 1) return fail(ctx, PNL_ERR_INVALID, "bad plan sizes");
+    const int T = pl->tile, dim = ctx->dim, dpe = ctx->dpe;
+    // light validation of the index arrays (a wrong index here would be an out-of-bounds access on the device)
+    for (int t = 0; t < pl->ntiles; t++) {
+        if (pl->tile_chunkA[t] < 0 || pl->tile_chunkA[t] >= pl->nchunks || pl->tile_chunkB[t] < 0 || pl->tile_chunkB[t] >= pl->nchunks ||
+            pl->tile_pair[t] < 0 || pl->tile_pair[t] >= pl->npairs)
+            return fail(ctx, PNL_ERR_INVALID, "tile %d out of range", t);
+        for (int l = 0; l < T; l++)
+            if (pl->tile_dslotA[(size_t)t*T+l] >= pl->num_dslots || pl->tile_dslotB[(size_t)t*T+l] >= pl->num_dslots)
+                return fail(ctx, PNL_ERR_INVALID, "tile %d: diagonal-block slot out of range", t);
+    }
+    for (size_t i = 0; i < (size_t)pl->nchunks*T; i++)
+        if (pl->chunk_cells[i] >= ctx->nc) return fail(ctx, PNL_ERR_INVALID, "chunk cell out of range");
+    for (int c = 0; c < pl->nchunks; c++)
+        if (pl->chunk_ndof[c] < 0 || pl->chunk_ndof[c] > pl->chunk_stride) return fail(ctx, PNL_ERR_INVALID, "chunk %d: bad DoF count", c);
+    for (size_t i = 0; i < (size_t)pl->nchunks*dpe*T; i++)
+        if (pl->chunk_slot[i] >= pl->chunk_stride) return fail(ctx, PNL_ERR_INVALID, "chunk slot out of range");
+    for (int k = 0; k < 2*pl->npairs; k++)
+        if (pl->pair_nodes[k] < 0 || pl->pair_nodes[k] >= pl->nnodes) return fail(ctx, PNL_ERR_INVALID, "pair node out of range");
+    for (int d = 0; d < pl->num_dslots; d++)
+        if (pl->d_cell[d] < 0 || pl->d_cell[d] >= ctx->nc || pl->d_pair[d] < 0 || pl->d_pair[d] >= pl->npairs)
+            return fail(ctx, PNL_ERR_INVALID, "diagonal-block slot %d out of range", d);
+    for (size_t i = 0; i < (size_t)pl->nfacets*dim; i++)
+        if (pl->fvid[i] < 0 || pl->fvid[i] >= ctx->nv) return fail(ctx, PNL_ERR_INVALID, "facet vertex out of range");
+    DevBuf *B = ctx->b_cp;
+    int nb = 0;
+#define UP(ptr, n) ((rc = upload(ctx, B[nb], ptr, (size_t)(n))) ? nullptr : B[nb++].p)
+    ClusterTiles CT;
+    std::memset(&CT, 0, sizeof(CT));
+    CT.npairs = pl->npairs; CT.chunk_stride = pl->chunk_stride; CT.S = S;
+    if (!(CT.pair_nodes = (const int*)UP(pl->pair_nodes, 2*pl->npairs))) return rc;
+    if (!(CT.node_off = (const int*)UP(pl->node_off, pl->nnodes+1))) return rc;
+    if (!(CT.node_dofs = (const int*)UP(pl->node_dofs, pl->node_off[pl->nnodes]))) return rc;
+    if (!(CT.chunk_cells = (const int*)UP(pl->chunk_cells, (size_t)pl->nchunks*T))) return rc;
+    if (!(CT.chunk_ndof = (const int*)UP(pl->chunk_ndof, pl->nchunks))) return rc;
+    if (!(CT.chunk_dofs = (const int*)UP(pl->chunk_dofs, (size_t)pl->nchunks*pl->chunk_stride))) return rc;
+    if (!(CT.chunk_slot = (const short*)UP(pl->chunk_slot, (size_t)pl->nchunks*dpe*T))) return rc;
+    if (!(CT.chunkA = (const int*)UP(pl->tile_chunkA, pl->ntiles))) return rc;
+    if (!(CT.chunkB = (const int*)UP(pl->tile_chunkB, pl->ntiles))) return rc;
+    if (!(CT.pair = (const int*)UP(pl->tile_pair, pl->ntiles))) return rc;
+    if (!(CT.flags = (const int*)UP(pl->tile_flags, pl->ntiles))) return rc;
+    if (!(CT.dslotA = (const int*)UP(pl->tile_dslotA, (size_t)pl->ntiles*T))) return rc;
+    if (!(CT.dslotB = (const int*)UP(pl->tile_dslotB, (size_t)pl->ntiles*T))) return rc;
+    const int *d_cell, *d_pair, *pair_foff, *fvid, *bt_cell, *bt_facet;
+    const unsigned *bt_slot;
+    if (!(d_cell = (const int*)UP(pl->d_cell, pl->num_dslots))) return rc;
+    if (!(d_pair = (const int*)UP(pl->d_pair, pl->num_dslots))) return rc;
+    if (!(pair_foff = (const int*)UP(pl->pair_foff, pl->npairs+1))) return rc;
+    if (!(fvid = (const int*)UP(pl->fvid, (size_t)pl->nfacets*dim))) return rc;
+    if (!(bt_cell = (const int*)UP(pl->bt_cell, pl->n_btouch))) return rc;
+    if (!(bt_facet = (const int*)UP(pl->bt_facet, (size_t)pl->n_btouch*dim))) return rc;
+    if (!(bt_slot = (const unsigned*)UP((const unsigned*)pl->bt_slot, pl->n_btouch))) return rc;
+    const int2 *sing_dev[3] = {nullptr, nullptr, nullptr};
+    const int *sing_pair_dev[3] = {nullptr, nullptr, nullptr};
+    for (int s = 0; s < 3; s++) {
+        const int n = pl->n_sing[s];
+        std::vector<int2> pr(n);
+        std::vector<int> pk(n);
+        for (int i = 0; i < n; i++) {
+            const int32_t *it = pl->sing_items[s]+3*(size_t)i;
+            if (it[0] < 0 || it[0] >= pl->npairs || it[1] < 0 || it[1] > it[2] || it[2] >= ctx->nc)
+                return fail(ctx, PNL_ERR_INVALID, "touching item %d of slot %d out of range", i, s);
+            pk[i] = it[0]; pr[i] = make_int2(it[1], it[2]);
+        }
+        if (!(sing_dev[s] = (const int2*)UP(pr.data(), n))) return rc;
+        if (!(sing_pair_dev[s] = (const int*)UP(pk.data(), n))) return rc;
+    }
+    // facet geometry (centre, unit normal, length, |ln(len/H0)|, ln(len)) like DevProblem::bgeo
+    int maxf = 0;
+    std::vector<double> geo((size_t)(2*dim+3)*std::max(pl->nfacets, 1), 0.);
+    for (int k = 0; k < pl->npairs; k++) maxf = std::max(maxf, pl->pair_foff[k+1]-pl->pair_foff[k]);
+    for (int f = 0; f < pl->nfacets; f++) {
+        const size_t nf = pl->nfacets;
+        double len = 1.;
+        const double *v0 = &ctx->vertices[(size_t)pl->fvid[(size_t)f*dim]*dim];
+        const double *v1 = &ctx->vertices[(size_t)pl->fvid[(size_t)f*dim+(dim-1)]*dim];
+        for (int d = 0; d < dim; d++) geo[(size_t)d*nf+f] = dim == 2 ? 0.5*(v0[d]+v1[d]) : v0[d];
+        if (dim == 2) {
+            const double n0 = v1[1]-v0[1], n1 = v0[0]-v1[0];
+            const double inv = 1./std::sqrt(n0*n0+n1*n1);
+            geo[(size_t)(dim+0)*nf+f] = n0*inv; geo[(size_t)(dim+1)*nf+f] = n1*inv;
+            const double dx = v1[0]-v0[0], dy = v1[1]-v0[1];
+            len = std::sqrt(dx*dx+dy*dy);
+        }
+        geo[(size_t)(2*dim)*nf+f] = len;
+        geo[(size_t)(2*dim+1)*nf+f] = std::fabs(std::log(len/ctx->H0));
+        geo[(size_t)(2*dim+2)*nf+f] = std::log(len);
+    }
+    const double *fgeo;
+    if (!(fgeo = (const double*)UP(geo.data(), geo.size()))) return rc;
+#undef UP
+    if ((rc = ensure(ctx, ctx->b_cpD, sizeof(double)*(size_t)std::max(pl->num_dslots, 1)*(dpe*(dpe+1)/2)))) return rc;
+    CT.D = (double*)ctx->b_cpD.p;
+    ctx->visited_pairs = 0;
+    const bool kt = ctx->P.k.fast;
+    if (dim == 2 && dpe == 3)
+        return kt ? clusters_tiled_impl<2, 3, TILE_P1, 1>(ctx, pl, CT, cluster_boundary, d_cell, d_pair, sing_dev, sing_pair_dev, pair_foff, fvid, fgeo, maxf, bt_cell, bt_facet, bt_slot)
+                  : clusters_tiled_impl<2, 3, TILE_P1, 0>(ctx, pl, CT, cluster_boundary, d_cell, d_pair, sing_dev, sing_pair_dev, pair_foff, fvid, fgeo, maxf, bt_cell, bt_facet, bt_slot);
+    if (dim == 2 && dpe == 6)
+        return kt ? clusters_tiled_impl<2, 6, TILE_P2, 1>(ctx, pl, CT, cluster_boundary, d_cell, d_pair, sing_dev, sing_pair_dev, pair_foff, fvid, fgeo, maxf, bt_cell, bt_facet, bt_slot)
+                  : clusters_tiled_impl<2, 6, TILE_P2, 0>(ctx, pl, CT, cluster_boundary, d_cell, d_pair, sing_dev, sing_pair_dev, pair_foff, fvid, fgeo, maxf, bt_cell, bt_facet, bt_slot);
+    if (dim == 1 && dpe == 2)
+        return kt ? clusters_tiled_impl<1, 2, TILE_P1, 1>(ctx, pl, CT, cluster_boundary, d_cell, d_pair, sing_dev, sing_pair_dev, pair_foff, fvid, fgeo, maxf, bt_cell, bt_facet, bt_slot)
+                  : clusters_tiled_impl<1, 2, TILE_P1, 0>(ctx, pl, CT, cluster_boundary, d_cell, d_pair, sing_dev, sing_pair_dev, pair_foff, fvid, fgeo, maxf, bt_cell, bt_facet, bt_slot);
+    return fail(ctx, PNL_ERR_UNSUPPORTED, "unsupported (dim=%d, dofs_per_element=%d)", dim, dpe);
 }
 
 int pnl_spmv(pnl_context *ctx, const double *data, const double *diag, const double *x, double *y) {

@@ -311,6 +311,72 @@ __device__ __forceinline__ void eval_distant_lds(const DevProblem &P, const doub
     }
 }
 
+// ---- sparse output (H2 near field, NA:1663-1964) -------------------------------------------------------------------
+// CSR or SSS target with the reference's addToEntry semantics (CSR_LinearOperator_{SCALAR}.pxi:150-170,
+// SSS_LinearOperator_{SCALAR}.pxi:104-130): binary search in the row, entries that are not in the pattern are dropped;
+// SSS (diag != nullptr) keeps I > J in data and the diagonal in its own vector.
+struct SparseOut {
+    const int *indptr, *indices;
+    double *data, *diag;
+    const int *pairs;                    // [np][2] cell pairs, c1 <= c2
+    const unsigned long long *masks;     // [np][4] requested entries of the symmetric local matrix (256-bit MASK_t)
+};
+
+__device__ __forceinline__ void sparse_add(const SparseOut &S, int I, int J, double v) {
+    if (I < 0 || J < 0) return;
+    if (S.diag) {
+        if (I == J) { atomic_add_f64(&S.diag[I], v); return; }
+        if (I < J) return;
+    }
+    int lo = S.indptr[I];
+    const int end = S.indptr[I+1];
+    int hi = end;
+    while (lo < hi) {
+        const int mid = (lo+hi) >> 1;
+        if (S.indices[mid] < J) lo = mid+1; else hi = mid;
+    }
+    if (lo < end && S.indices[lo] == J) atomic_add_f64(&S.data[lo], v);
+}
+
+
+// ---- tiled near-field assembly (clusters.nearFieldPlan): cluster-pair tiles, node membership ---------------------------
+struct ClusterTiles {
+    const int *chunkA, *chunkB, *pair, *flags;      // [ntiles]; flags bit 0: n1 == n2 (unordered pairs once, both S parts)
+    const int *dslotA, *dslotB;                     // [ntiles][64]: slot of the cell in the diagonal-block buffer D or -1
+    const int *chunk_cells;                         // [nchunks][64], -1 = padding
+    const int *chunk_ndof;                          // [nchunks]
+    const int *chunk_dofs;                          // [nchunks][chunk_stride] DoFs of the chunk that belong to its node
+    const short *chunk_slot;                        // [nchunks][dpe][64] slot in chunk_dofs or -1
+    int chunk_stride, npairs;
+    double *D;                                      // [num_dslots][dpe(dpe+1)/2]
+    const int *pair_nodes;                          // [npairs][2]
+    const int *node_off, *node_dofs;                // sorted DoFs of every node
+    int2 *wl_ds;                                    // [wl_cap] diagonal-block slots of the work-list entries (-1: not wanted)
+    int *wl_pair;                                   // [wl_cap] cluster pair of the work-list entries
+    const int *sing_pair;                           // cluster pair of the touching element pairs of the current launch
+    SparseOut S;                                    // the near-field matrix
+};
+
+__device__ __forceinline__ bool in_node(const ClusterTiles &CT, int node, int I) {
+    int lo = CT.node_off[node];
+    const int end = CT.node_off[node+1];
+    int hi = end;
+    while (lo < hi) {
+        const int mid = (lo+hi) >> 1;
+        if (CT.node_dofs[mid] < I) lo = mid+1; else hi = mid;
+    }
+    return lo < end && CT.node_dofs[lo] == I;
+}
+
+// does the DoF pair {I, J} belong to the cluster pair k = {n1, n2}: (I in n1, J in n2) or (I in n2, J in n1)
+__device__ __forceinline__ bool pair_has(const ClusterTiles &CT, int k, int I, int J) {
+    if (I < 0 || J < 0) return false;
+    const int n1 = CT.pair_nodes[2*k], n2 = CT.pair_nodes[2*k+1];
+    if (in_node(CT, n1, I) && in_node(CT, n2, J)) return true;
+    if (n1 == n2) return false;
+    return in_node(CT, n2, I) && in_node(CT, n1, J);
+}
+
 // ---------------------------------------------------------------------------------------------
 // Tile kernel: classification (NO:280-378 vertex test, NO:493-540 + FL2:622-642 order) and distant
 // evaluation for one TILE x TILE block of cell pairs.
@@ -349,7 +415,9 @@ struct TileSmem {
     static constexpr int o_ttn = o_lh+4*TILE;          // [PNL_MAXQ+2] points of order q if the tile kernel integrates it, else 0
     static constexpr int o_tto = o_ttn+PNL_MAXQ+2;         // [PNL_MAXQ+2] its offset (points) in the table blob
     static constexpr int o_chunk = o_tto+PNL_MAXQ+2;       // [PNL_GEN_MAXCHUNKS] list C chunks: order << 20 | start << 7 | count-1
-    static constexpr int n_int = o_chunk+PNL_GEN_MAXCHUNKS;
+    static constexpr int o_dslot = o_chunk+PNL_GEN_MAXCHUNKS;   // [2][TILE] cluster tiles
+    static constexpr int o_cell = o_dslot+2*TILE;          // [2][TILE]
+    static constexpr int n_int = o_cell+2*TILE;
     // shorts after the ints
     static constexpr int o_slot = 0;                       // [2][DPE][TILE]
     static constexpr int o_list = o_slot+2*DPE*TILE;       // [TILE*TILE] 16 bit: list A from the front, list C from the back;
@@ -390,11 +458,11 @@ __device__ __forceinline__ bool tile_eligible(int n) { return n == 2 || n == 3 |
 #ifndef PNL_TILE_WAVES
 #define PNL_TILE_WAVES 2      // waves per SIMD the tile kernel is register-limited to (measured: 2 beats 3 and 4)
 #endif
-template <int DIM, int DPE, int TILE, int KT>
+template <int DIM, int DPE, int TILE, int KT, bool CLUSTER>
 __global__ void __launch_bounds__(PNL_NTHREADS, PNL_TILE_WAVES)
 k_tile_distant(const DevProblem P, const int2 *__restrict__ tiles, double *__restrict__ A, long long ldA,
                double *__restrict__ Dglob, int cell_begin, int cell_end, int acc_stride, int4 *__restrict__ worklist,
-               unsigned *__restrict__ wl_count, unsigned wl_cap, int ablate, int ntiles) {
+               unsigned *__restrict__ wl_count, unsigned wl_cap, int ablate, int ntiles, const ClusterTiles CT) {
     using S = TileSmem<DIM, DPE, TILE>;
     constexpr int NV = S::NV, NC = S::NC, ND = S::ND;
     constexpr int PAIRS = TILE*TILE, PER_THREAD = PAIRS/PNL_NTHREADS;
@@ -413,6 +481,7 @@ k_tile_distant(const DevProblem P, const int2 *__restrict__ tiles, double *__res
 
     const int tid = threadIdx.x;
     int *s_chunk = s_int+S::o_chunk;
+    int *s_dslot = s_int+S::o_dslot, *s_cell = s_int+S::o_cell;     // cluster tiles: D slots and cell ids of both sides
     // statistics of order q = 2 + tid (+256) are kept in registers over all tiles of this workgroup: hot counters
     // see one atomic per workgroup, not one per tile
     unsigned long long st_cnt[(PNL_MAXQ+PNL_NTHREADS)/PNL_NTHREADS] = {0}, st_ev[(PNL_MAXQ+PNL_NTHREADS)/PNL_NTHREADS] = {0};
@@ -422,14 +491,21 @@ k_tile_distant(const DevProblem P, const int2 *__restrict__ tiles, double *__res
     // persistent workgroups: each one walks the tile list with stride gridDim.x (heavy tiles come first in the list)
 #pragma unroll 1
     for (int tile_idx = blockIdx.x; tile_idx < ntiles; tile_idx += gridDim.x) {
-    const int2 tl = tiles[tile_idx];
-    const int ta = tl.x, tb = tl.y;
-    const int nA = P.blk_ndof[ta], nB = P.blk_ndof[tb];
+    // dense: (block a, block b) of consecutive cells; cluster tiles: (chunk of n1.cells, chunk of n2.cells) of a cluster pair
+    const int ta = CLUSTER ? CT.chunkA[tile_idx] : tiles[tile_idx].x, tb = CLUSTER ? CT.chunkB[tile_idx] : tiles[tile_idx].y;
+    const int nA = CLUSTER ? CT.chunk_ndof[ta] : P.blk_ndof[ta], nB = CLUSTER ? CT.chunk_ndof[tb] : P.blk_ndof[tb];
+    const bool sym = CLUSTER ? (CT.flags[tile_idx] & 1) != 0 : true;
 
     // ---- stage cell data of both blocks in LDS (SoA: conflict-free per-lane reads) -------------
     for (int t = tid; t < 2*TILE; t += PNL_NTHREADS) {
         const int side = t/TILE, l = t%TILE;
-        const int c = (side ? tb : ta)*TILE+l;
+        const int craw = CLUSTER ? CT.chunk_cells[(size_t)(side ? tb : ta)*TILE+l] : (side ? tb : ta)*TILE+l;
+        const bool real = craw >= 0;
+        const int c = real ? craw : 0;
+        if (CLUSTER) {
+            s_cell[side*TILE+l] = craw;
+            s_dslot[side*TILE+l] = (side ? CT.dslotB : CT.dslotA)[(size_t)tile_idx*TILE+l];
+        }
 #pragma unroll
         for (int k = 0; k < NC; k++) s_v[(side*NC+k)*TILE+l] = P.cellv[(size_t)k*P.ncp+c];
 #pragma unroll
@@ -442,11 +518,11 @@ k_tile_distant(const DevProblem P, const int2 *__restrict__ tiles, double *__res
         s_lh[(side*2+0)*TILE+l] = (float)lh;
         s_lh[(side*2+1)*TILE+l] = (float)Ld;
 #pragma unroll
-        for (int k = 0; k < NV; k++) s_vid[(side*NV+k)*TILE+l] = P.cvid[(size_t)k*P.ncp+c];
+        for (int k = 0; k < NV; k++) s_vid[(side*NV+k)*TILE+l] = real ? P.cvid[(size_t)k*P.ncp+c] : -1-k;
 #pragma unroll
         for (int k = 0; k < DPE; k++) {
             // boundary DoFs (no slot) are sent to a trash row / column of the LDS sub-block: no branches in the hot loop
-            const short sl = P.cslot[(size_t)k*P.ncp+c];
+            const short sl = CLUSTER ? (real ? CT.chunk_slot[((size_t)(side ? tb : ta)*DPE+k)*TILE+l] : (short)-1) : P.cslot[(size_t)k*P.ncp+c];
             s_slot[(side*DPE+k)*TILE+l] = sl >= 0 ? sl : (short)(side ? nB : nA);
         }
     }
@@ -474,9 +550,13 @@ k_tile_distant(const DevProblem P, const int2 *__restrict__ tiles, double *__res
         int q = 0;
         const int va0 = s_vid[(0*NV+0)*TILE+i], vb0 = s_vid[(1*NV+0)*TILE+j];
         const int ca = ta*TILE+i;
-        bool ok = (va0 >= 0) && (vb0 >= 0) && (ta < tb || i < j) && (ca >= cell_begin) && (ca < cell_end) && !(ablate & 8);
+        // dense: upper triangle of the cell pairs, a-cells of the caller's range.  Cluster tiles: n1 == n2 -> unordered pairs
+        // once (chunk pair a <= b); n1 != n2 -> every ordered pair (X in n1.cells, Y in n2.cells); identical cells share all
+        // vertices and are left to the touching-pair lists like every other touching pair
+        bool ok = (va0 >= 0) && (vb0 >= 0) && !(ablate & 8) &&
+                  (CLUSTER ? (!sym || ta < tb || i < j) : ((ta < tb || i < j) && (ca >= cell_begin) && (ca < cell_end)));
         // variable order: this launch assembles the pairs of one order class only
-        if (P.cur_class >= 0 && ok) ok = P.cls_of[P.clabel[ca]*P.nlab+P.clabel[tb*TILE+j]] == P.cur_class;
+        if (!CLUSTER && P.cur_class >= 0 && ok) ok = P.cls_of[P.clabel[ca]*P.nlab+P.clabel[tb*TILE+j]] == P.cur_class;
         if (ok) {
             // NA:138-150: skip pairs with boundary DoFs only;  NO:311-323: shared vertices -> singular pair
             bool any_dof = false, shared = false;
@@ -551,7 +631,15 @@ k_tile_distant(const DevProblem P, const int2 *__restrict__ tiles, double *__res
                 const int p = ent & 4095, q = ent >> 12;
                 const int j = p%TILE, i = (p/TILE+PNL_DIAG_MULT*j)%TILE;
                 const int off = P.off[q];
-                if (base+t < wl_cap) worklist[base+t] = make_int4(ta*TILE+i, tb*TILE+j, off, (P.off[q+1]-off) | (q << 16));
+                if (base+t < wl_cap) {
+                    if (CLUSTER) {
+                        worklist[base+t] = make_int4(s_cell[i], s_cell[TILE+j], (int)(base+t), (P.off[q+1]-off) | (q << 16));
+                        const int dA = s_dslot[i], dB = s_dslot[TILE+j];
+                        CT.wl_ds[base+t] = make_int2(dA, (dB >= 0 && (sym || dA < 0)) ? dB : -1);
+                        CT.wl_pair[base+t] = CT.pair[tile_idx];
+                    } else
+                        worklist[base+t] = make_int4(ta*TILE+i, tb*TILE+j, off, (P.off[q+1]-off) | (q << 16));
+                }
             }
         }
     }
@@ -598,7 +686,12 @@ k_tile_distant(const DevProblem P, const int2 *__restrict__ tiles, double *__res
             }
 #pragma unroll
             for (int b = a; b < DPE; b++) {
-                if (!(ablate & 64)) {
+                if (CLUSTER) {
+                    // X's diagonal block if X is in cellsInter; Y's if Y is and the pair (Y, X) is not enumerated itself
+                    const int dA = s_dslot[i], dB = s_dslot[TILE+j];
+                    if (dA >= 0) lds_add_f64(&s_D[(0*TILE+i)*ND+e], vv*R.S1[e]);
+                    if (dB >= 0 && (sym || dA < 0)) lds_add_f64(&s_D[(1*TILE+j)*ND+e], vv*R.S2[e]);
+                } else if (!(ablate & 64)) {
                     lds_add_f64(&s_D[(0*TILE+i)*ND+e], vv*R.S1[e]);
                     lds_add_f64(&s_D[(1*TILE+j)*ND+e], vv*R.S2[e]);
                 } else if (R.S1[e]+R.S2[e] == 1.2345e300) s_D[0] = 1.;
@@ -671,20 +764,32 @@ k_tile_distant(const DevProblem P, const int2 *__restrict__ tiles, double *__res
     __syncthreads();
 
     // ---- flush: sub-block of A' (rows = DoFs of block a, cols = DoFs of block b) and diagonal blocks ----
-    const int *__restrict__ dofA = P.blk_dofs+(size_t)ta*P.blk_stride;
-    const int *__restrict__ dofB = P.blk_dofs+(size_t)tb*P.blk_stride;
+    const int *__restrict__ dofA = CLUSTER ? CT.chunk_dofs+(size_t)ta*CT.chunk_stride : P.blk_dofs+(size_t)ta*P.blk_stride;
+    const int *__restrict__ dofB = CLUSTER ? CT.chunk_dofs+(size_t)tb*CT.chunk_stride : P.blk_dofs+(size_t)tb*P.blk_stride;
     if (!(ablate & 4)) {
     for (int t = tid; t < nA*nB; t += PNL_NTHREADS) {
         const int r = t/nB, c = t-r*nB;
         const double v = s_acc[r*acc_stride+c];
-        if (v != 0.) atomic_add_f64(&A[(long long)dofA[r]*ldA+dofB[c]], v);
+        if (v != 0.) {
+            if (CLUSTER) {
+                // entry (I in n1, J in n2) of the near-field matrix and its mirror image (SSS keeps the one with I > J, a
+                // rank-local CSR the ones of its own blocks: addToEntry semantics)
+                sparse_add(CT.S, dofA[r], dofB[c], v);
+                sparse_add(CT.S, dofB[c], dofA[r], v);
+            } else atomic_add_f64(&A[(long long)dofA[r]*ldA+dofB[c]], v);
+        }
     }
     for (int t = tid; t < 2*TILE*ND; t += PNL_NTHREADS) {
         const double v = s_D[t];
         if (v != 0.) {
             const int side = t/(TILE*ND), rem = t-side*TILE*ND;
-            const int c = (side ? tb : ta)*TILE+rem/ND;
-            atomic_add_f64(&Dglob[(size_t)c*ND+rem%ND], v);
+            if (CLUSTER) {
+                const int ds = s_dslot[side*TILE+rem/ND];
+                if (ds >= 0) atomic_add_f64(&CT.D[(size_t)ds*ND+rem%ND], v);
+            } else {
+                const int c = (side ? tb : ta)*TILE+rem/ND;
+                atomic_add_f64(&Dglob[(size_t)c*ND+rem%ND], v);
+            }
         }
     }
     }
@@ -1456,33 +1561,6 @@ __device__ __forceinline__ unsigned eval_distant_cut(const DevProblem &P, const 
     return nevals;
 }
 
-// ---- sparse output (H2 near field, NA:1663-1964) -------------------------------------------------------------------
-// CSR or SSS target with the reference's addToEntry semantics (CSR_LinearOperator_{SCALAR}.pxi:150-170,
-// SSS_LinearOperator_{SCALAR}.pxi:104-130): binary search in the row, entries that are not in the pattern are dropped;
-// SSS (diag != nullptr) keeps I > J in data and the diagonal in its own vector.
-struct SparseOut {
-    const int *indptr, *indices;
-    double *data, *diag;
-    const int *pairs;                    // [np][2] cell pairs, c1 <= c2
-    const unsigned long long *masks;     // [np][4] requested entries of the symmetric local matrix (256-bit MASK_t)
-};
-
-__device__ __forceinline__ void sparse_add(const SparseOut &S, int I, int J, double v) {
-    if (I < 0 || J < 0) return;
-    if (S.diag) {
-        if (I == J) { atomic_add_f64(&S.diag[I], v); return; }
-        if (I < J) return;
-    }
-    int lo = S.indptr[I];
-    const int end = S.indptr[I+1];
-    int hi = end;
-    while (lo < hi) {
-        const int mid = (lo+hi) >> 1;
-        if (S.indices[mid] < J) lo = mid+1; else hi = mid;
-    }
-    if (lo < end && S.indices[lo] == J) atomic_add_f64(&S.data[lo], v);
-}
-
 // NA:503-520 addToMatrixElemElemSymMasked for one entry (p <= q) of the local matrix over 2*dpe local DoFs
 __device__ __forceinline__ void sparse_add_sym(const SparseOut &S, const unsigned long long *mask, int n2, int p, int q, int I, int J,
                                                double v) {
@@ -1597,7 +1675,8 @@ template <int DIM, int DPE, int KT, bool SPARSE>
 __global__ void __launch_bounds__(PNL_NTHREADS)
 k_worklist_sorted(const DevProblem P, const int4 *__restrict__ sorted, const unsigned *__restrict__ offs,
                   const unsigned *__restrict__ chunk_off, double *__restrict__ A, long long ldA, double *__restrict__ Dglob,
-                  int tab_max_pts, const SparseOut S, int qlast, int nmin) {
+                  int tab_max_pts, const SparseOut S, int qlast, int nmin, const ClusterTiles CT) {
+    const bool cluster = CT.npairs > 0;          // work list of the cluster tiles: entry.z indexes wl_pair / wl_ds
     constexpr int NV = DIM+1, NC = NV*DIM, ND = DPE*(DPE+1)/2, NG = DPE*DPE, NACC = NG+2*ND, LPP = 16, PPC = PNL_NTHREADS/LPP, NREP = (NACC+LPP-1)/LPP, ST = 4+DPE;   // LPP lanes per pair
     extern __shared__ double s_rule[];           // [tab_max_pts][ST]: bary[3], w, phi[DPE]
     __shared__ unsigned s_coff[PNL_WL_BINS+1];
@@ -1627,7 +1706,7 @@ k_worklist_sorted(const DevProblem P, const int4 *__restrict__ sorted, const uns
         const unsigned first = offs[q]+(unsigned)PPC*(chunk-s_coff[q]);
         const int cnt = (int)min((unsigned)PPC, offs[q+1]-first);
         const int4 e0 = sorted[first];
-        const int off = e0.z, n = e0.w & 0xffff, nn = n*n;
+        const int n = e0.w & 0xffff, nn = n*n, off = P.off[q];
         const bool in_lds = n <= tab_max_pts;
         if (q != staged_q) {
             __syncthreads();
@@ -1733,7 +1812,22 @@ k_worklist_sorted(const DevProblem P, const int4 *__restrict__ sorted, const uns
             const double s = row16_sum(acc[e]);
             mine[e/LPP] = (sub == (e & (LPP-1))) ? s : mine[e/LPP];
         }
-        if (valid && SPARSE) {
+        if (valid && cluster) {
+            const double vv = 2.*P.cvol[c1]*P.cvol[c2]*kern_scale<KT>(P.k);
+            const int k = CT.wl_pair[ent.z], n1 = CT.pair_nodes[2*k], n2 = CT.pair_nodes[2*k+1];
+            const int2 ds = CT.wl_ds[ent.z];
+#pragma unroll
+            for (int rep = 0; rep < NREP; rep++) {
+                const int e = sub+LPP*rep;
+                const double val = mine[rep];
+                if (e < NG) {
+                    const int a = e/DPE, b = e-a*DPE;
+                    const int I = P.cdof[(size_t)a*P.ncp+c1], J = P.cdof[(size_t)b*P.ncp+c2];
+                    if (I >= 0 && J >= 0 && in_node(CT, n1, I) && in_node(CT, n2, J)) { sparse_add(CT.S, I, J, -vv*val); sparse_add(CT.S, J, I, -vv*val); }
+                } else if (e < NG+ND) { if (ds.x >= 0) atomic_add_f64(&CT.D[(size_t)ds.x*ND+(e-NG)], vv*val); }
+                else if (e < NACC) { if (ds.y >= 0) atomic_add_f64(&CT.D[(size_t)ds.y*ND+(e-NG-ND)], vv*val); }
+            }
+        } else if (valid && SPARSE) {
             const double vv = 2.*P.cvol[c1]*P.cvol[c2]*kern_scale<KT>(P.k);
             const unsigned long long *mask = S.masks+4*(size_t)ent.x;
 #pragma unroll
@@ -1753,7 +1847,7 @@ k_worklist_sorted(const DevProblem P, const int4 *__restrict__ sorted, const uns
                 }
             }
         }
-        if (valid && !SPARSE) {
+        if (valid && !SPARSE && !cluster) {
             const double vv = 2.*P.cvol[c1]*P.cvol[c2]*kern_scale<KT>(P.k);
 #pragma unroll
             for (int rep = 0; rep < NREP; rep++) {
@@ -1778,7 +1872,8 @@ k_worklist_sorted(const DevProblem P, const int4 *__restrict__ sorted, const uns
 template <int DIM, int DPE, int KT, bool SPARSE>
 __global__ void __launch_bounds__(PNL_NTHREADS)
 k_worklist_lane(const DevProblem P, const int4 *__restrict__ sorted, const unsigned *__restrict__ offs, double *__restrict__ A,
-                long long ldA, double *__restrict__ Dglob, const SparseOut S, int dbg) {
+                long long ldA, double *__restrict__ Dglob, const SparseOut S, int dbg, const ClusterTiles CT) {
+    const bool cluster = CT.npairs > 0;             // work list of the cluster tiles: entry.z indexes wl_pair / wl_ds
     constexpr int NV = DIM+1, NC = NV*DIM, ND = DPE*(DPE+1)/2, ST = 4+DPE, STP = (ST+1) & ~1;
     __shared__ unsigned s_coff[PNL_WL_BINS+1];
     __shared__ double s_rule_all[PNL_NTHREADS/64][PNL_WL_LANE_MAXPTS*STP];
@@ -1841,7 +1936,23 @@ k_worklist_lane(const DevProblem P, const int4 *__restrict__ sorted, const unsig
         int ld1[DPE], ld2[DPE];
 #pragma unroll
         for (int a = 0; a < DPE; a++) { ld1[a] = P.cdof[(size_t)a*P.ncp+c1]; ld2[a] = P.cdof[(size_t)a*P.ncp+c2]; }
-        if (SPARSE) {
+        if (cluster) {
+            const int k = CT.wl_pair[ent.z], n1 = CT.pair_nodes[2*k], n2 = CT.pair_nodes[2*k+1];
+            const int2 ds = CT.wl_ds[ent.z];
+            bool in1[DPE], in2[DPE];
+#pragma unroll
+            for (int a = 0; a < DPE; a++) { in1[a] = ld1[a] >= 0 && in_node(CT, n1, ld1[a]); in2[a] = ld2[a] >= 0 && in_node(CT, n2, ld2[a]); }
+#pragma unroll
+            for (int a = 0; a < DPE; a++)
+#pragma unroll
+                for (int b = 0; b < DPE; b++)
+                    if (in1[a] && in2[b]) { sparse_add(CT.S, ld1[a], ld2[b], -vv*R.G[a][b]); sparse_add(CT.S, ld2[b], ld1[a], -vv*R.G[a][b]); }
+#pragma unroll
+            for (int e = 0; e < ND; e++) {
+                if (ds.x >= 0) atomic_add_f64(&CT.D[(size_t)ds.x*ND+e], vv*R.S1[e]);
+                if (ds.y >= 0) atomic_add_f64(&CT.D[(size_t)ds.y*ND+e], vv*R.S2[e]);
+            }
+        } else if (SPARSE) {
             const unsigned long long *mask = S.masks+4*(size_t)ent.x;
             int e = 0;
 #pragma unroll
@@ -1892,7 +2003,8 @@ template <int DIM, int DPE, int SLOT, int KT, bool STAGE, bool SPARSE>
 __global__ void __launch_bounds__(PNL_SING_THREADS)
 k_singular_pairs(const DevProblem P, const int2 *__restrict__ pairs, int npairs_in, double *__restrict__ A, long long ldA,
                  int cell_begin, int cell_end, const SparseOut S, const int4 *__restrict__ sorted,
-                 const unsigned *__restrict__ offs) {
+                 const unsigned *__restrict__ offs, const ClusterTiles CT) {
+    const bool cluster = CT.npairs > 0;          // touching element pairs of cluster pairs: pairs[wid] with cluster pair CT.sing_pair[wid]
     constexpr int NV = DIM+1;
     constexpr int DPV = 1, DPED = (DIM == 2 && DPE == 6) ? 1 : 0;
     constexpr int COMMON = SLOT+1;
@@ -2047,7 +2159,13 @@ k_singular_pairs(const DevProblem P, const int2 *__restrict__ pairs, int npairs_
             gj = (myJ[rep] == k) ? g : gj;
         }
         const double v = mine[rep]*vol;
-        if (SPARSE) {
+        if (cluster) {
+            // the DoF pair {gi, gj} gets the entry if it belongs to the cluster pair (what is left of the masks)
+            if (pair_has(CT, CT.sing_pair[wid], gi, gj)) {
+                if (gi == gj) sparse_add(CT.S, gi, gi, v);
+                else { sparse_add(CT.S, gi, gj, v); sparse_add(CT.S, gj, gi, v); }
+            }
+        } else if (SPARSE) {
             // local indices of the merged rows (FL2:874-884): p = perm[I], q = perm[J], entry (min, max)
             int pi = 0, pj = 0;
 #pragma unroll
@@ -2390,7 +2508,8 @@ __global__ void k_mp_stats(const DevProblem P, const unsigned *__restrict__ hist
 template <int DIM, int DPE, int KT>
 __global__ void __launch_bounds__(PNL_NTHREADS)
 k_boundary_items(const DevProblem P, const double *__restrict__ verts, const int *__restrict__ cells,
-                 const int *__restrict__ facets, const unsigned *__restrict__ masks, int ni, double fac, const SparseOut S) {
+                 const int *__restrict__ facets, const unsigned *__restrict__ masks, int ni, double fac, const SparseOut S,
+                 double *__restrict__ Dout) {
     constexpr int NV = DIM+1, NF = DIM, ND = DPE*(DPE+1)/2;
     const int lane = threadIdx.x & 63;
     const int nwaves = gridDim.x*(PNL_NTHREADS/64);
@@ -2566,7 +2685,8 @@ k_boundary_items(const DevProblem P, const double *__restrict__ verts, const int
             for (int k = 0; k < DPE; k++) { i = (myI == k) ? perm[k] : i; j = (myJ == k) ? perm[k] : j; }
             const int lo = min(i, j), hi = max(i, j);
             const int kk = DPE*lo-(lo*(lo+1) >> 1)+hi;
-            if ((mask >> kk) & 1u) {
+            if (Dout) atomic_add_f64(&Dout[(size_t)mask*ND+kk], fac*vol*mine);      // tiled near field: masks[] = slot in D
+            else if ((mask >> kk) & 1u) {
                 const int I = P.cdof[(size_t)lo*P.ncp+c1], J = P.cdof[(size_t)hi*P.ncp+c1];
                 const double v = fac*vol*mine;
                 if (lo == hi) sparse_add(S, I, I, v);
@@ -2602,4 +2722,127 @@ k_spmv(const int *__restrict__ indptr, const int *__restrict__ indices, const do
         if (diag) atomic_add_f64(&y[row], __builtin_fma(diag[row], xi, s));
         else y[row] = s;
     }
+}
+
+// ---- tiled near field: scatter of the per-(cluster pair, cell) diagonal blocks -----------------------------------------
+// D[d][.] of cell X = d_cell[d] in cluster pair d_pair[d]: every ordered local pair (p, q) goes to (I, J) = (ld[p], ld[q]) if
+// the DoF pair belongs to the cluster pair (mirror images are their own ordered pairs; SSS keeps I >= J)
+template <int DPE>
+__global__ void __launch_bounds__(PNL_NTHREADS)
+k_cluster_scatter_diag(const DevProblem P, const ClusterTiles CT, const int *__restrict__ d_cell, const int *__restrict__ d_pair, int nd) {
+    constexpr int ND = DPE*(DPE+1)/2;
+    const long long t = (long long)blockIdx.x*PNL_NTHREADS+threadIdx.x;
+    const int d = (int)(t/(DPE*DPE));
+    if (d >= nd) return;
+    const int ab = (int)(t-(long long)d*DPE*DPE), a = ab/DPE, b = ab-a*DPE;
+    const int lo = min(a, b), hi = max(a, b);
+    const double v = CT.D[(size_t)d*ND+DPE*lo-(lo*(lo+1) >> 1)+hi];
+    if (v == 0.) return;
+    const int c = d_cell[d];
+    const int I = P.cdof[(size_t)a*P.ncp+c], J = P.cdof[(size_t)b*P.ncp+c];
+    if (pair_has(CT, d_pair[d], I, J)) sparse_add(CT.S, I, J, v);
+}
+
+// Cluster-local Gauss-theorem term (NA:1842-1889), distant (cell, facet) pairs: thread per diagonal-block slot d (cell
+// d_cell[d] of cluster pair d_pair[d]), loop over a chunk of the facets of the boundary of the pair's cellsUnion
+// (pair_foff, facet vertex ids fvid and precomputed geometry fgeo like DevProblem::bgeo).  Same evaluation as
+// k_boundary_distant (NO:1022-1108, order FL2:1226-1243 / FL1:646-660).
+template <int DIM, int DPE, int KT>
+__global__ void __launch_bounds__(PNL_NTHREADS)
+k_cluster_boundary(const DevProblem P, const double *__restrict__ verts, const int *__restrict__ d_cell, const int *__restrict__ d_pair,
+                   int nd, const int *__restrict__ pair_foff, const int *__restrict__ fvid, const double *__restrict__ fgeo, int nftot,
+                   double *__restrict__ D, int facets_per_chunk) {
+    constexpr int NV = DIM+1, NC = NV*DIM, NF = DIM, ND = DPE*(DPE+1)/2;
+    const int d = blockIdx.x*PNL_NTHREADS+threadIdx.x;
+    if (d >= nd) return;
+    const int cc = d_cell[d], k = d_pair[d];
+    const int f0 = pair_foff[k]+blockIdx.y*facets_per_chunk, f1 = min(pair_foff[k+1], f0+facets_per_chunk);
+    if (f0 >= f1) return;
+    double av[NC], cen[DIM];
+    int vid[NV];
+#pragma unroll
+    for (int m = 0; m < NC; m++) av[m] = P.cellv[(size_t)m*P.ncp+cc];
+#pragma unroll
+    for (int dd = 0; dd < DIM; dd++) cen[dd] = P.ccen[(size_t)dd*P.ncp+cc];
+#pragma unroll
+    for (int m = 0; m < NV; m++) vid[m] = P.cvid[(size_t)m*P.ncp+cc];
+    const double h1 = P.ch[cc], vol1 = P.cvol[cc];
+    const double Ld1 = P.clog[(size_t)P.ncp+cc];
+    const float lh1 = (float)P.clog[cc], L1 = (float)Ld1;
+    double Dl[ND];
+#pragma unroll
+    for (int e = 0; e < ND; e++) Dl[e] = 0.;
+    unsigned long long npairs = 0, nevals = 0;
+    int overflow = 0;
+    for (int f = f0; f < f1; f++) {
+        double fv[NF*DIM], fc[DIM], nrm[DIM];
+        int fvd[NF];
+        bool shared = false;
+#pragma unroll
+        for (int m = 0; m < NF; m++) {
+            fvd[m] = fvid[(size_t)f*NF+m];
+#pragma unroll
+            for (int dd = 0; dd < DIM; dd++) fv[m*DIM+dd] = verts[(size_t)fvd[m]*DIM+dd];
+#pragma unroll
+            for (int kk = 0; kk < NV; kk++) shared = shared || (vid[kk] == fvd[m]);
+        }
+        if (shared) continue;                       // touching (cell, facet) pairs come as explicit items
+#pragma unroll
+        for (int dd = 0; dd < DIM; dd++) { fc[dd] = fgeo[(size_t)dd*nftot+f]; nrm[dd] = fgeo[(size_t)(DIM+dd)*nftot+f]; }
+        const double vol2 = fgeo[(size_t)(2*DIM)*nftot+f], Ld2 = fgeo[(size_t)(2*DIM+1)*nftot+f];
+        const float lh2 = (float)fgeo[(size_t)(2*DIM+2)*nftot+f], L2 = (float)Ld2;
+        double dc2 = 0.;
+#pragma unroll
+        for (int dd = 0; dd < DIM; dd++) dc2 += (cen[dd]-fc[dd])*(cen[dd]-fc[dd]);
+        const int q = quad_order_fast(P.bqo, h1, vol2, lh1, lh2, L1, L2, Ld1, Ld2, dc2);
+        if (q > P.qmax || q > PNL_MAXQ) { overflow++; continue; }
+        const int off = P.off[q], n = P.off[q+1]-off;
+        const int foff = P.foff[q], nf = P.foff[q+1]-foff;
+        const double *__restrict__ bary = P.bary+3*(size_t)off;
+        const double *__restrict__ w = P.w+off;
+        const double *__restrict__ phi = P.phi+(size_t)off*DPE;
+        const double *__restrict__ fb = P.fbary+2*(size_t)foff;
+        const double *__restrict__ fw = P.fw+foff;
+        npairs++;
+        nevals += (unsigned long long)n*nf;
+        const double vol = vol1*vol2*kern_scale<KT>(P.bkn);
+        for (int i = 0; i < n; i++) {
+            double x[DIM];
+#pragma unroll
+            for (int dd = 0; dd < DIM; dd++) {
+                double s = 0.;
+#pragma unroll
+                for (int m = 0; m < NV; m++) s = __builtin_fma(bary[3*i+m], av[m*DIM+dd], s);
+                x[dd] = s;
+            }
+            double r = 0.;
+            for (int m = 0; m < nf; m++) {
+                double d2 = 0., nw = 0.;
+#pragma unroll
+                for (int dd = 0; dd < DIM; dd++) {
+                    double y = 0.;
+#pragma unroll
+                    for (int t = 0; t < NF; t++) y = __builtin_fma(fb[2*m+t], fv[t*DIM+dd], y);
+                    const double wv = y-x[dd];
+                    d2 = __builtin_fma(wv, wv, d2);
+                    if (DIM == 2) nw = __builtin_fma(nrm[dd], wv, nw);
+                }
+                if (DIM != 2) nw = 1.;
+                r = __builtin_fma(fw[m]*nw, kern_eval<KT>(P.bkn, d2), r);
+            }
+            r *= w[i]*vol;
+            int e = 0;
+#pragma unroll
+            for (int a = 0; a < DPE; a++) {
+                const double pa = phi[i*DPE+a]*r;
+#pragma unroll
+                for (int b = a; b < DPE; b++) { Dl[e] = __builtin_fma(pa, phi[i*DPE+b], Dl[e]); e++; }
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < ND; e++)
+        if (Dl[e] != 0.) atomic_add_f64(&D[(size_t)d*ND+e], Dl[e]);
+    if (overflow) atomicAdd(&P.counters[5], (unsigned long long)overflow);
+    if (npairs) { atomicAdd(&P.counters[3], npairs); atomicAdd(&P.counters[4], nevals); }
 }

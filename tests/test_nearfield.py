@@ -130,7 +130,10 @@ def test_oracle_row_sharded_near_field_sums_to_full(zeroExterior):
 
 
 # ---- GPU -------------------------------------------------------------------------------------------------------------
-def _gpu_builder(noRef, s, element='P1', zeroExterior=True, domain='disc', params=None):
+def _gpu_builder(noRef, s, element='P1', zeroExterior=True, domain='disc', params=None, mode=None):
+    params = dict(params or {})
+    if mode is not None:
+        params['nearFieldAssembly'] = mode
     from pynucleus_amd import disc, interval, PHYSICAL, dofmapFactory, getFractionalKernel
     from pynucleus_amd.builder import nonlocalBuilder
     mesh = disc(noRef) if domain == 'disc' else interval(noRef)
@@ -147,6 +150,10 @@ def _gpu_vs_oracle(builder, Pnear, symmetric=True, tol=1e-11, counters=True):
     if symmetric:
         assert np.abs(Anear.diagonal-diag).max() <= tol*scale
     got = Anear.info['counters']
+    if Anear.info.get('mode') == 'tiles':
+        # the tiled decomposition visits ordered element pairs per cluster pair: its counts are its own
+        assert got['numAssembledCellPairs'] >= cnt['numAssembledCellPairs']
+        return Anear, _to_dense(builder.dm.num_dofs, indptr, indices, data, diag)
     for k in ('numCellPairs', 'numAssembledCellPairs'):
         # chunked assembly visits an element pair once per chunk that requests entries of it (like NA:1786-1791)
         assert (got[k] == cnt[k]) if counters else (got[k] >= cnt[k]), (k, got[k], cnt[k])
@@ -154,10 +161,14 @@ def _gpu_vs_oracle(builder, Pnear, symmetric=True, tol=1e-11, counters=True):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('noRef,s,element,symmetric', [(3, 0.75, 'P1', True), (3, 0.5, 'P1', False), (2, 0.25, 'P2', True)])
-def test_gpu_near_field_vs_oracle(noRef, s, element, symmetric):
+@pytest.mark.parametrize('mode', ['tiles', 'masks'])
+@pytest.mark.parametrize('noRef,s,element,symmetric', [(3, 0.75, 'P1', True), (3, 0.5, 'P1', False), (2, 0.25, 'P2', True),
+                                                       (4, 0.5, 'P1', True)])
+def test_gpu_near_field_vs_oracle(noRef, s, element, symmetric, mode):
+    """both device decompositions of assembleClusters -- cluster-pair tiles with LDS sub-blocks (default) and the
+    reference's element-pair masks -- against the oracle's masked assembly"""
     from pynucleus_amd import clusters
-    b = _gpu_builder(noRef, s, element)
+    b = _gpu_builder(noRef, s, element, mode=mode)
     root, Pnear, Pfar = clusters.getNearFieldClusters(b.dm, eta=3., minClusterSize=8)
     assert sum(len(v) for v in Pfar.values()) > 0
     Anear, Aref = _gpu_vs_oracle(b, Pnear, symmetric)
@@ -168,9 +179,10 @@ def test_gpu_near_field_vs_oracle(noRef, s, element, symmetric):
 
 
 @pytest.mark.gpu
-def test_gpu_covering_cluster_equals_gpu_dense():
+@pytest.mark.parametrize('mode', ['tiles', 'masks'])
+def test_gpu_covering_cluster_equals_gpu_dense(mode):
     from pynucleus_amd import clusters
-    b = _gpu_builder(3, 0.5, params={'target_order': 0.5})
+    b = _gpu_builder(3, 0.5, params={'target_order': 0.5}, mode=mode)
     root, Pnear = clusters.coveringCluster(b.dm)
     Anear, Aref = _gpu_vs_oracle(b, Pnear)
     Adense = b.getDense().toarray()
@@ -183,15 +195,19 @@ def test_gpu_near_field_chunked_and_regional():
     b = _gpu_builder(3, 0.25, zeroExterior=False, params={'maxMasksNNZ': 3000})
     root, Pnear = clusters.allLeafPairs(b.dm, 2)
     Anear, Aref = _gpu_vs_oracle(b, Pnear, counters=False)
+    b2 = _gpu_builder(3, 0.25, zeroExterior=False, mode='tiles')
+    A2, _ = _gpu_vs_oracle(b2, clusters.allLeafPairs(b2.dm, 2)[1])
+    assert A2.info['mode'] == 'tiles' and np.abs(A2.toarray()-Aref).max() <= 1e-11*np.abs(Aref).max()
     Adense = b.getDense().toarray()
     assert np.abs(Anear.toarray()-Adense).max() < 5e-3
     assert np.linalg.norm(Anear.toarray()-Adense) < 3e-2*np.linalg.norm(Adense)
 
 
 @pytest.mark.gpu
-def test_gpu_near_field_1d():
+@pytest.mark.parametrize('mode', ['tiles', 'masks'])
+def test_gpu_near_field_1d(mode):
     from pynucleus_amd import clusters
-    b = _gpu_builder(5, 0.75, domain='interval')
+    b = _gpu_builder(5, 0.75, domain='interval', mode=mode)
     root, Pnear, Pfar = clusters.getNearFieldClusters(b.dm, eta=3., minClusterSize=4)
     _gpu_vs_oracle(b, Pnear)
 
