@@ -185,6 +185,27 @@ typedef struct {
 } pnl_cluster_plan;
 int pnl_assemble_clusters_tiled(pnl_context *ctx, const pnl_cluster_plan *plan, int cluster_boundary, double *data_dev,
                                 double *diag_dev);
+/* ---- H2 far field (clusterMethodCy.pyx) -----------------------------------------------------------------------------
+ * Cluster tree (nodes with parent, level, box), its leaves (sorted DoFs, cells touching them), the admissible cluster pairs
+ * far[nfar][2] = (n1, n2) (getAdmissibleClusters :4046-4136), one interpolation order m for all nodes, the transfer
+ * operators transfer[node][M][M] (row: tensor index on the parent's Chebyshev grid; transferMatrixBuilder :2004-2073; unused
+ * for the root) and a volume quadrature rule for the leaf values.  pnl_h2_setup evaluates on the device the kernel
+ * interpolants -2 gamma(xi_i, eta_j) of every admissible pair (assembleFarFieldInteractions :2153-2238) and the leaf values
+ * int phi_I L_alpha (enterLeafValues :1205-1325).  pnl_h2_matvec adds the far field to y: upward pass, interactions,
+ * downward pass (H2Matrix.matvec :2269-2295 without the near-field term, which is pnl_spmv).  Tensor index
+ * alpha = alpha_0 + m alpha_1 (coordinate 0 fastest), M = m^dim. */
+typedef struct {
+    int32_t nnodes, nleaves, nfar, m, nlevels, nq;
+    const double *box;
+    const int32_t *parent, *level;
+    const int32_t *leaf_node, *leaf_dof_off, *leaf_dofs, *leaf_cell_off, *leaf_cells;
+    const int32_t *far;
+    const double *transfer;
+    const double *qbary, *qw, *qphi;
+} pnl_h2_plan;
+int pnl_h2_setup(pnl_context *ctx, const pnl_h2_plan *plan);
+int pnl_h2_matvec(pnl_context *ctx, const double *x_dev, double *y_dev);
+
 /* y = A x for the uploaded pattern (CSR: diag_dev NULL; SSS: lower triangle + diagonal, y = (L + D + L^T) x):
  * CSR_LinearOperator.matvec / SSS_LinearOperator.matvec */
 int pnl_spmv(pnl_context *ctx, const double *data_dev, const double *diag_dev, const double *x_dev, double *y_dev);

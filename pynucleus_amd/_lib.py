@@ -27,7 +27,7 @@ EXPORTS = ['pnl_create', 'pnl_destroy', 'pnl_error_string', 'pnl_version', 'pnl_
            'pnl_upload_mesh', 'pnl_upload_dofmap', 'pnl_set_kernel', 'pnl_set_order_formula', 'pnl_upload_distant_rules',
            'pnl_upload_singular_rule', 'pnl_upload_boundary', 'pnl_assemble_dense', 'pnl_tile_cells',
            'pnl_assemble_dense_tiles', 'pnl_get_counters', 'pnl_get_phase_ms', 'pnl_gemv', 'pnl_cg_jacobi',
-           'pnl_inv_diagonal', 'pnl_set_classes', 'pnl_select_class', 'pnl_upload_sparsity', 'pnl_assemble_pairs_masked', 'pnl_assemble_boundary_masked', 'pnl_assemble_clusters_tiled', 'pnl_spmv']
+           'pnl_inv_diagonal', 'pnl_set_classes', 'pnl_select_class', 'pnl_upload_sparsity', 'pnl_assemble_pairs_masked', 'pnl_assemble_boundary_masked', 'pnl_assemble_clusters_tiled', 'pnl_h2_setup', 'pnl_h2_matvec', 'pnl_spmv']
 
 
 class pnl_kernel(C.Structure):
@@ -47,6 +47,12 @@ class pnl_cluster_plan(C.Structure):
                                            'd_cell', 'd_pair')] +
                 [('n_sing', C.c_int32*3), ('n_btouch', C.c_int32), ('sing_items', C.c_void_p*3)] +
                 [(n, C.c_void_p) for n in ('pair_foff', 'fvid', 'bt_slot', 'bt_cell', 'bt_facet')])
+
+
+class pnl_h2_plan(C.Structure):
+    _fields_ = ([(n, C.c_int32) for n in ('nnodes', 'nleaves', 'nfar', 'm', 'nlevels', 'nq')] +
+                [(n, C.c_void_p) for n in ('box', 'parent', 'level', 'leaf_node', 'leaf_dof_off', 'leaf_dofs', 'leaf_cell_off',
+                                           'leaf_cells', 'far', 'transfer', 'qbary', 'qw', 'qphi')])
 
 
 class PnlError(RuntimeError):
@@ -96,6 +102,8 @@ def load():
     L.pnl_assemble_boundary_masked.argtypes = [vp, i32, vp, vp, vp, dbl, vp, vp]
     L.pnl_spmv.argtypes = [vp, vp, vp, vp, vp]
     L.pnl_assemble_clusters_tiled.argtypes = [vp, C.POINTER(pnl_cluster_plan), i32, vp, vp]
+    L.pnl_h2_setup.argtypes = [vp, C.POINTER(pnl_h2_plan)]
+    L.pnl_h2_matvec.argtypes = [vp, vp, vp]
     for name in EXPORTS:
         f = getattr(L, name)
         if name not in ('pnl_destroy', 'pnl_error_string', 'pnl_version'):

@@ -264,28 +264,33 @@ class nonlocalBuilder:
                     minSize=p.get('minClusterSize', max(self.dm.dofs_per_element*4, min(64, max(N//16, 8)))))
 
     def getH2(self, returnNearField=False, returnTree=False, **kwargs):
-        """NA:3094-3219.  Built here: cluster tree, admissibility and the near-field matrix on the GPU.  The far field
-        (Chebyshev kernel interpolation, transfer operators, H2Matrix.matvec: SURVEY 8f row 1) is not built yet, so the
-        full operator is only available when no admissible pair exists (then the dense operator is returned like the
-        reference's assembleDenseWhenH2Fails branch)."""
+        """NA:3094-3219: cluster tree, admissibility, near field (assembleClusters) and the Chebyshev-interpolated far field,
+        all on the GPU; returns an H2Matrix whose matvec is near-field SpMV + upward pass + interactions + downward pass.
+        Without an admissible pair the dense operator is returned (the reference's assembleDenseWhenH2Fails branch).  With a
+        communicator (row-sharded near field) the near-field operator alone is returned: the far field is not
+        distributed yet."""
         from . import clusters
+        from .h2 import h2Plan, H2Matrix, interpolationOrder
         rp = self.getH2RefinementParams()
         root, Pnear, Pfar = clusters.getNearFieldClusters(self.dm, rp['eta'], rp['minSize'], rp['maxLevels'])
         rank, size = self._rank_size()
         if sum(len(v) for v in Pfar.values()) == 0:
             h2 = self.getDense()
-        elif returnNearField and size > 1:
+        elif size > 1:
+            if not returnNearField:
+                raise NotImplementedError('distributed H2 far field; getH2(returnNearField=True) gives the row-sharded near field')
             # row-sharded near field: this rank's cluster pairs into its own unsymmetric CSR, matvec = local SpMV +
             # all-reduce of the N-vector (DistributedH2Matrix_globalData, clusterMethodCy.pyx:3127-3154)
             from .linear_operators import DistributedSparse_LinearOperator
             mine = clusters.partitionClusterPairs(Pnear, size)[rank]
             local = self.assembleClusters([Pnear[k] for k in mine], forceUnsymmetricMatrix=True, _symmetrizeMasks=True)
             h2 = DistributedSparse_LinearOperator(local, None if self.comm is True else self.comm)
-        elif returnNearField:
-            h2 = self.assembleClusters(Pnear)
         else:
-            raise NotImplementedError('H2 far field (clusterMethodCy.pyx:2153-2295) is not built yet; '
-                                      'getH2(returnNearField=True) returns the GPU-assembled near-field matrix')
+            Anear = self.assembleClusters(Pnear)
+            m = self.params.get('interpolation_order', None)
+            if m is None:
+                m = interpolationOrder(self.kernel, self.mesh, self.tables.target_order)
+            h2 = H2Matrix(Anear, h2Plan(self.dm, root, Pfar, m), self.context(), root, Pfar)
         out = (h2,)
         if returnNearField:
             out += (Pnear,)

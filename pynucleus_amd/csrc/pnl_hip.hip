@@ -63,7 +63,11 @@ struct pnl_context {
         b_foff, b_fbary, b_fw, b_bvid, b_bv, b_bgeo, b_counters, b_D, b_tiles,
         b_vec[6], b_clabel, b_blabel, b_clsof, b_scal, b_wl, b_wlcount, b_ttn, b_ttoff, b_tttab, b_wlsorted, b_wlaux,
         b_vertices, b_sp_indptr, b_sp_indices, b_mp_pairs, b_mp_masks, b_mp_wl, b_mp_sorted, b_mp_aux, b_bi_cells, b_bi_facets,
-        b_bi_masks, b_cp[28], b_cpD, b_wlds, b_wlpair;
+        b_bi_masks, b_cp[28], b_cpD, b_wlds, b_wlpair, b_h2[20];
+    H2Dev h2;
+    bool have_h2 = false;
+    std::vector<std::vector<int>> h2_levels;   // nodes of every level >= 1
+    std::vector<size_t> h2_level_off;
     int sp_nnz = -1;                // near-field sparsity pattern (pnl_upload_sparsity)
     unsigned wl_cap = 0;
     int tile = TILE_P1, nblocks = 0, ncp = 0, nU = 0;
@@ -1515,6 +1519,120 @@ int pnl_assemble_clusters_tiled(pnl_context *ctx, const pnl_cluster_plan *pl, in
         return kt ? clusters_tiled_impl<1, 2, TILE_P1, 1>(ctx, pl, CT, cluster_boundary, d_cell, d_pair, sing_dev, sing_pair_dev, pair_foff, fvid, fgeo, maxf, bt_cell, bt_facet, bt_slot)
                   : clusters_tiled_impl<1, 2, TILE_P1, 0>(ctx, pl, CT, cluster_boundary, d_cell, d_pair, sing_dev, sing_pair_dev, pair_foff, fvid, fgeo, maxf, bt_cell, bt_facet, bt_slot);
     return fail(ctx, PNL_ERR_UNSUPPORTED, "unsupported (dim=%d, dofs_per_element=%d)", dim, dpe);
+}
+
+int pnl_h2_setup(pnl_context *ctx, const pnl_h2_plan *pl) {
+    if (!ctx || !pl) return PNL_ERR_INVALID;
+    int rc;
+    if ((rc = check_ready(ctx))) return rc;
+    if ((rc = finalize(ctx))) return rc;
+    refresh_tables(ctx);
+    if (ctx->nlab > 0 || !std::isinf(ctx->C().kern[0].horizon2))
+        return fail(ctx, PNL_ERR_UNSUPPORTED, "H2 far field: constant order, infinite horizon only");
+    const int dim = ctx->dim, m = pl->m;
+    if (pl->nnodes <= 0 || pl->nleaves <= 0 || pl->nfar < 0 || m < 1 || m > 16 || pl->nq <= 0) return fail(ctx, PNL_ERR_INVALID, "bad H2 plan sizes");
+    int M = 1;
+    for (int d = 0; d < dim; d++) M *= m;
+    int nroot = 0;
+    for (int n = 0; n < pl->nnodes; n++) {
+        if (pl->parent[n] < -1 || pl->parent[n] >= pl->nnodes || pl->level[n] < 0 || pl->level[n] >= pl->nlevels)
+            return fail(ctx, PNL_ERR_INVALID, "node %d: bad parent / level", n);
+        if (pl->parent[n] < 0) nroot++;
+        else if (pl->level[pl->parent[n]] != pl->level[n]-1) return fail(ctx, PNL_ERR_INVALID, "node %d: level is not its parent's + 1", n);
+    }
+    if (nroot != 1) return fail(ctx, PNL_ERR_INVALID, "the tree needs exactly one root");
+    for (int i = 0; i < 2*pl->nfar; i++)
+        if (pl->far[i] < 0 || pl->far[i] >= pl->nnodes) return fail(ctx, PNL_ERR_INVALID, "far pair out of range");
+    std::vector<long long> voff(pl->nleaves);
+    long long vtot = 0;
+    std::vector<char> covered(ctx->N, 0);
+    for (int l = 0; l < pl->nleaves; l++) {
+        if (pl->leaf_node[l] < 0 || pl->leaf_node[l] >= pl->nnodes) return fail(ctx, PNL_ERR_INVALID, "leaf %d: bad node", l);
+        voff[l] = vtot;
+        vtot += (long long)(pl->leaf_dof_off[l+1]-pl->leaf_dof_off[l])*M;
+        for (int t = pl->leaf_dof_off[l]; t < pl->leaf_dof_off[l+1]; t++) {
+            const int I = pl->leaf_dofs[t];
+            if (I < 0 || I >= ctx->N || covered[I] || (t > pl->leaf_dof_off[l] && pl->leaf_dofs[t-1] >= I))
+                return fail(ctx, PNL_ERR_INVALID, "leaf %d: DoFs must be sorted and the leaves must partition the DoFs", l);
+            covered[I] = 1;
+        }
+        for (int t = pl->leaf_cell_off[l]; t < pl->leaf_cell_off[l+1]; t++)
+            if (pl->leaf_cells[t] < 0 || pl->leaf_cells[t] >= ctx->nc) return fail(ctx, PNL_ERR_INVALID, "leaf %d: bad cell", l);
+    }
+    DevBuf *B = ctx->b_h2;
+    H2Dev &H = ctx->h2;
+    std::memset(&H, 0, sizeof(H));
+    H.dim = dim; H.m = m; H.M = M; H.nnodes = pl->nnodes; H.nleaves = pl->nleaves; H.nfar = pl->nfar;
+    if ((rc = upload(ctx, B[0], pl->box, (size_t)pl->nnodes*dim*2))) return rc;
+    if ((rc = upload(ctx, B[1], pl->parent, (size_t)pl->nnodes))) return rc;
+    if ((rc = upload(ctx, B[2], pl->leaf_node, (size_t)pl->nleaves))) return rc;
+    if ((rc = upload(ctx, B[3], pl->leaf_dof_off, (size_t)pl->nleaves+1))) return rc;
+    if ((rc = upload(ctx, B[4], pl->leaf_dofs, (size_t)pl->leaf_dof_off[pl->nleaves]))) return rc;
+    if ((rc = upload(ctx, B[5], pl->leaf_cell_off, (size_t)pl->nleaves+1))) return rc;
+    if ((rc = upload(ctx, B[6], pl->leaf_cells, (size_t)pl->leaf_cell_off[pl->nleaves]))) return rc;
+    if ((rc = upload(ctx, B[7], voff.data(), voff.size()))) return rc;
+    if ((rc = upload(ctx, B[8], pl->far, (size_t)2*pl->nfar))) return rc;
+    if ((rc = upload(ctx, B[9], pl->transfer, (size_t)pl->nnodes*M*M))) return rc;
+    if ((rc = ensure(ctx, B[10], sizeof(double)*(size_t)std::max<long long>(vtot, 1)))) return rc;
+    if ((rc = ensure(ctx, B[11], sizeof(double)*(size_t)std::max(pl->nfar, 1)*M*M))) return rc;
+    if ((rc = ensure(ctx, B[12], sizeof(double)*(size_t)pl->nnodes*M))) return rc;
+    if ((rc = ensure(ctx, B[13], sizeof(double)*(size_t)pl->nnodes*M))) return rc;
+    if ((rc = upload(ctx, B[14], pl->qbary, (size_t)3*pl->nq))) return rc;
+    if ((rc = upload(ctx, B[15], pl->qw, (size_t)pl->nq))) return rc;
+    if ((rc = upload(ctx, B[16], pl->qphi, (size_t)pl->nq*ctx->dpe))) return rc;
+    H.box = (const double*)B[0].p; H.parent = (const int*)B[1].p; H.leaf_node = (const int*)B[2].p;
+    H.leaf_dof_off = (const int*)B[3].p; H.leaf_dofs = (const int*)B[4].p; H.leaf_cell_off = (const int*)B[5].p;
+    H.leaf_cells = (const int*)B[6].p; H.leaf_val_off = (const long long*)B[7].p; H.far = (const int*)B[8].p;
+    H.T = (const double*)B[9].p; H.V = (double*)B[10].p; H.K = (double*)B[11].p; H.cup = (double*)B[12].p; H.cdown = (double*)B[13].p;
+    // nodes per level (children lists), concatenated on the device
+    ctx->h2_levels.assign(pl->nlevels, std::vector<int>());
+    for (int n = 0; n < pl->nnodes; n++)
+        if (pl->parent[n] >= 0) ctx->h2_levels[pl->level[n]].push_back(n);
+    std::vector<int> cat;
+    ctx->h2_level_off.assign(pl->nlevels+1, 0);
+    for (int l = 0; l < pl->nlevels; l++) {
+        ctx->h2_level_off[l] = cat.size();
+        cat.insert(cat.end(), ctx->h2_levels[l].begin(), ctx->h2_levels[l].end());
+    }
+    ctx->h2_level_off[pl->nlevels] = cat.size();
+    if ((rc = upload(ctx, B[17], cat.data(), cat.size()))) return rc;
+    HIPCHK(ctx, hipMemsetAsync(H.V, 0, sizeof(double)*(size_t)std::max<long long>(vtot, 1), ctx->stream));
+    const double *qb = (const double*)B[14].p, *qw = (const double*)B[15].p, *qp = (const double*)B[16].p;
+    if (dim == 2 && ctx->dpe == 3) hipLaunchKernelGGL((k_h2_leaf_values<2, 3>), dim3(pl->nleaves), dim3(PNL_NTHREADS), 0, ctx->stream, ctx->P, H, pl->nq, qb, qw, qp);
+    else if (dim == 2 && ctx->dpe == 6) hipLaunchKernelGGL((k_h2_leaf_values<2, 6>), dim3(pl->nleaves), dim3(PNL_NTHREADS), 0, ctx->stream, ctx->P, H, pl->nq, qb, qw, qp);
+    else if (dim == 1 && ctx->dpe == 2) hipLaunchKernelGGL((k_h2_leaf_values<1, 2>), dim3(pl->nleaves), dim3(PNL_NTHREADS), 0, ctx->stream, ctx->P, H, pl->nq, qb, qw, qp);
+    else return fail(ctx, PNL_ERR_UNSUPPORTED, "unsupported (dim=%d, dofs_per_element=%d)", dim, ctx->dpe);
+    if (pl->nfar > 0) {
+        if (dim == 2) hipLaunchKernelGGL((k_h2_kernel_interp<2>), dim3(pl->nfar), dim3(PNL_NTHREADS), 0, ctx->stream, ctx->P, H);
+        else hipLaunchKernelGGL((k_h2_kernel_interp<1>), dim3(pl->nfar), dim3(PNL_NTHREADS), 0, ctx->stream, ctx->P, H);
+    }
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->have_h2 = true;
+    return PNL_OK;
+}
+
+int pnl_h2_matvec(pnl_context *ctx, const double *x, double *y) {
+    if (!ctx || !x || !y) return PNL_ERR_INVALID;
+    if (!ctx->have_h2) return fail(ctx, PNL_ERR_STATE, "pnl_h2_setup first");
+    const H2Dev &H = ctx->h2;
+    const int nlev = (int)ctx->h2_levels.size();
+    const int *lev = (const int*)ctx->b_h2[17].p;
+    HIPCHK(ctx, hipMemsetAsync(H.cup, 0, sizeof(double)*(size_t)H.nnodes*H.M, ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(H.cdown, 0, sizeof(double)*(size_t)H.nnodes*H.M, ctx->stream));
+    hipLaunchKernelGGL(k_h2_up_leaves, dim3(H.nleaves), dim3(64), 0, ctx->stream, H, x);
+    for (int l = nlev-1; l >= 1; l--) {
+        const int n = (int)ctx->h2_levels[l].size();
+        if (n) hipLaunchKernelGGL(k_h2_up_level, dim3(n), dim3(64), 0, ctx->stream, H, lev+ctx->h2_level_off[l], n);
+    }
+    if (H.nfar) hipLaunchKernelGGL(k_h2_far, dim3(H.nfar), dim3(64), 0, ctx->stream, H);
+    for (int l = 1; l < nlev; l++) {
+        const int n = (int)ctx->h2_levels[l].size();
+        if (n) hipLaunchKernelGGL(k_h2_down_level, dim3(n), dim3(64), 0, ctx->stream, H, lev+ctx->h2_level_off[l], n);
+    }
+    hipLaunchKernelGGL(k_h2_down_leaves, dim3(H.nleaves), dim3(64), 0, ctx->stream, H, y);
+    HIPCHK(ctx, hipGetLastError());
+    return PNL_OK;
 }
 
 int pnl_spmv(pnl_context *ctx, const double *data, const double *diag, const double *x, double *y) {

@@ -2846,3 +2846,176 @@ k_cluster_boundary(const DevProblem P, const double *__restrict__ verts, const i
     if (overflow) atomicAdd(&P.counters[5], (unsigned long long)overflow);
     if (npairs) { atomicAdd(&P.counters[3], npairs); atomicAdd(&P.counters[4], nevals); }
 }
+
+// =====================================================================================================================
+// H2 far field (clusterMethodCy.pyx): Chebyshev interpolation of the kernel on admissible cluster pairs
+// (assembleFarFieldInteractions :2153-2238, factor -2 for the (u(x)-u(y))(v(x)-v(y)) form), leaf values
+// int phi_I L_alpha (enterLeafValues :1205-1325), upward / downward passes with the transfer operators
+// (:1092-1124, :1157-1180; the transfer matrices :2004-2073 are built on the host) and H2Matrix.matvec :2269-2295.
+// Tensor index alpha = alpha_0 + m alpha_1 (coordinate 0 fastest) in every array of this file.
+struct H2Dev {
+    int dim, m, M, nnodes, nleaves, nfar;
+    const double *box;          // [nnodes][dim][2]
+    const int *parent;          // [nnodes] (-1: root)
+    const int *leaf_node;       // [nleaves]
+    const int *leaf_dof_off, *leaf_dofs;        // sorted DoFs of the leaves
+    const int *leaf_cell_off, *leaf_cells;      // cells touching them
+    const long long *leaf_val_off;              // [nleaves] offset of V_leaf[ndofs][M]
+    const int *far;             // [nfar][2] (n1, n2)
+    double *V, *K;              // leaf values, kernel interpolants [nfar][M][M]
+    const double *T;            // [nnodes][M_parent][M_child] transfer operator of every non-root node
+    double *cup, *cdown;        // [nnodes][M]
+};
+
+// j-th Chebyshev node of [a, b]: eta_j = cos((2 (m-j) - 1) pi / (2m)) (clusterMethodCy.pyx:2173, 1255)
+__device__ __forceinline__ double cheb_node(double a, double b, int m, int j) {
+    return (b-a)*0.5*(cos((2.0*(m-j)-1.0)/(2.0*m)*3.14159265358979323846)+1.0)+a;
+}
+
+// 1D Lagrange polynomial l on the Chebyshev nodes of [a, b] at x
+__device__ __forceinline__ double lagrange1d(double a, double b, int m, int l, double x) {
+    const double xl = cheb_node(a, b, m, l);
+    double v = 1.;
+    for (int k = 0; k < m; k++)
+        if (k != l) {
+            const double xk = cheb_node(a, b, m, k);
+            v *= (x-xk)/(xl-xk);
+        }
+    return v;
+}
+
+template <int DIM>
+__global__ void __launch_bounds__(PNL_NTHREADS)
+k_h2_kernel_interp(const DevProblem P, const H2Dev H) {
+    const int pr = blockIdx.x, n1 = H.far[2*pr], n2 = H.far[2*pr+1];
+    const double *b1 = H.box+(size_t)n1*DIM*2, *b2 = H.box+(size_t)n2*DIM*2;
+    for (int t = threadIdx.x; t < H.M*H.M; t += PNL_NTHREADS) {
+        const int i = t/H.M, j = t-i*H.M;
+        double d2 = 0.;
+        int ii = i, jj = j;
+#pragma unroll
+        for (int d = 0; d < DIM; d++) {
+            const double x = cheb_node(b1[2*d], b1[2*d+1], H.m, ii % H.m), y = cheb_node(b2[2*d], b2[2*d+1], H.m, jj % H.m);
+            ii /= H.m; jj /= H.m;
+            d2 += (x-y)*(x-y);
+        }
+        H.K[(size_t)pr*H.M*H.M+t] = -2.*kern_eval<0>(P.k, d2);
+    }
+}
+
+// V_leaf[lcl_dof][alpha] = sum over the cells of the leaf and the quadrature points of vol w phi_k(x) L_alpha(x)
+template <int DIM, int DPE>
+__global__ void __launch_bounds__(PNL_NTHREADS)
+k_h2_leaf_values(const DevProblem P, const H2Dev H, int nq, const double *__restrict__ qbary, const double *__restrict__ qw,
+                 const double *__restrict__ qphi) {
+    constexpr int NV = DIM+1;
+    const int lf = blockIdx.x, node = H.leaf_node[lf];
+    const double *bx = H.box+(size_t)node*DIM*2;
+    const int *dofs = H.leaf_dofs+H.leaf_dof_off[lf];
+    const int nd = H.leaf_dof_off[lf+1]-H.leaf_dof_off[lf];
+    const int *cells = H.leaf_cells+H.leaf_cell_off[lf];
+    const int ncl = H.leaf_cell_off[lf+1]-H.leaf_cell_off[lf];
+    double *V = H.V+H.leaf_val_off[lf];
+    for (int t = threadIdx.x; t < ncl*H.M; t += PNL_NTHREADS) {
+        const int c = cells[t/H.M], alpha = t % H.M;
+        int lcl[DPE];
+        bool any = false;
+#pragma unroll
+        for (int k = 0; k < DPE; k++) {
+            const int I = P.cdof[(size_t)k*P.ncp+c];
+            int lo = 0, hi = nd;
+            while (lo < hi) { const int mid = (lo+hi) >> 1; if (dofs[mid] < I) lo = mid+1; else hi = mid; }
+            lcl[k] = (I >= 0 && lo < nd && dofs[lo] == I) ? lo : -1;
+            any = any || lcl[k] >= 0;
+        }
+        if (!any) continue;
+        double acc[DPE];
+#pragma unroll
+        for (int k = 0; k < DPE; k++) acc[k] = 0.;
+        const double vol = P.cvol[c];
+        for (int j = 0; j < nq; j++) {
+            double L = 1.;
+            int aa = alpha;
+#pragma unroll
+            for (int d = 0; d < DIM; d++) {
+                double x = 0.;
+#pragma unroll
+                for (int v = 0; v < NV; v++) x = __builtin_fma(qbary[3*j+v], P.cellv[(size_t)(v*DIM+d)*P.ncp+c], x);
+                L *= lagrange1d(bx[2*d], bx[2*d+1], H.m, aa % H.m, x);
+                aa /= H.m;
+            }
+            const double wl = vol*qw[j]*L;
+#pragma unroll
+            for (int k = 0; k < DPE; k++) acc[k] = __builtin_fma(wl, qphi[j*DPE+k], acc[k]);
+        }
+#pragma unroll
+        for (int k = 0; k < DPE; k++)
+            if (lcl[k] >= 0) atomic_add_f64(&V[(size_t)lcl[k]*H.M+alpha], acc[k]);
+    }
+}
+
+// upward pass, leaves: cup[node][alpha] = sum_dofs x[dof] V[dof][alpha]
+__global__ void __launch_bounds__(64)
+k_h2_up_leaves(const H2Dev H, const double *__restrict__ x) {
+    const int lf = blockIdx.x, node = H.leaf_node[lf];
+    const int *dofs = H.leaf_dofs+H.leaf_dof_off[lf];
+    const int nd = H.leaf_dof_off[lf+1]-H.leaf_dof_off[lf];
+    const double *V = H.V+H.leaf_val_off[lf];
+    for (int a = threadIdx.x; a < H.M; a += 64) {
+        double s = 0.;
+        for (int k = 0; k < nd; k++) s = __builtin_fma(x[dofs[k]], V[(size_t)k*H.M+a], s);
+        H.cup[(size_t)node*H.M+a] = s;
+    }
+}
+
+// upward pass, one level: cup[parent] += T_child cup[child] for the nodes of the level (list of children)
+__global__ void __launch_bounds__(64)
+k_h2_up_level(const H2Dev H, const int *__restrict__ nodes, int n) {
+    const int c = nodes[blockIdx.x], p = H.parent[c];
+    (void)n;
+    const double *T = H.T+(size_t)c*H.M*H.M;
+    for (int i = threadIdx.x; i < H.M; i += 64) {
+        double s = 0.;
+        for (int j = 0; j < H.M; j++) s = __builtin_fma(T[(size_t)i*H.M+j], H.cup[(size_t)c*H.M+j], s);
+        atomic_add_f64(&H.cup[(size_t)p*H.M+i], s);
+    }
+}
+
+// far field: cdown[n1] += K cup[n2]
+__global__ void __launch_bounds__(64)
+k_h2_far(const H2Dev H) {
+    const int pr = blockIdx.x, n1 = H.far[2*pr], n2 = H.far[2*pr+1];
+    const double *K = H.K+(size_t)pr*H.M*H.M;
+    for (int i = threadIdx.x; i < H.M; i += 64) {
+        double s = 0.;
+        for (int j = 0; j < H.M; j++) s = __builtin_fma(K[(size_t)i*H.M+j], H.cup[(size_t)n2*H.M+j], s);
+        atomic_add_f64(&H.cdown[(size_t)n1*H.M+i], s);
+    }
+}
+
+// downward pass, one level: cdown[child] += T_child^T cdown[parent]
+__global__ void __launch_bounds__(64)
+k_h2_down_level(const H2Dev H, const int *__restrict__ nodes, int n) {
+    const int c = nodes[blockIdx.x], p = H.parent[c];
+    (void)n;
+    const double *T = H.T+(size_t)c*H.M*H.M;
+    for (int j = threadIdx.x; j < H.M; j += 64) {
+        double s = 0.;
+        for (int i = 0; i < H.M; i++) s = __builtin_fma(T[(size_t)i*H.M+j], H.cdown[(size_t)p*H.M+i], s);
+        H.cdown[(size_t)c*H.M+j] += s;           // every child is written by one workgroup, after its parent's level
+    }
+}
+
+// downward pass, leaves: y[dof] += sum_alpha V[dof][alpha] cdown[node][alpha]
+__global__ void __launch_bounds__(64)
+k_h2_down_leaves(const H2Dev H, double *__restrict__ y) {
+    const int lf = blockIdx.x, node = H.leaf_node[lf];
+    const int *dofs = H.leaf_dofs+H.leaf_dof_off[lf];
+    const int nd = H.leaf_dof_off[lf+1]-H.leaf_dof_off[lf];
+    const double *V = H.V+H.leaf_val_off[lf];
+    for (int k = threadIdx.x; k < nd; k += 64) {
+        double s = 0.;
+        for (int a = 0; a < H.M; a++) s = __builtin_fma(V[(size_t)k*H.M+a], H.cdown[(size_t)node*H.M+a], s);
+        y[dofs[k]] += s;                         // leaves partition the DoFs
+    }
+}

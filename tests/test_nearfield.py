@@ -215,10 +215,8 @@ def test_gpu_near_field_1d(mode):
 @pytest.mark.gpu
 def test_getH2_returns_near_field():
     b = _gpu_builder(4, 0.75, params={'eta': 3., 'minClusterSize': 16})
-    Anear, Pnear = b.getH2(returnNearField=True)
-    assert Anear.nnz > 0 and len(Pnear) > 0
-    with pytest.raises(NotImplementedError):
-        b.getH2()
+    h2, Pnear = b.getH2(returnNearField=True)
+    assert h2.Anear.nnz > 0 and len(Pnear) > 0 and h2.plan.far.shape[0] > 0
 
 
 @pytest.mark.gpu
