@@ -277,14 +277,17 @@ class nonlocalBuilder:
         if sum(len(v) for v in Pfar.values()) == 0:
             h2 = self.getDense()
         elif size > 1:
-            if not returnNearField:
-                raise NotImplementedError('distributed H2 far field; getH2(returnNearField=True) gives the row-sharded near field')
-            # row-sharded near field: this rank's cluster pairs into its own unsymmetric CSR, matvec = local SpMV +
-            # all-reduce of the N-vector (DistributedH2Matrix_globalData, clusterMethodCy.pyx:3127-3154)
+            # row-sharded near field: this rank's cluster pairs into its own unsymmetric CSR; the far field (a few MB of
+            # interpolants) is replicated and applied by rank 0; matvec = Bcast(x), local products, Allreduce(y)
+            # (DistributedH2Matrix_globalData, clusterMethodCy.pyx:3127-3154)
             from .linear_operators import DistributedSparse_LinearOperator
             mine = clusters.partitionClusterPairs(Pnear, size)[rank]
             local = self.assembleClusters([Pnear[k] for k in mine], forceUnsymmetricMatrix=True, _symmetrizeMasks=True)
-            h2 = DistributedSparse_LinearOperator(local, None if self.comm is True else self.comm)
+            m = self.params.get('interpolation_order', None)
+            if m is None:
+                m = interpolationOrder(self.kernel, self.mesh, self.tables.target_order)
+            far = H2Matrix(local, h2Plan(self.dm, root, Pfar, m), self.context(), root, Pfar) if rank == 0 else None
+            h2 = DistributedSparse_LinearOperator(local, None if self.comm is True else self.comm, far=far)
         else:
             Anear = self.assembleClusters(Pnear)
             m = self.params.get('interpolation_order', None)

@@ -236,9 +236,10 @@ class DistributedSparse_LinearOperator:
     the reference's DistributedH2Matrix_globalData (clusterMethodCy.pyx:3127-3154): Bcast(x), local product, Allreduce(y)
     -- an N-vector over RCCL (or gloo), never the matrix."""
 
-    def __init__(self, local, comm_group=None):
+    def __init__(self, local, comm_group=None, far=None):
         self.local = local
         self.group = comm_group
+        self.far = far               # H2Matrix over the local near field on the rank that applies the (replicated) far field
         self.num_rows, self.num_columns = local.num_rows, local.num_columns
         self.shape = local.shape
         self.info = local.info
@@ -251,12 +252,12 @@ class DistributedSparse_LinearOperator:
         if backend == 'gloo':
             xh = xd.cpu()
             dist.broadcast(xh, src=0, group=self.group)
-            yh = self.local.matvec(xh.to(dev)).cpu()
+            yh = (self.far if self.far is not None else self.local).matvec(xh.to(dev)).cpu()
             dist.all_reduce(yh, group=self.group)
             yd = yh.to(dev)
         else:
             dist.broadcast(xd, src=0, group=self.group)
-            yd = self.local.matvec(xd)
+            yd = (self.far if self.far is not None else self.local).matvec(xd)
             dist.all_reduce(yd, group=self.group)
         if isinstance(x, torch.Tensor):
             return yd

@@ -256,13 +256,18 @@ def _dist_near_worker(rank, world, port, out):
     mesh = disc(3)
     dm = P1_DoFMap(mesh, PHYSICAL)
     b = nonlocalBuilder(dm, getFractionalKernel(2, 0.75), {'eta': 3., 'minClusterSize': 8}, zeroExterior=True, comm=True)
-    op, Pnear = b.getH2(returnNearField=True)
+    op, Pnear, root = b.getH2(returnNearField=True, returnTree=True)
     x = np.linspace(-1., 1., dm.num_dofs)
-    y = op.matvec(x)
+    y = op.matvec(x)                                # near field (row-sharded) + far field (rank 0), all-reduced
     indptr, indices, data, diag, cnt = _oracle_near(b.tables, Pnear, symmetric=False)
     Aref = _to_dense(dm.num_dofs, indptr, indices, data, None)
-    e1 = float(np.abs(y-Aref@x).max()/np.abs(Aref@x).max())
     e2 = float(np.abs(op.toarray()-Aref).max()/np.abs(Aref).max())
+    if rank == 0:
+        from pynucleus_amd.quadrature import simplexXiaoGimbutas
+        from oracle import h2_oracle
+        m = op.far.plan.m
+        Aref = Aref+h2_oracle.far_field_dense(dm, b.kernel, root, op.far.Pfar, m, simplexXiaoGimbutas(m+2, 2, 2))
+    e1 = float(np.abs(y-Aref@x).max()/np.abs(Aref@x).max()) if rank == 0 else 0.
     if rank == 0:
         out.put((e1, e2, op.local.nnz, indices.shape[0]))
     dist.destroy_process_group()

@@ -64,6 +64,29 @@ elif what == 'c4':
         y = A.matvec(x)
     sync()
     print('   near-field SpMV: {:.3f} ms'.format(1e3*(time.time()-t0)/20))
+    sync(); t0 = time.time()
+    h2 = b.getH2()
+    sync(); t1 = time.time()
+    print('   getH2 (tree + near field + far-field setup): wall {:.2f} s; {}'.format(t1-t0, h2))
+    for _ in range(3):
+        y = h2.matvec(x)
+    sync(); t0 = time.time()
+    for _ in range(20):
+        y = h2.matvec(x)
+    sync()
+    t_h2 = (time.time()-t0)/20
+    if dm.num_dofs <= 50000:
+        D = b.getDense()
+        yd = D.matvec(x)
+        sync(); t0 = time.time()
+        for _ in range(20):
+            yd = D.matvec(x)
+        sync()
+        t_d = (time.time()-t0)/20
+        print('   H2 matvec {:.3f} ms vs dense GEMV {:.3f} ms; |(A_dense - A_h2) x| / |A_dense x| = {:.2e}'.format(
+            1e3*t_h2, 1e3*t_d, float(torch.linalg.norm(y-yd)/torch.linalg.norm(yd))))
+    else:
+        print('   H2 matvec {:.3f} ms'.format(1e3*t_h2))
 elif what == 'c3':
     N = size or 129
     mesh = uniformSquare(N)
