@@ -6,7 +6,9 @@ zero the N x N block in HBM, classify + integrate + scatter every element pair (
 Omega x Omega^c boundary term, mirror.  Inputs (mesh, DoF map, quadrature tables) are resident in HBM
 before the timed region starts.  Workload: 2D unit disc, P1, fractional kernel s = 0.5, horizon = inf,
 normalised, target_order 0.5, zeroExterior (BASELINE.json configs[1]); the mesh is the reference's
-uniform_disc refined --noRef times (default 6: 24 576 cells, 12 097 DoFs, 3.02e8 element pairs).
+uniform_disc refined --noRef times.  configs[1]'s "~2x10^4 DoFs" lies between noRef 6 (12 097 DoFs, 3.02e8 pairs) and noRef 7
+(48 769 DoFs, 98 304 cells, 4.83e9 pairs); the default is noRef 7, the largest refinement whose dense N x N block (19 GB) fits
+one MI355X (noRef 8 needs 307 GB) and the size at which the 1/2/4/8-GPU runs are not dominated by per-rank fixed costs.
 
 N > 1 (python -m torch.distributed.run ... bench.py --gpus N): the element pairs of the SAME problem are
 dealt over the ranks (strong scaling, no collective in the assembly path; every rank holds its partial
@@ -43,7 +45,7 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=2)
-    ap.add_argument('--noRef', type=int, default=6)
+    ap.add_argument('--noRef', type=int, default=7)
     ap.add_argument('--s', type=float, default=0.5)
     ap.add_argument('--cpu-seconds', type=float, default=15., help='target CPU time of the oracle sample (rank 0, N=1 only)')
     ap.add_argument('--no-cpu', action='store_true')
@@ -55,6 +57,7 @@ def main():
     import torch.distributed as dist
     from pynucleus_amd import disc, P1_DoFMap, PHYSICAL, getFractionalKernel
     from pynucleus_amd.builder import nonlocalBuilder
+    from pynucleus_amd._lib import PNL_FLAG_SYMMETRIC_FLUSH
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
@@ -85,7 +88,9 @@ def main():
         if world == 1:
             ctx.assemble_dense(A.data_ptr(), A.stride(0), True, 0, nc)
         else:
-            ctx.assemble_dense_tiles(A.data_ptr(), A.stride(0), True, tiles, c0, c1)
+            # N > 1: cross contributions are written on both sides by the flush (its work is shared by the ranks) instead
+            # of the N^2 mirror pass (which is not)
+            ctx.assemble_dense_tiles(A.data_ptr(), A.stride(0), True, tiles, c0, c1, flags=PNL_FLAG_SYMMETRIC_FLUSH)
 
     def sync():
         torch.cuda.synchronize(dev)

@@ -131,6 +131,8 @@ int pnl_upload_boundary(pnl_context *ctx, int nb, const int32_t *bcells_host);
  * (the reference's MPI split NA:1280-1285); zero_exterior adds the Omega x Omega^c term for the
  * same cells.  flags: PNL_FLAG_* below. */
 #define PNL_FLAG_NO_MIRROR 1   /* leave cross contributions in A'[I,J] only (operator = A' + A'^T), for sharded matvec */
+#define PNL_FLAG_SYMMETRIC_FLUSH 2   /* write every cross contribution at (I,J) and (J,I) instead of the N^2 mirror pass:
+                                      * the flush work is shared by the ranks, the mirror pass is not (multi-GPU) */
 int pnl_assemble_dense(pnl_context *ctx, double *A_dev, int64_t ldA, int zero_exterior, int cell_begin, int cell_end,
                        int flags);
 /* Like pnl_assemble_dense but with an explicit work list of block-tile pairs for the distant pairs

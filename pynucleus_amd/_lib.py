@@ -20,6 +20,7 @@ PNL_ERR_ORDER = -5
 PNL_INTERIOR = 0
 PNL_BOUNDARY = 1
 PNL_FLAG_NO_MIRROR = 1
+PNL_FLAG_SYMMETRIC_FLUSH = 2
 PNL_NUM_COUNTERS = 131
 
 # every symbol include/pnl_hip.h declares (checked by tests/test_abi.py)

@@ -125,7 +125,7 @@ class nonlocalBuilder:
         else:
             tiles = self.tiles_for_rank(rank, size)
             start, end = cell_range_of_rank(nc, rank, size)
-            ctx.assemble_dense_tiles(A.data_ptr(), A.stride(0), self.zeroExterior, tiles, start, end)
+            ctx.assemble_dense_tiles(A.data_ptr(), A.stride(0), self.zeroExterior, tiles, start, end, flags=_lib.PNL_FLAG_SYMMETRIC_FLUSH)
         cnt = ctx.counters()
         ms = ctx.phase_ms()
         for k in ('numCellPairs', 'numAssembledCellPairs', 'numIntegrations'):

@@ -83,6 +83,7 @@ struct pnl_context {
     std::vector<BlockAgg> blocks;
     hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     bool pure_launched = false;
+    bool symflush = false;          // PNL_FLAG_SYMMETRIC_FLUSH of the current assembly
     bool ev_valid = false;
     unsigned long long visited_pairs = 0;
     bool tiles_launched = false;
@@ -429,10 +430,16 @@ void refresh_tables(pnl_context *ctx) {
 
 // row stride of the LDS sub-block: nU + 1 columns (+1: trash column / row for boundary DoFs); PNL_ACC_PAD=m rounds it up
 // to 1 mod m so that consecutive rows start in different LDS banks
-int acc_stride_of(int nU) {
+int acc_stride_of(int nU, size_t fixed_bytes = 0) {
     int st = nU+1;
-    const int m = getenv("PNL_ACC_PAD") ? atoi(getenv("PNL_ACC_PAD")) : 0;
-    if (m > 1) while (st % m != 1) st++;
+    // rows that start in different LDS banks (stride = 1 mod 32 doubles) see fewer conflicts in the ds_add_f64 of the
+    // cross blocks (measured: -0.4 ms at noRef 6), if the bigger sub-block still leaves two workgroups per CU
+    const int m = getenv("PNL_ACC_PAD") ? atoi(getenv("PNL_ACC_PAD")) : 32;
+    if (m > 1) {
+        int padded = st;
+        while (padded % m != 1) padded++;
+        if (fixed_bytes+sizeof(double)*(size_t)(nU+1)*padded <= 80*1024) st = padded;
+    }
     return st;
 }
 
@@ -451,7 +458,8 @@ int launch_pure(pnl_context *ctx, double *A, int64_t ldA) {
                                        ctx->n_pure+ctx->n_mixed, lds, per_cu);
     const int grid = std::min(ctx->n_pure, 256*std::max(per_cu, 1));
     hipLaunchKernelGGL(kfun, dim3(grid), dim3(PNL_NTHREADS), lds, ctx->stream, ctx->P, (const int2*)ctx->b_tiles.p+ctx->n_mixed,
-                       ctx->n_pure, A, (long long)ldA, (double*)ctx->b_D.p, acc_stride, 2);
+                       ctx->n_pure, A, (long long)ldA, (double*)ctx->b_D.p, acc_stride, 2,
+                       (ctx->symflush ? 1 : 0) | (getenv("PNL_PURE_ABL") ? atoi(getenv("PNL_PURE_ABL")) : 0));
     HIPCHK(ctx, hipGetLastError());
     return PNL_OK;
 }
@@ -469,7 +477,7 @@ int launch_tiles(pnl_context *ctx, int ntiles_all, double *A, int64_t ldA, int c
     }
     const int ntiles = ctx->n_mixed;
     (void)ntiles_all;
-    const int acc_stride = acc_stride_of(ctx->nU);
+    const int acc_stride = acc_stride_of(ctx->nU, S::fixed_bytes);
     const size_t lds = S::fixed_bytes+sizeof(double)*(size_t)(ctx->nU+1)*acc_stride;
     if (getenv("PNL_VERBOSE")) {
         int nblk = -1;
@@ -502,7 +510,7 @@ int launch_tiles(pnl_context *ctx, int ntiles_all, double *A, int64_t ldA, int c
     if (grid > 0)
         hipLaunchKernelGGL(kfun, dim3(grid), dim3(PNL_NTHREADS), lds, ctx->stream, ctx->P, (const int2*)ctx->b_tiles.p, A,
                            (long long)ldA, (double*)ctx->b_D.p, cell_begin, cell_end, acc_stride, (int4*)ctx->b_wl.p,
-                           (unsigned*)ctx->b_wlcount.p, ctx->wl_cap, ctx->ablate, ntiles, ClusterTiles{});
+                           (unsigned*)ctx->b_wlcount.p, ctx->wl_cap, ctx->ablate | (ctx->symflush ? 256 : 0), ntiles, ClusterTiles{});
     HIPCHK(ctx, hipGetLastError());
     HIPCHK(ctx, hipEventRecord(ctx->ev[6], ctx->stream));
     {
@@ -527,10 +535,10 @@ int launch_tiles(pnl_context *ctx, int ntiles_all, double *A, int64_t ldA, int c
         if (ctx->wl_lane)
             hipLaunchKernelGGL((k_worklist_lane<DIM, DPE, KT, false>), dim3(256*4), dim3(PNL_NTHREADS), 0, ctx->stream, ctx->P,
                                (const int4*)ctx->b_wlsorted.p, (const unsigned*)offs, A, (long long)ldA, (double*)ctx->b_D.p, SparseOut{},
-                               getenv("PNL_WL_DBG") ? atoi(getenv("PNL_WL_DBG")) : 0, ClusterTiles{});
+                               (getenv("PNL_WL_DBG") ? atoi(getenv("PNL_WL_DBG")) : 0) | (ctx->symflush ? 8 : 0), ClusterTiles{});
         hipLaunchKernelGGL(wfun, dim3(256*2), dim3(PNL_NTHREADS), lds, ctx->stream, ctx->P, (const int4*)ctx->b_wlsorted.p,
                            (const unsigned*)offs, (const unsigned*)coff, A, (long long)ldA, (double*)ctx->b_D.p, tab_max,
-                           SparseOut{}, PNL_WL_BINS-1, nmin, ClusterTiles{});
+                           SparseOut{}, PNL_WL_BINS-1, nmin | (ctx->symflush ? 1 << 16 : 0), ClusterTiles{});
         HIPCHK(ctx, hipGetLastError());
     }
     return PNL_OK;
@@ -581,7 +589,9 @@ int launch_boundary(pnl_context *ctx, int cell_begin, int cell_end) {
     const int ncell = cell_end-cell_begin;
     const int gx = (ncell+PNL_NTHREADS-1)/PNL_NTHREADS;
     // small facet chunks: many waves in flight hide the latency of the per-facet dependent chain
-    const int per = getenv("PNL_BND_PER") ? atoi(getenv("PNL_BND_PER")) : 16;
+    // a rank's share of the cells may be small: shrink the facet chunks until the grid has a few thousand workgroups
+    int per = getenv("PNL_BND_PER") ? atoi(getenv("PNL_BND_PER")) : 16;
+    while (per > 1 && (long long)gx*((ctx->nb+per-1)/per) < 4096) per >>= 1;
     const int chunks = (ctx->nb+per-1)/per;
     if (ctx->P.bkn.fast)
         hipLaunchKernelGGL((k_boundary_distant<DIM, DPE, 1>), dim3(gx, chunks), dim3(PNL_NTHREADS), 0, ctx->stream, ctx->P,
@@ -610,6 +620,7 @@ template <int DIM, int DPE, int TILE>
 int assemble_impl(pnl_context *ctx, double *A, int64_t ldA, int zero_exterior, int ntiles, int cell_begin, int cell_end, int flags) {
     int rc;
     const int ncls = (int)ctx->cls.size();
+    ctx->symflush = (flags & PNL_FLAG_SYMMETRIC_FLUSH) != 0;
     HIPCHK(ctx, hipMemsetAsync(ctx->b_counters.p, 0, sizeof(unsigned long long)*PNL_NCOUNTERS, ctx->stream));
     HIPCHK(ctx, hipMemsetAsync(ctx->b_D.p, 0, sizeof(double)*(size_t)ctx->ncp*(DPE*(DPE+1)/2), ctx->stream));
     HIPCHK(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
@@ -627,7 +638,7 @@ int assemble_impl(pnl_context *ctx, double *A, int64_t ldA, int zero_exterior, i
         }
     HIPCHK(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
     // mirror the cross part before the symmetric contributions are added on both sides
-    if (!(flags & PNL_FLAG_NO_MIRROR)) {
+    if (!(flags & (PNL_FLAG_NO_MIRROR | PNL_FLAG_SYMMETRIC_FLUSH))) {
         const long long nb = (ctx->N+31)/32;
         hipLaunchKernelGGL(k_mirror, dim3((unsigned)(nb*(nb+1)/2)), dim3(PNL_NTHREADS), 0, ctx->stream, A, (long long)ldA, ctx->N);
         HIPCHK(ctx, hipGetLastError());

@@ -458,8 +458,9 @@ __device__ __forceinline__ bool tile_eligible(int n) { return n == 2 || n == 3 |
 #ifndef PNL_TILE_WAVES
 #define PNL_TILE_WAVES 2      // waves per SIMD the tile kernel is register-limited to (measured: 2 beats 3 and 4)
 #endif
+// P2 (78 local entries per pair) needs more than 256 VGPRs: one wave per SIMD without spills beats two with 600 B of scratch
 template <int DIM, int DPE, int TILE, int KT, bool CLUSTER>
-__global__ void __launch_bounds__(PNL_NTHREADS, PNL_TILE_WAVES)
+__global__ void __launch_bounds__(PNL_NTHREADS, (DPE > 3 ? 1 : PNL_TILE_WAVES))
 k_tile_distant(const DevProblem P, const int2 *__restrict__ tiles, double *__restrict__ A, long long ldA,
                double *__restrict__ Dglob, int cell_begin, int cell_end, int acc_stride, int4 *__restrict__ worklist,
                unsigned *__restrict__ wl_count, unsigned wl_cap, int ablate, int ntiles, const ClusterTiles CT) {
@@ -776,7 +777,10 @@ k_tile_distant(const DevProblem P, const int2 *__restrict__ tiles, double *__res
                 // rank-local CSR the ones of its own blocks: addToEntry semantics)
                 sparse_add(CT.S, dofA[r], dofB[c], v);
                 sparse_add(CT.S, dofB[c], dofA[r], v);
-            } else atomic_add_f64(&A[(long long)dofA[r]*ldA+dofB[c]], v);
+            } else {
+                atomic_add_f64(&A[(long long)dofA[r]*ldA+dofB[c]], v);
+                if (ablate & 256) atomic_add_f64(&A[(long long)dofB[c]*ldA+dofA[r]], v);     // PNL_FLAG_SYMMETRIC_FLUSH: no mirror pass
+            }
         }
     }
     for (int t = tid; t < 2*TILE*ND; t += PNL_NTHREADS) {
@@ -851,7 +855,7 @@ __device__ __forceinline__ double row16_sum(double v) {
 template <int DIM, int DPE, int KT>
 __global__ void __launch_bounds__(PNL_NTHREADS, 3)
 k_tile_pure(const DevProblem P, const int2 *__restrict__ tiles, int ntiles, double *__restrict__ A, long long ldA,
-            double *__restrict__ Dglob, int acc_stride, int q_uniform) {
+            double *__restrict__ Dglob, int acc_stride, int q_uniform, int symflush) {
     constexpr int TILE = 64, NV = DIM+1, NC = NV*DIM, ND = DPE*(DPE+1)/2, NP = (DIM == 2) ? 3 : 2, ST = 4+DPE;
     constexpr int JW = TILE/(PNL_NTHREADS/64);          // cells j per wave
     extern __shared__ double smem[];
@@ -989,17 +993,19 @@ k_tile_pure(const DevProblem P, const int2 *__restrict__ tiles, int ntiles, doub
             }
             // cross block -> LDS sub-block of A'
             const double vv = scale2*vola*volb;
+            if (!(symflush & 16)) {
 #pragma unroll
-            for (int b = 0; b < DPE; b++) {
-                const int sb = s_slotb[j*DPE+b];
+                for (int b = 0; b < DPE; b++) {
+                    const int sb = s_slotb[j*DPE+b];
 #pragma unroll
-                for (int a = 0; a < DPE; a++) lds_add_f64(&s_acc[sa[a]+sb], -vv*G[a][b]);
-            }
+                    for (int a = 0; a < DPE; a++) lds_add_f64(&s_acc[sa[a]+sb], -vv*G[a][b]);
+                }
+            } else if (G[0][0] == 1.2345e300) s_acc[0] = vv;
             // diagonal block of cell j: column sums over all cells i of the wave
             const double wa = valid ? vola : 0.;
             double cw[NP];
 #pragma unroll
-            for (int jp = 0; jp < NP; jp++) cw[jp] = wave_sum(wa*c[jp]);
+            for (int jp = 0; jp < NP; jp++) cw[jp] = (symflush & 32) ? wa*c[jp] : wave_sum(wa*c[jp]);
             if (lane < ND) {
                 int a = 0, idx = lane;
                 while (idx >= DPE-a) { idx -= DPE-a; a++; }
@@ -1033,10 +1039,14 @@ k_tile_pure(const DevProblem P, const int2 *__restrict__ tiles, int ntiles, doub
         // ---- flush ----
         const int *__restrict__ dofA = P.blk_dofs+(size_t)ta*P.blk_stride;
         const int *__restrict__ dofB = P.blk_dofs+(size_t)tb*P.blk_stride;
+        if (!(symflush & 64))
         for (int t = tid; t < nA*nB; t += PNL_NTHREADS) {
             const int r = t/nB, cc = t-r*nB;
             const double v = s_acc[r*acc_stride+cc];
-            if (v != 0.) atomic_add_f64(&A[(long long)dofA[r]*ldA+dofB[cc]], v);
+            if (v != 0.) {
+                atomic_add_f64(&A[(long long)dofA[r]*ldA+dofB[cc]], v);
+                if (symflush & 1) atomic_add_f64(&A[(long long)dofB[cc]*ldA+dofA[r]], v);
+            }
         }
         for (int t = tid; t < 2*TILE*ND; t += PNL_NTHREADS) {
             const double v = s_Da[t];
@@ -1675,7 +1685,9 @@ template <int DIM, int DPE, int KT, bool SPARSE>
 __global__ void __launch_bounds__(PNL_NTHREADS)
 k_worklist_sorted(const DevProblem P, const int4 *__restrict__ sorted, const unsigned *__restrict__ offs,
                   const unsigned *__restrict__ chunk_off, double *__restrict__ A, long long ldA, double *__restrict__ Dglob,
-                  int tab_max_pts, const SparseOut S, int qlast, int nmin, const ClusterTiles CT) {
+                  int tab_max_pts, const SparseOut S, int qlast, int nmin_flags, const ClusterTiles CT) {
+    const int nmin = nmin_flags & 0xffff;
+    const bool symflush = (nmin_flags >> 16) & 1;  // dense output: write (I, J) and (J, I) (PNL_FLAG_SYMMETRIC_FLUSH)
     const bool cluster = CT.npairs > 0;          // work list of the cluster tiles: entry.z indexes wl_pair / wl_ds
     constexpr int NV = DIM+1, NC = NV*DIM, ND = DPE*(DPE+1)/2, NG = DPE*DPE, NACC = NG+2*ND, LPP = 16, PPC = PNL_NTHREADS/LPP, NREP = (NACC+LPP-1)/LPP, ST = 4+DPE;   // LPP lanes per pair
     extern __shared__ double s_rule[];           // [tab_max_pts][ST]: bary[3], w, phi[DPE]
@@ -1856,7 +1868,10 @@ k_worklist_sorted(const DevProblem P, const int4 *__restrict__ sorted, const uns
                 if (e < NG) {
                     const int a = e/DPE, b = e-a*DPE;
                     const int I = P.cdof[(size_t)a*P.ncp+c1], J = P.cdof[(size_t)b*P.ncp+c2];
-                    if (I >= 0 && J >= 0) atomic_add_f64(&A[(long long)I*ldA+J], -vv*val);
+                    if (I >= 0 && J >= 0) {
+                        atomic_add_f64(&A[(long long)I*ldA+J], -vv*val);
+                        if (symflush) atomic_add_f64(&A[(long long)J*ldA+I], -vv*val);
+                    }
                 } else if (e < NG+ND) atomic_add_f64(&Dglob[(size_t)c1*ND+(e-NG)], vv*val);
                 else if (e < NACC) atomic_add_f64(&Dglob[(size_t)c2*ND+(e-NG-ND)], vv*val);
             }
@@ -1971,7 +1986,10 @@ k_worklist_lane(const DevProblem P, const int4 *__restrict__ sorted, const unsig
             for (int a = 0; a < DPE; a++)
 #pragma unroll
                 for (int b = 0; b < DPE; b++)
-                    if (ld1[a] >= 0 && ld2[b] >= 0 && !(dbg & 1)) atomic_add_f64(&A[(long long)ld1[a]*ldA+ld2[b]], -vv*R.G[a][b]);
+                    if (ld1[a] >= 0 && ld2[b] >= 0 && !(dbg & 1)) {
+                        atomic_add_f64(&A[(long long)ld1[a]*ldA+ld2[b]], -vv*R.G[a][b]);
+                        if (dbg & 8) atomic_add_f64(&A[(long long)ld2[b]*ldA+ld1[a]], -vv*R.G[a][b]);      // symmetric flush
+                    }
             if (!(dbg & 2))
 #pragma unroll
             for (int e = 0; e < ND; e++) {

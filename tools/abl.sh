@@ -1,7 +1,7 @@
 #!/bin/bash
-# ablation probe of the tile kernel (debug bits of PNL_ABLATE, see k_tile_distant)
+# ablation probe of the uniform-tile kernel (debug bits of PNL_PURE_ABL: 16 no LDS cross adds, 32 no DPP column sums, 64 no flush)
 cd $GRAFT_REPO_ROOT
-for a in 0 2 18 10 1 64 4; do
-  echo "== PNL_ABLATE=$a"
-  PNL_VERBOSE=1 PNL_ABLATE=$a python3 tools/perf_probe.py 6 2>&1 | grep -E "rep 2|pnl\]" | tail -2
+for a in 0 16 32 64 112; do
+  echo "== PNL_PURE_ABL=$a"
+  PNL_PURE_ABL=$a python3 tools/perf_probe.py 6 2>&1 | grep -E "rep 2" | tail -1 | sed 's/.*phases//'
 done

@@ -4,7 +4,7 @@
 # Usage: tools/profile_round.sh <round-tag> [noRef]
 set -o pipefail
 TAG=${1:-r01}
-NOREF=${2:-6}
+NOREF=${2:-7}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
