@@ -75,7 +75,9 @@ struct pnl_context {
     std::vector<int2> tiles_cached;   // tile list (as given by the caller) currently resident in b_tiles
     size_t tiles_cap = 0;
     // b_tiles holds the mixed tiles first, then the uniform ones (all pairs distant with the lowest order)
-    int n_mixed = 0, n_pure = 0, tiles_cb = -1, tiles_ce = -1;
+    int n_mixed = 0, n_pure = 0, tile_off = 0, tiles_cb = -1, tiles_ce = -1;
+    std::vector<int> cls_tile_off, cls_n_mixed, cls_n_pure;     // per order class: its slice of b_tiles (mixed tiles, then uniform)
+    std::vector<pnl_order_formula> tiles_forms;
     pnl_order_formula tiles_form;
     bool tiles_filter = true;
     bool use_pure = true;             // debug: PNL_PURE=0 sends every tile through the general kernel
@@ -457,7 +459,7 @@ int launch_pure(pnl_context *ctx, double *A, int64_t ldA) {
     if (getenv("PNL_VERBOSE")) fprintf(stderr, "[pnl] uniform tiles=%d of %d, lds=%zu bytes, occupancy API: %d blocks/CU\n", ctx->n_pure,
                                        ctx->n_pure+ctx->n_mixed, lds, per_cu);
     const int grid = std::min(ctx->n_pure, 256*std::max(per_cu, 1));
-    hipLaunchKernelGGL(kfun, dim3(grid), dim3(PNL_NTHREADS), lds, ctx->stream, ctx->P, (const int2*)ctx->b_tiles.p+ctx->n_mixed,
+    hipLaunchKernelGGL(kfun, dim3(grid), dim3(PNL_NTHREADS), lds, ctx->stream, ctx->P, (const int2*)ctx->b_tiles.p+ctx->tile_off+ctx->n_mixed,
                        ctx->n_pure, A, (long long)ldA, (double*)ctx->b_D.p, acc_stride, 2,
                        (ctx->symflush ? 1 : 0) | (getenv("PNL_PURE_ABL") ? atoi(getenv("PNL_PURE_ABL")) : 0));
     HIPCHK(ctx, hipGetLastError());
@@ -508,7 +510,7 @@ int launch_tiles(pnl_context *ctx, int ntiles_all, double *A, int64_t ldA, int c
     const int grid_mult = getenv("PNL_GRID_MULT") ? atoi(getenv("PNL_GRID_MULT")) : 1;
     const int grid = std::min(ntiles, 256*std::max(per_cu, 1)*std::max(grid_mult, 1));
     if (grid > 0)
-        hipLaunchKernelGGL(kfun, dim3(grid), dim3(PNL_NTHREADS), lds, ctx->stream, ctx->P, (const int2*)ctx->b_tiles.p, A,
+        hipLaunchKernelGGL(kfun, dim3(grid), dim3(PNL_NTHREADS), lds, ctx->stream, ctx->P, (const int2*)ctx->b_tiles.p+ctx->tile_off, A,
                            (long long)ldA, (double*)ctx->b_D.p, cell_begin, cell_end, acc_stride, (int4*)ctx->b_wl.p,
                            (unsigned*)ctx->b_wlcount.p, ctx->wl_cap, ctx->ablate | (ctx->symflush ? 256 : 0), ntiles, ClusterTiles{});
     HIPCHK(ctx, hipGetLastError());
@@ -631,6 +633,8 @@ int assemble_impl(pnl_context *ctx, double *A, int64_t ldA, int zero_exterior, i
         for (int k = 0; k < ncls; k++) {
             ctx->cur = k;
             refresh_tables(ctx);
+            ctx->tile_off = ctx->cls_tile_off[k]; ctx->n_mixed = ctx->cls_n_mixed[k]; ctx->n_pure = ctx->cls_n_pure[k];
+            if (ctx->n_mixed+ctx->n_pure == 0) continue;
             const int tb0 = ctx->tile_cell_filter ? cell_begin : 0, tb1 = ctx->tile_cell_filter ? cell_end : ctx->nc;
             rc = ctx->P.k.fast ? launch_tiles<DIM, DPE, TILE, 1>(ctx, ntiles, A, ldA, tb0, tb1)
                                : launch_tiles<DIM, DPE, TILE, 0>(ctx, ntiles, A, ldA, tb0, tb1);
@@ -1111,6 +1115,7 @@ int pnl_set_classes(pnl_context *ctx, int nclasses, int num_labels, const int32_
     ctx->nlab = num_labels;
     ctx->cell_labels.assign(cell_labels, cell_labels+(num_labels > 0 ? ctx->nc : 0));
     ctx->cls_of.assign(cls_of, cls_of+(size_t)num_labels*num_labels);
+    ctx->tiles_cached.clear(); ctx->tiles_forms.clear();
     ctx->facet_labels.clear();
     if (num_labels > 0 && facet_labels && ctx->have_boundary) {
         for (int f = 0; f < ctx->nb; f++)
@@ -1264,27 +1269,57 @@ static bool tile_is_uniform(const pnl_context *ctx, const pnl_order_formula &F, 
 
 static int upload_tiles(pnl_context *ctx, std::vector<int2> &tiles, int cell_begin, int cell_end) {
     // repeated assemblies of the same work list keep it resident
-    const pnl_order_formula &F = ctx->C().form[0];
+    const int ncls = (int)ctx->cls.size();
+    std::vector<pnl_order_formula> forms(ncls);
+    for (int k = 0; k < ncls; k++) forms[k] = ctx->cls[k]->form[0];
     if (tiles.size() == ctx->tiles_cached.size() && ctx->b_tiles.p && ctx->tiles_cb == cell_begin && ctx->tiles_ce == cell_end &&
-        std::memcmp(&F, &ctx->tiles_form, sizeof(F)) == 0 && ctx->tiles_filter == ctx->tile_cell_filter &&
+        forms.size() == ctx->tiles_forms.size() && std::memcmp(forms.data(), ctx->tiles_forms.data(), sizeof(pnl_order_formula)*ncls) == 0 &&
+        ctx->tiles_filter == ctx->tile_cell_filter &&
         (tiles.empty() || std::memcmp(tiles.data(), ctx->tiles_cached.data(), tiles.size()*sizeof(int2)) == 0))
         return PNL_OK;
     const int T = ctx->tile;
     const bool filter = ctx->tile_cell_filter;
-    const bool allow = ctx->use_pure && T == 64 && (ctx->dpe == 3 || ctx->dpe == 2) && ctx->qmax >= 2 && ctx->nlab == 0;
-    std::vector<int2> mixed, pure;
-    for (const int2 &t : tiles) {
-        bool u = allow && tile_is_uniform(ctx, F, t.x, t.y);
-        // the cell range of the MPI-style split applies to the a-cells: only blocks entirely inside qualify
-        if (u && filter && !(t.x*T >= cell_begin && (t.x+1)*T <= cell_end)) u = false;
-        (u ? pure : mixed).push_back(t);
+    const bool allow = ctx->use_pure && T == 64 && (ctx->dpe == 3 || ctx->dpe == 2) && ctx->qmax >= 2;
+    // variable order: a class only visits the tiles whose blocks hold a label pair of that class (most blocks carry one
+    // label, so the K passes together classify every tile about once instead of K times)
+    const int L = ctx->nlab;
+    std::vector<std::vector<int>> blk_labels;
+    if (L > 0) {
+        blk_labels.resize(ctx->nblocks);
+        for (int b = 0; b < ctx->nblocks; b++) {
+            auto &v = blk_labels[b];
+            for (int c = b*T; c < std::min((b+1)*T, ctx->nc); c++) v.push_back(ctx->cell_labels[c]);
+            std::sort(v.begin(), v.end());
+            v.erase(std::unique(v.begin(), v.end()), v.end());
+        }
     }
-    std::vector<int2> all(mixed);
-    all.insert(all.end(), pure.begin(), pure.end());
+    std::vector<int2> all;
+    ctx->cls_tile_off.assign(ncls, 0); ctx->cls_n_mixed.assign(ncls, 0); ctx->cls_n_pure.assign(ncls, 0);
+    std::vector<int2> mixed, pure;
+    for (int k = 0; k < ncls; k++) {
+        mixed.clear(); pure.clear();
+        for (const int2 &t : tiles) {
+            bool single = true;
+            if (L > 0) {
+                bool has = false;
+                for (int la : blk_labels[t.x]) for (int lb : blk_labels[t.y])
+                    has = has || ctx->cls_of[(size_t)la*L+lb] == k || ctx->cls_of[(size_t)lb*L+la] == k;
+                if (!has) continue;
+                single = blk_labels[t.x].size() == 1 && blk_labels[t.y].size() == 1;
+            }
+            bool u = allow && single && tile_is_uniform(ctx, forms[k], t.x, t.y);
+            // the cell range of the MPI-style split applies to the a-cells: only blocks entirely inside qualify
+            if (u && filter && !(t.x*T >= cell_begin && (t.x+1)*T <= cell_end)) u = false;
+            (u ? pure : mixed).push_back(t);
+        }
+        ctx->cls_tile_off[k] = (int)all.size(); ctx->cls_n_mixed[k] = (int)mixed.size(); ctx->cls_n_pure[k] = (int)pure.size();
+        all.insert(all.end(), mixed.begin(), mixed.end());
+        all.insert(all.end(), pure.begin(), pure.end());
+    }
     int rc = upload(ctx, ctx->b_tiles, all.data(), all.size());
     if (rc) return rc;
-    ctx->n_mixed = (int)mixed.size(); ctx->n_pure = (int)pure.size();
-    ctx->tiles_cached = tiles; ctx->tiles_cb = cell_begin; ctx->tiles_ce = cell_end; ctx->tiles_form = F;
+    ctx->tile_off = 0; ctx->n_mixed = ctx->cls_n_mixed[0]; ctx->n_pure = ctx->cls_n_pure[0];
+    ctx->tiles_cached = tiles; ctx->tiles_cb = cell_begin; ctx->tiles_ce = cell_end; ctx->tiles_forms = forms;
     ctx->tiles_filter = ctx->tile_cell_filter;
     return PNL_OK;
 }
