@@ -212,6 +212,34 @@ int pnl_h2_matvec(pnl_context *ctx, const double *x_dev, double *y_dev);
  * CSR_LinearOperator.matvec / SSS_LinearOperator.matvec */
 int pnl_spmv(pnl_context *ctx, const double *data_dev, const double *diag_dev, const double *x_dev, double *y_dev);
 
+/* ---- non-symmetric kernels with a fractional order s(x) evaluated per quadrature point --------------------------------
+ * Replaces fractionalLaplacian{1,2}D_nonsym (fractionalLaplacian2D.pyx:894-1184, fractionalLaplacian1D.pyx:410-604) with
+ * piecewise == False kernels gamma(x, y) = C(s(x)) |x-y|^(-d-2 s(x)) (kernels.py:147-149, kernelsCy.pyx:596-622), the
+ * non-symmetric branch of getDense (nonlocalAssembly_{SCALAR}.pxi:1411-1428, scatter :222-253) and the boundary term with
+ * the pointwise boundary kernel.  P1 elements, infinite horizon.
+ * type: 1 constant (p[0]), 2 smoothStep in x0, 3 linearStep in x0, 4 smoothStepRadial (fractionalOrders.pyx:338-540);
+ * p = sl, sr, r, interface (radius for type 4), slope.  normalized: variableFractionalLaplacianScaling
+ * (kernelNormalization.pyx:329-364) or 1/2. */
+typedef struct pnl_order_function {
+    int32_t type, normalized;
+    double p[6];
+} pnl_order_function;
+
+/* cell_smax[nc] / facet_smax[nb]: largest order over the centre and the vertices of a cell / boundary facet (the per-pair
+ * order of Kernel.evalParamsOnSimplices, kernelsCy.pyx:1825-1846, is the max of the two); c0 / bc0: constant term of the
+ * interior / boundary order formula; sing_fac / bsing_fac as in pnl_upload_singular_rule */
+int pnl_set_order_function(pnl_context *ctx, const pnl_order_function *f, const double *cell_smax, const double *facet_smax,
+                           double c0, double bc0, double sing_fac, double bsing_fac);
+/* near rules for the nkeys distinct orders of the touching pairs (the reference keys its rule dictionary by the singularity
+ * value, fractionalLaplacian2D.pyx:957): nodes[nkeys][2(dim+1) | (dim+1)+dim][M], w[nkeys][M], phi0 / phi1[nkeys][rows][M]
+ * = the x and y parts of the merged-DoF shape functions (PHI3 of the reference; boundary: phi0 = PHI, phi1 unused) */
+int pnl_upload_pointwise_rules(pnl_context *ctx, int which, int panel, int nkeys, int M, int rows, const double *nodes,
+                               const double *w, const double *phi0, const double *phi1);
+/* dense assembly; pairs[npairs][4] = (c1 <= c2 sharing `common` vertices, common, key into the near rules), bpairs[nbpairs][4]
+ * = (cell, boundary facet, common, key).  Distant pairs are found and classified on the device. */
+int pnl_assemble_dense_pointwise(pnl_context *ctx, double *A, int64_t ldA, int zero_exterior, int cell_begin, int cell_end,
+                                 int npairs, const int32_t *pairs, int nbpairs, const int32_t *bpairs);
+
 /* counters of the last assemble call (synchronises the stream) */
 int pnl_get_counters(pnl_context *ctx, int64_t *out, int n);
 /* device time of the last assemble call per phase in milliseconds (HIP events on the context's stream):

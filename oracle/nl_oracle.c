@@ -8,6 +8,7 @@
  *   KC  = kernelsCy.pyx                     Q   = ../../fem/PyNucleus_fem/quadrature.pyx
  */
 #define _POSIX_C_SOURCE 199309L
+#define _DEFAULT_SOURCE
 #include "nl_oracle.h"
 #include <math.h>
 #include <string.h>
@@ -798,6 +799,378 @@ int nlo_get_dense_rows(const nlo_problem *P, double *A, int zero_exterior, int c
 int nlo_get_dense(const nlo_problem *P, double *A, int zero_exterior, int cell_start, int cell_end,
                   int64_t *counters, double *seconds) {
     return nlo_get_dense_rows(P, A, zero_exterior, cell_start, cell_end, counters, seconds, 1);
+}
+
+/* ---- non-symmetric kernels, order s(x) per quadrature point ---------------------------------------------------------
+ * fractionalOrders.pyx:338-540: constantExtended, smoothStep, linearStep, smoothStepRadial */
+double nlo_pw_order(const nlo_problem *P, const double *x) {
+    const double *p = P->pw_p;                  /* sl, sr, r, interface | radius, slope */
+    switch (P->pw_type) {
+    case 1: return p[0];
+    case 2:
+        if (x[0] < p[3]-p[2]) return p[0];
+        else if (x[0] > p[3]+p[2]) return p[1];
+        return p[0] + (p[1]-p[0]) * (3.0*pow((x[0]-p[3])*p[4]+0.5, 2.0) - 2.0*pow((x[0]-p[3])*p[4]+0.5, 3.0));
+    case 3:
+        if (x[0] < p[3]-p[2]) return p[0];
+        else if (x[0] > p[3]+p[2]) return p[1];
+        return p[0] + p[4]*(x[0]-p[3]+p[2]);
+    default: {
+        double r = 0.;
+        for (int k = 0; k < P->dim; k++) r += x[k]*x[k];
+        r = sqrt(r);
+        if (r < p[3]-p[2]) return p[0];
+        else if (r > p[3]+p[2]) return p[1];
+        return p[0] + (p[1]-p[0]) * (3.0*pow((r-p[3])*p[4]+0.5, 2.0) - 2.0*pow((r-p[3])*p[4]+0.5, 3.0));
+    }
+    }
+}
+
+/* variableFractionalLaplacianScaling.evalPtr (kernelNormalization.pyx:416-440, infinite horizon, derivative 0); the
+ * boundary twin multiplies with phi = inverseTwoPoint(s) (KC:1990-1994) */
+static double pw_scaling(const nlo_problem *P, double s, int boundary) {
+    double C = 0.5;
+    if (P->pw_normalized) C = pow(2.0, 2.0*s) * s * tgamma(s+0.5*P->dim) * pow(M_PI, -0.5*P->dim) / tgamma(1.0-s) * 0.5;
+    return boundary ? (1./s)*C : C;
+}
+
+/* updateAndEvalFractional (KC:596-622) + fracKernelInfinite{1,2}D[boundary] (KC:159-174, 216-231): the order is s(x, y) = sFun(x) */
+static double pw_kernel(const nlo_problem *P, const double *x, const double *y, int boundary) {
+    const double s = nlo_pw_order(P, x);
+    const double C = pw_scaling(P, s, boundary);
+    double d2 = 0.;
+    for (int k = 0; k < P->dim; k++) d2 += (x[k]-y[k])*(x[k]-y[k]);
+    const double e = boundary ? (P->dim == 1 ? -s : -0.5-s) : (P->dim == 1 ? -0.5-s : -1.-s);
+    return C*pow(d2, e);
+}
+
+/* Kernel.evalParamsOnSimplices for a non-symmetric order (KC:1825-1846): the largest order over both centres and all vertices */
+static double pw_svalue_simplices(const nlo_problem *P, const double *ce1, const double *ce2, double s1[MAXV][2], int n1,
+                                  double s2[MAXV][2], int n2) {
+    double sValue = 0.;
+    sValue = fmax(sValue, nlo_pw_order(P, ce1));
+    sValue = fmax(sValue, nlo_pw_order(P, ce2));
+    for (int i = 0; i < n1; i++) sValue = fmax(sValue, nlo_pw_order(P, s1[i]));
+    for (int i = 0; i < n2; i++) sValue = fmax(sValue, nlo_pw_order(P, s2[i]));
+    return sValue;
+}
+
+double nlo_pw_svalue(const nlo_problem *P, int c1, int c2) {
+    double s1[MAXV][2], s2[MAXV][2], ce1[2], ce2[2];
+    simplex_of(P, c1, s1, ce1);
+    simplex_of(P, c2, s2, ce2);
+    return pw_svalue_simplices(P, ce1, ce2, s1, P->dim+1, s2, P->dim+1);
+}
+
+static int pw_key(const double *keys, int n, double sv) {       /* nearest key (host and oracle evaluate s(x) independently) */
+    int best = 0;
+    for (int k = 1; k < n; k++) if (fabs(keys[k]-sv) < fabs(keys[best]-sv)) best = k;
+    return best;
+}
+
+/* FL2:915-935 / FL1:431-450 */
+static nlo_order_formula pw_formula(const nlo_problem *P, double sv) {
+    nlo_order_formula F;
+    memset(&F, 0, sizeof(F));
+    F.c0 = P->pw_c0;
+    if (P->dim == 2) { F.a = sv-1.; F.b = 1.; F.e = sv; F.den0 = 0.4; }
+    else { F.a = 2.*sv-1.; F.b = 0.; F.e = 2.*sv; F.den0 = 0.8; }
+    return F;
+}
+
+/* FL2:1226-1243 / FL1:644-660 with s = max(0.5(-singularity-1), 0), singularity = 1-d-2 sValue */
+static nlo_order_formula pw_formula_boundary(const nlo_problem *P, double sv) {
+    nlo_order_formula F;
+    memset(&F, 0, sizeof(F));
+    F.c0 = P->pw_bc0;
+    const double st = fmax(0.5*(-(1.-P->dim-2.*sv)-1.), 0.);
+    if (P->dim == 2) { F.a = st-1.; F.b = 1.; F.e = st; F.den0 = 0.35; F.clip_num = 1; }
+    else { F.a = 2.*st-1.; F.b = 0.; F.e = 2.*st; F.den0 = 0.8; }
+    return F;
+}
+
+/* NO:849-930 eval_distant_nonsym (uncut) with the PHI / PSI tables of addQuadRule_nonSym NO:602-662;
+ * contrib[(2 dpe)^2], k = I*(2 dpe)+J */
+static void eval_distant_nonsym(const nlo_problem *P, double s1[MAXV][2], double s2[MAXV][2], double vol, int order, double *contrib) {
+    const int dim = P->dim, nV = dim+1, dpe = P->dpe, n2 = 2*dpe;
+    const int off = P->dist_off[order], n = P->dist_off[order+1]-off, nn = n*n;
+    const double *bary = P->dist_bary+3*off, *w = P->dist_w+off, *phi = P->dist_phi+(size_t)off*dpe;
+    double *temp = (double*)malloc(sizeof(double)*(2*(size_t)nn+4*(size_t)n)), *temp2 = temp+nn, *x = temp2+nn, *y = x+2*n;
+    for (int i = 0; i < n; i++)
+        for (int m = 0; m < dim; m++) {
+            double a = 0., b = 0.;
+            for (int k = 0; k < nV; k++) { a += bary[3*i+k]*s1[k][m]; b += bary[3*i+k]*s2[k][m]; }
+            x[2*i+m] = a; y[2*i+m] = b;
+        }
+    int k = 0;
+    for (int i = 0; i < n; i++)
+        for (int j = 0; j < n; j++) {
+            const double ww = w[i]*w[j];
+            temp[k] = ww*pw_kernel(P, x+2*i, y+2*j, 0);
+            temp2[k] = ww*pw_kernel(P, y+2*j, x+2*i, 0);
+            k++;
+        }
+    k = 0;
+    for (int I = 0; I < n2; I++)
+        for (int J = 0; J < n2; J++) {
+            double val = 0.;
+            for (int i = 0; i < n; i++)
+                for (int j = 0; j < n; j++) {
+                    const double PHI0 = I < dpe ? phi[i*dpe+I] : 0., PHI1 = I < dpe ? 0. : phi[j*dpe+I-dpe];
+                    const double PSIJ = J < dpe ? phi[i*dpe+J] : -phi[j*dpe+J-dpe];
+                    val += (temp[i*n+j]*PHI0 - temp2[i*n+j]*PHI1)*PSIJ;
+                }
+            contrib[k++] = val*vol;
+        }
+    free(temp);
+}
+
+/* FL2:1133-1184 / FL1:548-604 eval for touching pairs */
+static void eval_singular_nonsym(const nlo_problem *P, double s1[MAXV][2], double s2[MAXV][2], double vol12, int slot, int key,
+                                 const int *perm1, const int *perm2, const int *perm, double *contrib, int64_t *nevals) {
+    const int dim = P->dim, nV = dim+1, dpe = P->dpe, n2 = 2*dpe;
+    const int M = P->sing_M[slot], rows = P->sing_rows[slot];
+    const double *nodes = P->pw_nodes[slot]+(size_t)key*2*nV*M, *w = P->pw_w[slot]+(size_t)key*M;
+    const double *PHI0 = P->pw_phi0[slot]+(size_t)key*rows*M, *PHI1 = P->pw_phi1[slot]+(size_t)key*rows*M;
+    const double vol = P->sing_fac*vol12;
+    double *temp = (double*)malloc(sizeof(double)*2*M), *temp2 = temp+M;
+    for (int m = 0; m < M; m++) {
+        double x[2] = {0., 0.}, y[2] = {0., 0.};
+        for (int j = 0; j < dim; j++)
+            for (int k = 0; k < nV; k++) {
+                x[j] += s1[perm1[k]][j]*nodes[(size_t)k*M+m];
+                y[j] += s2[perm2[k]][j]*nodes[(size_t)(nV+k)*M+m];
+            }
+        temp[m] = w[m]*pw_kernel(P, x, y, 0);
+        temp2[m] = w[m]*pw_kernel(P, y, x, 0);
+    }
+    *nevals += M;
+    for (int k = 0; k < n2*n2; k++) contrib[k] = 0.;
+    for (int I = 0; I < rows; I++) {
+        const int i = perm[I];
+        for (int J = 0; J < rows; J++) {
+            const int j = perm[J];
+            double val = 0.;
+            for (int m = 0; m < M; m++)
+                val += (temp[m]*PHI0[(size_t)I*M+m] - temp2[m]*PHI1[(size_t)I*M+m]) * (PHI0[(size_t)J*M+m] - PHI1[(size_t)J*M+m]);
+            contrib[i*n2+j] = val*vol;
+        }
+    }
+    free(temp);
+}
+
+/* getPanelType (NO:493-540) for the non-symmetric local matrices; returns the panel and the pair's order */
+static int panel_nonsym(const nlo_problem *P, int c1, int c2, int *perm1, int *perm2, int *perm, double *sv) {
+    const int nV = P->dim+1, dpe = P->dpe;
+    for (int k = 0; k < nV; k++) { perm1[k] = k; perm2[k] = k; }
+    for (int k = 0; k < 2*dpe; k++) perm[k] = k;
+    *sv = nlo_pw_svalue(P, c1, c2);
+    if (c1 == c2) return -nV;
+    int mask1 = 0, mask2 = 0, common = 0;
+    for (int a = 0; a < nV; a++) {
+        int v1 = P->cells[c1*nV+a];
+        for (int b = 0; b < nV; b++) {
+            if (mask2 & (1 << b)) continue;
+            if (v1 == P->cells[c2*nV+b]) {
+                perm1[common] = a; perm2[common] = b;
+                mask1 += (1 << a); mask2 += (1 << b);
+                common++;
+                break;
+            }
+        }
+    }
+    if (common == 0) {
+        double s1[MAXV][2], s2[MAXV][2], ce1[2], ce2[2];
+        simplex_of(P, c1, s1, ce1);
+        simplex_of(P, c2, s2, ce2);
+        double d2 = 0.;
+        for (int j = 0; j < P->dim; j++) d2 += (ce1[j]-ce2[j])*(ce1[j]-ce2[j]);
+        const nlo_order_formula F = pw_formula(P, *sv);
+        /* h = get_h_simplex (nonlocalOperator.pyx:114-118, 152-160): the longest edge, which is what hVector holds */
+        return quad_order(&F, P->H0, P->h[c1], P->h[c2], sqrt(d2));
+    }
+    int i = 0;
+    for (int k = common; k < nV; k++) { while (mask1 & (1 << i)) i++; perm1[k] = i; mask1 += (1 << i); }
+    i = 0;
+    for (int k = common; k < nV; k++) { while (mask2 & (1 << i)) i++; perm2[k] = i; mask2 += (1 << i); }
+    const int *t1 = P->dof_perm_table + perm_rank(perm1, nV)*dpe;
+    const int *t2 = P->dof_perm_table + perm_rank(perm2, nV)*dpe;
+    const int dpv = P->dofs_per_vertex, dped = P->dofs_per_edge;
+    for (int k = 0; k < dpe; k++) perm[k] = t1[k];
+    if (common == 1) {
+        for (int k = dpv; k < dpe; k++) perm[dpe+k-dpv] = dpe+t2[k];
+    } else if (common == 2) {
+        for (int k = 2*dpv; k < nV*dpv; k++) perm[dpe+k-2*dpv] = dpe+t2[k];
+        for (int k = nV*dpv+dped; k < dpe; k++) perm[dpe+k-2*dpv-dped] = dpe+t2[k];
+    }
+    return -common;
+}
+
+/* NA:222-253 addToMatrixElemElem */
+static void scatter_elem_elem(double *A, int64_t N, const int *ld, int n2, const double *contrib, double fac) {
+    int k = 0;
+    for (int p = 0; p < n2; p++) {
+        const int I = ld[p];
+        if (I >= 0) {
+            for (int q = 0; q < n2; q++) {
+                const int J = ld[q];
+                if (J >= 0) A[(int64_t)I*N+J] += fac*contrib[k];
+                k++;
+            }
+        } else k += n2;
+    }
+}
+
+/* boundary term with the pointwise kernel: NO:1022-1108, FL2:1324-1407, FL1:726-785 with kernel.evalPtr(x, y), x in the cell */
+static int panel_boundary_pw(const nlo_problem *P, int c1, int b, int *perm1, int *perm2, int *perm, double *sv) {
+    double s1[MAXV][2], s2[MAXV][2], ce1[2], ce2[2], vol2;
+    simplex_of(P, c1, s1, ce1);
+    facet_of(P, b, s2, ce2, &vol2);
+    *sv = pw_svalue_simplices(P, ce1, ce2, s1, P->dim+1, s2, P->dim);
+    nlo_problem Q = *P;
+    Q.nclasses = 0;
+    Q.bqo = pw_formula_boundary(P, *sv);
+    return nlo_panel_boundary(&Q, c1, b, perm1, perm2, perm);
+}
+
+static void eval_boundary_pw(const nlo_problem *P, int c1, int b, int panel, double sv, const int *perm1, const int *perm2,
+                             const int *perm, double *contrib, int64_t *nevals) {
+    const int dim = P->dim, nV = dim+1, nF = dim, dpe = P->dpe;
+    const int E = dpe*(dpe+1)/2;
+    double s1[MAXV][2], s2[MAXV][2], ce[2], vol2, nrm[2] = {0., 0.};
+    simplex_of(P, c1, s1, ce);
+    facet_of(P, b, s2, ce, &vol2);
+    if (dim == 2) {
+        nrm[0] = s2[1][1]-s2[0][1];
+        nrm[1] = s2[0][0]-s2[1][0];
+        double v = 1./sqrt(nrm[0]*nrm[0]+nrm[1]*nrm[1]);
+        nrm[0] *= v; nrm[1] *= v;
+    }
+    for (int k = 0; k < E; k++) contrib[k] = 0.;
+    if (panel >= 1) {
+        const int off = P->dist_off[panel], n = P->dist_off[panel+1]-off;
+        const int foff = P->bfacet_off[panel], nf = P->bfacet_off[panel+1]-foff;
+        const double *bary = P->dist_bary+3*off, *w = P->dist_w+off, *phi = P->dist_phi+(size_t)off*dpe;
+        const double *fb = P->bfacet_bary+2*foff, *fw = P->bfacet_w+foff;
+        const double vol = P->vol[c1]*vol2;
+        double *temp = (double*)malloc(sizeof(double)*(size_t)n*nf);
+        for (int k = 0; k < n; k++)
+            for (int m = 0; m < nf; m++) {
+                double x[2] = {0., 0.}, y[2] = {0., 0.}, wv[2], normW = 0., nw;
+                for (int l = 0; l < dim; l++) {
+                    for (int q = 0; q < nV; q++) x[l] += bary[3*k+q]*s1[q][l];
+                    for (int q = 0; q < nF; q++) y[l] += fb[2*m+q]*s2[q][l];
+                }
+                if (dim == 1) nw = 1.;
+                else {
+                    for (int l = 0; l < dim; l++) { wv[l] = y[l]-x[l]; normW += wv[l]*wv[l]; }
+                    normW = 1./sqrt(normW);
+                    nw = nrm[0]*wv[0]*normW + nrm[1]*wv[1]*normW;
+                }
+                temp[k*nf+m] = (w[k]*fw[m])*nw*pw_kernel(P, x, y, 1);
+            }
+        *nevals += (int64_t)n*nf;
+        int e = 0;
+        for (int I = 0; I < dpe; I++)
+            for (int J = I; J < dpe; J++) {
+                double val = 0.;
+                for (int k = 0; k < n; k++)
+                    for (int m = 0; m < nf; m++) val += temp[k*nf+m]*phi[k*dpe+I]*phi[k*dpe+J];
+                contrib[e++] = val*vol;
+            }
+        free(temp);
+        return;
+    }
+    const int slot = -panel-1, key = pw_key(P->pw_bkeys, P->pw_nbkeys, sv);
+    const int M = P->bsing_M[slot];
+    const double *nodes = P->pw_bnodes[slot]+(size_t)key*(nV+nF)*M, *w = P->pw_bw[slot]+(size_t)key*M;
+    const double *PHI = P->pw_bphi[slot]+(size_t)key*dpe*M;
+    const double vol = dim == 2 ? P->bsing_fac*P->vol[c1]*vol2 : P->bsing_fac*P->vol[c1];
+    double *temp = (double*)malloc(sizeof(double)*M);
+    for (int m = 0; m < M; m++) {
+        double x[2] = {0., 0.}, y[2] = {0., 0.}, wv[2] = {0., 0.}, normW = 0., nw = 1.;
+        for (int j = 0; j < dim; j++) {
+            for (int k = 0; k < nV; k++) x[j] += s1[perm1[k]][j]*nodes[(size_t)k*M+m];
+            for (int k = 0; k < nF; k++) y[j] += s2[perm2[k]][j]*nodes[(size_t)(nV+k)*M+m];
+            wv[j] = x[j]-y[j];
+            normW += wv[j]*wv[j];
+        }
+        if (dim == 2) {
+            double inv = 1./sqrt(normW);
+            nw = nrm[0]*wv[0]*inv + nrm[1]*wv[1]*inv;
+        }
+        temp[m] = w[m]*nw*pw_kernel(P, x, y, 1);
+    }
+    *nevals += M;
+    for (int I = 0; I < dpe; I++) {
+        int i = perm[I];
+        for (int J = I; J < dpe; J++) {
+            int j = perm[J];
+            int k = j < i ? dpe*j-(j*(j+1) >> 1)+i : dpe*i-(i*(i+1) >> 1)+j;
+            double val = 0.;
+            for (int m = 0; m < M; m++) val += temp[m]*PHI[(size_t)I*M+m]*PHI[(size_t)J*M+m];
+            contrib[k] = val*vol;
+        }
+    }
+    free(temp);
+}
+
+/* NA:1386-1448 with symmetricCells == symmetricLocalMatrix == False */
+int nlo_get_dense_nonsym(const nlo_problem *P, double *A, int zero_exterior, int cell_start, int cell_end,
+                         int64_t *counters, double *seconds, int store) {
+    const int dpe = P->dpe, nV = P->dim+1, n2 = 2*dpe;
+    const int64_t N = P->num_dofs;
+    if (dpe > MAXDPE || nV > MAXV || !P->pw_type) return -1;
+    double contrib[4*MAXDPE*MAXDPE];
+    int perm1[MAXV], perm2[MAXV], perm[2*MAXDPE], ld[2*MAXDPE];
+    memset(counters, 0, sizeof(int64_t)*NLO_NUM_COUNTERS);
+    double t0 = now_s();
+    for (int c1 = cell_start; c1 < cell_end; c1++)
+        for (int c2 = c1; c2 < P->nc; c2++) {
+            counters[0]++;
+            int skip = 1;
+            for (int p = 0; p < dpe; p++) skip = skip && P->dofs[c1*dpe+p] < 0 && P->dofs[c2*dpe+p] < 0;
+            if (skip) continue;
+            for (int orient = 0; orient < (c1 == c2 ? 1 : 2); orient++) {
+                const int a = orient ? c2 : c1, b = orient ? c1 : c2;     /* swapCells NA:1418 */
+                for (int p = 0; p < dpe; p++) { ld[p] = P->dofs[a*dpe+p]; ld[dpe+p] = P->dofs[b*dpe+p]; }
+                double sv, s1[MAXV][2], s2[MAXV][2], ce[2];
+                const int panel = panel_nonsym(P, a, b, perm1, perm2, perm, &sv);
+                if (panel >= 1 && (panel > P->qmax || P->dist_off[panel+1] == P->dist_off[panel])) return -(1000+panel);
+                simplex_of(P, a, s1, ce);
+                simplex_of(P, b, s2, ce);
+                if (!orient) {
+                    counters[1]++;
+                    if (panel >= 1) counters[8+panel]++; else counters[8+NLO_MAX_ORDER+(-panel-1)]++;
+                }
+                if (panel >= 1) {
+                    eval_distant_nonsym(P, s1, s2, P->vol[a]*P->vol[b], panel, contrib);
+                    const int n = P->dist_off[panel+1]-P->dist_off[panel];
+                    counters[2] += (int64_t)n*n;
+                } else
+                    eval_singular_nonsym(P, s1, s2, P->vol[a]*P->vol[b], -panel-1, pw_key(P->pw_keys, P->pw_nkeys, sv), perm1, perm2,
+                                         perm, contrib, &counters[2]);
+                if (store) scatter_elem_elem(A, N, ld, n2, contrib, 1.);
+            }
+        }
+    double t1 = now_s();
+    if (zero_exterior) {
+        for (int c1 = cell_start; c1 < cell_end; c1++) {
+            for (int p = 0; p < dpe; p++) ld[p] = P->dofs[c1*dpe+p];
+            for (int b = 0; b < P->nb; b++) {
+                double sv;
+                int panel = panel_boundary_pw(P, c1, b, perm1, perm2, perm, &sv);
+                if (panel >= 1 && (panel > P->qmax || P->dist_off[panel+1] == P->dist_off[panel]
+                                   || P->bfacet_off[panel+1] == P->bfacet_off[panel])) return -(2000+panel);
+                counters[3]++;
+                eval_boundary_pw(P, c1, b, panel, sv, perm1, perm2, perm, contrib, &counters[4]);
+                if (store) scatter_elem_elem_sym(A, N, ld, dpe, contrib, 1.);
+            }
+        }
+    }
+    double t2 = now_s();
+    if (seconds) { seconds[0] = t1-t0; seconds[1] = t2-t1; }
+    return 0;
 }
 
 /* CSR_LinearOperator.addToEntry / SSS_LinearOperator.addToEntry

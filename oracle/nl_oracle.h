@@ -79,6 +79,19 @@ typedef struct nlo_problem_s {
     int32_t nclasses, num_labels;
     const struct nlo_problem_s *classes;
     const int32_t *cell_labels, *facet_labels, *cls_of;
+
+    /* non-symmetric kernels with an order s(x) evaluated per quadrature point (fractionalLaplacian{1,2}D_nonsym with
+     * piecewise == False): pw_type 0 = off, 1 constant, 2 smoothStep(x0), 3 linearStep(x0), 4 smoothStepRadial
+     * (fractionalOrders.pyx:338-540; pw_p = sl, sr, r, interface | radius, slope).  Near rules are keyed by the pair's
+     * order (the reference keys its dictionary by the singularity value, FL2:957): pw_keys sorted, tables [nkeys][...]
+     * with the point count / row count of sing_M / sing_rows (bsing_M for the boundary twin). */
+    int32_t pw_type, pw_normalized;
+    double pw_p[6];
+    double pw_c0, pw_bc0;             /* constant term of the interior / boundary order formula */
+    int32_t pw_nkeys, pw_nbkeys;
+    const double *pw_keys, *pw_bkeys;
+    const double *pw_nodes[3], *pw_w[3], *pw_phi0[3], *pw_phi1[3];
+    const double *pw_bnodes[2], *pw_bw[2], *pw_bphi[2];
 } nlo_problem;
 
 /* counters[0] pairs visited, [1] pairs assembled (panel != IGNORED, not all-boundary),
@@ -98,6 +111,12 @@ int nlo_get_dense(const nlo_problem *P, double *A, int zero_exterior, int cell_s
 /* same loops, only counting (for sampling the cost of a sub-range without storing A): A may be NULL */
 int nlo_get_dense_rows(const nlo_problem *P, double *A, int zero_exterior, int cell_start, int cell_end,
                        int64_t *counters, double *seconds, int store);
+/* non-symmetric local matrices (symmetricCells == symmetricLocalMatrix == False): both orientations of every pair are
+ * evaluated and scattered with addToMatrixElemElem (NA:1411-1428, 222-253); counters as nlo_get_dense */
+int nlo_get_dense_nonsym(const nlo_problem *P, double *A, int zero_exterior, int cell_start, int cell_end,
+                         int64_t *counters, double *seconds, int store);
+double nlo_pw_order(const nlo_problem *P, const double *x);
+double nlo_pw_svalue(const nlo_problem *P, int c1, int c2);
 /* H2 near field (NA:1663-1964): masked interior pairs (NA:1812-1832 with the scatter NA:503-520) into CSR (diag == NULL)
  * or SSS (strict lower triangle in data + diag); entries absent from the pattern are dropped like the reference's addToEntry.
  * pairs[np][2] with c1 <= c2, masks[np][4] (256-bit MASK_t).  counters: [0] pairs, [1] assembled, [2] kernel evaluations. */

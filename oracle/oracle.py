@@ -47,7 +47,12 @@ class nlo_problem(C.Structure):
                 ('bsing_M', C.c_int32*2), ('bpad', C.c_int32*2),
                 ('bsing_nodes', _P*2), ('bsing_w', _P*2), ('bsing_phi', _P*2), ('bsing_fac', C.c_double),
                 ('nclasses', C.c_int32), ('num_labels', C.c_int32), ('classes', _P), ('cell_labels', _P), ('facet_labels', _P),
-                ('cls_of', _P)]
+                ('cls_of', _P),
+                ('pw_type', C.c_int32), ('pw_normalized', C.c_int32), ('pw_p', C.c_double*6),
+                ('pw_c0', C.c_double), ('pw_bc0', C.c_double), ('pw_nkeys', C.c_int32), ('pw_nbkeys', C.c_int32),
+                ('pw_keys', _P), ('pw_bkeys', _P),
+                ('pw_nodes', _P*3), ('pw_w', _P*3), ('pw_phi0', _P*3), ('pw_phi1', _P*3),
+                ('pw_bnodes', _P*2), ('pw_bw', _P*2), ('pw_bphi', _P*2)]
 
 
 def build():
@@ -73,6 +78,10 @@ def lib():
         L.nlo_eval_boundary.argtypes = [C.POINTER(nlo_problem), C.c_int, C.c_int, C.c_int, ip, ip, ip, _P, _P]
         L.nlo_get_dense_rows.restype = C.c_int
         L.nlo_get_dense_rows.argtypes = [C.POINTER(nlo_problem), _P, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int]
+        L.nlo_get_dense_nonsym.restype = C.c_int
+        L.nlo_get_dense_nonsym.argtypes = [C.POINTER(nlo_problem), _P, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int]
+        L.nlo_pw_svalue.restype = C.c_double
+        L.nlo_pw_svalue.argtypes = [C.POINTER(nlo_problem), C.c_int, C.c_int]
         L.nlo_assemble_pairs_masked.restype = C.c_int
         L.nlo_assemble_pairs_masked.argtypes = [C.POINTER(nlo_problem), C.c_int, _P, _P, _P, _P, _P, _P, _P]
         L.nlo_assemble_boundary_masked.restype = C.c_int
@@ -130,13 +139,40 @@ class OracleProblem:
         P.h = ptr(mesh.hVector, np.float64)
         P.H0 = T.H0
         P.dof_perm_table = ptr(T.dof_perm_table, np.int32)
-        P.kernel = _kern(T.kernel)
-        P.qo = _qo(T.qo)
+        self.pointwise = bool(getattr(T, 'pointwise', False))
+        if not self.pointwise:
+            P.kernel = _kern(T.kernel)
+            P.qo = _qo(T.qo)
         P.qmax = T.qcap
         P.dist_off = ptr(T.dist_off, np.int32)
         P.dist_bary = ptr(T.dist_bary, np.float64)
         P.dist_w = ptr(T.dist_w, np.float64)
         P.dist_phi = ptr(T.dist_phi, np.float64)
+        if self.pointwise:
+            # non-symmetric kernel with an order per quadrature point: order function, near rules per distinct pair order
+            R = T.pw_rules()
+            P.pw_type, P.pw_normalized = T.order_type, int(T.kernel.normalized)
+            for i, v in enumerate(T.order_params):
+                P.pw_p[i] = v
+            P.pw_c0, P.pw_bc0 = T.pw_c0, T.pw_bc0
+            P.pw_nkeys, P.pw_nbkeys = len(R['keys']), len(R['bkeys'])
+            P.pw_keys, P.pw_bkeys = ptr(R['keys'], np.float64), ptr(R['bkeys'], np.float64)
+            for slot, (nodes, w, phi0, phi1) in R['rules'].items():
+                P.sing_M[slot], P.sing_rows[slot] = w.shape[1], phi0.shape[1]
+                P.pw_nodes[slot], P.pw_w[slot] = ptr(nodes, np.float64), ptr(w, np.float64)
+                P.pw_phi0[slot], P.pw_phi1[slot] = ptr(phi0, np.float64), ptr(phi1, np.float64)
+            for slot, (nodes, w, phi) in R['brules'].items():
+                P.bsing_M[slot] = w.shape[1]
+                P.pw_bnodes[slot], P.pw_bw[slot], P.pw_bphi[slot] = ptr(nodes, np.float64), ptr(w, np.float64), ptr(phi, np.float64)
+            P.sing_fac, P.bsing_fac = T.sing_fac, T.bsing_fac
+            P.bfacet_off = ptr(T.bfacet_off, np.int32)
+            P.bfacet_bary = ptr(T.bfacet_bary, np.float64)
+            P.bfacet_w = ptr(T.bfacet_w, np.float64)
+            P.nb = T.bcells.shape[0]
+            P.bcells = ptr(T.bcells, np.int32)
+            self.E = (2*T.dpe)**2
+            self.nV = T.dim+1
+            return
         for panel, r in T.singular.items():
             slot = -panel-1
             P.sing_M[slot], P.sing_rows[slot] = r.num_nodes, r.rows
@@ -197,8 +233,9 @@ class OracleProblem:
         A = np.zeros((N, N)) if store else None
         counters = np.zeros(NLO_NUM_COUNTERS, dtype=np.int64)
         seconds = np.zeros(2)
-        rc = lib().nlo_get_dense_rows(C.byref(self.P), A.ctypes.data if store else None, int(T.zeroExterior),
-                                      cell_start, cell_end, counters.ctypes.data, seconds.ctypes.data, int(store))
+        fun = lib().nlo_get_dense_nonsym if getattr(self, 'pointwise', False) else lib().nlo_get_dense_rows
+        rc = fun(C.byref(self.P), A.ctypes.data if store else None, int(T.zeroExterior),
+                 cell_start, cell_end, counters.ctypes.data, seconds.ctypes.data, int(store))
         if rc != 0:
             raise RuntimeError('oracle failed with code {}'.format(rc))
         hist = {q: int(counters[8+q]) for q in range(NLO_MAX_ORDER) if counters[8+q]}

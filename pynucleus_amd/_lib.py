@@ -28,7 +28,8 @@ EXPORTS = ['pnl_create', 'pnl_destroy', 'pnl_error_string', 'pnl_version', 'pnl_
            'pnl_upload_mesh', 'pnl_upload_dofmap', 'pnl_set_kernel', 'pnl_set_order_formula', 'pnl_upload_distant_rules',
            'pnl_upload_singular_rule', 'pnl_upload_boundary', 'pnl_assemble_dense', 'pnl_tile_cells',
            'pnl_assemble_dense_tiles', 'pnl_get_counters', 'pnl_get_phase_ms', 'pnl_gemv', 'pnl_cg_jacobi',
-           'pnl_inv_diagonal', 'pnl_set_classes', 'pnl_select_class', 'pnl_upload_sparsity', 'pnl_assemble_pairs_masked', 'pnl_assemble_boundary_masked', 'pnl_assemble_clusters_tiled', 'pnl_h2_setup', 'pnl_h2_matvec', 'pnl_spmv']
+           'pnl_inv_diagonal', 'pnl_set_classes', 'pnl_select_class', 'pnl_upload_sparsity', 'pnl_assemble_pairs_masked', 'pnl_assemble_boundary_masked', 'pnl_assemble_clusters_tiled', 'pnl_h2_setup', 'pnl_h2_matvec', 'pnl_spmv',
+           'pnl_set_order_function', 'pnl_upload_pointwise_rules', 'pnl_assemble_dense_pointwise']
 
 
 class pnl_kernel(C.Structure):
@@ -39,6 +40,10 @@ class pnl_kernel(C.Structure):
 class pnl_order_formula(C.Structure):
     _fields_ = [('c0', C.c_double), ('a', C.c_double), ('b', C.c_double), ('e', C.c_double), ('den0', C.c_double),
                 ('clip_num', C.c_int32), ('pad', C.c_int32)]
+
+
+class pnl_order_function(C.Structure):
+    _fields_ = [('type', C.c_int32), ('normalized', C.c_int32), ('p', C.c_double*6)]
 
 
 class pnl_cluster_plan(C.Structure):
@@ -105,6 +110,9 @@ def load():
     L.pnl_assemble_clusters_tiled.argtypes = [vp, C.POINTER(pnl_cluster_plan), i32, vp, vp]
     L.pnl_h2_setup.argtypes = [vp, C.POINTER(pnl_h2_plan)]
     L.pnl_h2_matvec.argtypes = [vp, vp, vp]
+    L.pnl_set_order_function.argtypes = [vp, C.POINTER(pnl_order_function), vp, vp, dbl, dbl, dbl, dbl]
+    L.pnl_upload_pointwise_rules.argtypes = [vp, i32, i32, i32, i32, i32, vp, vp, vp, vp]
+    L.pnl_assemble_dense_pointwise.argtypes = [vp, vp, i64, i32, i32, i32, i32, vp, i32, vp]
     for name in EXPORTS:
         f = getattr(L, name)
         if name not in ('pnl_destroy', 'pnl_error_string', 'pnl_version'):
@@ -175,6 +183,29 @@ class Context:
         if T.has_boundary_tables:
             bc, pbc = _hp(T.bcells, np.int32)
             self.check(L.pnl_upload_boundary(h, bc.shape[0], pbc))
+        if getattr(T, 'pointwise', False):
+            # non-symmetric kernel, order per quadrature point: order function, per-cell / per-facet maxima, near rules per
+            # distinct order of the touching pairs
+            self.check(L.pnl_set_classes(h, 1, 0, None, None, None))
+            f = pnl_order_function(int(T.order_type), int(T.kernel.normalized), (C.c_double*6)(*[float(x) for x in T.order_params]))
+            cs, pcs = _hp(T.cell_smax, np.float64)
+            fs, pfs = _hp(T.facet_smax, np.float64)
+            self.check(L.pnl_set_order_function(h, C.byref(f), pcs, pfs, float(T.pw_c0), float(T.pw_bc0), float(T.sing_fac),
+                                                float(T.bsing_fac)))
+            R = T.pw_rules()
+            for slot, (nodes, ww, phi0, phi1) in R['rules'].items():
+                n, pn = _hp(nodes, np.float64)
+                w_, pw_ = _hp(ww, np.float64)
+                a0, p0 = _hp(phi0, np.float64)
+                a1, p1 = _hp(phi1, np.float64)
+                self.check(L.pnl_upload_pointwise_rules(h, PNL_INTERIOR, -(slot+1), n.shape[0], w_.shape[1], a0.shape[1], pn, pw_, p0, p1))
+            for slot, (nodes, ww, phi) in R['brules'].items():
+                n, pn = _hp(nodes, np.float64)
+                w_, pw_ = _hp(ww, np.float64)
+                a0, p0 = _hp(phi, np.float64)
+                self.check(L.pnl_upload_pointwise_rules(h, PNL_BOUNDARY, -(slot+1), n.shape[0], w_.shape[1], a0.shape[1], pn, pw_, p0, None))
+            self._pw_pairs = (np.ascontiguousarray(R['pairs'], dtype=np.int32), np.ascontiguousarray(R['bpairs'], dtype=np.int32))
+            return
         classes = getattr(T, 'classes', None)
         if classes:
             cl, pcl = _hp(T.cell_labels, np.int32)
@@ -209,6 +240,12 @@ class Context:
         self.check(self.L.pnl_set_order_formula(self.h, which, C.byref(f)))
 
     # -- hot path --------------------------------------------------------
+    def assemble_dense_pointwise(self, A_ptr, ldA, zero_exterior, cell_begin, cell_end):
+        pairs, bpairs = self._pw_pairs
+        self.check(self.L.pnl_assemble_dense_pointwise(self.h, C.c_void_p(A_ptr), int(ldA), int(bool(zero_exterior)), int(cell_begin),
+                                                       int(cell_end), pairs.shape[0], pairs.ctypes.data, bpairs.shape[0],
+                                                       bpairs.ctypes.data))
+
     def set_stream(self, stream_ptr):
         self.check(self.L.pnl_set_stream(self.h, C.c_void_p(stream_ptr)))
 

@@ -88,6 +88,10 @@ class nonlocalBuilder:
         self._ctx.set_stream(torch.cuda.current_stream(self._ctx.device).cuda_stream)
         return self._ctx
 
+    def _symmetric_only(self, what):
+        if getattr(self.tables, 'pointwise', False):
+            raise NotImplementedError('{} for non-symmetric kernels with an order per quadrature point (getDense only)'.format(what))
+
     def _rank_size(self):
         if self.comm is None:
             return 0, 1
@@ -116,11 +120,16 @@ class nonlocalBuilder:
         dev = torch.device('cuda', ctx.device)
         N = self.dm.num_dofs
         nc = self.mesh.num_cells
-        self.PLogger.addValue('useSymmetricCells', True)
-        self.PLogger.addValue('useSymmetricLocalMatrix', True)
+        pointwise = bool(getattr(self.tables, 'pointwise', False))
+        self.PLogger.addValue('useSymmetricCells', not pointwise)
+        self.PLogger.addValue('useSymmetricLocalMatrix', not pointwise)
         A = torch.zeros((N, N), dtype=torch.float64, device=dev)
         rank, size = self._rank_size()
-        if size == 1:
+        if pointwise:
+            # non-symmetric kernel, order per quadrature point (NA:1411-1428): the reference's cellNo1 split across ranks
+            start, end = cell_range_of_rank(nc, rank, size)
+            ctx.assemble_dense_pointwise(A.data_ptr(), A.stride(0), self.zeroExterior, start, end)
+        elif size == 1:
             ctx.assemble_dense(A.data_ptr(), A.stride(0), self.zeroExterior, 0, nc)
         else:
             tiles = self.tiles_for_rank(rank, size)
@@ -152,6 +161,7 @@ class nonlocalBuilder:
         pairs inside the support of phi_I plus the Gauss-theorem term over the boundary of the support.  One masked
         assembly on the GPU into a diagonal-only SSS pattern; returns the diagonal as a numpy vector wrapped like the
         reference's diagonalOperator (``.data``, ``.diagonal``)."""
+        self._symmetric_only('getDiagonal')
         from . import clusters
         from .linear_operators import diagonalOperator
         Pnear = clusters.singleDoFClusters(self.dm)
@@ -161,6 +171,7 @@ class nonlocalBuilder:
     def getEntry(self, I, J):
         """NA:1538-1661: the entry A[I, J] alone: element pairs of (supp phi_I u supp phi_J)^2 and, with zeroExterior,
         the Gauss-theorem term over the boundary of that union, assembled on the GPU into a one-entry pattern."""
+        self._symmetric_only('getEntry')
         import torch
         from . import clusters
         from .linear_operators import CSR_LinearOperator
@@ -209,6 +220,7 @@ class nonlocalBuilder:
         (REMOTE / INTERACT / CUT, getRelativePosition), integrated (cut pairs through the sub-simplex loops NO:790-847) and
         scattered without masks into the sparsity pattern of all DoF pairs that share such an element pair.  Symmetric
         storage (SSS) unless params['forceUnsymmetric']."""
+        self._symmetric_only('getSparse')
         import torch
         import scipy.sparse as sp
         from .linear_operators import CSR_LinearOperator, SSS_LinearOperator
@@ -269,6 +281,7 @@ class nonlocalBuilder:
         Without an admissible pair the dense operator is returned (the reference's assembleDenseWhenH2Fails branch).  With a
         communicator (row-sharded near field) the near-field operator alone is returned: the far field is not
         distributed yet."""
+        self._symmetric_only('getH2')
         from . import clusters
         from .h2 import h2Plan, H2Matrix, interpolationOrder
         rp = self.getH2RefinementParams()
@@ -309,6 +322,7 @@ class nonlocalBuilder:
         (buildMasksForClusters NA:260-391) and the item list of the cluster-local Gauss-theorem term
         (NA:1842-1889).  Device side: classification, quadrature and masked scatter into CSR / SSS.
         Without zeroExterior the global Omega x Omega^c term is subtracted again (NA:1896-1913)."""
+        self._symmetric_only('assembleClusters')
         import torch
         from . import clusters
         from .linear_operators import CSR_LinearOperator, SSS_LinearOperator

@@ -13,6 +13,7 @@
 #include <vector>
 #include "pnl_hip.h"
 #include "pnl_kernels.h"
+#include "pnl_pointwise.h"
 
 namespace {
 
@@ -66,6 +67,12 @@ struct pnl_context {
         b_bi_masks, b_cp[28], b_cpD, b_wlds, b_wlpair, b_h2[20];
     H2Dev h2;
     bool have_h2 = false;
+    // non-symmetric kernels with an order per quadrature point (pnl_set_order_function)
+    PwDev pw;
+    bool have_pw = false, have_pw_rules[2][3] = {{false, false, false}, {false, false, false}};
+    int pw_nkeys[2] = {0, 0};
+    std::vector<double> pw_cell_smax, pw_facet_smax;
+    DevBuf b_pw_csm, b_pw_fsm, b_pw_rule[2][3][4], b_pw_pairs, b_pw_bpairs;
     std::vector<std::vector<int>> h2_levels;   // nodes of every level >= 1
     std::vector<size_t> h2_level_off;
     int sp_nnz = -1;                // near-field sparsity pattern (pnl_upload_sparsity)
@@ -1015,6 +1022,102 @@ k_cg_dir(const double *__restrict__ scal, const double *__restrict__ z, int n, d
 }  // namespace
 
 // =================================================================================================
+namespace {
+template <int DIM>
+int pointwise_impl(pnl_context *ctx, double *A, int64_t ldA, int zero_exterior, int cell_begin, int cell_end, int npairs,
+                   int nbpairs) {
+    constexpr int NV = DIM+1, DPE = NV, ND = DPE*(DPE+1)/2, ST = 4+DPE;
+    int rc;
+    DevProblem &P = ctx->P;
+    P.qmax = ctx->qmax;
+    P.off = (const int*)ctx->b_off.p; P.bary = (const double*)ctx->b_bary.p; P.w = (const double*)ctx->b_w.p;
+    P.phi = (const double*)ctx->b_phi.p; P.foff = (const int*)ctx->b_foff.p; P.fbary = (const double*)ctx->b_fbary.p;
+    P.fw = (const double*)ctx->b_fw.p;
+    P.cur_class = -1;
+    const PwDev &W = ctx->pw;
+    HIPCHK(ctx, hipMemsetAsync(ctx->b_counters.p, 0, sizeof(unsigned long long)*PNL_NCOUNTERS, ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(ctx->b_D.p, 0, sizeof(double)*(size_t)ctx->ncp*ND, ctx->stream));
+    HIPCHK(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
+    ctx->tiles_launched = true; ctx->pure_launched = false;
+    const int nbk = (ctx->nc+63)/64;
+    {
+        // all pairs of the cell range may end up in the list
+        double pairs = 0.;
+        for (long long c = cell_begin; c < cell_end; c++) pairs += (double)(ctx->nc-c);
+        const size_t want = (size_t)std::max<double>(pairs, 1024.);
+        if (want > 1500000000ull) return fail(ctx, PNL_ERR_UNSUPPORTED, "%zu pairs exceed the work list of the pointwise path", want);
+        if (ctx->wl_cap < want) {
+            if ((rc = ensure(ctx, ctx->b_wl, want*sizeof(int4)))) return rc;
+            ctx->wl_cap = (unsigned)want;
+        }
+        if ((rc = ensure(ctx, ctx->b_wlsorted, (size_t)ctx->wl_cap*sizeof(int4)))) return rc;
+        if ((rc = ensure(ctx, ctx->b_wlcount, sizeof(unsigned)))) return rc;
+        if ((rc = ensure(ctx, ctx->b_wlaux, sizeof(unsigned)*(4*(PNL_WL_BINS+1))))) return rc;
+        HIPCHK(ctx, hipMemsetAsync(ctx->b_wlcount.p, 0, sizeof(unsigned), ctx->stream));
+    }
+    hipLaunchKernelGGL((k_pw_classify<DIM>), dim3((unsigned)((long long)nbk*(nbk+1)/2)), dim3(PNL_NTHREADS), 0, ctx->stream, P, W,
+                       (int4*)ctx->b_wl.p, (unsigned*)ctx->b_wlcount.p, ctx->wl_cap, cell_begin, cell_end);
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipEventRecord(ctx->ev[7], ctx->stream));
+    HIPCHK(ctx, hipEventRecord(ctx->ev[6], ctx->stream));
+    {
+        unsigned *hist = (unsigned*)ctx->b_wlaux.p, *offs = hist+(PNL_WL_BINS+1), *coff = offs+(PNL_WL_BINS+1), *cursor = coff+(PNL_WL_BINS+1);
+        HIPCHK(ctx, hipMemsetAsync(hist, 0, sizeof(unsigned)*(PNL_WL_BINS+1), ctx->stream));
+        const int4 *wl = (const int4*)ctx->b_wl.p;
+        const unsigned *wlc = (const unsigned*)ctx->b_wlcount.p;
+        hipLaunchKernelGGL(k_wl_hist, dim3(512), dim3(PNL_NTHREADS), 0, ctx->stream, wl, wlc, ctx->wl_cap, hist);
+        hipLaunchKernelGGL(k_wl_scan, dim3(1), dim3(64), 0, ctx->stream, (const unsigned*)hist, offs, coff, cursor);
+        hipLaunchKernelGGL(k_wl_scatter, dim3(512), dim3(PNL_NTHREADS), 0, ctx->stream, wl, wlc, ctx->wl_cap, (const unsigned*)offs, cursor,
+                           (int4*)ctx->b_wlsorted.p);
+        // LDS: rule table + order / scaling of the second cell's points for the 16 pairs of a chunk
+        const int tab_max = 256;
+        const size_t lds = sizeof(double)*((size_t)tab_max*ST+(size_t)(PNL_NTHREADS/16)*tab_max*2);
+        auto kfun = k_pw_distant<DIM>;
+        HIPCHK(ctx, hipFuncSetAttribute((const void*)kfun, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kfun, dim3(256*4), dim3(PNL_NTHREADS), lds, ctx->stream, P, W, (const int4*)ctx->b_wlsorted.p,
+                           (const unsigned*)offs, A, (long long)ldA, (double*)ctx->b_D.p, tab_max);
+        HIPCHK(ctx, hipGetLastError());
+    }
+    HIPCHK(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
+    HIPCHK(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
+    if (npairs > 0) {
+        const unsigned grid = (unsigned)((2ll*npairs*64+PNL_NTHREADS-1)/PNL_NTHREADS);
+        const int4 *pp = (const int4*)ctx->b_pw_pairs.p;
+        hipLaunchKernelGGL((k_pw_singular<DIM, 0>), dim3(grid), dim3(PNL_NTHREADS), 0, ctx->stream, P, W, pp, npairs, A, (long long)ldA, cell_begin, cell_end);
+        hipLaunchKernelGGL((k_pw_singular<DIM, 1>), dim3(grid), dim3(PNL_NTHREADS), 0, ctx->stream, P, W, pp, npairs, A, (long long)ldA, cell_begin, cell_end);
+        if (DIM == 2)
+            hipLaunchKernelGGL((k_pw_singular<DIM, (DIM == 2 ? 2 : 1)>), dim3(grid), dim3(PNL_NTHREADS), 0, ctx->stream, P, W, pp, npairs, A, (long long)ldA, cell_begin, cell_end);
+        HIPCHK(ctx, hipGetLastError());
+    }
+    HIPCHK(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
+    if (zero_exterior && cell_end > cell_begin) {
+        const int ncell = cell_end-cell_begin, gx = (ncell+PNL_NTHREADS-1)/PNL_NTHREADS;
+        int per = 16;
+        while (per > 1 && (long long)gx*((ctx->nb+per-1)/per) < 4096) per >>= 1;
+        hipLaunchKernelGGL((k_pw_boundary_distant<DIM>), dim3(gx, (ctx->nb+per-1)/per), dim3(PNL_NTHREADS), 0, ctx->stream, P, W,
+                           (double*)ctx->b_D.p, cell_begin, cell_end, per);
+        if (nbpairs > 0) {
+            const unsigned grid = (unsigned)(((long long)nbpairs*64+PNL_NTHREADS-1)/PNL_NTHREADS);
+            const int4 *bp = (const int4*)ctx->b_pw_bpairs.p;
+            hipLaunchKernelGGL((k_pw_boundary_singular<DIM, 0>), dim3(grid), dim3(PNL_NTHREADS), 0, ctx->stream, P, W, bp, nbpairs, (double*)ctx->b_D.p, cell_begin, cell_end);
+            if (DIM == 2)
+                hipLaunchKernelGGL((k_pw_boundary_singular<DIM, (DIM == 2 ? 1 : 0)>), dim3(grid), dim3(PNL_NTHREADS), 0, ctx->stream, P, W, bp, nbpairs, (double*)ctx->b_D.p, cell_begin, cell_end);
+        }
+        HIPCHK(ctx, hipGetLastError());
+    }
+    HIPCHK(ctx, hipEventRecord(ctx->ev[4], ctx->stream));
+    {
+        const long long nt = (long long)ctx->nc*DPE*DPE;
+        hipLaunchKernelGGL((k_scatter_diag<DPE>), dim3((unsigned)((nt+PNL_NTHREADS-1)/PNL_NTHREADS)), dim3(PNL_NTHREADS), 0,
+                           ctx->stream, P, (const double*)ctx->b_D.p, A, (long long)ldA);
+        HIPCHK(ctx, hipGetLastError());
+    }
+    HIPCHK(ctx, hipEventRecord(ctx->ev[5], ctx->stream));
+    ctx->ev_valid = true;
+    return PNL_OK;
+}
+}  // namespace
+
 extern "C" {
 
 const char *pnl_version(void) { return "pnl_hip 0.1 (gfx950)"; }
@@ -1698,6 +1801,105 @@ int pnl_inv_diagonal(pnl_context *ctx, const double *A, int64_t ldA, int n, doub
     hipLaunchKernelGGL(k_diag_inv, dim3((n+PNL_NTHREADS-1)/PNL_NTHREADS), dim3(PNL_NTHREADS), 0, ctx->stream, A, (long long)ldA, n, dinv);
     HIPCHK(ctx, hipGetLastError());
     return PNL_OK;
+}
+
+// ---- non-symmetric kernels with an order s(x) per quadrature point ------------------------------------------------------
+int pnl_set_order_function(pnl_context *ctx, const pnl_order_function *f, const double *cell_smax, const double *facet_smax,
+                           double c0, double bc0, double sing_fac, double bsing_fac) {
+    if (!ctx || !f || !cell_smax) return fail(ctx, PNL_ERR_INVALID, "bad order-function arguments");
+    if (!ctx->have_mesh) return fail(ctx, PNL_ERR_STATE, "upload the mesh first");
+    if (f->type < 1 || f->type > 4) return fail(ctx, PNL_ERR_UNSUPPORTED, "order function type %d is not implemented", f->type);
+    if (ctx->have_dofs && ctx->dpe != ctx->dim+1) return fail(ctx, PNL_ERR_UNSUPPORTED, "pointwise variable orders are built for P1 elements");
+    std::memset(&ctx->pw, 0, sizeof(ctx->pw));
+    ctx->pw.type = f->type; ctx->pw.normalized = f->normalized;
+    for (int i = 0; i < 6; i++) ctx->pw.p[i] = f->p[i];
+    ctx->pw.c0 = c0; ctx->pw.bc0 = bc0; ctx->pw.sfac = sing_fac; ctx->pw.bfac = bsing_fac;
+    ctx->pw_cell_smax.assign(cell_smax, cell_smax+ctx->nc);
+    ctx->pw_facet_smax.clear();
+    if (facet_smax && ctx->have_boundary) ctx->pw_facet_smax.assign(facet_smax, facet_smax+ctx->nb);
+    for (int w = 0; w < 2; w++) for (int s = 0; s < 3; s++) ctx->have_pw_rules[w][s] = false;
+    ctx->have_pw = true;
+    return PNL_OK;
+}
+
+int pnl_upload_pointwise_rules(pnl_context *ctx, int which, int panel, int nkeys, int M, int rows, const double *nodes,
+                               const double *w, const double *phi0, const double *phi1) {
+    if (!ctx) return PNL_ERR_INVALID;
+    if (!ctx->have_pw || !ctx->have_dofs) return fail(ctx, PNL_ERR_STATE, "set the order function and the DoF map first");
+    const int slot = -panel-1, dim = ctx->dim, nV = dim+1, dpe = ctx->dpe;
+    const int nslots = which == PNL_INTERIOR ? nV : dim;
+    if (which < 0 || which > 1 || slot < 0 || slot >= nslots || nkeys <= 0 || M <= 0 || !nodes || !w || !phi0 ||
+        (which == PNL_INTERIOR && !phi1))
+        return fail(ctx, PNL_ERR_INVALID, "bad pointwise-rule arguments");
+    int rc;
+    if (which == PNL_INTERIOR) {
+        const int common = slot+1;
+        const int expect = common == nV ? dpe : (common == 1 ? 2*dpe-1 : 2*dpe-2);
+        if (rows != expect) return fail(ctx, PNL_ERR_INVALID, "pointwise rule has %d rows, expected %d", rows, expect);
+        if ((rc = upload(ctx, ctx->b_pw_rule[0][slot][0], nodes, (size_t)nkeys*2*nV*M))) return rc;
+        if ((rc = upload(ctx, ctx->b_pw_rule[0][slot][1], w, (size_t)nkeys*M))) return rc;
+        if ((rc = upload(ctx, ctx->b_pw_rule[0][slot][2], phi0, (size_t)nkeys*rows*M))) return rc;
+        if ((rc = upload(ctx, ctx->b_pw_rule[0][slot][3], phi1, (size_t)nkeys*rows*M))) return rc;
+        ctx->pw.M[slot] = M; ctx->pw.rows[slot] = rows;
+        ctx->pw.nodes[slot] = (const double*)ctx->b_pw_rule[0][slot][0].p; ctx->pw.w[slot] = (const double*)ctx->b_pw_rule[0][slot][1].p;
+        ctx->pw.phi0[slot] = (const double*)ctx->b_pw_rule[0][slot][2].p; ctx->pw.phi1[slot] = (const double*)ctx->b_pw_rule[0][slot][3].p;
+    } else {
+        if (rows != dpe) return fail(ctx, PNL_ERR_INVALID, "pointwise boundary rule has %d rows, expected %d", rows, dpe);
+        if ((rc = upload(ctx, ctx->b_pw_rule[1][slot][0], nodes, (size_t)nkeys*(nV+dim)*M))) return rc;
+        if ((rc = upload(ctx, ctx->b_pw_rule[1][slot][1], w, (size_t)nkeys*M))) return rc;
+        if ((rc = upload(ctx, ctx->b_pw_rule[1][slot][2], phi0, (size_t)nkeys*rows*M))) return rc;
+        ctx->pw.bM[slot] = M;
+        ctx->pw.bnodes[slot] = (const double*)ctx->b_pw_rule[1][slot][0].p; ctx->pw.bw[slot] = (const double*)ctx->b_pw_rule[1][slot][1].p;
+        ctx->pw.bphi[slot] = (const double*)ctx->b_pw_rule[1][slot][2].p;
+    }
+    ctx->pw_nkeys[which] = nkeys;
+    ctx->have_pw_rules[which][slot] = true;
+    return PNL_OK;
+}
+
+
+int pnl_assemble_dense_pointwise(pnl_context *ctx, double *A, int64_t ldA, int zero_exterior, int cell_begin, int cell_end,
+                                 int npairs, const int32_t *pairs, int nbpairs, const int32_t *bpairs) {
+    if (!ctx) return PNL_ERR_INVALID;
+    int rc;
+    if (!ctx->have_pw || !ctx->have_rules) return fail(ctx, PNL_ERR_STATE, "order function and distant rules must be set before assembling");
+    if ((rc = finalize(ctx))) return rc;
+    if (ctx->dpe != ctx->dim+1) return fail(ctx, PNL_ERR_UNSUPPORTED, "pointwise variable orders are built for P1 elements");
+    if (!A || ldA < ctx->N) return fail(ctx, PNL_ERR_INVALID, "bad output matrix (ldA=%lld, num_dofs=%d)", (long long)ldA, ctx->N);
+    if (cell_begin < 0 || cell_end > ctx->nc || cell_begin > cell_end) return fail(ctx, PNL_ERR_INVALID, "bad cell range");
+    if (npairs < 0 || nbpairs < 0 || (npairs && !pairs) || (nbpairs && !bpairs)) return fail(ctx, PNL_ERR_INVALID, "bad pair lists");
+    for (int s = 0; s <= ctx->dim; s++)
+        if (!ctx->have_pw_rules[0][s]) return fail(ctx, PNL_ERR_STATE, "pointwise rule for %d common vertices not uploaded", s+1);
+    if (zero_exterior) {
+        if (!ctx->have_boundary || (int)ctx->pw_facet_smax.size() != ctx->nb)
+            return fail(ctx, PNL_ERR_STATE, "zero_exterior needs boundary facets and their orders");
+        for (int s = 0; s < ctx->dim; s++)
+            if (!ctx->have_pw_rules[1][s]) return fail(ctx, PNL_ERR_STATE, "pointwise boundary rule for %d common vertices not uploaded", s+1);
+    }
+    for (int t = 0; t < npairs; t++) {
+        const int32_t *q = pairs+4*(size_t)t;
+        if (q[0] < 0 || q[1] < q[0] || q[1] >= ctx->nc || q[2] < 1 || q[2] > ctx->dim+1 || q[3] < 0 || q[3] >= ctx->pw_nkeys[0])
+            return fail(ctx, PNL_ERR_INVALID, "bad touching pair %d", t);
+    }
+    for (int t = 0; t < nbpairs; t++) {
+        const int32_t *q = bpairs+4*(size_t)t;
+        if (q[0] < 0 || q[0] >= ctx->nc || q[1] < 0 || q[1] >= ctx->nb || q[2] < 1 || q[2] > ctx->dim || q[3] < 0 || q[3] >= ctx->pw_nkeys[1])
+            return fail(ctx, PNL_ERR_INVALID, "bad touching cell/facet pair %d", t);
+    }
+    {
+        std::vector<double> sm(ctx->ncp, 0.);
+        std::copy(ctx->pw_cell_smax.begin(), ctx->pw_cell_smax.end(), sm.begin());
+        if ((rc = upload(ctx, ctx->b_pw_csm, sm.data(), sm.size()))) return rc;
+        if ((rc = upload(ctx, ctx->b_pw_fsm, ctx->pw_facet_smax.data(), ctx->pw_facet_smax.size()))) return rc;
+        if ((rc = upload(ctx, ctx->b_pw_pairs, pairs, (size_t)4*npairs))) return rc;
+        if ((rc = upload(ctx, ctx->b_pw_bpairs, bpairs, (size_t)4*nbpairs))) return rc;
+        ctx->pw.cell_smax = (const double*)ctx->b_pw_csm.p; ctx->pw.facet_smax = (const double*)ctx->b_pw_fsm.p;
+    }
+    unsigned long long visited = 0;
+    for (long long c = cell_begin; c < cell_end; c++) visited += (unsigned long long)(ctx->nc-c);
+    ctx->visited_pairs = visited;
+    return ctx->dim == 2 ? pointwise_impl<2>(ctx, A, ldA, zero_exterior, cell_begin, cell_end, npairs, nbpairs)
+                         : pointwise_impl<1>(ctx, A, ldA, zero_exterior, cell_begin, cell_end, npairs, nbpairs);
 }
 
 int pnl_get_counters(pnl_context *ctx, int64_t *out, int n) {

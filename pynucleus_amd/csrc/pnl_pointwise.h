@@ -1,0 +1,709 @@
+// Non-symmetric kernels with a fractional order s(x) evaluated per quadrature point (gfx950 only).
+//
+// Reference path: fractionalLaplacian{1,2}D_nonsym (FL2:894-1184, FL1:410-604) with piecewise == False kernels
+// (kernels.py:147-149): gamma(x, y) = C(s(x)) |x-y|^(-d-2 s(x)) (updateAndEvalFractional, KC:596-622), local matrix
+//   int_K1 int_K2 [u(x) gamma(x,y) - u(y) gamma(y,x)] [v(x) - v(y)]            (NO:849-930, contrib[(2 dpe)^2])
+// assembled for both orientations of every pair with addToMatrixElemElem (NA:1411-1428, 222-253).  For a kernel that is
+// evaluated per point the two orientations of a DISTANT pair are the same sums (the tensor rule is symmetric under the
+// swap), so they are computed once and added twice; touching pairs run both orientations because the singular rules are
+// not symmetric under the swap (the two differ at quadrature-error level, 1e-7).
+// The pair's order max(s over both centres and all vertices) (evalParamsOnSimplices, KC:1825-1846) enters the order
+// formula and selects the near rule; the host precomputes it per cell / facet and per touching pair.
+#pragma once
+#include "pnl_kernels.h"
+
+struct PwDev {
+    int type, normalized;       // 1 constant, 2 smoothStep(x0), 3 linearStep(x0), 4 smoothStepRadial (fractionalOrders.pyx:338-540)
+    double p[6];                // sl, sr, r, interface | radius, slope
+    double c0, bc0;             // constant term of the interior / boundary order formula
+    const double *cell_smax, *facet_smax;
+    int M[3], rows[3];
+    const double *nodes[3], *w[3], *phi0[3], *phi1[3];      // [nkeys][...] per slot
+    int bM[2], pad;
+    const double *bnodes[2], *bw[2], *bphi[2];
+    double sfac, bfac;
+};
+
+template <int DIM>
+__device__ __forceinline__ double pw_order(const PwDev &W, const double *x) {
+    const double *p = W.p;
+    if (W.type == 1) return p[0];
+    double t;
+    if (W.type == 4) {
+        double r = 0.;
+#pragma unroll
+        for (int k = 0; k < DIM; k++) r += x[k]*x[k];
+        t = sqrt(r);
+    } else t = x[0];
+    if (t < p[3]-p[2]) return p[0];
+    if (t > p[3]+p[2]) return p[1];
+    if (W.type == 3) return p[0]+p[4]*(t-p[3]+p[2]);
+    const double u = (t-p[3])*p[4]+0.5;
+    return p[0]+(p[1]-p[0])*(3.0*(u*u)-2.0*(u*u*u));
+}
+
+// variableFractionalLaplacianScaling (kernelNormalization.pyx:416-440), times 1/s for the boundary twin (KC:1990-1994)
+template <int DIM>
+__device__ __forceinline__ double pw_scaling(const PwDev &W, double s, bool boundary) {
+    double C = 0.5;
+    if (W.normalized) {
+        const double pi_pow = DIM == 1 ? 0.56418958354775628695 : 0.31830988618379067154;       // pi^(-d/2)
+        C = exp2(2.0*s)*s*tgamma(s+0.5*DIM)*pi_pow/tgamma(1.0-s)*0.5;
+    }
+    return boundary ? C/s : C;
+}
+
+__device__ __forceinline__ DevFormula pw_formula(const PwDev &W, int dim, double sv) {
+    DevFormula F;
+    F.c0 = W.c0; F.clip = 0; F.pad = 0;
+    if (dim == 2) { F.a = sv-1.; F.b = 1.; F.e = sv; F.den0 = 0.4; }
+    else { F.a = 2.*sv-1.; F.b = 0.; F.e = 2.*sv; F.den0 = 0.8; }
+    return F;
+}
+
+__device__ __forceinline__ DevFormula pw_formula_boundary(const PwDev &W, int dim, double sv) {
+    DevFormula F;
+    F.c0 = W.bc0; F.clip = 0; F.pad = 0;
+    const double st = fmax(0.5*(-(1.-dim-2.*sv)-1.), 0.);
+    if (dim == 2) { F.a = st-1.; F.b = 1.; F.e = st; F.den0 = 0.35; F.clip = 1; }
+    else { F.a = 2.*st-1.; F.b = 0.; F.e = 2.*st; F.den0 = 0.8; }
+    return F;
+}
+
+// ---- distant pairs: classification of all cell pairs c1 < c2 without a common vertex into the work list --------------
+// workgroup per 64x64 block of the upper triangle; entry = (c1, c2, rule offset, n | order << 16)
+template <int DIM>
+__global__ void __launch_bounds__(PNL_NTHREADS)
+k_pw_classify(const DevProblem P, const PwDev W, int4 *__restrict__ wl, unsigned *__restrict__ wl_count, unsigned wl_cap,
+              int cell_begin, int cell_end) {
+    constexpr int NV = DIM+1, DPE = NV, T = 64;
+    // linear block index -> (ta <= tb)
+    const int nbk = (P.nc+T-1)/T;
+    int ta = 0, rem = blockIdx.x;
+    while (rem >= nbk-ta) { rem -= nbk-ta; ta++; }
+    const int tb = ta+rem;
+    const int i = threadIdx.x & 63, jw = threadIdx.x >> 6;
+    const int c1 = ta*T+i;
+    int vid1[NV];
+    double cen1[DIM];
+    bool any1 = false;
+    const bool ok1 = c1 < P.nc && c1 >= cell_begin && c1 < cell_end;
+    const int cc1 = c1 < P.nc ? c1 : 0;
+#pragma unroll
+    for (int k = 0; k < NV; k++) vid1[k] = P.cvid[(size_t)k*P.ncp+cc1];
+#pragma unroll
+    for (int d = 0; d < DIM; d++) cen1[d] = P.ccen[(size_t)d*P.ncp+cc1];
+#pragma unroll
+    for (int k = 0; k < DPE; k++) any1 = any1 || P.cdof[(size_t)k*P.ncp+cc1] >= 0;
+    const double h1 = P.ch[cc1], sm1 = W.cell_smax[cc1];
+    unsigned long long visited = 0, assembled = 0, evals = 0;
+    for (int jj = 0; jj < 16; jj++) {
+        const int c2 = tb*T+jw*16+jj;
+        bool push = false;
+        int q = 0, off = 0, n = 0;
+        if (ok1 && c2 < P.nc && c2 > c1) {
+            visited++;
+            bool any = any1;
+#pragma unroll
+            for (int k = 0; k < DPE; k++) any = any || P.cdof[(size_t)k*P.ncp+c2] >= 0;
+            bool shared = false;
+#pragma unroll
+            for (int a = 0; a < NV; a++)
+#pragma unroll
+                for (int b = 0; b < NV; b++) shared = shared || (vid1[a] == P.cvid[(size_t)b*P.ncp+c2]);
+            if (any && !shared) {
+                double d2 = 0.;
+#pragma unroll
+                for (int d = 0; d < DIM; d++) { const double u = cen1[d]-P.ccen[(size_t)d*P.ncp+c2]; d2 += u*u; }
+                const DevFormula F = pw_formula(W, DIM, fmax(sm1, W.cell_smax[c2]));
+                q = quad_order(F, P.H0, h1, P.ch[c2], sqrt(d2));
+                if (q > P.qmax || q > PNL_MAXQ) atomicAdd(&P.counters[5], 1ull);
+                else {
+                    off = P.off[q]; n = P.off[q+1]-off; push = true;
+                    assembled++; evals += 2ull*n*n;
+                    atomicAdd(&P.counters[8+q], 1ull);
+                }
+            }
+        }
+        // wave-aggregated append
+        const unsigned long long m = __ballot(push);
+        if (m) {
+            const int lane = threadIdx.x & 63;
+            unsigned base = 0;
+            if (lane == __builtin_ctzll(m)) base = atomicAdd(wl_count, (unsigned)__popcll(m));
+            base = __shfl(base, __builtin_ctzll(m));
+            if (push) {
+                const unsigned pos = base+__popcll(m & ((1ull << lane)-1ull));
+                if (pos < wl_cap) wl[pos] = make_int4(c1, c2, off, n | (q << 16));
+            }
+        }
+    }
+    (void)visited;                               // the host knows the number of visited pairs
+    const double sa = wave_sum((double)assembled), se = wave_sum((double)evals);
+    if ((threadIdx.x & 63) == 0 && sa > 0.) {
+        atomicAdd(&P.counters[1], (unsigned long long)sa);
+        atomicAdd(&P.counters[2], (unsigned long long)se);
+    }
+}
+
+// ---- distant pairs from the sorted list: 16 lanes per pair split the rows of the tensor rule -------------------------
+// per point pair: L = ln d2 once, K1 = w_i w_j C(s(x_i)) exp(e(x_i) L), K2 = w_i w_j C(s(y_j)) exp(e(y_j) L);
+// order and scaling of the points of the second cell are computed once per pair and kept in LDS.
+#define PNL_PW_MAXPTS 128
+template <int DIM>
+__global__ void __launch_bounds__(PNL_NTHREADS)
+k_pw_distant(const DevProblem P, const PwDev W, const int4 *__restrict__ sorted, const unsigned *__restrict__ offs,
+             double *__restrict__ A, long long ldA, double *__restrict__ Dglob, int tab_max_pts) {
+    constexpr int NV = DIM+1, DPE = NV, NC = NV*DIM, ND = DPE*(DPE+1)/2, NG = DPE*DPE, NACC = 2*NG+2*ND, LPP = 16,
+                  PPC = PNL_NTHREADS/LPP, NREP = (NACC+LPP-1)/LPP, ST = 4+DPE;
+    extern __shared__ double s_mem[];            // rule [tab_max_pts][ST], then per pair of the chunk [PPC][tab_max_pts][2]: e(y_j), w_j C(y_j)
+    double *s_rule = s_mem, *s_y = s_mem+(size_t)tab_max_pts*ST;
+    __shared__ unsigned s_coff[PNL_WL_BINS+1];
+    const int tid = threadIdx.x, sub = tid & (LPP-1), g = tid/LPP;
+    if (tid == 0) {
+        unsigned run = 0;
+        for (int q = 0; q < PNL_WL_BINS; q++) {
+            s_coff[q] = run;
+            const int nq = (q >= 2 && q <= P.qmax && q <= PNL_MAXQ) ? P.off[q+1]-P.off[q] : 0;
+            if (nq > 0) run += (offs[q+1]-offs[q]+PPC-1u)/PPC;
+        }
+        s_coff[PNL_WL_BINS] = run;
+    }
+    __syncthreads();
+    const unsigned nchunks = s_coff[PNL_WL_BINS];
+    int staged_q = -1;
+    for (unsigned chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+        int lo = 0, hi = PNL_WL_BINS-1;
+        while (lo < hi) {
+            const int mid = (lo+hi+1) >> 1;
+            if (s_coff[mid] <= chunk) lo = mid; else hi = mid-1;
+        }
+        const int q = lo;
+        const unsigned first = offs[q]+(unsigned)PPC*(chunk-s_coff[q]);
+        const int cnt = (int)min((unsigned)PPC, offs[q+1]-first);
+        const int4 e0 = sorted[first];
+        const int n = e0.w & 0xffff, off = P.off[q];
+        const bool in_lds = n <= tab_max_pts;    // larger rules (orders > 30): tables from L2, second-cell data recomputed
+        auto rule = [&](int pt, int k) -> double {
+            if (in_lds) return s_rule[pt*ST+k];
+            return k < 3 ? P.bary[3*(size_t)(off+pt)+k] : (k == 3 ? P.w[off+pt] : P.phi[(size_t)(off+pt)*DPE+k-4]);
+        };
+        __syncthreads();                         // previous chunk's s_y reads are done
+        if (q != staged_q && in_lds) {
+            for (int t = tid; t < n*ST; t += PNL_NTHREADS) {
+                const int pt = t/ST, k = t-pt*ST;
+                s_rule[t] = k < 3 ? P.bary[3*(size_t)(off+pt)+k] : (k == 3 ? P.w[off+pt] : P.phi[(size_t)(off+pt)*DPE+k-4]);
+            }
+            staged_q = q;
+        }
+        __syncthreads();
+        const bool valid = g < cnt;
+        const int4 ent = valid ? sorted[first+g] : e0;
+        const int c1 = ent.x, c2 = ent.y;
+        double av[NC], bv[NC];
+#pragma unroll
+        for (int k = 0; k < NC; k++) { av[k] = P.cellv[(size_t)k*P.ncp+c1]; bv[k] = P.cellv[(size_t)k*P.ncp+c2]; }
+        double *my_y = s_y+(size_t)g*tab_max_pts*2;
+        for (int j = sub; j < n && in_lds; j += LPP) {
+            double y[DIM];
+#pragma unroll
+            for (int d = 0; d < DIM; d++) {
+                double sy = 0.;
+#pragma unroll
+                for (int m = 0; m < NV; m++) sy = __builtin_fma(s_rule[j*ST+m], bv[m*DIM+d], sy);
+                y[d] = sy;
+            }
+            const double s = pw_order<DIM>(W, y);
+            my_y[2*j] = -0.5*DIM-s;
+            my_y[2*j+1] = s_rule[j*ST+3]*pw_scaling<DIM>(W, s, false);
+        }
+        __syncthreads();
+        double G1[DPE][DPE], G2[DPE][DPE], S1[ND], S2[ND];
+#pragma unroll
+        for (int a = 0; a < DPE; a++)
+#pragma unroll
+            for (int b = 0; b < DPE; b++) { G1[a][b] = 0.; G2[a][b] = 0.; }
+#pragma unroll
+        for (int e = 0; e < ND; e++) { S1[e] = 0.; S2[e] = 0.; }
+#pragma unroll 1
+        for (int i = sub; i < n; i += LPP) {
+            double ti[ST];
+#pragma unroll
+            for (int m = 0; m < ST; m++) ti[m] = rule(i, m);
+            double x[DIM];
+#pragma unroll
+            for (int d = 0; d < DIM; d++) {
+                double sx = 0.;
+#pragma unroll
+                for (int m = 0; m < NV; m++) sx = __builtin_fma(ti[m], av[m*DIM+d], sx);
+                x[d] = sx;
+            }
+            const double sx_ = pw_order<DIM>(W, x);
+            const double ex = -0.5*DIM-sx_, cx = ti[3]*pw_scaling<DIM>(W, sx_, false);
+            double r1 = 0., u1[DPE], u2[DPE];
+#pragma unroll
+            for (int b = 0; b < DPE; b++) { u1[b] = 0.; u2[b] = 0.; }
+#pragma unroll 1
+            for (int j = 0; j < n; j++) {
+                double tj[ST];
+#pragma unroll
+                for (int m = 0; m < ST; m++) tj[m] = rule(j, m);
+                double d2 = 0., y[DIM];
+#pragma unroll
+                for (int d = 0; d < DIM; d++) {
+                    double sy = 0.;
+#pragma unroll
+                    for (int m = 0; m < NV; m++) sy = __builtin_fma(tj[m], bv[m*DIM+d], sy);
+                    y[d] = sy;
+                    const double t = x[d]-sy;
+                    d2 = __builtin_fma(t, t, d2);
+                }
+                double ey, cy;
+                if (in_lds) { ey = my_y[2*j]; cy = my_y[2*j+1]; }
+                else { const double s = pw_order<DIM>(W, y); ey = -0.5*DIM-s; cy = tj[3]*pw_scaling<DIM>(W, s, false); }
+                const double L = log(d2);
+                const double K1 = (cx*tj[3])*exp(ex*L), K2 = (ti[3]*cy)*exp(ey*L);
+                r1 += K1;
+                double t2[DPE];
+#pragma unroll
+                for (int b = 0; b < DPE; b++) { u1[b] = __builtin_fma(K1, tj[4+b], u1[b]); t2[b] = K2*tj[4+b]; u2[b] += t2[b]; }
+                int e = 0;
+#pragma unroll
+                for (int a = 0; a < DPE; a++)
+#pragma unroll
+                    for (int b = a; b < DPE; b++) { S2[e] = __builtin_fma(t2[a], tj[4+b], S2[e]); e++; }
+            }
+            int e = 0;
+#pragma unroll
+            for (int a = 0; a < DPE; a++) {
+                const double pa = ti[4+a];
+#pragma unroll
+                for (int b = 0; b < DPE; b++) {
+                    G1[a][b] = __builtin_fma(pa, u1[b], G1[a][b]);           // XY[a][b]: phi_a(x_i) sum_j K1 phi_b(y_j)
+                    G2[a][b] = __builtin_fma(u2[a], ti[4+b], G2[a][b]);      // YX[a][b]: sum_j K2 phi_a(y_j) phi_b(x_i)
+                }
+                const double pr = pa*r1;
+#pragma unroll
+                for (int b = a; b < DPE; b++) { S1[e] = __builtin_fma(pr, ti[4+b], S1[e]); e++; }
+            }
+        }
+        double acc[NACC];
+#pragma unroll
+        for (int a = 0; a < DPE; a++)
+#pragma unroll
+            for (int b = 0; b < DPE; b++) { acc[a*DPE+b] = G1[a][b]; acc[NG+a*DPE+b] = G2[a][b]; }
+#pragma unroll
+        for (int e = 0; e < ND; e++) { acc[2*NG+e] = S1[e]; acc[2*NG+ND+e] = S2[e]; }
+        double mine[NREP];
+#pragma unroll
+        for (int r = 0; r < NREP; r++) mine[r] = 0.;
+#pragma unroll
+        for (int e = 0; e < NACC; e++) {
+            const double s = row16_sum(acc[e]);
+            mine[e/LPP] = (sub == (e & (LPP-1))) ? s : mine[e/LPP];
+        }
+        if (valid) {
+            const double vv = 2.*P.cvol[c1]*P.cvol[c2];          // both orientations (see the header of this file)
+#pragma unroll
+            for (int rep = 0; rep < NREP; rep++) {
+                const int e = sub+LPP*rep;
+                const double val = mine[rep];
+                if (e < NG) {
+                    const int a = e/DPE, b = e-a*DPE;
+                    const int I = P.cdof[(size_t)a*P.ncp+c1], J = P.cdof[(size_t)b*P.ncp+c2];
+                    if (I >= 0 && J >= 0) atomic_add_f64(&A[(long long)I*ldA+J], -vv*val);
+                } else if (e < 2*NG) {
+                    const int a = (e-NG)/DPE, b = (e-NG)-a*DPE;
+                    const int I = P.cdof[(size_t)a*P.ncp+c2], J = P.cdof[(size_t)b*P.ncp+c1];
+                    if (I >= 0 && J >= 0) atomic_add_f64(&A[(long long)I*ldA+J], -vv*val);
+                } else if (e < 2*NG+ND) atomic_add_f64(&Dglob[(size_t)c1*ND+(e-2*NG)], vv*val);
+                else if (e < NACC) atomic_add_f64(&Dglob[(size_t)c2*ND+(e-2*NG-ND)], vv*val);
+            }
+        }
+    }
+}
+
+// ---- touching pairs (FL2:1133-1184, FL1:548-604): one wave per (pair, orientation), rule of the pair's order key ------
+// pairs[t] = (c1 <= c2, common, key); full (rows x rows) non-symmetric local matrix, scatter NA:222-253
+template <int DIM, int SLOT>
+__global__ void __launch_bounds__(PNL_NTHREADS)
+k_pw_singular(const DevProblem P, const PwDev W, const int4 *__restrict__ pairs, int npairs, double *__restrict__ A, long long ldA,
+              int cell_begin, int cell_end) {
+    constexpr int NV = DIM+1, DPE = NV, DPV = 1;
+    constexpr int COMMON = SLOT+1;
+    constexpr int ROWS = (COMMON == NV) ? DPE : (COMMON == 1 ? 2*DPE-DPV : 2*DPE-2*DPV);
+    constexpr int NE = ROWS*ROWS;
+    const int lane = threadIdx.x & 63;
+    const int wid = (blockIdx.x*PNL_NTHREADS+threadIdx.x) >> 6;
+    if (wid >= 2*npairs) return;
+    const int4 pr = pairs[wid >> 1];
+    if (pr.z != COMMON) return;
+    const int orient = wid & 1;
+    const int p1 = __builtin_amdgcn_readfirstlane(pr.x), p2 = __builtin_amdgcn_readfirstlane(pr.y);
+    if (p1 < cell_begin || p1 >= cell_end) return;
+    if (orient && p1 == p2) return;
+    const int c1 = orient ? p2 : p1, c2 = orient ? p1 : p2;
+    const int key = __builtin_amdgcn_readfirstlane(pr.w);
+    int ld[2*DPE];
+    bool any = false;
+#pragma unroll
+    for (int k = 0; k < DPE; k++) {
+        ld[k] = P.cdof[(size_t)k*P.ncp+c1];
+        ld[DPE+k] = P.cdof[(size_t)k*P.ncp+c2];
+        any = any || ld[k] >= 0 || ld[DPE+k] >= 0;
+    }
+    if (!any) return;
+    int perm1[NV], perm2[NV], perm[2*DPE];
+#pragma unroll
+    for (int k = 0; k < NV; k++) { perm1[k] = k; perm2[k] = k; }
+#pragma unroll
+    for (int k = 0; k < 2*DPE; k++) perm[k] = k;
+    if (c1 != c2) {
+        int mask1 = 0, mask2 = 0, common = 0;
+        int vid1[NV], vid2[NV];
+#pragma unroll
+        for (int a = 0; a < NV; a++) { vid1[a] = P.cvid[(size_t)a*P.ncp+c1]; vid2[a] = P.cvid[(size_t)a*P.ncp+c2]; }
+#pragma unroll
+        for (int a = 0; a < NV; a++) {
+            const int v1 = vid1[a];
+#pragma unroll
+            for (int b = 0; b < NV; b++) {
+                if (mask2 & (1 << b)) continue;
+                if (v1 == vid2[b]) {
+                    perm1[common] = a; perm2[common] = b;
+                    mask1 += (1 << a); mask2 += (1 << b);
+                    common++;
+                    break;
+                }
+            }
+        }
+        int i = 0;
+        for (int k = common; k < NV; k++) { while (mask1 & (1 << i)) i++; perm1[k] = i; mask1 += (1 << i); }
+        i = 0;
+        for (int k = common; k < NV; k++) { while (mask2 & (1 << i)) i++; perm2[k] = i; mask2 += (1 << i); }
+        const int *t1 = P.perm_table+perm_rank(perm1, NV)*DPE;
+        const int *t2 = P.perm_table+perm_rank(perm2, NV)*DPE;
+        for (int k = 0; k < DPE; k++) perm[k] = t1[k];
+        if (COMMON == 1) {
+            for (int k = DPV; k < DPE; k++) perm[DPE+k-DPV] = DPE+t2[k];
+        } else if (COMMON == 2) {
+            for (int k = 2*DPV; k < NV*DPV; k++) perm[DPE+k-2*DPV] = DPE+t2[k];
+        }
+    }
+    double s1[NV][DIM], s2[NV][DIM];
+#pragma unroll
+    for (int k = 0; k < NV; k++)
+#pragma unroll
+        for (int d = 0; d < DIM; d++) {
+            double a = 0., b = 0.;
+#pragma unroll
+            for (int m = 0; m < NV; m++) {
+                const double va = P.cellv[(size_t)(m*DIM+d)*P.ncp+c1], vb = P.cellv[(size_t)(m*DIM+d)*P.ncp+c2];
+                a = (perm1[k] == m) ? va : a;
+                b = (perm2[k] == m) ? vb : b;
+            }
+            s1[k][d] = a; s2[k][d] = b;
+        }
+    const int M = W.M[SLOT];
+    const double *__restrict__ nodes = W.nodes[SLOT]+(size_t)key*2*NV*M;
+    const double *__restrict__ w = W.w[SLOT]+(size_t)key*M;
+    const double *__restrict__ phi0 = W.phi0[SLOT]+(size_t)key*ROWS*M;
+    const double *__restrict__ phi1 = W.phi1[SLOT]+(size_t)key*ROWS*M;
+    double acc[NE];
+#pragma unroll
+    for (int e = 0; e < NE; e++) acc[e] = 0.;
+    for (int m = lane; m < M; m += 64) {
+        double x[DIM], y[DIM], d2 = 0.;
+#pragma unroll
+        for (int d = 0; d < DIM; d++) {
+            double xx = 0., yy = 0.;
+#pragma unroll
+            for (int k = 0; k < NV; k++) {
+                xx = __builtin_fma(s1[k][d], nodes[(size_t)k*M+m], xx);
+                yy = __builtin_fma(s2[k][d], nodes[(size_t)(NV+k)*M+m], yy);
+            }
+            x[d] = xx; y[d] = yy;
+            d2 = __builtin_fma(xx-yy, xx-yy, d2);
+        }
+        const double L = log(d2);
+        const double sx = pw_order<DIM>(W, x), sy = pw_order<DIM>(W, y);
+        const double t1 = w[m]*pw_scaling<DIM>(W, sx, false)*exp((-0.5*DIM-sx)*L);
+        const double t2 = w[m]*pw_scaling<DIM>(W, sy, false)*exp((-0.5*DIM-sy)*L);
+        double f[ROWS], ps[ROWS];
+#pragma unroll
+        for (int r = 0; r < ROWS; r++) {
+            const double a = phi0[(size_t)r*M+m], b = phi1[(size_t)r*M+m];
+            f[r] = t1*a-t2*b; ps[r] = a-b;
+        }
+#pragma unroll
+        for (int I = 0; I < ROWS; I++)
+#pragma unroll
+            for (int J = 0; J < ROWS; J++) acc[I*ROWS+J] = __builtin_fma(f[I], ps[J], acc[I*ROWS+J]);
+    }
+    const double vol = W.sfac*P.cvol[c1]*P.cvol[c2];
+    double mine = 0.;
+    int myI = 0, myJ = 0;
+#pragma unroll
+    for (int e = 0; e < NE; e++) {
+        const double s = wave_sum(acc[e]);
+        if (lane == e) { mine = s; myI = e/ROWS; myJ = e-(e/ROWS)*ROWS; }
+    }
+    if (lane < NE) {
+        int gi = -1, gj = -1;
+#pragma unroll
+        for (int k = 0; k < 2*DPE; k++) {
+            const int pk = perm[k];
+            int g = -1;
+#pragma unroll
+            for (int m = 0; m < 2*DPE; m++) g = (pk == m) ? ld[m] : g;
+            gi = (myI == k) ? g : gi;
+            gj = (myJ == k) ? g : gj;
+        }
+        if (gi >= 0 && gj >= 0) atomic_add_f64(&A[(long long)gi*ldA+gj], mine*vol);
+    }
+    if (lane == 0) {
+        if (!orient) { atomicAdd(&P.counters[1], 1ull); atomicAdd(&P.counters[128+SLOT], 1ull); }
+        atomicAdd(&P.counters[2], (unsigned long long)M);
+    }
+}
+
+// ---- Omega x Omega^c with the pointwise boundary kernel C(s(x))/s(x) |x-y|^(1-d-2 s(x)), x in the cell ----------------
+template <int DIM>
+__global__ void __launch_bounds__(PNL_NTHREADS)
+k_pw_boundary_distant(const DevProblem P, const PwDev W, double *__restrict__ Dglob, int cell_begin, int cell_end, int facets_per_chunk) {
+    constexpr int NV = DIM+1, DPE = NV, NC = NV*DIM, NF = DIM, ND = DPE*(DPE+1)/2;
+    const int c = cell_begin+blockIdx.x*PNL_NTHREADS+threadIdx.x;
+    const bool active = c < cell_end;
+    const int cc = active ? c : cell_begin;
+    double av[NC], cen[DIM];
+    int vid[NV];
+#pragma unroll
+    for (int k = 0; k < NC; k++) av[k] = P.cellv[(size_t)k*P.ncp+cc];
+#pragma unroll
+    for (int d = 0; d < DIM; d++) cen[d] = P.ccen[(size_t)d*P.ncp+cc];
+#pragma unroll
+    for (int k = 0; k < NV; k++) vid[k] = P.cvid[(size_t)k*P.ncp+cc];
+    const double h1 = P.ch[cc], vol1 = P.cvol[cc], sm1 = W.cell_smax[cc];
+    double D[ND];
+#pragma unroll
+    for (int e = 0; e < ND; e++) D[e] = 0.;
+    unsigned long long npairs = 0, nevals = 0;
+    int overflow = 0;
+    const int f0 = blockIdx.y*facets_per_chunk;
+    const int f1 = min(P.nb, f0+facets_per_chunk);
+    for (int f = f0; f < f1; f++) {
+        double fv[NF*DIM], fc[DIM], nrm[DIM];
+        int fvid[NF];
+#pragma unroll
+        for (int k = 0; k < NF; k++) fvid[k] = P.bvid[(size_t)k*P.nb+f];
+#pragma unroll
+        for (int k = 0; k < NF*DIM; k++) fv[k] = P.bv[(size_t)k*P.nb+f];
+#pragma unroll
+        for (int d = 0; d < DIM; d++) { fc[d] = P.bgeo[(size_t)d*P.nb+f]; nrm[d] = P.bgeo[(size_t)(DIM+d)*P.nb+f]; }
+        const double vol2 = P.bgeo[(size_t)(2*DIM)*P.nb+f];
+        bool shared = false;
+#pragma unroll
+        for (int k = 0; k < NV; k++)
+#pragma unroll
+            for (int m = 0; m < NF; m++) shared = shared || (vid[k] == fvid[m]);
+        if (!active || shared) continue;
+        double dc2 = 0.;
+#pragma unroll
+        for (int d = 0; d < DIM; d++) dc2 += (cen[d]-fc[d])*(cen[d]-fc[d]);
+        const DevFormula F = pw_formula_boundary(W, DIM, fmax(sm1, W.facet_smax[f]));
+        const int q = quad_order(F, P.H0, h1, vol2, sqrt(dc2));
+        if (q > P.qmax || q > PNL_MAXQ) { overflow++; continue; }
+        const int off = P.off[q], n = P.off[q+1]-off;
+        const int foff = P.foff[q], nf = P.foff[q+1]-foff;
+        const double *__restrict__ bary = P.bary+3*(size_t)off;
+        const double *__restrict__ w = P.w+off;
+        const double *__restrict__ phi = P.phi+(size_t)off*DPE;
+        const double *__restrict__ fb = P.fbary+2*(size_t)foff;
+        const double *__restrict__ fw = P.fw+foff;
+        npairs++;
+        nevals += (unsigned long long)n*nf;
+        const double vol = vol1*vol2;
+        for (int k = 0; k < n; k++) {
+            double x[DIM];
+#pragma unroll
+            for (int d = 0; d < DIM; d++) {
+                double s = 0.;
+#pragma unroll
+                for (int m = 0; m < NV; m++) s = __builtin_fma(bary[3*k+m], av[m*DIM+d], s);
+                x[d] = s;
+            }
+            const double sx = pw_order<DIM>(W, x);
+            // Gamma_b = (C/s) d2^(0.5 (1-d) - s); the 1/|y-x| of the normal factor is folded into the exponent (2D)
+            const double ex = 0.5*(1-DIM)-sx-(DIM == 2 ? 0.5 : 0.), cx = pw_scaling<DIM>(W, sx, true);
+            double r = 0.;
+            for (int m = 0; m < nf; m++) {
+                double d2 = 0., nw = 0.;
+#pragma unroll
+                for (int d = 0; d < DIM; d++) {
+                    double y = 0.;
+#pragma unroll
+                    for (int t = 0; t < NF; t++) y = __builtin_fma(fb[2*m+t], fv[t*DIM+d], y);
+                    const double wv = y-x[d];
+                    d2 = __builtin_fma(wv, wv, d2);
+                    if (DIM == 2) nw = __builtin_fma(nrm[d], wv, nw);
+                }
+                if (DIM != 2) nw = 1.;
+                r = __builtin_fma(fw[m]*nw, exp(ex*log(d2)), r);
+            }
+            r *= w[k]*vol*cx;
+            int e = 0;
+#pragma unroll
+            for (int a = 0; a < DPE; a++) {
+                const double pa = phi[k*DPE+a]*r;
+#pragma unroll
+                for (int b = a; b < DPE; b++) { D[e] = __builtin_fma(pa, phi[k*DPE+b], D[e]); e++; }
+            }
+        }
+    }
+    if (active) {
+#pragma unroll
+        for (int e = 0; e < ND; e++)
+            if (D[e] != 0.) atomic_add_f64(&Dglob[(size_t)c*ND+e], D[e]);
+        if (overflow) atomicAdd(&P.counters[5], (unsigned long long)overflow);
+    }
+    const double sp = wave_sum((double)npairs), se = wave_sum((double)nevals);
+    if ((threadIdx.x & 63) == 0 && sp > 0.) {
+        atomicAdd(&P.counters[3], (unsigned long long)sp);
+        atomicAdd(&P.counters[4], (unsigned long long)se);
+    }
+}
+
+// touching (cell, facet) pairs: pairs[t] = (cell, facet, common, key); one wave per pair
+template <int DIM, int SLOT>
+__global__ void __launch_bounds__(PNL_NTHREADS)
+k_pw_boundary_singular(const DevProblem P, const PwDev W, const int4 *__restrict__ pairs, int npairs, double *__restrict__ Dglob,
+                       int cell_begin, int cell_end) {
+    constexpr int NV = DIM+1, DPE = NV, NF = DIM, ND = DPE*(DPE+1)/2;
+    const int lane = threadIdx.x & 63;
+    const int wid = (blockIdx.x*PNL_NTHREADS+threadIdx.x) >> 6;
+    if (wid >= npairs) return;
+    const int4 pr = pairs[wid];
+    if (pr.z != SLOT+1) return;
+    const int c1 = __builtin_amdgcn_readfirstlane(pr.x), f = __builtin_amdgcn_readfirstlane(pr.y);
+    const int key = __builtin_amdgcn_readfirstlane(pr.w);
+    if (c1 < cell_begin || c1 >= cell_end) return;
+    int perm1[NV], perm2[NF], perm[DPE];
+#pragma unroll
+    for (int k = 0; k < NV; k++) perm1[k] = k;
+#pragma unroll
+    for (int k = 0; k < NF; k++) perm2[k] = k;
+    {
+        int mask1 = 0, mask2 = 0, common = 0;
+        for (int a = 0; a < NV; a++) {
+            const int v1 = P.cvid[(size_t)a*P.ncp+c1];
+            for (int b = 0; b < NF; b++) {
+                if (mask2 & (1 << b)) continue;
+                if (v1 == P.bvid[(size_t)b*P.nb+f]) {
+                    perm1[common] = a; perm2[common] = b;
+                    mask1 += (1 << a); mask2 += (1 << b);
+                    common++;
+                    break;
+                }
+            }
+        }
+        int i = 0;
+        for (int k = common; k < NV; k++) { while (mask1 & (1 << i)) i++; perm1[k] = i; mask1 += (1 << i); }
+        i = 0;
+        for (int k = common; k < NF; k++) { while (mask2 & (1 << i)) i++; perm2[k] = i; mask2 += (1 << i); }
+        const int *t1 = P.perm_table+perm_rank(perm1, NV)*DPE;
+        for (int k = 0; k < DPE; k++) perm[k] = t1[k];
+    }
+    double s1[NV][DIM], s2[NF][DIM], fv[NF][DIM], nrm[DIM];
+#pragma unroll
+    for (int k = 0; k < NF; k++)
+#pragma unroll
+        for (int d = 0; d < DIM; d++) fv[k][d] = P.bv[(size_t)(k*DIM+d)*P.nb+f];
+#pragma unroll
+    for (int k = 0; k < NV; k++)
+#pragma unroll
+        for (int d = 0; d < DIM; d++) {
+            double a = 0.;
+#pragma unroll
+            for (int m = 0; m < NV; m++) a = (perm1[k] == m) ? P.cellv[(size_t)(m*DIM+d)*P.ncp+c1] : a;
+            s1[k][d] = a;
+        }
+#pragma unroll
+    for (int k = 0; k < NF; k++)
+#pragma unroll
+        for (int d = 0; d < DIM; d++) {
+            double b = 0.;
+#pragma unroll
+            for (int m = 0; m < NF; m++) b = (perm2[k] == m) ? fv[m][d] : b;
+            s2[k][d] = b;
+        }
+    double vol2 = 1.;
+    if (DIM == 2) {
+        nrm[0] = fv[1][1]-fv[0][1];
+        nrm[1] = fv[0][0]-fv[1][0];
+        const double inv = 1./sqrt(nrm[0]*nrm[0]+nrm[1]*nrm[1]);
+        nrm[0] *= inv; nrm[1] *= inv;
+        vol2 = sqrt((fv[1][0]-fv[0][0])*(fv[1][0]-fv[0][0])+(fv[1][1]-fv[0][1])*(fv[1][1]-fv[0][1]));
+    }
+    const int M = W.bM[SLOT];
+    const double *__restrict__ nodes = W.bnodes[SLOT]+(size_t)key*(NV+NF)*M;
+    const double *__restrict__ w = W.bw[SLOT]+(size_t)key*M;
+    const double *__restrict__ PHI = W.bphi[SLOT]+(size_t)key*DPE*M;
+    double acc[ND];
+#pragma unroll
+    for (int e = 0; e < ND; e++) acc[e] = 0.;
+    for (int m = lane; m < M; m += 64) {
+        double x[DIM], d2 = 0., nw = 0.;
+#pragma unroll
+        for (int d = 0; d < DIM; d++) {
+            double xx = 0., y = 0.;
+#pragma unroll
+            for (int k = 0; k < NV; k++) xx = __builtin_fma(s1[k][d], nodes[(size_t)k*M+m], xx);
+#pragma unroll
+            for (int k = 0; k < NF; k++) y = __builtin_fma(s2[k][d], nodes[(size_t)(NV+k)*M+m], y);
+            x[d] = xx;
+            const double wv = xx-y;
+            d2 = __builtin_fma(wv, wv, d2);
+            if (DIM == 2) nw = __builtin_fma(nrm[d], wv, nw);
+        }
+        if (DIM != 2) nw = 1.;
+        const double sx = pw_order<DIM>(W, x);
+        const double ex = 0.5*(1-DIM)-sx-(DIM == 2 ? 0.5 : 0.);
+        const double t = w[m]*nw*pw_scaling<DIM>(W, sx, true)*exp(ex*log(d2));
+        double ps[DPE];
+#pragma unroll
+        for (int r = 0; r < DPE; r++) ps[r] = PHI[(size_t)r*M+m];
+        int e = 0;
+#pragma unroll
+        for (int I = 0; I < DPE; I++) {
+            const double tI = t*ps[I];
+#pragma unroll
+            for (int J = I; J < DPE; J++) { acc[e] = __builtin_fma(tI, ps[J], acc[e]); e++; }
+        }
+    }
+    const double vol = (DIM == 2) ? W.bfac*P.cvol[c1]*vol2 : W.bfac*P.cvol[c1];
+    double mine = 0.;
+    int myI = 0, myJ = 0;
+    {
+        int e = 0;
+#pragma unroll
+        for (int I = 0; I < DPE; I++)
+#pragma unroll
+            for (int J = I; J < DPE; J++) {
+                const double s = wave_sum(acc[e]);
+                if (lane == e) { mine = s; myI = I; myJ = J; }
+                e++;
+            }
+    }
+    if (lane < ND) {
+        int i = 0, j = 0;
+#pragma unroll
+        for (int k = 0; k < DPE; k++) { i = (myI == k) ? perm[k] : i; j = (myJ == k) ? perm[k] : j; }
+        const int lo = min(i, j), hi = max(i, j);
+        const int kk = DPE*lo-(lo*(lo+1) >> 1)+hi;
+        atomic_add_f64(&Dglob[(size_t)c1*ND+kk], mine*vol);
+    }
+    if (lane == 0) {
+        atomicAdd(&P.counters[3], 1ull);
+        atomicAdd(&P.counters[4], (unsigned long long)M);
+    }
+}

@@ -5,7 +5,8 @@ partition of the domain: variableConstFractionalOrder :203-217, piecewiseConstan
 leftRightFractionalOrder :285-336, layersFractionalOrder :826-882.  With ``piecewise=True`` the reference evaluates the
 order once per element pair at the two cell centres (Kernel.evalParams, kernelsCy.pyx:1852-1867); an order of this family
 is therefore a label per cell plus a small table sVals[label_x, label_y], which is what the GPU path consumes.
-Smoothly varying orders (smoothedLeftRight, feFractionalOrder, ...) are not built.
+Orders of one variable s(x) (constantNonSym, smoothedLeftRight, linearLeftRight, smoothedInnerOuter) are non-symmetric and
+evaluated per quadrature point (second half of this file); feFractionalOrder and lambda orders are not built.
 """
 import numpy as np
 
@@ -97,3 +98,138 @@ class piecewiseConstantFractionalOrder(variableFractionalOrder):
 
     def labels(self, points):
         return np.array([int(self.blockIndicator(p)) for p in np.atleast_2d(points)], dtype=np.int32)
+
+
+# ---- orders s(x) of one variable: non-symmetric, evaluated per quadrature point ------------------------------------------
+# fractionalOrders.pyx:338-540 (extendedFunction family), :153-183 singleVariableUnsymmetricFractionalOrder, :631-657.
+# The reference switches such kernels to piecewise=False (kernels.py:147-149): gamma(x, y) = C(s(x)) |x-y|^(-d-2 s(x)).
+# Every function knows its device encoding (type id + up to 6 parameters, include/pnl_hip.h pnl_order_function).
+
+class extendedFunction:
+    device_type = 0
+
+    def device_params(self):
+        raise NotImplementedError()
+
+    def __call__(self, x):
+        """vectorised: x[..., dim] -> s[...]"""
+        raise NotImplementedError()
+
+
+class constantExtended(extendedFunction):
+    device_type = 1
+
+    def __init__(self, value):
+        self.value = float(value)
+
+    def __call__(self, x):
+        return np.full(np.asarray(x).shape[:-1], self.value)
+
+    def device_params(self):
+        return [self.value, 0., 0., 0., 0., 0.]
+
+    def __repr__(self):
+        return '{}'.format(self.value)
+
+
+class smoothStep(extendedFunction):
+    """:390-445, cubic blend of sl and sr across |x0 - interface| <= r"""
+    device_type = 2
+
+    def __init__(self, sl, sr, r, interface=0.):
+        self.sl, self.sr, self.r, self.interface = float(sl), float(sr), float(r), float(interface)
+        self.slope = 0.5/self.r
+
+    def __call__(self, x):
+        x0 = np.asarray(x, dtype=float)[..., 0]
+        t = (x0-self.interface)*self.slope+0.5
+        mid = self.sl+(self.sr-self.sl)*(3.0*t**2-2.0*t**3)
+        return np.where(x0 < self.interface-self.r, self.sl, np.where(x0 > self.interface+self.r, self.sr, mid))
+
+    def device_params(self):
+        return [self.sl, self.sr, self.r, self.interface, self.slope, 0.]
+
+    def __repr__(self):
+        return 'smoothStep(sl={},sr={},r={},interface={})'.format(self.sl, self.sr, self.r, self.interface)
+
+
+class linearStep(extendedFunction):
+    """:447-498"""
+    device_type = 3
+
+    def __init__(self, sl, sr, r, interface=0.):
+        self.sl, self.sr, self.r, self.interface = float(sl), float(sr), float(r), float(interface)
+        self.slope = 0.5*(self.sr-self.sl)/self.r
+
+    def __call__(self, x):
+        x0 = np.asarray(x, dtype=float)[..., 0]
+        mid = self.sl+self.slope*(x0-self.interface+self.r)
+        return np.where(x0 < self.interface-self.r, self.sl, np.where(x0 > self.interface+self.r, self.sr, mid))
+
+    def device_params(self):
+        return [self.sl, self.sr, self.r, self.interface, self.slope, 0.]
+
+    def __repr__(self):
+        return 'linearStep(sl={},sr={},r={})'.format(self.sl, self.sr, self.r)
+
+
+class smoothStepRadial(extendedFunction):
+    """:500-539, the same blend in |x| across radius +- r"""
+    device_type = 4
+
+    def __init__(self, sl, sr, r, radius=0.5):
+        self.sl, self.sr, self.r, self.radius = float(sl), float(sr), float(r), float(radius)
+        self.slope = 0.5/self.r
+
+    def __call__(self, x):
+        x = np.asarray(x, dtype=float)
+        rr = np.sqrt((x**2).sum(axis=-1))
+        t = (rr-self.radius)*self.slope+0.5
+        mid = self.sl+(self.sr-self.sl)*(3.0*t**2-2.0*t**3)
+        return np.where(rr < self.radius-self.r, self.sl, np.where(rr > self.radius+self.r, self.sr, mid))
+
+    def device_params(self):
+        return [self.sl, self.sr, self.r, self.radius, self.slope, 0.]
+
+    def __repr__(self):
+        return 'smoothStepRadial(sl={},sr={},r={},radius={})'.format(self.sl, self.sr, self.r, self.radius)
+
+
+class singleVariableUnsymmetricFractionalOrder(fractionalOrderBase):
+    """s(x, y) = sFun(x) (:153-183)"""
+    symmetric = False
+
+    def __init__(self, sFun, smin, smax, numParameters=0):
+        self.sFun = sFun
+        self.min, self.max = float(smin), float(smax)
+        self.numParameters = numParameters
+
+    def __call__(self, x, y=None):
+        return float(self.sFun(np.atleast_1d(np.asarray(x, dtype=float))))
+
+    def evalPoints(self, x):
+        return self.sFun(x)
+
+    def __repr__(self):
+        return '{}({})'.format(type(self).__name__, self.sFun)
+
+
+class constantNonSymFractionalOrder(singleVariableUnsymmetricFractionalOrder):
+    def __init__(self, s):
+        super().__init__(constantExtended(s), s, s, 1)
+        self.value = float(s)
+
+
+class smoothedLeftRightFractionalOrder(singleVariableUnsymmetricFractionalOrder):
+    def __init__(self, sl, sr, r=0.1, slope=200., interface=0.):
+        super().__init__(smoothStep(sl, sr, r, interface), min(sl, sr), max(sl, sr), 2)
+
+
+class linearLeftRightFractionalOrder(singleVariableUnsymmetricFractionalOrder):
+    def __init__(self, sl, sr, r=0.1, interface=0.):
+        super().__init__(linearStep(sl, sr, r, interface), min(sl, sr), max(sl, sr), 2)
+
+
+class smoothedInnerOuterFractionalOrder(singleVariableUnsymmetricFractionalOrder):
+    def __init__(self, sl, sr, r=0.1, slope=200., radius=0.5):
+        super().__init__(smoothStepRadial(sl, sr, r, radius), min(sl, sr), max(sl, sr))

@@ -218,6 +218,8 @@ class Kernel:
     def __call__(self, x, y):
         x = np.atleast_1d(np.asarray(x, dtype=float))
         y = np.atleast_1d(np.asarray(y, dtype=float))
+        if getattr(self, 'pointwise', False):
+            return float(self.evalPoints(x, y))
         d2 = float(((x-y)**2).sum())
         if self.finiteHorizon and not d2 <= self.horizonValue**2:
             return 0.
@@ -242,17 +244,23 @@ class FractionalKernel(Kernel):
                  derivative=0, tempered=0., max_horizon=np.nan, manifold=False, normalized=True):
         if derivative != 0 or tempered != 0. or manifold:
             raise NotImplementedError('derivative / tempered / manifold fractional kernels')
-        from .fractionalOrders import variableFractionalOrder
+        from .fractionalOrders import variableFractionalOrder, singleVariableUnsymmetricFractionalOrder
         self.s = s
         self.derivative = derivative
         self.temperedValue = tempered
         self.manifold = manifold
         self.normalized = normalized
-        variableOrder = isinstance(s, variableFractionalOrder)
+        # orders of one variable s(x): evaluated per quadrature point, non-symmetric (kernels.py:147-149 forces piecewise=False)
+        self.pointwise = isinstance(s, singleVariableUnsymmetricFractionalOrder)
+        if self.pointwise:
+            piecewise = False
+            if horizon is not None and getattr(horizon, 'value', np.inf) != np.inf:
+                raise NotImplementedError('pointwise variable order with a finite horizon')
+        variableOrder = isinstance(s, variableFractionalOrder) or self.pointwise
         if variableOrder:
             # kernelsCy.pyx:1603-1621: parameters are set per element pair by evalParams
-            if not piecewise:
-                raise NotImplementedError('variable orders that are not piecewise constant per element pair')
+            if not piecewise and not self.pointwise:
+                raise NotImplementedError('two-variable orders that are not piecewise constant per element pair')
             self.sValue = np.nan
             self.singularityValue = np.nan
             shift = 0. if not boundary else 1.
@@ -275,10 +283,28 @@ class FractionalKernel(Kernel):
             self.variable = self.variableOrder = self.variableSingularity = self.variableScaling = True
             self.symmetric = bool(s.symmetric)
 
+    def scalingOfOrder(self, sv):
+        """variableFractionalLaplacianScaling (kernelNormalization.pyx:329-364) times phi = 1/s of the boundary twin; vectorised"""
+        from scipy.special import gamma as G
+        sv = np.asarray(sv, dtype=float)
+        C = 2.0**(2.0*sv)*sv*G(sv+0.5*self.dim)*pi**(-0.5*self.dim)/G(1.0-sv)*0.5 if self.normalized else np.full(sv.shape, 0.5)
+        return C/sv if self.boundary else C
+
+    def evalPoints(self, x, y):
+        """pointwise kernels: gamma(x, y) = C(s(x)) |x-y|^(shift-d-2 s(x)) for arrays of points (updateAndEvalFractional,
+        kernelsCy.pyx:596-622)"""
+        x = np.asarray(x, dtype=float)
+        y = np.asarray(y, dtype=float)
+        sv = self.s.evalPoints(x)
+        d2 = ((x-y)**2).sum(axis=-1)
+        return self.scalingOfOrder(sv)*d2**(0.5*((1. if self.boundary else 0.)-self.dim-2*sv))
+
     def evalParams(self, x, y):
         """kernelsCy.pyx:1852-1867 (piecewise): order, singularity and scaling of the element pair with centres x, y"""
         if not self.variable:
             return
+        if self.pointwise:
+            return                                          # evalParams does nothing for piecewise == False
         sv = self.s(x, y)
         self.sValue = sv
         self.singularityValue = (1. if self.boundary else 0.)-self.dim-2*sv
@@ -312,8 +338,8 @@ class FractionalKernel(Kernel):
         """Kernel obtained by eliminating the exterior via Gauss' theorem:
         Gamma_b = (C/s) |x-y|^{-(d-1)-2s}."""
         if self.variable:
-            return FractionalKernel(self.dim, self.s, self.horizon, None, None, phi=None, piecewise=self.piecewise, boundary=True,
-                                    normalized=self.normalized)
+            return FractionalKernel(self.dim, self.s, None if self.pointwise else self.horizon, None, None, phi=None,
+                                    piecewise=self.piecewise, boundary=True, normalized=self.normalized)
         return FractionalKernel(self.dim, self.s, self.horizon, None, self.scalingPrePhi,
                                 phi=constantTwoPoint(1./self.sValue), piecewise=self.piecewise, boundary=True,
                                 normalized=self.normalized)
@@ -323,8 +349,8 @@ class FractionalKernel(Kernel):
 
 
 def _getFractionalOrder(s):
-    from .fractionalOrders import variableFractionalOrder
-    if isinstance(s, (constFractionalOrder, variableFractionalOrder)):
+    from .fractionalOrders import variableFractionalOrder, singleVariableUnsymmetricFractionalOrder
+    if isinstance(s, (constFractionalOrder, variableFractionalOrder, singleVariableUnsymmetricFractionalOrder)):
         return s
     if isinstance(s, (float, int, np.floating)):
         return constFractionalOrder(float(s))
@@ -356,8 +382,8 @@ def getFractionalKernel(dim, s, horizon=None, interaction=None, scaling=None, no
     sFun = _getFractionalOrder(s)
     horizonFun = _getHorizon(horizon)
     interaction = _getInteraction(interaction, horizonFun)
-    from .fractionalOrders import variableFractionalOrder
-    if isinstance(sFun, variableFractionalOrder):
+    from .fractionalOrders import variableFractionalOrder, singleVariableUnsymmetricFractionalOrder
+    if isinstance(sFun, (variableFractionalOrder, singleVariableUnsymmetricFractionalOrder)):
         # variableFractionalLaplacianScaling (kernelNormalization.pyx:329-364) is evaluated per element pair in evalParams
         return FractionalKernel(dim, sFun, horizonFun, interaction, None, None, piecewise, boundary, derivative, tempered,
                                 max_horizon, manifold, normalized)

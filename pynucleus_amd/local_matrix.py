@@ -68,12 +68,14 @@ class orderFormula:
 
 
 class singularRule:
-    def __init__(self, qr, psi):
+    def __init__(self, qr, psi, phi0=None, phi1=None):
         self.nodes = np.ascontiguousarray(qr.nodes)
         self.weights = np.ascontiguousarray(qr.weights)
         self.psi = np.ascontiguousarray(psi)
         self.num_nodes = qr.num_nodes
         self.rows = psi.shape[0]
+        # non-symmetric local matrices (FL2:965-1075): psi = phi0 - phi1 with the x and the y parts kept apart
+        self.phi0, self.phi1 = phi0, phi1
 
 
 class nonlocalTables:
@@ -86,8 +88,13 @@ class nonlocalTables:
         self.dim = dim = mesh.dim
         assert mesh.manifold_dim == dim and dim in (1, 2)
         assert kernel.dim == dim, 'Kernel dimension must match dm.mesh dimension'
+        self.pointwise = bool(getattr(kernel, 'pointwise', False))
+        if self.pointwise:
+            self.variable = True
+            self._setup_pointwise(dm, kernel, params, zeroExterior, qcap)
+            return
         if not kernel.symmetric:
-            raise NotImplementedError('non-symmetric kernels (local matrices with (2 dpe)^2 entries, NA:1411-1428)')
+            raise NotImplementedError('non-symmetric piecewise kernels (NA:1411-1428 with evalParams per orientation)')
         self.variable = bool(kernel.variable)
         if self.variable:
             self._setup_variable(dm, kernel, params, zeroExterior, qcap)
@@ -157,6 +164,148 @@ class nonlocalTables:
         else:
             self.facet_labels = np.zeros(0, dtype=np.int32)
 
+    # ------------------------------------------------------------------
+    def _setup_pointwise(self, dm, kernel, params, zeroExterior, qcap):
+        """Non-symmetric kernels with an order s(x) evaluated per quadrature point (fractionalLaplacian{1,2}D_nonsym,
+        FL2:894-1184, FL1:410-604; kernel evaluation updateAndEvalFractional KC:596-622).  Per pair the reference sets the
+        singularity from the largest order at the two centres and all vertices (evalParamsOnSimplices, KC:1825-1846): that
+        value enters the order formula and keys the near-field rule (FL2:957, 990, 1075).  Here: per-cell / per-facet maxima,
+        order-formula constants as functions of the pair's order, and -- on request -- the table of near rules over the
+        distinct orders of the touching pairs.  The _nonsym constructors drop the caller's target_order and
+        quad_order_diagonal (FL2:911, FL1:427 pass num_dofs in their place), the boundary twins keep them."""
+        mesh = dm.mesh
+        if dm.dofs_per_element != mesh.dim+1:
+            raise NotImplementedError('pointwise variable orders are built for P1 elements')
+        self.classes = None
+        self.dpe = dm.dofs_per_element
+        self.num_dofs = dm.num_dofs
+        self.hmin = mesh.hmin
+        self.H0 = mesh.diam/np.sqrt(8)
+        self.dof_perm_table = dof_permutation_table(dm)
+        self.qcap = qcap
+        self.zeroExterior = bool(zeroExterior)
+        dim = self.dim
+        sF = kernel.s
+        logh = abs(np.log(self.hmin/self.H0))
+        if dim == 2:
+            self.target_order = 0.5
+            qd = max(np.ceil((self.target_order+1.+sF.max)/0.43*logh), 4)
+            qdV = max(np.ceil((self.target_order+1.+sF.max)/0.7*logh), 4)
+            self.quad_order_diagonal, self.quad_order_diagonalV = int(qd), int(qdV)
+            self.sing_fac = 4.0
+            self.pw_c0 = (0.5*self.target_order+0.5)*np.log(self.num_dofs*self.H0**2)
+        else:
+            self.target_order = dm.polynomialOrder+1-sF.min
+            qd = max(np.ceil(((self.target_order+2.)*np.log(self.num_dofs*self.H0)+(2.*sF.max-1.)*logh)/0.8), 2)
+            self.quad_order_diagonal = self.quad_order_diagonalV = int(qd)
+            self.sing_fac = 1.0
+            self.pw_c0 = (self.target_order+2.)*np.log(self.num_dofs*self.H0)
+        self._distant_rules(qcap)
+        self.order_type = int(sF.sFun.device_type)
+        self.order_params = np.array(sF.sFun.device_params(), dtype=np.float64)
+        verts = mesh.vertices[mesh.cells]                                  # [nc, nV, dim]
+        self.cell_smax = np.maximum(sF.evalPoints(verts.mean(axis=1)), sF.evalPoints(verts).max(axis=1))
+        self.has_boundary_tables = True
+        self.boundaryKernel = bk = kernel.getBoundaryKernel()
+        t_b = params.get('target_order', None)
+        qd_b = params.get('quad_order_diagonal', None)
+        if dim == 2:
+            if t_b is None:
+                t_b = 0.5
+            if qd_b is None:
+                qd_b = max(np.ceil((t_b+0.5+sF.max)/0.35*logh), 2)
+            self.bsing_fac = -2.0
+            self.pw_bc0 = (0.5*t_b+0.25)*np.log(self.num_dofs*self.H0**2)
+        else:
+            if t_b is None:
+                t_b = dm.polynomialOrder+1-sF.min
+            if qd_b is None:
+                qd_b = max(np.ceil(((t_b+1.)*np.log(self.num_dofs*self.H0)+(2.*sF.max-1.)*logh)/0.8), 2)
+            self.bsing_fac = 1.0
+            self.pw_bc0 = (t_b+1.)*np.log(self.num_dofs*self.H0)
+        self.bquad_order_diagonal = int(qd_b)
+        self._boundary_mesh()
+        fv = mesh.vertices[self.bcells]                                     # [nb, dim, dim]
+        self.facet_smax = np.maximum(sF.evalPoints(fv.mean(axis=1)), sF.evalPoints(fv).max(axis=1))
+        self._pw_rules = None
+
+    def pw_formula(self, sv, boundary=False):
+        """order-formula constants of a pair whose largest order is sv (FL2:915-935, FL1:431-450; FL2:1226-1243, FL1:644-660)"""
+        if not boundary:
+            if self.dim == 2:
+                return orderFormula(self.pw_c0, sv-1., 1., sv, 0.4, False)
+            return orderFormula(self.pw_c0, 2.*sv-1., 0., 2.*sv, 0.8, False)
+        if self.dim == 2:
+            return orderFormula(self.pw_bc0, sv-1., 1., sv, 0.35, True)
+        st = max(sv-0.5, 0.)
+        return orderFormula(self.pw_bc0, 2.*st-1., 0., 2.*st, 0.8, False)
+
+    def touching_pairs(self):
+        """(c1 <= c2, number of shared vertices) of all cell pairs with a common vertex, and the same for (cell, boundary facet)"""
+        from scipy.sparse import csr_matrix
+        mesh = self.dm.mesh
+        nc, nV = mesh.num_cells, self.dim+1
+        B = csr_matrix((np.ones(nc*nV, dtype=np.int32), (np.repeat(np.arange(nc), nV), mesh.cells.ravel())),
+                       shape=(nc, mesh.num_vertices))
+        Cm = (B@B.T).tocoo()
+        keep = Cm.row <= Cm.col
+        pairs = np.stack([Cm.row[keep], Cm.col[keep], Cm.data[keep]], axis=1).astype(np.int32)
+        nb = self.bcells.shape[0]
+        F = csr_matrix((np.ones(nb*self.dim, dtype=np.int32), (np.repeat(np.arange(nb), self.dim), self.bcells.ravel())),
+                       shape=(nb, mesh.num_vertices))
+        Cb = (B@F.T).tocoo()
+        bpairs = np.stack([Cb.row, Cb.col, Cb.data], axis=1).astype(np.int32)
+        return pairs, bpairs
+
+    def pw_rules(self):
+        """near-field rules over the distinct orders of the touching pairs (the reference builds them lazily, keyed by the
+        singularity value: FL2:957-1112, FL1:466-530; boundary FL2:1255-1314, FL1:672-712).
+        Returns dict(keys, rules[slot] = (nodes[nk, 2nV, M], w[nk, M], phi0[nk, rows, M], phi1[nk, rows, M]),
+        bkeys, brules[slot] = (nodes, w, phi), pairs[np, 4] = (c1, c2, common, key index), bpairs likewise)."""
+        if self._pw_rules is not None:
+            return self._pw_rules
+        dim, nV = self.dim, self.dim+1
+        pairs, bpairs = self.touching_pairs()
+        sv = np.maximum(self.cell_smax[pairs[:, 0]], self.cell_smax[pairs[:, 1]])
+        keys, kidx = np.unique(sv, return_inverse=True)
+        bsv = np.maximum(self.cell_smax[bpairs[:, 0]], self.facet_smax[bpairs[:, 1]])
+        bkeys, bkidx = np.unique(bsv, return_inverse=True)
+        rules = {}
+        dm_order = max(self.dm.polynomialOrder, 1)
+        for slot in range(nV):
+            panel = -(slot+1)
+            acc = [[], [], [], []]
+            for sval in keys:
+                sing = -dim-2.*sval
+                if dim == 2:
+                    qr = singularityCancelationQuadRule2D(panel, 2.+sing, self.quad_order_diagonal, self.quad_order_diagonalV)
+                else:
+                    qr = singularityCancelationQuadRule1D(panel, 2.+sing, self.quad_order_diagonal, 2*dm_order)
+                r = self._psi_tables({panel: qr})[panel]
+                acc[0].append(r.nodes); acc[1].append(r.weights); acc[2].append(r.phi0); acc[3].append(r.phi1)
+            rules[slot] = tuple(np.ascontiguousarray(np.stack(a)) for a in acc)
+        brules = {}
+        qd = self.bquad_order_diagonal
+        for slot in range(dim):
+            panel = -(slot+1)
+            acc = [[], [], []]
+            for sval in bkeys:
+                sing = 1.-dim-2.*sval
+                if dim == 2:
+                    sg = sing if (panel == COMMON_VERTEX or sing > -2.+1e-3) else 2.+sing          # FL2:1271-1274
+                    qr = singularityCancelationQuadRule2D_boundary(panel, sg, qd, qd)
+                    phi = self.dm.evalShapeFunctions(qr.nodes[:3])
+                else:
+                    sg = sing if sing > -1.+1e-3 else 2.+sing                                       # FL1:686-689
+                    qr = singularityCancelationQuadRule1D_boundary(COMMON_VERTEX, sg, qd, 1)
+                    phi = self.dm.evalShapeFunctions(qr.nodes[:2])
+                acc[0].append(qr.nodes); acc[1].append(qr.weights); acc[2].append(phi)
+            brules[slot] = tuple(np.ascontiguousarray(np.stack(a)) for a in acc)
+        self._pw_rules = dict(keys=keys, rules=rules, bkeys=bkeys, brules=brules,
+                              pairs=np.ascontiguousarray(np.column_stack([pairs, kidx]).astype(np.int32)),
+                              bpairs=np.ascontiguousarray(np.column_stack([bpairs, bkidx]).astype(np.int32)))
+        return self._pw_rules
+
     def class_of_pair(self, c1, c2):
         return int(self.cls_of[self.cell_labels[c1], self.cell_labels[c2]])
 
@@ -172,29 +321,31 @@ class nonlocalTables:
             py = dm.evalShapeFunctions(qr.nodes[nV:2*nV])
             common = -panel
             if common == nV:                                 # identical cells
-                psi = px-py
+                p0, p1 = px.copy(), py.copy()
             elif common == 1:
-                psi = np.zeros((2*dpe-dpv, qr.num_nodes))
+                p0 = np.zeros((2*dpe-dpv, qr.num_nodes))
+                p1 = np.zeros_like(p0)
                 for dof in range(dpv):
-                    psi[dof] = px[dof]-py[dof]
+                    p0[dof], p1[dof] = px[dof], py[dof]
                 for dof in range(dpv, dpe):
-                    psi[dof] = px[dof]
-                    psi[dpe+dof-dpv] = -py[dof]
+                    p0[dof] = px[dof]
+                    p1[dpe+dof-dpv] = py[dof]
             elif common == 2:
-                psi = np.zeros((2*dpe-2*dpv-dped, qr.num_nodes))
+                p0 = np.zeros((2*dpe-2*dpv-dped, qr.num_nodes))
+                p1 = np.zeros_like(p0)
                 for dof in range(2*dpv):
-                    psi[dof] = px[dof]-py[dof]
+                    p0[dof], p1[dof] = px[dof], py[dof]
                 for dof in range(nV*dpv, nV*dpv+dped):
-                    psi[dof] = px[dof]-py[dof]
+                    p0[dof], p1[dof] = px[dof], py[dof]
                 for dof in range(2*dpv, nV*dpv):
-                    psi[dof] = px[dof]
-                    psi[dpe+dof-2*dpv] = -py[dof]
+                    p0[dof] = px[dof]
+                    p1[dpe+dof-2*dpv] = py[dof]
                 for dof in range(nV*dpv+dped, dpe):
-                    psi[dof] = px[dof]
-                    psi[dpe+dof-2*dpv-dped] = -py[dof]
+                    p0[dof] = px[dof]
+                    p1[dpe+dof-2*dpv-dped] = py[dof]
             else:
                 raise NotImplementedError()
-            out[panel] = singularRule(qr, psi)
+            out[panel] = singularRule(qr, p0-p1, p0, p1)
         return out
 
     def _setup2D(self, kernel, target_order, quad_order_diagonal):

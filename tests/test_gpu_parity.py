@@ -155,3 +155,80 @@ def test_two_ranks_share_the_pairs():
         assert p.exitcode == 0
     assert pairs == nc*(nc+1)//2
     assert e1 < 1e-11 and e2 < TOL
+
+
+@pytest.mark.parametrize('case', ['smoothedLeftRight_disc', 'constantNonSym_disc', 'innerOuter_disc', 'smoothedLeftRight_interval',
+                                  'linearLeftRight_interval', 'constantNonSym_noext'])
+def test_pointwise_nonsymmetric_dense(case):
+    """a16: non-symmetric kernels with an order s(x) per quadrature point (fractionalLaplacian{1,2}D_nonsym, both orientations of
+    every pair, (2 dpe)^2 local matrices, near rules keyed by the pair's order): GPU == oracle entry-wise, same counters"""
+    from pynucleus_amd import disc, interval, PHYSICAL, P1_DoFMap, getFractionalKernel
+    from pynucleus_amd.builder import nonlocalBuilder
+    from pynucleus_amd.fractionalOrders import (smoothedLeftRightFractionalOrder, constantNonSymFractionalOrder,
+                                                smoothedInnerOuterFractionalOrder, linearLeftRightFractionalOrder)
+    from oracle.oracle import OracleProblem
+    zeroExterior = True
+    if case == 'smoothedLeftRight_disc':
+        mesh, s = disc(3), smoothedLeftRightFractionalOrder(0.25, 0.75, r=0.3)
+    elif case == 'constantNonSym_disc':
+        mesh, s = disc(2), constantNonSymFractionalOrder(0.4)
+    elif case == 'innerOuter_disc':
+        mesh, s = disc(3), smoothedInnerOuterFractionalOrder(0.3, 0.6, r=0.2)
+    elif case == 'smoothedLeftRight_interval':
+        mesh, s = interval(5), smoothedLeftRightFractionalOrder(0.25, 0.75)
+    elif case == 'linearLeftRight_interval':
+        mesh, s = interval(5), linearLeftRightFractionalOrder(0.6, 0.3, r=0.25)
+    else:
+        mesh, s, zeroExterior = disc(2), constantNonSymFractionalOrder(0.6), False
+    dm = P1_DoFMap(mesh, PHYSICAL)
+    b = nonlocalBuilder(dm, getFractionalKernel(mesh.dim, s), {}, zeroExterior=zeroExterior)
+    A = b.getDense()
+    Aref, cnt, _ = OracleProblem(b.tables).get_dense()
+    got = A.info['counters']
+    for key in ('numCellPairs', 'numAssembledCellPairs', 'numIntegrations', 'numBoundaryPairs', 'numBoundaryIntegrations',
+                'orders', 'singular'):
+        assert got[key] == cnt[key], (key, got[key], cnt[key])
+    Ag = A.toarray()
+    scale = np.abs(Aref).max()
+    assert np.abs(Ag-Aref).max() < TOL*scale, np.abs(Ag-Aref).max()/scale
+    if case.startswith('smoothed'):
+        assert np.abs(Aref-Aref.T).max() > 1e-6*scale          # genuinely non-symmetric
+
+
+def test_pointwise_stored_errors_disc():
+    """The reference's stored numbers for the non-symmetric path on the disc (noRef 5, N = 2977; the CPU oracle needs minutes
+    for this size, the GPU path milliseconds): runFractional --domain disc --s constantNonSym(0.25) --problem constant ->
+    Hs error 0.18399339204392906; --s twoDomainNonSym(0.25,0.75) --problem knownSolution -> L2 error 0.005965596537366911
+    (compared by the reference at relTol 1e-2 / 3e-2)"""
+    from math import gamma
+    from pynucleus_amd import driverMesh, PHYSICAL, P1_DoFMap, getFractionalKernel
+    from pynucleus_amd.builder import nonlocalBuilder
+    from pynucleus_amd.fractionalOrders import smoothedLeftRightFractionalOrder, constantNonSymFractionalOrder
+    from pynucleus_amd.quadrature import simplexXiaoGimbutas
+    from tests.test_pointwise import known_solution_problem
+    mesh = driverMesh('disc', 5)
+    dm = P1_DoFMap(mesh, PHYSICAL)
+    assert dm.num_dofs == 2977
+    s = 0.25
+    A = nonlocalBuilder(dm, getFractionalKernel(2, constantNonSymFractionalOrder(s)), {'target_order': 0.5}).getDense().toarray()
+    b = np.asarray(dm.assembleRHS(1.0))
+    u = np.linalg.solve(A, b)
+    C = 2.**(-2.*s)*gamma(1.)/gamma((2+2.*s)/2.)/gamma(1.+s)
+    hs = np.sqrt(abs(b@u-C*np.pi/(s+1)))
+    assert abs(hs-0.18399339204392906) <= 1e-3*0.18399339204392906, hs
+
+    kernel = getFractionalKernel(2, smoothedLeftRightFractionalOrder(0.25, 0.75))
+    A = nonlocalBuilder(dm, kernel, {'target_order': 0.5}).getDense().toarray()
+    assert np.abs(A-A.T).max() > 1e-3*np.abs(A).max()
+    rhs, sol, L2ex2 = known_solution_problem(2, kernel)
+    b = np.asarray(dm.assembleRHS(rhs, qr=simplexXiaoGimbutas(3, 2, 2)))
+
+    class Gauss2D:                                           # fem/PyNucleus_fem/quadrature.pyx:279-282, femCy.pyx:2646-2650
+        nodes = np.array([[0.5, 0.0, 0.5], [0.5, 0.5, 0.0], [0.0, 0.5, 0.5]])
+        weights = np.full(3, 1./3.)
+        num_nodes = 3
+    u = np.linalg.solve(A, b)
+    z = np.asarray(dm.assembleRHS(sol, qr=Gauss2D()))
+    M = dm.assembleMass()
+    err = float(np.sqrt(abs(L2ex2-2*z@u+u@(M@u))))
+    assert abs(err-0.005965596537366911) <= 3e-2*0.005965596537366911, err
