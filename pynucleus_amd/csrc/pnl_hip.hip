@@ -1069,6 +1069,7 @@ int pointwise_impl(pnl_context *ctx, double *A, int64_t ldA, int zero_exterior, 
         hipLaunchKernelGGL(k_wl_scan, dim3(1), dim3(64), 0, ctx->stream, (const unsigned*)hist, offs, coff, cursor);
         hipLaunchKernelGGL(k_wl_scatter, dim3(512), dim3(PNL_NTHREADS), 0, ctx->stream, wl, wlc, ctx->wl_cap, (const unsigned*)offs, cursor,
                            (int4*)ctx->b_wlsorted.p);
+        hipLaunchKernelGGL(k_pw_stats, dim3(1), dim3(PNL_WL_BINS), 0, ctx->stream, P, (const unsigned*)hist);
         // LDS: rule table + order / scaling of the second cell's points for the 16 pairs of a chunk
         const int tab_max = 256;
         const size_t lds = sizeof(double)*((size_t)tab_max*ST+(size_t)(PNL_NTHREADS/16)*tab_max*2);

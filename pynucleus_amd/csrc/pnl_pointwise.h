@@ -118,11 +118,7 @@ k_pw_classify(const DevProblem P, const PwDev W, int4 *__restrict__ wl, unsigned
                 const DevFormula F = pw_formula(W, DIM, fmax(sm1, W.cell_smax[c2]));
                 q = quad_order(F, P.H0, h1, P.ch[c2], sqrt(d2));
                 if (q > P.qmax || q > PNL_MAXQ) atomicAdd(&P.counters[5], 1ull);
-                else {
-                    off = P.off[q]; n = P.off[q+1]-off; push = true;
-                    assembled++; evals += 2ull*n*n;
-                    atomicAdd(&P.counters[8+q], 1ull);
-                }
+                else { off = P.off[q]; n = P.off[q+1]-off; push = true; }
             }
         }
         // wave-aggregated append
@@ -138,12 +134,19 @@ k_pw_classify(const DevProblem P, const PwDev W, int4 *__restrict__ wl, unsigned
             }
         }
     }
-    (void)visited;                               // the host knows the number of visited pairs
-    const double sa = wave_sum((double)assembled), se = wave_sum((double)evals);
-    if ((threadIdx.x & 63) == 0 && sa > 0.) {
-        atomicAdd(&P.counters[1], (unsigned long long)sa);
-        atomicAdd(&P.counters[2], (unsigned long long)se);
-    }
+    (void)visited; (void)assembled; (void)evals; // the host knows the number of visited pairs, k_pw_stats counts the rest
+}
+
+// statistics from the histogram of the sorted list: pairs per order, both orientations' kernel evaluations
+__global__ void k_pw_stats(const DevProblem P, const unsigned *__restrict__ hist) {
+    const int q = threadIdx.x;
+    if (q < 2 || q > P.qmax || q > PNL_MAXQ) return;
+    const unsigned long long c = hist[q];
+    if (!c) return;
+    const unsigned long long n = (unsigned long long)(P.off[q+1]-P.off[q]);
+    atomicAdd(&P.counters[8+q], c);
+    atomicAdd(&P.counters[1], c);
+    atomicAdd(&P.counters[2], 2ull*c*n*n);
 }
 
 // ---- distant pairs from the sorted list: 16 lanes per pair split the rows of the tensor rule -------------------------

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Timing probe of the BASELINE.json configurations other than the bench workload (not the bench contract):
    C3 square / constant kernel / finite horizon / getSparse, C4 disc s=0.75 near field (assembleClusters),
-   C5 disc P2 + variable order dense, plus disc P2 constant order.  usage: config_probe.py [c3|c4|c5|p2] [size]"""
+   C5 disc P2 + variable order dense, plus disc P2 constant order.     pw: disc P1, non-symmetric order s(x) per quadrature point (twoDomainNonSym).  usage: config_probe.py [c3|c4|c5|p2|pw] [size]"""
 import sys
 import time
 import numpy as np
@@ -38,6 +38,25 @@ if what in ('p2', 'c5'):
         print('{} noRef {} N {} nc {} rep {}: wall {:.1f} ms device {:.1f} ms, phases {} -> {:.3e} pairs/s'.format(
             what, noRef, dm.num_dofs, mesh.num_cells, rep, 1e3*(t1-t0), ms['total'], {k: round(v, 2) for k, v in ms.items()},
             cnt['numAssembledCellPairs']/(1e-3*ms['total'])), flush=True)
+        del A
+elif what == 'pw':
+    from pynucleus_amd.fractionalOrders import smoothedLeftRightFractionalOrder
+    noRef = size or 5
+    mesh = disc(noRef)
+    dm = P1_DoFMap(mesh, PHYSICAL)
+    t0 = time.time()
+    b = nonlocalBuilder(dm, getFractionalKernel(2, smoothedLeftRightFractionalOrder(0.25, 0.75)), {'target_order': 0.5}, zeroExterior=True)
+    R = b.tables.pw_rules()
+    print('pw noRef {} N {}: host tables {:.2f} s, {} near-rule keys, {} touching pairs'.format(noRef, dm.num_dofs, time.time()-t0,
+                                                                                            len(R['keys']), R['pairs'].shape[0]), flush=True)
+    for rep in range(3):
+        sync(); t0 = time.time()
+        A = b.getDense()
+        sync(); t1 = time.time()
+        cnt = A.info['counters']; ms = A.info['phase_ms']
+        print('pw noRef {} rep {}: wall {:.1f} ms device {:.1f} ms, phases {} -> {:.3e} pairs/s, {:.3e} kernel evaluations/s'.format(
+            noRef, rep, 1e3*(t1-t0), ms['total'], {k: round(v, 2) for k, v in ms.items()}, cnt['numAssembledCellPairs']/(1e-3*ms['total']),
+            cnt['numIntegrations']/(1e-3*ms['total'])), flush=True)
         del A
 elif what == 'c4':
     noRef = size or 6
