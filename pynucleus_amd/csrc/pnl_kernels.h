@@ -21,21 +21,22 @@
 template <int KT>
 __device__ __forceinline__ double kern_eval(const DevKernel &k, double d2) {
     if (KT == 1) {
-        // exponent = -qm/4 (s a multiple of 1/4 in 1D / 2D): d2^(-1/2) from v_rsq_f64 (~2^-23 relative) + 2 Newton steps, for
-        // odd qm one more refined rsqrt gives d2^(-1/4); then an integer power.  A few ulp instead of libm's pow at 1/7 of the
-        // cost.  The scale is applied once per pair (kern_scale); qm is wave-uniform, the branches are scalar.
+        // exponent = -qm/4 (s a multiple of 1/4 in 1D / 2D): d2^(-1/2) from v_rsq_f64 (~2^-23 relative) + one Halley step
+        // (cubic: r (1 + e/2 + 3 e^2/8), e = 1 - d2 r^2, five operations for full precision), for odd qm one more refined
+        // rsqrt gives d2^(-1/4); then an integer power.  A few ulp instead of libm's pow at 1/8 of the cost.  The scale is
+        // applied once per pair (kern_scale); qm is wave-uniform, the branches are scalar.
         double r = __builtin_amdgcn_rsq(d2);
-        const double h = 0.5*d2;
-        r = r*__builtin_fma(-h*r, r, 1.5);
-        r = r*__builtin_fma(-h*r, r, 1.5);
+        {
+            const double e = __builtin_fma(-(d2*r), r, 1.0);
+            r = __builtin_fma(r, e*__builtin_fma(0.375, e, 0.5), r);
+        }
         int p = k.qm;
         if (p == 6) return (r*r)*r;                      // s = 1/2 in 2D
         double base = r;
         if (p & 1) {
             double t = __builtin_amdgcn_rsq(r);
-            const double hr = 0.5*r;
-            t = t*__builtin_fma(-hr*t, t, 1.5);
-            t = t*__builtin_fma(-hr*t, t, 1.5);
+            const double e = __builtin_fma(-(r*t), t, 1.0);
+            t = __builtin_fma(t, e*__builtin_fma(0.375, e, 0.5), t);
             base = r*t;                                  // d2^(-1/4)
         } else p >>= 1;
         double res = (p & 1) ? base : 1.;
