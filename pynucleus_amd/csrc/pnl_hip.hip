@@ -1298,7 +1298,6 @@ int pnl_upload_distant_rules(pnl_context *ctx, int qmax, const int32_t *off, con
         ctx->P.tt_npts = npts;
     }
     ctx->qmax = qmax;
-    }
     ctx->have_rules = true;
     return PNL_OK;
 }
