@@ -457,6 +457,9 @@ __device__ __forceinline__ bool tile_eligible(int n) { return n == 2 || n == 3 |
 #endif
 
 #ifndef PNL_TILE_WAVES
+#ifndef PNL_PURE_WAVES
+#define PNL_PURE_WAVES 4
+#endif
 #define PNL_TILE_WAVES 2      // waves per SIMD the tile kernel is register-limited to (measured: 2 beats 3 and 4)
 #endif
 // P2 (78 local entries per pair) needs more than 256 VGPRs: one wave per SIMD without spills beats two with 600 B of scratch
@@ -854,7 +857,7 @@ __device__ __forceinline__ double row16_sum(double v) {
 // read, the points of cell i and the row sums that feed its diagonal block stay in registers for the whole tile, and the
 // column sums are reduced over the wave with DPP.  Same numbers as eval_distant_fixed (NO:722-789), same LDS sub-block.
 template <int DIM, int DPE, int KT>
-__global__ void __launch_bounds__(PNL_NTHREADS, 3)
+__global__ void __launch_bounds__(PNL_NTHREADS, PNL_PURE_WAVES)
 k_tile_pure(const DevProblem P, const int2 *__restrict__ tiles, int ntiles, double *__restrict__ A, long long ldA,
             double *__restrict__ Dglob, int acc_stride, int q_uniform, int symflush) {
     constexpr int TILE = 64, NV = DIM+1, NC = NV*DIM, ND = DPE*(DPE+1)/2, NP = (DIM == 2) ? 3 : 2, ST = 4+DPE;
@@ -869,25 +872,23 @@ k_tile_pure(const DevProblem P, const int2 *__restrict__ tiles, int ntiles, doub
     int *s_hb = s_slotb+TILE*DPE;
     double *s_acc = (double*)(s_hb+TILE);               // [nA+1][acc_stride]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // rule constants: wave-uniform global reads (scalar loads), so the weights products and shape functions at the points
+    // live in SGPRs instead of 54 VGPRs
+    double ww[NP][NP], ph[NP][DPE], bary[NP][NV];
     {
         const int off = P.off[q_uniform];
-        for (int t = tid; t < NP*ST; t += PNL_NTHREADS) {
-            const int pt = t/ST, k = t-pt*ST;
-            s_rule[t] = k < 3 ? P.bary[3*(size_t)(off+pt)+k] : (k == 3 ? P.w[off+pt] : P.phi[(size_t)(off+pt)*DPE+k-4]);
+        const double *__restrict__ gb = P.bary+3*(size_t)off, *__restrict__ gw = P.w+off, *__restrict__ gp = P.phi+(size_t)off*DPE;
+#pragma unroll
+        for (int i = 0; i < NP; i++) {
+#pragma unroll
+            for (int j = 0; j < NP; j++) ww[i][j] = gw[i]*gw[j];
+#pragma unroll
+            for (int a = 0; a < DPE; a++) ph[i][a] = gp[i*DPE+a];
+#pragma unroll
+            for (int k = 0; k < NV; k++) bary[i][k] = gb[3*i+k];
         }
     }
-    __syncthreads();
-    // rule in registers: weights products, shape functions at the points
-    double ww[NP][NP], ph[NP][DPE], bary[NP][NV];
-#pragma unroll
-    for (int i = 0; i < NP; i++) {
-#pragma unroll
-        for (int j = 0; j < NP; j++) ww[i][j] = s_rule[i*ST+3]*s_rule[j*ST+3];
-#pragma unroll
-        for (int a = 0; a < DPE; a++) ph[i][a] = s_rule[i*ST+4+a];
-#pragma unroll
-        for (int k = 0; k < NV; k++) bary[i][k] = s_rule[i*ST+k];
-    }
+    (void)s_rule;
     const double scale2 = 2.*kern_scale<KT>(P.k);
     unsigned long long npairs = 0;
 #pragma unroll 1
