@@ -643,8 +643,10 @@ int assemble_impl(pnl_context *ctx, double *A, int64_t ldA, int zero_exterior, i
             ctx->tile_off = ctx->cls_tile_off[k]; ctx->n_mixed = ctx->cls_n_mixed[k]; ctx->n_pure = ctx->cls_n_pure[k];
             if (ctx->n_mixed+ctx->n_pure == 0) continue;
             const int tb0 = ctx->tile_cell_filter ? cell_begin : 0, tb1 = ctx->tile_cell_filter ? cell_end : ctx->nc;
-            rc = ctx->P.k.fast ? launch_tiles<DIM, DPE, TILE, 1>(ctx, ntiles, A, ldA, tb0, tb1)
-                               : launch_tiles<DIM, DPE, TILE, 0>(ctx, ntiles, A, ldA, tb0, tb1);
+            // s = 1/2 in 2D (exponent -6/4) has its own instantiation: branch-free evaluations
+            if (ctx->P.k.fast && ctx->P.k.qm == 6 && DPE == 3 && !getenv("PNL_NO_KT2")) rc = launch_tiles<DIM, DPE, TILE, (DPE == 3 ? 2 : 1)>(ctx, ntiles, A, ldA, tb0, tb1);
+            else rc = ctx->P.k.fast ? launch_tiles<DIM, DPE, TILE, 1>(ctx, ntiles, A, ldA, tb0, tb1)
+                                    : launch_tiles<DIM, DPE, TILE, 0>(ctx, ntiles, A, ldA, tb0, tb1);
             if (rc) { ctx->cur = 0; return rc; }
         }
     HIPCHK(ctx, hipEventRecord(ctx->ev[1], ctx->stream));

@@ -18,9 +18,17 @@
 
 // ---------------------------------------------------------------------------------------------
 // kernel function gamma(|x-y|^2)   (KC:75-294)
+// KT: 0 general (pow / indicator / peridynamic, horizon test), 1 fractional with exponent -qm/4, qm a run-time (wave-uniform)
+// value, 2 the same with qm == 6 known at compile time (s = 1/2 in 2D): no branch per evaluation, so the compiler
+// interleaves the dependent chains of the independent evaluations of a pair.
 template <int KT>
 __device__ __forceinline__ double kern_eval(const DevKernel &k, double d2) {
-    if (KT == 1) {
+    if (KT == 2) {
+        double r = __builtin_amdgcn_rsq(d2);
+        const double e = __builtin_fma(-(d2*r), r, 1.0);
+        r = __builtin_fma(r, e*__builtin_fma(0.375, e, 0.5), r);
+        return (r*r)*r;
+    } else if (KT == 1) {
         // exponent = -qm/4 (s a multiple of 1/4 in 1D / 2D): d2^(-1/2) from v_rsq_f64 (~2^-23 relative) + one Halley step
         // (cubic: r (1 + e/2 + 3 e^2/8), e = 1 - d2 r^2, five operations for full precision), for odd qm one more refined
         // rsqrt gives d2^(-1/4); then an integer power.  A few ulp instead of libm's pow at 1/8 of the cost.  The scale is
@@ -56,7 +64,7 @@ __device__ __forceinline__ double kern_eval(const DevKernel &k, double d2) {
 }
 
 template <int KT>
-__device__ __forceinline__ double kern_scale(const DevKernel &k) { return KT == 1 ? k.scale : 1.; }
+__device__ __forceinline__ double kern_scale(const DevKernel &k) { return KT >= 1 ? k.scale : 1.; }
 
 // distant quadrature order  (FL2:622-642, :1226-1243, FL1:234-253, :646-660)
 __device__ __forceinline__ int quad_order(const DevFormula &F, double H0, double h1, double h2, double d) {
