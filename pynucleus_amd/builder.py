@@ -88,6 +88,18 @@ class nonlocalBuilder:
         self._ctx.set_stream(torch.cuda.current_stream(self._ctx.device).cuda_stream)
         return self._ctx
 
+    def _single_order_twin(self):
+        """A variable-order kernel whose order takes one value (varconst) has one kernel block and no jumps
+        (getKernelBlocksAndJumps, NA:2312-2384): its near field / H2 operator is the one of the constant-order kernel with
+        the same near-field quadrature orders.  Returns that builder, or None."""
+        T = self.tables
+        if getattr(T, 'pointwise', False) or not self.kernel.variable or not T.classes or len(T.classes) != 1:
+            return None
+        if getattr(self, '_twin', None) is None:
+            self._twin = nonlocalBuilder(self.dm, T.classes[0].kernel, self.params, zeroExterior=self.zeroExterior, comm=self.comm,
+                                         PLogger=self.PLogger, device=self.device)
+        return self._twin
+
     def _symmetric_only(self, what):
         if getattr(self.tables, 'pointwise', False):
             raise NotImplementedError('{} for non-symmetric kernels with an order per quadrature point (getDense only)'.format(what))
@@ -162,6 +174,8 @@ class nonlocalBuilder:
         assembly on the GPU into a diagonal-only SSS pattern; returns the diagonal as a numpy vector wrapped like the
         reference's diagonalOperator (``.data``, ``.diagonal``)."""
         self._symmetric_only('getDiagonal')
+        if self._single_order_twin() is not None:
+            return self._single_order_twin().getDiagonal()
         from . import clusters
         from .linear_operators import diagonalOperator
         Pnear = clusters.singleDoFClusters(self.dm)
@@ -172,6 +186,8 @@ class nonlocalBuilder:
         """NA:1538-1661: the entry A[I, J] alone: element pairs of (supp phi_I u supp phi_J)^2 and, with zeroExterior,
         the Gauss-theorem term over the boundary of that union, assembled on the GPU into a one-entry pattern."""
         self._symmetric_only('getEntry')
+        if self._single_order_twin() is not None:
+            return self._single_order_twin().getEntry(I, J)
         import torch
         from . import clusters
         from .linear_operators import CSR_LinearOperator
@@ -282,6 +298,8 @@ class nonlocalBuilder:
         communicator (row-sharded near field) the near-field operator alone is returned: the far field is not
         distributed yet."""
         self._symmetric_only('getH2')
+        if self._single_order_twin() is not None:
+            return self._single_order_twin().getH2(returnNearField, returnTree, **kwargs)
         from . import clusters
         from .h2 import h2Plan, H2Matrix, interpolationOrder
         rp = self.getH2RefinementParams()
@@ -323,6 +341,11 @@ class nonlocalBuilder:
         (NA:1842-1889).  Device side: classification, quadrature and masked scatter into CSR / SSS.
         Without zeroExterior the global Omega x Omega^c term is subtracted again (NA:1896-1913)."""
         self._symmetric_only('assembleClusters')
+        if self._single_order_twin() is not None:
+            return self._single_order_twin().assembleClusters(Pnear, forceUnsymmetricMatrix, Anear, jumps, myRoot, _clusterBoundary,
+                                                              _globalBoundary, _symmetrizeMasks, **kwargs)
+        if self.kernel.variable:
+            raise NotImplementedError('near field of a variable order with several kernel blocks: jump terms NA:1966-2156')
         import torch
         from . import clusters
         from .linear_operators import CSR_LinearOperator, SSS_LinearOperator

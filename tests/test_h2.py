@@ -74,3 +74,24 @@ def test_gpu_h2_far_field_vs_oracle_and_dense(noRef, s, element, domain):
     Ah2 = h2.toarray() if dm.num_dofs <= 200 else None
     if Ah2 is not None:
         assert np.abs(Ah2-Ah2.T).max() < 1e-10*np.abs(A).max()
+
+
+@pytest.mark.gpu
+def test_varconst_h2_is_constant_order_h2():
+    """tests/cache_testDistOp.py--...--svarconst(0.75)--...--buildDense--buildH2: a variable-order kernel with one kernel block
+    (no jumps, NA:2312-2384) goes through the constant-order near field and far field"""
+    import torch
+    from pynucleus_amd import disc, P1_DoFMap, PHYSICAL, getFractionalKernel
+    from pynucleus_amd.builder import nonlocalBuilder
+    from pynucleus_amd.fractionalOrders import variableConstFractionalOrder
+    mesh = disc(4)
+    dm = P1_DoFMap(mesh, PHYSICAL)
+    bv = nonlocalBuilder(dm, getFractionalKernel(2, variableConstFractionalOrder(0.75)), {'target_order': 0.5, 'eta': 3.})
+    bc = nonlocalBuilder(dm, getFractionalKernel(2, 0.75), {'target_order': 0.5, 'eta': 3.})
+    x = np.random.default_rng(0).standard_normal(dm.num_dofs)
+    yv = np.asarray(bv.getH2()*x)
+    yc = np.asarray(bc.getH2()*x)
+    yd = np.asarray(bv.getDense()*x)
+    assert np.abs(yv-yc).max() <= 1e-12*np.abs(yc).max()
+    assert np.abs(yv-yd).max() <= 3e-2*np.abs(yd).max()
+    assert np.abs(bv.getDiagonal().diagonal-bc.getDiagonal().diagonal).max() <= 1e-12*np.abs(bc.getDiagonal().diagonal).max()
