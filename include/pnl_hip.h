@@ -125,6 +125,13 @@ int pnl_upload_singular_rule(pnl_context *ctx, int which, int panel, int M, int 
 /* boundary facets bcells[nb][dim] (mesh.get_surface_mesh().cells, oriented as in their cell) */
 int pnl_upload_boundary(pnl_context *ctx, int nb, const int32_t *bcells_host);
 
+/* Finite-horizon operator without a host pair list (nonlocalBuilder.getSparse, nonlocalAssembly_{SCALAR}.pxi:1062-1260): the
+ * candidate cell pairs are generated on the device from the block tiles the horizon can reach, REMOTE pairs are dropped
+ * (getRelativePosition, interactionDomains.pyx:875-898; nonlocalOperator_{SCALAR}.pxi:515-517), the others are integrated
+ * (cut pairs through the sub-simplex loops) and scattered without masks into the uploaded pattern.  Replaces the loops
+ * NA:1150-1200 over the cells of the covering cluster pairs (clusterMethodCy.pyx:4139-4194). */
+int pnl_assemble_pairs_in_horizon(pnl_context *ctx, double *data, double *diag);
+
 /* ---- the hot path --------------------------------------------------------------------------- */
 /* nonlocalBuilder.getDense (NA:1262-1473): accumulates the operator into A_dev[num_dofs][ldA]
  * (caller zeroes it).  Cell pairs (c1,c2), c1<=c2, with c1 in [cell_begin, cell_end) are assembled
@@ -152,6 +159,7 @@ int pnl_upload_sparsity(pnl_context *ctx, int nnz, const int32_t *indptr_host, c
  * (NA:503-520) with the reference's addToEntry semantics: entries absent from the pattern are dropped
  * (CSR_LinearOperator_{SCALAR}.pxi:150-170), SSS keeps I >= J only (SSS_LinearOperator_{SCALAR}.pxi:104-130).
  * data_dev[nnz] (+ diag_dev[num_dofs] for SSS, NULL for CSR) are accumulated into; the caller zeroes them. */
+/* masks == NULL: every entry of every pair is requested */
 int pnl_assemble_pairs_masked(pnl_context *ctx, int np, const int32_t *pairs_host, const uint64_t *masks_host,
                               double *data_dev, double *diag_dev);
 /* Gauss-theorem boundary term over explicit items: the cluster-local term (NA:1842-1889; facets = boundary of

@@ -29,7 +29,7 @@ EXPORTS = ['pnl_create', 'pnl_destroy', 'pnl_error_string', 'pnl_version', 'pnl_
            'pnl_upload_singular_rule', 'pnl_upload_boundary', 'pnl_assemble_dense', 'pnl_tile_cells',
            'pnl_assemble_dense_tiles', 'pnl_get_counters', 'pnl_get_phase_ms', 'pnl_gemv', 'pnl_cg_jacobi',
            'pnl_inv_diagonal', 'pnl_set_classes', 'pnl_select_class', 'pnl_upload_sparsity', 'pnl_assemble_pairs_masked', 'pnl_assemble_boundary_masked', 'pnl_assemble_clusters_tiled', 'pnl_h2_setup', 'pnl_h2_matvec', 'pnl_spmv',
-           'pnl_set_order_function', 'pnl_upload_pointwise_rules', 'pnl_assemble_dense_pointwise']
+           'pnl_assemble_pairs_in_horizon', 'pnl_set_order_function', 'pnl_upload_pointwise_rules', 'pnl_assemble_dense_pointwise']
 
 
 class pnl_kernel(C.Structure):
@@ -110,6 +110,7 @@ def load():
     L.pnl_assemble_clusters_tiled.argtypes = [vp, C.POINTER(pnl_cluster_plan), i32, vp, vp]
     L.pnl_h2_setup.argtypes = [vp, C.POINTER(pnl_h2_plan)]
     L.pnl_h2_matvec.argtypes = [vp, vp, vp]
+    L.pnl_assemble_pairs_in_horizon.argtypes = [vp, vp, vp]
     L.pnl_set_order_function.argtypes = [vp, C.POINTER(pnl_order_function), vp, vp, dbl, dbl, dbl, dbl]
     L.pnl_upload_pointwise_rules.argtypes = [vp, i32, i32, i32, i32, i32, vp, vp, vp, vp]
     L.pnl_assemble_dense_pointwise.argtypes = [vp, vp, i64, i32, i32, i32, i32, vp, i32, vp]
@@ -240,6 +241,10 @@ class Context:
         self.check(self.L.pnl_set_order_formula(self.h, which, C.byref(f)))
 
     # -- hot path --------------------------------------------------------
+    def assemble_pairs_in_horizon(self, data_ptr, diag_ptr):
+        """finite horizon: candidate pairs generated on the device (no host pair list, no masks)"""
+        self.check(self.L.pnl_assemble_pairs_in_horizon(self.h, C.c_void_p(data_ptr), C.c_void_p(diag_ptr) if diag_ptr else None))
+
     def assemble_dense_pointwise(self, A_ptr, ldA, zero_exterior, cell_begin, cell_end):
         pairs, bpairs = self._pw_pairs
         self.check(self.L.pnl_assemble_dense_pointwise(self.h, C.c_void_p(A_ptr), int(ldA), int(bool(zero_exterior)), int(cell_begin),
@@ -275,8 +280,12 @@ class Context:
 
     def assemble_pairs_masked(self, pairs, masks, data_ptr, diag_ptr=None):
         p, pp = _hp(pairs, np.int32)
-        m, pm = _hp(masks, np.uint64)
-        assert p.ndim == 2 and p.shape[1] == 2 and m.shape == (p.shape[0], 4)
+        if masks is None:                       # every entry of every pair
+            pm = None
+        else:
+            m, pm = _hp(masks, np.uint64)
+            assert m.shape == (p.shape[0], 4)
+        assert p.ndim == 2 and p.shape[1] == 2
         self.check(self.L.pnl_assemble_pairs_masked(self.h, p.shape[0], pp, pm, C.c_void_p(data_ptr),
                                                     C.c_void_p(diag_ptr) if diag_ptr else None))
 

@@ -246,16 +246,33 @@ class nonlocalBuilder:
         dev = torch.device('cuda', ctx.device)
         dm = self.dm
         N, nc, dpe = dm.num_dofs, self.mesh.num_cells, dm.dofs_per_element
-        pairs = self.interactingCellPairs()
-        # sparsity pattern: DoFs I, J coupled through an element pair (c1, c2): G = C^T (P + P^T) C
+        symmetric = not self.params.get('forceUnsymmetric', False)
+        host_pairs = returnNearField or self.params.get('pairList', 'device') == 'host' or 'maxMasksNNZ' in self.params
         rows = np.repeat(np.arange(nc), dpe)
         d = dm.dofs.reshape(-1)
         m = d >= 0
-        C = sp.csr_matrix((np.ones(int(m.sum()), dtype=np.int8), (rows[m], d[m])), shape=(nc, N))
-        Pm = sp.csr_matrix((np.ones(pairs.shape[0], dtype=np.int8), (pairs[:, 0], pairs[:, 1])), shape=(nc, nc))
-        G = (C.T.astype(np.int32) @ ((Pm+Pm.T).astype(np.int32) @ C.astype(np.int32))).tocsr()
+        C = sp.csr_matrix((np.ones(int(m.sum()), dtype=np.int32), (rows[m], d[m])), shape=(nc, N))
+        if host_pairs:
+            # explicit candidate list (a superset of the pairs within the horizon) and the pattern of all its DoF pairs:
+            # G = C^T (P + P^T) C
+            pairs = self.interactingCellPairs()
+            Pm = sp.csr_matrix((np.ones(pairs.shape[0], dtype=np.int32), (pairs[:, 0], pairs[:, 1])), shape=(nc, nc))
+            G = (C.T @ ((Pm+Pm.T) @ C)).tocsr()
+        else:
+            # two cells interact unless all their vertex distances are >= delta (getRelativePosition): the pattern is the
+            # set of DoF pairs whose patches hold a vertex pair closer than delta, G = M Q M^T with M = DoF -> patch vertices
+            from scipy.spatial import cKDTree
+            pairs = None
+            nv = self.mesh.num_vertices
+            vp = cKDTree(self.mesh.vertices).query_pairs(self.kernel.horizonValue*(1.+1e-9), output_type='ndarray')
+            Q = sp.csr_matrix((np.ones(vp.shape[0], dtype=np.int32), (vp[:, 0], vp[:, 1])), shape=(nv, nv))
+            Q = Q+Q.T+sp.identity(nv, dtype=np.int32, format='csr')
+            B = sp.csr_matrix((np.ones(nc*self.mesh.cells.shape[1], dtype=np.int32),
+                               (np.repeat(np.arange(nc), self.mesh.cells.shape[1]), self.mesh.cells.reshape(-1))), shape=(nc, nv))
+            M = (C.T @ B).tocsr()
+            M.data[:] = 1
+            G = ((M @ Q) @ M.T).tocsr()
         G.sort_indices()
-        symmetric = not self.params.get('forceUnsymmetric', False)
         if symmetric:
             G = sp.tril(G, k=-1, format='csr')
             G.sort_indices()
@@ -263,25 +280,28 @@ class nonlocalBuilder:
         A = (SSS_LinearOperator if symmetric else CSR_LinearOperator)(indptr, indices, N, ctx, dev)
         A._bind()
         data_ptr, diag_ptr = A._ptrs()
-        E = (2*dpe)*(2*dpe+1)//2
-        full = np.zeros(4, dtype=np.uint64)
-        for k in range(E):
-            full[k//64] |= np.uint64(1) << np.uint64(k % 64)
-        maxNNZ = int(self.params.get('maxMasksNNZ', 10000000))
         totals = dict(numCellPairs=0, numAssembledCellPairs=0, numIntegrations=0)
         ms_total = 0.
-        for s0 in range(0, pairs.shape[0], maxNNZ):
-            chunk = pairs[s0:s0+maxNNZ]
-            ctx.assemble_pairs_masked(chunk, np.tile(full, (chunk.shape[0], 1)), data_ptr, diag_ptr)
+        if host_pairs:
+            maxNNZ = int(self.params.get('maxMasksNNZ', 10000000))
+            for s0 in range(0, pairs.shape[0], maxNNZ):
+                ctx.assemble_pairs_masked(pairs[s0:s0+maxNNZ], None, data_ptr, diag_ptr)
+                cnt = ctx.counters()
+                for k in totals:
+                    totals[k] += cnt[k]
+                ms_total += ctx.phase_ms()['total']
+        else:
+            # candidate pairs are generated on the device from the block tiles the horizon can reach
+            ctx.assemble_pairs_in_horizon(data_ptr, diag_ptr)
             cnt = ctx.counters()
             for k in totals:
-                totals[k] += cnt[k]
-            ms_total += ctx.phase_ms()['total']
+                totals[k] = cnt[k]
+            ms_total = ctx.phase_ms()['total']
         ctx.synchronize()
         for k, v in totals.items():
             self.PLogger.addValue(k, v)
         self.PLogger.addTimer('interior - compute', 1e-3*ms_total)
-        A.info = dict(counters=totals, interior_ms=ms_total, num_candidate_pairs=int(pairs.shape[0]))
+        A.info = dict(counters=totals, interior_ms=ms_total, num_candidate_pairs=int(pairs.shape[0]) if pairs is not None else totals['numCellPairs'])
         return (A, pairs) if returnNearField else A
 
     def getH2RefinementParams(self):

@@ -770,8 +770,9 @@ int launch_singular_sparse(pnl_context *ctx, const SparseOut &S, const int4 *sor
     return PNL_OK;
 }
 
+// classify == false: the work list b_mp_wl[0..np) has been filled on the device (k_fh_pairs)
 template <int DIM, int DPE, int KT>
-int pairs_masked_impl(pnl_context *ctx, int np, const SparseOut &S) {
+int pairs_masked_impl(pnl_context *ctx, int np, const SparseOut &S, bool classify = true, bool first = true) {
     int rc;
     if ((rc = ensure(ctx, ctx->b_mp_wl, (size_t)np*sizeof(int4)))) return rc;
     if ((rc = ensure(ctx, ctx->b_mp_sorted, (size_t)np*sizeof(int4)))) return rc;
@@ -783,9 +784,10 @@ int pairs_masked_impl(pnl_context *ctx, int np, const SparseOut &S) {
     HIPCHK(ctx, hipMemsetAsync(hist, 0, sizeof(unsigned)*(PNL_WL_BINS+1), ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(count, &unp, sizeof(unsigned), hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));          // unp lives on this stack frame
-    HIPCHK(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
-    hipLaunchKernelGGL((k_mp_classify<DIM, DPE>), dim3((np+PNL_NTHREADS-1)/PNL_NTHREADS), dim3(PNL_NTHREADS), 0, ctx->stream, ctx->P,
-                       S.pairs, np, wl);
+    if (first) HIPCHK(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
+    if (classify)
+        hipLaunchKernelGGL((k_mp_classify<DIM, DPE>), dim3((np+PNL_NTHREADS-1)/PNL_NTHREADS), dim3(PNL_NTHREADS), 0, ctx->stream, ctx->P,
+                           S.pairs, np, wl);
     hipLaunchKernelGGL(k_wl_hist, dim3(512), dim3(PNL_NTHREADS), 0, ctx->stream, (const int4*)wl, (const unsigned*)count, unp, hist);
     hipLaunchKernelGGL(k_wl_scan, dim3(1), dim3(64), 0, ctx->stream, (const unsigned*)hist, offs, coff, cursor);
     hipLaunchKernelGGL(k_wl_scatter, dim3(512), dim3(PNL_NTHREADS), 0, ctx->stream, (const int4*)wl, (const unsigned*)count, unp,
@@ -1182,6 +1184,56 @@ int pointwise_impl(pnl_context *ctx, double *A, int64_t ldA, int zero_exterior, 
 }
 }  // namespace
 
+// getSparse without a host pair list: block tiles the horizon can reach -> k_fh_pairs -> the sorted pipeline of the masked path
+namespace {
+template <int DIM, int DPE, int KT>
+int horizon_impl(pnl_context *ctx, SparseOut S) {
+    int rc;
+    const int T = ctx->tile, nbk = ctx->nblocks;
+    const double delta = std::sqrt(ctx->C().kern[0].horizon2);
+    std::vector<int2> tiles;
+    for (int a = 0; a < nbk; a++)
+        for (int b = a; b < nbk; b++) {
+            const auto &A = ctx->blocks[a], &B = ctx->blocks[b];
+            const double dx = A.cx-B.cx, dy = A.cy-B.cy;
+            // vertices lie within h of their cell's centre
+            if (std::sqrt(dx*dx+dy*dy)-A.rad-B.rad-A.hmax-B.hmax <= delta) tiles.push_back(make_int2(a, b));
+        }
+    if ((rc = upload(ctx, ctx->b_tiles, tiles.data(), tiles.size()))) return rc;
+    ctx->tiles_cached.clear(); ctx->tiles_cb = -1;            // b_tiles no longer holds the dense tile list
+    const size_t per_tile = (size_t)T*T, chunk_tiles = std::max<size_t>(1, (size_t)(48u << 20)/per_tile);
+    const size_t cap = std::min(tiles.size(), chunk_tiles)*per_tile;
+    if ((rc = ensure(ctx, ctx->b_mp_pairs, cap*sizeof(int2)))) return rc;
+    if ((rc = ensure(ctx, ctx->b_mp_wl, cap*sizeof(int4)))) return rc;
+    if ((rc = ensure(ctx, ctx->b_wlcount, sizeof(unsigned)))) return rc;
+    S.pairs = (const int*)ctx->b_mp_pairs.p;
+    S.masks = nullptr;
+    unsigned long long total = 0;
+    bool first = true;
+    for (size_t t0 = 0; t0 < tiles.size(); t0 += chunk_tiles) {
+        const int nt = (int)std::min(chunk_tiles, tiles.size()-t0);
+        HIPCHK(ctx, hipMemsetAsync(ctx->b_wlcount.p, 0, sizeof(unsigned), ctx->stream));
+        if (first) HIPCHK(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
+        hipLaunchKernelGGL((k_fh_pairs<DIM, DPE>), dim3(nt), dim3(PNL_NTHREADS), 0, ctx->stream, ctx->P, (const int2*)ctx->b_tiles.p+t0, T,
+                           (int2*)ctx->b_mp_pairs.p, (int4*)ctx->b_mp_wl.p, (unsigned*)ctx->b_wlcount.p, (unsigned)cap);
+        HIPCHK(ctx, hipGetLastError());
+        unsigned np = 0;
+        HIPCHK(ctx, hipMemcpyAsync(&np, ctx->b_wlcount.p, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        total += np;
+        if (np && (rc = pairs_masked_impl<DIM, DPE, KT>(ctx, (int)np, S, false, false))) return rc;
+        first = false;
+    }
+    ctx->visited_pairs = total;
+    if (total == 0) {
+        for (int e = 1; e < 8; e++) HIPCHK(ctx, hipEventRecord(ctx->ev[e], ctx->stream));
+        ctx->ev_valid = true; ctx->tiles_launched = true;
+    }
+    HIPCHK(ctx, hipMemsetAsync(ctx->b_wlcount.p, 0, sizeof(unsigned), ctx->stream));     // pnl_get_counters reads it as the dense work-list fill
+    return PNL_OK;
+}
+}  // namespace
+
 extern "C" {
 
 const char *pnl_version(void) { return "pnl_hip 0.1 (gfx950)"; }
@@ -1571,18 +1623,19 @@ static int sparse_ready(pnl_context *ctx, double *data, double *diag, SparseOut 
 
 int pnl_assemble_pairs_masked(pnl_context *ctx, int np, const int32_t *pairs, const uint64_t *masks, double *data, double *diag) {
     if (!ctx) return PNL_ERR_INVALID;
-    if (np < 0 || (np && (!pairs || !masks))) return fail(ctx, PNL_ERR_INVALID, "bad pair list");
+    if (np < 0 || (np && !pairs)) return fail(ctx, PNL_ERR_INVALID, "bad pair list");
     for (int i = 0; i < np; i++)
         if (pairs[2*i] < 0 || pairs[2*i] > pairs[2*i+1] || pairs[2*i+1] >= ctx->nc)
             return fail(ctx, PNL_ERR_INVALID, "pair %d = (%d, %d) is not an ordered pair of cells", i, pairs[2*i], pairs[2*i+1]);
     int rc;
     if ((rc = upload(ctx, ctx->b_mp_pairs, pairs, (size_t)2*np))) return rc;
-    if ((rc = upload(ctx, ctx->b_mp_masks, masks, (size_t)4*np))) return rc;
+    if (masks && (rc = upload(ctx, ctx->b_mp_masks, masks, (size_t)4*np))) return rc;
     if (ctx->nlab > 0) return fail(ctx, PNL_ERR_UNSUPPORTED, "cluster assembly with a variable order needs the jump terms (NA:1966-2156)");
     if (!std::isinf(ctx->C().kern[0].horizon2) && ctx->qmax > PNL_CUT_SHIFT)
         return fail(ctx, PNL_ERR_UNSUPPORTED, "finite horizon: upload distant rules up to order %d at most", PNL_CUT_SHIFT);
     SparseOut S;
     if ((rc = sparse_ready(ctx, data, diag, S))) return rc;
+    if (!masks) S.masks = nullptr;               // every entry of every pair is requested
     HIPCHK(ctx, hipMemsetAsync(ctx->b_counters.p, 0, sizeof(unsigned long long)*PNL_NCOUNTERS, ctx->stream));
     ctx->visited_pairs = (unsigned long long)np;
     if (np == 0) return PNL_OK;
@@ -1590,6 +1643,24 @@ int pnl_assemble_pairs_masked(pnl_context *ctx, int np, const int32_t *pairs, co
     if (ctx->dim == 2 && ctx->dpe == 3) return kt ? pairs_masked_impl<2, 3, 1>(ctx, np, S) : pairs_masked_impl<2, 3, 0>(ctx, np, S);
     if (ctx->dim == 2 && ctx->dpe == 6) return kt ? pairs_masked_impl<2, 6, 1>(ctx, np, S) : pairs_masked_impl<2, 6, 0>(ctx, np, S);
     if (ctx->dim == 1 && ctx->dpe == 2) return pairs_masked_impl<1, 2, 0>(ctx, np, S);
+    return fail(ctx, PNL_ERR_UNSUPPORTED, "unsupported (dim=%d, dofs_per_element=%d)", ctx->dim, ctx->dpe);
+}
+
+int pnl_assemble_pairs_in_horizon(pnl_context *ctx, double *data, double *diag) {
+    if (!ctx) return PNL_ERR_INVALID;
+    int rc;
+    if ((rc = check_ready(ctx))) return rc;
+    if ((rc = finalize(ctx))) return rc;
+    if (ctx->nlab > 0) return fail(ctx, PNL_ERR_UNSUPPORTED, "finite horizon with a variable order");
+    if (std::isinf(ctx->C().kern[0].horizon2)) return fail(ctx, PNL_ERR_STATE, "pnl_assemble_pairs_in_horizon needs a finite horizon");
+    if (ctx->qmax > PNL_CUT_SHIFT) return fail(ctx, PNL_ERR_UNSUPPORTED, "finite horizon: upload distant rules up to order %d at most", PNL_CUT_SHIFT);
+    SparseOut S;
+    if ((rc = sparse_ready(ctx, data, diag, S))) return rc;
+    HIPCHK(ctx, hipMemsetAsync(ctx->b_counters.p, 0, sizeof(unsigned long long)*PNL_NCOUNTERS, ctx->stream));
+    const int kt = ctx->P.k.fast ? 1 : 0;
+    if (ctx->dim == 2 && ctx->dpe == 3) return kt ? horizon_impl<2, 3, 1>(ctx, S) : horizon_impl<2, 3, 0>(ctx, S);
+    if (ctx->dim == 2 && ctx->dpe == 6) return kt ? horizon_impl<2, 6, 1>(ctx, S) : horizon_impl<2, 6, 0>(ctx, S);
+    if (ctx->dim == 1 && ctx->dpe == 2) return horizon_impl<1, 2, 0>(ctx, S);
     return fail(ctx, PNL_ERR_UNSUPPORTED, "unsupported (dim=%d, dofs_per_element=%d)", ctx->dim, ctx->dpe);
 }
 

@@ -1585,7 +1585,7 @@ __device__ __forceinline__ unsigned eval_distant_cut(const DevProblem &P, const 
 __device__ __forceinline__ void sparse_add_sym(const SparseOut &S, const unsigned long long *mask, int n2, int p, int q, int I, int J,
                                                double v) {
     const int k = n2*p-((p*(p-1)) >> 1)+(q-p);
-    if (!((mask[k >> 6] >> (k & 63)) & 1ull)) return;
+    if (mask && !((mask[k >> 6] >> (k & 63)) & 1ull)) return;     // no mask list: every entry is requested (getSparse)
     if (p == q) sparse_add(S, I, I, v);
     else { sparse_add(S, I, J, v); sparse_add(S, J, I, v); }
 }
@@ -1634,6 +1634,66 @@ k_mp_classify(const DevProblem P, const int *__restrict__ pairs, int npairs, int
         }
     }
     out[t] = make_int4(t, 0, off, n | (key << 16));
+}
+
+// Finite horizon (getSparse, NA:1062-1260): the candidate cell pairs c1 <= c2 of the block tiles that the horizon can reach
+// are generated and classified on the device -- the reference walks the cells of covering cluster pairs (NA:1150-1170) and
+// drops the REMOTE ones in getPanelType (NO:515-517).  One workgroup per tile of T x T cells; surviving pairs are appended to
+// `pairs` and to the work list in the format of k_mp_classify (pair index, 0, rule offset, n | key << 16).
+template <int DIM, int DPE>
+__global__ void __launch_bounds__(PNL_NTHREADS)
+k_fh_pairs(const DevProblem P, const int2 *__restrict__ tiles, int T, int2 *__restrict__ pairs, int4 *__restrict__ wl,
+           unsigned *__restrict__ count, unsigned cap) {
+    constexpr int NV = DIM+1;
+    const int2 tl = tiles[blockIdx.x];
+    const int lane = threadIdx.x & 63;
+    for (int idx = threadIdx.x; idx < T*T; idx += PNL_NTHREADS) {      // T*T is a multiple of the block size: uniform trip count
+        const int c1 = tl.x*T+idx%T, c2 = tl.y*T+idx/T;
+        bool push = false;
+        int key = 0, off = 0, n = 0;
+        if (c1 < P.nc && c2 < P.nc && c1 <= c2) {
+            bool any = false;
+#pragma unroll
+            for (int k = 0; k < DPE; k++) any = any || P.cdof[(size_t)k*P.ncp+c1] >= 0 || P.cdof[(size_t)k*P.ncp+c2] >= 0;
+            if (any) {
+                int common = 0;
+                if (c1 == c2) common = NV;
+                else {
+#pragma unroll
+                    for (int a = 0; a < NV; a++)
+#pragma unroll
+                        for (int b = 0; b < NV; b++) common += (P.cvid[(size_t)a*P.ncp+c1] == P.cvid[(size_t)b*P.ncp+c2]);
+                }
+                if (common > 0) { key = 121+common-1; push = true; }
+                else {
+                    double av[NV*DIM], bv[NV*DIM];
+#pragma unroll
+                    for (int k = 0; k < NV*DIM; k++) { av[k] = P.cellv[(size_t)k*P.ncp+c1]; bv[k] = P.cellv[(size_t)k*P.ncp+c2]; }
+                    const int rel = rel_position<DIM>(P.k.horizon2, av, bv);
+                    if (rel != PNL_REMOTE) {
+                        double d2 = 0.;
+#pragma unroll
+                        for (int d = 0; d < DIM; d++) { const double u = P.ccen[(size_t)d*P.ncp+c1]-P.ccen[(size_t)d*P.ncp+c2]; d2 += u*u; }
+                        const int q = quad_order(P.qo, P.H0, P.ch[c1], P.ch[c2], sqrt(d2));
+                        if (q > P.qmax || q > PNL_MAXQ || (rel == PNL_CUT && (q > PNL_CUT_SHIFT || P.off[q+1]-P.off[q] > PNL_WL_LANE_MAXPTS)))
+                            atomicAdd(&P.counters[5], 1ull);
+                        else { key = q+(rel == PNL_CUT ? PNL_CUT_SHIFT : 0); off = P.off[q]; n = P.off[q+1]-off; push = true; }
+                    }
+                }
+            }
+        }
+        const unsigned long long m = __ballot(push);
+        if (m) {
+            unsigned base = 0;
+            const int leader = __builtin_ctzll(m);
+            if (lane == leader) base = atomicAdd(count, (unsigned)__popcll(m));
+            base = __shfl(base, leader);
+            if (push) {
+                const unsigned pos = base+__popcll(m & ((1ull << lane)-1ull));
+                if (pos < cap) { pairs[pos] = make_int2(c1, c2); wl[pos] = make_int4((int)pos, 0, off, n | (key << 16)); }
+            }
+        }
+    }
 }
 
 // ---- work list of the orders the tile kernel does not unroll -------------------------------------------------------
@@ -1851,7 +1911,7 @@ k_worklist_sorted(const DevProblem P, const int4 *__restrict__ sorted, const uns
             }
         } else if (valid && SPARSE) {
             const double vv = 2.*P.cvol[c1]*P.cvol[c2]*kern_scale<KT>(P.k);
-            const unsigned long long *mask = S.masks+4*(size_t)ent.x;
+            const unsigned long long *mask = S.masks ? S.masks+4*(size_t)ent.x : nullptr;
 #pragma unroll
             for (int rep = 0; rep < NREP; rep++) {
                 const int e = sub+LPP*rep;
@@ -1978,7 +2038,7 @@ k_worklist_lane(const DevProblem P, const int4 *__restrict__ sorted, const unsig
                 if (ds.y >= 0) atomic_add_f64(&CT.D[(size_t)ds.y*ND+e], vv*R.S2[e]);
             }
         } else if (SPARSE) {
-            const unsigned long long *mask = S.masks+4*(size_t)ent.x;
+            const unsigned long long *mask = S.masks ? S.masks+4*(size_t)ent.x : nullptr;
             int e = 0;
 #pragma unroll
             for (int a = 0; a < DPE; a++) {
@@ -2200,7 +2260,7 @@ k_singular_pairs(const DevProblem P, const int2 *__restrict__ pairs, int npairs_
             for (int k = 0; k < 2*DPE; k++) { pi = (myI[rep] == k) ? perm[k] : pi; pj = (myJ[rep] == k) ? perm[k] : pj; }
             const int lo = min(pi, pj), hi = max(pi, pj);
             const int glo = (lo == pi) ? gi : gj, ghi = (lo == pi) ? gj : gi;
-            sparse_add_sym(S, S.masks+4*(size_t)pidx, 2*DPE, lo, hi, glo, ghi, v);
+            sparse_add_sym(S, S.masks ? S.masks+4*(size_t)pidx : nullptr, 2*DPE, lo, hi, glo, ghi, v);
         } else if (gi >= 0 && gj >= 0) {
             if (myI[rep] == myJ[rep]) atomic_add_f64(&A[(long long)gi*ldA+gi], v);
             else {

@@ -97,7 +97,7 @@ def _gpu_sparse(N, delta, kernel, interaction=None, s=None, element='P1', params
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('case', ['indicator', 'peridynamic', 'barycenter', 'fractional', 'P2', 'interval', 'chunked_csr'])
+@pytest.mark.parametrize('case', ['indicator', 'peridynamic', 'barycenter', 'fractional', 'P2', 'interval', 'chunked_csr', 'host_pairs'])
 def test_gpu_getSparse_vs_oracle(case):
     from oracle.oracle import OracleProblem
     if case == 'indicator':
@@ -112,6 +112,8 @@ def test_gpu_getSparse_vs_oracle(case):
         b = _gpu_sparse(9, 0.3, 'indicator', element='P2')
     elif case == 'interval':
         b = _gpu_sparse(6, 0.11, 'indicator', domain='interval')
+    elif case == 'host_pairs':
+        b = _gpu_sparse(17, 0.2, 'indicator', params={'pairList': 'host'})     # explicit candidate list instead of device-side tiles
     else:
         b = _gpu_sparse(17, 0.2, 'indicator', params={'forceUnsymmetric': True, 'maxMasksNNZ': 5000})
     A = b.getSparse()
