@@ -57,7 +57,9 @@ __device__ __forceinline__ double kern_eval(const DevKernel &k, double d2) {
         return res;
     } else {
         if (!(d2 <= k.horizon2)) return 0.;
-        if (k.ktype == 0) return k.scale*pow(d2, k.exponent);
+        // general exponent: exp(e ln d2) instead of pow (half the instructions; |e ln d2| < 60 keeps the relative error of the
+        // product below 1e-14, three orders under the parity tolerance)
+        if (k.ktype == 0) return k.scale*exp(k.exponent*log(d2));
         if (k.ktype == 1) return k.scale;
         return k.scale/sqrt(d2);
     }
