@@ -108,6 +108,12 @@ int pnl_upload_dofmap(pnl_context *ctx, int dpe, int dofs_per_vertex, int dofs_p
  * the near rules keyed by the class's singularity, FL2:664/688).  nclasses = 1, num_labels = 0 restores a constant order. */
 int pnl_set_classes(pnl_context *ctx, int nclasses, int num_labels, const int32_t *cell_labels_host,
                     const int32_t *facet_labels_host, const int32_t *cls_of_host);
+/* The order table of pnl_set_classes is not symmetric, s(label1, label2) != s(label2, label1) (a piecewise-constant,
+ * non-symmetric fractional order): every element pair is assembled in both orientations, each with the parameters
+ * Kernel.evalParams finds for that orientation -- the symmetricCells == False branch of getDense
+ * (nonlocalAssembly_{SCALAR}.pxi:1411-1428) with the fractionalLaplacian{1,2}D_nonsym local matrices, which for parameters
+ * frozen per orientation reduce to the symmetric local matrix (temp == temp2 in nonlocalOperator_{SCALAR}.pxi:899-923). */
+int pnl_set_nonsymmetric(pnl_context *ctx, int on);
 int pnl_select_class(pnl_context *ctx, int k);
 /* which = PNL_INTERIOR (gamma) or PNL_BOUNDARY (Gauss-theorem boundary kernel, KC:1982-2027) */
 int pnl_set_kernel(pnl_context *ctx, int which, const pnl_kernel *kernel);

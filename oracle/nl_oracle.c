@@ -959,12 +959,14 @@ static void eval_singular_nonsym(const nlo_problem *P, double s1[MAXV][2], doubl
     free(temp);
 }
 
-/* getPanelType (NO:493-540) for the non-symmetric local matrices; returns the panel and the pair's order */
+/* getPanelType (NO:493-540) for the non-symmetric local matrices (any order of c1, c2); returns the panel and, for
+ * pointwise orders, the pair's order.  Piecewise orders: the formula of the class of (label c1, label c2) (evalParams at
+ * the two centres in THIS orientation, NO:509-513) */
 static int panel_nonsym(const nlo_problem *P, int c1, int c2, int *perm1, int *perm2, int *perm, double *sv) {
     const int nV = P->dim+1, dpe = P->dpe;
     for (int k = 0; k < nV; k++) { perm1[k] = k; perm2[k] = k; }
     for (int k = 0; k < 2*dpe; k++) perm[k] = k;
-    *sv = nlo_pw_svalue(P, c1, c2);
+    *sv = P->pw_type ? nlo_pw_svalue(P, c1, c2) : 0.;
     if (c1 == c2) return -nV;
     int mask1 = 0, mask2 = 0, common = 0;
     for (int a = 0; a < nV; a++) {
@@ -985,7 +987,7 @@ static int panel_nonsym(const nlo_problem *P, int c1, int c2, int *perm1, int *p
         simplex_of(P, c2, s2, ce2);
         double d2 = 0.;
         for (int j = 0; j < P->dim; j++) d2 += (ce1[j]-ce2[j])*(ce1[j]-ce2[j]);
-        const nlo_order_formula F = pw_formula(P, *sv);
+        const nlo_order_formula F = P->pw_type ? pw_formula(P, *sv) : class_of_cells(P, c1, c2)->qo;
         /* h = get_h_simplex (nonlocalOperator.pyx:114-118, 152-160): the longest edge, which is what hVector holds */
         return quad_order(&F, P->H0, P->h[c1], P->h[c2], sqrt(d2));
     }
@@ -1120,7 +1122,8 @@ int nlo_get_dense_nonsym(const nlo_problem *P, double *A, int zero_exterior, int
                          int64_t *counters, double *seconds, int store) {
     const int dpe = P->dpe, nV = P->dim+1, n2 = 2*dpe;
     const int64_t N = P->num_dofs;
-    if (dpe > MAXDPE || nV > MAXV || !P->pw_type) return -1;
+    if (dpe > MAXDPE || nV > MAXV || (!P->pw_type && !P->nclasses)) return -1;
+    const int piecewise = !P->pw_type;          /* order frozen per orientation of the pair: temp == temp2, the local matrix is the symmetric one */
     double contrib[4*MAXDPE*MAXDPE];
     int perm1[MAXV], perm2[MAXV], perm[2*MAXDPE], ld[2*MAXDPE];
     memset(counters, 0, sizeof(int64_t)*NLO_NUM_COUNTERS);
@@ -1139,9 +1142,14 @@ int nlo_get_dense_nonsym(const nlo_problem *P, double *A, int zero_exterior, int
                 if (panel >= 1 && (panel > P->qmax || P->dist_off[panel+1] == P->dist_off[panel])) return -(1000+panel);
                 simplex_of(P, a, s1, ce);
                 simplex_of(P, b, s2, ce);
-                if (!orient) {
+                if (!orient || piecewise) {     /* piecewise: the two orientations may differ in order and rule, count both */
                     counters[1]++;
                     if (panel >= 1) counters[8+panel]++; else counters[8+NLO_MAX_ORDER+(-panel-1)]++;
+                }
+                if (piecewise) {
+                    nlo_eval(P, a, b, panel, perm1, perm2, perm, contrib, &counters[2]);
+                    if (store) scatter_elem_elem_sym(A, N, ld, n2, contrib, 1.);
+                    continue;
                 }
                 if (panel >= 1) {
                     eval_distant_nonsym(P, s1, s2, P->vol[a]*P->vol[b], panel, contrib);
@@ -1159,6 +1167,15 @@ int nlo_get_dense_nonsym(const nlo_problem *P, double *A, int zero_exterior, int
             for (int p = 0; p < dpe; p++) ld[p] = P->dofs[c1*dpe+p];
             for (int b = 0; b < P->nb; b++) {
                 double sv;
+                if (piecewise) {
+                    int panel = nlo_panel_boundary(P, c1, b, perm1, perm2, perm);
+                    if (panel >= 1 && (panel > P->qmax || P->dist_off[panel+1] == P->dist_off[panel]
+                                       || P->bfacet_off[panel+1] == P->bfacet_off[panel])) return -(2000+panel);
+                    counters[3]++;
+                    nlo_eval_boundary(P, c1, b, panel, perm1, perm2, perm, contrib, &counters[4]);
+                    if (store) scatter_elem_elem_sym(A, N, ld, dpe, contrib, 1.);
+                    continue;
+                }
                 int panel = panel_boundary_pw(P, c1, b, perm1, perm2, perm, &sv);
                 if (panel >= 1 && (panel > P->qmax || P->dist_off[panel+1] == P->dist_off[panel]
                                    || P->bfacet_off[panel+1] == P->bfacet_off[panel])) return -(2000+panel);

@@ -233,7 +233,7 @@ class OracleProblem:
         A = np.zeros((N, N)) if store else None
         counters = np.zeros(NLO_NUM_COUNTERS, dtype=np.int64)
         seconds = np.zeros(2)
-        fun = lib().nlo_get_dense_nonsym if getattr(self, 'pointwise', False) else lib().nlo_get_dense_rows
+        fun = lib().nlo_get_dense_nonsym if (getattr(self, 'pointwise', False) or getattr(T, 'nonsym', False)) else lib().nlo_get_dense_rows
         rc = fun(C.byref(self.P), A.ctypes.data if store else None, int(T.zeroExterior),
                  cell_start, cell_end, counters.ctypes.data, seconds.ctypes.data, int(store))
         if rc != 0:

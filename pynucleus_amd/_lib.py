@@ -29,7 +29,7 @@ EXPORTS = ['pnl_create', 'pnl_destroy', 'pnl_error_string', 'pnl_version', 'pnl_
            'pnl_upload_singular_rule', 'pnl_upload_boundary', 'pnl_assemble_dense', 'pnl_tile_cells',
            'pnl_assemble_dense_tiles', 'pnl_get_counters', 'pnl_get_phase_ms', 'pnl_gemv', 'pnl_cg_jacobi',
            'pnl_inv_diagonal', 'pnl_set_classes', 'pnl_select_class', 'pnl_upload_sparsity', 'pnl_assemble_pairs_masked', 'pnl_assemble_boundary_masked', 'pnl_assemble_clusters_tiled', 'pnl_h2_setup', 'pnl_h2_matvec', 'pnl_spmv',
-           'pnl_assemble_pairs_in_horizon', 'pnl_set_order_function', 'pnl_upload_pointwise_rules', 'pnl_assemble_dense_pointwise']
+           'pnl_assemble_pairs_in_horizon', 'pnl_set_nonsymmetric', 'pnl_set_order_function', 'pnl_upload_pointwise_rules', 'pnl_assemble_dense_pointwise']
 
 
 class pnl_kernel(C.Structure):
@@ -104,6 +104,7 @@ def load():
     L.pnl_upload_sparsity.argtypes = [vp, i32, vp, vp]
     L.pnl_set_classes.argtypes = [vp, i32, i32, vp, vp, vp]
     L.pnl_select_class.argtypes = [vp, i32]
+    L.pnl_set_nonsymmetric.argtypes = [vp, i32]
     L.pnl_assemble_pairs_masked.argtypes = [vp, i32, vp, vp, vp, vp]
     L.pnl_assemble_boundary_masked.argtypes = [vp, i32, vp, vp, vp, dbl, vp, vp]
     L.pnl_spmv.argtypes = [vp, vp, vp, vp, vp]
@@ -213,6 +214,8 @@ class Context:
             fl, pfl = _hp(T.facet_labels, np.int32)
             co, pco = _hp(T.cls_of, np.int32)
             self.check(L.pnl_set_classes(h, len(classes), T.num_labels, pcl, pfl if fl.shape[0] else None, pco))
+            if getattr(T, 'nonsym', False):
+                self.check(L.pnl_set_nonsymmetric(h, 1))
         else:
             self.check(L.pnl_set_classes(h, 1, 0, None, None, None))
             classes = [T]

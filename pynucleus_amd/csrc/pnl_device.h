@@ -66,5 +66,10 @@ struct DevProblem {
     // the class this launch assembles (-1: constant order, no filter)
     const int *clabel, *blabel, *cls_of;
     int nlab, cur_class;
+    // non-symmetric order table: every pair is assembled once per orientation with half the kernel (the tile machinery
+    // applies the factor 2 of the symmetric case); orient = 1 looks up cls_of[label2][label1]; idfac = weight of an
+    // identical pair relative to the halved kernel (1 symmetric, 2 non-symmetric: identical pairs are visited once)
+    int orient, pad2;
+    double idfac;
     unsigned long long *counters;
 };

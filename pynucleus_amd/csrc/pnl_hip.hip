@@ -45,16 +45,19 @@ struct pnl_context {
         pnl_order_formula form[2];
         bool have_kernel[2] = {false, false}, have_form[2] = {false, false};
         bool have_sing[2][3] = {{false, false, false}, {false, false, false}};
-        DevBuf b_sn[3], b_sw[3], b_sp[3], b_bn[2], b_bw[2], b_bp[2], b_spairs[3], b_bpairs[2];
+        DevBuf b_sn[3], b_sw[3], b_sp[3], b_bn[2], b_bw[2], b_bp[2], b_spairs[3], b_bpairs[2], b_spairs1[3];
         int sM[3] = {0, 0, 0}, sRows[3] = {0, 0, 0}, bM[2] = {0, 0};
         double sFac = 0., bFac = 0.;
         int n_spairs[3] = {0, 0, 0}, n_bpairs[2] = {0, 0};
+        int n_spairs1[3] = {0, 0, 0};   // non-symmetric order: touching pairs (c2, c1) of the second orientation
         ClassData() { std::memset(kern, 0, sizeof(kern)); std::memset(form, 0, sizeof(form)); }
     };
     std::vector<ClassData*> cls;
     int cur = 0;                      // class the setters and launchers currently act on
     ClassData &C() { return *cls[cur]; }
     int nlab = 0;                     // labels of the variable order (0: constant order)
+    bool nonsym = false;              // cls_of is not symmetric: both orientations of every pair (pnl_set_nonsymmetric)
+    int orient = 0;                   // orientation the launchers currently act on
     std::vector<int32_t> cell_labels, facet_labels, cls_of;
     bool have_mesh = false, have_dofs = false, have_rules = false, have_boundary = false;
     bool dirty = true;
@@ -321,6 +324,16 @@ int finalize(pnl_context *ctx) {
                 if (class_cc(pr.x, pr.y) == k) mine.push_back(pr);
             ctx->cls[k]->n_spairs[s] = (int)mine.size();
             if ((rc = upload(ctx, ctx->cls[k]->b_spairs[s], mine.data(), mine.size()))) return rc;
+            ctx->cls[k]->n_spairs1[s] = 0;
+            if (ctx->nonsym) {
+                // second orientation (swapCells, NA:1418): the pair (c2, c1) with the class of (label c2, label c1); identical
+                // pairs are visited once
+                std::vector<int2> swapped;
+                for (const int2 &pr : ctx->spairs_host[s])
+                    if (pr.x != pr.y && class_cc(pr.y, pr.x) == k) swapped.push_back(make_int2(pr.y, pr.x));
+                ctx->cls[k]->n_spairs1[s] = (int)swapped.size();
+                if ((rc = upload(ctx, ctx->cls[k]->b_spairs1[s], swapped.data(), swapped.size()))) return rc;
+            }
         }
     // boundary facets
     for (int k = 0; k < ncls; k++) ctx->cls[k]->n_bpairs[0] = ctx->cls[k]->n_bpairs[1] = 0;
@@ -449,7 +462,7 @@ int finalize(pnl_context *ctx) {
     P.perm_table = (const int*)ctx->b_perm.p;
     P.bvid = (const int*)ctx->b_bvid.p; P.bv = (const double*)ctx->b_bv.p; P.bgeo = (const double*)ctx->b_bgeo.p;
     P.counters = (unsigned long long*)ctx->b_counters.p;
-    P.nlab = nlab; P.cur_class = -1;
+    P.nlab = nlab; P.cur_class = -1; P.orient = 0; P.pad2 = 0; P.idfac = 1.;
     P.clabel = (const int*)ctx->b_clabel.p; P.blabel = (const int*)ctx->b_blabel.p; P.cls_of = (const int*)ctx->b_clsof.p;
     ctx->dirty = false;
     return PNL_OK;
@@ -483,6 +496,10 @@ void refresh_tables(pnl_context *ctx) {
     for (int s = 0; s < 2; s++) P.bM[s] = ctx->C().bM[s];
     P.sFac = ctx->C().sFac; P.bFac = ctx->C().bFac;
     P.cur_class = ctx->nlab > 0 ? ctx->cur : -1;
+    // non-symmetric order table: two passes per class with half the kernel each (see DevProblem::orient)
+    P.orient = ctx->nonsym ? ctx->orient : 0;
+    P.idfac = ctx->nonsym ? 2. : 1.;
+    if (ctx->nonsym) P.k.scale *= 0.5;
 }
 
 // row stride of the LDS sub-block: nU + 1 columns (+1: trash column / row for boundary DoFs); PNL_ACC_PAD=m rounds it up
@@ -613,7 +630,7 @@ int launch_tiles(pnl_context *ctx, int ntiles_all, double *A, int64_t ldA, int c
 template <int DIM, int DPE, int SLOT, int KT>
 int launch_singular_slot(pnl_context *ctx, int np, double *A, int64_t ldA, int cell_begin, int cell_end) {
     constexpr int NV = DIM+1;
-    const int2 *pairs = (const int2*)ctx->C().b_spairs[SLOT].p;
+    const int2 *pairs = (const int2*)(ctx->orient ? ctx->C().b_spairs1[SLOT].p : ctx->C().b_spairs[SLOT].p);
     const int M = ctx->P.sM[SLOT], rows = ctx->P.sRows[SLOT];
     const size_t lds = sizeof(double)*(size_t)(2*NV+1+rows)*M;
     const int waves_per_block = PNL_SING_THREADS/64;
@@ -637,7 +654,7 @@ int launch_singular_slot(pnl_context *ctx, int np, double *A, int64_t ldA, int c
 template <int DIM, int DPE, int KT>
 int launch_singular(pnl_context *ctx, double *A, int64_t ldA, int cell_begin, int cell_end) {
     for (int s = 0; s < DIM+1; s++) {
-        const int np = ctx->C().n_spairs[s];
+        const int np = ctx->orient ? ctx->C().n_spairs1[s] : ctx->C().n_spairs[s];
         if (!np) continue;
         if (!ctx->C().have_sing[0][s]) return fail(ctx, PNL_ERR_STATE, "singular rule for %d common vertices not uploaded", s+1);
         int rc;
@@ -694,9 +711,11 @@ int assemble_impl(pnl_context *ctx, double *A, int64_t ldA, int zero_exterior, i
     ctx->tiles_launched = ntiles > 0;
     // a piecewise-constant variable order is assembled class by class: every pass sees the kernel, order formula and
     // singular rules of one order value and skips the pairs of the other classes in its classification
+    const int norient = ctx->nonsym ? 2 : 1;
     if (ntiles > 0)
-        for (int k = 0; k < ncls; k++) {
-            ctx->cur = k;
+        for (int ko = 0; ko < ncls*norient; ko++) {
+            const int k = ko/norient;
+            ctx->cur = k; ctx->orient = ko%norient;
             refresh_tables(ctx);
             ctx->tile_off = ctx->cls_tile_off[k]; ctx->n_mixed = ctx->cls_n_mixed[k]; ctx->n_pure = ctx->cls_n_pure[k];
             if (ctx->n_mixed+ctx->n_pure == 0) continue;
@@ -705,8 +724,9 @@ int assemble_impl(pnl_context *ctx, double *A, int64_t ldA, int zero_exterior, i
             if (ctx->P.k.fast && ctx->P.k.qm == 6 && DPE == 3 && !getenv("PNL_NO_KT2")) rc = launch_tiles<DIM, DPE, TILE, (DPE == 3 ? 2 : 1)>(ctx, ntiles, A, ldA, tb0, tb1);
             else rc = ctx->P.k.fast ? launch_tiles<DIM, DPE, TILE, 1>(ctx, ntiles, A, ldA, tb0, tb1)
                                     : launch_tiles<DIM, DPE, TILE, 0>(ctx, ntiles, A, ldA, tb0, tb1);
-            if (rc) { ctx->cur = 0; return rc; }
+            if (rc) { ctx->cur = 0; ctx->orient = 0; return rc; }
         }
+    ctx->orient = 0;
     HIPCHK(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
     // mirror the cross part before the symmetric contributions are added on both sides
     if (!(flags & (PNL_FLAG_NO_MIRROR | PNL_FLAG_SYMMETRIC_FLUSH))) {
@@ -715,13 +735,14 @@ int assemble_impl(pnl_context *ctx, double *A, int64_t ldA, int zero_exterior, i
         HIPCHK(ctx, hipGetLastError());
     }
     HIPCHK(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
-    for (int k = 0; k < ncls; k++) {
-        ctx->cur = k;
+    for (int ko = 0; ko < ncls*norient; ko++) {
+        ctx->cur = ko/norient; ctx->orient = ko%norient;
         refresh_tables(ctx);
         rc = ctx->P.k.fast ? launch_singular<DIM, DPE, 1>(ctx, A, ldA, cell_begin, cell_end)
                            : launch_singular<DIM, DPE, 0>(ctx, A, ldA, cell_begin, cell_end);
-        if (rc) { ctx->cur = 0; return rc; }
+        if (rc) { ctx->cur = 0; ctx->orient = 0; return rc; }
     }
+    ctx->orient = 0;
     HIPCHK(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
     if (zero_exterior)
         for (int k = 0; k < ncls; k++) {
@@ -1335,6 +1356,7 @@ int pnl_set_classes(pnl_context *ctx, int nclasses, int num_labels, const int32_
     ctx->cell_labels.assign(cell_labels, cell_labels+(num_labels > 0 ? ctx->nc : 0));
     ctx->cls_of.assign(cls_of, cls_of+(size_t)num_labels*num_labels);
     ctx->tiles_cached.clear(); ctx->tiles_forms.clear();
+    ctx->nonsym = false;
     ctx->facet_labels.clear();
     if (num_labels > 0 && facet_labels && ctx->have_boundary) {
         for (int f = 0; f < ctx->nb; f++)
@@ -1342,6 +1364,15 @@ int pnl_set_classes(pnl_context *ctx, int nclasses, int num_labels, const int32_
         ctx->facet_labels.assign(facet_labels, facet_labels+ctx->nb);
     }
     ctx->dirty = true;
+    return PNL_OK;
+}
+
+int pnl_set_nonsymmetric(pnl_context *ctx, int on) {
+    if (!ctx) return PNL_ERR_INVALID;
+    if (on && ctx->nlab == 0) return fail(ctx, PNL_ERR_STATE, "pnl_set_classes with labels first: only a label table can be non-symmetric");
+    ctx->nonsym = on != 0;
+    ctx->dirty = true;
+    ctx->tiles_cached.clear(); ctx->tiles_forms.clear();
     return PNL_OK;
 }
 
@@ -1498,7 +1529,7 @@ static int upload_tiles(pnl_context *ctx, std::vector<int2> &tiles, int cell_beg
         return PNL_OK;
     const int T = ctx->tile;
     const bool filter = ctx->tile_cell_filter;
-    const bool allow = ctx->use_pure && T == 64 && (ctx->dpe == 3 || ctx->dpe == 2) && ctx->qmax >= 2;
+    const bool allow = ctx->use_pure && T == 64 && (ctx->dpe == 3 || ctx->dpe == 2) && ctx->qmax >= 2 && !ctx->nonsym;
     // variable order: a class only visits the tiles whose blocks hold a label pair of that class (most blocks carry one
     // label, so the K passes together classify every tile about once instead of K times)
     const int L = ctx->nlab;

@@ -571,7 +571,10 @@ k_tile_distant(const DevProblem P, const int2 *__restrict__ tiles, double *__res
         bool ok = (va0 >= 0) && (vb0 >= 0) && !(ablate & 8) &&
                   (CLUSTER ? (!sym || ta < tb || i < j) : ((ta < tb || i < j) && (ca >= cell_begin) && (ca < cell_end)));
         // variable order: this launch assembles the pairs of one order class only
-        if (!CLUSTER && P.cur_class >= 0 && ok) ok = P.cls_of[P.clabel[ca]*P.nlab+P.clabel[tb*TILE+j]] == P.cur_class;
+        if (!CLUSTER && P.cur_class >= 0 && ok) {
+            const int la = P.clabel[ca], lb = P.clabel[tb*TILE+j];
+            ok = P.cls_of[P.orient ? lb*P.nlab+la : la*P.nlab+lb] == P.cur_class;
+        }
         if (ok) {
             // NA:138-150: skip pairs with boundary DoFs only;  NO:311-323: shared vertices -> singular pair
             bool any_dof = false, shared = false;
@@ -2126,7 +2129,9 @@ k_singular_pairs(const DevProblem P, const int2 *__restrict__ pairs, int npairs_
         pr = make_int2(S.pairs[2*pidx], S.pairs[2*pidx+1]);
     } else pr = pairs[wid];
     const int c1 = __builtin_amdgcn_readfirstlane(pr.x), c2 = __builtin_amdgcn_readfirstlane(pr.y);
-    if (!SPARSE && (c1 < cell_begin || c1 >= cell_end)) continue;
+    // the cell range of the MPI-style split applies to the smaller cell number (cellNo1 of the reference loop; the lists of
+    // the second orientation of a non-symmetric order hold the pairs swapped)
+    if (!SPARSE && (min(c1, c2) < cell_begin || min(c1, c2) >= cell_end)) continue;
     // NA:138-150
     int ld[2*DPE];
     bool any = false;
@@ -2219,7 +2224,7 @@ k_singular_pairs(const DevProblem P, const int2 *__restrict__ pairs, int npairs_
             for (int J = I; J < ROWS; J++) { acc[e] = __builtin_fma(tI, ps[J], acc[e]); e++; }
         }
     }
-    const double vol = P.sFac*P.cvol[c1]*P.cvol[c2]*(c1 == c2 ? 1. : 2.)*kern_scale<KT>(P.k);
+    const double vol = P.sFac*P.cvol[c1]*P.cvol[c2]*(c1 == c2 ? P.idfac : 2.)*kern_scale<KT>(P.k);
     // reduce; lane (e mod 64) scatters entry e (NE <= 66 < 128: at most two entries per lane)
     double mine[2] = {0., 0.};
     int myI[2] = {0, 0}, myJ[2] = {0, 0};

@@ -93,8 +93,9 @@ class nonlocalTables:
             self.variable = True
             self._setup_pointwise(dm, kernel, params, zeroExterior, qcap)
             return
-        if not kernel.symmetric:
-            raise NotImplementedError('non-symmetric piecewise kernels (NA:1411-1428 with evalParams per orientation)')
+        # piecewise-constant order with s(label1, label2) != s(label2, label1): the non-symmetric local-matrix classes and both
+        # orientations of every pair (NA:1411-1428), each with the parameters evalParams finds for that orientation
+        self.nonsym = bool(kernel.variable and not kernel.symmetric)
         self.variable = bool(kernel.variable)
         if self.variable:
             self._setup_variable(dm, kernel, params, zeroExterior, qcap)
@@ -108,12 +109,16 @@ class nonlocalTables:
         self.qcap = qcap
         target_order = params.get('target_order', None)
         self.zeroExterior = bool(zeroExterior) and not kernel.finiteHorizon      # NA:919-922
+        # the _nonsym constructors drop the caller's target_order and quad_order_diagonal (FL2:911, FL1:427 pass num_dofs in
+        # their place); the boundary twins keep them
+        interior_target = None if params.get('_nonsymInterior', False) else target_order
+        interior_qd = None if params.get('_nonsymInterior', False) else params.get('quad_order_diagonal', None)
 
         sing = kernel.getSingularityValue()
         if dim == 2:
-            self._setup2D(kernel, target_order, params.get('quad_order_diagonal', None))
+            self._setup2D(kernel, interior_target, interior_qd)
         else:
-            self._setup1D(kernel, target_order, params.get('quad_order_diagonal', None))
+            self._setup1D(kernel, interior_target, interior_qd)
         self.singularityValue = sing
         self._distant_rules(qcap)
         # surface integrals (NA:953-955): the Gauss-theorem twin is built whenever it exists, not only for zeroExterior --
@@ -149,7 +154,10 @@ class nonlocalTables:
         centers = mesh.vertices[mesh.cells].mean(axis=1)
         self.cell_labels = np.ascontiguousarray(sFun.labels(centers), dtype=np.int32)
         assert self.cell_labels.min() >= 0 and self.cell_labels.max() < self.num_labels
-        self.classes = [nonlocalTables(dm, kernel.constantOrderKernel(sv), params, zeroExterior, qcap) for sv in vals]
+        cparams = dict(params or {})
+        if not kernel.symmetric:
+            cparams['_nonsymInterior'] = True
+        self.classes = [nonlocalTables(dm, kernel.constantOrderKernel(sv), cparams, zeroExterior, qcap) for sv in vals]
         c0 = self.classes[0]
         for name in ('dm', 'dim', 'dpe', 'num_dofs', 'hmin', 'H0', 'dof_perm_table', 'qcap', 'zeroExterior', 'has_boundary_tables',
                      'dist_off', 'dist_bary', 'dist_w', 'dist_phi', 'bfacet_off', 'bfacet_bary', 'bfacet_w', 'target_order',
