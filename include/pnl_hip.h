@@ -237,6 +237,11 @@ int pnl_spmv(pnl_context *ctx, const double *data_dev, const double *diag_dev, c
 typedef struct pnl_order_function {
     int32_t type, normalized;
     double p[6];
+    /* optional: the scaling C(s) as a Chebyshev series sum_k scal_cheb[k] T_k((s - scal_mid)/scal_half) over the range of
+     * the order (a polynomial instead of two Gamma functions per quadrature point); scal_n == 0: evaluate the formula */
+    int32_t scal_n, pad;
+    double scal_mid, scal_half;
+    double scal_cheb[32];
 } pnl_order_function;
 
 /* cell_smax[nc] / facet_smax[nb]: largest order over the centre and the vertices of a cell / boundary facet (the per-pair

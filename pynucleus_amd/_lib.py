@@ -43,7 +43,8 @@ class pnl_order_formula(C.Structure):
 
 
 class pnl_order_function(C.Structure):
-    _fields_ = [('type', C.c_int32), ('normalized', C.c_int32), ('p', C.c_double*6)]
+    _fields_ = [('type', C.c_int32), ('normalized', C.c_int32), ('p', C.c_double*6), ('scal_n', C.c_int32), ('pad', C.c_int32),
+                ('scal_mid', C.c_double), ('scal_half', C.c_double), ('scal_cheb', C.c_double*32)]
 
 
 class pnl_cluster_plan(C.Structure):
@@ -190,6 +191,11 @@ class Context:
             # distinct order of the touching pairs
             self.check(L.pnl_set_classes(h, 1, 0, None, None, None))
             f = pnl_order_function(int(T.order_type), int(T.kernel.normalized), (C.c_double*6)(*[float(x) for x in T.order_params]))
+            cheb = getattr(T, 'scaling_cheb', None)
+            if cheb is not None:
+                f.scal_n, f.scal_mid, f.scal_half = len(cheb[2]), cheb[0], cheb[1]
+                for i, v in enumerate(cheb[2]):
+                    f.scal_cheb[i] = float(v)
             cs, pcs = _hp(T.cell_smax, np.float64)
             fs, pfs = _hp(T.facet_smax, np.float64)
             self.check(L.pnl_set_order_function(h, C.byref(f), pcs, pfs, float(T.pw_c0), float(T.pw_bc0), float(T.sing_fac),

@@ -1161,8 +1161,12 @@ int pointwise_impl(pnl_context *ctx, double *A, int64_t ldA, int zero_exterior, 
         const size_t lds = sizeof(double)*((size_t)tab_max*ST+(size_t)(PNL_NTHREADS/16)*tab_max*2);
         auto kfun = k_pw_distant<DIM>;
         HIPCHK(ctx, hipFuncSetAttribute((const void*)kfun, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        const bool lane_kernel = !getenv("PNL_PW_NOLANE");
+        if (lane_kernel)
+            hipLaunchKernelGGL((k_pw_lane<DIM>), dim3(256*2), dim3(PNL_NTHREADS), 0, ctx->stream, P, W, (const int4*)ctx->b_wlsorted.p,
+                               (const unsigned*)offs, A, (long long)ldA, (double*)ctx->b_D.p);
         hipLaunchKernelGGL(kfun, dim3(256*4), dim3(PNL_NTHREADS), lds, ctx->stream, P, W, (const int4*)ctx->b_wlsorted.p,
-                           (const unsigned*)offs, A, (long long)ldA, (double*)ctx->b_D.p, tab_max);
+                           (const unsigned*)offs, A, (long long)ldA, (double*)ctx->b_D.p, tab_max, lane_kernel ? PNL_PW_LANE_MAXPTS+1 : 0);
         HIPCHK(ctx, hipGetLastError());
     }
     HIPCHK(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
@@ -1979,6 +1983,9 @@ int pnl_set_order_function(pnl_context *ctx, const pnl_order_function *f, const 
     std::memset(&ctx->pw, 0, sizeof(ctx->pw));
     ctx->pw.type = f->type; ctx->pw.normalized = f->normalized;
     for (int i = 0; i < 6; i++) ctx->pw.p[i] = f->p[i];
+    if (f->scal_n < 0 || f->scal_n > 32 || (f->scal_n > 0 && !(f->scal_half > 0.))) return fail(ctx, PNL_ERR_INVALID, "bad Chebyshev series of the scaling");
+    ctx->pw.scal_n = f->scal_n; ctx->pw.scal_mid = f->scal_mid; ctx->pw.scal_inv_half = f->scal_n > 0 ? 1./f->scal_half : 0.;
+    for (int i = 0; i < 32; i++) ctx->pw.scal_cheb[i] = i < f->scal_n ? f->scal_cheb[i] : 0.;
     ctx->pw.c0 = c0; ctx->pw.bc0 = bc0; ctx->pw.sfac = sing_fac; ctx->pw.bfac = bsing_fac;
     ctx->pw_cell_smax.assign(cell_smax, cell_smax+ctx->nc);
     ctx->pw_facet_smax.clear();

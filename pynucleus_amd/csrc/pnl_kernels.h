@@ -18,6 +18,59 @@
 
 // ---------------------------------------------------------------------------------------------
 // kernel function gamma(|x-y|^2)   (KC:75-294)
+// Branch-free ln and exp for the kernels with a general exponent: d2^e = exp(e ln d2), d2 a positive normal number and
+// |e ln d2| far from overflow.  Straight-line code (no special cases), so the independent evaluations of a pair interleave.
+// ln x: x = m 2^k with m in [sqrt(1/2), sqrt(2)); ln m = 2 atanh(f), f = (m-1)/(m+1), |f| < 0.172, odd series to f^21.
+__device__ __forceinline__ double pnl_log(double x) {
+    double m = __builtin_amdgcn_frexp_mant(x);           // [0.5, 1)
+    int k = __builtin_amdgcn_frexp_exp(x);
+    const bool low = m < 0.70710678118654752440;
+    m = low ? m+m : m;
+    k = low ? k-1 : k;
+    const double a = m-1.0, b = m+1.0;
+    double r = __builtin_amdgcn_rcp(b);
+    r = __builtin_fma(__builtin_fma(-b, r, 1.0), r, r);
+    r = __builtin_fma(__builtin_fma(-b, r, 1.0), r, r);
+    double f = a*r;
+    f = __builtin_fma(__builtin_fma(-f, b, a), r, f);
+    const double z = f*f;
+    double p = 1.0/21.0;
+    p = __builtin_fma(p, z, 1.0/19.0);
+    p = __builtin_fma(p, z, 1.0/17.0);
+    p = __builtin_fma(p, z, 1.0/15.0);
+    p = __builtin_fma(p, z, 1.0/13.0);
+    p = __builtin_fma(p, z, 1.0/11.0);
+    p = __builtin_fma(p, z, 1.0/9.0);
+    p = __builtin_fma(p, z, 1.0/7.0);
+    p = __builtin_fma(p, z, 1.0/5.0);
+    p = __builtin_fma(p, z, 1.0/3.0);
+    const double lm = __builtin_fma(f+f, z*p, f+f);       // 2 f + 2 f^3 (1/3 + ...)
+    const double kd = (double)k;
+    return __builtin_fma(kd, 6.93147180369123816490e-01, __builtin_fma(kd, 1.90821492927058770002e-10, lm));
+}
+
+// exp y, |y| < 700: y = n ln 2 + r, |r| <= 0.347, Taylor polynomial to r^13, scaled by 2^n
+__device__ __forceinline__ double pnl_exp(double y) {
+    const double n = __builtin_rint(y*1.44269504088896338700);
+    double r = __builtin_fma(-n, 6.93147180369123816490e-01, y);
+    r = __builtin_fma(-n, 1.90821492927058770002e-10, r);
+    double p = 1.0/6227020800.0;
+    p = __builtin_fma(p, r, 1.0/479001600.0);
+    p = __builtin_fma(p, r, 1.0/39916800.0);
+    p = __builtin_fma(p, r, 1.0/3628800.0);
+    p = __builtin_fma(p, r, 1.0/362880.0);
+    p = __builtin_fma(p, r, 1.0/40320.0);
+    p = __builtin_fma(p, r, 1.0/5040.0);
+    p = __builtin_fma(p, r, 1.0/720.0);
+    p = __builtin_fma(p, r, 1.0/120.0);
+    p = __builtin_fma(p, r, 1.0/24.0);
+    p = __builtin_fma(p, r, 1.0/6.0);
+    p = __builtin_fma(p, r, 0.5);
+    p = __builtin_fma(p, r, 1.0);
+    p = __builtin_fma(p, r, 1.0);
+    return __builtin_amdgcn_ldexp(p, (int)n);
+}
+
 // KT: 0 general (pow / indicator / peridynamic, horizon test), 1 fractional with exponent -qm/4, qm a run-time (wave-uniform)
 // value, 2 the same with qm == 6 known at compile time (s = 1/2 in 2D): no branch per evaluation, so the compiler
 // interleaves the dependent chains of the independent evaluations of a pair.
@@ -59,7 +112,7 @@ __device__ __forceinline__ double kern_eval(const DevKernel &k, double d2) {
         if (!(d2 <= k.horizon2)) return 0.;
         // general exponent: exp(e ln d2) instead of pow (half the instructions; |e ln d2| < 60 keeps the relative error of the
         // product below 1e-14, three orders under the parity tolerance)
-        if (k.ktype == 0) return k.scale*exp(k.exponent*log(d2));
+        if (k.ktype == 0) return k.scale*pnl_exp(k.exponent*pnl_log(d2));
         if (k.ktype == 1) return k.scale;
         return k.scale/sqrt(d2);
     }

@@ -15,6 +15,8 @@
 struct PwDev {
     int type, normalized;       // 1 constant, 2 smoothStep(x0), 3 linearStep(x0), 4 smoothStepRadial (fractionalOrders.pyx:338-540)
     double p[6];                // sl, sr, r, interface | radius, slope
+    int scal_n, pad0;           // scaling C(s) as a Chebyshev series over the range of the order (0: Gamma functions)
+    double scal_mid, scal_inv_half, scal_cheb[32];
     double c0, bc0;             // constant term of the interior / boundary order formula
     const double *cell_smax, *facet_smax;
     int M[3], rows[3];
@@ -46,7 +48,13 @@ __device__ __forceinline__ double pw_order(const PwDev &W, const double *x) {
 template <int DIM>
 __device__ __forceinline__ double pw_scaling(const PwDev &W, double s, bool boundary) {
     double C = 0.5;
-    if (W.normalized) {
+    if (W.normalized && W.scal_n > 0) {
+        // Clenshaw on the Chebyshev series of C(s) (host: local_matrix._setup_pointwise, checked there to 1e-14)
+        const double t = (s-W.scal_mid)*W.scal_inv_half, t2 = t+t;
+        double b1 = 0., b2 = 0.;
+        for (int k = W.scal_n-1; k >= 1; k--) { const double b0 = __builtin_fma(t2, b1, W.scal_cheb[k]-b2); b2 = b1; b1 = b0; }
+        C = __builtin_fma(t, b1, W.scal_cheb[0]-b2);
+    } else if (W.normalized) {
         const double pi_pow = DIM == 1 ? 0.56418958354775628695 : 0.31830988618379067154;       // pi^(-d/2)
         C = exp2(2.0*s)*s*tgamma(s+0.5*DIM)*pi_pow/tgamma(1.0-s)*0.5;
     }
@@ -149,14 +157,14 @@ __global__ void k_pw_stats(const DevProblem P, const unsigned *__restrict__ hist
     atomicAdd(&P.counters[2], 2ull*c*n*n);
 }
 
-// ---- distant pairs from the sorted list: 16 lanes per pair split the rows of the tensor rule -------------------------
+// ---- distant pairs from the sorted list, rules with more than PNL_PW_LANE_MAXPTS points: 16 lanes per pair split the rows
 // per point pair: L = ln d2 once, K1 = w_i w_j C(s(x_i)) exp(e(x_i) L), K2 = w_i w_j C(s(y_j)) exp(e(y_j) L);
 // order and scaling of the points of the second cell are computed once per pair and kept in LDS.
 #define PNL_PW_MAXPTS 128
 template <int DIM>
 __global__ void __launch_bounds__(PNL_NTHREADS)
 k_pw_distant(const DevProblem P, const PwDev W, const int4 *__restrict__ sorted, const unsigned *__restrict__ offs,
-             double *__restrict__ A, long long ldA, double *__restrict__ Dglob, int tab_max_pts) {
+             double *__restrict__ A, long long ldA, double *__restrict__ Dglob, int tab_max_pts, int nmin) {
     constexpr int NV = DIM+1, DPE = NV, NC = NV*DIM, ND = DPE*(DPE+1)/2, NG = DPE*DPE, NACC = 2*NG+2*ND, LPP = 16,
                   PPC = PNL_NTHREADS/LPP, NREP = (NACC+LPP-1)/LPP, ST = 4+DPE;
     extern __shared__ double s_mem[];            // rule [tab_max_pts][ST], then per pair of the chunk [PPC][tab_max_pts][2]: e(y_j), w_j C(y_j)
@@ -168,7 +176,7 @@ k_pw_distant(const DevProblem P, const PwDev W, const int4 *__restrict__ sorted,
         for (int q = 0; q < PNL_WL_BINS; q++) {
             s_coff[q] = run;
             const int nq = (q >= 2 && q <= P.qmax && q <= PNL_MAXQ) ? P.off[q+1]-P.off[q] : 0;
-            if (nq > 0) run += (offs[q+1]-offs[q]+PPC-1u)/PPC;
+            if (nq > 0 && nq >= nmin) run += (offs[q+1]-offs[q]+PPC-1u)/PPC;   // smaller rules: k_pw_lane
         }
         s_coff[PNL_WL_BINS] = run;
     }
@@ -264,8 +272,8 @@ k_pw_distant(const DevProblem P, const PwDev W, const int4 *__restrict__ sorted,
                 double ey, cy;
                 if (in_lds) { ey = my_y[2*j]; cy = my_y[2*j+1]; }
                 else { const double s = pw_order<DIM>(W, y); ey = -0.5*DIM-s; cy = tj[3]*pw_scaling<DIM>(W, s, false); }
-                const double L = log(d2);
-                const double K1 = (cx*tj[3])*exp(ex*L), K2 = (ti[3]*cy)*exp(ey*L);
+                const double L = pnl_log(d2);
+                const double K1 = (cx*tj[3])*pnl_exp(ex*L), K2 = (ti[3]*cy)*pnl_exp(ey*L);
                 r1 += K1;
                 double t2[DPE];
 #pragma unroll
@@ -321,6 +329,159 @@ k_pw_distant(const DevProblem P, const PwDev W, const int4 *__restrict__ sorted,
                     if (I >= 0 && J >= 0) atomic_add_f64(&A[(long long)I*ldA+J], -vv*val);
                 } else if (e < 2*NG+ND) atomic_add_f64(&Dglob[(size_t)c1*ND+(e-2*NG)], vv*val);
                 else if (e < NACC) atomic_add_f64(&Dglob[(size_t)c2*ND+(e-2*NG-ND)], vv*val);
+            }
+        }
+    }
+}
+
+// ---- distant pairs with at most PNL_PW_LANE_MAXPTS points per cell (orders 2-8 on triangles: almost all pairs): ONE PAIR PER
+// LANE.  The list is sorted by order, so the 64 pairs of a wave's chunk run the same trip counts; the rule sits in the wave's
+// LDS copy (broadcast reads), exponent and scaled weight of the second cell's points in a per-lane LDS column (conflict
+// free), the 2 NG + 2 ND accumulators in registers, no cross-lane work.
+#define PNL_PW_LANE_MAXPTS 16
+template <int DIM>
+__global__ void __launch_bounds__(PNL_NTHREADS)
+k_pw_lane(const DevProblem P, const PwDev W, const int4 *__restrict__ sorted, const unsigned *__restrict__ offs,
+          double *__restrict__ A, long long ldA, double *__restrict__ Dglob) {
+    constexpr int NV = DIM+1, DPE = NV, NC = NV*DIM, ND = DPE*(DPE+1)/2, ST = 4+DPE, NW = PNL_NTHREADS/64, MAXN = PNL_PW_LANE_MAXPTS;
+    __shared__ double s_rule[NW][MAXN*ST];
+    __shared__ double s_y[NW][MAXN*2*64];        // [j][e | wC][lane]
+    __shared__ unsigned s_coff[PNL_WL_BINS+1];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) {
+        unsigned run = 0;
+        for (int q = 0; q < PNL_WL_BINS; q++) {
+            s_coff[q] = run;
+            const int nq = (q >= 2 && q <= P.qmax && q <= PNL_MAXQ) ? P.off[q+1]-P.off[q] : 0;
+            if (nq > 0 && nq <= MAXN) run += (offs[q+1]-offs[q]+63u)/64u;
+        }
+        s_coff[PNL_WL_BINS] = run;
+    }
+    __syncthreads();
+    const unsigned nchunks = s_coff[PNL_WL_BINS];
+    double *rule = s_rule[wave], *ycol = s_y[wave]+lane;
+    int staged_q = -1;
+    for (unsigned chunk = blockIdx.x*NW+wave; chunk < nchunks; chunk += gridDim.x*NW) {
+        int lo = 0, hi = PNL_WL_BINS-1;
+        while (lo < hi) {
+            const int mid = (lo+hi+1) >> 1;
+            if (s_coff[mid] <= chunk) lo = mid; else hi = mid-1;
+        }
+        const int q = lo;
+        const unsigned first = offs[q]+64u*(chunk-s_coff[q]);
+        const int cnt = (int)min(64u, offs[q+1]-first);
+        const int off = P.off[q], n = P.off[q+1]-off;
+        if (q != staged_q) {
+            __builtin_amdgcn_wave_barrier();
+            for (int t = lane; t < n*ST; t += 64) {
+                const int pt = t/ST, k = t-pt*ST;
+                rule[t] = k < 3 ? P.bary[3*(size_t)(off+pt)+k] : (k == 3 ? P.w[off+pt] : P.phi[(size_t)(off+pt)*DPE+k-4]);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            staged_q = q;
+        }
+        const bool valid = lane < cnt;
+        const int4 ent = sorted[first+(valid ? lane : 0)];
+        const int c1 = ent.x, c2 = ent.y;
+        double av[NC], bv[NC];
+#pragma unroll
+        for (int k = 0; k < NC; k++) { av[k] = P.cellv[(size_t)k*P.ncp+c1]; bv[k] = P.cellv[(size_t)k*P.ncp+c2]; }
+        // order and scaling at the points of the second cell, once per pair
+        for (int j = 0; j < n; j++) {
+            double y[DIM];
+#pragma unroll
+            for (int d = 0; d < DIM; d++) {
+                double sy = 0.;
+#pragma unroll
+                for (int m = 0; m < NV; m++) sy = __builtin_fma(rule[j*ST+m], bv[m*DIM+d], sy);
+                y[d] = sy;
+            }
+            const double s = pw_order<DIM>(W, y);
+            ycol[(2*j)*64] = -0.5*DIM-s;
+            ycol[(2*j+1)*64] = rule[j*ST+3]*pw_scaling<DIM>(W, s, false);
+        }
+        double G1[DPE][DPE], G2[DPE][DPE], S1[ND], S2[ND];
+#pragma unroll
+        for (int a = 0; a < DPE; a++)
+#pragma unroll
+            for (int b = 0; b < DPE; b++) { G1[a][b] = 0.; G2[a][b] = 0.; }
+#pragma unroll
+        for (int e = 0; e < ND; e++) { S1[e] = 0.; S2[e] = 0.; }
+#pragma unroll 1
+        for (int i = 0; i < n; i++) {
+            double ti[ST];
+#pragma unroll
+            for (int m = 0; m < ST; m++) ti[m] = rule[i*ST+m];
+            double x[DIM];
+#pragma unroll
+            for (int d = 0; d < DIM; d++) {
+                double sx = 0.;
+#pragma unroll
+                for (int m = 0; m < NV; m++) sx = __builtin_fma(ti[m], av[m*DIM+d], sx);
+                x[d] = sx;
+            }
+            const double sx_ = pw_order<DIM>(W, x);
+            const double ex = -0.5*DIM-sx_, cx = ti[3]*pw_scaling<DIM>(W, sx_, false);
+            double r1 = 0., u1[DPE], u2[DPE];
+#pragma unroll
+            for (int b = 0; b < DPE; b++) { u1[b] = 0.; u2[b] = 0.; }
+#pragma unroll 3
+            for (int j = 0; j < n; j++) {       // three independent log / exp chains in flight (the rules have 3, 6, 12, 15 points)
+                double tj[ST];
+#pragma unroll
+                for (int m = 0; m < ST; m++) tj[m] = rule[j*ST+m];
+                double d2 = 0.;
+#pragma unroll
+                for (int d = 0; d < DIM; d++) {
+                    double sy = 0.;
+#pragma unroll
+                    for (int m = 0; m < NV; m++) sy = __builtin_fma(tj[m], bv[m*DIM+d], sy);
+                    const double t = x[d]-sy;
+                    d2 = __builtin_fma(t, t, d2);
+                }
+                const double L = pnl_log(d2);
+                const double K1 = (cx*tj[3])*pnl_exp(ex*L), K2 = (ti[3]*ycol[(2*j+1)*64])*pnl_exp(ycol[(2*j)*64]*L);
+                r1 += K1;
+                double t2[DPE];
+#pragma unroll
+                for (int b = 0; b < DPE; b++) { u1[b] = __builtin_fma(K1, tj[4+b], u1[b]); t2[b] = K2*tj[4+b]; u2[b] += t2[b]; }
+                int e = 0;
+#pragma unroll
+                for (int a = 0; a < DPE; a++)
+#pragma unroll
+                    for (int b = a; b < DPE; b++) { S2[e] = __builtin_fma(t2[a], tj[4+b], S2[e]); e++; }
+            }
+            int e = 0;
+#pragma unroll
+            for (int a = 0; a < DPE; a++) {
+                const double pa = ti[4+a];
+#pragma unroll
+                for (int b = 0; b < DPE; b++) {
+                    G1[a][b] = __builtin_fma(pa, u1[b], G1[a][b]);
+                    G2[a][b] = __builtin_fma(u2[a], ti[4+b], G2[a][b]);
+                }
+                const double pr = pa*r1;
+#pragma unroll
+                for (int b = a; b < DPE; b++) { S1[e] = __builtin_fma(pr, ti[4+b], S1[e]); e++; }
+            }
+        }
+        if (valid) {
+            const double vv = 2.*P.cvol[c1]*P.cvol[c2];          // both orientations
+            int d1[DPE], d2_[DPE];
+#pragma unroll
+            for (int a = 0; a < DPE; a++) { d1[a] = P.cdof[(size_t)a*P.ncp+c1]; d2_[a] = P.cdof[(size_t)a*P.ncp+c2]; }
+#pragma unroll
+            for (int a = 0; a < DPE; a++)
+#pragma unroll
+                for (int b = 0; b < DPE; b++) {
+                    if (d1[a] >= 0 && d2_[b] >= 0) atomic_add_f64(&A[(long long)d1[a]*ldA+d2_[b]], -vv*G1[a][b]);
+                    if (d2_[a] >= 0 && d1[b] >= 0) atomic_add_f64(&A[(long long)d2_[a]*ldA+d1[b]], -vv*G2[a][b]);
+                }
+#pragma unroll
+            for (int e = 0; e < ND; e++) {
+                atomic_add_f64(&Dglob[(size_t)c1*ND+e], vv*S1[e]);
+                atomic_add_f64(&Dglob[(size_t)c2*ND+e], vv*S2[e]);
             }
         }
     }
@@ -428,10 +589,10 @@ k_pw_singular(const DevProblem P, const PwDev W, const int4 *__restrict__ pairs,
             x[d] = xx; y[d] = yy;
             d2 = __builtin_fma(xx-yy, xx-yy, d2);
         }
-        const double L = log(d2);
+        const double L = pnl_log(d2);
         const double sx = pw_order<DIM>(W, x), sy = pw_order<DIM>(W, y);
-        const double t1 = w[m]*pw_scaling<DIM>(W, sx, false)*exp((-0.5*DIM-sx)*L);
-        const double t2 = w[m]*pw_scaling<DIM>(W, sy, false)*exp((-0.5*DIM-sy)*L);
+        const double t1 = w[m]*pw_scaling<DIM>(W, sx, false)*pnl_exp((-0.5*DIM-sx)*L);
+        const double t2 = w[m]*pw_scaling<DIM>(W, sy, false)*pnl_exp((-0.5*DIM-sy)*L);
         double f[ROWS], ps[ROWS];
 #pragma unroll
         for (int r = 0; r < ROWS; r++) {
@@ -551,7 +712,7 @@ k_pw_boundary_distant(const DevProblem P, const PwDev W, double *__restrict__ Dg
                     if (DIM == 2) nw = __builtin_fma(nrm[d], wv, nw);
                 }
                 if (DIM != 2) nw = 1.;
-                r = __builtin_fma(fw[m]*nw, exp(ex*log(d2)), r);
+                r = __builtin_fma(fw[m]*nw, pnl_exp(ex*pnl_log(d2)), r);
             }
             r *= w[k]*vol*cx;
             int e = 0;
@@ -671,7 +832,7 @@ k_pw_boundary_singular(const DevProblem P, const PwDev W, const int4 *__restrict
         if (DIM != 2) nw = 1.;
         const double sx = pw_order<DIM>(W, x);
         const double ex = 0.5*(1-DIM)-sx-(DIM == 2 ? 0.5 : 0.);
-        const double t = w[m]*nw*pw_scaling<DIM>(W, sx, true)*exp(ex*log(d2));
+        const double t = w[m]*nw*pw_scaling<DIM>(W, sx, true)*pnl_exp(ex*pnl_log(d2));
         double ps[DPE];
 #pragma unroll
         for (int r = 0; r < DPE; r++) ps[r] = PHI[(size_t)r*M+m];

@@ -236,6 +236,20 @@ class nonlocalTables:
         fv = mesh.vertices[self.bcells]                                     # [nb, dim, dim]
         self.facet_smax = np.maximum(sF.evalPoints(fv.mean(axis=1)), sF.evalPoints(fv).max(axis=1))
         self._pw_rules = None
+        # the scaling C(s) over [s.min, s.max] as a Chebyshev series: a polynomial per quadrature point on the device instead
+        # of two Gamma functions (the oracle keeps the formula)
+        self.scaling_cheb = None
+        if kernel.normalized and sF.max > sF.min:
+            from numpy.polynomial import chebyshev as Ch
+            mid, half = 0.5*(sF.max+sF.min), 0.5*(sF.max-sF.min)
+            for deg in (15, 23, 31):
+                c = Ch.chebinterpolate(lambda t: kernel.scalingOfOrder(mid+half*t), deg)
+                t = np.linspace(-1., 1., 401)
+                err = np.abs(Ch.chebval(t, c)/kernel.scalingOfOrder(mid+half*t)-1.).max()
+                if err < 1e-14:
+                    break
+            if err < 1e-14:
+                self.scaling_cheb = (mid, half, c)
 
     def pw_formula(self, sv, boundary=False):
         """order-formula constants of a pair whose largest order is sv (FL2:915-935, FL1:431-450; FL2:1226-1243, FL1:644-660)"""
