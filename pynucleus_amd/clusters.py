@@ -184,20 +184,21 @@ def getSparseNearField(dm, Pnear, symmetric=True):
     """sparsity pattern of the near field: CSR (indptr, indices); with symmetric=True only I > J is stored (SSS, the
     diagonal lives in its own vector)"""
     N = dm.num_dofs
-    rows, cols = [], []
+    parts = []
     for cp in Pnear:
-        I = np.repeat(cp.n1.dofs, cp.n2.dofs.shape[0])
-        J = np.tile(cp.n2.dofs, cp.n1.dofs.shape[0])
-        if symmetric:
-            m = I > J
-            I, J = I[m], J[m]
-        rows.append(I)
-        cols.append(J)
-    keys = np.unique(np.concatenate(rows).astype(np.int64)*N+np.concatenate(cols))
-    I, J = (keys//N).astype(np.int32), (keys % N).astype(np.int32)
-    indptr = np.zeros(N+1, dtype=np.int32)
-    np.add.at(indptr, I+1, 1)
-    return np.cumsum(indptr).astype(np.int32), J
+        I = np.asarray(cp.n1.dofs, dtype=np.int64)[:, None]
+        J = np.asarray(cp.n2.dofs, dtype=np.int64)[None, :]
+        k = (I << 32) | J                                           # one key per entry of the block, no repeat / tile copies
+        parts.append(k[I > J] if symmetric else k.ravel())
+    keys = np.concatenate(parts) if parts else np.zeros(0, dtype=np.int64)
+    keys.sort()
+    if keys.shape[0] > 1 and (keys[1:] == keys[:-1]).any():         # blocks of a cluster partition are disjoint as a rule
+        keys = np.unique(keys)
+    I = keys >> 32                                                  # (shifts instead of a 64-bit division per entry)
+    J = (keys & 0xffffffff).astype(np.int32)
+    indptr = np.zeros(N+1, dtype=np.int64)
+    indptr[1:] = np.cumsum(np.bincount(I, minlength=N))
+    return indptr.astype(np.int32), J
 
 
 def elemElemSymMaskTable(dpe):
