@@ -133,8 +133,18 @@ def _dist_worker(rank, world, port, out):
     e2 = float(np.abs(full.toarray()-Aref).max()/np.abs(Aref).max())
     pairs = torch.tensor([op.info['counters']['numAssembledCellPairs']], dtype=torch.float64)
     dist.all_reduce(pairs)
+    # the non-symmetric paths under the same split: order per quadrature point (cellNo1 ranges), piecewise non-symmetric table
+    from pynucleus_amd.fractionalOrders import smoothedLeftRightFractionalOrder, leftRightFractionalOrder
+    e3 = []
+    for sF in (smoothedLeftRightFractionalOrder(0.25, 0.75, r=0.3), leftRightFractionalOrder(0.25, 0.75, 0.3, 0.6)):
+        mesh3 = disc(3)
+        dm3 = P1_DoFMap(mesh3, PHYSICAL)
+        b3 = nonlocalBuilder(dm3, getFractionalKernel(2, sF), {}, zeroExterior=True, comm=True)
+        A3 = b3.getDense().toarray()
+        R3 = OracleProblem(b3.tables).get_dense()[0]
+        e3.append(float(np.abs(A3-R3).max()/np.abs(R3).max()))
     if rank == 0:
-        out.put((e1, e2, float(pairs.item()), mesh.num_cells))
+        out.put((e1, e2, float(pairs.item()), mesh.num_cells, max(e3)))
     dist.destroy_process_group()
 
 
@@ -149,12 +159,12 @@ def test_two_ranks_share_the_pairs():
     procs = [ctx.Process(target=_dist_worker, args=(r, 2, port, out)) for r in range(2)]
     for p in procs:
         p.start()
-    e1, e2, pairs, nc = out.get(timeout=300)
+    e1, e2, pairs, nc, e3 = out.get(timeout=300)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
     assert pairs == nc*(nc+1)//2
-    assert e1 < 1e-11 and e2 < TOL
+    assert e1 < 1e-11 and e2 < TOL and e3 < TOL
 
 
 @pytest.mark.parametrize('case', ['smoothedLeftRight_disc', 'constantNonSym_disc', 'innerOuter_disc', 'smoothedLeftRight_interval',
