@@ -668,7 +668,7 @@ int launch_singular(pnl_context *ctx, double *A, int64_t ldA, int cell_begin, in
 
 template <int DIM, int DPE, int KT>
 int launch_boundary(pnl_context *ctx, int cell_begin, int cell_end) {
-    if (ctx->nb == 0) return PNL_OK;
+    if (ctx->nb == 0 || cell_end <= cell_begin) return PNL_OK;
     const int ncell = cell_end-cell_begin;
     const int gx = (ncell+PNL_NTHREADS-1)/PNL_NTHREADS;
     // small facet chunks: many waves in flight hide the latency of the per-facet dependent chain

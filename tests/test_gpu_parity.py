@@ -275,3 +275,38 @@ def test_piecewise_nonsymmetric_order(case):
     scale = np.abs(Aref).max()
     assert np.abs(Ag-Aref).max() < TOL*scale, np.abs(Ag-Aref).max()/scale
     assert np.abs(Aref-Aref.T).max() <= 1e-13*scale
+
+
+@pytest.mark.parametrize('case', ['disc0', 'disc1', 'interval1', 'interval2_P1', 'empty_range', 'all_boundary'])
+def test_edge_cases(case):
+    """ragged / tiny inputs: fewer cells than one block, a single interior DoF, an empty cell range, a DoF map without any
+    interior DoF"""
+    import torch
+    from pynucleus_amd import disc, interval, PHYSICAL, NO_BOUNDARY, P1_DoFMap, getFractionalKernel
+    from pynucleus_amd.builder import nonlocalBuilder
+    from oracle.oracle import OracleProblem
+    if case == 'disc0':
+        mesh = disc(0)
+    elif case == 'disc1':
+        mesh = disc(1)
+    elif case == 'interval1':
+        mesh = interval(1)
+    else:
+        mesh = interval(2) if case == 'interval2_P1' else disc(1)
+    dm = P1_DoFMap(mesh, PHYSICAL)
+    b = nonlocalBuilder(dm, getFractionalKernel(mesh.dim, 0.5), {}, zeroExterior=True)
+    if case == 'empty_range':
+        ctx = b.context()
+        A = torch.zeros((dm.num_dofs, dm.num_dofs), dtype=torch.float64, device='cuda')
+        ctx.assemble_dense(A.data_ptr(), A.stride(0), True, 3, 3)
+        torch.cuda.synchronize()
+        assert float(A.abs().max()) == 0. and ctx.counters()['numAssembledCellPairs'] == 0
+        return
+    if case == 'all_boundary':
+        mesh = disc(0)                                   # 6 cells around one interior vertex: remove it too -> no DoF at all
+        dm = P1_DoFMap(mesh, PHYSICAL)
+        assert dm.num_dofs == 1
+    A = b.getDense()
+    Aref, cnt, _ = OracleProblem(b.tables).get_dense()
+    assert A.info['counters']['numAssembledCellPairs'] == cnt['numAssembledCellPairs']
+    assert np.abs(A.toarray()-Aref).max() <= TOL*np.abs(Aref).max()
