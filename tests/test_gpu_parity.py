@@ -310,3 +310,32 @@ def test_edge_cases(case):
     Aref, cnt, _ = OracleProblem(b.tables).get_dense()
     assert A.info['counters']['numAssembledCellPairs'] == cnt['numAssembledCellPairs']
     assert np.abs(A.toarray()-Aref).max() <= TOL*np.abs(Aref).max()
+
+
+def test_cells_without_locality_are_renumbered():
+    """a mesh whose cells are numbered at random (straight out of a generator): the builder renumbers the cells along a Morton
+    curve for the tile kernels' LDS sub-blocks; DoF numbers are those of the caller's DoFMap"""
+    from pynucleus_amd import disc, PHYSICAL, P1_DoFMap, getFractionalKernel, nonlocalTables
+    from pynucleus_amd.mesh import mesh2d
+    from pynucleus_amd.builder import nonlocalBuilder, block_dof_count
+    from oracle.oracle import OracleProblem
+    m0 = disc(4)
+    rng = np.random.default_rng(1)
+    shuffled = mesh2d(m0.vertices.copy(), np.ascontiguousarray(m0.cells[rng.permutation(m0.num_cells)]))
+    dm = P1_DoFMap(shuffled, PHYSICAL)
+    assert block_dof_count(dm.dofs, 64) > 100
+    kernel = getFractionalKernel(2, 0.5)
+    b = nonlocalBuilder(dm, kernel, {'target_order': 0.5})
+    assert hasattr(b.dm, 'cell_permutation') and block_dof_count(b.dm.dofs, 64) <= 64
+    A = b.getDense().toarray()
+    Aint = OracleProblem(b.tables).get_dense()[0]                  # the oracle on the renumbered cells: same DoFs, same operator
+    assert np.abs(A-Aint).max() <= TOL*np.abs(Aint).max()
+    # against the caller's numbering the operator differs only through the orientation of the touching pairs (which cell comes
+    # first in the singular rule), i.e. at the quadrature error of those rules -- the dependence on the cell numbering the
+    # reference itself has
+    Aref = OracleProblem(nonlocalTables(dm, kernel, {'target_order': 0.5})).get_dense()[0]
+    assert np.abs(A-Aref).max() <= 1e-6*np.abs(Aref).max()
+    # without the renumbering the sub-block does not fit: the library says so instead of computing something else
+    b2 = nonlocalBuilder(dm, kernel, {'target_order': 0.5, 'reorderCells': False})
+    with pytest.raises(NotImplementedError):
+        b2.getDense()
