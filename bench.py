@@ -47,6 +47,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--noRef', type=int, default=7)
     ap.add_argument('--s', type=float, default=0.5)
+    ap.add_argument('--sectors', type=int, default=6, help='triangles of the initial fan (6 = the reference disc; 12 at noRef 7 gives 97 921 DoFs)')
     ap.add_argument('--cpu-seconds', type=float, default=15., help='target CPU time of the oracle sample (rank 0, N=1 only)')
     ap.add_argument('--no-cpu', action='store_true')
     ap.add_argument('--solve', action='store_true', help='also run the CG-Jacobi solve of configs[1] (reported, not timed into value)')
@@ -71,7 +72,7 @@ def main():
         dist.init_process_group('nccl', device_id=dev)
 
     # ---- setup (not timed): tables on the host, upload into HBM ---------------------------------------------
-    mesh = disc(args.noRef)
+    mesh = disc(args.noRef, sectors=args.sectors)
     dm = P1_DoFMap(mesh, PHYSICAL)
     kernel = getFractionalKernel(2, args.s)
     builder = nonlocalBuilder(dm, kernel, {'target_order': 0.5}, zeroExterior=True, comm=(True if world > 1 else None))
@@ -153,7 +154,7 @@ def main():
         with open(pmc_fn) as f:
             rec = json.load(f)
         key = 'noRef{}'.format(args.noRef)
-        if key in rec and world == 1:
+        if key in rec and world == 1 and args.sectors == 6:
             traffic = rec[key].get(dominant+'_hbm_bytes_per_launch')
     # HBM view of the same launches: the algorithmic minimum is one write of the upper block triangle they fill
     hbm_alg_bytes = 8.*N*N/2
@@ -172,8 +173,8 @@ def main():
     out = dict(metric='element-pairs/sec assembled (2D P1 fractional s=0.5, dense) + % fp64 roofline', value=value,
                unit='element-pairs/s', n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=1e3*elapsed/args.steps,
                higher_is_better=True, scaling='strong', vs_baseline=None, dtype='f64', data='synthetic',
-               config=dict(workload='2D unit disc (uniform_disc refined {}x, {} cells), P1, {} DoFs, fractional s={}, horizon=inf, '
-                           'dense getDense incl. zeroExterior; {} element pairs/step'.format(args.noRef, nc, N, args.s, int(pairs_total)),
+               config=dict(workload='2D unit disc ({}uniform_disc refined {}x, {} cells), P1, {} DoFs, fractional s={}, horizon=inf, '
+                           'dense getDense incl. zeroExterior; {} element pairs/step'.format('' if args.sectors == 6 else '{}-sector '.format(args.sectors), args.noRef, nc, N, args.s, int(pairs_total)),
                            noRef=args.noRef, num_dofs=N, num_cells=nc, parallelism='pairs dealt over {} GPU(s)'.format(world)),
                roofline=roofline,
                phases_ms={k: round(v, 4) for k, v in phase_acc.items()},

@@ -321,10 +321,12 @@ def uniformSquare(N=2, M=None, ax=0, ay=0, bx=1, by=1):
     return mesh2d(np.array(vertices, dtype=REAL), np.array(cells, dtype=INDEX))
 
 
-def uniform_disc(radius=1.):
-    """Hexagon fan; refinement projects new boundary-ring vertices radially (mesh.py:946-960)."""
+def uniform_disc(radius=1., sectors=6):
+    """Hexagon fan; refinement projects new boundary-ring vertices radially (mesh.py:946-960).  sectors != 6 gives a fan of
+    that many triangles (not a reference mesh: used to reach DoF counts between two refinement levels, e.g. 12 sectors
+    refined 7 times = 97 921 interior vertices)."""
     points = [(0., 0.)]
-    n = 6
+    n = int(sectors)
     for i in range(n):
         points.append((radius*np.cos(i*2*np.pi/n), radius*np.sin(i*2*np.pi/n)))
     cells = []
@@ -336,10 +338,10 @@ def uniform_disc(radius=1.):
     return mesh
 
 
-def disc(noRef=0, radius=1.):
+def disc(noRef=0, radius=1., sectors=6):
     """The reference's 'disc' domain for horizon=inf: uniform_disc refined noRef times
     (nl/PyNucleus_nl/nonlocalProblems.py:146-222, fem mesh.py:709-723)."""
-    mesh = uniform_disc(radius)
+    mesh = uniform_disc(radius, sectors)
     for _ in range(noRef):
         mesh = mesh.refine()
     return mesh
