@@ -1601,6 +1601,7 @@ int pnl_assemble_dense(pnl_context *ctx, double *A, int64_t ldA, int zero_exteri
     unsigned long long visited = 0;
     for (long long c = cell_begin; c < cell_end; c++) visited += (unsigned long long)(ctx->nc-c);
     ctx->visited_pairs = visited;
+    if (getenv("PNL_FORCE_SYMFLUSH")) flags |= PNL_FLAG_SYMMETRIC_FLUSH;     // debug: both sides written by the flush, no mirror pass
     return dispatch(ctx, A, ldA, zero_exterior, (int)tiles.size(), cell_begin, cell_end, flags);
 }
 

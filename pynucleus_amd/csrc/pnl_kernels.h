@@ -849,10 +849,16 @@ k_tile_distant(const DevProblem P, const int2 *__restrict__ tiles, double *__res
                 sparse_add(CT.S, dofB[c], dofA[r], v);
             } else {
                 atomic_add_f64(&A[(long long)dofA[r]*ldA+dofB[c]], v);
-                if (ablate & 256) atomic_add_f64(&A[(long long)dofB[c]*ldA+dofA[r]], v);     // PNL_FLAG_SYMMETRIC_FLUSH: no mirror pass
             }
         }
     }
+    // PNL_FLAG_SYMMETRIC_FLUSH (no mirror pass): the transposed image in its own sweep, consecutive threads along a row of A
+    if (!CLUSTER && (ablate & 256))
+        for (int t = tid; t < nA*nB; t += PNL_NTHREADS) {
+            const int c = t/nA, r = t-c*nA;
+            const double v = s_acc[r*acc_stride+c];
+            if (v != 0.) atomic_add_f64(&A[(long long)dofB[c]*ldA+dofA[r]], v);
+        }
     for (int t = tid; t < 2*TILE*ND; t += PNL_NTHREADS) {
         const double v = s_D[t];
         if (v != 0.) {
@@ -1111,11 +1117,15 @@ k_tile_pure(const DevProblem P, const int2 *__restrict__ tiles, int ntiles, doub
         for (int t = tid; t < nA*nB; t += PNL_NTHREADS) {
             const int r = t/nB, cc = t-r*nB;
             const double v = s_acc[r*acc_stride+cc];
-            if (v != 0.) {
-                atomic_add_f64(&A[(long long)dofA[r]*ldA+dofB[cc]], v);
-                if (symflush & 1) atomic_add_f64(&A[(long long)dofB[cc]*ldA+dofA[r]], v);
-            }
+            if (v != 0.) atomic_add_f64(&A[(long long)dofA[r]*ldA+dofB[cc]], v);
         }
+        // PNL_FLAG_SYMMETRIC_FLUSH (no mirror pass): the transposed image in its own sweep, consecutive threads along a row of A
+        if (!(symflush & 64) && (symflush & 1))
+            for (int t = tid; t < nA*nB; t += PNL_NTHREADS) {
+                const int cc = t/nA, r = t-cc*nA;
+                const double v = s_acc[r*acc_stride+cc];
+                if (v != 0.) atomic_add_f64(&A[(long long)dofB[cc]*ldA+dofA[r]], v);
+            }
         for (int t = tid; t < 2*TILE*ND; t += PNL_NTHREADS) {
             const double v = s_Da[t];
             if (v != 0.) {
