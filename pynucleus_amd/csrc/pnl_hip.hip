@@ -1108,6 +1108,30 @@ k_cg_dir(const double *__restrict__ scal, const double *__restrict__ z, int n, d
 }  // namespace
 
 // =================================================================================================
+// Is every cell pair of the tile (block a, block b) a distant pair of order 2?  Conservative bound on the order formula
+// (FL2:622-642 / FL1:234-253): with d >= dmin = |centre_a - centre_b| - rad_a - rad_b (distance of cell centres),
+// h <= hmax and L = |ln(h/H0)| in [Lmin, Lmax] per block,
+//   (c0 + a L_other + b Lmax - e ln(d/h_other)) / (max(ln(d/h_self), 0) + den0)  <=  num_max / den_min,
+// and ceil(.) <= 2 for both roles makes the order max(., 2) = 2 exactly.  dmin > hmax_a + hmax_b also rules out shared
+// vertices (a vertex is closer than 2/3 h to its cell's centre).  Anything not provably uniform goes to the general kernel.
+static bool tile_is_uniform(const pnl_context *ctx, const pnl_order_formula &F, int ta, int tb) {
+    if (ta == tb) return false;
+    const auto &A = ctx->blocks[ta], &B = ctx->blocks[tb];
+    if (!A.full || !B.full || !(F.e >= 0.) || !(F.den0 > 0.)) return false;
+    const double dx = A.cx-B.cx, dy = A.cy-B.cy;
+    const double dmin = std::sqrt(dx*dx+dy*dy)-A.rad-B.rad;
+    if (!(dmin > A.hmax+B.hmax)) return false;
+    auto bound = [&](const pnl_context::BlockAgg &S, const pnl_context::BlockAgg &O) {
+        const double l_self = std::log(dmin/S.hmax), n_other = std::log(dmin/O.hmax);      // both > 0
+        const double aL = std::max(F.a*O.Lmin, F.a*O.Lmax);
+        const double bL = std::max(F.b*std::max(S.Lmin, O.Lmin), F.b*std::max(S.Lmax, O.Lmax));
+        const double num = F.c0+aL+bL-F.e*n_other, den = l_self+F.den0;
+        return num <= 2.*den*(1.-1e-9)-1e-9;
+    };
+    return bound(A, B) && bound(B, A);
+}
+
+
 namespace {
 template <int DIM>
 int pointwise_impl(pnl_context *ctx, double *A, int64_t ldA, int zero_exterior, int cell_begin, int cell_end, int npairs,
@@ -1141,10 +1165,60 @@ int pointwise_impl(pnl_context *ctx, double *A, int64_t ldA, int zero_exterior, 
         if ((rc = ensure(ctx, ctx->b_wlaux, sizeof(unsigned)*(4*(PNL_WL_BINS+1))))) return rc;
         HIPCHK(ctx, hipMemsetAsync(ctx->b_wlcount.p, 0, sizeof(unsigned), ctx->stream));
     }
-    hipLaunchKernelGGL((k_pw_classify<DIM>), dim3((unsigned)((long long)nbk*(nbk+1)/2)), dim3(PNL_NTHREADS), 0, ctx->stream, P, W,
-                       (int4*)ctx->b_wl.p, (unsigned*)ctx->b_wlcount.p, ctx->wl_cap, cell_begin, cell_end);
-    HIPCHK(ctx, hipGetLastError());
+    // block tiles of the upper triangle: uniform ones (every pair provably of order 2 for every pair order in the range of
+    // the two blocks) go to k_pw_tile, the others through classification and the sorted work list
+    std::vector<int2> mixed, uniform;
+    {
+        const int T = 64;
+        std::vector<double> smin(nbk, 1e300), smax(nbk, -1e300);
+        for (int c = 0; c < ctx->nc; c++) {
+            const int b = c/T;
+            smin[b] = std::min(smin[b], ctx->pw_cell_smax[c]); smax[b] = std::max(smax[b], ctx->pw_cell_smax[c]);
+        }
+        auto formula = [&](double sv) {
+            pnl_order_formula F;
+            std::memset(&F, 0, sizeof(F));
+            F.c0 = W.c0;
+            if (DIM == 2) { F.a = sv-1.; F.b = 1.; F.e = sv; F.den0 = 0.4; } else { F.a = 2.*sv-1.; F.b = 0.; F.e = 2.*sv; F.den0 = 0.8; }
+            return F;
+        };
+        const bool allow = ctx->tile == T && ctx->qmax >= 2 && !getenv("PNL_PW_NOTILE");
+        const int a0 = cell_begin/T, a1 = (cell_end+T-1)/T;
+        for (int d = 0; d < nbk; d++)
+            for (int a = a0; a < a1 && a+d < nbk; a++) {
+                const int b = a+d;
+                // the pair order max(m_c1, m_c2) lies between the larger of the block minima and the larger of the maxima; the
+                // formula is linear in it, so the two end points bound it
+                const double lo = std::max(smin[a], smin[b]), hi = std::max(smax[a], smax[b]);
+                bool u = allow && a*T >= cell_begin && (a+1)*T <= cell_end && tile_is_uniform(ctx, formula(lo), a, b) &&
+                         tile_is_uniform(ctx, formula(hi), a, b);
+                (u ? uniform : mixed).push_back(make_int2(a, b));
+            }
+        std::vector<int2> all(mixed);
+        all.insert(all.end(), uniform.begin(), uniform.end());
+        if ((rc = upload(ctx, ctx->b_tiles, all.data(), all.size()))) return rc;
+        ctx->tiles_cached.clear(); ctx->tiles_cb = -1;            // b_tiles no longer holds the dense tile list
+    }
+    if (!uniform.empty()) {
+        const int acc_stride = ctx->nU+1;
+        constexpr int NP = DIM == 2 ? 3 : 2;
+        const size_t lds = sizeof(double)*(64*NP*DIM+2*64*NP+64+2*64*ND)+sizeof(int)*(64*DPE+64)
+                           +2*sizeof(double)*(size_t)(ctx->nU+1)*acc_stride;
+        auto tfun = k_pw_tile<DIM>;
+        HIPCHK(ctx, hipFuncSetAttribute((const void*)tfun, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        int per_cu = 1;
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)tfun, PNL_NTHREADS, lds);
+        const int grid = std::min((int)uniform.size(), 256*std::max(per_cu, 1));
+        hipLaunchKernelGGL(tfun, dim3(grid), dim3(PNL_NTHREADS), lds, ctx->stream, P, W, (const int2*)ctx->b_tiles.p+mixed.size(),
+                           (int)uniform.size(), A, (long long)ldA, (double*)ctx->b_D.p, acc_stride);
+        HIPCHK(ctx, hipGetLastError());
+        ctx->pure_launched = true;
+    }
     HIPCHK(ctx, hipEventRecord(ctx->ev[7], ctx->stream));
+    if (!mixed.empty())
+        hipLaunchKernelGGL((k_pw_classify<DIM>), dim3((unsigned)mixed.size()), dim3(PNL_NTHREADS), 0, ctx->stream, P, W,
+                           (const int2*)ctx->b_tiles.p, (int4*)ctx->b_wl.p, (unsigned*)ctx->b_wlcount.p, ctx->wl_cap, cell_begin, cell_end);
+    HIPCHK(ctx, hipGetLastError());
     HIPCHK(ctx, hipEventRecord(ctx->ev[6], ctx->stream));
     {
         unsigned *hist = (unsigned*)ctx->b_wlaux.p, *offs = hist+(PNL_WL_BINS+1), *coff = offs+(PNL_WL_BINS+1), *cursor = coff+(PNL_WL_BINS+1);
@@ -1496,29 +1570,6 @@ int pnl_tile_cells(pnl_context *ctx) {
     if (!ctx) return PNL_ERR_INVALID;
     int rc = finalize(ctx);
     return rc ? rc : ctx->tile;
-}
-
-// Is every cell pair of the tile (block a, block b) a distant pair of order 2?  Conservative bound on the order formula
-// (FL2:622-642 / FL1:234-253): with d >= dmin = |centre_a - centre_b| - rad_a - rad_b (distance of cell centres),
-// h <= hmax and L = |ln(h/H0)| in [Lmin, Lmax] per block,
-//   (c0 + a L_other + b Lmax - e ln(d/h_other)) / (max(ln(d/h_self), 0) + den0)  <=  num_max / den_min,
-// and ceil(.) <= 2 for both roles makes the order max(., 2) = 2 exactly.  dmin > hmax_a + hmax_b also rules out shared
-// vertices (a vertex is closer than 2/3 h to its cell's centre).  Anything not provably uniform goes to the general kernel.
-static bool tile_is_uniform(const pnl_context *ctx, const pnl_order_formula &F, int ta, int tb) {
-    if (ta == tb) return false;
-    const auto &A = ctx->blocks[ta], &B = ctx->blocks[tb];
-    if (!A.full || !B.full || !(F.e >= 0.) || !(F.den0 > 0.)) return false;
-    const double dx = A.cx-B.cx, dy = A.cy-B.cy;
-    const double dmin = std::sqrt(dx*dx+dy*dy)-A.rad-B.rad;
-    if (!(dmin > A.hmax+B.hmax)) return false;
-    auto bound = [&](const pnl_context::BlockAgg &S, const pnl_context::BlockAgg &O) {
-        const double l_self = std::log(dmin/S.hmax), n_other = std::log(dmin/O.hmax);      // both > 0
-        const double aL = std::max(F.a*O.Lmin, F.a*O.Lmax);
-        const double bL = std::max(F.b*std::max(S.Lmin, O.Lmin), F.b*std::max(S.Lmax, O.Lmax));
-        const double num = F.c0+aL+bL-F.e*n_other, den = l_self+F.den0;
-        return num <= 2.*den*(1.-1e-9)-1e-9;
-    };
-    return bound(A, B) && bound(B, A);
 }
 
 static int upload_tiles(pnl_context *ctx, std::vector<int2> &tiles, int cell_begin, int cell_end) {

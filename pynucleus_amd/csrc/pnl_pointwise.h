@@ -79,17 +79,13 @@ __device__ __forceinline__ DevFormula pw_formula_boundary(const PwDev &W, int di
 }
 
 // ---- distant pairs: classification of all cell pairs c1 < c2 without a common vertex into the work list --------------
-// workgroup per 64x64 block of the upper triangle; entry = (c1, c2, rule offset, n | order << 16)
+// workgroup per 64x64 block of the tile list (the tiles that are not uniform); entry = (c1, c2, rule offset, n | order << 16)
 template <int DIM>
 __global__ void __launch_bounds__(PNL_NTHREADS)
-k_pw_classify(const DevProblem P, const PwDev W, int4 *__restrict__ wl, unsigned *__restrict__ wl_count, unsigned wl_cap,
-              int cell_begin, int cell_end) {
+k_pw_classify(const DevProblem P, const PwDev W, const int2 *__restrict__ tiles, int4 *__restrict__ wl,
+              unsigned *__restrict__ wl_count, unsigned wl_cap, int cell_begin, int cell_end) {
     constexpr int NV = DIM+1, DPE = NV, T = 64;
-    // linear block index -> (ta <= tb)
-    const int nbk = (P.nc+T-1)/T;
-    int ta = 0, rem = blockIdx.x;
-    while (rem >= nbk-ta) { rem -= nbk-ta; ta++; }
-    const int tb = ta+rem;
+    const int ta = tiles[blockIdx.x].x, tb = tiles[blockIdx.x].y;
     const int i = threadIdx.x & 63, jw = threadIdx.x >> 6;
     const int c1 = ta*T+i;
     int vid1[NV];
@@ -331,6 +327,225 @@ k_pw_distant(const DevProblem P, const PwDev W, const int4 *__restrict__ sorted,
                 else if (e < NACC) atomic_add_f64(&Dglob[(size_t)c2*ND+(e-2*NG-ND)], vv*val);
             }
         }
+    }
+}
+
+// ---- uniform tiles: every one of the 64 x 64 pairs is a distant pair of order 2 (host-side bound on the order formula over the
+// two blocks and the range of the pair order, see pw_tile_is_uniform).  Same decomposition as k_tile_pure: lane = cell i of
+// block a, the waves split the cells j of block b, both cross blocks accumulate in LDS sub-blocks (XY as A'[dofs a, dofs b], YX
+// transposed into the same shape) and are flushed row-wise, so a pair costs LDS atomics instead of 30 global ones.  Order and
+// scaled weight of the quadrature points are computed once per tile and cell, not per pair.
+template <int DIM>
+__global__ void __launch_bounds__(PNL_NTHREADS, 2)
+k_pw_tile(const DevProblem P, const PwDev W, const int2 *__restrict__ tiles, int ntiles, double *__restrict__ A, long long ldA,
+          double *__restrict__ Dglob, int acc_stride) {
+    constexpr int TILE = 64, NV = DIM+1, DPE = NV, NC = NV*DIM, ND = DPE*(DPE+1)/2, NP = (DIM == 2) ? 3 : 2;
+    constexpr int JW = TILE/(PNL_NTHREADS/64);
+    extern __shared__ double smem[];
+    double *s_y = smem;                                 // [TILE][NP*DIM]
+    double *s_ey = s_y+TILE*NP*DIM;                     // [TILE][NP] exponent at the points of the b-cells
+    double *s_cy = s_ey+TILE*NP;                        // [TILE][NP] weight * scaling
+    double *s_volb = s_cy+TILE*NP;                      // [TILE]
+    double *s_Da = s_volb+TILE;                         // [TILE][ND]
+    double *s_Db = s_Da+TILE*ND;                        // [TILE][ND]
+    int *s_slotb = (int*)(s_Db+TILE*ND);                // [TILE][DPE]
+    int *s_hb = s_slotb+TILE*DPE;                       // [TILE]
+    double *s_acc1 = (double*)(s_hb+TILE);              // [nA+1][acc_stride]  XY
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    double wq[NP], ph[NP][DPE], bary[NP][NV];
+    {
+        const int off = P.off[2];
+        const double *__restrict__ gb = P.bary+3*(size_t)off, *__restrict__ gw = P.w+off, *__restrict__ gp = P.phi+(size_t)off*DPE;
+#pragma unroll
+        for (int i = 0; i < NP; i++) {
+            wq[i] = gw[i];
+#pragma unroll
+            for (int a = 0; a < DPE; a++) ph[i][a] = gp[i*DPE+a];
+#pragma unroll
+            for (int k = 0; k < NV; k++) bary[i][k] = gb[3*i+k];
+        }
+    }
+    unsigned long long npairs = 0;
+#pragma unroll 1
+    for (int tile_idx = blockIdx.x; tile_idx < ntiles; tile_idx += gridDim.x) {
+        const int2 tl = tiles[tile_idx];
+        const int ta = tl.x, tb = tl.y;
+        const int nA = P.blk_ndof[ta], nB = P.blk_ndof[tb];
+        double *s_acc2 = s_acc1+(size_t)(nA+1)*acc_stride;   // YX transposed: [slot in a][slot in b]
+        __syncthreads();
+        if (tid < TILE) {
+            const int c = tb*TILE+tid;
+            double bv[NC];
+#pragma unroll
+            for (int k = 0; k < NC; k++) bv[k] = P.cellv[(size_t)k*P.ncp+c];
+#pragma unroll
+            for (int jp = 0; jp < NP; jp++) {
+                double y[DIM];
+#pragma unroll
+                for (int d = 0; d < DIM; d++) {
+                    double sy = 0.;
+#pragma unroll
+                    for (int k = 0; k < NV; k++) sy = __builtin_fma(bary[jp][k], bv[k*DIM+d], sy);
+                    y[d] = sy;
+                    s_y[tid*NP*DIM+jp*DIM+d] = sy;
+                }
+                const double sv = pw_order<DIM>(W, y);
+                s_ey[tid*NP+jp] = -0.5*DIM-sv;
+                s_cy[tid*NP+jp] = wq[jp]*pw_scaling<DIM>(W, sv, false);
+            }
+            s_volb[tid] = P.cvol[c];
+            int any = 0;
+#pragma unroll
+            for (int k = 0; k < DPE; k++) {
+                const int sl = P.cslot[(size_t)k*P.ncp+c];
+                s_slotb[tid*DPE+k] = sl >= 0 ? sl : nB;
+                any |= (sl >= 0);
+            }
+            s_hb[tid] = any;
+        }
+        for (int t = tid; t < 2*(nA+1)*acc_stride; t += PNL_NTHREADS) s_acc1[t] = 0.;
+        for (int t = tid; t < 2*TILE*ND; t += PNL_NTHREADS) s_Da[t] = 0.;
+        const int ca = ta*TILE+lane;
+        double x[NP][DIM], ex[NP], cx[NP];
+        {
+            double av[NC];
+#pragma unroll
+            for (int k = 0; k < NC; k++) av[k] = P.cellv[(size_t)k*P.ncp+ca];
+#pragma unroll
+            for (int ip = 0; ip < NP; ip++) {
+#pragma unroll
+                for (int d = 0; d < DIM; d++) {
+                    double sx = 0.;
+#pragma unroll
+                    for (int k = 0; k < NV; k++) sx = __builtin_fma(bary[ip][k], av[k*DIM+d], sx);
+                    x[ip][d] = sx;
+                }
+                const double sv = pw_order<DIM>(W, x[ip]);
+                ex[ip] = -0.5*DIM-sv;
+                cx[ip] = wq[ip]*pw_scaling<DIM>(W, sv, false);
+            }
+        }
+        int sa[DPE];
+        bool ha = false;
+#pragma unroll
+        for (int k = 0; k < DPE; k++) {
+            const int sl = P.cslot[(size_t)k*P.ncp+ca];
+            sa[k] = (sl >= 0 ? sl : nA)*acc_stride;
+            ha = ha || sl >= 0;
+        }
+        const double vola = P.cvol[ca];
+        double rr[NP];
+#pragma unroll
+        for (int ip = 0; ip < NP; ip++) rr[ip] = 0.;
+        __syncthreads();
+#pragma unroll 1
+        for (int jj = 0; jj < JW; jj++) {
+            const int j = wave*JW+jj;
+            const bool valid = ha || (s_hb[j] != 0);
+            npairs += (unsigned long long)__popcll(__ballot(valid));
+            const double volb = valid ? s_volb[j] : 0.;
+            double c2[NP], G1[DPE][DPE], G2[DPE][DPE];
+#pragma unroll
+            for (int jp = 0; jp < NP; jp++) c2[jp] = 0.;
+#pragma unroll
+            for (int a = 0; a < DPE; a++)
+#pragma unroll
+                for (int b = 0; b < DPE; b++) { G1[a][b] = 0.; G2[a][b] = 0.; }
+#pragma unroll
+            for (int ip = 0; ip < NP; ip++) {
+                double r1 = 0., u1[DPE], u2[DPE];
+#pragma unroll
+                for (int b = 0; b < DPE; b++) { u1[b] = 0.; u2[b] = 0.; }
+#pragma unroll
+                for (int jp = 0; jp < NP; jp++) {
+                    double d2 = 0.;
+#pragma unroll
+                    for (int d = 0; d < DIM; d++) { const double t = x[ip][d]-s_y[j*NP*DIM+jp*DIM+d]; d2 = __builtin_fma(t, t, d2); }
+                    const double L = pnl_log(d2);
+                    const double K1 = (cx[ip]*wq[jp])*pnl_exp(ex[ip]*L), K2 = (wq[ip]*s_cy[j*NP+jp])*pnl_exp(s_ey[j*NP+jp]*L);
+                    r1 += K1;
+                    c2[jp] += K2;
+#pragma unroll
+                    for (int b = 0; b < DPE; b++) { u1[b] = __builtin_fma(K1, ph[jp][b], u1[b]); u2[b] = __builtin_fma(K2, ph[jp][b], u2[b]); }
+                }
+                rr[ip] = __builtin_fma(volb, r1, rr[ip]);
+#pragma unroll
+                for (int a = 0; a < DPE; a++)
+#pragma unroll
+                    for (int b = 0; b < DPE; b++) {
+                        G1[a][b] = __builtin_fma(ph[ip][a], u1[b], G1[a][b]);      // XY[a][b]
+                        G2[a][b] = __builtin_fma(u2[a], ph[ip][b], G2[a][b]);      // YX[a][b]: row dof_j[a], column dof_i[b]
+                    }
+            }
+            const double vv = 2.*vola*volb;                                       // both orientations
+#pragma unroll
+            for (int b = 0; b < DPE; b++) {
+                const int sb = s_slotb[j*DPE+b];
+#pragma unroll
+                for (int a = 0; a < DPE; a++) {
+                    lds_add_f64(&s_acc1[sa[a]+sb], -vv*G1[a][b]);
+                    lds_add_f64(&s_acc2[sa[a]+sb], -vv*G2[b][a]);                 // transposed: [slot of i's DoF][slot of j's DoF]
+                }
+            }
+            const double wa = valid ? vola : 0.;
+            double cw[NP];
+#pragma unroll
+            for (int jp = 0; jp < NP; jp++) cw[jp] = wave_sum(wa*c2[jp]);
+            if (lane < ND) {
+                int a = 0, idx = lane;
+                while (idx >= DPE-a) { idx -= DPE-a; a++; }
+                const int b = a+idx;
+                double s2 = 0.;
+#pragma unroll
+                for (int jp = 0; jp < NP; jp++) {
+                    double pa = 0., pb = 0.;
+#pragma unroll
+                    for (int k = 0; k < DPE; k++) { pa = (a == k) ? ph[jp][k] : pa; pb = (b == k) ? ph[jp][k] : pb; }
+                    s2 = __builtin_fma(pa*pb, cw[jp], s2);
+                }
+                s_Db[j*ND+lane] = 2.*s_volb[j]*s2;
+            }
+        }
+        {
+            int e = 0;
+#pragma unroll
+            for (int a = 0; a < DPE; a++)
+#pragma unroll
+                for (int b = a; b < DPE; b++) {
+                    double s1 = 0.;
+#pragma unroll
+                    for (int ip = 0; ip < NP; ip++) s1 = __builtin_fma(ph[ip][a]*ph[ip][b], rr[ip], s1);
+                    lds_add_f64(&s_Da[lane*ND+e], 2.*vola*s1);
+                    e++;
+                }
+        }
+        __syncthreads();
+        const int *__restrict__ dofA = P.blk_dofs+(size_t)ta*P.blk_stride;
+        const int *__restrict__ dofB = P.blk_dofs+(size_t)tb*P.blk_stride;
+        for (int t = tid; t < nA*nB; t += PNL_NTHREADS) {
+            const int r = t/nB, cc = t-r*nB;
+            const double v = s_acc1[r*acc_stride+cc];
+            if (v != 0.) atomic_add_f64(&A[(long long)dofA[r]*ldA+dofB[cc]], v);
+        }
+        for (int t = tid; t < nA*nB; t += PNL_NTHREADS) {
+            const int cc = t/nA, r = t-cc*nA;
+            const double v = s_acc2[r*acc_stride+cc];
+            if (v != 0.) atomic_add_f64(&A[(long long)dofB[cc]*ldA+dofA[r]], v);
+        }
+        for (int t = tid; t < 2*TILE*ND; t += PNL_NTHREADS) {
+            const double v = s_Da[t];
+            if (v != 0.) {
+                const int side = t/(TILE*ND), rem = t-side*TILE*ND;
+                const int cc = (side ? tb : ta)*TILE+rem/ND;
+                atomic_add_f64(&Dglob[(size_t)cc*ND+rem%ND], v);
+            }
+        }
+    }
+    if (lane == 0 && npairs) {
+        atomicAdd(&P.counters[8+2], npairs);
+        atomicAdd(&P.counters[1], npairs);
+        atomicAdd(&P.counters[2], npairs*(unsigned long long)(2*NP*NP));
+        atomicAdd(&P.counters[6], npairs);
     }
 }
 

@@ -168,7 +168,7 @@ def test_two_ranks_share_the_pairs():
 
 
 @pytest.mark.parametrize('case', ['smoothedLeftRight_disc', 'constantNonSym_disc', 'innerOuter_disc', 'smoothedLeftRight_interval',
-                                  'linearLeftRight_interval', 'constantNonSym_noext'])
+                                  'linearLeftRight_interval', 'constantNonSym_noext', 'smoothedLeftRight_disc4'])
 def test_pointwise_nonsymmetric_dense(case):
     """a16: non-symmetric kernels with an order s(x) per quadrature point (fractionalLaplacian{1,2}D_nonsym, both orientations of
     every pair, (2 dpe)^2 local matrices, near rules keyed by the pair's order): GPU == oracle entry-wise, same counters"""
@@ -180,6 +180,8 @@ def test_pointwise_nonsymmetric_dense(case):
     zeroExterior = True
     if case == 'smoothedLeftRight_disc':
         mesh, s = disc(3), smoothedLeftRightFractionalOrder(0.25, 0.75, r=0.3)
+    elif case == 'smoothedLeftRight_disc4':              # 24 blocks of 64 cells: some tiles are uniform (k_pw_tile)
+        mesh, s = disc(4), smoothedLeftRightFractionalOrder(0.25, 0.75, r=0.3)
     elif case == 'constantNonSym_disc':
         mesh, s = disc(2), constantNonSymFractionalOrder(0.4)
     elif case == 'innerOuter_disc':
@@ -203,6 +205,8 @@ def test_pointwise_nonsymmetric_dense(case):
     assert np.abs(Ag-Aref).max() < TOL*scale, np.abs(Ag-Aref).max()/scale
     if case.startswith('smoothed'):
         assert np.abs(Aref-Aref.T).max() > 1e-6*scale          # genuinely non-symmetric
+    if case == 'smoothedLeftRight_disc4':
+        assert got['uniformTilePairs'] > 0
 
 
 def test_pointwise_stored_errors_disc():
