@@ -1215,7 +1215,22 @@ int pointwise_impl(pnl_context *ctx, double *A, int64_t ldA, int zero_exterior, 
         ctx->pure_launched = true;
     }
     HIPCHK(ctx, hipEventRecord(ctx->ev[7], ctx->stream));
-    if (!mixed.empty())
+    // the other tiles: classification, in-tile evaluation of the rules with at most 16 points (LDS sub-blocks), work list for the rest
+    const bool in_tile = ctx->tile == 64 && !getenv("PNL_PW_NOMIXED");
+    if (!mixed.empty() && in_tile) {
+        const int acc_stride = ctx->nU+1;
+        const size_t lds = sizeof(double)*(PNL_PW_LANE_MAXPTS*ST+64*PNL_PW_LANE_MAXPTS*2+2*64*ND)+sizeof(unsigned short)*64*64
+                           +sizeof(int)*(3*PNL_PW_NBUCK+2*64*DPE)+2*sizeof(double)*(size_t)(ctx->nU+1)*acc_stride;
+        if (lds > 160*1024) return fail(ctx, PNL_ERR_UNSUPPORTED, "a block of 64 cells touches %d DoFs: LDS sub-blocks of %zu bytes exceed 160 KiB", ctx->nU, lds);
+        auto mfun = k_pw_mixed<DIM>;
+        HIPCHK(ctx, hipFuncSetAttribute((const void*)mfun, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        int per_cu = 1;
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)mfun, PNL_NTHREADS, lds);
+        const int grid = std::min((int)mixed.size(), 256*std::max(per_cu, 1));
+        hipLaunchKernelGGL(mfun, dim3(grid), dim3(PNL_NTHREADS), lds, ctx->stream, P, W, (const int2*)ctx->b_tiles.p, (int)mixed.size(), A,
+                           (long long)ldA, (double*)ctx->b_D.p, acc_stride, (int4*)ctx->b_wl.p, (unsigned*)ctx->b_wlcount.p, ctx->wl_cap,
+                           cell_begin, cell_end);
+    } else if (!mixed.empty())
         hipLaunchKernelGGL((k_pw_classify<DIM>), dim3((unsigned)mixed.size()), dim3(PNL_NTHREADS), 0, ctx->stream, P, W,
                            (const int2*)ctx->b_tiles.p, (int4*)ctx->b_wl.p, (unsigned*)ctx->b_wlcount.p, ctx->wl_cap, cell_begin, cell_end);
     HIPCHK(ctx, hipGetLastError());
@@ -1235,7 +1250,7 @@ int pointwise_impl(pnl_context *ctx, double *A, int64_t ldA, int zero_exterior, 
         const size_t lds = sizeof(double)*((size_t)tab_max*ST+(size_t)(PNL_NTHREADS/16)*tab_max*2);
         auto kfun = k_pw_distant<DIM>;
         HIPCHK(ctx, hipFuncSetAttribute((const void*)kfun, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        const bool lane_kernel = !getenv("PNL_PW_NOLANE");
+        const bool lane_kernel = !getenv("PNL_PW_NOLANE");      // (with the in-tile evaluation only the rules of more than 16 points arrive here)
         if (lane_kernel)
             hipLaunchKernelGGL((k_pw_lane<DIM>), dim3(256*2), dim3(PNL_NTHREADS), 0, ctx->stream, P, W, (const int4*)ctx->b_wlsorted.p,
                                (const unsigned*)offs, A, (long long)ldA, (double*)ctx->b_D.p);

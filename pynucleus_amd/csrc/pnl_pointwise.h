@@ -549,11 +549,271 @@ k_pw_tile(const DevProblem P, const PwDev W, const int2 *__restrict__ tiles, int
     }
 }
 
+// ---- the other tiles: classification, counting sort by order and evaluation inside the tile ------------------------------
+// workgroup per 64 x 64 tile: every thread classifies 16 pairs (shared vertices -> skipped here, touching pairs come from the host
+// list; order from the pair-order formula); pairs whose rule has at most PNL_PW_LANE_MAXPTS points are bucketed by order in LDS
+// and integrated ONE PAIR PER LANE, a wave taking 64 pairs of one order at a time, with both cross blocks and the diagonal
+// blocks accumulated in LDS (ds_add_f64) and flushed once per tile; the few pairs of higher order go to the global work list
+// (k_pw_distant).  Exponent and scaled weight at the rule's points of the 64 cells of block b are tabulated in LDS per order.
+#define PNL_PW_LANE_MAXPTS 16
+#define PNL_PW_NBUCK 16
+template <int DIM>
+__global__ void __launch_bounds__(PNL_NTHREADS, 1)
+k_pw_mixed(const DevProblem P, const PwDev W, const int2 *__restrict__ tiles, int ntiles, double *__restrict__ A, long long ldA,
+           double *__restrict__ Dglob, int acc_stride, int4 *__restrict__ wl, unsigned *__restrict__ wl_count, unsigned wl_cap,
+           int cell_begin, int cell_end) {
+    constexpr int T = 64, NV = DIM+1, DPE = NV, NC = NV*DIM, ND = DPE*(DPE+1)/2, ST = 4+DPE, MAXN = PNL_PW_LANE_MAXPTS;
+    extern __shared__ double smem[];
+    double *s_rule = smem;                               // [MAXN][ST]
+    double *s_tab = s_rule+MAXN*ST;                      // [T][MAXN][2]: exponent, weight * scaling at the points of the b-cells
+    double *s_Da = s_tab+T*MAXN*2;                       // [T][ND]
+    double *s_Db = s_Da+T*ND;                            // [T][ND]
+    unsigned short *s_list = (unsigned short*)(s_Db+T*ND);   // [T*T] pair codes i | j << 8, grouped by bucket
+    int *s_cnt = (int*)(s_list+T*T);                     // [PNL_PW_NBUCK] counts, then [PNL_PW_NBUCK] offsets, [PNL_PW_NBUCK] cursors
+    int *s_slota = s_cnt+3*PNL_PW_NBUCK;                 // [T][DPE]
+    int *s_slotb = s_slota+T*DPE;                        // [T][DPE]
+    double *s_acc1 = (double*)(s_slotb+T*DPE);           // [nA+1][acc_stride] XY, then the same for YX transposed
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    unsigned long long nass = 0, nev = 0;
+#pragma unroll 1
+    for (int tile_idx = blockIdx.x; tile_idx < ntiles; tile_idx += gridDim.x) {
+        const int ta = tiles[tile_idx].x, tb = tiles[tile_idx].y;
+        const int nA = P.blk_ndof[ta], nB = P.blk_ndof[tb];
+        double *s_acc2 = s_acc1+(size_t)(nA+1)*acc_stride;
+        __syncthreads();
+        if (tid < 3*PNL_PW_NBUCK) s_cnt[tid] = 0;
+        for (int t = tid; t < 2*(nA+1)*acc_stride; t += PNL_NTHREADS) s_acc1[t] = 0.;
+        for (int t = tid; t < 2*T*ND; t += PNL_NTHREADS) s_Da[t] = 0.;
+        for (int t = tid; t < T*DPE; t += PNL_NTHREADS) {
+            const int c = t/DPE, k = t-c*DPE;
+            const int sla = (ta*T+c < P.nc) ? P.cslot[(size_t)k*P.ncp+ta*T+c] : -1, slb = (tb*T+c < P.nc) ? P.cslot[(size_t)k*P.ncp+tb*T+c] : -1;
+            s_slota[t] = sla >= 0 ? sla : nA;
+            s_slotb[t] = slb >= 0 ? slb : nB;
+        }
+        __syncthreads();
+        // ---- classification: thread -> cell i = tid & 63 of block a, 16 cells j of block b ----
+        const int ci = tid & 63, c1 = ta*T+ci;
+        const bool ok1 = c1 < P.nc && c1 >= cell_begin && c1 < cell_end;
+        const int cc1 = c1 < P.nc ? c1 : 0;
+        int vid1[NV];
+        double cen1[DIM];
+        bool any1 = false;
+#pragma unroll
+        for (int k = 0; k < NV; k++) vid1[k] = P.cvid[(size_t)k*P.ncp+cc1];
+#pragma unroll
+        for (int d = 0; d < DIM; d++) cen1[d] = P.ccen[(size_t)d*P.ncp+cc1];
+#pragma unroll
+        for (int k = 0; k < DPE; k++) any1 = any1 || P.cdof[(size_t)k*P.ncp+cc1] >= 0;
+        const double h1 = P.ch[cc1], sm1 = W.cell_smax[cc1];
+        int myq[16];
+#pragma unroll 1
+        for (int jj = 0; jj < 16; jj++) {
+            const int cj = (tid >> 6)*16+jj, c2 = tb*T+cj;
+            int q = 0;                                   // 0: nothing to do here
+            bool push = false;
+            int off = 0, n = 0;
+            if (ok1 && c2 < P.nc && c2 > c1) {
+                bool any = any1;
+#pragma unroll
+                for (int k = 0; k < DPE; k++) any = any || P.cdof[(size_t)k*P.ncp+c2] >= 0;
+                bool shared = false;
+#pragma unroll
+                for (int a = 0; a < NV; a++)
+#pragma unroll
+                    for (int b = 0; b < NV; b++) shared = shared || (vid1[a] == P.cvid[(size_t)b*P.ncp+c2]);
+                if (any && !shared) {
+                    double d2 = 0.;
+#pragma unroll
+                    for (int d = 0; d < DIM; d++) { const double u = cen1[d]-P.ccen[(size_t)d*P.ncp+c2]; d2 += u*u; }
+                    const DevFormula F = pw_formula(W, DIM, fmax(sm1, W.cell_smax[c2]));
+                    const int qq = quad_order(F, P.H0, h1, P.ch[c2], sqrt(d2));
+                    if (qq > P.qmax || qq > PNL_MAXQ) atomicAdd(&P.counters[5], 1ull);
+                    else {
+                        off = P.off[qq]; n = P.off[qq+1]-off;
+                        if (n <= MAXN && qq < PNL_PW_NBUCK) { q = qq; atomicAdd(&s_cnt[qq], 1); }
+                        else { push = true; q = -qq; }
+                    }
+                }
+            }
+            myq[jj] = q > 0 ? q : 0;
+            const unsigned long long m = __ballot(push);
+            if (m) {
+                unsigned base = 0;
+                const int leader = __builtin_ctzll(m);
+                if (lane == leader) base = atomicAdd(wl_count, (unsigned)__popcll(m));
+                base = __shfl(base, leader);
+                if (push) {
+                    const unsigned pos = base+__popcll(m & ((1ull << lane)-1ull));
+                    if (pos < wl_cap) wl[pos] = make_int4(c1, c2, off, n | ((-q) << 16));
+                }
+            }
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int run = 0;
+            for (int q = 0; q < PNL_PW_NBUCK; q++) { s_cnt[PNL_PW_NBUCK+q] = run; run += s_cnt[q]; }
+        }
+        __syncthreads();
+#pragma unroll 1
+        for (int jj = 0; jj < 16; jj++)
+            if (myq[jj] > 0) {
+                const int pos = s_cnt[PNL_PW_NBUCK+myq[jj]]+atomicAdd(&s_cnt[2*PNL_PW_NBUCK+myq[jj]], 1);
+                s_list[pos] = (unsigned short)(ci | (((tid >> 6)*16+jj) << 8));
+            }
+        __syncthreads();
+        // ---- evaluation, order by order ----
+#pragma unroll 1
+        for (int q = 2; q < PNL_PW_NBUCK; q++) {
+            const int cntq = s_cnt[q];
+            if (cntq == 0) continue;                     // uniform over the workgroup
+            const int off = P.off[q], n = P.off[q+1]-off, first = s_cnt[PNL_PW_NBUCK+q];
+            __syncthreads();
+            for (int t = tid; t < n*ST; t += PNL_NTHREADS) {
+                const int pt = t/ST, k = t-pt*ST;
+                s_rule[t] = k < 3 ? P.bary[3*(size_t)(off+pt)+k] : (k == 3 ? P.w[off+pt] : P.phi[(size_t)(off+pt)*DPE+k-4]);
+            }
+            __syncthreads();
+            for (int t = tid; t < T*n; t += PNL_NTHREADS) {
+                const int cj = t/n, j = t-cj*n, c2 = tb*T+cj;
+                if (c2 < P.nc) {
+                    double y[DIM];
+#pragma unroll
+                    for (int d = 0; d < DIM; d++) {
+                        double sy = 0.;
+#pragma unroll
+                        for (int m = 0; m < NV; m++) sy = __builtin_fma(s_rule[j*ST+m], P.cellv[(size_t)(m*DIM+d)*P.ncp+c2], sy);
+                        y[d] = sy;
+                    }
+                    const double sv = pw_order<DIM>(W, y);
+                    s_tab[(cj*MAXN+j)*2] = -0.5*DIM-sv;
+                    s_tab[(cj*MAXN+j)*2+1] = s_rule[j*ST+3]*pw_scaling<DIM>(W, sv, false);
+                }
+            }
+            __syncthreads();
+#pragma unroll 1
+            for (int base = wave*64; base < cntq; base += PNL_NTHREADS) {
+                const bool valid = base+lane < cntq;
+                const unsigned code = s_list[first+(valid ? base+lane : 0)];
+                const int li = code & 255, lj = code >> 8, c1p = ta*T+li, c2p = tb*T+lj;
+                double av[NC], bv[NC];
+#pragma unroll
+                for (int k = 0; k < NC; k++) { av[k] = P.cellv[(size_t)k*P.ncp+c1p]; bv[k] = P.cellv[(size_t)k*P.ncp+c2p]; }
+                const double *tabj = s_tab+(size_t)lj*MAXN*2;
+                double G1[DPE][DPE], G2[DPE][DPE], S1[ND], S2[ND];
+#pragma unroll
+                for (int a = 0; a < DPE; a++)
+#pragma unroll
+                    for (int b = 0; b < DPE; b++) { G1[a][b] = 0.; G2[a][b] = 0.; }
+#pragma unroll
+                for (int e = 0; e < ND; e++) { S1[e] = 0.; S2[e] = 0.; }
+#pragma unroll 1
+                for (int i = 0; i < n; i++) {
+                    double ti[ST];
+#pragma unroll
+                    for (int m = 0; m < ST; m++) ti[m] = s_rule[i*ST+m];
+                    double x[DIM];
+#pragma unroll
+                    for (int d = 0; d < DIM; d++) {
+                        double sx = 0.;
+#pragma unroll
+                        for (int m = 0; m < NV; m++) sx = __builtin_fma(ti[m], av[m*DIM+d], sx);
+                        x[d] = sx;
+                    }
+                    const double sx_ = pw_order<DIM>(W, x);
+                    const double ex = -0.5*DIM-sx_, cx = ti[3]*pw_scaling<DIM>(W, sx_, false);
+                    double r1 = 0., u1[DPE], u2[DPE];
+#pragma unroll
+                    for (int b = 0; b < DPE; b++) { u1[b] = 0.; u2[b] = 0.; }
+#pragma unroll 3
+                    for (int j = 0; j < n; j++) {
+                        double tj[ST];
+#pragma unroll
+                        for (int m = 0; m < ST; m++) tj[m] = s_rule[j*ST+m];
+                        double d2 = 0.;
+#pragma unroll
+                        for (int d = 0; d < DIM; d++) {
+                            double sy = 0.;
+#pragma unroll
+                            for (int m = 0; m < NV; m++) sy = __builtin_fma(tj[m], bv[m*DIM+d], sy);
+                            const double t = x[d]-sy;
+                            d2 = __builtin_fma(t, t, d2);
+                        }
+                        const double L = pnl_log(d2);
+                        const double K1 = (cx*tj[3])*pnl_exp(ex*L), K2 = (ti[3]*tabj[2*j+1])*pnl_exp(tabj[2*j]*L);
+                        r1 += K1;
+                        double t2[DPE];
+#pragma unroll
+                        for (int b = 0; b < DPE; b++) { u1[b] = __builtin_fma(K1, tj[4+b], u1[b]); t2[b] = K2*tj[4+b]; u2[b] += t2[b]; }
+                        int e = 0;
+#pragma unroll
+                        for (int a = 0; a < DPE; a++)
+#pragma unroll
+                            for (int b = a; b < DPE; b++) { S2[e] = __builtin_fma(t2[a], tj[4+b], S2[e]); e++; }
+                    }
+                    int e = 0;
+#pragma unroll
+                    for (int a = 0; a < DPE; a++) {
+                        const double pa = ti[4+a];
+#pragma unroll
+                        for (int b = 0; b < DPE; b++) {
+                            G1[a][b] = __builtin_fma(pa, u1[b], G1[a][b]);
+                            G2[a][b] = __builtin_fma(u2[a], ti[4+b], G2[a][b]);
+                        }
+                        const double pr = pa*r1;
+#pragma unroll
+                        for (int b = a; b < DPE; b++) { S1[e] = __builtin_fma(pr, ti[4+b], S1[e]); e++; }
+                    }
+                }
+                if (valid) {
+                    const double vv = 2.*P.cvol[c1p]*P.cvol[c2p];        // both orientations
+#pragma unroll
+                    for (int a = 0; a < DPE; a++) {
+                        const int ra = s_slota[li*DPE+a]*acc_stride;
+#pragma unroll
+                        for (int b = 0; b < DPE; b++) {
+                            const int cb = s_slotb[lj*DPE+b];
+                            lds_add_f64(&s_acc1[ra+cb], -vv*G1[a][b]);        // XY[a][b]: row dof_i[a], column dof_j[b]
+                            lds_add_f64(&s_acc2[ra+cb], -vv*G2[b][a]);        // YX[b][a]: row dof_j[b], column dof_i[a], stored transposed
+                        }
+                    }
+#pragma unroll
+                    for (int e = 0; e < ND; e++) { lds_add_f64(&s_Da[li*ND+e], vv*S1[e]); lds_add_f64(&s_Db[lj*ND+e], vv*S2[e]); }
+                }
+            }
+            if (wave == 0 && lane == 0) { nass += (unsigned long long)cntq; nev += 2ull*cntq*n*n; atomicAdd(&P.counters[8+q], (unsigned long long)cntq); }
+        }
+        __syncthreads();
+        const int *__restrict__ dofA = P.blk_dofs+(size_t)ta*P.blk_stride;
+        const int *__restrict__ dofB = P.blk_dofs+(size_t)tb*P.blk_stride;
+        for (int t = tid; t < nA*nB; t += PNL_NTHREADS) {
+            const int r = t/nB, cc = t-r*nB;
+            const double v = s_acc1[r*acc_stride+cc];
+            if (v != 0.) atomic_add_f64(&A[(long long)dofA[r]*ldA+dofB[cc]], v);
+        }
+        for (int t = tid; t < nA*nB; t += PNL_NTHREADS) {
+            const int cc = t/nA, r = t-cc*nA;
+            const double v = s_acc2[r*acc_stride+cc];
+            if (v != 0.) atomic_add_f64(&A[(long long)dofB[cc]*ldA+dofA[r]], v);
+        }
+        for (int t = tid; t < 2*T*ND; t += PNL_NTHREADS) {
+            const double v = s_Da[t];
+            if (v != 0.) {
+                const int side = t/(T*ND), rem = t-side*T*ND;
+                const int cc = (side ? tb : ta)*T+rem/ND;
+                atomic_add_f64(&Dglob[(size_t)cc*ND+rem%ND], v);
+            }
+        }
+    }
+    if (tid == 0 && nass) {
+        atomicAdd(&P.counters[1], nass);
+        atomicAdd(&P.counters[2], nev);
+    }
+}
+
 // ---- distant pairs with at most PNL_PW_LANE_MAXPTS points per cell (orders 2-8 on triangles: almost all pairs): ONE PAIR PER
 // LANE.  The list is sorted by order, so the 64 pairs of a wave's chunk run the same trip counts; the rule sits in the wave's
 // LDS copy (broadcast reads), exponent and scaled weight of the second cell's points in a per-lane LDS column (conflict
 // free), the 2 NG + 2 ND accumulators in registers, no cross-lane work.
-#define PNL_PW_LANE_MAXPTS 16
 template <int DIM>
 __global__ void __launch_bounds__(PNL_NTHREADS)
 k_pw_lane(const DevProblem P, const PwDev W, const int4 *__restrict__ sorted, const unsigned *__restrict__ offs,
