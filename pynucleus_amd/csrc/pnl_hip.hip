@@ -1151,10 +1151,13 @@ int pointwise_impl(pnl_context *ctx, double *A, int64_t ldA, int zero_exterior, 
     ctx->tiles_launched = true; ctx->pure_launched = false;
     const int nbk = (ctx->nc+63)/64;
     {
-        // all pairs of the cell range may end up in the list
+        // work list: only the pairs whose rule has more than 16 points arrive there when the tiles evaluate the others
+        // themselves (overflow is detected by pnl_get_counters); the tile-less variant lists every pair of the cell range
         double pairs = 0.;
         for (long long c = cell_begin; c < cell_end; c++) pairs += (double)(ctx->nc-c);
-        const size_t want = (size_t)std::max<double>(pairs, 1024.);
+        const bool tiles_evaluate = ctx->tile == 64 && !getenv("PNL_PW_NOMIXED");
+        const size_t want = tiles_evaluate ? (size_t)std::min<double>(std::max<double>(pairs*0.1, 1 << 20), 400e6)
+                                           : (size_t)std::max<double>(pairs, 1024.);
         if (want > 1500000000ull) return fail(ctx, PNL_ERR_UNSUPPORTED, "%zu pairs exceed the work list of the pointwise path", want);
         if (ctx->wl_cap < want) {
             if ((rc = ensure(ctx, ctx->b_wl, want*sizeof(int4)))) return rc;
