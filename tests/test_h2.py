@@ -95,3 +95,24 @@ def test_varconst_h2_is_constant_order_h2():
     assert np.abs(yv-yc).max() <= 1e-12*np.abs(yc).max()
     assert np.abs(yv-yd).max() <= 3e-2*np.abs(yd).max()
     assert np.abs(bv.getDiagonal().diagonal-bc.getDiagonal().diagonal).max() <= 1e-12*np.abs(bc.getDiagonal().diagonal).max()
+
+
+@pytest.mark.gpu
+def test_cg_on_h2_and_near_field_operators():
+    """the reference's cg_solver loop (solvers.pyx:363-444) on operators that only have a matvec: the H2 solution agrees with
+    the dense one to the H2 approximation error, same iteration count as the library's dense CG"""
+    from pynucleus_amd import disc, P1_DoFMap, PHYSICAL, getFractionalKernel
+    from pynucleus_amd.builder import nonlocalBuilder
+    from pynucleus_amd.solvers import cg
+    mesh = disc(4)
+    dm = P1_DoFMap(mesh, PHYSICAL)
+    b = nonlocalBuilder(dm, getFractionalKernel(2, 0.75), {'target_order': 0.5, 'eta': 3.})
+    rhs = np.asarray(dm.assembleRHS(1.0))
+    A = b.getDense()
+    ud, itd, resd = A.solve_cg_jacobi(rhs, tol=1e-10, maxiter=2000)
+    u2, it2, res2 = cg(A, rhs, tol=1e-10, maxiter=2000)
+    assert abs(it2-itd) <= 1 and np.abs(u2-ud).max() <= 1e-8*np.abs(ud).max()
+    H = b.getH2()
+    uh, ith, resh = cg(H, rhs, tol=1e-10, maxiter=2000)
+    assert resh[-1] <= 1e-10 and ith <= 2*itd          # (the interpolated far field is symmetric only to its own accuracy)
+    assert np.abs(uh-ud).max() <= 1e-3*np.abs(ud).max()
