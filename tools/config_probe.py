@@ -106,6 +106,12 @@ elif what == 'c4':
             1e3*t_h2, 1e3*t_d, float(torch.linalg.norm(y-yd)/torch.linalg.norm(yd))))
     else:
         print('   H2 matvec {:.3f} ms'.format(1e3*t_h2))
+    from pynucleus_amd.solvers import cg
+    rhs = torch.from_numpy(np.asarray(dm.assembleRHS(1.0))).to(x.device)
+    sync(); t0 = time.time()
+    u, its, res = cg(h2, rhs, tol=1e-8, maxiter=2000)
+    sync()
+    print('   CG-Jacobi on the H2 operator: {} iterations, {:.1f} ms, residual {:.2e}'.format(its, 1e3*(time.time()-t0), res[-1]))
 elif what == 'c3':
     N = size or 129
     mesh = uniformSquare(N)
