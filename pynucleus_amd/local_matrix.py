@@ -323,9 +323,12 @@ class nonlocalTables:
                     phi = self.dm.evalShapeFunctions(qr.nodes[:2])
                 acc[0].append(qr.nodes); acc[1].append(qr.weights); acc[2].append(phi)
             brules[slot] = tuple(np.ascontiguousarray(np.stack(a)) for a in acc)
+        # pairs of one rule next to each other: consecutive waves read the same tables
+        po = np.lexsort((kidx, pairs[:, 2]))
+        bo = np.lexsort((bkidx, bpairs[:, 2]))
         self._pw_rules = dict(keys=keys, rules=rules, bkeys=bkeys, brules=brules,
-                              pairs=np.ascontiguousarray(np.column_stack([pairs, kidx]).astype(np.int32)),
-                              bpairs=np.ascontiguousarray(np.column_stack([bpairs, bkidx]).astype(np.int32)))
+                              pairs=np.ascontiguousarray(np.column_stack([pairs, kidx])[po].astype(np.int32)),
+                              bpairs=np.ascontiguousarray(np.column_stack([bpairs, bkidx])[bo].astype(np.int32)))
         return self._pw_rules
 
     def class_of_pair(self, c1, c2):
