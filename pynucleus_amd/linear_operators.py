@@ -159,7 +159,15 @@ class CSR_LinearOperator:
 
     @property
     def diagonal(self):
-        return np.diag(self.toarray()).copy()
+        """stored diagonal entries (zero where the pattern has none), read off the CSR arrays"""
+        N = self.num_rows
+        rows = np.repeat(np.arange(N, dtype=np.int64), np.diff(self.indptr))
+        pos = np.nonzero(self.indices == rows)[0]
+        d = np.zeros(N)
+        if pos.shape[0]:
+            self.ctx.synchronize()
+            d[rows[pos]] = self.data_dev[torch.from_numpy(pos).to(self.device)].cpu().numpy()
+        return d
 
     def matvec(self, x, y=None):
         self._bind()
