@@ -611,6 +611,7 @@ k_tile_distant(const DevProblem P, const int2 *__restrict__ tiles, double *__res
     int overflow = 0;
     const int lane = tid & 63;
     const unsigned long long lt = (1ull << lane)-1ull;
+    int cnt234[3] = {0, 0, 0};
 #pragma unroll 2
     for (int it = 0; it < PER_THREAD; it++) {
         const int p = it*PNL_NTHREADS+tid;
@@ -653,7 +654,10 @@ k_tile_distant(const DevProblem P, const int2 *__restrict__ tiles, double *__res
                 if (q > P.qmax || q > PNL_MAXQ) { overflow++; q = 0; }
             }
         }
-        wave_bucket_add(s_cnt, q, false);                       // statistics only
+        // statistics: the three lowest orders (nearly all pairs) are counted with ballots on the scalar unit and added to the
+        // LDS histogram once per tile; the LDS atomics of the hot loop are left to the rare higher orders
+        cnt234[0] += __popcll(__ballot(q == 2)); cnt234[1] += __popcll(__ballot(q == 3)); cnt234[2] += __popcll(__ballot(q == 4));
+        wave_bucket_add(s_cnt, q > 4 ? q : 0, false);
         const int nq = q ? s_ttn[q] : 0;
         const int cls = !q ? 0 : (nq == NA ? 1 : (nq == NB ? 2 : (nq > 0 ? 3 : 4)));
         const unsigned short ent = (unsigned short)(p | ((q-2) << 12));
@@ -689,6 +693,10 @@ k_tile_distant(const DevProblem P, const int2 *__restrict__ tiles, double *__res
         }
     }
     if (overflow) atomicAdd(&P.counters[5], (unsigned long long)overflow);
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) if (cnt234[k]) atomicAdd(&s_cnt[2+k], cnt234[k]);
+    }
     __syncthreads();
     {
         // far pairs: one reservation in the global work list per tile, then a coalesced copy
