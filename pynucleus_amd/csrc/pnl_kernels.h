@@ -257,6 +257,8 @@ template <int DIM, int DPE, int KT, int N>
 __device__ __forceinline__ void eval_distant_fixed(const DevProblem &P, const double *__restrict__ tab, const double *av,
                                                    const double *bv, PairAcc<DIM, DPE> &R) {
     constexpr int NV = DIM+1, ST = 4+DPE;
+    // the weights are folded into the accumulations instead of being multiplied into every kernel value: with g = gamma(x_i, y_j)
+    //   row sum r_i = sum_j w_j g, column sum c_j = sum_i w_i g, u_b(i) = sum_j g (w_j phi_b(y_j)); w_i enters once per i
     double y[N][DIM], c[N];
 #pragma unroll
     for (int j = 0; j < N; j++) {
@@ -288,16 +290,17 @@ __device__ __forceinline__ void eval_distant_fixed(const DevProblem &P, const do
             double d2 = 0.;
 #pragma unroll
             for (int d = 0; d < DIM; d++) { double t = x[d]-y[j][d]; d2 = __builtin_fma(t, t, d2); }
-            const double K = (wi*tab[j*ST+3])*kern_eval<KT>(P.k, d2);
-            r += K;
-            c[j] += K;
+            const double g = kern_eval<KT>(P.k, d2);
+            const double wj = tab[j*ST+3];
+            r = __builtin_fma(wj, g, r);
+            c[j] = __builtin_fma(wi, g, c[j]);
 #pragma unroll
-            for (int b = 0; b < DPE; b++) u[b] = __builtin_fma(K, tab[j*ST+4+b], u[b]);
+            for (int b = 0; b < DPE; b++) u[b] = __builtin_fma(g, wj*tab[j*ST+4+b], u[b]);     // w_j phi_b(y_j): loop invariant
         }
         int e = 0;
 #pragma unroll
         for (int a = 0; a < DPE; a++) {
-            const double pa = tab[i*ST+4+a];
+            const double pa = wi*tab[i*ST+4+a];
 #pragma unroll
             for (int b = 0; b < DPE; b++) R.G[a][b] = __builtin_fma(pa, u[b], R.G[a][b]);
             const double pr = pa*r;
@@ -310,7 +313,7 @@ __device__ __forceinline__ void eval_distant_fixed(const DevProblem &P, const do
         int e = 0;
 #pragma unroll
         for (int a = 0; a < DPE; a++) {
-            const double pc = tab[j*ST+4+a]*c[j];
+            const double pc = tab[j*ST+4+a]*(tab[j*ST+3]*c[j]);
 #pragma unroll
             for (int b = a; b < DPE; b++) { R.S2[e] = __builtin_fma(pc, tab[j*ST+4+b], R.S2[e]); e++; }
         }
@@ -954,16 +957,15 @@ k_tile_pure(const DevProblem P, const int2 *__restrict__ tiles, int ntiles, doub
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // rule constants: wave-uniform global reads (scalar loads), so the weights products and shape functions at the points
     // live in SGPRs instead of 54 VGPRs
-    double ww[NP][NP], ph[NP][DPE], bary[NP][NV];
+    double wq[NP], wph[NP][DPE], ph[NP][DPE], bary[NP][NV];
     {
         const int off = P.off[q_uniform];
         const double *__restrict__ gb = P.bary+3*(size_t)off, *__restrict__ gw = P.w+off, *__restrict__ gp = P.phi+(size_t)off*DPE;
 #pragma unroll
         for (int i = 0; i < NP; i++) {
+            wq[i] = gw[i];
 #pragma unroll
-            for (int j = 0; j < NP; j++) ww[i][j] = gw[i]*gw[j];
-#pragma unroll
-            for (int a = 0; a < DPE; a++) ph[i][a] = gp[i*DPE+a];
+            for (int a = 0; a < DPE; a++) { ph[i][a] = gp[i*DPE+a]; wph[i][a] = gw[i]*gp[i*DPE+a]; }
 #pragma unroll
             for (int k = 0; k < NV; k++) bary[i][k] = gb[3*i+k];
         }
@@ -1061,17 +1063,18 @@ k_tile_pure(const DevProblem P, const int2 *__restrict__ tiles, int ntiles, doub
                     double d2 = 0.;
 #pragma unroll
                     for (int d = 0; d < DIM; d++) { const double t = x[ip][d]-y[jp][d]; d2 = __builtin_fma(t, t, d2); }
-                    const double K = ww[ip][jp]*kern_eval<KT>(P.k, d2);
-                    r += K;
-                    c[jp] += K;
+                    // weights folded into the accumulations (they are scalar constants): no multiply per kernel value
+                    const double g = kern_eval<KT>(P.k, d2);
+                    r = __builtin_fma(wq[jp], g, r);
+                    c[jp] = __builtin_fma(wq[ip], g, c[jp]);
 #pragma unroll
-                    for (int b = 0; b < DPE; b++) u[b] = __builtin_fma(K, ph[jp][b], u[b]);
+                    for (int b = 0; b < DPE; b++) u[b] = __builtin_fma(g, wph[jp][b], u[b]);
                 }
-                rr[ip] = __builtin_fma(volb, r, rr[ip]);
+                rr[ip] = __builtin_fma(volb*wq[ip], r, rr[ip]);
 #pragma unroll
                 for (int a = 0; a < DPE; a++)
 #pragma unroll
-                    for (int b = 0; b < DPE; b++) G[a][b] = __builtin_fma(ph[ip][a], u[b], G[a][b]);
+                    for (int b = 0; b < DPE; b++) G[a][b] = __builtin_fma(wph[ip][a], u[b], G[a][b]);
             }
             // cross block -> LDS sub-block of A'
             const double vv = scale2*vola*volb;
@@ -1098,7 +1101,7 @@ k_tile_pure(const DevProblem P, const int2 *__restrict__ tiles, int ntiles, doub
                     double pa = 0., pb = 0.;
 #pragma unroll
                     for (int k = 0; k < DPE; k++) { pa = (a == k) ? ph[jp][k] : pa; pb = (b == k) ? ph[jp][k] : pb; }
-                    s2 = __builtin_fma(pa*pb, cw[jp], s2);
+                    s2 = __builtin_fma(pa*pb*wq[jp], cw[jp], s2);
                 }
                 s_Db[j*ND+lane] = scale2*s_volb[j]*s2;       // this wave owns cell j: plain store
             }
