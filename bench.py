@@ -65,11 +65,19 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     assert world == args.gpus, 'launch with torch.distributed.run --nproc-per-node {} (WORLD_SIZE={})'.format(args.gpus, world)
     assert torch.cuda.is_available(), 'bench.py needs a GPU: the assembly path has no CPU implementation'
+    # rehearsal of the N > 1 path on a one-GPU box: PNL_BENCH_BACKEND=gloo puts every rank on cuda:0 and reduces on the host
+    backend = os.environ.get('PNL_BENCH_BACKEND', 'nccl')
+    if backend != 'nccl':
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
+    red_dev = dev if backend == 'nccl' else torch.device('cpu')
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=dev)
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     # ---- setup (not timed): tables on the host, upload into HBM ---------------------------------------------
     mesh = disc(args.noRef, sectors=args.sectors)
@@ -122,10 +130,10 @@ def main():
         for k, v in m.items():
             phase_acc[k] = phase_acc.get(k, 0.)+v/3.
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        pr = torch.tensor([cnt['numAssembledCellPairs']], dtype=torch.float64, device=dev)
+        pr = torch.tensor([cnt['numAssembledCellPairs']], dtype=torch.float64, device=red_dev)
         dist.all_reduce(pr)
         pairs_total = float(pr.item())
     else:
