@@ -6,7 +6,8 @@ anywhere, so the entry-level golden vectors are produced by the pinned CPU oracl
 checked against the reference's stored Hs errors and closed forms in tests/test_oracle_pinning.py):
   * local matrices of one cell pair of every panel type (identical, common edge, common vertex, distant
     orders 2..5) on the disc mesh noRef=2, P1, s=0.5 / 0.25 / 0.75;
-  * the complete 37 x 37 dense operator of that mesh including the boundary term.
+  * the complete 37 x 37 dense operator of that mesh including the boundary term;
+  * the same operator for a non-symmetric order per quadrature point (smoothedLeftRight) and a piecewise non-symmetric one.
 Inputs are fully determined by the mesh constructors, so the fixture holds only the outputs.
 """
 import os
@@ -41,5 +42,11 @@ mesh = interval(4)
 dm = P1_DoFMap(mesh, PHYSICAL)
 O = OracleProblem(nonlocalTables(dm, getFractionalKernel(1, 0.25)))
 out['dense_interval4_s0.25'] = O.get_dense()[0]
+# non-symmetric paths (added after the first fixture: the entries above are unchanged)
+from pynucleus_amd.fractionalOrders import smoothedLeftRightFractionalOrder, leftRightFractionalOrder  # noqa: E402
+mesh = disc(2)
+dm = P1_DoFMap(mesh, PHYSICAL)
+out['dense_disc2_smoothedLeftRight'] = OracleProblem(nonlocalTables(dm, getFractionalKernel(2, smoothedLeftRightFractionalOrder(0.25, 0.75, r=0.3)), {})).get_dense()[0]
+out['dense_disc2_leftRight_nonsym'] = OracleProblem(nonlocalTables(dm, getFractionalKernel(2, leftRightFractionalOrder(0.25, 0.75, 0.3, 0.6)), {})).get_dense()[0]
 np.savez_compressed(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'oracle_golden.npz'), **out)
 print({k: v.shape for k, v in out.items()})

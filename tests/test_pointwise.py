@@ -148,3 +148,18 @@ def test_piecewise_nonsymmetric_order_oracle():
     assert np.abs(A-A.T).max() <= 1e-13*np.abs(A).max()
     assert np.abs(A-0.5*(A1+A2)).max() <= 1e-6*np.abs(A).max()
     assert np.abs(A1-A2).max() > 1e-2*np.abs(A).max()
+
+
+def test_golden_nonsymmetric():
+    """regression net for the non-symmetric oracle paths (tests/golden/make_golden.py)"""
+    import os
+    from pynucleus_amd.fractionalOrders import leftRightFractionalOrder
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'oracle_golden.npz'))
+    mesh = disc(2)
+    dm = P1_DoFMap(mesh, PHYSICAL)
+    A = OracleProblem(nonlocalTables(dm, getFractionalKernel(2, smoothedLeftRightFractionalOrder(0.25, 0.75, r=0.3)), {})).get_dense()[0]
+    ref = gold['dense_disc2_smoothedLeftRight']
+    assert np.abs(A-ref).max() <= 1e-13*np.abs(ref).max()
+    A = OracleProblem(nonlocalTables(dm, getFractionalKernel(2, leftRightFractionalOrder(0.25, 0.75, 0.3, 0.6)), {})).get_dense()[0]
+    ref = gold['dense_disc2_leftRight_nonsym']
+    assert np.abs(A-ref).max() <= 1e-13*np.abs(ref).max()
