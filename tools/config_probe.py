@@ -22,7 +22,8 @@ def sync():
 
 if what in ('p2', 'c5'):
     noRef = size or 5
-    mesh = disc(noRef)
+    sectors = int(sys.argv[3]) if len(sys.argv) > 3 else 6
+    mesh = disc(noRef, sectors=sectors)
     dm = P2_DoFMap(mesh, PHYSICAL)
     if what == 'c5':
         orders = np.array([[0.3, 0.4, 0.5], [0.4, 0.5, 0.6], [0.5, 0.6, 0.7]])
