@@ -116,3 +116,23 @@ def test_cg_on_h2_and_near_field_operators():
     uh, ith, resh = cg(H, rhs, tol=1e-10, maxiter=2000)
     assert resh[-1] <= 1e-10 and ith <= 2*itd          # (the interpolated far field is symmetric only to its own accuracy)
     assert np.abs(uh-ud).max() <= 1e-3*np.abs(ud).max()
+
+
+@pytest.mark.gpu
+def test_stored_hs_errors_dense_and_h2():
+    """tests/cache_runFractional.py--domaindisc--sconst(0.75)--problemconstant--elementP1--solvercg-mg--matrixFormat{dense,H2}:
+    stored Hs errors 0.060319591944560894 (dense) and 0.059725648882225826 (H2), compared by the reference at relTol 1e-2"""
+    from math import gamma, pi
+    from pynucleus_amd import driverMesh, P1_DoFMap, PHYSICAL, getFractionalKernel, nonlocalBuilder
+    from pynucleus_amd.solvers import cg
+    s = 0.75
+    dm = P1_DoFMap(driverMesh('disc', 5), PHYSICAL)
+    builder = nonlocalBuilder(dm, getFractionalKernel(2, s), {'target_order': 0.5, 'eta': 3.})
+    b = np.asarray(dm.assembleRHS(1.0))
+    ex = 2.**(-2.*s)*gamma(1.)/gamma((2+2.*s)/2.)/gamma(1.+s)*pi/(s+1)
+    u = builder.getDense().solve_cg_jacobi(b, tol=1e-10, maxiter=5000)[0]
+    hs = np.sqrt(abs(b@u-ex))
+    assert abs(hs-0.060319591944560894) <= 1e-3*0.060319591944560894, hs
+    uh = cg(builder.getH2(), b, tol=1e-10, maxiter=5000)[0]
+    hh = np.sqrt(abs(b@uh-ex))
+    assert abs(hh-0.059725648882225826) <= 1e-2*0.059725648882225826, hh
