@@ -136,3 +136,23 @@ def test_stored_hs_errors_dense_and_h2():
     uh = cg(builder.getH2(), b, tol=1e-10, maxiter=5000)[0]
     hh = np.sqrt(abs(b@uh-ex))
     assert abs(hh-0.059725648882225826) <= 1e-2*0.059725648882225826, hh
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('domain,s,noRef,stored', [('interval', 0.25, 6, 0.0961124909768421), ('disc', 0.25, 5, 0.18185981625380002)])
+def test_stored_hs_errors_h2(domain, s, noRef, stored):
+    """tests/cache_runFractional.py--domain{interval,disc}--sconst(0.25)--problemconstant--elementP1--solvercg-mg--matrixFormatH2"""
+    from math import gamma, pi, sqrt
+    from pynucleus_amd import driverMesh, P1_DoFMap, PHYSICAL, getFractionalKernel, nonlocalBuilder
+    from pynucleus_amd.solvers import cg
+    dim = 1 if domain == 'interval' else 2
+    dm = P1_DoFMap(driverMesh(domain, noRef), PHYSICAL)
+    params = {'target_order': 2.-s, 'eta': 1.} if dim == 1 else {'target_order': 0.5, 'eta': 3.}
+    builder = nonlocalBuilder(dm, getFractionalKernel(dim, s), params)
+    b = np.asarray(dm.assembleRHS(1.0))
+    C = 2.**(-2.*s)*gamma(dim/2.)/gamma((dim+2.*s)/2.)/gamma(1.+s)
+    ex = C*sqrt(pi)*gamma(s+1)/gamma(s+3/2) if dim == 1 else C*pi/(s+1)
+    H = builder.getH2()
+    uh = cg(H, b, tol=1e-10, maxiter=5000)[0]
+    hh = np.sqrt(abs(b@uh-ex))
+    assert abs(hh-stored) <= 1e-2*stored, hh
