@@ -45,7 +45,7 @@ class DoFMap:
         self.dofs_per_face = 0
         self.dofs_per_cell = dofs_per_cell
         self.dofs_per_element = vpe*dofs_per_vertex+epe*self.dofs_per_edge+dofs_per_cell
-        assert dofs_per_vertex in (0, 1) and self.dofs_per_edge in (0, 1) and dofs_per_cell == 0, \
+        assert dofs_per_vertex in (0, 1) and self.dofs_per_edge in (0, 1) and (dofs_per_cell == 0 or (md == 1 and dofs_per_cell == 1)), \
             'only P1 / P2 Lagrange maps are implemented'
         cells = mesh.cells
         nc = cells.shape[0]
@@ -79,6 +79,9 @@ class DoFMap:
                 lo = np.minimum(c[:, a], c[:, b])
                 hi = np.maximum(c[:, a], c[:, b])
                 ent_keys.append(nvert+lo*nvert+hi)
+        if dofs_per_cell > 0:
+            # DoF in the interior of the cell (P2 on intervals): numbered after the cell's vertices (DoFMaps.pyx:300-305)
+            ent_keys.append(mesh.num_vertices*(mesh.num_vertices+1)+np.arange(nc, dtype=np.int64))
         keys = np.stack(ent_keys, axis=1)                     # [nc, slots], cell-major
         flat = keys.reshape(-1)
         is_boundary = np.zeros(flat.shape[0], dtype=bool)
@@ -239,14 +242,23 @@ class P2_DoFMap(DoFMap):
     polynomialOrder = 2
 
     def __init__(self, mesh, tag=None):
-        assert mesh.manifold_dim == 2, 'P2 is implemented on triangles'
-        super().__init__(mesh, 1, 1, 0, tag)
+        assert mesh.manifold_dim in (1, 2), 'P2 is implemented on intervals and triangles'
+        if mesh.manifold_dim == 1:
+            super().__init__(mesh, 1, 0, 1, tag)             # vertices + the midpoint of the cell (DoFMaps.pyx P2_DoFMap, 1D)
+        else:
+            super().__init__(mesh, 1, 1, 0, tag)
 
     def _set_nodes(self):
-        self.nodes = np.array([[1., 0., 0.], [0., 1., 0.], [0., 0., 1.],
-                               [.5, .5, 0.], [0., .5, .5], [.5, 0., .5]], dtype=REAL)
+        if self.mesh.manifold_dim == 1:
+            self.nodes = np.array([[1., 0.], [0., 1.], [.5, .5]], dtype=REAL)
+        else:
+            self.nodes = np.array([[1., 0., 0.], [0., 1., 0.], [0., 0., 1.],
+                                   [.5, .5, 0.], [0., .5, .5], [.5, 0., .5]], dtype=REAL)
 
     def evalShapeFunctions(self, bary):
+        if self.mesh.manifold_dim == 1:
+            l0, l1 = bary[0], bary[1]
+            return np.stack([l0*(2*l0-1), l1*(2*l1-1), 4*l0*l1])
         l0, l1, l2 = bary[0], bary[1], bary[2]
         return np.stack([l0*(2*l0-1), l1*(2*l1-1), l2*(2*l2-1), 4*l0*l1, 4*l1*l2, 4*l0*l2])
 

@@ -46,7 +46,8 @@ def test_interval_stored_errors():
     dm, A, b, u, cnt = solve_constant_problem(1, s, 6, {'target_order': 2.-s}, driver=True)
     C, ex = exact_hs_squared(1, s)
     hs = np.sqrt(abs(b@u-ex))
-    assert abs(hs-0.09611243700804001) <= 1e-3*0.09611243700804001, hs
+    # in 1D every rule is a Gauss-Jacobi rule (no third-party tables): the restatement reproduces the stored number to 2e-12
+    assert abs(hs-0.09611243700804001) <= 1e-9*0.09611243700804001, hs
     l2 = dm.L2norm_of_error(u, lambda x: C*max(1-x[0]**2, 0.)**s, order=12)
     assert abs(l2-0.026655318974538753) <= 3e-2*0.026655318974538753, l2
     assert cnt['numAssembledCellPairs'] == 128*129//2 and cnt['singular'][-2] == 128 and cnt['singular'][-1] == 127
@@ -150,3 +151,19 @@ def test_golden_interval():
     A = OracleProblem(nonlocalTables(dm, getFractionalKernel(1, 0.25))).get_dense()[0]
     ref = GOLD['dense_interval4_s0.25']
     assert np.abs(A-ref).max() <= 1e-13*np.abs(ref).max()
+
+
+@pytest.mark.parametrize('element,s,noRef,stored', [('P1', 0.75, 6, 0.04184296289342096), ('P2', 0.25, 5, 0.08454379705489531),
+                                                    ('P2', 0.75, 5, 0.03250922885004246)])
+def test_interval_stored_errors_exact(element, s, noRef, stored):
+    """tests/cache_runFractional.py--domaininterval--sconst(s)--problemconstant--element{P1,P2}--...--matrixFormatdense: in 1D the
+    reference's quadrature is Gauss-Jacobi throughout (reproducible without modepy), and the oracle lands on the stored Hs errors
+    to ~1e-12 relative -- also for P2 (vertex + cell-midpoint DoFs), the only reference numbers that pin the P2 machinery"""
+    from pynucleus_amd import dofmapFactory
+    dm = dofmapFactory(element, driverMesh('interval', noRef), PHYSICAL)
+    T = nonlocalTables(dm, getFractionalKernel(1, s), {'target_order': dm.polynomialOrder+1.-s})
+    A = OracleProblem(T).get_dense()[0]
+    b = np.asarray(dm.assembleRHS(1.0))
+    u = np.linalg.solve(A, b)
+    hs = np.sqrt(abs(b@u-exact_hs_squared(1, s)[1]))
+    assert abs(hs-stored) <= 1e-8*stored, (hs, stored)
