@@ -25,9 +25,9 @@ class FakePLogger:
         self.timings[key] = self.timings.get(key, 0.)+seconds
 
 
-def tile_cells(dpe):
+def tile_cells(dpe, dim=2):
     """cells per block of the GPU tile kernel (mirrors TILE_P1 / TILE_P2 in csrc/pnl_hip.hip)"""
-    return 32 if dpe == 6 else 64
+    return 32 if (dpe == 6 or (dim == 1 and dpe == 3)) else 64
 
 
 def upper_tiles(num_cells, T):
@@ -76,7 +76,7 @@ def with_cell_locality(dm):
     shrinks the blocks.  DoF numbers are unchanged; the operator changes only through the orientation of touching pairs (which
     cell comes first in the singular rule), i.e. at the quadrature error of those rules (1e-8 relative)."""
     import copy
-    T = tile_cells(dm.dofs_per_element)
+    T = tile_cells(dm.dofs_per_element, dm.mesh.dim)
     mesh = dm.mesh
     if mesh.num_cells <= T:
         return dm
@@ -216,7 +216,7 @@ class nonlocalBuilder:
     def tiles_for_rank(self, rank, size):
         """block-tile pairs (ta <= tb) of the upper block triangle owned by `rank`: the list is ordered by
         block distance (heavy near-diagonal tiles first) and dealt round-robin."""
-        T = tile_cells(self.dm.dofs_per_element)
+        T = tile_cells(self.dm.dofs_per_element, self.mesh.dim)
         if self._ctx is not None:
             assert self._ctx.tile_cells() == T
         return tiles_of_rank(self.mesh.num_cells, T, rank, size)

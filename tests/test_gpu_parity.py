@@ -343,3 +343,26 @@ def test_cells_without_locality_are_renumbered():
     b2 = nonlocalBuilder(dm, kernel, {'target_order': 0.5, 'reorderCells': False})
     with pytest.raises(NotImplementedError):
         b2.getDense()
+
+
+@pytest.mark.parametrize('noRef,s,zeroExterior', [(5, 0.25, True), (6, 0.75, True), (4, 0.4, False)])
+def test_interval_P2_dense(noRef, s, zeroExterior):
+    """P2 on intervals (vertex + cell-midpoint DoFs): the configuration whose oracle is pinned to the reference's stored numbers
+    to 1e-12 (tests/test_oracle_pinning.py::test_interval_stored_errors_exact)"""
+    _compare(_build('interval', noRef, s, element='P2', zeroExterior=zeroExterior))
+
+
+@pytest.mark.parametrize('element,s,noRef,stored', [('P1', 0.25, 6, 0.09611243700804001), ('P2', 0.25, 5, 0.08454379705489531),
+                                                    ('P2', 0.75, 5, 0.03250922885004246)])
+def test_interval_stored_errors_through_the_gpu(element, s, noRef, stored):
+    """the reference's stored Hs errors of runFractional --domain interval (reproducible to ~1e-12 without third-party tables)
+    through the product path: assembly on the GPU, solve on the host"""
+    from math import gamma, pi, sqrt
+    from pynucleus_amd import driverMesh, PHYSICAL, dofmapFactory, getFractionalKernel, nonlocalBuilder
+    dm = dofmapFactory(element, driverMesh('interval', noRef), PHYSICAL)
+    A = nonlocalBuilder(dm, getFractionalKernel(1, s), {'target_order': dm.polynomialOrder+1.-s}).getDense().toarray()
+    b = np.asarray(dm.assembleRHS(1.0))
+    u = np.linalg.solve(A, b)
+    C = 2.**(-2.*s)*gamma(0.5)/gamma((1+2.*s)/2.)/gamma(1.+s)
+    hs = np.sqrt(abs(b@u-C*sqrt(pi)*gamma(s+1)/gamma(s+3/2)))
+    assert abs(hs-stored) <= 1e-8*stored, (hs, stored)
