@@ -83,6 +83,39 @@ def test_oracle_pair_list_equals_all_pairs_loop():
     assert np.abs(data.reshape(N, N)-A).max() <= 1e-13*np.abs(A).max()
 
 
+def _poly_dirichlet_1d(kernel, nc, delta=0.2, s=0.75):
+    """runNonlocal --domain interval --problem poly-Dirichlet (nonlocalProblems.py:995-1004): f = 2 on (-1,1), u = 1-x^2 on the
+    interaction domain; the P1 solution is nodally exact (stored 'L2 error interpolated' 1e-13 for kernelType constant /
+    inverseDistance / fractional, tests/cache_runNonlocal.py--domaininterval--kernelType*--problempoly-Dirichlet--solverlu--
+    matrixFormatdense)"""
+    from pynucleus_amd import simpleInterval, P1_DoFMap, NO_BOUNDARY, getKernel, getFractionalKernel, INDICATOR, PERIDYNAMIC
+    mesh = simpleInterval(-1-delta, 1+delta, nc)
+    dm = P1_DoFMap(mesh, NO_BOUNDARY)
+    if kernel == 'fractional':
+        k = getFractionalKernel(1, s, horizon=delta)
+    else:
+        k = getKernel(1, kernel=INDICATOR if kernel == 'constant' else PERIDYNAMIC, horizon=delta)
+    return dm, k
+
+
+def _poly_dirichlet_error(dm, A):
+    X = dm.getDoFCoordinates()[:, 0]
+    inner = np.abs(X) < 1-1e-12
+    b = np.asarray(dm.assembleRHS(2.0))
+    u = np.linalg.solve(A[np.ix_(inner, inner)], b[inner]-A[np.ix_(inner, ~inner)]@(1-X[~inner]**2))
+    return np.abs(u-(1-X[inner]**2)).max()
+
+
+@pytest.mark.parametrize('kernel,nc,tol', [('constant', 24, 1e-13), ('inverseDistance', 24, 1e-13), ('constant', 48, 1e-13),
+                                           ('fractional', 48, 5e-9)])
+def test_oracle_interval_poly_dirichlet_known_answer(kernel, nc, tol):
+    from pynucleus_amd.local_matrix import nonlocalTables
+    from oracle.oracle import OracleProblem
+    dm, k = _poly_dirichlet_1d(kernel, nc)
+    A = OracleProblem(nonlocalTables(dm, k, {}, False)).get_dense()[0]
+    assert _poly_dirichlet_error(dm, A) <= tol
+
+
 # ---- GPU -------------------------------------------------------------------------------------------------------------
 def _gpu_sparse(N, delta, kernel, interaction=None, s=None, element='P1', params=None, domain='square'):
     from pynucleus_amd import uniformSquare, interval, NO_BOUNDARY, dofmapFactory, getKernel, getFractionalKernel, INDICATOR, PERIDYNAMIC
@@ -137,3 +170,13 @@ def test_gpu_dense_rejects_finite_horizon_in_the_all_pairs_kernel():
     A = torch.zeros((b.dm.num_dofs, b.dm.num_dofs), dtype=torch.float64, device='cuda')
     with pytest.raises(NotImplementedError):
         ctx.assemble_dense(A.data_ptr(), A.stride(0), False, 0, b.mesh.num_cells)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('kernel,nc,tol', [('constant', 24, 1e-13), ('inverseDistance', 48, 1e-13), ('fractional', 48, 5e-9)])
+def test_gpu_interval_poly_dirichlet_known_answer(kernel, nc, tol):
+    """the reference's stored runNonlocal 1D result (nodally exact P1 solution) through getSparse on the GPU"""
+    from pynucleus_amd.builder import nonlocalBuilder
+    dm, k = _poly_dirichlet_1d(kernel, nc)
+    A = nonlocalBuilder(dm, k, {}, zeroExterior=False).getSparse().toarray()
+    assert _poly_dirichlet_error(dm, A) <= tol

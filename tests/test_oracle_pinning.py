@@ -67,7 +67,7 @@ def test_interval_variable_const_order_stored_error():
     b = np.asarray(dm.assembleRHS(1.0))
     u = np.linalg.solve(A, b)
     hs = np.sqrt(abs(b@u-exact_hs_squared(1, s)[1]))
-    assert abs(hs-0.041842962898268554) <= 1e-3*0.041842962898268554, hs
+    assert abs(hs-0.041842962898268554) <= 1e-8*0.041842962898268554, hs      # measured 1.2e-10 (solver tolerance of the stored run)
     A0 = OracleProblem(nonlocalTables(dm, getFractionalKernel(1, s), params)).get_dense()[0]
     assert np.abs(A-A0).max() == 0.
 
