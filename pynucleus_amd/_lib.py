@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libpnl_hip.so')
+LIB_PATH = os.environ.get('PNL_LIB', os.path.join(_HERE, 'libpnl_hip.so'))      # PNL_LIB: A/B builds of the library (tuning)
 
 PNL_OK = 0
 PNL_ERR_INVALID = -1

@@ -50,6 +50,7 @@ struct DevProblem {
     // rules the tile kernel integrates one pair per lane, packed for one coalesced copy into LDS
     const int *tt_n, *tt_off;   // [PNL_MAXQ+2]
     const double *tt_tab;       // [tt_npts][4+dpe]: bary[3], w, phi[dpe]
+    const double *tt_wphi;      // [tt_npts][dpe]: w, w*phi[0..dpe-2] (wave-uniform scalar loads; the last product follows from sum_b phi_b = 1)
     int tt_npts, pad1;
     // singular rules (slot 0 vertex, 1 edge, 2 face)
     int sM[3], sRows[3];

@@ -65,7 +65,7 @@ struct pnl_context {
     DevProblem P;
     DevBuf b_cellv, b_ccen, b_cvol, b_ch, b_clog, b_cvid, b_cdof, b_cslot, b_blk_ndof, b_blk_dofs, b_perm, b_off, b_bary, b_w, b_phi,
         b_foff, b_fbary, b_fw, b_bvid, b_bv, b_bgeo, b_counters, b_D, b_tiles,
-        b_vec[6], b_clabel, b_blabel, b_clsof, b_scal, b_wl, b_wlcount, b_ttn, b_ttoff, b_tttab, b_wlsorted, b_wlaux,
+        b_vec[6], b_clabel, b_blabel, b_clsof, b_scal, b_wl, b_wlcount, b_ttn, b_ttoff, b_tttab, b_ttwphi, b_wlsorted, b_wlaux,
         b_vertices, b_sp_indptr, b_sp_indices, b_mp_pairs, b_mp_masks, b_mp_wl, b_mp_sorted, b_mp_aux, b_bi_cells, b_bi_facets,
         b_bi_masks, b_cp[28], b_cpD, b_wlds, b_wlpair, b_h2[20];
     H2Dev h2;
@@ -487,6 +487,7 @@ void refresh_tables(pnl_context *ctx) {
     P.phi = (const double*)ctx->b_phi.p; P.foff = (const int*)ctx->b_foff.p; P.fbary = (const double*)ctx->b_fbary.p;
     P.fw = (const double*)ctx->b_fw.p;
     P.tt_n = (const int*)ctx->b_ttn.p; P.tt_off = (const int*)ctx->b_ttoff.p; P.tt_tab = (const double*)ctx->b_tttab.p;
+    P.tt_wphi = (const double*)ctx->b_ttwphi.p;
     for (int s = 0; s < 3; s++) {
         P.sNodes[s] = (const double*)ctx->C().b_sn[s].p; P.sW[s] = (const double*)ctx->C().b_sw[s].p; P.sPsi[s] = (const double*)ctx->C().b_sp[s].p;
     }
@@ -565,7 +566,7 @@ int launch_tiles(pnl_context *ctx, int ntiles_all, double *A, int64_t ldA, int c
     const size_t lds = S::fixed_bytes+sizeof(double)*(size_t)(ctx->nU+1)*acc_stride;
     if (getenv("PNL_VERBOSE")) {
         int nblk = -1;
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nblk, (const void*)k_tile_distant<DIM, DPE, TILE, KT, false>, PNL_NTHREADS, lds);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nblk, (const void*)k_tile_distant<DIM, DPE, TILE, KT, false>, tile_threads(DPE, KT), lds);
         fprintf(stderr, "[pnl] tiles=%d nU=%d lds=%zu bytes, occupancy API: %d blocks/CU\n", ntiles, ctx->nU, lds, nblk);
     }
     if (lds > 160*1024)
@@ -588,11 +589,11 @@ int launch_tiles(pnl_context *ctx, int ntiles_all, double *A, int64_t ldA, int c
     auto kfun = k_tile_distant<DIM, DPE, TILE, KT, false>;
     HIPCHK(ctx, hipFuncSetAttribute((const void*)kfun, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     int per_cu = 2;
-    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)kfun, PNL_NTHREADS, lds);
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)kfun, tile_threads(DPE, KT), lds);
     const int grid_mult = getenv("PNL_GRID_MULT") ? atoi(getenv("PNL_GRID_MULT")) : 1;
     const int grid = std::min(ntiles, 256*std::max(per_cu, 1)*std::max(grid_mult, 1));
     if (grid > 0)
-        hipLaunchKernelGGL(kfun, dim3(grid), dim3(PNL_NTHREADS), lds, ctx->stream, tile_problem(ctx), (const int2*)ctx->b_tiles.p+ctx->tile_off, A,
+        hipLaunchKernelGGL(kfun, dim3(grid), dim3(tile_threads(DPE, KT)), lds, ctx->stream, tile_problem(ctx), (const int2*)ctx->b_tiles.p+ctx->tile_off, A,
                            (long long)ldA, (double*)(ctx->have_tile_order ? ctx->b_Dt.p : ctx->b_D.p), cell_begin, cell_end, acc_stride, (int4*)ctx->b_wl.p,
                            (unsigned*)ctx->b_wlcount.p, ctx->wl_cap, ctx->ablate | (ctx->symflush ? 256 : 0), ntiles, ClusterTiles{});
     HIPCHK(ctx, hipGetLastError());
@@ -901,11 +902,11 @@ int clusters_tiled_impl(pnl_context *ctx, const pnl_cluster_plan *pl, ClusterTil
         auto kfun = k_tile_distant<DIM, DPE, TILE, KT, true>;
         HIPCHK(ctx, hipFuncSetAttribute((const void*)kfun, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         int per_cu = 2;
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)kfun, PNL_NTHREADS, lds);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)kfun, tile_threads(DPE, KT), lds);
         if (getenv("PNL_VERBOSE")) fprintf(stderr, "[pnl] cluster tiles=%d nU=%d lds=%zu bytes, occupancy API: %d blocks/CU\n", pl->ntiles,
                                            pl->chunk_stride, lds, per_cu);
         const int grid = std::min(pl->ntiles, 256*std::max(per_cu, 1));
-        hipLaunchKernelGGL(kfun, dim3(grid), dim3(PNL_NTHREADS), lds, ctx->stream, ctx->P, (const int2*)nullptr, (double*)nullptr, 0ll,
+        hipLaunchKernelGGL(kfun, dim3(grid), dim3(tile_threads(DPE, KT)), lds, ctx->stream, ctx->P, (const int2*)nullptr, (double*)nullptr, 0ll,
                            (double*)nullptr, 0, ctx->nc, acc_stride, (int4*)ctx->b_wl.p, (unsigned*)ctx->b_wlcount.p, ctx->wl_cap, 0,
                            pl->ntiles, CT);
         HIPCHK(ctx, hipGetLastError());
@@ -1518,7 +1519,7 @@ int pnl_upload_distant_rules(pnl_context *ctx, int qmax, const int32_t *off, con
     {
         const int dpe = ctx->dpe, st = 4+dpe;
         std::vector<int32_t> tn(PNL_MAXQ+2, 0), to(PNL_MAXQ+2, 0);
-        std::vector<double> tab;
+        std::vector<double> tab, wphi;
         int npts = 0, nb = 0;
         // the tile kernel unrolls exactly two point counts (3 and 6 on triangles, 2 and 3 on intervals) and integrates the
         // other orders with at most PNL_GEN_MAXPTS points through a generic loop (list C)
@@ -1532,6 +1533,8 @@ int pnl_upload_distant_rules(pnl_context *ctx, int qmax, const int32_t *off, con
                 const size_t p = (size_t)off[q]+i;
                 tab.push_back(bary[3*p]); tab.push_back(bary[3*p+1]); tab.push_back(bary[3*p+2]); tab.push_back(w[p]);
                 for (int a = 0; a < dpe; a++) tab.push_back(phi[p*dpe+a]);
+                wphi.push_back(w[p]);
+                for (int a = 0; a+1 < dpe; a++) wphi.push_back(w[p]*phi[p*dpe+a]);
             }
             npts += n; nb++;
             (void)st;
@@ -1539,6 +1542,7 @@ int pnl_upload_distant_rules(pnl_context *ctx, int qmax, const int32_t *off, con
         if ((rc = upload(ctx, ctx->b_ttn, tn.data(), tn.size()))) return rc;
         if ((rc = upload(ctx, ctx->b_ttoff, to.data(), to.size()))) return rc;
         if ((rc = upload(ctx, ctx->b_tttab, tab.data(), tab.size()))) return rc;
+        if ((rc = upload(ctx, ctx->b_ttwphi, wphi.data(), wphi.size()))) return rc;
         ctx->P.tt_npts = npts;
     }
     ctx->qmax = qmax;

@@ -251,12 +251,19 @@ __device__ __forceinline__ void eval_distant_generic(const DevProblem &P, int of
     }
 }
 
-// compile-time number of points: y_j and the column sums stay in registers.  The rule comes from the tile's LDS copy
-// (layout per point: bary[3], w, phi[DPE]); all lanes read the same address, so every read is an LDS broadcast.
+// compile-time number of points, one order for the whole wave: y_j and the column sums stay in registers.  What is live over
+// the whole loop -- w_j and w_j phi_b(y_j) -- comes from the global table gwp (layout per point: w, w phi_0 .. w phi_{DPE-2}) with
+// wave-uniform addresses, i.e. scalar loads into SGPRs instead of 2 N DPE VGPRs; the per-i constants come from the tile's LDS
+// copy tab (layout per point: bary[3], w, phi[DPE]; same address in all lanes: broadcast reads).  The shape functions sum to one,
+// so u_{DPE-1}(i) = r_i - sum_{b < DPE-1} u_b(i) saves one FMA per point pair.
+// (The table is read through the constant address space: it is never written by a kernel, and loads from that address space
+// with a uniform address are scalar loads wherever they stand -- global loads after the first store of a kernel are not.)
+typedef const double __attribute__((address_space(4))) *pnl_const_f64_ptr;
 template <int DIM, int DPE, int KT, int N>
-__device__ __forceinline__ void eval_distant_fixed(const DevProblem &P, const double *__restrict__ tab, const double *av,
-                                                   const double *bv, PairAcc<DIM, DPE> &R) {
+__device__ __forceinline__ void eval_distant_fixed(const DevProblem &P, const double *__restrict__ tab, const double *gwp_global,
+                                                   const double *av, const double *bv, PairAcc<DIM, DPE> &R) {
     constexpr int NV = DIM+1, ST = 4+DPE;
+    const pnl_const_f64_ptr gwp = (pnl_const_f64_ptr)(unsigned long long)gwp_global;
     // the weights are folded into the accumulations instead of being multiplied into every kernel value: with g = gamma(x_i, y_j)
     //   row sum r_i = sum_j w_j g, column sum c_j = sum_i w_i g, u_b(i) = sum_j g (w_j phi_b(y_j)); w_i enters once per i
     double y[N][DIM], c[N];
@@ -291,12 +298,14 @@ __device__ __forceinline__ void eval_distant_fixed(const DevProblem &P, const do
 #pragma unroll
             for (int d = 0; d < DIM; d++) { double t = x[d]-y[j][d]; d2 = __builtin_fma(t, t, d2); }
             const double g = kern_eval<KT>(P.k, d2);
-            const double wj = tab[j*ST+3];
-            r = __builtin_fma(wj, g, r);
+            r = __builtin_fma(gwp[j*DPE], g, r);
             c[j] = __builtin_fma(wi, g, c[j]);
 #pragma unroll
-            for (int b = 0; b < DPE; b++) u[b] = __builtin_fma(g, wj*tab[j*ST+4+b], u[b]);     // w_j phi_b(y_j): loop invariant
+            for (int b = 0; b+1 < DPE; b++) u[b] = __builtin_fma(g, gwp[j*DPE+1+b], u[b]);
         }
+        u[DPE-1] = r;
+#pragma unroll
+        for (int b = 0; b+1 < DPE; b++) u[DPE-1] -= u[b];
         int e = 0;
 #pragma unroll
         for (int a = 0; a < DPE; a++) {
@@ -522,21 +531,32 @@ __device__ __forceinline__ bool tile_eligible(int n) { return n == 3; }
 __device__ __forceinline__ bool tile_eligible(int n) { return n == 2 || n == 3 || n == 4 || n == 6 || n == 7; }
 #endif
 
-#ifndef PNL_TILE_WAVES
 #ifndef PNL_PURE_WAVES
 #define PNL_PURE_WAVES 4
 #endif
-#define PNL_TILE_WAVES 2      // waves per SIMD the tile kernel is register-limited to (measured: 2 beats 3 and 4)
+// Occupancy of the general tile kernel: its LDS (about 72 KB) lets two workgroups share a CU, so the waves per SIMD come from the
+// workgroup size: 512 threads at <= 128 VGPRs give 4 waves per SIMD (the unrolled 6-point evaluator stays spill-free because
+// its loop-invariant rule constants live in SGPRs); measured at noRef 7: 256 x 2 waves 69.7 ms, 384 x 3 101.6 ms (spills in
+// the hot loop), 512 x 4 59.9 ms.
+#ifndef PNL_TILE_THREADS
+#define PNL_TILE_THREADS 512  // threads of a tile workgroup (P1 / P0)
 #endif
-// P2 (78 local entries per pair) needs more than 256 VGPRs: one wave per SIMD without spills beats two with 600 B of scratch
+#ifndef PNL_TILE_WAVES
+#define PNL_TILE_WAVES 4      // waves per SIMD the tile kernel is register-limited to
+#endif
+// P2 (78 local entries per pair) needs more than 256 VGPRs: one wave per SIMD without spills beats two with 600 B of scratch,
+// hence 256 threads per workgroup there; the general-exponent kernel (KT = 0: exp / log chains) spills at 128 VGPRs (57 ms against
+// 31 ms at noRef 6, s = 0.4) and keeps 256 threads x 2 waves as well
+__host__ __device__ constexpr int tile_threads(int dpe, int kt) { return (dpe > 3 || kt == 0) ? 256 : PNL_TILE_THREADS; }
+__host__ __device__ constexpr int tile_waves(int dpe, int kt) { return dpe > 3 ? 1 : (kt == 0 ? 2 : PNL_TILE_WAVES); }
 template <int DIM, int DPE, int TILE, int KT, bool CLUSTER>
-__global__ void __launch_bounds__(PNL_NTHREADS, (DPE > 3 ? 1 : PNL_TILE_WAVES))
+__global__ void __launch_bounds__(tile_threads(DPE, KT), tile_waves(DPE, KT))
 k_tile_distant(const DevProblem P, const int2 *__restrict__ tiles, double *__restrict__ A, long long ldA,
                double *__restrict__ Dglob, int cell_begin, int cell_end, int acc_stride, int4 *__restrict__ worklist,
                unsigned *__restrict__ wl_count, unsigned wl_cap, int ablate, int ntiles, const ClusterTiles CT) {
     using S = TileSmem<DIM, DPE, TILE>;
-    constexpr int NV = S::NV, NC = S::NC, ND = S::ND;
-    constexpr int PAIRS = TILE*TILE, PER_THREAD = PAIRS/PNL_NTHREADS;
+    constexpr int NV = S::NV, NC = S::NC, ND = S::ND, NT = tile_threads(DPE, KT);
+    constexpr int PAIRS = TILE*TILE, PER_THREAD = (PAIRS+NT-1)/NT;
     extern __shared__ double smem[];
     double *s_dbl = smem;
     int *s_int = (int*)(s_dbl+S::n_dbl);
@@ -555,10 +575,19 @@ k_tile_distant(const DevProblem P, const int2 *__restrict__ tiles, double *__res
     int *s_dslot = s_int+S::o_dslot, *s_cell = s_int+S::o_cell;     // cluster tiles: D slots and cell ids of both sides
     // statistics of order q = 2 + tid (+256) are kept in registers over all tiles of this workgroup: hot counters
     // see one atomic per workgroup, not one per tile
-    unsigned long long st_cnt[(PNL_MAXQ+PNL_NTHREADS)/PNL_NTHREADS] = {0}, st_ev[(PNL_MAXQ+PNL_NTHREADS)/PNL_NTHREADS] = {0};
+    unsigned long long st_cnt[(PNL_MAXQ+NT)/NT] = {0}, st_ev[(PNL_MAXQ+NT)/NT] = {0};
     // rules integrated inside the tile (the two unrolled point counts and the generic ones): staged once per workgroup
-    for (int t = tid; t < PNL_MAXQ+2; t += PNL_NTHREADS) { s_ttn[t] = P.tt_n[t]; s_tto[t] = P.tt_off[t]; }
-    for (int t = tid; t < P.tt_npts*(4+DPE); t += PNL_NTHREADS) s_tt[t] = P.tt_tab[t];
+    for (int t = tid; t < PNL_MAXQ+2; t += NT) { s_ttn[t] = P.tt_n[t]; s_tto[t] = P.tt_off[t]; }
+    for (int t = tid; t < P.tt_npts*(4+DPE); t += NT) s_tt[t] = P.tt_tab[t];
+    // the two orders integrated by the unrolled evaluators (lists A and B): the lowest ones with NA / NB points -- nearly all
+    // pairs; every wave of those lists works on ONE order, so the rule constants are wave-uniform (scalar loads).  Other orders
+    // with a packed rule go through list C, which is sorted by order
+    int qA0 = 0, qB0 = 0;
+    for (int q = 17; q >= 2; q--) {
+        const int n = P.tt_n[q];
+        qA0 = (n == ((DIM == 2) ? 3 : 2)) ? q : qA0;
+        qB0 = (n == ((DIM == 2) ? 6 : 3)) ? q : qB0;
+    }
     // persistent workgroups: each one walks the tile list with stride gridDim.x (heavy tiles come first in the list)
 #pragma unroll 1
     for (int tile_idx = blockIdx.x; tile_idx < ntiles; tile_idx += gridDim.x) {
@@ -568,7 +597,7 @@ k_tile_distant(const DevProblem P, const int2 *__restrict__ tiles, double *__res
     const bool sym = CLUSTER ? (CT.flags[tile_idx] & 1) != 0 : true;
 
     // ---- stage cell data of both blocks in LDS (SoA: conflict-free per-lane reads) -------------
-    for (int t = tid; t < 2*TILE; t += PNL_NTHREADS) {
+    for (int t = tid; t < 2*TILE; t += NT) {
         const int side = t/TILE, l = t%TILE;
         const int craw = CLUSTER ? CT.chunk_cells[(size_t)(side ? tb : ta)*TILE+l] : (side ? tb : ta)*TILE+l;
         const bool real = craw >= 0;
@@ -597,9 +626,9 @@ k_tile_distant(const DevProblem P, const int2 *__restrict__ tiles, double *__res
             s_slot[(side*DPE+k)*TILE+l] = sl >= 0 ? sl : (short)(side ? nB : nA);
         }
     }
-    for (int t = tid; t < (nA+1)*acc_stride; t += PNL_NTHREADS) s_acc[t] = 0.;
-    for (int t = tid; t < 2*TILE*ND; t += PNL_NTHREADS) s_D[t] = 0.;
-    for (int t = tid; t < 2*(PNL_MAXQ+2)+4; t += PNL_NTHREADS) s_cnt[t] = 0;    // s_cnt, s_cur and s_misc are adjacent
+    for (int t = tid; t < (nA+1)*acc_stride; t += NT) s_acc[t] = 0.;
+    for (int t = tid; t < 2*TILE*ND; t += NT) s_D[t] = 0.;
+    for (int t = tid; t < 2*(PNL_MAXQ+2)+4; t += NT) s_cnt[t] = 0;    // s_cnt, s_cur and s_misc are adjacent
     __syncthreads();
 
     // ---- classification ------------------------------------------------------------------------
@@ -617,7 +646,9 @@ k_tile_distant(const DevProblem P, const int2 *__restrict__ tiles, double *__res
     int cnt234[3] = {0, 0, 0};
 #pragma unroll 2
     for (int it = 0; it < PER_THREAD; it++) {
-        const int p = it*PNL_NTHREADS+tid;
+        const int praw = it*NT+tid;
+        const bool inside = (PAIRS%NT == 0) || praw < PAIRS;
+        const int p = inside ? praw : 0;
         const int j = p%TILE, i = (p/TILE+PNL_DIAG_MULT*j)%TILE;
         int q = 0;
         const int va0 = s_vid[(0*NV+0)*TILE+i], vb0 = s_vid[(1*NV+0)*TILE+j];
@@ -625,7 +656,7 @@ k_tile_distant(const DevProblem P, const int2 *__restrict__ tiles, double *__res
         // dense: upper triangle of the cell pairs, a-cells of the caller's range.  Cluster tiles: n1 == n2 -> unordered pairs
         // once (chunk pair a <= b); n1 != n2 -> every ordered pair (X in n1.cells, Y in n2.cells); identical cells share all
         // vertices and are left to the touching-pair lists like every other touching pair
-        bool ok = (va0 >= 0) && (vb0 >= 0) && !(ablate & 8) &&
+        bool ok = inside && (va0 >= 0) && (vb0 >= 0) && !(ablate & 8) &&
                   (CLUSTER ? (!sym || ta < tb || i < j) : ((ta < tb || i < j) && (ca >= cell_begin) && (ca < cell_end)));
         // variable order: this launch assembles the pairs of one order class only
         if (!CLUSTER && P.cur_class >= 0 && ok) {
@@ -662,7 +693,7 @@ k_tile_distant(const DevProblem P, const int2 *__restrict__ tiles, double *__res
         cnt234[0] += __popcll(__ballot(q == 2)); cnt234[1] += __popcll(__ballot(q == 3)); cnt234[2] += __popcll(__ballot(q == 4));
         wave_bucket_add(s_cnt, q > 4 ? q : 0, false);
         const int nq = q ? s_ttn[q] : 0;
-        const int cls = !q ? 0 : (nq == NA ? 1 : (nq == NB ? 2 : (nq > 0 ? 3 : 4)));
+        const int cls = !q ? 0 : (q == qA0 ? 1 : (q == qB0 ? 2 : (nq > 0 ? 3 : 4)));
         const unsigned short ent = (unsigned short)(p | ((q-2) << 12));
         // one returning atomic per class and wave
         const unsigned long long mA = __ballot(cls == 1), mB = __ballot(cls == 2), mC = __ballot(cls == 3), mF = __ballot(cls == 4);
@@ -708,7 +739,7 @@ k_tile_distant(const DevProblem P, const int2 *__restrict__ tiles, double *__res
             if (tid == 0) s_cur[0] = (int)atomicAdd(wl_count, (unsigned)nF);
             __syncthreads();
             const unsigned base = (unsigned)s_cur[0];
-            for (int t = tid; t < nF; t += PNL_NTHREADS) {
+            for (int t = tid; t < nF; t += NT) {
                 const int ent = s_l32[PAIRS-1-t];
                 const int p = ent & 4095, q = ent >> 12;
                 const int j = p%TILE, i = (p/TILE+PNL_DIAG_MULT*j)%TILE;
@@ -727,8 +758,8 @@ k_tile_distant(const DevProblem P, const int2 *__restrict__ tiles, double *__res
     }
     // statistics: one thread per order
 #pragma unroll
-    for (int r = 0; r < (PNL_MAXQ+PNL_NTHREADS)/PNL_NTHREADS; r++) {
-        const int q = 2+tid+r*PNL_NTHREADS;
+    for (int r = 0; r < (PNL_MAXQ+NT)/NT; r++) {
+        const int q = 2+tid+r*NT;
         if (q <= P.qmax) {
             const int cq = s_cnt[q];
             if (cq) {
@@ -786,21 +817,23 @@ k_tile_distant(const DevProblem P, const int2 *__restrict__ tiles, double *__res
     for (int pass = 0; pass < 2; pass++) {
         const int total = __builtin_amdgcn_readfirstlane(s_misc[pass]);
 #pragma unroll 1
-        for (int c0 = wave*64; c0 < total; c0 += PNL_NTHREADS) {
+        for (int c0 = wave*64; c0 < total; c0 += NT) {
             const int idx = c0+lane;
             const bool act = idx < total;
             const int ent = act ? (pass == 0 ? (int)s_list[idx] : s_l32[idx]) : 0;
-            const int p = ent & 4095, q = (ent >> 12)+2;
+            const int p = ent & 4095;
             const int j = p%TILE, i = (p/TILE+PNL_DIAG_MULT*j)%TILE;
-            const double *tab = s_tt+s_tto[q]*(4+DPE);
+            const int q = pass == 0 ? qA0 : qB0, to = __builtin_amdgcn_readfirstlane(s_tto[q]);
+            const double *tab = s_tt+to*(4+DPE);
+            const double *__restrict__ gwp = P.tt_wphi+to*DPE;
             double av[NC], bv[NC];
 #pragma unroll
             for (int k = 0; k < NC; k++) { av[k] = s_v[(0*NC+k)*TILE+i]; bv[k] = s_v[(1*NC+k)*TILE+j]; }
             PairAcc<DIM, DPE> R;
             R.clear();
             if (!act) continue;
-            if (pass == 0) eval_distant_fixed<DIM, DPE, KT, NA>(P, tab, av, bv, R);
-            else eval_distant_fixed<DIM, DPE, KT, NB>(P, tab, av, bv, R);
+            if (pass == 0) eval_distant_fixed<DIM, DPE, KT, NA>(P, tab, gwp, av, bv, R);
+            else eval_distant_fixed<DIM, DPE, KT, NB>(P, tab, gwp, av, bv, R);
             accumulate(R, i, j);
         }
     }
@@ -812,7 +845,7 @@ k_tile_distant(const DevProblem P, const int2 *__restrict__ tiles, double *__res
             int run = 0, nch = 0;
             for (int q = 2; q < 18 && q <= P.qmax; q++) {
                 const int nq = s_ttn[q], c = s_cnt[q];
-                if (!c || nq == 0 || nq == NA || nq == NB) continue;
+                if (!c || nq == 0 || q == qA0 || q == qB0) continue;
                 s_cur[q] = run;
                 for (int st = 0; st < c && nch < PNL_GEN_MAXCHUNKS; st += 64) s_chunk[nch++] = (q << 20) | ((run+st) << 7) | (min(64, c-st)-1);
                 run += c;
@@ -820,7 +853,7 @@ k_tile_distant(const DevProblem P, const int2 *__restrict__ tiles, double *__res
             s_misc[0] = nch;
         }
         __syncthreads();
-        for (int t = tid; t < nC; t += PNL_NTHREADS) {
+        for (int t = tid; t < nC; t += NT) {
             const int ent = s_list[PAIRS-1-t];
             const int q = (ent >> 12)+2;
             s_l32[atomicAdd(&s_cur[q], 1)] = ent & 4095;
@@ -828,7 +861,7 @@ k_tile_distant(const DevProblem P, const int2 *__restrict__ tiles, double *__res
         __syncthreads();
         const int nch = __builtin_amdgcn_readfirstlane(s_misc[0]);
 #pragma unroll 1
-        for (int ch = wave; ch < nch; ch += PNL_NTHREADS/64) {
+        for (int ch = wave; ch < nch; ch += NT/64) {
             const int desc = __builtin_amdgcn_readfirstlane(s_chunk[ch]);
             const int q = desc >> 20, start = (desc >> 7) & 8191, cnt = (desc & 127)+1;
             const bool act = lane < cnt;
@@ -839,7 +872,10 @@ k_tile_distant(const DevProblem P, const int2 *__restrict__ tiles, double *__res
             for (int k = 0; k < NC; k++) { av[k] = s_v[(0*NC+k)*TILE+i]; bv[k] = s_v[(1*NC+k)*TILE+j]; }
             PairAcc<DIM, DPE> R;
             R.clear();
-            eval_distant_lds<DIM, DPE, KT>(P, s_tt+s_tto[q]*(4+DPE), 4+DPE, s_ttn[q], av, bv, R);
+            const int nq = __builtin_amdgcn_readfirstlane(s_ttn[q]), to = __builtin_amdgcn_readfirstlane(s_tto[q]);
+            if (nq == NB) eval_distant_fixed<DIM, DPE, KT, NB>(P, s_tt+to*(4+DPE), P.tt_wphi+to*DPE, av, bv, R);
+            else if (nq == NA) eval_distant_fixed<DIM, DPE, KT, NA>(P, s_tt+to*(4+DPE), P.tt_wphi+to*DPE, av, bv, R);
+            else eval_distant_lds<DIM, DPE, KT>(P, s_tt+to*(4+DPE), 4+DPE, nq, av, bv, R);
             if (act) accumulate(R, i, j);
         }
     }
@@ -849,7 +885,7 @@ k_tile_distant(const DevProblem P, const int2 *__restrict__ tiles, double *__res
     const int *__restrict__ dofA = CLUSTER ? CT.chunk_dofs+(size_t)ta*CT.chunk_stride : P.blk_dofs+(size_t)ta*P.blk_stride;
     const int *__restrict__ dofB = CLUSTER ? CT.chunk_dofs+(size_t)tb*CT.chunk_stride : P.blk_dofs+(size_t)tb*P.blk_stride;
     if (!(ablate & 4)) {
-    for (int t = tid; t < nA*nB; t += PNL_NTHREADS) {
+    for (int t = tid; t < nA*nB; t += NT) {
         const int r = t/nB, c = t-r*nB;
         const double v = s_acc[r*acc_stride+c];
         if (v != 0.) {
@@ -865,12 +901,12 @@ k_tile_distant(const DevProblem P, const int2 *__restrict__ tiles, double *__res
     }
     // PNL_FLAG_SYMMETRIC_FLUSH (no mirror pass): the transposed image in its own sweep, consecutive threads along a row of A
     if (!CLUSTER && (ablate & 256))
-        for (int t = tid; t < nA*nB; t += PNL_NTHREADS) {
+        for (int t = tid; t < nA*nB; t += NT) {
             const int c = t/nA, r = t-c*nA;
             const double v = s_acc[r*acc_stride+c];
             if (v != 0.) atomic_add_f64(&A[(long long)dofB[c]*ldA+dofA[r]], v);
         }
-    for (int t = tid; t < 2*TILE*ND; t += PNL_NTHREADS) {
+    for (int t = tid; t < 2*TILE*ND; t += NT) {
         const double v = s_D[t];
         if (v != 0.) {
             const int side = t/(TILE*ND), rem = t-side*TILE*ND;
@@ -887,8 +923,8 @@ k_tile_distant(const DevProblem P, const int2 *__restrict__ tiles, double *__res
     __syncthreads();
     }   // tile loop
 #pragma unroll
-    for (int r = 0; r < (PNL_MAXQ+PNL_NTHREADS)/PNL_NTHREADS; r++) {
-        const int q = 2+tid+r*PNL_NTHREADS;
+    for (int r = 0; r < (PNL_MAXQ+NT)/NT; r++) {
+        const int q = 2+tid+r*NT;
         if (st_cnt[r]) {
             atomicAdd(&P.counters[8+q], st_cnt[r]);
             atomicAdd(&P.counters[1], st_cnt[r]);

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Timing probe of the BASELINE.json configurations other than the bench workload (not the bench contract):
    C3 square / constant kernel / finite horizon / getSparse, C4 disc s=0.75 near field (assembleClusters),
-   C5 disc P2 + variable order dense, plus disc P2 constant order.     pw: disc P1, non-symmetric order s(x) per quadrature point (twoDomainNonSym).  usage: config_probe.py [c3|c4|c5|p2|pw] [size]"""
+   C5 disc P2 + variable order dense, plus disc P2 constant order.     pw: disc P1, non-symmetric order s(x) per quadrature point (twoDomainNonSym).  c1: the user's view of the headline path, mesh -> builder -> getDense, first and repeated call.  usage: config_probe.py [c1|c3|c4|c5|p2|pw] [size]"""
 import sys
 import time
 import numpy as np
@@ -20,7 +20,20 @@ def sync():
     torch.cuda.synchronize()
 
 
-if what in ('p2', 'c5'):
+if what == 'c1':
+    noRef = size or 6
+    t0 = time.time(); mesh = disc(noRef); t1 = time.time()
+    dm = P1_DoFMap(mesh, PHYSICAL); t2 = time.time()
+    b = nonlocalBuilder(dm, getFractionalKernel(2, 0.5), {'target_order': 0.5}, zeroExterior=True); t3 = time.time()
+    print('c1 noRef {} N {}: mesh {:.2f} s, dofmap {:.2f} s, builder (tables) {:.2f} s'.format(noRef, dm.num_dofs, t1-t0, t2-t1, t3-t2), flush=True)
+    for rep in range(3):
+        sync(); t0 = time.time()
+        A = b.getDense()
+        sync(); t1 = time.time()
+        print('   getDense call {}: wall {:.3f} s, device {:.1f} ms, host phases {}'.format(rep, t1-t0, A.info['phase_ms']['total'],
+                                                                                     {k: round(v, 3) for k, v in A.info.get('host_s', {}).items()}), flush=True)
+        del A
+elif what in ('p2', 'c5'):
     noRef = size or 5
     sectors = int(sys.argv[3]) if len(sys.argv) > 3 else 6
     mesh = disc(noRef, sectors=sectors)
