@@ -65,7 +65,7 @@ struct pnl_context {
     DevProblem P;
     DevBuf b_cellv, b_ccen, b_cvol, b_ch, b_clog, b_cvid, b_cdof, b_cslot, b_blk_ndof, b_blk_dofs, b_perm, b_off, b_bary, b_w, b_phi,
         b_foff, b_fbary, b_fw, b_bvid, b_bv, b_bgeo, b_counters, b_D, b_tiles,
-        b_vec[6], b_clabel, b_blabel, b_clsof, b_scal, b_wl, b_wlcount, b_ttn, b_ttoff, b_tttab, b_ttwphi, b_wlsorted, b_wlaux,
+        b_vec[6], b_clabel, b_blabel, b_clsof, b_scal, b_wl, b_wlcount, b_tilectr, b_ttn, b_ttoff, b_tttab, b_ttwphi, b_wlsorted, b_wlaux,
         b_vertices, b_sp_indptr, b_sp_indices, b_mp_pairs, b_mp_masks, b_mp_wl, b_mp_sorted, b_mp_aux, b_bi_cells, b_bi_facets,
         b_bi_masks, b_cp[28], b_cpD, b_wlds, b_wlpair, b_h2[20];
     H2Dev h2;
@@ -585,6 +585,8 @@ int launch_tiles(pnl_context *ctx, int ntiles_all, double *A, int64_t ldA, int c
         int rc;
         if ((rc = ensure(ctx, ctx->b_wlcount, sizeof(unsigned)))) return rc;
         HIPCHK(ctx, hipMemsetAsync(ctx->b_wlcount.p, 0, sizeof(unsigned), ctx->stream));
+        if ((rc = ensure(ctx, ctx->b_tilectr, sizeof(unsigned)))) return rc;
+        HIPCHK(ctx, hipMemsetAsync(ctx->b_tilectr.p, 0, sizeof(unsigned), ctx->stream));
     }
     auto kfun = k_tile_distant<DIM, DPE, TILE, KT, false>;
     HIPCHK(ctx, hipFuncSetAttribute((const void*)kfun, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -595,7 +597,8 @@ int launch_tiles(pnl_context *ctx, int ntiles_all, double *A, int64_t ldA, int c
     if (grid > 0)
         hipLaunchKernelGGL(kfun, dim3(grid), dim3(tile_threads(DPE, KT)), lds, ctx->stream, tile_problem(ctx), (const int2*)ctx->b_tiles.p+ctx->tile_off, A,
                            (long long)ldA, (double*)(ctx->have_tile_order ? ctx->b_Dt.p : ctx->b_D.p), cell_begin, cell_end, acc_stride, (int4*)ctx->b_wl.p,
-                           (unsigned*)ctx->b_wlcount.p, ctx->wl_cap, ctx->ablate | (ctx->symflush ? 256 : 0), ntiles, ClusterTiles{});
+                           (unsigned*)ctx->b_wlcount.p, ctx->wl_cap, ctx->ablate | (ctx->symflush ? 256 : 0), ntiles, ClusterTiles{},
+                           (unsigned*)ctx->b_tilectr.p);
     HIPCHK(ctx, hipGetLastError());
     HIPCHK(ctx, hipEventRecord(ctx->ev[6], ctx->stream));
     {
@@ -896,6 +899,8 @@ int clusters_tiled_impl(pnl_context *ctx, const pnl_cluster_plan *pl, ClusterTil
         if ((rc = ensure(ctx, ctx->b_wlpair, (size_t)ctx->wl_cap*sizeof(int)))) return rc;
         if ((rc = ensure(ctx, ctx->b_wlcount, sizeof(unsigned)))) return rc;
         HIPCHK(ctx, hipMemsetAsync(ctx->b_wlcount.p, 0, sizeof(unsigned), ctx->stream));
+        if ((rc = ensure(ctx, ctx->b_tilectr, sizeof(unsigned)))) return rc;
+        HIPCHK(ctx, hipMemsetAsync(ctx->b_tilectr.p, 0, sizeof(unsigned), ctx->stream));
         CT.wl_ds = (int2*)ctx->b_wlds.p; CT.wl_pair = (int*)ctx->b_wlpair.p;
     }
     if (pl->ntiles > 0) {
@@ -908,7 +913,7 @@ int clusters_tiled_impl(pnl_context *ctx, const pnl_cluster_plan *pl, ClusterTil
         const int grid = std::min(pl->ntiles, 256*std::max(per_cu, 1));
         hipLaunchKernelGGL(kfun, dim3(grid), dim3(tile_threads(DPE, KT)), lds, ctx->stream, ctx->P, (const int2*)nullptr, (double*)nullptr, 0ll,
                            (double*)nullptr, 0, ctx->nc, acc_stride, (int4*)ctx->b_wl.p, (unsigned*)ctx->b_wlcount.p, ctx->wl_cap, 0,
-                           pl->ntiles, CT);
+                           pl->ntiles, CT, (unsigned*)ctx->b_tilectr.p);
         HIPCHK(ctx, hipGetLastError());
     }
     HIPCHK(ctx, hipEventRecord(ctx->ev[6], ctx->stream));

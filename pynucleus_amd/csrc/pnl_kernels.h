@@ -553,7 +553,8 @@ template <int DIM, int DPE, int TILE, int KT, bool CLUSTER>
 __global__ void __launch_bounds__(tile_threads(DPE, KT), tile_waves(DPE, KT))
 k_tile_distant(const DevProblem P, const int2 *__restrict__ tiles, double *__restrict__ A, long long ldA,
                double *__restrict__ Dglob, int cell_begin, int cell_end, int acc_stride, int4 *__restrict__ worklist,
-               unsigned *__restrict__ wl_count, unsigned wl_cap, int ablate, int ntiles, const ClusterTiles CT) {
+               unsigned *__restrict__ wl_count, unsigned wl_cap, int ablate, int ntiles, const ClusterTiles CT,
+               unsigned *__restrict__ tile_ctr) {
     using S = TileSmem<DIM, DPE, TILE>;
     constexpr int NV = S::NV, NC = S::NC, ND = S::ND, NT = tile_threads(DPE, KT);
     constexpr int PAIRS = TILE*TILE, PER_THREAD = (PAIRS+NT-1)/NT;
@@ -588,9 +589,11 @@ k_tile_distant(const DevProblem P, const int2 *__restrict__ tiles, double *__res
         qA0 = (n == ((DIM == 2) ? 3 : 2)) ? q : qA0;
         qB0 = (n == ((DIM == 2) ? 6 : 3)) ? q : qB0;
     }
-    // persistent workgroups: each one walks the tile list with stride gridDim.x (heavy tiles come first in the list)
+    // persistent workgroups: the first tile by block index, every further one from a global counter (heavy tiles come first in
+    // the list and tile costs differ by an order of magnitude: a static stride leaves 14 % of the wave slots idle at the end)
+    __shared__ int s_tile_next;
 #pragma unroll 1
-    for (int tile_idx = blockIdx.x; tile_idx < ntiles; tile_idx += gridDim.x) {
+    for (int tile_idx = blockIdx.x; tile_idx < ntiles; tile_idx = s_tile_next) {
     // dense: (block a, block b) of consecutive cells; cluster tiles: (chunk of n1.cells, chunk of n2.cells) of a cluster pair
     const int ta = CLUSTER ? CT.chunkA[tile_idx] : tiles[tile_idx].x, tb = CLUSTER ? CT.chunkB[tile_idx] : tiles[tile_idx].y;
     const int nA = CLUSTER ? CT.chunk_ndof[ta] : P.blk_ndof[ta], nB = CLUSTER ? CT.chunk_ndof[tb] : P.blk_ndof[tb];
@@ -732,6 +735,9 @@ k_tile_distant(const DevProblem P, const int2 *__restrict__ tiles, double *__res
         for (int k = 0; k < 3; k++) if (cnt234[k]) atomicAdd(&s_cnt[2+k], cnt234[k]);
     }
     __syncthreads();
+    // next tile of this workgroup (every thread has read the previous value before the barrier above; the barrier at the end
+    // of the tile publishes this one)
+    if (tid == 0) s_tile_next = (int)(gridDim.x+atomicAdd(tile_ctr, 1u));
     {
         // far pairs: one reservation in the global work list per tile, then a coalesced copy
         const int nF = s_misc[2];
