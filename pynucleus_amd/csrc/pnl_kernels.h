@@ -77,10 +77,13 @@ __device__ __forceinline__ double pnl_exp(double y) {
 template <int KT>
 __device__ __forceinline__ double kern_eval(const DevKernel &k, double d2) {
     if (KT == 2) {
-        double r = __builtin_amdgcn_rsq(d2);
-        const double e = __builtin_fma(-(d2*r), r, 1.0);
-        r = __builtin_fma(r, e*__builtin_fma(0.375, e, 0.5), r);
-        return (r*r)*r;
+        // d2^(-3/2) = r^3 (1 - e)^(-3/2) with r = v_rsq_f64(d2) (~2^-23 relative), e = 1 - d2 r^2 (|e| < 3e-7):
+        // r^3 (1 + e (3/2 + 15/8 e)), the next term 35/16 e^3 is below 1e-19; six operations after the rsq, chain depth five
+        const double r = __builtin_amdgcn_rsq(d2);
+        const double t = r*r;
+        const double e = __builtin_fma(-d2, t, 1.0);
+        const double g0 = r*t;
+        return __builtin_fma(g0, e*__builtin_fma(1.875, e, 1.5), g0);
     } else if (KT == 1) {
         // exponent = -qm/4 (s a multiple of 1/4 in 1D / 2D): d2^(-1/2) from v_rsq_f64 (~2^-23 relative) + one Halley step
         // (cubic: r (1 + e/2 + 3 e^2/8), e = 1 - d2 r^2, five operations for full precision), for odd qm one more refined
@@ -943,8 +946,11 @@ k_tile_distant(const DevProblem P, const int2 *__restrict__ tiles, double *__res
 // wave-wide sum with DPP row shifts / broadcasts (no LDS traffic); result in every lane
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ double dpp_add(double v) {
-    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xf, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xf, false);
+    // full row mask: lanes without a source read 0 (bound_ctrl), so the destination needs no zero-initialised "old" value
+    // (two v_mov_b32 less per step); partial row masks keep old = 0 in the disabled rows
+    constexpr bool BC = ROW_MASK == 0xf;
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xf, BC);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xf, BC);
     return v+__hiloint2double(hi, lo);
 }
 __device__ __forceinline__ double wave_sum(double v) {
@@ -957,6 +963,44 @@ __device__ __forceinline__ double wave_sum(double v) {
     const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63);
     const int hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
     return __hiloint2double(hi, lo);
+}
+
+// Three wave-wide sums at once (the column sums of the 3-point rule): the first two butterfly stages pack the three inputs
+// by lane & 3 (lanes 0, 1 -> a, b; lanes 2, 3 -> c), so that from then on ONE value per lane is reduced over the lanes of
+// equal lane & 3: row rotations by 4 and 8, then the gfx950 row / half-wave swaps (v_permlane16_swap, v_permlane32_swap).
+// 39 VALU operations instead of 3 x 24 for three separate wave_sum calls.
+template <int CTRL>
+__device__ __forceinline__ double dpp_get(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double add_xor16(double v) {      // v[l] + v[l ^ 16]
+    const auto lo = __builtin_amdgcn_permlane16_swap(__double2loint(v), __double2loint(v), false, false);
+    const auto hi = __builtin_amdgcn_permlane16_swap(__double2hiint(v), __double2hiint(v), false, false);
+    return __hiloint2double(hi[0], lo[0])+__hiloint2double(hi[1], lo[1]);
+}
+__device__ __forceinline__ double add_xor32(double v) {      // v[l] + v[l ^ 32]
+    const auto lo = __builtin_amdgcn_permlane32_swap(__double2loint(v), __double2loint(v), false, false);
+    const auto hi = __builtin_amdgcn_permlane32_swap(__double2hiint(v), __double2hiint(v), false, false);
+    return __hiloint2double(hi[0], lo[0])+__hiloint2double(hi[1], lo[1]);
+}
+__device__ __forceinline__ void wave_sum3(double a, double b, double c, double &A, double &B, double &C) {
+    const int lane = threadIdx.x & 63;
+    const bool o1 = (lane & 1) != 0, o2 = (lane & 2) != 0;
+    double x = o1 ? b : a;
+    x += dpp_get<0xB1>(o1 ? a : b);            // quad_perm [1,0,3,2]: even lanes hold a pair sum of a, odd lanes of b
+    const double y = c+dpp_get<0xB1>(c);       // pair sums of c in both lanes
+    double z = o2 ? y : x;
+    z += dpp_get<0x4E>(o2 ? x : y);            // quad_perm [2,3,0,1]: lane & 3 = 0: quad sum of a, 1: of b, 2 and 3: of c
+    z += dpp_get<0x124>(z);                    // row_ror:4
+    z += dpp_get<0x128>(z);                    // row_ror:8 -> row sums, by lane & 3
+    z = add_xor16(z);
+    z = add_xor32(z);
+    const int lo = __double2loint(z), hi = __double2hiint(z);
+    A = __hiloint2double(__builtin_amdgcn_readlane(hi, 0), __builtin_amdgcn_readlane(lo, 0));
+    B = __hiloint2double(__builtin_amdgcn_readlane(hi, 1), __builtin_amdgcn_readlane(lo, 1));
+    C = __hiloint2double(__builtin_amdgcn_readlane(hi, 2), __builtin_amdgcn_readlane(lo, 2));
 }
 
 // sum over the 16 lanes of a DPP row, result in every lane of the row
@@ -1131,8 +1175,11 @@ k_tile_pure(const DevProblem P, const int2 *__restrict__ tiles, int ntiles, doub
             // diagonal block of cell j: column sums over all cells i of the wave
             const double wa = valid ? vola : 0.;
             double cw[NP];
+            if (NP == 3) wave_sum3(wa*c[0], wa*c[1], wa*c[NP-1], cw[0], cw[1], cw[NP-1]);
+            else {
 #pragma unroll
-            for (int jp = 0; jp < NP; jp++) cw[jp] = (symflush & 32) ? wa*c[jp] : wave_sum(wa*c[jp]);
+                for (int jp = 0; jp < NP; jp++) cw[jp] = wave_sum(wa*c[jp]);
+            }
             if (lane < ND) {
                 int a = 0, idx = lane;
                 while (idx >= DPE-a) { idx -= DPE-a; a++; }
