@@ -1238,9 +1238,11 @@ int pointwise_impl(pnl_context *ctx, double *A, int64_t ldA, int zero_exterior, 
         int per_cu = 1;
         (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)mfun, PNL_NTHREADS, lds);
         const int grid = std::min((int)mixed.size(), 256*std::max(per_cu, 1));
+        if ((rc = ensure(ctx, ctx->b_tilectr, sizeof(unsigned)))) return rc;
+        HIPCHK(ctx, hipMemsetAsync(ctx->b_tilectr.p, 0, sizeof(unsigned), ctx->stream));
         hipLaunchKernelGGL(mfun, dim3(grid), dim3(PNL_NTHREADS), lds, ctx->stream, P, W, (const int2*)ctx->b_tiles.p, (int)mixed.size(), A,
                            (long long)ldA, (double*)ctx->b_D.p, acc_stride, (int4*)ctx->b_wl.p, (unsigned*)ctx->b_wlcount.p, ctx->wl_cap,
-                           cell_begin, cell_end);
+                           cell_begin, cell_end, (unsigned*)ctx->b_tilectr.p);
     } else if (!mixed.empty())
         hipLaunchKernelGGL((k_pw_classify<DIM>), dim3((unsigned)mixed.size()), dim3(PNL_NTHREADS), 0, ctx->stream, P, W,
                            (const int2*)ctx->b_tiles.p, (int4*)ctx->b_wl.p, (unsigned*)ctx->b_wlcount.p, ctx->wl_cap, cell_begin, cell_end);

@@ -561,7 +561,7 @@ template <int DIM>
 __global__ void __launch_bounds__(PNL_NTHREADS, 1)
 k_pw_mixed(const DevProblem P, const PwDev W, const int2 *__restrict__ tiles, int ntiles, double *__restrict__ A, long long ldA,
            double *__restrict__ Dglob, int acc_stride, int4 *__restrict__ wl, unsigned *__restrict__ wl_count, unsigned wl_cap,
-           int cell_begin, int cell_end) {
+           int cell_begin, int cell_end, unsigned *__restrict__ tile_ctr) {
     constexpr int T = 64, NV = DIM+1, DPE = NV, NC = NV*DIM, ND = DPE*(DPE+1)/2, ST = 4+DPE, MAXN = PNL_PW_LANE_MAXPTS;
     extern __shared__ double smem[];
     double *s_rule = smem;                               // [MAXN][ST]
@@ -575,12 +575,15 @@ k_pw_mixed(const DevProblem P, const PwDev W, const int2 *__restrict__ tiles, in
     double *s_acc1 = (double*)(s_slotb+T*DPE);           // [nA+1][acc_stride] XY, then the same for YX transposed
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     unsigned long long nass = 0, nev = 0;
+    // first tile by block index, the following ones from a global counter (tile costs differ widely, see k_tile_distant)
+    __shared__ int s_tile_next;
 #pragma unroll 1
-    for (int tile_idx = blockIdx.x; tile_idx < ntiles; tile_idx += gridDim.x) {
+    for (int tile_idx = blockIdx.x; tile_idx < ntiles; tile_idx = s_tile_next) {
         const int ta = tiles[tile_idx].x, tb = tiles[tile_idx].y;
         const int nA = P.blk_ndof[ta], nB = P.blk_ndof[tb];
         double *s_acc2 = s_acc1+(size_t)(nA+1)*acc_stride;
         __syncthreads();
+        if (tid == 0) s_tile_next = (int)(gridDim.x+atomicAdd(tile_ctr, 1u));      // published by the barriers below
         if (tid < 3*PNL_PW_NBUCK) s_cnt[tid] = 0;
         for (int t = tid; t < 2*(nA+1)*acc_stride; t += PNL_NTHREADS) s_acc1[t] = 0.;
         for (int t = tid; t < 2*T*ND; t += PNL_NTHREADS) s_Da[t] = 0.;
