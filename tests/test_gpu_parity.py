@@ -366,3 +366,82 @@ def test_interval_stored_errors_through_the_gpu(element, s, noRef, stored):
     C = 2.**(-2.*s)*gamma(0.5)/gamma((1+2.*s)/2.)/gamma(1.+s)
     hs = np.sqrt(abs(b@u-C*sqrt(pi)*gamma(s+1)/gamma(s+3/2)))
     assert abs(hs-stored) <= 1e-8*stored, (hs, stored)
+
+
+# ---- bench-size cases (BASELINE.json configs[1] family): oracle on shards, size-independent properties on the whole ------
+def test_disc_P1_dense_noRef5_with_uniform_tiles():
+    """N = 3 025, 1.9e7 pairs (6 s of oracle): the first size at which most pairs run through the uniform-tile kernel"""
+    A, _ = _compare(_build('disc', 5, 0.5, params={'target_order': 0.5}))
+    cnt = A.info['counters']
+    assert cnt.get('uniformTilePairs', 0) > 0.3*cnt['numAssembledCellPairs'], cnt
+
+
+def test_bench_size_shard_against_oracle():
+    """noRef 6 (N = 12 097, 3.0e8 pairs): the pairs whose first cell lies in a 96-cell slab that cuts through 64-cell blocks,
+    GPU shard against oracle shard entry-wise (the reference's cellNo1 split, NA:1280-1285) -- mixed, uniform and
+    range-filtered tiles at a size whose full oracle run would take two minutes"""
+    import torch
+    from oracle.oracle import OracleProblem
+    b = _build('disc', 6, 0.5, params={'target_order': 0.5})
+    N, nc = b.dm.num_dofs, b.mesh.num_cells
+    c0, c1 = nc//2+17, nc//2+17+96
+    ctx = b.context()
+    A = torch.zeros((N, N), dtype=torch.float64, device='cuda')
+    ctx.assemble_dense(A.data_ptr(), N, True, c0, c1)
+    ctx.synchronize()
+    cnt = ctx.counters()
+    Aref, cref, _ = OracleProblem(b.tables).get_dense(c0, c1)
+    for key in ('numAssembledCellPairs', 'numIntegrations', 'numBoundaryPairs', 'orders', 'singular'):
+        assert cnt[key] == cref[key], (key, cnt[key], cref[key])
+    err = np.abs(A.cpu().numpy()-Aref).max()/np.abs(Aref).max()
+    assert err < TOL, err
+
+
+def test_bench_size_properties():
+    """the bench workload itself (noRef 7, N = 48 769, 4.83e9 pairs, 19 GB): pair count, symmetry, determinism of the counters,
+    two cellNo1 shards (written with the multi-rank symmetric flush) adding up to the whole (linearity over the pair partition), and the known answer of the driver
+    problem: with f = 1 the energy b.u converges to C(2, s) pi / (s + 1) (analytic solution C (1-|x|^2)^s), the discrete
+    energy approaching it from below with the mesh"""
+    import torch
+    from math import gamma, pi
+    s = 0.5
+    b = _build('disc', 7, s, params={'target_order': 0.5})
+    N, nc = b.dm.num_dofs, b.mesh.num_cells
+    A = b.getDense()
+    cnt = A.info['counters']
+    assert cnt['numCellPairs'] == nc*(nc+1)//2
+    assert sum(cnt['orders'].values())+sum(cnt['singular'].values()) == cnt['numAssembledCellPairs']
+    M = A.A
+    scale = float(M.abs().max())
+    blk = 8192
+    for i in range(0, N, blk):                       # symmetry, blockwise (no second 19 GB copy)
+        assert float((M[i:i+blk, :]-M[:, i:i+blk].T).abs().max()) <= 1e-13*scale
+    # shards: the sum of two cell ranges is the operator
+    ctx = b.context()
+    P = torch.zeros((N, N), dtype=torch.float64, device='cuda')
+    half = nc//2+29
+    SYMMETRIC_FLUSH = 2                                # PNL_FLAG_SYMMETRIC_FLUSH: both shards accumulate into one block, no mirror pass
+    ctx.assemble_dense(P.data_ptr(), N, True, 0, half, SYMMETRIC_FLUSH)
+    c_lo = ctx.counters()
+    ctx.assemble_dense(P.data_ptr(), N, True, half, nc, SYMMETRIC_FLUSH)
+    c_hi = ctx.counters()
+    ctx.synchronize()
+    assert c_lo['numAssembledCellPairs']+c_hi['numAssembledCellPairs'] == cnt['numAssembledCellPairs']
+    assert c_lo['numIntegrations']+c_hi['numIntegrations'] == cnt['numIntegrations']
+    for i in range(0, N, blk):
+        assert float((P[i:i+blk]-M[i:i+blk]).abs().max()) <= 1e-12*scale
+    del P
+    # known answer
+    rhs = np.asarray(b.dm.assembleRHS(1.0))
+    u, its, res = A.solve_cg_jacobi(rhs, tol=1e-10, maxiter=500)
+    assert its < 200 and res < 1e-9
+    C2s = 2.**(-2.*s)*gamma(1.)/gamma(1.+s)**2        # C(d=2, s) = 2^{-2s} Gamma(d/2) / (Gamma((d+2s)/2) Gamma(1+s))
+    exact = C2s*pi/(s+1.)
+    energy = float(rhs@u)
+    assert 0. < exact-energy < 4e-3*exact, (energy, exact)
+    # ... at the rate of the method: |u - u_h|_Hs^2 = exact - energy = O(h) for s = 1/2 (boundary singularity), h ratio 4 to noRef 5
+    b5 = _build('disc', 5, s, params={'target_order': 0.5})
+    rhs5 = np.asarray(b5.dm.assembleRHS(1.0))
+    u5 = b5.getDense().solve_cg_jacobi(rhs5, tol=1e-10, maxiter=500)[0]
+    ratio = (exact-float(rhs5@u5))/(exact-energy)
+    assert 3. < ratio < 5.5, ratio
