@@ -828,11 +828,20 @@ int pairs_masked_impl(pnl_context *ctx, int np, const SparseOut &S, bool classif
         auto wfun = k_worklist_sorted<DIM, DPE, KT, true>;
         HIPCHK(ctx, hipFuncSetAttribute((const void*)wfun, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         const int nmin = ctx->wl_lane ? PNL_WL_LANE_MAXPTS+1 : 0;
+        // no masks (getSparse): diagonal blocks through the per-cell buffer, one scatter per cell at the end
+        constexpr int ND = DPE*(DPE+1)/2;
+        double *Dbuf = S.masks ? nullptr : (double*)ctx->b_D.p;
+        if (Dbuf) HIPCHK(ctx, hipMemsetAsync(Dbuf, 0, sizeof(double)*(size_t)ctx->ncp*ND, ctx->stream));
         if (ctx->wl_lane)
             hipLaunchKernelGGL((k_worklist_lane<DIM, DPE, KT, true>), dim3(256*4), dim3(PNL_NTHREADS), 0, ctx->stream, ctx->P,
-                               (const int4*)sorted, (const unsigned*)offs, (double*)nullptr, 0ll, (double*)nullptr, S, 0, ClusterTiles{});
+                               (const int4*)sorted, (const unsigned*)offs, (double*)nullptr, 0ll, Dbuf, S, 0, ClusterTiles{});
         hipLaunchKernelGGL(wfun, dim3(256*2), dim3(PNL_NTHREADS), lds, ctx->stream, ctx->P, (const int4*)sorted, (const unsigned*)offs,
-                           (const unsigned*)coff, (double*)nullptr, 0ll, (double*)nullptr, tab_max, S, PNL_MAXQ, nmin, ClusterTiles{});
+                           (const unsigned*)coff, (double*)nullptr, 0ll, Dbuf, tab_max, S, PNL_MAXQ, nmin, ClusterTiles{});
+        if (Dbuf) {
+            const long long n = (long long)ctx->nc*ND;
+            hipLaunchKernelGGL((k_scatter_diag_sparse<DPE>), dim3((unsigned)((n+PNL_NTHREADS-1)/PNL_NTHREADS)), dim3(PNL_NTHREADS), 0,
+                               ctx->stream, ctx->P, (const double*)Dbuf, ctx->nc, S);
+        }
         HIPCHK(ctx, hipGetLastError());
     }
     HIPCHK(ctx, hipEventRecord(ctx->ev[1], ctx->stream));

@@ -1758,6 +1758,25 @@ __device__ __forceinline__ void sparse_add_sym(const SparseOut &S, const unsigne
     else { sparse_add(S, I, J, v); sparse_add(S, J, I, v); }
 }
 
+// diagonal blocks of the mask-less sparse path: A[dof_a(c), dof_b(c)] += D_c[a, b] with the symmetric-entry semantics of
+// sparse_add_sym (one pattern search per cell entry instead of one per pair and entry)
+template <int DPE>
+__global__ void __launch_bounds__(PNL_NTHREADS)
+k_scatter_diag_sparse(const DevProblem P, const double *__restrict__ D, int nc, const SparseOut S) {
+    constexpr int ND = DPE*(DPE+1)/2;
+    const long long t = (long long)blockIdx.x*PNL_NTHREADS+threadIdx.x;
+    if (t >= (long long)nc*ND) return;
+    const double v = D[t];
+    if (v == 0.) return;
+    const int c = (int)(t/ND);
+    int idx = (int)(t-(long long)c*ND), a = 0;
+    while (idx >= DPE-a) { idx -= DPE-a; a++; }
+    const int b = a+idx;
+    const int I = P.cdof[(size_t)a*P.ncp+c], J = P.cdof[(size_t)b*P.ncp+c];
+    if (a == b) sparse_add(S, I, I, v);
+    else { sparse_add(S, I, J, v); sparse_add(S, J, I, v); }
+}
+
 // classification of explicit cell pairs (NO:280-378 + NO:493-540 with the exact fp64 order formula); entry =
 // (pair index, 0, rule offset, n | key << 16), key = order for distant pairs, 121 + (#shared vertices - 1) for touching ones
 template <int DIM, int DPE>
@@ -1893,27 +1912,58 @@ __global__ void k_wl_scan(const unsigned *__restrict__ hist, unsigned *__restric
     }
 }
 
+// Stable within a wave's slice: every wave owns a contiguous part of its workgroup's input range and hands out positions in
+// input order (ballot ranks), so runs of consecutive entries with one key stay consecutive.  The producers append whole
+// waves of neighbouring pairs (k_fh_pairs: 64 consecutive cells c1 against one c2), and the consumers run 64 consecutive
+// sorted entries per wave: coalesced cell data, neighbouring pattern rows, shared cells that can be summed over the wave.
 __global__ void __launch_bounds__(PNL_NTHREADS)
 k_wl_scatter(const int4 *__restrict__ wl, const unsigned *__restrict__ wl_count, unsigned wl_cap, const unsigned *__restrict__ offs,
              unsigned *__restrict__ cursor, int4 *__restrict__ sorted) {
-    __shared__ unsigned h[PNL_WL_BINS], base[PNL_WL_BINS];
+    constexpr int NW = PNL_NTHREADS/64;
+    __shared__ unsigned h[NW][PNL_WL_BINS], base[NW][PNL_WL_BINS];
     const unsigned count = min(*wl_count, wl_cap);
     const unsigned per = (count+gridDim.x-1)/gridDim.x;
-    const unsigned i0 = blockIdx.x*per, i1 = min(count, i0+per);
-    if (threadIdx.x < PNL_WL_BINS) h[threadIdx.x] = 0;
+    const unsigned b0 = blockIdx.x*per, b1 = min(count, b0+per);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned perw = ((b1 > b0 ? b1-b0 : 0u)+NW-1)/NW;
+    const unsigned i0 = min(b1, b0+wave*perw), i1 = min(b1, i0+perw);
+    const unsigned long long lt = (1ull << lane)-1ull;
+    for (int t = threadIdx.x; t < NW*PNL_WL_BINS; t += PNL_NTHREADS) (&h[0][0])[t] = 0;
     __syncthreads();
-    for (unsigned i = i0+threadIdx.x; i < i1; i += PNL_NTHREADS) atomicAdd(&h[(wl[i].w >> 16) & (PNL_WL_BINS-1)], 1u);
+    // pass 1: keys per wave slice; pass 2 hands out positions with the same loop
+    auto sweep = [&](bool place) {
+        for (unsigned i = i0; i < i1; i += 64) {
+            const bool act = i+lane < i1;
+            int4 e = make_int4(0, 0, 0, 0);
+            if (act) e = wl[i+lane];
+            const int q = act ? ((e.w >> 16) & (PNL_WL_BINS-1)) : -1;
+            unsigned long long todo = __ballot(act);
+            while (todo) {
+                const int leader = __ffsll((long long)todo)-1;
+                const int qL = __builtin_amdgcn_readlane(q, leader);
+                const unsigned long long same = __ballot(q == qL);
+                if (place) {
+                    const unsigned start = base[wave][qL]+h[wave][qL];          // the wave is the only writer of its row
+                    if (q == qL) sorted[start+__popcll(same & lt)] = e;
+                }
+                __builtin_amdgcn_wave_barrier();
+                if (lane == leader) h[wave][qL] += (unsigned)__popcll(same);
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                todo &= ~same;
+            }
+        }
+    };
+    sweep(false);
     __syncthreads();
     if (threadIdx.x < PNL_WL_BINS) {
-        base[threadIdx.x] = h[threadIdx.x] ? offs[threadIdx.x]+atomicAdd(&cursor[threadIdx.x], h[threadIdx.x]) : 0;
-        h[threadIdx.x] = 0;
+        unsigned tot = 0;
+        for (int w = 0; w < NW; w++) tot += h[w][threadIdx.x];
+        unsigned run = tot ? offs[threadIdx.x]+atomicAdd(&cursor[threadIdx.x], tot) : 0u;
+        for (int w = 0; w < NW; w++) { base[w][threadIdx.x] = run; run += h[w][threadIdx.x]; h[w][threadIdx.x] = 0; }
     }
     __syncthreads();
-    for (unsigned i = i0+threadIdx.x; i < i1; i += PNL_NTHREADS) {
-        const int4 e = wl[i];
-        const int q = (e.w >> 16) & (PNL_WL_BINS-1);
-        sorted[base[q]+atomicAdd(&h[q], 1u)] = e;
-    }
+    sweep(true);
 }
 
 // Distant pairs of the high orders from the sorted work list (NO:722-789; few pairs, thousands of point pairs each): a
@@ -2087,6 +2137,9 @@ k_worklist_sorted(const DevProblem P, const int4 *__restrict__ sorted, const uns
                 if (e < NG) {
                     const int a = e/DPE, b = e-a*DPE;
                     sparse_add_sym(S, mask, 2*DPE, a, DPE+b, P.cdof[(size_t)a*P.ncp+c1], P.cdof[(size_t)b*P.ncp+c2], -vv*val);
+                } else if (e < NACC && !S.masks && Dglob != nullptr) {
+                    const bool second = e >= NG+ND;
+                    atomic_add_f64(&Dglob[(size_t)(second ? c2 : c1)*ND+(e-NG-(second ? ND : 0))], vv*val);
                 } else if (e < NACC) {
                     // upper triangle of a diagonal block: entry index -> (a, b), a <= b
                     const bool second = e >= NG+ND;
@@ -2184,6 +2237,36 @@ k_worklist_lane(const DevProblem P, const int4 *__restrict__ sorted, const unsig
             if (lane == 0 && tot > 0.) atomicAdd(&P.counters[2], (unsigned long long)tot);
         } else
             eval_distant_lds<DIM, DPE, KT>(P, s_rule, STP, (dbg & 4) ? 1 : n, av, bv, R);
+        // without masks (getSparse) the diagonal blocks go through the per-cell buffer like in the dense path and are
+        // scattered once per cell (k_scatter_diag_sparse): 9 instead of 15 pattern searches per pair.  The sorted list keeps
+        // the producer's runs (k_fh_pairs lays 64 consecutive cells c1 against one c2), so a wave holds a few distinct
+        // cells on one side: their blocks are summed over the wave first, one atomic per distinct cell instead of one per lane
+        const bool dbuf = SPARSE && !cluster && !S.masks && Dglob != nullptr;
+        if (dbuf) {
+            const double vz = valid ? 2.*P.cvol[c1]*P.cvol[c2]*kern_scale<KT>(P.k) : 0.;
+#pragma unroll
+            for (int side = 0; side < 2; side++) {
+                const int cc = side ? c2 : c1;
+                unsigned long long todo = __ballot(valid);
+#pragma unroll 1
+                for (int round = 0; round < 4 && todo; round++) {
+                    const int leader = __ffsll((long long)todo)-1;
+                    const int cL = __builtin_amdgcn_readlane(cc, leader);
+                    const unsigned long long same = __ballot(valid && cc == cL) & todo;
+                    const bool mine = (same >> lane) & 1ull;
+#pragma unroll
+                    for (int e = 0; e < ND; e++) {
+                        const double s = wave_sum(mine ? vz*(side ? R.S2[e] : R.S1[e]) : 0.);
+                        if (lane == leader) atomic_add_f64(&Dglob[(size_t)cL*ND+e], s);
+                    }
+                    todo &= ~same;
+                }
+                if ((todo >> lane) & 1ull) {
+#pragma unroll
+                    for (int e = 0; e < ND; e++) atomic_add_f64(&Dglob[(size_t)cc*ND+e], vz*(side ? R.S2[e] : R.S1[e]));
+                }
+            }
+        }
         if (!valid) continue;
         const double vv = 2.*P.cvol[c1]*P.cvol[c2]*kern_scale<KT>(P.k);
         int ld1[DPE], ld2[DPE];
@@ -2214,8 +2297,10 @@ k_worklist_lane(const DevProblem P, const int4 *__restrict__ sorted, const unsig
                 for (int b = 0; b < DPE; b++) sparse_add_sym(S, mask, 2*DPE, a, DPE+b, ld1[a], ld2[b], -vv*R.G[a][b]);
 #pragma unroll
                 for (int b = a; b < DPE; b++) {
-                    sparse_add_sym(S, mask, 2*DPE, a, b, ld1[a], ld1[b], vv*R.S1[e]);
-                    sparse_add_sym(S, mask, 2*DPE, DPE+a, DPE+b, ld2[a], ld2[b], vv*R.S2[e]);
+                    if (!dbuf) {
+                        sparse_add_sym(S, mask, 2*DPE, a, b, ld1[a], ld1[b], vv*R.S1[e]);
+                        sparse_add_sym(S, mask, 2*DPE, DPE+a, DPE+b, ld2[a], ld2[b], vv*R.S2[e]);
+                    }
                     e++;
                 }
             }
