@@ -448,7 +448,7 @@ class nonlocalBuilder:
         dm = self.dm
         symmetric = not forceUnsymmetricMatrix
         if Anear is None:
-            indptr, indices = clusters.getSparseNearField(dm, Pnear, symmetric=symmetric)
+            indptr, indices = clusters.getSparseNearField(dm, Pnear, symmetric=symmetric, device=dev)
             Anear = (SSS_LinearOperator if symmetric else CSR_LinearOperator)(indptr, indices, dm.num_dofs, ctx, dev)
         Anear._bind()
         data_ptr, diag_ptr = Anear._ptrs()

@@ -180,10 +180,40 @@ def coveringCluster(dm):
 
 
 # ---------------------------------------------------------------------------------------------------------------------
-def getSparseNearField(dm, Pnear, symmetric=True):
+def getSparseNearField(dm, Pnear, symmetric=True, device=None):
     """sparsity pattern of the near field: CSR (indptr, indices); with symmetric=True only I > J is stored (SSS, the
-    diagonal lives in its own vector)"""
+    diagonal lives in its own vector).  With a torch device the keys of all blocks are generated, sorted and split into
+    rows there (5e7 entries at 49k DoFs: 0.6 s of numpy sort on the host, tens of ms on the GPU)."""
     N = dm.num_dofs
+    if device is not None and len(Pnear):
+        import torch
+        nr = np.array([len(cp.n1.dofs) for cp in Pnear], dtype=np.int64)
+        ncol = np.array([len(cp.n2.dofs) for cp in Pnear], dtype=np.int64)
+        rows_cat = torch.as_tensor(np.concatenate([np.asarray(cp.n1.dofs, dtype=np.int64) for cp in Pnear]), device=device)
+        cols_cat = torch.as_tensor(np.concatenate([np.asarray(cp.n2.dofs, dtype=np.int64) for cp in Pnear]), device=device)
+        size = torch.as_tensor(nr*ncol, device=device)
+        start = torch.cumsum(size, 0)-size
+        rp = torch.as_tensor(np.concatenate([[0], np.cumsum(nr)[:-1]]), device=device)
+        cp_ = torch.as_tensor(np.concatenate([[0], np.cumsum(ncol)[:-1]]), device=device)
+        nc_d = torch.as_tensor(ncol, device=device)
+        total = int((nr*ncol).sum())
+        blk = torch.repeat_interleave(torch.arange(len(Pnear), device=device), size, output_size=total)
+        loc = torch.arange(total, device=device)-start[blk]
+        r = torch.div(loc, nc_d[blk], rounding_mode='floor')
+        I = rows_cat[rp[blk]+r]
+        J = cols_cat[cp_[blk]+(loc-r*nc_d[blk])]
+        del blk, loc, r
+        keys = (I << 32) | J
+        if symmetric:
+            keys = keys[I > J]
+        del I, J
+        keys = torch.sort(keys).values
+        if keys.numel() > 1 and bool((keys[1:] == keys[:-1]).any()):
+            keys = torch.unique_consecutive(keys)
+        rows = keys >> 32
+        indptr = torch.zeros(N+1, dtype=torch.int64, device=device)
+        indptr[1:] = torch.cumsum(torch.bincount(rows, minlength=N), 0)
+        return indptr.to(torch.int32).cpu().numpy(), (keys & 0xffffffff).to(torch.int32).cpu().numpy()
     parts = []
     for cp in Pnear:
         I = np.asarray(cp.n1.dofs, dtype=np.int64)[:, None]

@@ -291,3 +291,19 @@ def test_two_ranks_row_sharded_near_field():
         assert p.exitcode == 0
     assert 0 < nnz_local < nnz_full
     assert e1 < 1e-11 and e2 < 1e-11
+
+
+def test_pattern_on_a_torch_device_equals_the_numpy_one():
+    """getSparseNearField(device=...) (keys generated and sorted with torch, on the GPU in production) gives the arrays of
+    the numpy route, SSS and CSR"""
+    import torch
+    from pynucleus_amd import disc, P1_DoFMap, PHYSICAL
+    from pynucleus_amd import clusters
+    dm = P1_DoFMap(disc(4), PHYSICAL)
+    root, Pnear, Pfar = clusters.getNearFieldClusters(dm, 3., 16, 200)
+    assert len(Pnear) > 10
+    for symmetric in (True, False):
+        a = clusters.getSparseNearField(dm, Pnear, symmetric)
+        b = clusters.getSparseNearField(dm, Pnear, symmetric, device=torch.device('cpu'))
+        assert a[0].dtype == b[0].dtype == np.int32 and a[1].dtype == b[1].dtype == np.int32
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
