@@ -526,14 +526,15 @@ class nearFieldPlan:
         for bit in range(16):
             for d in range(mesh.dim):
                 morton |= ((g[:, d] >> np.uint64(bit)) & np.uint64(1)) << np.uint64(mesh.dim*bit+d)
+        member = np.zeros(N+1, dtype=bool)                          # scratch flags, reset after every use (no O(N) work per node)
         for i, n in enumerate(nodes):
             # chunks of spatially compact cells (Morton order of the centres) share more DoFs: smaller LDS sub-blocks
             cells = n.cells[np.argsort(morton[n.cells], kind='stable')]
-            member = np.zeros(N+1, dtype=bool)
             member[n.dofs] = True
             # a chunk closes at `tile` cells or when one more cell would bring it above maxChunkDofs distinct DoFs (LDS budget)
             dall = dofs[cells]
             okall = (dall >= 0) & member[np.where(dall >= 0, dall, N)]
+            member[n.dofs] = False
             s0 = 0
             while s0 < cells.shape[0]:
                 s1 = min(s0+tile, cells.shape[0])
@@ -572,6 +573,9 @@ class nearFieldPlan:
         self.pair_dbase = np.zeros(len(pairs)+1, dtype=np.int64)
         d_cell, d_pair = [], []
         nV = mesh.dim+1
+        pos = np.full(nc, -1, dtype=np.int64)                       # scratch arrays over the cells, reset after every pair
+        in2 = np.zeros(nc, dtype=bool)
+        ptr, idx = adj
         for k, (a, b, cp) in enumerate(pairs):
             n1, n2 = nodes[a], nodes[b]
             sym = a == b
@@ -580,7 +584,6 @@ class nearFieldPlan:
             self.pair_dbase[k+1] = dbase+inter.shape[0]
             d_cell.append(inter)
             d_pair.append(np.full(inter.shape[0], k, dtype=np.int32))
-            pos = np.full(nc, -1, dtype=np.int64)
             pos[inter] = dbase+np.arange(inter.shape[0])
             ca = np.arange(self.node_chunk_off[a], self.node_chunk_off[a+1])
             cb = np.arange(self.node_chunk_off[b], self.node_chunk_off[b+1])
@@ -597,13 +600,13 @@ class nearFieldPlan:
             dsA.append(np.where(cellsA >= 0, pos[np.maximum(cellsA, 0)], -1))
             dsB.append(np.where(cellsB >= 0, pos[np.maximum(cellsB, 0)], -1))
             # touching element pairs {X, Y}, X in n1.cells, Y in n2.cells (folded, unique)
-            in2 = np.zeros(nc, dtype=bool)
             in2[n2.cells] = True
-            ptr, idx = adj
             cnt = ptr[n1.cells+1]-ptr[n1.cells]
             X = np.repeat(n1.cells, cnt)
-            Y = np.concatenate([idx[ptr[c]:ptr[c+1]] for c in n1.cells]) if n1.cells.shape[0] else np.zeros(0, dtype=np.int64)
+            # neighbours of all cells of n1 in one gather: position within the concatenated adjacency lists
+            Y = idx[np.repeat(ptr[n1.cells]-(np.cumsum(cnt)-cnt), cnt)+np.arange(int(cnt.sum()))]
             m = in2[Y]
+            in2[n2.cells] = False
             X, Y = X[m], Y[m]
             lo, hi = np.minimum(X, Y), np.maximum(X, Y)
             key = np.unique(lo.astype(np.int64)*nc+hi)
@@ -630,6 +633,7 @@ class nearFieldPlan:
                     bt_slot.append(pos[inter[cand[ci]]])
                     bt_cell.append(inter[cand[ci]])
                     bt_facet.append(facets[fi])
+            pos[inter] = -1
         cat = lambda L, dt, shape=None: (np.concatenate(L).astype(dt) if L else np.zeros((0,)+(shape or ()), dtype=dt))
         self.tile_chunkA, self.tile_chunkB = cat(tA, np.int32), cat(tB, np.int32)
         self.tile_pair, self.tile_flags = cat(tP, np.int32), cat(tF, np.int32)
