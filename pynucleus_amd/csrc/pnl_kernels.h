@@ -2563,7 +2563,10 @@ k_boundary_distant(const DevProblem P, double *__restrict__ Dglob, int cell_begi
     int overflow = 0;
     const int f0 = blockIdx.y*facets_per_chunk;
     const int f1 = min(P.nb, f0+facets_per_chunk);
+    const int lab1 = P.cur_class >= 0 ? P.clabel[cc] : 0;
     for (int f = f0; f < f1; f++) {
+        // variable order: this launch handles one order class; the test comes first, a pass skips most facets with two loads
+        if (P.cur_class >= 0 && P.cls_of[lab1*P.nlab+P.blabel[f]] != P.cur_class) continue;
         // facet data: wave-uniform, precomputed once per upload (centre, unit normal, length, logs)
         double fv[NF*DIM], fc[DIM], nrm[DIM];
         int fvid[NF];
@@ -2581,7 +2584,6 @@ k_boundary_distant(const DevProblem P, double *__restrict__ Dglob, int cell_begi
 #pragma unroll
             for (int m = 0; m < NF; m++) shared = shared || (vid[k] == fvid[m]);
         if (!active || shared) continue;
-        if (P.cur_class >= 0 && P.cls_of[P.clabel[cc]*P.nlab+P.blabel[f]] != P.cur_class) continue;
         double dc2 = 0.;
 #pragma unroll
         for (int d = 0; d < DIM; d++) dc2 += (cen[d]-fc[d])*(cen[d]-fc[d]);
