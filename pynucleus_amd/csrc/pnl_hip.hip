@@ -100,6 +100,7 @@ struct pnl_context {
     bool symflush = false;          // PNL_FLAG_SYMMETRIC_FLUSH of the current assembly
     bool ev_valid = false;
     unsigned long long visited_pairs = 0;
+    bool visited_is_assembled = false;      // finite-horizon tiles: every visited (non-REMOTE) pair is an assembled one
     bool tiles_launched = false;
     int ablate = 0;                 // debug: PNL_ABLATE env bits (1 no LDS accumulate, 2 no evaluation)
     bool tile_cell_filter = true;   // apply [cell_begin, cell_end) to the a-cells of the tiles too
@@ -798,7 +799,7 @@ int launch_singular_sparse(pnl_context *ctx, const SparseOut &S, const int4 *sor
 
 // classify == false: the work list b_mp_wl[0..np) has been filled on the device (k_fh_pairs)
 template <int DIM, int DPE, int KT>
-int pairs_masked_impl(pnl_context *ctx, int np, const SparseOut &S, bool classify = true, bool first = true) {
+int pairs_masked_impl(pnl_context *ctx, int np, const SparseOut &S, bool classify = true, bool first = true, bool keepD = false) {
     int rc;
     if ((rc = ensure(ctx, ctx->b_mp_wl, (size_t)np*sizeof(int4)))) return rc;
     if ((rc = ensure(ctx, ctx->b_mp_sorted, (size_t)np*sizeof(int4)))) return rc;
@@ -831,7 +832,7 @@ int pairs_masked_impl(pnl_context *ctx, int np, const SparseOut &S, bool classif
         // no masks (getSparse): diagonal blocks through the per-cell buffer, one scatter per cell at the end
         constexpr int ND = DPE*(DPE+1)/2;
         double *Dbuf = S.masks ? nullptr : (double*)ctx->b_D.p;
-        if (Dbuf) HIPCHK(ctx, hipMemsetAsync(Dbuf, 0, sizeof(double)*(size_t)ctx->ncp*ND, ctx->stream));
+        if (Dbuf && !keepD) HIPCHK(ctx, hipMemsetAsync(Dbuf, 0, sizeof(double)*(size_t)ctx->ncp*ND, ctx->stream));      // keepD: the tiles of a finite horizon have been there
         if (ctx->wl_lane)
             hipLaunchKernelGGL((k_worklist_lane<DIM, DPE, KT, true>), dim3(256*4), dim3(PNL_NTHREADS), 0, ctx->stream, ctx->P,
                                (const int4*)sorted, (const unsigned*)offs, (double*)nullptr, 0ll, Dbuf, S, 0, ClusterTiles{});
@@ -1346,18 +1347,53 @@ int horizon_impl(pnl_context *ctx, SparseOut S) {
     S.masks = nullptr;
     unsigned long long total = 0;
     bool first = true;
+    // The pairs inside the horizon are integrated by the tile kernel (LDS sub-block, one pattern search per sub-block entry
+    // instead of one per pair and entry); what it cannot do itself -- pairs cut by the horizon, touching pairs, orders
+    // without a packed rule -- it hands to the sorted sparse pipeline through the far list.  PNL_FH_NOTILES=1 keeps the
+    // pair generator k_fh_pairs, which sends every pair down that pipeline.
+    constexpr int TILE = (DPE == 6 || (DIM == 1 && DPE == 3)) ? 32 : 64, ND = DPE*(DPE+1)/2;
+    using TS = TileSmem<DIM, DPE, TILE>;
+    const int acc_stride = acc_stride_of(ctx->nU, TS::fixed_bytes);
+    const size_t lds = TS::fixed_bytes+sizeof(double)*(size_t)(ctx->nU+1)*acc_stride;
+    const bool use_tiles = T == TILE && lds <= 160*1024 && !getenv("PNL_FH_NOTILES");
+    ctx->visited_is_assembled = use_tiles;
     for (size_t t0 = 0; t0 < tiles.size(); t0 += chunk_tiles) {
         const int nt = (int)std::min(chunk_tiles, tiles.size()-t0);
         HIPCHK(ctx, hipMemsetAsync(ctx->b_wlcount.p, 0, sizeof(unsigned), ctx->stream));
         if (first) HIPCHK(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
-        hipLaunchKernelGGL((k_fh_pairs<DIM, DPE>), dim3(nt), dim3(PNL_NTHREADS), 0, ctx->stream, ctx->P, (const int2*)ctx->b_tiles.p+t0, T,
-                           (int2*)ctx->b_mp_pairs.p, (int4*)ctx->b_mp_wl.p, (unsigned*)ctx->b_wlcount.p, (unsigned)cap);
+        if (use_tiles) {
+            auto kfun = k_tile_distant<DIM, DPE, TILE, KT, false>;
+            HIPCHK(ctx, hipFuncSetAttribute((const void*)kfun, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            int per_cu = 2;
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)kfun, tile_threads(DPE, KT), lds);
+            if ((rc = ensure(ctx, ctx->b_tilectr, sizeof(unsigned)))) return rc;
+            HIPCHK(ctx, hipMemsetAsync(ctx->b_tilectr.p, 0, sizeof(unsigned), ctx->stream));
+            HIPCHK(ctx, hipMemsetAsync(ctx->b_D.p, 0, sizeof(double)*(size_t)ctx->ncp*ND, ctx->stream));
+            ClusterTiles CT{};
+            CT.S = S;
+            CT.wl_ds = (int2*)ctx->b_mp_pairs.p;                   // the pairs of the far-list entries
+            const int grid = std::min(nt, 256*std::max(per_cu, 1));
+            hipLaunchKernelGGL(kfun, dim3(grid), dim3(tile_threads(DPE, KT)), lds, ctx->stream, ctx->P, (const int2*)ctx->b_tiles.p+t0,
+                               (double*)nullptr, 0ll, (double*)ctx->b_D.p, 0, ctx->nc, acc_stride, (int4*)ctx->b_mp_wl.p,
+                               (unsigned*)ctx->b_wlcount.p, (unsigned)cap, 512, nt, CT, (unsigned*)ctx->b_tilectr.p);
+        } else
+            hipLaunchKernelGGL((k_fh_pairs<DIM, DPE>), dim3(nt), dim3(PNL_NTHREADS), 0, ctx->stream, ctx->P, (const int2*)ctx->b_tiles.p+t0, T,
+                               (int2*)ctx->b_mp_pairs.p, (int4*)ctx->b_mp_wl.p, (unsigned*)ctx->b_wlcount.p, (unsigned)cap);
         HIPCHK(ctx, hipGetLastError());
         unsigned np = 0;
         HIPCHK(ctx, hipMemcpyAsync(&np, ctx->b_wlcount.p, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        if (np > cap) return fail(ctx, PNL_ERR_STATE, "far list of the finite-horizon tiles overflowed (%u > %zu)", np, cap);
         total += np;
-        if (np && (rc = pairs_masked_impl<DIM, DPE, KT>(ctx, (int)np, S, false, false))) return rc;
+        if (np && (rc = pairs_masked_impl<DIM, DPE, KT>(ctx, (int)np, S, false, false, use_tiles))) return rc;
+        if (!np && use_tiles) {
+            // no far entries in this chunk: the diagonal blocks of its tiles still have to reach the matrix
+            const long long n = (long long)ctx->nc*ND;
+            hipLaunchKernelGGL((k_scatter_diag_sparse<DPE>), dim3((unsigned)((n+PNL_NTHREADS-1)/PNL_NTHREADS)), dim3(PNL_NTHREADS), 0,
+                               ctx->stream, ctx->P, (const double*)ctx->b_D.p, ctx->nc, S);
+            for (int e = 1; e < 8; e++) HIPCHK(ctx, hipEventRecord(ctx->ev[e], ctx->stream));
+            ctx->ev_valid = true; ctx->tiles_launched = true;
+        }
         first = false;
     }
     ctx->visited_pairs = total;
@@ -1691,7 +1727,7 @@ int pnl_assemble_dense(pnl_context *ctx, double *A, int64_t ldA, int zero_exteri
     // pairs visited by the reference loop: c1 in [begin,end), c2 in [c1, nc)
     unsigned long long visited = 0;
     for (long long c = cell_begin; c < cell_end; c++) visited += (unsigned long long)(ctx->nc-c);
-    ctx->visited_pairs = visited;
+    ctx->visited_pairs = visited; ctx->visited_is_assembled = false;
     if (getenv("PNL_FORCE_SYMFLUSH")) flags |= PNL_FLAG_SYMMETRIC_FLUSH;     // debug: both sides written by the flush, no mirror pass
     return dispatch(ctx, A, ldA, zero_exterior, (int)tiles.size(), cell_begin, cell_end, flags);
 }
@@ -1711,7 +1747,7 @@ int pnl_assemble_dense_tiles(pnl_context *ctx, double *A, int64_t ldA, int zero_
     }
     ctx->tile_cell_filter = false;
     if ((rc = upload_tiles(ctx, tiles, cell_begin, cell_end))) { ctx->tile_cell_filter = true; return rc; }
-    ctx->visited_pairs = 0;
+    ctx->visited_pairs = 0; ctx->visited_is_assembled = false;
     rc = dispatch(ctx, A, ldA, zero_exterior, ntiles, cell_begin, cell_end, flags);
     ctx->tile_cell_filter = true;
     return rc;
@@ -1764,7 +1800,7 @@ int pnl_assemble_pairs_masked(pnl_context *ctx, int np, const int32_t *pairs, co
     if ((rc = sparse_ready(ctx, data, diag, S))) return rc;
     if (!masks) S.masks = nullptr;               // every entry of every pair is requested
     HIPCHK(ctx, hipMemsetAsync(ctx->b_counters.p, 0, sizeof(unsigned long long)*PNL_NCOUNTERS, ctx->stream));
-    ctx->visited_pairs = (unsigned long long)np;
+    ctx->visited_pairs = (unsigned long long)np; ctx->visited_is_assembled = false;
     if (np == 0) return PNL_OK;
     const int kt = ctx->P.k.fast ? 1 : 0;
     if (ctx->dim == 2 && ctx->dpe == 3) return kt ? pairs_masked_impl<2, 3, 1>(ctx, np, S) : pairs_masked_impl<2, 3, 0>(ctx, np, S);
@@ -1918,7 +1954,7 @@ int pnl_assemble_clusters_tiled(pnl_context *ctx, const pnl_cluster_plan *pl, in
 #undef UP
     if ((rc = ensure(ctx, ctx->b_cpD, sizeof(double)*(size_t)std::max(pl->num_dslots, 1)*(dpe*(dpe+1)/2)))) return rc;
     CT.D = (double*)ctx->b_cpD.p;
-    ctx->visited_pairs = 0;
+    ctx->visited_pairs = 0; ctx->visited_is_assembled = false;
     const bool kt = ctx->P.k.fast;
     if (dim == 2 && dpe == 3)
         return kt ? clusters_tiled_impl<2, 3, TILE_P1, 1>(ctx, pl, CT, cluster_boundary, d_cell, d_pair, sing_dev, sing_pair_dev, pair_foff, fvid, fgeo, maxf, bt_cell, bt_facet, bt_slot)
@@ -2162,7 +2198,7 @@ int pnl_assemble_dense_pointwise(pnl_context *ctx, double *A, int64_t ldA, int z
     }
     unsigned long long visited = 0;
     for (long long c = cell_begin; c < cell_end; c++) visited += (unsigned long long)(ctx->nc-c);
-    ctx->visited_pairs = visited;
+    ctx->visited_pairs = visited; ctx->visited_is_assembled = false;
     return ctx->dim == 2 ? pointwise_impl<2>(ctx, A, ldA, zero_exterior, cell_begin, cell_end, npairs, nbpairs)
                          : pointwise_impl<1>(ctx, A, ldA, zero_exterior, cell_begin, cell_end, npairs, nbpairs);
 }
@@ -2173,7 +2209,7 @@ int pnl_get_counters(pnl_context *ctx, int64_t *out, int n) {
     unsigned long long tmp[PNL_NCOUNTERS];
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     HIPCHK(ctx, hipMemcpy(tmp, ctx->b_counters.p, sizeof(tmp), hipMemcpyDeviceToHost));
-    tmp[0] = ctx->visited_pairs;
+    tmp[0] = ctx->visited_is_assembled ? tmp[1] : ctx->visited_pairs;
     if (ctx->b_wlcount.p) {
         unsigned wl = 0;
         HIPCHK(ctx, hipMemcpy(&wl, ctx->b_wlcount.p, sizeof(wl), hipMemcpyDeviceToHost));

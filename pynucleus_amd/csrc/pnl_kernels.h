@@ -537,6 +537,15 @@ __device__ __forceinline__ bool tile_eligible(int n) { return n == 2 || n == 3 |
 #ifndef PNL_PURE_WAVES
 #define PNL_PURE_WAVES 4
 #endif
+// finite horizon (defined further down): relative position of two simplices, sorted-list keys of cut pairs
+#define PNL_CUT_SHIFT 60        // sorted-list bin of a cut pair = order + PNL_CUT_SHIFT (orders <= 60)
+#define PNL_INTERACT 0
+#define PNL_REMOTE 1
+#define PNL_CUT 2
+#define PNL_WL_LANE_MAXPTS 40
+template <int DIM>
+__device__ __forceinline__ int rel_position(double h2, const double *av, const double *bv);
+
 // Occupancy of the general tile kernel: its LDS (about 72 KB) lets two workgroups share a CU, so the waves per SIMD come from the
 // workgroup size: 512 threads at <= 128 VGPRs give 4 waves per SIMD (the unrolled 6-point evaluator stays spill-free because
 // its loop-invariant rule constants live in SGPRs); measured at noRef 7: 256 x 2 waves 69.7 ms, 384 x 3 101.6 ms (spills in
@@ -586,6 +595,7 @@ k_tile_distant(const DevProblem P, const int2 *__restrict__ tiles, double *__res
     // the two orders integrated by the unrolled evaluators (lists A and B): the lowest ones with NA / NB points -- nearly all
     // pairs; every wave of those lists works on ONE order, so the rule constants are wave-uniform (scalar loads).  Other orders
     // with a packed rule go through list C, which is sorted by order
+    const bool fh = !CLUSTER && (ablate & 512);       // finite horizon: sparse output CT.S, far list into the sparse pipeline
     int qA0 = 0, qB0 = 0;
     for (int q = 17; q >= 2; q--) {
         const int n = P.tt_n[q];
@@ -656,14 +666,14 @@ k_tile_distant(const DevProblem P, const int2 *__restrict__ tiles, double *__res
         const bool inside = (PAIRS%NT == 0) || praw < PAIRS;
         const int p = inside ? praw : 0;
         const int j = p%TILE, i = (p/TILE+PNL_DIAG_MULT*j)%TILE;
-        int q = 0;
+        int q = 0, fkey = 0;
         const int va0 = s_vid[(0*NV+0)*TILE+i], vb0 = s_vid[(1*NV+0)*TILE+j];
         const int ca = ta*TILE+i;
         // dense: upper triangle of the cell pairs, a-cells of the caller's range.  Cluster tiles: n1 == n2 -> unordered pairs
         // once (chunk pair a <= b); n1 != n2 -> every ordered pair (X in n1.cells, Y in n2.cells); identical cells share all
         // vertices and are left to the touching-pair lists like every other touching pair
         bool ok = inside && (va0 >= 0) && (vb0 >= 0) && !(ablate & 8) &&
-                  (CLUSTER ? (!sym || ta < tb || i < j) : ((ta < tb || i < j) && (ca >= cell_begin) && (ca < cell_end)));
+                  (CLUSTER ? (!sym || ta < tb || i < j) : ((ta < tb || i < j || (fh && i == j)) && (ca >= cell_begin) && (ca < cell_end)));
         // variable order: this launch assembles the pairs of one order class only
         if (!CLUSTER && P.cur_class >= 0 && ok) {
             const int la = P.clabel[ca], lb = P.clabel[tb*TILE+j];
@@ -681,7 +691,26 @@ k_tile_distant(const DevProblem P, const int2 *__restrict__ tiles, double *__res
 #pragma unroll
                 for (int m = 0; m < NV; m++) shared = shared || (va == s_vid[(1*NV+m)*TILE+j]);
             }
-            if (any_dof && !shared) {
+            // finite horizon (getSparse): REMOTE pairs are dropped, pairs CUT by the horizon and touching pairs go to the
+            // sorted sparse pipeline through the far list (keys order + PNL_CUT_SHIFT / 121 + shared vertices - 1, like
+            // k_fh_pairs), pairs inside the horizon are integrated here
+            int rel = PNL_INTERACT;
+            if (!CLUSTER && fh && any_dof) {
+                if (shared) {
+                    int common = 0;
+#pragma unroll
+                    for (int k = 0; k < NV; k++)
+#pragma unroll
+                        for (int m = 0; m < NV; m++) common += (s_vid[(0*NV+k)*TILE+i] == s_vid[(1*NV+m)*TILE+j]);
+                    fkey = 121+common-1;
+                } else {
+                    double av[NC], bv[NC];
+#pragma unroll
+                    for (int k = 0; k < NC; k++) { av[k] = s_v[(0*NC+k)*TILE+i]; bv[k] = s_v[(1*NC+k)*TILE+j]; }
+                    rel = rel_position<DIM>(P.k.horizon2, av, bv);
+                }
+            }
+            if (any_dof && !shared && rel != PNL_REMOTE) {
                 double d2 = 0.;
 #pragma unroll
                 for (int d = 0; d < DIM; d++) {
@@ -692,14 +721,20 @@ k_tile_distant(const DevProblem P, const int2 *__restrict__ tiles, double *__res
                 else q = quad_order_fast(P.qo, s_h[i], s_h[TILE+j], s_lh[i], s_lh[2*TILE+j], s_lh[TILE+i], s_lh[3*TILE+j],
                                          s_Ld[i], s_Ld[TILE+j], d2);
                 if (q > P.qmax || q > PNL_MAXQ) { overflow++; q = 0; }
+                else if (rel == PNL_CUT) {
+                    if (q > PNL_CUT_SHIFT || P.off[q+1]-P.off[q] > PNL_WL_LANE_MAXPTS) { overflow++; q = 0; }
+                    else fkey = q+PNL_CUT_SHIFT;
+                }
             }
         }
         // statistics: the three lowest orders (nearly all pairs) are counted with ballots on the scalar unit and added to the
         // LDS histogram once per tile; the LDS atomics of the hot loop are left to the rare higher orders
-        cnt234[0] += __popcll(__ballot(q == 2)); cnt234[1] += __popcll(__ballot(q == 3)); cnt234[2] += __popcll(__ballot(q == 4));
-        wave_bucket_add(s_cnt, q > 4 ? q : 0, false);
         const int nq = q ? s_ttn[q] : 0;
-        const int cls = !q ? 0 : (q == qA0 ? 1 : (q == qB0 ? 2 : (nq > 0 ? 3 : 4)));
+        const int key = fkey ? fkey : q;
+        const int cls = !key ? 0 : (fkey ? 4 : (q == qA0 ? 1 : (q == qB0 ? 2 : (nq > 0 ? 3 : 4))));
+        const int qs = (fh && cls == 4) ? 0 : q;         // finite horizon: the sparse pipeline counts what it is handed
+        cnt234[0] += __popcll(__ballot(qs == 2)); cnt234[1] += __popcll(__ballot(qs == 3)); cnt234[2] += __popcll(__ballot(qs == 4));
+        wave_bucket_add(s_cnt, qs > 4 ? qs : 0, false);
         const unsigned short ent = (unsigned short)(p | ((q-2) << 12));
         // one returning atomic per class and wave
         const unsigned long long mA = __ballot(cls == 1), mB = __ballot(cls == 2), mC = __ballot(cls == 3), mF = __ballot(cls == 4);
@@ -729,7 +764,7 @@ k_tile_distant(const DevProblem P, const int2 *__restrict__ tiles, double *__res
             const int leader = __ffsll((long long)mF)-1;
             if (lane == leader) base = atomicAdd(&s_misc[2], __popcll(mF));
             base = __builtin_amdgcn_readlane(base, leader);
-            if (cls == 4) s_l32[PAIRS-1-(base+__popcll(mF & lt))] = p | (q << 12);
+            if (cls == 4) s_l32[PAIRS-1-(base+__popcll(mF & lt))] = p | (key << 12);
         }
     }
     if (overflow) atomicAdd(&P.counters[5], (unsigned long long)overflow);
@@ -752,13 +787,19 @@ k_tile_distant(const DevProblem P, const int2 *__restrict__ tiles, double *__res
                 const int ent = s_l32[PAIRS-1-t];
                 const int p = ent & 4095, q = ent >> 12;
                 const int j = p%TILE, i = (p/TILE+PNL_DIAG_MULT*j)%TILE;
-                const int off = P.off[q];
+                const int off = (!CLUSTER && fh) ? 0 : P.off[q];
                 if (base+t < wl_cap) {
                     if (CLUSTER) {
                         worklist[base+t] = make_int4(s_cell[i], s_cell[TILE+j], (int)(base+t), (P.off[q+1]-off) | (q << 16));
                         const int dA = s_dslot[i], dB = s_dslot[TILE+j];
                         CT.wl_ds[base+t] = make_int2(dA, (dB >= 0 && (sym || dA < 0)) ? dB : -1);
                         CT.wl_pair[base+t] = CT.pair[tile_idx];
+                    } else if (fh) {
+                        // entry of the sorted sparse pipeline: (pair index, 0, rule offset, n | key << 16) + the pair itself
+                        const int qq = q >= 121 ? 0 : (q > PNL_CUT_SHIFT+1 ? q-PNL_CUT_SHIFT : q);
+                        const int o2 = qq ? P.off[qq] : 0, n2 = qq ? P.off[qq+1]-o2 : 0;
+                        worklist[base+t] = make_int4((int)(base+t), 0, o2, n2 | (q << 16));
+                        CT.wl_ds[base+t] = make_int2(ta*TILE+i, tb*TILE+j);
                     } else
                         worklist[base+t] = make_int4(ta*TILE+i, tb*TILE+j, off, (P.off[q+1]-off) | (q << 16));
                 }
@@ -901,6 +942,9 @@ k_tile_distant(const DevProblem P, const int2 *__restrict__ tiles, double *__res
             if (CLUSTER) {
                 // entry (I in n1, J in n2) of the near-field matrix and its mirror image (SSS keeps the one with I > J, a
                 // rank-local CSR the ones of its own blocks: addToEntry semantics)
+                sparse_add(CT.S, dofA[r], dofB[c], v);
+                sparse_add(CT.S, dofB[c], dofA[r], v);
+            } else if (fh) {
                 sparse_add(CT.S, dofA[r], dofB[c], v);
                 sparse_add(CT.S, dofB[c], dofA[r], v);
             } else {
@@ -1244,7 +1288,6 @@ k_tile_pure(const DevProblem P, const int2 *__restrict__ tiles, int ntiles, doub
     }
 }
 
-#define PNL_WL_LANE_MAXPTS 40
 // ---------------------------------------------------------------------------------------------
 // Finite horizon, l2 ball (interactionDomains.pyx): relative position of two simplices by their vertex distances
 // (ball2_retriangulation.getRelativePosition :875-898 = ball2_barycenter :990-1013) and the evaluation of pairs that
@@ -1254,11 +1297,6 @@ k_tile_pure(const DevProblem P, const int2 *__restrict__ tiles, int ntiles, doub
 // frame ROTATED so that the distinguished vertex (the only one inside / the only one outside) is vertex 0 -- the
 // reference's index arithmetic (inside+1)%3, (inside+2)%3 is exactly that rotation -- which keeps every array index
 // static; the rotation is undone on the barycentric coordinates of each quadrature point.
-#define PNL_CUT_SHIFT 60        // sorted-list bin of a cut pair = order + PNL_CUT_SHIFT (orders <= 60)
-#define PNL_INTERACT 0
-#define PNL_REMOTE 1
-#define PNL_CUT 2
-
 template <int DIM>
 __device__ __forceinline__ int rel_position(double h2, const double *av, const double *bv) {
     // no FMA contraction in the geometric predicates: symmetric meshes produce exact ties (d1 == d2, |x-y|^2 == horizon^2)
