@@ -132,9 +132,10 @@ int pnl_upload_singular_rule(pnl_context *ctx, int which, int panel, int M, int 
 int pnl_upload_boundary(pnl_context *ctx, int nb, const int32_t *bcells_host);
 
 /* Finite-horizon operator without a host pair list (nonlocalBuilder.getSparse, nonlocalAssembly_{SCALAR}.pxi:1062-1260): the
- * candidate cell pairs are generated on the device from the block tiles the horizon can reach, REMOTE pairs are dropped
+ * candidate cell pairs are those of the block tiles the horizon can reach, REMOTE pairs are dropped
  * (getRelativePosition, interactionDomains.pyx:875-898; nonlocalOperator_{SCALAR}.pxi:515-517), the others are integrated
- * (cut pairs through the sub-simplex loops) and scattered without masks into the uploaded pattern.  Replaces the loops
+ * (pairs inside the horizon tile-wise, cut pairs through the sub-simplex loops) and added without masks into the uploaded
+ * pattern.  Replaces the loops
  * NA:1150-1200 over the cells of the covering cluster pairs (clusterMethodCy.pyx:4139-4194). */
 int pnl_assemble_pairs_in_horizon(pnl_context *ctx, double *data, double *diag);
 

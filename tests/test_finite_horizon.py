@@ -180,3 +180,24 @@ def test_gpu_interval_poly_dirichlet_known_answer(kernel, nc, tol):
     dm, k = _poly_dirichlet_1d(kernel, nc)
     A = nonlocalBuilder(dm, k, {}, zeroExterior=False).getSparse().toarray()
     assert _poly_dirichlet_error(dm, A) <= tol
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('case', ['indicator', 'fractional', 'P2'])
+def test_gpu_horizon_tiles_and_pair_generator_agree(case, monkeypatch):
+    """the two device routes of pnl_assemble_pairs_in_horizon -- tile kernel in finite-horizon mode (default) and the pair
+    generator that sends every pair down the sorted sparse pipeline (PNL_FH_NOTILES=1) -- give the same counters and, to
+    summation order, the same matrix"""
+    def build():
+        if case == 'indicator':
+            return _gpu_sparse(33, 0.12, 'indicator')
+        if case == 'fractional':
+            return _gpu_sparse(17, 0.45, 'fractional', s=0.4)
+        return _gpu_sparse(9, 0.3, 'indicator', element='P2')
+    A = build().getSparse()
+    monkeypatch.setenv('PNL_FH_NOTILES', '1')
+    B = build().getSparse()
+    for key in ('numCellPairs', 'numAssembledCellPairs', 'numIntegrations'):
+        assert A.info['counters'][key] == B.info['counters'][key], key
+    a, b = A.toarray(), B.toarray()
+    assert np.abs(a-b).max() <= 1e-12*np.abs(b).max()
