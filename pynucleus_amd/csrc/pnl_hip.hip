@@ -1362,10 +1362,10 @@ int horizon_impl(pnl_context *ctx, SparseOut S) {
         HIPCHK(ctx, hipMemsetAsync(ctx->b_wlcount.p, 0, sizeof(unsigned), ctx->stream));
         if (first) HIPCHK(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
         if (use_tiles) {
-            auto kfun = k_tile_distant<DIM, DPE, TILE, KT, false>;
+            auto kfun = k_tile_distant<DIM, DPE, TILE, KT, false, true>;
             HIPCHK(ctx, hipFuncSetAttribute((const void*)kfun, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             int per_cu = 2;
-            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)kfun, tile_threads(DPE, KT), lds);
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)kfun, tile_threads(DPE, KT, true), lds);
             if ((rc = ensure(ctx, ctx->b_tilectr, sizeof(unsigned)))) return rc;
             HIPCHK(ctx, hipMemsetAsync(ctx->b_tilectr.p, 0, sizeof(unsigned), ctx->stream));
             HIPCHK(ctx, hipMemsetAsync(ctx->b_D.p, 0, sizeof(double)*(size_t)ctx->ncp*ND, ctx->stream));
@@ -1373,9 +1373,9 @@ int horizon_impl(pnl_context *ctx, SparseOut S) {
             CT.S = S;
             CT.wl_ds = (int2*)ctx->b_mp_pairs.p;                   // the pairs of the far-list entries
             const int grid = std::min(nt, 256*std::max(per_cu, 1));
-            hipLaunchKernelGGL(kfun, dim3(grid), dim3(tile_threads(DPE, KT)), lds, ctx->stream, ctx->P, (const int2*)ctx->b_tiles.p+t0,
+            hipLaunchKernelGGL(kfun, dim3(grid), dim3(tile_threads(DPE, KT, true)), lds, ctx->stream, ctx->P, (const int2*)ctx->b_tiles.p+t0,
                                (double*)nullptr, 0ll, (double*)ctx->b_D.p, 0, ctx->nc, acc_stride, (int4*)ctx->b_mp_wl.p,
-                               (unsigned*)ctx->b_wlcount.p, (unsigned)cap, 512, nt, CT, (unsigned*)ctx->b_tilectr.p);
+                               (unsigned*)ctx->b_wlcount.p, (unsigned)cap, 0, nt, CT, (unsigned*)ctx->b_tilectr.p);
         } else
             hipLaunchKernelGGL((k_fh_pairs<DIM, DPE>), dim3(nt), dim3(PNL_NTHREADS), 0, ctx->stream, ctx->P, (const int2*)ctx->b_tiles.p+t0, T,
                                (int2*)ctx->b_mp_pairs.p, (int4*)ctx->b_mp_wl.p, (unsigned*)ctx->b_wlcount.p, (unsigned)cap);

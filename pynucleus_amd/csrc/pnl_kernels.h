@@ -545,6 +545,9 @@ __device__ __forceinline__ bool tile_eligible(int n) { return n == 2 || n == 3 |
 #define PNL_WL_LANE_MAXPTS 40
 template <int DIM>
 __device__ __forceinline__ int rel_position(double h2, const double *av, const double *bv);
+template <int DIM, int DPE>
+__device__ __forceinline__ unsigned eval_distant_cut(const DevProblem &P, const double *__restrict__ tab, int stp, int n, const double *av,
+                                                     const double *bv, PairAcc<DIM, DPE> &R);
 
 // Occupancy of the general tile kernel: its LDS (about 72 KB) lets two workgroups share a CU, so the waves per SIMD come from the
 // workgroup size: 512 threads at <= 128 VGPRs give 4 waves per SIMD (the unrolled 6-point evaluator stays spill-free because
@@ -559,16 +562,17 @@ __device__ __forceinline__ int rel_position(double h2, const double *av, const d
 // P2 (78 local entries per pair) needs more than 256 VGPRs: one wave per SIMD without spills beats two with 600 B of scratch,
 // hence 256 threads per workgroup there; the general-exponent kernel (KT = 0: exp / log chains) spills at 128 VGPRs (57 ms against
 // 31 ms at noRef 6, s = 0.4) and keeps 256 threads x 2 waves as well
-__host__ __device__ constexpr int tile_threads(int dpe, int kt) { return (dpe > 3 || kt == 0) ? 256 : PNL_TILE_THREADS; }
-__host__ __device__ constexpr int tile_waves(int dpe, int kt) { return dpe > 3 ? 1 : (kt == 0 ? 2 : PNL_TILE_WAVES); }
-template <int DIM, int DPE, int TILE, int KT, bool CLUSTER>
-__global__ void __launch_bounds__(tile_threads(DPE, KT), tile_waves(DPE, KT))
+// (the finite-horizon variant carries the sub-simplex loops of the cut pairs: 256 threads x 2 waves as well)
+__host__ __device__ constexpr int tile_threads(int dpe, int kt, bool fh = false) { return (dpe > 3 || kt == 0 || fh) ? 256 : PNL_TILE_THREADS; }
+__host__ __device__ constexpr int tile_waves(int dpe, int kt, bool fh = false) { return dpe > 3 ? 1 : ((kt == 0 || fh) ? 2 : PNL_TILE_WAVES); }
+template <int DIM, int DPE, int TILE, int KT, bool CLUSTER, bool FH = false>
+__global__ void __launch_bounds__(tile_threads(DPE, KT, FH), tile_waves(DPE, KT, FH))
 k_tile_distant(const DevProblem P, const int2 *__restrict__ tiles, double *__restrict__ A, long long ldA,
                double *__restrict__ Dglob, int cell_begin, int cell_end, int acc_stride, int4 *__restrict__ worklist,
                unsigned *__restrict__ wl_count, unsigned wl_cap, int ablate, int ntiles, const ClusterTiles CT,
                unsigned *__restrict__ tile_ctr) {
     using S = TileSmem<DIM, DPE, TILE>;
-    constexpr int NV = S::NV, NC = S::NC, ND = S::ND, NT = tile_threads(DPE, KT);
+    constexpr int NV = S::NV, NC = S::NC, ND = S::ND, NT = tile_threads(DPE, KT, FH);
     constexpr int PAIRS = TILE*TILE, PER_THREAD = (PAIRS+NT-1)/NT;
     extern __shared__ double smem[];
     double *s_dbl = smem;
@@ -595,7 +599,7 @@ k_tile_distant(const DevProblem P, const int2 *__restrict__ tiles, double *__res
     // the two orders integrated by the unrolled evaluators (lists A and B): the lowest ones with NA / NB points -- nearly all
     // pairs; every wave of those lists works on ONE order, so the rule constants are wave-uniform (scalar loads).  Other orders
     // with a packed rule go through list C, which is sorted by order
-    const bool fh = !CLUSTER && (ablate & 512);       // finite horizon: sparse output CT.S, far list into the sparse pipeline
+    constexpr bool fh = !CLUSTER && FH;               // finite horizon: sparse output CT.S, far list into the sparse pipeline
     int qA0 = 0, qB0 = 0;
     for (int q = 17; q >= 2; q--) {
         const int n = P.tt_n[q];
@@ -764,7 +768,9 @@ k_tile_distant(const DevProblem P, const int2 *__restrict__ tiles, double *__res
             const int leader = __ffsll((long long)mF)-1;
             if (lane == leader) base = atomicAdd(&s_misc[2], __popcll(mF));
             base = __builtin_amdgcn_readlane(base, leader);
-            if (cls == 4) s_l32[PAIRS-1-(base+__popcll(mF & lt))] = p | (key << 12);
+            // finite horizon: cut pairs whose order has a packed rule are integrated in this tile (bit 20), not exported
+            if (cls == 4) s_l32[PAIRS-1-(base+__popcll(mF & lt))] = p | (key << 12) |
+                                                                    ((fh && fkey > PNL_CUT_SHIFT+1 && fkey < 121 && nq > 0) ? (1 << 20) : 0);
         }
     }
     if (overflow) atomicAdd(&P.counters[5], (unsigned long long)overflow);
@@ -779,7 +785,32 @@ k_tile_distant(const DevProblem P, const int2 *__restrict__ tiles, double *__res
     {
         // far pairs: one reservation in the global work list per tile, then a coalesced copy
         const int nF = s_misc[2];
-        if (nF) {
+        if (fh) {
+            // entries of the sorted sparse pipeline, one reservation per wave and 64 entries: (pair index, 0, rule offset,
+            // n | key << 16) + the pair itself, what k_fh_pairs writes
+#pragma unroll 1
+            for (int t0 = (tid >> 6)*64; t0 < nF; t0 += NT) {
+                const int t = t0+lane;
+                const int ent = t < nF ? s_l32[PAIRS-1-t] : (1 << 20);
+                const bool exp = !(ent & (1 << 20));
+                const unsigned long long m = __ballot(exp);
+                if (m) {
+                    unsigned base = 0;
+                    const int leader = __ffsll((long long)m)-1;
+                    if (lane == leader) base = atomicAdd(wl_count, (unsigned)__popcll(m));
+                    base = (unsigned)__builtin_amdgcn_readlane((int)base, leader);
+                    const unsigned pos = base+(unsigned)__popcll(m & lt);
+                    if (exp && pos < wl_cap) {
+                        const int p = ent & 4095, key = (ent >> 12) & 255;
+                        const int j = p%TILE, i = (p/TILE+PNL_DIAG_MULT*j)%TILE;
+                        const int qq = key >= 121 ? 0 : (key > PNL_CUT_SHIFT+1 ? key-PNL_CUT_SHIFT : key);
+                        const int o2 = qq ? P.off[qq] : 0, n2 = qq ? P.off[qq+1]-o2 : 0;
+                        worklist[pos] = make_int4((int)pos, 0, o2, n2 | (key << 16));
+                        CT.wl_ds[pos] = make_int2(ta*TILE+i, tb*TILE+j);
+                    }
+                }
+            }
+        } else if (nF) {
             if (tid == 0) s_cur[0] = (int)atomicAdd(wl_count, (unsigned)nF);
             __syncthreads();
             const unsigned base = (unsigned)s_cur[0];
@@ -787,19 +818,13 @@ k_tile_distant(const DevProblem P, const int2 *__restrict__ tiles, double *__res
                 const int ent = s_l32[PAIRS-1-t];
                 const int p = ent & 4095, q = ent >> 12;
                 const int j = p%TILE, i = (p/TILE+PNL_DIAG_MULT*j)%TILE;
-                const int off = (!CLUSTER && fh) ? 0 : P.off[q];
+                const int off = P.off[q];
                 if (base+t < wl_cap) {
                     if (CLUSTER) {
                         worklist[base+t] = make_int4(s_cell[i], s_cell[TILE+j], (int)(base+t), (P.off[q+1]-off) | (q << 16));
                         const int dA = s_dslot[i], dB = s_dslot[TILE+j];
                         CT.wl_ds[base+t] = make_int2(dA, (dB >= 0 && (sym || dA < 0)) ? dB : -1);
                         CT.wl_pair[base+t] = CT.pair[tile_idx];
-                    } else if (fh) {
-                        // entry of the sorted sparse pipeline: (pair index, 0, rule offset, n | key << 16) + the pair itself
-                        const int qq = q >= 121 ? 0 : (q > PNL_CUT_SHIFT+1 ? q-PNL_CUT_SHIFT : q);
-                        const int o2 = qq ? P.off[qq] : 0, n2 = qq ? P.off[qq+1]-o2 : 0;
-                        worklist[base+t] = make_int4((int)(base+t), 0, o2, n2 | (q << 16));
-                        CT.wl_ds[base+t] = make_int2(ta*TILE+i, tb*TILE+j);
                     } else
                         worklist[base+t] = make_int4(ta*TILE+i, tb*TILE+j, off, (P.off[q+1]-off) | (q << 16));
                 }
@@ -928,6 +953,41 @@ k_tile_distant(const DevProblem P, const int2 *__restrict__ tiles, double *__res
             else eval_distant_lds<DIM, DPE, KT>(P, s_tt+to*(4+DPE), 4+DPE, nq, av, bv, R);
             if (act) accumulate(R, i, j);
         }
+    }
+    if (fh) {
+        // ---- pairs cut by the horizon whose order has a packed rule: sub-simplex loops (eval_distant NO:790-847), one pair
+        // per lane, into the same LDS sub-block; the far list still holds them (bit 20)
+        const int nF = __builtin_amdgcn_readfirstlane(s_misc[2]);
+        unsigned long long ncutp = 0, ncute = 0;
+#pragma unroll 1
+        for (int t0 = wave*64; t0 < nF; t0 += NT) {
+            const int t = t0+lane;
+            const int ent = t < nF ? s_l32[PAIRS-1-t] : 0;
+            const bool cutl = (ent & (1 << 20)) != 0;
+            if (!__ballot(cutl)) continue;
+            const int p = ent & 4095, q = cutl ? ((ent >> 12) & 255)-PNL_CUT_SHIFT : 2;
+            const int j = p%TILE, i = (p/TILE+PNL_DIAG_MULT*j)%TILE;
+            double av[NC], bv[NC];
+#pragma unroll
+            for (int k = 0; k < NC; k++) { av[k] = s_v[(0*NC+k)*TILE+i]; bv[k] = s_v[(1*NC+k)*TILE+j]; }
+            PairAcc<DIM, DPE> R;
+            R.clear();
+            if (cutl) {
+                ncute += eval_distant_cut<DIM, DPE>(P, s_tt+s_tto[q]*(4+DPE), 4+DPE, s_ttn[q], av, bv, R);
+                ncutp++;
+                accumulate(R, i, j);
+            }
+            // order histogram: one global atomic per wave and distinct order (one or two)
+            unsigned long long todo = __ballot(cutl);
+            while (todo) {
+                const int leader = __ffsll((long long)todo)-1;
+                const int qL = __builtin_amdgcn_readlane(q, leader);
+                const unsigned long long same = __ballot(cutl && q == qL);
+                if (lane == leader) atomicAdd(&P.counters[8+qL], (unsigned long long)__popcll(same));
+                todo &= ~same;
+            }
+        }
+        if (ncutp) { atomicAdd(&P.counters[1], ncutp); atomicAdd(&P.counters[2], ncute); }
     }
     __syncthreads();
 

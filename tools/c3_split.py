@@ -14,3 +14,6 @@ for inter in (None, 'ball2_barycenter'):
     for rep in range(2):
         A = b.getSparse()
     print(inter, 'device %.1f ms' % A.info['interior_ms'], A.info['counters'], b.context().phase_ms())
+    cnt = b.context().counters()
+    off = b.tables.dist_off
+    print('   orders (order: points, pairs):', {int(q): (int(off[q+1]-off[q]), int(c)) for q, c in sorted(cnt['orders'].items())}, 'touching', cnt['singular'])
