@@ -6,6 +6,7 @@
 #define PNL_NTHREADS 256
 #define PNL_MAXQ 120            // nonlocalOperator.pyx:107 MAX_PANEL
 #define PNL_NCOUNTERS 131
+#define PNL_WL_SLOTS 256          // work-list fill counters: one per order class / class pass of an assembly
 
 struct DevKernel {
     int ktype;                  // 0 fractional, 1 indicator, 2 peridynamic
@@ -51,6 +52,7 @@ struct DevProblem {
     const int *tt_n, *tt_off;   // [PNL_MAXQ+2]
     const double *tt_tab;       // [tt_npts][4+dpe]: bary[3], w, phi[dpe]
     const double *tt_wphi;      // [tt_npts][dpe]: w, w*phi[0..dpe-2] (wave-uniform scalar loads; the last product follows from sum_b phi_b = 1)
+    const double *tt_wphif;     // [tt_npts][dpe+1]: w, w*phi[0..dpe-1] (second-generation tile kernels, pnl_tile2.h)
     int tt_npts, pad1;
     // singular rules (slot 0 vertex, 1 edge, 2 face)
     int sM[3], sRows[3];
@@ -73,4 +75,34 @@ struct DevProblem {
     int orient, pad2;
     double idfac;
     unsigned long long *counters;
+};
+
+// H2 far field (clusterMethodCy.pyx; kernels in pnl_kernels.h)
+struct H2Dev {
+    int dim, m, M, nnodes, nleaves, nfar;
+    const double *box;          // [nnodes][dim][2]
+    const int *parent;          // [nnodes] (-1: root)
+    const int *leaf_node;       // [nleaves]
+    const int *leaf_dof_off, *leaf_dofs;        // sorted DoFs of the leaves
+    const int *leaf_cell_off, *leaf_cells;      // cells touching them
+    const long long *leaf_val_off;              // [nleaves] offset of V_leaf[ndofs][M]
+    const int *far;             // [nfar][2] (n1, n2)
+    double *V, *K;              // leaf values, kernel interpolants [nfar][M][M]
+    const double *T;            // [nnodes][M_parent][M_child] transfer operator of every non-root node
+    double *cup, *cdown;        // [nnodes][M]
+};
+
+// order per quadrature point (kernels in pnl_pointwise.h)
+struct PwDev {
+    int type, normalized;       // 1 constant, 2 smoothStep(x0), 3 linearStep(x0), 4 smoothStepRadial (fractionalOrders.pyx:338-540)
+    double p[6];                // sl, sr, r, interface | radius, slope
+    int scal_n, pad0;           // scaling C(s) as a Chebyshev series over the range of the order (0: Gamma functions)
+    double scal_mid, scal_inv_half, scal_cheb[32];
+    double c0, bc0;             // constant term of the interior / boundary order formula
+    const double *cell_smax, *facet_smax;
+    int M[3], rows[3];
+    const double *nodes[3], *w[3], *phi0[3], *phi1[3];      // [nkeys][...] per slot
+    int bM[2], pad;
+    const double *bnodes[2], *bw[2], *bphi[2];
+    double sfac, bfac;
 };

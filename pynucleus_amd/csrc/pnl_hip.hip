@@ -15,161 +15,9 @@
 #include "pnl_kernels.h"
 #include "pnl_pointwise.h"
 
-namespace {
-
-constexpr int TILE_P1 = 64;     // cells per block for dpe <= 3
-constexpr int TILE_P2 = 32;     // cells per block for dpe == 6 (bigger LDS sub-block per cell)
-
-struct DevBuf {
-    void *p = nullptr;
-    size_t bytes = 0;
-    ~DevBuf() { release(); }
-    void release() { if (p) { (void)hipFree(p); p = nullptr; bytes = 0; } }
-};
-
-}  // namespace
-
-struct pnl_context {
-    int device = 0;
-    hipStream_t own_stream = nullptr, stream = nullptr;
-    std::string err;
-    // host copies
-    int dim = 0, nv = 0, nc = 0, dpe = 0, dpv = 0, dped = 0, N = 0, nb = 0, qmax = -1;
-    double H0 = 0.;
-    std::vector<double> vertices, vol, h;
-    std::vector<int32_t> cells, dofs, perm_table, bcells;
-    // per order class (one class for a constant order; pnl_set_classes for a piecewise-constant variable order): kernel,
-    // order formula, singular rules and the touching pairs that belong to the class
-    struct ClassData {
-        pnl_kernel kern[2];
-        pnl_order_formula form[2];
-        bool have_kernel[2] = {false, false}, have_form[2] = {false, false};
-        bool have_sing[2][3] = {{false, false, false}, {false, false, false}};
-        DevBuf b_sn[3], b_sw[3], b_sp[3], b_bn[2], b_bw[2], b_bp[2], b_spairs[3], b_bpairs[2], b_spairs1[3];
-        int sM[3] = {0, 0, 0}, sRows[3] = {0, 0, 0}, bM[2] = {0, 0};
-        double sFac = 0., bFac = 0.;
-        int n_spairs[3] = {0, 0, 0}, n_bpairs[2] = {0, 0};
-        int n_spairs1[3] = {0, 0, 0};   // non-symmetric order: touching pairs (c2, c1) of the second orientation
-        ClassData() { std::memset(kern, 0, sizeof(kern)); std::memset(form, 0, sizeof(form)); }
-    };
-    std::vector<ClassData*> cls;
-    int cur = 0;                      // class the setters and launchers currently act on
-    ClassData &C() { return *cls[cur]; }
-    int nlab = 0;                     // labels of the variable order (0: constant order)
-    bool nonsym = false;              // cls_of is not symmetric: both orientations of every pair (pnl_set_nonsymmetric)
-    int orient = 0;                   // orientation the launchers currently act on
-    std::vector<int32_t> cell_labels, facet_labels, cls_of;
-    bool have_mesh = false, have_dofs = false, have_rules = false, have_boundary = false;
-    bool dirty = true;
-    // device
-    DevProblem P;
-    DevBuf b_cellv, b_ccen, b_cvol, b_ch, b_clog, b_cvid, b_cdof, b_cslot, b_blk_ndof, b_blk_dofs, b_perm, b_off, b_bary, b_w, b_phi,
-        b_foff, b_fbary, b_fw, b_bvid, b_bv, b_bgeo, b_counters, b_D, b_tiles,
-        b_vec[6], b_clabel, b_blabel, b_clsof, b_scal, b_wl, b_wlcount, b_tilectr, b_ttn, b_ttoff, b_tttab, b_ttwphi, b_wlsorted, b_wlaux,
-        b_vertices, b_sp_indptr, b_sp_indices, b_mp_pairs, b_mp_masks, b_mp_wl, b_mp_sorted, b_mp_aux, b_bi_cells, b_bi_facets,
-        b_bi_masks, b_cp[28], b_cpD, b_wlds, b_wlpair, b_h2[20];
-    H2Dev h2;
-    bool have_h2 = false;
-    // non-symmetric kernels with an order per quadrature point (pnl_set_order_function)
-    bool have_tile_order = false;     // permuted cell tables for the tile kernels (finalize)
-    DevBuf b_cellv_t, b_cdof_t, b_cslot_t, b_Dt;    // b_Dt: diagonal blocks in the tile kernels' local order
-    PwDev pw;
-    bool have_pw = false, have_pw_rules[2][3] = {{false, false, false}, {false, false, false}};
-    int pw_nkeys[2] = {0, 0};
-    std::vector<double> pw_cell_smax, pw_facet_smax;
-    DevBuf b_pw_csm, b_pw_fsm, b_pw_rule[2][3][4], b_pw_pairs, b_pw_bpairs;
-    std::vector<std::vector<int>> h2_levels;   // nodes of every level >= 1
-    std::vector<size_t> h2_level_off;
-    int sp_nnz = -1;                // near-field sparsity pattern (pnl_upload_sparsity)
-    unsigned wl_cap = 0;
-    int tile = TILE_P1, nblocks = 0, ncp = 0, nU = 0;
-    std::vector<int2> spairs_host[3];
-    std::vector<int2> tiles_cached;   // tile list (as given by the caller) currently resident in b_tiles
-    size_t tiles_cap = 0;
-    // b_tiles holds the mixed tiles first, then the uniform ones (all pairs distant with the lowest order)
-    int n_mixed = 0, n_pure = 0, tile_off = 0, tiles_cb = -1, tiles_ce = -1;
-    std::vector<int> cls_tile_off, cls_n_mixed, cls_n_pure;     // per order class: its slice of b_tiles (mixed tiles, then uniform)
-    std::vector<pnl_order_formula> tiles_forms;
-    pnl_order_formula tiles_form;
-    bool tiles_filter = true;
-    bool use_pure = true;             // debug: PNL_PURE=0 sends every tile through the general kernel
-    struct BlockAgg { double cx, cy, rad, hmax, Lmin, Lmax; bool full; };
-    std::vector<BlockAgg> blocks;
-    hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    bool pure_launched = false;
-    bool symflush = false;          // PNL_FLAG_SYMMETRIC_FLUSH of the current assembly
-    bool ev_valid = false;
-    unsigned long long visited_pairs = 0;
-    bool visited_is_assembled = false;      // finite-horizon tiles: every visited (non-REMOTE) pair is an assembled one
-    bool tiles_launched = false;
-    int ablate = 0;                 // debug: PNL_ABLATE env bits (1 no LDS accumulate, 2 no evaluation)
-    bool tile_cell_filter = true;   // apply [cell_begin, cell_end) to the a-cells of the tiles too
-    bool wl_lane = true;            // debug: PNL_WL_LANE=0 sends every work-list order to the 16-lanes-per-pair kernel
-};
+#include "pnl_context.h"
 
 namespace {
-
-int fail(pnl_context *ctx, int code, const char *fmt, ...) {
-    char buf[512];
-    va_list ap;
-    va_start(ap, fmt);
-    vsnprintf(buf, sizeof(buf), fmt, ap);
-    va_end(ap);
-    if (ctx) ctx->err = buf;
-    return code;
-}
-
-#define HIPCHK(ctx, call)                                                                            \
-    do {                                                                                             \
-        hipError_t e_ = (call);                                                                      \
-        if (e_ != hipSuccess) return fail(ctx, PNL_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); \
-    } while (0)
-
-template <class T>
-int upload(pnl_context *ctx, DevBuf &b, const T *src, size_t n) {
-    const size_t bytes = std::max<size_t>(n*sizeof(T), 16);
-    if (b.bytes < bytes) {
-        b.release();
-        HIPCHK(ctx, hipMalloc(&b.p, bytes));
-        b.bytes = bytes;
-    }
-    if (n) HIPCHK(ctx, hipMemcpyAsync(b.p, src, n*sizeof(T), hipMemcpyHostToDevice, ctx->stream));
-    // host vectors passed here may be temporaries: make the copy synchronous
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    return PNL_OK;
-}
-
-int ensure(pnl_context *ctx, DevBuf &b, size_t bytes) {
-    bytes = std::max<size_t>(bytes, 16);
-    if (b.bytes < bytes) {
-        b.release();
-        HIPCHK(ctx, hipMalloc(&b.p, bytes));
-        b.bytes = bytes;
-    }
-    return PNL_OK;
-}
-
-DevKernel to_dev(const pnl_kernel &k, int dim) {
-    DevKernel d;
-    d.ktype = k.ktype;
-    d.exponent = k.exponent;
-    d.scale = k.scale;
-    d.horizon2 = k.horizon2;
-    d.interaction = k.interaction;
-    // quarter-integer exponents get the rsqrt-based evaluation
-    const double m4 = -4.*k.exponent;
-    const int qm = (int)std::lround(m4);
-    (void)dim;
-    d.qm = qm;
-    d.fast = (k.ktype == PNL_FRACTIONAL && std::isinf(k.horizon2) && qm >= 1 && qm <= 32 && std::fabs(m4-qm) < 1e-13) ? 1 : 0;
-    return d;
-}
-
-DevFormula to_dev(const pnl_order_formula &f) {
-    DevFormula d;
-    d.c0 = f.c0; d.a = f.a; d.b = f.b; d.e = f.e; d.den0 = f.den0; d.clip = f.clip_num; d.pad = 0;
-    return d;
-}
 
 // Build everything derived from mesh + DoF map: padded SoA cell arrays, per-block unique DoF lists,
 // touching cell pairs (NO:311-323 shared-vertex test, done once through the vertex->cell adjacency),
@@ -425,7 +273,7 @@ int finalize(pnl_context *ctx) {
         for (int c = 0; c < ncp; c++) { clog[c] = std::log(ch[c]); clog[(size_t)ncp+c] = std::fabs(std::log(ch[c]/ctx->H0)); }
         if ((rc = upload(ctx, ctx->b_clog, clog.data(), clog.size()))) return rc;
         // per-block aggregates for the host-side tile classification (uniform tiles)
-        ctx->blocks.assign(nblocks, pnl_context::BlockAgg{0., 0., 0., 0., 0., 0., false});
+        ctx->blocks.assign(nblocks, pnl_context::BlockAgg{0., 0., 0., 0., 0., 0., 0., false});
         for (int b = 0; b < nblocks; b++) {
             auto &B = ctx->blocks[b];
             const int c0 = b*T, c1 = std::min(nc, (b+1)*T);
@@ -433,11 +281,12 @@ int finalize(pnl_context *ctx) {
             double sx = 0., sy = 0.;
             for (int c = c0; c < c1; c++) { sx += ccen[c]; if (dim == 2) sy += ccen[(size_t)ncp+c]; }
             B.cx = sx/(c1-c0); B.cy = sy/(c1-c0);
-            B.rad = 0.; B.hmax = 0.; B.Lmin = 1e300; B.Lmax = -1e300;
+            B.rad = 0.; B.hmax = 0.; B.hmin = 1e300; B.Lmin = 1e300; B.Lmax = -1e300;
             for (int c = c0; c < c1; c++) {
                 const double dx = ccen[c]-B.cx, dy = dim == 2 ? ccen[(size_t)ncp+c]-B.cy : 0.;
                 B.rad = std::max(B.rad, std::sqrt(dx*dx+dy*dy));
                 B.hmax = std::max(B.hmax, ch[c]);
+                B.hmin = std::min(B.hmin, ch[c]);
                 B.Lmin = std::min(B.Lmin, clog[(size_t)ncp+c]);
                 B.Lmax = std::max(B.Lmax, clog[(size_t)ncp+c]);
             }
@@ -489,6 +338,7 @@ void refresh_tables(pnl_context *ctx) {
     P.fw = (const double*)ctx->b_fw.p;
     P.tt_n = (const int*)ctx->b_ttn.p; P.tt_off = (const int*)ctx->b_ttoff.p; P.tt_tab = (const double*)ctx->b_tttab.p;
     P.tt_wphi = (const double*)ctx->b_ttwphi.p;
+    P.tt_wphif = (const double*)ctx->b_ttwphif.p;
     for (int s = 0; s < 3; s++) {
         P.sNodes[s] = (const double*)ctx->C().b_sn[s].p; P.sW[s] = (const double*)ctx->C().b_sw[s].p; P.sPsi[s] = (const double*)ctx->C().b_sp[s].p;
     }
@@ -505,29 +355,6 @@ void refresh_tables(pnl_context *ctx) {
     if (ctx->nonsym) P.k.scale *= 0.5;
 }
 
-// row stride of the LDS sub-block: nU + 1 columns (+1: trash column / row for boundary DoFs); PNL_ACC_PAD=m rounds it up
-// to 1 mod m so that consecutive rows start in different LDS banks
-int acc_stride_of(int nU, size_t fixed_bytes = 0) {
-    int st = nU+1;
-    // rows that start in different LDS banks (stride = 1 mod 32 doubles) see fewer conflicts in the ds_add_f64 of the
-    // cross blocks (measured: -0.4 ms at noRef 6), if the bigger sub-block still leaves two workgroups per CU
-    const int m = getenv("PNL_ACC_PAD") ? atoi(getenv("PNL_ACC_PAD")) : 32;
-    if (m > 1) {
-        int padded = st;
-        while (padded % m != 1) padded++;
-        if (fixed_bytes+sizeof(double)*(size_t)(nU+1)*padded <= 80*1024) st = padded;
-    }
-    return st;
-}
-
-// the problem description the dense tile kernels see: cell tables in the conflict-reducing local vertex order
-DevProblem tile_problem(const pnl_context *ctx) {
-    DevProblem Pt = ctx->P;
-    if (ctx->have_tile_order) {
-        Pt.cellv = (const double*)ctx->b_cellv_t.p; Pt.cdof = (const int*)ctx->b_cdof_t.p; Pt.cslot = (const short*)ctx->b_cslot_t.p;
-    }
-    return Pt;
-}
 
 template <int DIM, int DPE, int KT>
 int launch_pure(pnl_context *ctx, double *A, int64_t ldA) {
@@ -543,15 +370,66 @@ int launch_pure(pnl_context *ctx, double *A, int64_t ldA) {
     if (getenv("PNL_VERBOSE")) fprintf(stderr, "[pnl] uniform tiles=%d of %d, lds=%zu bytes, occupancy API: %d blocks/CU\n", ctx->n_pure,
                                        ctx->n_pure+ctx->n_mixed, lds, per_cu);
     const int grid = std::min(ctx->n_pure, 256*std::max(per_cu, 1));
+    int pure_abl = 0;
+#ifdef PNL_DEBUG_ABLATE
+    pure_abl = getenv("PNL_PURE_ABL") ? atoi(getenv("PNL_PURE_ABL")) : 0;
+#endif
     hipLaunchKernelGGL(kfun, dim3(grid), dim3(PNL_NTHREADS), lds, ctx->stream, tile_problem(ctx), (const int2*)ctx->b_tiles.p+ctx->tile_off+ctx->n_mixed,
                        ctx->n_pure, A, (long long)ldA, (double*)(ctx->have_tile_order ? ctx->b_Dt.p : ctx->b_D.p), acc_stride, 2,
-                       (ctx->symflush ? 1 : 0) | (getenv("PNL_PURE_ABL") ? atoi(getenv("PNL_PURE_ABL")) : 0));
+                       (ctx->symflush ? 1 : 0) | pure_abl);
     HIPCHK(ctx, hipGetLastError());
     return PNL_OK;
 }
 
+// counting sort of a work-list region by order, then the sorted evaluation (k_worklist_lane / k_worklist_sorted)
+template <int DIM, int DPE, int KT>
+int run_worklist(pnl_context *ctx, const int4 *wl, const unsigned *wlc, unsigned cap, double *A, int64_t ldA) {
+    int rc;
+    if ((rc = ensure(ctx, ctx->b_wlsorted, (size_t)cap*sizeof(int4)))) return rc;
+    if ((rc = ensure(ctx, ctx->b_wlaux, sizeof(unsigned)*(4*(PNL_WL_BINS+1))))) return rc;
+    unsigned *hist = (unsigned*)ctx->b_wlaux.p, *offs = hist+(PNL_WL_BINS+1), *coff = offs+(PNL_WL_BINS+1), *cursor = coff+(PNL_WL_BINS+1);
+    HIPCHK(ctx, hipMemsetAsync(hist, 0, sizeof(unsigned)*(PNL_WL_BINS+1), ctx->stream));
+    hipLaunchKernelGGL(k_wl_hist, dim3(512), dim3(PNL_NTHREADS), 0, ctx->stream, wl, wlc, cap, hist);
+    hipLaunchKernelGGL(k_wl_scan, dim3(1), dim3(64), 0, ctx->stream, (const unsigned*)hist, offs, coff, cursor);
+    hipLaunchKernelGGL(k_wl_scatter, dim3(512), dim3(PNL_NTHREADS), 0, ctx->stream, wl, wlc, cap, (const unsigned*)offs, cursor,
+                       (int4*)ctx->b_wlsorted.p);
+    const int st = 4+DPE;
+    const int tab_max = (60*1024)/(st*(int)sizeof(double));
+    const size_t lds = (size_t)tab_max*st*sizeof(double);
+    auto wfun = k_worklist_sorted<DIM, DPE, KT, false>;
+    HIPCHK(ctx, hipFuncSetAttribute((const void*)wfun, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const int nmin = ctx->wl_lane ? PNL_WL_LANE_MAXPTS+1 : 0;
+    int dbg = 0;
+#ifdef PNL_DEBUG_ABLATE
+    dbg = getenv("PNL_WL_DBG") ? atoi(getenv("PNL_WL_DBG")) : 0;
+#endif
+    if (ctx->wl_lane)
+        hipLaunchKernelGGL((k_worklist_lane<DIM, DPE, KT, false>), dim3(256*4), dim3(PNL_NTHREADS), 0, ctx->stream, ctx->P,
+                           (const int4*)ctx->b_wlsorted.p, (const unsigned*)offs, A, (long long)ldA, (double*)ctx->b_D.p, SparseOut{},
+                           dbg | (ctx->symflush ? 8 : 0), ClusterTiles{});
+    hipLaunchKernelGGL(wfun, dim3(256*2), dim3(PNL_NTHREADS), lds, ctx->stream, ctx->P, (const int4*)ctx->b_wlsorted.p,
+                       (const unsigned*)offs, (const unsigned*)coff, A, (long long)ldA, (double*)ctx->b_D.p, tab_max,
+                       SparseOut{}, PNL_WL_BINS-1, nmin | (ctx->symflush ? 1 << 16 : 0), ClusterTiles{});
+    HIPCHK(ctx, hipGetLastError());
+    return PNL_OK;
+}
+
+// work list for the orders that are integrated one pair per wave: `regions` regions of equal capacity, sized generously;
+// an overflow is detected (check_overflow)
+int ensure_worklist(pnl_context *ctx, double pairs, int regions) {
+    const double frac = getenv("PNL_WL_FRAC") ? atof(getenv("PNL_WL_FRAC")) : 0.05;
+    const double floor_entries = getenv("PNL_WL_FRAC") ? 64. : (double)(1 << 20);
+    const size_t each = (size_t)std::min<double>(std::max<double>(pairs*frac, floor_entries), 400e6);
+    int rc;
+    if ((rc = ensure(ctx, ctx->b_wl, each*(size_t)regions*sizeof(int4)))) return rc;
+    ctx->wl_cap = (unsigned)std::min<size_t>(ctx->b_wl.bytes/sizeof(int4), 0xffffffffu);
+    ctx->wl_cap_each = (unsigned)each;
+    if ((rc = ensure(ctx, ctx->b_tilectr, sizeof(unsigned)))) return rc;
+    return PNL_OK;
+}
+
 template <int DIM, int DPE, int TILE, int KT>
-int launch_tiles(pnl_context *ctx, int ntiles_all, double *A, int64_t ldA, int cell_begin, int cell_end) {
+int launch_tiles(pnl_context *ctx, int wl_slot, double *A, int64_t ldA, int cell_begin, int cell_end) {
     using S = TileSmem<DIM, DPE, TILE>;
     HIPCHK(ctx, hipEventRecord(ctx->ev[7], ctx->stream));
     ctx->pure_launched = false;
@@ -559,10 +437,20 @@ int launch_tiles(pnl_context *ctx, int ntiles_all, double *A, int64_t ldA, int c
         int rc = launch_pure<DIM, (DPE <= 3 ? DPE : 3), KT>(ctx, A, ldA);
         if (rc) return rc;
         ctx->pure_launched = ctx->n_pure > 0;
+        if (DIM == 2 && DPE == 3) {
+            // tiles whose pairs are all of order 3 / all of order 4 (6-point rules): pnl_tile2.h
+            int off = ctx->tile_off+ctx->n_mixed+ctx->n_pure;
+            for (int q = 3; q <= 4; q++) {
+                const int n = ctx->cls_n_uni[q-2][ctx->cur];
+                if ((rc = pnl2_launch_uniform(ctx, KT, tile_problem(ctx), (const int2*)ctx->b_tiles.p+off, nullptr, n, q, A, ldA,
+                                              (double*)(ctx->have_tile_order ? ctx->b_Dt.p : ctx->b_D.p)))) return rc;
+                ctx->pure_launched = ctx->pure_launched || n > 0;
+                off += n;
+            }
+        }
         HIPCHK(ctx, hipEventRecord(ctx->ev[7], ctx->stream));
     }
     const int ntiles = ctx->n_mixed;
-    (void)ntiles_all;
     const int acc_stride = acc_stride_of(ctx->nU, S::fixed_bytes);
     const size_t lds = S::fixed_bytes+sizeof(double)*(size_t)(ctx->nU+1)*acc_stride;
     if (getenv("PNL_VERBOSE")) {
@@ -573,22 +461,9 @@ int launch_tiles(pnl_context *ctx, int ntiles_all, double *A, int64_t ldA, int c
     if (lds > 160*1024)
         return fail(ctx, PNL_ERR_UNSUPPORTED, "a block of %d cells touches %d DoFs: LDS sub-block of %zu bytes exceeds 160 KiB "
                     "(cells must be numbered with spatial locality)", TILE, ctx->nU, lds);
-    // work list for the orders that are integrated one pair per wave; sized generously, overflow is detected
-    {
-        const double pairs = (double)ntiles*TILE*TILE;
-        const double frac = getenv("PNL_WL_FRAC") ? atof(getenv("PNL_WL_FRAC")) : 0.05;
-        const size_t want = (size_t)std::min<double>(std::max<double>(pairs*frac, 1<<20), 400e6);
-        if (ctx->wl_cap < want) {
-            int rc;
-            if ((rc = ensure(ctx, ctx->b_wl, want*sizeof(int4)))) return rc;
-            ctx->wl_cap = (unsigned)want;
-        }
-        int rc;
-        if ((rc = ensure(ctx, ctx->b_wlcount, sizeof(unsigned)))) return rc;
-        HIPCHK(ctx, hipMemsetAsync(ctx->b_wlcount.p, 0, sizeof(unsigned), ctx->stream));
-        if ((rc = ensure(ctx, ctx->b_tilectr, sizeof(unsigned)))) return rc;
-        HIPCHK(ctx, hipMemsetAsync(ctx->b_tilectr.p, 0, sizeof(unsigned), ctx->stream));
-    }
+    // one region, reused by every class / orientation pass; the fill counter of pass p stays in slot p (check_overflow)
+    unsigned *wlc = (unsigned*)ctx->b_wlcount.p+wl_slot;
+    HIPCHK(ctx, hipMemsetAsync(ctx->b_tilectr.p, 0, sizeof(unsigned), ctx->stream));
     auto kfun = k_tile_distant<DIM, DPE, TILE, KT, false>;
     HIPCHK(ctx, hipFuncSetAttribute((const void*)kfun, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     int per_cu = 2;
@@ -598,39 +473,11 @@ int launch_tiles(pnl_context *ctx, int ntiles_all, double *A, int64_t ldA, int c
     if (grid > 0)
         hipLaunchKernelGGL(kfun, dim3(grid), dim3(tile_threads(DPE, KT)), lds, ctx->stream, tile_problem(ctx), (const int2*)ctx->b_tiles.p+ctx->tile_off, A,
                            (long long)ldA, (double*)(ctx->have_tile_order ? ctx->b_Dt.p : ctx->b_D.p), cell_begin, cell_end, acc_stride, (int4*)ctx->b_wl.p,
-                           (unsigned*)ctx->b_wlcount.p, ctx->wl_cap, ctx->ablate | (ctx->symflush ? 256 : 0), ntiles, ClusterTiles{},
+                           wlc, ctx->wl_cap_each, ctx->ablate | (ctx->symflush ? 256 : 0), ntiles, ClusterTiles{},
                            (unsigned*)ctx->b_tilectr.p);
     HIPCHK(ctx, hipGetLastError());
     HIPCHK(ctx, hipEventRecord(ctx->ev[6], ctx->stream));
-    {
-        // counting sort of the work list by order, then the sorted evaluation
-        int rc;
-        if ((rc = ensure(ctx, ctx->b_wlsorted, (size_t)ctx->wl_cap*sizeof(int4)))) return rc;
-        if ((rc = ensure(ctx, ctx->b_wlaux, sizeof(unsigned)*(4*(PNL_WL_BINS+1))))) return rc;
-        unsigned *hist = (unsigned*)ctx->b_wlaux.p, *offs = hist+(PNL_WL_BINS+1), *coff = offs+(PNL_WL_BINS+1), *cursor = coff+(PNL_WL_BINS+1);
-        HIPCHK(ctx, hipMemsetAsync(hist, 0, sizeof(unsigned)*(PNL_WL_BINS+1), ctx->stream));
-        const int4 *wl = (const int4*)ctx->b_wl.p;
-        const unsigned *wlc = (const unsigned*)ctx->b_wlcount.p;
-        hipLaunchKernelGGL(k_wl_hist, dim3(512), dim3(PNL_NTHREADS), 0, ctx->stream, wl, wlc, ctx->wl_cap, hist);
-        hipLaunchKernelGGL(k_wl_scan, dim3(1), dim3(64), 0, ctx->stream, (const unsigned*)hist, offs, coff, cursor);
-        hipLaunchKernelGGL(k_wl_scatter, dim3(512), dim3(PNL_NTHREADS), 0, ctx->stream, wl, wlc, ctx->wl_cap, (const unsigned*)offs, cursor,
-                           (int4*)ctx->b_wlsorted.p);
-        const int st = 4+DPE;
-        const int tab_max = (60*1024)/(st*(int)sizeof(double));
-        const size_t lds = (size_t)tab_max*st*sizeof(double);
-        auto wfun = k_worklist_sorted<DIM, DPE, KT, false>;
-        HIPCHK(ctx, hipFuncSetAttribute((const void*)wfun, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        const int nmin = ctx->wl_lane ? PNL_WL_LANE_MAXPTS+1 : 0;
-        if (ctx->wl_lane)
-            hipLaunchKernelGGL((k_worklist_lane<DIM, DPE, KT, false>), dim3(256*4), dim3(PNL_NTHREADS), 0, ctx->stream, ctx->P,
-                               (const int4*)ctx->b_wlsorted.p, (const unsigned*)offs, A, (long long)ldA, (double*)ctx->b_D.p, SparseOut{},
-                               (getenv("PNL_WL_DBG") ? atoi(getenv("PNL_WL_DBG")) : 0) | (ctx->symflush ? 8 : 0), ClusterTiles{});
-        hipLaunchKernelGGL(wfun, dim3(256*2), dim3(PNL_NTHREADS), lds, ctx->stream, ctx->P, (const int4*)ctx->b_wlsorted.p,
-                           (const unsigned*)offs, (const unsigned*)coff, A, (long long)ldA, (double*)ctx->b_D.p, tab_max,
-                           SparseOut{}, PNL_WL_BINS-1, nmin | (ctx->symflush ? 1 << 16 : 0), ClusterTiles{});
-        HIPCHK(ctx, hipGetLastError());
-    }
-    return PNL_OK;
+    return run_worklist<DIM, DPE, KT>(ctx, (const int4*)ctx->b_wl.p, wlc, ctx->wl_cap_each, A, ldA);
 }
 
 template <int DIM, int DPE, int SLOT, int KT>
@@ -705,6 +552,58 @@ int launch_boundary(pnl_context *ctx, int cell_begin, int cell_end) {
     return PNL_OK;
 }
 
+// dim 2, dpe 6: ONE launch of the uniform-tile kernels per order and ONE of the general P2 tile kernel over the tiles of all
+// order classes (every tile entry carries its class: kernel parameters and order formula come from per-class tables), then the
+// sorted work-list evaluation per class on that class's region of the work list
+template <int DIM, int DPE>
+int launch_tiles_single(pnl_context *ctx, double *A, int64_t ldA, int cell_begin, int cell_end) {
+    int rc;
+    const int ncls = (int)ctx->cls.size();
+    const bool var = ctx->nlab > 0;
+    ctx->kcls_host.resize(ncls); ctx->fcls_host.resize(ncls);
+    bool all_fast = true, all_half = true;
+    for (int k = 0; k < ncls; k++) {
+        ctx->cur = k; ctx->orient = 0;
+        refresh_tables(ctx);
+        ctx->kcls_host[k] = ctx->P.k; ctx->fcls_host[k] = ctx->P.qo;
+        all_fast = all_fast && ctx->P.k.fast;
+        all_half = all_half && ctx->P.k.fast && ctx->P.k.qm == 6;
+    }
+    const int kt = (all_half && !getenv("PNL_NO_KT2")) ? 2 : (all_fast ? 1 : 0);
+    if ((rc = ensure(ctx, ctx->b_kcls, sizeof(DevKernel)*ncls))) return rc;
+    if ((rc = ensure(ctx, ctx->b_fcls, sizeof(DevFormula)*ncls))) return rc;
+    HIPCHK(ctx, hipMemcpyAsync(ctx->b_kcls.p, ctx->kcls_host.data(), sizeof(DevKernel)*ncls, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->b_fcls.p, ctx->fcls_host.data(), sizeof(DevFormula)*ncls, hipMemcpyHostToDevice, ctx->stream));
+    ctx->cur = 0;
+    refresh_tables(ctx);
+    const int2 *tiles = (const int2*)ctx->b_tiles.p;
+    const int *tcls = var ? (const int*)ctx->b_tilecls.p : nullptr;
+    HIPCHK(ctx, hipMemsetAsync(ctx->b_tilectr.p, 0, sizeof(unsigned), ctx->stream));
+    HIPCHK(ctx, hipEventRecord(ctx->ev[7], ctx->stream));
+    ctx->pure_launched = false;
+    for (int q = 2; q <= 4; q++) {
+        const int n = ctx->sl_n[q-1];
+        if ((rc = pnl2_launch_uniform(ctx, kt, ctx->P, tiles+ctx->sl_off[q-1], tcls ? tcls+ctx->sl_off[q-1] : nullptr, n, q, A, ldA,
+                                      (double*)ctx->b_D.p))) return rc;
+        ctx->pure_launched = ctx->pure_launched || n > 0;
+    }
+    if (ctx->pure_launched) HIPCHK(ctx, hipEventRecord(ctx->ev[7], ctx->stream));
+    if ((rc = pnl2_launch_p2(ctx, kt, tiles+ctx->sl_off[0], tcls ? tcls+ctx->sl_off[0] : nullptr, ctx->sl_n[0], A, ldA, cell_begin, cell_end,
+                             ctx->wl_cap_each))) return rc;
+    HIPCHK(ctx, hipEventRecord(ctx->ev[6], ctx->stream));
+    for (int k = 0; k < ncls; k++) {
+        ctx->cur = k;
+        refresh_tables(ctx);
+        const int4 *wl = (const int4*)ctx->b_wl.p+(size_t)k*ctx->wl_cap_each;
+        const unsigned *wlc = (const unsigned*)ctx->b_wlcount.p+k;
+        rc = ctx->P.k.fast ? run_worklist<DIM, DPE, 1>(ctx, wl, wlc, ctx->wl_cap_each, A, ldA)
+                           : run_worklist<DIM, DPE, 0>(ctx, wl, wlc, ctx->wl_cap_each, A, ldA);
+        if (rc) { ctx->cur = 0; return rc; }
+    }
+    ctx->cur = 0;
+    return PNL_OK;
+}
+
 template <int DIM, int DPE, int TILE>
 int assemble_impl(pnl_context *ctx, double *A, int64_t ldA, int zero_exterior, int ntiles, int cell_begin, int cell_end, int flags) {
     int rc;
@@ -718,20 +617,31 @@ int assemble_impl(pnl_context *ctx, double *A, int64_t ldA, int zero_exterior, i
     // a piecewise-constant variable order is assembled class by class: every pass sees the kernel, order formula and
     // singular rules of one order value and skips the pairs of the other classes in its classification
     const int norient = ctx->nonsym ? 2 : 1;
-    if (ntiles > 0)
+    if (ntiles > 0) {
+        const bool single = DIM == 2 && DPE == 6;
+        if (ncls*norient > PNL_WL_SLOTS) return fail(ctx, PNL_ERR_UNSUPPORTED, "more than %d order classes x orientations", PNL_WL_SLOTS);
+        if ((rc = ensure(ctx, ctx->b_wlcount, sizeof(unsigned)*PNL_WL_SLOTS))) return rc;
+        HIPCHK(ctx, hipMemsetAsync(ctx->b_wlcount.p, 0, sizeof(unsigned)*PNL_WL_SLOTS, ctx->stream));
+        if ((rc = ensure_worklist(ctx, (double)ntiles*TILE*TILE, single ? ncls : 1))) return rc;
+        ctx->wl_slots = single ? ncls : ncls*norient;
+        if constexpr (DIM == 2 && DPE == 6) {
+            if ((rc = launch_tiles_single<DIM, DPE>(ctx, A, ldA, ctx->tile_cell_filter ? cell_begin : 0, ctx->tile_cell_filter ? cell_end : ctx->nc)))
+                { ctx->cur = 0; ctx->orient = 0; return rc; }
+        } else
         for (int ko = 0; ko < ncls*norient; ko++) {
             const int k = ko/norient;
             ctx->cur = k; ctx->orient = ko%norient;
             refresh_tables(ctx);
             ctx->tile_off = ctx->cls_tile_off[k]; ctx->n_mixed = ctx->cls_n_mixed[k]; ctx->n_pure = ctx->cls_n_pure[k];
-            if (ctx->n_mixed+ctx->n_pure == 0) continue;
+            if (ctx->n_mixed+ctx->n_pure+ctx->cls_n_uni[1][k]+ctx->cls_n_uni[2][k] == 0) continue;
             const int tb0 = ctx->tile_cell_filter ? cell_begin : 0, tb1 = ctx->tile_cell_filter ? cell_end : ctx->nc;
             // s = 1/2 in 2D (exponent -6/4) has its own instantiation: branch-free evaluations
-            if (ctx->P.k.fast && ctx->P.k.qm == 6 && DPE == 3 && !getenv("PNL_NO_KT2")) rc = launch_tiles<DIM, DPE, TILE, (DPE == 3 ? 2 : 1)>(ctx, ntiles, A, ldA, tb0, tb1);
-            else rc = ctx->P.k.fast ? launch_tiles<DIM, DPE, TILE, 1>(ctx, ntiles, A, ldA, tb0, tb1)
-                                    : launch_tiles<DIM, DPE, TILE, 0>(ctx, ntiles, A, ldA, tb0, tb1);
+            if (ctx->P.k.fast && ctx->P.k.qm == 6 && DPE == 3 && !getenv("PNL_NO_KT2")) rc = launch_tiles<DIM, DPE, TILE, (DPE == 3 ? 2 : 1)>(ctx, ko, A, ldA, tb0, tb1);
+            else rc = ctx->P.k.fast ? launch_tiles<DIM, DPE, TILE, 1>(ctx, ko, A, ldA, tb0, tb1)
+                                    : launch_tiles<DIM, DPE, TILE, 0>(ctx, ko, A, ldA, tb0, tb1);
             if (rc) { ctx->cur = 0; ctx->orient = 0; return rc; }
         }
+    }
     ctx->orient = 0;
     HIPCHK(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
     // mirror the cross part before the symmetric contributions are added on both sides
@@ -907,8 +817,9 @@ int clusters_tiled_impl(pnl_context *ctx, const pnl_cluster_plan *pl, ClusterTil
         }
         if ((rc = ensure(ctx, ctx->b_wlds, (size_t)ctx->wl_cap*sizeof(int2)))) return rc;
         if ((rc = ensure(ctx, ctx->b_wlpair, (size_t)ctx->wl_cap*sizeof(int)))) return rc;
-        if ((rc = ensure(ctx, ctx->b_wlcount, sizeof(unsigned)))) return rc;
+        if ((rc = ensure(ctx, ctx->b_wlcount, sizeof(unsigned)*PNL_WL_SLOTS))) return rc;
         HIPCHK(ctx, hipMemsetAsync(ctx->b_wlcount.p, 0, sizeof(unsigned), ctx->stream));
+        ctx->wl_slots = 1; ctx->wl_cap_each = ctx->wl_cap;
         if ((rc = ensure(ctx, ctx->b_tilectr, sizeof(unsigned)))) return rc;
         HIPCHK(ctx, hipMemsetAsync(ctx->b_tilectr.p, 0, sizeof(unsigned), ctx->stream));
         CT.wl_ds = (int2*)ctx->b_wlds.p; CT.wl_pair = (int*)ctx->b_wlpair.p;
@@ -1126,29 +1037,44 @@ k_cg_dir(const double *__restrict__ scal, const double *__restrict__ z, int n, d
 }  // namespace
 
 // =================================================================================================
-// Is every cell pair of the tile (block a, block b) a distant pair of order 2?  Conservative bound on the order formula
-// (FL2:622-642 / FL1:234-253): with d >= dmin = |centre_a - centre_b| - rad_a - rad_b (distance of cell centres),
-// h <= hmax and L = |ln(h/H0)| in [Lmin, Lmax] per block,
-//   (c0 + a L_other + b Lmax - e ln(d/h_other)) / (max(ln(d/h_self), 0) + den0)  <=  num_max / den_min,
-// and ceil(.) <= 2 for both roles makes the order max(., 2) = 2 exactly.  dmin > hmax_a + hmax_b also rules out shared
-// vertices (a vertex is closer than 2/3 h to its cell's centre).  Anything not provably uniform goes to the general kernel.
-static bool tile_is_uniform(const pnl_context *ctx, const pnl_order_formula &F, int ta, int tb) {
-    if (ta == tb) return false;
+// Are all cell pairs of the tile (block a, block b) distant pairs of ONE quadrature order q <= qlimit?  Returns q or 0.
+// Conservative bounds on the order formula (FL2:622-642 / FL1:234-253)
+//   order = max(ceil f(1,2), ceil f(2,1), 2),  f(self, other) = (c0 + a L_other + b max(L_self, L_other) - e ln(d/h_other)) / (max(ln(d/h_self), 0) + den0)
+// over the tile: the distance of the cell centres lies in [dmin, dmax] = |centre_a - centre_b| -+ (rad_a + rad_b), h in
+// [hmin, hmax] and L = |ln(h/H0)| in [Lmin, Lmax] per block.  f <= num_max/den_min for both roles gives order <= q, and
+// f >= num_min/den_max > q-1 for ONE role (for all pairs of the tile) gives order >= q.  dmin > hmax_a + hmax_b also rules
+// out shared vertices (a vertex is closer than 2/3 h to its cell's centre).  Anything not provably uniform goes to the
+// general kernel, whose per-pair formula decides.
+static int tile_uniform_order(const pnl_context *ctx, const pnl_order_formula &F, int ta, int tb, int qlimit) {
+    if (ta == tb) return 0;
     const auto &A = ctx->blocks[ta], &B = ctx->blocks[tb];
-    if (!A.full || !B.full || !(F.e >= 0.) || !(F.den0 > 0.)) return false;
-    const double dx = A.cx-B.cx, dy = A.cy-B.cy;
-    const double dmin = std::sqrt(dx*dx+dy*dy)-A.rad-B.rad;
-    if (!(dmin > A.hmax+B.hmax)) return false;
-    auto bound = [&](const pnl_context::BlockAgg &S, const pnl_context::BlockAgg &O) {
+    if (!A.full || !B.full || !(F.e >= 0.) || !(F.den0 > 0.)) return 0;
+    const double dx = A.cx-B.cx, dy = A.cy-B.cy, dc = std::sqrt(dx*dx+dy*dy);
+    const double dmin = dc-A.rad-B.rad, dmax = dc+A.rad+B.rad;
+    if (!(dmin > A.hmax+B.hmax)) return 0;
+    typedef pnl_context::BlockAgg Agg;
+    auto upper = [&](const Agg &S, const Agg &O, double q) {       // f(S, O) <= q for every pair
         const double l_self = std::log(dmin/S.hmax), n_other = std::log(dmin/O.hmax);      // both > 0
         const double aL = std::max(F.a*O.Lmin, F.a*O.Lmax);
         const double bL = std::max(F.b*std::max(S.Lmin, O.Lmin), F.b*std::max(S.Lmax, O.Lmax));
         const double num = F.c0+aL+bL-F.e*n_other, den = l_self+F.den0;
-        return num <= 2.*den*(1.-1e-9)-1e-9;
+        return num <= q*den*(1.-1e-9)-1e-9;
     };
-    return bound(A, B) && bound(B, A);
+    auto lower = [&](const Agg &S, const Agg &O, double q) {       // f(S, O) > q for every pair
+        const double l_self = std::log(dmax/S.hmin), n_other = std::log(dmax/O.hmin);
+        const double aL = std::min(F.a*O.Lmin, F.a*O.Lmax);
+        const double bL = std::min(F.b*std::max(S.Lmin, O.Lmin), F.b*std::max(S.Lmax, O.Lmax));
+        const double num = F.c0+aL+bL-F.e*n_other, den = l_self+F.den0;
+        return den > 0. && num >= q*den*(1.+1e-9)+1e-9;
+    };
+    for (int q = 2; q <= qlimit; q++)
+        if (upper(A, B, q) && upper(B, A, q)) {
+            if (q == 2) return 2;
+            return (lower(A, B, q-1) || lower(B, A, q-1)) ? q : 0;
+        }
+    return 0;
 }
-
+static bool tile_is_uniform(const pnl_context *ctx, const pnl_order_formula &F, int ta, int tb) { return tile_uniform_order(ctx, F, ta, tb, 2) == 2; }
 
 namespace {
 template <int DIM>
@@ -1182,9 +1108,10 @@ int pointwise_impl(pnl_context *ctx, double *A, int64_t ldA, int zero_exterior, 
             ctx->wl_cap = (unsigned)want;
         }
         if ((rc = ensure(ctx, ctx->b_wlsorted, (size_t)ctx->wl_cap*sizeof(int4)))) return rc;
-        if ((rc = ensure(ctx, ctx->b_wlcount, sizeof(unsigned)))) return rc;
+        if ((rc = ensure(ctx, ctx->b_wlcount, sizeof(unsigned)*PNL_WL_SLOTS))) return rc;
         if ((rc = ensure(ctx, ctx->b_wlaux, sizeof(unsigned)*(4*(PNL_WL_BINS+1))))) return rc;
         HIPCHK(ctx, hipMemsetAsync(ctx->b_wlcount.p, 0, sizeof(unsigned), ctx->stream));
+        ctx->wl_slots = 1; ctx->wl_cap_each = ctx->wl_cap;
     }
     // block tiles of the upper triangle: uniform ones (every pair provably of order 2 for every pair order in the range of
     // the two blocks) go to k_pw_tile, the others through classification and the sorted work list
@@ -1342,7 +1269,8 @@ int horizon_impl(pnl_context *ctx, SparseOut S) {
     const size_t cap = std::min(tiles.size(), chunk_tiles)*per_tile;
     if ((rc = ensure(ctx, ctx->b_mp_pairs, cap*sizeof(int2)))) return rc;
     if ((rc = ensure(ctx, ctx->b_mp_wl, cap*sizeof(int4)))) return rc;
-    if ((rc = ensure(ctx, ctx->b_wlcount, sizeof(unsigned)))) return rc;
+    if ((rc = ensure(ctx, ctx->b_wlcount, sizeof(unsigned)*PNL_WL_SLOTS))) return rc;
+    ctx->wl_slots = 1; ctx->wl_cap_each = (unsigned)cap;
     S.pairs = (const int*)ctx->b_mp_pairs.p;
     S.masks = nullptr;
     unsigned long long total = 0;
@@ -1424,7 +1352,9 @@ int pnl_create(int device_id, pnl_context **out) {
     for (auto &e : ctx->ev)
         if (hipEventCreate(&e) != hipSuccess) { delete ctx; return PNL_ERR_HIP; }
     std::memset(&ctx->P, 0, sizeof(ctx->P));
-    if (const char *e = getenv("PNL_ABLATE")) ctx->ablate = atoi(e);
+#ifdef PNL_DEBUG_ABLATE
+    if (const char *e = getenv("PNL_ABLATE")) ctx->ablate = atoi(e);      // result-changing debug switches: debug builds only
+#endif
     if (const char *e = getenv("PNL_WL_LANE")) ctx->wl_lane = atoi(e) != 0;
     if (const char *e = getenv("PNL_PURE")) ctx->use_pure = atoi(e) != 0;
     ctx->cls.push_back(new pnl_context::ClassData());
@@ -1451,10 +1381,32 @@ int pnl_set_stream(pnl_context *ctx, void *hip_stream) {
     return PNL_OK;
 }
 
+// Entries beyond a work list's capacity and pairs whose quadrature order exceeds the uploaded tables are dropped by the
+// kernels; the counters that tell (one fill counter per class pass, counter 5) are read here so that the loss fails the
+// first call that waits for the assembly instead of going unnoticed.
+static int check_overflow(pnl_context *ctx) {
+    if (ctx->b_wlcount.p && ctx->wl_cap_each > 0) {
+        unsigned wl[PNL_WL_SLOTS];
+        const int n = std::max(1, std::min(ctx->wl_slots, PNL_WL_SLOTS));
+        HIPCHK(ctx, hipMemcpy(wl, ctx->b_wlcount.p, sizeof(unsigned)*n, hipMemcpyDeviceToHost));
+        for (int i = 0; i < n; i++)
+            if (wl[i] > ctx->wl_cap_each)
+                return fail(ctx, PNL_ERR_STATE, "work list overflow (pass %d): %u entries needed, capacity %u; the assembled operator is "
+                            "incomplete", i, wl[i], ctx->wl_cap_each);
+    }
+    if (ctx->b_counters.p) {
+        unsigned long long ov = 0;
+        HIPCHK(ctx, hipMemcpy(&ov, (const unsigned long long*)ctx->b_counters.p+5, sizeof(ov), hipMemcpyDeviceToHost));
+        if (ov) return fail(ctx, PNL_ERR_ORDER, "%llu pairs need a quadrature order beyond the uploaded tables (qmax=%d); the assembled "
+                            "operator is incomplete", ov, ctx->qmax);
+    }
+    return PNL_OK;
+}
+
 int pnl_synchronize(pnl_context *ctx) {
     if (!ctx) return PNL_ERR_INVALID;
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    return PNL_OK;
+    return check_overflow(ctx);
 }
 
 int pnl_upload_mesh(pnl_context *ctx, int dim, int nv, const double *vertices, int nc, const int32_t *cells,
@@ -1596,6 +1548,32 @@ int pnl_upload_distant_rules(pnl_context *ctx, int qmax, const int32_t *off, con
         if ((rc = upload(ctx, ctx->b_tttab, tab.data(), tab.size()))) return rc;
         if ((rc = upload(ctx, ctx->b_ttwphi, wphi.data(), wphi.size()))) return rc;
         ctx->P.tt_npts = npts;
+        // second-generation tile kernels: w, w phi[0..dpe-1] of the packed points (point order of tab)
+        std::vector<double> wphif;
+        for (int q = 2; q <= qmax && q < 18; q++)
+            for (int i = 0; i < tn[q]; i++) {
+                const size_t p = (size_t)off[q]+i;
+                wphif.push_back(w[p]);
+                for (int a = 0; a < dpe; a++) wphif.push_back(w[p]*phi[p*dpe+a]);
+            }
+        if ((rc = upload(ctx, ctx->b_ttwphif, wphif.data(), wphif.size()))) return rc;
+        // rule blocks of the uniform-order tiles (2D, orders 2-4 with 3 or 6 points): bary[n][3], w[n], w phi[n][dpe],
+        // w phi_a phi_b[nd][n] (a <= b, row-major upper triangle)
+        std::vector<double> uni;
+        for (int q = 0; q < 5; q++) { ctx->uni_off[q] = -1; ctx->uni_np[q] = 0; }
+        for (int q = 2; q <= 4 && q <= qmax && ctx->dim == 2; q++) {
+            const int n = off[q+1]-off[q];
+            if (n != 3 && n != 6) continue;
+            ctx->uni_off[q] = (int)uni.size(); ctx->uni_np[q] = n;
+            for (int i = 0; i < n; i++) for (int k2 = 0; k2 < 3; k2++) uni.push_back(bary[3*((size_t)off[q]+i)+k2]);
+            for (int i = 0; i < n; i++) uni.push_back(w[off[q]+i]);
+            for (int i = 0; i < n; i++) for (int a = 0; a < dpe; a++) uni.push_back(w[off[q]+i]*phi[((size_t)off[q]+i)*dpe+a]);
+            for (int a = 0; a < dpe; a++)
+                for (int b = a; b < dpe; b++)
+                    for (int i = 0; i < n; i++) uni.push_back(w[off[q]+i]*phi[((size_t)off[q]+i)*dpe+a]*phi[((size_t)off[q]+i)*dpe+b]);
+        }
+        if ((rc = upload(ctx, ctx->b_uni, uni.data(), uni.size()))) return rc;
+        ctx->tiles_cached.clear(); ctx->tiles_forms.clear();
     }
     ctx->qmax = qmax;
     ctx->have_rules = true;
@@ -1660,7 +1638,13 @@ static int upload_tiles(pnl_context *ctx, std::vector<int2> &tiles, int cell_beg
         return PNL_OK;
     const int T = ctx->tile;
     const bool filter = ctx->tile_cell_filter;
-    const bool allow = ctx->use_pure && T == 64 && (ctx->dpe == 3 || ctx->dpe == 2) && ctx->qmax >= 2 && !ctx->nonsym;
+    // uniform tiles: order 2 through k_tile_pure (P1 in 1D and 2D), orders 2-4 through k_tile_uniform (2D: P1 orders 3 and 4, P2)
+    const bool p1 = T == 64 && (ctx->dpe == 3 || ctx->dpe == 2), p2 = ctx->dim == 2 && ctx->dpe == 6;
+    const bool allow = ctx->use_pure && (p1 || p2) && ctx->qmax >= 2 && !ctx->nonsym;
+    int qlimit = 2;
+    if (ctx->dim == 2) for (int q = 3; q <= 4 && ctx->uni_off[q] >= 0 && ctx->uni_np[q] == 6 && q <= ctx->qmax; q++) qlimit = q;
+    const bool q2ok = p1 ? true : (ctx->uni_off[2] >= 0 && ctx->uni_np[2] == 3);
+    if (getenv("PNL_UNI_QMAX")) qlimit = std::min(qlimit, std::max(2, atoi(getenv("PNL_UNI_QMAX"))));
     // variable order: a class only visits the tiles whose blocks hold a label pair of that class (most blocks carry one
     // label, so the K passes together classify every tile about once instead of K times)
     const int L = ctx->nlab;
@@ -1674,11 +1658,11 @@ static int upload_tiles(pnl_context *ctx, std::vector<int2> &tiles, int cell_beg
             v.erase(std::unique(v.begin(), v.end()), v.end());
         }
     }
-    std::vector<int2> all;
     ctx->cls_tile_off.assign(ncls, 0); ctx->cls_n_mixed.assign(ncls, 0); ctx->cls_n_pure.assign(ncls, 0);
-    std::vector<int2> mixed, pure;
-    for (int k = 0; k < ncls; k++) {
-        mixed.clear(); pure.clear();
+    for (int u = 0; u < 3; u++) ctx->cls_n_uni[u].assign(ncls, 0);
+    std::vector<std::vector<int2>> mixed(ncls), uni[3];
+    for (int u = 0; u < 3; u++) uni[u].resize(ncls);
+    for (int k = 0; k < ncls; k++)
         for (const int2 &t : tiles) {
             bool single = true;
             if (L > 0) {
@@ -1688,14 +1672,50 @@ static int upload_tiles(pnl_context *ctx, std::vector<int2> &tiles, int cell_beg
                 if (!has) continue;
                 single = blk_labels[t.x].size() == 1 && blk_labels[t.y].size() == 1;
             }
-            bool u = allow && single && tile_is_uniform(ctx, forms[k], t.x, t.y);
+            int q = (allow && single) ? tile_uniform_order(ctx, forms[k], t.x, t.y, qlimit) : 0;
+            if (q == 2 && !q2ok) q = 0;
             // the cell range of the MPI-style split applies to the a-cells: only blocks entirely inside qualify
-            if (u && filter && !(t.x*T >= cell_begin && (t.x+1)*T <= cell_end)) u = false;
-            (u ? pure : mixed).push_back(t);
+            if (q && filter && !(t.x*T >= cell_begin && (t.x+1)*T <= cell_end)) q = 0;
+            (q ? uni[q-2][k] : mixed[k]).push_back(t);
         }
-        ctx->cls_tile_off[k] = (int)all.size(); ctx->cls_n_mixed[k] = (int)mixed.size(); ctx->cls_n_pure[k] = (int)pure.size();
-        all.insert(all.end(), mixed.begin(), mixed.end());
-        all.insert(all.end(), pure.begin(), pure.end());
+    std::vector<int2> all;
+    std::vector<int32_t> allcls;
+    ctx->single_launch = p2;
+    if (!p2) {
+        // per class: [mixed][order 2][order 3][order 4]
+        for (int k = 0; k < ncls; k++) {
+            ctx->cls_tile_off[k] = (int)all.size(); ctx->cls_n_mixed[k] = (int)mixed[k].size();
+            all.insert(all.end(), mixed[k].begin(), mixed[k].end());
+            for (int u = 0; u < 3; u++) { ctx->cls_n_uni[u][k] = (int)uni[u][k].size(); all.insert(all.end(), uni[u][k].begin(), uni[u][k].end()); }
+            ctx->cls_n_pure[k] = ctx->cls_n_uni[0][k];
+        }
+    } else {
+        // one launch over all classes: [mixed tiles of all classes][order 2][order 3][order 4]; class word = 2 class + orientation
+        // (a non-symmetric order table visits every mixed tile once per orientation)
+        const int norient = ctx->nonsym ? 2 : 1;
+        ctx->sl_off[0] = 0;
+        for (int k = 0; k < ncls; k++) {
+            ctx->cls_n_mixed[k] = (int)mixed[k].size();
+            for (int o = 0; o < norient; o++)
+                for (const int2 &t : mixed[k]) { all.push_back(t); allcls.push_back(2*k+o); }
+        }
+        ctx->sl_n[0] = (int)all.size();
+        for (int u = 0; u < 3; u++) {
+            ctx->sl_off[u+1] = (int)all.size();
+            for (int k = 0; k < ncls; k++) {
+                ctx->cls_n_uni[u][k] = (int)uni[u][k].size();
+                for (const int2 &t : uni[u][k]) { all.push_back(t); allcls.push_back(2*k); }
+            }
+            ctx->sl_n[u+1] = (int)all.size()-ctx->sl_off[u+1];
+        }
+        for (int k = 0; k < ncls; k++) ctx->cls_n_pure[k] = ctx->cls_n_uni[0][k];
+        int rc2 = upload(ctx, ctx->b_tilecls, allcls.data(), allcls.size());
+        if (rc2) return rc2;
+    }
+    if (getenv("PNL_VERBOSE")) {
+        size_t nm = 0, nu[3] = {0, 0, 0};
+        for (int k = 0; k < ncls; k++) { nm += mixed[k].size(); for (int u = 0; u < 3; u++) nu[u] += uni[u][k].size(); }
+        fprintf(stderr, "[pnl] tiles: %zu mixed, uniform order 2/3/4: %zu / %zu / %zu (qlimit %d)\n", nm, nu[0], nu[1], nu[2], qlimit);
     }
     int rc = upload(ctx, ctx->b_tiles, all.data(), all.size());
     if (rc) return rc;
@@ -2210,14 +2230,8 @@ int pnl_get_counters(pnl_context *ctx, int64_t *out, int n) {
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     HIPCHK(ctx, hipMemcpy(tmp, ctx->b_counters.p, sizeof(tmp), hipMemcpyDeviceToHost));
     tmp[0] = ctx->visited_is_assembled ? tmp[1] : ctx->visited_pairs;
-    if (ctx->b_wlcount.p) {
-        unsigned wl = 0;
-        HIPCHK(ctx, hipMemcpy(&wl, ctx->b_wlcount.p, sizeof(wl), hipMemcpyDeviceToHost));
-        if (wl > ctx->wl_cap) return fail(ctx, PNL_ERR_STATE, "work list overflow: %u entries needed, capacity %u", wl, ctx->wl_cap);
-    }
     for (int i = 0; i < n && i < PNL_NCOUNTERS; i++) out[i] = (int64_t)tmp[i];
-    if (tmp[5]) return fail(ctx, PNL_ERR_ORDER, "%llu pairs need a quadrature order beyond the uploaded tables (qmax=%d)", tmp[5], ctx->qmax);
-    return PNL_OK;
+    return check_overflow(ctx);
 }
 
 int pnl_get_phase_ms(pnl_context *ctx, float *out, int n) {

@@ -15,166 +15,7 @@
 // FL2 = fractionalLaplacian2D.pyx, FL1 = fractionalLaplacian1D.pyx, KC = kernelsCy.pyx).
 #pragma once
 #include "pnl_device.h"
-
-// ---------------------------------------------------------------------------------------------
-// kernel function gamma(|x-y|^2)   (KC:75-294)
-// Branch-free ln and exp for the kernels with a general exponent: d2^e = exp(e ln d2), d2 a positive normal number and
-// |e ln d2| far from overflow.  Straight-line code (no special cases), so the independent evaluations of a pair interleave.
-// ln x: x = m 2^k with m in [sqrt(1/2), sqrt(2)); ln m = 2 atanh(f), f = (m-1)/(m+1), |f| < 0.172, odd series to f^21.
-__device__ __forceinline__ double pnl_log(double x) {
-    double m = __builtin_amdgcn_frexp_mant(x);           // [0.5, 1)
-    int k = __builtin_amdgcn_frexp_exp(x);
-    const bool low = m < 0.70710678118654752440;
-    m = low ? m+m : m;
-    k = low ? k-1 : k;
-    const double a = m-1.0, b = m+1.0;
-    double r = __builtin_amdgcn_rcp(b);
-    r = __builtin_fma(__builtin_fma(-b, r, 1.0), r, r);
-    r = __builtin_fma(__builtin_fma(-b, r, 1.0), r, r);
-    double f = a*r;
-    f = __builtin_fma(__builtin_fma(-f, b, a), r, f);
-    const double z = f*f;
-    double p = 1.0/21.0;
-    p = __builtin_fma(p, z, 1.0/19.0);
-    p = __builtin_fma(p, z, 1.0/17.0);
-    p = __builtin_fma(p, z, 1.0/15.0);
-    p = __builtin_fma(p, z, 1.0/13.0);
-    p = __builtin_fma(p, z, 1.0/11.0);
-    p = __builtin_fma(p, z, 1.0/9.0);
-    p = __builtin_fma(p, z, 1.0/7.0);
-    p = __builtin_fma(p, z, 1.0/5.0);
-    p = __builtin_fma(p, z, 1.0/3.0);
-    const double lm = __builtin_fma(f+f, z*p, f+f);       // 2 f + 2 f^3 (1/3 + ...)
-    const double kd = (double)k;
-    return __builtin_fma(kd, 6.93147180369123816490e-01, __builtin_fma(kd, 1.90821492927058770002e-10, lm));
-}
-
-// exp y, |y| < 700: y = n ln 2 + r, |r| <= 0.347, Taylor polynomial to r^13, scaled by 2^n
-__device__ __forceinline__ double pnl_exp(double y) {
-    const double n = __builtin_rint(y*1.44269504088896338700);
-    double r = __builtin_fma(-n, 6.93147180369123816490e-01, y);
-    r = __builtin_fma(-n, 1.90821492927058770002e-10, r);
-    double p = 1.0/6227020800.0;
-    p = __builtin_fma(p, r, 1.0/479001600.0);
-    p = __builtin_fma(p, r, 1.0/39916800.0);
-    p = __builtin_fma(p, r, 1.0/3628800.0);
-    p = __builtin_fma(p, r, 1.0/362880.0);
-    p = __builtin_fma(p, r, 1.0/40320.0);
-    p = __builtin_fma(p, r, 1.0/5040.0);
-    p = __builtin_fma(p, r, 1.0/720.0);
-    p = __builtin_fma(p, r, 1.0/120.0);
-    p = __builtin_fma(p, r, 1.0/24.0);
-    p = __builtin_fma(p, r, 1.0/6.0);
-    p = __builtin_fma(p, r, 0.5);
-    p = __builtin_fma(p, r, 1.0);
-    p = __builtin_fma(p, r, 1.0);
-    return __builtin_amdgcn_ldexp(p, (int)n);
-}
-
-// KT: 0 general (pow / indicator / peridynamic, horizon test), 1 fractional with exponent -qm/4, qm a run-time (wave-uniform)
-// value, 2 the same with qm == 6 known at compile time (s = 1/2 in 2D): no branch per evaluation, so the compiler
-// interleaves the dependent chains of the independent evaluations of a pair.
-template <int KT>
-__device__ __forceinline__ double kern_eval(const DevKernel &k, double d2) {
-    if (KT == 2) {
-        // d2^(-3/2) = r^3 (1 - e)^(-3/2) with r = v_rsq_f64(d2) (~2^-23 relative), e = 1 - d2 r^2 (|e| < 3e-7):
-        // r^3 (1 + e (3/2 + 15/8 e)), the next term 35/16 e^3 is below 1e-19; six operations after the rsq, chain depth five
-        const double r = __builtin_amdgcn_rsq(d2);
-        const double t = r*r;
-        const double e = __builtin_fma(-d2, t, 1.0);
-        const double g0 = r*t;
-        return __builtin_fma(g0, e*__builtin_fma(1.875, e, 1.5), g0);
-    } else if (KT == 1) {
-        // exponent = -qm/4 (s a multiple of 1/4 in 1D / 2D): d2^(-1/2) from v_rsq_f64 (~2^-23 relative) + one Halley step
-        // (cubic: r (1 + e/2 + 3 e^2/8), e = 1 - d2 r^2, five operations for full precision), for odd qm one more refined
-        // rsqrt gives d2^(-1/4); then an integer power.  A few ulp instead of libm's pow at 1/8 of the cost.  The scale is
-        // applied once per pair (kern_scale); qm is wave-uniform, the branches are scalar.
-        double r = __builtin_amdgcn_rsq(d2);
-        {
-            const double e = __builtin_fma(-(d2*r), r, 1.0);
-            r = __builtin_fma(r, e*__builtin_fma(0.375, e, 0.5), r);
-        }
-        int p = k.qm;
-        if (p == 6) return (r*r)*r;                      // s = 1/2 in 2D
-        double base = r;
-        if (p & 1) {
-            double t = __builtin_amdgcn_rsq(r);
-            const double e = __builtin_fma(-(r*t), t, 1.0);
-            t = __builtin_fma(t, e*__builtin_fma(0.375, e, 0.5), t);
-            base = r*t;                                  // d2^(-1/4)
-        } else p >>= 1;
-        double res = (p & 1) ? base : 1.;
-        p >>= 1;
-        while (p) {
-            base *= base;
-            if (p & 1) res *= base;
-            p >>= 1;
-        }
-        return res;
-    } else {
-        if (!(d2 <= k.horizon2)) return 0.;
-        // general exponent: exp(e ln d2) instead of pow (half the instructions; |e ln d2| < 60 keeps the relative error of the
-        // product below 1e-14, three orders under the parity tolerance)
-        if (k.ktype == 0) return k.scale*pnl_exp(k.exponent*pnl_log(d2));
-        if (k.ktype == 1) return k.scale;
-        return k.scale/sqrt(d2);
-    }
-}
-
-template <int KT>
-__device__ __forceinline__ double kern_scale(const DevKernel &k) { return KT >= 1 ? k.scale : 1.; }
-
-// distant quadrature order  (FL2:622-642, :1226-1243, FL1:234-253, :646-660)
-__device__ __forceinline__ int quad_order(const DevFormula &F, double H0, double h1, double h2, double d) {
-    double logdh1 = log(d/h1), logdh2 = log(d/h2);
-    double L1 = fabs(log(h1/H0)), L2 = fabs(log(h2/H0));
-    double Lm = fmax(L1, L2);
-    double n1 = logdh1, n2 = logdh2;
-    if (F.clip) { n1 = fmax(logdh1, 0.); n2 = fmax(logdh2, 0.); }
-    double p1 = ceil((F.c0 + F.a*L2 + F.b*Lm - F.e*n2)/(fmax(logdh1, 0.) + F.den0));
-    double p2 = ceil((F.c0 + F.a*L1 + F.b*Lm - F.e*n1)/(fmax(logdh2, 0.) + F.den0));
-    int q1 = (int)fmax(p1, 2.), q2 = (int)fmax(p2, 2.);
-    return q1 > q2 ? q1 : q2;
-}
-
-// Same order, decided in fp32 where that is safe: the fp32 value of the ceil() argument is off by < 2e-5 (v_log_f32 /
-// v_rcp_f32 are 1 ulp, the operands are O(10)), so whenever it is further than 2e-4 from an integer the fp64 formula
-// gives the same ceil; otherwise (0.03 % of the pairs) the exact fp64 formula decides.  lh = ln h and L = |ln(h/H0)| per
-// cell are staged once per tile in fp32, Ld = |ln(h/H0)| in fp64 for the exact path.
-__device__ __forceinline__ int quad_order_exact(const DevFormula &F, double h1, double h2, double Ld1, double Ld2, double d) {
-    const double logdh1 = log(d/h1), logdh2 = log(d/h2);
-    const double Lm = fmax(Ld1, Ld2);
-    double n1 = logdh1, n2 = logdh2;
-    if (F.clip) { n1 = fmax(logdh1, 0.); n2 = fmax(logdh2, 0.); }
-    const double p1 = ceil((F.c0 + F.a*Ld2 + F.b*Lm - F.e*n2)/(fmax(logdh1, 0.) + F.den0));
-    const double p2 = ceil((F.c0 + F.a*Ld1 + F.b*Lm - F.e*n1)/(fmax(logdh2, 0.) + F.den0));
-    const int q1 = (int)fmax(p1, 2.), q2 = (int)fmax(p2, 2.);
-    return q1 > q2 ? q1 : q2;
-}
-
-__device__ __forceinline__ int quad_order_fast(const DevFormula &F, double h1, double h2, float lh1, float lh2,
-                                               float L1, float L2, double Ld1, double Ld2, double d2) {
-    const float ld = 0.5f*0.69314718056f*__builtin_amdgcn_logf((float)d2);
-    const float logdh1 = ld-lh1, logdh2 = ld-lh2;
-    const float Lm = fmaxf(L1, L2);
-    const float n1 = F.clip ? fmaxf(logdh1, 0.f) : logdh1, n2 = F.clip ? fmaxf(logdh2, 0.f) : logdh2;
-    const float c0 = (float)F.c0, a = (float)F.a, b = (float)F.b, e = (float)F.e, den0 = (float)F.den0;
-    const float a1 = (c0+a*L2+b*Lm-e*n2)*__builtin_amdgcn_rcpf(fmaxf(logdh1, 0.f)+den0);
-    const float a2 = (c0+a*L1+b*Lm-e*n1)*__builtin_amdgcn_rcpf(fmaxf(logdh2, 0.f)+den0);
-    const float r1 = rintf(a1), r2 = rintf(a2);
-    const bool risky = (a1 > 1.5f && fabsf(a1-r1) < 2e-4f) || (a2 > 1.5f && fabsf(a2-r2) < 2e-4f) || !(a1 == a1) || !(a2 == a2);
-    if (risky) return quad_order_exact(F, h1, h2, Ld1, Ld2, sqrt(d2));
-    const int q1 = (int)fmaxf(ceilf(a1), 2.f), q2 = (int)fmaxf(ceilf(a2), 2.f);
-    return q1 > q2 ? q1 : q2;
-}
-
-// hardware fp64 adds (global_atomic_add_f64 / ds_add_f64, no CAS loop); built with -munsafe-fp-atomics
-__device__ __forceinline__ void atomic_add_f64(double *p, double v) {
-    (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ void lds_add_f64(double *p, double v) {
-    (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
+#include "pnl_common.h"
 
 // ---------------------------------------------------------------------------------------------
 // Distant pair, one pair per lane (NO:722-789, uncut branch).  The reference forms
@@ -261,7 +102,6 @@ __device__ __forceinline__ void eval_distant_generic(const DevProblem &P, int of
 // so u_{DPE-1}(i) = r_i - sum_{b < DPE-1} u_b(i) saves one FMA per point pair.
 // (The table is read through the constant address space: it is never written by a kernel, and loads from that address space
 // with a uniform address are scalar loads wherever they stand -- global loads after the first store of a kernel are not.)
-typedef const double __attribute__((address_space(4))) *pnl_const_f64_ptr;
 template <int DIM, int DPE, int KT, int N>
 __device__ __forceinline__ void eval_distant_fixed(const DevProblem &P, const double *__restrict__ tab, const double *gwp_global,
                                                    const double *av, const double *bv, PairAcc<DIM, DPE> &R) {
@@ -571,6 +411,13 @@ k_tile_distant(const DevProblem P, const int2 *__restrict__ tiles, double *__res
                double *__restrict__ Dglob, int cell_begin, int cell_end, int acc_stride, int4 *__restrict__ worklist,
                unsigned *__restrict__ wl_count, unsigned wl_cap, int ablate, int ntiles, const ClusterTiles CT,
                unsigned *__restrict__ tile_ctr) {
+    // debug switches that skip work (evaluation, accumulation, flush) exist only in PNL_DEBUG_ABLATE builds; bit 256 is
+    // PNL_FLAG_SYMMETRIC_FLUSH
+#ifdef PNL_DEBUG_ABLATE
+    const int abl = ablate;
+#else
+    const int abl = ablate & 256;
+#endif
     using S = TileSmem<DIM, DPE, TILE>;
     constexpr int NV = S::NV, NC = S::NC, ND = S::ND, NT = tile_threads(DPE, KT, FH);
     constexpr int PAIRS = TILE*TILE, PER_THREAD = (PAIRS+NT-1)/NT;
@@ -676,7 +523,7 @@ k_tile_distant(const DevProblem P, const int2 *__restrict__ tiles, double *__res
         // dense: upper triangle of the cell pairs, a-cells of the caller's range.  Cluster tiles: n1 == n2 -> unordered pairs
         // once (chunk pair a <= b); n1 != n2 -> every ordered pair (X in n1.cells, Y in n2.cells); identical cells share all
         // vertices and are left to the touching-pair lists like every other touching pair
-        bool ok = inside && (va0 >= 0) && (vb0 >= 0) && !(ablate & 8) &&
+        bool ok = inside && (va0 >= 0) && (vb0 >= 0) && !(abl & 8) &&
                   (CLUSTER ? (!sym || ta < tb || i < j) : ((ta < tb || i < j || (fh && i == j)) && (ca >= cell_begin) && (ca < cell_end)));
         // variable order: this launch assembles the pairs of one order class only
         if (!CLUSTER && P.cur_class >= 0 && ok) {
@@ -721,7 +568,7 @@ k_tile_distant(const DevProblem P, const int2 *__restrict__ tiles, double *__res
                     const double t = s_cen[(0*DIM+d)*TILE+i]-s_cen[(1*DIM+d)*TILE+j];
                     d2 += t*t;
                 }
-                if (ablate & 16) q = 2;
+                if (abl & 16) q = 2;
                 else q = quad_order_fast(P.qo, s_h[i], s_h[TILE+j], s_lh[i], s_lh[2*TILE+j], s_lh[TILE+i], s_lh[3*TILE+j],
                                          s_Ld[i], s_Ld[TILE+j], d2);
                 if (q > P.qmax || q > PNL_MAXQ) { overflow++; q = 0; }
@@ -852,7 +699,7 @@ k_tile_distant(const DevProblem P, const int2 *__restrict__ tiles, double *__res
     auto accumulate = [&](const PairAcc<DIM, DPE> &R, int i, int j) {
         // NA:1405-1410: symmetric cell pairs count twice
         const double vv = 2.*s_vol[i]*s_vol[TILE+j]*kern_scale<KT>(P.k);
-        if (ablate & 1) {
+        if (abl & 1) {
             double keep = 0.;
 #pragma unroll
             for (int a = 0; a < DPE; a++)
@@ -879,7 +726,7 @@ k_tile_distant(const DevProblem P, const int2 *__restrict__ tiles, double *__res
                     const int dA = s_dslot[i], dB = s_dslot[TILE+j];
                     if (dA >= 0) lds_add_f64(&s_D[(0*TILE+i)*ND+e], vv*R.S1[e]);
                     if (dB >= 0 && (sym || dA < 0)) lds_add_f64(&s_D[(1*TILE+j)*ND+e], vv*R.S2[e]);
-                } else if (!(ablate & 64)) {
+                } else if (!(abl & 64)) {
                     lds_add_f64(&s_D[(0*TILE+i)*ND+e], vv*R.S1[e]);
                     lds_add_f64(&s_D[(1*TILE+j)*ND+e], vv*R.S2[e]);
                 } else if (R.S1[e]+R.S2[e] == 1.2345e300) s_D[0] = 1.;
@@ -887,7 +734,7 @@ k_tile_distant(const DevProblem P, const int2 *__restrict__ tiles, double *__res
             }
         }
     };
-    if (!(ablate & 2))
+    if (!(abl & 2))
 #pragma unroll 1
     for (int pass = 0; pass < 2; pass++) {
         const int total = __builtin_amdgcn_readfirstlane(s_misc[pass]);
@@ -914,7 +761,7 @@ k_tile_distant(const DevProblem P, const int2 *__restrict__ tiles, double *__res
     }
     // ---- list C: counting sort by order into the (now free) storage of list B, then 64 pairs of one order per wave ----
     const int nC = s_misc[3];
-    if (nC && !(ablate & 2)) {
+    if (nC && !(abl & 2)) {
         __syncthreads();
         if (tid == 0) {
             int run = 0, nch = 0;
@@ -994,7 +841,7 @@ k_tile_distant(const DevProblem P, const int2 *__restrict__ tiles, double *__res
     // ---- flush: sub-block of A' (rows = DoFs of block a, cols = DoFs of block b) and diagonal blocks ----
     const int *__restrict__ dofA = CLUSTER ? CT.chunk_dofs+(size_t)ta*CT.chunk_stride : P.blk_dofs+(size_t)ta*P.blk_stride;
     const int *__restrict__ dofB = CLUSTER ? CT.chunk_dofs+(size_t)tb*CT.chunk_stride : P.blk_dofs+(size_t)tb*P.blk_stride;
-    if (!(ablate & 4)) {
+    if (!(abl & 4)) {
     for (int t = tid; t < nA*nB; t += NT) {
         const int r = t/nB, c = t-r*nB;
         const double v = s_acc[r*acc_stride+c];
@@ -1013,7 +860,7 @@ k_tile_distant(const DevProblem P, const int2 *__restrict__ tiles, double *__res
         }
     }
     // PNL_FLAG_SYMMETRIC_FLUSH (no mirror pass): the transposed image in its own sweep, consecutive threads along a row of A
-    if (!CLUSTER && (ablate & 256))
+    if (!CLUSTER && (abl & 256))
         for (int t = tid; t < nA*nB; t += NT) {
             const int c = t/nA, r = t-c*nA;
             const double v = s_acc[r*acc_stride+c];
@@ -1047,82 +894,6 @@ k_tile_distant(const DevProblem P, const int2 *__restrict__ tiles, double *__res
 }
 
 // ---------------------------------------------------------------------------------------------
-// wave-wide sum with DPP row shifts / broadcasts (no LDS traffic); result in every lane
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ double dpp_add(double v) {
-    // full row mask: lanes without a source read 0 (bound_ctrl), so the destination needs no zero-initialised "old" value
-    // (two v_mov_b32 less per step); partial row masks keep old = 0 in the disabled rows
-    constexpr bool BC = ROW_MASK == 0xf;
-    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xf, BC);
-    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xf, BC);
-    return v+__hiloint2double(hi, lo);
-}
-__device__ __forceinline__ double wave_sum(double v) {
-    v = dpp_add<0x111, 0xf>(v);      // row_shr:1
-    v = dpp_add<0x112, 0xf>(v);      // row_shr:2
-    v = dpp_add<0x114, 0xf>(v);      // row_shr:4
-    v = dpp_add<0x118, 0xf>(v);      // row_shr:8  -> lane 15 of every row holds the row sum
-    v = dpp_add<0x142, 0xa>(v);      // row_bcast:15 into rows 1 and 3
-    v = dpp_add<0x143, 0xc>(v);      // row_bcast:31 into rows 2 and 3 -> lane 63 holds the total
-    const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63);
-    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
-    return __hiloint2double(hi, lo);
-}
-
-// Three wave-wide sums at once (the column sums of the 3-point rule): the first two butterfly stages pack the three inputs
-// by lane & 3 (lanes 0, 1 -> a, b; lanes 2, 3 -> c), so that from then on ONE value per lane is reduced over the lanes of
-// equal lane & 3: row rotations by 4 and 8, then the gfx950 row / half-wave swaps (v_permlane16_swap, v_permlane32_swap).
-// 39 VALU operations instead of 3 x 24 for three separate wave_sum calls.
-template <int CTRL>
-__device__ __forceinline__ double dpp_get(double v) {
-    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, true);
-    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, true);
-    return __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ double add_xor16(double v) {      // v[l] + v[l ^ 16]
-    const auto lo = __builtin_amdgcn_permlane16_swap(__double2loint(v), __double2loint(v), false, false);
-    const auto hi = __builtin_amdgcn_permlane16_swap(__double2hiint(v), __double2hiint(v), false, false);
-    return __hiloint2double(hi[0], lo[0])+__hiloint2double(hi[1], lo[1]);
-}
-__device__ __forceinline__ double add_xor32(double v) {      // v[l] + v[l ^ 32]
-    const auto lo = __builtin_amdgcn_permlane32_swap(__double2loint(v), __double2loint(v), false, false);
-    const auto hi = __builtin_amdgcn_permlane32_swap(__double2hiint(v), __double2hiint(v), false, false);
-    return __hiloint2double(hi[0], lo[0])+__hiloint2double(hi[1], lo[1]);
-}
-__device__ __forceinline__ void wave_sum3(double a, double b, double c, double &A, double &B, double &C) {
-    const int lane = threadIdx.x & 63;
-    const bool o1 = (lane & 1) != 0, o2 = (lane & 2) != 0;
-    double x = o1 ? b : a;
-    x += dpp_get<0xB1>(o1 ? a : b);            // quad_perm [1,0,3,2]: even lanes hold a pair sum of a, odd lanes of b
-    const double y = c+dpp_get<0xB1>(c);       // pair sums of c in both lanes
-    double z = o2 ? y : x;
-    z += dpp_get<0x4E>(o2 ? x : y);            // quad_perm [2,3,0,1]: lane & 3 = 0: quad sum of a, 1: of b, 2 and 3: of c
-    z += dpp_get<0x124>(z);                    // row_ror:4
-    z += dpp_get<0x128>(z);                    // row_ror:8 -> row sums, by lane & 3
-    z = add_xor16(z);
-    z = add_xor32(z);
-    const int lo = __double2loint(z), hi = __double2hiint(z);
-    A = __hiloint2double(__builtin_amdgcn_readlane(hi, 0), __builtin_amdgcn_readlane(lo, 0));
-    B = __hiloint2double(__builtin_amdgcn_readlane(hi, 1), __builtin_amdgcn_readlane(lo, 1));
-    C = __hiloint2double(__builtin_amdgcn_readlane(hi, 2), __builtin_amdgcn_readlane(lo, 2));
-}
-
-// sum over the 16 lanes of a DPP row, result in every lane of the row
-template <int CTRL>
-__device__ __forceinline__ double dpp_row_add(double v) {
-    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
-    return v+__hiloint2double(hi, lo);
-}
-__device__ __forceinline__ double row16_sum(double v) {
-    v = dpp_row_add<0xB1>(v);        // quad_perm [1,0,3,2]
-    v = dpp_row_add<0x4E>(v);        // quad_perm [2,3,0,1]
-    v = dpp_row_add<0x141>(v);       // row_half_mirror
-    v = dpp_row_add<0x140>(v);       // row_mirror
-    return v;
-}
-
-// ---------------------------------------------------------------------------------------------
 // Uniform tiles: every one of the 64 x 64 cell pairs of the tile is a distant pair of the lowest order (host-side
 // conservative bound on the order formula over the two blocks, see classify_tiles in pnl_hip.hip) -- two thirds of all
 // pairs at noRef 6, more on finer meshes.  No classification, no lists: lane = cell i of block a, the four waves split the
@@ -1133,6 +904,9 @@ template <int DIM, int DPE, int KT>
 __global__ void __launch_bounds__(PNL_NTHREADS, PNL_PURE_WAVES)
 k_tile_pure(const DevProblem P, const int2 *__restrict__ tiles, int ntiles, double *__restrict__ A, long long ldA,
             double *__restrict__ Dglob, int acc_stride, int q_uniform, int symflush) {
+#ifndef PNL_DEBUG_ABLATE
+    symflush &= 1;                                      // the other bits skip work (debug builds only)
+#endif
     constexpr int TILE = 64, NV = DIM+1, NC = NV*DIM, ND = DPE*(DPE+1)/2, NP = (DIM == 2) ? 3 : 2, ST = 4+DPE;
     constexpr int JW = TILE/(PNL_NTHREADS/64);          // cells j per wave
     extern __shared__ double smem[];
@@ -2277,6 +2051,9 @@ template <int DIM, int DPE, int KT, bool SPARSE>
 __global__ void __launch_bounds__(PNL_NTHREADS)
 k_worklist_lane(const DevProblem P, const int4 *__restrict__ sorted, const unsigned *__restrict__ offs, double *__restrict__ A,
                 long long ldA, double *__restrict__ Dglob, const SparseOut S, int dbg, const ClusterTiles CT) {
+#ifndef PNL_DEBUG_ABLATE
+    dbg &= 8;                                           // the other bits skip work (debug builds only)
+#endif
     const bool cluster = CT.npairs > 0;             // work list of the cluster tiles: entry.z indexes wl_pair / wl_ds
     constexpr int NV = DIM+1, NC = NV*DIM, ND = DPE*(DPE+1)/2, ST = 4+DPE, STP = (ST+1) & ~1;
     __shared__ unsigned s_coff[PNL_WL_BINS+1];
@@ -3296,19 +3073,7 @@ k_cluster_boundary(const DevProblem P, const double *__restrict__ verts, const i
 // int phi_I L_alpha (enterLeafValues :1205-1325), upward / downward passes with the transfer operators
 // (:1092-1124, :1157-1180; the transfer matrices :2004-2073 are built on the host) and H2Matrix.matvec :2269-2295.
 // Tensor index alpha = alpha_0 + m alpha_1 (coordinate 0 fastest) in every array of this file.
-struct H2Dev {
-    int dim, m, M, nnodes, nleaves, nfar;
-    const double *box;          // [nnodes][dim][2]
-    const int *parent;          // [nnodes] (-1: root)
-    const int *leaf_node;       // [nleaves]
-    const int *leaf_dof_off, *leaf_dofs;        // sorted DoFs of the leaves
-    const int *leaf_cell_off, *leaf_cells;      // cells touching them
-    const long long *leaf_val_off;              // [nleaves] offset of V_leaf[ndofs][M]
-    const int *far;             // [nfar][2] (n1, n2)
-    double *V, *K;              // leaf values, kernel interpolants [nfar][M][M]
-    const double *T;            // [nnodes][M_parent][M_child] transfer operator of every non-root node
-    double *cup, *cdown;        // [nnodes][M]
-};
+// struct H2Dev: pnl_device.h
 
 // j-th Chebyshev node of [a, b]: eta_j = cos((2 (m-j) - 1) pi / (2m)) (clusterMethodCy.pyx:2173, 1255)
 __device__ __forceinline__ double cheb_node(double a, double b, int m, int j) {

@@ -12,19 +12,7 @@
 #pragma once
 #include "pnl_kernels.h"
 
-struct PwDev {
-    int type, normalized;       // 1 constant, 2 smoothStep(x0), 3 linearStep(x0), 4 smoothStepRadial (fractionalOrders.pyx:338-540)
-    double p[6];                // sl, sr, r, interface | radius, slope
-    int scal_n, pad0;           // scaling C(s) as a Chebyshev series over the range of the order (0: Gamma functions)
-    double scal_mid, scal_inv_half, scal_cheb[32];
-    double c0, bc0;             // constant term of the interior / boundary order formula
-    const double *cell_smax, *facet_smax;
-    int M[3], rows[3];
-    const double *nodes[3], *w[3], *phi0[3], *phi1[3];      // [nkeys][...] per slot
-    int bM[2], pad;
-    const double *bnodes[2], *bw[2], *bphi[2];
-    double sfac, bfac;
-};
+// struct PwDev: pnl_device.h
 
 template <int DIM>
 __device__ __forceinline__ double pw_order(const PwDev &W, const double *x) {

@@ -1,0 +1,787 @@
+// Second generation of the dense tile kernels (gfx950 only, 2D):
+//
+//   k_tile_uniform<DPE, NP, KT>  tiles whose cell pairs are ALL distant pairs of ONE quadrature order (host-side
+//                                conservative bounds on the order formula, tile_uniform_order in pnl_hip.hip): no
+//                                classification, no lists.  P2 (32-cell blocks): lane = (cell i of block a, half h), the two
+//                                halves of a wave take two cells j of block b at a time; P1 (64-cell blocks): lane = cell i.
+//                                NP = 3 (order 2) or 6 (orders 3 and 4) points per triangle.
+//   k_tile_p2<KT>                the general tile kernel for P2 (78 local entries per pair).  What made the first version
+//                                need 350-390 VGPRs were the 2 x 21 diagonal-block accumulators S1 / S2 beside the 36 of the
+//                                cross block G.  The diagonal blocks only depend on the row sums r_i = sum_j w_j g_ij and the
+//                                column sums c_j = sum_i w_i g_ij of the kernel values:
+//                                   S1[a,b] = sum_i w_i phi_a phi_b(x_i) r_i,   S2[a,b] = sum_j w_j phi_a phi_b(y_j) c_j,
+//                                so a pair adds N values per side to per-(cell, point) LDS buffers and the 21 entries per
+//                                cell are formed once per tile at the flush.  G + c + y fit 256 VGPRs: 512 threads, two
+//                                waves per SIMD.  Waves fetch their 64-pair chunks from an LDS counter, heavy chunks first.
+//
+// Same numbers as eval_distant (NO:722-789) in its factorised form (see pnl_kernels.h), same LDS sub-block of A'.
+#pragma once
+#include "pnl_common.h"
+
+// ---- group reductions ------------------------------------------------------------------------------------------------
+// three sums over groups of W = 32 or 64 consecutive lanes at once; the results are returned in every lane of the group.
+// (wave_sum3 of pnl_common.h with quad broadcasts instead of readlanes; W = 32 stops before the half-wave swap.)
+template <int W>
+__device__ __forceinline__ void group_sum3(double a, double b, double c, double &A, double &B, double &C) {
+    const int lane = threadIdx.x & 63;
+    const bool o1 = (lane & 1) != 0, o2 = (lane & 2) != 0;
+    double x = o1 ? b : a;
+    x += dpp_get<0xB1>(o1 ? a : b);            // quad_perm [1,0,3,2]
+    const double y = c+dpp_get<0xB1>(c);
+    double z = o2 ? y : x;
+    z += dpp_get<0x4E>(o2 ? x : y);            // quad_perm [2,3,0,1]: lane & 3 = 0: quad sum of a, 1: of b, 2 and 3: of c
+    z += dpp_get<0x124>(z);                    // row_ror:4
+    z += dpp_get<0x128>(z);                    // row_ror:8
+    z = add_xor16(z);
+    if (W == 64) z = add_xor32(z);
+    A = dpp_get<0x00>(z);                      // quad_perm [0,0,0,0]
+    B = dpp_get<0x55>(z);                      // quad_perm [1,1,1,1]
+    C = dpp_get<0xAA>(z);                      // quad_perm [2,2,2,2]
+}
+
+// layout of a uniform-tile rule block (doubles): bary[NP][3], w[NP], w phi[NP][DPE], w phi_a phi_b[ND][NP]
+__host__ __device__ constexpr int uni_rule_size(int dpe, int np) { return 3*np+np+np*dpe+(dpe*(dpe+1)/2)*np; }
+
+// ---------------------------------------------------------------------------------------------------------------------
+template <int DPE, int NP, int KT>
+__global__ void __launch_bounds__(256, 2)
+k_tile_uniform(const DevProblem P, const int2 *__restrict__ tiles, const int *__restrict__ tile_cls, const DevKernel *__restrict__ kcls,
+               int ntiles, double *__restrict__ A, long long ldA, double *__restrict__ Dglob, int acc_stride, int q_uniform,
+               int flags, const double *__restrict__ rule_g) {
+    constexpr int DIM = 2, NV = 3, NC = 6, ND = DPE*(DPE+1)/2, NT = 256, NW = NT/64;
+    constexpr int TILE = DPE == 6 ? 32 : 64, HALVES = 64/TILE, JW = TILE/NW, ITER = JW/HALVES;
+    constexpr int R_BARY = 0, R_W = 3*NP, R_WPH = R_W+NP, R_PP = R_WPH+NP*DPE;
+    const pnl_const_f64_ptr rule = (pnl_const_f64_ptr)(unsigned long long)rule_g;
+    extern __shared__ double smem[];
+    double *s_y = smem;                                  // [TILE][NP*DIM] quadrature points of the b-cells
+    double *s_volb = s_y+TILE*NP*DIM;                    // [TILE]
+    double *s_Ra = s_volb+TILE;                          // [TILE][NP] row sums of the a-cells (weighted: vol_b w_i)
+    double *s_Db = s_Ra+TILE*NP;                         // [TILE][ND] diagonal blocks of the b-cells
+    int *s_slotb = (int*)(s_Db+TILE*ND);                 // [TILE][DPE]
+    int *s_hb = s_slotb+TILE*DPE;                        // [TILE] has-a-DoF flags
+    double *s_acc = (double*)(s_hb+TILE);                // [nA+1][acc_stride]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane%TILE, half = lane/TILE;
+    // w phi_a phi_b at the points for the diagonal-block entry e = li this lane forms for the b-cells
+    double ppe[NP];
+#pragma unroll
+    for (int jp = 0; jp < NP; jp++) ppe[jp] = li < ND ? rule_g[R_PP+li*NP+jp] : 0.;
+    unsigned long long npairs = 0;
+#pragma unroll 1
+    for (int tile_idx = blockIdx.x; tile_idx < ntiles; tile_idx += gridDim.x) {
+        const int2 tl = tiles[tile_idx];
+        const int ta = tl.x, tb = tl.y;
+        const int nA = P.blk_ndof[ta], nB = P.blk_ndof[tb];
+        // variable order, piecewise constant: the tile's blocks carry one label each, the kernel of their class is tile-uniform
+        DevKernel kk = P.k;
+        if (tile_cls) kk = kcls[tile_cls[tile_idx] >> 1];
+        const double scale2 = 2.*kern_scale<KT>(kk);
+        __syncthreads();                                 // the previous tile's flush is done with the LDS buffers
+        if (tid < TILE) {
+            const int c = tb*TILE+tid;
+            double bv[NC];
+#pragma unroll
+            for (int k = 0; k < NC; k++) bv[k] = P.cellv[(size_t)k*P.ncp+c];
+#pragma unroll
+            for (int jp = 0; jp < NP; jp++)
+#pragma unroll
+                for (int d = 0; d < DIM; d++) {
+                    double sy = 0.;
+#pragma unroll
+                    for (int k = 0; k < NV; k++) sy = __builtin_fma(rule[R_BARY+3*jp+k], bv[k*DIM+d], sy);
+                    s_y[tid*NP*DIM+jp*DIM+d] = sy;
+                }
+            s_volb[tid] = P.cvol[c];
+            int any = 0;
+#pragma unroll
+            for (int k = 0; k < DPE; k++) {
+                const int sl = P.cslot[(size_t)k*P.ncp+c];
+                s_slotb[tid*DPE+k] = sl >= 0 ? sl : nB;
+                any |= (sl >= 0);
+            }
+            s_hb[tid] = any;
+        }
+        for (int t = tid; t < (nA+1)*acc_stride; t += NT) s_acc[t] = 0.;
+        for (int t = tid; t < TILE*NP; t += NT) s_Ra[t] = 0.;
+        // a side: lane = cell li (both halves of a P2 wave hold the same cells)
+        const int ca = ta*TILE+li;
+        double av[NC];
+#pragma unroll
+        for (int k = 0; k < NC; k++) av[k] = P.cellv[(size_t)k*P.ncp+ca];
+        int sa[DPE];
+        bool ha = false;
+#pragma unroll
+        for (int k = 0; k < DPE; k++) {
+            const int sl = P.cslot[(size_t)k*P.ncp+ca];
+            sa[k] = (sl >= 0 ? sl : nA)*acc_stride;
+            ha = ha || sl >= 0;
+        }
+        const double vola = P.cvol[ca];
+        __syncthreads();
+#pragma unroll 1
+        for (int jj = 0; jj < ITER; jj++) {
+            const int j = wave*JW+jj*HALVES+half;
+            double y[NP][DIM];
+#pragma unroll
+            for (int jp = 0; jp < NP; jp++)
+#pragma unroll
+                for (int d = 0; d < DIM; d++) y[jp][d] = s_y[j*NP*DIM+jp*DIM+d];
+            const bool valid = ha || (s_hb[j] != 0);     // NA:138-150: pairs with boundary DoFs only are skipped
+            npairs += (unsigned long long)__popcll(__ballot(valid));
+            const double volb = valid ? s_volb[j] : 0.;
+            double c[NP], G[DPE][DPE];
+#pragma unroll
+            for (int jp = 0; jp < NP; jp++) c[jp] = 0.;
+#pragma unroll
+            for (int a = 0; a < DPE; a++)
+#pragma unroll
+                for (int b = 0; b < DPE; b++) G[a][b] = 0.;
+            // rows of the tensor rule: fully unrolled for 3 points; for 6 points the loop stays rolled (its body already holds
+            // 36 independent chains) and everything indexed by ip is recomputed or read through the scalar cache
+#pragma unroll (NP == 3 ? 3 : 1)
+            for (int ip = 0; ip < NP; ip++) {
+                double x[DIM];
+#pragma unroll
+                for (int d = 0; d < DIM; d++) {
+                    double sx = 0.;
+#pragma unroll
+                    for (int k = 0; k < NV; k++) sx = __builtin_fma(rule[R_BARY+3*ip+k], av[k*DIM+d], sx);
+                    x[d] = sx;
+                }
+                const double wi = rule[R_W+ip];
+                double r = 0., u[DPE];
+#pragma unroll
+                for (int b = 0; b < DPE; b++) u[b] = 0.;
+#pragma unroll
+                for (int jp = 0; jp < NP; jp++) {
+                    double d2 = 0.;
+#pragma unroll
+                    for (int d = 0; d < DIM; d++) { const double t = x[d]-y[jp][d]; d2 = __builtin_fma(t, t, d2); }
+                    const double g = kern_eval<KT>(kk, d2);
+                    r = __builtin_fma(rule[R_W+jp], g, r);
+                    c[jp] = __builtin_fma(wi, g, c[jp]);
+#pragma unroll
+                    for (int b = 0; b < DPE; b++) u[b] = __builtin_fma(g, rule[R_WPH+jp*DPE+b], u[b]);
+                }
+                lds_add_f64(&s_Ra[li*NP+ip], volb*r);
+#pragma unroll
+                for (int a = 0; a < DPE; a++) {
+                    const double pa = rule[R_WPH+ip*DPE+a];
+#pragma unroll
+                    for (int b = 0; b < DPE; b++) G[a][b] = __builtin_fma(pa, u[b], G[a][b]);
+                }
+            }
+            // cross block -> LDS sub-block of A'
+            const double vv = scale2*vola*volb;
+#pragma unroll
+            for (int b = 0; b < DPE; b++) {
+                const int sb = s_slotb[j*DPE+b];
+#pragma unroll
+                for (int a = 0; a < DPE; a++) lds_add_f64(&s_acc[sa[a]+sb], -vv*G[a][b]);
+            }
+            // diagonal block of cell j: column sums over the cells i of the group, then entry e = li
+            const double wa = valid ? vola : 0.;
+            double s2 = 0.;
+#pragma unroll
+            for (int g3 = 0; g3 < NP; g3 += 3) {
+                double c0, c1, c2;
+                group_sum3<TILE>(wa*c[g3], wa*c[g3+1], wa*c[g3+2], c0, c1, c2);
+                s2 = __builtin_fma(ppe[g3], c0, s2);
+                s2 = __builtin_fma(ppe[g3+1], c1, s2);
+                s2 = __builtin_fma(ppe[g3+2], c2, s2);
+            }
+            if (li < ND) s_Db[j*ND+li] = scale2*s_volb[j]*s2;    // this group owns cell j: plain store
+        }
+        __syncthreads();
+        // ---- flush: one wave per row of the sub-block, lanes along the row of A ----
+        const int *__restrict__ dofA = P.blk_dofs+(size_t)ta*P.blk_stride;
+        const int *__restrict__ dofB = P.blk_dofs+(size_t)tb*P.blk_stride;
+#pragma unroll 1
+        for (int r = wave; r < nA; r += NW) {
+            double *__restrict__ row = A+(long long)dofA[r]*ldA;
+            for (int cc = lane; cc < nB; cc += 64) {
+                const double v = s_acc[r*acc_stride+cc];
+                if (v != 0.) atomic_add_f64(&row[dofB[cc]], v);
+            }
+        }
+        // PNL_FLAG_SYMMETRIC_FLUSH (no mirror pass): the transposed image, lanes along the row of A again
+        if (flags & 1)
+#pragma unroll 1
+            for (int cc = wave; cc < nB; cc += NW) {
+                double *__restrict__ row = A+(long long)dofB[cc]*ldA;
+                for (int r = lane; r < nA; r += 64) {
+                    const double v = s_acc[r*acc_stride+cc];
+                    if (v != 0.) atomic_add_f64(&row[dofA[r]], v);
+                }
+            }
+        for (int t = tid; t < 2*TILE*ND; t += NT) {
+            const int side = t/(TILE*ND), rem = t-side*TILE*ND, cl = rem/ND, e = rem-cl*ND;
+            const int cc = (side ? tb : ta)*TILE+cl;
+            double v;
+            if (side) v = s_Db[rem];
+            else {
+                double s1 = 0.;
+#pragma unroll
+                for (int ip = 0; ip < NP; ip++) s1 = __builtin_fma(rule_g[R_PP+e*NP+ip], s_Ra[cl*NP+ip], s1);
+                v = scale2*P.cvol[cc]*s1;
+            }
+            if (v != 0.) atomic_add_f64(&Dglob[(size_t)cc*ND+e], v);
+        }
+    }
+    // statistics: every lane of a wave holds the same count
+    if (lane == 0 && npairs) {
+        atomicAdd(&P.counters[8+q_uniform], npairs);
+        atomicAdd(&P.counters[1], npairs);
+        atomicAdd(&P.counters[2], npairs*(unsigned long long)(NP*NP));
+        atomicAdd(&P.counters[6], npairs);
+    }
+}
+
+// =====================================================================================================================
+// General P2 tile kernel
+#define P2_TILE 32
+#define P2_NT 512
+#define P2_MAXPTS 96
+#define P2_MAXCHUNKS 96
+struct P2Smem {
+    static constexpr int TILE = P2_TILE, NV = 3, NC = 6, DPE = 6, ND = 21, PAIRS = TILE*TILE, ST = 4+DPE;
+    // doubles
+    static constexpr int o_v = 0;                          // [2][NC][TILE]
+    static constexpr int o_cen = o_v+2*NC*TILE;            // [2][2][TILE]
+    static constexpr int o_vol = o_cen+4*TILE;             // [2][TILE]
+    static constexpr int o_h = o_vol+2*TILE;               // [2][TILE]
+    static constexpr int o_Ld = o_h+2*TILE;                // [2][TILE]
+    static constexpr int o_D = o_Ld+2*TILE;                // [2][TILE][ND] contributions formed per pair (list C)
+    static constexpr int NR = 15;                          // row / column sums per (side, cell): the 3-point rule, the first and
+                                                           // the second 6-point rule (orders 2, 3, 4 on triangles)
+    static constexpr int o_R = o_D+2*TILE*ND;              // [2][TILE][NR]
+    static constexpr int o_PP = o_R+2*TILE*NR;             // [ND][NR] (+ pad): w phi_a phi_b at the points of those rules
+    static constexpr int o_tt = o_PP+ND*NR+1;              // [P2_MAXPTS][ST]
+    static constexpr int n_dbl = o_tt+P2_MAXPTS*ST;
+    // ints
+    static constexpr int o_vid = 0;                        // [2][NV][TILE]
+    static constexpr int o_cnt = o_vid+2*NV*TILE;          // [PNL_MAXQ+2]
+    static constexpr int o_cur = o_cnt+PNL_MAXQ+2;         // [PNL_MAXQ+2]
+    static constexpr int o_misc = o_cur+PNL_MAXQ+2;        // [8]: |A|, |B|, |far|, |C|, #C chunks, next chunk, next tile, wl base
+    static constexpr int o_lh = o_misc+8;                  // float [2][2][TILE]
+    static constexpr int o_ttn = o_lh+4*TILE;              // [PNL_MAXQ+2]
+    static constexpr int o_tto = o_ttn+PNL_MAXQ+2;         // [PNL_MAXQ+2]
+    static constexpr int o_chunk = o_tto+PNL_MAXQ+2;       // [P2_MAXCHUNKS] list C chunks: order << 20 | start << 7 | count-1
+    static constexpr int o_l32 = o_chunk+P2_MAXCHUNKS;     // [PAIRS] list B from the front, far list from the back
+    static constexpr int n_int = o_l32+PAIRS;
+    // shorts
+    static constexpr int o_slot = 0;                       // [2][DPE][TILE]
+    static constexpr int o_list = o_slot+2*DPE*TILE;       // [PAIRS] list A from the front, list C from the back
+    static constexpr int o_csort = o_list+PAIRS;           // [PAIRS] list C sorted by order
+    static constexpr int n_short = o_csort+PAIRS;
+    static constexpr size_t fixed_bytes = sizeof(double)*n_dbl+sizeof(int)*n_int+sizeof(short)*n_short;
+};
+static_assert(P2Smem::n_int % 2 == 0 && P2Smem::n_short % 4 == 0, "LDS regions must keep 8-byte alignment");
+
+__device__ __forceinline__ int p2_wave_bucket_add(int *counters, int q) {
+    unsigned long long todo = __ballot(q > 0);
+    while (todo) {
+        const int leader = __ffsll((long long)todo)-1;
+        const int qL = __builtin_amdgcn_readlane(q, leader);
+        const unsigned long long same = __ballot(q == qL);
+        if ((int)(threadIdx.x & 63) == leader) atomicAdd(&counters[qL], __popcll(same));
+        todo &= ~same;
+    }
+    return 0;
+}
+
+// one pair per lane, N points per triangle known at compile time: cross block G, column sums c; the row sums go straight to
+// the per-(cell, point) LDS buffer Ra (scaled by vv).  gw: per point w, w phi[0..5] through the scalar cache; tab: the LDS
+// copy of the rule (per point bary[3], w, phi[6]) for everything indexed by the rolled loop variable i.
+template <int KT, int N>
+__device__ __forceinline__ void p2_eval_fixed(const DevKernel &kk, const double *__restrict__ tab, const double *gw_global,
+                                              const double *av, const double *bv, double vv, bool act, double *Ra,
+                                              double (&G)[6][6], double (&c)[N]) {
+    constexpr int ST = 10, GS = 7;
+    const pnl_const_f64_ptr gw = (pnl_const_f64_ptr)(unsigned long long)gw_global;
+    double y[N][2];
+#pragma unroll
+    for (int j = 0; j < N; j++) {
+        c[j] = 0.;
+#pragma unroll
+        for (int d = 0; d < 2; d++) {
+            double s = 0.;
+#pragma unroll
+            for (int k = 0; k < 3; k++) s = __builtin_fma(tab[j*ST+k], bv[k*2+d], s);
+            y[j][d] = s;
+        }
+    }
+#pragma unroll 1
+    for (int i = 0; i < N; i++) {
+        double x[2];
+#pragma unroll
+        for (int d = 0; d < 2; d++) {
+            double s = 0.;
+#pragma unroll
+            for (int k = 0; k < 3; k++) s = __builtin_fma(tab[i*ST+k], av[k*2+d], s);
+            x[d] = s;
+        }
+        const double wi = tab[i*ST+3];
+        double r = 0., u[6];
+#pragma unroll
+        for (int b = 0; b < 6; b++) u[b] = 0.;
+#pragma unroll
+        for (int j = 0; j < N; j++) {
+            double d2 = 0.;
+#pragma unroll
+            for (int d = 0; d < 2; d++) { const double t = x[d]-y[j][d]; d2 = __builtin_fma(t, t, d2); }
+            const double g = kern_eval<KT>(kk, d2);
+            r = __builtin_fma(gw[j*GS], g, r);
+            c[j] = __builtin_fma(wi, g, c[j]);
+#pragma unroll
+            for (int b = 0; b < 6; b++) u[b] = __builtin_fma(g, gw[j*GS+1+b], u[b]);
+        }
+        if (act) lds_add_f64(&Ra[i], vv*r);
+#pragma unroll
+        for (int a = 0; a < 6; a++) {
+            const double pa = wi*tab[i*ST+4+a];
+#pragma unroll
+            for (int b = 0; b < 6; b++) G[a][b] = __builtin_fma(pa, u[b], G[a][b]);
+        }
+    }
+}
+
+// runtime number of points (list C: orders with 7-16 points, a few per cent of the pairs), first sweep: G and S1
+template <int KT>
+__device__ __forceinline__ void p2_eval_lds_sweep1(const DevKernel &kk, const double *__restrict__ tab, int n, const double *av,
+                                                   const double *bv, double (&G)[6][6], double (&S)[21]) {
+    constexpr int ST = 10;
+#pragma unroll 1
+    for (int i = 0; i < n; i++) {
+        const double *__restrict__ ti = tab+i*ST;
+        double x[2];
+#pragma unroll
+        for (int d = 0; d < 2; d++) {
+            double s = 0.;
+#pragma unroll
+            for (int k = 0; k < 3; k++) s = __builtin_fma(ti[k], av[k*2+d], s);
+            x[d] = s;
+        }
+        const double wi = ti[3];
+        double r = 0., u[6];
+#pragma unroll
+        for (int b = 0; b < 6; b++) u[b] = 0.;
+#pragma unroll 2
+        for (int j = 0; j < n; j++) {
+            const double *__restrict__ tj = tab+j*ST;
+            double d2 = 0.;
+#pragma unroll
+            for (int d = 0; d < 2; d++) {
+                double sy = 0.;
+#pragma unroll
+                for (int k = 0; k < 3; k++) sy = __builtin_fma(tj[k], bv[k*2+d], sy);
+                const double t = x[d]-sy;
+                d2 = __builtin_fma(t, t, d2);
+            }
+            const double K = (wi*tj[3])*kern_eval<KT>(kk, d2);
+            r += K;
+#pragma unroll
+            for (int b = 0; b < 6; b++) u[b] = __builtin_fma(K, tj[4+b], u[b]);
+        }
+        int e = 0;
+#pragma unroll
+        for (int a = 0; a < 6; a++) {
+            const double pa = ti[4+a];
+#pragma unroll
+            for (int b = 0; b < 6; b++) G[a][b] = __builtin_fma(pa, u[b], G[a][b]);
+            const double pr = pa*r;
+#pragma unroll
+            for (int b = a; b < 6; b++) { S[e] = __builtin_fma(pr, ti[4+b], S[e]); e++; }
+        }
+    }
+}
+
+// second sweep: the column sums c_j = sum_i w_i w_j g_ij (the kernel values once more: cheaper than 21 FMAs per point pair) -> S2
+template <int KT>
+__device__ __forceinline__ void p2_eval_lds_sweep2(const DevKernel &kk, const double *__restrict__ tab, int n, const double *av,
+                                                   const double *bv, double (&S)[21]) {
+    constexpr int ST = 10;
+#pragma unroll 1
+    for (int j = 0; j < n; j++) {
+        const double *__restrict__ tj = tab+j*ST;
+        double y[2];
+#pragma unroll
+        for (int d = 0; d < 2; d++) {
+            double s = 0.;
+#pragma unroll
+            for (int k = 0; k < 3; k++) s = __builtin_fma(tj[k], bv[k*2+d], s);
+            y[d] = s;
+        }
+        double cc = 0.;
+#pragma unroll 2
+        for (int i = 0; i < n; i++) {
+            const double *__restrict__ ti = tab+i*ST;
+            double d2 = 0.;
+#pragma unroll
+            for (int d = 0; d < 2; d++) {
+                double sx = 0.;
+#pragma unroll
+                for (int k = 0; k < 3; k++) sx = __builtin_fma(ti[k], av[k*2+d], sx);
+                const double t = sx-y[d];
+                d2 = __builtin_fma(t, t, d2);
+            }
+            cc = __builtin_fma(ti[3], kern_eval<KT>(kk, d2), cc);
+        }
+        cc *= tj[3];
+        int e = 0;
+#pragma unroll
+        for (int a = 0; a < 6; a++) {
+            const double pc = tj[4+a]*cc;
+#pragma unroll
+            for (int b = a; b < 6; b++) { S[e] = __builtin_fma(pc, tj[4+b], S[e]); e++; }
+        }
+    }
+}
+
+template <int KT>
+__global__ void __launch_bounds__(P2_NT, 2)
+k_tile_p2(const DevProblem P, const int2 *__restrict__ tiles, const int *__restrict__ tile_cls, const DevKernel *__restrict__ kcls,
+          const DevFormula *__restrict__ fcls, double *__restrict__ A, long long ldA, double *__restrict__ Dglob, int cell_begin,
+          int cell_end, int acc_stride, int4 *__restrict__ worklist, unsigned *__restrict__ wl_count, unsigned wl_cap, int flags,
+          int ntiles, unsigned *__restrict__ tile_ctr) {
+    using S = P2Smem;
+    constexpr int TILE = S::TILE, NV = 3, NC = 6, DPE = 6, ND = 21, NT = P2_NT, PAIRS = S::PAIRS, PER_THREAD = PAIRS/NT, ST = S::ST;
+    constexpr int NA = 3, NB = 6, NWAVES = NT/64;
+    extern __shared__ double smem[];
+    double *s_dbl = smem;
+    int *s_int = (int*)(s_dbl+S::n_dbl);
+    short *s_short = (short*)(s_int+S::n_int);
+    double *s_acc = (double*)(s_short+S::n_short);          // [nA+1][acc_stride]
+    double *s_v = s_dbl+S::o_v, *s_cen = s_dbl+S::o_cen, *s_vol = s_dbl+S::o_vol, *s_h = s_dbl+S::o_h, *s_Ld = s_dbl+S::o_Ld;
+    double *s_D = s_dbl+S::o_D, *s_R = s_dbl+S::o_R, *s_PP = s_dbl+S::o_PP, *s_tt = s_dbl+S::o_tt;
+    constexpr int NR = S::NR;
+    int *s_vid = s_int+S::o_vid, *s_cnt = s_int+S::o_cnt, *s_cur = s_int+S::o_cur, *s_misc = s_int+S::o_misc;
+    float *s_lh = (float*)(s_int+S::o_lh);
+    int *s_ttn = s_int+S::o_ttn, *s_tto = s_int+S::o_tto, *s_chunk = s_int+S::o_chunk, *s_l32 = s_int+S::o_l32;
+    short *s_slot = s_short+S::o_slot;
+    unsigned short *s_list = (unsigned short*)(s_short+S::o_list), *s_csort = (unsigned short*)(s_short+S::o_csort);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const unsigned long long lt = (1ull << lane)-1ull;
+    unsigned long long st_cnt = 0, st_ev = 0;                // statistics of order q = 2 + tid, kept over all tiles
+    for (int t = tid; t < PNL_MAXQ+2; t += NT) { s_ttn[t] = P.tt_n[t]; s_tto[t] = P.tt_off[t]; }
+    for (int t = tid; t < P.tt_npts*ST; t += NT) s_tt[t] = P.tt_tab[t];
+    // the rules evaluated by the unrolled evaluators with row / column sums: the lowest order with 3 points and the two lowest
+    // orders with 6 points (every such order has its own points, hence its own sums)
+    int qA0 = 0, qB0 = 0, qB1 = 0;
+    for (int q = 17; q >= 2; q--) {
+        const int n = P.tt_n[q];
+        qA0 = (n == NA) ? q : qA0;
+        if (n == NB) { qB1 = qB0; qB0 = q; }
+    }
+    __syncthreads();
+    // w phi_a phi_b at the points of those rules
+    for (int t = tid; t < ND*NR; t += NT) {
+        const int e = t/NR, k = t-e*NR;
+        const int q = k < 3 ? qA0 : (k < 9 ? qB0 : qB1), i = k < 3 ? k : (k < 9 ? k-3 : k-9);
+        int a = 0, idx = e;
+        while (idx >= DPE-a) { idx -= DPE-a; a++; }
+        const int b = a+idx;
+        const double *tp = s_tt+(s_tto[q]+i)*ST;
+        s_PP[t] = q ? tp[3]*tp[4+a]*tp[4+b] : 0.;
+    }
+    const bool symflush = (flags & 256) != 0;
+#pragma unroll 1
+    for (int tile_idx = blockIdx.x; tile_idx < ntiles; tile_idx = s_misc[6]) {
+    const int ta = tiles[tile_idx].x, tb = tiles[tile_idx].y;
+    const int nA = P.blk_ndof[ta], nB = P.blk_ndof[tb];
+    // order class of this tile entry (variable order: kernel, order formula, work-list region of the class; bit 0: orientation)
+    const int tcls = tile_cls ? tile_cls[tile_idx] : (P.cur_class >= 0 ? 2*P.cur_class+P.orient : -1);
+    DevKernel kk = P.k;
+    DevFormula qo = P.qo;
+    if (tile_cls) { kk = kcls[tcls >> 1]; qo = fcls[tcls >> 1]; }
+    const int wl_region = tile_cls ? (tcls >> 1) : 0;
+
+    // ---- stage cell data of both blocks ----
+    for (int t = tid; t < 2*TILE; t += NT) {
+        const int side = t/TILE, l = t%TILE;
+        const int c = (side ? tb : ta)*TILE+l;
+#pragma unroll
+        for (int k = 0; k < NC; k++) s_v[(side*NC+k)*TILE+l] = P.cellv[(size_t)k*P.ncp+c];
+#pragma unroll
+        for (int d = 0; d < 2; d++) s_cen[(side*2+d)*TILE+l] = P.ccen[(size_t)d*P.ncp+c];
+        s_vol[side*TILE+l] = P.cvol[c];
+        s_h[side*TILE+l] = P.ch[c];
+        const double lh = P.clog[c], Ld = P.clog[(size_t)P.ncp+c];
+        s_Ld[side*TILE+l] = Ld;
+        s_lh[(side*2+0)*TILE+l] = (float)lh;
+        s_lh[(side*2+1)*TILE+l] = (float)Ld;
+#pragma unroll
+        for (int k = 0; k < NV; k++) s_vid[(side*NV+k)*TILE+l] = P.cvid[(size_t)k*P.ncp+c];
+#pragma unroll
+        for (int k = 0; k < DPE; k++) {
+            const short sl = P.cslot[(size_t)k*P.ncp+c];
+            s_slot[(side*DPE+k)*TILE+l] = sl >= 0 ? sl : (short)(side ? nB : nA);
+        }
+    }
+    for (int t = tid; t < (nA+1)*acc_stride; t += NT) s_acc[t] = 0.;
+    for (int t = tid; t < 2*TILE*(ND+NR); t += NT) s_D[t] = 0.;            // s_D and s_R are adjacent
+    for (int t = tid; t < 2*(PNL_MAXQ+2)+6; t += NT) s_cnt[t] = 0;          // s_cnt, s_cur and s_misc[0..5] are adjacent
+    __syncthreads();
+
+    // ---- classification (NO:280-378 vertex test, NO:493-540 + FL2:622-642 order) ----
+    int overflow = 0;
+    int cnt234[3] = {0, 0, 0};
+#pragma unroll
+    for (int it = 0; it < PER_THREAD; it++) {
+        const int p = it*NT+tid;
+        const int j = p%TILE, i = (p/TILE+21*j)%TILE;
+        int q = 0;
+        const int va0 = s_vid[(0*NV+0)*TILE+i], vb0 = s_vid[(1*NV+0)*TILE+j];
+        const int ca = ta*TILE+i;
+        bool ok = (va0 >= 0) && (vb0 >= 0) && (ta < tb || i < j) && (ca >= cell_begin) && (ca < cell_end);
+        if (tcls >= 0 && ok) {
+            const int la = P.clabel[ca], lb = P.clabel[tb*TILE+j];
+            ok = P.cls_of[(tcls & 1) ? lb*P.nlab+la : la*P.nlab+lb] == (tcls >> 1);
+        }
+        if (ok) {
+            bool any_dof = false, shared = false;
+#pragma unroll
+            for (int k = 0; k < DPE; k++)
+                any_dof = any_dof || (s_slot[(0*DPE+k)*TILE+i] < nA) || (s_slot[(1*DPE+k)*TILE+j] < nB);
+#pragma unroll
+            for (int k = 0; k < NV; k++) {
+                const int va = s_vid[(0*NV+k)*TILE+i];
+#pragma unroll
+                for (int m = 0; m < NV; m++) shared = shared || (va == s_vid[(1*NV+m)*TILE+j]);
+            }
+            if (any_dof && !shared) {
+                double d2 = 0.;
+#pragma unroll
+                for (int d = 0; d < 2; d++) {
+                    const double t = s_cen[(0*2+d)*TILE+i]-s_cen[(1*2+d)*TILE+j];
+                    d2 += t*t;
+                }
+                q = quad_order_fast(qo, s_h[i], s_h[TILE+j], s_lh[i], s_lh[2*TILE+j], s_lh[TILE+i], s_lh[3*TILE+j],
+                                    s_Ld[i], s_Ld[TILE+j], d2);
+                if (q > P.qmax || q > PNL_MAXQ) { overflow++; q = 0; }
+            }
+        }
+        const int nq = q ? s_ttn[q] : 0;
+        const int cls = !q ? 0 : (q == qA0 ? 1 : (q == qB0 ? 2 : (nq > 0 ? 3 : 4)));
+        cnt234[0] += __popcll(__ballot(q == 2)); cnt234[1] += __popcll(__ballot(q == 3)); cnt234[2] += __popcll(__ballot(q == 4));
+        p2_wave_bucket_add(s_cnt, q > 4 ? q : 0);
+        const unsigned short ent = (unsigned short)(p | ((q-2) << 12));
+        const unsigned long long mA = __ballot(cls == 1), mB = __ballot(cls == 2), mC = __ballot(cls == 3), mF = __ballot(cls == 4);
+        if (mC) {
+            int base = 0;
+            const int leader = __ffsll((long long)mC)-1;
+            if (lane == leader) base = atomicAdd(&s_misc[3], __popcll(mC));
+            base = __builtin_amdgcn_readlane(base, leader);
+            if (cls == 3) s_list[PAIRS-1-(base+__popcll(mC & lt))] = ent;
+        }
+        if (mA) {
+            int base = 0;
+            const int leader = __ffsll((long long)mA)-1;
+            if (lane == leader) base = atomicAdd(&s_misc[0], __popcll(mA));
+            base = __builtin_amdgcn_readlane(base, leader);
+            if (cls == 1) s_list[base+__popcll(mA & lt)] = ent;
+        }
+        if (mB) {
+            int base = 0;
+            const int leader = __ffsll((long long)mB)-1;
+            if (lane == leader) base = atomicAdd(&s_misc[1], __popcll(mB));
+            base = __builtin_amdgcn_readlane(base, leader);
+            if (cls == 2) s_l32[base+__popcll(mB & lt)] = ent;
+        }
+        if (mF) {
+            int base = 0;
+            const int leader = __ffsll((long long)mF)-1;
+            if (lane == leader) base = atomicAdd(&s_misc[2], __popcll(mF));
+            base = __builtin_amdgcn_readlane(base, leader);
+            if (cls == 4) s_l32[PAIRS-1-(base+__popcll(mF & lt))] = p | (q << 12);
+        }
+    }
+    if (overflow) atomicAdd(&P.counters[5], (unsigned long long)overflow);
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) if (cnt234[k]) atomicAdd(&s_cnt[2+k], cnt234[k]);
+    }
+    __syncthreads();
+    // next tile of this workgroup from the global counter (heavy, near-diagonal tiles come first in the list)
+    if (tid == 0) s_misc[6] = (int)(gridDim.x+atomicAdd(tile_ctr, 1u));
+    {
+        // far pairs (orders without a packed rule): one reservation in the class's region of the global work list per tile
+        const int nF = s_misc[2];
+        if (nF) {
+            if (tid == 0) s_misc[7] = (int)atomicAdd(wl_count+wl_region, (unsigned)nF);
+            __syncthreads();
+            const unsigned base = (unsigned)s_misc[7];
+            int4 *__restrict__ wl = worklist+(size_t)wl_region*wl_cap;
+            for (int t = tid; t < nF; t += NT) {
+                const int ent = s_l32[PAIRS-1-t];
+                const int p = ent & 4095, q = ent >> 12;
+                const int j = p%TILE, i = (p/TILE+21*j)%TILE;
+                const int off = P.off[q];
+                if (base+t < wl_cap) wl[base+t] = make_int4(ta*TILE+i, tb*TILE+j, off, (P.off[q+1]-off) | (q << 16));
+            }
+        }
+    }
+    // statistics: one thread per order
+    {
+        const int q = 2+tid;
+        if (q <= P.qmax && q <= PNL_MAXQ) {
+            const int cq = s_cnt[q];
+            if (cq) {
+                const int ne = s_ttn[q];
+                const unsigned long long n = (unsigned long long)(ne ? ne : P.off[q+1]-P.off[q]);
+                st_cnt += (unsigned long long)cq;
+                st_ev += n*n*cq;
+            }
+        }
+    }
+    // ---- list C: counting sort by order, 64 pairs of one order per chunk ----
+    const int nC = s_misc[3];
+    if (nC) {
+        __syncthreads();
+        if (tid == 0) {
+            int run = 0, nch = 0;
+            for (int q = 17; q >= 2; q--) {                    // heavy orders first
+                if (q > P.qmax) continue;
+                const int nq = s_ttn[q], c = s_cnt[q];
+                if (!c || nq == 0 || q == qA0 || q == qB0) continue;
+                s_cur[q] = run;
+                for (int st = 0; st < c && nch < P2_MAXCHUNKS; st += 64) s_chunk[nch++] = (q << 20) | ((run+st) << 7) | (min(64, c-st)-1);
+                run += c;
+            }
+            s_misc[4] = nch;
+        }
+        __syncthreads();
+        for (int t = tid; t < nC; t += NT) {
+            const int ent = s_list[PAIRS-1-t];
+            const int q = (ent >> 12)+2;
+            s_csort[atomicAdd(&s_cur[q], 1)] = (unsigned short)(ent & 4095);
+        }
+    }
+    __syncthreads();
+
+    // ---- evaluation: waves fetch chunks of 64 pairs of one order: list C (7-16 points), list B (6), list A (3) ----
+    {
+        const int nchC = __builtin_amdgcn_readfirstlane(s_misc[4]);
+        const int totB = __builtin_amdgcn_readfirstlane(s_misc[1]), totA = __builtin_amdgcn_readfirstlane(s_misc[0]);
+        const int nchB = (totB+63) >> 6, nchA = (totA+63) >> 6, nch = nchC+nchB+nchA;
+        const double scale2 = 2.*kern_scale<KT>(kk);
+#pragma unroll 1
+        while (true) {
+            int ch = 0;
+            if (lane == 0) ch = atomicAdd(&s_misc[5], 1);
+            ch = __builtin_amdgcn_readfirstlane(ch);
+            if (ch >= nch) break;
+            int p, q;
+            bool act;
+            if (ch < nchC) {
+                const int desc = __builtin_amdgcn_readfirstlane(s_chunk[ch]);
+                q = desc >> 20;
+                const int start = (desc >> 7) & 8191, cnt = (desc & 127)+1;
+                act = lane < cnt;
+                p = s_csort[start+(act ? lane : 0)];
+            } else if (ch < nchC+nchB) {
+                const int idx = (ch-nchC)*64+lane;
+                act = idx < totB;
+                p = act ? (s_l32[idx] & 4095) : 0;
+                q = qB0;
+            } else {
+                const int idx = (ch-nchC-nchB)*64+lane;
+                act = idx < totA;
+                p = act ? ((int)s_list[idx] & 4095) : 0;
+                q = qA0;
+            }
+            const int j = p%TILE, i = (p/TILE+21*j)%TILE;
+            const int nq = __builtin_amdgcn_readfirstlane(s_ttn[q]), to = __builtin_amdgcn_readfirstlane(s_tto[q]);
+            const double *tab = s_tt+to*ST;
+            double av[NC], bv[NC];
+#pragma unroll
+            for (int k = 0; k < NC; k++) { av[k] = s_v[(0*NC+k)*TILE+i]; bv[k] = s_v[(1*NC+k)*TILE+j]; }
+            // NA:1405-1410: symmetric cell pairs count twice
+            const double vv = act ? scale2*s_vol[i]*s_vol[TILE+j] : 0.;
+            double G[6][6];
+#pragma unroll
+            for (int a = 0; a < 6; a++)
+#pragma unroll
+                for (int b = 0; b < 6; b++) G[a][b] = 0.;
+            if (q == qB0 || q == qB1) {
+                const int ro = q == qB0 ? 3 : 9;
+                double c[NB];
+                p2_eval_fixed<KT, NB>(kk, tab, P.tt_wphif+to*7, av, bv, vv, act, s_R+(0*TILE+i)*NR+ro, G, c);
+                if (act)
+#pragma unroll
+                    for (int jp = 0; jp < NB; jp++) lds_add_f64(&s_R[(1*TILE+j)*NR+ro+jp], vv*c[jp]);
+            } else if (q == qA0) {
+                double c[NA];
+                p2_eval_fixed<KT, NA>(kk, tab, P.tt_wphif+to*7, av, bv, vv, act, s_R+(0*TILE+i)*NR, G, c);
+                if (act)
+#pragma unroll
+                    for (int jp = 0; jp < NA; jp++) lds_add_f64(&s_R[(1*TILE+j)*NR+jp], vv*c[jp]);
+            } else {
+                double Sd[21];
+#pragma unroll
+                for (int e = 0; e < 21; e++) Sd[e] = 0.;
+                p2_eval_lds_sweep1<KT>(kk, tab, nq, av, bv, G, Sd);
+#pragma unroll
+                for (int e = 0; e < 21; e++) { if (act) lds_add_f64(&s_D[(0*TILE+i)*ND+e], vv*Sd[e]); Sd[e] = 0.; }
+                p2_eval_lds_sweep2<KT>(kk, tab, nq, av, bv, Sd);
+                if (act)
+#pragma unroll
+                    for (int e = 0; e < 21; e++) lds_add_f64(&s_D[(1*TILE+j)*ND+e], vv*Sd[e]);
+            }
+            // cross block -> LDS sub-block of A'
+            if (!act) continue;
+            int sb[6];
+#pragma unroll
+            for (int b = 0; b < 6; b++) sb[b] = s_slot[(1*DPE+b)*TILE+j];
+#pragma unroll
+            for (int a = 0; a < 6; a++) {
+                const int sa = (int)s_slot[(0*DPE+a)*TILE+i]*acc_stride;
+#pragma unroll
+                for (int b = 0; b < 6; b++) lds_add_f64(&s_acc[sa+sb[b]], -vv*G[a][b]);
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- flush: one wave per row of the sub-block, lanes along the row of A; diagonal blocks from the row / column sums ----
+    const int *__restrict__ dofA = P.blk_dofs+(size_t)ta*P.blk_stride;
+    const int *__restrict__ dofB = P.blk_dofs+(size_t)tb*P.blk_stride;
+#pragma unroll 1
+    for (int r = wave; r < nA; r += NWAVES) {
+        double *__restrict__ row = A+(long long)dofA[r]*ldA;
+        for (int cc = lane; cc < nB; cc += 64) {
+            const double v = s_acc[r*acc_stride+cc];
+            if (v != 0.) atomic_add_f64(&row[dofB[cc]], v);
+        }
+    }
+    if (symflush)
+#pragma unroll 1
+        for (int cc = wave; cc < nB; cc += NWAVES) {
+            double *__restrict__ row = A+(long long)dofB[cc]*ldA;
+            for (int r = lane; r < nA; r += 64) {
+                const double v = s_acc[r*acc_stride+cc];
+                if (v != 0.) atomic_add_f64(&row[dofA[r]], v);
+            }
+        }
+    for (int t = tid; t < 2*TILE*ND; t += NT) {
+        const int sc = t/ND, e = t-sc*ND;                    // sc = side*TILE + cell
+        double v = s_D[t];
+#pragma unroll
+        for (int k = 0; k < NR; k++) v = __builtin_fma(s_PP[e*NR+k], s_R[sc*NR+k], v);
+        if (v != 0.) {
+            const int side = sc/TILE, c = (side ? tb : ta)*TILE+(sc-side*TILE);
+            atomic_add_f64(&Dglob[(size_t)c*ND+e], v);
+        }
+    }
+    __syncthreads();
+    }   // tile loop
+    {
+        const int q = 2+tid;
+        if (st_cnt) {
+            atomicAdd(&P.counters[8+q], st_cnt);
+            atomicAdd(&P.counters[1], st_cnt);
+            atomicAdd(&P.counters[2], st_ev);
+        }
+    }
+}

@@ -1,0 +1,89 @@
+// Launchers of the second-generation tile kernels (pnl_tile2.h): uniform-order tiles (P1 orders 3 / 4, P2 orders 2-4) and the
+// general P2 tile kernel.  Called from assemble_impl / launch_tiles in pnl_hip.hip.
+#include "pnl_context.h"
+#include "pnl_tile2.h"
+
+namespace {
+
+size_t uniform_lds(int dpe, int np, int tile, int nU, int acc_stride) {
+    const int nd = dpe*(dpe+1)/2;
+    return sizeof(double)*(size_t)(tile*np*2+tile+tile*np+tile*nd)+sizeof(int)*(size_t)(tile*dpe+tile)
+           +sizeof(double)*(size_t)(nU+1)*acc_stride;
+}
+
+template <int DPE, int NP, int KT>
+int launch_uniform_t(pnl_context *ctx, const DevProblem &Pt, const int2 *tiles, const int *tile_cls, int ntiles, int q, double *A,
+                     int64_t ldA, double *Dglob) {
+    constexpr int TILE = DPE == 6 ? 32 : 64;
+    const size_t fixed = uniform_lds(DPE, NP, TILE, -1, 0);
+    const int acc_stride = acc_stride_of(ctx->nU, fixed);
+    const size_t lds = fixed+sizeof(double)*(size_t)(ctx->nU+1)*acc_stride;
+    if (lds > 160*1024)
+        return fail(ctx, PNL_ERR_UNSUPPORTED, "a block of %d cells touches %d DoFs: LDS sub-block of %zu bytes exceeds 160 KiB", TILE, ctx->nU, lds);
+    auto kfun = k_tile_uniform<DPE, NP, KT>;
+    HIPCHK(ctx, hipFuncSetAttribute((const void*)kfun, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const int per_cu = std::max(1, std::min(2, (int)((160*1024)/lds)));
+    const int grid = std::min(ntiles, 256*per_cu);
+    if (getenv("PNL_VERBOSE"))
+        fprintf(stderr, "[pnl] uniform tiles of order %d: %d, dpe=%d np=%d kt=%d lds=%zu bytes (%d per CU), acc_stride=%d\n", q, ntiles, DPE,
+                NP, KT, lds, per_cu, acc_stride);
+    hipLaunchKernelGGL(kfun, dim3(grid), dim3(256), lds, ctx->stream, Pt, tiles, tile_cls, (const DevKernel*)ctx->b_kcls.p, ntiles, A,
+                       (long long)ldA, Dglob, acc_stride, q, ctx->symflush ? 1 : 0, (const double*)ctx->b_uni.p+ctx->uni_off[q]);
+    HIPCHK(ctx, hipGetLastError());
+    return PNL_OK;
+}
+
+template <int DPE, int NP>
+int launch_uniform_kt(pnl_context *ctx, int kt, const DevProblem &Pt, const int2 *tiles, const int *tile_cls, int ntiles, int q,
+                      double *A, int64_t ldA, double *Dglob) {
+    if (kt == 2) return launch_uniform_t<DPE, NP, 2>(ctx, Pt, tiles, tile_cls, ntiles, q, A, ldA, Dglob);
+    if (kt == 1) return launch_uniform_t<DPE, NP, 1>(ctx, Pt, tiles, tile_cls, ntiles, q, A, ldA, Dglob);
+    return launch_uniform_t<DPE, NP, 0>(ctx, Pt, tiles, tile_cls, ntiles, q, A, ldA, Dglob);
+}
+
+template <int KT>
+int launch_p2_t(pnl_context *ctx, const int2 *tiles, const int *tile_cls, int ntiles, double *A, int64_t ldA, int cell_begin,
+                int cell_end, unsigned wl_cap_each) {
+    using S = P2Smem;
+    // one workgroup per CU: rows of the sub-block start in different LDS banks (stride = 1 mod 32 doubles) if that fits
+    int stride = ctx->nU+1;
+    while (stride % 32 != 1) stride++;
+    size_t lds = S::fixed_bytes+sizeof(double)*(size_t)(ctx->nU+1)*stride;
+    if (lds > 160*1024) { stride = (ctx->nU+1) | 1; lds = S::fixed_bytes+sizeof(double)*(size_t)(ctx->nU+1)*stride; }
+    if (lds > 160*1024)
+        return fail(ctx, PNL_ERR_UNSUPPORTED, "a block of %d cells touches %d DoFs: LDS sub-block of %zu bytes exceeds 160 KiB "
+                    "(cells must be numbered with spatial locality)", P2_TILE, ctx->nU, lds);
+    auto kfun = k_tile_p2<KT>;
+    HIPCHK(ctx, hipFuncSetAttribute((const void*)kfun, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const int grid_mult = getenv("PNL_GRID_MULT") ? atoi(getenv("PNL_GRID_MULT")) : 1;
+    const int grid = std::min(ntiles, 256*std::max(grid_mult, 1));
+    if (getenv("PNL_VERBOSE")) fprintf(stderr, "[pnl] P2 general tiles=%d nU=%d kt=%d lds=%zu bytes acc_stride=%d\n", ntiles, ctx->nU, KT, lds, stride);
+    hipLaunchKernelGGL(kfun, dim3(grid), dim3(P2_NT), lds, ctx->stream, ctx->P, tiles, tile_cls, (const DevKernel*)ctx->b_kcls.p,
+                       (const DevFormula*)ctx->b_fcls.p, A, (long long)ldA, (double*)ctx->b_D.p, cell_begin, cell_end, stride,
+                       (int4*)ctx->b_wl.p, (unsigned*)ctx->b_wlcount.p, wl_cap_each, ctx->symflush ? 256 : 0, ntiles,
+                       (unsigned*)ctx->b_tilectr.p);
+    HIPCHK(ctx, hipGetLastError());
+    return PNL_OK;
+}
+
+}  // namespace
+
+// uniform tiles of one order; Pt / Dglob: the cell tables (and diagonal-block buffer) the tile kernels use
+int pnl2_launch_uniform(pnl_context *ctx, int kt, const DevProblem &Pt, const int2 *tiles, const int *tile_cls, int ntiles, int q,
+                        double *A, int64_t ldA, double *Dglob) {
+    if (ntiles <= 0) return PNL_OK;
+    if (q < 2 || q > 4 || ctx->uni_off[q] < 0) return fail(ctx, PNL_ERR_STATE, "no uniform-tile rule for order %d", q);
+    const int np = ctx->uni_np[q];
+    if (ctx->dpe == 6 && np == 3) return launch_uniform_kt<6, 3>(ctx, kt, Pt, tiles, tile_cls, ntiles, q, A, ldA, Dglob);
+    if (ctx->dpe == 6 && np == 6) return launch_uniform_kt<6, 6>(ctx, kt, Pt, tiles, tile_cls, ntiles, q, A, ldA, Dglob);
+    if (ctx->dpe == 3 && np == 6) return launch_uniform_kt<3, 6>(ctx, kt, Pt, tiles, tile_cls, ntiles, q, A, ldA, Dglob);
+    return fail(ctx, PNL_ERR_UNSUPPORTED, "uniform tiles: dpe=%d with %d points", ctx->dpe, np);
+}
+
+int pnl2_launch_p2(pnl_context *ctx, int kt, const int2 *tiles, const int *tile_cls, int ntiles, double *A, int64_t ldA,
+                   int cell_begin, int cell_end, unsigned wl_cap_each) {
+    if (ntiles <= 0) return PNL_OK;
+    if (kt == 2) return launch_p2_t<2>(ctx, tiles, tile_cls, ntiles, A, ldA, cell_begin, cell_end, wl_cap_each);
+    if (kt == 1) return launch_p2_t<1>(ctx, tiles, tile_cls, ntiles, A, ldA, cell_begin, cell_end, wl_cap_each);
+    return launch_p2_t<0>(ctx, tiles, tile_cls, ntiles, A, ldA, cell_begin, cell_end, wl_cap_each);
+}
