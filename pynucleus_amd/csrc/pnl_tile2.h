@@ -42,33 +42,103 @@ __device__ __forceinline__ void group_sum3(double a, double b, double c, double 
 // layout of a uniform-tile rule block (doubles): bary[NP][3], w[NP], w phi[NP][DPE], w phi_a phi_b[ND][NP]
 __host__ __device__ constexpr int uni_rule_size(int dpe, int np) { return 3*np+np+np*dpe+(dpe*(dpe+1)/2)*np; }
 
+// workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every global atomic / store of the wave
+// (s_waitcnt vmcnt(0)): the flush of a tile would have to retire before the next tile may start.  The tile kernels below
+// never read global memory that the same launch writes, so their barriers only have to order the LDS.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// LDS of k_tile_uniform in bytes without the sub-block of A' (host and device agree through this function)
+__host__ __device__ constexpr size_t uniform_fixed_lds(int dpe, int np, int tile, int nUe) {
+    return sizeof(double)*(size_t)(tile*np*2+tile*6+2*tile+2*tile*np+tile*np+(dpe*(dpe+1)/2)*np)
+           +sizeof(int)*(size_t)(2*tile*dpe+2*tile+4*nUe);
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
+// Software pipeline over the tiles of a workgroup: while the flush of tile n (global atomics) is in flight the inputs of
+// tile n+1 are already staged in LDS -- they are loaded BEFORE the flush is issued (the memory counter retires in order:
+// a load issued behind the atomics would wait for all of them) and the barriers do not wait for global memory.  The flush
+// reads the DoF numbers from LDS for the same reason and zeroes the sub-block as it goes.
 template <int DPE, int NP, int KT>
 __global__ void __launch_bounds__(256, 2)
 k_tile_uniform(const DevProblem P, const int2 *__restrict__ tiles, const int *__restrict__ tile_cls, const DevKernel *__restrict__ kcls,
                int ntiles, double *__restrict__ A, long long ldA, double *__restrict__ Dglob, int acc_stride, int q_uniform,
-               int flags, const double *__restrict__ rule_g) {
+               int flags, const double *__restrict__ rule_g, int nUe) {
     constexpr int DIM = 2, NV = 3, NC = 6, ND = DPE*(DPE+1)/2, NT = 256, NW = NT/64;
     constexpr int TILE = DPE == 6 ? 32 : 64, HALVES = 64/TILE, JW = TILE/NW, ITER = JW/HALVES;
     constexpr int R_BARY = 0, R_W = 3*NP, R_WPH = R_W+NP, R_PP = R_WPH+NP*DPE;
     const pnl_const_f64_ptr rule = (pnl_const_f64_ptr)(unsigned long long)rule_g;
+#ifndef PNL_DEBUG_ABLATE
+    flags &= 1;                                          // the other bits skip work (debug builds only)
+#endif
     extern __shared__ double smem[];
     double *s_y = smem;                                  // [TILE][NP*DIM] quadrature points of the b-cells
-    double *s_volb = s_y+TILE*NP*DIM;                    // [TILE]
-    double *s_Ra = s_volb+TILE;                          // [TILE][NP] row sums of the a-cells (weighted: vol_b w_i)
-    double *s_Db = s_Ra+TILE*NP;                         // [TILE][ND] diagonal blocks of the b-cells
-    int *s_slotb = (int*)(s_Db+TILE*ND);                 // [TILE][DPE]
-    int *s_hb = s_slotb+TILE*DPE;                        // [TILE] has-a-DoF flags
-    double *s_acc = (double*)(s_hb+TILE);                // [nA+1][acc_stride]
+    double *s_av = s_y+TILE*NP*DIM;                      // [TILE][NC] vertices of the a-cells
+    double *s_vola = s_av+TILE*NC;                       // [TILE]
+    double *s_volb = s_vola+TILE;                        // [TILE]
+    double *s_Ra = s_volb+TILE;                          // [2][TILE][NP] row sums of the a-cells, scaled (ping-pong over tiles)
+    double *s_Rb = s_Ra+2*TILE*NP;                       // [TILE][NP] column sums of the b-cells, scaled
+    double *s_PP = s_Rb+TILE*NP;                         // [ND][NP] w phi_a phi_b at the points
+    int *s_slotb = (int*)(s_PP+ND*NP);                   // [TILE][DPE] column of the sub-block (trash column nUe)
+    int *s_sa = s_slotb+TILE*DPE;                        // [TILE][DPE] row offset in the sub-block (trash row nUe)
+    int *s_ha = s_sa+TILE*DPE;                           // [TILE] has-a-DoF flags
+    int *s_hb = s_ha+TILE;
+    int *s_dof = s_hb+TILE;                              // [2][2][nUe] global DoFs of both blocks (ping-pong over tiles)
+    double *s_acc = (double*)(s_dof+4*nUe);              // [nUe+1][acc_stride]; nUe even
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane%TILE, half = lane/TILE;
-    // w phi_a phi_b at the points for the diagonal-block entry e = li this lane forms for the b-cells
-    double ppe[NP];
-#pragma unroll
-    for (int jp = 0; jp < NP; jp++) ppe[jp] = li < ND ? rule_g[R_PP+li*NP+jp] : 0.;
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
     unsigned long long npairs = 0;
+
+    // inputs of tile t -> LDS (b-side: threads [0, TILE), a-side: threads [TILE, 2 TILE), DoF lists: everybody)
+    auto stage = [&](int t, int buf) {
+        const int2 tl = tiles[t];
+        const int nA = P.blk_ndof[tl.x], nB = P.blk_ndof[tl.y];
+        if (tid < 2*TILE) {
+            const bool bside = tid < TILE;
+            const int l = bside ? tid : tid-TILE, c = (bside ? tl.y : tl.x)*TILE+l;
+            double v[NC];
+#pragma unroll
+            for (int k = 0; k < NC; k++) v[k] = P.cellv[(size_t)k*P.ncp+c];
+            const double vol = P.cvol[c];
+            int sl[DPE], any = 0;
+#pragma unroll
+            for (int k = 0; k < DPE; k++) { sl[k] = P.cslot[(size_t)k*P.ncp+c]; any |= (sl[k] >= 0); }
+            if (bside) {
+#pragma unroll
+                for (int jp = 0; jp < NP; jp++)
+#pragma unroll
+                    for (int d = 0; d < DIM; d++) {
+                        double sy = 0.;
+#pragma unroll
+                        for (int k = 0; k < NV; k++) sy = __builtin_fma(rule[R_BARY+3*jp+k], v[k*DIM+d], sy);
+                        s_y[l*NP*DIM+jp*DIM+d] = sy;
+                    }
+                s_volb[l] = vol; s_hb[l] = any;
+#pragma unroll
+                for (int k = 0; k < DPE; k++) s_slotb[l*DPE+k] = sl[k] >= 0 ? sl[k] : nUe;
+            } else {
+#pragma unroll
+                for (int k = 0; k < NC; k++) s_av[l*NC+k] = v[k];
+                s_vola[l] = vol; s_ha[l] = any;
+#pragma unroll
+                for (int k = 0; k < DPE; k++) s_sa[l*DPE+k] = (sl[k] >= 0 ? sl[k] : nUe)*acc_stride;
+            }
+        }
+        const int *__restrict__ dofA = P.blk_dofs+(size_t)tl.x*P.blk_stride;
+        const int *__restrict__ dofB = P.blk_dofs+(size_t)tl.y*P.blk_stride;
+        for (int k = tid; k < nA; k += NT) s_dof[(buf*2+0)*nUe+k] = dofA[k];
+        for (int k = tid; k < nB; k += NT) s_dof[(buf*2+1)*nUe+k] = dofB[k];
+    };
+
+    int tile_idx = blockIdx.x, buf = 0;
+    if (tile_idx >= ntiles) return;
+    for (int t = tid; t < ND*NP; t += NT) s_PP[t] = rule_g[R_PP+t];
+    for (int t = tid; t < (nUe+1)*acc_stride; t += NT) s_acc[t] = 0.;
+    for (int t = tid; t < 2*TILE*NP; t += NT) s_Ra[t] = 0.;
+    stage(tile_idx, 0);
+    lds_barrier();
 #pragma unroll 1
-    for (int tile_idx = blockIdx.x; tile_idx < ntiles; tile_idx += gridDim.x) {
+    while (true) {
         const int2 tl = tiles[tile_idx];
         const int ta = tl.x, tb = tl.y;
         const int nA = P.blk_ndof[ta], nB = P.blk_ndof[tb];
@@ -76,48 +146,16 @@ k_tile_uniform(const DevProblem P, const int2 *__restrict__ tiles, const int *__
         DevKernel kk = P.k;
         if (tile_cls) kk = kcls[tile_cls[tile_idx] >> 1];
         const double scale2 = 2.*kern_scale<KT>(kk);
-        __syncthreads();                                 // the previous tile's flush is done with the LDS buffers
-        if (tid < TILE) {
-            const int c = tb*TILE+tid;
-            double bv[NC];
-#pragma unroll
-            for (int k = 0; k < NC; k++) bv[k] = P.cellv[(size_t)k*P.ncp+c];
-#pragma unroll
-            for (int jp = 0; jp < NP; jp++)
-#pragma unroll
-                for (int d = 0; d < DIM; d++) {
-                    double sy = 0.;
-#pragma unroll
-                    for (int k = 0; k < NV; k++) sy = __builtin_fma(rule[R_BARY+3*jp+k], bv[k*DIM+d], sy);
-                    s_y[tid*NP*DIM+jp*DIM+d] = sy;
-                }
-            s_volb[tid] = P.cvol[c];
-            int any = 0;
-#pragma unroll
-            for (int k = 0; k < DPE; k++) {
-                const int sl = P.cslot[(size_t)k*P.ncp+c];
-                s_slotb[tid*DPE+k] = sl >= 0 ? sl : nB;
-                any |= (sl >= 0);
-            }
-            s_hb[tid] = any;
-        }
-        for (int t = tid; t < (nA+1)*acc_stride; t += NT) s_acc[t] = 0.;
-        for (int t = tid; t < TILE*NP; t += NT) s_Ra[t] = 0.;
+        double *__restrict__ Ra = s_Ra+buf*TILE*NP;
         // a side: lane = cell li (both halves of a P2 wave hold the same cells)
-        const int ca = ta*TILE+li;
         double av[NC];
 #pragma unroll
-        for (int k = 0; k < NC; k++) av[k] = P.cellv[(size_t)k*P.ncp+ca];
+        for (int k = 0; k < NC; k++) av[k] = s_av[li*NC+k];
         int sa[DPE];
-        bool ha = false;
 #pragma unroll
-        for (int k = 0; k < DPE; k++) {
-            const int sl = P.cslot[(size_t)k*P.ncp+ca];
-            sa[k] = (sl >= 0 ? sl : nA)*acc_stride;
-            ha = ha || sl >= 0;
-        }
-        const double vola = P.cvol[ca];
-        __syncthreads();
+        for (int k = 0; k < DPE; k++) sa[k] = s_sa[li*DPE+k];
+        const bool ha = s_ha[li] != 0;
+        const double vola = s_vola[li];
 #pragma unroll 1
         for (int jj = 0; jj < ITER; jj++) {
             const int j = wave*JW+jj*HALVES+half;
@@ -129,6 +167,8 @@ k_tile_uniform(const DevProblem P, const int2 *__restrict__ tiles, const int *__
             const bool valid = ha || (s_hb[j] != 0);     // NA:138-150: pairs with boundary DoFs only are skipped
             npairs += (unsigned long long)__popcll(__ballot(valid));
             const double volb = valid ? s_volb[j] : 0.;
+            // NA:1405-1410: symmetric cell pairs count twice
+            const double vv = scale2*vola*volb;
             double c[NP], G[DPE][DPE];
 #pragma unroll
             for (int jp = 0; jp < NP; jp++) c[jp] = 0.;
@@ -163,7 +203,7 @@ k_tile_uniform(const DevProblem P, const int2 *__restrict__ tiles, const int *__
 #pragma unroll
                     for (int b = 0; b < DPE; b++) u[b] = __builtin_fma(g, rule[R_WPH+jp*DPE+b], u[b]);
                 }
-                lds_add_f64(&s_Ra[li*NP+ip], volb*r);
+                lds_add_f64(&Ra[li*NP+ip], vv*r);
 #pragma unroll
                 for (int a = 0; a < DPE; a++) {
                     const double pa = rule[R_WPH+ip*DPE+a];
@@ -172,61 +212,73 @@ k_tile_uniform(const DevProblem P, const int2 *__restrict__ tiles, const int *__
                 }
             }
             // cross block -> LDS sub-block of A'
-            const double vv = scale2*vola*volb;
+            if (!(flags & 4)) {
 #pragma unroll
-            for (int b = 0; b < DPE; b++) {
-                const int sb = s_slotb[j*DPE+b];
+                for (int b = 0; b < DPE; b++) {
+                    const int sb = s_slotb[j*DPE+b];
 #pragma unroll
-                for (int a = 0; a < DPE; a++) lds_add_f64(&s_acc[sa[a]+sb], -vv*G[a][b]);
-            }
-            // diagonal block of cell j: column sums over the cells i of the group, then entry e = li
+                    for (int a = 0; a < DPE; a++) lds_add_f64(&s_acc[sa[a]+sb], -vv*G[a][b]);
+                }
+            } else if (G[0][0]+G[1][2]+G[DPE-1][DPE-1] == 1.2345e300) s_acc[0] = vv;
+            // column sums over the cells i of the group -> scaled column sums of cell j (this group owns cell j: plain stores)
+            const double sb2 = scale2*s_volb[j];
             const double wa = valid ? vola : 0.;
-            double s2 = 0.;
 #pragma unroll
             for (int g3 = 0; g3 < NP; g3 += 3) {
                 double c0, c1, c2;
                 group_sum3<TILE>(wa*c[g3], wa*c[g3+1], wa*c[g3+2], c0, c1, c2);
-                s2 = __builtin_fma(ppe[g3], c0, s2);
-                s2 = __builtin_fma(ppe[g3+1], c1, s2);
-                s2 = __builtin_fma(ppe[g3+2], c2, s2);
+                const int k = li-g3;
+                if (k >= 0 && k < 3) s_Rb[j*NP+li] = sb2*(k == 0 ? c0 : (k == 1 ? c1 : c2));
             }
-            if (li < ND) s_Db[j*ND+li] = scale2*s_volb[j]*s2;    // this group owns cell j: plain store
         }
-        __syncthreads();
-        // ---- flush: one wave per row of the sub-block, lanes along the row of A ----
-        const int *__restrict__ dofA = P.blk_dofs+(size_t)ta*P.blk_stride;
-        const int *__restrict__ dofB = P.blk_dofs+(size_t)tb*P.blk_stride;
+        lds_barrier();
+        // ---- the next tile's inputs, then the flush of this one ----
+        const int nxt = tile_idx+(int)gridDim.x;
+        const bool more = nxt < ntiles;
+        if (more) stage(nxt, buf^1);
+        const int *__restrict__ dA = s_dof+(buf*2+0)*nUe, *__restrict__ dB = s_dof+(buf*2+1)*nUe;
+        const bool sym = (flags & 1) != 0;
+        if (!(flags & 2))
 #pragma unroll 1
-        for (int r = wave; r < nA; r += NW) {
-            double *__restrict__ row = A+(long long)dofA[r]*ldA;
+        for (int r = wv; r < nA; r += NW) {
+            double *__restrict__ row = A+(long long)__builtin_amdgcn_readfirstlane(dA[r])*ldA;
             for (int cc = lane; cc < nB; cc += 64) {
                 const double v = s_acc[r*acc_stride+cc];
-                if (v != 0.) atomic_add_f64(&row[dofB[cc]], v);
-            }
-        }
-        // PNL_FLAG_SYMMETRIC_FLUSH (no mirror pass): the transposed image, lanes along the row of A again
-        if (flags & 1)
-#pragma unroll 1
-            for (int cc = wave; cc < nB; cc += NW) {
-                double *__restrict__ row = A+(long long)dofB[cc]*ldA;
-                for (int r = lane; r < nA; r += 64) {
-                    const double v = s_acc[r*acc_stride+cc];
-                    if (v != 0.) atomic_add_f64(&row[dofA[r]], v);
+                if (v != 0.) {
+                    if (!sym) s_acc[r*acc_stride+cc] = 0.;
+                    atomic_add_f64(&row[dB[cc]], v);
                 }
             }
+        }
+        // PNL_FLAG_SYMMETRIC_FLUSH (no mirror pass): the transposed image, lanes along the row of A again; it zeroes the
+        // sub-block, so every wave must have finished the first sweep
+        if (sym) lds_barrier();
+        if (sym)
+#pragma unroll 1
+            for (int cc = wv; cc < nB; cc += NW) {
+                double *__restrict__ row = A+(long long)__builtin_amdgcn_readfirstlane(dB[cc])*ldA;
+                for (int r = lane; r < nA; r += 64) {
+                    const double v = s_acc[r*acc_stride+cc];
+                    if (v != 0.) {
+                        s_acc[r*acc_stride+cc] = 0.;
+                        atomic_add_f64(&row[dA[r]], v);
+                    }
+                }
+            }
+        if (flags & 2) for (int t = tid; t < (nUe+1)*acc_stride; t += NT) s_acc[t] = 0.;
+        // diagonal blocks of both sides from the scaled row / column sums
         for (int t = tid; t < 2*TILE*ND; t += NT) {
             const int side = t/(TILE*ND), rem = t-side*TILE*ND, cl = rem/ND, e = rem-cl*ND;
-            const int cc = (side ? tb : ta)*TILE+cl;
-            double v;
-            if (side) v = s_Db[rem];
-            else {
-                double s1 = 0.;
+            const double *__restrict__ R = side ? s_Rb+cl*NP : Ra+cl*NP;
+            double v = 0.;
 #pragma unroll
-                for (int ip = 0; ip < NP; ip++) s1 = __builtin_fma(rule_g[R_PP+e*NP+ip], s_Ra[cl*NP+ip], s1);
-                v = scale2*P.cvol[cc]*s1;
-            }
-            if (v != 0.) atomic_add_f64(&Dglob[(size_t)cc*ND+e], v);
+            for (int ip = 0; ip < NP; ip++) v = __builtin_fma(s_PP[e*NP+ip], R[ip], v);
+            if (v != 0.) atomic_add_f64(&Dglob[(size_t)((side ? tb : ta)*TILE+cl)*ND+e], v);
         }
+        for (int t = tid; t < TILE*NP; t += NT) s_Ra[(buf^1)*TILE*NP+t] = 0.;
+        if (!more) break;
+        lds_barrier();
+        tile_idx = nxt; buf ^= 1;
     }
     // statistics: every lane of a wave holds the same count
     if (lane == 0 && npairs) {
@@ -245,36 +297,42 @@ k_tile_uniform(const DevProblem P, const int2 *__restrict__ tiles, const int *__
 #define P2_MAXCHUNKS 96
 struct P2Smem {
     static constexpr int TILE = P2_TILE, NV = 3, NC = 6, DPE = 6, ND = 21, PAIRS = TILE*TILE, ST = 4+DPE;
+    static constexpr int NR = 15;                          // row / column sums per (side, cell): the 3-point rule, the first and
+                                                           // the second 6-point rule (orders 2, 3, 4 on triangles)
+    static constexpr int MAXLAB = 16;                      // label tables up to MAXLAB x MAXLAB are kept in LDS
     // doubles
     static constexpr int o_v = 0;                          // [2][NC][TILE]
     static constexpr int o_cen = o_v+2*NC*TILE;            // [2][2][TILE]
     static constexpr int o_vol = o_cen+4*TILE;             // [2][TILE]
     static constexpr int o_h = o_vol+2*TILE;               // [2][TILE]
     static constexpr int o_Ld = o_h+2*TILE;                // [2][TILE]
-    static constexpr int o_D = o_Ld+2*TILE;                // [2][TILE][ND] contributions formed per pair (list C)
-    static constexpr int NR = 15;                          // row / column sums per (side, cell): the 3-point rule, the first and
-                                                           // the second 6-point rule (orders 2, 3, 4 on triangles)
-    static constexpr int o_R = o_D+2*TILE*ND;              // [2][TILE][NR]
-    static constexpr int o_PP = o_R+2*TILE*NR;             // [ND][NR] (+ pad): w phi_a phi_b at the points of those rules
+    static constexpr int o_D = o_Ld+2*TILE;                // [2 buffers][2][TILE][ND] contributions formed per pair (list C)
+    static constexpr int o_R = o_D+4*TILE*ND;              // [2 buffers][2][TILE][NR]
+    static constexpr int o_PP = o_R+4*TILE*NR;             // [ND][NR] (+ pad): w phi_a phi_b at the points of those rules
     static constexpr int o_tt = o_PP+ND*NR+1;              // [P2_MAXPTS][ST]
     static constexpr int n_dbl = o_tt+P2_MAXPTS*ST;
     // ints
     static constexpr int o_vid = 0;                        // [2][NV][TILE]
     static constexpr int o_cnt = o_vid+2*NV*TILE;          // [PNL_MAXQ+2]
     static constexpr int o_cur = o_cnt+PNL_MAXQ+2;         // [PNL_MAXQ+2]
-    static constexpr int o_misc = o_cur+PNL_MAXQ+2;        // [8]: |A|, |B|, |far|, |C|, #C chunks, next chunk, next tile, wl base
+    static constexpr int o_misc = o_cur+PNL_MAXQ+2;        // [8]: |A|, |B|, |far|, |C|, #C chunks, next chunk, tile after next, wl base
     static constexpr int o_lh = o_misc+8;                  // float [2][2][TILE]
     static constexpr int o_ttn = o_lh+4*TILE;              // [PNL_MAXQ+2]
     static constexpr int o_tto = o_ttn+PNL_MAXQ+2;         // [PNL_MAXQ+2]
-    static constexpr int o_chunk = o_tto+PNL_MAXQ+2;       // [P2_MAXCHUNKS] list C chunks: order << 20 | start << 7 | count-1
-    static constexpr int o_l32 = o_chunk+P2_MAXCHUNKS;     // [PAIRS] list B from the front, far list from the back
-    static constexpr int n_int = o_l32+PAIRS;
+    static constexpr int o_off = o_tto+PNL_MAXQ+2;         // [PNL_MAXQ+2] offsets of the full rule tables (work-list entries)
+    static constexpr int o_chunk = o_off+PNL_MAXQ+2;       // [P2_MAXCHUNKS] list C chunks: order << 20 | start << 7 | count-1
+    static constexpr int o_lab = o_chunk+P2_MAXCHUNKS;     // [2][TILE] labels of the cells (variable order)
+    static constexpr int o_clsof = o_lab+2*TILE;           // [MAXLAB*MAXLAB] class of a label pair
+    static constexpr int o_l32 = o_clsof+MAXLAB*MAXLAB;    // [PAIRS] list B from the front, far list from the back
+    static constexpr int n_int = o_l32+PAIRS;              // then [2 buffers][2][nUe] global DoFs of both blocks
     // shorts
     static constexpr int o_slot = 0;                       // [2][DPE][TILE]
     static constexpr int o_list = o_slot+2*DPE*TILE;       // [PAIRS] list A from the front, list C from the back
     static constexpr int o_csort = o_list+PAIRS;           // [PAIRS] list C sorted by order
     static constexpr int n_short = o_csort+PAIRS;
-    static constexpr size_t fixed_bytes = sizeof(double)*n_dbl+sizeof(int)*n_int+sizeof(short)*n_short;
+    __host__ __device__ static constexpr size_t fixed_bytes(int nUe) {
+        return sizeof(double)*n_dbl+sizeof(int)*(size_t)(n_int+4*nUe)+sizeof(short)*n_short;
+    }
 };
 static_assert(P2Smem::n_int % 2 == 0 && P2Smem::n_short % 4 == 0, "LDS regions must keep 8-byte alignment");
 
@@ -438,34 +496,41 @@ __device__ __forceinline__ void p2_eval_lds_sweep2(const DevKernel &kk, const do
     }
 }
 
+// Software pipeline over the tiles of a workgroup like k_tile_uniform: the cell data of the next tile is staged BEFORE the
+// flush of the current one is issued, the barriers order the LDS only, the flush takes the DoF numbers from LDS and zeroes
+// the sub-block as it reads it.  Tile indices come from a global counter two tiles ahead (tickets).
 template <int KT>
 __global__ void __launch_bounds__(P2_NT, 2)
 k_tile_p2(const DevProblem P, const int2 *__restrict__ tiles, const int *__restrict__ tile_cls, const DevKernel *__restrict__ kcls,
           const DevFormula *__restrict__ fcls, double *__restrict__ A, long long ldA, double *__restrict__ Dglob, int cell_begin,
           int cell_end, int acc_stride, int4 *__restrict__ worklist, unsigned *__restrict__ wl_count, unsigned wl_cap, int flags,
-          int ntiles, unsigned *__restrict__ tile_ctr) {
+          int ntiles, unsigned *__restrict__ tile_ctr, int nUe) {
     using S = P2Smem;
     constexpr int TILE = S::TILE, NV = 3, NC = 6, DPE = 6, ND = 21, NT = P2_NT, PAIRS = S::PAIRS, PER_THREAD = PAIRS/NT, ST = S::ST;
-    constexpr int NA = 3, NB = 6, NWAVES = NT/64;
+    constexpr int NA = 3, NB = 6, NWAVES = NT/64, NR = S::NR, MAXLAB = S::MAXLAB;
     extern __shared__ double smem[];
     double *s_dbl = smem;
     int *s_int = (int*)(s_dbl+S::n_dbl);
-    short *s_short = (short*)(s_int+S::n_int);
-    double *s_acc = (double*)(s_short+S::n_short);          // [nA+1][acc_stride]
+    int *s_dof = s_int+S::n_int;                            // [2][2][nUe]
+    short *s_short = (short*)(s_dof+4*nUe);
+    double *s_acc = (double*)(s_short+S::n_short);          // [nUe+1][acc_stride]
     double *s_v = s_dbl+S::o_v, *s_cen = s_dbl+S::o_cen, *s_vol = s_dbl+S::o_vol, *s_h = s_dbl+S::o_h, *s_Ld = s_dbl+S::o_Ld;
-    double *s_D = s_dbl+S::o_D, *s_R = s_dbl+S::o_R, *s_PP = s_dbl+S::o_PP, *s_tt = s_dbl+S::o_tt;
-    constexpr int NR = S::NR;
+    double *s_Dall = s_dbl+S::o_D, *s_Rall = s_dbl+S::o_R, *s_PP = s_dbl+S::o_PP, *s_tt = s_dbl+S::o_tt;
     int *s_vid = s_int+S::o_vid, *s_cnt = s_int+S::o_cnt, *s_cur = s_int+S::o_cur, *s_misc = s_int+S::o_misc;
     float *s_lh = (float*)(s_int+S::o_lh);
-    int *s_ttn = s_int+S::o_ttn, *s_tto = s_int+S::o_tto, *s_chunk = s_int+S::o_chunk, *s_l32 = s_int+S::o_l32;
+    int *s_ttn = s_int+S::o_ttn, *s_tto = s_int+S::o_tto, *s_off = s_int+S::o_off, *s_chunk = s_int+S::o_chunk, *s_l32 = s_int+S::o_l32;
+    int *s_lab = s_int+S::o_lab, *s_clsof = s_int+S::o_clsof;
     short *s_slot = s_short+S::o_slot;
     unsigned short *s_list = (unsigned short*)(s_short+S::o_list), *s_csort = (unsigned short*)(s_short+S::o_csort);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
     const unsigned long long lt = (1ull << lane)-1ull;
     unsigned long long st_cnt = 0, st_ev = 0;                // statistics of order q = 2 + tid, kept over all tiles
-    for (int t = tid; t < PNL_MAXQ+2; t += NT) { s_ttn[t] = P.tt_n[t]; s_tto[t] = P.tt_off[t]; }
+    const bool lab_lds = P.nlab <= MAXLAB;
+    for (int t = tid; t < PNL_MAXQ+2; t += NT) { s_ttn[t] = P.tt_n[t]; s_tto[t] = P.tt_off[t]; s_off[t] = t <= P.qmax+1 ? P.off[t] : 0; }
     for (int t = tid; t < P.tt_npts*ST; t += NT) s_tt[t] = P.tt_tab[t];
+    if (P.nlab > 0 && lab_lds) for (int t = tid; t < P.nlab*P.nlab; t += NT) s_clsof[t] = P.cls_of[t];
     // the rules evaluated by the unrolled evaluators with row / column sums: the lowest order with 3 points and the two lowest
     // orders with 6 points (every such order has its own points, hence its own sums)
     int qA0 = 0, qB0 = 0, qB1 = 0;
@@ -474,8 +539,51 @@ k_tile_p2(const DevProblem P, const int2 *__restrict__ tiles, const int *__restr
         qA0 = (n == NA) ? q : qA0;
         if (n == NB) { qB1 = qB0; qB0 = q; }
     }
-    __syncthreads();
-    // w phi_a phi_b at the points of those rules
+    const bool symflush = (flags & 256) != 0;
+
+    // cell data of both blocks of tile t -> LDS (64 threads), DoF lists -> buffer buf (everybody)
+    auto stage = [&](int t, int buf) {
+        const int ta = tiles[t].x, tb = tiles[t].y;
+        const int nA = P.blk_ndof[ta], nB = P.blk_ndof[tb];
+        if (tid < 2*TILE) {
+            const int side = tid/TILE, l = tid%TILE;
+            const int c = (side ? tb : ta)*TILE+l;
+#pragma unroll
+            for (int k = 0; k < NC; k++) s_v[(side*NC+k)*TILE+l] = P.cellv[(size_t)k*P.ncp+c];
+#pragma unroll
+            for (int d = 0; d < 2; d++) s_cen[(side*2+d)*TILE+l] = P.ccen[(size_t)d*P.ncp+c];
+            s_vol[side*TILE+l] = P.cvol[c];
+            s_h[side*TILE+l] = P.ch[c];
+            const double lh = P.clog[c], Ld = P.clog[(size_t)P.ncp+c];
+            s_Ld[side*TILE+l] = Ld;
+            s_lh[(side*2+0)*TILE+l] = (float)lh;
+            s_lh[(side*2+1)*TILE+l] = (float)Ld;
+#pragma unroll
+            for (int k = 0; k < NV; k++) s_vid[(side*NV+k)*TILE+l] = P.cvid[(size_t)k*P.ncp+c];
+#pragma unroll
+            for (int k = 0; k < DPE; k++) {
+                // boundary DoFs (no slot) are sent to the trash row / column nUe of the LDS sub-block: no branches in the hot loop
+                const short sl = P.cslot[(size_t)k*P.ncp+c];
+                s_slot[(side*DPE+k)*TILE+l] = sl >= 0 ? sl : (short)nUe;
+            }
+            if (P.nlab > 0) s_lab[side*TILE+l] = P.clabel[c];
+        }
+        const int *__restrict__ dofA = P.blk_dofs+(size_t)ta*P.blk_stride;
+        const int *__restrict__ dofB = P.blk_dofs+(size_t)tb*P.blk_stride;
+        for (int k = tid; k < nA; k += NT) s_dof[(buf*2+0)*nUe+k] = dofA[k];
+        for (int k = tid; k < nB; k += NT) s_dof[(buf*2+1)*nUe+k] = dofB[k];
+    };
+
+    int n_cur = blockIdx.x, n_nxt = (int)(gridDim.x+blockIdx.x), buf = 0;
+    if (n_cur >= ntiles) return;
+    unsigned pending = 0;                                    // thread 0: ticket of the tile after n_nxt
+    if (tid == 0) pending = atomicAdd(tile_ctr, 1u);
+    for (int t = tid; t < (nUe+1)*acc_stride; t += NT) s_acc[t] = 0.;
+    for (int t = tid; t < 4*TILE*(ND+NR); t += NT) s_Dall[t] = 0.;             // s_D and s_R (both buffers) are adjacent
+    for (int t = tid; t < 2*(PNL_MAXQ+2)+6; t += NT) s_cnt[t] = 0;             // s_cnt, s_cur and s_misc[0..5] are adjacent
+    stage(n_cur, 0);
+    lds_barrier();
+    // w phi_a phi_b at the points of the unrolled rules
     for (int t = tid; t < ND*NR; t += NT) {
         const int e = t/NR, k = t-e*NR;
         const int q = k < 3 ? qA0 : (k < 9 ? qB0 : qB1), i = k < 3 ? k : (k < 9 ? k-3 : k-9);
@@ -485,9 +593,9 @@ k_tile_p2(const DevProblem P, const int2 *__restrict__ tiles, const int *__restr
         const double *tp = s_tt+(s_tto[q]+i)*ST;
         s_PP[t] = q ? tp[3]*tp[4+a]*tp[4+b] : 0.;
     }
-    const bool symflush = (flags & 256) != 0;
 #pragma unroll 1
-    for (int tile_idx = blockIdx.x; tile_idx < ntiles; tile_idx = s_misc[6]) {
+    while (true) {
+    const int tile_idx = n_cur;
     const int ta = tiles[tile_idx].x, tb = tiles[tile_idx].y;
     const int nA = P.blk_ndof[ta], nB = P.blk_ndof[tb];
     // order class of this tile entry (variable order: kernel, order formula, work-list region of the class; bit 0: orientation)
@@ -496,33 +604,7 @@ k_tile_p2(const DevProblem P, const int2 *__restrict__ tiles, const int *__restr
     DevFormula qo = P.qo;
     if (tile_cls) { kk = kcls[tcls >> 1]; qo = fcls[tcls >> 1]; }
     const int wl_region = tile_cls ? (tcls >> 1) : 0;
-
-    // ---- stage cell data of both blocks ----
-    for (int t = tid; t < 2*TILE; t += NT) {
-        const int side = t/TILE, l = t%TILE;
-        const int c = (side ? tb : ta)*TILE+l;
-#pragma unroll
-        for (int k = 0; k < NC; k++) s_v[(side*NC+k)*TILE+l] = P.cellv[(size_t)k*P.ncp+c];
-#pragma unroll
-        for (int d = 0; d < 2; d++) s_cen[(side*2+d)*TILE+l] = P.ccen[(size_t)d*P.ncp+c];
-        s_vol[side*TILE+l] = P.cvol[c];
-        s_h[side*TILE+l] = P.ch[c];
-        const double lh = P.clog[c], Ld = P.clog[(size_t)P.ncp+c];
-        s_Ld[side*TILE+l] = Ld;
-        s_lh[(side*2+0)*TILE+l] = (float)lh;
-        s_lh[(side*2+1)*TILE+l] = (float)Ld;
-#pragma unroll
-        for (int k = 0; k < NV; k++) s_vid[(side*NV+k)*TILE+l] = P.cvid[(size_t)k*P.ncp+c];
-#pragma unroll
-        for (int k = 0; k < DPE; k++) {
-            const short sl = P.cslot[(size_t)k*P.ncp+c];
-            s_slot[(side*DPE+k)*TILE+l] = sl >= 0 ? sl : (short)(side ? nB : nA);
-        }
-    }
-    for (int t = tid; t < (nA+1)*acc_stride; t += NT) s_acc[t] = 0.;
-    for (int t = tid; t < 2*TILE*(ND+NR); t += NT) s_D[t] = 0.;            // s_D and s_R are adjacent
-    for (int t = tid; t < 2*(PNL_MAXQ+2)+6; t += NT) s_cnt[t] = 0;          // s_cnt, s_cur and s_misc[0..5] are adjacent
-    __syncthreads();
+    double *__restrict__ s_D = s_Dall+buf*2*TILE*ND, *__restrict__ s_R = s_Rall+buf*2*TILE*NR;
 
     // ---- classification (NO:280-378 vertex test, NO:493-540 + FL2:622-642 order) ----
     int overflow = 0;
@@ -536,14 +618,15 @@ k_tile_p2(const DevProblem P, const int2 *__restrict__ tiles, const int *__restr
         const int ca = ta*TILE+i;
         bool ok = (va0 >= 0) && (vb0 >= 0) && (ta < tb || i < j) && (ca >= cell_begin) && (ca < cell_end);
         if (tcls >= 0 && ok) {
-            const int la = P.clabel[ca], lb = P.clabel[tb*TILE+j];
-            ok = P.cls_of[(tcls & 1) ? lb*P.nlab+la : la*P.nlab+lb] == (tcls >> 1);
+            const int la = s_lab[i], lb = s_lab[TILE+j];
+            const int idx = (tcls & 1) ? lb*P.nlab+la : la*P.nlab+lb;
+            ok = (lab_lds ? s_clsof[idx] : P.cls_of[idx]) == (tcls >> 1);
         }
         if (ok) {
             bool any_dof = false, shared = false;
 #pragma unroll
             for (int k = 0; k < DPE; k++)
-                any_dof = any_dof || (s_slot[(0*DPE+k)*TILE+i] < nA) || (s_slot[(1*DPE+k)*TILE+j] < nB);
+                any_dof = any_dof || (s_slot[(0*DPE+k)*TILE+i] < nUe) || (s_slot[(1*DPE+k)*TILE+j] < nUe);
 #pragma unroll
             for (int k = 0; k < NV; k++) {
                 const int va = s_vid[(0*NV+k)*TILE+i];
@@ -602,23 +685,21 @@ k_tile_p2(const DevProblem P, const int2 *__restrict__ tiles, const int *__restr
 #pragma unroll
         for (int k = 0; k < 3; k++) if (cnt234[k]) atomicAdd(&s_cnt[2+k], cnt234[k]);
     }
-    __syncthreads();
-    // next tile of this workgroup from the global counter (heavy, near-diagonal tiles come first in the list)
-    if (tid == 0) s_misc[6] = (int)(gridDim.x+atomicAdd(tile_ctr, 1u));
+    lds_barrier();
     {
         // far pairs (orders without a packed rule): one reservation in the class's region of the global work list per tile
         const int nF = s_misc[2];
         if (nF) {
             if (tid == 0) s_misc[7] = (int)atomicAdd(wl_count+wl_region, (unsigned)nF);
-            __syncthreads();
+            lds_barrier();
             const unsigned base = (unsigned)s_misc[7];
             int4 *__restrict__ wl = worklist+(size_t)wl_region*wl_cap;
             for (int t = tid; t < nF; t += NT) {
                 const int ent = s_l32[PAIRS-1-t];
                 const int p = ent & 4095, q = ent >> 12;
                 const int j = p%TILE, i = (p/TILE+21*j)%TILE;
-                const int off = P.off[q];
-                if (base+t < wl_cap) wl[base+t] = make_int4(ta*TILE+i, tb*TILE+j, off, (P.off[q+1]-off) | (q << 16));
+                const int off = s_off[q];
+                if (base+t < wl_cap) wl[base+t] = make_int4(ta*TILE+i, tb*TILE+j, off, (s_off[q+1]-off) | (q << 16));
             }
         }
     }
@@ -629,7 +710,7 @@ k_tile_p2(const DevProblem P, const int2 *__restrict__ tiles, const int *__restr
             const int cq = s_cnt[q];
             if (cq) {
                 const int ne = s_ttn[q];
-                const unsigned long long n = (unsigned long long)(ne ? ne : P.off[q+1]-P.off[q]);
+                const unsigned long long n = (unsigned long long)(ne ? ne : s_off[q+1]-s_off[q]);
                 st_cnt += (unsigned long long)cq;
                 st_ev += n*n*cq;
             }
@@ -638,7 +719,7 @@ k_tile_p2(const DevProblem P, const int2 *__restrict__ tiles, const int *__restr
     // ---- list C: counting sort by order, 64 pairs of one order per chunk ----
     const int nC = s_misc[3];
     if (nC) {
-        __syncthreads();
+        lds_barrier();
         if (tid == 0) {
             int run = 0, nch = 0;
             for (int q = 17; q >= 2; q--) {                    // heavy orders first
@@ -651,14 +732,14 @@ k_tile_p2(const DevProblem P, const int2 *__restrict__ tiles, const int *__restr
             }
             s_misc[4] = nch;
         }
-        __syncthreads();
+        lds_barrier();
         for (int t = tid; t < nC; t += NT) {
             const int ent = s_list[PAIRS-1-t];
             const int q = (ent >> 12)+2;
             s_csort[atomicAdd(&s_cur[q], 1)] = (unsigned short)(ent & 4095);
         }
     }
-    __syncthreads();
+    lds_barrier();
 
     // ---- evaluation: waves fetch chunks of 64 pairs of one order: list C (7-16 points), list B (6), list A (3) ----
     {
@@ -742,26 +823,40 @@ k_tile_p2(const DevProblem P, const int2 *__restrict__ tiles, const int *__restr
             }
         }
     }
-    __syncthreads();
+    lds_barrier();
 
-    // ---- flush: one wave per row of the sub-block, lanes along the row of A; diagonal blocks from the row / column sums ----
-    const int *__restrict__ dofA = P.blk_dofs+(size_t)ta*P.blk_stride;
-    const int *__restrict__ dofB = P.blk_dofs+(size_t)tb*P.blk_stride;
+    // ---- the next tile's cell data, then the flush of this one: one wave per row of the sub-block, lanes along the row of A;
+    // diagonal blocks from the row / column sums ----
+    const bool more = n_nxt < ntiles;
+    if (more) stage(n_nxt, buf^1);
+    if (tid == 0) {
+        s_misc[6] = (int)(2*gridDim.x+pending);
+        pending = atomicAdd(tile_ctr, 1u);
+    }
+    for (int t = tid; t < 2*(PNL_MAXQ+2)+6; t += NT) s_cnt[t] = 0;           // s_cnt, s_cur and s_misc[0..5] are adjacent
+    const int *__restrict__ dA = s_dof+(buf*2+0)*nUe, *__restrict__ dB = s_dof+(buf*2+1)*nUe;
 #pragma unroll 1
-    for (int r = wave; r < nA; r += NWAVES) {
-        double *__restrict__ row = A+(long long)dofA[r]*ldA;
+    for (int r = wv; r < nA; r += NWAVES) {
+        double *__restrict__ row = A+(long long)__builtin_amdgcn_readfirstlane(dA[r])*ldA;
         for (int cc = lane; cc < nB; cc += 64) {
             const double v = s_acc[r*acc_stride+cc];
-            if (v != 0.) atomic_add_f64(&row[dofB[cc]], v);
+            if (v != 0.) {
+                if (!symflush) s_acc[r*acc_stride+cc] = 0.;
+                atomic_add_f64(&row[dB[cc]], v);
+            }
         }
     }
+    if (symflush) lds_barrier();                              // the transposed sweep zeroes what the first one reads
     if (symflush)
 #pragma unroll 1
-        for (int cc = wave; cc < nB; cc += NWAVES) {
-            double *__restrict__ row = A+(long long)dofB[cc]*ldA;
+        for (int cc = wv; cc < nB; cc += NWAVES) {
+            double *__restrict__ row = A+(long long)__builtin_amdgcn_readfirstlane(dB[cc])*ldA;
             for (int r = lane; r < nA; r += 64) {
                 const double v = s_acc[r*acc_stride+cc];
-                if (v != 0.) atomic_add_f64(&row[dofA[r]], v);
+                if (v != 0.) {
+                    s_acc[r*acc_stride+cc] = 0.;
+                    atomic_add_f64(&row[dA[r]], v);
+                }
             }
         }
     for (int t = tid; t < 2*TILE*ND; t += NT) {
@@ -774,7 +869,12 @@ k_tile_p2(const DevProblem P, const int2 *__restrict__ tiles, const int *__restr
             atomic_add_f64(&Dglob[(size_t)c*ND+e], v);
         }
     }
-    __syncthreads();
+    // the buffers the tile before this one accumulated into (their flush is complete) are zeroed for the next tile
+    for (int t = tid; t < 2*TILE*ND; t += NT) s_Dall[(buf^1)*2*TILE*ND+t] = 0.;
+    for (int t = tid; t < 2*TILE*NR; t += NT) s_Rall[(buf^1)*2*TILE*NR+t] = 0.;
+    if (!more) break;
+    lds_barrier();
+    n_cur = n_nxt; n_nxt = s_misc[6]; buf ^= 1;
     }   // tile loop
     {
         const int q = 2+tid;

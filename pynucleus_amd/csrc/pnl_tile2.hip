@@ -5,19 +5,18 @@
 
 namespace {
 
-size_t uniform_lds(int dpe, int np, int tile, int nU, int acc_stride) {
-    const int nd = dpe*(dpe+1)/2;
-    return sizeof(double)*(size_t)(tile*np*2+tile+tile*np+tile*nd)+sizeof(int)*(size_t)(tile*dpe+tile)
-           +sizeof(double)*(size_t)(nU+1)*acc_stride;
-}
-
 template <int DPE, int NP, int KT>
 int launch_uniform_t(pnl_context *ctx, const DevProblem &Pt, const int2 *tiles, const int *tile_cls, int ntiles, int q, double *A,
                      int64_t ldA, double *Dglob) {
     constexpr int TILE = DPE == 6 ? 32 : 64;
-    const size_t fixed = uniform_lds(DPE, NP, TILE, -1, 0);
-    const int acc_stride = acc_stride_of(ctx->nU, fixed);
-    const size_t lds = fixed+sizeof(double)*(size_t)(ctx->nU+1)*acc_stride;
+    const int nUe = (ctx->nU+1) & ~1;                     // even: the sub-block follows the int arrays at an 8-byte boundary
+    const size_t fixed = uniform_fixed_lds(DPE, NP, TILE, nUe);
+    // sub-block [nUe+1][acc_stride]: rows in different LDS banks (stride = 1 mod 32 doubles) if two workgroups still share a CU,
+    // else an odd stride
+    int acc_stride = nUe+1;
+    while (acc_stride % 32 != 1) acc_stride++;
+    if (fixed+sizeof(double)*(size_t)(nUe+1)*acc_stride > 80*1024) acc_stride = (nUe+1) | 1;
+    const size_t lds = fixed+sizeof(double)*(size_t)(nUe+1)*acc_stride;
     if (lds > 160*1024)
         return fail(ctx, PNL_ERR_UNSUPPORTED, "a block of %d cells touches %d DoFs: LDS sub-block of %zu bytes exceeds 160 KiB", TILE, ctx->nU, lds);
     auto kfun = k_tile_uniform<DPE, NP, KT>;
@@ -27,8 +26,13 @@ int launch_uniform_t(pnl_context *ctx, const DevProblem &Pt, const int2 *tiles, 
     if (getenv("PNL_VERBOSE"))
         fprintf(stderr, "[pnl] uniform tiles of order %d: %d, dpe=%d np=%d kt=%d lds=%zu bytes (%d per CU), acc_stride=%d\n", q, ntiles, DPE,
                 NP, KT, lds, per_cu, acc_stride);
+    int uni_abl = 0;
+#ifdef PNL_DEBUG_ABLATE
+    uni_abl = getenv("PNL_UNI_ABL") ? atoi(getenv("PNL_UNI_ABL")) : 0;
+#endif
     hipLaunchKernelGGL(kfun, dim3(grid), dim3(256), lds, ctx->stream, Pt, tiles, tile_cls, (const DevKernel*)ctx->b_kcls.p, ntiles, A,
-                       (long long)ldA, Dglob, acc_stride, q, ctx->symflush ? 1 : 0, (const double*)ctx->b_uni.p+ctx->uni_off[q]);
+                       (long long)ldA, Dglob, acc_stride, q, (ctx->symflush ? 1 : 0) | uni_abl, (const double*)ctx->b_uni.p+ctx->uni_off[q],
+                       nUe);
     HIPCHK(ctx, hipGetLastError());
     return PNL_OK;
 }
@@ -45,23 +49,24 @@ template <int KT>
 int launch_p2_t(pnl_context *ctx, const int2 *tiles, const int *tile_cls, int ntiles, double *A, int64_t ldA, int cell_begin,
                 int cell_end, unsigned wl_cap_each) {
     using S = P2Smem;
+    const int nUe = (ctx->nU+1) & ~1;
     // one workgroup per CU: rows of the sub-block start in different LDS banks (stride = 1 mod 32 doubles) if that fits
-    int stride = ctx->nU+1;
+    int stride = nUe+1;
     while (stride % 32 != 1) stride++;
-    size_t lds = S::fixed_bytes+sizeof(double)*(size_t)(ctx->nU+1)*stride;
-    if (lds > 160*1024) { stride = (ctx->nU+1) | 1; lds = S::fixed_bytes+sizeof(double)*(size_t)(ctx->nU+1)*stride; }
+    size_t lds = S::fixed_bytes(nUe)+sizeof(double)*(size_t)(nUe+1)*stride;
+    if (lds > 160*1024) { stride = (nUe+1) | 1; lds = S::fixed_bytes(nUe)+sizeof(double)*(size_t)(nUe+1)*stride; }
     if (lds > 160*1024)
         return fail(ctx, PNL_ERR_UNSUPPORTED, "a block of %d cells touches %d DoFs: LDS sub-block of %zu bytes exceeds 160 KiB "
                     "(cells must be numbered with spatial locality)", P2_TILE, ctx->nU, lds);
     auto kfun = k_tile_p2<KT>;
     HIPCHK(ctx, hipFuncSetAttribute((const void*)kfun, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    const int grid_mult = getenv("PNL_GRID_MULT") ? atoi(getenv("PNL_GRID_MULT")) : 1;
-    const int grid = std::min(ntiles, 256*std::max(grid_mult, 1));
+    // two tiles per workgroup are taken by block index, the rest through tickets: a grid of at most ntiles / 2 workgroups
+    const int grid = std::max(1, std::min((ntiles+1)/2, 256));
     if (getenv("PNL_VERBOSE")) fprintf(stderr, "[pnl] P2 general tiles=%d nU=%d kt=%d lds=%zu bytes acc_stride=%d\n", ntiles, ctx->nU, KT, lds, stride);
     hipLaunchKernelGGL(kfun, dim3(grid), dim3(P2_NT), lds, ctx->stream, ctx->P, tiles, tile_cls, (const DevKernel*)ctx->b_kcls.p,
                        (const DevFormula*)ctx->b_fcls.p, A, (long long)ldA, (double*)ctx->b_D.p, cell_begin, cell_end, stride,
                        (int4*)ctx->b_wl.p, (unsigned*)ctx->b_wlcount.p, wl_cap_each, ctx->symflush ? 256 : 0, ntiles,
-                       (unsigned*)ctx->b_tilectr.p);
+                       (unsigned*)ctx->b_tilectr.p, nUe);
     HIPCHK(ctx, hipGetLastError());
     return PNL_OK;
 }
