@@ -65,6 +65,13 @@ struct pnl_context {
     // second-generation tile kernels (pnl_tile2.h): per-class kernel / order-formula tables, rules of the uniform-order tiles,
     // class word of every tile entry (2 class + orientation), w and w phi of the packed rules
     DevBuf b_kcls, b_fcls, b_uni, b_tilecls, b_ttwphif;
+    // block-slot storage (pnl_tile2.h): padded column offsets of the blocks, row offsets, copies (block, slot) of every DoF,
+    // the tiles that several order classes visit, the storage itself (allocated by the first assembly that uses it)
+    DevBuf b_scolbase, b_srowoff, b_cpoff, b_cpslot, b_cprow, b_multitiles, b_slotA;
+    int slot_S = 0, n_multitiles = 0;
+    long long slot_total = 0;         // doubles
+    bool slot_full_list = false;      // the current tile list is the whole upper block triangle (pnl_assemble_dense)
+    bool slot_used = false;           // the tile kernels of the current assembly wrote the block-slot storage
     std::vector<DevKernel> kcls_host;
     std::vector<DevFormula> fcls_host;
     int uni_off[5] = {-1, -1, -1, -1, -1}, uni_np[5] = {0, 0, 0, 0, 0};
@@ -204,6 +211,14 @@ inline DevProblem tile_problem(const pnl_context *ctx) {
 
 // pnl_tile2.hip
 int pnl2_launch_uniform(pnl_context *ctx, int kt, const DevProblem &Pt, const int2 *tiles, const int *tile_cls, int ntiles, int q,
-                        double *A, int64_t ldA, double *Dglob);
+                        double *A, int64_t ldA, double *Dglob, const SlotOut &SO);
 int pnl2_launch_p2(pnl_context *ctx, int kt, const int2 *tiles, const int *tile_cls, int ntiles, double *A, int64_t ldA,
-                   int cell_begin, int cell_end, unsigned wl_cap_each);
+                   int cell_begin, int cell_end, unsigned wl_cap_each, const SlotOut &SO);
+int pnl2_zero_slot_tiles(pnl_context *ctx, const SlotOut &SO);
+int pnl2_fold_mirror(pnl_context *ctx, const SlotOut &SO, double *A, int64_t ldA);
+inline SlotOut slot_out(const pnl_context *ctx) {
+    SlotOut SO;
+    SO.A2 = (double*)ctx->b_slotA.p; SO.rowoff = (const long long*)ctx->b_srowoff.p; SO.colbase = (const int*)ctx->b_scolbase.p;
+    SO.S = ctx->slot_S; SO.pad = 0;
+    return SO;
+}

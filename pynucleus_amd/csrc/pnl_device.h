@@ -106,3 +106,11 @@ struct PwDev {
     const double *bnodes[2], *bw[2], *bphi[2];
     double sfac, bfac;
 };
+
+// block-slot storage of the one-sided operator (pnl_tile2.h)
+struct SlotOut {
+    double *A2;                 // block-slot storage (nullptr: flush with atomics into A)
+    const long long *rowoff;    // [nblocks]
+    const int *colbase;         // [nblocks+1], multiples of 8
+    int S, pad;
+};

@@ -298,6 +298,33 @@ int finalize(pnl_context *ctx) {
     if ((rc = upload(ctx, ctx->b_cslot, cslot.data(), cslot.size()))) return rc;
     if ((rc = upload(ctx, ctx->b_blk_ndof, blk_ndof.data(), blk_ndof.size()))) return rc;
     if ((rc = upload(ctx, ctx->b_blk_dofs, blk_dofs.data(), blk_dofs.size()))) return rc;
+    {
+        // block-slot storage (pnl_tile2.h): padded column offsets, row offsets, the copies (block, slot) of every DoF
+        std::vector<int32_t> colbase(nblocks+1, 0);
+        for (int b = 0; b < nblocks; b++) colbase[b+1] = colbase[b]+((blk_ndof[b]+7) & ~7);
+        const int S = colbase[nblocks];
+        std::vector<long long> rowoff(nblocks, 0);
+        long long run = 0;
+        for (int a = 0; a < nblocks; a++) { rowoff[a] = run; run += (long long)blk_ndof[a]*(S-colbase[a]); }
+        ctx->slot_S = S; ctx->slot_total = run;
+        std::vector<int32_t> cpoff(ctx->N+1, 0);
+        for (int b = 0; b < nblocks; b++) for (int g : lists[b]) cpoff[g+1]++;
+        for (int g = 0; g < ctx->N; g++) cpoff[g+1] += cpoff[g];
+        std::vector<int2> cp(cpoff[ctx->N]);
+        std::vector<int32_t> fillp(cpoff.begin(), cpoff.end()-1);
+        std::vector<long long> cprow(cp.size());
+        for (int b = 0; b < nblocks; b++)
+            for (size_t r = 0; r < lists[b].size(); r++) {
+                const int k = fillp[lists[b][r]]++;
+                cp[k] = make_int2(b, colbase[b]+(int)r);
+                cprow[k] = rowoff[b]+(long long)r*(S-colbase[b])-colbase[b];
+            }
+        if ((rc = upload(ctx, ctx->b_cprow, cprow.data(), cprow.size()))) return rc;
+        if ((rc = upload(ctx, ctx->b_scolbase, colbase.data(), colbase.size()))) return rc;
+        if ((rc = upload(ctx, ctx->b_srowoff, rowoff.data(), rowoff.size()))) return rc;
+        if ((rc = upload(ctx, ctx->b_cpoff, cpoff.data(), cpoff.size()))) return rc;
+        if ((rc = upload(ctx, ctx->b_cpslot, cp.data(), cp.size()))) return rc;
+    }
     if ((rc = upload(ctx, ctx->b_perm, ctx->perm_table.data(), ctx->perm_table.size()))) return rc;
     if ((rc = ensure(ctx, ctx->b_counters, sizeof(unsigned long long)*PNL_NCOUNTERS))) return rc;
     if ((rc = ensure(ctx, ctx->b_D, sizeof(double)*(size_t)ncp*(dpe*(dpe+1)/2)))) return rc;
@@ -383,7 +410,7 @@ int launch_pure(pnl_context *ctx, double *A, int64_t ldA) {
 
 // counting sort of a work-list region by order, then the sorted evaluation (k_worklist_lane / k_worklist_sorted)
 template <int DIM, int DPE, int KT>
-int run_worklist(pnl_context *ctx, const int4 *wl, const unsigned *wlc, unsigned cap, double *A, int64_t ldA) {
+int run_worklist(pnl_context *ctx, const int4 *wl, const unsigned *wlc, unsigned cap, double *A, int64_t ldA, bool sym) {
     int rc;
     if ((rc = ensure(ctx, ctx->b_wlsorted, (size_t)cap*sizeof(int4)))) return rc;
     if ((rc = ensure(ctx, ctx->b_wlaux, sizeof(unsigned)*(4*(PNL_WL_BINS+1))))) return rc;
@@ -406,10 +433,10 @@ int run_worklist(pnl_context *ctx, const int4 *wl, const unsigned *wlc, unsigned
     if (ctx->wl_lane)
         hipLaunchKernelGGL((k_worklist_lane<DIM, DPE, KT, false>), dim3(256*4), dim3(PNL_NTHREADS), 0, ctx->stream, ctx->P,
                            (const int4*)ctx->b_wlsorted.p, (const unsigned*)offs, A, (long long)ldA, (double*)ctx->b_D.p, SparseOut{},
-                           dbg | (ctx->symflush ? 8 : 0), ClusterTiles{});
+                           dbg | (sym ? 8 : 0), ClusterTiles{});
     hipLaunchKernelGGL(wfun, dim3(256*2), dim3(PNL_NTHREADS), lds, ctx->stream, ctx->P, (const int4*)ctx->b_wlsorted.p,
                        (const unsigned*)offs, (const unsigned*)coff, A, (long long)ldA, (double*)ctx->b_D.p, tab_max,
-                       SparseOut{}, PNL_WL_BINS-1, nmin | (ctx->symflush ? 1 << 16 : 0), ClusterTiles{});
+                       SparseOut{}, PNL_WL_BINS-1, nmin | (sym ? 1 << 16 : 0), ClusterTiles{});
     HIPCHK(ctx, hipGetLastError());
     return PNL_OK;
 }
@@ -443,7 +470,7 @@ int launch_tiles(pnl_context *ctx, int wl_slot, double *A, int64_t ldA, int cell
             for (int q = 3; q <= 4; q++) {
                 const int n = ctx->cls_n_uni[q-2][ctx->cur];
                 if ((rc = pnl2_launch_uniform(ctx, KT, tile_problem(ctx), (const int2*)ctx->b_tiles.p+off, nullptr, n, q, A, ldA,
-                                              (double*)(ctx->have_tile_order ? ctx->b_Dt.p : ctx->b_D.p)))) return rc;
+                                              (double*)(ctx->have_tile_order ? ctx->b_Dt.p : ctx->b_D.p), SlotOut{}))) return rc;
                 ctx->pure_launched = ctx->pure_launched || n > 0;
                 off += n;
             }
@@ -477,7 +504,7 @@ int launch_tiles(pnl_context *ctx, int wl_slot, double *A, int64_t ldA, int cell
                            (unsigned*)ctx->b_tilectr.p);
     HIPCHK(ctx, hipGetLastError());
     HIPCHK(ctx, hipEventRecord(ctx->ev[6], ctx->stream));
-    return run_worklist<DIM, DPE, KT>(ctx, (const int4*)ctx->b_wl.p, wlc, ctx->wl_cap_each, A, ldA);
+    return run_worklist<DIM, DPE, KT>(ctx, (const int4*)ctx->b_wl.p, wlc, ctx->wl_cap_each, A, ldA, ctx->symflush);
 }
 
 template <int DIM, int DPE, int SLOT, int KT>
@@ -556,7 +583,7 @@ int launch_boundary(pnl_context *ctx, int cell_begin, int cell_end) {
 // order classes (every tile entry carries its class: kernel parameters and order formula come from per-class tables), then the
 // sorted work-list evaluation per class on that class's region of the work list
 template <int DIM, int DPE>
-int launch_tiles_single(pnl_context *ctx, double *A, int64_t ldA, int cell_begin, int cell_end) {
+int launch_tiles_single(pnl_context *ctx, double *A, int64_t ldA, int cell_begin, int cell_end, bool slot_ok) {
     int rc;
     const int ncls = (int)ctx->cls.size();
     const bool var = ctx->nlab > 0;
@@ -579,25 +606,41 @@ int launch_tiles_single(pnl_context *ctx, double *A, int64_t ldA, int cell_begin
     const int2 *tiles = (const int2*)ctx->b_tiles.p;
     const int *tcls = var ? (const int*)ctx->b_tilecls.p : nullptr;
     HIPCHK(ctx, hipMemsetAsync(ctx->b_tilectr.p, 0, sizeof(unsigned), ctx->stream));
+    // block-slot storage when the whole upper block triangle is assembled by this call and mirrored afterwards
+    SlotOut SO{};
+    ctx->slot_used = false;
+    if (slot_ok && !ctx->nonsym && !getenv("PNL_NO_SLOT")) {
+        size_t free_b = 0, total_b = 0;
+        const size_t need = sizeof(double)*(size_t)ctx->slot_total;
+        if (ctx->b_slotA.bytes >= need || (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > need+(size_t(2) << 30))) {
+            if ((rc = ensure(ctx, ctx->b_slotA, need))) return rc;
+            SO = slot_out(ctx);
+            ctx->slot_used = true;
+            if (var && (rc = pnl2_zero_slot_tiles(ctx, SO))) return rc;
+        }
+    }
     HIPCHK(ctx, hipEventRecord(ctx->ev[7], ctx->stream));
     ctx->pure_launched = false;
     for (int q = 2; q <= 4; q++) {
         const int n = ctx->sl_n[q-1];
         if ((rc = pnl2_launch_uniform(ctx, kt, ctx->P, tiles+ctx->sl_off[q-1], tcls ? tcls+ctx->sl_off[q-1] : nullptr, n, q, A, ldA,
-                                      (double*)ctx->b_D.p))) return rc;
+                                      (double*)ctx->b_D.p, SO))) return rc;
         ctx->pure_launched = ctx->pure_launched || n > 0;
     }
     if (ctx->pure_launched) HIPCHK(ctx, hipEventRecord(ctx->ev[7], ctx->stream));
     if ((rc = pnl2_launch_p2(ctx, kt, tiles+ctx->sl_off[0], tcls ? tcls+ctx->sl_off[0] : nullptr, ctx->sl_n[0], A, ldA, cell_begin, cell_end,
-                             ctx->wl_cap_each))) return rc;
+                             ctx->wl_cap_each, SO))) return rc;
     HIPCHK(ctx, hipEventRecord(ctx->ev[6], ctx->stream));
+    // block-slot storage: A = A' + A'^T is formed now (it overwrites A); the work-list kernels then write both images
+    if (ctx->slot_used && (rc = pnl2_fold_mirror(ctx, SO, A, ldA))) return rc;
+    const bool sym = ctx->symflush || ctx->slot_used;
     for (int k = 0; k < ncls; k++) {
         ctx->cur = k;
         refresh_tables(ctx);
         const int4 *wl = (const int4*)ctx->b_wl.p+(size_t)k*ctx->wl_cap_each;
         const unsigned *wlc = (const unsigned*)ctx->b_wlcount.p+k;
-        rc = ctx->P.k.fast ? run_worklist<DIM, DPE, 1>(ctx, wl, wlc, ctx->wl_cap_each, A, ldA)
-                           : run_worklist<DIM, DPE, 0>(ctx, wl, wlc, ctx->wl_cap_each, A, ldA);
+        rc = ctx->P.k.fast ? run_worklist<DIM, DPE, 1>(ctx, wl, wlc, ctx->wl_cap_each, A, ldA, sym)
+                           : run_worklist<DIM, DPE, 0>(ctx, wl, wlc, ctx->wl_cap_each, A, ldA, sym);
         if (rc) { ctx->cur = 0; return rc; }
     }
     ctx->cur = 0;
@@ -625,7 +668,10 @@ int assemble_impl(pnl_context *ctx, double *A, int64_t ldA, int zero_exterior, i
         if ((rc = ensure_worklist(ctx, (double)ntiles*TILE*TILE, single ? ncls : 1))) return rc;
         ctx->wl_slots = single ? ncls : ncls*norient;
         if constexpr (DIM == 2 && DPE == 6) {
-            if ((rc = launch_tiles_single<DIM, DPE>(ctx, A, ldA, ctx->tile_cell_filter ? cell_begin : 0, ctx->tile_cell_filter ? cell_end : ctx->nc)))
+            // the block-slot storage needs every tile of the upper block triangle written by this call, then the fold + mirror pass
+            const bool slot_ok = ctx->slot_full_list && cell_begin == 0 && cell_end == ctx->nc &&
+                                 !(flags & (PNL_FLAG_NO_MIRROR | PNL_FLAG_SYMMETRIC_FLUSH));
+            if ((rc = launch_tiles_single<DIM, DPE>(ctx, A, ldA, ctx->tile_cell_filter ? cell_begin : 0, ctx->tile_cell_filter ? cell_end : ctx->nc, slot_ok)))
                 { ctx->cur = 0; ctx->orient = 0; return rc; }
         } else
         for (int ko = 0; ko < ncls*norient; ko++) {
@@ -645,7 +691,9 @@ int assemble_impl(pnl_context *ctx, double *A, int64_t ldA, int zero_exterior, i
     ctx->orient = 0;
     HIPCHK(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
     // mirror the cross part before the symmetric contributions are added on both sides
-    if (!(flags & (PNL_FLAG_NO_MIRROR | PNL_FLAG_SYMMETRIC_FLUSH))) {
+    if (ntiles > 0 && ctx->slot_used) {
+        // folded and mirrored inside launch_tiles_single
+    } else if (!(flags & (PNL_FLAG_NO_MIRROR | PNL_FLAG_SYMMETRIC_FLUSH))) {
         const long long nb = (ctx->N+31)/32;
         hipLaunchKernelGGL(k_mirror, dim3((unsigned)(nb*(nb+1)/2)), dim3(PNL_NTHREADS), 0, ctx->stream, A, (long long)ldA, ctx->N);
         HIPCHK(ctx, hipGetLastError());
@@ -1709,6 +1757,25 @@ static int upload_tiles(pnl_context *ctx, std::vector<int2> &tiles, int cell_beg
             ctx->sl_n[u+1] = (int)all.size()-ctx->sl_off[u+1];
         }
         for (int k = 0; k < ncls; k++) ctx->cls_n_pure[k] = ctx->cls_n_uni[0][k];
+        // tiles that are visited more than once (several classes, both orientations) add into the block-slot storage
+        // (bit 30 of the class word) and are zeroed before
+        {
+            std::vector<long long> keys(all.size());
+            for (size_t i = 0; i < all.size(); i++) keys[i] = (long long)all[i].x*ctx->nblocks+all[i].y;
+            std::vector<long long> sorted(keys);
+            std::sort(sorted.begin(), sorted.end());
+            std::vector<int2> multi;
+            for (size_t i = 0; i+1 < sorted.size(); i++)
+                if (sorted[i] == sorted[i+1] && (i == 0 || sorted[i-1] != sorted[i]))
+                    multi.push_back(make_int2((int)(sorted[i]/ctx->nblocks), (int)(sorted[i]%ctx->nblocks)));
+            std::vector<long long> mk(multi.size());
+            for (size_t i = 0; i < multi.size(); i++) mk[i] = (long long)multi[i].x*ctx->nblocks+multi[i].y;
+            for (size_t i = 0; i < all.size(); i++)
+                if (std::binary_search(mk.begin(), mk.end(), keys[i])) allcls[i] |= (1 << 30);
+            ctx->n_multitiles = (int)multi.size();
+            int rc3 = upload(ctx, ctx->b_multitiles, multi.data(), multi.size());
+            if (rc3) return rc3;
+        }
         int rc2 = upload(ctx, ctx->b_tilecls, allcls.data(), allcls.size());
         if (rc2) return rc2;
     }
@@ -1749,6 +1816,7 @@ int pnl_assemble_dense(pnl_context *ctx, double *A, int64_t ldA, int zero_exteri
     for (long long c = cell_begin; c < cell_end; c++) visited += (unsigned long long)(ctx->nc-c);
     ctx->visited_pairs = visited; ctx->visited_is_assembled = false;
     if (getenv("PNL_FORCE_SYMFLUSH")) flags |= PNL_FLAG_SYMMETRIC_FLUSH;     // debug: both sides written by the flush, no mirror pass
+    ctx->slot_full_list = true;
     return dispatch(ctx, A, ldA, zero_exterior, (int)tiles.size(), cell_begin, cell_end, flags);
 }
 
@@ -1766,6 +1834,7 @@ int pnl_assemble_dense_tiles(pnl_context *ctx, double *A, int64_t ldA, int zero_
         if (tiles[i].x < 0 || tiles[i].y >= ctx->nblocks || tiles[i].x > tiles[i].y) return fail(ctx, PNL_ERR_INVALID, "bad tile %d", i);
     }
     ctx->tile_cell_filter = false;
+    ctx->slot_full_list = false;
     if ((rc = upload_tiles(ctx, tiles, cell_begin, cell_end))) { ctx->tile_cell_filter = true; return rc; }
     ctx->visited_pairs = 0; ctx->visited_is_assembled = false;
     rc = dispatch(ctx, A, ldA, zero_exterior, ntiles, cell_begin, cell_end, flags);

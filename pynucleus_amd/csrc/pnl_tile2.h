@@ -42,6 +42,105 @@ __device__ __forceinline__ void group_sum3(double a, double b, double c, double 
 // layout of a uniform-tile rule block (doubles): bary[NP][3], w[NP], w phi[NP][DPE], w phi_a phi_b[ND][NP]
 __host__ __device__ constexpr int uni_rule_size(int dpe, int np) { return 3*np+np+np*dpe+(dpe*(dpe+1)/2)*np; }
 
+// ---- block-slot storage of the one-sided operator A' ---------------------------------------------------------------------
+// A tile (block a, block b) accumulates into rows = DoFs of block a, columns = DoFs of block b.  DoFs on block borders belong
+// to several blocks, so in DoF numbering the sub-blocks of different tiles overlap and the flush has to ADD (fp64 atomics: one
+// 256-byte request per ~50 ns and CU, the price of a P2 tile's 89 x 89 sub-block is 12 us against 10 us for computing it).  In
+// slot numbering -- every block keeps private copies of its DoFs: row (a, r), column (b, c) -- every entry belongs to exactly
+// one tile: the flush is a plain coalesced store, nothing has to be zeroed first, and one gather pass (k_fold_mirror) sums
+// the copies, A[I][J] = sum over copies (a, r) of I and (b, c) of J, and symmetrises in the same sweep.
+//   row (a, r) of the storage holds the columns of the blocks b >= a: W_a = S - colbase[a] entries, S = sum of the padded
+//   block widths; rowoff[a] = offset of row (a, 0).
+// struct SlotOut: pnl_device.h
+
+// copies of a DoF: cp[k] = (block a, global slot column colbase[a] + r), cprow[k] = offset of that slot's storage row minus
+// colbase[a], so that entry (row copy k, column copy l) sits at A2[cprow[k] + cp[l].y] (stored iff cp[l].x >= cp[k].x)
+//
+// A = A' + A'^T with A' gathered from the block-slot storage; every entry of A is written (no zero fill needed before).
+// 32 x 32 blocks of the upper block triangle, both images through an LDS transpose like k_mirror.  A thread keeps the copies
+// of its two columns in registers (DoFs have 1.3 copies on average, at most a handful) and walks the rows.
+#define PNL_FOLD_MAXE 160       // copies of 32 consecutive DoFs kept in LDS (1.3 per DoF on average)
+__global__ void __launch_bounds__(256)
+k_fold_mirror(const double *__restrict__ A2, const int *__restrict__ cpoff, const int2 *__restrict__ cp, const long long *__restrict__ cprow,
+              double *__restrict__ A, long long ldA, int N) {
+    __shared__ double t1[32][33], t2[32][33];
+    __shared__ int s_off[2][33];
+    __shared__ int2 s_cp[2][PNL_FOLD_MAXE];
+    __shared__ long long s_row[2][PNL_FOLD_MAXE];
+    const int nb = (N+31)/32;
+    const int bid = blockIdx.x;
+    int bi = 0;
+    {
+        const double fb = ((2.*nb+1.)-sqrt((2.*nb+1.)*(2.*nb+1.)-8.*bid))*0.5;
+        bi = (int)fb;
+        while (bi > 0 && (long long)bi*nb-(long long)bi*(bi-1)/2 > bid) bi--;
+        while ((long long)(bi+1)*nb-(long long)(bi+1)*bi/2 <= bid) bi++;
+    }
+    const int bj = bi+(bid-(int)((long long)bi*nb-(long long)bi*(bi-1)/2));
+    const int tid = threadIdx.x, tx = tid & 31, ty = tid >> 5;     // 32 x 8
+    // the copy tables of the two DoF ranges go through LDS: two dependent global loads per workgroup instead of three per
+    // thread and row before the first entry of the storage can be requested
+    if (tid < 66) {
+        const int side = tid/33, k = tid-side*33;
+        s_off[side][k] = cpoff[min((side ? bj : bi)*32+k, N)];
+    }
+    __syncthreads();
+    const int o0 = s_off[0][0], n0 = s_off[0][32]-o0, o1 = s_off[1][0], n1 = s_off[1][32]-o1;
+    const bool in_lds = n0 <= PNL_FOLD_MAXE && n1 <= PNL_FOLD_MAXE;
+    if (in_lds) {
+        for (int k = tid; k < n0+n1; k += 256) {
+            const int side = k >= n0, kk = side ? k-n0 : k, g = (side ? o1 : o0)+kk;
+            s_cp[side][kk] = cp[g];
+            s_row[side][kk] = cprow[g];
+        }
+    }
+    __syncthreads();
+    // A'[rows of range sr][column tx of range sc] -> t[.][tx]
+    auto gather = [&](int sr, int sc, double (*t)[33]) {
+        const int j0 = s_off[sc][tx]-s_off[sc][0], j1 = s_off[sc][tx+1]-s_off[sc][0];
+        const int ob_r = s_off[sr][0], ob_c = s_off[sc][0];
+#pragma unroll
+        for (int rr = 0; rr < 4; rr++) {
+            const int r = ty+8*rr;
+            const int i0 = s_off[sr][r]-ob_r, i1 = s_off[sr][r+1]-ob_r;
+            double s = 0.;
+            for (int ci = i0; ci < i1; ci++) {
+                const int a = in_lds ? s_cp[sr][ci].x : cp[ob_r+ci].x;
+                const double *__restrict__ rowp = A2+(in_lds ? s_row[sr][ci] : cprow[ob_r+ci]);
+                for (int cj = j0; cj < j1; cj++) {
+                    const int2 c2 = in_lds ? s_cp[sc][cj] : cp[ob_c+cj];
+                    if (c2.x >= a) s += rowp[c2.y];
+                }
+            }
+            t[r][tx] = s;
+        }
+    };
+    gather(0, 1, t1);
+    if (bi != bj) gather(1, 0, t2);
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int I = bi*32+r, J = bj*32+tx;
+        if (I < N && J < N) {
+            if (bi != bj) A[(long long)I*ldA+J] = t1[r][tx]+t2[tx][r];
+            else A[(long long)I*ldA+J] = (r != tx) ? t1[r][tx]+t1[tx][r] : t1[r][tx];
+        }
+        const int I2 = bj*32+r, J2 = bi*32+tx;
+        if (bi != bj && I2 < N && J2 < N) A[(long long)I2*ldA+J2] = t2[r][tx]+t1[tx][r];
+    }
+}
+
+// sub-blocks of the tiles that are visited more than once (several order classes) are accumulated with atomics: zero them first
+__global__ void __launch_bounds__(256)
+k_zero_slot_tiles(const SlotOut SO, const int2 *__restrict__ tiles, const int *__restrict__ blk_ndof) {
+    const int a = tiles[blockIdx.x].x, b = tiles[blockIdx.x].y;
+    const int nA = blk_ndof[a], nBp = SO.colbase[b+1]-SO.colbase[b], W = SO.S-SO.colbase[a];
+    double *__restrict__ base = SO.A2+SO.rowoff[a]+(SO.colbase[b]-SO.colbase[a]);
+    for (int t = threadIdx.x; t < nA*nBp; t += 256) {
+        const int r = t/nBp, c = t-r*nBp;
+        base[(long long)r*W+c] = 0.;
+    }
+}
+
 // workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every global atomic / store of the wave
 // (s_waitcnt vmcnt(0)): the flush of a tile would have to retire before the next tile may start.  The tile kernels below
 // never read global memory that the same launch writes, so their barriers only have to order the LDS.
@@ -62,7 +161,7 @@ template <int DPE, int NP, int KT>
 __global__ void __launch_bounds__(256, 2)
 k_tile_uniform(const DevProblem P, const int2 *__restrict__ tiles, const int *__restrict__ tile_cls, const DevKernel *__restrict__ kcls,
                int ntiles, double *__restrict__ A, long long ldA, double *__restrict__ Dglob, int acc_stride, int q_uniform,
-               int flags, const double *__restrict__ rule_g, int nUe) {
+               int flags, const double *__restrict__ rule_g, int nUe, const SlotOut SO) {
     constexpr int DIM = 2, NV = 3, NC = 6, ND = DPE*(DPE+1)/2, NT = 256, NW = NT/64;
     constexpr int TILE = DPE == 6 ? 32 : 64, HALVES = 64/TILE, JW = TILE/NW, ITER = JW/HALVES;
     constexpr int R_BARY = 0, R_W = 3*NP, R_WPH = R_W+NP, R_PP = R_WPH+NP*DPE;
@@ -144,7 +243,7 @@ k_tile_uniform(const DevProblem P, const int2 *__restrict__ tiles, const int *__
         const int nA = P.blk_ndof[ta], nB = P.blk_ndof[tb];
         // variable order, piecewise constant: the tile's blocks carry one label each, the kernel of their class is tile-uniform
         DevKernel kk = P.k;
-        if (tile_cls) kk = kcls[tile_cls[tile_idx] >> 1];
+        if (tile_cls) kk = kcls[(tile_cls[tile_idx] & 0xffff) >> 1];
         const double scale2 = 2.*kern_scale<KT>(kk);
         double *__restrict__ Ra = s_Ra+buf*TILE*NP;
         // a side: lane = cell li (both halves of a P2 wave hold the same cells)
@@ -238,7 +337,22 @@ k_tile_uniform(const DevProblem P, const int2 *__restrict__ tiles, const int *__
         if (more) stage(nxt, buf^1);
         const int *__restrict__ dA = s_dof+(buf*2+0)*nUe, *__restrict__ dB = s_dof+(buf*2+1)*nUe;
         const bool sym = (flags & 1) != 0;
-        if (!(flags & 2))
+        if (SO.A2) {
+            // block-slot storage: this tile owns its nA x nB sub-block, plain 16-byte stores of every entry
+            const int ca = SO.colbase[ta], W = SO.S-ca;
+            double *__restrict__ base = SO.A2+SO.rowoff[ta]+(SO.colbase[tb]-ca);
+#pragma unroll 1
+            for (int r = wv; r < nA; r += NW) {
+                double *__restrict__ row = base+(long long)r*W;
+                for (int cc = 2*lane; cc < nB; cc += 128) {
+                    double2 v;
+                    v.x = s_acc[r*acc_stride+cc]; v.y = s_acc[r*acc_stride+cc+1];
+                    s_acc[r*acc_stride+cc] = 0.; s_acc[r*acc_stride+cc+1] = 0.;
+                    if (cc+1 >= nB) v.y = 0.;
+                    *(double2*)(row+cc) = v;
+                }
+            }
+        } else if (!(flags & 2))
 #pragma unroll 1
         for (int r = wv; r < nA; r += NW) {
             double *__restrict__ row = A+(long long)__builtin_amdgcn_readfirstlane(dA[r])*ldA;
@@ -504,7 +618,7 @@ __global__ void __launch_bounds__(P2_NT, 2)
 k_tile_p2(const DevProblem P, const int2 *__restrict__ tiles, const int *__restrict__ tile_cls, const DevKernel *__restrict__ kcls,
           const DevFormula *__restrict__ fcls, double *__restrict__ A, long long ldA, double *__restrict__ Dglob, int cell_begin,
           int cell_end, int acc_stride, int4 *__restrict__ worklist, unsigned *__restrict__ wl_count, unsigned wl_cap, int flags,
-          int ntiles, unsigned *__restrict__ tile_ctr, int nUe) {
+          int ntiles, unsigned *__restrict__ tile_ctr, int nUe, const SlotOut SO) {
     using S = P2Smem;
     constexpr int TILE = S::TILE, NV = 3, NC = 6, DPE = 6, ND = 21, NT = P2_NT, PAIRS = S::PAIRS, PER_THREAD = PAIRS/NT, ST = S::ST;
     constexpr int NA = 3, NB = 6, NWAVES = NT/64, NR = S::NR, MAXLAB = S::MAXLAB;
@@ -599,7 +713,7 @@ k_tile_p2(const DevProblem P, const int2 *__restrict__ tiles, const int *__restr
     const int ta = tiles[tile_idx].x, tb = tiles[tile_idx].y;
     const int nA = P.blk_ndof[ta], nB = P.blk_ndof[tb];
     // order class of this tile entry (variable order: kernel, order formula, work-list region of the class; bit 0: orientation)
-    const int tcls = tile_cls ? tile_cls[tile_idx] : (P.cur_class >= 0 ? 2*P.cur_class+P.orient : -1);
+    const int tcls = tile_cls ? (tile_cls[tile_idx] & 0xffff) : (P.cur_class >= 0 ? 2*P.cur_class+P.orient : -1);
     DevKernel kk = P.k;
     DevFormula qo = P.qo;
     if (tile_cls) { kk = kcls[tcls >> 1]; qo = fcls[tcls >> 1]; }
@@ -835,6 +949,28 @@ k_tile_p2(const DevProblem P, const int2 *__restrict__ tiles, const int *__restr
     }
     for (int t = tid; t < 2*(PNL_MAXQ+2)+6; t += NT) s_cnt[t] = 0;           // s_cnt, s_cur and s_misc[0..5] are adjacent
     const int *__restrict__ dA = s_dof+(buf*2+0)*nUe, *__restrict__ dB = s_dof+(buf*2+1)*nUe;
+    if (SO.A2) {
+        // block-slot storage: plain 16-byte stores of the whole sub-block; a tile that is visited once per order class
+        // (bit 30 of its class word) adds instead, its sub-block has been zeroed
+        const int ca = SO.colbase[ta], W = SO.S-ca;
+        double *__restrict__ base = SO.A2+SO.rowoff[ta]+(SO.colbase[tb]-ca);
+        const bool multi = tile_cls && (tile_cls[tile_idx] & (1 << 30));
+#pragma unroll 1
+        for (int r = wv; r < nA; r += NWAVES) {
+            double *__restrict__ row = base+(long long)r*W;
+            for (int cc = 2*lane; cc < nB; cc += 128) {
+                double2 v;
+                v.x = s_acc[r*acc_stride+cc]; v.y = s_acc[r*acc_stride+cc+1];
+                s_acc[r*acc_stride+cc] = 0.; s_acc[r*acc_stride+cc+1] = 0.;
+                if (cc+1 >= nB) v.y = 0.;
+                if (!multi) *(double2*)(row+cc) = v;
+                else {
+                    if (v.x != 0.) atomic_add_f64(row+cc, v.x);
+                    if (v.y != 0.) atomic_add_f64(row+cc+1, v.y);
+                }
+            }
+        }
+    } else
 #pragma unroll 1
     for (int r = wv; r < nA; r += NWAVES) {
         double *__restrict__ row = A+(long long)__builtin_amdgcn_readfirstlane(dA[r])*ldA;

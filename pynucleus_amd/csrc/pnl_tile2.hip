@@ -7,7 +7,7 @@ namespace {
 
 template <int DPE, int NP, int KT>
 int launch_uniform_t(pnl_context *ctx, const DevProblem &Pt, const int2 *tiles, const int *tile_cls, int ntiles, int q, double *A,
-                     int64_t ldA, double *Dglob) {
+                     int64_t ldA, double *Dglob, const SlotOut &SO) {
     constexpr int TILE = DPE == 6 ? 32 : 64;
     const int nUe = (ctx->nU+1) & ~1;                     // even: the sub-block follows the int arrays at an 8-byte boundary
     const size_t fixed = uniform_fixed_lds(DPE, NP, TILE, nUe);
@@ -32,22 +32,22 @@ int launch_uniform_t(pnl_context *ctx, const DevProblem &Pt, const int2 *tiles, 
 #endif
     hipLaunchKernelGGL(kfun, dim3(grid), dim3(256), lds, ctx->stream, Pt, tiles, tile_cls, (const DevKernel*)ctx->b_kcls.p, ntiles, A,
                        (long long)ldA, Dglob, acc_stride, q, (ctx->symflush ? 1 : 0) | uni_abl, (const double*)ctx->b_uni.p+ctx->uni_off[q],
-                       nUe);
+                       nUe, SO);
     HIPCHK(ctx, hipGetLastError());
     return PNL_OK;
 }
 
 template <int DPE, int NP>
 int launch_uniform_kt(pnl_context *ctx, int kt, const DevProblem &Pt, const int2 *tiles, const int *tile_cls, int ntiles, int q,
-                      double *A, int64_t ldA, double *Dglob) {
-    if (kt == 2) return launch_uniform_t<DPE, NP, 2>(ctx, Pt, tiles, tile_cls, ntiles, q, A, ldA, Dglob);
-    if (kt == 1) return launch_uniform_t<DPE, NP, 1>(ctx, Pt, tiles, tile_cls, ntiles, q, A, ldA, Dglob);
-    return launch_uniform_t<DPE, NP, 0>(ctx, Pt, tiles, tile_cls, ntiles, q, A, ldA, Dglob);
+                      double *A, int64_t ldA, double *Dglob, const SlotOut &SO) {
+    if (kt == 2) return launch_uniform_t<DPE, NP, 2>(ctx, Pt, tiles, tile_cls, ntiles, q, A, ldA, Dglob, SO);
+    if (kt == 1) return launch_uniform_t<DPE, NP, 1>(ctx, Pt, tiles, tile_cls, ntiles, q, A, ldA, Dglob, SO);
+    return launch_uniform_t<DPE, NP, 0>(ctx, Pt, tiles, tile_cls, ntiles, q, A, ldA, Dglob, SO);
 }
 
 template <int KT>
 int launch_p2_t(pnl_context *ctx, const int2 *tiles, const int *tile_cls, int ntiles, double *A, int64_t ldA, int cell_begin,
-                int cell_end, unsigned wl_cap_each) {
+                int cell_end, unsigned wl_cap_each, const SlotOut &SO) {
     using S = P2Smem;
     const int nUe = (ctx->nU+1) & ~1;
     // one workgroup per CU: rows of the sub-block start in different LDS banks (stride = 1 mod 32 doubles) if that fits
@@ -66,7 +66,7 @@ int launch_p2_t(pnl_context *ctx, const int2 *tiles, const int *tile_cls, int nt
     hipLaunchKernelGGL(kfun, dim3(grid), dim3(P2_NT), lds, ctx->stream, ctx->P, tiles, tile_cls, (const DevKernel*)ctx->b_kcls.p,
                        (const DevFormula*)ctx->b_fcls.p, A, (long long)ldA, (double*)ctx->b_D.p, cell_begin, cell_end, stride,
                        (int4*)ctx->b_wl.p, (unsigned*)ctx->b_wlcount.p, wl_cap_each, ctx->symflush ? 256 : 0, ntiles,
-                       (unsigned*)ctx->b_tilectr.p, nUe);
+                       (unsigned*)ctx->b_tilectr.p, nUe, SO);
     HIPCHK(ctx, hipGetLastError());
     return PNL_OK;
 }
@@ -75,20 +75,36 @@ int launch_p2_t(pnl_context *ctx, const int2 *tiles, const int *tile_cls, int nt
 
 // uniform tiles of one order; Pt / Dglob: the cell tables (and diagonal-block buffer) the tile kernels use
 int pnl2_launch_uniform(pnl_context *ctx, int kt, const DevProblem &Pt, const int2 *tiles, const int *tile_cls, int ntiles, int q,
-                        double *A, int64_t ldA, double *Dglob) {
+                        double *A, int64_t ldA, double *Dglob, const SlotOut &SO) {
     if (ntiles <= 0) return PNL_OK;
     if (q < 2 || q > 4 || ctx->uni_off[q] < 0) return fail(ctx, PNL_ERR_STATE, "no uniform-tile rule for order %d", q);
     const int np = ctx->uni_np[q];
-    if (ctx->dpe == 6 && np == 3) return launch_uniform_kt<6, 3>(ctx, kt, Pt, tiles, tile_cls, ntiles, q, A, ldA, Dglob);
-    if (ctx->dpe == 6 && np == 6) return launch_uniform_kt<6, 6>(ctx, kt, Pt, tiles, tile_cls, ntiles, q, A, ldA, Dglob);
-    if (ctx->dpe == 3 && np == 6) return launch_uniform_kt<3, 6>(ctx, kt, Pt, tiles, tile_cls, ntiles, q, A, ldA, Dglob);
+    if (ctx->dpe == 6 && np == 3) return launch_uniform_kt<6, 3>(ctx, kt, Pt, tiles, tile_cls, ntiles, q, A, ldA, Dglob, SO);
+    if (ctx->dpe == 6 && np == 6) return launch_uniform_kt<6, 6>(ctx, kt, Pt, tiles, tile_cls, ntiles, q, A, ldA, Dglob, SO);
+    if (ctx->dpe == 3 && np == 6) return launch_uniform_kt<3, 6>(ctx, kt, Pt, tiles, tile_cls, ntiles, q, A, ldA, Dglob, SO);
     return fail(ctx, PNL_ERR_UNSUPPORTED, "uniform tiles: dpe=%d with %d points", ctx->dpe, np);
 }
 
 int pnl2_launch_p2(pnl_context *ctx, int kt, const int2 *tiles, const int *tile_cls, int ntiles, double *A, int64_t ldA,
-                   int cell_begin, int cell_end, unsigned wl_cap_each) {
+                   int cell_begin, int cell_end, unsigned wl_cap_each, const SlotOut &SO) {
     if (ntiles <= 0) return PNL_OK;
-    if (kt == 2) return launch_p2_t<2>(ctx, tiles, tile_cls, ntiles, A, ldA, cell_begin, cell_end, wl_cap_each);
-    if (kt == 1) return launch_p2_t<1>(ctx, tiles, tile_cls, ntiles, A, ldA, cell_begin, cell_end, wl_cap_each);
-    return launch_p2_t<0>(ctx, tiles, tile_cls, ntiles, A, ldA, cell_begin, cell_end, wl_cap_each);
+    if (kt == 2) return launch_p2_t<2>(ctx, tiles, tile_cls, ntiles, A, ldA, cell_begin, cell_end, wl_cap_each, SO);
+    if (kt == 1) return launch_p2_t<1>(ctx, tiles, tile_cls, ntiles, A, ldA, cell_begin, cell_end, wl_cap_each, SO);
+    return launch_p2_t<0>(ctx, tiles, tile_cls, ntiles, A, ldA, cell_begin, cell_end, wl_cap_each, SO);
+}
+
+int pnl2_zero_slot_tiles(pnl_context *ctx, const SlotOut &SO) {
+    if (ctx->n_multitiles <= 0) return PNL_OK;
+    hipLaunchKernelGGL(k_zero_slot_tiles, dim3(ctx->n_multitiles), dim3(256), 0, ctx->stream, SO, (const int2*)ctx->b_multitiles.p,
+                       (const int*)ctx->b_blk_ndof.p);
+    HIPCHK(ctx, hipGetLastError());
+    return PNL_OK;
+}
+
+int pnl2_fold_mirror(pnl_context *ctx, const SlotOut &SO, double *A, int64_t ldA) {
+    const long long nb = (ctx->N+31)/32;
+    hipLaunchKernelGGL(k_fold_mirror, dim3((unsigned)(nb*(nb+1)/2)), dim3(256), 0, ctx->stream, (const double*)SO.A2, (const int*)ctx->b_cpoff.p,
+                       (const int2*)ctx->b_cpslot.p, (const long long*)ctx->b_cprow.p, A, (long long)ldA, ctx->N);
+    HIPCHK(ctx, hipGetLastError());
+    return PNL_OK;
 }
