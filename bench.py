@@ -40,6 +40,190 @@ def algorithmic_flops(orders, npoints, dpe=3):
     return total
 
 
+def flops_from_counters(cnt, dpe):
+    """SURVEY.md 8(d) summed over what was integrated: every kernel evaluation costs (F_gamma + 12) + 3 E flops, every
+    assembled pair E more (F_gamma = 7 with F_pow counted as 1, E = (2 dpe)(2 dpe + 1)/2 local entries)."""
+    E = (2*dpe)*(2*dpe+1)//2
+    return cnt['numIntegrations']*(19+3*E)+E*cnt['numAssembledCellPairs']
+
+
+def cpu_baseline(args, T, N, nc, gpu_value):
+    """The reference runs one MPI rank per core over cellNo1 ranges (NA:1280-1285), single-threaded inside a rank.
+    (i) one core, (ii) all host cores with one worker per core over cell ranges of the same workload (count-only at this
+    size: N x N doubles do not fit the sample's budget), (iii) one core WITH the N x N scatter (NA:204-253) on the noRef 6
+    member of the same family, whose 1.2 GB block fits."""
+    import numpy as np
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle.oracle import OracleProblem
+    O = OracleProblem(T)
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        pass
+    try:                                                     # cgroup CPU quota (the GPU box grants a share of its host cores)
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()
+        if quota != 'max':
+            cores = max(1, min(cores, int(float(quota)/float(period)+0.5)))
+    except (OSError, ValueError):
+        pass
+    cores = min(cores, int(os.environ.get('PNL_BENCH_CPU_WORKERS', '64')))
+    per_pair = 1.1e-6
+    # (i) one core: rows of cells around nc/2, about a third of the CPU budget
+    k1 = max(1, min(nc//2, int(args.cpu_seconds/3./per_pair/(nc/2))))
+    ca, cb = nc//2, nc//2+k1
+    _, c1, secs = O.get_dense(ca, cb, store=False)
+    t1 = secs[0]+secs[1]
+    one = c1['numAssembledCellPairs']/t1
+    # (ii) all cores: every worker its own range of cell rows (ctypes releases the GIL; the oracle has no shared state)
+    kk = max(1, min((nc-cb)//cores, int(args.cpu_seconds/3./per_pair/(nc/2))))
+    ranges = [(cb+i*kk, cb+(i+1)*kk) for i in range(cores)]
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(cores) as ex:
+        res = list(ex.map(lambda r: O.get_dense(r[0], r[1], store=False), ranges))
+    tall = time.perf_counter()-t0
+    pairs_all = sum(r[1]['numAssembledCellPairs'] for r in res)
+    allc = pairs_all/tall
+    out = dict(value=allc, unit='element-pairs/s', cores=cores, kind='port',
+               sample='oracle/nl_oracle.c (C restatement of the reference loop, gcc -O3): {} workers, one per host core (nproc = {}), '
+                      'each over its own cellNo1 range of {} cell rows x all partners c2 >= c1 of the same workload, {} pairs incl. '
+                      'their share of the boundary term in {:.1f} s wall (count-only: no N x N scatter target at this size)'.format(
+                          cores, cores, kk, pairs_all, tall),
+               seconds=tall, speedup_gpu_over_cpu=gpu_value/allc,
+               one_core=dict(value=one, cores=1, sample='cell rows [{}, {}) x all partners, {} pairs in {:.1f} s (count-only)'.format(
+                   ca, cb, c1['numAssembledCellPairs'], t1), speedup_gpu_over_cpu=gpu_value/one))
+    # (iii) the scatter-included rate on a size whose block fits on the host
+    try:
+        from pynucleus_amd import disc, P1_DoFMap, PHYSICAL, getFractionalKernel
+        from pynucleus_amd.local_matrix import nonlocalTables
+        mesh6 = disc(6)
+        dm6 = P1_DoFMap(mesh6, PHYSICAL)
+        T6 = nonlocalTables(dm6, getFractionalKernel(2, args.s), {'target_order': 0.5}, True)
+        O6 = OracleProblem(T6)
+        nc6 = mesh6.num_cells
+        k6 = max(1, min(nc6//2, int(args.cpu_seconds/3./per_pair/(nc6/2))))
+        _, c6, s6 = O6.get_dense(nc6//2, nc6//2+k6, store=True)
+        t6 = s6[0]+s6[1]
+        out['one_core_storing'] = dict(value=c6['numAssembledCellPairs']/t6, cores=1,
+                                       sample='noRef 6 (N = {}, 1.2 GB block on the host), cell rows [{}, {}) x all partners with the '
+                                              'N x N scatter (addToMatrixElemElemSym), {} pairs in {:.1f} s'.format(
+                                                  dm6.num_dofs, nc6//2, nc6//2+k6, c6['numAssembledCellPairs'], t6))
+    except MemoryError as e:                                 # small hosts: the storing sample is optional
+        out['one_core_storing'] = dict(error=repr(e))
+    return out
+
+
+def extra_configs(dev):
+    """Short legs of the other BASELINE.json configurations on one GPU: device time from the library's HIP events on its
+    stream, wall time around the builder call, pairs/s and the SURVEY 8(d) fraction of the vector fp64 peak."""
+    import numpy as np
+    import torch
+    from pynucleus_amd import (disc, uniformSquare, P1_DoFMap, P2_DoFMap, PHYSICAL, NO_BOUNDARY, getFractionalKernel, getKernel,
+                               INDICATOR)
+    from pynucleus_amd.builder import nonlocalBuilder
+    from pynucleus_amd.fractionalOrders import layersFractionalOrder
+    res = {}
+
+    def sync():
+        torch.cuda.synchronize(dev)
+
+    def dense_leg(name, dm, kernel, dpe, reps=3):
+        b = nonlocalBuilder(dm, kernel, {'target_order': 0.5}, zeroExterior=True)
+        ms, wall, cnt = [], [], None
+        for rep in range(reps+1):                            # the first call carries the uploads and tile lists
+            sync(); t0 = time.perf_counter()
+            A = b.getDense()
+            sync(); t1 = time.perf_counter()
+            cnt = A.info['counters']
+            last_ms = A.info['phase_ms']
+            if rep:
+                ms.append(A.info['phase_ms']['total']); wall.append(t1-t0)
+            first = t1-t0 if rep == 0 else first
+            del A
+        dev_s, pairs = 1e-3*float(np.mean(ms)), cnt['numAssembledCellPairs']
+        fl = flops_from_counters(cnt, dpe)
+        res[name] = dict(num_dofs=dm.num_dofs, num_cells=dm.mesh.num_cells, element_pairs=pairs, device_ms=1e3*dev_s,
+                         wall_ms=1e3*float(np.mean(wall)), first_call_ms=1e3*first, pairs_per_s=pairs/dev_s,
+                         algorithmic_tflops=fl/dev_s/1e12, frac_fp64_peak=fl/dev_s/1e12/FP64_VECTOR_PEAK_TFLOPS,
+                         phases_ms={k: round(v, 3) for k, v in last_ms.items()},
+                         kernel_ms={k: round(v, 3) for k, v in b.context().kernel_ms().items()})
+        del b
+        torch.cuda.empty_cache()
+
+    legs = []
+    # C5: P2, variable order (3 layers), dense, noRef 6
+    def c5():
+        mesh = disc(6)
+        dm = P2_DoFMap(mesh, PHYSICAL)
+        orders = np.array([[0.3, 0.4, 0.5], [0.4, 0.5, 0.6], [0.5, 0.6, 0.7]])
+        dense_leg('C5_P2_layers_dense_noRef6', dm, getFractionalKernel(2, layersFractionalOrder(2, np.array([-1., -0.3, 0.3, 1.]), orders)), 6)
+    # P2, constant order s = 1/2 (the kernel VERDICT r01 asked to raise)
+    def p2():
+        mesh = disc(6)
+        dense_leg('P2_const_dense_noRef6', P2_DoFMap(mesh, PHYSICAL), getFractionalKernel(2, 0.5), 6)
+    # C3: square 129^2, constant kernel, delta = 0.1, getSparse
+    def c3():
+        mesh = uniformSquare(129)
+        dm = P1_DoFMap(mesh, NO_BOUNDARY)
+        b = nonlocalBuilder(dm, getKernel(2, kernel=INDICATOR, horizon=0.1), {}, zeroExterior=False)
+        out = []
+        for rep in range(3):
+            sync(); t0 = time.perf_counter()
+            A = b.getSparse()
+            sync(); t1 = time.perf_counter()
+            out.append((t1-t0, A.info['interior_ms'], A.info['counters'], A.nnz))
+            del A
+        c = out[-1][2]
+        dev_s = 1e-3*out[-1][1]
+        fl = flops_from_counters(c, 3)
+        res['C3_square129_constant_delta0.1_getSparse'] = dict(
+            num_dofs=dm.num_dofs, num_cells=mesh.num_cells, element_pairs=c['numAssembledCellPairs'], kernel_evaluations=c['numIntegrations'],
+            nnz=out[-1][3], device_ms=out[-1][1], wall_ms=1e3*out[-1][0], first_call_ms=1e3*out[0][0],
+            pairs_per_s=c['numAssembledCellPairs']/dev_s, algorithmic_tflops=fl/dev_s/1e12, frac_fp64_peak=fl/dev_s/1e12/FP64_VECTOR_PEAK_TFLOPS)
+    # C4: disc noRef 7, s = 0.75, H2: near field + far-field setup end to end, matvec
+    def c4():
+        mesh = disc(7)
+        dm = P1_DoFMap(mesh, PHYSICAL)
+        b = nonlocalBuilder(dm, getFractionalKernel(2, 0.75), {'target_order': 0.5, 'eta': 3.}, zeroExterior=True)
+        walls = []
+        for rep in range(2):
+            sync(); t0 = time.perf_counter()
+            h2 = b.getH2()
+            sync(); walls.append(time.perf_counter()-t0)
+        near = h2.Anear
+        c = near.info.get('counters', {})
+        x = torch.randn(dm.num_dofs, dtype=torch.float64, device=dev)
+        for _ in range(3):
+            y = h2.matvec(x)
+        sync(); t0 = time.perf_counter()
+        for _ in range(20):
+            y = h2.matvec(x)
+        sync()
+        mv = (time.perf_counter()-t0)/20
+        r = dict(num_dofs=dm.num_dofs, num_cells=mesh.num_cells, getH2_first_ms=1e3*walls[0], getH2_ms=1e3*walls[-1], matvec_ms=1e3*mv,
+                 dense_matvec_hbm_floor_ms=1e3*8.*dm.num_dofs**2/(HBM_PEAK_GBS*1e9))
+        if c:
+            dev_s = 1e-3*near.info['interior_ms']
+            fl = flops_from_counters(c, 3)
+            r.update(near_field_element_pairs=c['numAssembledCellPairs'], near_field_device_ms=near.info['interior_ms'],
+                     near_field_nnz=near.nnz, pairs_per_s=c['numAssembledCellPairs']/dev_s, algorithmic_tflops=fl/dev_s/1e12,
+                     frac_fp64_peak=fl/dev_s/1e12/FP64_VECTOR_PEAK_TFLOPS)
+        res['C4_disc_noRef7_s0.75_H2'] = r
+    # the north star's "~10^5 DoFs on 1 MI355X": 12-sector fan refined 7 times, P1, dense (76 GB block)
+    def big():
+        mesh = disc(7, sectors=12)
+        dense_leg('dense_97537dofs_P1_s0.5', P1_DoFMap(mesh, PHYSICAL), getFractionalKernel(2, 0.5), 3, reps=2)
+    for name, leg in (('P2', p2), ('C5', c5), ('C3', c3), ('C4', c4), ('dense_1e5', big)):
+        t0 = time.perf_counter()
+        try:
+            leg()
+        except Exception as e:                               # a failing leg must not take the headline line with it
+            res[name+'_error'] = repr(e)
+        res.setdefault('leg_seconds', {})[name] = round(time.perf_counter()-t0, 2)
+        torch.cuda.empty_cache()
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -51,6 +235,7 @@ def main():
     ap.add_argument('--cpu-seconds', type=float, default=15., help='target CPU time of the oracle sample (rank 0, N=1 only)')
     ap.add_argument('--no-cpu', action='store_true')
     ap.add_argument('--solve', action='store_true', help='also run the CG-Jacobi solve of configs[1] (reported, not timed into value)')
+    ap.add_argument('--no-extra', action='store_true', help='skip the short legs of the other BASELINE.json configurations (N=1 only)')
     args = ap.parse_args()
 
     import numpy as np
@@ -110,7 +295,7 @@ def main():
     for _ in range(args.warmup):
         step()
     sync()
-    tile_ms, pure_ms, wl_ms, phase_acc = [], [], [], {}
+    phase_acc = {}
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -119,16 +304,17 @@ def main():
     # phases of the last step from HIP events recorded on the stream the kernels ran on
     ms = ctx.phase_ms()
     cnt = ctx.counters()
-    # a few extra (untimed) steps to average the dominant kernel's duration from its own HIP events
+    # a few extra (untimed) steps to average every tile kernel's duration from its own HIP events (recorded by the library
+    # on the stream the kernels run on)
+    kacc = {}
     for _ in range(3):
         step()
         torch.cuda.synchronize(dev)
         m = ctx.phase_ms()
-        tile_ms.append(m['tiles'])
-        pure_ms.append(m['tiles_uniform'])
-        wl_ms.append(m['worklist'])
         for k, v in m.items():
             phase_acc[k] = phase_acc.get(k, 0.)+v/3.
+        for k, v in ctx.kernel_ms().items():
+            kacc[k] = kacc.get(k, 0.)+v/3.
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -141,41 +327,47 @@ def main():
     value = pairs_total*args.steps/elapsed
 
     # ---- roofline of the dominant kernel: algorithmic flops / its own event-timed duration --------------------------
-    # Distant pairs of the orders packed into the tile rule table (<= 16 points) are integrated by two kernels:
-    # k_tile_pure (tiles whose 4096 pairs are all of order 2) and k_tile_distant (all other tiles).  The counters tell
-    # how many order-2 pairs the uniform-tile kernel took; the rest of the histogram belongs to k_tile_distant.
+    # Distant pairs of the orders packed into the tile rule table (<= 16 points) are integrated by the tile kernels: the
+    # uniform-tile kernels (tiles whose pairs are all of order 2: k_tile_pure; all of order 3 / 4: k_tile_uniform) and the
+    # general one (k_tile_distant: every other tile).  The counters tell how many pairs of each order the uniform kernels
+    # took; the rest of the histogram belongs to the general kernel.
     T = builder.tables
     tile_orders = {q: c for q, c in cnt['orders'].items() if T.num_points(q) <= 16 and q < 18}
-    pure_pairs = cnt.get('uniformTilePairs', 0)
-    mixed_orders = dict(tile_orders)
-    mixed_orders[2] = mixed_orders.get(2, 0)-pure_pairs
-    flops_mixed = algorithmic_flops(mixed_orders, T.num_points)
-    flops_pure = algorithmic_flops({2: pure_pairs}, T.num_points)
-    mixed_s = 1e-3*float(np.mean(tile_ms))
-    pure_s = 1e-3*float(np.mean(pure_ms))
-    dominant = 'k_tile_distant' if mixed_s >= pure_s else 'k_tile_pure'
-    dom_flops, dom_s = (flops_mixed, mixed_s) if dominant == 'k_tile_distant' else (flops_pure, pure_s)
+    uni = cnt.get('uniformTilePairsByOrder', {})
+    mixed_orders = {q: c-uni.get(q, 0) for q, c in tile_orders.items()}
+    kernels = {'k_tile_distant': (algorithmic_flops(mixed_orders, T.num_points), 1e-3*kacc.get('tile_general', 0.)),
+               'k_tile_pure': (algorithmic_flops({2: uni.get(2, 0)}, T.num_points), 1e-3*kacc.get('tile_uniform2', 0.)),
+               'k_tile_uniform<3,6> (order 3)': (algorithmic_flops({3: uni.get(3, 0)}, T.num_points), 1e-3*kacc.get('tile_uniform3', 0.)),
+               'k_tile_uniform<3,6> (order 4)': (algorithmic_flops({4: uni.get(4, 0)}, T.num_points), 1e-3*kacc.get('tile_uniform4', 0.))}
+    dominant = max(kernels, key=lambda k: kernels[k][1])
+    dom_flops, dom_s = kernels[dominant]
     achieved = dom_flops/dom_s/1e12 if dom_s > 0 else 0.
-    traffic = None
+    both_s = sum(v[1] for v in kernels.values())
+    all_flops = sum(v[0] for v in kernels.values())
+    # HBM traffic of the dominant kernel: PMC counters cannot be read inside this process; tools/pmc_traffic.sh runs this
+    # command under rocprofv3 --pmc (separate passes) and records the library build it measured.  The number is used only
+    # if it belongs to the library and the workload of this run, never a stale constant.
+    traffic, traffic_note = None, 'no PMC record (tools/pmc_traffic.sh) for this library build and workload'
     pmc_fn = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
-    if os.path.exists(pmc_fn):
+    if os.path.exists(pmc_fn) and world == 1:
+        import hashlib
+        from pynucleus_amd import _lib as _l
+        with open(_l.LIB_PATH, 'rb') as f:
+            lib_sha = hashlib.sha256(f.read()).hexdigest()[:16]
         with open(pmc_fn) as f:
             rec = json.load(f)
-        key = 'noRef{}'.format(args.noRef)
-        if key in rec and world == 1 and args.sectors == 6:
-            traffic = rec[key].get(dominant+'_hbm_bytes_per_launch')
+        key = 'noRef{}{}'.format(args.noRef, '' if args.sectors == 6 else '_s{}'.format(args.sectors))
+        if key in rec and rec[key].get('lib_sha16') == lib_sha:
+            traffic = rec[key].get(dominant.split('<')[0].split(' ')[0]+'_hbm_bytes_per_launch')
+            traffic_note = 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command ({}), FETCH_SIZE doubled per MI355X_MICROARCH.md'.format(rec[key].get('tag'))
     # HBM view of the same launches: the algorithmic minimum is one write of the upper block triangle they fill
     hbm_alg_bytes = 8.*N*N/2
-    both_s = mixed_s+pure_s
     roofline = dict(bound='fp64_valu', kernel=dominant, achieved=achieved, peak=FP64_VECTOR_PEAK_TFLOPS, unit='TFLOP/s',
-                    frac=achieved/FP64_VECTOR_PEAK_TFLOPS, traffic=traffic, algorithmic_flops_per_launch=dom_flops,
+                    frac=achieved/FP64_VECTOR_PEAK_TFLOPS, traffic=traffic, traffic_note=traffic_note, algorithmic_flops_per_launch=dom_flops,
                     kernel_ms=1e3*dom_s,
-                    other_tile_kernel=dict(kernel='k_tile_pure' if dominant == 'k_tile_distant' else 'k_tile_distant',
-                                           algorithmic_flops_per_launch=flops_pure if dominant == 'k_tile_distant' else flops_mixed,
-                                           kernel_ms=1e3*(pure_s if dominant == 'k_tile_distant' else mixed_s),
-                                           achieved=((flops_pure/pure_s) if dominant == 'k_tile_distant' else (flops_mixed/mixed_s))/1e12
-                                           if min(pure_s, mixed_s) > 0 else 0.),
-                    tile_phase_achieved=(flops_mixed+flops_pure)/both_s/1e12 if both_s > 0 else 0.,
+                    tile_kernels={k: dict(algorithmic_flops_per_launch=v[0], kernel_ms=1e3*v[1],
+                                          achieved=v[0]/v[1]/1e12 if v[1] > 0 else 0.) for k, v in kernels.items()},
+                    tile_phase_achieved=all_flops/both_s/1e12 if both_s > 0 else 0.,
                     hbm_algorithmic_GBs=hbm_alg_bytes/both_s/1e9 if both_s > 0 else 0., hbm_peak_GBs=HBM_PEAK_GBS)
 
     out = dict(metric='element-pairs/sec assembled (2D P1 fractional s=0.5, dense) + % fp64 roofline', value=value,
@@ -188,25 +380,16 @@ def main():
                phases_ms={k: round(v, 4) for k, v in phase_acc.items()},
                kernel_evaluations_per_step=cnt['numIntegrations'] if world == 1 else None)
 
-    # ---- CPU baseline: the C oracle (single thread, reference loop order) on a bounded sample of the same workload ----
+    # ---- CPU baseline: the C oracle (reference loop order) on bounded samples of the same workload -------------------
     if rank == 0 and world == 1 and not args.no_cpu:
-        from oracle.oracle import OracleProblem
-        O = OracleProblem(T)
-        store = N*N*8 <= 4e9
-        # rows of cells around nc/2: about cpu_seconds of work at ~1.1 us per pair
-        want_pairs = args.cpu_seconds/1.1e-6
-        k = max(1, min(nc//2, int(want_pairs/(nc/2))))
-        ca, cb = nc//2, nc//2+k
-        _, ccnt, secs = O.get_dense(ca, cb, store=store)
-        cpu_pairs = ccnt['numAssembledCellPairs']
-        cpu_t = secs[0]+secs[1]
-        out['cpu_baseline'] = dict(value=cpu_pairs/cpu_t, unit='element-pairs/s', cores=1, kind='port',
-                                   sample='oracle/nl_oracle.c (C restatement of the reference loop, gcc -O3, 1 thread) on cell rows '
-                                          '[{}, {}) x all partners c2 >= c1 of the same workload: {} pairs incl. their share of the '
-                                          'boundary term in {:.1f} s{}'.format(ca, cb, cpu_pairs, cpu_t,
-                                                                               '' if store else ' (count-only: no N x N scatter target)'),
-                                   seconds=cpu_t, speedup_gpu_over_cpu=value/(cpu_pairs/cpu_t))
-    if args.solve and world == 1:
+        out['cpu_baseline'] = cpu_baseline(args, T, N, nc, value)
+    # ---- the other BASELINE.json configurations, each a short driver-timed leg (N = 1 only) ---------------------------
+    if rank == 0 and world == 1 and not args.no_extra:
+        del A
+        builder = ctx = None
+        torch.cuda.empty_cache()
+        out['configs'] = extra_configs(dev)
+    if args.solve and world == 1 and args.no_extra:
         from pynucleus_amd.linear_operators import Dense_LinearOperator
         op = Dense_LinearOperator(A, ctx)
         b = torch.from_numpy(np.asarray(dm.assembleRHS(1.0))).to(dev)

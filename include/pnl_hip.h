@@ -79,9 +79,10 @@ enum pnl_counter {
     PNL_C_ORDER_OVERFLOW,              /* pairs whose order exceeded the tables (error)  */
     PNL_C_UNIFORM_TILE_PAIRS,          /* pairs integrated by the uniform-tile kernel (subset of assembled) */
     PNL_C_RESERVED7,
-    PNL_C_HIST0 = 8                    /* [8+q]: distant pairs of order q, q < 120; [128..130]: vertex/edge/face */
+    PNL_C_HIST0 = 8,                   /* [8+q]: distant pairs of order q, q < 120; [128..130]: vertex/edge/face */
+    PNL_C_UNIFORM_Q2 = 131             /* [131..133]: pairs integrated by the uniform-tile kernels of order 2, 3, 4 */
 };
-#define PNL_NUM_COUNTERS 131
+#define PNL_NUM_COUNTERS 134
 
 /* ---- lifetime ---------------------------------------------------------------- */
 int pnl_create(int device_id, pnl_context **ctx);
@@ -266,6 +267,12 @@ int pnl_get_counters(pnl_context *ctx, int64_t *out, int n);
  * [0] general tile kernel (distant pairs, one per lane), [1] work-list kernels (high orders),
  * [2] singular pairs, [3] boundary term, [4] mirror + diagonal scatter, [5] total, [6] uniform-tile kernel */
 int pnl_get_phase_ms(pnl_context *ctx, float *out, int n);
+/* device time of the tile kernels of the last assemble call, one HIP-event pair around each launch (milliseconds, 0 if the
+ * kernel did not run; with several order classes the last launch of a slot): [0] general tile kernel, [1] uniform tiles of
+ * order 2, [2] order 3, [3] order 4, [4] fold + mirror of the block-slot storage, [5] work-list kernels */
+enum pnl_kernel_slot { PNL_K_TILE_GENERAL = 0, PNL_K_TILE_UNIFORM2, PNL_K_TILE_UNIFORM3, PNL_K_TILE_UNIFORM4, PNL_K_FOLD_MIRROR,
+                       PNL_K_WORKLIST, PNL_NUM_KERNEL_SLOTS };
+int pnl_get_kernel_ms(pnl_context *ctx, float *out, int n);
 
 /* ---- adjacent solve path: Dense_LinearOperator.matvec (dgemv, DenseLinearOperator_{SCALAR}.pxi:14-18)
  *      and cg_solver + jacobi (base/PyNucleus_base/solvers.pyx:363-444, 229-245) ------------------- */

@@ -21,13 +21,13 @@ PNL_INTERIOR = 0
 PNL_BOUNDARY = 1
 PNL_FLAG_NO_MIRROR = 1
 PNL_FLAG_SYMMETRIC_FLUSH = 2
-PNL_NUM_COUNTERS = 131
+PNL_NUM_COUNTERS = 134
 
 # every symbol include/pnl_hip.h declares (checked by tests/test_abi.py)
 EXPORTS = ['pnl_create', 'pnl_destroy', 'pnl_error_string', 'pnl_version', 'pnl_set_stream', 'pnl_synchronize',
            'pnl_upload_mesh', 'pnl_upload_dofmap', 'pnl_set_kernel', 'pnl_set_order_formula', 'pnl_upload_distant_rules',
            'pnl_upload_singular_rule', 'pnl_upload_boundary', 'pnl_assemble_dense', 'pnl_tile_cells',
-           'pnl_assemble_dense_tiles', 'pnl_get_counters', 'pnl_get_phase_ms', 'pnl_gemv', 'pnl_cg_jacobi',
+           'pnl_assemble_dense_tiles', 'pnl_get_counters', 'pnl_get_phase_ms', 'pnl_get_kernel_ms', 'pnl_gemv', 'pnl_cg_jacobi',
            'pnl_inv_diagonal', 'pnl_set_classes', 'pnl_select_class', 'pnl_upload_sparsity', 'pnl_assemble_pairs_masked', 'pnl_assemble_boundary_masked', 'pnl_assemble_clusters_tiled', 'pnl_h2_setup', 'pnl_h2_matvec', 'pnl_spmv',
            'pnl_assemble_pairs_in_horizon', 'pnl_set_nonsymmetric', 'pnl_set_order_function', 'pnl_upload_pointwise_rules', 'pnl_assemble_dense_pointwise']
 
@@ -99,6 +99,7 @@ def load():
     L.pnl_assemble_dense_tiles.argtypes = [vp, vp, i64, i32, i32, vp, i32, i32, i32]
     L.pnl_get_counters.argtypes = [vp, vp, i32]
     L.pnl_get_phase_ms.argtypes = [vp, vp, i32]
+    L.pnl_get_kernel_ms.argtypes = [vp, vp, i32]
     L.pnl_gemv.argtypes = [vp, vp, i64, i32, vp, vp, i32]
     L.pnl_cg_jacobi.argtypes = [vp, vp, i64, i32, vp, vp, dbl, i32, C.POINTER(C.c_int), C.POINTER(C.c_double)]
     L.pnl_inv_diagonal.argtypes = [vp, vp, i64, i32, vp]
@@ -342,13 +343,20 @@ class Context:
         sing = {-1-k: int(out[128+k]) for k in range(3)}
         return dict(numCellPairs=int(out[0]), numAssembledCellPairs=int(out[1]), numIntegrations=int(out[2]),
                     numBoundaryPairs=int(out[3]), numBoundaryIntegrations=int(out[4]), orders=hist, singular=sing,
-                    uniformTilePairs=int(out[6]))
+                    uniformTilePairs=int(out[6]), uniformTilePairsByOrder={2+k: int(out[131+k]) for k in range(3)})
 
     def phase_ms(self):
         out = np.zeros(7, dtype=np.float32)
         self.check(self.L.pnl_get_phase_ms(self.h, out.ctypes.data, 7))
         return dict(tiles=float(out[0]), tiles_uniform=float(out[6]), worklist=float(out[1]), singular=float(out[2]),
                     boundary=float(out[3]), scatter_mirror=float(out[4]), total=float(out[5]))
+
+    def kernel_ms(self):
+        """device time of each tile-kernel launch of the last assembly (HIP events on the library's stream)"""
+        out = np.zeros(6, dtype=np.float32)
+        self.check(self.L.pnl_get_kernel_ms(self.h, out.ctypes.data, 6))
+        return dict(tile_general=float(out[0]), tile_uniform2=float(out[1]), tile_uniform3=float(out[2]), tile_uniform4=float(out[3]),
+                    fold_mirror=float(out[4]), worklist=float(out[5]))
 
     def gemv(self, A_ptr, ldA, n, x_ptr, y_ptr, symmetric_half=False):
         self.check(self.L.pnl_gemv(self.h, C.c_void_p(A_ptr), int(ldA), int(n), C.c_void_p(x_ptr), C.c_void_p(y_ptr),

@@ -174,6 +174,9 @@ class nonlocalBuilder:
         separate and all-reduces the N-vector in matvec instead."""
         import torch
         from .linear_operators import Dense_LinearOperator, DistributedDense_LinearOperator
+        if trySparsification:
+            # NA:1287-1348, 1451-1469 (cluster-based compression of the dense loop) is not built: refuse instead of ignoring
+            raise NotImplementedError('getDense(trySparsification=True) is not implemented; use getSparse / getH2')
         if self.kernel.finiteHorizon:
             # the reference's all-pairs loop visits every pair and ignores the REMOTE ones; the same matrix is obtained from
             # the pairs within the horizon (getSparse), stored densely

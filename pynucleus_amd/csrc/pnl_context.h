@@ -109,6 +109,8 @@ struct pnl_context {
     struct BlockAgg { double cx, cy, rad, hmax, hmin, Lmin, Lmax; bool full; };
     std::vector<BlockAgg> blocks;
     hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t kev[PNL_NUM_KERNEL_SLOTS][2] = {};   // event pair around every tile-kernel launch (pnl_get_kernel_ms)
+    bool kev_set[PNL_NUM_KERNEL_SLOTS] = {};
     bool pure_launched = false;
     bool symflush = false;          // PNL_FLAG_SYMMETRIC_FLUSH of the current assembly
     bool ev_valid = false;
@@ -208,6 +210,9 @@ inline DevProblem tile_problem(const pnl_context *ctx) {
     return Pt;
 }
 
+
+inline void kt_begin(pnl_context *ctx, int slot) { (void)hipEventRecord(ctx->kev[slot][0], ctx->stream); }
+inline void kt_end(pnl_context *ctx, int slot) { (void)hipEventRecord(ctx->kev[slot][1], ctx->stream); ctx->kev_set[slot] = true; }
 
 // pnl_tile2.hip
 int pnl2_launch_uniform(pnl_context *ctx, int kt, const DevProblem &Pt, const int2 *tiles, const int *tile_cls, int ntiles, int q,

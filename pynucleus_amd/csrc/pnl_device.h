@@ -5,7 +5,7 @@
 
 #define PNL_NTHREADS 256
 #define PNL_MAXQ 120            // nonlocalOperator.pyx:107 MAX_PANEL
-#define PNL_NCOUNTERS 131
+#define PNL_NCOUNTERS 134
 #define PNL_WL_SLOTS 256          // work-list fill counters: one per order class / class pass of an assembly
 
 struct DevKernel {

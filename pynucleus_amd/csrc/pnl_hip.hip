@@ -401,9 +401,11 @@ int launch_pure(pnl_context *ctx, double *A, int64_t ldA) {
 #ifdef PNL_DEBUG_ABLATE
     pure_abl = getenv("PNL_PURE_ABL") ? atoi(getenv("PNL_PURE_ABL")) : 0;
 #endif
+    kt_begin(ctx, PNL_K_TILE_UNIFORM2);
     hipLaunchKernelGGL(kfun, dim3(grid), dim3(PNL_NTHREADS), lds, ctx->stream, tile_problem(ctx), (const int2*)ctx->b_tiles.p+ctx->tile_off+ctx->n_mixed,
                        ctx->n_pure, A, (long long)ldA, (double*)(ctx->have_tile_order ? ctx->b_Dt.p : ctx->b_D.p), acc_stride, 2,
                        (ctx->symflush ? 1 : 0) | pure_abl);
+    kt_end(ctx, PNL_K_TILE_UNIFORM2);
     HIPCHK(ctx, hipGetLastError());
     return PNL_OK;
 }
@@ -497,11 +499,13 @@ int launch_tiles(pnl_context *ctx, int wl_slot, double *A, int64_t ldA, int cell
     (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)kfun, tile_threads(DPE, KT), lds);
     const int grid_mult = getenv("PNL_GRID_MULT") ? atoi(getenv("PNL_GRID_MULT")) : 1;
     const int grid = std::min(ntiles, 256*std::max(per_cu, 1)*std::max(grid_mult, 1));
+    kt_begin(ctx, PNL_K_TILE_GENERAL);
     if (grid > 0)
         hipLaunchKernelGGL(kfun, dim3(grid), dim3(tile_threads(DPE, KT)), lds, ctx->stream, tile_problem(ctx), (const int2*)ctx->b_tiles.p+ctx->tile_off, A,
                            (long long)ldA, (double*)(ctx->have_tile_order ? ctx->b_Dt.p : ctx->b_D.p), cell_begin, cell_end, acc_stride, (int4*)ctx->b_wl.p,
                            wlc, ctx->wl_cap_each, ctx->ablate | (ctx->symflush ? 256 : 0), ntiles, ClusterTiles{},
                            (unsigned*)ctx->b_tilectr.p);
+    kt_end(ctx, PNL_K_TILE_GENERAL);
     HIPCHK(ctx, hipGetLastError());
     HIPCHK(ctx, hipEventRecord(ctx->ev[6], ctx->stream));
     return run_worklist<DIM, DPE, KT>(ctx, (const int4*)ctx->b_wl.p, wlc, ctx->wl_cap_each, A, ldA, ctx->symflush);
@@ -652,6 +656,7 @@ int assemble_impl(pnl_context *ctx, double *A, int64_t ldA, int zero_exterior, i
     int rc;
     const int ncls = (int)ctx->cls.size();
     ctx->symflush = (flags & PNL_FLAG_SYMMETRIC_FLUSH) != 0;
+    for (bool &b : ctx->kev_set) b = false;
     HIPCHK(ctx, hipMemsetAsync(ctx->b_counters.p, 0, sizeof(unsigned long long)*PNL_NCOUNTERS, ctx->stream));
     HIPCHK(ctx, hipMemsetAsync(ctx->b_D.p, 0, sizeof(double)*(size_t)ctx->ncp*(DPE*(DPE+1)/2), ctx->stream));
     if (ctx->have_tile_order) HIPCHK(ctx, hipMemsetAsync(ctx->b_Dt.p, 0, sizeof(double)*(size_t)ctx->ncp*(DPE*(DPE+1)/2), ctx->stream));
@@ -1399,6 +1404,9 @@ int pnl_create(int device_id, pnl_context **out) {
     ctx->stream = ctx->own_stream;
     for (auto &e : ctx->ev)
         if (hipEventCreate(&e) != hipSuccess) { delete ctx; return PNL_ERR_HIP; }
+    for (auto &pr : ctx->kev)
+        for (auto &e : pr)
+            if (hipEventCreate(&e) != hipSuccess) { delete ctx; return PNL_ERR_HIP; }
     std::memset(&ctx->P, 0, sizeof(ctx->P));
 #ifdef PNL_DEBUG_ABLATE
     if (const char *e = getenv("PNL_ABLATE")) ctx->ablate = atoi(e);      // result-changing debug switches: debug builds only
@@ -1416,6 +1424,9 @@ void pnl_destroy(pnl_context *ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     for (auto &e : ctx->ev)
         if (e) (void)hipEventDestroy(e);
+    for (auto &pr : ctx->kev)
+        for (auto &e : pr)
+            if (e) (void)hipEventDestroy(e);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     for (auto *c : ctx->cls) delete c;
     delete ctx;
@@ -2323,6 +2334,17 @@ int pnl_get_phase_ms(pnl_context *ctx, float *out, int n) {
     t[4] += tmp;
     HIPCHK(ctx, hipEventElapsedTime(&t[5], ctx->ev[0], ctx->ev[5]));
     for (int i = 0; i < n && i < 7; i++) out[i] = t[i];
+    return PNL_OK;
+}
+
+int pnl_get_kernel_ms(pnl_context *ctx, float *out, int n) {
+    if (!ctx || !out || n <= 0) return PNL_ERR_INVALID;
+    if (!ctx->ev_valid) return fail(ctx, PNL_ERR_STATE, "nothing assembled yet");
+    HIPCHK(ctx, hipEventSynchronize(ctx->ev[5]));
+    for (int s = 0; s < n && s < PNL_NUM_KERNEL_SLOTS; s++) {
+        out[s] = 0.f;
+        if (ctx->kev_set[s]) HIPCHK(ctx, hipEventElapsedTime(&out[s], ctx->kev[s][0], ctx->kev[s][1]));
+    }
     return PNL_OK;
 }
 

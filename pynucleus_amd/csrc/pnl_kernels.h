@@ -1118,7 +1118,8 @@ k_tile_pure(const DevProblem P, const int2 *__restrict__ tiles, int ntiles, doub
         atomicAdd(&P.counters[8+q_uniform], npairs);
         atomicAdd(&P.counters[1], npairs);
         atomicAdd(&P.counters[2], npairs*(unsigned long long)(NP*NP));
-        atomicAdd(&P.counters[6], npairs);               // pairs integrated by this kernel (reporting)
+        atomicAdd(&P.counters[6], npairs);               // pairs integrated by the uniform-tile kernels (reporting)
+        if (q_uniform >= 2 && q_uniform <= 4) atomicAdd(&P.counters[131+q_uniform-2], npairs);
     }
 }
 

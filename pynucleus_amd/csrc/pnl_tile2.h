@@ -400,6 +400,7 @@ k_tile_uniform(const DevProblem P, const int2 *__restrict__ tiles, const int *__
         atomicAdd(&P.counters[1], npairs);
         atomicAdd(&P.counters[2], npairs*(unsigned long long)(NP*NP));
         atomicAdd(&P.counters[6], npairs);
+        atomicAdd(&P.counters[131+q_uniform-2], npairs);
     }
 }
 

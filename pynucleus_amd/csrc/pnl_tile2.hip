@@ -30,9 +30,11 @@ int launch_uniform_t(pnl_context *ctx, const DevProblem &Pt, const int2 *tiles, 
 #ifdef PNL_DEBUG_ABLATE
     uni_abl = getenv("PNL_UNI_ABL") ? atoi(getenv("PNL_UNI_ABL")) : 0;
 #endif
+    kt_begin(ctx, PNL_K_TILE_UNIFORM2+(q-2));
     hipLaunchKernelGGL(kfun, dim3(grid), dim3(256), lds, ctx->stream, Pt, tiles, tile_cls, (const DevKernel*)ctx->b_kcls.p, ntiles, A,
                        (long long)ldA, Dglob, acc_stride, q, (ctx->symflush ? 1 : 0) | uni_abl, (const double*)ctx->b_uni.p+ctx->uni_off[q],
                        nUe, SO);
+    kt_end(ctx, PNL_K_TILE_UNIFORM2+(q-2));
     HIPCHK(ctx, hipGetLastError());
     return PNL_OK;
 }
@@ -63,10 +65,12 @@ int launch_p2_t(pnl_context *ctx, const int2 *tiles, const int *tile_cls, int nt
     // two tiles per workgroup are taken by block index, the rest through tickets: a grid of at most ntiles / 2 workgroups
     const int grid = std::max(1, std::min((ntiles+1)/2, 256));
     if (getenv("PNL_VERBOSE")) fprintf(stderr, "[pnl] P2 general tiles=%d nU=%d kt=%d lds=%zu bytes acc_stride=%d\n", ntiles, ctx->nU, KT, lds, stride);
+    kt_begin(ctx, PNL_K_TILE_GENERAL);
     hipLaunchKernelGGL(kfun, dim3(grid), dim3(P2_NT), lds, ctx->stream, ctx->P, tiles, tile_cls, (const DevKernel*)ctx->b_kcls.p,
                        (const DevFormula*)ctx->b_fcls.p, A, (long long)ldA, (double*)ctx->b_D.p, cell_begin, cell_end, stride,
                        (int4*)ctx->b_wl.p, (unsigned*)ctx->b_wlcount.p, wl_cap_each, ctx->symflush ? 256 : 0, ntiles,
                        (unsigned*)ctx->b_tilectr.p, nUe, SO);
+    kt_end(ctx, PNL_K_TILE_GENERAL);
     HIPCHK(ctx, hipGetLastError());
     return PNL_OK;
 }
@@ -103,8 +107,10 @@ int pnl2_zero_slot_tiles(pnl_context *ctx, const SlotOut &SO) {
 
 int pnl2_fold_mirror(pnl_context *ctx, const SlotOut &SO, double *A, int64_t ldA) {
     const long long nb = (ctx->N+31)/32;
+    kt_begin(ctx, PNL_K_FOLD_MIRROR);
     hipLaunchKernelGGL(k_fold_mirror, dim3((unsigned)(nb*(nb+1)/2)), dim3(256), 0, ctx->stream, (const double*)SO.A2, (const int*)ctx->b_cpoff.p,
                        (const int2*)ctx->b_cpslot.p, (const long long*)ctx->b_cprow.p, A, (long long)ldA, ctx->N);
+    kt_end(ctx, PNL_K_FOLD_MIRROR);
     HIPCHK(ctx, hipGetLastError());
     return PNL_OK;
 }

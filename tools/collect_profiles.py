@@ -29,7 +29,7 @@ def short(name):
 
 
 summary = collections.defaultdict(dict)
-for d in ('pmc_fetch', 'pmc_write', 'pmc_tcc'):
+for d in ('pmc_fetch', 'pmc_write', 'pmc_tcc', 'pmc_sq'):
     for fn in glob.glob(os.path.join(src, d, '*', '*counter_collection.csv')):
         agg = collections.defaultdict(lambda: collections.defaultdict(float))
         calls = collections.defaultdict(set)
@@ -53,8 +53,11 @@ rec['comment'] = ('HBM traffic per launch of the tile kernels from rocprofv3 --p
                   'FETCH_SIZE and WRITE_SIZE in separate passes (KB units x 1024).  FETCH_SIZE doubled per MI355X_MICROARCH.md '
                   '(gfx950 reports half of wide coalesced reads); WRITE_SIZE is dominated by 8-byte fp64 atomics.  '
                   'Raw values: profiles/<tag>_pmc_summary_noRef<N>.json.')
-entry = {'tag': tag}
-for k in ('k_tile_distant', 'k_tile_pure'):
+import hashlib
+with open(os.path.join(root, 'pynucleus_amd', 'libpnl_hip.so'), 'rb') as f:
+    lib_sha = hashlib.sha256(f.read()).hexdigest()[:16]
+entry = {'tag': tag, 'lib_sha16': lib_sha}
+for k in ('k_tile_distant', 'k_tile_pure', 'k_tile_uniform', 'k_tile_p2', 'k_fold_mirror'):
     if k in summary and 'FETCH_SIZE' in summary[k] and 'WRITE_SIZE' in summary[k]:
         entry[k+'_hbm_bytes_per_launch'] = int(1024*(2*summary[k]['FETCH_SIZE']+summary[k]['WRITE_SIZE']))
         entry[k+'_fetch_size_kb'] = summary[k]['FETCH_SIZE']
