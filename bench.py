@@ -10,9 +10,10 @@ uniform_disc refined --noRef times.  configs[1]'s "~2x10^4 DoFs" lies between no
 (48 769 DoFs, 98 304 cells, 4.83e9 pairs); the default is noRef 7, the largest refinement whose dense N x N block (19 GB) fits
 one MI355X (noRef 8 needs 307 GB) and the size at which the 1/2/4/8-GPU runs are not dominated by per-rank fixed costs.
 
-N > 1 (python -m torch.distributed.run ... bench.py --gpus N): the element pairs of the SAME problem are
-dealt over the ranks (strong scaling, no collective in the assembly path; every rank holds its partial
-N x N block, the operator is their sum and its matvec all-reduces an N-vector over RCCL).
+N > 1 (python -m torch.distributed.run ... bench.py --gpus N): the block rows of the upper block triangle of the SAME
+problem are dealt over the ranks by work (strong scaling, no collective in the assembly path); every rank holds the one-sided
+slab of its rows, about N^2 / (2 N_gpus) doubles, the operator is DistributedSlab_LinearOperator and its matvec all-reduces
+an N-vector over RCCL.
 
 Prints ONE JSON line on rank 0.
 """
@@ -243,7 +244,6 @@ def main():
     import torch.distributed as dist
     from pynucleus_amd import disc, P1_DoFMap, PHYSICAL, getFractionalKernel
     from pynucleus_amd.builder import nonlocalBuilder
-    from pynucleus_amd._lib import PNL_FLAG_SYMMETRIC_FLUSH
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
@@ -254,6 +254,9 @@ def main():
     backend = os.environ.get('PNL_BENCH_BACKEND', 'nccl')
     if backend != 'nccl':
         local_rank = 0
+    elif torch.cuda.device_count() < world:
+        raise SystemExit('bench.py --gpus {}: only {} GPU(s) visible (PNL_BENCH_BACKEND=gloo rehearses the N > 1 path on one GPU)'.format(
+            world, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     red_dev = dev if backend == 'nccl' else torch.device('cpu')
@@ -271,20 +274,23 @@ def main():
     builder = nonlocalBuilder(dm, kernel, {'target_order': 0.5}, zeroExterior=True, comm=(True if world > 1 else None))
     ctx = builder.context()
     N, nc = dm.num_dofs, mesh.num_cells
-    A = torch.zeros((N, N), dtype=torch.float64, device=dev)
-    if world > 1:
-        tiles = builder.tiles_for_rank(rank, world)
-        from pynucleus_amd.builder import cell_range_of_rank
-        c0, c1 = cell_range_of_rank(nc, rank, world)
+    if world == 1:
+        A = torch.zeros((N, N), dtype=torch.float64, device=dev)
+    else:
+        # row-owned storage (DistributedSlab_LinearOperator): this rank's one-sided slab of its block rows, ~N^2 / (2 P)
+        # doubles, and its partial per-cell diagonal blocks; the tiles are dealt by block rows of equal work; no N x N
+        # array and no collective in the assembly (the matvec all-reduces an N-vector)
+        from pynucleus_amd.builder import row_slab_of_rank, tile_cells
+        c0, c1, tiles, rows, cols = row_slab_of_rank(builder.dm, tile_cells(builder.dm.dofs_per_element, 2), rank, world)
+        A = torch.zeros((max(rows.shape[0], 1), max(cols.shape[0], 1)), dtype=torch.float64, device=dev)
+        ctx.set_row_slab(rows, cols)
 
     def step():
         A.zero_()
         if world == 1:
             ctx.assemble_dense(A.data_ptr(), A.stride(0), True, 0, nc)
-        else:
-            # N > 1: cross contributions are written on both sides by the flush (its work is shared by the ranks) instead
-            # of the N^2 mirror pass (which is not)
-            ctx.assemble_dense_tiles(A.data_ptr(), A.stride(0), True, tiles, c0, c1, flags=PNL_FLAG_SYMMETRIC_FLUSH)
+        elif rows.shape[0]:
+            ctx.assemble_dense_tiles(A.data_ptr(), A.stride(0), True, tiles, c0, c1)
 
     def sync():
         torch.cuda.synchronize(dev)
@@ -375,7 +381,7 @@ def main():
                higher_is_better=True, scaling='strong', vs_baseline=None, dtype='f64', data='synthetic',
                config=dict(workload='2D unit disc ({}uniform_disc refined {}x, {} cells), P1, {} DoFs, fractional s={}, horizon=inf, '
                            'dense getDense incl. zeroExterior; {} element pairs/step'.format('' if args.sectors == 6 else '{}-sector '.format(args.sectors), args.noRef, nc, N, args.s, int(pairs_total)),
-                           noRef=args.noRef, num_dofs=N, num_cells=nc, parallelism='pairs dealt over {} GPU(s)'.format(world)),
+                           noRef=args.noRef, num_dofs=N, num_cells=nc, parallelism='block rows of the upper triangle dealt over {} GPU(s), row-owned one-sided slabs'.format(world)),
                roofline=roofline,
                phases_ms={k: round(v, 4) for k, v in phase_acc.items()},
                kernel_evaluations_per_step=cnt['numIntegrations'] if world == 1 else None)

@@ -274,6 +274,23 @@ enum pnl_kernel_slot { PNL_K_TILE_GENERAL = 0, PNL_K_TILE_UNIFORM2, PNL_K_TILE_U
                        PNL_K_WORKLIST, PNL_NUM_KERNEL_SLOTS };
 int pnl_get_kernel_ms(pnl_context *ctx, float *out, int n);
 
+/* ---- row slab of a rank: distributed dense operator (the reference's DistributedH2Matrix_globalData.matvec,
+ *      clusterMethodCy.pyx:3127-3154, on a row partition, tree_node.partition :1854-1896) ------------------------------
+ * After pnl_set_row_slab the dense assemble calls write ONE-SIDED into a slab of nrows x ncols doubles (leading dimension
+ * ldA >= ncols): row r holds global DoF rowdofs[r], column j global DoF coldofs[j] (both increasing); cross blocks at (c1's
+ * DoF, c2's DoF) for c1 < c2, the symmetric local matrices of touching pairs once at (min, max); no mirror pass; the
+ * per-cell diagonal blocks stay in the per-cell buffer (pnl_get_diag_blocks: 2 x ncp x ND doubles, the rank's partial
+ * sums over ALL cells).  The rows must contain every DoF of the cells in the caller's cell range and of the cells touching
+ * them, the columns every DoF of the cells from cell_begin on.  The rank's part of the operator is
+ * A' + A'^T - diag(A') + scatter(D); pnl_slab_matvec applies it (y is overwritten; the caller all-reduces y over the
+ * ranks).  nrows = 0 restores the full N x N output. */
+int pnl_set_row_slab(pnl_context *ctx, int nrows, const int32_t *rowdofs_host, int ncols, const int32_t *coldofs_host);
+int pnl_diag_blocks_size(pnl_context *ctx);
+int pnl_get_diag_blocks(pnl_context *ctx, double *dst_dev);
+int pnl_slab_matvec(pnl_context *ctx, const double *slab_dev, int64_t ld, const double *diag_blocks_dev, const double *x_dev,
+                    double *y_dev);
+int pnl_slab_diagonal(pnl_context *ctx, const double *slab_dev, int64_t ld, const double *diag_blocks_dev, double *diag_dev);
+
 /* ---- adjacent solve path: Dense_LinearOperator.matvec (dgemv, DenseLinearOperator_{SCALAR}.pxi:14-18)
  *      and cg_solver + jacobi (base/PyNucleus_base/solvers.pyx:363-444, 229-245) ------------------- */
 /* y = A x (n x n, row-major, leading dimension ldA); symmetric_half: y = (A + A^T) x for PNL_FLAG_NO_MIRROR storage */

@@ -27,7 +27,7 @@ PNL_NUM_COUNTERS = 134
 EXPORTS = ['pnl_create', 'pnl_destroy', 'pnl_error_string', 'pnl_version', 'pnl_set_stream', 'pnl_synchronize',
            'pnl_upload_mesh', 'pnl_upload_dofmap', 'pnl_set_kernel', 'pnl_set_order_formula', 'pnl_upload_distant_rules',
            'pnl_upload_singular_rule', 'pnl_upload_boundary', 'pnl_assemble_dense', 'pnl_tile_cells',
-           'pnl_assemble_dense_tiles', 'pnl_get_counters', 'pnl_get_phase_ms', 'pnl_get_kernel_ms', 'pnl_gemv', 'pnl_cg_jacobi',
+           'pnl_assemble_dense_tiles', 'pnl_get_counters', 'pnl_get_phase_ms', 'pnl_get_kernel_ms', 'pnl_set_row_slab', 'pnl_diag_blocks_size', 'pnl_get_diag_blocks', 'pnl_slab_matvec', 'pnl_slab_diagonal', 'pnl_gemv', 'pnl_cg_jacobi',
            'pnl_inv_diagonal', 'pnl_set_classes', 'pnl_select_class', 'pnl_upload_sparsity', 'pnl_assemble_pairs_masked', 'pnl_assemble_boundary_masked', 'pnl_assemble_clusters_tiled', 'pnl_h2_setup', 'pnl_h2_matvec', 'pnl_spmv',
            'pnl_assemble_pairs_in_horizon', 'pnl_set_nonsymmetric', 'pnl_set_order_function', 'pnl_upload_pointwise_rules', 'pnl_assemble_dense_pointwise']
 
@@ -100,6 +100,11 @@ def load():
     L.pnl_get_counters.argtypes = [vp, vp, i32]
     L.pnl_get_phase_ms.argtypes = [vp, vp, i32]
     L.pnl_get_kernel_ms.argtypes = [vp, vp, i32]
+    L.pnl_set_row_slab.argtypes = [vp, i32, vp, i32, vp]
+    L.pnl_diag_blocks_size.argtypes = [vp]
+    L.pnl_get_diag_blocks.argtypes = [vp, vp]
+    L.pnl_slab_matvec.argtypes = [vp, vp, i64, vp, vp, vp]
+    L.pnl_slab_diagonal.argtypes = [vp, vp, i64, vp, vp]
     L.pnl_gemv.argtypes = [vp, vp, i64, i32, vp, vp, i32]
     L.pnl_cg_jacobi.argtypes = [vp, vp, i64, i32, vp, vp, dbl, i32, C.POINTER(C.c_int), C.POINTER(C.c_double)]
     L.pnl_inv_diagonal.argtypes = [vp, vp, i64, i32, vp]
@@ -350,6 +355,26 @@ class Context:
         self.check(self.L.pnl_get_phase_ms(self.h, out.ctypes.data, 7))
         return dict(tiles=float(out[0]), tiles_uniform=float(out[6]), worklist=float(out[1]), singular=float(out[2]),
                     boundary=float(out[3]), scatter_mirror=float(out[4]), total=float(out[5]))
+
+    def set_row_slab(self, rowdofs, coldofs):
+        rd = np.ascontiguousarray(rowdofs, dtype=np.int32)
+        cd = np.ascontiguousarray(coldofs, dtype=np.int32)
+        self.check(self.L.pnl_set_row_slab(self.h, int(rd.shape[0]), rd.ctypes.data if rd.shape[0] else None, int(cd.shape[0]),
+                                           cd.ctypes.data if cd.shape[0] else None))
+
+    def diag_blocks_size(self):
+        n = self.L.pnl_diag_blocks_size(self.h)
+        self.check(min(n, 0))
+        return n
+
+    def get_diag_blocks(self, dst_ptr):
+        self.check(self.L.pnl_get_diag_blocks(self.h, C.c_void_p(dst_ptr)))
+
+    def slab_matvec(self, slab_ptr, ld, dblocks_ptr, x_ptr, y_ptr):
+        self.check(self.L.pnl_slab_matvec(self.h, C.c_void_p(slab_ptr), int(ld), C.c_void_p(dblocks_ptr), C.c_void_p(x_ptr), C.c_void_p(y_ptr)))
+
+    def slab_diagonal(self, slab_ptr, ld, dblocks_ptr, diag_ptr):
+        self.check(self.L.pnl_slab_diagonal(self.h, C.c_void_p(slab_ptr), int(ld), C.c_void_p(dblocks_ptr), C.c_void_p(diag_ptr)))
 
     def kernel_ms(self):
         """device time of each tile-kernel launch of the last assembly (HIP events on the library's stream)"""

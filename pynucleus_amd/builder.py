@@ -45,6 +45,41 @@ def cell_range_of_rank(num_cells, rank, size):
     return int(np.ceil(num_cells*rank/size)), int(np.ceil(num_cells*(rank+1)/size))
 
 
+def block_rows_of_rank(num_blocks, rank, size):
+    """contiguous range [a0, a1) of cell blocks owned by `rank`: block row a of the upper block triangle holds
+    num_blocks - a tiles, the ranges hold equal numbers of tiles (tree_node.partition, clusterMethodCy.pyx:1854-1896, hangs
+    one subtree per rank under the root; here the rows of the dense block are dealt by work)"""
+    cut = lambda k: int(round(num_blocks*(1.-np.sqrt(max(0., 1.-k/float(size))))))
+    a0, a1 = cut(rank), (num_blocks if rank == size-1 else cut(rank+1))
+    return min(a0, num_blocks), min(max(a1, a0), num_blocks)
+
+
+def row_slab_of_rank(dm, T, rank, size):
+    """(cell_begin, cell_end, tiles, row DoFs, column DoFs) of the rank's one-sided row slab (include/pnl_hip.h,
+    pnl_set_row_slab): rows = DoFs of its cells and of the cells touching them, columns = DoFs of its cells and of all
+    later cells (+ the rows)."""
+    mesh = dm.mesh
+    nc = mesh.num_cells
+    nb = (nc+T-1)//T
+    a0, a1 = block_rows_of_rank(nb, rank, size)
+    c0, c1 = min(a0*T, nc), min(a1*T, nc)
+    tiles = np.array([(a, b) for a in range(a0, a1) for b in range(a, nb)], dtype=np.int32).reshape(-1, 2)
+    dofs = np.asarray(dm.dofs)
+    cells = np.asarray(mesh.cells)
+    if c1 <= c0:
+        return c0, c1, tiles, np.zeros(0, dtype=np.int32), np.zeros(0, dtype=np.int32)
+    mine = np.zeros(nc, dtype=bool)
+    mine[c0:c1] = True
+    vert = np.zeros(mesh.num_vertices, dtype=bool)
+    vert[cells[c0:c1].ravel()] = True
+    touching = vert[cells].any(axis=1) | mine
+    rows = np.unique(dofs[touching].ravel())
+    rows = rows[rows >= 0].astype(np.int32)
+    cols = np.unique(np.concatenate([dofs[c0:].ravel(), rows]))
+    cols = cols[cols >= 0].astype(np.int32)
+    return c0, c1, tiles, rows, cols
+
+
 def block_dof_count(dofs, T):
     """largest number of distinct DoFs of T consecutive cells: the side of the LDS sub-block a tile accumulates into"""
     nc = dofs.shape[0]
@@ -185,6 +220,9 @@ class nonlocalBuilder:
             A = torch.from_numpy(S.toarray()).to(torch.device('cuda', ctx.device))
             return Dense_LinearOperator(A, ctx, S.info)
         ctx = self.context()
+        if getattr(ctx, '_slab_owner', None) is not None:
+            ctx.set_row_slab(np.zeros(0, dtype=np.int32), np.zeros(0, dtype=np.int32))   # a row slab of an earlier distributed operator
+            ctx._slab_owner = None
         dev = torch.device('cuda', ctx.device)
         N = self.dm.num_dofs
         nc = self.mesh.num_cells
@@ -199,6 +237,12 @@ class nonlocalBuilder:
             ctx.assemble_dense_pointwise(A.data_ptr(), A.stride(0), self.zeroExterior, start, end)
         elif size == 1:
             ctx.assemble_dense(A.data_ptr(), A.stride(0), self.zeroExterior, 0, nc)
+        elif distributed:
+            # row-owned storage: this rank's one-sided slab + its partial per-cell diagonal blocks, no N x N array anywhere
+            del A
+            from .linear_operators import DistributedSlab_LinearOperator
+            group = None if self.comm is True else self.comm
+            return DistributedSlab_LinearOperator.assemble(self, rank, size, group)
         else:
             tiles = self.tiles_for_rank(rank, size)
             start, end = cell_range_of_rank(nc, rank, size)

@@ -70,6 +70,10 @@ struct pnl_context {
     DevBuf b_scolbase, b_srowoff, b_cpoff, b_cpslot, b_cprow, b_multitiles, b_slotA;
     int slot_S = 0, n_multitiles = 0;
     long long slot_total = 0;         // doubles
+    // row slab of a rank (pnl_set_row_slab, pnl_slab.hip)
+    DevBuf b_rowmap, b_rowdof, b_colmap, b_coldof;
+    std::vector<int32_t> slab_rowdofs, slab_coldofs;
+    int slab_rows = 0, slab_cols = 0;
     bool slot_full_list = false;      // the current tile list is the whole upper block triangle (pnl_assemble_dense)
     bool slot_used = false;           // the tile kernels of the current assembly wrote the block-slot storage
     std::vector<DevKernel> kcls_host;

@@ -75,7 +75,16 @@ struct DevProblem {
     int orient, pad2;
     double idfac;
     unsigned long long *counters;
+    // row slab of a rank (pnl_set_row_slab): row / column of the output that holds global DoF I, or -1 (nullptr: I); onesided:
+    // symmetric contributions are written once, at (min, max), the operator is A' + A'^T - diag(A')
+    const int *rowmap, *colmap;
+    int onesided, pad3;
 };
+
+// row of the dense output that global DoF I is stored in (identity without a row slab); -1: not stored by this rank
+__device__ __forceinline__ long long pnl_row(const DevProblem &P, int I) { return P.rowmap ? (long long)P.rowmap[I] : (long long)I; }
+// ... and the column of global DoF J (the columns of a rank's slab are the DoFs of its cells and of all later cells)
+__device__ __forceinline__ int pnl_col(const DevProblem &P, int J) { return P.colmap ? P.colmap[J] : J; }
 
 // H2 far field (clusterMethodCy.pyx; kernels in pnl_kernels.h)
 struct H2Dev {

@@ -674,7 +674,7 @@ int assemble_impl(pnl_context *ctx, double *A, int64_t ldA, int zero_exterior, i
         ctx->wl_slots = single ? ncls : ncls*norient;
         if constexpr (DIM == 2 && DPE == 6) {
             // the block-slot storage needs every tile of the upper block triangle written by this call, then the fold + mirror pass
-            const bool slot_ok = ctx->slot_full_list && cell_begin == 0 && cell_end == ctx->nc &&
+            const bool slot_ok = ctx->slot_full_list && ctx->slab_rows == 0 && cell_begin == 0 && cell_end == ctx->nc &&
                                  !(flags & (PNL_FLAG_NO_MIRROR | PNL_FLAG_SYMMETRIC_FLUSH));
             if ((rc = launch_tiles_single<DIM, DPE>(ctx, A, ldA, ctx->tile_cell_filter ? cell_begin : 0, ctx->tile_cell_filter ? cell_end : ctx->nc, slot_ok)))
                 { ctx->cur = 0; ctx->orient = 0; return rc; }
@@ -725,7 +725,7 @@ int assemble_impl(pnl_context *ctx, double *A, int64_t ldA, int zero_exterior, i
         }
     ctx->cur = 0;
     HIPCHK(ctx, hipEventRecord(ctx->ev[4], ctx->stream));
-    {
+    if (ctx->slab_rows == 0) {
         const long long nt = (long long)ctx->nc*DPE*DPE;
         hipLaunchKernelGGL((k_scatter_diag<DPE>), dim3((unsigned)((nt+PNL_NTHREADS-1)/PNL_NTHREADS)), dim3(PNL_NTHREADS), 0,
                            ctx->stream, ctx->P, (const double*)ctx->b_D.p, A, (long long)ldA);
@@ -1458,6 +1458,9 @@ static int check_overflow(pnl_context *ctx) {
         HIPCHK(ctx, hipMemcpy(&ov, (const unsigned long long*)ctx->b_counters.p+5, sizeof(ov), hipMemcpyDeviceToHost));
         if (ov) return fail(ctx, PNL_ERR_ORDER, "%llu pairs need a quadrature order beyond the uploaded tables (qmax=%d); the assembled "
                             "operator is incomplete", ov, ctx->qmax);
+        HIPCHK(ctx, hipMemcpy(&ov, (const unsigned long long*)ctx->b_counters.p+7, sizeof(ov), hipMemcpyDeviceToHost));
+        if (ov) return fail(ctx, PNL_ERR_STATE, "%llu entries of touching pairs have no row in the slab (pnl_set_row_slab needs the DoFs of the "
+                            "cells touching the rank's cells)", ov);
     }
     return PNL_OK;
 }
@@ -1812,13 +1815,36 @@ static int make_tiles(pnl_context *ctx, std::vector<int2> &tiles, int cell_begin
     return PNL_OK;
 }
 
+// A row slab (pnl_set_row_slab) is written one-sided: no mirror pass, no scatter of the per-cell diagonal blocks (they stay
+// in the per-cell buffer, pnl_get_diag_blocks), columns are counted from col0.  The rows of every cell of the caller's cell
+// range must be in the slab.
+static int slab_prepare(pnl_context *ctx, double *&A, int &flags, int cell_begin, int cell_end) {
+    if (ctx->slab_rows <= 0) return PNL_OK;
+    if (flags & PNL_FLAG_SYMMETRIC_FLUSH) return fail(ctx, PNL_ERR_INVALID, "a row slab is one-sided: PNL_FLAG_SYMMETRIC_FLUSH does not apply");
+    if (ctx->have_pw) return fail(ctx, PNL_ERR_UNSUPPORTED, "row slabs are not implemented for kernels with an order per quadrature point");
+    const auto &rd = ctx->slab_rowdofs, &cd = ctx->slab_coldofs;
+    for (int c = cell_begin; c < ctx->nc; c++)
+        for (int k = 0; k < ctx->dpe; k++) {
+            const int g = ctx->dofs[(size_t)c*ctx->dpe+k];
+            if (g < 0) continue;
+            if (c < cell_end && !std::binary_search(rd.begin(), rd.end(), g))
+                return fail(ctx, PNL_ERR_INVALID, "DoF %d of cell %d is not a row of the slab", g, c);
+            if (!std::binary_search(cd.begin(), cd.end(), g))
+                return fail(ctx, PNL_ERR_INVALID, "DoF %d of cell %d is not a column of the slab", g, c);
+        }
+    flags |= PNL_FLAG_NO_MIRROR;
+    (void)A;
+    return PNL_OK;
+}
+
 int pnl_assemble_dense(pnl_context *ctx, double *A, int64_t ldA, int zero_exterior, int cell_begin, int cell_end, int flags) {
     if (!ctx) return PNL_ERR_INVALID;
     int rc;
     if ((rc = check_ready(ctx))) return rc;
     if ((rc = finalize(ctx))) return rc;
-    if (!A || ldA < ctx->N) return fail(ctx, PNL_ERR_INVALID, "bad output matrix (ldA=%lld, num_dofs=%d)", (long long)ldA, ctx->N);
+    if (!A || ldA < (ctx->slab_rows ? ctx->slab_cols : ctx->N)) return fail(ctx, PNL_ERR_INVALID, "bad output matrix (ldA=%lld, num_dofs=%d)", (long long)ldA, ctx->N);
     if (cell_begin < 0 || cell_end > ctx->nc || cell_begin > cell_end) return fail(ctx, PNL_ERR_INVALID, "bad cell range");
+    if ((rc = slab_prepare(ctx, A, flags, cell_begin, cell_end))) return rc;
     std::vector<int2> tiles;
     if (cell_end > cell_begin) make_tiles(ctx, tiles, cell_begin, cell_end);
     if ((rc = upload_tiles(ctx, tiles, cell_begin, cell_end))) return rc;
@@ -1837,8 +1863,9 @@ int pnl_assemble_dense_tiles(pnl_context *ctx, double *A, int64_t ldA, int zero_
     int rc;
     if ((rc = check_ready(ctx))) return rc;
     if ((rc = finalize(ctx))) return rc;
-    if (!A || ldA < ctx->N || ntiles < 0 || (ntiles && !tiles_host)) return fail(ctx, PNL_ERR_INVALID, "bad arguments");
+    if (!A || ldA < (ctx->slab_rows ? ctx->slab_cols : ctx->N) || ntiles < 0 || (ntiles && !tiles_host)) return fail(ctx, PNL_ERR_INVALID, "bad arguments");
     if (cell_begin < 0 || cell_end > ctx->nc || cell_begin > cell_end) return fail(ctx, PNL_ERR_INVALID, "bad cell range");
+    if ((rc = slab_prepare(ctx, A, flags, cell_begin, cell_end))) return rc;
     std::vector<int2> tiles(ntiles);
     for (int i = 0; i < ntiles; i++) {
         tiles[i] = make_int2(tiles_host[2*i], tiles_host[2*i+1]);

@@ -855,7 +855,7 @@ k_tile_distant(const DevProblem P, const int2 *__restrict__ tiles, double *__res
                 sparse_add(CT.S, dofA[r], dofB[c], v);
                 sparse_add(CT.S, dofB[c], dofA[r], v);
             } else {
-                atomic_add_f64(&A[(long long)dofA[r]*ldA+dofB[c]], v);
+                atomic_add_f64(&A[pnl_row(P, dofA[r])*ldA+pnl_col(P, dofB[c])], v);
             }
         }
     }
@@ -1095,7 +1095,7 @@ k_tile_pure(const DevProblem P, const int2 *__restrict__ tiles, int ntiles, doub
         for (int t = tid; t < nA*nB; t += PNL_NTHREADS) {
             const int r = t/nB, cc = t-r*nB;
             const double v = s_acc[r*acc_stride+cc];
-            if (v != 0.) atomic_add_f64(&A[(long long)dofA[r]*ldA+dofB[cc]], v);
+            if (v != 0.) atomic_add_f64(&A[pnl_row(P, dofA[r])*ldA+pnl_col(P, dofB[cc])], v);
         }
         // PNL_FLAG_SYMMETRIC_FLUSH (no mirror pass): the transposed image in its own sweep, consecutive threads along a row of A
         if (!(symflush & 64) && (symflush & 1))
@@ -2033,7 +2033,7 @@ k_worklist_sorted(const DevProblem P, const int4 *__restrict__ sorted, const uns
                     const int a = e/DPE, b = e-a*DPE;
                     const int I = P.cdof[(size_t)a*P.ncp+c1], J = P.cdof[(size_t)b*P.ncp+c2];
                     if (I >= 0 && J >= 0) {
-                        atomic_add_f64(&A[(long long)I*ldA+J], -vv*val);
+                        atomic_add_f64(&A[pnl_row(P, I)*ldA+pnl_col(P, J)], -vv*val);
                         if (symflush) atomic_add_f64(&A[(long long)J*ldA+I], -vv*val);
                     }
                 } else if (e < NG+ND) atomic_add_f64(&Dglob[(size_t)c1*ND+(e-NG)], vv*val);
@@ -2186,7 +2186,7 @@ k_worklist_lane(const DevProblem P, const int4 *__restrict__ sorted, const unsig
 #pragma unroll
                 for (int b = 0; b < DPE; b++)
                     if (ld1[a] >= 0 && ld2[b] >= 0 && !(dbg & 1)) {
-                        atomic_add_f64(&A[(long long)ld1[a]*ldA+ld2[b]], -vv*R.G[a][b]);
+                        atomic_add_f64(&A[pnl_row(P, ld1[a])*ldA+pnl_col(P, ld2[b])], -vv*R.G[a][b]);
                         if (dbg & 8) atomic_add_f64(&A[(long long)ld2[b]*ldA+ld1[a]], -vv*R.G[a][b]);      // symmetric flush
                     }
             if (!(dbg & 2))
@@ -2393,7 +2393,15 @@ k_singular_pairs(const DevProblem P, const int2 *__restrict__ pairs, int npairs_
             const int glo = (lo == pi) ? gi : gj, ghi = (lo == pi) ? gj : gi;
             sparse_add_sym(S, S.masks ? S.masks+4*(size_t)pidx : nullptr, 2*DPE, lo, hi, glo, ghi, v);
         } else if (gi >= 0 && gj >= 0) {
-            if (myI[rep] == myJ[rep]) atomic_add_f64(&A[(long long)gi*ldA+gi], v);
+            if (P.onesided) {
+                // row slab of a rank: every symmetric contribution once, at (min, max); rows that the slab does not hold are
+                // counted (counter 7) and fail the assembly
+                const int lo = min(gi, gj), hi = max(gi, gj);
+                const long long row = pnl_row(P, lo);
+                const int col = pnl_col(P, hi);
+                if (row >= 0 && col >= 0) atomic_add_f64(&A[row*ldA+col], v);
+                else atomicAdd(&P.counters[7], 1ull);
+            } else if (myI[rep] == myJ[rep]) atomic_add_f64(&A[(long long)gi*ldA+gi], v);
             else {
                 atomic_add_f64(&A[(long long)gi*ldA+gj], v);
                 atomic_add_f64(&A[(long long)gj*ldA+gi], v);

@@ -225,8 +225,8 @@ k_tile_uniform(const DevProblem P, const int2 *__restrict__ tiles, const int *__
         }
         const int *__restrict__ dofA = P.blk_dofs+(size_t)tl.x*P.blk_stride;
         const int *__restrict__ dofB = P.blk_dofs+(size_t)tl.y*P.blk_stride;
-        for (int k = tid; k < nA; k += NT) s_dof[(buf*2+0)*nUe+k] = dofA[k];
-        for (int k = tid; k < nB; k += NT) s_dof[(buf*2+1)*nUe+k] = dofB[k];
+        for (int k = tid; k < nA; k += NT) s_dof[(buf*2+0)*nUe+k] = P.rowmap ? P.rowmap[dofA[k]] : dofA[k];
+        for (int k = tid; k < nB; k += NT) s_dof[(buf*2+1)*nUe+k] = P.colmap ? P.colmap[dofB[k]] : dofB[k];
     };
 
     int tile_idx = blockIdx.x, buf = 0;
@@ -685,8 +685,8 @@ k_tile_p2(const DevProblem P, const int2 *__restrict__ tiles, const int *__restr
         }
         const int *__restrict__ dofA = P.blk_dofs+(size_t)ta*P.blk_stride;
         const int *__restrict__ dofB = P.blk_dofs+(size_t)tb*P.blk_stride;
-        for (int k = tid; k < nA; k += NT) s_dof[(buf*2+0)*nUe+k] = dofA[k];
-        for (int k = tid; k < nB; k += NT) s_dof[(buf*2+1)*nUe+k] = dofB[k];
+        for (int k = tid; k < nA; k += NT) s_dof[(buf*2+0)*nUe+k] = P.rowmap ? P.rowmap[dofA[k]] : dofA[k];
+        for (int k = tid; k < nB; k += NT) s_dof[(buf*2+1)*nUe+k] = P.colmap ? P.colmap[dofB[k]] : dofB[k];
     };
 
     int n_cur = blockIdx.x, n_nxt = (int)(gridDim.x+blockIdx.x), buf = 0;

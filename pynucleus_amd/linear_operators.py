@@ -115,6 +115,120 @@ class DistributedDense_LinearOperator(Dense_LinearOperator):
         return Dense_LinearOperator(self.A, self.ctx, self.info)
 
 
+class DistributedSlab_LinearOperator:
+    """Row-owned distributed dense operator: every rank keeps the one-sided slab of its block rows,
+    rows x (N - col0) doubles <= N^2 / P, and its partial per-cell diagonal blocks; matvec = local slab products + ONE
+    all-reduce of the N-vector (DistributedH2Matrix_globalData.matvec, clusterMethodCy.pyx:3127-3154).  No collective in
+    the assembly."""
+
+    def __init__(self, slab, dblocks, rowdofs, coldofs, num_dofs, ctx, group, info=None):
+        self.slab, self.dblocks = slab, dblocks
+        self.rowdofs, self.coldofs = np.ascontiguousarray(rowdofs, dtype=np.int32), np.ascontiguousarray(coldofs, dtype=np.int32)
+        self.num_rows = self.num_columns = int(num_dofs)
+        self.shape = (self.num_rows, self.num_columns)
+        self.ctx, self.group = ctx, group
+        self.device = slab.device
+        self.info = info or {}
+
+    @classmethod
+    def assemble(cls, builder, rank, size, group):
+        from .builder import row_slab_of_rank, tile_cells
+        ctx = builder.context()
+        dm = builder.dm
+        dev = torch.device('cuda', ctx.device)
+        T = tile_cells(dm.dofs_per_element, builder.mesh.dim)
+        c0, c1, tiles, rows, cols = row_slab_of_rank(dm, T, rank, size)
+        N = dm.num_dofs
+        ncols = max(int(cols.shape[0]), 1)
+        slab = torch.zeros((max(rows.shape[0], 1), ncols), dtype=torch.float64, device=dev)
+        dblocks = torch.zeros(ctx.diag_blocks_size(), dtype=torch.float64, device=dev)
+        op = cls(slab, dblocks, rows, cols, N, ctx, group)
+        if rows.shape[0]:
+            ctx.set_row_slab(rows, cols)
+            ctx._slab_owner = op
+            ctx.assemble_dense_tiles(slab.data_ptr(), slab.stride(0), builder.zeroExterior, tiles, c0, c1)
+            ctx.get_diag_blocks(dblocks.data_ptr())
+            op.info = dict(counters=ctx.counters(), phase_ms=ctx.phase_ms(), cell_range=(c0, c1), num_tiles=int(tiles.shape[0]),
+                           slab_rows=int(rows.shape[0]), slab_cols=int(ncols), slab_bytes=int(rows.shape[0])*int(ncols)*8)
+        else:
+            op.info = dict(counters=dict(numAssembledCellPairs=0, numIntegrations=0), cell_range=(c0, c1), num_tiles=0, slab_rows=0,
+                           slab_cols=int(ncols), slab_bytes=0)
+        return op
+
+    def _bind(self):
+        if getattr(self.ctx, '_slab_owner', None) is not self and self.rowdofs.shape[0]:
+            self.ctx.set_row_slab(self.rowdofs, self.coldofs)
+            self.ctx._slab_owner = self
+
+    def _local(self, xd):
+        yd = torch.zeros(self.num_rows, dtype=torch.float64, device=self.device)
+        if self.rowdofs.shape[0]:
+            self._bind()
+            torch.cuda.current_stream(self.device).synchronize()
+            self.ctx.slab_matvec(self.slab.data_ptr(), self.slab.stride(0), self.dblocks.data_ptr(), xd.data_ptr(), yd.data_ptr())
+            self.ctx.synchronize()
+        return yd
+
+    def matvec(self, x, y=None):
+        import torch.distributed as dist
+        xd = _as_dev(x, self.device).contiguous()
+        if dist.is_initialized():
+            red = xd if dist.get_backend(self.group) != 'gloo' else xd.cpu()
+            dist.broadcast(red, src=dist.get_global_rank(self.group, 0) if self.group is not None else 0, group=self.group)
+            xd = red.to(self.device)
+        yd = self._local(xd)
+        if dist.is_initialized():
+            red = yd if dist.get_backend(self.group) != 'gloo' else yd.cpu()
+            dist.all_reduce(red, group=self.group)
+            yd = red.to(self.device)
+        if isinstance(x, torch.Tensor):
+            return yd
+        out = yd.cpu().numpy()
+        if y is not None:
+            y[:] = out
+            return y
+        return out
+
+    __mul__ = matvec
+    dot = matvec
+
+    @property
+    def diagonal(self):
+        import torch.distributed as dist
+        d = torch.zeros(self.num_rows, dtype=torch.float64, device=self.device)
+        if self.rowdofs.shape[0]:
+            self._bind()
+            torch.cuda.current_stream(self.device).synchronize()
+            self.ctx.slab_diagonal(self.slab.data_ptr(), self.slab.stride(0), self.dblocks.data_ptr(), d.data_ptr())
+            self.ctx.synchronize()
+        if dist.is_initialized():
+            red = d if dist.get_backend(self.group) != 'gloo' else d.cpu()
+            dist.all_reduce(red, group=self.group)
+            d = red.to(self.device)
+        return d.cpu().numpy()
+
+    def local_bytes(self):
+        return int(self.slab.numel()*8+self.dblocks.numel()*8)
+
+    def toarray(self):
+        """the full matrix on every rank (tests, small problems only): N products with unit vectors would be wasteful, so
+        the local part is expanded on the host and summed over the ranks"""
+        import torch.distributed as dist
+        N = self.num_rows
+        X = torch.eye(N, dtype=torch.float64, device=self.device)
+        cols = [self._local(X[:, j].contiguous()) for j in range(N)]
+        A = torch.stack(cols, dim=1)
+        if dist.is_initialized():
+            red = A if dist.get_backend(self.group) != 'gloo' else A.cpu()
+            dist.all_reduce(red, group=self.group)
+            A = red
+        return A.cpu().numpy()
+
+    def __repr__(self):
+        return '<{}x{} DistributedSlab_LinearOperator: {} rows x {} columns on {}>'.format(self.num_rows, self.num_columns,
+                                                                                        self.rowdofs.shape[0], self.coldofs.shape[0], self.device)
+
+
 class CSR_LinearOperator:
     """Near-field matrix in HBM, CSR layout (base/PyNucleus_base/CSR_LinearOperator_{SCALAR}.pxi:20-60: ``indptr``,
     ``indices``, ``data``).  The pattern is fixed by getSparseNearField; ``data`` is filled by
