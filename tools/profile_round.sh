@@ -10,7 +10,7 @@ OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 python3 $R/bench.py --steps 10 --warmup 2 --noRef $NOREF > $OUT/bench_noRef$NOREF.json 2> $OUT/bench_noRef$NOREF.err || exit 1
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $R/bench.py --steps 5 --warmup 1 --noRef $NOREF --no-cpu --no-extra > $OUT/bench_prof.json 2> $OUT/bench_prof.err || exit 2
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $R/bench.py --steps 20 --warmup 1 --noRef $NOREF --no-cpu --no-extra > $OUT/bench_prof.json 2> $OUT/bench_prof.err || exit 2
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $R/bench.py --steps 2 --warmup 1 --noRef $NOREF --no-cpu --no-extra > /dev/null 2>&1 || exit 3
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $R/bench.py --steps 2 --warmup 1 --noRef $NOREF --no-cpu --no-extra > /dev/null 2>&1 || exit 4
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_BUSY_CYCLES SQ_WAVES --output-format csv -d $OUT/pmc_sq -- python3 $R/bench.py --steps 2 --warmup 1 --noRef $NOREF --no-cpu --no-extra > /dev/null 2>&1 || echo "sq pass failed"
