@@ -93,7 +93,9 @@ def test_disc_stored_hs_error_s025():
     dm, A, b, u, cnt = solve_constant_problem(2, s, 5, {'target_order': 0.5}, driver=True)
     assert dm.num_dofs == 2977
     hs = np.sqrt(abs(b@u-exact_hs_squared(2, s)[1]))
-    assert abs(hs-0.1839933908571473) <= 1e-3*0.1839933908571473, hs
+    # observed 5.6e-6 (the difference between our degree-exact triangle rules and the reference's Xiao-Gimbutas tables); a
+    # regression in a rule or in the scaling constant shows at 1e-4 or more
+    assert abs(hs-0.1839933908571473) <= 1e-5*0.1839933908571473, hs
     assert np.abs(A-A.T).max() == 0.
     assert cnt['numAssembledCellPairs'] == 6144*6145//2
 
