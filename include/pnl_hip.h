@@ -274,6 +274,31 @@ enum pnl_kernel_slot { PNL_K_TILE_GENERAL = 0, PNL_K_TILE_UNIFORM2, PNL_K_TILE_U
                        PNL_K_WORKLIST, PNL_NUM_KERNEL_SLOTS };
 int pnl_get_kernel_ms(pnl_context *ctx, float *out, int n);
 
+/* ---- host-side planning of the H2 / near-field assembly (no GPU needed): cluster tree + admissibility
+ *      (tree_node.refine clusterMethodCy.pyx:354-663 -- median splits here --, getAdmissibleClusters :4046-4136), cells of
+ *      the cluster nodes (NA:2887-2898), the tile work lists of pnl_assemble_clusters_tiled (what clusters.nearFieldPlan
+ *      built in numpy: chunks, tiles, touching pairs, boundary facets of cellsUnion nonlocalAssembly.pyx:540-578) and the
+ *      transfer matrices of the far field (transferMatrixBuilder :2004-2073) ------------------------------------------ */
+typedef struct pnl_tree pnl_tree;
+typedef struct pnl_nfplan pnl_nfplan;
+/* boxes[N][dim][2] support boxes of the DoFs, (d2c_ptr, d2c_idx) DoF -> cells CSR; do_admissibility: 1 tree + recursion from
+ * (root, root), 0 tree only, -1 root only */
+int pnl_tree_build(int N, int dim, const double *boxes, const int64_t *d2c_ptr, const int32_t *d2c_idx, int nc, double eta,
+                   int min_size, int max_levels, int do_admissibility, pnl_tree **out);
+void pnl_tree_destroy(pnl_tree *T);
+int pnl_tree_sizes(const pnl_tree *T, int64_t *out3);                /* nodes, near pairs, far pairs */
+int pnl_tree_get(const pnl_tree *T, int32_t *range, int32_t *parent, int32_t *children, int32_t *level, double *box, int32_t *perm,
+                 int32_t *near, int32_t *far);
+int pnl_tree_node_cells(const pnl_tree *T, int n, const int32_t *node_ids, int64_t *off, int32_t *cells);
+int pnl_h2_transfer_matrices(int nnodes, int dim, int m, const double *box, const int32_t *parent, double *out);
+int pnl_nfplan_build(int dim, int nv, const double *vertices, int nc, const int32_t *cells, int dpe, int N, const int32_t *dofs,
+                     int nnodes, const int64_t *node_off, const int32_t *node_dofs, const int64_t *node_cell_off,
+                     const int32_t *node_cells, int npairs, const int32_t *pair_nodes, int tile, int max_chunk_dofs,
+                     pnl_nfplan **out);
+void pnl_nfplan_destroy(pnl_nfplan *P);
+int pnl_nfplan_sizes(const pnl_nfplan *P, int64_t *out9);
+int pnl_nfplan_get(const pnl_nfplan *P, int which, void *dst);
+
 /* ---- row slab of a rank: distributed dense operator (the reference's DistributedH2Matrix_globalData.matvec,
  *      clusterMethodCy.pyx:3127-3154, on a row partition, tree_node.partition :1854-1896) ------------------------------
  * After pnl_set_row_slab the dense assemble calls write ONE-SIDED into a slab of nrows x ncols doubles (leading dimension

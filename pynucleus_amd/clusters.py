@@ -95,12 +95,23 @@ class tree_node:
 class nearFieldClusterPair:
     def __init__(self, n1, n2):
         self.n1, self.n2 = n1, n2
-        self.cellsUnion = self.cellsInter = None
+        self._union = self._inter = None
 
     def set_cells(self):
-        c1, c2 = self.n1.cells, self.n2.cells
-        self.cellsUnion = np.union1d(c1, c2)
-        self.cellsInter = np.intersect1d(c1, c2)
+        """nonlocalAssembly.pyx:382-392; computed on first use"""
+        return self
+
+    @property
+    def cellsUnion(self):
+        if self._union is None:
+            self._union = np.union1d(self.n1.cells, self.n2.cells)
+        return self._union
+
+    @property
+    def cellsInter(self):
+        if self._inter is None:
+            self._inter = np.intersect1d(self.n1.cells, self.n2.cells)
+        return self._inter
 
     def __repr__(self):
         return 'nearFieldClusterPair({} x {} DoFs)'.format(self.n1.get_num_dofs(), self.n2.get_num_dofs())
@@ -109,6 +120,117 @@ class nearFieldClusterPair:
 class farFieldClusterPair:
     def __init__(self, n1, n2):
         self.n1, self.n2 = n1, n2
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The tree, the admissibility recursion and the cells of the nodes come from libpnl_hip.so (csrc/pnl_plan.hip, host code:
+# no GPU needed); the classes below are views on its arrays with the attributes of tree_node.  The numpy versions above
+# stay as the reference the CPU tests compare with (PNL_PLAN=numpy selects them).
+def _use_native():
+    import os
+    return os.environ.get('PNL_PLAN', 'native') != 'numpy'
+
+
+class _nativeTree:
+    def __init__(self, dm, eta, minSize, maxLevels, mode):
+        import ctypes as C
+        from . import _lib
+        L = _lib.load()
+        boxes, (ptr, idx) = getDoFBoxesAndCells(dm)
+        self.dm, self.L = dm, L
+        self.boxes, self.d2c = boxes, (ptr, idx)
+        N, dim = dm.num_dofs, dm.mesh.dim
+        b = np.ascontiguousarray(boxes, dtype=np.float64)
+        p = np.ascontiguousarray(ptr, dtype=np.int64)
+        ix = np.ascontiguousarray(idx, dtype=np.int32)
+        h = C.c_void_p()
+        rc = L.pnl_tree_build(N, dim, b.ctypes.data, p.ctypes.data, ix.ctypes.data, dm.mesh.num_cells, float(eta), int(minSize),
+                              int(maxLevels), int(mode), C.byref(h))
+        if rc:
+            raise RuntimeError('pnl_tree_build failed: {}'.format(rc))
+        self.h = h
+        sz = np.zeros(3, dtype=np.int64)
+        L.pnl_tree_sizes(h, sz.ctypes.data)
+        nn, nnear, nfar = int(sz[0]), int(sz[1]), int(sz[2])
+        self.range = np.zeros((nn, 2), dtype=np.int32)
+        self.parent = np.zeros(nn, dtype=np.int32)
+        self.children = np.zeros((nn, 2), dtype=np.int32)
+        self.level = np.zeros(nn, dtype=np.int32)
+        self.box = np.zeros((nn, dim, 2))
+        self.perm = np.zeros(N, dtype=np.int32)
+        self.near = np.zeros((nnear, 2), dtype=np.int32)
+        self.far = np.zeros((nfar, 3), dtype=np.int32)
+        L.pnl_tree_get(h, self.range.ctypes.data, self.parent.ctypes.data, self.children.ctypes.data, self.level.ctypes.data,
+                       self.box.ctypes.data, self.perm.ctypes.data, self.near.ctypes.data, self.far.ctypes.data)
+        self._nodes = {}
+        self._cells = {}
+
+    def __del__(self):
+        try:
+            self.L.pnl_tree_destroy(self.h)
+        except Exception:
+            pass
+
+    def node(self, k):
+        n = self._nodes.get(k)
+        if n is None:
+            n = self._nodes[k] = native_node(self, int(k))
+        return n
+
+    def load_cells(self, ids):
+        """cells of many nodes in one call"""
+        ids = np.ascontiguousarray([k for k in ids if k not in self._cells], dtype=np.int32)
+        if ids.shape[0] == 0:
+            return
+        off = np.zeros(ids.shape[0]+1, dtype=np.int64)
+        self.L.pnl_tree_node_cells(self.h, ids.shape[0], ids.ctypes.data, off.ctypes.data, None)
+        cells = np.zeros(int(off[-1]), dtype=np.int32)
+        self.L.pnl_tree_node_cells(self.h, ids.shape[0], ids.ctypes.data, off.ctypes.data, cells.ctypes.data)
+        for i, k in enumerate(ids):
+            self._cells[int(k)] = cells[off[i]:off[i+1]]
+
+
+class native_node(tree_node):
+    """a node of the C++ tree with the attributes of tree_node (dofs sorted ascending, box [dim, 2], children, cells)"""
+
+    def __init__(self, T, k):
+        self._T, self._k = T, k
+        self.levelNo = int(T.level[k])
+        self.box = T.box[k]
+        self._dofs = self._cells_ = None
+        self._boxes, self._d2c = T.boxes, T.d2c
+        self._coords = None
+
+    @property
+    def parent(self):
+        p = int(self._T.parent[self._k])
+        return self._T.node(p) if p >= 0 else None
+
+    @property
+    def children(self):
+        c = self._T.children[self._k]
+        return [self._T.node(int(c[0])), self._T.node(int(c[1]))] if c[0] >= 0 else []
+
+    @property
+    def is_leaf(self):
+        return self._T.children[self._k, 0] < 0
+
+    @property
+    def dofs(self):
+        if self._dofs is None:
+            b, e = self._T.range[self._k]
+            d = self._T.perm[b:e]
+            self._dofs = d if self.is_leaf else np.sort(d)
+        return self._dofs
+
+    @property
+    def cells(self):
+        if self._k not in self._T._cells:
+            self._T.load_cells([self._k])
+        return self._T._cells[self._k]
+
+    def refine(self, minSize, maxLevels):
+        return                                               # the native tree is refined completely when it is built
 
 
 def distBoxes(b1, b2):
@@ -120,7 +242,9 @@ def diamBox(b):
     return float(np.sqrt(((b[:, 1]-b[:, 0])**2).sum()))
 
 
-def getTree(dm):
+def getTree(dm, native=None):
+    if (native if native is not None else False):
+        return _nativeTree(dm, 3., 1 << 30, 1, -1).node(0)
     boxes, d2c = getDoFBoxesAndCells(dm)
     coords = boxes.mean(axis=2)
     root = tree_node(None, np.arange(dm.num_dofs, dtype=np.int32), boxes, coords, d2c, 0)
@@ -161,9 +285,17 @@ def getAdmissibleClusters(n1, n2, eta, minSize, maxLevels, Pfar, Pnear, level=0)
 def getNearFieldClusters(dm, eta=3., minClusterSize=None, maxLevels=200):
     """(root, Pnear, Pfar) for dm; both orientations (n1,n2) and (n2,n1) of off-diagonal pairs are listed, like the
     reference's recursion from (root, root)"""
-    root = getTree(dm)
     if minClusterSize is None:
         minClusterSize = max(dm.num_dofs//64, 8)
+    if _use_native():
+        T = _nativeTree(dm, eta, minClusterSize, maxLevels, 1)
+        T.load_cells(np.unique(T.near))
+        Pnear = [nearFieldClusterPair(T.node(a), T.node(b)) for a, b in T.near]
+        Pfar = {}
+        for a, b, lvl in T.far:
+            Pfar.setdefault(int(lvl), []).append(farFieldClusterPair(T.node(a), T.node(b)))
+        return T.node(0), Pnear, Pfar
+    root = getTree(dm)
     Pnear, Pfar = [], {}
     getAdmissibleClusters(root, root, eta, minClusterSize, maxLevels, Pfar, Pnear)
     for cp in Pnear:
@@ -515,6 +647,8 @@ class nearFieldPlan:
         self.node_off = np.zeros(len(nodes)+1, dtype=np.int32)
         self.node_off[1:] = np.cumsum([n.dofs.shape[0] for n in nodes])
         self.node_dofs = np.concatenate([n.dofs for n in nodes]).astype(np.int32) if nodes else np.zeros(0, dtype=np.int32)
+        if _use_native():
+            return self._build_native(dm, nodes, pairs, tile, maxChunkDofs)
         # ---- chunks of every node's cell list ---------------------------------------------------------------------------
         dofs = dm.dofs
         chunk_cells, chunk_ndof, chunk_dofl, chunk_slot = [], [], [], []
@@ -651,6 +785,62 @@ class nearFieldPlan:
             order = np.argsort(-w, kind='stable')
             for name in ('tile_chunkA', 'tile_chunkB', 'tile_pair', 'tile_flags', 'tile_dslotA', 'tile_dslotB'):
                 setattr(self, name, np.ascontiguousarray(getattr(self, name)[order]))
+
+    def _build_native(self, dm, nodes, pairs, tile, maxChunkDofs):
+        """the same lists from csrc/pnl_plan.hip (pnl_nfplan_build)"""
+        import ctypes as C
+        from . import _lib
+        L = _lib.load()
+        mesh = dm.mesh
+        dpe, dim = dm.dofs_per_element, mesh.dim
+        T = getattr(nodes[0], '_T', None) if nodes else None
+        if T is not None:
+            T.load_cells([n._k for n in nodes if isinstance(n, native_node)])
+        node_cells = [np.asarray(n.cells, dtype=np.int32) for n in nodes]
+        node_cell_off = np.zeros(len(nodes)+1, dtype=np.int64)
+        node_cell_off[1:] = np.cumsum([c.shape[0] for c in node_cells])
+        cells_cat = np.ascontiguousarray(np.concatenate(node_cells) if node_cells else np.zeros(0), dtype=np.int32)
+        node_off = np.ascontiguousarray(self.node_off, dtype=np.int64)
+        node_dofs = np.ascontiguousarray(self.node_dofs, dtype=np.int32)
+        verts = np.ascontiguousarray(mesh.vertices, dtype=np.float64)
+        mcells = np.ascontiguousarray(mesh.cells, dtype=np.int32)
+        dofs = np.ascontiguousarray(dm.dofs, dtype=np.int32)
+        pn = np.ascontiguousarray(self.pair_nodes, dtype=np.int32)
+        h = C.c_void_p()
+        rc = L.pnl_nfplan_build(dim, mesh.num_vertices, verts.ctypes.data, mesh.num_cells, mcells.ctypes.data, dpe, dm.num_dofs,
+                                dofs.ctypes.data, len(nodes), node_off.ctypes.data, node_dofs.ctypes.data, node_cell_off.ctypes.data,
+                                cells_cat.ctypes.data, pn.shape[0], pn.ctypes.data, int(tile), int(maxChunkDofs), C.byref(h))
+        if rc:
+            raise RuntimeError('pnl_nfplan_build failed: {}'.format(rc))
+        try:
+            sz = np.zeros(9, dtype=np.int64)
+            L.pnl_nfplan_sizes(h, sz.ctypes.data)
+            nchunks, nU, ntiles = int(sz[0]), int(sz[1]), int(sz[2])
+
+            def get(which, shape, dt=np.int32):
+                a = np.zeros(shape, dtype=dt)
+                if a.size:
+                    L.pnl_nfplan_get(h, which, a.ctypes.data)
+                return a
+            self.nU = nU
+            self.node_chunk_off = get(0, len(nodes)+1)
+            self.chunk_cells = get(1, (nchunks, tile))
+            self.chunk_ndof = get(2, nchunks)
+            self.chunk_dofs = get(3, (nchunks, nU))
+            self.chunk_slot = get(4, (nchunks, dpe, tile), np.int16)
+            self.tile_chunkA, self.tile_chunkB = get(5, ntiles), get(6, ntiles)
+            self.tile_pair, self.tile_flags = get(7, ntiles), get(8, ntiles)
+            self.tile_dslotA, self.tile_dslotB = get(9, (ntiles, tile)), get(10, (ntiles, tile))
+            self.sing_items = [get(11+s, (int(sz[3+s]), 3)) for s in range(3)]
+            self.num_dslots = int(sz[6])
+            self.d_cell, self.d_pair = get(14, self.num_dslots), get(15, self.num_dslots)
+            self.pair_foff = get(16, pn.shape[0]+1)
+            self.fvid = get(17, (int(sz[7]), dim))
+            self.bt_slot, self.bt_cell = get(18, int(sz[8])), get(19, int(sz[8]))
+            self.bt_facet = get(20, (int(sz[8]), dim))
+            self.pair_dbase = None
+        finally:
+            L.pnl_nfplan_destroy(h)
 
     @property
     def num_pairs(self):

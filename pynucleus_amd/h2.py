@@ -78,9 +78,16 @@ class h2Plan:
         far = [(nid[id(cp.n1)], nid[id(cp.n2)]) for lvl in sorted(Pfar) for cp in Pfar[lvl]]
         self.far = np.array(far, dtype=np.int32).reshape(-1, 2)
         self.transfer = np.zeros((len(nodes), self.M, self.M))
-        for k, n in enumerate(nodes):
-            if parent[k] >= 0:
-                self.transfer[k] = transferMatrix(nodes[parent[k]].box, n.box, self.m)
+        from .clusters import _use_native
+        if _use_native() and dim <= 2:
+            from . import _lib
+            rc = _lib.load().pnl_h2_transfer_matrices(len(nodes), dim, self.m, self.box.ctypes.data, self.parent.ctypes.data,
+                                                      self.transfer.ctypes.data)
+            assert rc == 0, rc
+        else:
+            for k, n in enumerate(nodes):
+                if parent[k] >= 0:
+                    self.transfer[k] = transferMatrix(nodes[parent[k]].box, n.box, self.m)
         # quadrature of the leaf values: order m + polynomial degree + 1 (CM:1236-1247, "Sauter Schwab p. 428")
         qr = simplexXiaoGimbutas(self.m+dm.polynomialOrder+1, dim, dim)
         self.qbary = np.zeros((qr.num_nodes, 3))
