@@ -77,6 +77,9 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise PnlError('{} is missing: the HIP extension has not been built (run __graft_entry__.build()); '
                        'there is no CPU fallback for the assembly path'.format(LIB_PATH))
+    # torch ships its own HIP runtime: it has to be in the process BEFORE this library resolves libamdhip64, or the two
+    # runtimes collide and no device is found (the host-only planning entry points would otherwise load us first)
+    import torch  # noqa: F401
     L = C.CDLL(LIB_PATH)
     vp, i32, i64, dbl = C.c_void_p, C.c_int, C.c_int64, C.c_double
     L.pnl_create.argtypes = [i32, C.POINTER(vp)]

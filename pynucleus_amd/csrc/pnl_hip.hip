@@ -1395,12 +1395,14 @@ int pnl_create(int device_id, pnl_context **out) {
     if (!out) return PNL_ERR_INVALID;
     *out = nullptr;
     int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return PNL_ERR_HIP;
+    hipError_t e0;
+    auto hiperr = [](const char *what, hipError_t e) { fprintf(stderr, "[pnl] pnl_create: %s failed: %s\n", what, hipGetErrorString(e)); return PNL_ERR_HIP; };
+    if ((e0 = hipGetDeviceCount(&ndev)) != hipSuccess || ndev <= 0) return hiperr("hipGetDeviceCount", e0);
     if (device_id < 0 || device_id >= ndev) return PNL_ERR_INVALID;
-    if (hipSetDevice(device_id) != hipSuccess) return PNL_ERR_HIP;
+    if ((e0 = hipSetDevice(device_id)) != hipSuccess) return hiperr("hipSetDevice", e0);
     pnl_context *ctx = new pnl_context();
     ctx->device = device_id;
-    if (hipStreamCreate(&ctx->own_stream) != hipSuccess) { delete ctx; return PNL_ERR_HIP; }
+    if ((e0 = hipStreamCreate(&ctx->own_stream)) != hipSuccess) { delete ctx; return hiperr("hipStreamCreate", e0); }
     ctx->stream = ctx->own_stream;
     for (auto &e : ctx->ev)
         if (hipEventCreate(&e) != hipSuccess) { delete ctx; return PNL_ERR_HIP; }
