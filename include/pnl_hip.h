@@ -299,6 +299,16 @@ void pnl_nfplan_destroy(pnl_nfplan *P);
 int pnl_nfplan_sizes(const pnl_nfplan *P, int64_t *out9);
 int pnl_nfplan_get(const pnl_nfplan *P, int which, void *dst);
 
+/* sparsity pattern of a finite-horizon operator (getSparse NA:1062-1260): the DoF pairs (I, J) for which a cell holding I and
+ * a cell holding J have a vertex pair closer than delta (the pairs getRelativePosition does not call REMOTE,
+ * interactionDomains.pyx:875-898); strict_lower: only J < I (SSS storage).  Rows sorted, CSR through the getters. */
+typedef struct pnl_pattern pnl_pattern;
+int pnl_horizon_pattern(int dim, int nv, const double *vertices, int nc, const int32_t *cells, int dpe, int N, const int32_t *dofs,
+                        double delta, int strict_lower, pnl_pattern **out);
+int64_t pnl_pattern_nnz(const pnl_pattern *P);
+int pnl_pattern_get(const pnl_pattern *P, int32_t *indptr, int32_t *indices);
+void pnl_pattern_destroy(pnl_pattern *P);
+
 /* ---- row slab of a rank: distributed dense operator (the reference's DistributedH2Matrix_globalData.matvec,
  *      clusterMethodCy.pyx:3127-3154, on a row partition, tree_node.partition :1854-1896) ------------------------------
  * After pnl_set_row_slab the dense assemble calls write ONE-SIDED into a slab of nrows x ncols doubles (leading dimension

@@ -364,9 +364,29 @@ class nonlocalBuilder:
             pairs = self.interactingCellPairs()
             Pm = sp.csr_matrix((np.ones(pairs.shape[0], dtype=np.int32), (pairs[:, 0], pairs[:, 1])), shape=(nc, nc))
             G = (C.T @ ((Pm+Pm.T) @ C)).tocsr()
-        else:
+        elif self.params.get('patternBuilder', 'native') == 'native' and self.mesh.dim <= 2:
             # two cells interact unless all their vertex distances are >= delta (getRelativePosition): the pattern is the
-            # set of DoF pairs whose patches hold a vertex pair closer than delta, G = M Q M^T with M = DoF -> patch vertices
+            # set of DoF pairs whose patches hold a vertex pair closer than delta; built by libpnl_hip.so (csrc/pnl_plan.hip)
+            import ctypes as Ct
+            L = _lib.load()
+            verts = np.ascontiguousarray(self.mesh.vertices, dtype=np.float64)
+            mcells = np.ascontiguousarray(self.mesh.cells, dtype=np.int32)
+            dofs32 = np.ascontiguousarray(dm.dofs, dtype=np.int32)
+            h = Ct.c_void_p()
+            rc = L.pnl_horizon_pattern(self.mesh.dim, self.mesh.num_vertices, verts.ctypes.data, nc, mcells.ctypes.data, dpe, N,
+                                       dofs32.ctypes.data, float(self.kernel.horizonValue), int(symmetric), Ct.byref(h))
+            if rc:
+                raise RuntimeError('pnl_horizon_pattern failed: {}'.format(rc))
+            indptr = np.zeros(N+1, dtype=np.int32)
+            indices = np.zeros(int(L.pnl_pattern_nnz(h)), dtype=np.int32)
+            L.pnl_pattern_get(h, indptr.ctypes.data, indices.ctypes.data if indices.shape[0] else None)
+            L.pnl_pattern_destroy(h)
+            pairs = None
+            self._sparse_pattern = ((symmetric, host_pairs, float(self.kernel.horizonValue)), (indptr, indices, pairs))
+            return self._assembleSparse(indptr, indices, pairs, symmetric, host_pairs, returnNearField)
+        else:
+            # the same pattern through scipy sparse products, G = M Q M^T with M = DoF -> patch vertices (params['patternBuilder']
+            # = 'scipy': the reference implementation the native builder is tested against)
             from scipy.spatial import cKDTree
             pairs = None
             nv = self.mesh.num_vertices

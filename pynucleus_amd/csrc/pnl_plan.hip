@@ -662,3 +662,177 @@ int pnl_nfplan_get(const pnl_nfplan *P, int which, void *dst) {
 }
 
 }  // extern "C"
+
+// =====================================================================================================================
+// Sparsity pattern of a finite-horizon operator (getSparse, NA:1062-1260): two cells interact unless all their vertex
+// distances are >= delta (getRelativePosition, interactionDomains.pyx:875-898), so the pattern is the set of DoF pairs (I, J)
+// for which a cell holding I and a cell holding J have a vertex pair closer than delta -- G = M Q M^T with Q the vertex pairs
+// within delta and M = DoF -> vertices of its patch (builder.getSparse formed it with scipy sparse products: 0.45 s at
+// 129^2 vertices).  Here: vertices within delta through a uniform grid, then per DoF a bitmap over the DoFs, rows in
+// parallel.
+struct pnl_pattern {
+    std::vector<int32_t> indptr, indices;
+};
+
+extern "C" {
+
+int pnl_horizon_pattern(int dim, int nv, const double *vertices, int nc, const int32_t *cells, int dpe, int N, const int32_t *dofs,
+                        double delta, int strict_lower, pnl_pattern **out) {
+    if (!out || dim < 1 || dim > 2 || nv <= 0 || nc <= 0 || !vertices || !cells || !dofs || !(delta > 0.) || N <= 0) return PNL_ERR_INVALID;
+    const int nV = dim+1;
+    const double r = delta*(1.+1e-9), r2 = r*r;
+    // vertex -> cells, DoF -> cells
+    std::vector<int64_t> vptr(nv+1, 0), dptr(N+1, 0);
+    for (int c = 0; c < nc; c++) {
+        for (int k = 0; k < nV; k++) vptr[cells[(size_t)c*nV+k]+1]++;
+        for (int k = 0; k < dpe; k++) { const int g = dofs[(size_t)c*dpe+k]; if (g >= 0) dptr[g+1]++; }
+    }
+    for (int v = 0; v < nv; v++) vptr[v+1] += vptr[v];
+    for (int g = 0; g < N; g++) dptr[g+1] += dptr[g];
+    std::vector<int32_t> vcells(vptr[nv]), dcells(dptr[N]);
+    {
+        std::vector<int64_t> fv(vptr.begin(), vptr.end()-1), fd(dptr.begin(), dptr.end()-1);
+        for (int c = 0; c < nc; c++) {
+            for (int k = 0; k < nV; k++) vcells[fv[cells[(size_t)c*nV+k]]++] = c;
+            for (int k = 0; k < dpe; k++) { const int g = dofs[(size_t)c*dpe+k]; if (g >= 0) dcells[fd[g]++] = c; }
+        }
+    }
+    // uniform grid of width r over the vertices
+    double lo[2] = {INFINITY, INFINITY}, hi[2] = {-INFINITY, -INFINITY};
+    for (int v = 0; v < nv; v++) for (int d = 0; d < dim; d++) { lo[d] = std::min(lo[d], vertices[(size_t)v*dim+d]); hi[d] = std::max(hi[d], vertices[(size_t)v*dim+d]); }
+    int ng[2] = {1, 1};
+    for (int d = 0; d < dim; d++) ng[d] = std::max(1, std::min(4096, (int)std::floor((hi[d]-lo[d])/r)+1));
+    auto gcell = [&](int v, int d) { return std::min(ng[d]-1, std::max(0, (int)std::floor((vertices[(size_t)v*dim+d]-lo[d])/r))); };
+    const int ncellg = ng[0]*ng[1];
+    std::vector<int32_t> gptr(ncellg+1, 0), gverts(nv);
+    for (int v = 0; v < nv; v++) gptr[gcell(v, 0)+(dim == 2 ? ng[0]*gcell(v, 1) : 0)+1]++;
+    for (int g = 0; g < ncellg; g++) gptr[g+1] += gptr[g];
+    {
+        std::vector<int32_t> fill(gptr.begin(), gptr.end()-1);
+        for (int v = 0; v < nv; v++) gverts[fill[gcell(v, 0)+(dim == 2 ? ng[0]*gcell(v, 1) : 0)]++] = v;
+    }
+    auto tnow = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double tp0 = tnow();
+    // vertices within r of every vertex (Q, the vertex itself included): one grid query per vertex, in parallel
+    const int nthreads = plan_threads();
+    std::vector<int64_t> qptr(nv+1, 0);
+    std::vector<int32_t> qidx;
+    {
+        struct QOut { std::vector<int32_t> len, idx; };
+        std::vector<QOut> qo(nthreads);
+        std::vector<double> wv(nv, 1.);
+        par_ranges(nv, wv, nthreads, [&](int tid, int v0, int v1) {
+            QOut &O = qo[tid];
+            for (int v = v0; v < v1; v++) {
+                const int gx = gcell(v, 0), gy = dim == 2 ? gcell(v, 1) : 0;
+                int cnt = 0;
+                for (int yy = std::max(0, gy-1); yy <= std::min(ng[1]-1, gy+1); yy++)
+                    for (int xx = std::max(0, gx-1); xx <= std::min(ng[0]-1, gx+1); xx++) {
+                        const int g = xx+ng[0]*yy;
+                        for (int q = gptr[g]; q < gptr[g+1]; q++) {
+                            const int u = gverts[q];
+                            double d2 = 0.;
+                            for (int d = 0; d < dim; d++) { const double t = vertices[(size_t)v*dim+d]-vertices[(size_t)u*dim+d]; d2 += t*t; }
+                            if (d2 <= r2) { O.idx.push_back(u); cnt++; }
+                        }
+                    }
+                O.len.push_back(cnt);
+            }
+        });
+        size_t total = 0;
+        for (QOut &O : qo) total += O.idx.size();
+        qidx.reserve(total);
+        int v = 0;
+        for (QOut &O : qo) {
+            for (int l : O.len) { qptr[v+1] = qptr[v]+l; v++; }
+            qidx.insert(qidx.end(), O.idx.begin(), O.idx.end());
+        }
+    }
+    // the distinct DoFs of the cells holding a vertex
+    std::vector<int64_t> udptr(nv+1, 0);
+    std::vector<int32_t> udofs;
+    {
+        std::vector<int32_t> tmp;
+        for (int u = 0; u < nv; u++) {
+            tmp.clear();
+            for (int64_t p = vptr[u]; p < vptr[u+1]; p++)
+                for (int k = 0; k < dpe; k++) { const int J = dofs[(size_t)vcells[p]*dpe+k]; if (J >= 0) tmp.push_back(J); }
+            std::sort(tmp.begin(), tmp.end());
+            tmp.erase(std::unique(tmp.begin(), tmp.end()), tmp.end());
+            udofs.insert(udofs.end(), tmp.begin(), tmp.end());
+            udptr[u+1] = (int64_t)udofs.size();
+        }
+    }
+    const double tp1 = tnow();
+    // rows in parallel: cells of I -> their vertices -> vertices within r -> cells holding those -> their DoFs
+    struct Rows { std::vector<int32_t> len, idx; };
+    std::vector<Rows> rows(nthreads);
+    std::vector<double> w(N, 1.);
+    par_ranges(N, w, nthreads, [&](int tid, int i0, int i1) {
+        Rows &R = rows[tid];
+        const int nwords = (N+63)/64;
+        std::vector<uint64_t> bits(nwords, 0);
+        std::vector<int32_t> vstamp(nv, -1), ustamp(nv, -1), vlist;
+        for (int I = i0; I < i1; I++) {
+            // vertices within r of a vertex of a cell of I
+            vlist.clear();
+            for (int64_t p = dptr[I]; p < dptr[I+1]; p++) {
+                const int c1 = dcells[p];
+                for (int k = 0; k < nV; k++) {
+                    const int v = cells[(size_t)c1*nV+k];
+                    if (vstamp[v] == I) continue;                 // this source vertex has been expanded for I
+                    vstamp[v] = I;
+                    for (int64_t q = qptr[v]; q < qptr[v+1]; q++) {
+                        const int u = qidx[q];
+                        if (ustamp[u] != I) { ustamp[u] = I; vlist.push_back(u); }
+                    }
+                }
+            }
+            // DoFs of the cells holding those vertices
+            int wlo = nwords, whi = -1;
+            for (int u : vlist)
+                for (int64_t p = udptr[u]; p < udptr[u+1]; p++) {
+                    const int J = udofs[p];
+                    if (strict_lower && J >= I) continue;
+                    bits[J >> 6] |= 1ull << (J & 63);
+                    wlo = std::min(wlo, J >> 6); whi = std::max(whi, J >> 6);
+                }
+            int cnt = 0;
+            for (int wq = wlo; wq <= whi; wq++) {
+                uint64_t b = bits[wq];
+                bits[wq] = 0;
+                while (b) { const int t = __builtin_ctzll(b); R.idx.push_back(wq*64+t); b &= b-1; cnt++; }
+            }
+            R.len.push_back(cnt);
+        }
+    });
+    const double tp2 = tnow();
+    pnl_pattern *P = new pnl_pattern();
+    P->indptr.assign(N+1, 0);
+    {
+        int I = 0;
+        size_t total = 0;
+        for (Rows &R : rows) total += R.idx.size();
+        P->indices.reserve(total);
+        for (Rows &R : rows) {
+            for (int l : R.len) { P->indptr[I+1] = P->indptr[I]+l; I++; }
+            P->indices.insert(P->indices.end(), R.idx.begin(), R.idx.end());
+        }
+    }
+    if (getenv("PNL_PLAN_TIMING")) fprintf(stderr, "[pnl_pattern] vertex neighbours %.3f rows %.3f merge %.3f s (%d threads)\n", tp1-tp0, tp2-tp1, tnow()-tp2, nthreads);
+    *out = P;
+    return PNL_OK;
+}
+
+int64_t pnl_pattern_nnz(const pnl_pattern *P) { return P ? (int64_t)P->indices.size() : -1; }
+
+int pnl_pattern_get(const pnl_pattern *P, int32_t *indptr, int32_t *indices) {
+    if (!P || !indptr) return PNL_ERR_INVALID;
+    std::copy(P->indptr.begin(), P->indptr.end(), indptr);
+    if (indices) std::copy(P->indices.begin(), P->indices.end(), indices);
+    return PNL_OK;
+}
+
+void pnl_pattern_destroy(pnl_pattern *P) { delete P; }
+
+}  // extern "C"

@@ -96,3 +96,50 @@ def test_native_tree_partition_properties():
         for cp in Pfar[lvl]:
             cover[np.ix_(cp.n1.dofs, cp.n2.dofs)] += 1
     assert cover.min() == 1 and cover.max() == 1
+
+
+@pytest.mark.parametrize('case', ['square_P1', 'square_P2', 'interval_P1', 'square_P1_unsym'])
+def test_native_horizon_pattern_equals_sparse_products(case):
+    """pnl_horizon_pattern against G = M Q M^T formed with scipy (what builder.getSparse did in round 1)"""
+    import ctypes as C
+    import scipy.sparse as sp
+    from scipy.spatial import cKDTree
+    from pynucleus_amd import uniformSquare, NO_BOUNDARY, dofmapFactory, _lib
+    sym = True
+    if case == 'square_P1':
+        mesh, el, delta = uniformSquare(17), 'P1', 0.2
+    elif case == 'square_P2':
+        mesh, el, delta = uniformSquare(9), 'P2', 0.3
+    elif case == 'interval_P1':
+        mesh, el, delta = interval(6), 'P1', 0.11
+    else:
+        mesh, el, delta, sym = uniformSquare(13), 'P1', 0.17, False
+    dm = dofmapFactory(el, mesh, NO_BOUNDARY)
+    N, nc, dpe, nv = dm.num_dofs, mesh.num_cells, dm.dofs_per_element, mesh.num_vertices
+    rows = np.repeat(np.arange(nc), dpe)
+    d = np.asarray(dm.dofs).reshape(-1)
+    m = d >= 0
+    Cm = sp.csr_matrix((np.ones(int(m.sum()), dtype=np.int32), (rows[m], d[m])), shape=(nc, N))
+    vp = cKDTree(mesh.vertices).query_pairs(delta*(1.+1e-9), output_type='ndarray')
+    Q = sp.csr_matrix((np.ones(vp.shape[0], dtype=np.int32), (vp[:, 0], vp[:, 1])), shape=(nv, nv))
+    Q = Q+Q.T+sp.identity(nv, dtype=np.int32, format='csr')
+    B = sp.csr_matrix((np.ones(nc*mesh.cells.shape[1], dtype=np.int32),
+                       (np.repeat(np.arange(nc), mesh.cells.shape[1]), np.asarray(mesh.cells).reshape(-1))), shape=(nc, nv))
+    M = (Cm.T @ B).tocsr()
+    M.data[:] = 1
+    G = ((M @ Q) @ M.T).tocsr()
+    if sym:
+        G = sp.tril(G, k=-1, format='csr')
+    G.sort_indices()
+    L = _lib.load()
+    verts = np.ascontiguousarray(mesh.vertices, dtype=np.float64)
+    mcells = np.ascontiguousarray(mesh.cells, dtype=np.int32)
+    dofs32 = np.ascontiguousarray(dm.dofs, dtype=np.int32)
+    h = C.c_void_p()
+    assert L.pnl_horizon_pattern(mesh.dim, nv, verts.ctypes.data, nc, mcells.ctypes.data, dpe, N, dofs32.ctypes.data, float(delta), int(sym),
+                                 C.byref(h)) == 0
+    indptr = np.zeros(N+1, dtype=np.int32)
+    indices = np.zeros(int(L.pnl_pattern_nnz(h)), dtype=np.int32)
+    L.pnl_pattern_get(h, indptr.ctypes.data, indices.ctypes.data)
+    L.pnl_pattern_destroy(h)
+    assert np.array_equal(indptr, G.indptr) and np.array_equal(indices, G.indices)
