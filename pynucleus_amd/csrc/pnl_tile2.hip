@@ -86,6 +86,7 @@ int pnl2_launch_uniform(pnl_context *ctx, int kt, const DevProblem &Pt, const in
     if (ctx->dpe == 6 && np == 3) return launch_uniform_kt<6, 3>(ctx, kt, Pt, tiles, tile_cls, ntiles, q, A, ldA, Dglob, SO);
     if (ctx->dpe == 6 && np == 6) return launch_uniform_kt<6, 6>(ctx, kt, Pt, tiles, tile_cls, ntiles, q, A, ldA, Dglob, SO);
     if (ctx->dpe == 3 && np == 6) return launch_uniform_kt<3, 6>(ctx, kt, Pt, tiles, tile_cls, ntiles, q, A, ldA, Dglob, SO);
+    if (ctx->dpe == 3 && np == 3) return launch_uniform_kt<3, 3>(ctx, kt, Pt, tiles, tile_cls, ntiles, q, A, ldA, Dglob, SO);
     return fail(ctx, PNL_ERR_UNSUPPORTED, "uniform tiles: dpe=%d with %d points", ctx->dpe, np);
 }
 
