@@ -1212,7 +1212,8 @@ int nlo_assemble_pairs_masked(const nlo_problem *P, int np, const int32_t *pairs
     const int dpe = P->dpe, n2 = 2*dpe;
     double contrib[MAXE];
     int perm1[MAXV], perm2[MAXV], perm[2*MAXDPE], ld[2*MAXDPE];
-    if (P->nclasses) return -3;                 /* variable orders need the jump terms NA:1966-2156: not restated */
+    /* variable orders: nlo_panel / nlo_eval take the class of the pair (evalParams at the two centres, NO:509-513); the interface
+     * terms NA:1966-2156 are boundary items of the class problems (oracle.py assemble_clusters_variable) */
     counters[0] = counters[1] = counters[2] = 0;
     for (int t = 0; t < np; t++) {
         const int c1 = pairs[2*t], c2 = pairs[2*t+1];

@@ -275,3 +275,175 @@ class OracleProblem:
             if rc:
                 raise RuntimeError('oracle failed with code {}'.format(rc))
         return data, diag, dict(numCellPairs=int(cnt[0]), numAssembledCellPairs=int(cnt[1]), numIntegrations=int(cnt[2]))
+
+
+# -- variable order: kernel blocks, interfaces and the boundary items of assembleClusters -----------------------------------
+def kernel_blocks_and_jumps(dm, T):
+    """getKernelBlocksAndJumps (NA:2312-2384) in plain loops.  blocks: order value -> set of DoFs whose cells all carry that
+    order, key None for DoFs on an interface (INTERFACE_DOF); jumps: (cell1, cell2) sorted -> the shared vertices in the order
+    they have in the cell visited last (the reference overwrites the entry when it meets the pair from the other side)."""
+    mesh = dm.mesh
+    sFun = T.kernel.s
+    centers = mesh.vertices[mesh.cells].mean(axis=1)
+    lab = sFun.labels(centers)
+    orders = [float(sFun.sVals[l, l]) for l in lab]                    # P0 interpolation of s.diagonal() (NA:2329)
+    dofOrders = {}
+    for c in range(mesh.num_cells):
+        for d in dm.dofs[c]:
+            if d < 0:
+                continue
+            if d not in dofOrders:
+                dofOrders[d] = orders[c]
+            elif dofOrders[d] is not None and dofOrders[d] != orders[c]:
+                dofOrders[d] = None
+    blocks = {}
+    for d, o in dofOrders.items():
+        blocks.setdefault(o, set()).add(int(d))
+    jumps = {}
+    facet_of = {}
+    nV = mesh.cells.shape[1]
+    for c in range(mesh.num_cells):
+        vs = [int(v) for v in mesh.cells[c]]
+        for k in range(nV):
+            f = tuple(sorted(vs[:k]+vs[k+1:]))
+            facet_of.setdefault(f, []).append(c)
+    conn = [[] for _ in range(mesh.num_cells)]                      # mesh.getCellConnectivity(mesh.dim): cells across a facet
+    for f, cs in facet_of.items():
+        if len(cs) == 2:
+            conn[cs[0]].append(cs[1])
+            conn[cs[1]].append(cs[0])
+    for c1 in range(mesh.num_cells):
+        for c2 in conn[c1]:
+            if orders[c1] != orders[c2]:
+                shared = [int(v) for v in mesh.cells[c1] if v in mesh.cells[c2]]
+                jumps[(min(c1, c2), max(c1, c2))] = shared
+    return blocks, jumps
+
+
+def variable_items_reference(dm, Pnear, T, zeroExterior=True, evalShift=1e-9):
+    """The boundary integrals of assembleClusters for a piecewise-constant order, as the reference walks them (NA:1966-2156):
+    the kernel parameters of every (cell, facet) integral are evaluated at the cell centre and at the facet centre moved by
+    evalShift along (dy, -dx) (NA:2034-2042, 2065-2071, 2095-2101, 2137-2147; in 1D away from the cell / to the right and
+    then to the left of the vertex).  Returns a list of items (class, fac, cell, facet vertices, mask) with
+    class = cls_of[label(centre), label(shifted facet centre)]; tests compare it with the product's vectorised list."""
+    mesh = dm.mesh
+    dim = mesh.dim
+    sFun = T.kernel.s
+    dpe = dm.dofs_per_element
+    centers = mesh.vertices[mesh.cells].mean(axis=1)
+
+    def cls(c, y):
+        return int(T.cls_of[sFun.labels(centers[c][None, :])[0], sFun.labels(np.asarray(y)[None, :])[0]])
+
+    def shifted(facet, sign):
+        X = mesh.vertices[list(facet)]
+        cen = X.mean(axis=0)
+        if dim == 1:
+            return cen+sign*evalShift
+        return cen+sign*evalShift*np.array([X[1, 1]-X[0, 1], X[0, 0]-X[1, 0]])
+
+    def surface(cellIds):
+        # boundaryEdges / boundaryVertices (nonlocalAssembly.pyx:506-578): facets of exactly one cell, oriented as in it
+        seen = {}
+        for c in cellIds:
+            vs = [int(v) for v in mesh.cells[c]]
+            fs = [(vs[0], vs[1]), (vs[1], vs[2]), (vs[2], vs[0])] if dim == 2 else [(vs[0],), (vs[1],)]
+            for f in fs:
+                key = tuple(sorted(f))
+                if key in seen:
+                    del seen[key]
+                else:
+                    seen[key] = f
+        return list(seen.values())
+
+    _, jumps = kernel_blocks_and_jumps(dm, T)
+    items = []
+    for cp in Pnear:
+        ci = [int(c) for c in cp.cellsInter]
+        if not ci:
+            continue
+        U = set(int(c) for c in cp.cellsUnion)
+        d1, d2 = set(int(d) for d in cp.n1.dofs), set(int(d) for d in cp.n2.dofs)
+
+        def mask_of(c):                                         # getElemSymMaskCluster NA:463-478
+            m, k = 0, 0
+            for p in range(dpe):
+                for q in range(p, dpe):
+                    if int(dm.dofs[c, p]) in d1 and int(dm.dofs[c, q]) in d2:
+                        m |= 1 << k
+                    k += 1
+            return m
+
+        surf = surface(sorted(U))
+        for c in ci:
+            m = mask_of(c)
+            if m == 0:
+                continue
+            for f in surf:
+                if dim == 1:
+                    y = shifted(f, 1. if centers[c, 0] < mesh.vertices[f[0], 0] else -1.)
+                else:
+                    y = shifted(f, 1.)
+                items.append((cls(c, y), 1., c, f, m))
+        for (ca, cb), f in jumps.items():
+            if ca in U or cb in U:
+                continue
+            f = tuple(f)
+            for side, base in ((1., 1.), (-1., -1.)):          # right of the facet with +1, then left with -1 (NA:2065-2124)
+                y = shifted(f, side)
+                for c in ci:
+                    m = mask_of(c)
+                    if m == 0:
+                        continue
+                    fac = base
+                    if dim == 1 and not centers[c, 0] < y[0]:
+                        fac = -base
+                    items.append((cls(c, y), fac, c, f, m))
+    if not zeroExterior:
+        full = 0
+        for c in range(mesh.num_cells):
+            m, k = 0, 0
+            for p in range(dpe):
+                for q in range(p, dpe):
+                    if dm.dofs[c, p] >= 0 and dm.dofs[c, q] >= 0:
+                        m |= 1 << k
+                    k += 1
+            if m == 0:
+                continue
+            for b in range(T.bcells.shape[0]):
+                f = tuple(int(v) for v in np.atleast_1d(T.bcells[b]))
+                if dim == 1:
+                    y = shifted(f, 1. if centers[c, 0] < mesh.vertices[f[0], 0] else -1.)
+                else:
+                    y = shifted(f, 1.)
+                items.append((cls(c, y), -1., c, f, m))
+    return items
+
+
+def assemble_clusters_variable(op, pairs, masks, groups, indptr, indices, symmetric=True):
+    """variable order: masked interior pairs with the class of every pair (nlo_assemble_pairs_masked) plus the boundary items
+    grouped as (class, fac, cells, facets, masks), each integrated with the tables of its class (NA:1966-2156)"""
+    N = op.tables.dm.num_dofs
+    data = np.zeros(indices.shape[0])
+    diag = np.zeros(N) if symmetric else None
+    pairs = np.ascontiguousarray(pairs, dtype=np.int32)
+    masks = np.ascontiguousarray(masks, dtype=np.uint64)
+    indptr = np.ascontiguousarray(indptr, dtype=np.int32)
+    indices = np.ascontiguousarray(indices, dtype=np.int32)
+    cnt = np.zeros(3, dtype=np.int64)
+    dptr = diag.ctypes.data if symmetric else None
+    rc = lib().nlo_assemble_pairs_masked(C.byref(op.P), pairs.shape[0], pairs.ctypes.data, masks.ctypes.data, indptr.ctypes.data,
+                                         indices.ctypes.data, data.ctypes.data, dptr, cnt.ctypes.data)
+    if rc:
+        raise RuntimeError('oracle failed with code {}'.format(rc))
+    for k, fac, cc, ff, mm in groups:
+        cc = np.ascontiguousarray(cc, dtype=np.int32)
+        ff = np.ascontiguousarray(ff, dtype=np.int32)
+        mm = np.ascontiguousarray(mm, dtype=np.uint32)
+        if cc.shape[0] == 0:
+            continue
+        rc = lib().nlo_assemble_boundary_masked(C.byref(op._class_problems[k].P), cc.shape[0], cc.ctypes.data, ff.ctypes.data,
+                                                mm.ctypes.data, float(fac), indptr.ctypes.data, indices.ctypes.data, data.ctypes.data, dptr)
+        if rc:
+            raise RuntimeError('oracle failed with code {}'.format(rc))
+    return data, diag, dict(numCellPairs=int(cnt[0]), numAssembledCellPairs=int(cnt[1]), numIntegrations=int(cnt[2]))

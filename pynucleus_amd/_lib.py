@@ -325,6 +325,10 @@ class Context:
         self.check(self.L.pnl_assemble_pairs_masked(self.h, p.shape[0], pp, pm, C.c_void_p(data_ptr),
                                                     C.c_void_p(diag_ptr) if diag_ptr else None))
 
+    def select_class(self, k):
+        """variable order: the kernel class the next pnl_assemble_boundary_masked integrates with"""
+        self.check(self.L.pnl_select_class(self.h, int(k)))
+
     def assemble_boundary_masked(self, cells, facets, masks, fac, data_ptr, diag_ptr=None):
         c, pc = _hp(cells, np.int32)
         f, pf = _hp(facets, np.int32)

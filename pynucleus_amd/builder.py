@@ -501,13 +501,13 @@ class nonlocalBuilder:
         if self._single_order_twin() is not None:
             return self._single_order_twin().assembleClusters(Pnear, forceUnsymmetricMatrix, Anear, jumps, myRoot, _clusterBoundary,
                                                               _globalBoundary, _symmetrizeMasks, **kwargs)
-        if self.kernel.variable:
-            raise NotImplementedError('near field of a variable order with several kernel blocks: jump terms NA:1966-2156')
+        if self.kernel.variable and (not self.kernel.symmetric or self.kernel.finiteHorizon):
+            raise NotImplementedError('near field of a non-symmetric or finite-horizon variable order')
         import torch
         from . import clusters
         from .linear_operators import CSR_LinearOperator, SSS_LinearOperator
-        if jumps:
-            raise NotImplementedError('variable-order jump terms')
+        # jumps (getKernelBlocksAndJumps NA:2312-2384) are a function of the mesh and the order: derived in
+        # clusters.variableBoundaryItems, the argument is accepted for the reference's call signature
         if myRoot is not None:
             raise NotImplementedError('distributed near-field assembly by subtree')
         ctx = self.context()
@@ -553,7 +553,16 @@ class nonlocalBuilder:
                 sing[q] = sing.get(q, 0)+c
             ms_total += ctx.phase_ms()['total']
         nitems = 0
-        if self.tables.has_boundary_tables and not self.kernel.variable and _clusterBoundary:
+        if self.tables.has_boundary_tables and self.kernel.variable:
+            # piecewise-constant order: cluster exterior with the order of the region outside every facet, the interfaces of
+            # the order, the global term -- one launch per (kernel class, sign) (NA:1966-2156)
+            for k, fac, cells, facets, bmasks in clusters.variableBoundaryItems(dm, Pnear, self.tables, self.zeroExterior, _symmetrizeMasks,
+                                                                                _clusterBoundary, _globalBoundary):
+                ctx.select_class(k)
+                ctx.assemble_boundary_masked(cells, facets, bmasks, fac, data_ptr, diag_ptr)
+                nitems += int(cells.shape[0])
+            ctx.select_class(0)
+        elif self.tables.has_boundary_tables and _clusterBoundary:
             cells, facets, bmasks = clusters.clusterBoundaryItems(dm, Pnear, symmetrize=_symmetrizeMasks)
             nitems = int(cells.shape[0])
             ctx.assemble_boundary_masked(cells, facets, bmasks, 1., data_ptr, diag_ptr)

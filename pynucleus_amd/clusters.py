@@ -509,6 +509,149 @@ def clusterBoundaryItems(dm, Pnear, symmetrize=False):
             np.concatenate(out_m).astype(np.uint32))
 
 
+def _clusterCellMasks(dm, cp, ci, sym):
+    """getElemSymMaskCluster NA:463-478 for the cells ci: bit k of the dpe(dpe+1)/2 local entries (p <= q) is set when
+    DoF p lies in n1 and DoF q in n2 (or the other way round when the transposed pair is folded in)"""
+    dpe = dm.dofs_per_element
+    in1 = np.zeros(dm.num_dofs+1, dtype=bool)
+    in2 = np.zeros(dm.num_dofs+1, dtype=bool)
+    in1[cp.n1.dofs] = True
+    in2[cp.n2.dofs] = True
+    d = np.where(dm.dofs[ci] >= 0, dm.dofs[ci], dm.num_dofs)
+    m1, m2 = in1[d], in2[d]
+    mask = np.zeros(ci.shape[0], dtype=np.uint32)
+    k = 0
+    for p in range(dpe):
+        for q in range(p, dpe):
+            bit = m1[:, p] & m2[:, q]
+            if sym:
+                bit = bit | (m2[:, p] & m1[:, q])
+            mask |= (bit.astype(np.uint32) << np.uint32(k))
+            k += 1
+    return mask
+
+
+def facetTables(mesh):
+    """fv[nc, nf, dim]: the facets of every cell (vertex ids, oriented as in the cell: the normal (dy, -dx) points out of it),
+    keys[nc, nf]: orientation-free facet keys, nbr[nc, nf]: the cell on the other side or -1"""
+    cells = mesh.cells.astype(np.int64)
+    nc, nv = cells.shape[0], mesh.num_vertices
+    if mesh.manifold_dim == 2:
+        fv = np.stack([cells[:, [0, 1]], cells[:, [1, 2]], cells[:, [2, 0]]], axis=1)
+        keys = fv.min(axis=2)*nv+fv.max(axis=2)
+    else:
+        fv = cells[:, :, None]
+        keys = cells.copy()
+    nf = keys.shape[1]
+    flat = keys.reshape(-1)
+    order = np.argsort(flat, kind='stable')
+    sk = flat[order]
+    i = np.nonzero(sk[1:] == sk[:-1])[0]
+    nbr = np.full(flat.shape[0], -1, dtype=np.int64)
+    nbr[order[i]] = order[i+1]//nf
+    nbr[order[i+1]] = order[i]//nf
+    return fv, keys, nbr.reshape(nc, nf)
+
+
+def variableBoundaryItems(dm, Pnear, T, zeroExterior=True, symmetrize=False, clusterBoundary=True, globalBoundary=True):
+    """Boundary items of the near field of a piecewise-constant variable order, grouped by (kernel class, sign):
+
+    (i)   cluster exterior (NA:2007-2049): (cell of cellsInter) x (facet of the surface of cellsUnion).  The reference moves
+          the facet centre by evalShift along the outer normal (dy, -dx) before the kernel parameters are evaluated
+          (NA:2034-2042): the order is the one between the cell and the region OUTSIDE the facet -- here the label of the
+          cell across the facet, or the label of the domain-boundary facet.
+    (ii)  interfaces of the order (NA:2050-2124): every interface facet (getKernelBlocksAndJumps NA:2354-2384) none of whose
+          two cells lies in cellsUnion, against every cell of cellsInter: +1 with the order of the region the normal points
+          to, -1 with the order of the region behind it (in 1D the sign follows the side the cell lies on, NA:2079-2083).
+    (iii) without zeroExterior the global Omega x Omega^c term with -1 (NA:2126-2156), the order between the cell and the
+          boundary facet.
+
+    Returns a list of (class, fac, cells[ni], facets[ni, dim], masks[ni])."""
+    mesh = dm.mesh
+    dim = mesh.dim
+    L = np.asarray(T.cell_labels, dtype=np.int64)
+    cls_of = np.asarray(T.cls_of, dtype=np.int64)
+    fv, keys, nbr = facetTables(mesh)
+    nc, nf = nbr.shape
+    nv = mesh.num_vertices
+    # label of the region outside every (cell, facet)
+    outlab = L[np.maximum(nbr, 0)]
+    bc = np.asarray(T.bcells, dtype=np.int64).reshape(-1, dim)
+    if bc.shape[0]:
+        bkeys = bc.min(axis=1)*nv+bc.max(axis=1) if dim == 2 else bc[:, 0]
+        o = np.argsort(bkeys)
+        cb, jb = np.nonzero(nbr < 0)
+        pos = np.searchsorted(bkeys[o], keys[cb, jb])
+        assert (bkeys[o][pos] == keys[cb, jb]).all()
+        outlab[cb, jb] = np.asarray(T.facet_labels, dtype=np.int64)[o[pos]]
+    # interfaces: facets between cells of different labels, taken from the side of the lower cell number (the reference compares
+    # the cells' own orders, NA:2326-2329, 2360; items whose two classes coincide cancel and are dropped below)
+    jc, jj = np.nonzero((nbr > np.arange(nc)[:, None]) & (L[:, None] != outlab))
+    jn = nbr[jc, jj]
+    jfv = fv[jc, jj]                                                  # [nj, dim]
+    groups = {}
+
+    def add(k, fac, cells, facets, masks):
+        # k: class per item
+        for kk in np.unique(k):
+            sel = k == kk
+            g = groups.setdefault((int(kk), float(fac)), ([], [], []))
+            g[0].append(cells[sel])
+            g[1].append(facets[sel])
+            g[2].append(masks[sel])
+
+    xc = mesh.vertices[mesh.cells].mean(axis=1)
+    inU = np.zeros(nc, dtype=bool)
+    have = {(id(cp.n1), id(cp.n2)) for cp in Pnear}
+    for cp in (Pnear if clusterBoundary else []):
+        ci = cp.cellsInter
+        if ci.shape[0] == 0:
+            continue
+        sym = symmetrize and (id(cp.n2), id(cp.n1)) not in have
+        mask = _clusterCellMasks(dm, cp, ci, sym)
+        keep = mask != 0
+        ci, mask = ci[keep].astype(np.int64), mask[keep]
+        if ci.shape[0] == 0:
+            continue
+        U = np.asarray(cp.cellsUnion, dtype=np.int64)
+        inU[U] = True
+        nb = nbr[U]
+        uc, uj = np.nonzero((nb < 0) | ~inU[np.maximum(nb, 0)])
+        sf, sl = fv[U[uc], uj], outlab[U[uc], uj]
+        ns = sf.shape[0]
+        add(cls_of[L[ci][:, None], sl[None, :]].reshape(-1), 1., np.repeat(ci, ns), np.tile(sf, (ci.shape[0], 1)), np.repeat(mask, ns))
+        js = np.nonzero(~inU[jc] & ~inU[jn])[0]
+        inU[U] = False
+        if js.shape[0]:
+            nj = js.shape[0]
+            kfar = cls_of[L[ci][:, None], L[jn[js]][None, :]]          # the region the normal of the facet (as in cell jc) points to
+            knear = cls_of[L[ci][:, None], L[jc[js]][None, :]]
+            if dim == 1:
+                xv = mesh.vertices[jfv[js, 0], 0]
+                sgn = np.where((xc[ci, 0][:, None] < xv[None, :]) == (xc[jc[js], 0] < xv)[None, :], 1., -1.)
+            else:
+                sgn = np.ones(kfar.shape)
+            cells = np.repeat(ci, nj)
+            facets = np.tile(jfv[js], (ci.shape[0], 1))
+            masks = np.repeat(mask, nj)
+            differ = (kfar != knear).reshape(-1)                        # equal classes cancel
+            for s in (1., -1.):
+                sel = differ & (sgn.reshape(-1) == s)
+                if sel.any():
+                    add(kfar.reshape(-1)[sel], s, cells[sel], facets[sel], masks[sel])
+                    add(knear.reshape(-1)[sel], -s, cells[sel], facets[sel], masks[sel])
+    if not zeroExterior and globalBoundary and bc.shape[0]:
+        cells, facets, masks = globalBoundaryItems(dm, T.bcells)
+        nb_ = bc.shape[0]
+        fl = np.tile(np.asarray(T.facet_labels, dtype=np.int64), cells.shape[0]//nb_)
+        add(cls_of[L[cells], fl], -1., cells, facets, masks)
+    out = []
+    for (k, fac), (c, f, m) in sorted(groups.items()):
+        out.append((k, fac, np.concatenate(c).astype(np.int32), np.ascontiguousarray(np.concatenate(f), dtype=np.int32),
+                    np.concatenate(m).astype(np.uint32)))
+    return out
+
+
 def globalBoundaryItems(dm, bcells):
     """every cell x every facet of the domain boundary with all entries requested (getElemSymMask NA:170-186): the
     global Omega x Omega^c term of NA:1896-1913 / 1945-1964"""

@@ -1927,7 +1927,7 @@ int pnl_assemble_pairs_masked(pnl_context *ctx, int np, const int32_t *pairs, co
     int rc;
     if ((rc = upload(ctx, ctx->b_mp_pairs, pairs, (size_t)2*np))) return rc;
     if (masks && (rc = upload(ctx, ctx->b_mp_masks, masks, (size_t)4*np))) return rc;
-    if (ctx->nlab > 0) return fail(ctx, PNL_ERR_UNSUPPORTED, "cluster assembly with a variable order needs the jump terms (NA:1966-2156)");
+    if (ctx->nlab > 0 && ctx->nonsym) return fail(ctx, PNL_ERR_UNSUPPORTED, "cluster assembly with a non-symmetric order table");
     if (!std::isinf(ctx->C().kern[0].horizon2) && ctx->qmax > PNL_CUT_SHIFT)
         return fail(ctx, PNL_ERR_UNSUPPORTED, "finite horizon: upload distant rules up to order %d at most", PNL_CUT_SHIFT);
     SparseOut S;
@@ -1936,11 +1936,23 @@ int pnl_assemble_pairs_masked(pnl_context *ctx, int np, const int32_t *pairs, co
     HIPCHK(ctx, hipMemsetAsync(ctx->b_counters.p, 0, sizeof(unsigned long long)*PNL_NCOUNTERS, ctx->stream));
     ctx->visited_pairs = (unsigned long long)np; ctx->visited_is_assembled = false;
     if (np == 0) return PNL_OK;
-    const int kt = ctx->P.k.fast ? 1 : 0;
-    if (ctx->dim == 2 && ctx->dpe == 3) return kt ? pairs_masked_impl<2, 3, 1>(ctx, np, S) : pairs_masked_impl<2, 3, 0>(ctx, np, S);
-    if (ctx->dim == 2 && ctx->dpe == 6) return kt ? pairs_masked_impl<2, 6, 1>(ctx, np, S) : pairs_masked_impl<2, 6, 0>(ctx, np, S);
-    if (ctx->dim == 1 && ctx->dpe == 2) return pairs_masked_impl<1, 2, 0>(ctx, np, S);
-    return fail(ctx, PNL_ERR_UNSUPPORTED, "unsupported (dim=%d, dofs_per_element=%d)", ctx->dim, ctx->dpe);
+    // variable order (piecewise constant, symmetric table): the pair list once per class, k_mp_classify keeps the pairs of the
+    // class (the interface terms of NA:1966-2156 are boundary items, pnl_assemble_boundary_masked after pnl_select_class)
+    const int ncls = ctx->nlab > 0 ? (int)ctx->cls.size() : 1, cur0 = ctx->cur;
+    for (int k = 0; k < ncls; k++) {
+        if (ctx->nlab > 0) { ctx->cur = k; refresh_tables(ctx); }
+        const int kt = ctx->P.k.fast ? 1 : 0;
+        const bool first = k == 0;
+        if (ctx->dim == 2 && ctx->dpe == 3)
+            rc = kt ? pairs_masked_impl<2, 3, 1>(ctx, np, S, true, first) : pairs_masked_impl<2, 3, 0>(ctx, np, S, true, first);
+        else if (ctx->dim == 2 && ctx->dpe == 6)
+            rc = kt ? pairs_masked_impl<2, 6, 1>(ctx, np, S, true, first) : pairs_masked_impl<2, 6, 0>(ctx, np, S, true, first);
+        else if (ctx->dim == 1 && ctx->dpe == 2) rc = pairs_masked_impl<1, 2, 0>(ctx, np, S, true, first);
+        else rc = fail(ctx, PNL_ERR_UNSUPPORTED, "unsupported (dim=%d, dofs_per_element=%d)", ctx->dim, ctx->dpe);
+        if (rc) break;
+    }
+    ctx->cur = cur0;
+    return rc;
 }
 
 int pnl_assemble_pairs_in_horizon(pnl_context *ctx, double *data, double *diag) {

@@ -1662,6 +1662,8 @@ k_mp_classify(const DevProblem P, const int *__restrict__ pairs, int npairs, int
     bool any = false;
 #pragma unroll
     for (int k = 0; k < DPE; k++) any = any || P.cdof[(size_t)k*P.ncp+c1] >= 0 || P.cdof[(size_t)k*P.ncp+c2] >= 0;
+    // variable order: one pass per class, a pair belongs to the class of its two labels (symmetric class table)
+    if (P.cur_class >= 0 && P.cls_of[P.clabel[c1]*P.nlab+P.clabel[c2]] != P.cur_class) any = false;
     int key = 0, off = 0, n = 0;
     if (any) {
         int common = 0;
