@@ -220,6 +220,10 @@ typedef struct {
     const int32_t *far;
     const double *transfer;
     const double *qbary, *qw, *qphi;
+    /* variable order (pnl_set_classes): kernel class of every admissible pair -- the order between the kernel blocks of its two
+     * clusters (the reference evaluates the variable kernel at the interpolation points, clusterMethodCy.pyx:2213); NULL for a
+     * constant order */
+    const int32_t *far_class;
 } pnl_h2_plan;
 int pnl_h2_setup(pnl_context *ctx, const pnl_h2_plan *plan);
 int pnl_h2_matvec(pnl_context *ctx, const double *x_dev, double *y_dev);
@@ -285,6 +289,13 @@ typedef struct pnl_nfplan pnl_nfplan;
  * (root, root), 0 tree only, -1 root only */
 int pnl_tree_build(int N, int dim, const double *boxes, const int64_t *d2c_ptr, const int32_t *d2c_idx, int nc, double eta,
                    int min_size, int max_levels, int do_admissibility, pnl_tree **out);
+/* variable order: dof_block[N] >= 0 names the kernel block of every DoF (getKernelBlocksAndJumps NA:2312-2352, the reference
+ * hangs one child per block below the leaves of the partition tree, NA:2619-2640), mixed_block the block of the interface DoFs:
+ * nodes with DoFs of several blocks are split by block first, only pairs of single-block nodes other than mixed_block can be
+ * admissible (mixed_node, clusterMethodCy.pyx:4038) */
+int pnl_tree_build_blocks(int N, int dim, const double *boxes, const int64_t *d2c_ptr, const int32_t *d2c_idx, int nc, double eta,
+                          int min_size, int max_levels, int do_admissibility, const int32_t *dof_block, int mixed_block,
+                          pnl_tree **out);
 void pnl_tree_destroy(pnl_tree *T);
 int pnl_tree_sizes(const pnl_tree *T, int64_t *out3);                /* nodes, near pairs, far pairs */
 int pnl_tree_get(const pnl_tree *T, int32_t *range, int32_t *parent, int32_t *children, int32_t *level, double *box, int32_t *perm,

@@ -458,7 +458,20 @@ class nonlocalBuilder:
         from . import clusters
         from .h2 import h2Plan, H2Matrix, interpolationOrder
         rp = self.getH2RefinementParams()
-        root, Pnear, Pfar = clusters.getNearFieldClusters(self.dm, rp['eta'], rp['minSize'], rp['maxLevels'])
+        far_class = None
+        if self.kernel.variable:
+            # kernel blocks (getKernelBlocksAndJumps NA:2312-2352): clusters of one block each, the interface DoFs stay in the near
+            # field; the far field between two clusters uses the order between their blocks
+            if not self.kernel.symmetric or self.kernel.finiteHorizon:
+                raise NotImplementedError('H2 operator of a non-symmetric or finite-horizon variable order')
+            blk, mixed = clusters.dofKernelBlocks(self.dm, self.tables)
+            root, Pnear, Pfar = clusters.getNearFieldClusters(self.dm, rp['eta'], rp['minSize'], rp['maxLevels'], blk, mixed)
+            cls_of = self.tables.cls_of
+
+            def far_class(cp):
+                return int(cls_of[blk[cp.n1.dofs[0]], blk[cp.n2.dofs[0]]])
+        else:
+            root, Pnear, Pfar = clusters.getNearFieldClusters(self.dm, rp['eta'], rp['minSize'], rp['maxLevels'])
         rank, size = self._rank_size()
         if sum(len(v) for v in Pfar.values()) == 0:
             h2 = self.getDense()
@@ -472,7 +485,7 @@ class nonlocalBuilder:
             m = self.params.get('interpolation_order', None)
             if m is None:
                 m = interpolationOrder(self.kernel, self.mesh, self.tables.target_order)
-            far = H2Matrix(local, h2Plan(self.dm, root, Pfar, m), self.context(), root, Pfar) if rank == 0 else None
+            far = H2Matrix(local, h2Plan(self.dm, root, Pfar, m, far_class), self.context(), root, Pfar) if rank == 0 else None
             h2 = DistributedSparse_LinearOperator(local, None if self.comm is True else self.comm, far=far)
         else:
             # full CSR near field by default: its SpMV needs no atomics for the transposed half (0.16 ms against 0.39 ms with
@@ -481,7 +494,7 @@ class nonlocalBuilder:
             m = self.params.get('interpolation_order', None)
             if m is None:
                 m = interpolationOrder(self.kernel, self.mesh, self.tables.target_order)
-            h2 = H2Matrix(Anear, h2Plan(self.dm, root, Pfar, m), self.context(), root, Pfar)
+            h2 = H2Matrix(Anear, h2Plan(self.dm, root, Pfar, m, far_class), self.context(), root, Pfar)
         out = (h2,)
         if returnNearField:
             out += (Pnear,)

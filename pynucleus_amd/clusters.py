@@ -132,7 +132,7 @@ def _use_native():
 
 
 class _nativeTree:
-    def __init__(self, dm, eta, minSize, maxLevels, mode):
+    def __init__(self, dm, eta, minSize, maxLevels, mode, dof_block=None, mixed_block=-1):
         import ctypes as C
         from . import _lib
         L = _lib.load()
@@ -144,8 +144,10 @@ class _nativeTree:
         p = np.ascontiguousarray(ptr, dtype=np.int64)
         ix = np.ascontiguousarray(idx, dtype=np.int32)
         h = C.c_void_p()
-        rc = L.pnl_tree_build(N, dim, b.ctypes.data, p.ctypes.data, ix.ctypes.data, dm.mesh.num_cells, float(eta), int(minSize),
-                              int(maxLevels), int(mode), C.byref(h))
+        self.dof_block = None if dof_block is None else np.ascontiguousarray(dof_block, dtype=np.int32)
+        rc = L.pnl_tree_build_blocks(N, dim, b.ctypes.data, p.ctypes.data, ix.ctypes.data, dm.mesh.num_cells, float(eta), int(minSize),
+                                     int(maxLevels), int(mode), None if dof_block is None else self.dof_block.ctypes.data,
+                                     int(mixed_block), C.byref(h))
         if rc:
             raise RuntimeError('pnl_tree_build failed: {}'.format(rc))
         self.h = h
@@ -282,13 +284,31 @@ def getAdmissibleClusters(n1, n2, eta, minSize, maxLevels, Pfar, Pnear, level=0)
     return added
 
 
-def getNearFieldClusters(dm, eta=3., minClusterSize=None, maxLevels=200):
+def dofKernelBlocks(dm, T):
+    """getKernelBlocksAndJumps NA:2312-2352 for a piecewise-constant order: block of every DoF = the label shared by all its
+    cells, or num_labels for DoFs on an interface (INTERFACE_DOF).  Returns (dof_block[num_dofs], mixed_block)."""
+    lab = np.asarray(T.cell_labels, dtype=np.int64)
+    L = int(T.num_labels)
+    lo = np.full(dm.num_dofs+1, L, dtype=np.int64)
+    hi = np.full(dm.num_dofs+1, -1, dtype=np.int64)
+    d = np.where(dm.dofs >= 0, dm.dofs, dm.num_dofs).reshape(-1)
+    rep = np.repeat(lab, dm.dofs.shape[1])
+    np.minimum.at(lo, d, rep)
+    np.maximum.at(hi, d, rep)
+    blk = np.where(lo == hi, lo, L)[:dm.num_dofs]
+    return blk.astype(np.int32), L
+
+
+def getNearFieldClusters(dm, eta=3., minClusterSize=None, maxLevels=200, dof_block=None, mixed_block=-1):
     """(root, Pnear, Pfar) for dm; both orientations (n1,n2) and (n2,n1) of off-diagonal pairs are listed, like the
-    reference's recursion from (root, root)"""
+    reference's recursion from (root, root).  dof_block / mixed_block (dofKernelBlocks): clusters are split by kernel block
+    before anything else and only pairs of single-block clusters can be admissible (variable orders, NA:2619-2640)."""
     if minClusterSize is None:
         minClusterSize = max(dm.num_dofs//64, 8)
+    if dof_block is not None and not _use_native():
+        raise NotImplementedError('cluster trees by kernel block: native planner only')
     if _use_native():
-        T = _nativeTree(dm, eta, minClusterSize, maxLevels, 1)
+        T = _nativeTree(dm, eta, minClusterSize, maxLevels, 1, dof_block, mixed_block)
         T.load_cells(np.unique(T.near))
         Pnear = [nearFieldClusterPair(T.node(a), T.node(b)) for a, b in T.near]
         Pfar = {}

@@ -2120,8 +2120,12 @@ int pnl_h2_setup(pnl_context *ctx, const pnl_h2_plan *pl) {
     if ((rc = check_ready(ctx))) return rc;
     if ((rc = finalize(ctx))) return rc;
     refresh_tables(ctx);
-    if (ctx->nlab > 0 || !std::isinf(ctx->C().kern[0].horizon2))
-        return fail(ctx, PNL_ERR_UNSUPPORTED, "H2 far field: constant order, infinite horizon only");
+    if (!std::isinf(ctx->C().kern[0].horizon2)) return fail(ctx, PNL_ERR_UNSUPPORTED, "H2 far field: infinite horizon only");
+    if (ctx->nlab > 0 && (ctx->nonsym || (pl->nfar > 0 && !pl->far_class)))
+        return fail(ctx, PNL_ERR_UNSUPPORTED, "H2 far field of a variable order: symmetric order table and a kernel class per admissible pair");
+    if (pl->far_class)
+        for (int i = 0; i < pl->nfar; i++)
+            if (pl->far_class[i] < 0 || pl->far_class[i] >= (int)ctx->cls.size()) return fail(ctx, PNL_ERR_INVALID, "far pair %d: bad kernel class", i);
     const int dim = ctx->dim, m = pl->m;
     if (pl->nnodes <= 0 || pl->nleaves <= 0 || pl->nfar < 0 || m < 1 || m > 16 || pl->nq <= 0) return fail(ctx, PNL_ERR_INVALID, "bad H2 plan sizes");
     int M = 1;
@@ -2196,8 +2200,17 @@ int pnl_h2_setup(pnl_context *ctx, const pnl_h2_plan *pl) {
     else if (dim == 1 && ctx->dpe == 2) hipLaunchKernelGGL((k_h2_leaf_values<1, 2>), dim3(pl->nleaves), dim3(PNL_NTHREADS), 0, ctx->stream, ctx->P, H, pl->nq, qb, qw, qp);
     else return fail(ctx, PNL_ERR_UNSUPPORTED, "unsupported (dim=%d, dofs_per_element=%d)", dim, ctx->dpe);
     if (pl->nfar > 0) {
-        if (dim == 2) hipLaunchKernelGGL((k_h2_kernel_interp<2>), dim3(pl->nfar), dim3(PNL_NTHREADS), 0, ctx->stream, ctx->P, H);
-        else hipLaunchKernelGGL((k_h2_kernel_interp<1>), dim3(pl->nfar), dim3(PNL_NTHREADS), 0, ctx->stream, ctx->P, H);
+        const DevKernel *kcls = nullptr;
+        const int *fcls = nullptr;
+        if (pl->far_class) {
+            std::vector<DevKernel> kc;
+            for (auto *c : ctx->cls) kc.push_back(to_dev(c->kern[0], dim));
+            if ((rc = upload(ctx, B[18], kc.data(), kc.size()))) return rc;
+            if ((rc = upload(ctx, B[19], pl->far_class, (size_t)pl->nfar))) return rc;
+            kcls = (const DevKernel*)B[18].p; fcls = (const int*)B[19].p;
+        }
+        if (dim == 2) hipLaunchKernelGGL((k_h2_kernel_interp<2>), dim3(pl->nfar), dim3(PNL_NTHREADS), 0, ctx->stream, ctx->P, H, kcls, fcls);
+        else hipLaunchKernelGGL((k_h2_kernel_interp<1>), dim3(pl->nfar), dim3(PNL_NTHREADS), 0, ctx->stream, ctx->P, H, kcls, fcls);
     }
     HIPCHK(ctx, hipGetLastError());
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));

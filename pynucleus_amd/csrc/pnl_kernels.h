@@ -3105,8 +3105,9 @@ __device__ __forceinline__ double lagrange1d(double a, double b, int m, int l, d
 
 template <int DIM>
 __global__ void __launch_bounds__(PNL_NTHREADS)
-k_h2_kernel_interp(const DevProblem P, const H2Dev H) {
+k_h2_kernel_interp(const DevProblem P, const H2Dev H, const DevKernel *__restrict__ kcls, const int *__restrict__ far_class) {
     const int pr = blockIdx.x, n1 = H.far[2*pr], n2 = H.far[2*pr+1];
+    const DevKernel kn = far_class ? kcls[far_class[pr]] : P.k;
     const double *b1 = H.box+(size_t)n1*DIM*2, *b2 = H.box+(size_t)n2*DIM*2;
     for (int t = threadIdx.x; t < H.M*H.M; t += PNL_NTHREADS) {
         const int i = t/H.M, j = t-i*H.M;
@@ -3118,7 +3119,7 @@ k_h2_kernel_interp(const DevProblem P, const H2Dev H) {
             ii /= H.m; jj /= H.m;
             d2 += (x-y)*(x-y);
         }
-        H.K[(size_t)pr*H.M*H.M+t] = -2.*kern_eval<0>(P.k, d2);
+        H.K[(size_t)pr*H.M*H.M+t] = -2.*kern_eval<0>(kn, d2);
     }
 }
 

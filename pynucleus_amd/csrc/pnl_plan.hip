@@ -28,6 +28,7 @@ namespace {
 
 struct PNode {
     int beg, end, parent, child[2], level;
+    int block;                               // kernel block of all DoFs of the node, -1: several blocks (never admissible)
     double box[3][2];
 };
 
@@ -43,9 +44,19 @@ struct pnl_tree {
     std::vector<int64_t> d2c_ptr;
     std::vector<int32_t> d2c_idx;
     std::vector<double> boxes, coords;
+    // variable order: kernel block of every DoF (getKernelBlocksAndJumps NA:2312-2352), mixed_block = the interface DoFs
+    std::vector<int32_t> dof_block;
+    int mixed_block = -1;
 };
 
 namespace {
+
+int block_of_range(const pnl_tree *T, int beg, int end) {
+    if (T->dof_block.empty()) return 0;
+    const int b = T->dof_block[T->perm[beg]];
+    for (int t = beg+1; t < end; t++) if (T->dof_block[T->perm[t]] != b) return -1;
+    return b;
+}
 
 double dist_boxes(const PNode &a, const PNode &b, int dim) {
     double s = 0.;
@@ -74,6 +85,28 @@ void set_box(pnl_tree *T, PNode &n) {
 void refine(pnl_tree *T, int k, int minSize, int maxLevels, std::vector<double> &xs, std::vector<int32_t> &tmp) {
     const PNode nd = T->nodes[k];
     const int n = nd.end-nd.beg;
+    if (nd.block < 0) {
+        // DoFs of several kernel blocks: split off the lowest block (the reference hangs the blocks below the node, NA:2619-2640;
+        // here a chain of binary nodes), whatever the size and the depth
+        int bmin = T->dof_block[T->perm[nd.beg]];
+        for (int t = nd.beg; t < nd.end; t++) bmin = std::min(bmin, T->dof_block[T->perm[t]]);
+        tmp.resize(n);
+        int nl = 0;
+        for (int t = 0; t < n; t++) if (T->dof_block[T->perm[nd.beg+t]] == bmin) tmp[nl++] = T->perm[nd.beg+t];
+        int nr = nl;
+        for (int t = 0; t < n; t++) if (T->dof_block[T->perm[nd.beg+t]] != bmin) tmp[nr++] = T->perm[nd.beg+t];
+        std::copy(tmp.begin(), tmp.begin()+n, T->perm.begin()+nd.beg);
+        for (int c = 0; c < 2; c++) {
+            PNode ch;
+            ch.beg = c ? nd.beg+nl : nd.beg; ch.end = c ? nd.end : nd.beg+nl;
+            ch.parent = k; ch.child[0] = ch.child[1] = -1; ch.level = nd.level+1;
+            ch.block = block_of_range(T, ch.beg, ch.end);
+            set_box(T, ch);
+            T->nodes[k].child[c] = (int)T->nodes.size();
+            T->nodes.push_back(ch);
+        }
+        return;
+    }
     if (nd.level+1 >= maxLevels || n <= minSize) return;
     int ax = 0;
     double best = -1.;
@@ -101,6 +134,7 @@ void refine(pnl_tree *T, int k, int minSize, int maxLevels, std::vector<double> 
         PNode ch;
         ch.beg = c ? nd.beg+nl : nd.beg; ch.end = c ? nd.end : nd.beg+nl;
         ch.parent = k; ch.child[0] = ch.child[1] = -1; ch.level = nd.level+1;
+        ch.block = nd.block;
         set_box(T, ch);
         T->nodes[k].child[c] = (int)T->nodes.size();
         T->nodes.push_back(ch);
@@ -110,7 +144,9 @@ void refine(pnl_tree *T, int k, int minSize, int maxLevels, std::vector<double> 
 bool admissible_rec(pnl_tree *T, int n1, int n2, double eta, int maxLevels, int level) {
     const PNode &a = T->nodes[n1], &b = T->nodes[n2];
     const double dist = dist_boxes(a, b, T->dim);
-    if (eta*dist >= std::max(diam_box(a, T->dim), diam_box(b, T->dim))) {
+    // clusters of one kernel block each; the interface block stays in the near field (mixed_node, CM:4038)
+    const bool pure = a.block >= 0 && b.block >= 0 && a.block != T->mixed_block && b.block != T->mixed_block;
+    if (pure && eta*dist >= std::max(diam_box(a, T->dim), diam_box(b, T->dim))) {
         T->far.push_back(n1); T->far.push_back(n2); T->far.push_back(level);
         return true;
     }
@@ -140,9 +176,17 @@ extern "C" {
 
 int pnl_tree_build(int N, int dim, const double *boxes, const int64_t *d2c_ptr, const int32_t *d2c_idx, int nc, double eta,
                    int min_size, int max_levels, int do_admissibility, pnl_tree **out) {
+    return pnl_tree_build_blocks(N, dim, boxes, d2c_ptr, d2c_idx, nc, eta, min_size, max_levels, do_admissibility, nullptr, -1, out);
+}
+
+int pnl_tree_build_blocks(int N, int dim, const double *boxes, const int64_t *d2c_ptr, const int32_t *d2c_idx, int nc, double eta,
+                          int min_size, int max_levels, int do_admissibility, const int32_t *dof_block, int mixed_block,
+                          pnl_tree **out) {
     if (!out || N <= 0 || dim < 1 || dim > 3 || !boxes || !d2c_ptr || !d2c_idx) return PNL_ERR_INVALID;
+    if (dof_block) for (int i = 0; i < N; i++) if (dof_block[i] < 0) return PNL_ERR_INVALID;
     pnl_tree *T = new pnl_tree();
     T->N = N; T->dim = dim; T->nc = nc;
+    if (dof_block) { T->dof_block.assign(dof_block, dof_block+N); T->mixed_block = mixed_block; }
     T->boxes.assign(boxes, boxes+(size_t)N*dim*2);
     T->coords.resize((size_t)N*dim);
     for (int i = 0; i < N; i++) for (int d = 0; d < dim; d++) T->coords[(size_t)i*dim+d] = (boxes[((size_t)i*dim+d)*2]+boxes[((size_t)i*dim+d)*2+1])/2.;
@@ -152,6 +196,7 @@ int pnl_tree_build(int N, int dim, const double *boxes, const int64_t *d2c_ptr, 
     std::iota(T->perm.begin(), T->perm.end(), 0);
     PNode root;
     root.beg = 0; root.end = N; root.parent = -1; root.child[0] = root.child[1] = -1; root.level = 0;
+    root.block = block_of_range(T, 0, N);
     set_box(T, root);
     T->nodes.push_back(root);
     // the recursion from (root, root) reaches every node through its diagonal pair, which is never admissible: the tree

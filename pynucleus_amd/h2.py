@@ -46,7 +46,7 @@ def transferMatrix(boxP, boxC, m):
 class h2Plan:
     """flattened cluster tree + admissible pairs for pnl_h2_setup"""
 
-    def __init__(self, dm, root, Pfar, m):
+    def __init__(self, dm, root, Pfar, m, far_class=None):
         from .quadrature import simplexXiaoGimbutas
         mesh = dm.mesh
         dim = mesh.dim
@@ -77,6 +77,8 @@ class h2Plan:
         self.leaf_cells = np.concatenate([nodes[k].cells for k in leaves]).astype(np.int32)
         far = [(nid[id(cp.n1)], nid[id(cp.n2)]) for lvl in sorted(Pfar) for cp in Pfar[lvl]]
         self.far = np.array(far, dtype=np.int32).reshape(-1, 2)
+        # variable order: kernel class per admissible pair, far_class(cp) -> class
+        self.far_class = None if far_class is None else np.array([far_class(cp) for lvl in sorted(Pfar) for cp in Pfar[lvl]], dtype=np.int32)
         self.transfer = np.zeros((len(nodes), self.M, self.M))
         from .clusters import _use_native
         if _use_native() and dim <= 2:
@@ -111,6 +113,7 @@ class h2Plan:
             setattr(P, name, ptr(getattr(self, name), np.int32))
         P.transfer = ptr(self.transfer, np.float64)
         P.qbary, P.qw, P.qphi = ptr(self.qbary, np.float64), ptr(self.qw, np.float64), ptr(self.qphi, np.float64)
+        P.far_class = None if self.far_class is None else ptr(self.far_class, np.int32)
         return P
 
 
