@@ -87,6 +87,10 @@ __device__ __forceinline__ long long pnl_row(const DevProblem &P, int I) { retur
 __device__ __forceinline__ int pnl_col(const DevProblem &P, int J) { return P.colmap ? P.colmap[J] : J; }
 
 // H2 far field (clusterMethodCy.pyx; kernels in pnl_kernels.h)
+// copy table of k_fold_mirror (pnl_tile2.h): storage offset of the copy's row, block << 5 | local DoF, slot column
+#define PNL_FOLD_TAB 63
+struct FoldEntry { long long off; int ar, cy; };
+
 struct H2Dev {
     int dim, m, M, nnodes, nleaves, nfar;
     const double *box;          // [nnodes][dim][2]

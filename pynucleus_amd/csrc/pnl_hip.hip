@@ -324,6 +324,22 @@ int finalize(pnl_context *ctx) {
         if ((rc = upload(ctx, ctx->b_srowoff, rowoff.data(), rowoff.size()))) return rc;
         if ((rc = upload(ctx, ctx->b_cpoff, cpoff.data(), cpoff.size()))) return rc;
         if ((rc = upload(ctx, ctx->b_cpslot, cp.data(), cp.size()))) return rc;
+        // the same tables packed per range of 32 DoFs (k_fold_mirror loads a range with one round trip): header (count) +
+        // PNL_FOLD_TAB entries (row offset, block << 5 | local DoF, slot column); ranges with more copies use the lists above
+        const int nranges = (ctx->N+31)/32;
+        std::vector<FoldEntry> tab((size_t)nranges*(PNL_FOLD_TAB+1));
+        for (int q = 0; q < nranges; q++) {
+            FoldEntry *e = &tab[(size_t)q*(PNL_FOLD_TAB+1)];
+            const int g0 = cpoff[q*32], g1 = cpoff[std::min(ctx->N, q*32+32)];
+            e[0].off = g1-g0; e[0].ar = 0; e[0].cy = 0;
+            if (g1-g0 > PNL_FOLD_TAB) continue;
+            for (int I = q*32; I < std::min(ctx->N, q*32+32); I++)
+                for (int g = cpoff[I]; g < cpoff[I+1]; g++) {
+                    FoldEntry &x = e[1+g-g0];
+                    x.off = cprow[g]; x.ar = (cp[g].x << 5) | (I-q*32); x.cy = cp[g].y;
+                }
+        }
+        if ((rc = upload(ctx, ctx->b_foldtab, tab.data(), tab.size()))) return rc;
     }
     if ((rc = upload(ctx, ctx->b_perm, ctx->perm_table.data(), ctx->perm_table.size()))) return rc;
     if ((rc = ensure(ctx, ctx->b_counters, sizeof(unsigned long long)*PNL_NCOUNTERS))) return rc;

@@ -57,66 +57,88 @@ __host__ __device__ constexpr int uni_rule_size(int dpe, int np) { return 3*np+n
 // colbase[a], so that entry (row copy k, column copy l) sits at A2[cprow[k] + cp[l].y] (stored iff cp[l].x >= cp[k].x)
 //
 // A = A' + A'^T with A' gathered from the block-slot storage; every entry of A is written (no zero fill needed before).
-// 32 x 32 blocks of the upper block triangle, both images through an LDS transpose like k_mirror.  A thread keeps the copies
-// of its two columns in registers (DoFs have 1.3 copies on average, at most a handful) and walks the rows.
-#define PNL_FOLD_MAXE 160       // copies of 32 consecutive DoFs kept in LDS (1.3 per DoF on average)
+// 32 x 32 blocks of the upper block triangle, both images through an LDS transpose like k_mirror.
+// The gather runs over the COPIES: the copies of the 32 row DoFs x the copies of the 32 column DoFs form a grid of about
+// 42 x 42 candidate entries of the storage (1.3 copies per DoF); thread (ty, tx) takes the copy rows ty + 8 u and the copy
+// columns tx, tx + 32, loads the stored ones (six independent loads in flight) and adds them to the LDS image of the block
+// with ds_add_f64.  No per-entry walk whose length differs from lane to lane: the kernel was bound by instruction issue
+// (1,050 VALU instructions per wave for 8 entries per thread) as much as by the chain of dependent loads.
+// Tables of a range of 32 DoFs come packed (FoldEntry[1 + PNL_FOLD_TAB], pnl_device.h): header + copies, one load per thread.
 __global__ void __launch_bounds__(256)
-k_fold_mirror(const double *__restrict__ A2, const int *__restrict__ cpoff, const int2 *__restrict__ cp, const long long *__restrict__ cprow,
-              double *__restrict__ A, long long ldA, int N) {
+k_fold_mirror(const double *__restrict__ A2, const FoldEntry *__restrict__ tab, const int *__restrict__ cpoff, const int2 *__restrict__ cp,
+              const long long *__restrict__ cprow, double *__restrict__ A, long long ldA, int N) {
     __shared__ double t1[32][33], t2[32][33];
-    __shared__ int s_off[2][33];
-    __shared__ int2 s_cp[2][PNL_FOLD_MAXE];
-    __shared__ long long s_row[2][PNL_FOLD_MAXE];
-    const int nb = (N+31)/32;
-    const int bid = blockIdx.x;
-    int bi = 0;
+    __shared__ FoldEntry s_tab[2][PNL_FOLD_TAB+1];
+    const unsigned nb = (unsigned)(N+31)/32;
+    const unsigned bid = blockIdx.x;
+    // bid = bi nb - bi (bi-1)/2 + (bj - bi); the grid has less than 2^31 blocks, so 32-bit arithmetic is exact
+    unsigned bi;
     {
-        const double fb = ((2.*nb+1.)-sqrt((2.*nb+1.)*(2.*nb+1.)-8.*bid))*0.5;
-        bi = (int)fb;
-        while (bi > 0 && (long long)bi*nb-(long long)bi*(bi-1)/2 > bid) bi--;
-        while ((long long)(bi+1)*nb-(long long)(bi+1)*bi/2 <= bid) bi++;
+        const float t = 2.f*(float)nb+1.f;
+        const float fb = (t-sqrtf(fmaxf(t*t-8.f*(float)bid, 0.f)))*0.5f;
+        bi = (unsigned)fmaxf(fb, 0.f);
+        if (bi >= nb) bi = nb-1;
+        while (bi > 0 && bi*nb-bi*(bi-1)/2 > bid) bi--;
+        while (bi+1 < nb && (bi+1)*nb-(bi+1)*bi/2 <= bid) bi++;
     }
-    const int bj = bi+(bid-(int)((long long)bi*nb-(long long)bi*(bi-1)/2));
+    const unsigned bj = bi+(bid-(bi*nb-bi*(bi-1)/2));
     const int tid = threadIdx.x, tx = tid & 31, ty = tid >> 5;     // 32 x 8
-    // the copy tables of the two DoF ranges go through LDS: two dependent global loads per workgroup instead of three per
-    // thread and row before the first entry of the storage can be requested
-    if (tid < 66) {
-        const int side = tid/33, k = tid-side*33;
-        s_off[side][k] = cpoff[min((side ? bj : bi)*32+k, N)];
+    if (tid < 2*(PNL_FOLD_TAB+1)) {
+        const int side = tid >= PNL_FOLD_TAB+1, k = tid-side*(PNL_FOLD_TAB+1);
+        s_tab[side][k] = tab[(size_t)(side ? bj : bi)*(PNL_FOLD_TAB+1)+k];
     }
+    for (int k = tid; k < 32*33; k += 256) { (&t1[0][0])[k] = 0.; (&t2[0][0])[k] = 0.; }
     __syncthreads();
-    const int o0 = s_off[0][0], n0 = s_off[0][32]-o0, o1 = s_off[1][0], n1 = s_off[1][32]-o1;
-    const bool in_lds = n0 <= PNL_FOLD_MAXE && n1 <= PNL_FOLD_MAXE;
-    if (in_lds) {
-        for (int k = tid; k < n0+n1; k += 256) {
-            const int side = k >= n0, kk = side ? k-n0 : k, g = (side ? o1 : o0)+kk;
-            s_cp[side][kk] = cp[g];
-            s_row[side][kk] = cprow[g];
-        }
-    }
-    __syncthreads();
-    // A'[rows of range sr][column tx of range sc] -> t[.][tx]
-    auto gather = [&](int sr, int sc, double (*t)[33]) {
-        const int j0 = s_off[sc][tx]-s_off[sc][0], j1 = s_off[sc][tx+1]-s_off[sc][0];
-        const int ob_r = s_off[sr][0], ob_c = s_off[sc][0];
+    const int n0 = (int)s_tab[0][0].off, n1 = (int)s_tab[1][0].off;
+    if (n0 <= PNL_FOLD_TAB && n1 <= PNL_FOLD_TAB) {
 #pragma unroll
-        for (int rr = 0; rr < 4; rr++) {
-            const int r = ty+8*rr;
-            const int i0 = s_off[sr][r]-ob_r, i1 = s_off[sr][r+1]-ob_r;
-            double s = 0.;
-            for (int ci = i0; ci < i1; ci++) {
-                const int a = in_lds ? s_cp[sr][ci].x : cp[ob_r+ci].x;
-                const double *__restrict__ rowp = A2+(in_lds ? s_row[sr][ci] : cprow[ob_r+ci]);
-                for (int cj = j0; cj < j1; cj++) {
-                    const int2 c2 = in_lds ? s_cp[sc][cj] : cp[ob_c+cj];
-                    if (c2.x >= a) s += rowp[c2.y];
+        for (int g = 0; g < 2; g++) {                                   // g = 0: rows of range 0 -> t1, g = 1: rows of range 1 -> t2
+            if (g && bi == bj) break;
+            const int nr = g ? n1 : n0, nc = g ? n0 : n1;
+            double *__restrict__ tf = g ? &t2[0][0] : &t1[0][0];
+            for (int cj = tx; cj < nc; cj += 32) {
+                const FoldEntry col = s_tab[1-g][1+cj];
+                const int cb = col.ar >> 5, c = col.ar & 31;
+                for (int ci0 = ty; ci0 < nr; ci0 += 48) {
+                    double v[6];
+                    int dst[6];
+#pragma unroll
+                    for (int u = 0; u < 6; u++) {
+                        const int ci = ci0+8*u;
+                        dst[u] = -1;
+                        v[u] = 0.;
+                        if (ci < nr) {
+                            const FoldEntry rw = s_tab[g][1+ci];
+                            if (cb >= (rw.ar >> 5)) { v[u] = A2[rw.off+col.cy]; dst[u] = (rw.ar & 31)*33+c; }
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < 6; u++) if (dst[u] >= 0) lds_add_f64(tf+dst[u], v[u]);
                 }
             }
-            t[r][tx] = s;
         }
-    };
-    gather(0, 1, t1);
-    if (bi != bj) gather(1, 0, t2);
+    } else {
+        // more copies than the packed table holds: per-entry walk over the lists in global memory
+        auto gather = [&](int br, int bc, double (*t)[33]) {
+            const int J = min(bc*32+tx, N), j0 = cpoff[J], j1 = cpoff[min(J+1, N)];
+#pragma unroll 1
+            for (int rr = 0; rr < 4; rr++) {
+                const int r = ty+8*rr, I = min(br*32+r, N);
+                double s = 0.;
+                for (int ci = cpoff[I]; ci < cpoff[min(I+1, N)]; ci++) {
+                    const int a = cp[ci].x;
+                    const double *__restrict__ rowp = A2+cprow[ci];
+                    for (int cj = j0; cj < j1; cj++) {
+                        const int2 c2 = cp[cj];
+                        if (c2.x >= a) s += rowp[c2.y];
+                    }
+                }
+                t[r][tx] = s;
+            }
+        };
+        gather((int)bi, (int)bj, t1);
+        if (bi != bj) gather((int)bj, (int)bi, t2);
+    }
     __syncthreads();
     for (int r = ty; r < 32; r += 8) {
         const int I = bi*32+r, J = bj*32+tx;

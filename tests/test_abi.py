@@ -3,6 +3,7 @@ not need a GPU behave as documented.  No compute calls here (CPU-only container)
 import ctypes
 import os
 import re
+import numpy as np
 import pytest
 from pynucleus_amd import _lib
 
@@ -54,3 +55,22 @@ def test_product_does_not_import_oracle():
             if fn.endswith(('.py', '.hip', '.h')):
                 src = open(os.path.join(dirpath, fn)).read()
                 assert 'import oracle' not in src and 'from oracle' not in src and 'nl_oracle' not in src, fn
+
+
+@pytest.mark.gpu
+def test_work_list_overflow_fails_the_call(monkeypatch):
+    """a work list that is too small (PNL_WL_FRAC shrinks it to 64 entries per pass) must not pass silently: the status of
+    pnl_synchronize / pnl_get_counters says the operator is incomplete (the check INTEGRATION.md's stub performs)"""
+    from pynucleus_amd import disc, P1_DoFMap, P2_DoFMap, PHYSICAL, getFractionalKernel
+    from pynucleus_amd.builder import nonlocalBuilder
+    from pynucleus_amd._lib import PnlError
+    mesh = disc(4)
+    for DoFMap in (P1_DoFMap, P2_DoFMap):
+        dm = DoFMap(mesh, PHYSICAL)
+        monkeypatch.delenv('PNL_WL_FRAC', raising=False)
+        A = nonlocalBuilder(dm, getFractionalKernel(2, 0.75), {}).getDense()
+        assert np.isfinite(A.toarray()).all()
+        monkeypatch.setenv('PNL_WL_FRAC', '1e-12')
+        with pytest.raises(PnlError, match='work list overflow'):
+            nonlocalBuilder(dm, getFractionalKernel(2, 0.75), {}).getDense()
+    monkeypatch.delenv('PNL_WL_FRAC', raising=False)

@@ -53,6 +53,7 @@ elif what in ('p2', 'c5'):
             what, noRef, dm.num_dofs, mesh.num_cells, rep, 1e3*(t1-t0), ms['total'], {k: round(v, 2) for k, v in ms.items()},
             cnt['numAssembledCellPairs']/(1e-3*ms['total'])), flush=True)
         del A
+    print('   kernel ms', {k: round(v, 3) for k, v in b.context().kernel_ms().items()}, flush=True)
 elif what == 'pw':
     from pynucleus_amd.fractionalOrders import smoothedLeftRightFractionalOrder
     noRef = size or 5
