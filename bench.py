@@ -285,8 +285,12 @@ def main():
         A = torch.zeros((max(rows.shape[0], 1), max(cols.shape[0], 1)), dtype=torch.float64, device=dev)
         ctx.set_row_slab(rows, cols)
 
+    # the library says whether assemble_dense adds to A (zero fill needed, part of the step) or overwrites every entry
+    overwrites = world == 1 and ctx.dense_overwrites(0, nc)
+
     def step():
-        A.zero_()
+        if not overwrites:
+            A.zero_()
         if world == 1:
             ctx.assemble_dense(A.data_ptr(), A.stride(0), True, 0, nc)
         elif rows.shape[0]:

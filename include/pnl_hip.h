@@ -150,6 +150,10 @@ int pnl_assemble_pairs_in_horizon(pnl_context *ctx, double *data, double *diag);
                                       * the flush work is shared by the ranks, the mirror pass is not (multi-GPU) */
 int pnl_assemble_dense(pnl_context *ctx, double *A_dev, int64_t ldA, int zero_exterior, int cell_begin, int cell_end,
                        int flags);
+/* 1 if pnl_assemble_dense with these arguments OVERWRITES every entry of A (the operator is formed in the block-slot storage and
+ * folded into A in one sweep: P2 elements in 2D, whole cell range, mirrored, room for the storage), 0 if it ADDS to A and the
+ * caller has to zero the matrix first (the reference allocates a zeroed matrix, NA:1262-1290), < 0 on error */
+int pnl_dense_overwrites(pnl_context *ctx, int cell_begin, int cell_end, int flags);
 /* Like pnl_assemble_dense but with an explicit work list of block-tile pairs for the distant pairs
  * (multi-GPU balancing): tiles[2*i] <= tiles[2*i+1] are cell-block indices, block size pnl_tile_cells().
  * Touching pairs, the Omega x Omega^c term and nothing else are restricted to c1 in [cell_begin, cell_end). */

@@ -229,8 +229,10 @@ class nonlocalBuilder:
         pointwise = bool(getattr(self.tables, 'pointwise', False))
         self.PLogger.addValue('useSymmetricCells', not pointwise)
         self.PLogger.addValue('useSymmetricLocalMatrix', not pointwise)
-        A = torch.zeros((N, N), dtype=torch.float64, device=dev)
         rank, size = self._rank_size()
+        # the block-slot path forms the operator in its own storage and writes every entry of A in one sweep: no zero fill
+        overwrites = (not pointwise) and size == 1 and ctx.dense_overwrites(0, nc)
+        A = (torch.empty if overwrites else torch.zeros)((N, N), dtype=torch.float64, device=dev)
         if pointwise:
             # non-symmetric kernel, order per quadrature point (NA:1411-1428): the reference's cellNo1 split across ranks
             start, end = cell_range_of_rank(nc, rank, size)

@@ -6,61 +6,109 @@
 // read-only tables through the constant address space: loads with a wave-uniform address are scalar loads (SGPRs)
 typedef const double __attribute__((address_space(4))) *pnl_const_f64_ptr;
 
-// ---------------------------------------------------------------------------------------------
-// kernel function gamma(|x-y|^2)   (KC:75-294)
-// Branch-free ln and exp for the kernels with a general exponent: d2^e = exp(e ln d2), d2 a positive normal number and
-// |e ln d2| far from overflow.  Straight-line code (no special cases), so the independent evaluations of a pair interleave.
-// ln x: x = m 2^k with m in [sqrt(1/2), sqrt(2)); ln m = 2 atanh(f), f = (m-1)/(m+1), |f| < 0.172, odd series to f^21.
+// ---- ln and exp for the general kernel exponent: d2^e = exp(e ln d2) ------------------------------------------------------
+// Table-driven range reduction (64 intervals each), then short polynomials: 25 fp64 operations and three table loads per
+// power instead of 55 operations with the long series; a few 1e-16 relative, like the series.
+// 1 / c_j (rounded) and -ln of that rounded value, c_j the centre of [1/2 + j/128, 1/2 + (j+1)/128)
+static __constant__ double PNL_LOG_TAB[64][2] = {
+    {1.9844961240310077, -0.6853650401178903}, {1.9541984732824427, -0.6699801212784109},
+    {1.9248120300751879, -0.6548283162578087}, {1.8962962962962964, -0.6399026660411331},
+    {1.8686131386861313, -0.6251965186514375}, {1.841726618705036, -0.6107035113488708},
+    {1.8156028368794326, -0.5964175541013942}, {1.7902097902097902, -0.5823328142196552},
+    {1.7655172413793103, -0.5684437020589881}, {1.7414965986394557, -0.5547448577008262},
+    {1.7181208053691275, -0.5412311385341033}, {1.695364238410596, -0.5278976076646381},
+    {1.673202614379085, -0.514739523087127}, {1.6516129032258065, -0.5017523275603158},
+    {1.6305732484076434, -0.4889316391312545}, {1.610062893081761, -0.476273242259331},
+    {1.5900621118012421, -0.46377307949509944}, {1.5705521472392638, -0.4514272436728002},
+    {1.5515151515151515, -0.4392319705789819}, {1.532934131736527, -0.4271836320628074},
+    {1.514792899408284, -0.415278729556489}, {1.4970760233918128, -0.4035138879769026},
+    {1.4797687861271676, -0.3918858499817835}, {1.4628571428571429, -0.38039147055604844},
+    {1.4463276836158192, -0.3690277119057333}, {1.4301675977653632, -0.35779163863880753},
+    {1.4143646408839778, -0.34668041321373666}, {1.3989071038251366, -0.33569129163814154},
+    {1.3837837837837839, -0.3248216194012377}, {1.3689839572192513, -0.3140688276249758},
+    {1.3544973544973544, -0.30343042941992004}, {1.3403141361256545, -0.2929040164329327},
+    {1.3264248704663213, -0.28248725557467697}, {1.3128205128205128, -0.27217788591581565},
+    {1.299492385786802, -0.2619737157415739}, {1.2864321608040201, -0.2518726197550701},
+    {1.2736318407960199, -0.2418725364204867}, {1.2610837438423645, -0.23197146543777517},
+    {1.248780487804878, -0.2221674653411543}, {1.2367149758454106, -0.21245865121419336},
+    {1.2248803827751196, -0.20284319251475144}, {1.2132701421800949, -0.19331931100349606},
+    {1.2018779342723005, -0.18388527877013738}, {1.1906976744186046, -0.17453941635189965},
+    {1.1797235023041475, -0.16528009093910292}, {1.1689497716894977, -0.1561057146630616},
+    {1.158371040723982, -0.14701474296180975}, {1.147982062780269, -0.1380056730194437},
+    {1.1377777777777778, -0.12907704227514236}, {1.1277533039647578, -0.12022742699815989},
+    {1.1179039301310043, -0.11145544092532278}, {1.1082251082251082, -0.10275973395776894},
+    {1.0987124463519313, -0.09413899091386191}, {1.0893617021276596, -0.08559193033540353},
+    {1.080168776371308, -0.0771173033444312}, {1.0711297071129706, -0.06871389254805173},
+    {1.062240663900415, -0.06038051098890748}, {1.0534979423868314, -0.0521160011390141},
+    {1.0448979591836736, -0.04391923393483558}, {1.0364372469635628, -0.03578910785158529},
+    {1.0281124497991967, -0.02772454801485477}, {1.0199203187250996, -0.019724505347778573},
+    {1.0118577075098814, -0.011787955752042173}, {1.003921568627451, -0.003913899321136315},
+};
+// 2^(j/64)
+static __constant__ double PNL_EXP_TAB[64] = {
+    1.0, 1.0108892860517005, 1.0218971486541166, 1.0330248790212284,
+    1.0442737824274138, 1.0556451783605572, 1.0671404006768237, 1.0787607977571199,
+    1.0905077326652577, 1.102382583307841, 1.1143867425958924, 1.1265216186082418,
+    1.1387886347566916, 1.1511892299529827, 1.1637248587775775, 1.1763969916502812,
+    1.189207115002721, 1.202156731452703, 1.215247359980469, 1.22848053610687,
+    1.241857812073484, 1.255380757024691, 1.2690509571917332, 1.2828700160787783,
+    1.2968395546510096, 1.3109612115247644, 1.3252366431597413, 1.339667524053303,
+    1.3542555469368927, 1.3690024229745905, 1.383909881963832, 1.3989796725383112,
+    1.4142135623730951, 1.42961333839197, 1.4451808069770467, 1.460917794180647,
+    1.4768261459394993, 1.4929077282912648, 1.5091644275934228, 1.5255981507445384,
+    1.5422108254079407, 1.559004400237837, 1.5759808451078865, 1.593142151342267,
+    1.6104903319492543, 1.6280274218573478, 1.645755478153965, 1.6636765803267364,
+    1.681792830507429, 1.7001063537185235, 1.718619298122478, 1.7373338352737062,
+    1.7562521603732995, 1.7753764925265212, 1.7947090750031072, 1.8142521755003989,
+    1.8340080864093424, 1.8539791250833855, 1.8741676341103, 1.8945759815869656,
+    1.9152065613971474, 1.9360617934922943, 1.9571441241754002, 1.978456026387951,
+};
+// ln 2 / 64 = hi + lo with 36 significant bits in hi (n hi is exact for |n| < 2^17), 64 / ln 2
+#define PNL_LN2_64_HI 0.010830424696223417
+#define PNL_LN2_64_LO 2.572804622327669e-14
+#define PNL_64_LN2 92.33248261689366
+
+// ln x, x > 0 normal: x = m 2^k, m in [1/2, 1); j = top six fraction bits of m, u = m / c_j - 1 (one FMA, |u| <= 2^-7),
+// ln x = k ln 2 + ln c_j + log1p(u), log1p by its series to u^7 (next term 2^-56 / 8).
+// Exponent and mantissa are taken apart with integer operations on the high word and int <-> double conversions go through
+// the 2^52 trick: v_frexp_*_f64, v_ldexp_f64, v_rndne_f64 and the f64 conversions issue at a quarter of the FMA rate.
 __device__ __forceinline__ double pnl_log(double x) {
-    double m = __builtin_amdgcn_frexp_mant(x);           // [0.5, 1)
-    int k = __builtin_amdgcn_frexp_exp(x);
-    const bool low = m < 0.70710678118654752440;
-    m = low ? m+m : m;
-    k = low ? k-1 : k;
-    const double a = m-1.0, b = m+1.0;
-    double r = __builtin_amdgcn_rcp(b);
-    r = __builtin_fma(__builtin_fma(-b, r, 1.0), r, r);
-    r = __builtin_fma(__builtin_fma(-b, r, 1.0), r, r);
-    double f = a*r;
-    f = __builtin_fma(__builtin_fma(-f, b, a), r, f);
-    const double z = f*f;
-    double p = 1.0/21.0;
-    p = __builtin_fma(p, z, 1.0/19.0);
-    p = __builtin_fma(p, z, 1.0/17.0);
-    p = __builtin_fma(p, z, 1.0/15.0);
-    p = __builtin_fma(p, z, 1.0/13.0);
-    p = __builtin_fma(p, z, 1.0/11.0);
-    p = __builtin_fma(p, z, 1.0/9.0);
-    p = __builtin_fma(p, z, 1.0/7.0);
-    p = __builtin_fma(p, z, 1.0/5.0);
-    p = __builtin_fma(p, z, 1.0/3.0);
-    const double lm = __builtin_fma(f+f, z*p, f+f);       // 2 f + 2 f^3 (1/3 + ...)
-    const double kd = (double)k;
-    return __builtin_fma(kd, 6.93147180369123816490e-01, __builtin_fma(kd, 1.90821492927058770002e-10, lm));
+    const int hi = __double2hiint(x);
+    const double m = __hiloint2double((hi & 0x800fffff) | 0x3fe00000, __double2loint(x));
+    const int j = (hi >> 14) & 63;
+    // k = biased exponent - 1022 as a double: 2^52 + 2^31 + k has the low word k ^ 0x80000000
+    const double kd = __hiloint2double(0x43300000, (((hi >> 20) & 0x7ff)-1022) ^ 0x80000000)-4503601774854144.0;
+    const double u = __builtin_fma(m, PNL_LOG_TAB[j][0], -1.0);
+    double p = 1.0/7.0;
+    p = __builtin_fma(p, u, -1.0/6.0);
+    p = __builtin_fma(p, u, 0.2);
+    p = __builtin_fma(p, u, -0.25);
+    p = __builtin_fma(p, u, 1.0/3.0);
+    p = __builtin_fma(p, u, -0.5);
+    p = __builtin_fma(p*u, u, u);
+    return __builtin_fma(kd, 6.93147180369123816490e-01, __builtin_fma(kd, 1.90821492927058770002e-10, PNL_LOG_TAB[j][1]+p));
 }
 
-// exp y, |y| < 700: y = n ln 2 + r, |r| <= 0.347, Taylor polynomial to r^13, scaled by 2^n
+// exp y, |y| < 700: y = n ln 2 / 64 + r, |r| <= ln 2 / 128, exp y = 2^(n >> 6) 2^((n & 63)/64) exp r, exp r to r^5 (next 3e-17);
+// n = rint(y 64 / ln 2) from the low word of y 64 / ln 2 + 1.5 2^52, the power of two added to the exponent field (the result
+// is a normal number: kernel values, |y| < 700)
 __device__ __forceinline__ double pnl_exp(double y) {
-    const double n = __builtin_rint(y*1.44269504088896338700);
-    double r = __builtin_fma(-n, 6.93147180369123816490e-01, y);
-    r = __builtin_fma(-n, 1.90821492927058770002e-10, r);
-    double p = 1.0/6227020800.0;
-    p = __builtin_fma(p, r, 1.0/479001600.0);
-    p = __builtin_fma(p, r, 1.0/39916800.0);
-    p = __builtin_fma(p, r, 1.0/3628800.0);
-    p = __builtin_fma(p, r, 1.0/362880.0);
-    p = __builtin_fma(p, r, 1.0/40320.0);
-    p = __builtin_fma(p, r, 1.0/5040.0);
-    p = __builtin_fma(p, r, 1.0/720.0);
-    p = __builtin_fma(p, r, 1.0/120.0);
+    const double big = __builtin_fma(y, PNL_64_LN2, 6755399441055744.0);
+    const int ni = __double2loint(big);
+    const double n = big-6755399441055744.0;
+    double r = __builtin_fma(-n, PNL_LN2_64_HI, y);
+    r = __builtin_fma(-n, PNL_LN2_64_LO, r);
+    double p = 1.0/120.0;
     p = __builtin_fma(p, r, 1.0/24.0);
     p = __builtin_fma(p, r, 1.0/6.0);
     p = __builtin_fma(p, r, 0.5);
     p = __builtin_fma(p, r, 1.0);
     p = __builtin_fma(p, r, 1.0);
-    return __builtin_amdgcn_ldexp(p, (int)n);
+    const double v = p*PNL_EXP_TAB[ni & 63];
+    return __hiloint2double(__double2hiint(v)+((ni >> 6) << 20), __double2loint(v));
 }
 
+// ---- kernel function gamma(|x-y|^2)   (KC:75-294) ----------------------------------------------------------------------
 // KT: 0 general (pow / indicator / peridynamic, horizon test), 1 fractional with exponent -qm/4, qm a run-time (wave-uniform)
 // value, 2 the same with qm == 6 known at compile time (s = 1/2 in 2D): no branch per evaluation, so the compiler
 // interleaves the dependent chains of the independent evaluations of a pair.

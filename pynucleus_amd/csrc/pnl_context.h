@@ -26,6 +26,11 @@ struct DevBuf {
 struct pnl_context {
     int device = 0;
     hipStream_t own_stream = nullptr, stream = nullptr;
+    // side streams for the per-class passes of a variable order (work list, touching pairs, boundary): the passes only add
+    // to A / the diagonal blocks with atomics, so they may overlap; each fills the other's tail (ClassFork in pnl_hip.hip)
+    static constexpr int NAUX = 4;
+    hipStream_t aux[NAUX] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev_fork = nullptr, ev_join[NAUX] = {nullptr, nullptr, nullptr, nullptr};
     std::string err;
     // host copies
     int dim = 0, nv = 0, nc = 0, dpe = 0, dpv = 0, dped = 0, N = 0, nb = 0, qmax = -1;
@@ -67,7 +72,7 @@ struct pnl_context {
     DevBuf b_kcls, b_fcls, b_uni, b_tilecls, b_ttwphif;
     // block-slot storage (pnl_tile2.h): padded column offsets of the blocks, row offsets, copies (block, slot) of every DoF,
     // the tiles that several order classes visit, the storage itself (allocated by the first assembly that uses it)
-    DevBuf b_scolbase, b_srowoff, b_cpoff, b_cpslot, b_cprow, b_foldtab, b_multitiles, b_slotA;
+    DevBuf b_scolbase, b_srowoff, b_cpoff, b_cpslot, b_cprow, b_foldtab, b_bkcls, b_bfcls, b_multitiles, b_slotA;
     int slot_S = 0, n_multitiles = 0;
     long long slot_total = 0;         // doubles
     // row slab of a rank (pnl_set_row_slab, pnl_slab.hip)
@@ -77,6 +82,8 @@ struct pnl_context {
     bool slot_full_list = false;      // the current tile list is the whole upper block triangle (pnl_assemble_dense)
     bool slot_used = false;           // the tile kernels of the current assembly wrote the block-slot storage
     std::vector<DevKernel> kcls_host;
+    std::vector<DevKernel> bkcls_host;
+    std::vector<DevFormula> bfcls_host;
     std::vector<DevFormula> fcls_host;
     int uni_off[5] = {-1, -1, -1, -1, -1}, uni_np[5] = {0, 0, 0, 0, 0};
     H2Dev h2;

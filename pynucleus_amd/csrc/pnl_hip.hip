@@ -426,18 +426,51 @@ int launch_pure(pnl_context *ctx, double *A, int64_t ldA) {
     return PNL_OK;
 }
 
-// counting sort of a work-list region by order, then the sorted evaluation (k_worklist_lane / k_worklist_sorted)
+// The per-class passes of a variable order run on side streams (pnl_context::aux): fork from the caller's stream, class k on
+// stream k mod NAUX (ctx->stream is redirected while a class is being launched), join back.  One class: nothing happens.
+struct ClassFork {
+    pnl_context *ctx;
+    hipStream_t main;
+    bool on, used[pnl_context::NAUX] = {false, false, false, false};
+    ClassFork(pnl_context *c, int nclasses) : ctx(c), main(c->stream), on(nclasses > 1 && !getenv("PNL_NO_FORK")) {
+        if (on) (void)hipEventRecord(ctx->ev_fork, main);
+    }
+    void use(int k) {
+        if (!on) return;
+        const int j = k % pnl_context::NAUX;
+        if (!used[j]) { (void)hipStreamWaitEvent(ctx->aux[j], ctx->ev_fork, 0); used[j] = true; }
+        ctx->stream = ctx->aux[j];
+    }
+    void join() {
+        if (!on) return;
+        ctx->stream = main;
+        for (int j = 0; j < pnl_context::NAUX; j++)
+            if (used[j]) {
+                (void)hipEventRecord(ctx->ev_join[j], ctx->aux[j]);
+                (void)hipStreamWaitEvent(main, ctx->ev_join[j], 0);
+                used[j] = false;
+            }
+        on = false;
+    }
+    ~ClassFork() { join(); }
+};
+
+// counting sort of a work-list region by order, then the sorted evaluation (k_worklist_lane / k_worklist_sorted);
+// region: which copy of the sort buffers to use (passes that may run concurrently need their own)
 template <int DIM, int DPE, int KT>
-int run_worklist(pnl_context *ctx, const int4 *wl, const unsigned *wlc, unsigned cap, double *A, int64_t ldA, bool sym) {
+int run_worklist(pnl_context *ctx, const int4 *wl, const unsigned *wlc, unsigned cap, double *A, int64_t ldA, bool sym, int region = 0,
+                 int nregions = 1) {
     int rc;
-    if ((rc = ensure(ctx, ctx->b_wlsorted, (size_t)cap*sizeof(int4)))) return rc;
-    if ((rc = ensure(ctx, ctx->b_wlaux, sizeof(unsigned)*(4*(PNL_WL_BINS+1))))) return rc;
-    unsigned *hist = (unsigned*)ctx->b_wlaux.p, *offs = hist+(PNL_WL_BINS+1), *coff = offs+(PNL_WL_BINS+1), *cursor = coff+(PNL_WL_BINS+1);
+    if ((rc = ensure(ctx, ctx->b_wlsorted, (size_t)cap*nregions*sizeof(int4)))) return rc;
+    if ((rc = ensure(ctx, ctx->b_wlaux, sizeof(unsigned)*(4*(PNL_WL_BINS+1))*nregions))) return rc;
+    unsigned *hist = (unsigned*)ctx->b_wlaux.p+(size_t)region*4*(PNL_WL_BINS+1), *offs = hist+(PNL_WL_BINS+1), *coff = offs+(PNL_WL_BINS+1),
+             *cursor = coff+(PNL_WL_BINS+1);
+    int4 *wlsorted = (int4*)ctx->b_wlsorted.p+(size_t)region*cap;
     HIPCHK(ctx, hipMemsetAsync(hist, 0, sizeof(unsigned)*(PNL_WL_BINS+1), ctx->stream));
     hipLaunchKernelGGL(k_wl_hist, dim3(512), dim3(PNL_NTHREADS), 0, ctx->stream, wl, wlc, cap, hist);
     hipLaunchKernelGGL(k_wl_scan, dim3(1), dim3(64), 0, ctx->stream, (const unsigned*)hist, offs, coff, cursor);
     hipLaunchKernelGGL(k_wl_scatter, dim3(512), dim3(PNL_NTHREADS), 0, ctx->stream, wl, wlc, cap, (const unsigned*)offs, cursor,
-                       (int4*)ctx->b_wlsorted.p);
+                       wlsorted);
     const int st = 4+DPE;
     const int tab_max = (60*1024)/(st*(int)sizeof(double));
     const size_t lds = (size_t)tab_max*st*sizeof(double);
@@ -450,9 +483,9 @@ int run_worklist(pnl_context *ctx, const int4 *wl, const unsigned *wlc, unsigned
 #endif
     if (ctx->wl_lane)
         hipLaunchKernelGGL((k_worklist_lane<DIM, DPE, KT, false>), dim3(256*4), dim3(PNL_NTHREADS), 0, ctx->stream, ctx->P,
-                           (const int4*)ctx->b_wlsorted.p, (const unsigned*)offs, A, (long long)ldA, (double*)ctx->b_D.p, SparseOut{},
+                           (const int4*)wlsorted, (const unsigned*)offs, A, (long long)ldA, (double*)ctx->b_D.p, SparseOut{},
                            dbg | (sym ? 8 : 0), ClusterTiles{});
-    hipLaunchKernelGGL(wfun, dim3(256*2), dim3(PNL_NTHREADS), lds, ctx->stream, ctx->P, (const int4*)ctx->b_wlsorted.p,
+    hipLaunchKernelGGL(wfun, dim3(256*2), dim3(PNL_NTHREADS), lds, ctx->stream, ctx->P, (const int4*)wlsorted,
                        (const unsigned*)offs, (const unsigned*)coff, A, (long long)ldA, (double*)ctx->b_D.p, tab_max,
                        SparseOut{}, PNL_WL_BINS-1, nmin | (sym ? 1 << 16 : 0), ClusterTiles{});
     HIPCHK(ctx, hipGetLastError());
@@ -571,8 +604,10 @@ int launch_singular(pnl_context *ctx, double *A, int64_t ldA, int cell_begin, in
     return PNL_OK;
 }
 
+// what: 1 distant pairs, 2 touching pairs, 3 both; bkcls / bfcls: class tables for the one-launch distant pass of a variable order
 template <int DIM, int DPE, int KT>
-int launch_boundary(pnl_context *ctx, int cell_begin, int cell_end) {
+int launch_boundary(pnl_context *ctx, int cell_begin, int cell_end, int what = 3, const DevKernel *bkcls = nullptr,
+                    const DevFormula *bfcls = nullptr, bool all_fast = false) {
     if (ctx->nb == 0 || cell_end <= cell_begin) return PNL_OK;
     const int ncell = cell_end-cell_begin;
     const int gx = (ncell+PNL_NTHREADS-1)/PNL_NTHREADS;
@@ -581,13 +616,16 @@ int launch_boundary(pnl_context *ctx, int cell_begin, int cell_end) {
     int per = getenv("PNL_BND_PER") ? atoi(getenv("PNL_BND_PER")) : 16;
     while (per > 1 && (long long)gx*((ctx->nb+per-1)/per) < 4096) per >>= 1;
     const int chunks = (ctx->nb+per-1)/per;
-    if (ctx->P.bkn.fast)
-        hipLaunchKernelGGL((k_boundary_distant<DIM, DPE, 1>), dim3(gx, chunks), dim3(PNL_NTHREADS), 0, ctx->stream, ctx->P,
-                           (double*)ctx->b_D.p, cell_begin, cell_end, per);
-    else
-        hipLaunchKernelGGL((k_boundary_distant<DIM, DPE, 0>), dim3(gx, chunks), dim3(PNL_NTHREADS), 0, ctx->stream, ctx->P,
-                           (double*)ctx->b_D.p, cell_begin, cell_end, per);
-    HIPCHK(ctx, hipGetLastError());
+    if (what & 1) {
+        if (bkcls ? all_fast : ctx->P.bkn.fast)
+            hipLaunchKernelGGL((k_boundary_distant<DIM, DPE, 1>), dim3(gx, chunks), dim3(PNL_NTHREADS), 0, ctx->stream, ctx->P,
+                               (double*)ctx->b_D.p, cell_begin, cell_end, per, bkcls, bfcls);
+        else
+            hipLaunchKernelGGL((k_boundary_distant<DIM, DPE, 0>), dim3(gx, chunks), dim3(PNL_NTHREADS), 0, ctx->stream, ctx->P,
+                               (double*)ctx->b_D.p, cell_begin, cell_end, per, bkcls, bfcls);
+        HIPCHK(ctx, hipGetLastError());
+    }
+    if (what & 2)
     for (int s = 0; s < DIM; s++) {
         const int np = ctx->C().n_bpairs[s];
         if (!np) continue;
@@ -602,6 +640,16 @@ int launch_boundary(pnl_context *ctx, int cell_begin, int cell_end) {
         HIPCHK(ctx, hipGetLastError());
     }
     return PNL_OK;
+}
+
+// block-slot storage of the one-sided operator (pnl_tile2.h): allocated when the device has room for it next to the caller's matrix
+bool slot_storage_ready(pnl_context *ctx) {
+    if (ctx->nonsym || getenv("PNL_NO_SLOT")) return false;
+    size_t free_b = 0, total_b = 0;
+    const size_t need = sizeof(double)*(size_t)ctx->slot_total;
+    if (ctx->b_slotA.bytes >= need) return true;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b <= need+(size_t(2) << 30)) return false;
+    return ensure(ctx, ctx->b_slotA, need) == PNL_OK;
 }
 
 // dim 2, dpe 6: ONE launch of the uniform-tile kernels per order and ONE of the general P2 tile kernel over the tiles of all
@@ -634,15 +682,10 @@ int launch_tiles_single(pnl_context *ctx, double *A, int64_t ldA, int cell_begin
     // block-slot storage when the whole upper block triangle is assembled by this call and mirrored afterwards
     SlotOut SO{};
     ctx->slot_used = false;
-    if (slot_ok && !ctx->nonsym && !getenv("PNL_NO_SLOT")) {
-        size_t free_b = 0, total_b = 0;
-        const size_t need = sizeof(double)*(size_t)ctx->slot_total;
-        if (ctx->b_slotA.bytes >= need || (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > need+(size_t(2) << 30))) {
-            if ((rc = ensure(ctx, ctx->b_slotA, need))) return rc;
-            SO = slot_out(ctx);
-            ctx->slot_used = true;
-            if (var && (rc = pnl2_zero_slot_tiles(ctx, SO))) return rc;
-        }
+    if (slot_ok && slot_storage_ready(ctx)) {
+        SO = slot_out(ctx);
+        ctx->slot_used = true;
+        if (var && (rc = pnl2_zero_slot_tiles(ctx, SO))) return rc;
     }
     HIPCHK(ctx, hipEventRecord(ctx->ev[7], ctx->stream));
     ctx->pure_launched = false;
@@ -659,17 +702,27 @@ int launch_tiles_single(pnl_context *ctx, double *A, int64_t ldA, int cell_begin
     // block-slot storage: A = A' + A'^T is formed now (it overwrites A); the work-list kernels then write both images
     if (ctx->slot_used && (rc = pnl2_fold_mirror(ctx, SO, A, ldA))) return rc;
     const bool sym = ctx->symflush || ctx->slot_used;
-    for (int k = 0; k < ncls; k++) {
-        ctx->cur = k;
-        refresh_tables(ctx);
-        const int4 *wl = (const int4*)ctx->b_wl.p+(size_t)k*ctx->wl_cap_each;
-        const unsigned *wlc = (const unsigned*)ctx->b_wlcount.p+k;
-        rc = ctx->P.k.fast ? run_worklist<DIM, DPE, 1>(ctx, wl, wlc, ctx->wl_cap_each, A, ldA, sym)
-                           : run_worklist<DIM, DPE, 0>(ctx, wl, wlc, ctx->wl_cap_each, A, ldA, sym);
-        if (rc) { ctx->cur = 0; return rc; }
+    {
+        ClassFork fork(ctx, ncls);
+        for (int k = 0; k < ncls; k++) {
+            ctx->cur = k;
+            refresh_tables(ctx);
+            fork.use(k);
+            const int4 *wl = (const int4*)ctx->b_wl.p+(size_t)k*ctx->wl_cap_each;
+            const unsigned *wlc = (const unsigned*)ctx->b_wlcount.p+k;
+            rc = ctx->P.k.fast ? run_worklist<DIM, DPE, 1>(ctx, wl, wlc, ctx->wl_cap_each, A, ldA, sym, k, ncls)
+                               : run_worklist<DIM, DPE, 0>(ctx, wl, wlc, ctx->wl_cap_each, A, ldA, sym, k, ncls);
+            if (rc) { ctx->cur = 0; return rc; }
+        }
     }
     ctx->cur = 0;
     return PNL_OK;
+}
+
+// the whole upper block triangle is assembled by this call and mirrored afterwards
+bool slot_eligible(const pnl_context *ctx, int cell_begin, int cell_end, int flags) {
+    return ctx->dim == 2 && ctx->dpe == 6 && ctx->slot_full_list && ctx->slab_rows == 0 && cell_begin == 0 && cell_end == ctx->nc &&
+           !(flags & (PNL_FLAG_NO_MIRROR | PNL_FLAG_SYMMETRIC_FLUSH));
 }
 
 template <int DIM, int DPE, int TILE>
@@ -695,8 +748,7 @@ int assemble_impl(pnl_context *ctx, double *A, int64_t ldA, int zero_exterior, i
         ctx->wl_slots = single ? ncls : ncls*norient;
         if constexpr (DIM == 2 && DPE == 6) {
             // the block-slot storage needs every tile of the upper block triangle written by this call, then the fold + mirror pass
-            const bool slot_ok = ctx->slot_full_list && ctx->slab_rows == 0 && cell_begin == 0 && cell_end == ctx->nc &&
-                                 !(flags & (PNL_FLAG_NO_MIRROR | PNL_FLAG_SYMMETRIC_FLUSH));
+            const bool slot_ok = slot_eligible(ctx, cell_begin, cell_end, flags);
             if ((rc = launch_tiles_single<DIM, DPE>(ctx, A, ldA, ctx->tile_cell_filter ? cell_begin : 0, ctx->tile_cell_filter ? cell_end : ctx->nc, slot_ok)))
                 { ctx->cur = 0; ctx->orient = 0; return rc; }
         } else
@@ -725,16 +777,40 @@ int assemble_impl(pnl_context *ctx, double *A, int64_t ldA, int zero_exterior, i
         HIPCHK(ctx, hipGetLastError());
     }
     HIPCHK(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
-    for (int ko = 0; ko < ncls*norient; ko++) {
-        ctx->cur = ko/norient; ctx->orient = ko%norient;
-        refresh_tables(ctx);
-        rc = ctx->P.k.fast ? launch_singular<DIM, DPE, 1>(ctx, A, ldA, cell_begin, cell_end)
-                           : launch_singular<DIM, DPE, 0>(ctx, A, ldA, cell_begin, cell_end);
-        if (rc) { ctx->cur = 0; ctx->orient = 0; return rc; }
+    {
+        ClassFork fork(ctx, ncls*norient);
+        for (int ko = 0; ko < ncls*norient; ko++) {
+            ctx->cur = ko/norient; ctx->orient = ko%norient;
+            refresh_tables(ctx);
+            fork.use(ko);
+            rc = ctx->P.k.fast ? launch_singular<DIM, DPE, 1>(ctx, A, ldA, cell_begin, cell_end)
+                               : launch_singular<DIM, DPE, 0>(ctx, A, ldA, cell_begin, cell_end);
+            if (rc) { ctx->cur = 0; ctx->orient = 0; return rc; }
+        }
     }
     ctx->orient = 0;
     HIPCHK(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
-    if (zero_exterior)
+    if (zero_exterior) {
+        // variable order: the distant (cell, facet) pairs of ALL classes in one launch with per-class kernel / order-formula
+        // tables; the touching pairs per class (their rules are per class), on side streams
+        const bool one_pass = ncls > 1 && ctx->nlab > 0 && !getenv("PNL_BND_PER_CLASS");
+        bool all_fast = true;
+        if (one_pass) {
+            std::vector<DevKernel> &bk = ctx->bkcls_host;
+            std::vector<DevFormula> &bf = ctx->bfcls_host;
+            bk.resize(ncls); bf.resize(ncls);
+            for (int k = 0; k < ncls; k++) {
+                ctx->cur = k;
+                refresh_tables(ctx);
+                bk[k] = ctx->P.bkn; bf[k] = ctx->P.bqo;
+                all_fast = all_fast && ctx->P.bkn.fast;
+            }
+            if ((rc = ensure(ctx, ctx->b_bkcls, sizeof(DevKernel)*ncls))) return rc;
+            if ((rc = ensure(ctx, ctx->b_bfcls, sizeof(DevFormula)*ncls))) return rc;
+            HIPCHK(ctx, hipMemcpyAsync(ctx->b_bkcls.p, bk.data(), sizeof(DevKernel)*ncls, hipMemcpyHostToDevice, ctx->stream));
+            HIPCHK(ctx, hipMemcpyAsync(ctx->b_bfcls.p, bf.data(), sizeof(DevFormula)*ncls, hipMemcpyHostToDevice, ctx->stream));
+        }
+        ClassFork fork(ctx, ncls);
         for (int k = 0; k < ncls; k++) {
             ctx->cur = k;
             refresh_tables(ctx);
@@ -742,8 +818,13 @@ int assemble_impl(pnl_context *ctx, double *A, int64_t ldA, int zero_exterior, i
                 ctx->cur = 0;
                 return fail(ctx, PNL_ERR_STATE, "zero_exterior needs boundary facets, boundary kernel and order formula");
             }
-            if ((rc = launch_boundary<DIM, DPE, 0>(ctx, cell_begin, cell_end))) { ctx->cur = 0; return rc; }
+            if (one_pass && k == 0 &&
+                (rc = launch_boundary<DIM, DPE, 0>(ctx, cell_begin, cell_end, 1, (const DevKernel*)ctx->b_bkcls.p, (const DevFormula*)ctx->b_bfcls.p,
+                                                   all_fast))) { ctx->cur = 0; return rc; }
+            fork.use(k);
+            if ((rc = launch_boundary<DIM, DPE, 0>(ctx, cell_begin, cell_end, one_pass ? 2 : 3))) { ctx->cur = 0; return rc; }
         }
+    }
     ctx->cur = 0;
     HIPCHK(ctx, hipEventRecord(ctx->ev[4], ctx->stream));
     if (ctx->slab_rows == 0) {
@@ -1425,6 +1506,11 @@ int pnl_create(int device_id, pnl_context **out) {
     ctx->device = device_id;
     if ((e0 = hipStreamCreate(&ctx->own_stream)) != hipSuccess) { delete ctx; return hiperr("hipStreamCreate", e0); }
     ctx->stream = ctx->own_stream;
+    for (auto &st : ctx->aux)
+        if ((e0 = hipStreamCreateWithFlags(&st, hipStreamNonBlocking)) != hipSuccess) { delete ctx; return hiperr("hipStreamCreateWithFlags", e0); }
+    if (hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess) { delete ctx; return PNL_ERR_HIP; }
+    for (auto &e : ctx->ev_join)
+        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { delete ctx; return PNL_ERR_HIP; }
     for (auto &e : ctx->ev)
         if (hipEventCreate(&e) != hipSuccess) { delete ctx; return PNL_ERR_HIP; }
     for (auto &pr : ctx->kev)
@@ -1450,6 +1536,9 @@ void pnl_destroy(pnl_context *ctx) {
     for (auto &pr : ctx->kev)
         for (auto &e : pr)
             if (e) (void)hipEventDestroy(e);
+    for (auto &st : ctx->aux) if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
+    if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+    for (auto &e : ctx->ev_join) if (e) (void)hipEventDestroy(e);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     for (auto *c : ctx->cls) delete c;
     delete ctx;
@@ -1878,6 +1967,19 @@ int pnl_assemble_dense(pnl_context *ctx, double *A, int64_t ldA, int zero_exteri
     if (getenv("PNL_FORCE_SYMFLUSH")) flags |= PNL_FLAG_SYMMETRIC_FLUSH;     // debug: both sides written by the flush, no mirror pass
     ctx->slot_full_list = true;
     return dispatch(ctx, A, ldA, zero_exterior, (int)tiles.size(), cell_begin, cell_end, flags);
+}
+
+int pnl_dense_overwrites(pnl_context *ctx, int cell_begin, int cell_end, int flags) {
+    if (!ctx) return PNL_ERR_INVALID;
+    int rc;
+    if ((rc = check_ready(ctx))) return rc;
+    if ((rc = finalize(ctx))) return rc;
+    if (getenv("PNL_FORCE_SYMFLUSH")) return 0;
+    const bool full = ctx->slot_full_list;
+    ctx->slot_full_list = true;                          // what pnl_assemble_dense sets
+    const bool ok = slot_eligible(ctx, cell_begin, cell_end, flags) && slot_storage_ready(ctx);
+    ctx->slot_full_list = full;
+    return ok ? 1 : 0;
 }
 
 int pnl_assemble_dense_tiles(pnl_context *ctx, double *A, int64_t ldA, int zero_exterior, int ntiles, const int32_t *tiles_host,

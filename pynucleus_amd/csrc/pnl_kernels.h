@@ -2426,7 +2426,8 @@ k_singular_pairs(const DevProblem P, const int2 *__restrict__ pairs, int npairs_
 // into the kernel exponent (P.bkn = Gamma_b with exponent - 1/2), so one rsqrt-type evaluation does both.
 template <int DIM, int DPE, int KT>
 __global__ void __launch_bounds__(PNL_NTHREADS)
-k_boundary_distant(const DevProblem P, double *__restrict__ Dglob, int cell_begin, int cell_end, int facets_per_chunk) {
+k_boundary_distant(const DevProblem P, double *__restrict__ Dglob, int cell_begin, int cell_end, int facets_per_chunk,
+                   const DevKernel *__restrict__ bkcls, const DevFormula *__restrict__ bfcls) {
     constexpr int NV = DIM+1, NC = NV*DIM, NF = DIM, ND = DPE*(DPE+1)/2;
     const int c = cell_begin+blockIdx.x*PNL_NTHREADS+threadIdx.x;
     const bool active = c < cell_end;
@@ -2451,8 +2452,15 @@ k_boundary_distant(const DevProblem P, double *__restrict__ Dglob, int cell_begi
     const int f1 = min(P.nb, f0+facets_per_chunk);
     const int lab1 = P.cur_class >= 0 ? P.clabel[cc] : 0;
     for (int f = f0; f < f1; f++) {
-        // variable order: this launch handles one order class; the test comes first, a pass skips most facets with two loads
-        if (P.cur_class >= 0 && P.cls_of[lab1*P.nlab+P.blabel[f]] != P.cur_class) continue;
+        // variable order: with class tables (bkcls, bfcls) ONE launch integrates every (cell, facet) with the kernel and order
+        // formula of the pair's class; without them this launch handles class P.cur_class and skips the other pairs
+        DevKernel bkn = P.bkn;
+        DevFormula bqo = P.bqo;
+        if (P.cur_class >= 0) {
+            const int kc = P.cls_of[lab1*P.nlab+P.blabel[f]];
+            if (bkcls) { bkn = bkcls[kc]; bqo = bfcls[kc]; }
+            else if (kc != P.cur_class) continue;
+        }
         // facet data: wave-uniform, precomputed once per upload (centre, unit normal, length, logs)
         double fv[NF*DIM], fc[DIM], nrm[DIM];
         int fvid[NF];
@@ -2473,7 +2481,7 @@ k_boundary_distant(const DevProblem P, double *__restrict__ Dglob, int cell_begi
         double dc2 = 0.;
 #pragma unroll
         for (int d = 0; d < DIM; d++) dc2 += (cen[d]-fc[d])*(cen[d]-fc[d]);
-        const int q = quad_order_fast(P.bqo, h1, vol2, lh1, lh2, L1, L2, Ld1, Ld2, dc2);
+        const int q = quad_order_fast(bqo, h1, vol2, lh1, lh2, L1, L2, Ld1, Ld2, dc2);
         if (q > P.qmax || q > PNL_MAXQ) { overflow++; continue; }
         const int off = P.off[q], n = P.off[q+1]-off;
         const int foff = P.foff[q], nf = P.foff[q+1]-foff;
@@ -2484,7 +2492,7 @@ k_boundary_distant(const DevProblem P, double *__restrict__ Dglob, int cell_begi
         const double *__restrict__ fw = P.fw+foff;
         npairs++;
         nevals += (unsigned long long)n*nf;
-        const double vol = vol1*vol2*kern_scale<KT>(P.bkn);
+        const double vol = vol1*vol2*kern_scale<KT>(bkn);
         for (int k = 0; k < n; k++) {
             double x[DIM];
 #pragma unroll
@@ -2507,7 +2515,7 @@ k_boundary_distant(const DevProblem P, double *__restrict__ Dglob, int cell_begi
                     if (DIM == 2) nw = __builtin_fma(nrm[d], wv, nw);
                 }
                 if (DIM != 2) nw = 1.;
-                r = __builtin_fma(fw[m]*nw, kern_eval<KT>(P.bkn, d2), r);
+                r = __builtin_fma(fw[m]*nw, kern_eval<KT>(bkn, d2), r);
             }
             r *= w[k]*vol;
             int e = 0;
