@@ -400,7 +400,7 @@ void refresh_tables(pnl_context *ctx) {
 
 
 template <int DIM, int DPE, int KT>
-int launch_pure(pnl_context *ctx, double *A, int64_t ldA) {
+int launch_pure(pnl_context *ctx, double *A, int64_t ldA, const SlotOut &SO) {
     if (ctx->n_pure == 0) return PNL_OK;
     constexpr int NP = DIM == 2 ? 3 : 2, ND = DPE*(DPE+1)/2;
     const int acc_stride = acc_stride_of(ctx->nU);
@@ -420,7 +420,7 @@ int launch_pure(pnl_context *ctx, double *A, int64_t ldA) {
     kt_begin(ctx, PNL_K_TILE_UNIFORM2);
     hipLaunchKernelGGL(kfun, dim3(grid), dim3(PNL_NTHREADS), lds, ctx->stream, tile_problem(ctx), (const int2*)ctx->b_tiles.p+ctx->tile_off+ctx->n_mixed,
                        ctx->n_pure, A, (long long)ldA, (double*)(ctx->have_tile_order ? ctx->b_Dt.p : ctx->b_D.p), acc_stride, 2,
-                       (ctx->symflush ? 1 : 0) | pure_abl);
+                       (ctx->symflush ? 1 : 0) | pure_abl, SO);
     kt_end(ctx, PNL_K_TILE_UNIFORM2);
     HIPCHK(ctx, hipGetLastError());
     return PNL_OK;
@@ -507,7 +507,7 @@ int ensure_worklist(pnl_context *ctx, double pairs, int regions) {
 }
 
 template <int DIM, int DPE, int TILE, int KT>
-int launch_tiles(pnl_context *ctx, int wl_slot, double *A, int64_t ldA, int cell_begin, int cell_end) {
+int launch_tiles(pnl_context *ctx, int wl_slot, double *A, int64_t ldA, int cell_begin, int cell_end, const SlotOut &SO = SlotOut{}) {
     using S = TileSmem<DIM, DPE, TILE>;
     HIPCHK(ctx, hipEventRecord(ctx->ev[7], ctx->stream));
     ctx->pure_launched = false;
@@ -516,8 +516,8 @@ int launch_tiles(pnl_context *ctx, int wl_slot, double *A, int64_t ldA, int cell
         // order-2 uniform tiles: k_tile_pure, or (PNL_PURE_V2=1, 2D P1) the pipelined k_tile_uniform<3, 3>
         if (DIM == 2 && DPE == 3 && getenv("PNL_PURE_V2") && ctx->uni_off[2] >= 0 && ctx->uni_np[2] == 3)
             rc = pnl2_launch_uniform(ctx, KT, tile_problem(ctx), (const int2*)ctx->b_tiles.p+ctx->tile_off+ctx->n_mixed, nullptr, ctx->n_pure, 2,
-                                     A, ldA, (double*)(ctx->have_tile_order ? ctx->b_Dt.p : ctx->b_D.p), SlotOut{});
-        else rc = launch_pure<DIM, (DPE <= 3 ? DPE : 3), KT>(ctx, A, ldA);
+                                     A, ldA, (double*)(ctx->have_tile_order ? ctx->b_Dt.p : ctx->b_D.p), SO);
+        else rc = launch_pure<DIM, (DPE <= 3 ? DPE : 3), KT>(ctx, A, ldA, SO);
         if (rc) return rc;
         ctx->pure_launched = ctx->n_pure > 0;
         if (DIM == 2 && DPE == 3) {
@@ -526,7 +526,7 @@ int launch_tiles(pnl_context *ctx, int wl_slot, double *A, int64_t ldA, int cell
             for (int q = 3; q <= 4; q++) {
                 const int n = ctx->cls_n_uni[q-2][ctx->cur];
                 if ((rc = pnl2_launch_uniform(ctx, KT, tile_problem(ctx), (const int2*)ctx->b_tiles.p+off, nullptr, n, q, A, ldA,
-                                              (double*)(ctx->have_tile_order ? ctx->b_Dt.p : ctx->b_D.p), SlotOut{}))) return rc;
+                                              (double*)(ctx->have_tile_order ? ctx->b_Dt.p : ctx->b_D.p), SO))) return rc;
                 ctx->pure_launched = ctx->pure_launched || n > 0;
                 off += n;
             }
@@ -558,11 +558,13 @@ int launch_tiles(pnl_context *ctx, int wl_slot, double *A, int64_t ldA, int cell
         hipLaunchKernelGGL(kfun, dim3(grid), dim3(tile_threads(DPE, KT)), lds, ctx->stream, tile_problem(ctx), (const int2*)ctx->b_tiles.p+ctx->tile_off, A,
                            (long long)ldA, (double*)(ctx->have_tile_order ? ctx->b_Dt.p : ctx->b_D.p), cell_begin, cell_end, acc_stride, (int4*)ctx->b_wl.p,
                            wlc, ctx->wl_cap_each, ctx->ablate | (ctx->symflush ? 256 : 0), ntiles, ClusterTiles{},
-                           (unsigned*)ctx->b_tilectr.p);
+                           (unsigned*)ctx->b_tilectr.p, SO);
     kt_end(ctx, PNL_K_TILE_GENERAL);
     HIPCHK(ctx, hipGetLastError());
     HIPCHK(ctx, hipEventRecord(ctx->ev[6], ctx->stream));
-    return run_worklist<DIM, DPE, KT>(ctx, (const int4*)ctx->b_wl.p, wlc, ctx->wl_cap_each, A, ldA, ctx->symflush);
+    // block-slot storage: A = A' + A'^T is formed now (it overwrites A); the work-list kernels then write both images
+    if (SO.A2) { int rc = pnl2_fold_mirror(ctx, SO, A, ldA); if (rc) return rc; }
+    return run_worklist<DIM, DPE, KT>(ctx, (const int4*)ctx->b_wl.p, wlc, ctx->wl_cap_each, A, ldA, ctx->symflush || SO.A2 != nullptr);
 }
 
 template <int DIM, int DPE, int SLOT, int KT>
@@ -721,7 +723,9 @@ int launch_tiles_single(pnl_context *ctx, double *A, int64_t ldA, int cell_begin
 
 // the whole upper block triangle is assembled by this call and mirrored afterwards
 bool slot_eligible(const pnl_context *ctx, int cell_begin, int cell_end, int flags) {
-    return ctx->dim == 2 && ctx->dpe == 6 && ctx->slot_full_list && ctx->slab_rows == 0 && cell_begin == 0 && cell_end == ctx->nc &&
+    // P2: every tile list (several order classes: multi-visit tiles accumulate); P1: one class, every tile visited by one kernel
+    const bool elem = ctx->dpe == 6 || (ctx->dpe == 3 && ctx->cls.size() == 1 && !ctx->nonsym && ctx->use_pure && !getenv("PNL_NO_SLOT_P1"));
+    return ctx->dim == 2 && elem && ctx->slot_full_list && ctx->slab_rows == 0 && cell_begin == 0 && cell_end == ctx->nc &&
            !(flags & (PNL_FLAG_NO_MIRROR | PNL_FLAG_SYMMETRIC_FLUSH));
 }
 
@@ -751,7 +755,12 @@ int assemble_impl(pnl_context *ctx, double *A, int64_t ldA, int zero_exterior, i
             const bool slot_ok = slot_eligible(ctx, cell_begin, cell_end, flags);
             if ((rc = launch_tiles_single<DIM, DPE>(ctx, A, ldA, ctx->tile_cell_filter ? cell_begin : 0, ctx->tile_cell_filter ? cell_end : ctx->nc, slot_ok)))
                 { ctx->cur = 0; ctx->orient = 0; return rc; }
-        } else
+        } else {
+        // 2D P1, one order class: block-slot storage like the P2 path (plain stores instead of 47 GB of fp64 atomics at 48,769
+        // DoFs, fold + mirror instead of zero fill + mirror)
+        SlotOut SO{};
+        ctx->slot_used = false;
+        if (slot_eligible(ctx, cell_begin, cell_end, flags) && slot_storage_ready(ctx)) { SO = slot_out(ctx); ctx->slot_used = true; }
         for (int ko = 0; ko < ncls*norient; ko++) {
             const int k = ko/norient;
             ctx->cur = k; ctx->orient = ko%norient;
@@ -760,10 +769,11 @@ int assemble_impl(pnl_context *ctx, double *A, int64_t ldA, int zero_exterior, i
             if (ctx->n_mixed+ctx->n_pure+ctx->cls_n_uni[1][k]+ctx->cls_n_uni[2][k] == 0) continue;
             const int tb0 = ctx->tile_cell_filter ? cell_begin : 0, tb1 = ctx->tile_cell_filter ? cell_end : ctx->nc;
             // s = 1/2 in 2D (exponent -6/4) has its own instantiation: branch-free evaluations
-            if (ctx->P.k.fast && ctx->P.k.qm == 6 && DPE == 3 && !getenv("PNL_NO_KT2")) rc = launch_tiles<DIM, DPE, TILE, (DPE == 3 ? 2 : 1)>(ctx, ko, A, ldA, tb0, tb1);
-            else rc = ctx->P.k.fast ? launch_tiles<DIM, DPE, TILE, 1>(ctx, ko, A, ldA, tb0, tb1)
-                                    : launch_tiles<DIM, DPE, TILE, 0>(ctx, ko, A, ldA, tb0, tb1);
+            if (ctx->P.k.fast && ctx->P.k.qm == 6 && DPE == 3 && !getenv("PNL_NO_KT2")) rc = launch_tiles<DIM, DPE, TILE, (DPE == 3 ? 2 : 1)>(ctx, ko, A, ldA, tb0, tb1, SO);
+            else rc = ctx->P.k.fast ? launch_tiles<DIM, DPE, TILE, 1>(ctx, ko, A, ldA, tb0, tb1, SO)
+                                    : launch_tiles<DIM, DPE, TILE, 0>(ctx, ko, A, ldA, tb0, tb1, SO);
             if (rc) { ctx->cur = 0; ctx->orient = 0; return rc; }
+        }
         }
     }
     ctx->orient = 0;
@@ -989,7 +999,7 @@ int clusters_tiled_impl(pnl_context *ctx, const pnl_cluster_plan *pl, ClusterTil
         const int grid = std::min(pl->ntiles, 256*std::max(per_cu, 1));
         hipLaunchKernelGGL(kfun, dim3(grid), dim3(tile_threads(DPE, KT)), lds, ctx->stream, ctx->P, (const int2*)nullptr, (double*)nullptr, 0ll,
                            (double*)nullptr, 0, ctx->nc, acc_stride, (int4*)ctx->b_wl.p, (unsigned*)ctx->b_wlcount.p, ctx->wl_cap, 0,
-                           pl->ntiles, CT, (unsigned*)ctx->b_tilectr.p);
+                           pl->ntiles, CT, (unsigned*)ctx->b_tilectr.p, SlotOut{});
         HIPCHK(ctx, hipGetLastError());
     }
     HIPCHK(ctx, hipEventRecord(ctx->ev[6], ctx->stream));
@@ -1458,7 +1468,7 @@ int horizon_impl(pnl_context *ctx, SparseOut S) {
             const int grid = std::min(nt, 256*std::max(per_cu, 1));
             hipLaunchKernelGGL(kfun, dim3(grid), dim3(tile_threads(DPE, KT, true)), lds, ctx->stream, ctx->P, (const int2*)ctx->b_tiles.p+t0,
                                (double*)nullptr, 0ll, (double*)ctx->b_D.p, 0, ctx->nc, acc_stride, (int4*)ctx->b_mp_wl.p,
-                               (unsigned*)ctx->b_wlcount.p, (unsigned)cap, 0, nt, CT, (unsigned*)ctx->b_tilectr.p);
+                               (unsigned*)ctx->b_wlcount.p, (unsigned)cap, 0, nt, CT, (unsigned*)ctx->b_tilectr.p, SlotOut{});
         } else
             hipLaunchKernelGGL((k_fh_pairs<DIM, DPE>), dim3(nt), dim3(PNL_NTHREADS), 0, ctx->stream, ctx->P, (const int2*)ctx->b_tiles.p+t0, T,
                                (int2*)ctx->b_mp_pairs.p, (int4*)ctx->b_mp_wl.p, (unsigned*)ctx->b_wlcount.p, (unsigned)cap);

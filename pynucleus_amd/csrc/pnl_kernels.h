@@ -410,7 +410,7 @@ __global__ void __launch_bounds__(tile_threads(DPE, KT, FH), tile_waves(DPE, KT,
 k_tile_distant(const DevProblem P, const int2 *__restrict__ tiles, double *__restrict__ A, long long ldA,
                double *__restrict__ Dglob, int cell_begin, int cell_end, int acc_stride, int4 *__restrict__ worklist,
                unsigned *__restrict__ wl_count, unsigned wl_cap, int ablate, int ntiles, const ClusterTiles CT,
-               unsigned *__restrict__ tile_ctr) {
+               unsigned *__restrict__ tile_ctr, const SlotOut SO) {
     // debug switches that skip work (evaluation, accumulation, flush) exist only in PNL_DEBUG_ABLATE builds; bit 256 is
     // PNL_FLAG_SYMMETRIC_FLUSH
 #ifdef PNL_DEBUG_ABLATE
@@ -842,6 +842,15 @@ k_tile_distant(const DevProblem P, const int2 *__restrict__ tiles, double *__res
     const int *__restrict__ dofA = CLUSTER ? CT.chunk_dofs+(size_t)ta*CT.chunk_stride : P.blk_dofs+(size_t)ta*P.blk_stride;
     const int *__restrict__ dofB = CLUSTER ? CT.chunk_dofs+(size_t)tb*CT.chunk_stride : P.blk_dofs+(size_t)tb*P.blk_stride;
     if (!(abl & 4)) {
+    if (!CLUSTER && !fh && SO.A2) {
+        // block-slot storage (pnl_tile2.h): this tile owns its nA x nB sub-block of the storage, plain stores of every entry
+        const int ca = SO.colbase[ta], W = SO.S-ca;
+        double *__restrict__ base = SO.A2+SO.rowoff[ta]+(SO.colbase[tb]-ca);
+        for (int t = tid; t < nA*nB; t += NT) {
+            const int r = t/nB, c = t-r*nB;
+            base[(long long)r*W+c] = s_acc[r*acc_stride+c];
+        }
+    } else
     for (int t = tid; t < nA*nB; t += NT) {
         const int r = t/nB, c = t-r*nB;
         const double v = s_acc[r*acc_stride+c];
@@ -903,7 +912,7 @@ k_tile_distant(const DevProblem P, const int2 *__restrict__ tiles, double *__res
 template <int DIM, int DPE, int KT>
 __global__ void __launch_bounds__(PNL_NTHREADS, PNL_PURE_WAVES)
 k_tile_pure(const DevProblem P, const int2 *__restrict__ tiles, int ntiles, double *__restrict__ A, long long ldA,
-            double *__restrict__ Dglob, int acc_stride, int q_uniform, int symflush) {
+            double *__restrict__ Dglob, int acc_stride, int q_uniform, int symflush, const SlotOut SO) {
 #ifndef PNL_DEBUG_ABLATE
     symflush &= 1;                                      // the other bits skip work (debug builds only)
 #endif
@@ -1091,7 +1100,15 @@ k_tile_pure(const DevProblem P, const int2 *__restrict__ tiles, int ntiles, doub
         // ---- flush ----
         const int *__restrict__ dofA = P.blk_dofs+(size_t)ta*P.blk_stride;
         const int *__restrict__ dofB = P.blk_dofs+(size_t)tb*P.blk_stride;
-        if (!(symflush & 64))
+        if (SO.A2) {
+            // block-slot storage (pnl_tile2.h): plain stores of the tile's own sub-block, every entry
+            const int ca = SO.colbase[ta], W = SO.S-ca;
+            double *__restrict__ base = SO.A2+SO.rowoff[ta]+(SO.colbase[tb]-ca);
+            for (int t = tid; t < nA*nB; t += PNL_NTHREADS) {
+                const int r = t/nB, cc = t-r*nB;
+                base[(long long)r*W+cc] = s_acc[r*acc_stride+cc];
+            }
+        } else if (!(symflush & 64))
         for (int t = tid; t < nA*nB; t += PNL_NTHREADS) {
             const int r = t/nB, cc = t-r*nB;
             const double v = s_acc[r*acc_stride+cc];

@@ -70,18 +70,24 @@ k_fold_mirror(const double *__restrict__ A2, const FoldEntry *__restrict__ tab, 
     __shared__ double t1[32][33], t2[32][33];
     __shared__ FoldEntry s_tab[2][PNL_FOLD_TAB+1];
     const unsigned nb = (unsigned)(N+31)/32;
-    const unsigned bid = blockIdx.x;
-    // bid = bi nb - bi (bi-1)/2 + (bj - bi); the grid has less than 2^31 blocks, so 32-bit arithmetic is exact
-    unsigned bi;
+    // 8 x 8 super-blocks of the upper block triangle, 64 consecutive workgroups each: the workgroups in flight share the
+    // storage rows of 8 row ranges and 8 column ranges (pages, DRAM rows, L2 lines of the XCD) instead of sweeping one block
+    // row against thousands of unrelated column ranges
+    const unsigned nbs = (nb+7)/8;
+    const unsigned sbid = blockIdx.x >> 6, inner = blockIdx.x & 63;
+    // sbid = I nbs - I (I-1)/2 + (J - I); the grid has less than 2^31 blocks, so 32-bit arithmetic is exact
+    unsigned I;
     {
-        const float t = 2.f*(float)nb+1.f;
-        const float fb = (t-sqrtf(fmaxf(t*t-8.f*(float)bid, 0.f)))*0.5f;
-        bi = (unsigned)fmaxf(fb, 0.f);
-        if (bi >= nb) bi = nb-1;
-        while (bi > 0 && bi*nb-bi*(bi-1)/2 > bid) bi--;
-        while (bi+1 < nb && (bi+1)*nb-(bi+1)*bi/2 <= bid) bi++;
+        const float t = 2.f*(float)nbs+1.f;
+        const float fb = (t-sqrtf(fmaxf(t*t-8.f*(float)sbid, 0.f)))*0.5f;
+        I = (unsigned)fmaxf(fb, 0.f);
+        if (I >= nbs) I = nbs-1;
+        while (I > 0 && I*nbs-I*(I-1)/2 > sbid) I--;
+        while (I+1 < nbs && (I+1)*nbs-(I+1)*I/2 <= sbid) I++;
     }
-    const unsigned bj = bi+(bid-(bi*nb-bi*(bi-1)/2));
+    const unsigned J = I+(sbid-(I*nbs-I*(I-1)/2));
+    const unsigned bi = 8*I+(inner >> 3), bj = 8*J+(inner & 7);
+    if (bi > bj || bj >= nb) return;                     // lower part of a diagonal super-block, padding of the last one
     const int tid = threadIdx.x, tx = tid & 31, ty = tid >> 5;     // 32 x 8
     if (tid < 2*(PNL_FOLD_TAB+1)) {
         const int side = tid >= PNL_FOLD_TAB+1, k = tid-side*(PNL_FOLD_TAB+1);
