@@ -165,6 +165,10 @@ int pnl_assemble_dense_tiles(pnl_context *ctx, double *A_dev, int64_t ldA, int z
  * column indices strictly increasing per row.  For an SSS_LinearOperator only the strict lower triangle (I > J) is
  * listed and the diagonal lives in its own vector (SSS_LinearOperator_{SCALAR}.pxi:23-60). */
 int pnl_upload_sparsity(pnl_context *ctx, int nnz, const int32_t *indptr_host, const int32_t *indices_host);
+/* the same with the pattern already in device memory (built there by the host layer's getSparseNearField): device-to-device
+ * copies on the context's stream; only the two ends of indptr are checked -- the caller guarantees sorted, in-range rows (use
+ * pnl_upload_sparsity for a validated upload) */
+int pnl_upload_sparsity_device(pnl_context *ctx, int nnz, const int32_t *indptr_dev, const int32_t *indices_dev);
 /* 'interior' loop over the recorded element pairs (NA:1776-1832): pairs[np][2] with c1 <= c2, masks[np][4] = the
  * 256-bit MASK_t of requested entries of the symmetric local matrix (bit k(p,q), p <= q over the 2*dpe local DoFs,
  * buildMasksForClusters NA:260-391).  Panel + quadrature as in pnl_assemble_dense; scatter = addToMatrixElemElemSymMasked

@@ -28,7 +28,7 @@ EXPORTS = ['pnl_create', 'pnl_destroy', 'pnl_error_string', 'pnl_version', 'pnl_
            'pnl_upload_mesh', 'pnl_upload_dofmap', 'pnl_set_kernel', 'pnl_set_order_formula', 'pnl_upload_distant_rules',
            'pnl_upload_singular_rule', 'pnl_upload_boundary', 'pnl_assemble_dense', 'pnl_dense_overwrites', 'pnl_tile_cells',
            'pnl_assemble_dense_tiles', 'pnl_get_counters', 'pnl_get_phase_ms', 'pnl_get_kernel_ms', 'pnl_tree_build', 'pnl_tree_build_blocks', 'pnl_tree_destroy', 'pnl_tree_sizes', 'pnl_tree_get', 'pnl_tree_node_cells', 'pnl_h2_transfer_matrices', 'pnl_nfplan_build', 'pnl_nfplan_destroy', 'pnl_nfplan_sizes', 'pnl_nfplan_get', 'pnl_horizon_pattern', 'pnl_pattern_nnz', 'pnl_pattern_get', 'pnl_pattern_destroy', 'pnl_set_row_slab', 'pnl_diag_blocks_size', 'pnl_get_diag_blocks', 'pnl_slab_matvec', 'pnl_slab_diagonal', 'pnl_gemv', 'pnl_cg_jacobi',
-           'pnl_inv_diagonal', 'pnl_set_classes', 'pnl_select_class', 'pnl_upload_sparsity', 'pnl_assemble_pairs_masked', 'pnl_assemble_boundary_masked', 'pnl_assemble_clusters_tiled', 'pnl_h2_setup', 'pnl_h2_matvec', 'pnl_spmv',
+           'pnl_inv_diagonal', 'pnl_set_classes', 'pnl_select_class', 'pnl_upload_sparsity', 'pnl_upload_sparsity_device', 'pnl_assemble_pairs_masked', 'pnl_assemble_boundary_masked', 'pnl_assemble_clusters_tiled', 'pnl_h2_setup', 'pnl_h2_matvec', 'pnl_spmv',
            'pnl_assemble_pairs_in_horizon', 'pnl_set_nonsymmetric', 'pnl_set_order_function', 'pnl_upload_pointwise_rules', 'pnl_assemble_dense_pointwise']
 
 
@@ -130,6 +130,7 @@ def load():
     L.pnl_cg_jacobi.argtypes = [vp, vp, i64, i32, vp, vp, dbl, i32, C.POINTER(C.c_int), C.POINTER(C.c_double)]
     L.pnl_inv_diagonal.argtypes = [vp, vp, i64, i32, vp]
     L.pnl_upload_sparsity.argtypes = [vp, i32, vp, vp]
+    L.pnl_upload_sparsity_device.argtypes = [vp, i32, vp, vp]
     L.pnl_set_classes.argtypes = [vp, i32, i32, vp, vp, vp]
     L.pnl_select_class.argtypes = [vp, i32]
     L.pnl_set_nonsymmetric.argtypes = [vp, i32]
@@ -322,6 +323,11 @@ class Context:
         ip, pip = _hp(indptr, np.int32)
         ix, pix = _hp(indices, np.int32)
         self.check(self.L.pnl_upload_sparsity(self.h, ix.shape[0], pip, pix))
+
+    def upload_sparsity_device(self, indptr_t, indices_t):
+        """pattern as int32 torch tensors on this context's device"""
+        self.check(self.L.pnl_upload_sparsity_device(self.h, int(indices_t.numel()), C.c_void_p(indptr_t.data_ptr()),
+                                                     C.c_void_p(indices_t.data_ptr()) if indices_t.numel() else None))
 
     def assemble_pairs_masked(self, pairs, masks, data_ptr, diag_ptr=None):
         p, pp = _hp(pairs, np.int32)

@@ -16,7 +16,16 @@ import numpy as np
 
 
 def getDoFBoxesAndCells(dm):
-    """boxes[N, dim, 2] of the DoF supports and the DoF -> cells graph as CSR (indptr, indices)"""
+    """boxes[N, dim, 2] of the DoF supports and the DoF -> cells graph as CSR (indptr, indices); kept on the DoF map"""
+    cached = getattr(dm, '_boxes_and_cells', None)
+    if cached is not None and cached[0] is dm.dofs and cached[1] is dm.mesh:
+        return cached[2]
+    out = _getDoFBoxesAndCells(dm)
+    dm._boxes_and_cells = (dm.dofs, dm.mesh, out)
+    return out
+
+
+def _getDoFBoxesAndCells(dm):
     mesh = dm.mesh
     v = mesh.vertices[mesh.cells]                       # [nc, k, dim]
     lo, hi = v.min(axis=1), v.max(axis=1)               # [nc, dim]
@@ -365,7 +374,9 @@ def getSparseNearField(dm, Pnear, symmetric=True, device=None):
         rows = keys >> 32
         indptr = torch.zeros(N+1, dtype=torch.int64, device=device)
         indptr[1:] = torch.cumsum(torch.bincount(rows, minlength=N), 0)
-        return indptr.to(torch.int32).cpu().numpy(), (keys & 0xffffffff).to(torch.int32).cpu().numpy()
+        # int32 tensors on the device: the operators hand them to the library device-to-device and copy them to the host only
+        # when somebody reads .indptr / .indices
+        return indptr.to(torch.int32), (keys & 0xffffffff).to(torch.int32)
     parts = []
     for cp in Pnear:
         I = np.asarray(cp.n1.dofs, dtype=np.int64)[:, None]

@@ -2033,6 +2033,24 @@ int pnl_upload_sparsity(pnl_context *ctx, int nnz, const int32_t *indptr, const 
     return PNL_OK;
 }
 
+int pnl_upload_sparsity_device(pnl_context *ctx, int nnz, const int32_t *indptr_dev, const int32_t *indices_dev) {
+    if (!ctx) return PNL_ERR_INVALID;
+    if (!ctx->have_dofs) return fail(ctx, PNL_ERR_STATE, "upload the DoF map first");
+    if (nnz < 0 || !indptr_dev || (nnz && !indices_dev)) return fail(ctx, PNL_ERR_INVALID, "bad sparsity pattern (nnz=%d)", nnz);
+    int rc;
+    if ((rc = ensure(ctx, ctx->b_sp_indptr, sizeof(int32_t)*((size_t)ctx->N+1)))) return rc;
+    if ((rc = ensure(ctx, ctx->b_sp_indices, sizeof(int32_t)*(size_t)std::max(nnz, 1)))) return rc;
+    HIPCHK(ctx, hipMemcpyAsync(ctx->b_sp_indptr.p, indptr_dev, sizeof(int32_t)*((size_t)ctx->N+1), hipMemcpyDeviceToDevice, ctx->stream));
+    if (nnz) HIPCHK(ctx, hipMemcpyAsync(ctx->b_sp_indices.p, indices_dev, sizeof(int32_t)*(size_t)nnz, hipMemcpyDeviceToDevice, ctx->stream));
+    int32_t ends[2] = {-1, -1};
+    HIPCHK(ctx, hipMemcpyAsync(&ends[0], ctx->b_sp_indptr.p, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(&ends[1], (const int32_t*)ctx->b_sp_indptr.p+ctx->N, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (ends[0] != 0 || ends[1] != nnz) { ctx->sp_nnz = -1; return fail(ctx, PNL_ERR_INVALID, "bad sparsity pattern: indptr runs from %d to %d, nnz=%d", ends[0], ends[1], nnz); }
+    ctx->sp_nnz = nnz;
+    return PNL_OK;
+}
+
 static int sparse_ready(pnl_context *ctx, double *data, double *diag, SparseOut &S) {
     int rc;
     if ((rc = check_ready(ctx))) return rc;

@@ -236,19 +236,40 @@ class CSR_LinearOperator:
     symmetric = False
 
     def __init__(self, indptr, indices, num_dofs, ctx, device):
-        self.indptr = np.ascontiguousarray(indptr, dtype=np.int32)
-        self.indices = np.ascontiguousarray(indices, dtype=np.int32)
+        # the pattern either as host arrays or as int32 torch tensors on the device (getSparseNearField builds it there);
+        # device patterns reach the library device-to-device and are copied to the host when .indptr / .indices is read
+        self._pattern_dev = None
+        if isinstance(indptr, torch.Tensor):
+            self._pattern_dev = (indptr.to(torch.int32).contiguous(), indices.to(torch.int32).contiguous())
+            self._indptr = self._indices = None
+            self._nnz = int(indices.numel())
+        else:
+            self._indptr = np.ascontiguousarray(indptr, dtype=np.int32)
+            self._indices = np.ascontiguousarray(indices, dtype=np.int32)
+            self._nnz = int(self._indices.shape[0])
         self.num_rows = self.num_columns = int(num_dofs)
         self.shape = (self.num_rows, self.num_columns)
         self.ctx = ctx
         self.device = device
-        self.data_dev = torch.zeros(max(self.indices.shape[0], 1), dtype=torch.float64, device=device)
+        self.data_dev = torch.zeros(max(self._nnz, 1), dtype=torch.float64, device=device)
         self.diag_dev = None
         self.info = {}
 
     @property
+    def indptr(self):
+        if self._indptr is None:
+            self._indptr = self._pattern_dev[0].cpu().numpy()
+        return self._indptr
+
+    @property
+    def indices(self):
+        if self._indices is None:
+            self._indices = self._pattern_dev[1].cpu().numpy()
+        return self._indices
+
+    @property
     def nnz(self):
-        return int(self.indices.shape[0])
+        return self._nnz
 
     @property
     def data(self):
@@ -261,7 +282,10 @@ class CSR_LinearOperator:
     def _bind(self):
         """make this operator's pattern the one resident in the context"""
         if getattr(self.ctx, '_pattern_owner', None) is not self:
-            self.ctx.upload_sparsity(self.indptr, self.indices)
+            if self._pattern_dev is not None and self._pattern_dev[0].device.type == 'cuda':
+                self.ctx.upload_sparsity_device(*self._pattern_dev)
+            else:
+                self.ctx.upload_sparsity(self.indptr, self.indices)
             self.ctx._pattern_owner = self
 
     def toarray(self):

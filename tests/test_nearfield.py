@@ -305,5 +305,7 @@ def test_pattern_on_a_torch_device_equals_the_numpy_one():
     for symmetric in (True, False):
         a = clusters.getSparseNearField(dm, Pnear, symmetric)
         b = clusters.getSparseNearField(dm, Pnear, symmetric, device=torch.device('cpu'))
+        assert b[0].dtype == b[1].dtype == torch.int32          # tensors on the device they were built on
+        b = (b[0].numpy(), b[1].numpy())
         assert a[0].dtype == b[0].dtype == np.int32 and a[1].dtype == b[1].dtype == np.int32
         assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
