@@ -72,7 +72,7 @@ struct pnl_context {
     DevBuf b_kcls, b_fcls, b_uni, b_tilecls, b_ttwphif;
     // block-slot storage (pnl_tile2.h): padded column offsets of the blocks, row offsets, copies (block, slot) of every DoF,
     // the tiles that several order classes visit, the storage itself (allocated by the first assembly that uses it)
-    DevBuf b_scolbase, b_srowoff, b_cpoff, b_cpslot, b_cprow, b_foldtab, b_bkcls, b_bfcls, b_multitiles, b_slotA;
+    DevBuf b_scolbase, b_srowoff, b_cpoff, b_cpslot, b_cprow, b_foldtab, b_bkcls, b_bfcls, b_bdefer, b_multitiles, b_slotA;
     int slot_S = 0, n_multitiles = 0;
     long long slot_total = 0;         // doubles
     // row slab of a rank (pnl_set_row_slab, pnl_slab.hip)

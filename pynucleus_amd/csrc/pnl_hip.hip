@@ -620,12 +620,38 @@ int launch_boundary(pnl_context *ctx, int cell_begin, int cell_end, int what = 3
     while (per > 1 && (long long)gx*((ctx->nb+per-1)/per) < 4096) per >>= 1;
     const int chunks = (ctx->nb+per-1)/per;
     if (what & 1) {
-        if (bkcls ? all_fast : ctx->P.bkn.fast)
+        // pairs with more than `defer` point pairs are integrated one per wave (k_boundary_items) instead of by one lane; the
+        // list holds at least 64 items per facet -- pairs that do not fit are integrated in place
+        const int defer = getenv("PNL_BND_DEFER") ? atoi(getenv("PNL_BND_DEFER")) : 48;
+        const bool use_list = defer > 0;
+        const unsigned cap = (unsigned)std::min<long long>(std::max<long long>(65536, 64ll*ctx->nb), 1ll << 24);
+        int *dcells = nullptr, *dfacets = nullptr, *dcls = nullptr;
+        unsigned *dslots = nullptr, *dcount = nullptr;
+        if (use_list) {
+            int rc;
+            if ((rc = ensure(ctx, ctx->b_bdefer, sizeof(int)*(size_t)cap*(3+DIM)+sizeof(unsigned)))) return rc;
+            dcells = (int*)ctx->b_bdefer.p; dfacets = dcells+cap; dslots = (unsigned*)(dfacets+(size_t)cap*DIM); dcls = (int*)(dslots+cap);
+            dcount = (unsigned*)(dcls+cap);
+            HIPCHK(ctx, hipMemsetAsync(dcount, 0, sizeof(unsigned), ctx->stream));
+        }
+        const bool fast = bkcls ? all_fast : (ctx->P.bkn.fast != 0);
+        if (fast)
             hipLaunchKernelGGL((k_boundary_distant<DIM, DPE, 1>), dim3(gx, chunks), dim3(PNL_NTHREADS), 0, ctx->stream, ctx->P,
-                               (double*)ctx->b_D.p, cell_begin, cell_end, per, bkcls, bfcls);
+                               (double*)ctx->b_D.p, cell_begin, cell_end, per, bkcls, bfcls, defer, dcells, dfacets, dslots, dcount, cap, dcls);
         else
             hipLaunchKernelGGL((k_boundary_distant<DIM, DPE, 0>), dim3(gx, chunks), dim3(PNL_NTHREADS), 0, ctx->stream, ctx->P,
-                               (double*)ctx->b_D.p, cell_begin, cell_end, per, bkcls, bfcls);
+                               (double*)ctx->b_D.p, cell_begin, cell_end, per, bkcls, bfcls, defer, dcells, dfacets, dslots, dcount, cap, dcls);
+        if (use_list) {
+            const double *verts = (const double*)ctx->b_vertices.p;
+            if (fast)
+                hipLaunchKernelGGL((k_boundary_items<DIM, DPE, 1>), dim3(256*4), dim3(PNL_NTHREADS), 0, ctx->stream, ctx->P, verts,
+                                   (const int*)dcells, (const int*)dfacets, (const unsigned*)dslots, (int)cap, 1., SparseOut{},
+                                   (double*)ctx->b_D.p, (const unsigned*)dcount, bkcls ? (const int*)dcls : nullptr, bkcls, bfcls);
+            else
+                hipLaunchKernelGGL((k_boundary_items<DIM, DPE, 0>), dim3(256*4), dim3(PNL_NTHREADS), 0, ctx->stream, ctx->P, verts,
+                                   (const int*)dcells, (const int*)dfacets, (const unsigned*)dslots, (int)cap, 1., SparseOut{},
+                                   (double*)ctx->b_D.p, (const unsigned*)dcount, bkcls ? (const int*)dcls : nullptr, bkcls, bfcls);
+        }
         HIPCHK(ctx, hipGetLastError());
     }
     if (what & 2)
@@ -948,10 +974,10 @@ int boundary_masked_impl(pnl_context *ctx, int ni, double fac, const SparseOut &
     const double *verts = (const double*)ctx->b_vertices.p;
     if (ctx->P.bkn.fast)
         hipLaunchKernelGGL((k_boundary_items<DIM, DPE, 1>), dim3(grid), dim3(PNL_NTHREADS), 0, ctx->stream, ctx->P, verts, cells, facets,
-                           masks, ni, fac, S, (double*)nullptr);
+                           masks, ni, fac, S, (double*)nullptr, (const unsigned*)nullptr, (const int*)nullptr, (const DevKernel*)nullptr, (const DevFormula*)nullptr);
     else
         hipLaunchKernelGGL((k_boundary_items<DIM, DPE, 0>), dim3(grid), dim3(PNL_NTHREADS), 0, ctx->stream, ctx->P, verts, cells, facets,
-                           masks, ni, fac, S, (double*)nullptr);
+                           masks, ni, fac, S, (double*)nullptr, (const unsigned*)nullptr, (const int*)nullptr, (const DevKernel*)nullptr, (const DevFormula*)nullptr);
     HIPCHK(ctx, hipGetLastError());
     return PNL_OK;
 }
@@ -1079,10 +1105,10 @@ int clusters_tiled_impl(pnl_context *ctx, const pnl_cluster_plan *pl, ClusterTil
             const int g2 = std::min((pl->n_btouch+3)/4, 256*8);
             if (ctx->P.bkn.fast)
                 hipLaunchKernelGGL((k_boundary_items<DIM, DPE, 1>), dim3(g2), dim3(PNL_NTHREADS), 0, ctx->stream, ctx->P, verts, bt_cell,
-                                   bt_facet, bt_slot, pl->n_btouch, 1., SparseOut{}, CT.D);
+                                   bt_facet, bt_slot, pl->n_btouch, 1., SparseOut{}, CT.D, (const unsigned*)nullptr, (const int*)nullptr, (const DevKernel*)nullptr, (const DevFormula*)nullptr);
             else
                 hipLaunchKernelGGL((k_boundary_items<DIM, DPE, 0>), dim3(g2), dim3(PNL_NTHREADS), 0, ctx->stream, ctx->P, verts, bt_cell,
-                                   bt_facet, bt_slot, pl->n_btouch, 1., SparseOut{}, CT.D);
+                                   bt_facet, bt_slot, pl->n_btouch, 1., SparseOut{}, CT.D, (const unsigned*)nullptr, (const int*)nullptr, (const DevKernel*)nullptr, (const DevFormula*)nullptr);
             HIPCHK(ctx, hipGetLastError());
         }
     }

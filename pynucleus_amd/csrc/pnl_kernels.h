@@ -2444,7 +2444,9 @@ k_singular_pairs(const DevProblem P, const int2 *__restrict__ pairs, int npairs_
 template <int DIM, int DPE, int KT>
 __global__ void __launch_bounds__(PNL_NTHREADS)
 k_boundary_distant(const DevProblem P, double *__restrict__ Dglob, int cell_begin, int cell_end, int facets_per_chunk,
-                   const DevKernel *__restrict__ bkcls, const DevFormula *__restrict__ bfcls) {
+                   const DevKernel *__restrict__ bkcls, const DevFormula *__restrict__ bfcls, int defer_evals,
+                   int *__restrict__ dcells, int *__restrict__ dfacets, unsigned *__restrict__ dslots, unsigned *__restrict__ dcount,
+                   unsigned dcap, int *__restrict__ dcls) {
     constexpr int NV = DIM+1, NC = NV*DIM, NF = DIM, ND = DPE*(DPE+1)/2;
     const int c = cell_begin+blockIdx.x*PNL_NTHREADS+threadIdx.x;
     const bool active = c < cell_end;
@@ -2473,8 +2475,9 @@ k_boundary_distant(const DevProblem P, double *__restrict__ Dglob, int cell_begi
         // formula of the pair's class; without them this launch handles class P.cur_class and skips the other pairs
         DevKernel bkn = P.bkn;
         DevFormula bqo = P.bqo;
+        int kc = -1;
         if (P.cur_class >= 0) {
-            const int kc = P.cls_of[lab1*P.nlab+P.blabel[f]];
+            kc = P.cls_of[lab1*P.nlab+P.blabel[f]];
             if (bkcls) { bkn = bkcls[kc]; bqo = bfcls[kc]; }
             else if (kc != P.cur_class) continue;
         }
@@ -2502,6 +2505,20 @@ k_boundary_distant(const DevProblem P, double *__restrict__ Dglob, int cell_begi
         if (q > P.qmax || q > PNL_MAXQ) { overflow++; continue; }
         const int off = P.off[q], n = P.off[q+1]-off;
         const int foff = P.foff[q], nf = P.foff[q+1]-foff;
+        // the few pairs close to the boundary need rules with hundreds of point pairs: one lane would keep its wave (and the
+        // launch) waiting for it.  They go to a list of (cell, facet) items that k_boundary_items integrates one per wave,
+        // lanes over the point pairs, into the same per-cell blocks.
+        if (dcells && n*nf > defer_evals) {
+            const unsigned idx = atomicAdd(dcount, 1u);
+            if (idx < dcap) {
+                dcells[idx] = c;
+                dslots[idx] = (unsigned)c;
+                if (bkcls) dcls[idx] = kc;
+#pragma unroll
+                for (int k = 0; k < NF; k++) dfacets[(size_t)idx*NF+k] = fvid[k];
+                continue;
+            }
+        }
         const double *__restrict__ bary = P.bary+3*(size_t)off;
         const double *__restrict__ w = P.w+off;
         const double *__restrict__ phi = P.phi+(size_t)off*DPE;
@@ -2765,7 +2782,11 @@ template <int DIM, int DPE, int KT>
 __global__ void __launch_bounds__(PNL_NTHREADS)
 k_boundary_items(const DevProblem P, const double *__restrict__ verts, const int *__restrict__ cells,
                  const int *__restrict__ facets, const unsigned *__restrict__ masks, int ni, double fac, const SparseOut S,
-                 double *__restrict__ Dout) {
+                 double *__restrict__ Dout, const unsigned *__restrict__ ni_dev, const int *__restrict__ item_cls,
+                 const DevKernel *__restrict__ bkcls, const DevFormula *__restrict__ bfcls) {
+    // item count produced on the device (k_boundary_distant's deferred pairs): at most the capacity ni;
+    // item_cls: kernel class per item (variable order), parameters from the class tables
+    if (ni_dev) ni = (int)min(*ni_dev, (unsigned)ni);
     constexpr int NV = DIM+1, NF = DIM, ND = DPE*(DPE+1)/2;
     const int lane = threadIdx.x & 63;
     const int nwaves = gridDim.x*(PNL_NTHREADS/64);
@@ -2773,6 +2794,12 @@ k_boundary_items(const DevProblem P, const double *__restrict__ verts, const int
     for (int wid = (blockIdx.x*PNL_NTHREADS+threadIdx.x) >> 6; wid < ni; wid += nwaves) {
         const int c1 = __builtin_amdgcn_readfirstlane(cells[wid]);
         const unsigned mask = (unsigned)__builtin_amdgcn_readfirstlane((int)masks[wid]);
+        DevKernel bkn = P.bkn;
+        DevFormula bqo = P.bqo;
+        if (item_cls) {
+            const int kc = __builtin_amdgcn_readfirstlane(item_cls[wid]);
+            bkn = bkcls[kc]; bqo = bfcls[kc];
+        }
         int fvid[NF];
         double fv[NF][DIM], cv[NV][DIM];
 #pragma unroll
@@ -2829,7 +2856,7 @@ k_boundary_items(const DevProblem P, const double *__restrict__ verts, const int
                 const double u = P.ccen[(size_t)d*P.ncp+c1]-fc*(1./NF);
                 dc2 += u*u;
             }
-            const int q = quad_order(P.bqo, P.H0, P.ch[c1], vol2, sqrt(dc2));
+            const int q = quad_order(bqo, P.H0, P.ch[c1], vol2, sqrt(dc2));
             if (q > P.qmax || q > PNL_MAXQ || P.off[q+1] == P.off[q] || P.foff[q+1] == P.foff[q]) {
                 if (lane == 0) atomicAdd(&P.counters[5], 1ull);
                 continue;
@@ -2850,7 +2877,7 @@ k_boundary_items(const DevProblem P, const double *__restrict__ verts, const int
                     if (DIM == 2) nw = __builtin_fma(nrm[d], wv, nw);
                 }
                 if (DIM != 2) nw = 1.;
-                const double t = (P.w[off+i]*P.fw[foff+m])*nw*kern_eval<KT>(P.bkn, d2);
+                const double t = (P.w[off+i]*P.fw[foff+m])*nw*kern_eval<KT>(bkn, d2);
                 int e = 0;
 #pragma unroll
                 for (int a = 0; a < DPE; a++) {
@@ -2859,7 +2886,7 @@ k_boundary_items(const DevProblem P, const double *__restrict__ verts, const int
                     for (int b = a; b < DPE; b++) { acc[e] = __builtin_fma(ta, P.phi[(size_t)(off+i)*DPE+b], acc[e]); e++; }
                 }
             }
-            vol = P.cvol[c1]*vol2*kern_scale<KT>(P.bkn);
+            vol = P.cvol[c1]*vol2*kern_scale<KT>(bkn);
             nevals += (unsigned long long)n*nf;
         } else {
             int i = 0;
@@ -2906,7 +2933,7 @@ k_boundary_items(const DevProblem P, const double *__restrict__ verts, const int
                     if (DIM == 2) nw = __builtin_fma(nrm[d], wv, nw);
                 }
                 if (DIM != 2) nw = 1.;
-                const double t = w[m]*nw*kern_eval<KT>(P.bkn, d2);
+                const double t = w[m]*nw*kern_eval<KT>(bkn, d2);
                 double ps[DPE];
 #pragma unroll
                 for (int r = 0; r < DPE; r++) ps[r] = PHI[(size_t)r*M+m];
@@ -2918,7 +2945,7 @@ k_boundary_items(const DevProblem P, const double *__restrict__ verts, const int
                     for (int J = I; J < DPE; J++) { acc[e] = __builtin_fma(tI, ps[J], acc[e]); e++; }
                 }
             }
-            vol = ((DIM == 2) ? P.bFac*P.cvol[c1]*vol2 : P.bFac*P.cvol[c1])*kern_scale<KT>(P.bkn);
+            vol = ((DIM == 2) ? P.bFac*P.cvol[c1]*vol2 : P.bFac*P.cvol[c1])*kern_scale<KT>(bkn);
             nevals += (unsigned long long)M;
         }
         npairs++;
