@@ -1887,7 +1887,10 @@ k_worklist_sorted(const DevProblem P, const int4 *__restrict__ sorted, const uns
     __syncthreads();
     const unsigned nchunks = s_coff[PNL_WL_BINS];
     int staged_q = -1;
-    for (unsigned chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+    // heaviest chunks first (the highest orders have thousands of point pairs per pair): the launch does not end on a few
+    // workgroups that picked up the expensive pairs last
+    for (unsigned rchunk = blockIdx.x; rchunk < nchunks; rchunk += gridDim.x) {
+        const unsigned chunk = nchunks-1u-rchunk;
         // order of this chunk: last q with chunk_off[q] <= chunk
         int lo = 0, hi = PNL_WL_BINS-1;
         while (lo < hi) {
