@@ -155,6 +155,10 @@ class nonlocalBuilder:
         self.zeroExterior = False if kernel.finiteHorizon else bool(zeroExterior)
         self.tables = nonlocalTables(self.dm, kernel, self.params, self.zeroExterior)
         self._uploaded = False
+        # operators of the previous kernel keep their data but must not re-run a device set-up with the new tables
+        if getattr(self, '_ctx', None) is not None:
+            self._ctx._kernel_epoch = getattr(self._ctx, '_kernel_epoch', 0)+1
+            self._ctx._h2_owner = None
 
     # ------------------------------------------------------------------
     def _device_index(self):
@@ -217,7 +221,19 @@ class nonlocalBuilder:
             # the pairs within the horizon (getSparse), stored densely
             ctx = self.context()
             S = self.getSparse()
-            A = torch.from_numpy(S.toarray()).to(torch.device('cuda', ctx.device))
+            # scattered into the dense block on the device (no N x N array on the host)
+            dev = torch.device('cuda', ctx.device)
+            N = self.dm.num_dofs
+            ctx.synchronize()
+            indptr = torch.as_tensor(S.indptr, device=dev).to(torch.int64)
+            cols = torch.as_tensor(S.indices, device=dev).to(torch.int64)
+            rows = torch.repeat_interleave(torch.arange(N, device=dev), indptr[1:]-indptr[:-1], output_size=int(cols.numel()))
+            A = torch.zeros((N, N), dtype=torch.float64, device=dev)
+            data = S.data_dev[:cols.numel()]
+            A[rows, cols] = data
+            if S.symmetric:
+                A[cols, rows] = data
+                A.diagonal().copy_(S.diag_dev)
             return Dense_LinearOperator(A, ctx, S.info)
         ctx = self.context()
         if getattr(ctx, '_slab_owner', None) is not None:

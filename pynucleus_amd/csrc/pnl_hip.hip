@@ -1154,7 +1154,8 @@ k_gemv(const double *__restrict__ A, long long ldA, int n, const double *__restr
     if (row >= n) return;
     const double *__restrict__ a = A+(long long)row*ldA;
     double s0 = 0., s1 = 0.;
-    const bool aligned = (((uintptr_t)a) & 15) == 0;
+    // 16-byte loads need both the row and x aligned (x may be a storage-offset view)
+    const bool aligned = ((((uintptr_t)a) | ((uintptr_t)x)) & 15) == 0;
     if (aligned) {
         const int n2 = n >> 1;
         const double2 *a2 = (const double2*)a;

@@ -131,11 +131,15 @@ class H2Matrix:
         P = plan.as_struct(keep)
         ctx.check(ctx.L.pnl_h2_setup(ctx.h, C.byref(P)))
         ctx._h2_owner = self
+        self._epoch = getattr(ctx, '_kernel_epoch', 0)
 
     def matvec(self, x, y=None):
         import torch
         from .linear_operators import _as_dev
         if getattr(self.ctx, '_h2_owner', None) is not self:
+            if getattr(self.ctx, '_kernel_epoch', 0) != self._epoch:
+                raise RuntimeError('this H2Matrix belongs to a kernel the builder no longer holds (setKernel was called): '
+                                   'its far field cannot be set up again; assemble a new operator')
             keep = []
             P = self.plan.as_struct(keep)
             self.ctx.check(self.ctx.L.pnl_h2_setup(self.ctx.h, C.byref(P)))

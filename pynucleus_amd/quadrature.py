@@ -121,14 +121,20 @@ def _load_triangle_tables():
 
 
 def triangleRuleSource():
-    """'modepy' if the reference's own table source is importable, else 'builtin'."""
+    """Source of the triangle rules for distant pairs: 'builtin' (the repo's tables, data/triangle_rules.json) unless the
+    environment asks for the reference's own source with PNL_TRIANGLE_RULES=modepy and modepy is importable.  Deterministic by
+    default: the assembled operators, the golden fixtures and the point counts the tile kernels key on do not depend on what
+    happens to be installed."""
     global _TRIANGLE_SOURCE
     if _TRIANGLE_SOURCE is None:
-        try:
-            import modepy  # noqa: F401
-            _TRIANGLE_SOURCE = 'modepy'
-        except Exception:
-            _TRIANGLE_SOURCE = 'builtin'
+        import os
+        _TRIANGLE_SOURCE = 'builtin'
+        if os.environ.get('PNL_TRIANGLE_RULES', 'builtin') == 'modepy':
+            try:
+                import modepy  # noqa: F401
+                _TRIANGLE_SOURCE = 'modepy'
+            except Exception:
+                raise RuntimeError('PNL_TRIANGLE_RULES=modepy but modepy cannot be imported')
     return _TRIANGLE_SOURCE
 
 
