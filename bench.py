@@ -281,7 +281,8 @@ def main():
         # doubles, and its partial per-cell diagonal blocks; the tiles are dealt by block rows of equal work; no N x N
         # array and no collective in the assembly (the matvec all-reduces an N-vector)
         from pynucleus_amd.builder import row_slab_of_rank, tile_cells
-        c0, c1, tiles, rows, cols = row_slab_of_rank(builder.dm, tile_cells(builder.dm.dofs_per_element, 2), rank, world)
+        Tc = tile_cells(builder.dm.dofs_per_element, 2)
+        c0, c1, tiles, rows, cols = row_slab_of_rank(builder.dm, Tc, rank, world, ctx.block_row_costs((nc+Tc-1)//Tc))
         A = torch.zeros((max(rows.shape[0], 1), max(cols.shape[0], 1)), dtype=torch.float64, device=dev)
         ctx.set_row_slab(rows, cols)
 

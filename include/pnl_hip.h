@@ -150,6 +150,10 @@ int pnl_assemble_pairs_in_horizon(pnl_context *ctx, double *data, double *diag);
                                       * the flush work is shared by the ranks, the mirror pass is not (multi-GPU) */
 int pnl_assemble_dense(pnl_context *ctx, double *A_dev, int64_t ldA, int zero_exterior, int cell_begin, int cell_end,
                        int flags);
+/* Estimated cost of every block row a of the upper block triangle (tiles (a, b), b >= a, weighted by the kernel that will take them,
+ * plus the per-cell work of the row's cells), for dealing contiguous block-row ranges of equal WORK over ranks
+ * (tree_node.partition clusterMethodCy.pyx:1854-1896 deals by DoF count); n = number of blocks = ceil(num_cells / pnl_tile_cells) */
+int pnl_block_row_costs(pnl_context *ctx, double *cost_out, int n);
 /* 1 if pnl_assemble_dense with these arguments OVERWRITES every entry of A (the operator is formed in the block-slot storage and
  * folded into A in one sweep: P2 elements in 2D, whole cell range, mirrored, room for the storage), 0 if it ADDS to A and the
  * caller has to zero the matrix first (the reference allocates a zeroed matrix, NA:1262-1290), < 0 on error */

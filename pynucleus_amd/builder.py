@@ -45,23 +45,29 @@ def cell_range_of_rank(num_cells, rank, size):
     return int(np.ceil(num_cells*rank/size)), int(np.ceil(num_cells*(rank+1)/size))
 
 
-def block_rows_of_rank(num_blocks, rank, size):
+def block_rows_of_rank(num_blocks, rank, size, costs=None):
     """contiguous range [a0, a1) of cell blocks owned by `rank`: block row a of the upper block triangle holds
     num_blocks - a tiles, the ranges hold equal numbers of tiles (tree_node.partition, clusterMethodCy.pyx:1854-1896, hangs
     one subtree per rank under the root; here the rows of the dense block are dealt by work)"""
+    if costs is not None:
+        # ranges of equal estimated WORK (Context.block_row_costs: tiles weighted by the kernel that takes them + per-cell work)
+        cum = np.concatenate([[0.], np.cumsum(np.asarray(costs, dtype=np.float64))])
+        cut = lambda k: int(np.searchsorted(cum, cum[-1]*k/float(size), side='left')) if 0 < k < size else (0 if k <= 0 else num_blocks)
+        a0, a1 = cut(rank), cut(rank+1)
+        return min(a0, num_blocks), min(max(a1, a0), num_blocks)
     cut = lambda k: int(round(num_blocks*(1.-np.sqrt(max(0., 1.-k/float(size))))))
     a0, a1 = cut(rank), (num_blocks if rank == size-1 else cut(rank+1))
     return min(a0, num_blocks), min(max(a1, a0), num_blocks)
 
 
-def row_slab_of_rank(dm, T, rank, size):
+def row_slab_of_rank(dm, T, rank, size, costs=None):
     """(cell_begin, cell_end, tiles, row DoFs, column DoFs) of the rank's one-sided row slab (include/pnl_hip.h,
     pnl_set_row_slab): rows = DoFs of its cells and of the cells touching them, columns = DoFs of its cells and of all
     later cells (+ the rows)."""
     mesh = dm.mesh
     nc = mesh.num_cells
     nb = (nc+T-1)//T
-    a0, a1 = block_rows_of_rank(nb, rank, size)
+    a0, a1 = block_rows_of_rank(nb, rank, size, costs)
     c0, c1 = min(a0*T, nc), min(a1*T, nc)
     tiles = np.array([(a, b) for a in range(a0, a1) for b in range(a, nb)], dtype=np.int32).reshape(-1, 2)
     dofs = np.asarray(dm.dofs)

@@ -15,6 +15,7 @@
 #include "pnl_kernels.h"
 #include "pnl_pointwise.h"
 
+#include <thread>
 #include "pnl_context.h"
 
 namespace {
@@ -2005,6 +2006,40 @@ int pnl_assemble_dense(pnl_context *ctx, double *A, int64_t ldA, int zero_exteri
     if (getenv("PNL_FORCE_SYMFLUSH")) flags |= PNL_FLAG_SYMMETRIC_FLUSH;     // debug: both sides written by the flush, no mirror pass
     ctx->slot_full_list = true;
     return dispatch(ctx, A, ldA, zero_exterior, (int)tiles.size(), cell_begin, cell_end, flags);
+}
+
+// Estimated cost of every block row of the upper block triangle, in units of one uniform order-2 tile: what a rank that owns
+// the row spends on its tiles (classified like upload_tiles does, weights from the measured time per tile of the kernels:
+// profiles/r02b_*) plus the per-cell work of its cells (touching pairs, boundary term).
+int pnl_block_row_costs(pnl_context *ctx, double *out, int n) {
+    if (!ctx || !out) return PNL_ERR_INVALID;
+    int rc;
+    if ((rc = check_ready(ctx))) return rc;
+    if ((rc = finalize(ctx))) return rc;
+    if (n != ctx->nblocks) return fail(ctx, PNL_ERR_INVALID, "pnl_block_row_costs: %d blocks expected", ctx->nblocks);
+    const int T = ctx->tile, nb = ctx->nblocks;
+    const bool p1 = T == 64 && (ctx->dpe == 3 || ctx->dpe == 2), p2 = ctx->dim == 2 && ctx->dpe == 6;
+    const bool allow = ctx->use_pure && (p1 || p2) && ctx->qmax >= 2 && !ctx->nonsym && ctx->cls.size() == 1;
+    int qlimit = 2;
+    if (ctx->dim == 2) for (int q = 3; q <= 4 && ctx->uni_off[q] >= 0 && ctx->uni_np[q] == 6 && q <= ctx->qmax; q++) qlimit = q;
+    const pnl_order_formula F = ctx->cls[0]->form[0];
+    // ns per tile at 98,304 cells (P1: 51 / 138 / 204 incl. its work-list pairs) and 24,576 cells (P2: 50 / 87 / 125)
+    const double w_uni3 = p2 ? 1.75 : 2.7, w_mixed = p2 ? 2.5 : 4.0, w_cells = p2 ? 30. : 57.;
+    const int nthreads = (int)std::max(1u, std::min(8u, std::thread::hardware_concurrency()));
+    std::vector<std::thread> pool;
+    for (int t = 0; t < nthreads; t++)
+        pool.emplace_back([&, t]() {
+            for (int a = t; a < nb; a += nthreads) {
+                double c = w_cells;
+                for (int b = a; b < nb; b++) {
+                    const int q = allow ? tile_uniform_order(ctx, F, a, b, qlimit) : 0;
+                    c += q == 2 ? 1. : (q ? w_uni3 : w_mixed);
+                }
+                out[a] = c;
+            }
+        });
+    for (auto &th : pool) th.join();
+    return PNL_OK;
 }
 
 int pnl_dense_overwrites(pnl_context *ctx, int cell_begin, int cell_end, int flags) {

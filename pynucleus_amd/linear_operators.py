@@ -137,7 +137,8 @@ class DistributedSlab_LinearOperator:
         dm = builder.dm
         dev = torch.device('cuda', ctx.device)
         T = tile_cells(dm.dofs_per_element, builder.mesh.dim)
-        c0, c1, tiles, rows, cols = row_slab_of_rank(dm, T, rank, size)
+        nblocks = (dm.mesh.num_cells+T-1)//T
+        c0, c1, tiles, rows, cols = row_slab_of_rank(dm, T, rank, size, ctx.block_row_costs(nblocks))
         N = dm.num_dofs
         ncols = max(int(cols.shape[0]), 1)
         slab = torch.zeros((max(rows.shape[0], 1), ncols), dtype=torch.float64, device=dev)
