@@ -1,0 +1,141 @@
+"""The BASELINE.json configurations other than the bench workload at THEIR sizes (C3: square 129^2, constant kernel, horizon 0.1,
+getSparse; C4: disc noRef 7, s = 0.75, H2; C5: disc noRef 6, P2, three-layer variable order, dense), checked through
+size-independent properties and through shards the oracle can afford -- what tests/test_gpu_parity.py::test_bench_size_* do for
+the bench workload (C2)."""
+import numpy as np
+import pytest
+
+TOL = 1e-11
+
+
+@pytest.mark.gpu
+def test_c5_p2_layers_noRef6_shard_and_properties():
+    """C5: 24 576 P2 cells, N = 48 769, layers(0.3 ... 0.7): a 40-cell cellNo1 shard that straddles 32-cell blocks and the
+    layer boundary against the oracle entry-wise (five kernel classes, multi-class tiles, class-aware boundary pass, deferred
+    boundary pairs); the whole operator: pair count, counter identities, symmetry, two shards adding up to the whole"""
+    import torch
+    from pynucleus_amd import disc, P2_DoFMap, PHYSICAL, getFractionalKernel
+    from pynucleus_amd.builder import nonlocalBuilder
+    from pynucleus_amd.fractionalOrders import layersFractionalOrder
+    from oracle.oracle import OracleProblem
+    orders = np.array([[0.3, 0.4, 0.5], [0.4, 0.5, 0.6], [0.5, 0.6, 0.7]])
+    s = layersFractionalOrder(2, np.array([-1., -0.3, 0.3, 1.]), orders)
+    dm = P2_DoFMap(disc(6), PHYSICAL)
+    b = nonlocalBuilder(dm, getFractionalKernel(2, s), {'target_order': 0.5}, zeroExterior=True)
+    N, nc = b.dm.num_dofs, b.mesh.num_cells
+    lab = b.tables.cell_labels
+    # a shard whose cells carry two labels
+    change = np.nonzero(lab[1:] != lab[:-1])[0]
+    c0 = int(change[len(change)//2])-19
+    c1 = c0+40
+    assert np.unique(lab[c0:c1]).shape[0] >= 2
+    ctx = b.context()
+    A = torch.zeros((N, N), dtype=torch.float64, device='cuda')
+    ctx.assemble_dense(A.data_ptr(), N, True, c0, c1)
+    ctx.synchronize()
+    cnt = ctx.counters()
+    Aref, cref, _ = OracleProblem(b.tables).get_dense(c0, c1)
+    for key in ('numAssembledCellPairs', 'numIntegrations', 'numBoundaryPairs', 'numBoundaryIntegrations', 'orders', 'singular'):
+        assert cnt[key] == cref[key], (key, cnt[key], cref[key])
+    # rows of the shard's DoFs and their mirror images hold everything the shard wrote
+    err = float((A.cpu()-torch.from_numpy(Aref)).abs().max())/np.abs(Aref).max()
+    assert err < TOL, err
+    del A, Aref
+    # the whole operator (block-slot path, one launch over the classes)
+    Aop = b.getDense()
+    c = Aop.info['counters']
+    assert c['numCellPairs'] == nc*(nc+1)//2
+    assert sum(c['orders'].values())+sum(c['singular'].values()) == c['numAssembledCellPairs']
+    M = Aop.A
+    scale = float(M.abs().max())
+    blk = 8192
+    for i in range(0, N, blk):
+        assert float((M[i:i+blk, :]-M[:, i:i+blk].T).abs().max()) <= 1e-13*scale
+    P = torch.zeros((N, N), dtype=torch.float64, device='cuda')
+    half = nc//2+13
+    SYMMETRIC_FLUSH = 2
+    ctx.assemble_dense(P.data_ptr(), N, True, 0, half, SYMMETRIC_FLUSH)
+    c_lo = ctx.counters()
+    ctx.assemble_dense(P.data_ptr(), N, True, half, nc, SYMMETRIC_FLUSH)
+    c_hi = ctx.counters()
+    ctx.synchronize()
+    assert c_lo['numAssembledCellPairs']+c_hi['numAssembledCellPairs'] == c['numAssembledCellPairs']
+    assert c_lo['numIntegrations']+c_hi['numIntegrations'] == c['numIntegrations']
+    for i in range(0, N, blk):
+        assert float((P[i:i+blk]-M[i:i+blk]).abs().max()) <= 1e-12*scale
+
+
+@pytest.mark.gpu
+def test_c4_h2_noRef7_properties():
+    """C4: disc noRef 7 (98 304 cells, N = 48 769), s = 0.75: the cluster pairs tile the matrix exactly once, the H2 operator
+    is symmetric in the energy sense, agrees with the dense operator within the reference's H2 tolerance and solves the
+    driver problem to the same energy"""
+    import torch
+    from pynucleus_amd import disc, P1_DoFMap, PHYSICAL, getFractionalKernel
+    from pynucleus_amd.builder import nonlocalBuilder
+    from pynucleus_amd.h2 import H2Matrix
+    from pynucleus_amd import solvers
+    dm = P1_DoFMap(disc(7), PHYSICAL)
+    b = nonlocalBuilder(dm, getFractionalKernel(2, 0.75), {'target_order': 0.5, 'eta': 3.}, zeroExterior=True)
+    N = dm.num_dofs
+    h2, Pnear = b.getH2(returnNearField=True)
+    assert isinstance(h2, H2Matrix)
+    covered = sum(len(cp.n1.dofs)*len(cp.n2.dofs) for cp in Pnear)
+    covered += sum(len(cp.n1.dofs)*len(cp.n2.dofs) for lvl in h2.Pfar.values() for cp in lvl)
+    assert covered == N*N
+    assert h2.Anear.nnz < 0.1*N*N
+    D = b.getDense()
+    rng = np.random.default_rng(3)
+    x = torch.as_tensor(rng.standard_normal(N), device='cuda')
+    y = torch.as_tensor(rng.standard_normal(N), device='cuda')
+    hx, hy, dx = h2.matvec(x), h2.matvec(y), D.matvec(x)
+    # tests/test_nearField.py: epsRelH2 = 1e-1 entry-wise; cache_testDistOp: |(A_dense - A_h2) x| ~ 1e-4 of |A x|
+    rel = float((hx-dx).norm()/dx.norm())
+    assert rel < 5e-3, rel
+    assert abs(float(y@hx)-float(x@hy)) <= 1e-10*abs(float(y@hx))+1e-10*float(hx.norm()*y.norm())
+    rhs = np.asarray(dm.assembleRHS(1.0))
+    ud = D.solve_cg_jacobi(rhs, tol=1e-9, maxiter=2000)[0]
+    uh = solvers.cg(h2, rhs, tol=1e-9, maxiter=2000)[0]
+    e_d, e_h = float(rhs@np.asarray(ud)), float(rhs@np.asarray(uh))
+    assert abs(e_d-e_h) < 2e-3*e_d, (e_d, e_h)
+
+
+@pytest.mark.gpu
+def test_c3_square129_getSparse_properties():
+    """C3: square with 129^2 vertices, constant kernel, horizon 0.1 (two cells wide: every touching pair is cut by the
+    horizon): the sparse operator has zero row sums (no exterior term), is positive semi-definite in the energy sense, acts
+    as -Laplace on quadratics in the interior, and the device pair generator visits exactly the host's pair list"""
+    import torch
+    from pynucleus_amd import uniformSquare, P1_DoFMap, NO_BOUNDARY, getKernel, INDICATOR
+    from pynucleus_amd.builder import nonlocalBuilder
+    from pynucleus_amd import clusters
+    delta = 0.1
+    mesh = uniformSquare(129, 129, 0., 0., 1., 1.)
+    dm = P1_DoFMap(mesh, NO_BOUNDARY)
+    b = nonlocalBuilder(dm, getKernel(2, kernel=INDICATOR, horizon=delta), {}, zeroExterior=False)
+    A = b.getSparse()
+    N = dm.num_dofs
+    cnt = A.info['counters']
+    ones = torch.ones(N, dtype=torch.float64, device='cuda')
+    r = A.matvec(ones)
+    scale = float(torch.as_tensor(A.diagonal).abs().max())
+    assert float(r.abs().max()) <= 1e-11*scale
+    rng = np.random.default_rng(1)
+    x = torch.as_tensor(rng.standard_normal(N), device='cuda')
+    assert float(x@A.matvec(x)) > 0.
+    # -Laplace on x0^2 (normalised constant kernel): (A q)_I / int phi_I -> -2 away from the boundary layer of width delta
+    X = dm.getDoFCoordinates()
+    q = torch.as_tensor(X[:, 0]**2, device='cuda')
+    mass = np.asarray(dm.assembleRHS(1.0))
+    inner = (X[:, 0] > 2*delta) & (X[:, 0] < 1-2*delta) & (X[:, 1] > 2*delta) & (X[:, 1] < 1-2*delta)
+    lap = (A.matvec(q).cpu().numpy()/mass)[inner]
+    assert np.abs(lap+2.).max() < 0.08, np.abs(lap+2.).max()
+    # the same operator from the host's explicit pair list (interactingCellPairs), entry for entry
+    b2 = nonlocalBuilder(dm, getKernel(2, kernel=INDICATOR, horizon=delta), {'pairList': 'host'}, zeroExterior=False)
+    A2 = b2.getSparse()
+    # (the host route keeps the structural zeros of its coarser pattern: compare the operators, not the arrays)
+    assert A2.info['counters']['numAssembledCellPairs'] == cnt['numAssembledCellPairs']
+    assert A2.nnz >= A.nnz
+    for _ in range(3):
+        v = torch.as_tensor(rng.standard_normal(N), device='cuda')
+        assert float((A.matvec(v)-A2.matvec(v)).abs().max()) <= 1e-11*scale*np.sqrt(N)
