@@ -62,22 +62,27 @@ def test_row_slab_memory_at_size():
     assert max(sizes) <= 1.2*N*N/8 and sum(sizes) <= 0.75*N*N
 
 
-def _slab_worker(rank, world, port, out, element, noRef):
+def _slab_worker(rank, world, port, out, element, noRef, backend='gloo'):
     try:
-        _slab_worker_body(rank, world, port, out, element, noRef)
+        _slab_worker_body(rank, world, port, out, element, noRef, backend)
     except BaseException as e:                                # a rank that dies must not leave the others in a collective
         import traceback
         out.put(dict(error='rank {}: {}\n{}'.format(rank, repr(e), traceback.format_exc())))
+        out.close()
+        out.join_thread()                                     # the feeder thread must have sent the report before the hard exit
         os._exit(1)
 
 
-def _slab_worker_body(rank, world, port, out, element, noRef):
+def _slab_worker_body(rank, world, port, out, element, noRef, backend='gloo'):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     import torch
     import torch.distributed as dist
-    dist.init_process_group('gloo', rank=rank, world_size=world)
     torch.cuda.set_device(0)
+    if backend == 'nccl':
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', 0))
+    else:
+        dist.init_process_group('gloo', rank=rank, world_size=world)
     from pynucleus_amd import disc, P1_DoFMap, P2_DoFMap, PHYSICAL, getFractionalKernel
     from pynucleus_amd.builder import nonlocalBuilder
     from pynucleus_amd.solvers import cg
@@ -85,7 +90,12 @@ def _slab_worker_body(rank, world, port, out, element, noRef):
     mesh = disc(noRef)
     dm = (P2_DoFMap if element == 'P2' else P1_DoFMap)(mesh, PHYSICAL)
     b = nonlocalBuilder(dm, getFractionalKernel(2, 0.5), {'target_order': 0.5}, zeroExterior=True, comm=True)
-    op = b.getDense(distributed=True)
+    if world == 1:
+        # getDense returns the plain dense operator for one rank: build the row-owned operator directly
+        from pynucleus_amd.linear_operators import DistributedSlab_LinearOperator
+        op = DistributedSlab_LinearOperator.assemble(b, 0, 1, None)
+    else:
+        op = b.getDense(distributed=True)
     Aref, cref, _ = OracleProblem(b.tables).get_dense()
     scale = np.abs(Aref).max()
     # matvec against the oracle
@@ -95,9 +105,10 @@ def _slab_worker_body(rank, world, port, out, element, noRef):
     # the whole matrix (N local products, summed over the ranks)
     e_full = float(np.abs(op.toarray()-Aref).max()/scale)
     e_diag = float(np.abs(op.diagonal-np.diag(Aref)).max()/scale)
-    pairs = torch.tensor([op.info['counters']['numAssembledCellPairs']], dtype=torch.float64)
+    cdev = torch.device('cuda', 0) if backend == 'nccl' else torch.device('cpu')
+    pairs = torch.tensor([op.info['counters']['numAssembledCellPairs']], dtype=torch.float64, device=cdev)
     dist.all_reduce(pairs)
-    byt = torch.tensor([float(op.local_bytes()), float(op.rowdofs.shape[0])], dtype=torch.float64)
+    byt = torch.tensor([float(op.local_bytes()), float(op.rowdofs.shape[0])], dtype=torch.float64, device=cdev)
     gathered = [torch.zeros_like(byt) for _ in range(world)]
     dist.all_gather(gathered, byt)
     # the solve the driver runs (CG-Jacobi on the distributed operator)
@@ -135,3 +146,25 @@ def test_row_slab_operator(world, element, noRef):
     N = r['N']
     assert max(r['bytes']) <= 1.8*8.*N*N/world+8.*2*21*4096, r    # per-rank storage ~ N^2 / P (+ halo rows on this tiny mesh, per-cell blocks)
     assert sum(r['rows']) <= 2.2*N, r                         # GEMV rows ~ N / P per rank (+ halo)
+
+
+@pytest.mark.gpu
+def test_row_slab_operator_over_rccl_single_rank():
+    """the RCCL branch itself (backend 'nccl' IS RCCL on ROCm): a one-rank communicator on the one GPU of the test box runs
+    init_process_group('nccl'), the all-reduce of the N-vector on device tensors in matvec / CG and the all-gather, i.e. the
+    collectives of the N > 1 path with the library the multi-GPU run uses"""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    out = ctx.Queue()
+    port = 29700+(os.getpid()+911) % 2000
+    p = ctx.Process(target=_slab_worker, args=(0, 1, port, out, 'P1', 4, 'nccl'))
+    p.start()
+    r = out.get(timeout=150)
+    if 'error' in r:
+        p.kill()
+        raise AssertionError(r['error'])
+    p.join(timeout=120)
+    assert p.exitcode == 0
+    assert r['pairs'] == r['ref_pairs']
+    assert r['e_mv'] < TOL and r['e_full'] < TOL and r['e_diag'] < TOL, r
+    assert r['e_solve'] < 1e-7, r
