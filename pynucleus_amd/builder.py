@@ -500,8 +500,8 @@ class nonlocalBuilder:
         if sum(len(v) for v in Pfar.values()) == 0:
             h2 = self.getDense()
         elif size > 1:
-            # row-sharded near field: this rank's cluster pairs into its own unsymmetric CSR; the far field (a few MB of
-            # interpolants) is replicated and applied by rank 0; matvec = Bcast(x), local products, Allreduce(y)
+            # row-sharded near field: this rank's cluster pairs into its own unsymmetric CSR; matvec = Bcast(x), local products
+            # (near field + this rank's share of the far field), Allreduce(y)
             # (DistributedH2Matrix_globalData, clusterMethodCy.pyx:3127-3154)
             from .linear_operators import DistributedSparse_LinearOperator
             mine = clusters.partitionClusterPairs(Pnear, size)[rank]
@@ -509,8 +509,17 @@ class nonlocalBuilder:
             m = self.params.get('interpolation_order', None)
             if m is None:
                 m = interpolationOrder(self.kernel, self.mesh, self.tables.target_order)
-            far = H2Matrix(local, h2Plan(self.dm, root, Pfar, m, far_class), self.context(), root, Pfar) if rank == 0 else None
-            h2 = DistributedSparse_LinearOperator(local, None if self.comm is True else self.comm, far=far)
+            # the admissible pairs are dealt round-robin (they cost the same: one M x M product each); every rank runs the
+            # upward pass on the broadcast x (replicated, O(N M)), its share of the interactions and the downward pass of what
+            # it computed; the all-reduce of the N-vector sums near and far parts (DistributedH2Matrix_globalData, CM:3127-3154)
+            Pfar_local, k = {}, 0
+            for lvl in sorted(Pfar):
+                for cp in Pfar[lvl]:
+                    if k % size == rank:
+                        Pfar_local.setdefault(lvl, []).append(cp)
+                    k += 1
+            far = H2Matrix(local, h2Plan(self.dm, root, Pfar_local, m, far_class), self.context(), root, Pfar_local)
+            h2 = DistributedSparse_LinearOperator(local, None if self.comm is True else self.comm, far=far, Pfar=Pfar)
         else:
             # full CSR near field by default: its SpMV needs no atomics for the transposed half (0.16 ms against 0.39 ms with
             # SSS at 49k DoFs) and HBM is not the constraint; params['forceUnsymmetric'] = False keeps the reference's SSS

@@ -383,10 +383,11 @@ class DistributedSparse_LinearOperator:
     the reference's DistributedH2Matrix_globalData (clusterMethodCy.pyx:3127-3154): Bcast(x), local product, Allreduce(y)
     -- an N-vector over RCCL (or gloo), never the matrix."""
 
-    def __init__(self, local, comm_group=None, far=None):
+    def __init__(self, local, comm_group=None, far=None, Pfar=None):
         self.local = local
         self.group = comm_group
-        self.far = far               # H2Matrix over the local near field on the rank that applies the (replicated) far field
+        self.far = far               # H2Matrix over the local near field with this rank's share of the admissible pairs
+        self.Pfar = Pfar             # all admissible pairs (every rank knows the whole tree)
         self.num_rows, self.num_columns = local.num_rows, local.num_columns
         self.shape = local.shape
         self.info = local.info

@@ -258,15 +258,19 @@ def _dist_near_worker(rank, world, port, out):
     b = nonlocalBuilder(dm, getFractionalKernel(2, 0.75), {'eta': 3., 'minClusterSize': 8}, zeroExterior=True, comm=True)
     op, Pnear, root = b.getH2(returnNearField=True, returnTree=True)
     x = np.linspace(-1., 1., dm.num_dofs)
-    y = op.matvec(x)                                # near field (row-sharded) + far field (rank 0), all-reduced
+    y = op.matvec(x)                                # near field (row-sharded) + far field (pairs dealt over the ranks), all-reduced
     indptr, indices, data, diag, cnt = _oracle_near(b.tables, Pnear, symmetric=False)
     Aref = _to_dense(dm.num_dofs, indptr, indices, data, None)
     e2 = float(np.abs(op.toarray()-Aref).max()/np.abs(Aref).max())
+    nfar_all = sum(len(v) for v in op.Pfar.values())
+    nfar_mine = torch.tensor([float(op.far.plan.far.shape[0])], dtype=torch.float64)
+    dist.all_reduce(nfar_mine)
+    assert 0 < op.far.plan.far.shape[0] < nfar_all and int(nfar_mine.item()) == nfar_all     # every admissible pair on one rank
     if rank == 0:
         from pynucleus_amd.quadrature import simplexXiaoGimbutas
         from oracle import h2_oracle
         m = op.far.plan.m
-        Aref = Aref+h2_oracle.far_field_dense(dm, b.kernel, root, op.far.Pfar, m, simplexXiaoGimbutas(m+2, 2, 2))
+        Aref = Aref+h2_oracle.far_field_dense(dm, b.kernel, root, op.Pfar, m, simplexXiaoGimbutas(m+2, 2, 2))
     e1 = float(np.abs(y-Aref@x).max()/np.abs(Aref@x).max()) if rank == 0 else 0.
     if rank == 0:
         out.put((e1, e2, op.local.nnz, indices.shape[0]))
