@@ -236,9 +236,22 @@ typedef struct {
      * clusters (the reference evaluates the variable kernel at the interpolation points, clusterMethodCy.pyx:2213); NULL for a
      * constant order */
     const int32_t *far_class;
+    /* 1: the leaves cover only a part of the DoFs (a rank's own subtrees; DistributedH2Matrix_localData clusterMethodCy.pyx:3368-3920):
+     * the upward pass reads x, and the downward pass adds to y, at the DoFs of these leaves only; 0: the leaves partition the DoFs */
+    int32_t partial_leaves;
 } pnl_h2_plan;
 int pnl_h2_setup(pnl_context *ctx, const pnl_h2_plan *plan);
 int pnl_h2_matvec(pnl_context *ctx, const double *x_dev, double *y_dev);
+/* The phases of pnl_h2_matvec on caller-owned coefficient arrays cup / cdown [nnodes][M] (device memory), for operators that exchange
+ * cluster coefficients between ranks instead of vector entries (communicateFar, clusterMethodCy.pyx:3610-3647):
+ *   pnl_h2_upward    cup = 0; leaves of the plan: cup[leaf] = V^T x; then level by level cup[parent] += T cup[child]
+ *   pnl_h2_interact  cdown = 0; cdown[n1] += K cup[n2] over the plan's admissible pairs
+ *   pnl_h2_downward  level by level cdown[child] += T^T cdown[parent]; y[dofs of the plan's leaves] += V cdown[leaf]
+ * pnl_h2_sizes: out2 = (number of nodes, M) */
+int pnl_h2_upward(pnl_context *ctx, const double *x_dev, double *cup_dev);
+int pnl_h2_interact(pnl_context *ctx, const double *cup_dev, double *cdown_dev);
+int pnl_h2_downward(pnl_context *ctx, double *cdown_dev, double *y_dev);
+int pnl_h2_sizes(pnl_context *ctx, int32_t *out2);
 
 /* y = A x for the uploaded pattern (CSR: diag_dev NULL; SSS: lower triangle + diagonal, y = (L + D + L^T) x):
  * CSR_LinearOperator.matvec / SSS_LinearOperator.matvec */

@@ -28,7 +28,7 @@ EXPORTS = ['pnl_create', 'pnl_destroy', 'pnl_error_string', 'pnl_version', 'pnl_
            'pnl_upload_mesh', 'pnl_upload_dofmap', 'pnl_set_kernel', 'pnl_set_order_formula', 'pnl_upload_distant_rules',
            'pnl_upload_singular_rule', 'pnl_upload_boundary', 'pnl_assemble_dense', 'pnl_dense_overwrites', 'pnl_block_row_costs', 'pnl_tile_cells',
            'pnl_assemble_dense_tiles', 'pnl_get_counters', 'pnl_get_phase_ms', 'pnl_get_kernel_ms', 'pnl_tree_build', 'pnl_tree_build_blocks', 'pnl_tree_destroy', 'pnl_tree_sizes', 'pnl_tree_get', 'pnl_tree_node_cells', 'pnl_h2_transfer_matrices', 'pnl_nfplan_build', 'pnl_nfplan_destroy', 'pnl_nfplan_sizes', 'pnl_nfplan_get', 'pnl_horizon_pattern', 'pnl_pattern_nnz', 'pnl_pattern_get', 'pnl_pattern_destroy', 'pnl_set_row_slab', 'pnl_diag_blocks_size', 'pnl_get_diag_blocks', 'pnl_slab_matvec', 'pnl_slab_diagonal', 'pnl_gemv', 'pnl_cg_jacobi',
-           'pnl_inv_diagonal', 'pnl_set_classes', 'pnl_select_class', 'pnl_upload_sparsity', 'pnl_upload_sparsity_device', 'pnl_assemble_pairs_masked', 'pnl_assemble_boundary_masked', 'pnl_assemble_clusters_tiled', 'pnl_h2_setup', 'pnl_h2_matvec', 'pnl_spmv',
+           'pnl_inv_diagonal', 'pnl_set_classes', 'pnl_select_class', 'pnl_upload_sparsity', 'pnl_upload_sparsity_device', 'pnl_assemble_pairs_masked', 'pnl_assemble_boundary_masked', 'pnl_assemble_clusters_tiled', 'pnl_h2_setup', 'pnl_h2_matvec', 'pnl_h2_upward', 'pnl_h2_interact', 'pnl_h2_downward', 'pnl_h2_sizes', 'pnl_spmv',
            'pnl_assemble_pairs_in_horizon', 'pnl_set_nonsymmetric', 'pnl_set_order_function', 'pnl_upload_pointwise_rules', 'pnl_assemble_dense_pointwise']
 
 
@@ -59,7 +59,8 @@ class pnl_cluster_plan(C.Structure):
 class pnl_h2_plan(C.Structure):
     _fields_ = ([(n, C.c_int32) for n in ('nnodes', 'nleaves', 'nfar', 'm', 'nlevels', 'nq')] +
                 [(n, C.c_void_p) for n in ('box', 'parent', 'level', 'leaf_node', 'leaf_dof_off', 'leaf_dofs', 'leaf_cell_off',
-                                           'leaf_cells', 'far', 'transfer', 'qbary', 'qw', 'qphi', 'far_class')])
+                                           'leaf_cells', 'far', 'transfer', 'qbary', 'qw', 'qphi', 'far_class')] +
+                [('partial_leaves', C.c_int32)])
 
 
 class PnlError(RuntimeError):
@@ -141,6 +142,10 @@ def load():
     L.pnl_assemble_clusters_tiled.argtypes = [vp, C.POINTER(pnl_cluster_plan), i32, vp, vp]
     L.pnl_h2_setup.argtypes = [vp, C.POINTER(pnl_h2_plan)]
     L.pnl_h2_matvec.argtypes = [vp, vp, vp]
+    L.pnl_h2_upward.argtypes = [vp, vp, vp]
+    L.pnl_h2_interact.argtypes = [vp, vp, vp]
+    L.pnl_h2_downward.argtypes = [vp, vp, vp]
+    L.pnl_h2_sizes.argtypes = [vp, vp]
     L.pnl_assemble_pairs_in_horizon.argtypes = [vp, vp, vp]
     L.pnl_set_order_function.argtypes = [vp, C.POINTER(pnl_order_function), vp, vp, dbl, dbl, dbl, dbl]
     L.pnl_upload_pointwise_rules.argtypes = [vp, i32, i32, i32, i32, i32, vp, vp, vp, vp]

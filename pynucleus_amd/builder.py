@@ -499,6 +499,15 @@ class nonlocalBuilder:
         rank, size = self._rank_size()
         if sum(len(v) for v in Pfar.values()) == 0:
             h2 = self.getDense()
+        elif size > 1 and self.params.get('localFarFieldIndexing', False):
+            # rank-local data with halo exchange (the reference's assembleOnRoot=False, localFarFieldIndexing=True,
+            # DistributedH2Matrix_localData CM:3368-3920): rows owned by subtrees, ghost x entries for the near field, cluster
+            # coefficients for the far field, no N-vector collective
+            from .distributed_h2 import DistributedH2Matrix_localData
+            m = self.params.get('interpolation_order', None)
+            if m is None:
+                m = interpolationOrder(self.kernel, self.mesh, self.tables.target_order)
+            h2 = DistributedH2Matrix_localData(self, root, Pnear, Pfar, m, far_class, None if self.comm is True else self.comm)
         elif size > 1:
             # row-sharded near field: this rank's cluster pairs into its own unsymmetric CSR; matvec = Bcast(x), local products
             # (near field + this rank's share of the far field), Allreduce(y)

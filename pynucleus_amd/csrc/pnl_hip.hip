@@ -2365,6 +2365,9 @@ int pnl_h2_setup(pnl_context *ctx, const pnl_h2_plan *pl) {
         for (int t = pl->leaf_cell_off[l]; t < pl->leaf_cell_off[l+1]; t++)
             if (pl->leaf_cells[t] < 0 || pl->leaf_cells[t] >= ctx->nc) return fail(ctx, PNL_ERR_INVALID, "leaf %d: bad cell", l);
     }
+    if (!pl->partial_leaves)
+        for (int I = 0; I < ctx->N; I++)
+            if (!covered[I]) return fail(ctx, PNL_ERR_INVALID, "DoF %d belongs to no leaf (set partial_leaves for a rank-local plan)", I);
     DevBuf *B = ctx->b_h2;
     H2Dev &H = ctx->h2;
     std::memset(&H, 0, sizeof(H));
@@ -2441,6 +2444,57 @@ int pnl_h2_matvec(pnl_context *ctx, const double *x, double *y) {
         if (n) hipLaunchKernelGGL(k_h2_up_level, dim3(n), dim3(64), 0, ctx->stream, H, lev+ctx->h2_level_off[l], n);
     }
     if (H.nfar) hipLaunchKernelGGL(k_h2_far, dim3(H.nfar), dim3(64), 0, ctx->stream, H);
+    for (int l = 1; l < nlev; l++) {
+        const int n = (int)ctx->h2_levels[l].size();
+        if (n) hipLaunchKernelGGL(k_h2_down_level, dim3(n), dim3(64), 0, ctx->stream, H, lev+ctx->h2_level_off[l], n);
+    }
+    hipLaunchKernelGGL(k_h2_down_leaves, dim3(H.nleaves), dim3(64), 0, ctx->stream, H, y);
+    HIPCHK(ctx, hipGetLastError());
+    return PNL_OK;
+}
+
+int pnl_h2_sizes(pnl_context *ctx, int32_t *out2) {
+    if (!ctx || !out2) return PNL_ERR_INVALID;
+    if (!ctx->have_h2) return fail(ctx, PNL_ERR_STATE, "pnl_h2_setup first");
+    out2[0] = ctx->h2.nnodes; out2[1] = ctx->h2.M;
+    return PNL_OK;
+}
+
+int pnl_h2_upward(pnl_context *ctx, const double *x, double *cup) {
+    if (!ctx || !x || !cup) return PNL_ERR_INVALID;
+    if (!ctx->have_h2) return fail(ctx, PNL_ERR_STATE, "pnl_h2_setup first");
+    H2Dev H = ctx->h2;
+    H.cup = cup;
+    const int nlev = (int)ctx->h2_levels.size();
+    const int *lev = (const int*)ctx->b_h2[17].p;
+    HIPCHK(ctx, hipMemsetAsync(cup, 0, sizeof(double)*(size_t)H.nnodes*H.M, ctx->stream));
+    hipLaunchKernelGGL(k_h2_up_leaves, dim3(H.nleaves), dim3(64), 0, ctx->stream, H, x);
+    for (int l = nlev-1; l >= 1; l--) {
+        const int n = (int)ctx->h2_levels[l].size();
+        if (n) hipLaunchKernelGGL(k_h2_up_level, dim3(n), dim3(64), 0, ctx->stream, H, lev+ctx->h2_level_off[l], n);
+    }
+    HIPCHK(ctx, hipGetLastError());
+    return PNL_OK;
+}
+
+int pnl_h2_interact(pnl_context *ctx, const double *cup, double *cdown) {
+    if (!ctx || !cup || !cdown) return PNL_ERR_INVALID;
+    if (!ctx->have_h2) return fail(ctx, PNL_ERR_STATE, "pnl_h2_setup first");
+    H2Dev H = ctx->h2;
+    H.cup = const_cast<double*>(cup); H.cdown = cdown;
+    HIPCHK(ctx, hipMemsetAsync(cdown, 0, sizeof(double)*(size_t)H.nnodes*H.M, ctx->stream));
+    if (H.nfar) hipLaunchKernelGGL(k_h2_far, dim3(H.nfar), dim3(64), 0, ctx->stream, H);
+    HIPCHK(ctx, hipGetLastError());
+    return PNL_OK;
+}
+
+int pnl_h2_downward(pnl_context *ctx, double *cdown, double *y) {
+    if (!ctx || !cdown || !y) return PNL_ERR_INVALID;
+    if (!ctx->have_h2) return fail(ctx, PNL_ERR_STATE, "pnl_h2_setup first");
+    H2Dev H = ctx->h2;
+    H.cdown = cdown;
+    const int nlev = (int)ctx->h2_levels.size();
+    const int *lev = (const int*)ctx->b_h2[17].p;
     for (int l = 1; l < nlev; l++) {
         const int n = (int)ctx->h2_levels[l].size();
         if (n) hipLaunchKernelGGL(k_h2_down_level, dim3(n), dim3(64), 0, ctx->stream, H, lev+ctx->h2_level_off[l], n);

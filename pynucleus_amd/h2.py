@@ -46,10 +46,9 @@ def transferMatrix(boxP, boxC, m):
 class h2Plan:
     """flattened cluster tree + admissible pairs for pnl_h2_setup"""
 
-    def __init__(self, dm, root, Pfar, m, far_class=None):
-        from .quadrature import simplexXiaoGimbutas
-        mesh = dm.mesh
-        dim = mesh.dim
+    @staticmethod
+    def flatten(root):
+        """(nodes, parent, level) of the tree in depth-first order: the node numbering of the plan"""
         nodes, parent, level = [], [], []
 
         def walk(n, p, lvl):
@@ -60,6 +59,15 @@ class h2Plan:
             for c in n.children:
                 walk(c, k, lvl+1)
         walk(root, -1, 0)
+        return nodes, parent, level
+
+    def __init__(self, dm, root, Pfar, m, far_class=None, flat=None, far_pairs=None, leaf_mask=None):
+        """far_pairs: explicit list of admissible pairs (default: all of Pfar, level by level); leaf_mask[node]: only these leaves
+        take part in the upward / downward pass (a rank's own subtrees)"""
+        from .quadrature import simplexXiaoGimbutas
+        mesh = dm.mesh
+        dim = mesh.dim
+        nodes, parent, level = flat if flat is not None else h2Plan.flatten(root)
         self.nodes = nodes
         nid = {id(n): k for k, n in enumerate(nodes)}
         self.m, self.M = int(m), int(m)**dim
@@ -67,7 +75,9 @@ class h2Plan:
         self.level = np.array(level, dtype=np.int32)
         self.nlevels = int(self.level.max())+1
         self.box = np.ascontiguousarray(np.stack([n.box for n in nodes]), dtype=np.float64)        # [nnodes, dim, 2]
-        leaves = [k for k, n in enumerate(nodes) if n.is_leaf]
+        leaves = [k for k, n in enumerate(nodes) if n.is_leaf and (leaf_mask is None or leaf_mask[k])]
+        self.partial_leaves = leaf_mask is not None
+        assert len(leaves) > 0
         self.leaf_node = np.array(leaves, dtype=np.int32)
         self.leaf_dof_off = np.zeros(len(leaves)+1, dtype=np.int32)
         self.leaf_cell_off = np.zeros(len(leaves)+1, dtype=np.int32)
@@ -75,10 +85,13 @@ class h2Plan:
         self.leaf_cell_off[1:] = np.cumsum([nodes[k].cells.shape[0] for k in leaves])
         self.leaf_dofs = np.concatenate([nodes[k].dofs for k in leaves]).astype(np.int32)
         self.leaf_cells = np.concatenate([nodes[k].cells for k in leaves]).astype(np.int32)
-        far = [(nid[id(cp.n1)], nid[id(cp.n2)]) for lvl in sorted(Pfar) for cp in Pfar[lvl]]
+        if far_pairs is None:
+            far_pairs = [cp for lvl in sorted(Pfar) for cp in Pfar[lvl]]
+        self.nid = nid
+        far = [(nid[id(cp.n1)], nid[id(cp.n2)]) for cp in far_pairs]
         self.far = np.array(far, dtype=np.int32).reshape(-1, 2)
         # variable order: kernel class per admissible pair, far_class(cp) -> class
-        self.far_class = None if far_class is None else np.array([far_class(cp) for lvl in sorted(Pfar) for cp in Pfar[lvl]], dtype=np.int32)
+        self.far_class = None if far_class is None else np.array([far_class(cp) for cp in far_pairs], dtype=np.int32)
         self.transfer = np.zeros((len(nodes), self.M, self.M))
         from .clusters import _use_native
         if _use_native() and dim <= 2:
@@ -114,6 +127,7 @@ class h2Plan:
         P.transfer = ptr(self.transfer, np.float64)
         P.qbary, P.qw, P.qphi = ptr(self.qbary, np.float64), ptr(self.qw, np.float64), ptr(self.qphi, np.float64)
         P.far_class = None if self.far_class is None else ptr(self.far_class, np.int32)
+        P.partial_leaves = 1 if self.partial_leaves else 0
         return P
 
 

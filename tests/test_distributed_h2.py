@@ -1,0 +1,123 @@
+"""H2 operator with rank-local data and halo exchange (DistributedH2Matrix_localData / DistributedLinearOperator,
+clusterMethodCy.pyx:3157-3920): ownership logic on the CPU, the operator on 2 and 3 ranks (gloo, one card) against the oracle."""
+import os
+import numpy as np
+import pytest
+
+TOL = 1e-11
+
+
+def test_subtree_owners_partition_the_tree():
+    from pynucleus_amd import disc, P1_DoFMap, PHYSICAL, clusters
+    from pynucleus_amd.h2 import h2Plan
+    from pynucleus_amd.distributed_h2 import subtree_owners
+    dm = P1_DoFMap(disc(4), PHYSICAL)
+    root, Pnear, Pfar = clusters.getNearFieldClusters(dm, 3., 8, 200)
+    flat = h2Plan.flatten(root)
+    nodes, parent, level = flat
+    for size in (1, 2, 3, 5, 8):
+        owner, cut = subtree_owners(flat, size)
+        assert set(np.unique(owner[owner >= 0])) == set(range(size))          # every rank owns something
+        dof_owner = np.full(dm.num_dofs, -1)
+        for k in cut:
+            assert (dof_owner[nodes[k].dofs] == -1).all()                     # the owned subtrees are disjoint
+            dof_owner[nodes[k].dofs] = owner[k]
+        assert (dof_owner >= 0).all()                                         # ... and cover the DoFs
+        for k in range(len(nodes)):                                           # a node below a subtree root has its owner
+            if parent[k] >= 0 and owner[parent[k]] >= 0:
+                assert owner[k] == owner[parent[k]]
+        assert (owner < 0).sum() < 8*size                                     # a handful of shared nodes on top
+        counts = np.bincount(dof_owner, minlength=size)
+        assert counts.max() <= 2.5*dm.num_dofs/size+64
+
+
+def _worker(rank, world, port, out, noRef, s):
+    try:
+        _worker_body(rank, world, port, out, noRef, s)
+    except BaseException as e:
+        import traceback
+        out.put(dict(error='rank {}: {}\n{}'.format(rank, repr(e), traceback.format_exc())))
+        out.close()
+        out.join_thread()
+        os._exit(1)
+
+
+def _worker_body(rank, world, port, out, noRef, s):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    from pynucleus_amd import disc, P1_DoFMap, PHYSICAL, getFractionalKernel, clusters
+    from pynucleus_amd.builder import nonlocalBuilder
+    from pynucleus_amd.distributed_h2 import DistributedH2Matrix_localData
+    from pynucleus_amd.quadrature import simplexXiaoGimbutas
+    from pynucleus_amd.solvers import cg
+    from oracle import h2_oracle
+    from oracle.oracle import OracleProblem
+    dm = P1_DoFMap(disc(noRef), PHYSICAL)
+    b = nonlocalBuilder(dm, getFractionalKernel(2, s), {'eta': 3., 'minClusterSize': 8, 'localFarFieldIndexing': True},
+                        zeroExterior=True, comm=True)
+    op, Pnear, root = b.getH2(returnNearField=True, returnTree=True)
+    assert isinstance(op, DistributedH2Matrix_localData)
+    N = dm.num_dofs
+    # reference: oracle near field over all cluster pairs + oracle far field
+    indptr, indices = clusters.getSparseNearField(dm, Pnear, symmetric=False)
+    pairs, masks = clusters.buildMasksForClusters(dm, Pnear)
+    bc, bf, bm = clusters.clusterBoundaryItems(dm, Pnear)
+    data, diag, cnt = OracleProblem(b.tables).assemble_clusters(pairs, masks, bc, bf, bm, indptr, indices, False, None)
+    Aref = np.zeros((N, N))
+    Aref[np.repeat(np.arange(N), np.diff(indptr)), indices] = data
+    m = op.plan.m
+    Aref = Aref+h2_oracle.far_field_dense(dm, b.kernel, root, op.Pfar, m, simplexXiaoGimbutas(m+2, 2, 2))
+    x = np.cos(0.37*np.arange(N))
+    y = op.matvec(x)
+    e_mv = float(np.abs(y-Aref@x).max()/np.abs(Aref@x).max())
+    # the distributed interface: owned rows from owned entries
+    xo = torch.as_tensor(x[op.owned], device='cuda')
+    yo = op.matvec_owned(xo).cpu().numpy()
+    e_own = float(np.abs(yo-(Aref@x)[op.owned]).max()/np.abs(Aref@x).max())
+    rhs = np.asarray(dm.assembleRHS(1.0))
+    u = cg(op, rhs, tol=1e-10, maxiter=500)[0]
+    uref = np.linalg.solve(Aref, rhs)
+    e_solve = float(np.abs(np.asarray(u)-uref).max()/np.abs(uref).max())
+    stats = torch.tensor([float(op.owned.shape[0]), float(op.num_ghosts), float(op.num_ghost_clusters), float(op.num_far_pairs),
+                          float(op.local.nnz)], dtype=torch.float64)
+    gathered = [torch.zeros_like(stats) for _ in range(world)]
+    dist.all_gather(gathered, stats)
+    if rank == 0:
+        out.put(dict(e_mv=e_mv, e_own=e_own, e_solve=e_solve, N=N, stats=[g.tolist() for g in gathered],
+                     nfar=sum(len(v) for v in op.Pfar.values()), nnz=int(indices.shape[0]), top=int(op._top.numel()), M=int(op.M)))
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('world,noRef,s', [(2, 4, 0.75), (3, 4, 0.25)])
+def test_halo_h2_operator(world, noRef, s):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    out = ctx.Queue()
+    port = 29700+(os.getpid()+31*world) % 2000
+    procs = [ctx.Process(target=_worker, args=(r, world, port, out, noRef, s)) for r in range(world)]
+    for p in procs:
+        p.start()
+    r = out.get(timeout=240)
+    if 'error' in r:
+        for p in procs:
+            p.kill()
+        raise AssertionError(r['error'])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert r['e_mv'] < TOL and r['e_own'] < TOL, r
+    assert r['e_solve'] < 1e-7, r
+    st = np.array(r['stats'])
+    N = r['N']
+    assert st[:, 0].sum() == N                                # rows are owned exactly once
+    assert st[:, 3].sum() == r['nfar']                        # every admissible pair on one rank
+    assert st[:, 4].sum() == r['nnz']                         # ... and every near-field entry
+    # communication per matvec: ghost entries + M per ghost cluster + the shared top nodes, well below the N-vector all-reduce
+    # of the global-data operator for the coefficient part
+    assert (st[:, 1] < N).all()
+    assert r['top'] < 8*world
