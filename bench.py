@@ -275,7 +275,9 @@ def main():
     ctx = builder.context()
     N, nc = dm.num_dofs, mesh.num_cells
     if world == 1:
-        A = torch.zeros((N, N), dtype=torch.float64, device=dev)
+        # rows start on 64-byte lines (leading dimension rounded up to 8 doubles): the fold / mirror passes write whole lines
+        ldA = (N+7) & ~7
+        A = torch.zeros((N, ldA), dtype=torch.float64, device=dev)[:, :N] if not os.environ.get('PNL_BENCH_NO_LDA_PAD') else torch.zeros((N, N), dtype=torch.float64, device=dev)
     else:
         # row-owned storage (DistributedSlab_LinearOperator): this rank's one-sided slab of its block rows, ~N^2 / (2 P)
         # doubles, and its partial per-cell diagonal blocks; the tiles are dealt by block rows of equal work; no N x N

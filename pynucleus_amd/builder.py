@@ -254,7 +254,9 @@ class nonlocalBuilder:
         rank, size = self._rank_size()
         # the block-slot path forms the operator in its own storage and writes every entry of A in one sweep: no zero fill
         overwrites = (not pointwise) and size == 1 and ctx.dense_overwrites(0, nc)
-        A = (torch.empty if overwrites else torch.zeros)((N, N), dtype=torch.float64, device=dev)
+        # rows start on 64-byte lines when this rank holds the whole block: the fold / mirror / GEMV passes move whole lines
+        ldA = ((N+7) & ~7) if size == 1 else N
+        A = (torch.empty if overwrites else torch.zeros)((N, ldA), dtype=torch.float64, device=dev)[:, :N]
         if pointwise:
             # non-symmetric kernel, order per quadrature point (NA:1411-1428): the reference's cellNo1 split across ranks
             start, end = cell_range_of_rank(nc, rank, size)

@@ -844,12 +844,11 @@ k_tile_distant(const DevProblem P, const int2 *__restrict__ tiles, double *__res
     if (!(abl & 4)) {
     if (!CLUSTER && !fh && SO.A2) {
         // block-slot storage (pnl_tile2.h): this tile owns its nA x nB sub-block of the storage, plain stores of every entry
-        // (over the padded width, a multiple of 8 doubles: a wave writes whole 64-byte lines)
-        const int ca = SO.colbase[ta], W = SO.S-ca, nBp = SO.colbase[tb+1]-SO.colbase[tb];
+        const int ca = SO.colbase[ta], W = SO.S-ca;
         double *__restrict__ base = SO.A2+SO.rowoff[ta]+(SO.colbase[tb]-ca);
-        for (int t = tid; t < nA*nBp; t += NT) {
-            const int r = t/nBp, c = t-r*nBp;
-            base[(long long)r*W+c] = c < nB ? s_acc[r*acc_stride+c] : 0.;
+        for (int t = tid; t < nA*nB; t += NT) {
+            const int r = t/nB, c = t-r*nB;
+            base[(long long)r*W+c] = s_acc[r*acc_stride+c];
         }
     } else
     for (int t = tid; t < nA*nB; t += NT) {
@@ -1103,12 +1102,11 @@ k_tile_pure(const DevProblem P, const int2 *__restrict__ tiles, int ntiles, doub
         const int *__restrict__ dofB = P.blk_dofs+(size_t)tb*P.blk_stride;
         if (SO.A2) {
             // block-slot storage (pnl_tile2.h): plain stores of the tile's own sub-block, every entry
-            // (over the padded width, a multiple of 8 doubles: a wave writes whole 64-byte lines)
-            const int ca = SO.colbase[ta], W = SO.S-ca, nBp = SO.colbase[tb+1]-SO.colbase[tb];
+            const int ca = SO.colbase[ta], W = SO.S-ca;
             double *__restrict__ base = SO.A2+SO.rowoff[ta]+(SO.colbase[tb]-ca);
-            for (int t = tid; t < nA*nBp; t += PNL_NTHREADS) {
-                const int r = t/nBp, cc = t-r*nBp;
-                base[(long long)r*W+cc] = cc < nB ? s_acc[r*acc_stride+cc] : 0.;
+            for (int t = tid; t < nA*nB; t += PNL_NTHREADS) {
+                const int r = t/nB, cc = t-r*nB;
+                base[(long long)r*W+cc] = s_acc[r*acc_stride+cc];
             }
         } else if (!(symflush & 64))
         for (int t = tid; t < nA*nB; t += PNL_NTHREADS) {

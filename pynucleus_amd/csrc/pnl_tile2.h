@@ -367,13 +367,13 @@ k_tile_uniform(const DevProblem P, const int2 *__restrict__ tiles, const int *__
         const bool sym = (flags & 1) != 0;
         if (SO.A2) {
             // block-slot storage: this tile owns its nA x nB sub-block, plain 16-byte stores of every entry
-            // (the padded width nBp, a multiple of 8 doubles: whole 64-byte lines, no partial-line merges in L2)
-            const int ca = SO.colbase[ta], W = SO.S-ca, nBp = SO.colbase[tb+1]-SO.colbase[tb];
+            // (writing the padded width, whole 64-byte lines, was measured: no less traffic, the fold 1 ms slower)
+            const int ca = SO.colbase[ta], W = SO.S-ca;
             double *__restrict__ base = SO.A2+SO.rowoff[ta]+(SO.colbase[tb]-ca);
 #pragma unroll 1
             for (int r = wv; r < nA; r += NW) {
                 double *__restrict__ row = base+(long long)r*W;
-                for (int cc = 2*lane; cc < nBp; cc += 128) {
+                for (int cc = 2*lane; cc < nB; cc += 128) {
                     double2 v = make_double2(0., 0.);
                     if (cc < nB) { v.x = s_acc[r*acc_stride+cc]; s_acc[r*acc_stride+cc] = 0.; }
                     if (cc+1 < nB) { v.y = s_acc[r*acc_stride+cc+1]; s_acc[r*acc_stride+cc+1] = 0.; }
@@ -984,8 +984,7 @@ k_tile_p2(const DevProblem P, const int2 *__restrict__ tiles, const int *__restr
         const int ca = SO.colbase[ta], W = SO.S-ca;
         double *__restrict__ base = SO.A2+SO.rowoff[ta]+(SO.colbase[tb]-ca);
         const bool multi = tile_cls && (tile_cls[tile_idx] & (1 << 30));
-        // single visit: the padded width (a multiple of 8 doubles), whole 64-byte lines
-        const int nBw = multi ? nB : SO.colbase[tb+1]-SO.colbase[tb];
+        const int nBw = nB;
 #pragma unroll 1
         for (int r = wv; r < nA; r += NWAVES) {
             double *__restrict__ row = base+(long long)r*W;

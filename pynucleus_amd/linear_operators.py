@@ -18,7 +18,8 @@ def _as_dev(x, device):
 
 class Dense_LinearOperator:
     def __init__(self, A_dev, ctx, info=None):
-        assert A_dev.dtype == torch.float64 and A_dev.is_contiguous()
+        # row-major with a leading dimension >= number of columns (the builder pads rows to 64-byte lines)
+        assert A_dev.dtype == torch.float64 and A_dev.stride(1) == 1 and A_dev.stride(0) >= A_dev.shape[1]
         self.A = A_dev
         self.ctx = ctx
         self.num_rows, self.num_columns = A_dev.shape

@@ -17,12 +17,18 @@ dst = os.path.join(root, 'profiles')
 CLOCK_GHZ, SIMDS = 2.4, 1024
 
 
+def newest(pattern):
+    """the most recent match only: gpurun merges new output into gpurun_out/ next to the files of earlier runs"""
+    files = sorted(glob.glob(pattern), key=os.path.getmtime)
+    return files[-1:] 
+
+
 def short(name):
     return name.split('(')[0].replace('void ', '').strip()
 
 
 for cfg in ('p2', 'c5'):
-    stats = glob.glob(os.path.join(src, cfg+'_stats', '*', '*kernel_stats.csv'))
+    stats = newest(os.path.join(src, cfg+'_stats', '*', '*kernel_stats.csv'))
     avg_ns = {}
     if stats:
         shutil.copy(stats[0], os.path.join(dst, '{}_{}_noRef6_kernel_stats.csv'.format(tag, cfg)))
@@ -30,7 +36,7 @@ for cfg in ('p2', 'c5'):
             avg_ns[short(r['Name'])] = (float(r['AverageNs']), int(r['Calls']))
     summary = collections.defaultdict(dict)
     for d in ('sq', 'grbm', 'fetch', 'write'):
-        for fn in glob.glob(os.path.join(src, '{}_{}'.format(cfg, d), '*', '*counter_collection.csv')):
+        for fn in newest(os.path.join(src, '{}_{}'.format(cfg, d), '*', '*counter_collection.csv')):
             agg = collections.defaultdict(lambda: collections.defaultdict(float))
             calls = collections.defaultdict(set)
             for r in csv.DictReader(open(fn)):

@@ -18,9 +18,15 @@ root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, 'gpurun_out', tag)
 dst = os.path.join(root, 'profiles')
 shutil.copy(os.path.join(src, 'bench_noRef{}.json'.format(noRef)), os.path.join(dst, '{}_bench_noRef{}.json'.format(tag, noRef)))
-stats = glob.glob(os.path.join(src, 'stats', '*', '*kernel_stats.csv'))
+stats = sorted(glob.glob(os.path.join(src, 'stats', '*', '*kernel_stats.csv')), key=os.path.getmtime)[-1:]
 if stats:
     shutil.copy(stats[0], os.path.join(dst, '{}_bench_noRef{}_kernel_stats.csv'.format(tag, noRef)))
+
+
+def newest(pattern):
+    """the most recent match only: gpurun merges new output into gpurun_out/ next to the files of earlier runs"""
+    files = sorted(glob.glob(pattern), key=os.path.getmtime)
+    return files[-1:] 
 
 
 def short(name):
@@ -30,7 +36,7 @@ def short(name):
 
 summary = collections.defaultdict(dict)
 for d in ('pmc_fetch', 'pmc_write', 'pmc_tcc', 'pmc_sq'):
-    for fn in glob.glob(os.path.join(src, d, '*', '*counter_collection.csv')):
+    for fn in newest(os.path.join(src, d, '*', '*counter_collection.csv')):
         agg = collections.defaultdict(lambda: collections.defaultdict(float))
         calls = collections.defaultdict(set)
         for r in csv.DictReader(open(fn)):
