@@ -473,7 +473,10 @@ int run_worklist(pnl_context *ctx, const int4 *wl, const unsigned *wlc, unsigned
     hipLaunchKernelGGL(k_wl_scatter, dim3(512), dim3(PNL_NTHREADS), 0, ctx->stream, wl, wlc, cap, (const unsigned*)offs, cursor,
                        wlsorted);
     const int st = 4+DPE;
-    const int tab_max = (60*1024)/(st*(int)sizeof(double));
+    // LDS copy of the rule: 18 KB (8 workgroups per CU; rules with more points are read from global memory; 60 KB / 2 workgroups per CU was 0.6 ms slower at 98,304 cells)
+    const int wl_kb = getenv("PNL_WL_LDS_KB") ? std::max(4, atoi(getenv("PNL_WL_LDS_KB"))) : 18;
+    const int tab_max = (wl_kb*1024)/(st*(int)sizeof(double));
+    const int wl_grid = 256*std::max(1, std::min(8, 150/wl_kb));
     const size_t lds = (size_t)tab_max*st*sizeof(double);
     auto wfun = k_worklist_sorted<DIM, DPE, KT, false>;
     HIPCHK(ctx, hipFuncSetAttribute((const void*)wfun, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -486,7 +489,7 @@ int run_worklist(pnl_context *ctx, const int4 *wl, const unsigned *wlc, unsigned
         hipLaunchKernelGGL((k_worklist_lane<DIM, DPE, KT, false>), dim3(256*4), dim3(PNL_NTHREADS), 0, ctx->stream, ctx->P,
                            (const int4*)wlsorted, (const unsigned*)offs, A, (long long)ldA, (double*)ctx->b_D.p, SparseOut{},
                            dbg | (sym ? 8 : 0), ClusterTiles{});
-    hipLaunchKernelGGL(wfun, dim3(256*2), dim3(PNL_NTHREADS), lds, ctx->stream, ctx->P, (const int4*)wlsorted,
+    hipLaunchKernelGGL(wfun, dim3(wl_grid), dim3(PNL_NTHREADS), lds, ctx->stream, ctx->P, (const int4*)wlsorted,
                        (const unsigned*)offs, (const unsigned*)coff, A, (long long)ldA, (double*)ctx->b_D.p, tab_max,
                        SparseOut{}, PNL_WL_BINS-1, nmin | (sym ? 1 << 16 : 0), ClusterTiles{});
     HIPCHK(ctx, hipGetLastError());
