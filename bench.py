@@ -357,20 +357,18 @@ def main():
     achieved = dom_flops/dom_s/1e12 if dom_s > 0 else 0.
     both_s = sum(v[1] for v in kernels.values())
     all_flops = sum(v[0] for v in kernels.values())
-    # HBM traffic of the dominant kernel: PMC counters cannot be read inside this process; tools/pmc_traffic.sh runs this
-    # command under rocprofv3 --pmc (separate passes) and records the library build it measured.  The number is used only
+    # HBM traffic of the dominant kernel: PMC counters cannot be read inside this process; tools/profile_round.sh runs this
+    # command under rocprofv3 --pmc (separate passes) and tools/collect_profiles.py records the kernel sources it measured.  The number is used only
     # if it belongs to the library and the workload of this run, never a stale constant.
-    traffic, traffic_note = None, 'no PMC record (tools/pmc_traffic.sh) for this library build and workload'
+    traffic, traffic_note = None, 'no PMC record (tools/profile_round.sh + tools/collect_profiles.py) for these kernel sources and this workload'
     pmc_fn = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
     if os.path.exists(pmc_fn) and world == 1:
-        import hashlib
         from pynucleus_amd import _lib as _l
-        with open(_l.LIB_PATH, 'rb') as f:
-            lib_sha = hashlib.sha256(f.read()).hexdigest()[:16]
+        src_sha = _l.source_sha16()
         with open(pmc_fn) as f:
             rec = json.load(f)
         key = 'noRef{}{}'.format(args.noRef, '' if args.sectors == 6 else '_s{}'.format(args.sectors))
-        if key in rec and rec[key].get('lib_sha16') == lib_sha:
+        if key in rec and rec[key].get('src_sha16') == src_sha:
             traffic = rec[key].get(dominant.split('<')[0].split(' ')[0]+'_hbm_bytes_per_launch')
             traffic_note = 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command ({}), FETCH_SIZE doubled per MI355X_MICROARCH.md'.format(rec[key].get('tag'))
     # HBM view of the same launches: the algorithmic minimum is one write of the upper block triangle they fill

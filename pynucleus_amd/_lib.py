@@ -32,6 +32,21 @@ EXPORTS = ['pnl_create', 'pnl_destroy', 'pnl_error_string', 'pnl_version', 'pnl_
            'pnl_assemble_pairs_in_horizon', 'pnl_set_nonsymmetric', 'pnl_set_order_function', 'pnl_upload_pointwise_rules', 'pnl_assemble_dense_pointwise']
 
 
+def source_sha16():
+    """hash of the kernel / ABI sources the library is built from (identifies a build independently of the compiler's output:
+    bench.py uses the PMC traffic record of profiles/pmc_traffic.json only if it was measured with these sources)"""
+    import glob
+    import hashlib
+    root = os.path.dirname(_HERE)
+    files = sorted(glob.glob(os.path.join(_HERE, 'csrc', '*.h'))+glob.glob(os.path.join(_HERE, 'csrc', '*.hip'))
+                   +[os.path.join(root, 'include', 'pnl_hip.h'), os.path.join(_HERE, 'csrc', 'Makefile')])
+    h = hashlib.sha256()
+    for fn in files:
+        with open(fn, 'rb') as f:
+            h.update(os.path.basename(fn).encode()+b'\0'+f.read())
+    return h.hexdigest()[:16]
+
+
 class pnl_kernel(C.Structure):
     _fields_ = [('ktype', C.c_int32), ('interaction', C.c_int32), ('exponent', C.c_double), ('scale', C.c_double),
                 ('horizon2', C.c_double)]

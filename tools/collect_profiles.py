@@ -57,12 +57,14 @@ if os.path.exists(traffic_fn):
     rec = json.load(open(traffic_fn))
 rec['comment'] = ('HBM traffic per launch of the tile kernels from rocprofv3 --pmc passes of bench.py (tools/profile_round.sh): '
                   'FETCH_SIZE and WRITE_SIZE in separate passes (KB units x 1024).  FETCH_SIZE doubled per MI355X_MICROARCH.md '
-                  '(gfx950 reports half of wide coalesced reads); WRITE_SIZE is dominated by 8-byte fp64 atomics.  '
+                  '(gfx950 reports half of wide coalesced reads); WRITE_SIZE: plain 8- and 16-byte stores into the block-slot storage.  '
                   'Raw values: profiles/<tag>_pmc_summary_noRef<N>.json.')
 import hashlib
 with open(os.path.join(root, 'pynucleus_amd', 'libpnl_hip.so'), 'rb') as f:
     lib_sha = hashlib.sha256(f.read()).hexdigest()[:16]
-entry = {'tag': tag, 'lib_sha16': lib_sha}
+sys.path.insert(0, root)
+from pynucleus_amd._lib import source_sha16
+entry = {'tag': tag, 'lib_sha16': lib_sha, 'src_sha16': source_sha16()}
 for k in ('k_tile_distant', 'k_tile_pure', 'k_tile_uniform', 'k_tile_p2', 'k_fold_mirror'):
     if k in summary and 'FETCH_SIZE' in summary[k] and 'WRITE_SIZE' in summary[k]:
         entry[k+'_hbm_bytes_per_launch'] = int(1024*(2*summary[k]['FETCH_SIZE']+summary[k]['WRITE_SIZE']))
