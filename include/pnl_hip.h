@@ -341,6 +341,9 @@ int pnl_nfplan_get(const pnl_nfplan *P, int which, void *dst);
 typedef struct pnl_pattern pnl_pattern;
 int pnl_horizon_pattern(int dim, int nv, const double *vertices, int nc, const int32_t *cells, int dpe, int N, const int32_t *dofs,
                         double delta, int strict_lower, pnl_pattern **out);
+/* pattern of the near field of the cluster pairs pairs[npairs][2] (node ids of the tree): union of the blocks n1.dofs x n2.dofs,
+ * getSparseNearField NA:3226-3289; strict_lower keeps I > J (SSS) */
+int pnl_near_pattern(const pnl_tree *T, int npairs, const int32_t *pairs, int strict_lower, pnl_pattern **out);
 int64_t pnl_pattern_nnz(const pnl_pattern *P);
 int pnl_pattern_get(const pnl_pattern *P, int32_t *indptr, int32_t *indices);
 void pnl_pattern_destroy(pnl_pattern *P);

@@ -346,6 +346,32 @@ def getSparseNearField(dm, Pnear, symmetric=True, device=None):
     diagonal lives in its own vector).  With a torch device the keys of all blocks are generated, sorted and split into
     rows there (5e7 entries at 49k DoFs: 0.6 s of numpy sort on the host, tens of ms on the GPU)."""
     N = dm.num_dofs
+    # cluster pairs of ONE native tree: the pattern in C++ (bitmap per leaf, threaded)
+    if len(Pnear) and _use_native() and all(isinstance(cp.n1, native_node) and isinstance(cp.n2, native_node) for cp in Pnear):
+        T = Pnear[0].n1._T
+        if all(cp.n1._T is T and cp.n2._T is T for cp in Pnear):
+            import ctypes as C
+            pairs = np.ascontiguousarray([(cp.n1._k, cp.n2._k) for cp in Pnear], dtype=np.int32)
+            h = C.c_void_p()
+            rc = T.L.pnl_near_pattern(T.h, pairs.shape[0], pairs.ctypes.data, 1 if symmetric else 0, C.byref(h))
+            if rc == 0:
+                nnz = int(T.L.pnl_pattern_nnz(h))
+                if device is not None and getattr(device, 'type', 'cpu') == 'cuda':
+                    # filled straight into pinned host memory (torch caches the allocation), copied asynchronously
+                    import torch
+                    ip = torch.empty(N+1, dtype=torch.int32, pin_memory=True)
+                    ix = torch.empty(max(nnz, 1), dtype=torch.int32, pin_memory=True)
+                    T.L.pnl_pattern_get(h, C.c_void_p(ip.data_ptr()), C.c_void_p(ix.data_ptr()))
+                    T.L.pnl_pattern_destroy(h)
+                    return ip.to(device, non_blocking=True), ix[:nnz].to(device, non_blocking=True)
+                indptr = np.empty(N+1, dtype=np.int32)
+                indices = np.empty(nnz, dtype=np.int32)
+                T.L.pnl_pattern_get(h, indptr.ctypes.data, indices.ctypes.data)
+                T.L.pnl_pattern_destroy(h)
+                if device is not None:
+                    import torch
+                    return torch.from_numpy(indptr).to(device), torch.from_numpy(indices).to(device)
+                return indptr, indices
     if device is not None and len(Pnear):
         import torch
         nr = np.array([len(cp.n1.dofs) for cp in Pnear], dtype=np.int64)

@@ -45,7 +45,11 @@ int finalize(pnl_context *ctx) {
     const bool reorder = dpe == nV && dim == 2 && !getenv("PNL_NO_REORDER");
     if (reorder) {
         static const int perms[6][3] = {{0, 1, 2}, {1, 2, 0}, {2, 0, 1}, {0, 2, 1}, {2, 1, 0}, {1, 0, 2}};
-        for (int b = 0; b < nblocks; b++) {
+        // the blocks are independent: a few host threads (0.24 s on one thread at 98,304 cells)
+        const int nthr = (int)std::max(1u, std::min(8u, std::thread::hardware_concurrency()));
+        std::vector<std::thread> pool;
+        for (int th = 0; th < nthr; th++) pool.emplace_back([&, th]() {
+        for (int b = th; b < nblocks; b += nthr) {
             std::vector<std::pair<long long, int>> seen;   // (vertex*3+pos) -> count, small per block
             auto get = [&](int v, int pos) { for (auto &e : seen) if (e.first == (long long)v*3+pos) return e.second; return 0; };
             auto add = [&](int v, int pos, int d) { for (auto &e : seen) if (e.first == (long long)v*3+pos) { e.second += d; return; } seen.push_back({(long long)v*3+pos, d}); };
@@ -62,6 +66,8 @@ int finalize(pnl_context *ctx) {
                     for (int k = 0; k < 3; k++) { lperm[(size_t)c*3+k] = perms[best][k]; add(ctx->cells[(size_t)c*3+perms[best][k]], k, 1); }
                 }
         }
+        });
+        for (auto &t : pool) t.join();
     }
     for (int c = 0; c < ncp; c++) {
         for (int k = 0; k < nV; k++) cvid[(size_t)k*ncp+c] = -1-k;

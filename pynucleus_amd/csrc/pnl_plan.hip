@@ -717,9 +717,72 @@ int pnl_nfplan_get(const pnl_nfplan *P, int which, void *dst) {
 // parallel.
 struct pnl_pattern {
     std::vector<int32_t> indptr, indices;
+    // near-field pattern: the rows of a leaf share one sorted column list; pnl_pattern_get writes the rows straight into the
+    // caller's array (no 200 MB intermediate copy)
+    std::vector<std::vector<int32_t>> leaf_cols;
+    std::vector<int32_t> leaf_of;
+    long long nnz_gen = -1;
 };
 
 extern "C" {
+
+// Sparsity pattern of the near field (getSparseNearField NA:3226-3289): the union of the blocks n1.dofs x n2.dofs of the cluster
+// pairs, CSR with sorted rows; strict_lower keeps I > J (SSS).  The rows of a leaf share one column set: the DoFs of the column
+// clusters paired with the leaf or one of its ancestors -- marked in a bitmap per leaf, emitted in order.
+int pnl_near_pattern(const pnl_tree *T, int npairs, const int32_t *pairs, int strict_lower, pnl_pattern **out) {
+    if (!T || !out || npairs < 0 || (npairs && !pairs)) return PNL_ERR_INVALID;
+    const int N = T->N, nn = (int)T->nodes.size();
+    for (int k = 0; k < 2*npairs; k++) if (pairs[k] < 0 || pairs[k] >= nn) return PNL_ERR_INVALID;
+    // column clusters per row cluster
+    std::vector<std::vector<int32_t>> cols_of(nn);
+    for (int k = 0; k < npairs; k++) cols_of[pairs[2*k]].push_back(pairs[2*k+1]);
+    std::vector<int32_t> leaves;
+    for (int n = 0; n < nn; n++) if (T->nodes[n].child[0] < 0) leaves.push_back(n);
+    const int nl = (int)leaves.size();
+    std::vector<std::vector<int32_t>> leaf_cols(nl);
+    std::vector<double> w(nl);
+    for (int l = 0; l < nl; l++) w[l] = 1.+(T->nodes[leaves[l]].end-T->nodes[leaves[l]].beg);
+    const int nthreads = plan_threads();
+    par_ranges(nl, w, nthreads, [&](int, int l0, int l1) {
+        std::vector<uint64_t> bits(((size_t)N+63)/64);
+        for (int l = l0; l < l1; l++) {
+            std::fill(bits.begin(), bits.end(), 0ull);
+            bool any = false;
+            for (int a = leaves[l]; a >= 0; a = T->nodes[a].parent)
+                for (int32_t n2 : cols_of[a]) {
+                    const PNode &B = T->nodes[n2];
+                    for (int t = B.beg; t < B.end; t++) { const int J = T->perm[t]; bits[J >> 6] |= 1ull << (J & 63); }
+                    any = true;
+                }
+            if (!any) continue;
+            auto &v = leaf_cols[l];
+            for (size_t wd = 0; wd < bits.size(); wd++) {
+                uint64_t m = bits[wd];
+                while (m) { const int b = __builtin_ctzll(m); v.push_back((int32_t)(wd*64+b)); m &= m-1; }
+            }
+        }
+    });
+    pnl_pattern *P = new pnl_pattern();
+    P->indptr.assign((size_t)N+1, 0);
+    std::vector<int32_t> leaf_of(N, -1);
+    for (int l = 0; l < nl; l++) {
+        const PNode &L = T->nodes[leaves[l]];
+        for (int t = L.beg; t < L.end; t++) leaf_of[T->perm[t]] = l;
+    }
+    long long total = 0;
+    for (int I = 0; I < N; I++) {
+        const auto &v = leaf_cols[leaf_of[I]];
+        const long long cnt = strict_lower ? (std::lower_bound(v.begin(), v.end(), I)-v.begin()) : (long long)v.size();
+        total += cnt;
+        if (total >= (1ll << 31)) { delete P; return PNL_ERR_UNSUPPORTED; }
+        P->indptr[I+1] = (int32_t)total;
+    }
+    P->nnz_gen = total;
+    P->leaf_cols.swap(leaf_cols);
+    P->leaf_of.swap(leaf_of);
+    *out = P;
+    return PNL_OK;
+}
 
 int pnl_horizon_pattern(int dim, int nv, const double *vertices, int nc, const int32_t *cells, int dpe, int N, const int32_t *dofs,
                         double delta, int strict_lower, pnl_pattern **out) {
@@ -869,12 +932,22 @@ int pnl_horizon_pattern(int dim, int nv, const double *vertices, int nc, const i
     return PNL_OK;
 }
 
-int64_t pnl_pattern_nnz(const pnl_pattern *P) { return P ? (int64_t)P->indices.size() : -1; }
+int64_t pnl_pattern_nnz(const pnl_pattern *P) { return P ? (P->nnz_gen >= 0 ? (int64_t)P->nnz_gen : (int64_t)P->indices.size()) : -1; }
 
 int pnl_pattern_get(const pnl_pattern *P, int32_t *indptr, int32_t *indices) {
     if (!P || !indptr) return PNL_ERR_INVALID;
     std::copy(P->indptr.begin(), P->indptr.end(), indptr);
-    if (indices) std::copy(P->indices.begin(), P->indices.end(), indices);
+    if (!indices) return PNL_OK;
+    if (P->nnz_gen < 0) { std::copy(P->indices.begin(), P->indices.end(), indices); return PNL_OK; }
+    const int N = (int)P->indptr.size()-1;
+    std::vector<double> wr(N);
+    for (int I = 0; I < N; I++) wr[I] = 1.+(P->indptr[I+1]-P->indptr[I]);
+    par_ranges(N, wr, plan_threads(), [&](int, int i0, int i1) {
+        for (int I = i0; I < i1; I++) {
+            const auto &v = P->leaf_cols[P->leaf_of[I]];
+            std::copy(v.begin(), v.begin()+(P->indptr[I+1]-P->indptr[I]), indices+P->indptr[I]);
+        }
+    });
     return PNL_OK;
 }
 

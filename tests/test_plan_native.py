@@ -143,3 +143,26 @@ def test_native_horizon_pattern_equals_sparse_products(case):
     L.pnl_pattern_get(h, indptr.ctypes.data, indices.ctypes.data)
     L.pnl_pattern_destroy(h)
     assert np.array_equal(indptr, G.indptr) and np.array_equal(indices, G.indices)
+
+
+@pytest.mark.parametrize('symmetric', [True, False])
+def test_native_near_pattern_equals_the_numpy_one(symmetric, monkeypatch):
+    """pnl_near_pattern (bitmap per leaf over the cluster pairs of the native tree) against the sorted-keys construction"""
+    from pynucleus_amd import disc, P1_DoFMap, P2_DoFMap, PHYSICAL, clusters
+    for DoFMap, noRef in ((P1_DoFMap, 4), (P2_DoFMap, 3)):
+        dm = DoFMap(disc(noRef), PHYSICAL)
+        root, Pnear, Pfar = clusters.getNearFieldClusters(dm, 3., 8, 200)
+        assert isinstance(Pnear[0].n1, clusters.native_node)
+        a = clusters.getSparseNearField(dm, Pnear, symmetric)
+        monkeypatch.setenv('PNL_PLAN', 'numpy')
+        b = clusters.getSparseNearField(dm, Pnear, symmetric)
+        monkeypatch.delenv('PNL_PLAN')
+        assert a[0].dtype == b[0].dtype == np.int32 and a[1].dtype == b[1].dtype == np.int32
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+        # a subset of the pairs (what a rank owns) and the all-leaf cover
+        sub = Pnear[::3]
+        a = clusters.getSparseNearField(dm, sub, symmetric)
+        monkeypatch.setenv('PNL_PLAN', 'numpy')
+        b = clusters.getSparseNearField(dm, sub, symmetric)
+        monkeypatch.delenv('PNL_PLAN')
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
