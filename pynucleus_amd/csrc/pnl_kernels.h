@@ -2997,7 +2997,19 @@ k_spmv(const int *__restrict__ indptr, const int *__restrict__ indices, const do
     const int b = indptr[row], e = indptr[row+1];
     const double xi = x[row];
     double s = 0.;
-    for (int t = b+lane; t < e; t += 64) {
+    int t = b+lane;
+    if (!diag) {
+        // four independent (index, value, x) load chains per lane in flight: rows of the near field hold ~1000 entries
+        double s1 = 0., s2 = 0., s3 = 0.;
+        for (; t+192 < e; t += 256) {
+            const int J0 = indices[t], J1 = indices[t+64], J2 = indices[t+128], J3 = indices[t+192];
+            const double a0 = data[t], a1 = data[t+64], a2 = data[t+128], a3 = data[t+192];
+            s = __builtin_fma(a0, x[J0], s); s1 = __builtin_fma(a1, x[J1], s1);
+            s2 = __builtin_fma(a2, x[J2], s2); s3 = __builtin_fma(a3, x[J3], s3);
+        }
+        s += s1+(s2+s3);
+    }
+    for (; t < e; t += 64) {
         const int J = indices[t];
         const double a = data[t];
         s = __builtin_fma(a, x[J], s);
