@@ -214,7 +214,14 @@ def extra_configs(dev):
     def big():
         mesh = disc(7, sectors=12)
         dense_leg('dense_97537dofs_P1_s0.5', P1_DoFMap(mesh, PHYSICAL), getFractionalKernel(2, 0.5), 3, reps=2)
-    for name, leg in (('P2', p2), ('C5', c5), ('C3', c3), ('C4', c4), ('dense_1e5', big)):
+    # BASELINE configs[4] at its stated size: P2, three-layer variable order, ~10^5 DoFs -- here on ONE MI355X (76 GB block + 80 GB
+    # block-slot storage)
+    def c5big():
+        mesh = disc(6, sectors=12)
+        orders = np.array([[0.3, 0.4, 0.5], [0.4, 0.5, 0.6], [0.5, 0.6, 0.7]])
+        dense_leg('C5_P2_layers_dense_97537dofs', P2_DoFMap(mesh, PHYSICAL),
+                  getFractionalKernel(2, layersFractionalOrder(2, np.array([-1., -0.3, 0.3, 1.]), orders)), 6, reps=2)
+    for name, leg in (('P2', p2), ('C5', c5), ('C3', c3), ('C4', c4), ('dense_1e5', big), ('C5_1e5', c5big)):
         t0 = time.perf_counter()
         try:
             leg()
