@@ -57,7 +57,7 @@ if os.path.exists(traffic_fn):
     rec = json.load(open(traffic_fn))
 rec['comment'] = ('HBM traffic per launch of the tile kernels from rocprofv3 --pmc passes of bench.py (tools/profile_round.sh): '
                   'FETCH_SIZE and WRITE_SIZE in separate passes (KB units x 1024).  FETCH_SIZE doubled per MI355X_MICROARCH.md '
-                  '(gfx950 reports half of wide coalesced reads); WRITE_SIZE: plain 8- and 16-byte stores into the block-slot storage.  '
+                  '(gfx950 reports half of wide coalesced reads; not for k_fold_mirror, whose 8-byte gathers are calibrated on their known volume); WRITE_SIZE: plain 8- and 16-byte stores into the block-slot storage.  '
                   'Raw values: profiles/<tag>_pmc_summary_noRef<N>.json.')
 import hashlib
 with open(os.path.join(root, 'pynucleus_amd', 'libpnl_hip.so'), 'rb') as f:
@@ -67,7 +67,11 @@ from pynucleus_amd._lib import source_sha16
 entry = {'tag': tag, 'lib_sha16': lib_sha, 'src_sha16': source_sha16()}
 for k in ('k_tile_distant', 'k_tile_pure', 'k_tile_uniform', 'k_tile_p2', 'k_fold_mirror'):
     if k in summary and 'FETCH_SIZE' in summary[k] and 'WRITE_SIZE' in summary[k]:
-        entry[k+'_hbm_bytes_per_launch'] = int(1024*(2*summary[k]['FETCH_SIZE']+summary[k]['WRITE_SIZE']))
+        # FETCH_SIZE x 2 for the tile kernels (their known input volume, ~13 KB of cell data per tile, matches the doubled value);
+        # the fold pass reads every stored entry of the block-slot storage exactly once with 8-byte gathers -- a known byte count
+        # (8 x slot entries, 20 GB at 48,769 DoFs) that the RAW counter reproduces to 25 %, so it is not doubled there
+        fac = 1 if k == 'k_fold_mirror' else 2
+        entry[k+'_hbm_bytes_per_launch'] = int(1024*(fac*summary[k]['FETCH_SIZE']+summary[k]['WRITE_SIZE']))
         entry[k+'_fetch_size_kb'] = summary[k]['FETCH_SIZE']
         entry[k+'_write_size_kb'] = summary[k]['WRITE_SIZE']
 rec['noRef{}'.format(noRef)] = entry
