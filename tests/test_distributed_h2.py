@@ -93,7 +93,7 @@ def _worker_body(rank, world, port, out, noRef, s):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('world,noRef,s', [(2, 4, 0.75), (3, 4, 0.25)])
+@pytest.mark.parametrize('world,noRef,s', [(2, 4, 0.75), (3, 4, 0.25), (4, 5, 0.5)])
 def test_halo_h2_operator(world, noRef, s):
     import torch.multiprocessing as mp
     ctx = mp.get_context('spawn')
