@@ -33,7 +33,7 @@ for r in range(P):
         ctx.assemble_dense_tiles(A.data_ptr(), A.stride(0), True, tiles, c0, c1)
     t3h = time.perf_counter()
     torch.cuda.synchronize(); t3 = time.perf_counter()
-    print('   pipelined: {:.2f} ms/step (host {:.2f} ms/step)'.format(1e3*(t3-t2)/5, 1e3*(t3h-t2)/5), flush=True)
+    print('   pipelined: {:.2f} ms/step (host {:.2f} ms/step); kernel ms {}'.format(1e3*(t3-t2)/5, 1e3*(t3h-t2)/5, {k: round(v, 2) for k, v in ctx.kernel_ms().items()}), flush=True)
     print('rank {}: cells [{}, {}) tiles {} slab {} x {} ({:.2f} GB): step {:.2f} ms, phases {}'.format(
         r, c0, c1, tiles.shape[0], rows.shape[0], cols.shape[0], A.numel()*8/1e9, 1e3*(t1-t0), {k: round(v, 2) for k, v in ms.items()}), flush=True)
     tot += t1-t0
