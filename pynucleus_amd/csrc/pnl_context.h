@@ -31,6 +31,10 @@ struct pnl_context {
     static constexpr int NAUX = 4;
     hipStream_t aux[NAUX] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_join[NAUX] = {nullptr, nullptr, nullptr, nullptr};
+    // recorded behind the fold + mirror pass of a block-slot assembly: from here on A only receives atomic adds, so the touching
+    // pairs and the boundary term run on side streams next to the work-list kernels (one order class)
+    hipEvent_t ev_fold = nullptr;
+    bool fold_event_set = false;
     std::string err;
     // host copies
     int dim = 0, nv = 0, nc = 0, dpe = 0, dpv = 0, dped = 0, N = 0, nb = 0, qmax = -1;
@@ -72,7 +76,7 @@ struct pnl_context {
     DevBuf b_kcls, b_fcls, b_uni, b_tilecls, b_ttwphif;
     // block-slot storage (pnl_tile2.h): padded column offsets of the blocks, row offsets, copies (block, slot) of every DoF,
     // the tiles that several order classes visit, the storage itself (allocated by the first assembly that uses it)
-    DevBuf b_scolbase, b_srowoff, b_cpoff, b_cpslot, b_cprow, b_foldtab, b_bkcls, b_bfcls, b_bdefer, b_multitiles, b_slotA;
+    DevBuf b_scolbase, b_srowoff, b_cpoff, b_cpslot, b_cprow, b_foldtab, b_bkcls, b_bfcls, b_bdefer, b_multitiles, b_slotA, b_candtiles, b_candq;
     int slot_S = 0, n_multitiles = 0;
     long long slot_total = 0;         // doubles
     // row slab of a rank (pnl_set_row_slab, pnl_slab.hip)

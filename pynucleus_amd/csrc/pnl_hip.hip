@@ -573,7 +573,12 @@ int launch_tiles(pnl_context *ctx, int wl_slot, double *A, int64_t ldA, int cell
     HIPCHK(ctx, hipGetLastError());
     HIPCHK(ctx, hipEventRecord(ctx->ev[6], ctx->stream));
     // block-slot storage: A = A' + A'^T is formed now (it overwrites A); the work-list kernels then write both images
-    if (SO.A2) { int rc = pnl2_fold_mirror(ctx, SO, A, ldA); if (rc) return rc; }
+    if (SO.A2) {
+        int rc = pnl2_fold_mirror(ctx, SO, A, ldA);
+        if (rc) return rc;
+        HIPCHK(ctx, hipEventRecord(ctx->ev_fold, ctx->stream));
+        ctx->fold_event_set = true;
+    }
     return run_worklist<DIM, DPE, KT>(ctx, (const int4*)ctx->b_wl.p, wlc, ctx->wl_cap_each, A, ldA, ctx->symflush || SO.A2 != nullptr);
 }
 
@@ -777,6 +782,7 @@ int assemble_impl(pnl_context *ctx, double *A, int64_t ldA, int zero_exterior, i
     if (ctx->have_tile_order) HIPCHK(ctx, hipMemsetAsync(ctx->b_Dt.p, 0, sizeof(double)*(size_t)ctx->ncp*(DPE*(DPE+1)/2), ctx->stream));
     HIPCHK(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
     ctx->tiles_launched = ntiles > 0;
+    ctx->fold_event_set = false;
     // a piecewise-constant variable order is assembled class by class: every pass sees the kernel, order formula and
     // singular rules of one order value and skips the pairs of the other classes in its classification
     const int norient = ctx->nonsym ? 2 : 1;
@@ -824,6 +830,13 @@ int assemble_impl(pnl_context *ctx, double *A, int64_t ldA, int zero_exterior, i
         HIPCHK(ctx, hipGetLastError());
     }
     HIPCHK(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
+    // one order class behind a fold pass: the touching pairs (side stream 0) and the boundary term (side stream 1) start at the
+    // fold, next to the work-list kernels on the caller's stream -- everything after the fold only adds with atomics.  The
+    // phase timers then show what is left of them after the work list ("singular"), the boundary phase reads 0
+    hipStream_t const main_stream = ctx->stream;
+    const bool overlap = ctx->fold_event_set && ncls*norient == 1 && !getenv("PNL_NO_OVERLAP");
+    struct StreamGuard { pnl_context *c; hipStream_t s; ~StreamGuard() { c->stream = s; } } stream_guard{ctx, main_stream};
+    if (overlap) { HIPCHK(ctx, hipStreamWaitEvent(ctx->aux[0], ctx->ev_fold, 0)); ctx->stream = ctx->aux[0]; }
     {
         ClassFork fork(ctx, ncls*norient);
         for (int ko = 0; ko < ncls*norient; ko++) {
@@ -836,7 +849,11 @@ int assemble_impl(pnl_context *ctx, double *A, int64_t ldA, int zero_exterior, i
         }
     }
     ctx->orient = 0;
-    HIPCHK(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
+    if (overlap) {
+        HIPCHK(ctx, hipEventRecord(ctx->ev_join[0], ctx->aux[0]));
+        HIPCHK(ctx, hipStreamWaitEvent(ctx->aux[1], ctx->ev_fold, 0));
+        ctx->stream = zero_exterior ? ctx->aux[1] : main_stream;
+    } else HIPCHK(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
     if (zero_exterior) {
         // variable order: the distant (cell, facet) pairs of ALL classes in one launch with per-class kernel / order-formula
         // tables; the touching pairs per class (their rules are per class), on side streams
@@ -873,6 +890,15 @@ int assemble_impl(pnl_context *ctx, double *A, int64_t ldA, int zero_exterior, i
         }
     }
     ctx->cur = 0;
+    if (overlap) {
+        if (zero_exterior) {
+            HIPCHK(ctx, hipEventRecord(ctx->ev_join[1], ctx->aux[1]));
+            HIPCHK(ctx, hipStreamWaitEvent(main_stream, ctx->ev_join[1], 0));
+        }
+        HIPCHK(ctx, hipStreamWaitEvent(main_stream, ctx->ev_join[0], 0));
+        ctx->stream = main_stream;
+        HIPCHK(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
+    }
     HIPCHK(ctx, hipEventRecord(ctx->ev[4], ctx->stream));
     if (ctx->slab_rows == 0) {
         const long long nt = (long long)ctx->nc*DPE*DPE;
@@ -1557,6 +1583,7 @@ int pnl_create(int device_id, pnl_context **out) {
     for (auto &st : ctx->aux)
         if ((e0 = hipStreamCreateWithFlags(&st, hipStreamNonBlocking)) != hipSuccess) { delete ctx; return hiperr("hipStreamCreateWithFlags", e0); }
     if (hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess) { delete ctx; return PNL_ERR_HIP; }
+    if (hipEventCreateWithFlags(&ctx->ev_fold, hipEventDisableTiming) != hipSuccess) { delete ctx; return PNL_ERR_HIP; }
     for (auto &e : ctx->ev_join)
         if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { delete ctx; return PNL_ERR_HIP; }
     for (auto &e : ctx->ev)
@@ -1586,6 +1613,7 @@ void pnl_destroy(pnl_context *ctx) {
             if (e) (void)hipEventDestroy(e);
     for (auto &st : ctx->aux) if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+    if (ctx->ev_fold) (void)hipEventDestroy(ctx->ev_fold);
     for (auto &e : ctx->ev_join) if (e) (void)hipEventDestroy(e);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     for (auto *c : ctx->cls) delete c;
@@ -1909,6 +1937,41 @@ static int upload_tiles(pnl_context *ctx, std::vector<int2> &tiles, int cell_beg
             }
         });
         for (auto &th : pool) th.join();
+        // tiles the bounds left open: the exact order range of their cell pairs, on the device (constant order, 2D)
+        if (allow && L == 0 && ctx->dim == 2 && (T == 64 || T == 32) && !getenv("PNL_NO_EXACT_TILES")) {
+            std::vector<int2> cand;
+            std::vector<size_t> cand_idx;
+            for (size_t i = 0; i < tiles.size(); i++) {
+                const int2 &t = tiles[i];
+                if (qof[i] != 0 || t.x == t.y || !ctx->blocks[t.x].full || !ctx->blocks[t.y].full) continue;
+                if (filter && !(t.x*T >= cell_begin && (t.x+1)*T <= cell_end)) continue;
+                cand.push_back(t); cand_idx.push_back(i);
+            }
+            if (!cand.empty()) {
+                int rc;
+                if ((rc = upload(ctx, ctx->b_candtiles, cand.data(), cand.size()))) return rc;
+                if ((rc = ensure(ctx, ctx->b_candq, cand.size()))) return rc;
+                const int grid = (int)std::min<size_t>(cand.size(), 256*8);
+                const DevFormula qo = to_dev(forms[k]);
+                if (T == 64)
+                    hipLaunchKernelGGL(k_tile_order_range<64>, dim3(grid), dim3(256), 0, ctx->stream, ctx->P, qo, (const int2*)ctx->b_candtiles.p,
+                                       (int)cand.size(), (signed char*)ctx->b_candq.p);
+                else
+                    hipLaunchKernelGGL(k_tile_order_range<32>, dim3(grid), dim3(256), 0, ctx->stream, ctx->P, qo, (const int2*)ctx->b_candtiles.p,
+                                       (int)cand.size(), (signed char*)ctx->b_candq.p);
+                HIPCHK(ctx, hipGetLastError());
+                std::vector<signed char> cq(cand.size());
+                HIPCHK(ctx, hipMemcpyAsync(cq.data(), ctx->b_candq.p, cand.size(), hipMemcpyDeviceToHost, ctx->stream));
+                HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+                size_t moved = 0;
+                for (size_t c = 0; c < cand.size(); c++) {
+                    const int q = cq[c];
+                    if (q < 2 || q > qlimit || (q == 2 && !q2ok)) continue;
+                    qof[cand_idx[c]] = (signed char)q; moved++;
+                }
+                if (getenv("PNL_VERBOSE")) fprintf(stderr, "[pnl] exact order range: %zu of %zu open tiles are uniform\n", moved, cand.size());
+            }
+        }
         for (size_t i = 0; i < tiles.size(); i++) {
             const int q = qof[i];
             if (q < 0) continue;

@@ -3306,3 +3306,54 @@ k_h2_down_leaves(const H2Dev H, double *__restrict__ y) {
         y[dofs[k]] += s;                         // leaves partition the DoFs
     }
 }
+
+// ---------------------------------------------------------------------------------------------
+// Exact order range of a tile (block a, block b), a != b, both blocks full: the order formula (FL2:622-642) of all
+// TILE x TILE cell pairs, evaluated with the SAME function the general tile kernels use (quad_order_fast), and the
+// shared-vertex test of getProtoPanelType (NO:280-378).  out[t] = q if every pair is a distant pair of order q, else 0.
+// Run once per tile list on the tiles the host's two-sided bounds (tile_uniform_order) could not settle: the ring where
+// the order steps from q to q+1 is a few cells wide, the bounds over two 64-cell blocks leave a band of several blocks.
+template <int TILE>
+__global__ void __launch_bounds__(256)
+k_tile_order_range(const DevProblem P, const DevFormula qo, const int2 *__restrict__ tiles, int ntiles, signed char *__restrict__ out) {
+    __shared__ double s_cen[4][TILE], s_h[2][TILE], s_Ld[2][TILE];
+    __shared__ float s_lh[4][TILE];
+    __shared__ int s_vid[6][TILE];
+    __shared__ int s_red[3];
+    const int tid = threadIdx.x;
+#pragma unroll 1
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const int2 tl = tiles[t];
+        for (int u = tid; u < 2*TILE; u += 256) {
+            const int side = u/TILE, l = u-side*TILE, c = (side ? tl.y : tl.x)*TILE+l;
+            s_cen[side*2+0][l] = P.ccen[c];
+            s_cen[side*2+1][l] = P.ccen[(size_t)P.ncp+c];
+            s_h[side][l] = P.ch[c];
+            const double lh = P.clog[c], Ld = P.clog[(size_t)P.ncp+c];
+            s_Ld[side][l] = Ld;
+            s_lh[side*2+0][l] = (float)lh;
+            s_lh[side*2+1][l] = (float)Ld;
+#pragma unroll
+            for (int k = 0; k < 3; k++) s_vid[side*3+k][l] = P.cvid[(size_t)k*P.ncp+c];
+        }
+        if (tid == 0) { s_red[0] = 1 << 30; s_red[1] = 0; s_red[2] = 0; }
+        __syncthreads();
+        int mn = 1 << 30, mx = 0, bad = 0;
+        for (int p = tid; p < TILE*TILE; p += 256) {
+            const int i = p/TILE, j = p-i*TILE;
+            const int a0 = s_vid[0][i], a1 = s_vid[1][i], a2 = s_vid[2][i];
+            const int b0 = s_vid[3][j], b1 = s_vid[4][j], b2 = s_vid[5][j];
+            // padding cells carry negative vertex ids: never uniform
+            bad |= (a0 < 0) | (b0 < 0);
+            bad |= (a0 == b0) | (a0 == b1) | (a0 == b2) | (a1 == b0) | (a1 == b1) | (a1 == b2) | (a2 == b0) | (a2 == b1) | (a2 == b2);
+            const double dx = s_cen[0][i]-s_cen[2][j], dy = s_cen[1][i]-s_cen[3][j];
+            const int q = quad_order_fast(qo, s_h[0][i], s_h[1][j], s_lh[0][i], s_lh[2][j], s_lh[1][i], s_lh[3][j], s_Ld[0][i], s_Ld[1][j],
+                                          dx*dx+dy*dy);
+            mn = min(mn, q); mx = max(mx, q);
+        }
+        atomicMin(&s_red[0], mn); atomicMax(&s_red[1], mx); atomicOr(&s_red[2], bad);
+        __syncthreads();
+        if (tid == 0) out[t] = (signed char)((!s_red[2] && s_red[0] == s_red[1] && s_red[0] >= 2 && s_red[0] < 120) ? s_red[0] : 0);
+        __syncthreads();
+    }
+}
