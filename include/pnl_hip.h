@@ -375,6 +375,53 @@ int pnl_gemv(pnl_context *ctx, const double *A_dev, int64_t ldA, int n, const do
  * *iters and the final residual norm in *residual. */
 int pnl_cg_jacobi(pnl_context *ctx, const double *A_dev, int64_t ldA, int n, const double *b_dev, double *x_dev,
                   double tol, int maxiter, int *iters, double *residual);
+
+/* ---- solver side on the device: geometric multigrid over a hierarchy of assembled nonlocal operators
+ *      (fractionalLevel, nl/PyNucleus_nl/helpers.py:312-380), multigrid-preconditioned CG, theta time stepping -----------
+ * y = alpha A x + beta b for a dense row-major nrows x ncols block (LinearOperator.residual = (alpha, beta) = (-1, 1);
+ * b_dev may be y_dev) and y = alpha A x + beta y for a CSR matrix on the device (restriction / prolongation
+ * multilevelSolver/PyNucleus_multilevelSolver/restriction_*_P1.pxi, mass matrix). */
+int pnl_gemv_axpby(pnl_context *ctx, const double *A_dev, int64_t ldA, int nrows, int ncols, const double *x_dev, double alpha,
+                   double beta, const double *b_dev, double *y_dev);
+int pnl_csr_matvec(pnl_context *ctx, int nrows, const int32_t *indptr_dev, const int32_t *indices_dev, const double *data_dev,
+                   const double *x_dev, double alpha, double beta, double *y_dev);
+/* One level of the hierarchy, level 0 = coarsest (multigrid_{SCALAR}.pxi:86-135 levelMemory: A, R, P): the dense operator and
+ * its diagonal (Jacobi smoother, smoothers_{SCALAR}.pxi:118-131), the restriction to the next coarser level (n_coarse x n)
+ * and the prolongation from it (n x n_coarse) as CSR arrays on the device (unused on level 0, where only n counts). */
+typedef struct {
+    int32_t n;
+    int32_t pad;
+    const double *A_dev;
+    int64_t ldA;
+    const double *diag_dev;
+    const int32_t *R_indptr_dev, *R_indices_dev;
+    const double *R_data_dev;
+    const int32_t *P_indptr_dev, *P_indices_dev;
+    const double *P_data_dev;
+} pnl_mg_level_desc;
+typedef struct pnl_mg pnl_mg;
+/* multigrid.__init__ / setup (:86-235): V cycle, Jacobi smoother with damping omega and presmooth / postsmooth sweeps
+ * (defaults of the reference: 2/3, 1, 1), coarse solver = multiplication with the inverse of the coarsest operator
+ * (coarse_inverse_dev, n_0 x n_0 row-major; the reference factorises it with LU).  The level arrays stay owned by the caller
+ * and must outlive the object. */
+int pnl_mg_create(pnl_context *ctx, int nlevels, const pnl_mg_level_desc *levels, const double *coarse_inverse_dev, double omega,
+                  int presmooth, int postsmooth, pnl_mg **out);
+int pnl_mg_destroy(pnl_mg *mg);
+/* one cycle on the finest level (solveOnLevel :237-292); x_is_zero: the first residual is b (simpleResidual) */
+int pnl_mg_cycle(pnl_mg *mg, const double *b_dev, double *x_dev, int x_is_zero);
+/* multigrid.solve (:296-390): cycles until ||b - A x||_2 <= tol or maxiter; residuals[0..min(iters+1, cap)) = the norms */
+int pnl_mg_solve(pnl_mg *mg, const double *b_dev, double *x_dev, double tol, int maxiter, int x_is_zero, int *iters, double *residuals,
+                 int residuals_cap);
+/* cg_solver.solve (base/PyNucleus_base/solvers.pyx:363-444) preconditioned by one cycle (multigridPreconditioner :470-497);
+ * A_dev NULL: the finest operator of the hierarchy; convergence on sqrt(r.Br) like the reference */
+int pnl_mg_cg(pnl_mg *mg, const double *A_dev, int64_t ldA, const double *b_dev, double *x_dev, double tol, int maxiter, int x_is_zero,
+              int *iters, double *residuals, int residuals_cap);
+/* CrankNicolson.step (base/PyNucleus_base/timestepping.py:93-112) for M u_t + S u = g:
+ * (M/dt + theta S) u_new = (M/dt) u - (1-theta) S u + forcing, forcing = (1-theta) g(t) + theta g(t+dt) (setRHS :76-91),
+ * solved by pnl_mg_cg on the hierarchy mg of M/dt + theta S from the initial guess u (u_dev is overwritten). */
+int pnl_theta_step(pnl_mg *mg, const double *S_dev, int64_t ldS, const int32_t *M_indptr_dev, const int32_t *M_indices_dev,
+                   const double *M_data_dev, double dt, double theta, const double *forcing_dev, double *u_dev, double tol, int maxiter,
+                   int *iters, double *residual);
 /* 1/diag(A) into dinv_dev (jacobi_solver.setup, solvers.pyx:233-237) */
 int pnl_inv_diagonal(pnl_context *ctx, const double *A_dev, int64_t ldA, int n, double *dinv_dev);
 

@@ -1,0 +1,161 @@
+"""TEST INFRASTRUCTURE -- CPU restatement (numpy, dense) of the solver side of the reference for SURVEY 8(f) row 4:
+geometric multigrid on a hierarchy of assembled nonlocal operators, multigrid-preconditioned CG and the theta time
+stepper of the fractional heat equation.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+import this module; the product (pynucleus_amd/) never does.
+
+Parity: pinned by the reference's own stored numbers (tests/test_solver_side.py):
+  tests/cache_runFractionalHeat.py--domaininterval--sconst(0.25)--problemconstant--elementP1--solvercg-mg--matrixFormatdense
+  tests/cache_runFractionalHeat.py--domaininterval--sconst(0.25)--problemknownSolution--elementP1--solvercg-jacobi--matrixFormatH2
+  tests/cache_runFractionalHeat.py--domaininterval--sconst(0.75)--problemknownSolution--elementP1--solvercg-mg--matrixFormatH2
+  tests/cache_runFractional.py--domaininterval--sconst(0.25)--problemconstant--elementP1--solvercg-mg--matrixFormatdense
+
+Reference routines restated (file:line):
+  restriction_1D_P1.pxi / restriction_2D_P1.pxi:8-72       buildRestriction_{1,2}D_P1 (children 2c, 2c+1 / 4c .. 4c+3)
+  multigrid_{SCALAR}.pxi:237-292                            multigrid.solveOnLevel
+  multigrid_{SCALAR}.pxi:296-390                            multigrid.solve
+  smoothers_{SCALAR}.pxi:88-108, 118-131                    separableSmoother.eval, jacobiPreconditioner
+  base/PyNucleus_base/solvers.pyx:363-444                   cg_solver.solve
+  base/PyNucleus_base/timestepping.py:64-112                CrankNicolson.setRHS / step
+  nl/PyNucleus_nl/discretizedProblems.py:740-785            buildTransientHierarchy, determineTimeSteps
+  nl/PyNucleus_nl/discretizedProblems.py:276-333            L2 errors of a transient solution
+  nl/PyNucleus_nl/nonlocalProblems.py:651-662, 710-727, 1641-1672   the 'constant' / 'knownSolution' problems, transient version
+"""
+import numpy as np
+
+
+def build_restriction_P1(dm_coarse, dm_fine):
+    """R[coarse dof, fine dof]: 1 at the coarse vertex, 1/2 at the midpoints of its edges.  Walks the coarse cells and
+    their children like the reference does (the refinement numbers the children of cell c 2c, 2c+1 in 1D:
+    (c0, m), (m, c1); 4c .. 4c+3 in 2D: (c0, m01, m02), (c1, m12, m01), (c2, m02, m12), (m01, m12, m02))."""
+    dim = dm_coarse.mesh.manifold_dim
+    R = np.zeros((dm_coarse.num_dofs, dm_fine.num_dofs))
+
+    def enter(I, J, v):
+        if I >= 0 and J >= 0:
+            R[I, J] = v
+    for c in range(dm_coarse.mesh.num_cells):
+        if dim == 1:
+            s0, s1 = 2*c, 2*c+1
+            enter(dm_coarse.dofs[c, 0], dm_fine.dofs[s0, 0], 1.0)
+            enter(dm_coarse.dofs[c, 0], dm_fine.dofs[s0, 1], 0.5)
+            enter(dm_coarse.dofs[c, 1], dm_fine.dofs[s0, 1], 0.5)
+            enter(dm_coarse.dofs[c, 1], dm_fine.dofs[s1, 1], 1.0)
+        else:
+            s0, s1, s2 = 4*c, 4*c+1, 4*c+2
+            d0, d1, d2 = dm_coarse.dofs[c]
+            enter(d0, dm_fine.dofs[s0, 0], 1.0); enter(d0, dm_fine.dofs[s0, 1], 0.5); enter(d0, dm_fine.dofs[s0, 2], 0.5)
+            enter(d1, dm_fine.dofs[s0, 1], 0.5); enter(d1, dm_fine.dofs[s1, 0], 1.0); enter(d1, dm_fine.dofs[s1, 1], 0.5)
+            enter(d2, dm_fine.dofs[s0, 2], 0.5); enter(d2, dm_fine.dofs[s1, 1], 0.5); enter(d2, dm_fine.dofs[s2, 0], 1.0)
+    return R
+
+
+class Multigrid:
+    """levels[l] = {'A': dense operator, 'R': restriction to level l-1, 'P': prolongation from it}; level 0 = coarsest."""
+
+    def __init__(self, levels, omega=2./3., presmoothingSteps=1, postsmoothingSteps=1):
+        self.levels = levels
+        self.invD = [None]+[omega/np.diag(L['A']) for L in levels[1:]]
+        self.pre, self.post = presmoothingSteps, postsmoothingSteps
+        self.coarse_inverse = np.linalg.inv(levels[0]['A'])
+
+    def smooth(self, l, b, x, steps, simple):
+        A = self.levels[l]['A']
+        for _ in range(steps):
+            res = b.copy() if simple else b-A@x
+            simple = False
+            x += self.invD[l]*res
+
+    def solveOnLevel(self, l, b, x, simple=False):
+        if l == 0:
+            x[:] = self.coarse_inverse@b
+            return
+        L = self.levels[l]
+        self.smooth(l, b, x, self.pre, simple)
+        res = b-L['A']@x
+        defect = L['R']@res
+        solcg = np.zeros(self.levels[l-1]['A'].shape[0])
+        self.solveOnLevel(l-1, defect, solcg, True)
+        x += L['P']@solcg
+        self.smooth(l, b, x, self.post, False)
+
+    def solve(self, b, x=None, tol=1e-8, maxiter=50):
+        simple = x is None
+        x = np.zeros_like(b) if x is None else x.copy()
+        A = self.levels[-1]['A']
+        residuals = [np.linalg.norm(b if simple else b-A@x)]
+        it = 0
+        while residuals[-1] > tol and it < maxiter:
+            it += 1
+            self.solveOnLevel(len(self.levels)-1, b, x, simple)
+            simple = False
+            residuals.append(np.linalg.norm(b-A@x))
+        return x, it, residuals
+
+    def precondition(self, r):
+        z = np.zeros_like(r)
+        self.solveOnLevel(len(self.levels)-1, r, z, True)
+        return z
+
+
+def cg(A, b, x0=None, tol=1e-8, maxiter=1000, B=None):
+    """cg_solver.solve: convergence on sqrt(r.Br), residual recomputed every 50 iterations."""
+    B = B or (lambda r: r.copy())
+    x = np.zeros_like(b) if x0 is None else x0.copy()
+    r = b.copy() if x0 is None else b-A@x
+    p = B(r)
+    betaOld = r@p
+    residuals = [np.sqrt(abs(betaOld))]
+    its = 0
+    if residuals[-1] > tol:
+        k = 0
+        its = maxiter
+        for i in range(maxiter):
+            Ap = A@p
+            alpha = betaOld/(p@Ap)
+            x += alpha*p
+            r -= alpha*Ap
+            if k == 50:
+                r = b-A@x
+                k = 0
+            Br = B(r)
+            beta = r@Br
+            residuals.append(np.sqrt(abs(beta)))
+            its = i
+            if residuals[-1] <= tol:
+                break
+            p = Br+(beta/betaOld)*p
+            betaOld = beta
+            k += 1
+            if i == maxiter-1:
+                its = maxiter
+    return x, its, residuals
+
+
+def theta_step(S, M, dt, theta, forcing, u, solve):
+    """CrankNicolson.step: (M/dt + theta S) u_new = M u / dt - (1 - theta) S u + forcing"""
+    rhs = M@u/dt-(1.-theta)*(S@u)+forcing
+    return solve(rhs, u)
+
+
+def heat_time_steps(h, finalTime=1.0, timeStepperType='Crank-Nicolson'):
+    """determineTimeSteps (discretizedProblems.py:774-783)"""
+    dt = np.sqrt(h) if timeStepperType == 'Crank-Nicolson' else h
+    n = int(np.around(finalTime/dt))
+    return finalTime/n, n
+
+
+def transient_errors(us, times, M, z_of_t, exactL2Squared_of_t):
+    """(final L2 error, L2(0,T;L2) error, L2(0,T;L2) norm) as discretizedProblems.py:276-333 computes them"""
+    nt = len(times)-1
+
+    def fac(k):
+        if k == 0:
+            return times[1]-times[0]
+        if k == nt:
+            return times[k]-times[k-1]
+        return times[k+1]-times[k-1]
+
+    def err2(k):
+        return abs(exactL2Squared_of_t(times[k])-2*(z_of_t(times[k])@us[k])+us[k]@(M@us[k]))
+    return (np.sqrt(err2(nt)), np.sqrt(sum(fac(k)*err2(k) for k in range(nt+1))),
+            np.sqrt(sum(fac(k)*abs(us[k]@(M@us[k])) for k in range(nt+1))))

@@ -29,7 +29,8 @@ EXPORTS = ['pnl_create', 'pnl_destroy', 'pnl_error_string', 'pnl_version', 'pnl_
            'pnl_upload_singular_rule', 'pnl_upload_boundary', 'pnl_assemble_dense', 'pnl_dense_overwrites', 'pnl_block_row_costs', 'pnl_tile_cells',
            'pnl_assemble_dense_tiles', 'pnl_get_counters', 'pnl_get_phase_ms', 'pnl_get_kernel_ms', 'pnl_tree_build', 'pnl_tree_build_blocks', 'pnl_tree_destroy', 'pnl_tree_sizes', 'pnl_tree_get', 'pnl_tree_node_cells', 'pnl_h2_transfer_matrices', 'pnl_nfplan_build', 'pnl_nfplan_destroy', 'pnl_nfplan_sizes', 'pnl_nfplan_get', 'pnl_horizon_pattern', 'pnl_near_pattern', 'pnl_pattern_nnz', 'pnl_pattern_get', 'pnl_pattern_destroy', 'pnl_set_row_slab', 'pnl_diag_blocks_size', 'pnl_get_diag_blocks', 'pnl_slab_matvec', 'pnl_slab_diagonal', 'pnl_gemv', 'pnl_cg_jacobi',
            'pnl_inv_diagonal', 'pnl_set_classes', 'pnl_select_class', 'pnl_upload_sparsity', 'pnl_upload_sparsity_device', 'pnl_assemble_pairs_masked', 'pnl_assemble_boundary_masked', 'pnl_assemble_clusters_tiled', 'pnl_h2_setup', 'pnl_h2_matvec', 'pnl_h2_upward', 'pnl_h2_interact', 'pnl_h2_downward', 'pnl_h2_sizes', 'pnl_spmv',
-           'pnl_assemble_pairs_in_horizon', 'pnl_set_nonsymmetric', 'pnl_set_order_function', 'pnl_upload_pointwise_rules', 'pnl_assemble_dense_pointwise']
+           'pnl_assemble_pairs_in_horizon', 'pnl_set_nonsymmetric', 'pnl_set_order_function', 'pnl_upload_pointwise_rules', 'pnl_assemble_dense_pointwise',
+           'pnl_gemv_axpby', 'pnl_csr_matvec', 'pnl_mg_create', 'pnl_mg_destroy', 'pnl_mg_cycle', 'pnl_mg_solve', 'pnl_mg_cg', 'pnl_theta_step']
 
 
 def source_sha16():
@@ -55,6 +56,12 @@ class pnl_kernel(C.Structure):
 class pnl_order_formula(C.Structure):
     _fields_ = [('c0', C.c_double), ('a', C.c_double), ('b', C.c_double), ('e', C.c_double), ('den0', C.c_double),
                 ('clip_num', C.c_int32), ('pad', C.c_int32)]
+
+
+class pnl_mg_level_desc(C.Structure):
+    _fields_ = [('n', C.c_int32), ('pad', C.c_int32), ('A_dev', C.c_void_p), ('ldA', C.c_int64), ('diag_dev', C.c_void_p),
+                ('R_indptr_dev', C.c_void_p), ('R_indices_dev', C.c_void_p), ('R_data_dev', C.c_void_p),
+                ('P_indptr_dev', C.c_void_p), ('P_indices_dev', C.c_void_p), ('P_data_dev', C.c_void_p)]
 
 
 class pnl_order_function(C.Structure):
@@ -147,6 +154,14 @@ def load():
     L.pnl_gemv.argtypes = [vp, vp, i64, i32, vp, vp, i32]
     L.pnl_cg_jacobi.argtypes = [vp, vp, i64, i32, vp, vp, dbl, i32, C.POINTER(C.c_int), C.POINTER(C.c_double)]
     L.pnl_inv_diagonal.argtypes = [vp, vp, i64, i32, vp]
+    L.pnl_gemv_axpby.argtypes = [vp, vp, i64, i32, i32, vp, dbl, dbl, vp, vp]
+    L.pnl_csr_matvec.argtypes = [vp, i32, vp, vp, vp, vp, dbl, dbl, vp]
+    L.pnl_mg_create.argtypes = [vp, i32, C.POINTER(pnl_mg_level_desc), vp, dbl, i32, i32, C.POINTER(C.c_void_p)]
+    L.pnl_mg_destroy.argtypes = [vp]
+    L.pnl_mg_cycle.argtypes = [vp, vp, vp, i32]
+    L.pnl_mg_solve.argtypes = [vp, vp, vp, dbl, i32, i32, C.POINTER(C.c_int), C.POINTER(C.c_double), i32]
+    L.pnl_mg_cg.argtypes = [vp, vp, i64, vp, vp, dbl, i32, i32, C.POINTER(C.c_int), C.POINTER(C.c_double), i32]
+    L.pnl_theta_step.argtypes = [vp, vp, i64, vp, vp, vp, dbl, dbl, vp, vp, dbl, i32, C.POINTER(C.c_int), C.POINTER(C.c_double)]
     L.pnl_upload_sparsity.argtypes = [vp, i32, vp, vp]
     L.pnl_upload_sparsity_device.argtypes = [vp, i32, vp, vp]
     L.pnl_set_classes.argtypes = [vp, i32, i32, vp, vp, vp]
@@ -459,6 +474,52 @@ class Context:
         it, res = C.c_int(0), C.c_double(0.)
         self.check(self.L.pnl_cg_jacobi(self.h, C.c_void_p(A_ptr), int(ldA), int(n), C.c_void_p(b_ptr), C.c_void_p(x_ptr),
                                         float(tol), int(maxiter), C.byref(it), C.byref(res)))
+        return it.value, res.value
+
+    # -- solver side (multigrid, theta stepping) --------------------------------------------------
+    def gemv_axpby(self, A_ptr, ldA, nrows, ncols, x_ptr, alpha, beta, b_ptr, y_ptr):
+        self.check(self.L.pnl_gemv_axpby(self.h, C.c_void_p(A_ptr), int(ldA), int(nrows), int(ncols), C.c_void_p(x_ptr), float(alpha),
+                                         float(beta), C.c_void_p(b_ptr) if b_ptr else None, C.c_void_p(y_ptr)))
+
+    def csr_matvec(self, nrows, indptr_ptr, indices_ptr, data_ptr, x_ptr, alpha, beta, y_ptr):
+        self.check(self.L.pnl_csr_matvec(self.h, int(nrows), C.c_void_p(indptr_ptr), C.c_void_p(indices_ptr), C.c_void_p(data_ptr),
+                                         C.c_void_p(x_ptr), float(alpha), float(beta), C.c_void_p(y_ptr)))
+
+    def mg_create(self, descs, coarse_inverse_ptr, omega, presmooth, postsmooth):
+        arr = (pnl_mg_level_desc*len(descs))(*descs)
+        out = C.c_void_p()
+        self.check(self.L.pnl_mg_create(self.h, len(descs), arr, C.c_void_p(coarse_inverse_ptr), float(omega), int(presmooth), int(postsmooth),
+                                        C.byref(out)))
+        return out
+
+    def mg_destroy(self, mg):
+        self.L.pnl_mg_destroy(mg)
+
+    def mg_cycle(self, mg, b_ptr, x_ptr, x_is_zero):
+        self.check(self.L.pnl_mg_cycle(mg, C.c_void_p(b_ptr), C.c_void_p(x_ptr), int(bool(x_is_zero))))
+
+    def mg_solve(self, mg, b_ptr, x_ptr, tol, maxiter, x_is_zero):
+        it = C.c_int(0)
+        res = (C.c_double*(maxiter+2))()
+        self.check(self.L.pnl_mg_solve(mg, C.c_void_p(b_ptr), C.c_void_p(x_ptr), float(tol), int(maxiter), int(bool(x_is_zero)), C.byref(it),
+                                       res, maxiter+2))
+        return it.value, list(res[:it.value+1])
+
+    def mg_cg(self, mg, A_ptr, ldA, b_ptr, x_ptr, tol, maxiter, x_is_zero):
+        it = C.c_int(0)
+        res = (C.c_double*(maxiter+2))()
+        self.check(self.L.pnl_mg_cg(mg, C.c_void_p(A_ptr) if A_ptr else None, int(ldA), C.c_void_p(b_ptr), C.c_void_p(x_ptr), float(tol),
+                                    int(maxiter), int(bool(x_is_zero)), C.byref(it), res, maxiter+2))
+        out = list(res)                       # initial value + one entry per iteration performed, the rest still zero
+        while len(out) > 1 and out[-1] == 0.:
+            out.pop()
+        return it.value, out
+
+    def theta_step(self, mg, S_ptr, ldS, M_indptr_ptr, M_indices_ptr, M_data_ptr, dt, theta, forcing_ptr, u_ptr, tol, maxiter):
+        it, res = C.c_int(0), C.c_double(0.)
+        self.check(self.L.pnl_theta_step(mg, C.c_void_p(S_ptr), int(ldS), C.c_void_p(M_indptr_ptr), C.c_void_p(M_indices_ptr),
+                                         C.c_void_p(M_data_ptr), float(dt), float(theta), C.c_void_p(forcing_ptr) if forcing_ptr else None,
+                                         C.c_void_p(u_ptr), float(tol), int(maxiter), C.byref(it), C.byref(res)))
         return it.value, res.value
 
     def inv_diagonal(self, A_ptr, ldA, n, out_ptr):

@@ -744,7 +744,11 @@ int launch_tiles_single(pnl_context *ctx, double *A, int64_t ldA, int cell_begin
                              ctx->wl_cap_each, SO))) return rc;
     HIPCHK(ctx, hipEventRecord(ctx->ev[6], ctx->stream));
     // block-slot storage: A = A' + A'^T is formed now (it overwrites A); the work-list kernels then write both images
-    if (ctx->slot_used && (rc = pnl2_fold_mirror(ctx, SO, A, ldA))) return rc;
+    if (ctx->slot_used) {
+        if ((rc = pnl2_fold_mirror(ctx, SO, A, ldA))) return rc;
+        HIPCHK(ctx, hipEventRecord(ctx->ev_fold, ctx->stream));
+        ctx->fold_event_set = true;
+    }
     const bool sym = ctx->symflush || ctx->slot_used;
     {
         ClassFork fork(ctx, ncls);

@@ -1,0 +1,364 @@
+"""Solver side of the nonlocal operators on the GPU: geometric multigrid on a hierarchy of assembled
+nonlocal operators, multigrid-preconditioned CG, the theta time stepper of the fractional heat equation.
+
+Host-side mirror of
+  * ``fractionalLevel`` / ``paramsForFractionalHierarchy`` (nl/PyNucleus_nl/helpers.py:312-411): one uniformly refined mesh
+    per level, the operator assembled on every level (here: ``nonlocalBuilder.getDense`` on the device),
+  * ``buildRestriction_{1,2}D_P1`` (multilevelSolver/PyNucleus_multilevelSolver/restriction_*_P1.pxi): R = P^T with the
+    weights 1 (coincident vertex) and 1/2 (edge midpoint),
+  * ``multigrid`` (multigrid_{SCALAR}.pxi:86-390): V cycle, Jacobi smoother (omega = 2/3, one pre- and one post-sweep),
+    direct coarse solve; ``asPreconditioner`` (:293-295),
+  * ``CrankNicolson`` / ``ImplicitEuler`` (base/PyNucleus_base/timestepping.py:64-160) driving
+    ``discretizedTransientProblem`` (nl/PyNucleus_nl/discretizedProblems.py:722-905).
+
+The cycle, the CG loop and the time step run inside libpnl_hip.so (csrc/pnl_solver.hip: pnl_mg_cycle, pnl_mg_solve,
+pnl_mg_cg, pnl_theta_step); this module builds the hierarchy, keeps the level data alive in HBM and hands pointers over.
+No CPU fallback: without the HIP library / a GPU the constructors raise.
+"""
+import numpy as np
+from . import _lib
+
+
+# ---- transfer operators --------------------------------------------------------------------------------------------
+def _vertex_dofs(dm):
+    """DoF of every mesh vertex (-1: boundary) for a P1 map"""
+    v2d = np.full(dm.mesh.num_vertices, -1, dtype=np.int64)
+    v2d[dm.mesh.cells.ravel()] = dm.dofs.ravel()
+    return v2d
+
+
+def buildProlongation(dm_coarse, dm_fine):
+    """P (n_fine x n_coarse, scipy CSR) between the P1 spaces of a mesh and its uniform refinement: a fine vertex is a
+    coarse vertex (weight 1) or the midpoint of a coarse edge (1/2, 1/2) -- the transpose of buildRestriction_*_P1."""
+    import scipy.sparse as sp
+    if dm_coarse.polynomialOrder != 1 or dm_fine.polynomialOrder != 1:
+        raise NotImplementedError('prolongation is built for P1 elements only')
+    mc, mf = dm_coarse.mesh, dm_fine.mesh
+    nvc = mc.num_vertices
+    dim = mc.manifold_dim
+    if dim == 1:
+        assert mf.num_cells == 2*mc.num_cells
+        mids = mf.cells[0::2, 1][:, None]                    # children (c0, m), (m, c1)
+        ends = mc.cells[:, [0, 1]][:, None, :]
+    elif dim == 2:
+        assert mf.num_cells == 4*mc.num_cells
+        # children (c0, m01, m02), (c1, m12, m01), (c2, m02, m12), (m01, m12, m02)
+        mids = np.stack([mf.cells[0::4, 1], mf.cells[0::4, 2], mf.cells[1::4, 1]], axis=1)
+        c = mc.cells
+        ends = np.stack([c[:, [0, 1]], c[:, [0, 2]], c[:, [1, 2]]], axis=1)
+    else:
+        raise NotImplementedError(dim)
+    assert (mf.cells[0::(2 if dim == 1 else 4), 0] == mc.cells[:, 0]).all() and mids.min() >= nvc, \
+        'the fine mesh is not the uniform refinement of the coarse one'
+    vc, vf = _vertex_dofs(dm_coarse), _vertex_dofs(dm_fine)
+    # vertex-level prolongation: identity on the old vertices, 1/2 from both ends of the edge on the new ones
+    m = mids.ravel()
+    e = ends.reshape(-1, 2)
+    m, first = np.unique(m, return_index=True)
+    e = e[first]
+    rows = np.concatenate([np.arange(nvc), m, m])
+    cols = np.concatenate([np.arange(nvc), e[:, 0], e[:, 1]])
+    vals = np.concatenate([np.ones(nvc), np.full(2*m.shape[0], 0.5)])
+    keep = (vf[rows] >= 0) & (vc[cols] >= 0)
+    P = sp.csr_matrix((vals[keep], (vf[rows[keep]], vc[cols[keep]])), shape=(dm_fine.num_dofs, dm_coarse.num_dofs))
+    P.sum_duplicates()
+    P.sort_indices()
+    return P
+
+
+def buildRestriction(dm_coarse, dm_fine):
+    R = buildProlongation(dm_coarse, dm_fine).T.tocsr()
+    R.sort_indices()
+    return R
+
+
+class _DevCSR:
+    """CSR matrix in HBM (int32 indices, fp64 values) for pnl_csr_matvec"""
+
+    def __init__(self, M, device):
+        import torch
+        M = M.tocsr()
+        M.sort_indices()
+        self.shape = M.shape
+        self.indptr = torch.from_numpy(M.indptr.astype(np.int32)).to(device)
+        self.indices = torch.from_numpy(M.indices.astype(np.int32)).to(device)
+        self.data = torch.from_numpy(M.data.astype(np.float64)).to(device)
+        self.host = M
+
+    def matvec(self, ctx, x, alpha=1., beta=0., y=None):
+        import torch
+        if y is None:
+            y = torch.zeros(self.shape[0], dtype=torch.float64, device=x.device)
+        ctx.csr_matvec(self.shape[0], self.indptr.data_ptr(), self.indices.data_ptr(), self.data.data_ptr(), x.data_ptr(), alpha, beta,
+                       y.data_ptr())
+        return y
+
+    def todense_dev(self):
+        import torch
+        return torch.from_numpy(self.host.toarray()).to(self.data.device)
+
+
+# ---- hierarchy ------------------------------------------------------------------------------------------------------
+def _seed_mesh(domain):
+    from .mesh import simpleInterval, uniform_disc
+    if domain == 'interval':
+        mesh = simpleInterval(-1., 1.)
+    elif domain == 'disc':
+        mesh = uniform_disc(1.)
+    else:
+        raise NotImplementedError(domain)
+    # the factory mesh is refined until a P1 space has a DoF (nonlocalProblems.py:209-212)
+    while mesh.num_vertices-mesh.boundaryVertices.shape[0] == 0:
+        mesh = mesh.refine()
+    return mesh
+
+
+class fractionalHierarchy:
+    """Levels 0 .. noRef of uniformly refined meshes with the nonlocal operator assembled on every one of them
+    (helpers.py:312-380 with 'assemble': 'ALL').  levels[l] = {'mesh', 'DoFMap', 'A' (Dense_LinearOperator in HBM),
+    'M' (scipy CSR, buildMass), 'P', 'R' (scipy CSR; l > 0)}."""
+
+    def __init__(self, domain, noRef, kernel, params=None, element='P1', buildMass=False, tag=None, device=None, mesh=None):
+        from .dofmap import dofmapFactory
+        from .mesh import PHYSICAL
+        from .builder import nonlocalBuilder
+        if element != 'P1':
+            raise NotImplementedError('hierarchies are built for P1 elements (restriction_*_P1.pxi); got {}'.format(element))
+        self.kernel, self.params = kernel, dict(params or {})
+        mesh = mesh if mesh is not None else _seed_mesh(domain)
+        self.levels = []
+        self._builders = []
+        for lvl in range(noRef+1):
+            if lvl > 0:
+                mesh = mesh.refine()
+            dm = dofmapFactory(element, mesh, PHYSICAL if tag is None else tag)
+            b = nonlocalBuilder(dm, kernel, dict(self.params), device=device)
+            A = b.getDense()
+            b.context().synchronize()
+            L = {'mesh': mesh, 'DoFMap': dm, 'A': A}
+            if buildMass:
+                L['M'] = dm.assembleMass()
+            if lvl > 0:
+                L['P'] = buildProlongation(self.levels[-1]['DoFMap'], dm)
+                L['R'] = L['P'].T.tocsr()
+            self.levels.append(L)
+            self._builders.append(b)
+
+    @property
+    def finest(self):
+        return self.levels[-1]
+
+    def context(self):
+        return self._builders[-1].context()
+
+    def getLevelList(self):
+        return self.levels
+
+
+def buildTransientHierarchy(levels, alpha, beta):
+    """levels with A <- alpha M + beta A (discretizedProblems.py:740-749), formed in HBM"""
+    import torch
+    from .linear_operators import Dense_LinearOperator
+    out = []
+    for L in levels:
+        A = L['A']
+        Md = torch.from_numpy(L['M'].toarray()).to(A.A.device)
+        A.ctx.synchronize()
+        T = (Md*alpha).add_(A.A, alpha=beta)
+        N = {k: v for k, v in L.items() if k in ('P', 'R', 'mesh', 'DoFMap', 'M')}
+        N['A'] = Dense_LinearOperator(T, A.ctx)
+        out.append(N)
+    return out
+
+
+# ---- multigrid --------------------------------------------------------------------------------------------------------
+class multigrid:
+    """multigrid(hierarchy, smoother=('jacobi', {'omega': 2/3})) like the reference's solver class; ``hierarchy`` is a
+    fractionalHierarchy or a list of level dicts with 'A' (Dense_LinearOperator), 'R', 'P'."""
+
+    def __init__(self, hierarchy, smoother=('jacobi', {'omega': 2.0/3.0}), ctx=None):
+        import torch
+        levels = hierarchy.getLevelList() if hasattr(hierarchy, 'getLevelList') else list(hierarchy)
+        if len(levels) < 1:
+            raise AssertionError('empty hierarchy')
+        name, sp = smoother if isinstance(smoother, tuple) else (smoother, {})
+        if name != 'jacobi':
+            raise NotImplementedError('smoother {}: the device cycle has the Jacobi smoother only'.format(name))
+        self.omega = float(sp.get('omega', 2.0/3.0))
+        self.presmoothingSteps = int(sp.get('presmoothingSteps', 1))
+        self.postsmoothingSteps = int(sp.get('postsmoothingSteps', 1))
+        self.levels = levels
+        self.A = levels[-1]['A']
+        self.ctx = ctx or self.A.ctx
+        self.device = self.A.A.device
+        self.maxIter = 50
+        self.tolerance = 1e-8
+        self.num_rows = self.A.num_rows
+        # level data in HBM (kept alive by this object: the library only stores the pointers)
+        self._keep = []
+        descs = []
+        for l, L in enumerate(levels):
+            A = L['A']
+            A.ctx.synchronize()
+            d = _lib.pnl_mg_level_desc()
+            d.n = A.num_rows
+            d.A_dev = A.A.data_ptr()
+            d.ldA = A.A.stride(0)
+            diag = torch.diagonal(A.A).contiguous().clone()
+            self._keep.append(diag)
+            d.diag_dev = diag.data_ptr()
+            if l > 0:
+                R, P = _DevCSR(L['R'], self.device), _DevCSR(L['P'], self.device)
+                assert R.shape == (levels[l-1]['A'].num_rows, A.num_rows) and P.shape == (A.num_rows, levels[l-1]['A'].num_rows)
+                self._keep += [R, P]
+                d.R_indptr_dev, d.R_indices_dev, d.R_data_dev = R.indptr.data_ptr(), R.indices.data_ptr(), R.data.data_ptr()
+                d.P_indptr_dev, d.P_indices_dev, d.P_data_dev = P.indptr.data_ptr(), P.indices.data_ptr(), P.data.data_ptr()
+            descs.append(d)
+        A0 = levels[0]['A']
+        # coarse solver: the inverse of the coarsest operator (a handful of DoFs), applied with the GEMV
+        A0.ctx.synchronize()
+        self._coarse_inv = torch.from_numpy(np.linalg.inv(A0.A.cpu().numpy())).to(self.device).contiguous()
+        torch.cuda.current_stream(self.device).synchronize()
+        self._set_stream()
+        self._mg = self.ctx.mg_create(descs, self._coarse_inv.data_ptr(), self.omega, self.presmoothingSteps, self.postsmoothingSteps)
+
+    def _set_stream(self):
+        import torch
+        self.ctx.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def __del__(self):
+        try:
+            if getattr(self, '_mg', None):
+                self.ctx.mg_destroy(self._mg)
+                self._mg = None
+        except Exception:
+            pass
+
+    def _vec(self, v):
+        import torch
+        if isinstance(v, torch.Tensor):
+            return v.to(device=self.device, dtype=torch.float64).contiguous()
+        return torch.from_numpy(np.ascontiguousarray(np.asarray(v, dtype=np.float64))).to(self.device)
+
+    def _ret(self, like, xd):
+        import torch
+        return xd if isinstance(like, torch.Tensor) else xd.cpu().numpy()
+
+    def cycle(self, b, x=None):
+        """one V cycle (solveOnLevel on the finest level); returns the new iterate"""
+        import torch
+        bd = self._vec(b)
+        zero = x is None
+        xd = torch.zeros_like(bd) if zero else self._vec(x).clone()
+        self._set_stream()
+        self.ctx.mg_cycle(self._mg, bd.data_ptr(), xd.data_ptr(), zero)
+        self.ctx.synchronize()
+        return self._ret(b, xd)
+
+    def solve(self, b, x=None, tol=None, maxiter=None):
+        """multigrid.solve: returns (x, iterations, residual norms)"""
+        import torch
+        bd = self._vec(b)
+        zero = x is None
+        xd = torch.zeros_like(bd) if zero else self._vec(x).clone()
+        self._set_stream()
+        its, res = self.ctx.mg_solve(self._mg, bd.data_ptr(), xd.data_ptr(), self.tolerance if tol is None else tol,
+                                     self.maxIter if maxiter is None else maxiter, zero)
+        return self._ret(b, xd), its, res
+
+    def cg(self, b, x=None, tol=1e-8, maxiter=100, A=None):
+        """CG on A (default: the finest operator) preconditioned by one V cycle: (x, iterations, sqrt(r.Br) history)"""
+        import torch
+        bd = self._vec(b)
+        zero = x is None
+        xd = torch.zeros_like(bd) if zero else self._vec(x).clone()
+        self._set_stream()
+        Aptr, ld = (A.A.data_ptr(), A.A.stride(0)) if A is not None else (None, 0)
+        its, res = self.ctx.mg_cg(self._mg, Aptr, ld, bd.data_ptr(), xd.data_ptr(), tol, maxiter, zero)
+        return self._ret(b, xd), its, res
+
+    def asPreconditioner(self, maxIter=1):
+        """callable r -> B r: maxIter V cycles from a zero guess (multigridPreconditioner)"""
+        def B(r):
+            z = self.cycle(r)
+            for _ in range(maxIter-1):
+                z = self.cycle(r, z)
+            return z
+        return B
+
+    def __str__(self):
+        return 'V-cycle multigrid, {} levels, Jacobi ({}/{} sweeps, {:.3} damping), DoFs {}'.format(
+            len(self.levels), self.presmoothingSteps, self.postsmoothingSteps, self.omega, [L['A'].num_rows for L in self.levels])
+
+
+# ---- time stepping --------------------------------------------------------------------------------------------------------
+class CrankNicolson:
+    """Theta method for M u_t + S u = g(t) on the finest level of a hierarchy with mass matrices (timestepping.py:64-112):
+    (M/dt + theta S) u_{k+1} = (M/dt) u_k - (1 - theta) S u_k + (1 - theta) g(t_k) + theta g(t_{k+1}).
+    The system is solved by multigrid-preconditioned CG on the transient hierarchy alpha M + beta A
+    (buildTransientSolver, discretizedProblems.py:751-768) inside pnl_theta_step."""
+
+    def __init__(self, hierarchy, dt, theta=0.5, tol=1e-8, maxiter=100, smoother=('jacobi', {'omega': 2.0/3.0})):
+        assert 0. <= theta <= 1. and dt > 0.
+        levels = hierarchy.getLevelList() if hasattr(hierarchy, 'getLevelList') else list(hierarchy)
+        self.dt, self.theta, self.tol, self.maxiter = float(dt), float(theta), tol, maxiter
+        self.S = levels[-1]['A']
+        self.device = self.S.A.device
+        self.M = _DevCSR(levels[-1]['M'], self.device)
+        self.transient = buildTransientHierarchy(levels, 1./self.dt, self.theta)
+        self.solver = multigrid(self.transient, smoother=smoother)
+        self.iterations = []
+
+    def setRHS(self, g_t, g_tdt):
+        """forcing of one step from the load vectors at t and t + dt (setRHS, timestepping.py:76-91)"""
+        return (1.-self.theta)*np.asarray(g_t)+self.theta*np.asarray(g_tdt)
+
+    def step(self, t, u, forcing):
+        """advance u (a device vector, overwritten) from t to t + dt; returns t + dt"""
+        import torch
+        mg = self.solver
+        f = mg._vec(forcing)
+        assert isinstance(u, torch.Tensor) and u.device == self.device and u.dtype == torch.float64 and u.is_contiguous()
+        mg._set_stream()
+        its, res = mg.ctx.theta_step(mg._mg, self.S.A.data_ptr(), self.S.A.stride(0), self.M.indptr.data_ptr(), self.M.indices.data_ptr(),
+                                     self.M.data.data_ptr(), self.dt, self.theta, f.data_ptr(), u.data_ptr(), self.tol, self.maxiter)
+        self.iterations.append(its)
+        return t+self.dt
+
+
+class ImplicitEuler(CrankNicolson):
+    def __init__(self, hierarchy, dt, **kwargs):
+        super().__init__(hierarchy, dt, theta=1., **kwargs)
+
+
+def determineTimeSteps(h, finalTime, timeStepperType='Crank-Nicolson'):
+    """discretizedProblems.py:774-783: dt = sqrt(h) (Crank-Nicolson) or h (implicit Euler), rounded to divide finalTime"""
+    dt = np.sqrt(h) if timeStepperType == 'Crank-Nicolson' else h
+    n = int(np.around(finalTime/dt))
+    return finalTime/n, n
+
+
+def solveFractionalHeat(hierarchy, initial, load, finalTime=1.0, timeStepperType='Crank-Nicolson', theta=0.5, tol=1e-8, maxiter=100):
+    """discretizedTransientProblem.solve (discretizedProblems.py:889-905): u_t + (-Laplace)^s u = f on the finest level,
+    u(0) = interpolant of ``initial``; ``load(t)`` returns the load vector int f(t) phi_i.  Returns (times, [u_k] on the host,
+    stepper)."""
+    import torch
+    L = hierarchy.finest if hasattr(hierarchy, 'finest') else hierarchy[-1]
+    dm = L['DoFMap']
+    dt, nt = determineTimeSteps(dm.mesh.h, finalTime, timeStepperType)
+    stepper = (CrankNicolson(hierarchy, dt, theta=theta, tol=tol, maxiter=maxiter) if timeStepperType == 'Crank-Nicolson'
+               else ImplicitEuler(hierarchy, dt, tol=tol, maxiter=maxiter))
+    times = np.linspace(0., finalTime, nt+1)
+    u0 = np.asarray(dm.interpolate(initial), dtype=np.float64)
+    u = torch.from_numpy(u0.copy()).to(stepper.device)
+    us = [u0]
+    g_prev = np.asarray(load(times[0]))
+    t = 0.
+    for k in range(nt):
+        g_next = np.asarray(load(times[k+1]))
+        t = stepper.step(t, u, stepper.setRHS(g_prev, g_next))
+        g_prev = g_next
+        stepper.solver.ctx.synchronize()
+        us.append(u.cpu().numpy().copy())
+    assert abs(t-finalTime) < 1e-10
+    return times, us, stepper

@@ -1,0 +1,297 @@
+"""SURVEY 8(f) row 4, the solver side: geometric multigrid on hierarchies of assembled nonlocal operators, multigrid-
+preconditioned CG and the theta time stepper of the fractional heat equation.
+
+CPU part: the numpy restatement (oracle/solver_oracle.py) against the reference's own stored numbers
+(tests/cache_runFractionalHeat.py--..., tests/cache_runFractional.py--...--solvercg-mg--..., compared there at
+rTol 1e-2 ... 3e-2) and the host-side transfer operators of the product against the oracle's cell walk.
+GPU part: the device cycle / CG / time step (libpnl_hip.so through the C ABI) against the oracle on the same hierarchy.
+"""
+import numpy as np
+import pytest
+from math import gamma
+from scipy.special import hyp2f1
+from pynucleus_amd import P1_DoFMap, PHYSICAL, getFractionalKernel, nonlocalTables
+from pynucleus_amd.multigrid import buildProlongation, buildRestriction, _seed_mesh, determineTimeSteps
+from pynucleus_amd.quadrature import simplexXiaoGimbutas
+from oracle.oracle import OracleProblem
+from oracle import solver_oracle as SO
+
+
+def oracle_hierarchy(domain, noRef, s, params, mass=False):
+    mesh = _seed_mesh(domain)
+    dim = mesh.manifold_dim
+    levels = []
+    for l in range(noRef+1):
+        if l > 0:
+            mesh = mesh.refine()
+        dm = P1_DoFMap(mesh, PHYSICAL)
+        L = {'mesh': mesh, 'DoFMap': dm, 'A': OracleProblem(nonlocalTables(dm, getFractionalKernel(dim, s), dict(params))).get_dense()[0]}
+        if mass:
+            L['M'] = dm.assembleMass().toarray()
+        if l > 0:
+            L['R'] = SO.build_restriction_P1(levels[-1]['DoFMap'], dm)
+            L['P'] = L['R'].T.copy()
+        levels.append(L)
+    return levels
+
+
+def transient_problem(dim, s, problem):
+    """nonlocalProblems.py:651-662 ('constant'), :710-727 ('knownSolution') on the interval, transient version :1641-1672:
+    u(t, x) = cos(t) u_ss(x), f(t) = -sin(t) u_ss + cos(t) f_ss"""
+    assert dim == 1
+    beta = 0.7
+    if problem == 'knownSolution':
+        def uss(x):
+            return max(1.-x[0]**2, 0.)**beta
+
+        def fss(x):
+            return 2**(2*s)*gamma(s+0.5)*gamma(beta+1.)/np.sqrt(np.pi)/gamma(beta+1.-s)*hyp2f1(s+0.5, -beta+s, 0.5, x[0]**2)
+        L2ex2 = np.sqrt(np.pi)*gamma(1+2*beta)/gamma(1.5+2*beta)
+    else:
+        C = 2.**(-2.*s)*gamma(0.5)/gamma((1+2.*s)/2.)/gamma(1.+s)
+
+        def uss(x):
+            return C*max(1.-x[0]**2, 0.)**s
+
+        def fss(x):
+            return 1.
+        L2ex2 = C**2*np.sqrt(np.pi)*gamma(1+2*s)/gamma(1.5+2*s)
+    return uss, fss, L2ex2
+
+
+# the reference's stored numbers: (final L2 error, L2(0,T;L2) error, L2(0,T;L2) norm)
+HEAT_FIXTURES = {
+    # cache_runFractionalHeat.py--domaininterval--sconst(0.25)--problemconstant--elementP1--solvercg-mg--matrixFormatdense
+    (0.25, 'constant'): (0.01455872345929613, 0.03218338586612875, 1.7018299503210628, 2e-6),
+    # ...--sconst(0.25)--problemknownSolution--elementP1--solvercg-jacobi--matrixFormatH2
+    (0.25, 'knownSolution'): (0.0008912208343986159, 0.0018388585398440504, 1.3228634831094461, 2e-5),
+    # ...--sconst(0.75)--problemknownSolution--elementP1--solvercg-mg--matrixFormatH2 (H2 approximation in the stored run)
+    (0.75, 'knownSolution'): (0.001419170068070812, 0.002695812286552434, 1.3216806035576412, 5e-4),
+}
+
+
+def heat_setup(levels, s, problem):
+    dm = levels[-1]['DoFMap']
+    uss, fss, L2ex2 = transient_problem(1, s, problem)
+    qr = simplexXiaoGimbutas(3, 1, 1)                        # buildQuadratureRule, discretizedProblems.py:771-772
+    z_ss, f_ss = np.asarray(dm.assembleRHS(uss, qr)), np.asarray(dm.assembleRHS(fss, qr))
+
+    def load(t):
+        return -np.sin(t)*z_ss+np.cos(t)*f_ss
+    return uss, load, z_ss, L2ex2
+
+
+@pytest.mark.parametrize('s,problem', sorted(HEAT_FIXTURES))
+def test_oracle_heat_reproduces_the_stored_errors(s, problem):
+    """runFractionalHeat --domain interval --element P1 (noRef 6, Crank-Nicolson, dt = sqrt(h) = 1/8, finalTime 1)"""
+    levels = oracle_hierarchy('interval', 6, s, {'target_order': 2.-s}, mass=True)
+    L = levels[-1]
+    uss, load, z_ss, L2ex2 = heat_setup(levels, s, problem)
+    dt, nt = SO.heat_time_steps(L['mesh'].h)
+    assert (dt, nt) == (0.125, 8)
+    theta = 0.5
+    trans = [dict(K, A=K['M']/dt+theta*K['A']) for K in levels]
+    mg = SO.Multigrid(trans)
+    times = np.linspace(0., 1., nt+1)
+    u = np.asarray(L['DoFMap'].interpolate(uss), dtype=float)
+    us, its = [u.copy()], []
+
+    def solve(rhs, x0):
+        x, it, _ = SO.cg(trans[-1]['A'], rhs, x0=x0, tol=1e-10, maxiter=100, B=mg.precondition)
+        its.append(it)
+        return x
+    for k in range(nt):
+        forcing = (1-theta)*load(times[k])+theta*load(times[k+1])
+        u = SO.theta_step(L['A'], L['M'], dt, theta, forcing, u, solve)
+        us.append(u.copy())
+    e_final, e_l2, norm = SO.transient_errors(us, times, L['M'], lambda t: np.cos(t)*z_ss, lambda t: np.cos(t)**2*L2ex2)
+    ref = HEAT_FIXTURES[(s, problem)]
+    rtol = ref[3]
+    assert abs(e_final-ref[0]) <= rtol*ref[0] and abs(e_l2-ref[1]) <= rtol*ref[1], (e_final, e_l2, ref)
+    assert abs(norm-ref[2]) <= 1e-6*ref[2], (norm, ref[2])
+    assert max(its) <= 8                                      # multigrid-preconditioned CG: mesh-independent iteration counts
+
+
+def test_oracle_multigrid_is_a_solver_for_the_stored_steady_run():
+    """runFractional --domain interval --s const(0.25) --solver cg-mg --matrixFormat dense: the multigrid-preconditioned CG
+    reaches the solution whose Hs error the reference stores (0.09611243700804001), in a handful of iterations; the
+    stand-alone V cycle contracts at a mesh-independent rate"""
+    s = 0.25
+    levels = oracle_hierarchy('interval', 6, s, {'target_order': 2.-s})
+    dm = levels[-1]['DoFMap']
+    b = np.asarray(dm.assembleRHS(1.0))
+    mg = SO.Multigrid(levels)
+    x, its, res = SO.cg(levels[-1]['A'], b, tol=1e-10, B=mg.precondition)
+    C = 2.**(-2.*s)*gamma(0.5)/gamma((1+2.*s)/2.)/gamma(1.+s)
+    ex = C*np.sqrt(np.pi)*gamma(s+1)/gamma(s+3/2)
+    hs = np.sqrt(abs(b@x-ex))
+    assert abs(hs-0.09611243700804001) <= 1e-8*0.09611243700804001 and its <= 10
+    x2, it2, r2 = mg.solve(b, tol=1e-9*np.linalg.norm(b), maxiter=50)
+    assert it2 < 50 and np.abs(x2-x).max() <= 1e-7*np.abs(x).max()
+    rates = [r2[k+1]/r2[k] for k in range(2, len(r2)-1)]
+    assert max(rates) < 0.5
+
+
+@pytest.mark.parametrize('domain', ['interval', 'disc'])
+def test_transfer_operators_equal_the_cell_walk(domain):
+    mesh = _seed_mesh(domain)
+    for _ in range(3):
+        fine = mesh.refine()
+        dc, df = P1_DoFMap(mesh, PHYSICAL), P1_DoFMap(fine, PHYSICAL)
+        P, R = buildProlongation(dc, df), buildRestriction(dc, df)
+        Ro = SO.build_restriction_P1(dc, df)
+        assert np.abs(R.toarray()-Ro).max() == 0. and np.abs(P.toarray().T-Ro).max() == 0.
+        # interpolation of a linear function that vanishes on the boundary vertices is exact where no boundary vertex is involved
+        assert P.shape == (df.num_dofs, dc.num_dofs) and P.toarray().max() == 1.
+        mesh = fine
+
+
+def test_time_step_rule():
+    assert determineTimeSteps(2./128, 1.0) == (0.125, 8)
+    dt, n = determineTimeSteps(2./128, 1.0, 'Implicit Euler')
+    assert n == 64 and dt == 1./64
+
+
+# ---- device -----------------------------------------------------------------------------------------------------------------
+def device_hierarchy(domain, noRef, s, params, mass=False):
+    from pynucleus_amd.multigrid import fractionalHierarchy
+    dim = 1 if domain == 'interval' else 2
+    return fractionalHierarchy(domain, noRef, getFractionalKernel(dim, s), params, buildMass=mass)
+
+
+def as_oracle_levels(H):
+    out = []
+    for L in H.getLevelList():
+        K = {'A': L['A'].toarray().copy()}
+        if 'M' in L:
+            K['M'] = L['M'].toarray()
+        if 'R' in L:
+            K['R'], K['P'] = L['R'].toarray(), L['P'].toarray()
+        out.append(K)
+    return out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('domain,noRef,s', [('interval', 6, 0.25), ('disc', 3, 0.75)])
+def test_gpu_cycle_solve_and_cg_against_the_oracle(domain, noRef, s):
+    from pynucleus_amd.multigrid import multigrid
+    params = {'target_order': 2.-s} if domain == 'interval' else {}
+    H = device_hierarchy(domain, noRef, s, params)
+    levels_o = oracle_hierarchy(domain, noRef, s, params)
+    # the device hierarchy is the oracle's: operators at the assembly tolerance, transfer operators exactly
+    for L, K in zip(H.getLevelList(), levels_o):
+        assert np.abs(L['A'].toarray()-K['A']).max() <= 1e-10*np.abs(K['A']).max()
+    # solver parity on identical data: the oracle runs on the matrices the GPU assembled
+    lv = as_oracle_levels(H)
+    mo = SO.Multigrid(lv)
+    mg = multigrid(H)
+    dm = H.finest['DoFMap']
+    b = np.asarray(dm.assembleRHS(1.0))
+    n = b.shape[0]
+    rng = np.random.default_rng(0)
+    x0 = rng.standard_normal(n)
+    # one cycle from zero and from a guess
+    xo = np.zeros(n); mo.solveOnLevel(len(lv)-1, b, xo, True)
+    assert np.abs(mg.cycle(b)-xo).max() <= 1e-12*np.abs(xo).max()
+    xo = x0.copy(); mo.solveOnLevel(len(lv)-1, b, xo, False)
+    assert np.abs(mg.cycle(b, x0)-xo).max() <= 1e-12*np.abs(xo).max()
+    # stationary iteration
+    tol = 1e-9*np.linalg.norm(b)
+    xs, its, res = mg.solve(b, tol=tol, maxiter=60)
+    xso, itso, reso = mo.solve(b, tol=tol, maxiter=60)
+    assert its == itso and its < 60
+    assert np.allclose(res, reso, rtol=1e-6, atol=1e-14*res[0])
+    assert np.abs(xs-xso).max() <= 1e-10*np.abs(xso).max()
+    # multigrid-preconditioned CG
+    xc, itc, resc = mg.cg(b, tol=1e-10)
+    xco, itco, resco = SO.cg(lv[-1]['A'], b, tol=1e-10, B=mo.precondition)
+    assert itc == itco and itc <= 12
+    assert np.allclose(resc, resco, rtol=1e-5, atol=1e-13)
+    assert np.abs(xc-xco).max() <= 1e-9*np.abs(xco).max()
+    assert np.abs(lv[-1]['A']@xc-b).max() <= 1e-8*np.abs(b).max()
+    # the generic Krylov loop of the package with the cycle as a callable preconditioner runs the same iteration
+    B = mg.asPreconditioner()
+    z = B(b)
+    assert np.abs(z-mo.precondition(b)).max() <= 1e-12*np.abs(z).max()
+
+
+@pytest.mark.gpu
+def test_gpu_steady_run_cg_mg_reproduces_the_stored_hs_errors():
+    """the reference's stored Hs errors through multigrid-preconditioned CG on the device:
+    interval s = 0.25 (cache_runFractional.py--domaininterval--sconst(0.25)--problemconstant--elementP1--solvercg-mg--
+    matrixFormatdense: 0.09611243700804001) and disc s = 0.25, noRef 5 (...domaindisc--sconst(0.25)...: 0.1839933908571473)"""
+    from pynucleus_amd.multigrid import multigrid
+    for domain, noRef, s, params, stored, rtol, nd in (('interval', 6, 0.25, {'target_order': 1.75}, 0.09611243700804001, 1e-8, 127),
+                                                       ('disc', 5, 0.25, {'target_order': 0.5}, 0.1839933908571473, 1e-5, 2977)):
+        H = device_hierarchy(domain, noRef, s, params)
+        dm = H.finest['DoFMap']
+        assert dm.num_dofs == nd
+        b = np.asarray(dm.assembleRHS(1.0))
+        x, its, res = multigrid(H).cg(b, tol=1e-10)
+        dim = 1 if domain == 'interval' else 2
+        C = 2.**(-2.*s)*gamma(dim/2.)/gamma((dim+2.*s)/2.)/gamma(1.+s)
+        ex = C*np.sqrt(np.pi)*gamma(s+1)/gamma(s+3/2) if dim == 1 else C*np.pi/(s+1)
+        hs = np.sqrt(abs(b@x-ex))
+        assert abs(hs-stored) <= rtol*stored, (domain, hs)
+        assert its <= 12, its
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('s,problem', sorted(HEAT_FIXTURES))
+def test_gpu_fractional_heat_reproduces_the_stored_errors(s, problem):
+    from pynucleus_amd.multigrid import solveFractionalHeat
+    H = device_hierarchy('interval', 6, s, {'target_order': 2.-s}, mass=True)
+    L = H.finest
+    uss, load, z_ss, L2ex2 = heat_setup(H.getLevelList(), s, problem)
+    times, us, stepper = solveFractionalHeat(H, uss, load, finalTime=1.0, tol=1e-10)
+    M = L['M'].toarray()
+    e_final, e_l2, norm = SO.transient_errors(us, times, M, lambda t: np.cos(t)*z_ss, lambda t: np.cos(t)**2*L2ex2)
+    ref = HEAT_FIXTURES[(s, problem)]
+    assert abs(e_final-ref[0]) <= ref[3]*ref[0] and abs(e_l2-ref[1]) <= ref[3]*ref[1], (e_final, e_l2, ref)
+    assert abs(norm-ref[2]) <= 1e-6*ref[2]
+    assert len(us) == 9 and max(stepper.iterations) <= 8
+    # step-by-step parity with the oracle's time stepper on the same (device-assembled) matrices
+    lv = as_oracle_levels(H)
+    dt, theta = 0.125, 0.5
+    trans = [dict(K, A=K['M']/dt+theta*K['A']) for K in lv]
+    mo = SO.Multigrid(trans)
+    u = us[0].copy()
+    for k in range(8):
+        forcing = (1-theta)*load(times[k])+theta*load(times[k+1])
+        u = SO.theta_step(lv[-1]['A'], lv[-1]['M'], dt, theta, forcing, u,
+                          lambda rhs, x0: SO.cg(trans[-1]['A'], rhs, x0=x0, tol=1e-10, maxiter=100, B=mo.precondition)[0])
+        assert np.abs(u-us[k+1]).max() <= 1e-9*np.abs(u).max(), k
+
+
+@pytest.mark.gpu
+def test_gpu_solver_kernels():
+    """pnl_gemv_axpby / pnl_csr_matvec against numpy (odd sizes, unaligned views, beta paths)"""
+    import torch
+    import scipy.sparse as sp
+    from pynucleus_amd import _lib
+    from pynucleus_amd.multigrid import _DevCSR
+    ctx = _lib.Context(0)
+    ctx.set_stream(torch.cuda.current_stream(0).cuda_stream)
+    rng = np.random.default_rng(1)
+    for (nr, nc, ld) in ((1, 1, 1), (7, 5, 8), (129, 777, 784), (300, 1025, 1025)):
+        A = rng.standard_normal((nr, ld)); x = rng.standard_normal(nc+1); b = rng.standard_normal(nr)
+        Ad, xd, bd = torch.from_numpy(A).cuda(), torch.from_numpy(x).cuda(), torch.from_numpy(b).cuda()
+        for off in (0, 1):
+            xv = xd[off:off+nc]
+            y = torch.empty(nr, dtype=torch.float64, device='cuda')
+            torch.cuda.synchronize()
+            ctx.gemv_axpby(Ad.data_ptr(), ld, nr, nc, xv.data_ptr(), -1., 1., bd.data_ptr(), y.data_ptr())
+            ctx.synchronize()
+            ref = b-A[:, :nc]@x[off:off+nc]
+            assert np.abs(y.cpu().numpy()-ref).max() <= 1e-12*max(1., np.abs(ref).max())
+            ctx.gemv_axpby(Ad.data_ptr(), ld, nr, nc, xv.data_ptr(), 2., 0., 0, y.data_ptr())
+            ctx.synchronize()
+            assert np.abs(y.cpu().numpy()-2*A[:, :nc]@x[off:off+nc]).max() <= 1e-12*max(1., np.abs(ref).max())
+    S = sp.random(211, 97, density=0.05, random_state=3, format='csr')
+    D = _DevCSR(S, torch.device('cuda', 0))
+    x = rng.standard_normal(97); y0 = rng.standard_normal(211)
+    y = torch.from_numpy(y0.copy()).cuda()
+    torch.cuda.synchronize()
+    D.matvec(ctx, torch.from_numpy(x).cuda(), alpha=0.5, beta=-2., y=y)
+    ctx.synchronize()
+    assert np.abs(y.cpu().numpy()-(0.5*S@x-2*y0)).max() <= 1e-13
