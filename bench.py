@@ -221,7 +221,49 @@ def extra_configs(dev):
         orders = np.array([[0.3, 0.4, 0.5], [0.4, 0.5, 0.6], [0.5, 0.6, 0.7]])
         dense_leg('C5_P2_layers_dense_97537dofs', P2_DoFMap(mesh, PHYSICAL),
                   getFractionalKernel(2, layersFractionalOrder(2, np.array([-1., -0.3, 0.3, 1.]), orders)), 6, reps=2)
-    for name, leg in (('P2', p2), ('C5', c5), ('C3', c3), ('C4', c4), ('dense_1e5', big), ('C5_1e5', c5big)):
+    # solver side: hierarchy of the headline operator (levels 0 .. 7, assembled on the device), multigrid-
+    # preconditioned CG for f = 1, and the GEMV it is made of against the HBM roofline (8 N^2 bytes per product)
+    def solver():
+        from pynucleus_amd.multigrid import fractionalHierarchy, multigrid
+        sync(); t0 = time.perf_counter()
+        H = fractionalHierarchy('disc', 7, getFractionalKernel(2, 0.5), {'target_order': 0.5})
+        sync(); t_h = time.perf_counter()-t0
+        dm = H.finest['DoFMap']
+        A = H.finest['A']
+        mg = multigrid(H)
+        b = torch.from_numpy(np.asarray(dm.assembleRHS(1.0))).to(dev)
+        x, its, hist = mg.cg(b, tol=1e-8)
+        sync(); t0 = time.perf_counter()
+        x, its, hist = mg.cg(b, tol=1e-8)
+        sync(); t_cg = time.perf_counter()-t0
+        sync(); t0 = time.perf_counter()
+        for _ in range(5):
+            mg.cycle(b)
+        sync(); t_cyc = (time.perf_counter()-t0)/5
+        xj, itj, resj = A.solve_cg_jacobi(b, tol=1e-8, maxiter=2000)
+        sync(); t0 = time.perf_counter()
+        xj, itj, resj = A.solve_cg_jacobi(b, tol=1e-8, maxiter=2000)
+        sync(); t_j = time.perf_counter()-t0
+        n = dm.num_dofs
+        y = torch.empty_like(b)
+        ctx = A.ctx
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+        for _ in range(3):
+            ctx.gemv_axpby(A.A.data_ptr(), A.A.stride(0), n, n, x.data_ptr(), -1., 1., b.data_ptr(), y.data_ptr())
+        ev0.record()
+        for _ in range(20):
+            ctx.gemv_axpby(A.A.data_ptr(), A.A.stride(0), n, n, x.data_ptr(), -1., 1., b.data_ptr(), y.data_ptr())
+        ev1.record(); sync()
+        gemv_ms = ev0.elapsed_time(ev1)/20
+        gbs = 8.*n*n/(gemv_ms*1e-3)/1e9
+        res['solver_cg_mg_disc_noRef7'] = dict(
+            num_dofs=n, levels=[L['A'].num_rows for L in H.getLevelList()], hierarchy_assembly_s=round(t_h, 3),
+            cg_mg_iterations=its, cg_mg_ms=1e3*t_cg, final_residual=hist[-1], vcycle_ms=1e3*t_cyc,
+            cg_jacobi_iterations=itj, cg_jacobi_ms=1e3*t_j,
+            residual_check=float(torch.linalg.norm(b-A.matvec(x))/torch.linalg.norm(b)),
+            gemv_ms=gemv_ms, gemv_GBs=gbs, gemv_frac_hbm_peak=gbs/HBM_PEAK_GBS)
+    for name, leg in (('P2', p2), ('C5', c5), ('C3', c3), ('C4', c4), ('solver', solver), ('dense_1e5', big), ('C5_1e5', c5big)):
         t0 = time.perf_counter()
         try:
             leg()
