@@ -108,12 +108,39 @@ __device__ __forceinline__ double pnl_exp(double y) {
     return __hiloint2double(__double2hiint(v)+((ni >> 6) << 20), __double2loint(v));
 }
 
+// General power through tables in LDS (the tile kernels of a general exponent): x = 2^k m, m in [1, 2), j = top seven fraction
+// bits of m, u = m T[j] - 1 with T[j] = fl(1 / c_j) (one FMA, |u| <= 2^-8),
+//   scale x^e = (scale c_j^e) 2^(e k) (1 + u)^e = T[128 + j] T[256 + k + 96] (1 + u)^e,
+// the last factor by its binomial series to u^6 (coefficients C(e, i) of the kernel class in DevKernel::pb; the next term is
+// below 1e-16 for |e| <= 2).  18 operations and three LDS gathers against 36 operations and three L1 gathers of
+// exp(e ln x) above; the tables (PNL_POW_TAB_DOUBLES doubles per exponent, built in long double by pow_table in
+// pnl_hip.hip) are copied to LDS by the kernel.  Exponents of x outside 2^-96 ... 2^31 are clamped (|x - y| < 1e-14).
+#define PNL_POW_TAB_DOUBLES 384
+__device__ __forceinline__ void pnl_pow_tab_fill(double *dst, const double *__restrict__ src, int tid, int nthreads) {
+    if (src) for (int t = tid; t < PNL_POW_TAB_DOUBLES; t += nthreads) dst[t] = src[t];
+}
+__device__ __forceinline__ double pnl_pow_tab(double x, const DevKernel &k, const double *__restrict__ T) {
+    const int hi = __double2hiint(x);
+    const int j = (hi >> 13) & 127;
+    const int kx = min(max(((hi >> 20) & 0x7ff)-(1023-96), 0), 127);
+    const double m = __hiloint2double((hi & 0x000fffff) | 0x3ff00000, __double2loint(x));
+    const double u = __builtin_fma(m, T[j], -1.0);
+    double p = k.pb[5];
+    p = __builtin_fma(p, u, k.pb[4]);
+    p = __builtin_fma(p, u, k.pb[3]);
+    p = __builtin_fma(p, u, k.pb[2]);
+    p = __builtin_fma(p, u, k.pb[1]);
+    p = __builtin_fma(p, u, k.pb[0]);
+    p = __builtin_fma(p, u, 1.0);
+    return (T[128+j]*T[256+kx])*p;
+}
+
 // ---- kernel function gamma(|x-y|^2)   (KC:75-294) ----------------------------------------------------------------------
 // KT: 0 general (pow / indicator / peridynamic, horizon test), 1 fractional with exponent -qm/4, qm a run-time (wave-uniform)
 // value, 2 the same with qm == 6 known at compile time (s = 1/2 in 2D): no branch per evaluation, so the compiler
 // interleaves the dependent chains of the independent evaluations of a pair.
 template <int KT>
-__device__ __forceinline__ double kern_eval(const DevKernel &k, double d2) {
+__device__ __forceinline__ double kern_eval(const DevKernel &k, double d2, const double *__restrict__ ltab = nullptr) {
     if (KT == 2) {
         // d2^(-3/2) = r^3 (1 - e)^(-3/2) with r = v_rsq_f64(d2) (~2^-23 relative), e = 1 - d2 r^2 (|e| < 3e-7):
         // r^3 (1 + e (3/2 + 15/8 e)), the next term 35/16 e^3 is below 1e-19; six operations after the rsq, chain depth five
@@ -153,7 +180,7 @@ __device__ __forceinline__ double kern_eval(const DevKernel &k, double d2) {
         if (!(d2 <= k.horizon2)) return 0.;
         // general exponent: exp(e ln d2) instead of pow (half the instructions; |e ln d2| < 60 keeps the relative error of the
         // product below 1e-14, three orders under the parity tolerance)
-        if (k.ktype == 0) return k.scale*pnl_exp(k.exponent*pnl_log(d2));
+        if (k.ktype == 0) return ltab ? pnl_pow_tab(d2, k, ltab) : k.scale*pnl_exp(k.exponent*pnl_log(d2));
         if (k.ktype == 1) return k.scale;
         return k.scale/sqrt(d2);
     }

@@ -121,6 +121,9 @@ struct pnl_context {
     pnl_order_formula tiles_form;
     bool tiles_filter = true;
     bool use_pure = true;             // debug: PNL_PURE=0 sends every tile through the general kernel
+    // tables of the general power (pnl_pow_tab, pnl_common.h), one per (exponent, scale) seen by this context
+    struct PowTab { double exponent, scale; DevBuf buf; };
+    std::vector<PowTab*> powtabs;
     struct BlockAgg { double cx, cy, rad, hmax, hmin, Lmin, Lmax; bool full; };
     std::vector<BlockAgg> blocks;
     hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -191,6 +194,11 @@ inline DevKernel to_dev(const pnl_kernel &k, int dim) {
     (void)dim;
     d.qm = qm;
     d.fast = (k.ktype == PNL_FRACTIONAL && std::isinf(k.horizon2) && qm >= 1 && qm <= 32 && std::fabs(m4-qm) < 1e-13) ? 1 : 0;
+    {
+        long double b = 1.L;
+        for (int i = 0; i < 6; i++) { b *= ((long double)k.exponent-i)/(long double)(i+1); d.pb[i] = (double)b; }
+    }
+    d.ptab = nullptr;
     return d;
 }
 

@@ -13,6 +13,10 @@ struct DevKernel {
     int fast;                   // 1: fractional, exponent == -qm/4 with an integer qm, no horizon (s = 1/4, 1/2, 3/4 in 1D / 2D)
     double exponent, scale, horizon2;
     int interaction, qm;        // finite horizon: 1 ball2_retriangulation, 2 ball2_barycenter; qm: see fast
+    // general exponent (fractional, not fast): binomial coefficients C(exponent, 1..6) and the tables of pnl_pow_tab
+    // (pnl_common.h) in device memory: [128] 1/c_j, [128] scale c_j^exponent, [128] 2^(exponent (i - 96)); nullptr: none
+    double pb[6];
+    const double *ptab;
 };
 
 struct DevFormula {

@@ -369,6 +369,27 @@ int finalize(pnl_context *ctx) {
     return PNL_OK;
 }
 
+// Tables of pnl_pow_tab for x^exponent * scale (long double on the host, rounded once):  x = 2^k m, m in [1, 2), j = top seven
+// fraction bits of m, c_j = 1 / fl(1 / (1 + (j + 1/2) / 128)), u = m fl(1/c_j) - 1 (one FMA, |u| <= 2^-8):
+//   x^e = 2^(e k) c_j^e (1 + u)^e.
+static const double *pow_table(pnl_context *ctx, const DevKernel &k) {
+    if (k.ktype != PNL_FRACTIONAL || k.fast || getenv("PNL_NO_POWTAB")) return nullptr;
+    for (auto *t : ctx->powtabs) if (t->exponent == k.exponent && t->scale == k.scale) return (const double*)t->buf.p;
+    std::vector<double> tab(PNL_POW_TAB_DOUBLES);
+    for (int j = 0; j < 128; j++) {
+        const double invc = (double)(1.L/(1.L+((long double)j+0.5L)/128.L));
+        const long double c = 1.L/(long double)invc;
+        tab[j] = invc;
+        tab[128+j] = (double)((long double)k.scale*powl(c, (long double)k.exponent));
+        tab[256+j] = (double)exp2l((long double)k.exponent*(long double)(j-96));
+    }
+    auto *t = new pnl_context::PowTab;
+    t->exponent = k.exponent; t->scale = k.scale;
+    if (upload(ctx, t->buf, tab.data(), tab.size()) != PNL_OK) { delete t; return nullptr; }
+    ctx->powtabs.push_back(t);
+    return (const double*)t->buf.p;
+}
+
 void refresh_tables(pnl_context *ctx) {
     DevProblem &P = ctx->P;
     P.k = to_dev(ctx->C().kern[0], ctx->dim);
@@ -403,6 +424,7 @@ void refresh_tables(pnl_context *ctx) {
     P.orient = ctx->nonsym ? ctx->orient : 0;
     P.idfac = ctx->nonsym ? 2. : 1.;
     if (ctx->nonsym) P.k.scale *= 0.5;
+    P.k.ptab = pow_table(ctx, P.k);                      // after the last change of the scale: the tables carry it
 }
 
 
@@ -411,7 +433,7 @@ int launch_pure(pnl_context *ctx, double *A, int64_t ldA, const SlotOut &SO) {
     if (ctx->n_pure == 0) return PNL_OK;
     constexpr int NP = DIM == 2 ? 3 : 2, ND = DPE*(DPE+1)/2;
     const int acc_stride = acc_stride_of(ctx->nU);
-    const size_t lds = sizeof(double)*(64*NP*DIM+64+2*64*ND+NP*(4+DPE))+sizeof(int)*(64*DPE+64)
+    const size_t lds = sizeof(double)*(64*NP*DIM+64+2*64*ND+NP*(4+DPE)+PNL_POW_TAB_DOUBLES)+sizeof(int)*(64*DPE+64)
                        +sizeof(double)*(size_t)(ctx->nU+1)*acc_stride;
     auto kfun = k_tile_pure<DIM, DPE, KT>;
     HIPCHK(ctx, hipFuncSetAttribute((const void*)kfun, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -1618,6 +1640,8 @@ void pnl_destroy(pnl_context *ctx) {
     for (auto &st : ctx->aux) if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_fold) (void)hipEventDestroy(ctx->ev_fold);
+    for (auto *t : ctx->powtabs) delete t;
+    ctx->powtabs.clear();
     for (auto &e : ctx->ev_join) if (e) (void)hipEventDestroy(e);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     for (auto *c : ctx->cls) delete c;
@@ -1941,13 +1965,15 @@ static int upload_tiles(pnl_context *ctx, std::vector<int2> &tiles, int cell_beg
             }
         });
         for (auto &th : pool) th.join();
-        // tiles the bounds left open: the exact order range of their cell pairs, on the device (constant order, 2D)
-        if (allow && L == 0 && ctx->dim == 2 && (T == 64 || T == 32) && !getenv("PNL_NO_EXACT_TILES")) {
+        // tiles the bounds left open: the exact order range of their cell pairs, on the device (2D; variable order: tiles whose
+        // two blocks carry one label each -- their pairs all belong to this class and see its order formula)
+        if (allow && ctx->dim == 2 && (T == 64 || T == 32) && !getenv("PNL_NO_EXACT_TILES")) {
             std::vector<int2> cand;
             std::vector<size_t> cand_idx;
             for (size_t i = 0; i < tiles.size(); i++) {
                 const int2 &t = tiles[i];
                 if (qof[i] != 0 || t.x == t.y || !ctx->blocks[t.x].full || !ctx->blocks[t.y].full) continue;
+                if (L > 0 && !(blk_labels[t.x].size() == 1 && blk_labels[t.y].size() == 1)) continue;
                 if (filter && !(t.x*T >= cell_begin && (t.x+1)*T <= cell_end)) continue;
                 cand.push_back(t); cand_idx.push_back(i);
             }

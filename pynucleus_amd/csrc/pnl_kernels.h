@@ -104,7 +104,8 @@ __device__ __forceinline__ void eval_distant_generic(const DevProblem &P, int of
 // with a uniform address are scalar loads wherever they stand -- global loads after the first store of a kernel are not.)
 template <int DIM, int DPE, int KT, int N>
 __device__ __forceinline__ void eval_distant_fixed(const DevProblem &P, const double *__restrict__ tab, const double *gwp_global,
-                                                   const double *av, const double *bv, PairAcc<DIM, DPE> &R) {
+                                                   const double *av, const double *bv, PairAcc<DIM, DPE> &R,
+                                                   const double *__restrict__ lpow = nullptr) {
     constexpr int NV = DIM+1, ST = 4+DPE;
     const pnl_const_f64_ptr gwp = (pnl_const_f64_ptr)(unsigned long long)gwp_global;
     // the weights are folded into the accumulations instead of being multiplied into every kernel value: with g = gamma(x_i, y_j)
@@ -140,7 +141,7 @@ __device__ __forceinline__ void eval_distant_fixed(const DevProblem &P, const do
             double d2 = 0.;
 #pragma unroll
             for (int d = 0; d < DIM; d++) { double t = x[d]-y[j][d]; d2 = __builtin_fma(t, t, d2); }
-            const double g = kern_eval<KT>(P.k, d2);
+            const double g = kern_eval<KT>(P.k, d2, lpow);
             r = __builtin_fma(gwp[j*DPE], g, r);
             c[j] = __builtin_fma(wi, g, c[j]);
 #pragma unroll
@@ -177,7 +178,7 @@ __device__ __forceinline__ void eval_distant_fixed(const DevProblem &P, const do
 // per i; S2 is accumulated directly per point pair (no per-lane column sums of runtime length).
 template <int DIM, int DPE, int KT>
 __device__ __forceinline__ void eval_distant_lds(const DevProblem &P, const double *__restrict__ tab, int stp, int n, const double *av,
-                                                 const double *bv, PairAcc<DIM, DPE> &R) {
+                                                 const double *bv, PairAcc<DIM, DPE> &R, const double *__restrict__ lpow = nullptr) {
     constexpr int NV = DIM+1;
 #pragma unroll 1
     for (int i = 0; i < n; i++) {
@@ -206,7 +207,7 @@ __device__ __forceinline__ void eval_distant_lds(const DevProblem &P, const doub
                 const double t = x[d]-sy;
                 d2 = __builtin_fma(t, t, d2);
             }
-            const double K = (wi*tj[3])*kern_eval<KT>(P.k, d2);
+            const double K = (wi*tj[3])*kern_eval<KT>(P.k, d2, lpow);
             r += K;
             double t[DPE];
 #pragma unroll
@@ -323,7 +324,8 @@ struct TileSmem {
     static constexpr int o_D = o_h+2*TILE;                 // [2][TILE][ND]
     static constexpr int o_Ld = o_D+2*TILE*ND;             // [2][TILE] |ln(h/H0)| in fp64
     static constexpr int o_tt = o_Ld+2*TILE;               // [PNL_TT_MAXPTS][4+DPE] rules integrated one pair per lane
-    static constexpr int n_dbl = o_tt+PNL_TT_MAXPTS*(4+DPE);
+    static constexpr int o_pow = o_tt+PNL_TT_MAXPTS*(4+DPE);   // [PNL_POW_TAB_DOUBLES] tables of the general power (pnl_pow_tab)
+    static constexpr int n_dbl = o_pow+PNL_POW_TAB_DOUBLES;
     // ints after the doubles
     static constexpr int o_vid = 0;                        // [2][NV][TILE]
     static constexpr int o_cnt = o_vid+2*NV*TILE;          // [PNL_MAXQ+2]
@@ -443,6 +445,9 @@ k_tile_distant(const DevProblem P, const int2 *__restrict__ tiles, double *__res
     // rules integrated inside the tile (the two unrolled point counts and the generic ones): staged once per workgroup
     for (int t = tid; t < PNL_MAXQ+2; t += NT) { s_ttn[t] = P.tt_n[t]; s_tto[t] = P.tt_off[t]; }
     for (int t = tid; t < P.tt_npts*(4+DPE); t += NT) s_tt[t] = P.tt_tab[t];
+    double *s_pow = s_dbl+S::o_pow;
+    if (KT == 0) pnl_pow_tab_fill(s_pow, P.k.ptab, tid, NT);
+    const double *__restrict__ lpow = (KT == 0 && P.k.ptab) ? s_pow : nullptr;
     // the two orders integrated by the unrolled evaluators (lists A and B): the lowest ones with NA / NB points -- nearly all
     // pairs; every wave of those lists works on ONE order, so the rule constants are wave-uniform (scalar loads).  Other orders
     // with a packed rule go through list C, which is sorted by order
@@ -754,8 +759,8 @@ k_tile_distant(const DevProblem P, const int2 *__restrict__ tiles, double *__res
             PairAcc<DIM, DPE> R;
             R.clear();
             if (!act) continue;
-            if (pass == 0) eval_distant_fixed<DIM, DPE, KT, NA>(P, tab, gwp, av, bv, R);
-            else eval_distant_fixed<DIM, DPE, KT, NB>(P, tab, gwp, av, bv, R);
+            if (pass == 0) eval_distant_fixed<DIM, DPE, KT, NA>(P, tab, gwp, av, bv, R, lpow);
+            else eval_distant_fixed<DIM, DPE, KT, NB>(P, tab, gwp, av, bv, R, lpow);
             accumulate(R, i, j);
         }
     }
@@ -795,9 +800,9 @@ k_tile_distant(const DevProblem P, const int2 *__restrict__ tiles, double *__res
             PairAcc<DIM, DPE> R;
             R.clear();
             const int nq = __builtin_amdgcn_readfirstlane(s_ttn[q]), to = __builtin_amdgcn_readfirstlane(s_tto[q]);
-            if (nq == NB) eval_distant_fixed<DIM, DPE, KT, NB>(P, s_tt+to*(4+DPE), P.tt_wphi+to*DPE, av, bv, R);
-            else if (nq == NA) eval_distant_fixed<DIM, DPE, KT, NA>(P, s_tt+to*(4+DPE), P.tt_wphi+to*DPE, av, bv, R);
-            else eval_distant_lds<DIM, DPE, KT>(P, s_tt+to*(4+DPE), 4+DPE, nq, av, bv, R);
+            if (nq == NB) eval_distant_fixed<DIM, DPE, KT, NB>(P, s_tt+to*(4+DPE), P.tt_wphi+to*DPE, av, bv, R, lpow);
+            else if (nq == NA) eval_distant_fixed<DIM, DPE, KT, NA>(P, s_tt+to*(4+DPE), P.tt_wphi+to*DPE, av, bv, R, lpow);
+            else eval_distant_lds<DIM, DPE, KT>(P, s_tt+to*(4+DPE), 4+DPE, nq, av, bv, R, lpow);
             if (act) accumulate(R, i, j);
         }
     }
@@ -924,7 +929,8 @@ k_tile_pure(const DevProblem P, const int2 *__restrict__ tiles, int ntiles, doub
     double *s_Da = s_volb+TILE;                         // [TILE][ND]
     double *s_Db = s_Da+TILE*ND;                        // [TILE][ND]
     double *s_rule = s_Db+TILE*ND;                      // [NP][ST]
-    int *s_slotb = (int*)(s_rule+NP*ST);                // [TILE][DPE] (+ [TILE] has-DoF flags)
+    double *s_pow = s_rule+NP*ST;                       // tables of the general power (KT == 0, pnl_pow_tab)
+    int *s_slotb = (int*)(s_pow+PNL_POW_TAB_DOUBLES);   // [TILE][DPE] (+ [TILE] has-DoF flags)
     int *s_hb = s_slotb+TILE*DPE;
     double *s_acc = (double*)(s_hb+TILE);               // [nA+1][acc_stride]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -945,6 +951,8 @@ k_tile_pure(const DevProblem P, const int2 *__restrict__ tiles, int ntiles, doub
     }
     (void)s_rule;
     const double scale2 = 2.*kern_scale<KT>(P.k);
+    if (KT == 0) pnl_pow_tab_fill(s_pow, P.k.ptab, threadIdx.x, PNL_NTHREADS);      // the first barrier of the tile loop publishes it
+    const double *__restrict__ ptab = (KT == 0 && P.k.ptab) ? s_pow : nullptr;
     unsigned long long npairs = 0;
 #pragma unroll 1
     for (int tile_idx = blockIdx.x; tile_idx < ntiles; tile_idx += gridDim.x) {
@@ -1037,7 +1045,7 @@ k_tile_pure(const DevProblem P, const int2 *__restrict__ tiles, int ntiles, doub
 #pragma unroll
                     for (int d = 0; d < DIM; d++) { const double t = x[ip][d]-y[jp][d]; d2 = __builtin_fma(t, t, d2); }
                     // weights folded into the accumulations (they are scalar constants): no multiply per kernel value
-                    const double g = kern_eval<KT>(P.k, d2);
+                    const double g = kern_eval<KT>(P.k, d2, ptab);
                     r = __builtin_fma(wq[jp], g, r);
                     c[jp] = __builtin_fma(wq[ip], g, c[jp]);
 #pragma unroll

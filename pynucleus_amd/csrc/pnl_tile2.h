@@ -190,6 +190,7 @@ __global__ void __launch_bounds__(256, 2)
 k_tile_uniform(const DevProblem P, const int2 *__restrict__ tiles, const int *__restrict__ tile_cls, const DevKernel *__restrict__ kcls,
                int ntiles, double *__restrict__ A, long long ldA, double *__restrict__ Dglob, int acc_stride, int q_uniform,
                int flags, const double *__restrict__ rule_g, int nUe, const SlotOut SO) {
+    const int flags_in = flags;
     constexpr int DIM = 2, NV = 3, NC = 6, ND = DPE*(DPE+1)/2, NT = 256, NW = NT/64;
     constexpr int TILE = DPE == 6 ? 32 : 64, HALVES = 64/TILE, JW = TILE/NW, ITER = JW/HALVES;
     constexpr int R_BARY = 0, R_W = 3*NP, R_WPH = R_W+NP, R_PP = R_WPH+NP*DPE;
@@ -211,10 +212,15 @@ k_tile_uniform(const DevProblem P, const int2 *__restrict__ tiles, const int *__
     int *s_hb = s_ha+TILE;
     int *s_dof = s_hb+TILE;                              // [2][2][nUe] global DoFs of both blocks (ping-pong over tiles)
     double *s_acc = (double*)(s_dof+4*nUe);              // [nUe+1][acc_stride]; nUe even
+    // tables of the general power (KT == 0) behind the sub-block, if the launcher made room for them (bit 8 of flags: they
+    // must not cost the second workgroup per CU)
+    const bool have_pow = KT == 0 && (flags_in & 8) != 0;
+    double *s_pow = s_acc+(size_t)(nUe+1)*acc_stride;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane%TILE, half = lane/TILE;
     const int wv = __builtin_amdgcn_readfirstlane(wave);
     unsigned long long npairs = 0;
+    const double *cur_ptab = nullptr;                    // general power: whose tables s_pow holds
 
     // inputs of tile t -> LDS (b-side: threads [0, TILE), a-side: threads [TILE, 2 TILE), DoF lists: everybody)
     auto stage = [&](int t, int buf) {
@@ -255,11 +261,17 @@ k_tile_uniform(const DevProblem P, const int2 *__restrict__ tiles, const int *__
         const int *__restrict__ dofB = P.blk_dofs+(size_t)tl.y*P.blk_stride;
         for (int k = tid; k < nA; k += NT) s_dof[(buf*2+0)*nUe+k] = P.rowmap ? P.rowmap[dofA[k]] : dofA[k];
         for (int k = tid; k < nB; k += NT) s_dof[(buf*2+1)*nUe+k] = P.colmap ? P.colmap[dofB[k]] : dofB[k];
+        if (have_pow && tile_cls) {
+            const double *pt = kcls[(tile_cls[t] & 0xffff) >> 1].ptab;
+            if (pt != cur_ptab) { cur_ptab = pt; pnl_pow_tab_fill(s_pow, pt, tid, NT); }
+        }
     };
 
     int tile_idx = blockIdx.x, buf = 0;
     if (tile_idx >= ntiles) return;
     for (int t = tid; t < ND*NP; t += NT) s_PP[t] = rule_g[R_PP+t];
+    // tables of the general power: of P.k, or of the kernel class of the tile (copied when the class changes, by stage())
+    if (have_pow && !tile_cls) { cur_ptab = P.k.ptab; pnl_pow_tab_fill(s_pow, cur_ptab, tid, NT); }
     for (int t = tid; t < (nUe+1)*acc_stride; t += NT) s_acc[t] = 0.;
     for (int t = tid; t < 2*TILE*NP; t += NT) s_Ra[t] = 0.;
     stage(tile_idx, 0);
@@ -273,6 +285,7 @@ k_tile_uniform(const DevProblem P, const int2 *__restrict__ tiles, const int *__
         DevKernel kk = P.k;
         if (tile_cls) kk = kcls[(tile_cls[tile_idx] & 0xffff) >> 1];
         const double scale2 = 2.*kern_scale<KT>(kk);
+        const double *__restrict__ ptab = (have_pow && kk.ptab) ? s_pow : nullptr;
         double *__restrict__ Ra = s_Ra+buf*TILE*NP;
         // a side: lane = cell li (both halves of a P2 wave hold the same cells)
         double av[NC];
@@ -324,7 +337,7 @@ k_tile_uniform(const DevProblem P, const int2 *__restrict__ tiles, const int *__
                     double d2 = 0.;
 #pragma unroll
                     for (int d = 0; d < DIM; d++) { const double t = x[d]-y[jp][d]; d2 = __builtin_fma(t, t, d2); }
-                    const double g = kern_eval<KT>(kk, d2);
+                    const double g = kern_eval<KT>(kk, d2, ptab);
                     r = __builtin_fma(rule[R_W+jp], g, r);
                     c[jp] = __builtin_fma(wi, g, c[jp]);
 #pragma unroll
@@ -453,7 +466,8 @@ struct P2Smem {
     static constexpr int o_R = o_D+4*TILE*ND;              // [2 buffers][2][TILE][NR]
     static constexpr int o_PP = o_R+4*TILE*NR;             // [ND][NR] (+ pad): w phi_a phi_b at the points of those rules
     static constexpr int o_tt = o_PP+ND*NR+1;              // [P2_MAXPTS][ST]
-    static constexpr int n_dbl = o_tt+P2_MAXPTS*ST;
+    static constexpr int o_pow = o_tt+P2_MAXPTS*ST;        // [PNL_POW_TAB_DOUBLES] tables of the general power (KT == 0)
+    static constexpr int n_dbl = o_pow+PNL_POW_TAB_DOUBLES;
     // ints
     static constexpr int o_vid = 0;                        // [2][NV][TILE]
     static constexpr int o_cnt = o_vid+2*NV*TILE;          // [PNL_MAXQ+2]
@@ -497,7 +511,7 @@ __device__ __forceinline__ int p2_wave_bucket_add(int *counters, int q) {
 template <int KT, int N>
 __device__ __forceinline__ void p2_eval_fixed(const DevKernel &kk, const double *__restrict__ tab, const double *gw_global,
                                               const double *av, const double *bv, double vv, bool act, double *Ra,
-                                              double (&G)[6][6], double (&c)[N]) {
+                                              double (&G)[6][6], double (&c)[N], const double *__restrict__ ptab) {
     constexpr int ST = 10, GS = 7;
     const pnl_const_f64_ptr gw = (pnl_const_f64_ptr)(unsigned long long)gw_global;
     double y[N][2];
@@ -531,7 +545,7 @@ __device__ __forceinline__ void p2_eval_fixed(const DevKernel &kk, const double 
             double d2 = 0.;
 #pragma unroll
             for (int d = 0; d < 2; d++) { const double t = x[d]-y[j][d]; d2 = __builtin_fma(t, t, d2); }
-            const double g = kern_eval<KT>(kk, d2);
+            const double g = kern_eval<KT>(kk, d2, ptab);
             r = __builtin_fma(gw[j*GS], g, r);
             c[j] = __builtin_fma(wi, g, c[j]);
 #pragma unroll
@@ -550,7 +564,7 @@ __device__ __forceinline__ void p2_eval_fixed(const DevKernel &kk, const double 
 // runtime number of points (list C: orders with 7-16 points, a few per cent of the pairs), first sweep: G and S1
 template <int KT>
 __device__ __forceinline__ void p2_eval_lds_sweep1(const DevKernel &kk, const double *__restrict__ tab, int n, const double *av,
-                                                   const double *bv, double (&G)[6][6], double (&S)[21]) {
+                                                   const double *bv, double (&G)[6][6], double (&S)[21], const double *__restrict__ ptab) {
     constexpr int ST = 10;
 #pragma unroll 1
     for (int i = 0; i < n; i++) {
@@ -579,7 +593,7 @@ __device__ __forceinline__ void p2_eval_lds_sweep1(const DevKernel &kk, const do
                 const double t = x[d]-sy;
                 d2 = __builtin_fma(t, t, d2);
             }
-            const double K = (wi*tj[3])*kern_eval<KT>(kk, d2);
+            const double K = (wi*tj[3])*kern_eval<KT>(kk, d2, ptab);
             r += K;
 #pragma unroll
             for (int b = 0; b < 6; b++) u[b] = __builtin_fma(K, tj[4+b], u[b]);
@@ -600,7 +614,7 @@ __device__ __forceinline__ void p2_eval_lds_sweep1(const DevKernel &kk, const do
 // second sweep: the column sums c_j = sum_i w_i w_j g_ij (the kernel values once more: cheaper than 21 FMAs per point pair) -> S2
 template <int KT>
 __device__ __forceinline__ void p2_eval_lds_sweep2(const DevKernel &kk, const double *__restrict__ tab, int n, const double *av,
-                                                   const double *bv, double (&S)[21]) {
+                                                   const double *bv, double (&S)[21], const double *__restrict__ ptab) {
     constexpr int ST = 10;
 #pragma unroll 1
     for (int j = 0; j < n; j++) {
@@ -626,7 +640,7 @@ __device__ __forceinline__ void p2_eval_lds_sweep2(const DevKernel &kk, const do
                 const double t = sx-y[d];
                 d2 = __builtin_fma(t, t, d2);
             }
-            cc = __builtin_fma(ti[3], kern_eval<KT>(kk, d2), cc);
+            cc = __builtin_fma(ti[3], kern_eval<KT>(kk, d2, ptab), cc);
         }
         cc *= tj[3];
         int e = 0;
@@ -673,6 +687,10 @@ k_tile_p2(const DevProblem P, const int2 *__restrict__ tiles, const int *__restr
     const bool lab_lds = P.nlab <= MAXLAB;
     for (int t = tid; t < PNL_MAXQ+2; t += NT) { s_ttn[t] = P.tt_n[t]; s_tto[t] = P.tt_off[t]; s_off[t] = t <= P.qmax+1 ? P.off[t] : 0; }
     for (int t = tid; t < P.tt_npts*ST; t += NT) s_tt[t] = P.tt_tab[t];
+    // tables of the general power: of P.k, or of the kernel class of the tile visit (copied when the class changes, by stage())
+    double *s_pow = s_dbl+S::o_pow;
+    const double *cur_ptab = nullptr;
+    if (KT == 0 && !tile_cls) { cur_ptab = P.k.ptab; pnl_pow_tab_fill(s_pow, cur_ptab, tid, NT); }
     if (P.nlab > 0 && lab_lds) for (int t = tid; t < P.nlab*P.nlab; t += NT) s_clsof[t] = P.cls_of[t];
     // the rules evaluated by the unrolled evaluators with row / column sums: the lowest order with 3 points and the two lowest
     // orders with 6 points (every such order has its own points, hence its own sums)
@@ -715,6 +733,10 @@ k_tile_p2(const DevProblem P, const int2 *__restrict__ tiles, const int *__restr
         const int *__restrict__ dofB = P.blk_dofs+(size_t)tb*P.blk_stride;
         for (int k = tid; k < nA; k += NT) s_dof[(buf*2+0)*nUe+k] = P.rowmap ? P.rowmap[dofA[k]] : dofA[k];
         for (int k = tid; k < nB; k += NT) s_dof[(buf*2+1)*nUe+k] = P.colmap ? P.colmap[dofB[k]] : dofB[k];
+        if (KT == 0 && tile_cls) {
+            const double *pt = kcls[(tile_cls[t] & 0xffff) >> 1].ptab;
+            if (pt != cur_ptab) { cur_ptab = pt; pnl_pow_tab_fill(s_pow, pt, tid, NT); }
+        }
     };
 
     int n_cur = blockIdx.x, n_nxt = (int)(gridDim.x+blockIdx.x), buf = 0;
@@ -890,6 +912,7 @@ k_tile_p2(const DevProblem P, const int2 *__restrict__ tiles, const int *__restr
         const int totB = __builtin_amdgcn_readfirstlane(s_misc[1]), totA = __builtin_amdgcn_readfirstlane(s_misc[0]);
         const int nchB = (totB+63) >> 6, nchA = (totA+63) >> 6, nch = nchC+nchB+nchA;
         const double scale2 = 2.*kern_scale<KT>(kk);
+        const double *__restrict__ ptab = (KT == 0 && kk.ptab) ? s_pow : nullptr;
 #pragma unroll 1
         while (true) {
             int ch = 0;
@@ -931,13 +954,13 @@ k_tile_p2(const DevProblem P, const int2 *__restrict__ tiles, const int *__restr
             if (q == qB0 || q == qB1) {
                 const int ro = q == qB0 ? 3 : 9;
                 double c[NB];
-                p2_eval_fixed<KT, NB>(kk, tab, P.tt_wphif+to*7, av, bv, vv, act, s_R+(0*TILE+i)*NR+ro, G, c);
+                p2_eval_fixed<KT, NB>(kk, tab, P.tt_wphif+to*7, av, bv, vv, act, s_R+(0*TILE+i)*NR+ro, G, c, ptab);
                 if (act)
 #pragma unroll
                     for (int jp = 0; jp < NB; jp++) lds_add_f64(&s_R[(1*TILE+j)*NR+ro+jp], vv*c[jp]);
             } else if (q == qA0) {
                 double c[NA];
-                p2_eval_fixed<KT, NA>(kk, tab, P.tt_wphif+to*7, av, bv, vv, act, s_R+(0*TILE+i)*NR, G, c);
+                p2_eval_fixed<KT, NA>(kk, tab, P.tt_wphif+to*7, av, bv, vv, act, s_R+(0*TILE+i)*NR, G, c, ptab);
                 if (act)
 #pragma unroll
                     for (int jp = 0; jp < NA; jp++) lds_add_f64(&s_R[(1*TILE+j)*NR+jp], vv*c[jp]);
@@ -945,10 +968,10 @@ k_tile_p2(const DevProblem P, const int2 *__restrict__ tiles, const int *__restr
                 double Sd[21];
 #pragma unroll
                 for (int e = 0; e < 21; e++) Sd[e] = 0.;
-                p2_eval_lds_sweep1<KT>(kk, tab, nq, av, bv, G, Sd);
+                p2_eval_lds_sweep1<KT>(kk, tab, nq, av, bv, G, Sd, ptab);
 #pragma unroll
                 for (int e = 0; e < 21; e++) { if (act) lds_add_f64(&s_D[(0*TILE+i)*ND+e], vv*Sd[e]); Sd[e] = 0.; }
-                p2_eval_lds_sweep2<KT>(kk, tab, nq, av, bv, Sd);
+                p2_eval_lds_sweep2<KT>(kk, tab, nq, av, bv, Sd, ptab);
                 if (act)
 #pragma unroll
                     for (int e = 0; e < 21; e++) lds_add_f64(&s_D[(1*TILE+j)*ND+e], vv*Sd[e]);

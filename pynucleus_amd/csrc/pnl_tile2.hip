@@ -16,9 +16,15 @@ int launch_uniform_t(pnl_context *ctx, const DevProblem &Pt, const int2 *tiles, 
     int acc_stride = nUe+1;
     while (acc_stride % 32 != 1) acc_stride++;
     if (fixed+sizeof(double)*(size_t)(nUe+1)*acc_stride > 80*1024) acc_stride = (nUe+1) | 1;
-    const size_t lds = fixed+sizeof(double)*(size_t)(nUe+1)*acc_stride;
+    size_t lds = fixed+sizeof(double)*(size_t)(nUe+1)*acc_stride;
     if (lds > 160*1024)
         return fail(ctx, PNL_ERR_UNSUPPORTED, "a block of %d cells touches %d DoFs: LDS sub-block of %zu bytes exceeds 160 KiB", TILE, ctx->nU, lds);
+    // general exponent: the tables of pnl_pow_tab behind the sub-block, unless they cost the second workgroup per CU
+    int pow_flag = 0;
+    if (KT == 0) {
+        const size_t with = lds+sizeof(double)*PNL_POW_TAB_DOUBLES;
+        if (with <= 160*1024 && std::min<size_t>(2, (160*1024)/with) == std::min<size_t>(2, (160*1024)/lds)) { lds = with; pow_flag = 8; }
+    }
     auto kfun = k_tile_uniform<DPE, NP, KT>;
     HIPCHK(ctx, hipFuncSetAttribute((const void*)kfun, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int per_cu = std::max(1, std::min(2, (int)((160*1024)/lds)));
@@ -32,7 +38,7 @@ int launch_uniform_t(pnl_context *ctx, const DevProblem &Pt, const int2 *tiles, 
 #endif
     kt_begin(ctx, PNL_K_TILE_UNIFORM2+(q-2));
     hipLaunchKernelGGL(kfun, dim3(grid), dim3(256), lds, ctx->stream, Pt, tiles, tile_cls, (const DevKernel*)ctx->b_kcls.p, ntiles, A,
-                       (long long)ldA, Dglob, acc_stride, q, (ctx->symflush ? 1 : 0) | uni_abl, (const double*)ctx->b_uni.p+ctx->uni_off[q],
+                       (long long)ldA, Dglob, acc_stride, q, (ctx->symflush ? 1 : 0) | uni_abl | pow_flag, (const double*)ctx->b_uni.p+ctx->uni_off[q],
                        nUe, SO);
     kt_end(ctx, PNL_K_TILE_UNIFORM2+(q-2));
     HIPCHK(ctx, hipGetLastError());
