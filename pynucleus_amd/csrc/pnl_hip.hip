@@ -461,13 +461,17 @@ struct ClassFork {
     pnl_context *ctx;
     hipStream_t main;
     bool on, used[pnl_context::NAUX] = {false, false, false, false};
-    ClassFork(pnl_context *c, int nclasses) : ctx(c), main(c->stream), on(nclasses > 1 && !getenv("PNL_NO_FORK")) {
-        if (on) (void)hipEventRecord(ctx->ev_fork, main);
+    hipEvent_t start;
+    // from: an event recorded earlier on the caller's stream (the fold pass) -- the side streams start there instead of behind
+    // everything the caller's stream holds, so consecutive forked phases run back to back on every side stream
+    ClassFork(pnl_context *c, int nclasses, hipEvent_t from = nullptr)
+        : ctx(c), main(c->stream), on(nclasses > 1 && !getenv("PNL_NO_FORK")), start(from ? from : c->ev_fork) {
+        if (on && !from) (void)hipEventRecord(ctx->ev_fork, main);
     }
     void use(int k) {
         if (!on) return;
         const int j = k % pnl_context::NAUX;
-        if (!used[j]) { (void)hipStreamWaitEvent(ctx->aux[j], ctx->ev_fork, 0); used[j] = true; }
+        if (!used[j]) { (void)hipStreamWaitEvent(ctx->aux[j], start, 0); used[j] = true; }
         ctx->stream = ctx->aux[j];
     }
     void join() {
@@ -504,7 +508,7 @@ int run_worklist(pnl_context *ctx, const int4 *wl, const unsigned *wlc, unsigned
     // LDS copy of the rule: 18 KB (8 workgroups per CU; rules with more points are read from global memory; 60 KB / 2 workgroups per CU was 0.6 ms slower at 98,304 cells)
     const int wl_kb = getenv("PNL_WL_LDS_KB") ? std::max(4, atoi(getenv("PNL_WL_LDS_KB"))) : 18;
     const int tab_max = (wl_kb*1024)/(st*(int)sizeof(double));
-    const int wl_grid = 256*std::max(1, std::min(8, 150/wl_kb));
+    const int wl_grid = 256*std::max(1, std::min(8, 150/(wl_kb+(KT == 0 ? 3 : 0))));      // KT == 0: + 3 KB of power tables
     const size_t lds = (size_t)tab_max*st*sizeof(double);
     auto wfun = k_worklist_sorted<DIM, DPE, KT, false>;
     HIPCHK(ctx, hipFuncSetAttribute((const void*)wfun, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -809,6 +813,27 @@ int assemble_impl(pnl_context *ctx, double *A, int64_t ldA, int zero_exterior, i
     HIPCHK(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
     ctx->tiles_launched = ntiles > 0;
     ctx->fold_event_set = false;
+    // variable order, zero exterior: the distant (cell, facet) pairs of ALL classes run in one launch with per-class kernel /
+    // order-formula tables; the tables go up now, ahead of the tile kernels, so that the launch needs nothing from the
+    // caller's stream later than the fold
+    const bool bnd_one_pass = zero_exterior && ncls > 1 && ctx->nlab > 0 && !getenv("PNL_BND_PER_CLASS");
+    bool bnd_all_fast = true;
+    if (bnd_one_pass) {
+        std::vector<DevKernel> &bk = ctx->bkcls_host;
+        std::vector<DevFormula> &bf = ctx->bfcls_host;
+        bk.resize(ncls); bf.resize(ncls);
+        for (int k = 0; k < ncls; k++) {
+            ctx->cur = k;
+            refresh_tables(ctx);
+            bk[k] = ctx->P.bkn; bf[k] = ctx->P.bqo;
+            bnd_all_fast = bnd_all_fast && ctx->P.bkn.fast;
+        }
+        ctx->cur = 0;
+        if ((rc = ensure(ctx, ctx->b_bkcls, sizeof(DevKernel)*ncls))) return rc;
+        if ((rc = ensure(ctx, ctx->b_bfcls, sizeof(DevFormula)*ncls))) return rc;
+        HIPCHK(ctx, hipMemcpyAsync(ctx->b_bkcls.p, bk.data(), sizeof(DevKernel)*ncls, hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(ctx->b_bfcls.p, bf.data(), sizeof(DevFormula)*ncls, hipMemcpyHostToDevice, ctx->stream));
+    }
     // a piecewise-constant variable order is assembled class by class: every pass sees the kernel, order formula and
     // singular rules of one order value and skips the pairs of the other classes in its classification
     const int norient = ctx->nonsym ? 2 : 1;
@@ -863,8 +888,11 @@ int assemble_impl(pnl_context *ctx, double *A, int64_t ldA, int zero_exterior, i
     const bool overlap = ctx->fold_event_set && ncls*norient == 1 && !getenv("PNL_NO_OVERLAP");
     struct StreamGuard { pnl_context *c; hipStream_t s; ~StreamGuard() { c->stream = s; } } stream_guard{ctx, main_stream};
     if (overlap) { HIPCHK(ctx, hipStreamWaitEvent(ctx->aux[0], ctx->ev_fold, 0)); ctx->stream = ctx->aux[0]; }
+    // several classes behind a fold pass: the side streams of the touching pairs and of the boundary term start at the fold
+    // too, class k follows the work list of class k on its stream, nothing waits for the other classes
+    hipEvent_t const chain = (ctx->fold_event_set && !overlap && !getenv("PNL_NO_OVERLAP")) ? ctx->ev_fold : nullptr;
     {
-        ClassFork fork(ctx, ncls*norient);
+        ClassFork fork(ctx, ncls*norient, chain);
         for (int ko = 0; ko < ncls*norient; ko++) {
             ctx->cur = ko/norient; ctx->orient = ko%norient;
             refresh_tables(ctx);
@@ -883,24 +911,9 @@ int assemble_impl(pnl_context *ctx, double *A, int64_t ldA, int zero_exterior, i
     if (zero_exterior) {
         // variable order: the distant (cell, facet) pairs of ALL classes in one launch with per-class kernel / order-formula
         // tables; the touching pairs per class (their rules are per class), on side streams
-        const bool one_pass = ncls > 1 && ctx->nlab > 0 && !getenv("PNL_BND_PER_CLASS");
-        bool all_fast = true;
-        if (one_pass) {
-            std::vector<DevKernel> &bk = ctx->bkcls_host;
-            std::vector<DevFormula> &bf = ctx->bfcls_host;
-            bk.resize(ncls); bf.resize(ncls);
-            for (int k = 0; k < ncls; k++) {
-                ctx->cur = k;
-                refresh_tables(ctx);
-                bk[k] = ctx->P.bkn; bf[k] = ctx->P.bqo;
-                all_fast = all_fast && ctx->P.bkn.fast;
-            }
-            if ((rc = ensure(ctx, ctx->b_bkcls, sizeof(DevKernel)*ncls))) return rc;
-            if ((rc = ensure(ctx, ctx->b_bfcls, sizeof(DevFormula)*ncls))) return rc;
-            HIPCHK(ctx, hipMemcpyAsync(ctx->b_bkcls.p, bk.data(), sizeof(DevKernel)*ncls, hipMemcpyHostToDevice, ctx->stream));
-            HIPCHK(ctx, hipMemcpyAsync(ctx->b_bfcls.p, bf.data(), sizeof(DevFormula)*ncls, hipMemcpyHostToDevice, ctx->stream));
-        }
-        ClassFork fork(ctx, ncls);
+        const bool one_pass = bnd_one_pass;
+        const bool all_fast = bnd_all_fast;
+        ClassFork fork(ctx, ncls, chain);
         for (int k = 0; k < ncls; k++) {
             ctx->cur = k;
             refresh_tables(ctx);
@@ -908,6 +921,7 @@ int assemble_impl(pnl_context *ctx, double *A, int64_t ldA, int zero_exterior, i
                 ctx->cur = 0;
                 return fail(ctx, PNL_ERR_STATE, "zero_exterior needs boundary facets, boundary kernel and order formula");
             }
+            if (chain) fork.use(k);
             if (one_pass && k == 0 &&
                 (rc = launch_boundary<DIM, DPE, 0>(ctx, cell_begin, cell_end, 1, (const DevKernel*)ctx->b_bkcls.p, (const DevFormula*)ctx->b_bfcls.p,
                                                    all_fast))) { ctx->cur = 0; return rc; }

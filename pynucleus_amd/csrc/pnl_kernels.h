@@ -1880,7 +1880,10 @@ k_worklist_sorted(const DevProblem P, const int4 *__restrict__ sorted, const uns
     constexpr int NV = DIM+1, NC = NV*DIM, ND = DPE*(DPE+1)/2, NG = DPE*DPE, NACC = NG+2*ND, LPP = 16, PPC = PNL_NTHREADS/LPP, NREP = (NACC+LPP-1)/LPP, ST = 4+DPE;   // LPP lanes per pair
     extern __shared__ double s_rule[];           // [tab_max_pts][ST]: bary[3], w, phi[DPE]
     __shared__ unsigned s_coff[PNL_WL_BINS+1];
+    __shared__ double s_pow[KT == 0 ? PNL_POW_TAB_DOUBLES : 1];      // tables of the general power (pnl_pow_tab)
     const int tid = threadIdx.x, sub = tid & (LPP-1), g = tid/LPP;
+    if (KT == 0) pnl_pow_tab_fill(s_pow, P.k.ptab, tid, PNL_NTHREADS);       // published by the barrier below
+    const double *__restrict__ lpow = (KT == 0 && P.k.ptab) ? s_pow : nullptr;
     // chunks of PPC pairs over the orders this kernel owns: 2 <= q <= qlast (the sparse path keeps skipped pairs in bin 0 and
     // the touching pairs in the bins above qlast) with at least nmin points (the smaller rules go to k_worklist_lane)
     if (tid == 0) {
@@ -1977,7 +1980,7 @@ k_worklist_sorted(const DevProblem P, const int4 *__restrict__ sorted, const uns
                     const double t = x[d]-sy;
                     d2 = __builtin_fma(t, t, d2);
                 }
-                const double K = (ti[3]*tj[3])*kern_eval<KT>(P.k, d2);
+                const double K = (ti[3]*tj[3])*kern_eval<KT>(P.k, d2, lpow);
                 r += K;
                 double t[DPE];
 #pragma unroll
@@ -2089,7 +2092,10 @@ k_worklist_lane(const DevProblem P, const int4 *__restrict__ sorted, const unsig
     constexpr int NV = DIM+1, NC = NV*DIM, ND = DPE*(DPE+1)/2, ST = 4+DPE, STP = (ST+1) & ~1;
     __shared__ unsigned s_coff[PNL_WL_BINS+1];
     __shared__ double s_rule_all[PNL_NTHREADS/64][PNL_WL_LANE_MAXPTS*STP];
+    __shared__ double s_pow[KT == 0 ? PNL_POW_TAB_DOUBLES : 1];      // tables of the general power (pnl_pow_tab)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (KT == 0) pnl_pow_tab_fill(s_pow, P.k.ptab, tid, PNL_NTHREADS);       // published by the barrier below
+    const double *__restrict__ lpow = (KT == 0 && P.k.ptab) ? s_pow : nullptr;
     if (tid == 0) {
         unsigned run = 0;
         const bool finite = SPARSE && P.k.horizon2 < 1e300;
@@ -2142,7 +2148,7 @@ k_worklist_lane(const DevProblem P, const int4 *__restrict__ sorted, const unsig
             const double tot = wave_sum((double)ne);
             if (lane == 0 && tot > 0.) atomicAdd(&P.counters[2], (unsigned long long)tot);
         } else
-            eval_distant_lds<DIM, DPE, KT>(P, s_rule, STP, (dbg & 4) ? 1 : n, av, bv, R);
+            eval_distant_lds<DIM, DPE, KT>(P, s_rule, STP, (dbg & 4) ? 1 : n, av, bv, R, lpow);
         // without masks (getSparse) the diagonal blocks go through the per-cell buffer like in the dense path and are
         // scattered once per cell (k_scatter_diag_sparse): 9 instead of 15 pattern searches per pair.  The sorted list keeps
         // the producer's runs (k_fh_pairs lays 64 consecutive cells c1 against one c2), so a wave holds a few distinct
