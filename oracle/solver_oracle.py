@@ -49,6 +49,37 @@ def build_restriction_P1(dm_coarse, dm_fine):
     return R
 
 
+# buildRestriction_1D_P2 (restriction_1D_P2.pxi:44-62) and buildRestriction_2D_P2 (restriction_2D_P2.pxi:84-134) as tables:
+# coarse local DoF -> [(child, fine local DoF, weight)]
+_R_P2 = {
+    1: {0: [(0, 0, 1.0), (0, 2, 0.375), (1, 2, -0.125)],
+        1: [(0, 2, -0.125), (1, 1, 1.0), (1, 2, 0.375)],
+        2: [(0, 1, 1.0), (0, 2, 0.75), (1, 2, 0.75)]},
+    2: {0: [(0, 0, 1.0), (0, 3, 0.375), (0, 5, 0.375), (1, 4, -0.125), (1, 5, -0.125), (2, 3, -0.125), (2, 4, -0.125)],
+        1: [(0, 3, -0.125), (0, 4, -0.125), (1, 0, 1.0), (1, 3, 0.375), (1, 5, 0.375), (2, 4, -0.125), (2, 5, -0.125)],
+        2: [(0, 4, -0.125), (0, 5, -0.125), (1, 3, -0.125), (1, 4, -0.125), (2, 0, 1.0), (2, 3, 0.375), (2, 5, 0.375)],
+        3: [(0, 1, 1.0), (0, 3, 0.75), (0, 4, 0.5), (1, 4, 0.5), (1, 5, 0.75), (2, 4, 0.25)],
+        4: [(0, 4, 0.25), (1, 1, 1.0), (1, 3, 0.75), (1, 4, 0.5), (2, 4, 0.5), (2, 5, 0.75)],
+        5: [(0, 2, 1.0), (0, 4, 0.5), (0, 5, 0.75), (1, 4, 0.25), (2, 3, 0.75), (2, 4, 0.5)]},
+}
+
+
+def build_restriction_P2(dm_coarse, dm_fine):
+    dim = dm_coarse.mesh.manifold_dim
+    nchild = 2 if dim == 1 else 4
+    R = np.zeros((dm_coarse.num_dofs, dm_fine.num_dofs))
+    for c in range(dm_coarse.mesh.num_cells):
+        for loc, entries in _R_P2[dim].items():
+            I = dm_coarse.dofs[c, loc]
+            if I < 0:
+                continue
+            for child, floc, w in entries:
+                J = dm_fine.dofs[nchild*c+child, floc]
+                if J >= 0:
+                    R[I, J] = w
+    return R
+
+
 class Multigrid:
     """levels[l] = {'A': dense operator, 'R': restriction to level l-1, 'P': prolongation from it}; level 0 = coarsest."""
 

@@ -4,8 +4,8 @@ nonlocal operators, multigrid-preconditioned CG, the theta time stepper of the f
 Host-side mirror of
   * ``fractionalLevel`` / ``paramsForFractionalHierarchy`` (nl/PyNucleus_nl/helpers.py:312-411): one uniformly refined mesh
     per level, the operator assembled on every level (here: ``nonlocalBuilder.getDense`` on the device),
-  * ``buildRestriction_{1,2}D_P1`` (multilevelSolver/PyNucleus_multilevelSolver/restriction_*_P1.pxi): R = P^T with the
-    weights 1 (coincident vertex) and 1/2 (edge midpoint),
+  * ``buildRestriction_{1,2}D_P1`` / ``_P2`` (multilevelSolver/PyNucleus_multilevelSolver/restriction_*.pxi): R = P^T, P = the
+    coarse shape functions at the fine nodes,
   * ``multigrid`` (multigrid_{SCALAR}.pxi:86-390): V cycle, Jacobi smoother (omega = 2/3, one pre- and one post-sweep),
     direct coarse solve; ``asPreconditioner`` (:293-295),
   * ``CrankNicolson`` / ``ImplicitEuler`` (base/PyNucleus_base/timestepping.py:64-160) driving
@@ -27,41 +27,46 @@ def _vertex_dofs(dm):
     return v2d
 
 
+# parent barycentrics of the vertices of the children of a uniformly refined cell, in the child numbering of mesh.refine()
+# (1D: (c0, m), (m, c1); 2D: (c0, m01, m02), (c1, m12, m01), (c2, m02, m12), (m01, m12, m02))
+_CHILDREN = {
+    1: np.array([[[1., 0.], [.5, .5]], [[.5, .5], [0., 1.]]]),
+    2: np.array([[[1., 0., 0.], [.5, .5, 0.], [.5, 0., .5]], [[0., 1., 0.], [0., .5, .5], [.5, .5, 0.]],
+                 [[0., 0., 1.], [.5, 0., .5], [0., .5, .5]], [[.5, .5, 0.], [0., .5, .5], [.5, 0., .5]]]),
+}
+
+
 def buildProlongation(dm_coarse, dm_fine):
-    """P (n_fine x n_coarse, scipy CSR) between the P1 spaces of a mesh and its uniform refinement: a fine vertex is a
-    coarse vertex (weight 1) or the midpoint of a coarse edge (1/2, 1/2) -- the transpose of buildRestriction_*_P1."""
+    """P (n_fine x n_coarse, scipy CSR) between the Lagrange spaces of a mesh and its uniform refinement: the coarse shape
+    functions evaluated at the fine nodes, P[I, J] = phi_J(x_I).  For P1 that is 1 at a coincident vertex and 1/2 at the two
+    ends of a bisected edge, for P2 the weights 1, 3/8, -1/8, 3/4, 1/2, 1/4 -- the transposes of buildRestriction_{1,2}D_P1 /
+    _P2 (multilevelSolver/PyNucleus_multilevelSolver/restriction_*.pxi), which tabulate exactly these values; the elements of
+    the two levels may differ (P1 coarse, P2 fine)."""
     import scipy.sparse as sp
-    if dm_coarse.polynomialOrder != 1 or dm_fine.polynomialOrder != 1:
-        raise NotImplementedError('prolongation is built for P1 elements only')
     mc, mf = dm_coarse.mesh, dm_fine.mesh
-    nvc = mc.num_vertices
     dim = mc.manifold_dim
-    if dim == 1:
-        assert mf.num_cells == 2*mc.num_cells
-        mids = mf.cells[0::2, 1][:, None]                    # children (c0, m), (m, c1)
-        ends = mc.cells[:, [0, 1]][:, None, :]
-    elif dim == 2:
-        assert mf.num_cells == 4*mc.num_cells
-        # children (c0, m01, m02), (c1, m12, m01), (c2, m02, m12), (m01, m12, m02)
-        mids = np.stack([mf.cells[0::4, 1], mf.cells[0::4, 2], mf.cells[1::4, 1]], axis=1)
-        c = mc.cells
-        ends = np.stack([c[:, [0, 1]], c[:, [0, 2]], c[:, [1, 2]]], axis=1)
-    else:
+    if dim not in _CHILDREN:
         raise NotImplementedError(dim)
-    assert (mf.cells[0::(2 if dim == 1 else 4), 0] == mc.cells[:, 0]).all() and mids.min() >= nvc, \
+    CH = _CHILDREN[dim]
+    nchild = CH.shape[0]
+    assert mf.num_cells == nchild*mc.num_cells and (mf.cells[0::nchild, 0] == mc.cells[:, 0]).all(), \
         'the fine mesh is not the uniform refinement of the coarse one'
-    vc, vf = _vertex_dofs(dm_coarse), _vertex_dofs(dm_fine)
-    # vertex-level prolongation: identity on the old vertices, 1/2 from both ends of the edge on the new ones
-    m = mids.ravel()
-    e = ends.reshape(-1, 2)
-    m, first = np.unique(m, return_index=True)
-    e = e[first]
-    rows = np.concatenate([np.arange(nvc), m, m])
-    cols = np.concatenate([np.arange(nvc), e[:, 0], e[:, 1]])
-    vals = np.concatenate([np.ones(nvc), np.full(2*m.shape[0], 0.5)])
-    keep = (vf[rows] >= 0) & (vc[cols] >= 0)
-    P = sp.csr_matrix((vals[keep], (vf[rows[keep]], vc[cols[keep]])), shape=(dm_fine.num_dofs, dm_coarse.num_dofs))
-    P.sum_duplicates()
+    rows, cols, vals = [], [], []
+    for ch in range(nchild):
+        bary = dm_fine.nodes@CH[ch]                                  # parent barycentrics of the nodes of child ch
+        W = np.asarray(dm_coarse.evalShapeFunctions(np.ascontiguousarray(bary.T)))   # [dpe_coarse, dpe_fine]
+        W[np.abs(W) < 1e-14] = 0.
+        fd = dm_fine.dofs[ch::nchild]                               # [nc, dpe_fine]
+        cd = dm_coarse.dofs                                         # [nc, dpe_coarse]
+        jj, ii = np.nonzero(W)
+        for j, i in zip(jj, ii):
+            m = (fd[:, i] >= 0) & (cd[:, j] >= 0)
+            rows.append(fd[m, i]); cols.append(cd[m, j]); vals.append(np.full(int(m.sum()), W[j, i]))
+    rows, cols, vals = np.concatenate(rows), np.concatenate(cols), np.concatenate(vals)
+    # a node shared by several cells gets the same weight from each of them: keep one copy
+    key = rows.astype(np.int64)*dm_coarse.num_dofs+cols
+    _, first = np.unique(key, return_index=True)
+    P = sp.csr_matrix((vals[first], (rows[first], cols[first])), shape=(dm_fine.num_dofs, dm_coarse.num_dofs))
     P.sort_indices()
     return P
 
@@ -122,8 +127,8 @@ class fractionalHierarchy:
         from .dofmap import dofmapFactory
         from .mesh import PHYSICAL
         from .builder import nonlocalBuilder
-        if element != 'P1':
-            raise NotImplementedError('hierarchies are built for P1 elements (restriction_*_P1.pxi); got {}'.format(element))
+        if element not in ('P1', 'P2'):
+            raise NotImplementedError('hierarchies are built for P1 and P2 elements (restriction_*_P1.pxi, _P2.pxi); got {}'.format(element))
         self.kernel, self.params = kernel, dict(params or {})
         mesh = mesh if mesh is not None else _seed_mesh(domain)
         self.levels = []

@@ -10,26 +10,27 @@ import numpy as np
 import pytest
 from math import gamma
 from scipy.special import hyp2f1
-from pynucleus_amd import P1_DoFMap, PHYSICAL, getFractionalKernel, nonlocalTables
+from pynucleus_amd import P1_DoFMap, P2_DoFMap, PHYSICAL, getFractionalKernel, nonlocalTables
 from pynucleus_amd.multigrid import buildProlongation, buildRestriction, _seed_mesh, determineTimeSteps
 from pynucleus_amd.quadrature import simplexXiaoGimbutas
 from oracle.oracle import OracleProblem
 from oracle import solver_oracle as SO
 
 
-def oracle_hierarchy(domain, noRef, s, params, mass=False):
+def oracle_hierarchy(domain, noRef, s, params, mass=False, element='P1'):
     mesh = _seed_mesh(domain)
     dim = mesh.manifold_dim
     levels = []
+    DM, build_restriction = (P1_DoFMap, SO.build_restriction_P1) if element == 'P1' else (P2_DoFMap, SO.build_restriction_P2)
     for l in range(noRef+1):
         if l > 0:
             mesh = mesh.refine()
-        dm = P1_DoFMap(mesh, PHYSICAL)
+        dm = DM(mesh, PHYSICAL)
         L = {'mesh': mesh, 'DoFMap': dm, 'A': OracleProblem(nonlocalTables(dm, getFractionalKernel(dim, s), dict(params))).get_dense()[0]}
         if mass:
             L['M'] = dm.assembleMass().toarray()
         if l > 0:
-            L['R'] = SO.build_restriction_P1(levels[-1]['DoFMap'], dm)
+            L['R'] = build_restriction(levels[-1]['DoFMap'], dm)
             L['P'] = L['R'].T.copy()
         levels.append(L)
     return levels
@@ -133,16 +134,27 @@ def test_oracle_multigrid_is_a_solver_for_the_stored_steady_run():
 
 
 @pytest.mark.parametrize('domain', ['interval', 'disc'])
-def test_transfer_operators_equal_the_cell_walk(domain):
+@pytest.mark.parametrize('element', ['P1', 'P2'])
+def test_transfer_operators_equal_the_cell_walk(domain, element):
+    """the product's prolongation (coarse shape functions at the fine nodes) against the reference's tabulated weights
+    (restriction_{1,2}D_P1.pxi, restriction_{1,2}D_P2.pxi) walked cell by cell"""
     mesh = _seed_mesh(domain)
+    DM, walk = (P1_DoFMap, SO.build_restriction_P1) if element == 'P1' else (P2_DoFMap, SO.build_restriction_P2)
     for _ in range(3):
         fine = mesh.refine()
-        dc, df = P1_DoFMap(mesh, PHYSICAL), P1_DoFMap(fine, PHYSICAL)
+        dc, df = DM(mesh, PHYSICAL), DM(fine, PHYSICAL)
         P, R = buildProlongation(dc, df), buildRestriction(dc, df)
-        Ro = SO.build_restriction_P1(dc, df)
+        Ro = walk(dc, df)
         assert np.abs(R.toarray()-Ro).max() == 0. and np.abs(P.toarray().T-Ro).max() == 0.
-        # interpolation of a linear function that vanishes on the boundary vertices is exact where no boundary vertex is involved
         assert P.shape == (df.num_dofs, dc.num_dofs) and P.toarray().max() == 1.
+        # the prolongation reproduces coarse functions: the interpolant of a coarse FE function at the fine nodes
+        uc = np.random.default_rng(0).standard_normal(dc.num_dofs)
+        xf = df.getDoFCoordinates()
+        if element == 'P1' and domain == 'interval':
+            xc = dc.getDoFCoordinates()[:, 0]
+            order = np.argsort(xc)
+            ref = np.interp(xf[:, 0], np.concatenate(([-1.], xc[order], [1.])), np.concatenate(([0.], uc[order], [0.])))
+            assert np.abs(P@uc-ref).max() < 1e-14
         mesh = fine
 
 
@@ -153,10 +165,10 @@ def test_time_step_rule():
 
 
 # ---- device -----------------------------------------------------------------------------------------------------------------
-def device_hierarchy(domain, noRef, s, params, mass=False):
+def device_hierarchy(domain, noRef, s, params, mass=False, element='P1'):
     from pynucleus_amd.multigrid import fractionalHierarchy
     dim = 1 if domain == 'interval' else 2
-    return fractionalHierarchy(domain, noRef, getFractionalKernel(dim, s), params, buildMass=mass)
+    return fractionalHierarchy(domain, noRef, getFractionalKernel(dim, s), params, buildMass=mass, element=element)
 
 
 def as_oracle_levels(H):
@@ -172,12 +184,13 @@ def as_oracle_levels(H):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('domain,noRef,s', [('interval', 6, 0.25), ('disc', 3, 0.75)])
-def test_gpu_cycle_solve_and_cg_against_the_oracle(domain, noRef, s):
+@pytest.mark.parametrize('domain,noRef,s,element', [('interval', 6, 0.25, 'P1'), ('disc', 3, 0.75, 'P1'), ('interval', 4, 0.75, 'P2'),
+                                                    ('disc', 2, 0.4, 'P2')])
+def test_gpu_cycle_solve_and_cg_against_the_oracle(domain, noRef, s, element):
     from pynucleus_amd.multigrid import multigrid
     params = {'target_order': 2.-s} if domain == 'interval' else {}
-    H = device_hierarchy(domain, noRef, s, params)
-    levels_o = oracle_hierarchy(domain, noRef, s, params)
+    H = device_hierarchy(domain, noRef, s, params, element=element)
+    levels_o = oracle_hierarchy(domain, noRef, s, params, element=element)
     # the device hierarchy is the oracle's: operators at the assembly tolerance, transfer operators exactly
     for L, K in zip(H.getLevelList(), levels_o):
         assert np.abs(L['A'].toarray()-K['A']).max() <= 1e-10*np.abs(K['A']).max()
