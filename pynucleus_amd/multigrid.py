@@ -123,7 +123,8 @@ class fractionalHierarchy:
     (helpers.py:312-380 with 'assemble': 'ALL').  levels[l] = {'mesh', 'DoFMap', 'A' (Dense_LinearOperator in HBM),
     'M' (scipy CSR, buildMass), 'P', 'R' (scipy CSR; l > 0)}."""
 
-    def __init__(self, domain, noRef, kernel, params=None, element='P1', buildMass=False, tag=None, device=None, mesh=None):
+    def __init__(self, domain, noRef, kernel, params=None, element='P1', buildMass=False, tag=None, device=None, mesh=None,
+                 matrixFormat='dense', h2MinDoFs=2000):
         from .dofmap import dofmapFactory
         from .mesh import PHYSICAL
         from .builder import nonlocalBuilder
@@ -138,7 +139,8 @@ class fractionalHierarchy:
                 mesh = mesh.refine()
             dm = dofmapFactory(element, mesh, PHYSICAL if tag is None else tag)
             b = nonlocalBuilder(dm, kernel, dict(self.params), device=device)
-            A = b.getDense()
+            # matrixFormat 'H2': the levels with at least h2MinDoFs DoFs carry the H2 operator (getH2), the coarse ones stay dense
+            A = b.getH2() if (matrixFormat.upper() == 'H2' and dm.num_dofs >= h2MinDoFs) else b.getDense()
             b.context().synchronize()
             L = {'mesh': mesh, 'DoFMap': dm, 'A': A}
             if buildMass:
@@ -181,7 +183,7 @@ class multigrid:
     """multigrid(hierarchy, smoother=('jacobi', {'omega': 2/3})) like the reference's solver class; ``hierarchy`` is a
     fractionalHierarchy or a list of level dicts with 'A' (Dense_LinearOperator), 'R', 'P'."""
 
-    def __init__(self, hierarchy, smoother=('jacobi', {'omega': 2.0/3.0}), ctx=None):
+    def __init__(self, hierarchy, smoother=('jacobi', {'omega': 2.0/3.0}), ctx=None, native=None):
         import torch
         levels = hierarchy.getLevelList() if hasattr(hierarchy, 'getLevelList') else list(hierarchy)
         if len(levels) < 1:
@@ -192,13 +194,21 @@ class multigrid:
         self.omega = float(sp.get('omega', 2.0/3.0))
         self.presmoothingSteps = int(sp.get('presmoothingSteps', 1))
         self.postsmoothingSteps = int(sp.get('postsmoothingSteps', 1))
+        from .linear_operators import Dense_LinearOperator
         self.levels = levels
         self.A = levels[-1]['A']
-        self.ctx = ctx or self.A.ctx
-        self.device = self.A.A.device
         self.maxIter = 50
         self.tolerance = 1e-8
         self.num_rows = self.A.num_rows
+        self._mg = None
+        # every level a dense operator: the cycle runs inside the library.  Otherwise (H2 / sparse levels) the same cycle is
+        # driven from here over the operators' device matvecs (vectors stay in HBM, transfer operators through pnl_csr_matvec)
+        self._native = all(isinstance(L['A'], Dense_LinearOperator) for L in levels) and native is not False
+        if not self._native:
+            self._setup_generic(ctx)
+            return
+        self.ctx = ctx or self.A.ctx
+        self.device = self.A.A.device
         # level data in HBM (kept alive by this object: the library only stores the pointers)
         self._keep = []
         descs = []
@@ -226,6 +236,52 @@ class multigrid:
         torch.cuda.current_stream(self.device).synchronize()
         self._set_stream()
         self._mg = self.ctx.mg_create(descs, self._coarse_inv.data_ptr(), self.omega, self.presmoothingSteps, self.postsmoothingSteps)
+
+    def _setup_generic(self, ctx):
+        import torch
+        A = self.A
+        self.device = getattr(A, 'device', None)
+        if self.device is None:
+            self.device = A.A.device
+        self.ctx = ctx or A.ctx
+        self._g = []
+        for l, L in enumerate(self.levels):
+            op = L['A']
+            G = {'A': op, 'n': op.num_rows}
+            if l > 0:
+                d = op.diagonal
+                d = d() if callable(d) else d
+                G['invD'] = self.omega/self._vec(d)
+                G['R'], G['P'] = _DevCSR(L['R'], self.device), _DevCSR(L['P'], self.device)
+            self._g.append(G)
+        A0 = self.levels[0]['A']
+        self._coarse_inv = torch.from_numpy(np.linalg.inv(np.asarray(A0.toarray()))).to(self.device).contiguous()
+
+    def _generic_smooth(self, l, b, x, steps, simple):
+        G = self._g[l]
+        for _ in range(steps):
+            res = b if simple else b-G['A'].matvec(x)
+            simple = False
+            x.addcmul_(G['invD'], res)
+
+    def _generic_level(self, l, b, x, simple):
+        """multigrid.solveOnLevel (multigrid_{SCALAR}.pxi:237-292) over operator matvecs; x is updated in place"""
+        import torch
+        if l == 0:
+            x.copy_(self._coarse_inv@b)
+            return
+        G = self._g[l]
+        self._generic_smooth(l, b, x, self.presmoothingSteps, simple)
+        res = b-G['A'].matvec(x) if not (simple and self.presmoothingSteps == 0) else b
+        self._set_stream()
+        defect = G['R'].matvec(self.ctx, res.contiguous())
+        solcg = torch.zeros(self._g[l-1]['n'], dtype=torch.float64, device=self.device)
+        self.ctx.synchronize()
+        self._generic_level(l-1, defect, solcg, True)
+        self._set_stream()
+        G['P'].matvec(self.ctx, solcg, alpha=1., beta=1., y=x)
+        self.ctx.synchronize()
+        self._generic_smooth(l, b, x, self.postsmoothingSteps, False)
 
     def _set_stream(self):
         import torch
@@ -255,6 +311,10 @@ class multigrid:
         bd = self._vec(b)
         zero = x is None
         xd = torch.zeros_like(bd) if zero else self._vec(x).clone()
+        if not self._native:
+            torch.cuda.current_stream(self.device).synchronize()
+            self._generic_level(len(self.levels)-1, bd, xd, zero)
+            return self._ret(b, xd)
         self._set_stream()
         self.ctx.mg_cycle(self._mg, bd.data_ptr(), xd.data_ptr(), zero)
         self.ctx.synchronize()
@@ -266,9 +326,19 @@ class multigrid:
         bd = self._vec(b)
         zero = x is None
         xd = torch.zeros_like(bd) if zero else self._vec(x).clone()
+        tol = self.tolerance if tol is None else tol
+        maxiter = self.maxIter if maxiter is None else maxiter
+        if not self._native:
+            res = [float(torch.linalg.norm(bd if zero else bd-self.A.matvec(xd)))]
+            its = 0
+            while res[-1] > tol and its < maxiter:
+                its += 1
+                self._generic_level(len(self.levels)-1, bd, xd, zero)
+                zero = False
+                res.append(float(torch.linalg.norm(bd-self.A.matvec(xd))))
+            return self._ret(b, xd), its, res
         self._set_stream()
-        its, res = self.ctx.mg_solve(self._mg, bd.data_ptr(), xd.data_ptr(), self.tolerance if tol is None else tol,
-                                     self.maxIter if maxiter is None else maxiter, zero)
+        its, res = self.ctx.mg_solve(self._mg, bd.data_ptr(), xd.data_ptr(), tol, maxiter, zero)
         return self._ret(b, xd), its, res
 
     def cg(self, b, x=None, tol=1e-8, maxiter=100, A=None):
@@ -276,6 +346,11 @@ class multigrid:
         import torch
         bd = self._vec(b)
         zero = x is None
+        if not self._native:
+            from .solvers import cg as _cg
+            xd, its, res = _cg(A if A is not None else self.A, bd, x0=None if zero else self._vec(x), tol=tol, maxiter=maxiter,
+                               preconditioner=self.asPreconditioner())
+            return self._ret(b, xd), its, res
         xd = torch.zeros_like(bd) if zero else self._vec(x).clone()
         self._set_stream()
         Aptr, ld = (A.A.data_ptr(), A.A.stride(0)) if A is not None else (None, 0)

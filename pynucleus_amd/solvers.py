@@ -25,21 +25,28 @@ def cg(A, b, x0=None, tol=1e-8, maxiter=1000, preconditioner='jacobi'):
     bd = _dev_vector(b, device)
     x = torch.zeros_like(bd) if x0 is None else _dev_vector(x0, device).clone()
     dinv = None
+    B = None
     if preconditioner == 'jacobi':
         d = A.diagonal
         d = d() if callable(d) else d
         dinv = 1./_dev_vector(d, device)
+    elif callable(preconditioner):
+        # r -> B r on device vectors, e.g. multigrid.asPreconditioner() (multigridPreconditioner, multigrid_{SCALAR}.pxi:470-497)
+        B = preconditioner
     elif preconditioner is not None:
         raise NotImplementedError(preconditioner)
     r = bd-A.matvec(x) if x0 is not None else bd.clone()
     residuals = []
-    if dinv is None:
+    if B is not None:
+        p = B(r).clone()
+        betaOld = float(torch.dot(r, p))
+    elif dinv is None:
         p = r.clone()
         betaOld = float(torch.dot(r, p))
     else:
         p = dinv*r
         betaOld = float(torch.dot(r, p))
-    conv = float(np.sqrt(betaOld))
+    conv = float(np.sqrt(abs(betaOld)))
     residuals.append(conv)
     its = 0
     if conv > tol:
@@ -52,9 +59,9 @@ def cg(A, b, x0=None, tol=1e-8, maxiter=1000, preconditioner='jacobi'):
             if k == 50:
                 r = bd-A.matvec(x)                      # recalculate the residual to avoid rounding errors
                 k = 0
-            Br = r if dinv is None else dinv*r
+            Br = B(r) if B is not None else (r if dinv is None else dinv*r)
             beta = float(torch.dot(r, Br))
-            conv = float(np.sqrt(beta))
+            conv = float(np.sqrt(abs(beta)))
             residuals.append(conv)
             its = i
             if conv <= tol:
