@@ -2038,10 +2038,27 @@ static int upload_tiles(pnl_context *ctx, std::vector<int2> &tiles, int cell_beg
         // (a non-symmetric order table visits every mixed tile once per orientation)
         const int norient = ctx->nonsym ? 2 : 1;
         ctx->sl_off[0] = 0;
+        // symmetric order tables: a tile that holds pairs of several classes gets ONE entry that names the set of them (bit 29
+        // + class bits); k_tile_p2 works through the classes inside one visit and flushes once with plain stores
+        const bool one_visit = norient == 1 && ncls > 1 && ncls <= 28 && !getenv("PNL_P2_VISIT_PER_CLASS");
+        std::vector<unsigned> tile_mask;
+        if (one_visit) {
+            tile_mask.assign((size_t)ctx->nblocks*ctx->nblocks, 0u);
+            for (int k = 0; k < ncls; k++)
+                for (const int2 &t : mixed[k]) tile_mask[(size_t)t.x*ctx->nblocks+t.y] |= 1u << k;
+            // the multi-class tiles first (several classifications each: the heavy ones), in tile-list order
+            for (const int2 &t : tiles) {
+                const unsigned m = tile_mask[(size_t)t.x*ctx->nblocks+t.y];
+                if (m & (m-1u)) { all.push_back(t); allcls.push_back((int)((1u << 29) | m)); }
+            }
+        }
         for (int k = 0; k < ncls; k++) {
             ctx->cls_n_mixed[k] = (int)mixed[k].size();
             for (int o = 0; o < norient; o++)
-                for (const int2 &t : mixed[k]) { all.push_back(t); allcls.push_back(2*k+o); }
+                for (const int2 &t : mixed[k]) {
+                    if (one_visit) { const unsigned m = tile_mask[(size_t)t.x*ctx->nblocks+t.y]; if (m & (m-1u)) continue; }
+                    all.push_back(t); allcls.push_back(2*k+o);
+                }
         }
         ctx->sl_n[0] = (int)all.size();
         for (int u = 0; u < 3; u++) {

@@ -733,7 +733,7 @@ k_tile_p2(const DevProblem P, const int2 *__restrict__ tiles, const int *__restr
         const int *__restrict__ dofB = P.blk_dofs+(size_t)tb*P.blk_stride;
         for (int k = tid; k < nA; k += NT) s_dof[(buf*2+0)*nUe+k] = P.rowmap ? P.rowmap[dofA[k]] : dofA[k];
         for (int k = tid; k < nB; k += NT) s_dof[(buf*2+1)*nUe+k] = P.colmap ? P.colmap[dofB[k]] : dofB[k];
-        if (KT == 0 && tile_cls) {
+        if (KT == 0 && tile_cls && !(tile_cls[t] & (1 << 29))) {
             const double *pt = kcls[(tile_cls[t] & 0xffff) >> 1].ptab;
             if (pt != cur_ptab) { cur_ptab = pt; pnl_pow_tab_fill(s_pow, pt, tid, NT); }
         }
@@ -763,13 +763,31 @@ k_tile_p2(const DevProblem P, const int2 *__restrict__ tiles, const int *__restr
     const int tile_idx = n_cur;
     const int ta = tiles[tile_idx].x, tb = tiles[tile_idx].y;
     const int nA = P.blk_ndof[ta], nB = P.blk_ndof[tb];
-    // order class of this tile entry (variable order: kernel, order formula, work-list region of the class; bit 0: orientation)
-    const int tcls = tile_cls ? (tile_cls[tile_idx] & 0xffff) : (P.cur_class >= 0 ? 2*P.cur_class+P.orient : -1);
+    // order class of this tile entry (variable order: kernel, order formula, work-list region of the class; bit 0: orientation).
+    // Bit 29 of the class word: the tile holds pairs of SEVERAL classes, bits 0..27 are the set of them -- the classes are
+    // worked through one after the other (classification, lists, evaluation per class) into the same LDS sub-block and sums,
+    // ONE flush with plain stores at the end, instead of one visit per class with an atomic flush each
+    const int cword = tile_cls ? tile_cls[tile_idx] : 0;
+    const bool multik = tile_cls && (cword & (1 << 29)) != 0;
+    unsigned cmask = multik ? ((unsigned)cword & 0x0fffffffu) : 0u;
+    double *__restrict__ s_D = s_Dall+buf*2*TILE*ND, *__restrict__ s_R = s_Rall+buf*2*TILE*NR;
+    bool first_class = true;
+#pragma unroll 1
+    do {
+    int tcls;
+    if (multik) { const int kc = __ffs((int)cmask)-1; cmask &= cmask-1u; tcls = 2*kc; }
+    else tcls = tile_cls ? (cword & 0xffff) : (P.cur_class >= 0 ? 2*P.cur_class+P.orient : -1);
     DevKernel kk = P.k;
     DevFormula qo = P.qo;
     if (tile_cls) { kk = kcls[tcls >> 1]; qo = fcls[tcls >> 1]; }
     const int wl_region = tile_cls ? (tcls >> 1) : 0;
-    double *__restrict__ s_D = s_Dall+buf*2*TILE*ND, *__restrict__ s_R = s_Rall+buf*2*TILE*NR;
+    if (!first_class) {
+        // the lists and counters of the previous class are done with (barrier behind its evaluation)
+        for (int t = tid; t < 2*(PNL_MAXQ+2)+6; t += NT) s_cnt[t] = 0;
+    }
+    if (KT == 0 && multik && kk.ptab != cur_ptab) { cur_ptab = kk.ptab; pnl_pow_tab_fill(s_pow, cur_ptab, tid, NT); }
+    if (!first_class) lds_barrier();
+    first_class = false;
 
     // ---- classification (NO:280-378 vertex test, NO:493-540 + FL2:622-642 order) ----
     int overflow = 0;
@@ -990,6 +1008,7 @@ k_tile_p2(const DevProblem P, const int2 *__restrict__ tiles, const int *__restr
         }
     }
     lds_barrier();
+    } while (cmask);   // classes of a multi-class tile
 
     // ---- the next tile's cell data, then the flush of this one: one wave per row of the sub-block, lanes along the row of A;
     // diagonal blocks from the row / column sums ----
