@@ -340,3 +340,30 @@ def test_gpu_generic_cycle_equals_the_library_cycle_and_takes_h2_levels():
     hs = np.sqrt(abs(b@x-C*np.pi/(s+1)))
     assert abs(hs-0.059725648882225826) <= 1e-2*0.059725648882225826, hs
     assert its <= 15, its
+
+
+@pytest.mark.gpu
+def test_gpu_fractional_heat_on_the_disc_reproduces_the_stored_errors():
+    """runFractionalHeat --domain disc --s const(0.25) --problem constant --element P1 --solver cg-mg --matrixFormat dense
+    (noRef 5, 2977 DoFs, Crank-Nicolson): stored errors 0.03181790573759944 / 0.07058538202611951, norm 1.489665512411283
+    (compared by the reference at rTol 3e-2); the triangle rule of the load vector is this package's degree-3 rule, not the
+    reference's Xiao-Gimbutas table, hence the 1e-3"""
+    from pynucleus_amd.multigrid import solveFractionalHeat
+    s = 0.25
+    H = device_hierarchy('disc', 5, s, {'target_order': 0.5}, mass=True)
+    dm = H.finest['DoFMap']
+    assert dm.num_dofs == 2977
+    C = 2.**(-2.*s)*gamma(1.)/gamma((2+2.*s)/2.)/gamma(1.+s)
+    L2ex2 = C**2*np.pi/(1+2*s)                              # nonlocalProblems.py:747
+
+    def uss(x):
+        return C*max(1.-x[0]**2-x[1]**2, 0.)**s
+    qr = simplexXiaoGimbutas(3, 2, 2)
+    z_ss, f_ss = np.asarray(dm.assembleRHS(uss, qr)), np.asarray(dm.assembleRHS(1.0, qr))
+    times, us, stepper = solveFractionalHeat(H, uss, lambda t: -np.sin(t)*z_ss+np.cos(t)*f_ss, finalTime=1.0, tol=1e-10)
+    M = H.finest['M']
+    e_final, e_l2, norm = SO.transient_errors(us, times, M, lambda t: np.cos(t)*z_ss, lambda t: np.cos(t)**2*L2ex2)
+    assert abs(norm-1.489665512411283) <= 1e-4*1.489665512411283, norm
+    assert abs(e_final-0.03181790573759944) <= 1e-3*0.03181790573759944, e_final
+    assert abs(e_l2-0.07058538202611951) <= 1e-3*0.07058538202611951, e_l2
+    assert max(stepper.iterations) <= 10
