@@ -190,3 +190,61 @@ def transient_errors(us, times, M, z_of_t, exactL2Squared_of_t):
         return abs(exactL2Squared_of_t(times[k])-2*(z_of_t(times[k])@us[k])+us[k]@(M@us[k]))
     return (np.sqrt(err2(nt)), np.sqrt(sum(fac(k)*err2(k) for k in range(nt+1))),
             np.sqrt(sum(fac(k)*abs(us[k]@(M@us[k])) for k in range(nt+1))))
+
+
+def gmres(A, b, x0=None, tol=1e-8, maxiter=50, restarts=1, B=None, left=True):
+    """gmres_solver.solve (base/PyNucleus_base/solvers.pyx:504-659), dense numpy"""
+    x = np.zeros_like(b) if x0 is None else x0.copy()
+    L = B if left else None
+    R = B if not left else None
+    n = b.shape[0]
+    Q = np.zeros((maxiter+1, n))
+    H = np.zeros((maxiter+1, maxiter))
+    c, sn, gamma, y = np.zeros(maxiter), np.zeros(maxiter), np.zeros(maxiter+1), np.zeros(maxiter+1)
+    residuals, allIter, breakout = [], 0, False
+    for _ in range(restarts):
+        if breakout:
+            break
+        r = b-A@x
+        if L is not None:
+            r = L(r)
+        gamma[0] = np.linalg.norm(r)
+        if not residuals:
+            residuals.append(abs(gamma[0]))
+        if abs(gamma[0]) < tol:
+            break
+        Q[0] = r/gamma[0]
+        i = -1
+        for i in range(maxiter):
+            w = L(A@Q[i]) if L is not None else (A@R(Q[i]) if R is not None else A@Q[i])
+            w = np.array(w, copy=True)
+            for j in range(i+1):
+                H[j, i] = Q[j]@w
+                w -= H[j, i]*Q[j]
+            H[i+1, i] = np.linalg.norm(w)
+            if not abs(H[i+1, i]) > 1e-15:
+                breakout = True
+                break
+            Q[i+1] = w/H[i+1, i]
+            for j in range(i):
+                rho, sigma = H[j, i], H[j+1, i]
+                H[j, i] = c[j]*rho+sn[j]*sigma
+                H[j+1, i] = -sn[j]*rho+c[j]*sigma
+            beta = np.sqrt(H[i, i]**2+H[i+1, i]**2)
+            c[i], sn[i] = H[i, i]/beta, H[i+1, i]/beta
+            H[i, i] = beta
+            gamma[i+1] = -sn[i]*gamma[i]
+            gamma[i] = c[i]*gamma[i]
+            residuals.append(abs(gamma[i+1]))
+            if abs(gamma[i+1]) < tol:
+                breakout = True
+                break
+        allIter += i
+        for j in range(i, -1, -1):
+            t = gamma[j]
+            for l in range(j+1, i+1):
+                t -= H[j, l]*y[l]
+            y[j] = t/H[j, j]
+        upd = y[:i+1]@Q[:i+1]
+        x += R(upd) if R is not None else upd
+    return x, allIter, residuals
