@@ -80,6 +80,19 @@ class Dense_LinearOperator:
             return xd, its, res
         return xd.cpu().numpy(), its, res
 
+    # operator files: the reference's layout (DenseLinearOperator_{SCALAR}.pxi:86-94) on any h5py-like group (create_dataset,
+    # attrs, item access); h5py itself is not a dependency of this package
+    def HDF5write(self, node):
+        node.create_dataset('data', data=np.ascontiguousarray(self.data))
+        node.attrs['type'] = 'dense'
+
+    @staticmethod
+    def HDF5read(node, ctx, device=None):
+        """the operator back in HBM, bound to the context ``ctx`` (a builder's ``context()``)"""
+        dev = torch.device('cuda', ctx.device) if device is None else device
+        A = torch.from_numpy(np.array(node['data'], dtype=np.float64)).to(dev)
+        return Dense_LinearOperator(A, ctx)
+
     def __repr__(self):
         return '<{}x{} Dense_LinearOperator on {}>'.format(self.num_rows, self.num_columns, self.A.device)
 
@@ -296,6 +309,35 @@ class CSR_LinearOperator:
         rows = np.repeat(np.arange(N), np.diff(self.indptr))
         A[rows, self.indices] = self.data
         return A
+
+    # operator files: CSR_LinearOperator_{SCALAR}.pxi:268-290 / SSS_LinearOperator_{SCALAR}.pxi:273-293 on an h5py-like group
+    def HDF5write(self, node):
+        node.create_dataset('indices', data=np.ascontiguousarray(self.indices))
+        node.create_dataset('indptr', data=np.ascontiguousarray(self.indptr))
+        node.create_dataset('data', data=np.ascontiguousarray(self.data))
+        if self.symmetric:
+            node.create_dataset('diagonal', data=np.ascontiguousarray(self.diagonal))
+            node.attrs['type'] = 'sss'
+        else:
+            node.attrs['type'] = 'csr'
+            node.attrs['num_rows'] = self.num_rows
+            node.attrs['num_columns'] = self.num_columns
+
+    @classmethod
+    def HDF5read(cls, node, ctx, device=None):
+        dev = torch.device('cuda', ctx.device) if device is None else device
+        indptr = np.array(node['indptr'], dtype=np.int32)
+        kind = node.attrs['type']
+        kind = kind.decode() if isinstance(kind, bytes) else str(kind)
+        op_cls = SSS_LinearOperator if kind == 'sss' else CSR_LinearOperator
+        B = op_cls(indptr, np.array(node['indices'], dtype=np.int32), indptr.shape[0]-1, ctx, dev)
+        data = np.array(node['data'], dtype=np.float64)
+        B.data_dev[:data.shape[0]] = torch.from_numpy(data).to(dev)
+        if kind == 'sss':
+            B.diag_dev.copy_(torch.from_numpy(np.array(node['diagonal'], dtype=np.float64)).to(dev))
+        else:
+            assert B.num_rows == int(node.attrs['num_rows'])
+        return B
 
     @property
     def diagonal(self):

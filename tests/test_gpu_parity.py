@@ -445,3 +445,48 @@ def test_bench_size_properties():
     u5 = b5.getDense().solve_cg_jacobi(rhs5, tol=1e-10, maxiter=500)[0]
     ratio = (exact-float(rhs5@u5))/(exact-energy)
     assert 3. < ratio < 5.5, ratio
+
+
+class _Group(dict):
+    """the part of h5py.Group the operators' HDF5write / HDF5read use (h5py is not installed here)"""
+
+    def __init__(self):
+        super().__init__()
+        self.attrs = {}
+
+    def create_dataset(self, name, data=None, **kwargs):
+        self[name] = np.array(data, copy=True)
+
+    def create_group(self, name):
+        self[name] = _Group()
+        return self[name]
+
+
+def test_operator_files_round_trip():
+    """HDF5write / HDF5read of the dense, CSR and SSS operators in the reference's layout (DenseLinearOperator_{SCALAR}.pxi:86-94,
+    CSR_LinearOperator_{SCALAR}.pxi:268-290, SSS_LinearOperator_{SCALAR}.pxi:273-293): same datasets and attributes, the operator
+    read back applies like the one written"""
+    from pynucleus_amd import uniformSquare, disc, P1_DoFMap, PHYSICAL, NO_BOUNDARY, getFractionalKernel, getKernel, INDICATOR
+    from pynucleus_amd.builder import nonlocalBuilder
+    from pynucleus_amd.linear_operators import Dense_LinearOperator, CSR_LinearOperator
+    rng = np.random.default_rng(0)
+    b = nonlocalBuilder(P1_DoFMap(disc(2), PHYSICAL), getFractionalKernel(2, 0.5), {})
+    A = b.getDense()
+    g = _Group()
+    A.HDF5write(g)
+    assert g.attrs['type'] == 'dense' and g['data'].shape == A.shape
+    A2 = Dense_LinearOperator.HDF5read(g, b.context())
+    x = rng.standard_normal(A.num_rows)
+    assert np.abs(A2*x-A*x).max() == 0.
+    dm = P1_DoFMap(uniformSquare(17), NO_BOUNDARY)
+    for params in ({}, {'forceUnsymmetric': True}):                 # SSS (default) and CSR
+        bs = nonlocalBuilder(dm, getKernel(2, kernel=INDICATOR, horizon=0.2), params, zeroExterior=False)
+        S = bs.getSparse()
+        g = _Group()
+        S.HDF5write(g)
+        assert g.attrs['type'] in ('csr', 'sss') and set(g) >= {'indices', 'indptr', 'data'}
+        S2 = CSR_LinearOperator.HDF5read(g, bs.context())
+        assert type(S2) is type(S)
+        x = rng.standard_normal(S.num_rows)
+        assert np.abs(S2*x-S*x).max() <= 1e-14*np.abs(S*x).max()
+        assert np.abs(S2.toarray()-S.toarray()).max() == 0.
