@@ -299,7 +299,11 @@ class nonlocalBuilder:
         pairs inside the support of phi_I plus the Gauss-theorem term over the boundary of the support.  One masked
         assembly on the GPU into a diagonal-only SSS pattern; returns the diagonal as a numpy vector wrapped like the
         reference's diagonalOperator (``.data``, ``.diagonal``)."""
-        self._symmetric_only('getDiagonal')
+        if getattr(self.tables, 'pointwise', False):
+            # order per quadrature point: the cluster path is not built for these kernels; the diagonal of the dense operator
+            # (assembled on the device, O(N^2) work instead of the reference's O(N))
+            from .linear_operators import diagonalOperator
+            return diagonalOperator(self.getDense().diagonal)
         if self._single_order_twin() is not None:
             return self._single_order_twin().getDiagonal()
         from . import clusters
@@ -311,7 +315,11 @@ class nonlocalBuilder:
     def getEntry(self, I, J):
         """NA:1538-1661: the entry A[I, J] alone: element pairs of (supp phi_I u supp phi_J)^2 and, with zeroExterior,
         the Gauss-theorem term over the boundary of that union, assembled on the GPU into a one-entry pattern."""
-        self._symmetric_only('getEntry')
+        if getattr(self.tables, 'pointwise', False):
+            # as getDiagonal: from the dense operator on the device
+            A = self.getDense()
+            A.ctx.synchronize()
+            return float(A.A[int(I), int(J)].item())
         if self._single_order_twin() is not None:
             return self._single_order_twin().getEntry(I, J)
         import torch

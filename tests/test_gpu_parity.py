@@ -207,6 +207,11 @@ def test_pointwise_nonsymmetric_dense(case):
         assert np.abs(Aref-Aref.T).max() > 1e-6*scale          # genuinely non-symmetric
     if case == 'smoothedLeftRight_disc4':
         assert got['uniformTilePairs'] > 0
+    if case == 'smoothedLeftRight_disc':
+        # getDiagonal / getEntry of these kernels come from the dense device path
+        d = b.getDiagonal()
+        assert np.abs(np.asarray(d.diagonal)-np.diag(Aref)).max() < TOL*scale
+        assert abs(b.getEntry(3, 11)-Aref[3, 11]) < TOL*scale and abs(b.getEntry(11, 3)-Aref[11, 3]) < TOL*scale
 
 
 def test_pointwise_stored_errors_disc():
