@@ -433,7 +433,7 @@ int launch_pure(pnl_context *ctx, double *A, int64_t ldA, const SlotOut &SO) {
     if (ctx->n_pure == 0) return PNL_OK;
     constexpr int NP = DIM == 2 ? 3 : 2, ND = DPE*(DPE+1)/2;
     const int acc_stride = acc_stride_of(ctx->nU);
-    const size_t lds = sizeof(double)*(64*NP*DIM+64+2*64*ND+NP*(4+DPE)+PNL_POW_TAB_DOUBLES)+sizeof(int)*(64*DPE+64)
+    const size_t lds = sizeof(double)*(64*NP*DIM+64+2*64*ND+NP*(4+DPE)+(KT == 0 ? PNL_POW_TAB_DOUBLES : 0))+sizeof(int)*(64*DPE+64)
                        +sizeof(double)*(size_t)(ctx->nU+1)*acc_stride;
     auto kfun = k_tile_pure<DIM, DPE, KT>;
     HIPCHK(ctx, hipFuncSetAttribute((const void*)kfun, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -544,7 +544,7 @@ int ensure_worklist(pnl_context *ctx, double pairs, int regions) {
 
 template <int DIM, int DPE, int TILE, int KT>
 int launch_tiles(pnl_context *ctx, int wl_slot, double *A, int64_t ldA, int cell_begin, int cell_end, const SlotOut &SO = SlotOut{}) {
-    using S = TileSmem<DIM, DPE, TILE>;
+    using S = TileSmem<DIM, DPE, TILE, KT == 0>;
     HIPCHK(ctx, hipEventRecord(ctx->ev[7], ctx->stream));
     ctx->pure_launched = false;
     if (TILE == 64 && DPE <= 3) {
@@ -1064,7 +1064,7 @@ template <int DIM, int DPE, int TILE, int KT>
 int clusters_tiled_impl(pnl_context *ctx, const pnl_cluster_plan *pl, ClusterTiles CT, int cluster_boundary, const int *d_cell,
                         const int *d_pair, const int2 *sing_dev[3], const int *sing_pair_dev[3], const int *pair_foff, const int *fvid,
                         const double *fgeo, int maxf, const int *bt_cell, const int *bt_facet, const unsigned *bt_slot) {
-    using S = TileSmem<DIM, DPE, TILE>;
+    using S = TileSmem<DIM, DPE, TILE, KT == 0>;
     constexpr int ND = DPE*(DPE+1)/2;
     int rc;
     const int acc_stride = pl->chunk_stride+1;
@@ -1559,7 +1559,7 @@ int horizon_impl(pnl_context *ctx, SparseOut S) {
     // without a packed rule -- it hands to the sorted sparse pipeline through the far list.  PNL_FH_NOTILES=1 keeps the
     // pair generator k_fh_pairs, which sends every pair down that pipeline.
     constexpr int TILE = (DPE == 6 || (DIM == 1 && DPE == 3)) ? 32 : 64, ND = DPE*(DPE+1)/2;
-    using TS = TileSmem<DIM, DPE, TILE>;
+    using TS = TileSmem<DIM, DPE, TILE, KT == 0>;
     const int acc_stride = acc_stride_of(ctx->nU, TS::fixed_bytes);
     const size_t lds = TS::fixed_bytes+sizeof(double)*(size_t)(ctx->nU+1)*acc_stride;
     const bool use_tiles = T == TILE && lds <= 160*1024 && !getenv("PNL_FH_NOTILES");

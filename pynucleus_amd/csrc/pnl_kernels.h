@@ -313,7 +313,7 @@ __device__ __forceinline__ bool pair_has(const ClusterTiles &CT, int k, int I, i
 #ifndef PNL_DIAG_MULT
 #define PNL_DIAG_MULT 21
 #endif
-template <int DIM, int DPE, int TILE>
+template <int DIM, int DPE, int TILE, bool POW = false>
 struct TileSmem {
     static constexpr int NV = DIM+1, NC = NV*DIM, ND = DPE*(DPE+1)/2;
     // doubles
@@ -324,8 +324,8 @@ struct TileSmem {
     static constexpr int o_D = o_h+2*TILE;                 // [2][TILE][ND]
     static constexpr int o_Ld = o_D+2*TILE*ND;             // [2][TILE] |ln(h/H0)| in fp64
     static constexpr int o_tt = o_Ld+2*TILE;               // [PNL_TT_MAXPTS][4+DPE] rules integrated one pair per lane
-    static constexpr int o_pow = o_tt+PNL_TT_MAXPTS*(4+DPE);   // [PNL_POW_TAB_DOUBLES] tables of the general power (pnl_pow_tab)
-    static constexpr int n_dbl = o_pow+PNL_POW_TAB_DOUBLES;
+    static constexpr int o_pow = o_tt+PNL_TT_MAXPTS*(4+DPE);   // [PNL_POW_TAB_DOUBLES] tables of the general power (POW: KT == 0 only)
+    static constexpr int n_dbl = o_pow+(POW ? PNL_POW_TAB_DOUBLES : 0);
     // ints after the doubles
     static constexpr int o_vid = 0;                        // [2][NV][TILE]
     static constexpr int o_cnt = o_vid+2*NV*TILE;          // [PNL_MAXQ+2]
@@ -420,7 +420,7 @@ k_tile_distant(const DevProblem P, const int2 *__restrict__ tiles, double *__res
 #else
     const int abl = ablate & 256;
 #endif
-    using S = TileSmem<DIM, DPE, TILE>;
+    using S = TileSmem<DIM, DPE, TILE, KT == 0>;
     constexpr int NV = S::NV, NC = S::NC, ND = S::ND, NT = tile_threads(DPE, KT, FH);
     constexpr int PAIRS = TILE*TILE, PER_THREAD = (PAIRS+NT-1)/NT;
     extern __shared__ double smem[];
@@ -930,7 +930,7 @@ k_tile_pure(const DevProblem P, const int2 *__restrict__ tiles, int ntiles, doub
     double *s_Db = s_Da+TILE*ND;                        // [TILE][ND]
     double *s_rule = s_Db+TILE*ND;                      // [NP][ST]
     double *s_pow = s_rule+NP*ST;                       // tables of the general power (KT == 0, pnl_pow_tab)
-    int *s_slotb = (int*)(s_pow+PNL_POW_TAB_DOUBLES);   // [TILE][DPE] (+ [TILE] has-DoF flags)
+    int *s_slotb = (int*)(s_pow+(KT == 0 ? PNL_POW_TAB_DOUBLES : 0));   // [TILE][DPE] (+ [TILE] has-DoF flags)
     int *s_hb = s_slotb+TILE*DPE;
     double *s_acc = (double*)(s_hb+TILE);               // [nA+1][acc_stride]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
