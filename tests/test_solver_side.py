@@ -113,6 +113,36 @@ def test_oracle_heat_reproduces_the_stored_errors(s, problem):
     assert max(its) <= 8                                      # multigrid-preconditioned CG: mesh-independent iteration counts
 
 
+@pytest.mark.parametrize('s,stored_norm,rtol', [(0.25, 1.7019259587916384, 1e-5), (0.75, 0.9832074391209417, 1e-6)])
+def test_oracle_heat_P2_norm(s, stored_norm, rtol):
+    """runFractionalHeat --domain interval --element P2 --solver cg-mg --matrixFormat dense (noRef 5, dt = 1/6): the P2 hierarchy
+    (transfer weights of restriction_1D_P2.pxi) through the same time stepper reproduces the stored L2(0,T;L2) NORM; the stored
+    error norms (0.0124 / 0.00044) are not reproduced (0.0139 / 0.00074 here: they hinge on the quadrature of the boundary-
+    singular load, which that run takes from a rule this container does not have) -- those stay unpinned for P2"""
+    levels = oracle_hierarchy('interval', 5, s, {'target_order': 2.-s}, mass=True, element='P2')
+    L = levels[-1]
+    uss, load, z_ss, L2ex2 = heat_setup(levels, s, 'constant')
+    dt, nt = SO.heat_time_steps(L['mesh'].h)
+    assert nt == 6
+    trans = [dict(K, A=K['M']/dt+0.5*K['A']) for K in levels]
+    mg = SO.Multigrid(trans)
+    times = np.linspace(0., 1., nt+1)
+    u = np.asarray(L['DoFMap'].interpolate(uss), dtype=float)
+    us, its = [u.copy()], []
+    for k in range(nt):
+        forcing = 0.5*load(times[k])+0.5*load(times[k+1])
+
+        def solve(rhs, x0):
+            x, it, _ = SO.cg(trans[-1]['A'], rhs, x0=x0, tol=1e-10, maxiter=100, B=mg.precondition)
+            its.append(it)
+            return x
+        u = SO.theta_step(L['A'], L['M'], dt, 0.5, forcing, u, solve)
+        us.append(u.copy())
+    norm = SO.transient_errors(us, times, L['M'], lambda t: np.cos(t)*z_ss, lambda t: np.cos(t)**2*L2ex2)[2]
+    assert abs(norm-stored_norm) <= rtol*stored_norm, norm
+    assert max(its) <= 12
+
+
 def test_oracle_multigrid_is_a_solver_for_the_stored_steady_run():
     """runFractional --domain interval --s const(0.25) --solver cg-mg --matrixFormat dense: the multigrid-preconditioned CG
     reaches the solution whose Hs error the reference stores (0.09611243700804001), in a handful of iterations; the
