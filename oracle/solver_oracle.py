@@ -248,3 +248,31 @@ def gmres(A, b, x0=None, tol=1e-8, maxiter=50, restarts=1, B=None, left=True):
         upd = y[:i+1]@Q[:i+1]
         x += R(upd) if R is not None else upd
     return x, allIter, residuals
+
+
+def bicgstab(A, b, x0=None, tol=1e-8, maxiter=50, B=None):
+    """bicgstab_solver.solve (base/PyNucleus_base/solvers.pyx:716-787), dense numpy"""
+    x = np.zeros_like(b) if x0 is None else x0.copy()
+    r = b.copy() if x0 is None else b-A@x
+    p = r.copy()
+    r0 = B(r) if B is not None else r.copy()
+    kappa = r@r0
+    residuals = [np.sqrt(abs(kappa))]
+    for k in range(maxiter):
+        p2 = B(p) if B is not None else p
+        temp = A@p2
+        alpha = kappa/(temp@r0)
+        s = r-alpha*temp
+        s2 = B(s) if B is not None else s
+        temp2 = A@s2
+        omega = (temp2@s)/(temp2@temp2)
+        x = x+alpha*p2+omega*s2
+        r = s-omega*temp2
+        residuals.append(np.linalg.norm(r))
+        if residuals[-1] < tol:
+            return x, k, residuals
+        kappaNew = r@r0
+        beta = kappaNew/kappa*alpha/omega
+        kappa = kappaNew
+        p = r+beta*(p-omega*temp)
+    return x, maxiter, residuals

@@ -163,3 +163,51 @@ def gmres(A, b, x0=None, tol=1e-8, maxiter=50, restarts=1, preconditioner=None, 
     if isinstance(b, torch.Tensor):
         return x, allIter, residuals
     return x.cpu().numpy(), allIter, residuals
+
+
+def bicgstab(A, b, x0=None, tol=1e-8, maxiter=50, preconditioner=None):
+    """bicgstab_solver.solve (solvers.pyx:716-787): right-preconditioned stabilised BiCG, r0 = B r, stopping on the 2-norm of
+    the residual.  Returns (x, iterations, residuals)."""
+    import torch
+    device = getattr(A, 'device', None)
+    if device is None:
+        device = A.A.device if hasattr(A, 'A') else torch.device('cuda', torch.cuda.current_device())
+    bd = _dev_vector(b, device)
+    x = torch.zeros_like(bd) if x0 is None else _dev_vector(x0, device).clone()
+    B = None
+    if preconditioner == 'jacobi':
+        d = A.diagonal
+        d = d() if callable(d) else d
+        dinv = 1./_dev_vector(d, device)
+        B = lambda r: dinv*r                                   # noqa: E731
+    elif callable(preconditioner):
+        B = preconditioner
+    elif preconditioner is not None:
+        raise NotImplementedError(preconditioner)
+    r = bd.clone() if x0 is None else bd-A.matvec(x)
+    p = r.clone()
+    r0 = B(r).clone() if B is not None else r.clone()
+    kappa = float(torch.dot(r, r0))
+    residuals = [float(np.sqrt(abs(kappa)))]
+    its = maxiter
+    for k in range(maxiter):
+        p2 = B(p) if B is not None else p
+        temp = A.matvec(p2.contiguous())
+        alpha = kappa/float(torch.dot(temp, r0))
+        s_ = r-alpha*temp
+        s2 = B(s_) if B is not None else s_
+        temp2 = A.matvec(s2.contiguous())
+        omega = float(torch.dot(temp2, s_))/float(torch.dot(temp2, temp2))
+        x = x+alpha*p2+omega*s2
+        r = s_-omega*temp2
+        residuals.append(float(torch.linalg.norm(r)))
+        if residuals[-1] < tol:
+            its = k
+            break
+        kappaNew = float(torch.dot(r, r0))
+        beta = kappaNew/kappa*alpha/omega
+        kappa = kappaNew
+        p = r+beta*(p-omega*temp)
+    if isinstance(b, torch.Tensor):
+        return x, its, residuals
+    return x.cpu().numpy(), its, residuals

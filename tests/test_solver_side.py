@@ -419,6 +419,9 @@ def test_oracle_gmres_jacobi_reproduces_the_stored_nonsymmetric_run():
     # right preconditioning and restarts reach the same solution
     x2 = SO.gmres(A, b, tol=1e-10, maxiter=20, restarts=20, B=lambda r: dinv*r, left=False)[0]
     assert np.abs(x2-x).max() <= 1e-7*np.abs(x).max()
+    # BiCGStab (bicgstab_solver) on the same system
+    x3, it3, res3 = SO.bicgstab(A, b, tol=1e-10, maxiter=200, B=lambda r: dinv*r)
+    assert it3 < 200 and np.abs(x3-x).max() <= 1e-7*np.abs(x).max()
 
 
 @pytest.mark.gpu
@@ -448,6 +451,12 @@ def test_gpu_gmres_on_a_nonsymmetric_operator_against_the_oracle(order):
         C = 2.**(-2.*s)*gamma(0.5)/gamma((1+2.*s)/2.)/gamma(1.+s)
         hs = np.sqrt(abs(b@x-C*np.sqrt(np.pi)*gamma(s+1)/gamma(s+3/2)))
         assert abs(hs-0.09611243700814974) <= 1e-8*0.09611243700814974, hs
+    # BiCGStab with the Jacobi preconditioner: the oracle's iteration
+    from pynucleus_amd.solvers import bicgstab
+    xb, itb, resb = bicgstab(Aop, b, tol=1e-10, maxiter=200, preconditioner='jacobi')
+    xbo, itbo, resbo = SO.bicgstab(A, b, tol=1e-10, maxiter=200, B=lambda r: dinv*r)
+    assert abs(itb-itbo) <= 1 and itb < 200 and np.abs(xb-xbo).max() <= 1e-7*np.abs(xbo).max()
+    assert np.abs(A@xb-b).max() <= 1e-7*np.abs(b).max()
     # gmres-mg: the V cycle of the hierarchy as preconditioner, far fewer iterations
     mg = multigrid(H)
     xm, itm, resm = gmres(Aop, b, tol=1e-10, maxiter=120, preconditioner=mg.asPreconditioner())
