@@ -209,6 +209,29 @@ def extra_configs(dev):
             r.update(near_field_element_pairs=c['numAssembledCellPairs'], near_field_device_ms=near.info['interior_ms'],
                      near_field_nnz=near.nnz, pairs_per_s=c['numAssembledCellPairs']/dev_s, algorithmic_tflops=fl/dev_s/1e12,
                      frac_fp64_peak=fl/dev_s/1e12/FP64_VECTOR_PEAK_TFLOPS)
+        # the solve of that configuration: (-Laplace)^s u = 1 with the H2 operator, Jacobi-CG against multigrid-preconditioned CG
+        # (H2 operator on the finest level, dense operators below: the operator-agnostic cycle of pynucleus_amd/multigrid.py)
+        try:
+            from pynucleus_amd.solvers import cg as _cg
+            from pynucleus_amd.multigrid import fractionalHierarchy, multigrid
+            bb = torch.from_numpy(np.asarray(dm.assembleRHS(1.0))).to(dev)
+            _cg(h2, bb, tol=1e-8, maxiter=5)
+            sync(); t0 = time.perf_counter()
+            xj, itj, _ = _cg(h2, bb, tol=1e-8, maxiter=2000)
+            sync(); tj = time.perf_counter()-t0
+            sync(); t0 = time.perf_counter()
+            Hh = fractionalHierarchy('disc', 7, getFractionalKernel(2, 0.75), {'target_order': 0.5, 'eta': 3.}, matrixFormat='H2', h2MinDoFs=20000)
+            mgh = multigrid(Hh)
+            sync(); th = time.perf_counter()-t0
+            mgh.cg(bb, tol=1e-8, maxiter=3)
+            sync(); t0 = time.perf_counter()
+            xm, itm, _ = mgh.cg(bb, tol=1e-8)
+            sync(); tm = time.perf_counter()-t0
+            r.update(solve_cg_jacobi_iterations=itj, solve_cg_jacobi_ms=1e3*tj, solve_cg_mg_iterations=itm, solve_cg_mg_ms=1e3*tm,
+                     solve_hierarchy_s=th, solve_difference=float(torch.linalg.norm(xm-xj)/torch.linalg.norm(xj)))
+            del Hh, mgh
+        except Exception as e:
+            r['solve_error'] = repr(e)
         res['C4_disc_noRef7_s0.75_H2'] = r
     # the north star's "~10^5 DoFs on 1 MI355X": 12-sector fan refined 7 times, P1, dense (76 GB block)
     def big():
