@@ -496,3 +496,43 @@ def test_operator_files_round_trip():
         x = rng.standard_normal(S.num_rows)
         assert np.abs(S2*x-S*x).max() <= 1e-14*np.abs(S*x).max()
         assert np.abs(S2.toarray()-S.toarray()).max() == 0.
+
+
+def test_general_exponent_at_scale_properties():
+    """s = 0.4 (no rsqrt shortcut: the table-driven power of the tile kernels, pnl_pow_tab) at 24,576 cells / 12,097 DoFs: symmetry,
+    two cell-range shards adding up to the operator, the energy of the driver problem below the exact value and converging, and
+    the tile kernels' power against the L1-table path (PNL_NO_POWTAB) entry by entry"""
+    import os
+    import torch
+    from math import gamma, pi
+    s = 0.4
+    b = _build('disc', 6, s, params={'target_order': 0.5})
+    N, nc = b.dm.num_dofs, b.mesh.num_cells
+    A = b.getDense()
+    cnt = A.info['counters']
+    assert cnt['numCellPairs'] == nc*(nc+1)//2
+    M = A.A
+    scale = float(M.abs().max())
+    assert float((M-M.T).abs().max()) <= 1e-13*scale
+    ctx = b.context()
+    P = torch.zeros((N, N), dtype=torch.float64, device='cuda')
+    half = nc//2+17
+    ctx.assemble_dense(P.data_ptr(), N, True, 0, half, 2)
+    ctx.assemble_dense(P.data_ptr(), N, True, half, nc, 2)
+    ctx.synchronize()
+    assert float((P-M).abs().max()) <= 1e-12*scale
+    del P
+    rhs = np.asarray(b.dm.assembleRHS(1.0))
+    u, its, res = A.solve_cg_jacobi(rhs, tol=1e-10, maxiter=800)
+    exact = 2.**(-2.*s)*gamma(1.)/gamma(1.+s)**2*pi/(s+1.)
+    energy = float(rhs@u)
+    assert 0. < exact-energy < 1e-2*exact, (energy, exact)
+    # the same operator with exp(e ln x) from the __constant__ tables
+    os.environ['PNL_NO_POWTAB'] = '1'
+    try:
+        b2 = _build('disc', 6, s, params={'target_order': 0.5})
+        A2 = b2.getDense()
+        assert A2.info['counters']['numIntegrations'] == cnt['numIntegrations']
+        assert float((A2.A-M).abs().max()) <= 1e-13*scale
+    finally:
+        del os.environ['PNL_NO_POWTAB']
