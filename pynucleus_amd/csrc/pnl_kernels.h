@@ -405,8 +405,14 @@ __device__ __forceinline__ unsigned eval_distant_cut(const DevProblem &P, const 
 // hence 256 threads per workgroup there; the general-exponent kernel (KT = 0: exp / log chains) spills at 128 VGPRs (57 ms against
 // 31 ms at noRef 6, s = 0.4) and keeps 256 threads x 2 waves as well
 // (the finite-horizon variant carries the sub-simplex loops of the cut pairs: 256 threads x 2 waves as well)
-__host__ __device__ constexpr int tile_threads(int dpe, int kt, bool fh = false) { return (dpe > 3 || kt == 0 || fh) ? 256 : PNL_TILE_THREADS; }
-__host__ __device__ constexpr int tile_waves(int dpe, int kt, bool fh = false) { return dpe > 3 ? 1 : ((kt == 0 || fh) ? 2 : PNL_TILE_WAVES); }
+// general exponent (KT == 0): 256 threads x 2 waves per SIMD while exp(e ln x) needed the registers (57 against 31 ms at 128
+// VGPRs); with the table-driven power (pnl_pow_tab) the 512 x 4 configuration of the other kernels is faster again (P1, s = 0.4,
+// 98,304 cells: 46.5 -> 35.6 ms).  -DPNL_KT0_WIDE=0 restores the narrow one.
+#ifndef PNL_KT0_WIDE
+#define PNL_KT0_WIDE 1
+#endif
+__host__ __device__ constexpr int tile_threads(int dpe, int kt, bool fh = false) { return (dpe > 3 || (kt == 0 && !PNL_KT0_WIDE) || fh) ? 256 : PNL_TILE_THREADS; }
+__host__ __device__ constexpr int tile_waves(int dpe, int kt, bool fh = false) { return dpe > 3 ? 1 : (((kt == 0 && !PNL_KT0_WIDE) || fh) ? 2 : PNL_TILE_WAVES); }
 template <int DIM, int DPE, int TILE, int KT, bool CLUSTER, bool FH = false>
 __global__ void __launch_bounds__(tile_threads(DPE, KT, FH), tile_waves(DPE, KT, FH))
 k_tile_distant(const DevProblem P, const int2 *__restrict__ tiles, double *__restrict__ A, long long ldA,

@@ -22,8 +22,15 @@ int launch_uniform_t(pnl_context *ctx, const DevProblem &Pt, const int2 *tiles, 
     // general exponent: the tables of pnl_pow_tab behind the sub-block, unless they cost the second workgroup per CU
     int pow_flag = 0;
     if (KT == 0) {
-        const size_t with = lds+sizeof(double)*PNL_POW_TAB_DOUBLES;
-        if (with <= 160*1024 && std::min<size_t>(2, (160*1024)/with) == std::min<size_t>(2, (160*1024)/lds)) { lds = with; pow_flag = 8; }
+        const size_t tab = sizeof(double)*PNL_POW_TAB_DOUBLES;
+        const size_t per_cu0 = std::min<size_t>(2, (160*1024)/lds);
+        if (lds+tab <= 160*1024 && std::min<size_t>(2, (160*1024)/(lds+tab)) == per_cu0) { lds += tab; pow_flag = 8; }
+        else if (!getenv("PNL_UNI_KEEP_STRIDE")) {
+            // the padded row stride of the sub-block (fewer LDS bank conflicts) or the tables: the tables win (measured)
+            const int odd = (nUe+1) | 1;
+            const size_t alt = fixed+sizeof(double)*(size_t)(nUe+1)*odd+tab;
+            if (alt <= 160*1024 && std::min<size_t>(2, (160*1024)/alt) == per_cu0) { acc_stride = odd; lds = alt; pow_flag = 8; }
+        }
     }
     auto kfun = k_tile_uniform<DPE, NP, KT>;
     HIPCHK(ctx, hipFuncSetAttribute((const void*)kfun, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
