@@ -413,7 +413,7 @@ def main():
 
     # ---- roofline of the dominant kernel: algorithmic flops / its own event-timed duration --------------------------
     # Distant pairs of the orders packed into the tile rule table (<= 16 points) are integrated by the tile kernels: the
-    # uniform-tile kernels (tiles whose pairs are all of order 2: k_tile_pure; all of order 3 / 4: k_tile_uniform) and the
+    # uniform-tile kernels (tiles whose pairs are all of order 2: k_tile_uniform<3,3>; all of order 3 / 4: k_tile_uniform<3,6>) and the
     # general one (k_tile_distant: every other tile).  The counters tell how many pairs of each order the uniform kernels
     # took; the rest of the histogram belongs to the general kernel.
     T = builder.tables
@@ -421,7 +421,7 @@ def main():
     uni = cnt.get('uniformTilePairsByOrder', {})
     mixed_orders = {q: c-uni.get(q, 0) for q, c in tile_orders.items()}
     kernels = {'k_tile_distant': (algorithmic_flops(mixed_orders, T.num_points), 1e-3*kacc.get('tile_general', 0.)),
-               'k_tile_pure': (algorithmic_flops({2: uni.get(2, 0)}, T.num_points), 1e-3*kacc.get('tile_uniform2', 0.)),
+               'k_tile_uniform<3,3> (order 2)': (algorithmic_flops({2: uni.get(2, 0)}, T.num_points), 1e-3*kacc.get('tile_uniform2', 0.)),
                'k_tile_uniform<3,6> (order 3)': (algorithmic_flops({3: uni.get(3, 0)}, T.num_points), 1e-3*kacc.get('tile_uniform3', 0.)),
                'k_tile_uniform<3,6> (order 4)': (algorithmic_flops({4: uni.get(4, 0)}, T.num_points), 1e-3*kacc.get('tile_uniform4', 0.))}
     dominant = max(kernels, key=lambda k: kernels[k][1])
@@ -441,7 +441,10 @@ def main():
             rec = json.load(f)
         key = 'noRef{}{}'.format(args.noRef, '' if args.sectors == 6 else '_s{}'.format(args.sectors))
         if key in rec and rec[key].get('src_sha16') == src_sha:
-            traffic = rec[key].get(dominant.split('<')[0].split(' ')[0]+'_hbm_bytes_per_launch')
+            # record keys: k_tile_distant, k_tile_uniform_3_3 (order 2), k_tile_uniform_3_6 (orders 3 and 4), k_fold_mirror
+            tkey = {'k_tile_distant': 'k_tile_distant', 'k_tile_uniform<3,3> (order 2)': 'k_tile_uniform_3_3',
+                    'k_tile_uniform<3,6> (order 3)': 'k_tile_uniform_3_6', 'k_tile_uniform<3,6> (order 4)': 'k_tile_uniform_3_6'}[dominant]
+            traffic = rec[key].get(tkey+'_hbm_bytes_per_launch')
             traffic_note = 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command ({}), FETCH_SIZE doubled per MI355X_MICROARCH.md'.format(rec[key].get('tag'))
     # HBM view of the same launches: the algorithmic minimum is one write of the upper block triangle they fill
     hbm_alg_bytes = 8.*N*N/2

@@ -20,24 +20,37 @@ int launch_uniform_t(pnl_context *ctx, const DevProblem &Pt, const int2 *tiles, 
     if (lds > 160*1024)
         return fail(ctx, PNL_ERR_UNSUPPORTED, "a block of %d cells touches %d DoFs: LDS sub-block of %zu bytes exceeds 160 KiB", TILE, ctx->nU, lds);
     // general exponent: the tables of pnl_pow_tab behind the sub-block, unless they cost the second workgroup per CU
-    // P1: 138-168 VGPRs allow three waves per SIMD and three 50 KB workgroups share a CU (order-3 tiles of a general exponent
-    // 36.4 -> 28.8 ms at 98,304 cells, s = 1/2: 17.8 -> 17.2); P2: two workgroups of 80 KB
-    const size_t cap_cu = (size_t)std::max(1, getenv("PNL_UNI_PER_CU") ? atoi(getenv("PNL_UNI_PER_CU")) : 3);
+    // P1: 108-168 VGPRs allow three or four waves per SIMD and as many 38-53 KB workgroups share a CU (order-3 tiles of a general
+    // exponent 36.4 -> 28.8 ms at 98,304 cells, s = 1/2: 17.8 -> 17.2; order-2 tiles of s = 1/2 with four: 42.8 -> 41.3 ms);
+    // P2: two workgroups of 80 KB
+    const size_t cap_cu = (size_t)std::max(1, getenv("PNL_UNI_PER_CU") ? atoi(getenv("PNL_UNI_PER_CU")) : 4);
+    auto kfun = k_tile_uniform<DPE, NP, KT>;
+    HIPCHK(ctx, hipFuncSetAttribute((const void*)kfun, hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::min<size_t>(160*1024, lds+sizeof(double)*PNL_POW_TAB_DOUBLES)));
+    // workgroups that are really resident per CU (LDS and registers): the tile loop strides by the grid, a workgroup that has
+    // to wait for a slot would start its share of the tiles late
+    auto resident = [&](size_t bytes) -> int {
+        int occ = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)kfun, 256, bytes) != hipSuccess || occ < 1) {
+            (void)hipGetLastError();
+            occ = (int)std::min<size_t>(2, (160*1024)/bytes);
+        }
+        return std::max(1, std::min((int)cap_cu, occ));
+    };
     int pow_flag = 0;
     if (KT == 0) {
+        // general exponent: the tables of pnl_pow_tab behind the sub-block, unless they cost a resident workgroup
         const size_t tab = sizeof(double)*PNL_POW_TAB_DOUBLES;
-        const size_t per_cu0 = std::min<size_t>(cap_cu, (160*1024)/lds);
-        if (lds+tab <= 160*1024 && std::min<size_t>(cap_cu, (160*1024)/(lds+tab)) == per_cu0) { lds += tab; pow_flag = 8; }
+        const int per_cu0 = resident(lds);
+        if (lds+tab <= 160*1024 && resident(lds+tab) == per_cu0) { lds += tab; pow_flag = 8; }
         else if (!getenv("PNL_UNI_KEEP_STRIDE")) {
             // the padded row stride of the sub-block (fewer LDS bank conflicts) or the tables: the tables win (measured)
             const int odd = (nUe+1) | 1;
             const size_t alt = fixed+sizeof(double)*(size_t)(nUe+1)*odd+tab;
-            if (alt <= 160*1024 && std::min<size_t>(cap_cu, (160*1024)/alt) == per_cu0) { acc_stride = odd; lds = alt; pow_flag = 8; }
+            if (alt <= 160*1024 && resident(alt) == per_cu0) { acc_stride = odd; lds = alt; pow_flag = 8; }
         }
     }
-    auto kfun = k_tile_uniform<DPE, NP, KT>;
     HIPCHK(ctx, hipFuncSetAttribute((const void*)kfun, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    const int per_cu = std::max(1, std::min((int)cap_cu, (int)((160*1024)/lds)));
+    const int per_cu = resident(lds);
     const int grid = std::min(ntiles, 256*per_cu);
     if (getenv("PNL_VERBOSE"))
         fprintf(stderr, "[pnl] uniform tiles of order %d: %d, dpe=%d np=%d kt=%d lds=%zu bytes (%d per CU), acc_stride=%d\n", q, ntiles, DPE,

@@ -30,7 +30,13 @@ def newest(pattern):
 
 
 def short(name):
-    n = name.split('(')[0].split('<')[0].split()[-1]
+    head = name.split('(')[0]
+    n = head.split('<')[0].split()[-1]
+    if n == 'k_tile_uniform' and '<' in head:
+        # the instantiations are different kernels of the step: <DPE, NP, KT> -> k_tile_uniform_<DPE>_<NP>
+        args = [a.strip() for a in head.split('<', 1)[1].rstrip('>').split(',')]
+        if len(args) >= 2:
+            return 'k_tile_uniform_{}_{}'.format(args[0], args[1])
     return n
 
 
@@ -65,7 +71,7 @@ with open(os.path.join(root, 'pynucleus_amd', 'libpnl_hip.so'), 'rb') as f:
 sys.path.insert(0, root)
 from pynucleus_amd._lib import source_sha16
 entry = {'tag': tag, 'lib_sha16': lib_sha, 'src_sha16': source_sha16()}
-for k in ('k_tile_distant', 'k_tile_pure', 'k_tile_uniform', 'k_tile_p2', 'k_fold_mirror'):
+for k in ('k_tile_distant', 'k_tile_pure', 'k_tile_uniform_3_3', 'k_tile_uniform_3_6', 'k_tile_uniform_6_3', 'k_tile_uniform_6_6', 'k_tile_p2', 'k_fold_mirror'):
     if k in summary and 'FETCH_SIZE' in summary[k] and 'WRITE_SIZE' in summary[k]:
         # FETCH_SIZE x 2 for the tile kernels (their known input volume, ~13 KB of cell data per tile, matches the doubled value);
         # the fold pass reads every stored entry of the block-slot storage exactly once with 8-byte gathers -- a known byte count
