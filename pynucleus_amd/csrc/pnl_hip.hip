@@ -1107,6 +1107,17 @@ int clusters_tiled_impl(pnl_context *ctx, const pnl_cluster_plan *pl, ClusterTil
         HIPCHK(ctx, hipGetLastError());
     }
     HIPCHK(ctx, hipEventRecord(ctx->ev[6], ctx->stream));
+    // behind the tile kernel everything only adds (sparse data, diagonal-block buffer) with atomics: the touching pairs run on side
+    // stream 0 and the cluster-local boundary term on side stream 1 next to the work-list kernels; joined before the diagonal
+    // blocks are scattered.  The phase timers then show what is left of them after the work list
+    hipStream_t const main_stream = ctx->stream;
+    const bool overlap = !getenv("PNL_NO_OVERLAP");
+    struct StreamGuard { pnl_context *c; hipStream_t s; ~StreamGuard() { c->stream = s; } } stream_guard{ctx, main_stream};
+    if (overlap) {
+        HIPCHK(ctx, hipEventRecord(ctx->ev_fold, main_stream));
+        HIPCHK(ctx, hipStreamWaitEvent(ctx->aux[0], ctx->ev_fold, 0));
+        HIPCHK(ctx, hipStreamWaitEvent(ctx->aux[1], ctx->ev_fold, 0));
+    }
     {
         if ((rc = ensure(ctx, ctx->b_wlsorted, (size_t)ctx->wl_cap*sizeof(int4)))) return rc;
         if ((rc = ensure(ctx, ctx->b_wlaux, sizeof(unsigned)*(4*(PNL_WL_BINS+1))))) return rc;
@@ -1119,13 +1130,16 @@ int clusters_tiled_impl(pnl_context *ctx, const pnl_cluster_plan *pl, ClusterTil
         hipLaunchKernelGGL(k_wl_scatter, dim3(512), dim3(PNL_NTHREADS), 0, ctx->stream, wl, wlc, ctx->wl_cap, (const unsigned*)offs, cursor,
                            (int4*)ctx->b_wlsorted.p);
         const int st = 4+DPE;
-        const int tab_max = (60*1024)/(st*(int)sizeof(double));
+        // LDS copy of the rule: see run_worklist (PNL_WL_CL_KB: A/B switch of the cluster path)
+        const int wl_kb = getenv("PNL_WL_CL_KB") ? std::max(4, atoi(getenv("PNL_WL_CL_KB"))) : 18;      // 60 KB / two workgroups per CU: + 4 ms at C4
+        const int tab_max = (wl_kb*1024)/(st*(int)sizeof(double));
         const size_t wlds = (size_t)tab_max*st*sizeof(double);
+        const int wl_grid = 256*std::max(1, std::min(8, 150/(wl_kb+(KT == 0 ? 3 : 0))));
         auto wfun = k_worklist_sorted<DIM, DPE, KT, false>;
         HIPCHK(ctx, hipFuncSetAttribute((const void*)wfun, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wlds));
         hipLaunchKernelGGL((k_worklist_lane<DIM, DPE, KT, false>), dim3(256*4), dim3(PNL_NTHREADS), 0, ctx->stream, ctx->P,
                            (const int4*)ctx->b_wlsorted.p, (const unsigned*)offs, (double*)nullptr, 0ll, (double*)nullptr, SparseOut{}, 0, CT);
-        hipLaunchKernelGGL(wfun, dim3(256*2), dim3(PNL_NTHREADS), wlds, ctx->stream, ctx->P, (const int4*)ctx->b_wlsorted.p,
+        hipLaunchKernelGGL(wfun, dim3(wl_grid), dim3(PNL_NTHREADS), wlds, ctx->stream, ctx->P, (const int4*)ctx->b_wlsorted.p,
                            (const unsigned*)offs, (const unsigned*)coff, (double*)nullptr, 0ll, (double*)nullptr, tab_max, SparseOut{},
                            PNL_WL_BINS-1, PNL_WL_LANE_MAXPTS+1, CT);
         HIPCHK(ctx, hipGetLastError());
@@ -1133,6 +1147,7 @@ int clusters_tiled_impl(pnl_context *ctx, const pnl_cluster_plan *pl, ClusterTil
     HIPCHK(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
     HIPCHK(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
     // touching element pairs
+    if (overlap) ctx->stream = ctx->aux[0];
     for (int s = 0; s < DIM+1; s++) {
         const int np = pl->n_sing[s];
         if (!np) continue;
@@ -1161,7 +1176,10 @@ int clusters_tiled_impl(pnl_context *ctx, const pnl_cluster_plan *pl, ClusterTil
 #undef PNL_LAUNCH_SING
         HIPCHK(ctx, hipGetLastError());
     }
-    HIPCHK(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
+    if (overlap) {
+        HIPCHK(ctx, hipEventRecord(ctx->ev_join[0], ctx->aux[0]));
+        ctx->stream = ctx->aux[1];
+    } else HIPCHK(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
     // cluster-local Gauss-theorem term into the diagonal-block buffer
     if (cluster_boundary && pl->num_dslots > 0 && pl->nfacets > 0) {
         if (!ctx->C().have_kernel[1] || !ctx->C().have_form[1]) return fail(ctx, PNL_ERR_STATE, "boundary kernel and order formula must be set");
@@ -1188,6 +1206,13 @@ int clusters_tiled_impl(pnl_context *ctx, const pnl_cluster_plan *pl, ClusterTil
                                    bt_facet, bt_slot, pl->n_btouch, 1., SparseOut{}, CT.D, (const unsigned*)nullptr, (const int*)nullptr, (const DevKernel*)nullptr, (const DevFormula*)nullptr);
             HIPCHK(ctx, hipGetLastError());
         }
+    }
+    if (overlap) {
+        HIPCHK(ctx, hipEventRecord(ctx->ev_join[1], ctx->aux[1]));
+        ctx->stream = main_stream;
+        HIPCHK(ctx, hipStreamWaitEvent(main_stream, ctx->ev_join[0], 0));
+        HIPCHK(ctx, hipStreamWaitEvent(main_stream, ctx->ev_join[1], 0));
+        HIPCHK(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
     }
     HIPCHK(ctx, hipEventRecord(ctx->ev[4], ctx->stream));
     if (pl->num_dslots > 0) {
