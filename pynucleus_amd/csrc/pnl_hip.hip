@@ -1003,7 +1003,10 @@ int pairs_masked_impl(pnl_context *ctx, int np, const SparseOut &S, bool classif
     HIPCHK(ctx, hipEventRecord(ctx->ev[6], ctx->stream));
     {
         const int st = 4+DPE;
-        const int tab_max = (60*1024)/(st*(int)sizeof(double));
+        // LDS copy of the rule: see run_worklist (PNL_WL_MP_KB: A/B switch of the sparse path)
+        const int wl_kb = getenv("PNL_WL_MP_KB") ? std::max(4, atoi(getenv("PNL_WL_MP_KB"))) : 60;
+        const int tab_max = (wl_kb*1024)/(st*(int)sizeof(double));
+        const int wl_grid = 256*std::max(1, std::min(8, 150/(wl_kb+(KT == 0 ? 3 : 0))));
         const size_t lds = (size_t)tab_max*st*sizeof(double);
         auto wfun = k_worklist_sorted<DIM, DPE, KT, true>;
         HIPCHK(ctx, hipFuncSetAttribute((const void*)wfun, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -1015,7 +1018,7 @@ int pairs_masked_impl(pnl_context *ctx, int np, const SparseOut &S, bool classif
         if (ctx->wl_lane)
             hipLaunchKernelGGL((k_worklist_lane<DIM, DPE, KT, true>), dim3(256*4), dim3(PNL_NTHREADS), 0, ctx->stream, ctx->P,
                                (const int4*)sorted, (const unsigned*)offs, (double*)nullptr, 0ll, Dbuf, S, 0, ClusterTiles{});
-        hipLaunchKernelGGL(wfun, dim3(256*2), dim3(PNL_NTHREADS), lds, ctx->stream, ctx->P, (const int4*)sorted, (const unsigned*)offs,
+        hipLaunchKernelGGL(wfun, dim3(wl_grid), dim3(PNL_NTHREADS), lds, ctx->stream, ctx->P, (const int4*)sorted, (const unsigned*)offs,
                            (const unsigned*)coff, (double*)nullptr, 0ll, Dbuf, tab_max, S, PNL_MAXQ, nmin, ClusterTiles{});
         if (Dbuf) {
             const long long n = (long long)ctx->nc*ND;
