@@ -83,18 +83,50 @@ def build_restriction_P2(dm_coarse, dm_fine):
 class Multigrid:
     """levels[l] = {'A': dense operator, 'R': restriction to level l-1, 'P': prolongation from it}; level 0 = coarsest."""
 
-    def __init__(self, levels, omega=2./3., presmoothingSteps=1, postsmoothingSteps=1):
+    def __init__(self, levels, omega=2./3., presmoothingSteps=1, postsmoothingSteps=1, chebyshev=None):
+        """chebyshev: None (Jacobi smoother) or the parameters of chebyshevSmoother (smoothers.pyx:439-457): degree, lowerBound,
+        upperBound, rhoA (0: power method linalg.pyx:811-829 from the vector default_rng(0).standard_normal(n), relative change 1e-3, at
+        most 51 steps -- the reference's absolute tolerance 0.01 stops after two steps on these operators and underestimates rho)"""
         self.levels = levels
         self.invD = [None]+[omega/np.diag(L['A']) for L in levels[1:]]
         self.pre, self.post = presmoothingSteps, postsmoothingSteps
         self.coarse_inverse = np.linalg.inv(levels[0]['A'])
+        self.cheb = None
+        if chebyshev is not None:
+            self.cheb = [None]+[self.chebyshev_coefficients(L['A'], **chebyshev) for L in levels[1:]]
+
+    @staticmethod
+    def chebyshev_coefficients(A, degree=3, rhoA=0., lowerBound=1.0/30.0, upperBound=1.1):
+        if rhoA == 0.:
+            n = A.shape[0]
+            x = np.random.default_rng(0).standard_normal(n)
+            x /= np.linalg.norm(x)
+            lold, rhoA, k = 0., 1., 0
+            while abs(rhoA-lold) > 1e-3*abs(rhoA) and k <= 50:
+                x = A@x
+                lold = rhoA
+                rhoA = np.linalg.norm(x)
+                x /= rhoA
+                k += 1
+        a, b = rhoA*lowerBound, rhoA*upperBound
+        roots = 0.5*(b-a)*(1+np.cos(np.pi*(np.arange(degree)+0.5)/degree))+a
+        poly = np.poly(roots)
+        poly /= np.polyval(poly, 0.)
+        return -poly[:-1]
 
     def smooth(self, l, b, x, steps, simple):
         A = self.levels[l]['A']
         for _ in range(steps):
             res = b.copy() if simple else b-A@x
             simple = False
-            x += self.invD[l]*res
+            if self.cheb is not None:
+                c = self.cheb[l]
+                y = c[0]*res
+                for ck in c[1:]:
+                    y = ck*res+A@y
+                x += y
+            else:
+                x += self.invD[l]*res
 
     def solveOnLevel(self, l, b, x, simple=False):
         if l == 0:

@@ -189,8 +189,11 @@ class multigrid:
         if len(levels) < 1:
             raise AssertionError('empty hierarchy')
         name, sp = smoother if isinstance(smoother, tuple) else (smoother, {})
-        if name != 'jacobi':
-            raise NotImplementedError('smoother {}: the device cycle has the Jacobi smoother only'.format(name))
+        if name not in ('jacobi', 'chebyshev'):
+            raise NotImplementedError('smoother {}: Jacobi (library cycle) and Chebyshev (operator-agnostic cycle) are built'.format(name))
+        self.smootherType, self.smootherParams = name, dict(sp)
+        if name == 'chebyshev':
+            native = False                                     # the polynomial smoother runs through the operators' matvecs
         self.omega = float(sp.get('omega', 2.0/3.0))
         self.presmoothingSteps = int(sp.get('presmoothingSteps', 1))
         self.postsmoothingSteps = int(sp.get('postsmoothingSteps', 1))
@@ -249,20 +252,65 @@ class multigrid:
             op = L['A']
             G = {'A': op, 'n': op.num_rows}
             if l > 0:
-                d = op.diagonal
-                d = d() if callable(d) else d
-                G['invD'] = self.omega/self._vec(d)
+                if self.smootherType == 'chebyshev':
+                    G['cheb'] = self._chebyshev_coefficients(op)
+                else:
+                    d = op.diagonal
+                    d = d() if callable(d) else d
+                    G['invD'] = self.omega/self._vec(d)
                 G['R'], G['P'] = _DevCSR(L['R'], self.device), _DevCSR(L['P'], self.device)
             self._g.append(G)
         A0 = self.levels[0]['A']
         self._coarse_inv = torch.from_numpy(np.linalg.inv(np.asarray(A0.toarray()))).to(self.device).contiguous()
+
+    def estimateSpectralRadius(self, op, eps=1e-3, kMax=50):
+        """power method (base/PyNucleus_base/linalg.pyx:811-829) on the device.  Two deliberate differences: the reference starts from
+        a random vector on the unit sphere and stops on an ABSOLUTE change of eps -- with the eigenvalues of these operators
+        (0.1 and below) that is after two steps, and the estimate (root mean square of the spectrum) can lie below the largest
+        eigenvalue by more than the 10 % the upper bound allows: the smoother then amplifies the top of the spectrum.  Here: a
+        fixed pseudo-random start vector (numpy default_rng(0): reproducible), a RELATIVE change of eps = 1e-3 and up to 50
+        steps."""
+        import torch
+        n = op.num_rows
+        x0 = np.random.default_rng(0).standard_normal(n)
+        x = torch.from_numpy(x0/np.linalg.norm(x0)).to(self.device)
+        lold, lam, k = 0., 1., 0
+        while abs(lam-lold) > eps*abs(lam) and k <= kMax:
+            x = op.matvec(x)
+            lold = lam
+            lam = float(torch.linalg.norm(x))
+            x = x/lam
+            k += 1
+        return lam
+
+    def _chebyshev_coefficients(self, op):
+        """chebyshevPreconditioner.__init__ (multilevelSolver/PyNucleus_multilevelSolver/smoothers.pyx:390-424): the polynomial
+        with the Chebyshev roots of [rhoA lowerBound, rhoA upperBound], scaled to C(0) = 1; p(A) r = sum_k coeffs[k] A^(deg-1-k) r"""
+        sp = self.smootherParams
+        degree = int(sp.get('degree', 3))
+        rhoA = float(sp.get('rhoA', 0.))
+        if rhoA == 0.:
+            rhoA = self.estimateSpectralRadius(op)
+        a, b = rhoA*float(sp.get('lowerBound', 1.0/30.0)), rhoA*float(sp.get('upperBound', 1.1))
+        std_roots = np.cos(np.pi*(np.arange(degree, dtype=np.float64)+0.5)/degree)
+        scaled_poly = np.poly(0.5*(b-a)*(1+std_roots)+a)
+        scaled_poly /= np.polyval(scaled_poly, 0.)
+        return -scaled_poly[:-1]
 
     def _generic_smooth(self, l, b, x, steps, simple):
         G = self._g[l]
         for _ in range(steps):
             res = b if simple else b-G['A'].matvec(x)
             simple = False
-            x.addcmul_(G['invD'], res)
+            if 'cheb' in G:
+                # chebyshevPreconditioner.matvec (smoothers.pyx:426-436): y = c_0 r; y = c_k r + A y
+                c = G['cheb']
+                y = c[0]*res
+                for ck in c[1:]:
+                    y = ck*res+G['A'].matvec(y)
+                x.add_(y)
+            else:
+                x.addcmul_(G['invD'], res)
 
     def _generic_level(self, l, b, x, simple):
         """multigrid.solveOnLevel (multigrid_{SCALAR}.pxi:237-292) over operator matvecs; x is updated in place"""
@@ -367,8 +415,9 @@ class multigrid:
         return B
 
     def __str__(self):
-        return 'V-cycle multigrid, {} levels, Jacobi ({}/{} sweeps, {:.3} damping), DoFs {}'.format(
-            len(self.levels), self.presmoothingSteps, self.postsmoothingSteps, self.omega, [L['A'].num_rows for L in self.levels])
+        sm = ('Chebyshev (degree {})'.format(int(self.smootherParams.get('degree', 3))) if self.smootherType == 'chebyshev'
+              else 'Jacobi ({}/{} sweeps, {:.3} damping)'.format(self.presmoothingSteps, self.postsmoothingSteps, self.omega))
+        return 'V-cycle multigrid, {} levels, {}, DoFs {}'.format(len(self.levels), sm, [L['A'].num_rows for L in self.levels])
 
 
 # ---- time stepping --------------------------------------------------------------------------------------------------------

@@ -496,3 +496,38 @@ def test_gpu_cg_mg_at_scale_is_mesh_independent():
     bal = M@(u1-u0)/dt+0.5*(A*(u1+u0))-b
     assert np.abs(bal).max() <= 1e-7*np.abs(b).max()
     assert st.iterations[0] <= 10
+
+
+def test_oracle_chebyshev_smoother():
+    """chebyshevSmoother (smoothers.pyx:390-457) in the oracle cycle: degree-3 polynomial on [rho/30, 1.1 rho]; the cycle is a
+    contraction and cg-mg with it reaches the stored Hs error of the interval run"""
+    s = 0.25
+    levels = oracle_hierarchy('interval', 6, s, {'target_order': 2.-s})
+    b = np.asarray(levels[-1]['DoFMap'].assembleRHS(1.0))
+    mg = SO.Multigrid(levels, chebyshev={'degree': 3})
+    x, its, res = mg.solve(b, tol=1e-9*np.linalg.norm(b), maxiter=60)
+    assert its < 60 and max(res[k+1]/res[k] for k in range(2, len(res)-1)) < 0.6
+    xc, itc, _ = SO.cg(levels[-1]['A'], b, tol=1e-10, B=mg.precondition)
+    C = 2.**(-2.*s)*gamma(0.5)/gamma((1+2.*s)/2.)/gamma(1.+s)
+    hs = np.sqrt(abs(b@xc-C*np.sqrt(np.pi)*gamma(s+1)/gamma(s+3/2)))
+    assert abs(hs-0.09611243700804001) <= 1e-8*0.09611243700804001 and itc <= 10
+
+
+@pytest.mark.gpu
+def test_gpu_chebyshev_smoother_against_the_oracle():
+    from pynucleus_amd.multigrid import multigrid
+    H = device_hierarchy('disc', 3, 0.75, {})
+    lv = as_oracle_levels(H)
+    b = np.asarray(H.finest['DoFMap'].assembleRHS(1.0))
+    mo = SO.Multigrid(lv, chebyshev={'degree': 3})
+    mg = multigrid(H, smoother=('chebyshev', {'degree': 3}))
+    assert not mg._native and 'Chebyshev' in str(mg)
+    for l in range(1, len(lv)):
+        assert np.allclose(mg._g[l]['cheb'], mo.cheb[l], rtol=1e-10)
+    xo = np.zeros(b.shape[0]); mo.solveOnLevel(len(lv)-1, b, xo, True)
+    assert np.abs(mg.cycle(b)-xo).max() <= 1e-11*np.abs(xo).max()
+    xs, its, res = mg.solve(b, tol=1e-9*np.linalg.norm(b), maxiter=60)
+    xso, itso, reso = mo.solve(b, tol=1e-9*np.linalg.norm(b), maxiter=60)
+    assert its == itso and its < 60 and np.abs(xs-xso).max() <= 1e-9*np.abs(xso).max()
+    xc, itc, _ = mg.cg(b, tol=1e-10)
+    assert itc <= 12 and np.abs(lv[-1]['A']@xc-b).max() <= 1e-8*np.abs(b).max()
