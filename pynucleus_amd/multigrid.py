@@ -169,9 +169,12 @@ def buildTransientHierarchy(levels, alpha, beta):
     out = []
     for L in levels:
         A = L['A']
-        Md = torch.from_numpy(L['M'].toarray()).to(A.A.device)
         A.ctx.synchronize()
-        T = (Md*alpha).add_(A.A, alpha=beta)
+        T = (A.A*beta).contiguous()
+        M = L['M'].tocoo()                                   # the mass matrix stays sparse: its entries are added on the device
+        dev = A.A.device
+        T.index_put_((torch.from_numpy(M.row.astype(np.int64)).to(dev), torch.from_numpy(M.col.astype(np.int64)).to(dev)),
+                     torch.from_numpy(alpha*M.data.astype(np.float64)).to(dev), accumulate=True)
         N = {k: v for k, v in L.items() if k in ('P', 'R', 'mesh', 'DoFMap', 'M')}
         N['A'] = Dense_LinearOperator(T, A.ctx)
         out.append(N)
