@@ -280,7 +280,25 @@ def extra_configs(dev):
         ev1.record(); sync()
         gemv_ms = ev0.elapsed_time(ev1)/20
         gbs = 8.*n*n/(gemv_ms*1e-3)/1e9
-        res['solver_cg_mg_disc_noRef7'] = dict(
+        # one Crank-Nicolson step of the fractional heat equation (pnl_theta_step: rhs, then cg-mg on M/dt + S/2) at 12,097 DoFs
+        heat = {}
+        try:
+            from pynucleus_amd.multigrid import CrankNicolson
+            H6 = fractionalHierarchy('disc', 6, getFractionalKernel(2, 0.5), {'target_order': 0.5}, buildMass=True)
+            dm6 = H6.finest['DoFMap']
+            st = CrankNicolson(H6, (dm6.mesh.h)**0.5, theta=0.5, tol=1e-10)
+            u6 = torch.from_numpy(np.asarray(dm6.interpolate(lambda p: max(1.-p[0]**2-p[1]**2, 0.)**0.5))).to(dev)
+            f6 = np.asarray(dm6.assembleRHS(1.0))
+            st.step(0., u6, f6)
+            sync(); t0 = time.perf_counter()
+            for k in range(5):
+                st.step(0., u6, f6)
+            sync()
+            heat = dict(heat_num_dofs=dm6.num_dofs, heat_dt=st.dt, heat_step_ms=1e3*(time.perf_counter()-t0)/5, heat_cg_mg_iterations=st.iterations[-1])
+            del H6, st
+        except Exception as e:
+            heat = dict(heat_error=repr(e))
+        res['solver_cg_mg_disc_noRef7'] = dict(heat, 
             num_dofs=n, levels=[L['A'].num_rows for L in H.getLevelList()], hierarchy_assembly_s=round(t_h, 3),
             cg_mg_iterations=its, cg_mg_ms=1e3*t_cg, final_residual=hist[-1], vcycle_ms=1e3*t_cyc,
             cg_jacobi_iterations=itj, cg_jacobi_ms=1e3*t_j,
