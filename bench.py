@@ -315,6 +315,127 @@ def extra_configs(dev):
     return res
 
 
+def self_launch(gpus, argv):
+    """`python3 bench.py --gpus N` without a launcher: start the N ranks as children through torch.distributed.run (one process
+    per GPU, rendezvous on 127.0.0.1) and hand their exit code on.  Called BEFORE this process imports torch or touches the GPU:
+    a process that has initialised the GPU must never be replaced or forked into ranks."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')          # dmabuf IPC (RCCL across processes on this driver)
+    env.setdefault('OMP_NUM_THREADS', '4')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(gpus), '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)]+list(argv)
+    return subprocess.call(cmd, env=env)
+
+
+def gather_ranks(value, world, red_dev):
+    """one float per rank -> list on every rank (all_gather of a one-element tensor: RCCL on the GPU, gloo on the host)"""
+    import torch
+    import torch.distributed as dist
+    if world == 1:
+        return [float(value)]
+    t = torch.tensor([float(value)], dtype=torch.float64, device=red_dev)
+    parts = [torch.zeros_like(t) for _ in range(world)]
+    dist.all_gather(parts, t)
+    return [float(p.item()) for p in parts]
+
+
+def operator_leg(args, world, rank, dev, red_dev, backend, builder, ctx, dm, A, slab_maps, device_ms, sync):
+    """matvec and Jacobi-CG with the operator the timed steps assembled (untimed into `value`; reported beside it)."""
+    import numpy as np
+    import torch
+    from pynucleus_amd.linear_operators import Dense_LinearOperator, DistributedSlab_LinearOperator
+    from pynucleus_amd.solvers import cg
+    N = dm.num_dofs
+    if world == 1:
+        op = Dense_LinearOperator(A, ctx)
+        local_bytes = 8*N*int(A.stride(0))
+    else:
+        rows, cols = slab_maps
+        dblocks = torch.zeros(ctx.diag_blocks_size(), dtype=torch.float64, device=dev)
+        if rows.shape[0]:
+            ctx.get_diag_blocks(dblocks.data_ptr())
+        op = DistributedSlab_LinearOperator(A, dblocks, rows, cols, N, ctx, None)
+        ctx._slab_owner = op
+        local_bytes = op.local_bytes()
+    x = torch.from_numpy(np.random.default_rng(0).standard_normal(N)).to(dev)
+    for _ in range(3):
+        y = op.matvec(x)
+    sync(); t0 = time.perf_counter()
+    reps = 20
+    for _ in range(reps):
+        y = op.matvec(x)
+    sync()
+    mv = max(gather_ranks((time.perf_counter()-t0)/reps, world, red_dev))
+    b = torch.from_numpy(np.asarray(dm.assembleRHS(1.0))).to(dev)
+    sync(); t0 = time.perf_counter()
+    if world == 1:
+        u, its, res = op.solve_cg_jacobi(b, tol=1e-8, maxiter=5000)
+        res_final = float(res)
+    else:
+        u, its, res = cg(op, b, tol=1e-8, maxiter=5000)
+        res_final = float(res[-1])
+    sync()
+    t_cg = max(gather_ranks(time.perf_counter()-t0, world, red_dev))
+    dms = gather_ranks(device_ms, world, red_dev)
+    lb = gather_ranks(local_bytes, world, red_dev)
+    energy = float(torch.dot(b, u))
+    return dict(matvec_ms=1e3*mv, matvec_algorithmic_GBs=8.*N*N/mv/1e9 if world == 1 else sum(lb)/mv/1e9,
+                matvec_note=('k_gemv on the N x N block: 8 N^2 bytes per product' if world == 1 else
+                             'local one-sided slab products (A\' x and A\'^T x) + one all-reduce of the N-vector ({} backend); GB/s = bytes of all slabs / time'.format(backend)),
+                cg_jacobi_iterations=int(its), cg_jacobi_ms=1e3*t_cg, cg_residual=res_final, energy_b_dot_u=energy,
+                device_ms_per_rank=[round(v, 3) for v in dms], device_ms_min=min(dms), device_ms_max=max(dms),
+                operator_bytes_per_rank=[int(v) for v in lb], operator_bytes_total=int(sum(lb)))
+
+
+def c4_distributed_leg(args, world, rank, dev, sync):
+    """BASELINE configs[3] on N > 1 ranks: getH2 with a communicator -- near-field cluster pairs row-sharded by row cluster
+    (clusters.partitionClusterPairs; NA:3247-3260, clusterMethodCy.pyx:1854-1896), far field dealt over the ranks, matvec =
+    Bcast(x) + local near/far products + all-reduce of the N-vector (clusterMethodCy.pyx:3127-3154)."""
+    import numpy as np
+    import torch
+    from pynucleus_amd import disc, P1_DoFMap, PHYSICAL, getFractionalKernel
+    from pynucleus_amd.builder import nonlocalBuilder
+    from pynucleus_amd.solvers import cg
+    red_dev = dev if os.environ.get('PNL_BENCH_BACKEND', 'nccl') == 'nccl' else torch.device('cpu')
+    try:
+        dm = P1_DoFMap(disc(args.noRef, sectors=args.sectors), PHYSICAL)
+        b4 = nonlocalBuilder(dm, getFractionalKernel(2, 0.75), {'target_order': 0.5, 'eta': 3.}, zeroExterior=True, comm=True)
+        walls = []
+        for rep in range(2):
+            sync(); t0 = time.perf_counter()
+            h2 = b4.getH2()
+            sync(); walls.append(time.perf_counter()-t0)
+        c = h2.info.get('counters', {})
+        near_ms = gather_ranks(h2.info.get('interior_ms', 0.), world, red_dev)
+        pairs = gather_ranks(c.get('numAssembledCellPairs', 0), world, red_dev)
+        nnz = gather_ranks(h2.local.nnz, world, red_dev)
+        x = torch.from_numpy(np.random.default_rng(0).standard_normal(dm.num_dofs)).to(dev)
+        for _ in range(3):
+            y = h2.matvec(x)
+        sync(); t0 = time.perf_counter()
+        for _ in range(20):
+            y = h2.matvec(x)
+        sync()
+        mv = max(gather_ranks((time.perf_counter()-t0)/20, world, red_dev))
+        rhs = torch.from_numpy(np.asarray(dm.assembleRHS(1.0))).to(dev)
+        sync(); t0 = time.perf_counter()
+        u, its, res = cg(h2, rhs, tol=1e-8, maxiter=2000)
+        sync()
+        t_cg = max(gather_ranks(time.perf_counter()-t0, world, red_dev))
+        return dict(num_dofs=dm.num_dofs, getH2_first_ms=1e3*max(gather_ranks(walls[0], world, red_dev)),
+                    getH2_ms=1e3*max(gather_ranks(walls[-1], world, red_dev)), near_field_device_ms_per_rank=[round(v, 3) for v in near_ms],
+                    near_field_element_pairs_per_rank=[int(v) for v in pairs], near_field_element_pairs=int(sum(pairs)),
+                    near_field_nnz_per_rank=[int(v) for v in nnz], pairs_per_s=sum(pairs)/(1e-3*max(near_ms)) if max(near_ms) > 0 else 0.,
+                    matvec_ms=1e3*mv, cg_jacobi_iterations=int(its), cg_jacobi_ms=1e3*t_cg, cg_residual=float(res[-1]))
+    except Exception as e:                                   # the headline line survives a failing leg (every rank fails alike)
+        return dict(error=repr(e))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -325,9 +446,11 @@ def main():
     ap.add_argument('--sectors', type=int, default=6, help='triangles of the initial fan (6 = the reference disc; 12 at noRef 7 gives 97 921 DoFs)')
     ap.add_argument('--cpu-seconds', type=float, default=15., help='target CPU time of the oracle sample (rank 0, N=1 only)')
     ap.add_argument('--no-cpu', action='store_true')
-    ap.add_argument('--solve', action='store_true', help='also run the CG-Jacobi solve of configs[1] (reported, not timed into value)')
     ap.add_argument('--no-extra', action='store_true', help='skip the short legs of the other BASELINE.json configurations (N=1 only)')
     args = ap.parse_args()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # bare command: this process becomes the launcher of its own ranks (nothing GPU-related has been imported yet)
+        sys.exit(self_launch(args.gpus, sys.argv[1:]))
 
     import numpy as np
     import torch
@@ -484,6 +607,14 @@ def main():
                phases_ms={k: round(v, 4) for k, v in phase_acc.items()},
                kernel_evaluations_per_step=cnt['numIntegrations'] if world == 1 else None)
 
+    # ---- the assembled operator at work (north star: "RCCL all-reduce over xGMI for the assembled matvec"): y = A x and a
+    # Jacobi-CG solve of A u = f, f = 1.  N = 1: k_gemv on the N x N block; N > 1: DistributedSlab_LinearOperator -- local slab
+    # product, ONE all-reduce of the N-vector (DistributedH2Matrix_globalData.matvec, clusterMethodCy.pyx:3127-3154) ----------
+    out['operator'] = operator_leg(args, world, rank, dev, red_dev, backend, builder, ctx, dm, A, None if world == 1 else (rows, cols),
+                                   phase_acc.get('total', 0.), sync)
+    if world > 1 and not args.no_extra:
+        out.setdefault('configs', {})['C4_disc_noRef{}_s0.75_H2_row_sharded'.format(args.noRef)] = c4_distributed_leg(args, world, rank, dev, sync)
+
     # ---- CPU baseline: the C oracle (reference loop order) on bounded samples of the same workload -------------------
     if rank == 0 and world == 1 and not args.no_cpu:
         out['cpu_baseline'] = cpu_baseline(args, T, N, nc, value)
@@ -493,15 +624,6 @@ def main():
         builder = ctx = None
         torch.cuda.empty_cache()
         out['configs'] = extra_configs(dev)
-    if args.solve and world == 1 and args.no_extra:
-        from pynucleus_amd.linear_operators import Dense_LinearOperator
-        op = Dense_LinearOperator(A, ctx)
-        b = torch.from_numpy(np.asarray(dm.assembleRHS(1.0))).to(dev)
-        torch.cuda.synchronize(dev)
-        t1 = time.perf_counter()
-        u, its, res = op.solve_cg_jacobi(b, tol=1e-8, maxiter=5000)
-        torch.cuda.synchronize(dev)
-        out['cg_jacobi'] = dict(iterations=its, residual=res, seconds=time.perf_counter()-t1)
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

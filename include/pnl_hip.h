@@ -84,6 +84,16 @@ enum pnl_counter {
 };
 #define PNL_NUM_COUNTERS 134
 
+/* Options (process-wide).  The library reads no environment variable on its assembly path; an option exists once it has been
+ * set here (value NULL removes it).  A product build accepts
+ *   "PNL_WL_FRAC"     capacity of the device work lists as a fraction of the candidate pairs (tests force the overflow report),
+ *   "PNL_FH_NOTILES"  finite horizon: every pair through the per-pair pipeline instead of the block tiles,
+ *   "PNL_NO_POWTAB"   general exponent: exp(e ln x) instead of the table-driven power,
+ *   "PNL_VERBOSE", "PNL_PLAN_TIMING"   diagnostics on stderr,
+ * and returns PNL_ERR_UNSUPPORTED for any other name.  A tuning build (make EXTRA=-DPNL_TUNING; pnl_version says so) accepts every
+ * name and falls back to the environment: the A/B switches named in DESIGN.md live there. */
+int pnl_set_option(const char *name, const char *value);
+
 /* ---- lifetime ---------------------------------------------------------------- */
 int pnl_create(int device_id, pnl_context **ctx);
 void pnl_destroy(pnl_context *ctx);
@@ -344,6 +354,10 @@ int pnl_horizon_pattern(int dim, int nv, const double *vertices, int nc, const i
 /* pattern of the near field of the cluster pairs pairs[npairs][2] (node ids of the tree): union of the blocks n1.dofs x n2.dofs,
  * getSparseNearField NA:3226-3289; strict_lower keeps I > J (SSS) */
 int pnl_near_pattern(const pnl_tree *T, int npairs, const int32_t *pairs, int strict_lower, pnl_pattern **out);
+/* The row pointer of a pattern is int32 (the reference's INDEX_t; pnl_upload_sparsity and the CSR / SSS operators index with
+ * it): both builders return PNL_ERR_UNSUPPORTED for a pattern with more stored entries than the limit instead of wrapping.
+ * pnl_pattern_set_max_nnz lowers the limit (process-wide, 1 ... 2^31 - 1; other values leave it unchanged) and returns the old one. */
+int64_t pnl_pattern_set_max_nnz(int64_t max_nnz);
 int64_t pnl_pattern_nnz(const pnl_pattern *P);
 int pnl_pattern_get(const pnl_pattern *P, int32_t *indptr, int32_t *indices);
 void pnl_pattern_destroy(pnl_pattern *P);

@@ -27,7 +27,7 @@ PNL_NUM_COUNTERS = 134
 EXPORTS = ['pnl_create', 'pnl_destroy', 'pnl_error_string', 'pnl_version', 'pnl_set_stream', 'pnl_synchronize',
            'pnl_upload_mesh', 'pnl_upload_dofmap', 'pnl_set_kernel', 'pnl_set_order_formula', 'pnl_upload_distant_rules',
            'pnl_upload_singular_rule', 'pnl_upload_boundary', 'pnl_assemble_dense', 'pnl_dense_overwrites', 'pnl_block_row_costs', 'pnl_tile_cells',
-           'pnl_assemble_dense_tiles', 'pnl_get_counters', 'pnl_get_phase_ms', 'pnl_get_kernel_ms', 'pnl_tree_build', 'pnl_tree_build_blocks', 'pnl_tree_destroy', 'pnl_tree_sizes', 'pnl_tree_get', 'pnl_tree_node_cells', 'pnl_h2_transfer_matrices', 'pnl_nfplan_build', 'pnl_nfplan_destroy', 'pnl_nfplan_sizes', 'pnl_nfplan_get', 'pnl_horizon_pattern', 'pnl_near_pattern', 'pnl_pattern_nnz', 'pnl_pattern_get', 'pnl_pattern_destroy', 'pnl_set_row_slab', 'pnl_diag_blocks_size', 'pnl_get_diag_blocks', 'pnl_slab_matvec', 'pnl_slab_diagonal', 'pnl_gemv', 'pnl_cg_jacobi',
+           'pnl_assemble_dense_tiles', 'pnl_get_counters', 'pnl_get_phase_ms', 'pnl_get_kernel_ms', 'pnl_tree_build', 'pnl_tree_build_blocks', 'pnl_tree_destroy', 'pnl_tree_sizes', 'pnl_tree_get', 'pnl_tree_node_cells', 'pnl_h2_transfer_matrices', 'pnl_nfplan_build', 'pnl_nfplan_destroy', 'pnl_nfplan_sizes', 'pnl_nfplan_get', 'pnl_horizon_pattern', 'pnl_near_pattern', 'pnl_pattern_set_max_nnz', 'pnl_set_option', 'pnl_pattern_nnz', 'pnl_pattern_get', 'pnl_pattern_destroy', 'pnl_set_row_slab', 'pnl_diag_blocks_size', 'pnl_get_diag_blocks', 'pnl_slab_matvec', 'pnl_slab_diagonal', 'pnl_gemv', 'pnl_cg_jacobi',
            'pnl_inv_diagonal', 'pnl_set_classes', 'pnl_select_class', 'pnl_upload_sparsity', 'pnl_upload_sparsity_device', 'pnl_assemble_pairs_masked', 'pnl_assemble_boundary_masked', 'pnl_assemble_clusters_tiled', 'pnl_h2_setup', 'pnl_h2_matvec', 'pnl_h2_upward', 'pnl_h2_interact', 'pnl_h2_downward', 'pnl_h2_sizes', 'pnl_spmv',
            'pnl_assemble_pairs_in_horizon', 'pnl_set_nonsymmetric', 'pnl_set_order_function', 'pnl_upload_pointwise_rules', 'pnl_assemble_dense_pointwise',
            'pnl_gemv_axpby', 'pnl_csr_matvec', 'pnl_mg_create', 'pnl_mg_destroy', 'pnl_mg_cycle', 'pnl_mg_solve', 'pnl_mg_cg', 'pnl_theta_step']
@@ -145,6 +145,8 @@ def load():
     L.pnl_horizon_pattern.argtypes = [i32, i32, vp, i32, vp, i32, i32, vp, dbl, i32, C.POINTER(vp)]
     L.pnl_near_pattern.argtypes = [vp, i32, vp, i32, C.POINTER(vp)]
     L.pnl_pattern_nnz.argtypes = [vp]
+    L.pnl_pattern_set_max_nnz.argtypes = [i64]
+    L.pnl_set_option.argtypes = [C.c_char_p, C.c_char_p]
     L.pnl_pattern_get.argtypes = [vp, vp, vp]
     L.pnl_pattern_destroy.argtypes = [vp]
     L.pnl_diag_blocks_size.argtypes = [vp]
@@ -183,12 +185,19 @@ def load():
     L.pnl_assemble_dense_pointwise.argtypes = [vp, vp, i64, i32, i32, i32, i32, vp, i32, vp]
     for name in EXPORTS:
         f = getattr(L, name)
-        if name == 'pnl_pattern_nnz':
+        if name in ('pnl_pattern_nnz', 'pnl_pattern_set_max_nnz'):
             f.restype = C.c_int64
         elif name not in ('pnl_destroy', 'pnl_error_string', 'pnl_version'):
             f.restype = C.c_int
     _LIB = L
     return L
+
+
+def set_option(name, value=None):
+    """pnl_set_option: a library option (include/pnl_hip.h lists the ones a product build accepts); value None removes it"""
+    rc = load().pnl_set_option(name.encode(), None if value is None else str(value).encode())
+    if rc:
+        raise PnlError('pnl_set_option({!r}) failed: {} (a product build accepts only the options listed in include/pnl_hip.h)'.format(name, rc))
 
 
 def _hp(a, dtype):
@@ -507,11 +516,11 @@ class Context:
 
     def mg_cg(self, mg, A_ptr, ldA, b_ptr, x_ptr, tol, maxiter, x_is_zero):
         it = C.c_int(0)
-        res = (C.c_double*(maxiter+2))()
+        res = (C.c_double*(maxiter+2))(*([float('nan')]*(maxiter+2)))
         self.check(self.L.pnl_mg_cg(mg, C.c_void_p(A_ptr) if A_ptr else None, int(ldA), C.c_void_p(b_ptr), C.c_void_p(x_ptr), float(tol),
                                     int(maxiter), int(bool(x_is_zero)), C.byref(it), res, maxiter+2))
-        out = list(res)                       # initial value + one entry per iteration performed, the rest still zero
-        while len(out) > 1 and out[-1] == 0.:
+        out = list(res)                       # initial value + one entry per iteration performed; unwritten entries stay NaN
+        while len(out) > 1 and out[-1] != out[-1]:
             out.pop()
         return it.value, out
 

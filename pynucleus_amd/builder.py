@@ -409,6 +409,9 @@ class nonlocalBuilder:
             h = Ct.c_void_p()
             rc = L.pnl_horizon_pattern(self.mesh.dim, self.mesh.num_vertices, verts.ctypes.data, nc, mcells.ctypes.data, dpe, N,
                                        dofs32.ctypes.data, float(self.kernel.horizonValue), int(symmetric), Ct.byref(h))
+            if rc == _lib.PNL_ERR_UNSUPPORTED:
+                raise _lib.PnlError('getSparse: the pattern has more than 2^31 - 1 stored entries (INDEX_t is 32 bits); use a smaller '
+                                    'horizon or mesh, or getDense')
             if rc:
                 raise RuntimeError('pnl_horizon_pattern failed: {}'.format(rc))
             indptr = np.zeros(N+1, dtype=np.int32)

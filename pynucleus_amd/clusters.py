@@ -354,6 +354,9 @@ def getSparseNearField(dm, Pnear, symmetric=True, device=None):
             pairs = np.ascontiguousarray([(cp.n1._k, cp.n2._k) for cp in Pnear], dtype=np.int32)
             h = C.c_void_p()
             rc = T.L.pnl_near_pattern(T.h, pairs.shape[0], pairs.ctypes.data, 1 if symmetric else 0, C.byref(h))
+            if rc == -2:                                         # PNL_ERR_UNSUPPORTED
+                from ._lib import PnlError
+                raise PnlError('getSparseNearField: the near-field pattern has more than 2^31 - 1 stored entries (INDEX_t is 32 bits)')
             if rc == 0:
                 nnz = int(T.L.pnl_pattern_nnz(h))
                 if device is not None and getattr(device, 'type', 'cpu') == 'cuda':

@@ -208,13 +208,19 @@ inline DevFormula to_dev(const pnl_order_formula &f) {
     return d;
 }
 
+// Options of the library.  The product build reads NO environment variable on the assembly path: an option exists only after
+// pnl_set_option(name, value) named it (include/pnl_hip.h lists the options a product build accepts -- the hooks the parity
+// tests use to reach the alternative code paths).  Tuning builds (make EXTRA=-DPNL_TUNING) accept every name and fall back to the
+// environment, which is how the A/B measurements of DESIGN.md were made.  Returns the value string or nullptr.
+const char *pnl_tune(const char *name);
+
 // row stride of the LDS sub-block: nU + 1 columns (+1: trash column / row for boundary DoFs); PNL_ACC_PAD=m rounds it up
 // to 1 mod m so that consecutive rows start in different LDS banks
 inline int acc_stride_of(int nU, size_t fixed_bytes = 0) {
     int st = nU+1;
     // rows that start in different LDS banks (stride = 1 mod 32 doubles) see fewer conflicts in the ds_add_f64 of the
     // cross blocks (measured: -0.4 ms at noRef 6), if the bigger sub-block still leaves two workgroups per CU
-    const int m = getenv("PNL_ACC_PAD") ? atoi(getenv("PNL_ACC_PAD")) : 32;
+    const int m = pnl_tune("PNL_ACC_PAD") ? atoi(pnl_tune("PNL_ACC_PAD")) : 32;
     if (m > 1) {
         int padded = st;
         while (padded % m != 1) padded++;

@@ -42,7 +42,7 @@ int finalize(pnl_context *ctx) {
     // a ds_add_f64 then hit the same LDS address ~2.3 instead of ~4.3 times (greedy + local search).
     std::vector<int> lperm((size_t)nc*nV);
     for (int c = 0; c < nc; c++) for (int k = 0; k < nV; k++) lperm[(size_t)c*nV+k] = k;
-    const bool reorder = dpe == nV && dim == 2 && !getenv("PNL_NO_REORDER");
+    const bool reorder = dpe == nV && dim == 2 && !pnl_tune("PNL_NO_REORDER");
     if (reorder) {
         static const int perms[6][3] = {{0, 1, 2}, {1, 2, 0}, {2, 0, 1}, {0, 2, 1}, {2, 1, 0}, {1, 0, 2}};
         // the blocks are independent: a few host threads (0.24 s on one thread at 98,304 cells)
@@ -373,7 +373,7 @@ int finalize(pnl_context *ctx) {
 // fraction bits of m, c_j = 1 / fl(1 / (1 + (j + 1/2) / 128)), u = m fl(1/c_j) - 1 (one FMA, |u| <= 2^-8):
 //   x^e = 2^(e k) c_j^e (1 + u)^e.
 static const double *pow_table(pnl_context *ctx, const DevKernel &k) {
-    if (k.ktype != PNL_FRACTIONAL || k.fast || getenv("PNL_NO_POWTAB")) return nullptr;
+    if (k.ktype != PNL_FRACTIONAL || k.fast || pnl_tune("PNL_NO_POWTAB")) return nullptr;
     for (auto *t : ctx->powtabs) if (t->exponent == k.exponent && t->scale == k.scale) return (const double*)t->buf.p;
     std::vector<double> tab(PNL_POW_TAB_DOUBLES);
     for (int j = 0; j < 128; j++) {
@@ -439,12 +439,12 @@ int launch_pure(pnl_context *ctx, double *A, int64_t ldA, const SlotOut &SO) {
     HIPCHK(ctx, hipFuncSetAttribute((const void*)kfun, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     int per_cu = 2;
     (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)kfun, PNL_NTHREADS, lds);
-    if (getenv("PNL_VERBOSE")) fprintf(stderr, "[pnl] uniform tiles=%d of %d, lds=%zu bytes, occupancy API: %d blocks/CU\n", ctx->n_pure,
+    if (pnl_tune("PNL_VERBOSE")) fprintf(stderr, "[pnl] uniform tiles=%d of %d, lds=%zu bytes, occupancy API: %d blocks/CU\n", ctx->n_pure,
                                        ctx->n_pure+ctx->n_mixed, lds, per_cu);
     const int grid = std::min(ctx->n_pure, 256*std::max(per_cu, 1));
     int pure_abl = 0;
 #ifdef PNL_DEBUG_ABLATE
-    pure_abl = getenv("PNL_PURE_ABL") ? atoi(getenv("PNL_PURE_ABL")) : 0;
+    pure_abl = pnl_tune("PNL_PURE_ABL") ? atoi(pnl_tune("PNL_PURE_ABL")) : 0;
 #endif
     kt_begin(ctx, PNL_K_TILE_UNIFORM2);
     hipLaunchKernelGGL(kfun, dim3(grid), dim3(PNL_NTHREADS), lds, ctx->stream, tile_problem(ctx), (const int2*)ctx->b_tiles.p+ctx->tile_off+ctx->n_mixed,
@@ -465,7 +465,7 @@ struct ClassFork {
     // from: an event recorded earlier on the caller's stream (the fold pass) -- the side streams start there instead of behind
     // everything the caller's stream holds, so consecutive forked phases run back to back on every side stream
     ClassFork(pnl_context *c, int nclasses, hipEvent_t from = nullptr)
-        : ctx(c), main(c->stream), on(nclasses > 1 && !getenv("PNL_NO_FORK")), start(from ? from : c->ev_fork) {
+        : ctx(c), main(c->stream), on(nclasses > 1 && !pnl_tune("PNL_NO_FORK")), start(from ? from : c->ev_fork) {
         if (on && !from) (void)hipEventRecord(ctx->ev_fork, main);
     }
     void use(int k) {
@@ -506,7 +506,7 @@ int run_worklist(pnl_context *ctx, const int4 *wl, const unsigned *wlc, unsigned
                        wlsorted);
     const int st = 4+DPE;
     // LDS copy of the rule: 18 KB (8 workgroups per CU; rules with more points are read from global memory; 60 KB / 2 workgroups per CU was 0.6 ms slower at 98,304 cells)
-    const int wl_kb = getenv("PNL_WL_LDS_KB") ? std::max(4, atoi(getenv("PNL_WL_LDS_KB"))) : 18;
+    const int wl_kb = pnl_tune("PNL_WL_LDS_KB") ? std::max(4, atoi(pnl_tune("PNL_WL_LDS_KB"))) : 18;
     const int tab_max = (wl_kb*1024)/(st*(int)sizeof(double));
     const int wl_grid = 256*std::max(1, std::min(8, 150/(wl_kb+(KT == 0 ? 3 : 0))));      // KT == 0: + 3 KB of power tables
     const size_t lds = (size_t)tab_max*st*sizeof(double);
@@ -515,7 +515,7 @@ int run_worklist(pnl_context *ctx, const int4 *wl, const unsigned *wlc, unsigned
     const int nmin = ctx->wl_lane ? PNL_WL_LANE_MAXPTS+1 : 0;
     int dbg = 0;
 #ifdef PNL_DEBUG_ABLATE
-    dbg = getenv("PNL_WL_DBG") ? atoi(getenv("PNL_WL_DBG")) : 0;
+    dbg = pnl_tune("PNL_WL_DBG") ? atoi(pnl_tune("PNL_WL_DBG")) : 0;
 #endif
     if (ctx->wl_lane)
         hipLaunchKernelGGL((k_worklist_lane<DIM, DPE, KT, false>), dim3(256*4), dim3(PNL_NTHREADS), 0, ctx->stream, ctx->P,
@@ -531,8 +531,8 @@ int run_worklist(pnl_context *ctx, const int4 *wl, const unsigned *wlc, unsigned
 // work list for the orders that are integrated one pair per wave: `regions` regions of equal capacity, sized generously;
 // an overflow is detected (check_overflow)
 int ensure_worklist(pnl_context *ctx, double pairs, int regions) {
-    const double frac = getenv("PNL_WL_FRAC") ? atof(getenv("PNL_WL_FRAC")) : 0.05;
-    const double floor_entries = getenv("PNL_WL_FRAC") ? 64. : (double)(1 << 20);
+    const double frac = pnl_tune("PNL_WL_FRAC") ? atof(pnl_tune("PNL_WL_FRAC")) : 0.05;
+    const double floor_entries = pnl_tune("PNL_WL_FRAC") ? 64. : (double)(1 << 20);
     const size_t each = (size_t)std::min<double>(std::max<double>(pairs*frac, floor_entries), 400e6);
     int rc;
     if ((rc = ensure(ctx, ctx->b_wl, each*(size_t)regions*sizeof(int4)))) return rc;
@@ -551,7 +551,7 @@ int launch_tiles(pnl_context *ctx, int wl_slot, double *A, int64_t ldA, int cell
         int rc;
         // order-2 uniform tiles: 2D P1 the pipelined k_tile_uniform<3, 3> (with three or four workgroups per CU it beats k_tile_pure:
         // 41.3 against 45.5 ms at 98,304 cells, s = 1/2; PNL_PURE_V1=1 keeps k_tile_pure), 1D k_tile_pure
-        if (DIM == 2 && DPE == 3 && !getenv("PNL_PURE_V1") && ctx->uni_off[2] >= 0 && ctx->uni_np[2] == 3)
+        if (DIM == 2 && DPE == 3 && !pnl_tune("PNL_PURE_V1") && ctx->uni_off[2] >= 0 && ctx->uni_np[2] == 3)
             rc = pnl2_launch_uniform(ctx, KT, tile_problem(ctx), (const int2*)ctx->b_tiles.p+ctx->tile_off+ctx->n_mixed, nullptr, ctx->n_pure, 2,
                                      A, ldA, (double*)(ctx->have_tile_order ? ctx->b_Dt.p : ctx->b_D.p), SO);
         else rc = launch_pure<DIM, (DPE <= 3 ? DPE : 3), KT>(ctx, A, ldA, SO);
@@ -573,7 +573,7 @@ int launch_tiles(pnl_context *ctx, int wl_slot, double *A, int64_t ldA, int cell
     const int ntiles = ctx->n_mixed;
     const int acc_stride = acc_stride_of(ctx->nU, S::fixed_bytes);
     const size_t lds = S::fixed_bytes+sizeof(double)*(size_t)(ctx->nU+1)*acc_stride;
-    if (getenv("PNL_VERBOSE")) {
+    if (pnl_tune("PNL_VERBOSE")) {
         int nblk = -1;
         (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nblk, (const void*)k_tile_distant<DIM, DPE, TILE, KT, false>, tile_threads(DPE, KT), lds);
         fprintf(stderr, "[pnl] tiles=%d nU=%d lds=%zu bytes, occupancy API: %d blocks/CU\n", ntiles, ctx->nU, lds, nblk);
@@ -588,7 +588,7 @@ int launch_tiles(pnl_context *ctx, int wl_slot, double *A, int64_t ldA, int cell
     HIPCHK(ctx, hipFuncSetAttribute((const void*)kfun, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     int per_cu = 2;
     (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)kfun, tile_threads(DPE, KT), lds);
-    const int grid_mult = getenv("PNL_GRID_MULT") ? atoi(getenv("PNL_GRID_MULT")) : 1;
+    const int grid_mult = pnl_tune("PNL_GRID_MULT") ? atoi(pnl_tune("PNL_GRID_MULT")) : 1;
     const int grid = std::min(ntiles, 256*std::max(per_cu, 1)*std::max(grid_mult, 1));
     kt_begin(ctx, PNL_K_TILE_GENERAL);
     if (grid > 0)
@@ -658,13 +658,13 @@ int launch_boundary(pnl_context *ctx, int cell_begin, int cell_end, int what = 3
     // small facet chunks: many waves in flight hide the latency of the per-facet dependent chain
     // a rank's share of the cells may be small: shrink the facet chunks until the grid has a few thousand workgroups
     // (measured at 98,304 cells x 768 facets: 16 per chunk 5.4 ms, 32 per chunk 4.5 ms, 64 the same; 8: 6.9 ms, 1: 33.6 ms)
-    int per = getenv("PNL_BND_PER") ? atoi(getenv("PNL_BND_PER")) : 32;
+    int per = pnl_tune("PNL_BND_PER") ? atoi(pnl_tune("PNL_BND_PER")) : 32;
     while (per > 1 && (long long)gx*((ctx->nb+per-1)/per) < 4096) per >>= 1;
     const int chunks = (ctx->nb+per-1)/per;
     if (what & 1) {
         // pairs with more than `defer` point pairs are integrated one per wave (k_boundary_items) instead of by one lane; the
         // list holds at least 64 items per facet -- pairs that do not fit are integrated in place
-        const int defer = getenv("PNL_BND_DEFER") ? atoi(getenv("PNL_BND_DEFER")) : 48;
+        const int defer = pnl_tune("PNL_BND_DEFER") ? atoi(pnl_tune("PNL_BND_DEFER")) : 48;
         const bool use_list = defer > 0;
         const unsigned cap = (unsigned)std::min<long long>(std::max<long long>(65536, 64ll*ctx->nb), 1ll << 24);
         int *dcells = nullptr, *dfacets = nullptr, *dcls = nullptr;
@@ -715,7 +715,7 @@ int launch_boundary(pnl_context *ctx, int cell_begin, int cell_end, int what = 3
 
 // block-slot storage of the one-sided operator (pnl_tile2.h): allocated when the device has room for it next to the caller's matrix
 bool slot_storage_ready(pnl_context *ctx) {
-    if (ctx->nonsym || getenv("PNL_NO_SLOT")) return false;
+    if (ctx->nonsym || pnl_tune("PNL_NO_SLOT")) return false;
     size_t free_b = 0, total_b = 0;
     const size_t need = sizeof(double)*(size_t)ctx->slot_total;
     if (ctx->b_slotA.bytes >= need) return true;
@@ -740,7 +740,7 @@ int launch_tiles_single(pnl_context *ctx, double *A, int64_t ldA, int cell_begin
         all_fast = all_fast && ctx->P.k.fast;
         all_half = all_half && ctx->P.k.fast && ctx->P.k.qm == 6;
     }
-    const int kt = (all_half && !getenv("PNL_NO_KT2")) ? 2 : (all_fast ? 1 : 0);
+    const int kt = (all_half && !pnl_tune("PNL_NO_KT2")) ? 2 : (all_fast ? 1 : 0);
     if ((rc = ensure(ctx, ctx->b_kcls, sizeof(DevKernel)*ncls))) return rc;
     if ((rc = ensure(ctx, ctx->b_fcls, sizeof(DevFormula)*ncls))) return rc;
     HIPCHK(ctx, hipMemcpyAsync(ctx->b_kcls.p, ctx->kcls_host.data(), sizeof(DevKernel)*ncls, hipMemcpyHostToDevice, ctx->stream));
@@ -797,7 +797,7 @@ int launch_tiles_single(pnl_context *ctx, double *A, int64_t ldA, int cell_begin
 // the whole upper block triangle is assembled by this call and mirrored afterwards
 bool slot_eligible(const pnl_context *ctx, int cell_begin, int cell_end, int flags) {
     // P2: every tile list (several order classes: multi-visit tiles accumulate); P1: one class, every tile visited by one kernel
-    const bool elem = ctx->dpe == 6 || (ctx->dpe == 3 && ctx->cls.size() == 1 && !ctx->nonsym && ctx->use_pure && !getenv("PNL_NO_SLOT_P1"));
+    const bool elem = ctx->dpe == 6 || (ctx->dpe == 3 && ctx->cls.size() == 1 && !ctx->nonsym && ctx->use_pure && !pnl_tune("PNL_NO_SLOT_P1"));
     return ctx->dim == 2 && elem && ctx->slot_full_list && ctx->slab_rows == 0 && cell_begin == 0 && cell_end == ctx->nc &&
            !(flags & (PNL_FLAG_NO_MIRROR | PNL_FLAG_SYMMETRIC_FLUSH));
 }
@@ -817,7 +817,7 @@ int assemble_impl(pnl_context *ctx, double *A, int64_t ldA, int zero_exterior, i
     // variable order, zero exterior: the distant (cell, facet) pairs of ALL classes run in one launch with per-class kernel /
     // order-formula tables; the tables go up now, ahead of the tile kernels, so that the launch needs nothing from the
     // caller's stream later than the fold
-    const bool bnd_one_pass = zero_exterior && ncls > 1 && ctx->nlab > 0 && !getenv("PNL_BND_PER_CLASS");
+    const bool bnd_one_pass = zero_exterior && ncls > 1 && ctx->nlab > 0 && !pnl_tune("PNL_BND_PER_CLASS");
     bool bnd_all_fast = true;
     if (bnd_one_pass) {
         std::vector<DevKernel> &bk = ctx->bkcls_host;
@@ -864,7 +864,7 @@ int assemble_impl(pnl_context *ctx, double *A, int64_t ldA, int zero_exterior, i
             if (ctx->n_mixed+ctx->n_pure+ctx->cls_n_uni[1][k]+ctx->cls_n_uni[2][k] == 0) continue;
             const int tb0 = ctx->tile_cell_filter ? cell_begin : 0, tb1 = ctx->tile_cell_filter ? cell_end : ctx->nc;
             // s = 1/2 in 2D (exponent -6/4) has its own instantiation: branch-free evaluations
-            if (ctx->P.k.fast && ctx->P.k.qm == 6 && DPE == 3 && !getenv("PNL_NO_KT2")) rc = launch_tiles<DIM, DPE, TILE, (DPE == 3 ? 2 : 1)>(ctx, ko, A, ldA, tb0, tb1, SO);
+            if (ctx->P.k.fast && ctx->P.k.qm == 6 && DPE == 3 && !pnl_tune("PNL_NO_KT2")) rc = launch_tiles<DIM, DPE, TILE, (DPE == 3 ? 2 : 1)>(ctx, ko, A, ldA, tb0, tb1, SO);
             else rc = ctx->P.k.fast ? launch_tiles<DIM, DPE, TILE, 1>(ctx, ko, A, ldA, tb0, tb1, SO)
                                     : launch_tiles<DIM, DPE, TILE, 0>(ctx, ko, A, ldA, tb0, tb1, SO);
             if (rc) { ctx->cur = 0; ctx->orient = 0; return rc; }
@@ -886,12 +886,12 @@ int assemble_impl(pnl_context *ctx, double *A, int64_t ldA, int zero_exterior, i
     // fold, next to the work-list kernels on the caller's stream -- everything after the fold only adds with atomics.  The
     // phase timers then show what is left of them after the work list ("singular"), the boundary phase reads 0
     hipStream_t const main_stream = ctx->stream;
-    const bool overlap = ctx->fold_event_set && ncls*norient == 1 && !getenv("PNL_NO_OVERLAP");
+    const bool overlap = ctx->fold_event_set && ncls*norient == 1 && !pnl_tune("PNL_NO_OVERLAP");
     struct StreamGuard { pnl_context *c; hipStream_t s; ~StreamGuard() { c->stream = s; } } stream_guard{ctx, main_stream};
     if (overlap) { HIPCHK(ctx, hipStreamWaitEvent(ctx->aux[0], ctx->ev_fold, 0)); ctx->stream = ctx->aux[0]; }
     // several classes behind a fold pass: the side streams of the touching pairs and of the boundary term start at the fold
     // too, class k follows the work list of class k on its stream, nothing waits for the other classes
-    hipEvent_t const chain = (ctx->fold_event_set && !overlap && !getenv("PNL_NO_OVERLAP")) ? ctx->ev_fold : nullptr;
+    hipEvent_t const chain = (ctx->fold_event_set && !overlap && !pnl_tune("PNL_NO_OVERLAP")) ? ctx->ev_fold : nullptr;
     {
         ClassFork fork(ctx, ncls*norient, chain);
         for (int ko = 0; ko < ncls*norient; ko++) {
@@ -1004,7 +1004,7 @@ int pairs_masked_impl(pnl_context *ctx, int np, const SparseOut &S, bool classif
     {
         const int st = 4+DPE;
         // LDS copy of the rule: see run_worklist (PNL_WL_MP_KB: A/B switch of the sparse path)
-        const int wl_kb = getenv("PNL_WL_MP_KB") ? std::max(4, atoi(getenv("PNL_WL_MP_KB"))) : 60;
+        const int wl_kb = pnl_tune("PNL_WL_MP_KB") ? std::max(4, atoi(pnl_tune("PNL_WL_MP_KB"))) : 60;
         const int tab_max = (wl_kb*1024)/(st*(int)sizeof(double));
         const int wl_grid = 256*std::max(1, std::min(8, 150/(wl_kb+(KT == 0 ? 3 : 0))));
         const size_t lds = (size_t)tab_max*st*sizeof(double);
@@ -1101,7 +1101,7 @@ int clusters_tiled_impl(pnl_context *ctx, const pnl_cluster_plan *pl, ClusterTil
         HIPCHK(ctx, hipFuncSetAttribute((const void*)kfun, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         int per_cu = 2;
         (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)kfun, tile_threads(DPE, KT), lds);
-        if (getenv("PNL_VERBOSE")) fprintf(stderr, "[pnl] cluster tiles=%d nU=%d lds=%zu bytes, occupancy API: %d blocks/CU\n", pl->ntiles,
+        if (pnl_tune("PNL_VERBOSE")) fprintf(stderr, "[pnl] cluster tiles=%d nU=%d lds=%zu bytes, occupancy API: %d blocks/CU\n", pl->ntiles,
                                            pl->chunk_stride, lds, per_cu);
         const int grid = std::min(pl->ntiles, 256*std::max(per_cu, 1));
         hipLaunchKernelGGL(kfun, dim3(grid), dim3(tile_threads(DPE, KT)), lds, ctx->stream, ctx->P, (const int2*)nullptr, (double*)nullptr, 0ll,
@@ -1114,7 +1114,7 @@ int clusters_tiled_impl(pnl_context *ctx, const pnl_cluster_plan *pl, ClusterTil
     // stream 0 and the cluster-local boundary term on side stream 1 next to the work-list kernels; joined before the diagonal
     // blocks are scattered.  The phase timers then show what is left of them after the work list
     hipStream_t const main_stream = ctx->stream;
-    const bool overlap = !getenv("PNL_NO_OVERLAP");
+    const bool overlap = !pnl_tune("PNL_NO_OVERLAP");
     struct StreamGuard { pnl_context *c; hipStream_t s; ~StreamGuard() { c->stream = s; } } stream_guard{ctx, main_stream};
     if (overlap) {
         HIPCHK(ctx, hipEventRecord(ctx->ev_fold, main_stream));
@@ -1134,7 +1134,7 @@ int clusters_tiled_impl(pnl_context *ctx, const pnl_cluster_plan *pl, ClusterTil
                            (int4*)ctx->b_wlsorted.p);
         const int st = 4+DPE;
         // LDS copy of the rule: see run_worklist (PNL_WL_CL_KB: A/B switch of the cluster path)
-        const int wl_kb = getenv("PNL_WL_CL_KB") ? std::max(4, atoi(getenv("PNL_WL_CL_KB"))) : 18;      // 60 KB / two workgroups per CU: + 4 ms at C4
+        const int wl_kb = pnl_tune("PNL_WL_CL_KB") ? std::max(4, atoi(pnl_tune("PNL_WL_CL_KB"))) : 18;      // 60 KB / two workgroups per CU: + 4 ms at C4
         const int tab_max = (wl_kb*1024)/(st*(int)sizeof(double));
         const size_t wlds = (size_t)tab_max*st*sizeof(double);
         const int wl_grid = 256*std::max(1, std::min(8, 150/(wl_kb+(KT == 0 ? 3 : 0))));
@@ -1187,7 +1187,7 @@ int clusters_tiled_impl(pnl_context *ctx, const pnl_cluster_plan *pl, ClusterTil
     if (cluster_boundary && pl->num_dslots > 0 && pl->nfacets > 0) {
         if (!ctx->C().have_kernel[1] || !ctx->C().have_form[1]) return fail(ctx, PNL_ERR_STATE, "boundary kernel and order formula must be set");
         // few cells (those of cellsInter), many facets each: small facet chunks give the parallelism
-        const int per = getenv("PNL_CB_PER") ? atoi(getenv("PNL_CB_PER")) : 2;
+        const int per = pnl_tune("PNL_CB_PER") ? atoi(pnl_tune("PNL_CB_PER")) : 2;
         const dim3 grid((pl->num_dslots+PNL_NTHREADS-1)/PNL_NTHREADS, (maxf+per-1)/per);
         const double *verts = (const double*)ctx->b_vertices.p;
         if (ctx->P.bkn.fast)
@@ -1407,7 +1407,7 @@ int pointwise_impl(pnl_context *ctx, double *A, int64_t ldA, int zero_exterior, 
         // themselves (overflow is detected by pnl_get_counters); the tile-less variant lists every pair of the cell range
         double pairs = 0.;
         for (long long c = cell_begin; c < cell_end; c++) pairs += (double)(ctx->nc-c);
-        const bool tiles_evaluate = ctx->tile == 64 && !getenv("PNL_PW_NOMIXED");
+        const bool tiles_evaluate = ctx->tile == 64 && !pnl_tune("PNL_PW_NOMIXED");
         const size_t want = tiles_evaluate ? (size_t)std::min<double>(std::max<double>(pairs*0.1, 1 << 20), 400e6)
                                            : (size_t)std::max<double>(pairs, 1024.);
         if (want > 1500000000ull) return fail(ctx, PNL_ERR_UNSUPPORTED, "%zu pairs exceed the work list of the pointwise path", want);
@@ -1438,7 +1438,7 @@ int pointwise_impl(pnl_context *ctx, double *A, int64_t ldA, int zero_exterior, 
             if (DIM == 2) { F.a = sv-1.; F.b = 1.; F.e = sv; F.den0 = 0.4; } else { F.a = 2.*sv-1.; F.b = 0.; F.e = 2.*sv; F.den0 = 0.8; }
             return F;
         };
-        const bool allow = ctx->tile == T && ctx->qmax >= 2 && !getenv("PNL_PW_NOTILE");
+        const bool allow = ctx->tile == T && ctx->qmax >= 2 && !pnl_tune("PNL_PW_NOTILE");
         const int a0 = cell_begin/T, a1 = (cell_end+T-1)/T;
         for (int d = 0; d < nbk; d++)
             for (int a = a0; a < a1 && a+d < nbk; a++) {
@@ -1472,7 +1472,7 @@ int pointwise_impl(pnl_context *ctx, double *A, int64_t ldA, int zero_exterior, 
     }
     HIPCHK(ctx, hipEventRecord(ctx->ev[7], ctx->stream));
     // the other tiles: classification, in-tile evaluation of the rules with at most 16 points (LDS sub-blocks), work list for the rest
-    const bool in_tile = ctx->tile == 64 && !getenv("PNL_PW_NOMIXED");
+    const bool in_tile = ctx->tile == 64 && !pnl_tune("PNL_PW_NOMIXED");
     if (!mixed.empty() && in_tile) {
         const int acc_stride = ctx->nU+1;
         const size_t lds = sizeof(double)*(PNL_PW_LANE_MAXPTS*ST+64*PNL_PW_LANE_MAXPTS*2+2*64*ND)+sizeof(unsigned short)*64*64
@@ -1508,7 +1508,7 @@ int pointwise_impl(pnl_context *ctx, double *A, int64_t ldA, int zero_exterior, 
         const size_t lds = sizeof(double)*((size_t)tab_max*ST+(size_t)(PNL_NTHREADS/16)*tab_max*2);
         auto kfun = k_pw_distant<DIM>;
         HIPCHK(ctx, hipFuncSetAttribute((const void*)kfun, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        const bool lane_kernel = !getenv("PNL_PW_NOLANE");      // (with the in-tile evaluation only the rules of more than 16 points arrive here)
+        const bool lane_kernel = !pnl_tune("PNL_PW_NOLANE");      // (with the in-tile evaluation only the rules of more than 16 points arrive here)
         if (lane_kernel)
             hipLaunchKernelGGL((k_pw_lane<DIM>), dim3(256*2), dim3(PNL_NTHREADS), 0, ctx->stream, P, W, (const int4*)ctx->b_wlsorted.p,
                                (const unsigned*)offs, A, (long long)ldA, (double*)ctx->b_D.p);
@@ -1591,7 +1591,7 @@ int horizon_impl(pnl_context *ctx, SparseOut S) {
     using TS = TileSmem<DIM, DPE, TILE, KT == 0>;
     const int acc_stride = acc_stride_of(ctx->nU, TS::fixed_bytes);
     const size_t lds = TS::fixed_bytes+sizeof(double)*(size_t)(ctx->nU+1)*acc_stride;
-    const bool use_tiles = T == TILE && lds <= 160*1024 && !getenv("PNL_FH_NOTILES");
+    const bool use_tiles = T == TILE && lds <= 160*1024 && !pnl_tune("PNL_FH_NOTILES");
     ctx->visited_is_assembled = use_tiles;
     for (size_t t0 = 0; t0 < tiles.size(); t0 += chunk_tiles) {
         const int nt = (int)std::min(chunk_tiles, tiles.size()-t0);
@@ -1642,9 +1642,52 @@ int horizon_impl(pnl_context *ctx, SparseOut S) {
 }
 }  // namespace
 
+// ---- options (pnl_context.h: pnl_tune) --------------------------------------------------------------------------------------
+#include <map>
+#include <mutex>
+namespace {
+std::mutex g_opt_mutex;
+std::map<std::string, std::string> g_options;
+// the options a product build accepts: the hooks through which the parity tests reach the alternative code paths, and the
+// diagnostics line
+const char *const k_product_options[] = {"PNL_WL_FRAC", "PNL_FH_NOTILES", "PNL_NO_POWTAB", "PNL_VERBOSE", "PNL_PLAN_TIMING"};
+}  // namespace
+
+const char *pnl_tune(const char *name) {
+    {
+        std::lock_guard<std::mutex> lk(g_opt_mutex);
+        auto it = g_options.find(name);
+        if (it != g_options.end()) return it->second.c_str();      // std::map nodes are stable; values change only through pnl_set_option
+    }
+#ifdef PNL_TUNING
+    return getenv(name);
+#else
+    return nullptr;
+#endif
+}
+
 extern "C" {
 
-const char *pnl_version(void) { return "pnl_hip 0.1 (gfx950)"; }
+const char *pnl_version(void) {
+#ifdef PNL_TUNING
+    return "pnl_hip 0.1 (gfx950, tuning build)";
+#else
+    return "pnl_hip 0.1 (gfx950)";
+#endif
+}
+
+int pnl_set_option(const char *name, const char *value) {
+    if (!name) return PNL_ERR_INVALID;
+#ifndef PNL_TUNING
+    bool known = false;
+    for (const char *k : k_product_options) known = known || std::strcmp(k, name) == 0;
+    if (!known) return PNL_ERR_UNSUPPORTED;
+#endif
+    std::lock_guard<std::mutex> lk(g_opt_mutex);
+    if (value) g_options[name] = value;
+    else g_options.erase(name);
+    return PNL_OK;
+}
 
 int pnl_create(int device_id, pnl_context **out) {
     if (!out) return PNL_ERR_INVALID;
@@ -1672,10 +1715,10 @@ int pnl_create(int device_id, pnl_context **out) {
             if (hipEventCreate(&e) != hipSuccess) { delete ctx; return PNL_ERR_HIP; }
     std::memset(&ctx->P, 0, sizeof(ctx->P));
 #ifdef PNL_DEBUG_ABLATE
-    if (const char *e = getenv("PNL_ABLATE")) ctx->ablate = atoi(e);      // result-changing debug switches: debug builds only
+    if (const char *e = pnl_tune("PNL_ABLATE")) ctx->ablate = atoi(e);      // result-changing debug switches: debug builds only
 #endif
-    if (const char *e = getenv("PNL_WL_LANE")) ctx->wl_lane = atoi(e) != 0;
-    if (const char *e = getenv("PNL_PURE")) ctx->use_pure = atoi(e) != 0;
+    if (const char *e = pnl_tune("PNL_WL_LANE")) ctx->wl_lane = atoi(e) != 0;
+    if (const char *e = pnl_tune("PNL_PURE")) ctx->use_pure = atoi(e) != 0;
     ctx->cls.push_back(new pnl_context::ClassData());
     *out = ctx;
     return PNL_OK;
@@ -1975,7 +2018,7 @@ static int upload_tiles(pnl_context *ctx, std::vector<int2> &tiles, int cell_beg
     int qlimit = 2;
     if (ctx->dim == 2) for (int q = 3; q <= 4 && ctx->uni_off[q] >= 0 && ctx->uni_np[q] == 6 && q <= ctx->qmax; q++) qlimit = q;
     const bool q2ok = p1 ? true : (ctx->uni_off[2] >= 0 && ctx->uni_np[2] == 3);
-    if (getenv("PNL_UNI_QMAX")) qlimit = std::min(qlimit, std::max(2, atoi(getenv("PNL_UNI_QMAX"))));
+    if (pnl_tune("PNL_UNI_QMAX")) qlimit = std::min(qlimit, std::max(2, atoi(pnl_tune("PNL_UNI_QMAX"))));
     // variable order: a class only visits the tiles whose blocks hold a label pair of that class (most blocks carry one
     // label, so the K passes together classify every tile about once instead of K times)
     const int L = ctx->nlab;
@@ -2020,7 +2063,7 @@ static int upload_tiles(pnl_context *ctx, std::vector<int2> &tiles, int cell_beg
         for (auto &th : pool) th.join();
         // tiles the bounds left open: the exact order range of their cell pairs, on the device (2D; variable order: tiles whose
         // two blocks carry one label each -- their pairs all belong to this class and see its order formula)
-        if (allow && ctx->dim == 2 && (T == 64 || T == 32) && !getenv("PNL_NO_EXACT_TILES")) {
+        if (allow && ctx->dim == 2 && (T == 64 || T == 32) && !pnl_tune("PNL_NO_EXACT_TILES")) {
             std::vector<int2> cand;
             std::vector<size_t> cand_idx;
             for (size_t i = 0; i < tiles.size(); i++) {
@@ -2052,7 +2095,7 @@ static int upload_tiles(pnl_context *ctx, std::vector<int2> &tiles, int cell_beg
                     if (q < 2 || q > qlimit || (q == 2 && !q2ok)) continue;
                     qof[cand_idx[c]] = (signed char)q; moved++;
                 }
-                if (getenv("PNL_VERBOSE")) fprintf(stderr, "[pnl] exact order range: %zu of %zu open tiles are uniform\n", moved, cand.size());
+                if (pnl_tune("PNL_VERBOSE")) fprintf(stderr, "[pnl] exact order range: %zu of %zu open tiles are uniform\n", moved, cand.size());
             }
         }
         for (size_t i = 0; i < tiles.size(); i++) {
@@ -2079,7 +2122,7 @@ static int upload_tiles(pnl_context *ctx, std::vector<int2> &tiles, int cell_beg
         ctx->sl_off[0] = 0;
         // symmetric order tables: a tile that holds pairs of several classes gets ONE entry that names the set of them (bit 29
         // + class bits); k_tile_p2 works through the classes inside one visit and flushes once with plain stores
-        const bool one_visit = norient == 1 && ncls > 1 && ncls <= 28 && !getenv("PNL_P2_VISIT_PER_CLASS");
+        const bool one_visit = norient == 1 && ncls > 1 && ncls <= 28 && !pnl_tune("PNL_P2_VISIT_PER_CLASS");
         std::vector<unsigned> tile_mask;
         if (one_visit) {
             tile_mask.assign((size_t)ctx->nblocks*ctx->nblocks, 0u);
@@ -2131,7 +2174,7 @@ static int upload_tiles(pnl_context *ctx, std::vector<int2> &tiles, int cell_beg
         int rc2 = upload(ctx, ctx->b_tilecls, allcls.data(), allcls.size());
         if (rc2) return rc2;
     }
-    if (getenv("PNL_VERBOSE")) {
+    if (pnl_tune("PNL_VERBOSE")) {
         size_t nm = 0, nu[3] = {0, 0, 0};
         for (int k = 0; k < ncls; k++) { nm += mixed[k].size(); for (int u = 0; u < 3; u++) nu[u] += uni[u][k].size(); }
         fprintf(stderr, "[pnl] tiles: %zu mixed, uniform order 2/3/4: %zu / %zu / %zu (qlimit %d)\n", nm, nu[0], nu[1], nu[2], qlimit);
@@ -2190,7 +2233,7 @@ int pnl_assemble_dense(pnl_context *ctx, double *A, int64_t ldA, int zero_exteri
     unsigned long long visited = 0;
     for (long long c = cell_begin; c < cell_end; c++) visited += (unsigned long long)(ctx->nc-c);
     ctx->visited_pairs = visited; ctx->visited_is_assembled = false;
-    if (getenv("PNL_FORCE_SYMFLUSH")) flags |= PNL_FLAG_SYMMETRIC_FLUSH;     // debug: both sides written by the flush, no mirror pass
+    if (pnl_tune("PNL_FORCE_SYMFLUSH")) flags |= PNL_FLAG_SYMMETRIC_FLUSH;     // debug: both sides written by the flush, no mirror pass
     ctx->slot_full_list = true;
     return dispatch(ctx, A, ldA, zero_exterior, (int)tiles.size(), cell_begin, cell_end, flags);
 }
@@ -2234,7 +2277,7 @@ int pnl_dense_overwrites(pnl_context *ctx, int cell_begin, int cell_end, int fla
     int rc;
     if ((rc = check_ready(ctx))) return rc;
     if ((rc = finalize(ctx))) return rc;
-    if (getenv("PNL_FORCE_SYMFLUSH")) return 0;
+    if (pnl_tune("PNL_FORCE_SYMFLUSH")) return 0;
     const bool full = ctx->slot_full_list;
     ctx->slot_full_list = true;                          // what pnl_assemble_dense sets
     const bool ok = slot_eligible(ctx, cell_begin, cell_end, flags) && slot_storage_ready(ctx);

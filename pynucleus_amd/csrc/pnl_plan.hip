@@ -24,6 +24,8 @@
 #include <cstdlib>
 #include "pnl_hip.h"
 
+extern "C++" const char *pnl_tune(const char *name);     // pnl_hip.hip: options set through pnl_set_option
+
 namespace {
 
 struct PNode {
@@ -356,7 +358,7 @@ int pnl_nfplan_build(int dim, int nv, const double *vertices, int nc, const int3
     const int nV = dim+1;
     pnl_nfplan *P = new pnl_nfplan();
     P->tile = tile; P->dpe = dpe; P->dim = dim;
-    const bool timing = getenv("PNL_PLAN_TIMING") != nullptr;
+    const bool timing = pnl_tune("PNL_PLAN_TIMING") != nullptr;
     auto tnow = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     double tt[8] = {0}, t_last = tnow();
     auto lap = [&](int k) { const double t = tnow(); tt[k] += t-t_last; t_last = t; };
@@ -715,6 +717,10 @@ int pnl_nfplan_get(const pnl_nfplan *P, int which, void *dst) {
 // within delta and M = DoF -> vertices of its patch (builder.getSparse formed it with scipy sparse products: 0.45 s at
 // 129^2 vertices).  Here: vertices within delta through a uniform grid, then per DoF a bitmap over the DoFs, rows in
 // parallel.
+// largest number of stored entries a pattern may have: the row pointer is int32 like the reference's INDEX_t
+// (pnl_pattern_set_max_nnz lowers it; tests force the guard with it)
+static long long g_pattern_max_nnz = 2147483647ll;
+
 struct pnl_pattern {
     std::vector<int32_t> indptr, indices;
     // near-field pattern: the rows of a leaf share one sorted column list; pnl_pattern_get writes the rows straight into the
@@ -774,7 +780,7 @@ int pnl_near_pattern(const pnl_tree *T, int npairs, const int32_t *pairs, int st
         const auto &v = leaf_cols[leaf_of[I]];
         const long long cnt = strict_lower ? (std::lower_bound(v.begin(), v.end(), I)-v.begin()) : (long long)v.size();
         total += cnt;
-        if (total >= (1ll << 31)) { delete P; return PNL_ERR_UNSUPPORTED; }
+        if (total > g_pattern_max_nnz) { delete P; return PNL_ERR_UNSUPPORTED; }
         P->indptr[I+1] = (int32_t)total;
     }
     P->nnz_gen = total;
@@ -921,15 +927,23 @@ int pnl_horizon_pattern(int dim, int nv, const double *vertices, int nc, const i
         int I = 0;
         size_t total = 0;
         for (Rows &R : rows) total += R.idx.size();
+        // INDEX_t is 32 bits (the CSR / SSS operators and pnl_upload_sparsity index with int32): refuse instead of wrapping
+        if ((long long)total > g_pattern_max_nnz) { delete P; return PNL_ERR_UNSUPPORTED; }
         P->indices.reserve(total);
         for (Rows &R : rows) {
-            for (int l : R.len) { P->indptr[I+1] = P->indptr[I]+l; I++; }
+            for (int l : R.len) { P->indptr[I+1] = (int32_t)((long long)P->indptr[I]+l); I++; }
             P->indices.insert(P->indices.end(), R.idx.begin(), R.idx.end());
         }
     }
-    if (getenv("PNL_PLAN_TIMING")) fprintf(stderr, "[pnl_pattern] vertex neighbours %.3f rows %.3f merge %.3f s (%d threads)\n", tp1-tp0, tp2-tp1, tnow()-tp2, nthreads);
+    if (pnl_tune("PNL_PLAN_TIMING")) fprintf(stderr, "[pnl_pattern] vertex neighbours %.3f rows %.3f merge %.3f s (%d threads)\n", tp1-tp0, tp2-tp1, tnow()-tp2, nthreads);
     *out = P;
     return PNL_OK;
+}
+
+int64_t pnl_pattern_set_max_nnz(int64_t max_nnz) {
+    const long long old = g_pattern_max_nnz;
+    if (max_nnz > 0 && max_nnz <= 2147483647ll) g_pattern_max_nnz = max_nnz;
+    return old;
 }
 
 int64_t pnl_pattern_nnz(const pnl_pattern *P) { return P ? (P->nnz_gen >= 0 ? (int64_t)P->nnz_gen : (int64_t)P->indices.size()) : -1; }

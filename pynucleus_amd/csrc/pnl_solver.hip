@@ -277,7 +277,17 @@ int pnl_mg_solve(pnl_mg *mg, const double *b_dev, double *x_dev, double tol, int
     };
     if (top == 0) {
         // one level: the coarse solver is the solver
+        // residual history like the multi-level case: ||b - A x0|| before, ||b - A x|| after the one (direct) solve
+        int nres1 = 0;
+        if (residuals && residuals_cap > 0) {
+            if ((rc = residual_norm(simple))) return rc;
+            residuals[nres1++] = std::sqrt(n2);
+        }
         if ((rc = gemv(ctx, mg->coarse_inv, L.n, L.n, L.n, b_dev, 1., 0., nullptr, x_dev))) return rc;
+        if (residuals && nres1 < residuals_cap && L.A_dev) {
+            if ((rc = residual_norm(false))) return rc;
+            residuals[nres1++] = std::sqrt(n2);
+        }
         if (iters) *iters = 1;
         return PNL_OK;
     }
@@ -356,8 +366,10 @@ int pnl_mg_cg(pnl_mg *mg, const double *A_dev, int64_t ldA, const double *b_dev,
 int pnl_theta_step(pnl_mg *mg, const double *S_dev, int64_t ldS, const int32_t *M_indptr_dev, const int32_t *M_indices_dev,
                    const double *M_data_dev, double dt, double theta, const double *forcing_dev, double *u_dev, double tol, int maxiter,
                    int *iters, double *residual) {
-    if (!mg || !S_dev || !M_indptr_dev || !M_indices_dev || !M_data_dev || !u_dev || !(dt > 0.) || theta < 0. || theta > 1.) return PNL_ERR_INVALID;
+    if (!mg) return PNL_ERR_INVALID;
     pnl_context *ctx = mg->ctx;
+    if (!S_dev || !M_indptr_dev || !M_indices_dev || !M_data_dev || !u_dev || !(dt > 0.) || theta < 0. || theta > 1.)
+        return fail(ctx, PNL_ERR_INVALID, "pnl_theta_step: null operator / vector, dt <= 0 or theta outside [0, 1]");
     const int n = mg->lv[mg->nlevels-1].n;
     if (ldS < n) return fail(ctx, PNL_ERR_INVALID, "pnl_theta_step: ldS < n");
     double *rhs = (double*)mg->work.p;

@@ -23,7 +23,7 @@ int launch_uniform_t(pnl_context *ctx, const DevProblem &Pt, const int2 *tiles, 
     // P1: 108-168 VGPRs allow three or four waves per SIMD and as many 38-53 KB workgroups share a CU (order-3 tiles of a general
     // exponent 36.4 -> 28.8 ms at 98,304 cells, s = 1/2: 17.8 -> 17.2; order-2 tiles of s = 1/2 with four: 42.8 -> 41.3 ms);
     // P2: two workgroups of 80 KB
-    const size_t cap_cu = (size_t)std::max(1, getenv("PNL_UNI_PER_CU") ? atoi(getenv("PNL_UNI_PER_CU")) : 4);
+    const size_t cap_cu = (size_t)std::max(1, pnl_tune("PNL_UNI_PER_CU") ? atoi(pnl_tune("PNL_UNI_PER_CU")) : 4);
     auto kfun = k_tile_uniform<DPE, NP, KT>;
     HIPCHK(ctx, hipFuncSetAttribute((const void*)kfun, hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::min<size_t>(160*1024, lds+sizeof(double)*PNL_POW_TAB_DOUBLES)));
     // workgroups that are really resident per CU (LDS and registers): the tile loop strides by the grid, a workgroup that has
@@ -42,7 +42,7 @@ int launch_uniform_t(pnl_context *ctx, const DevProblem &Pt, const int2 *tiles, 
         const size_t tab = sizeof(double)*PNL_POW_TAB_DOUBLES;
         const int per_cu0 = resident(lds);
         if (lds+tab <= 160*1024 && resident(lds+tab) == per_cu0) { lds += tab; pow_flag = 8; }
-        else if (!getenv("PNL_UNI_KEEP_STRIDE")) {
+        else if (!pnl_tune("PNL_UNI_KEEP_STRIDE")) {
             // the padded row stride of the sub-block (fewer LDS bank conflicts) or the tables: the tables win (measured)
             const int odd = (nUe+1) | 1;
             const size_t alt = fixed+sizeof(double)*(size_t)(nUe+1)*odd+tab;
@@ -52,12 +52,12 @@ int launch_uniform_t(pnl_context *ctx, const DevProblem &Pt, const int2 *tiles, 
     HIPCHK(ctx, hipFuncSetAttribute((const void*)kfun, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int per_cu = resident(lds);
     const int grid = std::min(ntiles, 256*per_cu);
-    if (getenv("PNL_VERBOSE"))
+    if (pnl_tune("PNL_VERBOSE"))
         fprintf(stderr, "[pnl] uniform tiles of order %d: %d, dpe=%d np=%d kt=%d lds=%zu bytes (%d per CU), acc_stride=%d\n", q, ntiles, DPE,
                 NP, KT, lds, per_cu, acc_stride);
     int uni_abl = 0;
 #ifdef PNL_DEBUG_ABLATE
-    uni_abl = getenv("PNL_UNI_ABL") ? atoi(getenv("PNL_UNI_ABL")) : 0;
+    uni_abl = pnl_tune("PNL_UNI_ABL") ? atoi(pnl_tune("PNL_UNI_ABL")) : 0;
 #endif
     kt_begin(ctx, PNL_K_TILE_UNIFORM2+(q-2));
     hipLaunchKernelGGL(kfun, dim3(grid), dim3(256), lds, ctx->stream, Pt, tiles, tile_cls, (const DevKernel*)ctx->b_kcls.p, ntiles, A,
@@ -93,7 +93,7 @@ int launch_p2_t(pnl_context *ctx, const int2 *tiles, const int *tile_cls, int nt
     HIPCHK(ctx, hipFuncSetAttribute((const void*)kfun, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     // two tiles per workgroup are taken by block index, the rest through tickets: a grid of at most ntiles / 2 workgroups
     const int grid = std::max(1, std::min((ntiles+1)/2, 256));
-    if (getenv("PNL_VERBOSE")) fprintf(stderr, "[pnl] P2 general tiles=%d nU=%d kt=%d lds=%zu bytes acc_stride=%d\n", ntiles, ctx->nU, KT, lds, stride);
+    if (pnl_tune("PNL_VERBOSE")) fprintf(stderr, "[pnl] P2 general tiles=%d nU=%d kt=%d lds=%zu bytes acc_stride=%d\n", ntiles, ctx->nU, KT, lds, stride);
     kt_begin(ctx, PNL_K_TILE_GENERAL);
     hipLaunchKernelGGL(kfun, dim3(grid), dim3(P2_NT), lds, ctx->stream, ctx->P, tiles, tile_cls, (const DevKernel*)ctx->b_kcls.p,
                        (const DevFormula*)ctx->b_fcls.p, A, (long long)ldA, (double*)ctx->b_D.p, cell_begin, cell_end, stride,

@@ -62,6 +62,12 @@ class DistributedH2Matrix_localData:
         nodes, parent, level = flat
         nid = {id(n): k for k, n in enumerate(nodes)}
         owner, cut = subtree_owners(flat, size)
+        # every rank computes the ownership of ALL ranks, so the check below fails on every rank alike (no rank walks on into a
+        # collective the others never reach)
+        empty = sorted(set(range(size))-set(int(owner[k]) for k in cut))
+        if empty:
+            raise NotImplementedError('rank(s) {} would own no subtree ({} subtrees at the cut level for {} ranks: tree too shallow or '
+                                      'DoF weights too skewed); use the all-reduce operator (localFarFieldIndexing=False)'.format(empty, len(cut), size))
         self.node_owner = owner
         dof_owner = np.full(N, -1, dtype=np.int64)
         for k in cut:

@@ -25,16 +25,13 @@ class Dense_LinearOperator:
         self.num_rows, self.num_columns = A_dev.shape
         self.shape = (self.num_rows, self.num_columns)
         self.info = info or {}
-        self._host = None
 
     # reference API -------------------------------------------------------
     @property
     def data(self):
-        """the matrix as a numpy array (copied from HBM on first use)"""
-        if self._host is None:
-            self.ctx.synchronize()
-            self._host = self.A.cpu().numpy()
-        return self._host
+        """the matrix as a numpy array: a fresh copy from HBM on every access (the device block may be assembled into again)"""
+        self.ctx.synchronize()
+        return self.A.cpu().numpy()
 
     def toarray(self):
         return self.data
@@ -125,7 +122,6 @@ class DistributedDense_LinearOperator(Dense_LinearOperator):
         import torch.distributed as dist
         self.ctx.synchronize()
         dist.all_reduce(self.A, group=self.group)
-        self._host = None
         return Dense_LinearOperator(self.A, self.ctx, self.info)
 
 
@@ -434,6 +430,17 @@ class DistributedSparse_LinearOperator:
         self.num_rows, self.num_columns = local.num_rows, local.num_columns
         self.shape = local.shape
         self.info = local.info
+        self.device = local.device
+
+    @property
+    def diagonal(self):
+        """sum over the ranks of the local diagonals (every diagonal entry belongs to exactly one rank's blocks)"""
+        import torch.distributed as dist
+        d = torch.from_numpy(np.ascontiguousarray(self.local.diagonal, dtype=np.float64))
+        if dist.get_backend(self.group) != 'gloo':
+            d = d.to(self.device)
+        dist.all_reduce(d, group=self.group)
+        return d.cpu().numpy()
 
     def matvec(self, x, y=None):
         import torch.distributed as dist

@@ -439,6 +439,10 @@ class CrankNicolson:
         self.M = _DevCSR(levels[-1]['M'], self.device)
         self.transient = buildTransientHierarchy(levels, 1./self.dt, self.theta)
         self.solver = multigrid(self.transient, smoother=smoother)
+        if not getattr(self.solver, '_native', False):
+            # pnl_theta_step drives the library's own V cycle: dense levels and the Jacobi smoother
+            raise NotImplementedError('time stepping needs the library multigrid (dense levels, Jacobi smoother); '
+                                      'got smoother={!r} / a level that is not dense'.format(smoother))
         self.iterations = []
 
     def setRHS(self, g_t, g_tdt):

@@ -58,19 +58,40 @@ def test_product_does_not_import_oracle():
 
 
 @pytest.mark.gpu
-def test_work_list_overflow_fails_the_call(monkeypatch):
-    """a work list that is too small (PNL_WL_FRAC shrinks it to 64 entries per pass) must not pass silently: the status of
-    pnl_synchronize / pnl_get_counters says the operator is incomplete (the check INTEGRATION.md's stub performs)"""
+def test_work_list_overflow_fails_the_call():
+    """a work list that is too small (the option PNL_WL_FRAC shrinks it to 64 entries per pass) must not pass silently: the status
+    of pnl_synchronize / pnl_get_counters says the operator is incomplete (the check INTEGRATION.md's stub performs)"""
     from pynucleus_amd import disc, P1_DoFMap, P2_DoFMap, PHYSICAL, getFractionalKernel
     from pynucleus_amd.builder import nonlocalBuilder
     from pynucleus_amd._lib import PnlError
     mesh = disc(4)
-    for DoFMap in (P1_DoFMap, P2_DoFMap):
-        dm = DoFMap(mesh, PHYSICAL)
-        monkeypatch.delenv('PNL_WL_FRAC', raising=False)
-        A = nonlocalBuilder(dm, getFractionalKernel(2, 0.75), {}).getDense()
-        assert np.isfinite(A.toarray()).all()
-        monkeypatch.setenv('PNL_WL_FRAC', '1e-12')
-        with pytest.raises(PnlError, match='work list overflow'):
-            nonlocalBuilder(dm, getFractionalKernel(2, 0.75), {}).getDense()
-    monkeypatch.delenv('PNL_WL_FRAC', raising=False)
+    try:
+        for DoFMap in (P1_DoFMap, P2_DoFMap):
+            dm = DoFMap(mesh, PHYSICAL)
+            _lib.set_option('PNL_WL_FRAC', None)
+            A = nonlocalBuilder(dm, getFractionalKernel(2, 0.75), {}).getDense()
+            assert np.isfinite(A.toarray()).all()
+            _lib.set_option('PNL_WL_FRAC', '1e-12')
+            with pytest.raises(PnlError, match='work list overflow'):
+                nonlocalBuilder(dm, getFractionalKernel(2, 0.75), {}).getDense()
+    finally:
+        _lib.set_option('PNL_WL_FRAC', None)
+
+
+def test_options_are_explicit_not_environment(monkeypatch):
+    """the product library reads no environment variable on the assembly path: options exist only through pnl_set_option, and a
+    product build refuses the A/B switches of the tuning builds"""
+    L = _lib.load()
+    if b'tuning' in L.pnl_version():
+        pytest.skip('tuning build')
+    assert L.pnl_set_option(b'PNL_NO_POWTAB', b'1') == 0
+    assert L.pnl_set_option(b'PNL_NO_POWTAB', None) == 0
+    assert L.pnl_set_option(b'PNL_NO_SLOT', b'1') == _lib.PNL_ERR_UNSUPPORTED
+    with pytest.raises(_lib.PnlError):
+        _lib.set_option('PNL_UNI_PER_CU', 1)
+    # no getenv on the assembly path of the product sources (the planner's thread count is the one deployment knob)
+    import glob
+    for fn in glob.glob(os.path.join(ROOT, 'pynucleus_amd', 'csrc', '*.h*')):
+        src = open(fn).read()
+        calls = re.findall(r'\bgetenv\("([A-Z_0-9]+)"\)', src)
+        assert set(calls) <= {'PNL_PLAN_THREADS'}, (fn, calls)

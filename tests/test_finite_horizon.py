@@ -206,7 +206,7 @@ def test_gpu_interval_poly_dirichlet_known_answer(kernel, nc, tol):
 @pytest.mark.parametrize('case', ['indicator', 'fractional', 'P2'])
 def test_gpu_horizon_tiles_and_pair_generator_agree(case, monkeypatch):
     """the two device routes of pnl_assemble_pairs_in_horizon -- tile kernel in finite-horizon mode (default) and the pair
-    generator that sends every pair down the sorted sparse pipeline (PNL_FH_NOTILES=1) -- give the same counters and, to
+    generator that sends every pair down the sorted sparse pipeline (option PNL_FH_NOTILES) -- give the same counters and, to
     summation order, the same matrix"""
     def build():
         if case == 'indicator':
@@ -214,9 +214,13 @@ def test_gpu_horizon_tiles_and_pair_generator_agree(case, monkeypatch):
         if case == 'fractional':
             return _gpu_sparse(17, 0.45, 'fractional', s=0.4)
         return _gpu_sparse(9, 0.3, 'indicator', element='P2')
+    from pynucleus_amd import _lib
     A = build().getSparse()
-    monkeypatch.setenv('PNL_FH_NOTILES', '1')
-    B = build().getSparse()
+    _lib.set_option('PNL_FH_NOTILES', '1')
+    try:
+        B = build().getSparse()
+    finally:
+        _lib.set_option('PNL_FH_NOTILES', None)
     for key in ('numCellPairs', 'numAssembledCellPairs', 'numIntegrations'):
         assert A.info['counters'][key] == B.info['counters'][key], key
     a, b = A.toarray(), B.toarray()

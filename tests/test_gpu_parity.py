@@ -501,7 +501,7 @@ def test_operator_files_round_trip():
 def test_general_exponent_at_scale_properties():
     """s = 0.4 (no rsqrt shortcut: the table-driven power of the tile kernels, pnl_pow_tab) at 24,576 cells / 12,097 DoFs: symmetry,
     two cell-range shards adding up to the operator, the energy of the driver problem below the exact value and converging, and
-    the tile kernels' power against the L1-table path (PNL_NO_POWTAB) entry by entry"""
+    the tile kernels' power against the exp / ln path (option PNL_NO_POWTAB) entry by entry"""
     import os
     import torch
     from math import gamma, pi
@@ -528,11 +528,12 @@ def test_general_exponent_at_scale_properties():
     energy = float(rhs@u)
     assert 0. < exact-energy < 1e-2*exact, (energy, exact)
     # the same operator with exp(e ln x) from the __constant__ tables
-    os.environ['PNL_NO_POWTAB'] = '1'
+    from pynucleus_amd import _lib
+    _lib.set_option('PNL_NO_POWTAB', '1')
     try:
         b2 = _build('disc', 6, s, params={'target_order': 0.5})
         A2 = b2.getDense()
         assert A2.info['counters']['numIntegrations'] == cnt['numIntegrations']
         assert float((A2.A-M).abs().max()) <= 1e-13*scale
     finally:
-        del os.environ['PNL_NO_POWTAB']
+        _lib.set_option('PNL_NO_POWTAB', None)

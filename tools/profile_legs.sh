@@ -1,0 +1,19 @@
+#!/bin/bash
+# Kernel stats (rocprofv3 --kernel-trace --stats) and SQ counters (separate --pmc pass) of the bench legs other than the headline:
+# C3 (getSparse, square 129^2), C4 (getH2 / near field, disc noRef 7), C5 (P2 + layers, noRef 6), P2 constant order, P1 with a
+# general exponent, and the 97,537-DoF dense leg.  Run through gpurun from the repo root:  tools/profile_legs.sh <round-tag> [legs...]
+set -o pipefail
+TAG=${1:-r03}
+shift
+LEGS=${@:-c3 c4 c5 p2 s04 big}
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$R/gpurun_out/${TAG}_legs
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+SQ="SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_BUSY_CYCLES SQ_WAVES"
+for leg in $LEGS; do
+  echo "== $leg" 
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${leg}_stats -- python3 $R/tools/leg_probe.py $leg > $OUT/${leg}_stats.log 2>&1 || { echo "stats pass of $leg failed"; tail -5 $OUT/${leg}_stats.log; exit 1; }
+  rocprofv3 --kernel-trace --pmc $SQ --output-format csv -d $OUT/${leg}_sq -- python3 $R/tools/leg_probe.py $leg > $OUT/${leg}_sq.log 2>&1 || echo "sq pass of $leg failed"
+  grep "^LEG" $OUT/${leg}_stats.log
+done
