@@ -3,7 +3,13 @@
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this
 module.  The reference cannot be built or imported in this environment (SURVEY.md
 section 8c), so there is no oracle/_ref: the oracle is the C restatement in
-nl_oracle.c fed with the same precomputed quadrature tables as the GPU library.
+nl_oracle.c, fed with the oracle's OWN host tables (oracle/tables.py: kernel constants,
+order formulas, near rules and PSI tables, boundary twins, class tables -- restated from the
+reference text independently of pynucleus_amd/).  A caller may hand over the product's
+``nonlocalTables``: only the user's inputs are read off it (mesh, DoF numbering, kernel type /
+order / horizon / normalisation, params) plus the one shared, unpinned input, the triangle rules
+of distant pairs.  Kernels with an order per quadrature point (the ``pointwise`` tables of the
+non-symmetric path) are the exception: their rule tables are still the product's.
 """
 import ctypes as C
 import os
@@ -99,16 +105,50 @@ def _qo(f):
     return nlo_order_formula(f.c0, f.a, f.b, f.e, f.den0, int(f.clip_num), 0)
 
 
+def kernel_spec(kernel):
+    """the user's inputs of a kernel object (duck-typed: nothing is imported from the product), nothing derived"""
+    finite = bool(np.isfinite(kernel.horizonValue))
+    spec = dict(kernelType=int(kernel.kernelType), horizon=float(kernel.horizonValue), normalized=bool(getattr(kernel, 'normalized', True)),
+                interaction=int(getattr(kernel.interaction, 'device_id', 0)) if finite else 0)
+    s = getattr(kernel, 's', None)
+    if s is None:
+        return spec
+    if hasattr(s, 'sVals'):
+        sv = np.array(s.sVals, dtype=np.float64)
+        if hasattr(s, 'layerBoundaries'):
+            spec['s'] = ('layers', np.array(s.layerBoundaries, dtype=np.float64), sv)
+        elif hasattr(s, 'interface'):
+            spec['s'] = ('leftRight', sv[0, 0], sv[1, 1], sv[0, 1], sv[1, 0], float(s.interface))
+        elif sv.shape == (1, 1):
+            spec['s'] = ('varconst', float(sv[0, 0]))
+        else:
+            raise NotImplementedError('oracle tables for the order {}'.format(type(s).__name__))
+    else:
+        spec['s'] = float(getattr(s, 'value', s))
+    return spec
+
+
+def own_tables(T):
+    """the oracle's own tables for the problem a product ``nonlocalTables`` describes (module docstring)"""
+    from .tables import OracleTables
+    if isinstance(T, OracleTables) or getattr(T, 'pointwise', False):
+        return T
+    finite = bool(np.isfinite(T.kernel.horizonValue))
+    return OracleTables(T.dm, kernel_spec(T.kernel), getattr(T, 'params', {}), (not finite) and bool(T.zeroExterior),
+                        (T.dist_off, T.dist_bary, T.dist_w))
+
+
 class OracleProblem:
     """Holds the numpy arrays alive and exposes the C entry points."""
 
-    def __init__(self, tables):
-        T = self.tables = tables
+    def __init__(self, tables, own=True):
+        self.given_tables = tables
+        T = self.tables = own_tables(tables) if own else tables
         dm, mesh = T.dm, T.dm.mesh
         self._keep = []
         if getattr(T, 'classes', None):
             # variable order: one full problem description per class, the top-level one carries the labels
-            self._class_problems = [OracleProblem(c) for c in T.classes]
+            self._class_problems = [OracleProblem(c, own=False) for c in T.classes]
             arr = (nlo_problem*len(self._class_problems))(*[op.P for op in self._class_problems])
             self._keep.append(arr)
             base = self._class_problems[0]

@@ -85,6 +85,7 @@ class nonlocalTables:
         params = params or {}
         mesh = dm.mesh
         self.dm, self.kernel = dm, kernel
+        self.params = dict(params)                          # the caller's inputs, as given
         self.dim = dim = mesh.dim
         assert mesh.manifold_dim == dim and dim in (1, 2)
         assert kernel.dim == dim, 'Kernel dimension must match dm.mesh dimension'

@@ -1,0 +1,165 @@
+"""The product's host tables (pynucleus_amd/local_matrix.py, quadrature.py, kernels.py, fractionalOrders.py) against the oracle's
+OWN tables (oracle/tables.py, written from the reference text with no shared code), entry by entry: kernel exponent and scaling,
+order-formula constants, near rules with their merged-DoF PSI tables (face / edge / vertex, P1 and P2, 1D and 2D), the boundary
+twins, facet rules, DoF permutation table, and the class tables / labels of piecewise-constant variable orders -- for the
+kernels of BASELINE.json's configurations C1 - C5.  ("weak" #1: these tables used to be common-mode between the GPU
+path and its checker.)  The one shared input is the triangle-rule table of distant pairs (modepy's Xiao-Gimbutas nodes are
+unavailable offline: SURVEY 8c, unpinned)."""
+import numpy as np
+import pytest
+from pynucleus_amd import (disc, interval, uniformSquare, P1_DoFMap, P2_DoFMap, PHYSICAL, NO_BOUNDARY, getFractionalKernel, getKernel,
+                           INDICATOR, PERIDYNAMIC)
+from pynucleus_amd.fractionalOrders import variableConstFractionalOrder, leftRightFractionalOrder, layersFractionalOrder
+from pynucleus_amd.local_matrix import nonlocalTables
+from oracle.oracle import own_tables, OracleProblem
+from oracle import tables as OT
+
+TOL = 1e-14
+
+
+def close(a, b, what):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    if a.size:
+        scale = max(1., float(np.abs(b).max()))
+        assert float(np.abs(a-b).max()) <= TOL*scale, (what, float(np.abs(a-b).max()), scale)
+
+
+def same_rule(p, o, what):
+    assert p.num_nodes == o.num_nodes and p.rows == o.rows, what
+    close(p.nodes, o.nodes, what+' nodes')
+    close(p.weights, o.weights, what+' weights')
+    close(p.psi, o.psi, what+' psi')
+
+
+def same_constant_tables(P, O, what):
+    pk, ok = P.kernel.device_params(), O.kernel.device_params()
+    for key in ('ktype', 'exponent', 'scale', 'horizon2', 'interaction'):
+        assert pk[key] == pytest.approx(ok[key], rel=TOL, abs=0.), (what, key, pk[key], ok[key])
+    for key in ('c0', 'a', 'b', 'e', 'den0', 'clip_num'):
+        assert getattr(P.qo, key) == pytest.approx(getattr(O.qo, key), rel=TOL, abs=TOL), (what, 'qo', key)
+    assert P.sing_fac == O.sing_fac and P.quad_order_diagonal == O.quad_order_diagonal and P.quad_order_diagonalV == O.quad_order_diagonalV
+    assert P.target_order == pytest.approx(O.target_order, rel=TOL)
+    assert sorted(P.singular) == sorted(O.singular)
+    for panel in P.singular:
+        same_rule(P.singular[panel], O.singular[panel], '{} near rule {}'.format(what, panel))
+    assert bool(P.has_boundary_tables) == bool(O.has_boundary_tables)
+    if P.has_boundary_tables:
+        bk, obk = P.boundaryKernel.device_params(), O.boundaryKernel.device_params()
+        for key in ('ktype', 'exponent', 'scale', 'horizon2'):
+            assert bk[key] == pytest.approx(obk[key], rel=TOL, abs=0.), (what, 'boundary kernel', key)
+        for key in ('c0', 'a', 'b', 'e', 'den0', 'clip_num'):
+            assert getattr(P.bqo, key) == pytest.approx(getattr(O.bqo, key), rel=TOL, abs=TOL), (what, 'bqo', key)
+        assert P.bsing_fac == O.bsing_fac and P.bquad_order_diagonal == O.bquad_order_diagonal
+        assert sorted(P.bsingular) == sorted(O.bsingular)
+        for panel in P.bsingular:
+            same_rule(P.bsingular[panel], O.bsingular[panel], '{} boundary near rule {}'.format(what, panel))
+
+
+def same_tables(P, O, what):
+    assert (P.dim, P.dpe, P.qcap) == (O.dim, O.dpe, O.qcap)
+    assert P.H0 == pytest.approx(O.H0, rel=TOL)
+    assert bool(P.zeroExterior) == bool(O.zeroExterior)
+    assert np.array_equal(P.dof_perm_table, O.dof_perm_table), what
+    close(P.dist_phi, O.dist_phi, what+' shape functions at the distant rules')
+    assert np.array_equal(P.bfacet_off, O.bfacet_off)
+    close(P.bfacet_bary, O.bfacet_bary, what+' facet rules')
+    close(P.bfacet_w, O.bfacet_w, what+' facet weights')
+    if P.classes:
+        assert O.classes and len(P.classes) == len(O.classes)
+        close(P.class_s, O.class_s, what+' class orders')
+        assert np.array_equal(P.cls_of, O.cls_of) and P.num_labels == O.num_labels
+        assert np.array_equal(P.cell_labels, O.cell_labels), what+' cell labels'
+        assert bool(getattr(P, 'nonsym', False)) == bool(O.nonsym)
+        if P.has_boundary_tables:
+            assert np.array_equal(P.bcells, O.bcells) and np.array_equal(P.facet_labels, O.facet_labels), what+' facets'
+        for k, (pc, oc) in enumerate(zip(P.classes, O.classes)):
+            same_constant_tables(pc, oc, '{} class {}'.format(what, k))
+    else:
+        same_constant_tables(P, O, what)
+        if P.has_boundary_tables:
+            assert np.array_equal(P.bcells, O.bcells), what+' boundary facets (order and orientation)'
+
+
+LAYERS = layersFractionalOrder(2, np.array([-1., -0.3, 0.3, 1.]), np.array([[0.3, 0.4, 0.5], [0.4, 0.5, 0.6], [0.5, 0.6, 0.7]]))
+CASES = {
+    'C1_interval_P1_s0.25': (lambda: P1_DoFMap(interval(6), PHYSICAL), lambda: getFractionalKernel(1, 0.25), {}, True),
+    'interval_P1_s0.75': (lambda: P1_DoFMap(interval(6), PHYSICAL), lambda: getFractionalKernel(1, 0.75), {}, True),
+    'interval_P2_s0.25': (lambda: P2_DoFMap(interval(5), PHYSICAL), lambda: getFractionalKernel(1, 0.25), {}, True),
+    'interval_P2_s0.75_qd': (lambda: P2_DoFMap(interval(5), PHYSICAL), lambda: getFractionalKernel(1, 0.75), {'quad_order_diagonal': 9, 'target_order': 2.}, True),
+    'C2_disc_P1_s0.5': (lambda: P1_DoFMap(disc(3), PHYSICAL), lambda: getFractionalKernel(2, 0.5), {'target_order': 0.5}, True),
+    'disc_P1_s0.25': (lambda: P1_DoFMap(disc(3), PHYSICAL), lambda: getFractionalKernel(2, 0.25), {}, True),
+    'C4_disc_P1_s0.75': (lambda: P1_DoFMap(disc(4), PHYSICAL), lambda: getFractionalKernel(2, 0.75), {'target_order': 0.5, 'eta': 3.}, True),
+    'disc_P1_s0.4_noexterior': (lambda: P1_DoFMap(disc(2), NO_BOUNDARY), lambda: getFractionalKernel(2, 0.4), {}, False),
+    'disc_P1_unnormalised': (lambda: P1_DoFMap(disc(2), PHYSICAL), lambda: getFractionalKernel(2, 0.6, normalized=False), {}, True),
+    'disc_P2_s0.5': (lambda: P2_DoFMap(disc(2), PHYSICAL), lambda: getFractionalKernel(2, 0.5), {'target_order': 0.5}, True),
+    'disc_P2_s0.7_qd': (lambda: P2_DoFMap(disc(2), PHYSICAL), lambda: getFractionalKernel(2, 0.7), {'quad_order_diagonal': 6}, True),
+    'C3_square_constant_delta': (lambda: P1_DoFMap(uniformSquare(9), NO_BOUNDARY), lambda: getKernel(2, kernel=INDICATOR, horizon=0.3), {}, False),
+    'square_peridynamic': (lambda: P1_DoFMap(uniformSquare(9), NO_BOUNDARY), lambda: getKernel(2, kernel=PERIDYNAMIC, horizon=0.3), {}, False),
+    'square_truncated_fractional': (lambda: P2_DoFMap(uniformSquare(5), NO_BOUNDARY), lambda: getFractionalKernel(2, 0.4, horizon=0.45), {}, False),
+    'interval_constant_delta': (lambda: P1_DoFMap(interval(5, 0., 1.), NO_BOUNDARY), lambda: getKernel(1, kernel=INDICATOR, horizon=0.2), {}, False),
+    'interval_truncated_fractional': (lambda: P1_DoFMap(interval(5, 0., 1.), NO_BOUNDARY), lambda: getFractionalKernel(1, 0.3, horizon=0.2), {}, False),
+    'interval_varconst': (lambda: P1_DoFMap(interval(5), PHYSICAL), lambda: getFractionalKernel(1, variableConstFractionalOrder(0.75)), {}, True),
+    'interval_leftRight': (lambda: P2_DoFMap(interval(5), PHYSICAL), lambda: getFractionalKernel(1, leftRightFractionalOrder(0.25, 0.75)), {}, True),
+    'disc_P1_leftRight': (lambda: P1_DoFMap(disc(3), PHYSICAL), lambda: getFractionalKernel(2, leftRightFractionalOrder(0.25, 0.75)), {'target_order': 0.5}, True),
+    'disc_P1_leftRight_nonsym': (lambda: P1_DoFMap(disc(3), PHYSICAL), lambda: getFractionalKernel(2, leftRightFractionalOrder(0.25, 0.75, 0.3, 0.6)), {'target_order': 0.5}, True),
+    'disc_P1_layers': (lambda: P1_DoFMap(disc(3), PHYSICAL), lambda: getFractionalKernel(2, LAYERS), {'target_order': 0.5}, True),
+    'C5_disc_P2_layers': (lambda: P2_DoFMap(disc(3), PHYSICAL), lambda: getFractionalKernel(2, LAYERS), {'target_order': 0.5}, True),
+    'disc_P2_layers_noexterior': (lambda: P2_DoFMap(disc(2), NO_BOUNDARY), lambda: getFractionalKernel(2, LAYERS), {}, False),
+}
+
+
+@pytest.mark.parametrize('name', sorted(CASES))
+def test_product_tables_equal_oracle_tables(name):
+    mk_dm, mk_kernel, params, zeroExterior = CASES[name]
+    P = nonlocalTables(mk_dm(), mk_kernel(), params, zeroExterior)
+    O = own_tables(P)
+    assert isinstance(O, OT.OracleTables) and O is not P
+    same_tables(P, O, name)
+
+
+def test_oracle_problem_uses_its_own_tables():
+    """OracleProblem(product tables) runs on oracle/tables.py; own=False (shared tables) gives the same matrix to the last bit
+    when the two sets of tables agree -- and a product-side constant that is off shows up as a difference between the two"""
+    dm = P1_DoFMap(disc(2), PHYSICAL)
+    P = nonlocalTables(dm, getFractionalKernel(2, 0.5), {'target_order': 0.5}, True)
+    Oown, Oshared = OracleProblem(P), OracleProblem(P, own=False)
+    assert isinstance(Oown.tables, OT.OracleTables) and Oshared.tables is P
+    A, cA, _ = Oown.get_dense()
+    B, cB, _ = Oshared.get_dense()
+    assert cA == cB and np.array_equal(A, B)
+    P.kernel.scalingValue *= 1.+1e-9              # a wrong constant on the product side ...
+    C = OracleProblem(P, own=False).get_dense()[0]
+    D = OracleProblem(P).get_dense()[0]
+    assert np.array_equal(D, A) and not np.array_equal(C, A)     # ... no longer cancels out in the checker
+
+
+def test_independent_checks_of_the_rules():
+    """known answers the oracle's rules must reproduce by themselves: Gauss-Jacobi moments, the near rules on the singular
+    integrals int_K int_K |x-y|^(sing+2) and the partition of unity of the shape functions"""
+    from scipy.special import beta as B
+    (x,), w = OT.gauss_jacobi([(7, 0.3, 1.2)])
+    for k in range(7):
+        assert (w*x**k).sum() == pytest.approx(B(0.3+k+1, 1.2+1), rel=1e-13)
+    for order in (1, 2):
+        lam = np.random.default_rng(0).dirichlet(np.ones(3), size=20).T
+        assert np.allclose(OT.shape_functions(2, order, lam).sum(axis=0), 1., atol=1e-14)
+        nodes = OT.element_nodes(2, order)
+        assert np.allclose(OT.shape_functions(2, order, nodes.T), np.eye(nodes.shape[0]), atol=1e-14)
+    # 1D identical cells: int_0^1 int_0^1 |x-y|^a dx dy = 2 / ((a+1)(a+2)); the rule of singularity sigma carries the factor
+    # (eta0 eta1)^-sigma in its weights, i.e. it integrates f(x, y) (eta0 eta1)^sigma ... with f = |x-y|^sigma / eta0... :
+    # with x = eta0 (1 - eta1), y = eta0: |x - y| = eta0 eta1, so sum_m w_m |x_m - y_m|^sigma = 2 / ((sigma+1)(sigma+2))
+    for sigma in (-0.5, 0.5):
+        nodes, w = OT.near_rule_1d(OT.COMMON_EDGE, sigma, 5, 4)
+        d = np.abs(nodes[1]-nodes[3])
+        assert (w*d**sigma).sum() == pytest.approx(2./((sigma+1.)*(sigma+2.)), rel=1e-12)
+    # 2D: the three near rules integrate 1 over K x K to area^2 = 1/4 of the reference triangles (the weights include the
+    # Jacobians; FL2:851 multiplies by 4 vol1 vol2)
+    for panel in (OT.COMMON_FACE, OT.COMMON_EDGE, OT.COMMON_VERTEX):
+        nodes, w = OT.near_rule_2d(panel, 0., 6, 6)
+        assert w.sum() == pytest.approx(0.25, rel=1e-12)
+        assert np.allclose(nodes[:3].sum(axis=0), 1.) and np.allclose(nodes[3:].sum(axis=0), 1.) and nodes.min() > -1e-14
+    for panel in (OT.COMMON_EDGE, OT.COMMON_VERTEX):
+        nodes, w = OT.near_rule_2d_boundary(panel, 0., 6, 6)
+        assert w.sum() == pytest.approx(0.5, rel=1e-12)              # triangle (1/2) x facet (1); FL2:1375: -2 vol1 vol2
+        assert np.allclose(nodes[:3].sum(axis=0), 1.) and np.allclose(nodes[3:].sum(axis=0), 1.) and nodes.min() > -1e-14
