@@ -147,7 +147,7 @@ def extra_configs(dev):
                          wall_ms=1e3*float(np.mean(wall)), first_call_ms=1e3*first, pairs_per_s=pairs/dev_s,
                          algorithmic_tflops=fl/dev_s/1e12, frac_fp64_peak=fl/dev_s/1e12/FP64_VECTOR_PEAK_TFLOPS,
                          phases_ms={k: round(v, 3) for k, v in last_ms.items()},
-                         kernel_ms={k: round(v, 3) for k, v in b.context().kernel_ms().items()})
+                         kernel_ms={k: round(v, 3) for k, v in b.dense_context().kernel_ms().items()})
         del b
         torch.cuda.empty_cache()
 

@@ -107,6 +107,12 @@ int pnl_synchronize(pnl_context *ctx);
 /* vertices[nv][dim], cells[nc][dim+1], vol[nc], h[nc] (mesh.volVector / hVector), H0 = diam/sqrt(8) */
 int pnl_upload_mesh(pnl_context *ctx, int dim, int nv, const double *vertices_host, int nc, const int32_t *cells_host,
                     const double *vol_host, const double *h_host, double H0);
+/* Cells renumbered by the host (spatial locality, label-following blocks): orig[nc] = the caller's number of every uploaded cell.
+ * Touching pairs then keep the orientation the reference's loop gives them -- cellNo1 <= cellNo2 in the CALLER's numbering decides
+ * which cell is the first argument of the singular rule (NA:1386-1396) -- so the operator does not depend on the renumbering
+ * beyond summation order.  A cell of volume 0 without DoFs is padding inside the mesh: it forms no pair and is not counted.
+ * orig = NULL: the numbering of the upload. */
+int pnl_set_cell_order(pnl_context *ctx, int nc, const int32_t *orig_host);
 /* dofs[nc][dpe] (negative = boundary DoF, dm.dofs), dof_perm_table[(dim+1)!][dpe]
  * (precomputedDoFPermutations, NO:66-109) */
 int pnl_upload_dofmap(pnl_context *ctx, int dpe, int dofs_per_vertex, int dofs_per_edge, int num_dofs,

@@ -137,6 +137,98 @@ def with_cell_locality(dm):
     return dm2
 
 
+def label_blocks(dm, labels, max_dofs=None):
+    """Cell blocks that follow the interfaces of a piecewise-constant order.
+
+    A tile of the dense path is uniform -- no per-pair classification, the fast kernels -- only if its two blocks of T consecutive
+    cells carry one label each; a block that straddles an interface makes ALL its tiles multi-class.  Here every straddling block
+    is split into one block per label: the fragments of consecutive straddling blocks are merged while they fit (T cells and the
+    DoF count of the largest ordinary block, so that the LDS sub-blocks keep their size), and every new block is filled up to T
+    cells with zero-volume copies of its own first cell (in-mesh padding: csrc/pnl_hip.hip finalize()).  Returns a shallow copy
+    of dm whose mesh has the renumbered + padded cells (DoF numbers unchanged; dofs = -1 and volume 0 for the copies), or dm
+    itself when no block straddles."""
+    import copy
+    T = tile_cells(dm.dofs_per_element, dm.mesh.dim)
+    mesh = dm.mesh
+    nc = mesh.num_cells
+    labels = np.asarray(labels)
+    dofs = np.asarray(dm.dofs)
+    nb = (nc+T-1)//T
+    if max_dofs is None:
+        max_dofs = block_dof_count(dofs, T)
+    order, is_dummy = [], []
+    pend = {}                                   # label -> (cells, set of DoFs) of the open merged fragment
+
+    def close(lab):
+        cells, _ = pend.pop(lab)
+        order.extend(cells)
+        is_dummy.extend([False]*len(cells))
+        pad = T-len(cells)
+        order.extend([cells[0]]*pad)
+        is_dummy.extend([True]*pad)
+
+    nsplit = 0
+    for b in range(nb):
+        c0, c1 = b*T, min(nc, (b+1)*T)
+        lb = labels[c0:c1]
+        if (lb == lb[0]).all() and c1-c0 == T:
+            # an ordinary block ends the run of straddling blocks: open fragments are closed first (keeps them compact)
+            for lab in sorted(pend):
+                close(lab)
+            order.extend(range(c0, c1))
+            is_dummy.extend([False]*T)
+            continue
+        if (lb == lb[0]).all():
+            # the short block behind the last full one: stays where it is (the library pads behind the last cell)
+            for lab in sorted(pend):
+                close(lab)
+            order.extend(range(c0, c1))
+            is_dummy.extend([False]*(c1-c0))
+            continue
+        nsplit += 1
+        for lab in np.unique(lb):
+            frag = [c for c in range(c0, c1) if labels[c] == lab]
+            fd = set(int(g) for g in dofs[frag].ravel() if g >= 0)
+            if lab in pend:
+                cells, dset = pend[lab]
+                if len(cells)+len(frag) <= T and len(dset | fd) <= max_dofs:
+                    pend[lab] = (cells+frag, dset | fd)
+                    continue
+                close(lab)
+            pend[lab] = (frag, fd)
+        # a label that this block does not hold ends its run: its fragment is closed
+        for lab in sorted(set(pend)-set(int(x) for x in np.unique(lb))):
+            close(lab)
+    tail_short = nc % T != 0 and len(order) % T != 0
+    for lab in sorted(pend):
+        close(lab)
+    if nsplit == 0:
+        return dm
+    order = np.asarray(order, dtype=np.int64)
+    is_dummy = np.asarray(is_dummy, dtype=bool)
+    if tail_short:
+        # the short last block must stay last: move it behind the blocks closed after it
+        k = (nc//T)*T
+        pos = int(np.nonzero(order == k)[0][0])
+        ntail = nc-k
+        idx = np.r_[0:pos, pos+ntail:order.shape[0], pos:pos+ntail]
+        order, is_dummy = order[idx], is_dummy[idx]
+    mesh2 = copy.copy(mesh)
+    mesh2.cells = np.ascontiguousarray(mesh.cells[order])
+    mesh2.resetMeshInfo()
+    mesh2._compute()
+    mesh2._info['volVector'] = np.where(is_dummy, 0., mesh2._info['volVector'])
+    dm2 = copy.copy(dm)
+    dm2.mesh = mesh2
+    d2 = np.array(dofs[order], copy=True)
+    d2[is_dummy] = -1
+    dm2.dofs = np.ascontiguousarray(d2)
+    dm2.cell_permutation = order
+    dm2.cell_is_padding = is_dummy
+    dm2.num_split_blocks = nsplit
+    return dm2
+
+
 class nonlocalBuilder:
     def __init__(self, dm, kernel, params={}, zeroExterior=True, comm=None, PLogger=None, dm2=None, device=None, **kwargs):
         if 'boundary' in kwargs:
@@ -161,6 +253,7 @@ class nonlocalBuilder:
         self.zeroExterior = False if kernel.finiteHorizon else bool(zeroExterior)
         self.tables = nonlocalTables(self.dm, kernel, self.params, self.zeroExterior)
         self._uploaded = False
+        self._blocked = None
         # operators of the previous kernel keep their data but must not re-run a device set-up with the new tables
         if getattr(self, '_ctx', None) is not None:
             self._ctx._kernel_epoch = getattr(self._ctx, '_kernel_epoch', 0)+1
@@ -185,6 +278,44 @@ class nonlocalBuilder:
             self._uploaded = True
         self._ctx.set_stream(torch.cuda.current_stream(self._ctx.device).cuda_stream)
         return self._ctx
+
+    def _blocked_dense(self):
+        """(context, number of cells) of the dense path of a piecewise-constant variable order in 2D on one GPU: its own context
+        over the label-following cell blocks of label_blocks() -- the same DoFs, the same tables, the same operator; the tile
+        kernels meet (nearly) no multi-class tile.  None when it does not apply (one label, no straddling block, 1D, comm,
+        params['labelBlocks'] = False)."""
+        T = self.tables
+        if (not self.params.get('labelBlocks', True) or getattr(T, 'pointwise', False) or not T.classes or T.num_labels < 2
+                or self.mesh.dim != 2 or self.comm is not None):
+            return None
+        if getattr(self, '_blocked', None) is None:
+            import copy
+            dmb = label_blocks(self.dm, T.cell_labels)
+            if dmb is self.dm:
+                self._blocked = False
+                return None
+            Tb = copy.copy(T)
+            Tb.dm = dmb
+            Tb.cell_labels = np.ascontiguousarray(np.asarray(T.cell_labels)[dmb.cell_permutation], dtype=np.int32)
+            Tb.classes = []
+            for c in T.classes:
+                cb = copy.copy(c)
+                cb.dm = dmb
+                Tb.classes.append(cb)
+            ctx = _lib.Context(self._device_index())
+            ctx.upload_tables(Tb)
+            self._blocked = (ctx, dmb, Tb)
+        if self._blocked is False:
+            return None
+        import torch
+        ctx, dmb, Tb = self._blocked
+        ctx.set_stream(torch.cuda.current_stream(ctx.device).cuda_stream)
+        return ctx, dmb.mesh.num_cells
+
+    def dense_context(self):
+        """the context getDense() assembles on (its kernel timers / counters): the label-blocked twin when there is one"""
+        blocked = self._blocked_dense()
+        return blocked[0] if blocked is not None else self.context()
 
     def _single_order_twin(self):
         """A variable-order kernel whose order takes one value (varconst) has one kernel block and no jumps
@@ -248,6 +379,9 @@ class nonlocalBuilder:
         dev = torch.device('cuda', ctx.device)
         N = self.dm.num_dofs
         nc = self.mesh.num_cells
+        blocked = self._blocked_dense()
+        if blocked is not None:
+            ctx, nc = blocked
         pointwise = bool(getattr(self.tables, 'pointwise', False))
         self.PLogger.addValue('useSymmetricCells', not pointwise)
         self.PLogger.addValue('useSymmetricLocalMatrix', not pointwise)

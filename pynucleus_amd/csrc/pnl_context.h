@@ -38,6 +38,9 @@ struct pnl_context {
     std::string err;
     // host copies
     int dim = 0, nv = 0, nc = 0, dpe = 0, dpv = 0, dped = 0, N = 0, nb = 0, qmax = -1;
+    int nreal = 0;                            // cells of positive volume (the others are in-mesh padding, finalize())
+    std::vector<int> cell_orig;               // the caller's number of every cell (pnl_set_cell_order), empty = the numbering of the upload
+    std::vector<int> real_from;               // [nc + 1] number of real cells with index >= c
     double H0 = 0.;
     std::vector<double> vertices, vol, h;
     std::vector<int32_t> cells, dofs, perm_table, bcells;

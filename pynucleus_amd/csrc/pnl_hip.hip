@@ -69,6 +69,15 @@ int finalize(pnl_context *ctx) {
         });
         for (auto &t : pool) t.join();
     }
+    // Cells of volume ZERO are padding inside the mesh (builder.label_blocks: a block of cells that would straddle an interface
+    // of a piecewise-constant order is split into one block per label, filled up with zero-volume copies of its own cells).
+    // They keep their geometry (every kernel value stays finite), carry no DoFs, negative vertex ids like the padding behind
+    // the last cell (the tile kernels drop every pair that holds one), and belong to no touching pair.
+    ctx->nreal = 0;
+    std::vector<char> dummy(nc, 0);
+    for (int c = 0; c < nc; c++) { dummy[c] = ctx->vol[c] == 0.; ctx->nreal += !dummy[c]; }
+    ctx->real_from.assign((size_t)nc+1, 0);                  // number of real cells with index >= c
+    for (int c = nc-1; c >= 0; c--) ctx->real_from[c] = ctx->real_from[c+1]+(dummy[c] ? 0 : 1);
     for (int c = 0; c < ncp; c++) {
         for (int k = 0; k < nV; k++) cvid[(size_t)k*ncp+c] = -1-k;
         if (c >= nc) continue;
@@ -76,7 +85,7 @@ int finalize(pnl_context *ctx) {
         for (int k = 0; k < nV; k++) {
             const int v = ctx->cells[(size_t)c*nV+k];
             if (v < 0 || v >= ctx->nv) return fail(ctx, PNL_ERR_INVALID, "cell %d references vertex %d", c, v);
-            cvid[(size_t)k*ncp+c] = v;
+            if (!dummy[c]) cvid[(size_t)k*ncp+c] = v;
             for (int d = 0; d < dim; d++) {
                 const double x = ctx->vertices[(size_t)v*dim+d];
                 cellv[(size_t)(k*dim+d)*ncp+c] = x;
@@ -90,6 +99,7 @@ int finalize(pnl_context *ctx) {
         for (int k = 0; k < dpe; k++) {
             const int g = ctx->dofs[(size_t)c*dpe+k];
             if (g >= ctx->N) return fail(ctx, PNL_ERR_INVALID, "DoF id %d >= num_dofs %d", g, ctx->N);
+            if (dummy[c] && g >= 0) return fail(ctx, PNL_ERR_INVALID, "cell %d has volume zero and a DoF", c);
             cdof[(size_t)k*ncp+c] = g;
         }
     }
@@ -142,16 +152,17 @@ int finalize(pnl_context *ctx) {
     // touching cell pairs via vertex -> cells adjacency
     std::vector<int> vptr(ctx->nv+1, 0);
     for (int c = 0; c < nc; c++)
-        for (int k = 0; k < nV; k++) vptr[ctx->cells[(size_t)c*nV+k]+1]++;
+        for (int k = 0; k < nV && !dummy[c]; k++) vptr[ctx->cells[(size_t)c*nV+k]+1]++;
     for (int v = 0; v < ctx->nv; v++) vptr[v+1] += vptr[v];
     std::vector<int> vcells(vptr[ctx->nv]), fill(vptr.begin(), vptr.end()-1);
     for (int c = 0; c < nc; c++)
-        for (int k = 0; k < nV; k++) vcells[fill[ctx->cells[(size_t)c*nV+k]]++] = c;
+        for (int k = 0; k < nV && !dummy[c]; k++) vcells[fill[ctx->cells[(size_t)c*nV+k]]++] = c;
     for (int s = 0; s < 3; s++) ctx->spairs_host[s].clear();
     {
         std::vector<int> nbr;
         for (int c1 = 0; c1 < nc; c1++) {
             nbr.clear();
+            if (dummy[c1]) continue;
             for (int k = 0; k < nV; k++) {
                 const int v = ctx->cells[(size_t)c1*nV+k];
                 for (int t = vptr[v]; t < vptr[v+1]; t++)
@@ -163,7 +174,12 @@ int finalize(pnl_context *ctx) {
                 while (u < nbr.size() && nbr[u] == nbr[t]) u++;
                 const int common = (nbr[t] == c1) ? nV : (int)(u-t);
                 if (common < 1 || common > nV) return fail(ctx, PNL_ERR_INVALID, "degenerate cell pair (%d,%d)", c1, nbr[t]);
-                ctx->spairs_host[common-1].push_back(make_int2(c1, nbr[t]));
+                // which cell is cellNo1 of a touching pair decides the orientation of its singular rule (NA:1386-1396: c1 <= c2 in
+                // the CALLER's numbering): renumbered cells keep it (pnl_set_cell_order)
+                if (!ctx->cell_orig.empty() && ctx->cell_orig[c1] > ctx->cell_orig[nbr[t]])
+                    ctx->spairs_host[common-1].push_back(make_int2(nbr[t], c1));
+                else
+                    ctx->spairs_host[common-1].push_back(make_int2(c1, nbr[t]));
                 t = u;
             }
         }
@@ -1793,7 +1809,17 @@ int pnl_upload_mesh(pnl_context *ctx, int dim, int nv, const double *vertices, i
     ctx->cells.assign(cells, cells+(size_t)nc*(dim+1));
     ctx->vol.assign(vol, vol+nc);
     ctx->h.assign(h, h+nc);
+    ctx->cell_orig.clear();
     ctx->have_mesh = true;
+    ctx->dirty = true;
+    return PNL_OK;
+}
+
+int pnl_set_cell_order(pnl_context *ctx, int nc, const int32_t *orig) {
+    if (!ctx) return PNL_ERR_INVALID;
+    if (!ctx->have_mesh) return fail(ctx, PNL_ERR_STATE, "upload the mesh first");
+    if (orig && nc != ctx->nc) return fail(ctx, PNL_ERR_INVALID, "pnl_set_cell_order: %d cells expected", ctx->nc);
+    if (orig) ctx->cell_orig.assign(orig, orig+nc); else ctx->cell_orig.clear();
     ctx->dirty = true;
     return PNL_OK;
 }
@@ -2231,7 +2257,8 @@ int pnl_assemble_dense(pnl_context *ctx, double *A, int64_t ldA, int zero_exteri
     if ((rc = upload_tiles(ctx, tiles, cell_begin, cell_end))) return rc;
     // pairs visited by the reference loop: c1 in [begin,end), c2 in [c1, nc)
     unsigned long long visited = 0;
-    for (long long c = cell_begin; c < cell_end; c++) visited += (unsigned long long)(ctx->nc-c);
+    for (long long c = cell_begin; c < cell_end; c++)
+        if (ctx->real_from[c] != ctx->real_from[c+1]) visited += (unsigned long long)ctx->real_from[c];      // zero-volume padding cells do not count
     ctx->visited_pairs = visited; ctx->visited_is_assembled = false;
     if (pnl_tune("PNL_FORCE_SYMFLUSH")) flags |= PNL_FLAG_SYMMETRIC_FLUSH;     // debug: both sides written by the flush, no mirror pass
     ctx->slot_full_list = true;

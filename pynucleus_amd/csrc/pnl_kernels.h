@@ -2472,7 +2472,7 @@ k_boundary_distant(const DevProblem P, double *__restrict__ Dglob, int cell_begi
                    unsigned dcap, int *__restrict__ dcls) {
     constexpr int NV = DIM+1, NC = NV*DIM, NF = DIM, ND = DPE*(DPE+1)/2;
     const int c = cell_begin+blockIdx.x*PNL_NTHREADS+threadIdx.x;
-    const bool active = c < cell_end;
+    bool active = c < cell_end;
     const int cc = active ? c : cell_begin;
     double av[NC], cen[DIM];
     int vid[NV];
@@ -2482,6 +2482,7 @@ k_boundary_distant(const DevProblem P, double *__restrict__ Dglob, int cell_begi
     for (int d = 0; d < DIM; d++) cen[d] = P.ccen[(size_t)d*P.ncp+cc];
 #pragma unroll
     for (int k = 0; k < NV; k++) vid[k] = P.cvid[(size_t)k*P.ncp+cc];
+    active = active && vid[0] >= 0;                      // zero-volume padding cells inside the mesh meet no facet
     const double h1 = P.ch[cc], vol1 = P.cvol[cc];
     const double Ld1 = fabs(log(h1/P.H0));
     const float lh1 = (float)log(h1), L1 = (float)Ld1;
@@ -3363,8 +3364,9 @@ k_tile_order_range(const DevProblem P, const DevFormula qo, const int2 *__restri
             const int i = p/TILE, j = p-i*TILE;
             const int a0 = s_vid[0][i], a1 = s_vid[1][i], a2 = s_vid[2][i];
             const int b0 = s_vid[3][j], b1 = s_vid[4][j], b2 = s_vid[5][j];
-            // padding cells carry negative vertex ids: never uniform
-            bad |= (a0 < 0) | (b0 < 0);
+            // padding cells carry negative vertex ids: their pairs do not exist (blocks with padding BEHIND the last cell never
+            // come here: their coordinates are not those of a cell)
+            if (a0 < 0 || b0 < 0) continue;
             bad |= (a0 == b0) | (a0 == b1) | (a0 == b2) | (a1 == b0) | (a1 == b1) | (a1 == b2) | (a2 == b0) | (a2 == b1) | (a2 == b2);
             const double dx = s_cen[0][i]-s_cen[2][j], dy = s_cen[1][i]-s_cen[3][j];
             const int q = quad_order_fast(qo, s_h[0][i], s_h[1][j], s_lh[0][i], s_lh[2][j], s_lh[1][i], s_lh[3][j], s_Ld[0][i], s_Ld[1][j],

@@ -175,9 +175,11 @@ k_zero_slot_tiles(const SlotOut SO, const int2 *__restrict__ tiles, const int *_
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // LDS of k_tile_uniform in bytes without the sub-block of A' (host and device agree through this function)
-__host__ __device__ constexpr size_t uniform_fixed_lds(int dpe, int np, int tile, int nUe) {
+// dof_lists: the global DoF numbers of both blocks, double-buffered (the flush into A in DoF numbering; the block-slot storage
+// does not need them: 1.4 KB that let the P2 kernels of a general exponent keep their power tables next to the second workgroup)
+__host__ __device__ constexpr size_t uniform_fixed_lds(int dpe, int np, int tile, int nUe, bool dof_lists = true) {
     return sizeof(double)*(size_t)(tile*np*2+tile*6+2*tile+2*tile*np+tile*np+(dpe*(dpe+1)/2)*np)
-           +sizeof(int)*(size_t)(2*tile*dpe+2*tile+4*nUe);
+           +sizeof(int)*(size_t)(2*tile*dpe+2*tile+(dof_lists ? 4*nUe : 0));
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -213,8 +215,9 @@ k_tile_uniform(const DevProblem P, const int2 *__restrict__ tiles, const int *__
     int *s_sa = s_slotb+TILE*DPE;                        // [TILE][DPE] row offset in the sub-block (trash row nUe)
     int *s_ha = s_sa+TILE*DPE;                           // [TILE] has-a-DoF flags
     int *s_hb = s_ha+TILE;
-    int *s_dof = s_hb+TILE;                              // [2][2][nUe] global DoFs of both blocks (ping-pong over tiles)
-    double *s_acc = (double*)(s_dof+4*nUe);              // [nUe+1][acc_stride]; nUe even
+    int *s_dof = s_hb+TILE;                              // [2][2][nUe] global DoFs of both blocks (ping-pong over tiles);
+    const bool dof_lists = SO.A2 == nullptr;             // not with the block-slot storage (uniform_fixed_lds)
+    double *s_acc = (double*)(s_dof+(dof_lists ? 4*nUe : 0));    // [nUe+1][acc_stride]; nUe even
     // tables of the general power (KT == 0) behind the sub-block, if the launcher made room for them (bit 8 of flags: they
     // must not cost the second workgroup per CU)
     const bool have_pow = KT == 0 && (flags_in & 8) != 0;
@@ -239,6 +242,8 @@ k_tile_uniform(const DevProblem P, const int2 *__restrict__ tiles, const int *__
             int sl[DPE], any = 0;
 #pragma unroll
             for (int k = 0; k < DPE; k++) { sl[k] = P.cslot[(size_t)k*P.ncp+c]; any |= (sl[k] >= 0); }
+            // bit 1: a real cell (zero-volume padding cells inside the mesh carry negative vertex ids: their pairs do not exist)
+            any |= (P.cvid[c] >= 0) ? 2 : 0;
             if (bside) {
 #pragma unroll
                 for (int jp = 0; jp < NP; jp++)
@@ -262,8 +267,10 @@ k_tile_uniform(const DevProblem P, const int2 *__restrict__ tiles, const int *__
         }
         const int *__restrict__ dofA = P.blk_dofs+(size_t)tl.x*P.blk_stride;
         const int *__restrict__ dofB = P.blk_dofs+(size_t)tl.y*P.blk_stride;
-        for (int k = tid; k < nA; k += NT) s_dof[(buf*2+0)*nUe+k] = P.rowmap ? P.rowmap[dofA[k]] : dofA[k];
-        for (int k = tid; k < nB; k += NT) s_dof[(buf*2+1)*nUe+k] = P.colmap ? P.colmap[dofB[k]] : dofB[k];
+        if (dof_lists) {
+            for (int k = tid; k < nA; k += NT) s_dof[(buf*2+0)*nUe+k] = P.rowmap ? P.rowmap[dofA[k]] : dofA[k];
+            for (int k = tid; k < nB; k += NT) s_dof[(buf*2+1)*nUe+k] = P.colmap ? P.colmap[dofB[k]] : dofB[k];
+        }
         if (have_pow && tile_cls) {
             const double *pt = kcls[(tile_cls[t] & 0xffff) >> 1].ptab;
             if (pt != cur_ptab) { cur_ptab = pt; pnl_pow_tab_fill(s_pow, pt, tid, NT); }
@@ -297,7 +304,7 @@ k_tile_uniform(const DevProblem P, const int2 *__restrict__ tiles, const int *__
         int sa[DPE];
 #pragma unroll
         for (int k = 0; k < DPE; k++) sa[k] = s_sa[li*DPE+k];
-        const bool ha = s_ha[li] != 0;
+        const int fa = s_ha[li];
         const double vola = s_vola[li];
 #pragma unroll 1
         for (int jj = 0; jj < ITER; jj++) {
@@ -307,7 +314,9 @@ k_tile_uniform(const DevProblem P, const int2 *__restrict__ tiles, const int *__
             for (int jp = 0; jp < NP; jp++)
 #pragma unroll
                 for (int d = 0; d < DIM; d++) y[jp][d] = s_y[j*NP*DIM+jp*DIM+d];
-            const bool valid = ha || (s_hb[j] != 0);     // NA:138-150: pairs with boundary DoFs only are skipped
+            // NA:138-150: pairs with boundary DoFs only are skipped; pairs that hold a padding cell do not exist
+            const int fb = s_hb[j];
+            const bool valid = (((fa | fb) & 1) != 0) && (((fa & fb) & 2) != 0);
             npairs += (unsigned long long)__popcll(__ballot(valid));
             const double volb = valid ? s_volb[j] : 0.;
             // NA:1405-1410: symmetric cell pairs count twice
@@ -380,7 +389,7 @@ k_tile_uniform(const DevProblem P, const int2 *__restrict__ tiles, const int *__
         const bool more = nxt < ntiles;
         if (more) stage(nxt, buf^1);
         const int *__restrict__ dA = s_dof+(buf*2+0)*nUe, *__restrict__ dB = s_dof+(buf*2+1)*nUe;
-        const bool sym = (flags & 1) != 0;
+        const bool sym = (flags & 1) != 0 && dof_lists;
         if (SO.A2) {
             // block-slot storage: this tile owns its nA x nB sub-block, plain 16-byte stores of every entry
             // (writing the padded width, whole 64-byte lines, was measured: no less traffic, the fold 1 ms slower)

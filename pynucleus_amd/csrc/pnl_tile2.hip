@@ -10,7 +10,7 @@ int launch_uniform_t(pnl_context *ctx, const DevProblem &Pt, const int2 *tiles, 
                      int64_t ldA, double *Dglob, const SlotOut &SO) {
     constexpr int TILE = DPE == 6 ? 32 : 64;
     const int nUe = (ctx->nU+1) & ~1;                     // even: the sub-block follows the int arrays at an 8-byte boundary
-    const size_t fixed = uniform_fixed_lds(DPE, NP, TILE, nUe);
+    const size_t fixed = uniform_fixed_lds(DPE, NP, TILE, nUe, SO.A2 == nullptr);
     // sub-block [nUe+1][acc_stride]: rows in different LDS banks (stride = 1 mod 32 doubles) if two workgroups still share a CU,
     // else an odd stride
     int acc_stride = nUe+1;

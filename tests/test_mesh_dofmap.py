@@ -89,3 +89,38 @@ def test_rhs_and_mass():
     assert np.isclose(np.asarray(b).sum(), mesh.volume)
     M = dm.assembleMass()
     assert np.isclose(M.sum(), mesh.volume)
+
+
+def test_label_blocks_partition():
+    """builder.label_blocks: every cell once, padding = zero-volume copies without DoFs, no block of T cells holds two labels,
+    the largest block keeps its DoF count (host logic of the C5 path; the GPU side is tests/test_gpu_parity.py)"""
+    from pynucleus_amd import disc, P1_DoFMap, P2_DoFMap, PHYSICAL
+    from pynucleus_amd.fractionalOrders import layersFractionalOrder, leftRightFractionalOrder
+    from pynucleus_amd.builder import label_blocks, block_dof_count, tile_cells
+    orders = (layersFractionalOrder(2, np.array([-1., -0.3, 0.3, 1.]), np.array([[0.3, 0.4, 0.5], [0.4, 0.5, 0.6], [0.5, 0.6, 0.7]])),
+              leftRightFractionalOrder(0.25, 0.75, interface=0.1))
+    for DoFMap in (P1_DoFMap, P2_DoFMap):
+        for noRef in (3, 4):
+            mesh = disc(noRef)
+            dm = DoFMap(mesh, PHYSICAL)
+            T = tile_cells(dm.dofs_per_element, 2)
+            for s in orders:
+                lab = s.labels(mesh.getCellCenters())
+                dmb = label_blocks(dm, lab)
+                assert dmb is not dm
+                perm, pad = dmb.cell_permutation, dmb.cell_is_padding
+                assert sorted(perm[~pad].tolist()) == list(range(mesh.num_cells))
+                assert (dmb.dofs[pad] == -1).all() and (dmb.mesh.volVector[pad] == 0.).all() and (dmb.mesh.volVector[~pad] > 0.).all()
+                assert np.array_equal(dmb.dofs[~pad], dm.dofs[perm[~pad]]) and np.array_equal(dmb.mesh.cells, mesh.cells[perm])
+                lab2 = lab[perm]
+                nc2 = dmb.mesh.num_cells
+                for b in range((nc2+T-1)//T):
+                    assert len(np.unique(lab2[b*T:(b+1)*T])) == 1
+                    # padding copies a cell of its own block
+                    blk = slice(b*T, min(nc2, (b+1)*T))
+                    assert set(perm[blk][pad[blk]].tolist()) <= set(perm[blk][~pad[blk]].tolist())
+                assert block_dof_count(dmb.dofs, T) <= block_dof_count(dm.dofs, T)
+                assert dmb.num_dofs == dm.num_dofs
+    # one label: nothing to do
+    dm = P1_DoFMap(disc(3), PHYSICAL)
+    assert label_blocks(dm, np.zeros(dm.mesh.num_cells, dtype=np.int32)) is dm

@@ -36,7 +36,7 @@ def dense(name, dm, kernel, dpe, reps=3):
     print('LEG', name, json.dumps(dict(num_dofs=dm.num_dofs, device_ms=round(ms, 3), wall_ms=round(1e3*wall, 2), frac_fp64_peak=round(fl/ms/1e9/PEAK, 4),
                                        pairs=info['counters']['numAssembledCellPairs'],
                                        phases_ms={k: round(v, 3) for k, v in info['phase_ms'].items()},
-                                       kernel_ms={k: round(v, 3) for k, v in b.context().kernel_ms().items() if v})), flush=True)
+                                       kernel_ms={k: round(v, 3) for k, v in b.dense_context().kernel_ms().items() if v})), flush=True)
 
 
 if what == 'c5':
@@ -64,7 +64,7 @@ elif what == 'c3':
     print('LEG', 'C3_square{}_delta0.1'.format(size or 129), json.dumps(dict(num_dofs=dm.num_dofs, device_ms=round(ms, 3), wall_ms=round(1e3*wall, 2),
           frac_fp64_peak=round(fl/ms/1e9/PEAK, 4), pairs=c['numAssembledCellPairs'], evals=c['numIntegrations'],
           phases_ms={k: round(v, 3) for k, v in A.info.get('phase_ms', {}).items()},
-          kernel_ms={k: round(v, 3) for k, v in b.context().kernel_ms().items() if v})), flush=True)
+          kernel_ms={k: round(v, 3) for k, v in b.dense_context().kernel_ms().items() if v})), flush=True)
 elif what == 'c4':
     dm = P1_DoFMap(disc(size or 7), PHYSICAL)
     b = nonlocalBuilder(dm, getFractionalKernel(2, 0.75), {'target_order': 0.5, 'eta': 3.}, zeroExterior=True)
@@ -79,4 +79,4 @@ elif what == 'c4':
     print('LEG', 'C4_H2_noRef{}'.format(size or 7), json.dumps(dict(num_dofs=dm.num_dofs, getH2_ms=round(1e3*wall, 2), near_device_ms=round(ms, 3),
           frac_fp64_peak=round(fl/ms/1e9/PEAK, 4), pairs=c['numAssembledCellPairs'], host_s={k: round(v, 4) for k, v in getattr(h2, 'host_s', {}).items()},
           phases_ms={k: round(v, 3) for k, v in near.info.get('phase_ms', {}).items()},
-          kernel_ms={k: round(v, 3) for k, v in b.context().kernel_ms().items() if v})), flush=True)
+          kernel_ms={k: round(v, 3) for k, v in b.dense_context().kernel_ms().items() if v})), flush=True)
