@@ -711,7 +711,14 @@ class nonlocalBuilder:
         # jumps (getKernelBlocksAndJumps NA:2312-2384) are a function of the mesh and the order: derived in
         # clusters.variableBoundaryItems, the argument is accepted for the reference's call signature
         if myRoot is not None:
-            raise NotImplementedError('distributed near-field assembly by subtree')
+            # NA:3247-3260 / :1697-1712: the near field of ONE rank -- the cluster pairs whose row cluster n1 lies in the subtree
+            # myRoot (the reference hangs one subtree per rank under the root, clusterMethodCy.pyx:1854-1896), stored as
+            # unsymmetric CSR with complete blocks n1 x n2; writes into rows of other subtrees are dropped by the pattern
+            # (NA:2174, 2240).  The operator is the sum over the subtrees.
+            mine = np.zeros(self.dm.num_dofs, dtype=bool)
+            mine[np.asarray(myRoot.get_dofs() if hasattr(myRoot, 'get_dofs') else myRoot.dofs)] = True
+            Pnear = [cp for cp in Pnear if cp.n1.dofs.shape[0] and mine[cp.n1.dofs[0]]]
+            forceUnsymmetricMatrix, _symmetrizeMasks = True, True
         ctx = self.context()
         dev = torch.device('cuda', ctx.device)
         dm = self.dm

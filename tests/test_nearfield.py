@@ -313,3 +313,38 @@ def test_pattern_on_a_torch_device_equals_the_numpy_one():
         b = (b[0].numpy(), b[1].numpy())
         assert a[0].dtype == b[0].dtype == np.int32 and a[1].dtype == b[1].dtype == np.int32
         assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('mode', ['tiles', 'masks'])
+def test_gpu_assemble_clusters_by_subtree(mode):
+    """assembleClusters(Pnear, myRoot=subtree) (NA:3247-3260, 1697-1712): the near field of the rank that owns `subtree` -- the
+    cluster pairs whose row cluster lies in it, complete blocks in unsymmetric CSR; over the children of the root the parts
+    add up to the near field, each part equals the oracle's blocks of its pairs"""
+    from pynucleus_amd import clusters
+    b = _gpu_builder(3, 0.75, zeroExterior=True)
+    if mode == 'masks':
+        b.params['maxMasksNNZ'] = 10000000
+    dm = b.dm
+    rp = dict(b.getH2RefinementParams(), minSize=8)
+    root, Pnear, Pfar = clusters.getNearFieldClusters(dm, rp['eta'], rp['minSize'], rp['maxLevels'])
+    full = b.assembleClusters(Pnear, forceUnsymmetricMatrix=True).toarray()
+    scale = np.abs(full).max()
+    total = np.zeros_like(full)
+    kids = root.children
+    assert len(kids) >= 2
+    seen = 0
+    for kid in kids:
+        part = b.assembleClusters(Pnear, myRoot=kid)
+        mine = [cp for cp in Pnear if cp.n1.dofs[0] in set(kid.dofs.tolist())]
+        seen += len(mine)
+        P = part.toarray()
+        rows = np.zeros(dm.num_dofs, dtype=bool)
+        rows[kid.dofs] = True
+        assert np.abs(P[~rows]).max() == 0.                       # only rows of the subtree
+        indptr, indices, data, diag, cnt = _oracle_near(b.tables, mine, symmetric=False, symmetrize=True)
+        ref = _to_dense(dm.num_dofs, indptr, indices, data, None)
+        assert np.abs(P-ref).max() <= 1e-11*scale
+        total += P
+    assert seen == len(Pnear)
+    assert np.abs(total-full).max() <= 1e-12*scale
