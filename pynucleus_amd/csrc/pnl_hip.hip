@@ -1401,10 +1401,13 @@ static int tile_uniform_order(const pnl_context *ctx, const pnl_order_formula &F
 static bool tile_is_uniform(const pnl_context *ctx, const pnl_order_formula &F, int ta, int tb) { return tile_uniform_order(ctx, F, ta, tb, 2) == 2; }
 
 namespace {
-template <int DIM>
+template <int DIM, int DPE>
 int pointwise_impl(pnl_context *ctx, double *A, int64_t ldA, int zero_exterior, int cell_begin, int cell_end, int npairs,
                    int nbpairs) {
-    constexpr int NV = DIM+1, DPE = NV, ND = DPE*(DPE+1)/2, ST = 4+DPE;
+    // P1: tile kernels with LDS sub-blocks (k_pw_tile, k_pw_mixed, k_pw_lane).  P2 (FL2:894-1184 is element-agnostic): every
+    // distant pair through classification, the sorted work list and k_pw_distant (16 lanes per pair, global atomics)
+    constexpr int NV = DIM+1, ND = DPE*(DPE+1)/2, ST = 4+DPE;
+    constexpr bool P1 = DPE == NV;
     int rc;
     DevProblem &P = ctx->P;
     P.qmax = ctx->qmax;
@@ -1423,7 +1426,7 @@ int pointwise_impl(pnl_context *ctx, double *A, int64_t ldA, int zero_exterior, 
         // themselves (overflow is detected by pnl_get_counters); the tile-less variant lists every pair of the cell range
         double pairs = 0.;
         for (long long c = cell_begin; c < cell_end; c++) pairs += (double)(ctx->nc-c);
-        const bool tiles_evaluate = ctx->tile == 64 && !pnl_tune("PNL_PW_NOMIXED");
+        const bool tiles_evaluate = P1 && ctx->tile == 64 && !pnl_tune("PNL_PW_NOMIXED");
         const size_t want = tiles_evaluate ? (size_t)std::min<double>(std::max<double>(pairs*0.1, 1 << 20), 400e6)
                                            : (size_t)std::max<double>(pairs, 1024.);
         if (want > 1500000000ull) return fail(ctx, PNL_ERR_UNSUPPORTED, "%zu pairs exceed the work list of the pointwise path", want);
@@ -1454,7 +1457,7 @@ int pointwise_impl(pnl_context *ctx, double *A, int64_t ldA, int zero_exterior, 
             if (DIM == 2) { F.a = sv-1.; F.b = 1.; F.e = sv; F.den0 = 0.4; } else { F.a = 2.*sv-1.; F.b = 0.; F.e = 2.*sv; F.den0 = 0.8; }
             return F;
         };
-        const bool allow = ctx->tile == T && ctx->qmax >= 2 && !pnl_tune("PNL_PW_NOTILE");
+        const bool allow = P1 && ctx->tile == T && ctx->qmax >= 2 && !pnl_tune("PNL_PW_NOTILE");
         const int a0 = cell_begin/T, a1 = (cell_end+T-1)/T;
         for (int d = 0; d < nbk; d++)
             for (int a = a0; a < a1 && a+d < nbk; a++) {
@@ -1471,7 +1474,7 @@ int pointwise_impl(pnl_context *ctx, double *A, int64_t ldA, int zero_exterior, 
         if ((rc = upload(ctx, ctx->b_tiles, all.data(), all.size()))) return rc;
         ctx->tiles_cached.clear(); ctx->tiles_cb = -1;            // b_tiles no longer holds the dense tile list
     }
-    if (!uniform.empty()) {
+    if constexpr (P1) if (!uniform.empty()) {
         const int acc_stride = ctx->nU+1;
         constexpr int NP = DIM == 2 ? 3 : 2;
         const size_t lds = sizeof(double)*(64*NP*DIM+2*64*NP+64+2*64*ND)+sizeof(int)*(64*DPE+64)
@@ -1488,8 +1491,8 @@ int pointwise_impl(pnl_context *ctx, double *A, int64_t ldA, int zero_exterior, 
     }
     HIPCHK(ctx, hipEventRecord(ctx->ev[7], ctx->stream));
     // the other tiles: classification, in-tile evaluation of the rules with at most 16 points (LDS sub-blocks), work list for the rest
-    const bool in_tile = ctx->tile == 64 && !pnl_tune("PNL_PW_NOMIXED");
-    if (!mixed.empty() && in_tile) {
+    const bool in_tile = P1 && ctx->tile == 64 && !pnl_tune("PNL_PW_NOMIXED");
+    if constexpr (P1) if (!mixed.empty() && in_tile) {
         const int acc_stride = ctx->nU+1;
         const size_t lds = sizeof(double)*(PNL_PW_LANE_MAXPTS*ST+64*PNL_PW_LANE_MAXPTS*2+2*64*ND)+sizeof(unsigned short)*64*64
                            +sizeof(int)*(3*PNL_PW_NBUCK+2*64*DPE)+2*sizeof(double)*(size_t)(ctx->nU+1)*acc_stride;
@@ -1504,8 +1507,9 @@ int pointwise_impl(pnl_context *ctx, double *A, int64_t ldA, int zero_exterior, 
         hipLaunchKernelGGL(mfun, dim3(grid), dim3(PNL_NTHREADS), lds, ctx->stream, P, W, (const int2*)ctx->b_tiles.p, (int)mixed.size(), A,
                            (long long)ldA, (double*)ctx->b_D.p, acc_stride, (int4*)ctx->b_wl.p, (unsigned*)ctx->b_wlcount.p, ctx->wl_cap,
                            cell_begin, cell_end, (unsigned*)ctx->b_tilectr.p);
-    } else if (!mixed.empty())
-        hipLaunchKernelGGL((k_pw_classify<DIM>), dim3((unsigned)mixed.size()), dim3(PNL_NTHREADS), 0, ctx->stream, P, W,
+    }
+    if (!mixed.empty() && !in_tile)
+        hipLaunchKernelGGL((k_pw_classify<DIM, DPE>), dim3((unsigned)mixed.size()), dim3(PNL_NTHREADS), 0, ctx->stream, P, W,
                            (const int2*)ctx->b_tiles.p, (int4*)ctx->b_wl.p, (unsigned*)ctx->b_wlcount.p, ctx->wl_cap, cell_begin, cell_end);
     HIPCHK(ctx, hipGetLastError());
     HIPCHK(ctx, hipEventRecord(ctx->ev[6], ctx->stream));
@@ -1522,10 +1526,10 @@ int pointwise_impl(pnl_context *ctx, double *A, int64_t ldA, int zero_exterior, 
         // LDS: rule table + order / scaling of the second cell's points for the 16 pairs of a chunk
         const int tab_max = 256;
         const size_t lds = sizeof(double)*((size_t)tab_max*ST+(size_t)(PNL_NTHREADS/16)*tab_max*2);
-        auto kfun = k_pw_distant<DIM>;
+        auto kfun = k_pw_distant<DIM, DPE>;
         HIPCHK(ctx, hipFuncSetAttribute((const void*)kfun, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        const bool lane_kernel = !pnl_tune("PNL_PW_NOLANE");      // (with the in-tile evaluation only the rules of more than 16 points arrive here)
-        if (lane_kernel)
+        const bool lane_kernel = P1 && !pnl_tune("PNL_PW_NOLANE");      // (with the in-tile evaluation only the rules of more than 16 points arrive here)
+        if constexpr (P1) if (lane_kernel)
             hipLaunchKernelGGL((k_pw_lane<DIM>), dim3(256*2), dim3(PNL_NTHREADS), 0, ctx->stream, P, W, (const int4*)ctx->b_wlsorted.p,
                                (const unsigned*)offs, A, (long long)ldA, (double*)ctx->b_D.p);
         hipLaunchKernelGGL(kfun, dim3(256*4), dim3(PNL_NTHREADS), lds, ctx->stream, P, W, (const int4*)ctx->b_wlsorted.p,
@@ -1537,10 +1541,10 @@ int pointwise_impl(pnl_context *ctx, double *A, int64_t ldA, int zero_exterior, 
     if (npairs > 0) {
         const unsigned grid = (unsigned)((2ll*npairs*64+PNL_NTHREADS-1)/PNL_NTHREADS);
         const int4 *pp = (const int4*)ctx->b_pw_pairs.p;
-        hipLaunchKernelGGL((k_pw_singular<DIM, 0>), dim3(grid), dim3(PNL_NTHREADS), 0, ctx->stream, P, W, pp, npairs, A, (long long)ldA, cell_begin, cell_end);
-        hipLaunchKernelGGL((k_pw_singular<DIM, 1>), dim3(grid), dim3(PNL_NTHREADS), 0, ctx->stream, P, W, pp, npairs, A, (long long)ldA, cell_begin, cell_end);
+        hipLaunchKernelGGL((k_pw_singular<DIM, DPE, 0>), dim3(grid), dim3(PNL_NTHREADS), 0, ctx->stream, P, W, pp, npairs, A, (long long)ldA, cell_begin, cell_end);
+        hipLaunchKernelGGL((k_pw_singular<DIM, DPE, 1>), dim3(grid), dim3(PNL_NTHREADS), 0, ctx->stream, P, W, pp, npairs, A, (long long)ldA, cell_begin, cell_end);
         if (DIM == 2)
-            hipLaunchKernelGGL((k_pw_singular<DIM, (DIM == 2 ? 2 : 1)>), dim3(grid), dim3(PNL_NTHREADS), 0, ctx->stream, P, W, pp, npairs, A, (long long)ldA, cell_begin, cell_end);
+            hipLaunchKernelGGL((k_pw_singular<DIM, DPE, (DIM == 2 ? 2 : 1)>), dim3(grid), dim3(PNL_NTHREADS), 0, ctx->stream, P, W, pp, npairs, A, (long long)ldA, cell_begin, cell_end);
         HIPCHK(ctx, hipGetLastError());
     }
     HIPCHK(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
@@ -1548,14 +1552,14 @@ int pointwise_impl(pnl_context *ctx, double *A, int64_t ldA, int zero_exterior, 
         const int ncell = cell_end-cell_begin, gx = (ncell+PNL_NTHREADS-1)/PNL_NTHREADS;
         int per = 16;
         while (per > 1 && (long long)gx*((ctx->nb+per-1)/per) < 4096) per >>= 1;
-        hipLaunchKernelGGL((k_pw_boundary_distant<DIM>), dim3(gx, (ctx->nb+per-1)/per), dim3(PNL_NTHREADS), 0, ctx->stream, P, W,
+        hipLaunchKernelGGL((k_pw_boundary_distant<DIM, DPE>), dim3(gx, (ctx->nb+per-1)/per), dim3(PNL_NTHREADS), 0, ctx->stream, P, W,
                            (double*)ctx->b_D.p, cell_begin, cell_end, per);
         if (nbpairs > 0) {
             const unsigned grid = (unsigned)(((long long)nbpairs*64+PNL_NTHREADS-1)/PNL_NTHREADS);
             const int4 *bp = (const int4*)ctx->b_pw_bpairs.p;
-            hipLaunchKernelGGL((k_pw_boundary_singular<DIM, 0>), dim3(grid), dim3(PNL_NTHREADS), 0, ctx->stream, P, W, bp, nbpairs, (double*)ctx->b_D.p, cell_begin, cell_end);
+            hipLaunchKernelGGL((k_pw_boundary_singular<DIM, DPE, 0>), dim3(grid), dim3(PNL_NTHREADS), 0, ctx->stream, P, W, bp, nbpairs, (double*)ctx->b_D.p, cell_begin, cell_end);
             if (DIM == 2)
-                hipLaunchKernelGGL((k_pw_boundary_singular<DIM, (DIM == 2 ? 1 : 0)>), dim3(grid), dim3(PNL_NTHREADS), 0, ctx->stream, P, W, bp, nbpairs, (double*)ctx->b_D.p, cell_begin, cell_end);
+                hipLaunchKernelGGL((k_pw_boundary_singular<DIM, DPE, (DIM == 2 ? 1 : 0)>), dim3(grid), dim3(PNL_NTHREADS), 0, ctx->stream, P, W, bp, nbpairs, (double*)ctx->b_D.p, cell_begin, cell_end);
         }
         HIPCHK(ctx, hipGetLastError());
     }
@@ -2786,7 +2790,8 @@ int pnl_set_order_function(pnl_context *ctx, const pnl_order_function *f, const 
     if (!ctx || !f || !cell_smax) return fail(ctx, PNL_ERR_INVALID, "bad order-function arguments");
     if (!ctx->have_mesh) return fail(ctx, PNL_ERR_STATE, "upload the mesh first");
     if (f->type < 1 || f->type > 4) return fail(ctx, PNL_ERR_UNSUPPORTED, "order function type %d is not implemented", f->type);
-    if (ctx->have_dofs && ctx->dpe != ctx->dim+1) return fail(ctx, PNL_ERR_UNSUPPORTED, "pointwise variable orders are built for P1 elements");
+    if (ctx->have_dofs && !(ctx->dpe == ctx->dim+1 || (ctx->dim == 2 && ctx->dpe == 6) || (ctx->dim == 1 && ctx->dpe == 3)))
+        return fail(ctx, PNL_ERR_UNSUPPORTED, "pointwise variable orders: P1 and P2 elements");
     std::memset(&ctx->pw, 0, sizeof(ctx->pw));
     ctx->pw.type = f->type; ctx->pw.normalized = f->normalized;
     for (int i = 0; i < 6; i++) ctx->pw.p[i] = f->p[i];
@@ -2814,7 +2819,7 @@ int pnl_upload_pointwise_rules(pnl_context *ctx, int which, int panel, int nkeys
     int rc;
     if (which == PNL_INTERIOR) {
         const int common = slot+1;
-        const int expect = common == nV ? dpe : (common == 1 ? 2*dpe-1 : 2*dpe-2);
+        const int expect = common == nV ? dpe : (common == 1 ? 2*dpe-ctx->dpv : 2*dpe-2*ctx->dpv-ctx->dped);
         if (rows != expect) return fail(ctx, PNL_ERR_INVALID, "pointwise rule has %d rows, expected %d", rows, expect);
         if ((rc = upload(ctx, ctx->b_pw_rule[0][slot][0], nodes, (size_t)nkeys*2*nV*M))) return rc;
         if ((rc = upload(ctx, ctx->b_pw_rule[0][slot][1], w, (size_t)nkeys*M))) return rc;
@@ -2844,7 +2849,8 @@ int pnl_assemble_dense_pointwise(pnl_context *ctx, double *A, int64_t ldA, int z
     int rc;
     if (!ctx->have_pw || !ctx->have_rules) return fail(ctx, PNL_ERR_STATE, "order function and distant rules must be set before assembling");
     if ((rc = finalize(ctx))) return rc;
-    if (ctx->dpe != ctx->dim+1) return fail(ctx, PNL_ERR_UNSUPPORTED, "pointwise variable orders are built for P1 elements");
+    if (!(ctx->dpe == ctx->dim+1 || (ctx->dim == 2 && ctx->dpe == 6) || (ctx->dim == 1 && ctx->dpe == 3)))
+        return fail(ctx, PNL_ERR_UNSUPPORTED, "pointwise variable orders: P1 and P2 elements");
     if (!A || ldA < ctx->N) return fail(ctx, PNL_ERR_INVALID, "bad output matrix (ldA=%lld, num_dofs=%d)", (long long)ldA, ctx->N);
     if (cell_begin < 0 || cell_end > ctx->nc || cell_begin > cell_end) return fail(ctx, PNL_ERR_INVALID, "bad cell range");
     if (npairs < 0 || nbpairs < 0 || (npairs && !pairs) || (nbpairs && !bpairs)) return fail(ctx, PNL_ERR_INVALID, "bad pair lists");
@@ -2878,8 +2884,11 @@ int pnl_assemble_dense_pointwise(pnl_context *ctx, double *A, int64_t ldA, int z
     unsigned long long visited = 0;
     for (long long c = cell_begin; c < cell_end; c++) visited += (unsigned long long)(ctx->nc-c);
     ctx->visited_pairs = visited; ctx->visited_is_assembled = false;
-    return ctx->dim == 2 ? pointwise_impl<2>(ctx, A, ldA, zero_exterior, cell_begin, cell_end, npairs, nbpairs)
-                         : pointwise_impl<1>(ctx, A, ldA, zero_exterior, cell_begin, cell_end, npairs, nbpairs);
+    if (ctx->dim == 2)
+        return ctx->dpe == 6 ? pointwise_impl<2, 6>(ctx, A, ldA, zero_exterior, cell_begin, cell_end, npairs, nbpairs)
+                             : pointwise_impl<2, 3>(ctx, A, ldA, zero_exterior, cell_begin, cell_end, npairs, nbpairs);
+    return ctx->dpe == 3 ? pointwise_impl<1, 3>(ctx, A, ldA, zero_exterior, cell_begin, cell_end, npairs, nbpairs)
+                         : pointwise_impl<1, 2>(ctx, A, ldA, zero_exterior, cell_begin, cell_end, npairs, nbpairs);
 }
 
 int pnl_get_counters(pnl_context *ctx, int64_t *out, int n) {

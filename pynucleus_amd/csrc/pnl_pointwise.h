@@ -68,11 +68,11 @@ __device__ __forceinline__ DevFormula pw_formula_boundary(const PwDev &W, int di
 
 // ---- distant pairs: classification of all cell pairs c1 < c2 without a common vertex into the work list --------------
 // workgroup per 64x64 block of the tile list (the tiles that are not uniform); entry = (c1, c2, rule offset, n | order << 16)
-template <int DIM>
+template <int DIM, int DPE>
 __global__ void __launch_bounds__(PNL_NTHREADS)
 k_pw_classify(const DevProblem P, const PwDev W, const int2 *__restrict__ tiles, int4 *__restrict__ wl,
               unsigned *__restrict__ wl_count, unsigned wl_cap, int cell_begin, int cell_end) {
-    constexpr int NV = DIM+1, DPE = NV, T = 64;
+    constexpr int NV = DIM+1, T = 64;
     const int ta = tiles[blockIdx.x].x, tb = tiles[blockIdx.x].y;
     const int i = threadIdx.x & 63, jw = threadIdx.x >> 6;
     const int c1 = ta*T+i;
@@ -145,11 +145,11 @@ __global__ void k_pw_stats(const DevProblem P, const unsigned *__restrict__ hist
 // per point pair: L = ln d2 once, K1 = w_i w_j C(s(x_i)) exp(e(x_i) L), K2 = w_i w_j C(s(y_j)) exp(e(y_j) L);
 // order and scaling of the points of the second cell are computed once per pair and kept in LDS.
 #define PNL_PW_MAXPTS 128
-template <int DIM>
+template <int DIM, int DPE>
 __global__ void __launch_bounds__(PNL_NTHREADS)
 k_pw_distant(const DevProblem P, const PwDev W, const int4 *__restrict__ sorted, const unsigned *__restrict__ offs,
              double *__restrict__ A, long long ldA, double *__restrict__ Dglob, int tab_max_pts, int nmin) {
-    constexpr int NV = DIM+1, DPE = NV, NC = NV*DIM, ND = DPE*(DPE+1)/2, NG = DPE*DPE, NACC = 2*NG+2*ND, LPP = 16,
+    constexpr int NV = DIM+1, NC = NV*DIM, ND = DPE*(DPE+1)/2, NG = DPE*DPE, NACC = 2*NG+2*ND, LPP = 16,
                   PPC = PNL_NTHREADS/LPP, NREP = (NACC+LPP-1)/LPP, ST = 4+DPE;
     extern __shared__ double s_mem[];            // rule [tab_max_pts][ST], then per pair of the chunk [PPC][tab_max_pts][2]: e(y_j), w_j C(y_j)
     double *s_rule = s_mem, *s_y = s_mem+(size_t)tab_max_pts*ST;
@@ -955,14 +955,17 @@ k_pw_lane(const DevProblem P, const PwDev W, const int4 *__restrict__ sorted, co
 
 // ---- touching pairs (FL2:1133-1184, FL1:548-604): one wave per (pair, orientation), rule of the pair's order key ------
 // pairs[t] = (c1 <= c2, common, key); full (rows x rows) non-symmetric local matrix, scatter NA:222-253
-template <int DIM, int SLOT>
+template <int DIM, int DPE, int SLOT>
 __global__ void __launch_bounds__(PNL_NTHREADS)
 k_pw_singular(const DevProblem P, const PwDev W, const int4 *__restrict__ pairs, int npairs, double *__restrict__ A, long long ldA,
               int cell_begin, int cell_end) {
-    constexpr int NV = DIM+1, DPE = NV, DPV = 1;
+    constexpr int NV = DIM+1, DPV = 1, DPED = (DIM == 2 && DPE == 6) ? 1 : 0;
     constexpr int COMMON = SLOT+1;
-    constexpr int ROWS = (COMMON == NV) ? DPE : (COMMON == 1 ? 2*DPE-DPV : 2*DPE-2*DPV);
-    constexpr int NE = ROWS*ROWS;
+    // merged local DoFs: shared vertices (and the shared edge) first (FL2:965-1075, FL1:466-530)
+    constexpr int ROWS = (COMMON == NV) ? DPE : (COMMON == 1 ? 2*DPE-DPV : 2*DPE-2*DPV-DPED);
+    // the ROWS x ROWS local matrix in groups of RG rows (P2: up to 11 x 11 entries do not fit the registers of a lane at once; the
+    // point loop runs once per group -- touching pairs are few)
+    constexpr int NGRP = ROWS > 8 ? 2 : 1, RG = (ROWS+NGRP-1)/NGRP, NE = RG*ROWS;
     const int lane = threadIdx.x & 63;
     const int wid = (blockIdx.x*PNL_NTHREADS+threadIdx.x) >> 6;
     if (wid >= 2*npairs) return;
@@ -1018,6 +1021,7 @@ k_pw_singular(const DevProblem P, const PwDev W, const int4 *__restrict__ pairs,
             for (int k = DPV; k < DPE; k++) perm[DPE+k-DPV] = DPE+t2[k];
         } else if (COMMON == 2) {
             for (int k = 2*DPV; k < NV*DPV; k++) perm[DPE+k-2*DPV] = DPE+t2[k];
+            for (int k = NV*DPV+DPED; k < DPE; k++) perm[DPE+k-2*DPV-DPED] = DPE+t2[k];
         }
     }
     double s1[NV][DIM], s2[NV][DIM];
@@ -1039,57 +1043,68 @@ k_pw_singular(const DevProblem P, const PwDev W, const int4 *__restrict__ pairs,
     const double *__restrict__ w = W.w[SLOT]+(size_t)key*M;
     const double *__restrict__ phi0 = W.phi0[SLOT]+(size_t)key*ROWS*M;
     const double *__restrict__ phi1 = W.phi1[SLOT]+(size_t)key*ROWS*M;
-    double acc[NE];
-#pragma unroll
-    for (int e = 0; e < NE; e++) acc[e] = 0.;
-    for (int m = lane; m < M; m += 64) {
-        double x[DIM], y[DIM], d2 = 0.;
-#pragma unroll
-        for (int d = 0; d < DIM; d++) {
-            double xx = 0., yy = 0.;
-#pragma unroll
-            for (int k = 0; k < NV; k++) {
-                xx = __builtin_fma(s1[k][d], nodes[(size_t)k*M+m], xx);
-                yy = __builtin_fma(s2[k][d], nodes[(size_t)(NV+k)*M+m], yy);
-            }
-            x[d] = xx; y[d] = yy;
-            d2 = __builtin_fma(xx-yy, xx-yy, d2);
-        }
-        const double L = pnl_log(d2);
-        const double sx = pw_order<DIM>(W, x), sy = pw_order<DIM>(W, y);
-        const double t1 = w[m]*pw_scaling<DIM>(W, sx, false)*pnl_exp((-0.5*DIM-sx)*L);
-        const double t2 = w[m]*pw_scaling<DIM>(W, sy, false)*pnl_exp((-0.5*DIM-sy)*L);
-        double f[ROWS], ps[ROWS];
-#pragma unroll
-        for (int r = 0; r < ROWS; r++) {
-            const double a = phi0[(size_t)r*M+m], b = phi1[(size_t)r*M+m];
-            f[r] = t1*a-t2*b; ps[r] = a-b;
-        }
-#pragma unroll
-        for (int I = 0; I < ROWS; I++)
-#pragma unroll
-            for (int J = 0; J < ROWS; J++) acc[I*ROWS+J] = __builtin_fma(f[I], ps[J], acc[I*ROWS+J]);
-    }
     const double vol = W.sfac*P.cvol[c1]*P.cvol[c2];
-    double mine = 0.;
-    int myI = 0, myJ = 0;
+#pragma unroll 1
+    for (int grp = 0; grp < NGRP; grp++) {
+        const int r0 = grp*RG;
+        double acc[NE];
 #pragma unroll
-    for (int e = 0; e < NE; e++) {
-        const double s = wave_sum(acc[e]);
-        if (lane == e) { mine = s; myI = e/ROWS; myJ = e-(e/ROWS)*ROWS; }
-    }
-    if (lane < NE) {
-        int gi = -1, gj = -1;
+        for (int e = 0; e < NE; e++) acc[e] = 0.;
+        for (int m = lane; m < M; m += 64) {
+            double x[DIM], y[DIM], d2 = 0.;
 #pragma unroll
-        for (int k = 0; k < 2*DPE; k++) {
-            const int pk = perm[k];
-            int g = -1;
+            for (int d = 0; d < DIM; d++) {
+                double xx = 0., yy = 0.;
 #pragma unroll
-            for (int m = 0; m < 2*DPE; m++) g = (pk == m) ? ld[m] : g;
-            gi = (myI == k) ? g : gi;
-            gj = (myJ == k) ? g : gj;
+                for (int k = 0; k < NV; k++) {
+                    xx = __builtin_fma(s1[k][d], nodes[(size_t)k*M+m], xx);
+                    yy = __builtin_fma(s2[k][d], nodes[(size_t)(NV+k)*M+m], yy);
+                }
+                x[d] = xx; y[d] = yy;
+                d2 = __builtin_fma(xx-yy, xx-yy, d2);
+            }
+            const double L = pnl_log(d2);
+            const double sx = pw_order<DIM>(W, x), sy = pw_order<DIM>(W, y);
+            const double t1 = w[m]*pw_scaling<DIM>(W, sx, false)*pnl_exp((-0.5*DIM-sx)*L);
+            const double t2 = w[m]*pw_scaling<DIM>(W, sy, false)*pnl_exp((-0.5*DIM-sy)*L);
+            double ps[ROWS];
+#pragma unroll
+            for (int r = 0; r < ROWS; r++) ps[r] = phi0[(size_t)r*M+m]-phi1[(size_t)r*M+m];
+#pragma unroll
+            for (int I = 0; I < RG; I++) {
+                const int r = min(r0+I, ROWS-1);
+                const double f = t1*phi0[(size_t)r*M+m]-t2*phi1[(size_t)r*M+m];
+#pragma unroll
+                for (int J = 0; J < ROWS; J++) acc[I*ROWS+J] = __builtin_fma(f, ps[J], acc[I*ROWS+J]);
+            }
         }
-        if (gi >= 0 && gj >= 0) atomic_add_f64(&A[(long long)gi*ldA+gj], mine*vol);
+        // reduce; lane (e mod 64) scatters entry e of the group
+        double mine[(NE+63)/64];
+#pragma unroll
+        for (int r = 0; r < (NE+63)/64; r++) mine[r] = 0.;
+#pragma unroll
+        for (int e = 0; e < NE; e++) {
+            const double sum = wave_sum(acc[e]);
+            if (lane == (e & 63)) mine[e >> 6] = sum;
+        }
+#pragma unroll
+        for (int rep = 0; rep < (NE+63)/64; rep++) {
+            const int e = lane+64*rep;
+            if (e >= NE) continue;
+            const int myI = r0+e/ROWS, myJ = e-(e/ROWS)*ROWS;
+            if (myI >= ROWS) continue;
+            int gi = -1, gj = -1;
+#pragma unroll
+            for (int k = 0; k < 2*DPE; k++) {
+                const int pk = perm[k];
+                int g = -1;
+#pragma unroll
+                for (int m = 0; m < 2*DPE; m++) g = (pk == m) ? ld[m] : g;
+                gi = (myI == k) ? g : gi;
+                gj = (myJ == k) ? g : gj;
+            }
+            if (gi >= 0 && gj >= 0) atomic_add_f64(&A[(long long)gi*ldA+gj], mine[rep]*vol);
+        }
     }
     if (lane == 0) {
         if (!orient) { atomicAdd(&P.counters[1], 1ull); atomicAdd(&P.counters[128+SLOT], 1ull); }
@@ -1098,10 +1113,10 @@ k_pw_singular(const DevProblem P, const PwDev W, const int4 *__restrict__ pairs,
 }
 
 // ---- Omega x Omega^c with the pointwise boundary kernel C(s(x))/s(x) |x-y|^(1-d-2 s(x)), x in the cell ----------------
-template <int DIM>
+template <int DIM, int DPE>
 __global__ void __launch_bounds__(PNL_NTHREADS)
 k_pw_boundary_distant(const DevProblem P, const PwDev W, double *__restrict__ Dglob, int cell_begin, int cell_end, int facets_per_chunk) {
-    constexpr int NV = DIM+1, DPE = NV, NC = NV*DIM, NF = DIM, ND = DPE*(DPE+1)/2;
+    constexpr int NV = DIM+1, NC = NV*DIM, NF = DIM, ND = DPE*(DPE+1)/2;
     const int c = cell_begin+blockIdx.x*PNL_NTHREADS+threadIdx.x;
     const bool active = c < cell_end;
     const int cc = active ? c : cell_begin;
@@ -1204,11 +1219,11 @@ k_pw_boundary_distant(const DevProblem P, const PwDev W, double *__restrict__ Dg
 }
 
 // touching (cell, facet) pairs: pairs[t] = (cell, facet, common, key); one wave per pair
-template <int DIM, int SLOT>
+template <int DIM, int DPE, int SLOT>
 __global__ void __launch_bounds__(PNL_NTHREADS)
 k_pw_boundary_singular(const DevProblem P, const PwDev W, const int4 *__restrict__ pairs, int npairs, double *__restrict__ Dglob,
                        int cell_begin, int cell_end) {
-    constexpr int NV = DIM+1, DPE = NV, NF = DIM, ND = DPE*(DPE+1)/2;
+    constexpr int NV = DIM+1, NF = DIM, ND = DPE*(DPE+1)/2;
     const int lane = threadIdx.x & 63;
     const int wid = (blockIdx.x*PNL_NTHREADS+threadIdx.x) >> 6;
     if (wid >= npairs) return;

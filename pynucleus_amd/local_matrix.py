@@ -183,8 +183,6 @@ class nonlocalTables:
         distinct orders of the touching pairs.  The _nonsym constructors drop the caller's target_order and
         quad_order_diagonal (FL2:911, FL1:427 pass num_dofs in their place), the boundary twins keep them."""
         mesh = dm.mesh
-        if dm.dofs_per_element != mesh.dim+1:
-            raise NotImplementedError('pointwise variable orders are built for P1 elements')
         self.classes = None
         self.dpe = dm.dofs_per_element
         self.num_dofs = dm.num_dofs

@@ -168,17 +168,29 @@ def test_two_ranks_share_the_pairs():
 
 
 @pytest.mark.parametrize('case', ['smoothedLeftRight_disc', 'constantNonSym_disc', 'innerOuter_disc', 'smoothedLeftRight_interval',
-                                  'linearLeftRight_interval', 'constantNonSym_noext', 'smoothedLeftRight_disc4'])
+                                  'linearLeftRight_interval', 'constantNonSym_noext', 'smoothedLeftRight_disc4',
+                                  'smoothedLeftRight_disc_P2', 'innerOuter_disc_P2_noext', 'smoothedLeftRight_interval_P2',
+                                  'constantNonSym_disc_P2'])
 def test_pointwise_nonsymmetric_dense(case):
     """a16: non-symmetric kernels with an order s(x) per quadrature point (fractionalLaplacian{1,2}D_nonsym, both orientations of
     every pair, (2 dpe)^2 local matrices, near rules keyed by the pair's order): GPU == oracle entry-wise, same counters"""
-    from pynucleus_amd import disc, interval, PHYSICAL, P1_DoFMap, getFractionalKernel
+    from pynucleus_amd import disc, interval, PHYSICAL, P1_DoFMap, P2_DoFMap, getFractionalKernel
     from pynucleus_amd.builder import nonlocalBuilder
     from pynucleus_amd.fractionalOrders import (smoothedLeftRightFractionalOrder, constantNonSymFractionalOrder,
                                                 smoothedInnerOuterFractionalOrder, linearLeftRightFractionalOrder)
     from oracle.oracle import OracleProblem
     zeroExterior = True
-    if case == 'smoothedLeftRight_disc':
+    DoFMap = P2_DoFMap if '_P2' in case else P1_DoFMap
+    # P2 (FL2:894-1184 / FL1:410-604 are element-agnostic): (2 x 6)^2 local matrices, merged-DoF rows 6 / 9 / 11
+    if case == 'smoothedLeftRight_disc_P2':
+        mesh, s = disc(3), smoothedLeftRightFractionalOrder(0.25, 0.75, r=0.3)
+    elif case == 'innerOuter_disc_P2_noext':
+        mesh, s, zeroExterior = disc(2), smoothedInnerOuterFractionalOrder(0.3, 0.6, r=0.2), False
+    elif case == 'smoothedLeftRight_interval_P2':
+        mesh, s = interval(5), smoothedLeftRightFractionalOrder(0.25, 0.75)
+    elif case == 'constantNonSym_disc_P2':
+        mesh, s = disc(2), constantNonSymFractionalOrder(0.4)
+    elif case == 'smoothedLeftRight_disc':
         mesh, s = disc(3), smoothedLeftRightFractionalOrder(0.25, 0.75, r=0.3)
     elif case == 'smoothedLeftRight_disc4':              # 24 blocks of 64 cells: some tiles are uniform (k_pw_tile)
         mesh, s = disc(4), smoothedLeftRightFractionalOrder(0.25, 0.75, r=0.3)
@@ -192,7 +204,7 @@ def test_pointwise_nonsymmetric_dense(case):
         mesh, s = interval(5), linearLeftRightFractionalOrder(0.6, 0.3, r=0.25)
     else:
         mesh, s, zeroExterior = disc(2), constantNonSymFractionalOrder(0.6), False
-    dm = P1_DoFMap(mesh, PHYSICAL)
+    dm = DoFMap(mesh, PHYSICAL)
     b = nonlocalBuilder(dm, getFractionalKernel(mesh.dim, s), {}, zeroExterior=zeroExterior)
     A = b.getDense()
     Aref, cnt, _ = OracleProblem(b.tables).get_dense()
