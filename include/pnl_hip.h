@@ -279,7 +279,7 @@ int pnl_spmv(pnl_context *ctx, const double *data_dev, const double *diag_dev, c
  * non-symmetric branch of getDense (nonlocalAssembly_{SCALAR}.pxi:1411-1428, scatter :222-253) and the boundary term with
  * the pointwise boundary kernel.  P1 elements, infinite horizon.
  * type: 1 constant (p[0]), 2 smoothStep in x0, 3 linearStep in x0, 4 smoothStepRadial (fractionalOrders.pyx:338-540);
- * p = sl, sr, r, interface (radius for type 4), slope.  normalized: variableFractionalLaplacianScaling
+ * p = sl, sr, r, interface (radius for type 4), slope; type 5: pnl_set_order_vertex_values.  normalized: variableFractionalLaplacianScaling
  * (kernelNormalization.pyx:329-364) or 1/2. */
 typedef struct pnl_order_function {
     int32_t type, normalized;
@@ -296,6 +296,10 @@ typedef struct pnl_order_function {
  * interior / boundary order formula; sing_fac / bsing_fac as in pnl_upload_singular_rule */
 int pnl_set_order_function(pnl_context *ctx, const pnl_order_function *f, const double *cell_smax, const double *facet_smax,
                            double c0, double bc0, double sing_fac, double bsing_fac);
+/* type 5 (feFractionalOrder / lookupExtended, fractionalOrders.pyx:541-587, 660-668): the order is a continuous P1 function on the
+ * mesh of the assembly, values[nv] at its vertices.  A quadrature point is known by its cell and barycentric coordinates, so
+ * s(x) = sum_k lambda_k(x) values[vertex k of the cell] needs no point location. */
+int pnl_set_order_vertex_values(pnl_context *ctx, int nv, const double *values_host);
 /* near rules for the nkeys distinct orders of the touching pairs (the reference keys its rule dictionary by the singularity
  * value, fractionalLaplacian2D.pyx:957): nodes[nkeys][2(dim+1) | (dim+1)+dim][M], w[nkeys][M], phi0 / phi1[nkeys][rows][M]
  * = the x and y parts of the merged-DoF shape functions (PHI3 of the reference; boundary: phi0 = PHI, phi1 unused) */

@@ -803,10 +803,41 @@ int nlo_get_dense(const nlo_problem *P, double *A, int zero_exterior, int cell_s
 
 /* ---- non-symmetric kernels, order s(x) per quadrature point ---------------------------------------------------------
  * fractionalOrders.pyx:338-540: constantExtended, smoothStep, linearStep, smoothStepRadial */
+/* lookupExtended.evalPtr (fractionalOrders.pyx:573-587): find the cell that holds x (cellFinder2), evaluate the P1 function
+ * there.  Point location by barycentric coordinates over all cells, starting at the cell found last. */
+static double fe_order_lookup(const nlo_problem *P, const double *x) {
+    static int last = 0;
+    const int nV = P->dim+1;
+    double best_val = 0., best_min = -1e300;
+    for (int t = 0; t < P->nc; t++) {
+        const int c = (last+t) % P->nc;
+        double lam[3];
+        const int32_t *cv = P->cells+(size_t)c*nV;
+        if (P->dim == 1) {
+            const double a = P->vertices[cv[0]], b = P->vertices[cv[1]];
+            lam[1] = (x[0]-a)/(b-a); lam[0] = 1.-lam[1]; lam[2] = 0.;
+        } else {
+            const double *v0 = P->vertices+2*(size_t)cv[0], *v1 = P->vertices+2*(size_t)cv[1], *v2 = P->vertices+2*(size_t)cv[2];
+            const double det = (v1[0]-v0[0])*(v2[1]-v0[1])-(v2[0]-v0[0])*(v1[1]-v0[1]);
+            lam[1] = ((x[0]-v0[0])*(v2[1]-v0[1])-(v2[0]-v0[0])*(x[1]-v0[1]))/det;
+            lam[2] = ((v1[0]-v0[0])*(x[1]-v0[1])-(x[0]-v0[0])*(v1[1]-v0[1]))/det;
+            lam[0] = 1.-lam[1]-lam[2];
+        }
+        double mn = lam[0] < lam[1] ? lam[0] : lam[1];
+        if (P->dim == 2 && lam[2] < mn) mn = lam[2];
+        double val = 0.;
+        for (int k = 0; k < nV; k++) val += lam[k]*P->pw_vertex_s[cv[k]];
+        if (mn >= -1e-12) { last = c; return val; }
+        if (mn > best_min) { best_min = mn; best_val = val; }
+    }
+    return best_val;                             /* a point on the curved boundary side of the mesh: the nearest cell */
+}
+
 double nlo_pw_order(const nlo_problem *P, const double *x) {
     const double *p = P->pw_p;                  /* sl, sr, r, interface | radius, slope */
     switch (P->pw_type) {
     case 1: return p[0];
+    case 5: return fe_order_lookup(P, x);
     case 2:
         if (x[0] < p[3]-p[2]) return p[0];
         else if (x[0] > p[3]+p[2]) return p[1];

@@ -58,7 +58,7 @@ class nlo_problem(C.Structure):
                 ('pw_c0', C.c_double), ('pw_bc0', C.c_double), ('pw_nkeys', C.c_int32), ('pw_nbkeys', C.c_int32),
                 ('pw_keys', _P), ('pw_bkeys', _P),
                 ('pw_nodes', _P*3), ('pw_w', _P*3), ('pw_phi0', _P*3), ('pw_phi1', _P*3),
-                ('pw_bnodes', _P*2), ('pw_bw', _P*2), ('pw_bphi', _P*2)]
+                ('pw_bnodes', _P*2), ('pw_bw', _P*2), ('pw_bphi', _P*2), ('pw_vertex_s', _P)]
 
 
 def build():
@@ -113,7 +113,9 @@ def kernel_spec(kernel):
     s = getattr(kernel, 's', None)
     if s is None:
         return spec
-    if hasattr(s, 'sVals'):
+    if callable(getattr(s, 'spec', None)):
+        spec['s'] = s.spec()                           # the constructor's inputs of a piecewise-constant order
+    elif hasattr(s, 'sVals'):
         sv = np.array(s.sVals, dtype=np.float64)
         if hasattr(s, 'layerBoundaries'):
             spec['s'] = ('layers', np.array(s.layerBoundaries, dtype=np.float64), sv)
@@ -195,6 +197,8 @@ class OracleProblem:
             for i, v in enumerate(T.order_params):
                 P.pw_p[i] = v
             P.pw_c0, P.pw_bc0 = T.pw_c0, T.pw_bc0
+            if int(T.order_type) == 5:
+                P.pw_vertex_s = ptr(T.order_vertex_values, np.float64)
             P.pw_nkeys, P.pw_nbkeys = len(R['keys']), len(R['bkeys'])
             P.pw_keys, P.pw_bkeys = ptr(R['keys'], np.float64), ptr(R['bkeys'], np.float64)
             for slot, (nodes, w, phi0, phi1) in R['rules'].items():

@@ -321,6 +321,37 @@ def order_table(spec):
                     out[k] = next(i for i in range(nl) if bnd[i] <= v <= bnd[i+1])
             return out
         return orders, labels
+    if kind == 'innerOuter':
+        # fractionalOrders.pyx:664-691: r2x < r^2 is "inner"
+        dim, sii, soo, r, center, sio, soi = spec[1:8]
+        if not np.isfinite(sio):
+            sio = 0.5*(sii+soo)
+        if not np.isfinite(soi):
+            soi = 0.5*(sii+soo)
+        center = np.asarray(center, dtype=np.float64)[:dim]
+        return (np.array([[sii, sio], [soi, soo]], dtype=np.float64),
+                lambda pts: (((np.asarray(pts)[:, :dim]-center)**2).sum(axis=1) >= r*r).astype(np.int32))
+    if kind == 'islands':
+        # fractionalOrders.pyx:754-789: in an island iff r <= |x_i| <= r2 for every coordinate
+        sii, soo, r, r2, sio, soi = spec[1:7]
+        if not np.isfinite(sio):
+            sio = 0.5*(sii+soo)
+        if not np.isfinite(soi):
+            soi = 0.5*(sii+soo)
+
+        def labels(pts):
+            out = np.zeros(len(pts), dtype=np.int32)
+            for k, p in enumerate(np.asarray(pts)):
+                out[k] = 0 if all(r <= abs(v) <= r2 for v in p[:2]) else 1
+            return out
+        return np.array([[sii, sio], [soi, soo]], dtype=np.float64), labels
+    if kind == 'product':
+        # fractionalOrders.pyx:733-752 (sumFractionalOrder.eval multiplies the two values)
+        sv1, lab1 = order_table(spec[1])
+        sv2, lab2 = order_table(spec[2])
+        L2 = sv2.shape[0]
+        sv = np.kron(sv1, sv2)
+        return sv, (lambda pts: (lab1(pts)*L2+lab2(pts)).astype(np.int32))
     raise NotImplementedError(kind)
 
 

@@ -14,5 +14,6 @@ from .local_matrix import nonlocalTables  # noqa: F401
 from .fractionalOrders import (variableConstFractionalOrder, leftRightFractionalOrder, layersFractionalOrder,  # noqa: F401
                                piecewiseConstantFractionalOrder, constantNonSymFractionalOrder,
                                smoothedLeftRightFractionalOrder, linearLeftRightFractionalOrder,
-                               smoothedInnerOuterFractionalOrder)
+                               smoothedInnerOuterFractionalOrder, feFractionalOrder, innerOuterFractionalOrder,
+                               islandsFractionalOrder, sumFractionalOrder)
 from .builder import nonlocalBuilder, assembleNonlocalOperator  # noqa: F401

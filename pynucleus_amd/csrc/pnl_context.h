@@ -102,6 +102,8 @@ struct pnl_context {
     bool have_pw = false, have_pw_rules[2][3] = {{false, false, false}, {false, false, false}};
     int pw_nkeys[2] = {0, 0};
     std::vector<double> pw_cell_smax, pw_facet_smax;
+    std::vector<double> pw_vertex_s;           // order function of type 5: values at the mesh vertices
+    DevBuf b_pw_cellsv;
     DevBuf b_pw_csm, b_pw_fsm, b_pw_rule[2][3][4], b_pw_pairs, b_pw_bpairs;
     std::vector<std::vector<int>> h2_levels;   // nodes of every level >= 1
     std::vector<size_t> h2_level_off;

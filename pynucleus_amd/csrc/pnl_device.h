@@ -122,6 +122,8 @@ struct PwDev {
     int bM[2], pad;
     const double *bnodes[2], *bw[2], *bphi[2];
     double sfac, bfac;
+    const double *cell_sv;      // type 5: values of the P1 order function at the vertices of every cell, [(dim+1)][ncp]
+    long long sv_stride;        // ncp
 };
 
 // block-slot storage of the one-sided operator (pnl_tile2.h)

@@ -1407,7 +1407,8 @@ int pointwise_impl(pnl_context *ctx, double *A, int64_t ldA, int zero_exterior, 
     // P1: tile kernels with LDS sub-blocks (k_pw_tile, k_pw_mixed, k_pw_lane).  P2 (FL2:894-1184 is element-agnostic): every
     // distant pair through classification, the sorted work list and k_pw_distant (16 lanes per pair, global atomics)
     constexpr int NV = DIM+1, ND = DPE*(DPE+1)/2, ST = 4+DPE;
-    constexpr bool P1 = DPE == NV;
+    constexpr bool P1el = DPE == NV;
+    const bool P1 = P1el && ctx->pw.type != 5;           // a P1 order function (type 5) is known per cell: the generic kernels
     int rc;
     DevProblem &P = ctx->P;
     P.qmax = ctx->qmax;
@@ -1474,7 +1475,7 @@ int pointwise_impl(pnl_context *ctx, double *A, int64_t ldA, int zero_exterior, 
         if ((rc = upload(ctx, ctx->b_tiles, all.data(), all.size()))) return rc;
         ctx->tiles_cached.clear(); ctx->tiles_cb = -1;            // b_tiles no longer holds the dense tile list
     }
-    if constexpr (P1) if (!uniform.empty()) {
+    if constexpr (P1el) if (P1 && !uniform.empty()) {
         const int acc_stride = ctx->nU+1;
         constexpr int NP = DIM == 2 ? 3 : 2;
         const size_t lds = sizeof(double)*(64*NP*DIM+2*64*NP+64+2*64*ND)+sizeof(int)*(64*DPE+64)
@@ -1492,7 +1493,7 @@ int pointwise_impl(pnl_context *ctx, double *A, int64_t ldA, int zero_exterior, 
     HIPCHK(ctx, hipEventRecord(ctx->ev[7], ctx->stream));
     // the other tiles: classification, in-tile evaluation of the rules with at most 16 points (LDS sub-blocks), work list for the rest
     const bool in_tile = P1 && ctx->tile == 64 && !pnl_tune("PNL_PW_NOMIXED");
-    if constexpr (P1) if (!mixed.empty() && in_tile) {
+    if constexpr (P1el) if (!mixed.empty() && in_tile) {
         const int acc_stride = ctx->nU+1;
         const size_t lds = sizeof(double)*(PNL_PW_LANE_MAXPTS*ST+64*PNL_PW_LANE_MAXPTS*2+2*64*ND)+sizeof(unsigned short)*64*64
                            +sizeof(int)*(3*PNL_PW_NBUCK+2*64*DPE)+2*sizeof(double)*(size_t)(ctx->nU+1)*acc_stride;
@@ -1529,7 +1530,7 @@ int pointwise_impl(pnl_context *ctx, double *A, int64_t ldA, int zero_exterior, 
         auto kfun = k_pw_distant<DIM, DPE>;
         HIPCHK(ctx, hipFuncSetAttribute((const void*)kfun, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         const bool lane_kernel = P1 && !pnl_tune("PNL_PW_NOLANE");      // (with the in-tile evaluation only the rules of more than 16 points arrive here)
-        if constexpr (P1) if (lane_kernel)
+        if constexpr (P1el) if (lane_kernel)
             hipLaunchKernelGGL((k_pw_lane<DIM>), dim3(256*2), dim3(PNL_NTHREADS), 0, ctx->stream, P, W, (const int4*)ctx->b_wlsorted.p,
                                (const unsigned*)offs, A, (long long)ldA, (double*)ctx->b_D.p);
         hipLaunchKernelGGL(kfun, dim3(256*4), dim3(PNL_NTHREADS), lds, ctx->stream, P, W, (const int4*)ctx->b_wlsorted.p,
@@ -2789,7 +2790,7 @@ int pnl_set_order_function(pnl_context *ctx, const pnl_order_function *f, const 
                            double c0, double bc0, double sing_fac, double bsing_fac) {
     if (!ctx || !f || !cell_smax) return fail(ctx, PNL_ERR_INVALID, "bad order-function arguments");
     if (!ctx->have_mesh) return fail(ctx, PNL_ERR_STATE, "upload the mesh first");
-    if (f->type < 1 || f->type > 4) return fail(ctx, PNL_ERR_UNSUPPORTED, "order function type %d is not implemented", f->type);
+    if (f->type < 1 || f->type > 5) return fail(ctx, PNL_ERR_UNSUPPORTED, "order function type %d is not implemented", f->type);
     if (ctx->have_dofs && !(ctx->dpe == ctx->dim+1 || (ctx->dim == 2 && ctx->dpe == 6) || (ctx->dim == 1 && ctx->dpe == 3)))
         return fail(ctx, PNL_ERR_UNSUPPORTED, "pointwise variable orders: P1 and P2 elements");
     std::memset(&ctx->pw, 0, sizeof(ctx->pw));
@@ -2803,7 +2804,16 @@ int pnl_set_order_function(pnl_context *ctx, const pnl_order_function *f, const 
     ctx->pw_facet_smax.clear();
     if (facet_smax && ctx->have_boundary) ctx->pw_facet_smax.assign(facet_smax, facet_smax+ctx->nb);
     for (int w = 0; w < 2; w++) for (int s = 0; s < 3; s++) ctx->have_pw_rules[w][s] = false;
+    ctx->pw_vertex_s.clear();
     ctx->have_pw = true;
+    return PNL_OK;
+}
+
+int pnl_set_order_vertex_values(pnl_context *ctx, int nv, const double *values) {
+    if (!ctx || !values) return PNL_ERR_INVALID;
+    if (!ctx->have_pw || ctx->pw.type != 5) return fail(ctx, PNL_ERR_STATE, "set an order function of type 5 first");
+    if (nv != ctx->nv) return fail(ctx, PNL_ERR_INVALID, "pnl_set_order_vertex_values: %d vertices expected", ctx->nv);
+    ctx->pw_vertex_s.assign(values, values+nv);
     return PNL_OK;
 }
 
@@ -2849,6 +2859,15 @@ int pnl_assemble_dense_pointwise(pnl_context *ctx, double *A, int64_t ldA, int z
     int rc;
     if (!ctx->have_pw || !ctx->have_rules) return fail(ctx, PNL_ERR_STATE, "order function and distant rules must be set before assembling");
     if ((rc = finalize(ctx))) return rc;
+    if (ctx->pw.type == 5) {
+        if ((int)ctx->pw_vertex_s.size() != ctx->nv) return fail(ctx, PNL_ERR_STATE, "order function of type 5 without vertex values");
+        const int nV = ctx->dim+1;
+        std::vector<double> sv((size_t)nV*ctx->ncp, 0.);
+        for (int c = 0; c < ctx->nc; c++)
+            for (int k = 0; k < nV; k++) sv[(size_t)k*ctx->ncp+c] = ctx->pw_vertex_s[ctx->cells[(size_t)c*nV+k]];
+        if ((rc = upload(ctx, ctx->b_pw_cellsv, sv.data(), sv.size()))) return rc;
+        ctx->pw.cell_sv = (const double*)ctx->b_pw_cellsv.p; ctx->pw.sv_stride = ctx->ncp;
+    }
     if (!(ctx->dpe == ctx->dim+1 || (ctx->dim == 2 && ctx->dpe == 6) || (ctx->dim == 1 && ctx->dpe == 3)))
         return fail(ctx, PNL_ERR_UNSUPPORTED, "pointwise variable orders: P1 and P2 elements");
     if (!A || ldA < ctx->N) return fail(ctx, PNL_ERR_INVALID, "bad output matrix (ldA=%lld, num_dofs=%d)", (long long)ldA, ctx->N);

@@ -32,6 +32,19 @@ __device__ __forceinline__ double pw_order(const PwDev &W, const double *x) {
     return p[0]+(p[1]-p[0])*(3.0*(u*u)-2.0*(u*u*u));
 }
 
+// order at a quadrature point that is known by its cell: lam = barycentric coordinates in the cell, sv = the values of a P1 order
+// function (type 5, feFractionalOrder) at the cell's vertices in the same vertex order; every other type evaluates s(x)
+template <int DIM>
+__device__ __forceinline__ double pw_order_at(const PwDev &W, const double *x, const double *lam, const double *sv) {
+    if (W.type == 5) {
+        double s = 0.;
+#pragma unroll
+        for (int k = 0; k < DIM+1; k++) s = __builtin_fma(lam[k], sv[k], s);
+        return s;
+    }
+    return pw_order<DIM>(W, x);
+}
+
 // variableFractionalLaplacianScaling (kernelNormalization.pyx:416-440), times 1/s for the boundary twin (KC:1990-1994)
 template <int DIM>
 __device__ __forceinline__ double pw_scaling(const PwDev &W, double s, bool boundary) {
@@ -195,9 +208,14 @@ k_pw_distant(const DevProblem P, const PwDev W, const int4 *__restrict__ sorted,
         const bool valid = g < cnt;
         const int4 ent = valid ? sorted[first+g] : e0;
         const int c1 = ent.x, c2 = ent.y;
-        double av[NC], bv[NC];
+        double av[NC], bv[NC], sva[NV], svb[NV];
 #pragma unroll
         for (int k = 0; k < NC; k++) { av[k] = P.cellv[(size_t)k*P.ncp+c1]; bv[k] = P.cellv[(size_t)k*P.ncp+c2]; }
+#pragma unroll
+        for (int k = 0; k < NV; k++) {
+            sva[k] = W.type == 5 ? W.cell_sv[(size_t)k*W.sv_stride+c1] : 0.;
+            svb[k] = W.type == 5 ? W.cell_sv[(size_t)k*W.sv_stride+c2] : 0.;
+        }
         double *my_y = s_y+(size_t)g*tab_max_pts*2;
         for (int j = sub; j < n && in_lds; j += LPP) {
             double y[DIM];
@@ -208,7 +226,7 @@ k_pw_distant(const DevProblem P, const PwDev W, const int4 *__restrict__ sorted,
                 for (int m = 0; m < NV; m++) sy = __builtin_fma(s_rule[j*ST+m], bv[m*DIM+d], sy);
                 y[d] = sy;
             }
-            const double s = pw_order<DIM>(W, y);
+            const double s = pw_order_at<DIM>(W, y, s_rule+j*ST, svb);
             my_y[2*j] = -0.5*DIM-s;
             my_y[2*j+1] = s_rule[j*ST+3]*pw_scaling<DIM>(W, s, false);
         }
@@ -233,7 +251,7 @@ k_pw_distant(const DevProblem P, const PwDev W, const int4 *__restrict__ sorted,
                 for (int m = 0; m < NV; m++) sx = __builtin_fma(ti[m], av[m*DIM+d], sx);
                 x[d] = sx;
             }
-            const double sx_ = pw_order<DIM>(W, x);
+            const double sx_ = pw_order_at<DIM>(W, x, ti, sva);
             const double ex = -0.5*DIM-sx_, cx = ti[3]*pw_scaling<DIM>(W, sx_, false);
             double r1 = 0., u1[DPE], u2[DPE];
 #pragma unroll
@@ -255,7 +273,7 @@ k_pw_distant(const DevProblem P, const PwDev W, const int4 *__restrict__ sorted,
                 }
                 double ey, cy;
                 if (in_lds) { ey = my_y[2*j]; cy = my_y[2*j+1]; }
-                else { const double s = pw_order<DIM>(W, y); ey = -0.5*DIM-s; cy = tj[3]*pw_scaling<DIM>(W, s, false); }
+                else { const double s = pw_order_at<DIM>(W, y, tj, svb); ey = -0.5*DIM-s; cy = tj[3]*pw_scaling<DIM>(W, s, false); }
                 const double L = pnl_log(d2);
                 const double K1 = (cx*tj[3])*pnl_exp(ex*L), K2 = (ti[3]*cy)*pnl_exp(ey*L);
                 r1 += K1;
@@ -1038,6 +1056,19 @@ k_pw_singular(const DevProblem P, const PwDev W, const int4 *__restrict__ pairs,
             }
             s1[k][d] = a; s2[k][d] = b;
         }
+    // type 5: the order function at the (permuted) vertices of both cells
+    double sv1[NV], sv2[NV];
+#pragma unroll
+    for (int k = 0; k < NV; k++) {
+        double a = 0., b = 0.;
+#pragma unroll
+        for (int m = 0; m < NV; m++) {
+            const double va = W.type == 5 ? W.cell_sv[(size_t)m*W.sv_stride+c1] : 0., vb = W.type == 5 ? W.cell_sv[(size_t)m*W.sv_stride+c2] : 0.;
+            a = (perm1[k] == m) ? va : a;
+            b = (perm2[k] == m) ? vb : b;
+        }
+        sv1[k] = a; sv2[k] = b;
+    }
     const int M = W.M[SLOT];
     const double *__restrict__ nodes = W.nodes[SLOT]+(size_t)key*2*NV*M;
     const double *__restrict__ w = W.w[SLOT]+(size_t)key*M;
@@ -1051,20 +1082,22 @@ k_pw_singular(const DevProblem P, const PwDev W, const int4 *__restrict__ pairs,
 #pragma unroll
         for (int e = 0; e < NE; e++) acc[e] = 0.;
         for (int m = lane; m < M; m += 64) {
-            double x[DIM], y[DIM], d2 = 0.;
+            double x[DIM], y[DIM], d2 = 0., lx[NV], ly[NV];
+#pragma unroll
+            for (int k = 0; k < NV; k++) { lx[k] = nodes[(size_t)k*M+m]; ly[k] = nodes[(size_t)(NV+k)*M+m]; }
 #pragma unroll
             for (int d = 0; d < DIM; d++) {
                 double xx = 0., yy = 0.;
 #pragma unroll
                 for (int k = 0; k < NV; k++) {
-                    xx = __builtin_fma(s1[k][d], nodes[(size_t)k*M+m], xx);
-                    yy = __builtin_fma(s2[k][d], nodes[(size_t)(NV+k)*M+m], yy);
+                    xx = __builtin_fma(s1[k][d], lx[k], xx);
+                    yy = __builtin_fma(s2[k][d], ly[k], yy);
                 }
                 x[d] = xx; y[d] = yy;
                 d2 = __builtin_fma(xx-yy, xx-yy, d2);
             }
             const double L = pnl_log(d2);
-            const double sx = pw_order<DIM>(W, x), sy = pw_order<DIM>(W, y);
+            const double sx = pw_order_at<DIM>(W, x, lx, sv1), sy = pw_order_at<DIM>(W, y, ly, sv2);
             const double t1 = w[m]*pw_scaling<DIM>(W, sx, false)*pnl_exp((-0.5*DIM-sx)*L);
             const double t2 = w[m]*pw_scaling<DIM>(W, sy, false)*pnl_exp((-0.5*DIM-sy)*L);
             double ps[ROWS];
@@ -1129,6 +1162,9 @@ k_pw_boundary_distant(const DevProblem P, const PwDev W, double *__restrict__ Dg
 #pragma unroll
     for (int k = 0; k < NV; k++) vid[k] = P.cvid[(size_t)k*P.ncp+cc];
     const double h1 = P.ch[cc], vol1 = P.cvol[cc], sm1 = W.cell_smax[cc];
+    double sv[NV];
+#pragma unroll
+    for (int k = 0; k < NV; k++) sv[k] = W.type == 5 ? W.cell_sv[(size_t)k*W.sv_stride+cc] : 0.;
     double D[ND];
 #pragma unroll
     for (int e = 0; e < ND; e++) D[e] = 0.;
@@ -1177,7 +1213,7 @@ k_pw_boundary_distant(const DevProblem P, const PwDev W, double *__restrict__ Dg
                 for (int m = 0; m < NV; m++) s = __builtin_fma(bary[3*k+m], av[m*DIM+d], s);
                 x[d] = s;
             }
-            const double sx = pw_order<DIM>(W, x);
+            const double sx = pw_order_at<DIM>(W, x, bary+3*k, sv);
             // Gamma_b = (C/s) d2^(0.5 (1-d) - s); the 1/|y-x| of the normal factor is folded into the exponent (2D)
             const double ex = 0.5*(1-DIM)-sx-(DIM == 2 ? 0.5 : 0.), cx = pw_scaling<DIM>(W, sx, true);
             double r = 0.;
@@ -1281,6 +1317,14 @@ k_pw_boundary_singular(const DevProblem P, const PwDev W, const int4 *__restrict
             for (int m = 0; m < NF; m++) b = (perm2[k] == m) ? fv[m][d] : b;
             s2[k][d] = b;
         }
+    double sv1[NV];
+#pragma unroll
+    for (int k = 0; k < NV; k++) {
+        double a = 0.;
+#pragma unroll
+        for (int m = 0; m < NV; m++) a = (perm1[k] == m) ? (W.type == 5 ? W.cell_sv[(size_t)m*W.sv_stride+c1] : 0.) : a;
+        sv1[k] = a;
+    }
     double vol2 = 1.;
     if (DIM == 2) {
         nrm[0] = fv[1][1]-fv[0][1];
@@ -1297,12 +1341,14 @@ k_pw_boundary_singular(const DevProblem P, const PwDev W, const int4 *__restrict
 #pragma unroll
     for (int e = 0; e < ND; e++) acc[e] = 0.;
     for (int m = lane; m < M; m += 64) {
-        double x[DIM], d2 = 0., nw = 0.;
+        double x[DIM], d2 = 0., nw = 0., lx[NV];
+#pragma unroll
+        for (int k = 0; k < NV; k++) lx[k] = nodes[(size_t)k*M+m];
 #pragma unroll
         for (int d = 0; d < DIM; d++) {
             double xx = 0., y = 0.;
 #pragma unroll
-            for (int k = 0; k < NV; k++) xx = __builtin_fma(s1[k][d], nodes[(size_t)k*M+m], xx);
+            for (int k = 0; k < NV; k++) xx = __builtin_fma(s1[k][d], lx[k], xx);
 #pragma unroll
             for (int k = 0; k < NF; k++) y = __builtin_fma(s2[k][d], nodes[(size_t)(NV+k)*M+m], y);
             x[d] = xx;
@@ -1311,7 +1357,7 @@ k_pw_boundary_singular(const DevProblem P, const PwDev W, const int4 *__restrict
             if (DIM == 2) nw = __builtin_fma(nrm[d], wv, nw);
         }
         if (DIM != 2) nw = 1.;
-        const double sx = pw_order<DIM>(W, x);
+        const double sx = pw_order_at<DIM>(W, x, lx, sv1);
         const double ex = 0.5*(1-DIM)-sx-(DIM == 2 ? 0.5 : 0.);
         const double t = w[m]*nw*pw_scaling<DIM>(W, sx, true)*pnl_exp(ex*pnl_log(d2));
         double ps[DPE];

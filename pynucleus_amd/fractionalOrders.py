@@ -51,6 +51,9 @@ class variableConstFractionalOrder(variableFractionalOrder):
     def labels(self, points):
         return np.zeros(np.atleast_2d(points).shape[0], dtype=np.int32)
 
+    def spec(self):
+        return ('varconst', self.value)
+
 
 class leftRightFractionalOrder(variableFractionalOrder):
     """fractionalOrders.pyx:285-336: x[0] < interface is 'left'"""
@@ -66,6 +69,9 @@ class leftRightFractionalOrder(variableFractionalOrder):
 
     def labels(self, points):
         return (np.atleast_2d(points)[:, 0] >= self.interface).astype(np.int32)
+
+    def spec(self):
+        return ('leftRight', self.sVals[0, 0], self.sVals[1, 1], self.sVals[0, 1], self.sVals[1, 0], self.interface)
 
 
 class layersFractionalOrder(variableFractionalOrder):
@@ -86,6 +92,74 @@ class layersFractionalOrder(variableFractionalOrder):
         lab = np.clip(np.searchsorted(b, c, side='left')-1, 0, n-1)
         lab = np.where(c <= b[0], 0, np.where(c >= b[n], n-1, lab))
         return lab.astype(np.int32)
+
+    def spec(self):
+        return ('layers', self.layerBoundaries.copy(), self.sVals.copy())
+
+
+class innerOuterFractionalOrder(variableFractionalOrder):
+    """fractionalOrders.pyx:664-731: inside / outside the ball of radius r around center (|x - center|^2 < r^2 is 'inner')"""
+
+    def __init__(self, dim, sii, soo, r, center, sio=np.nan, soi=np.nan):
+        if not np.isfinite(sio):
+            sio = 0.5*(sii+soo)
+        if not np.isfinite(soi):
+            soi = 0.5*(sii+soo)
+        super().__init__([[sii, sio], [soi, soo]])
+        self.symmetric = bool(sio == soi)
+        self.dim, self.r = int(dim), float(r)
+        self.center = np.ascontiguousarray(center, dtype=np.float64)[:self.dim]
+
+    def labels(self, points):
+        p = np.atleast_2d(points)[:, :self.dim]
+        return (((p-self.center)**2).sum(axis=1) >= self.r*self.r).astype(np.int32)
+
+    def spec(self):
+        return ('innerOuter', self.dim, self.sVals[0, 0], self.sVals[1, 1], self.r, self.center.copy(), self.sVals[0, 1], self.sVals[1, 0])
+
+
+class islandsFractionalOrder(variableFractionalOrder):
+    """fractionalOrders.pyx:754-822 (2D): the 'islands' are the points whose coordinates all satisfy r <= |x_i| <= r2"""
+
+    def __init__(self, sii, soo, r, r2, sio=np.nan, soi=np.nan):
+        if not np.isfinite(sio):
+            sio = 0.5*(sii+soo)
+        if not np.isfinite(soi):
+            soi = 0.5*(sii+soo)
+        super().__init__([[sii, sio], [soi, soo]])
+        self.symmetric = bool(sio == soi)
+        self.r, self.r2 = float(r), float(r2)
+
+    def labels(self, points):
+        p = np.abs(np.atleast_2d(points)[:, :2])
+        return (~((p >= self.r) & (p <= self.r2)).all(axis=1)).astype(np.int32)
+
+    def spec(self):
+        return ('islands', self.sVals[0, 0], self.sVals[1, 1], self.r, self.r2, self.sVals[0, 1], self.sVals[1, 0])
+
+
+class sumFractionalOrder(variableFractionalOrder):
+    """fractionalOrders.pyx:733-752: s(x, y) = s1(x, y) * s2(x, y) (the reference's eval multiplies the two values; fac1 / fac2 are
+    stored and not used there).  Piecewise-constant factors: the labels are the pairs of labels."""
+
+    def __init__(self, s1, fac1, s2, fac2):
+        assert isinstance(s1, variableFractionalOrder) and isinstance(s2, variableFractionalOrder)
+        self.s1, self.s2, self.fac1, self.fac2 = s1, s2, float(fac1), float(fac2)
+        L1, L2 = s1.numLabels, s2.numLabels
+        sv = np.zeros((L1*L2, L1*L2))
+        for a in range(L1):
+            for b in range(L2):
+                for c in range(L1):
+                    for d in range(L2):
+                        sv[a*L2+b, c*L2+d] = s1.sVals[a, c]*s2.sVals[b, d]
+        super().__init__(sv)
+        self.symmetric = bool(s1.symmetric and s2.symmetric)
+
+    def labels(self, points):
+        return (self.s1.labels(points)*self.s2.numLabels+self.s2.labels(points)).astype(np.int32)
+
+    def spec(self):
+        return ('product', self.s1.spec(), self.s2.spec())
 
 
 class piecewiseConstantFractionalOrder(variableFractionalOrder):
@@ -195,6 +269,51 @@ class smoothStepRadial(extendedFunction):
         return 'smoothStepRadial(sl={},sr={},r={},radius={})'.format(self.sl, self.sr, self.r, self.radius)
 
 
+class lookupExtended(extendedFunction):
+    """fractionalOrders.pyx:541-625: a finite-element function looked up in the cell that holds x.  Here: continuous P1
+    functions -- the values at the mesh vertices (u[dof] of the vertex's DoF, 0 for a boundary DoF that the DoFMap dropped)."""
+    device_type = 5
+
+    def __init__(self, mesh, dm, u):
+        assert dm.dofs_per_element == mesh.dim+1, 'feFractionalOrder: P1 functions'
+        self.mesh, self.dm, self.u = mesh, dm, np.ascontiguousarray(u, dtype=np.float64)
+        assert self.u.shape[0] == dm.num_dofs
+        vals = np.zeros(mesh.num_vertices)
+        dofs, cells = np.asarray(dm.dofs), np.asarray(mesh.cells)
+        ok = dofs >= 0
+        vals[cells[ok]] = self.u[dofs[ok]]
+        self.vertex_values = vals
+
+    def device_params(self):
+        return [0.]*6
+
+    def cell_values(self, cells):
+        """values at the vertices of the given simplices (cells[n, k] vertex numbers)"""
+        return self.vertex_values[np.asarray(cells)]
+
+    def __call__(self, x):
+        """host evaluation by point location (barycentric coordinates over all cells; small meshes / tests)"""
+        x = np.atleast_2d(np.asarray(x, dtype=np.float64))
+        V = self.mesh.vertices[self.mesh.cells]                     # [nc, nV, dim]
+        out = np.zeros(x.shape[0])
+        for i, pt in enumerate(x):
+            if self.mesh.dim == 1:
+                l1 = (pt[0]-V[:, 0, 0])/(V[:, 1, 0]-V[:, 0, 0])
+                lam = np.stack([1.-l1, l1], axis=1)
+            else:
+                d0, d1, dp = V[:, 1]-V[:, 0], V[:, 2]-V[:, 0], pt[None, :2]-V[:, 0]
+                det = d0[:, 0]*d1[:, 1]-d1[:, 0]*d0[:, 1]
+                l1 = (dp[:, 0]*d1[:, 1]-d1[:, 0]*dp[:, 1])/det
+                l2 = (d0[:, 0]*dp[:, 1]-dp[:, 0]*d0[:, 1])/det
+                lam = np.stack([1.-l1-l2, l1, l2], axis=1)
+            c = int(np.argmax(lam.min(axis=1)))
+            out[i] = (lam[c]*self.vertex_values[self.mesh.cells[c]]).sum()
+        return out if out.shape[0] > 1 else float(out[0])
+
+    def __repr__(self):
+        return 'lookupExtended({} vertex values)'.format(self.vertex_values.shape[0])
+
+
 class singleVariableUnsymmetricFractionalOrder(fractionalOrderBase):
     """s(x, y) = sFun(x) (:153-183)"""
     symmetric = False
@@ -228,6 +347,23 @@ class smoothedLeftRightFractionalOrder(singleVariableUnsymmetricFractionalOrder)
 class linearLeftRightFractionalOrder(singleVariableUnsymmetricFractionalOrder):
     def __init__(self, sl, sr, r=0.1, interface=0.):
         super().__init__(linearStep(sl, sr, r, interface), min(sl, sr), max(sl, sr), 2)
+
+
+class feFractionalOrder(singleVariableUnsymmetricFractionalOrder):
+    """fractionalOrders.pyx:660-668: the order is a finite-element function, s(x) = sum_i vec_i phi_i(x).  ``vec``: the coefficient
+    vector (an object with ``.dm`` like the reference's fe_vector, or an array together with ``dm``); P1 spaces on the mesh of the
+    assembly."""
+
+    def __init__(self, vec, smin, smax, dm=None):
+        dm = dm if dm is not None else vec.dm
+        u = np.asarray(getattr(vec, 'toarray', lambda: vec)())
+        self.vec = vec
+        super().__init__(lookupExtended(dm.mesh, dm, u), smin, smax, numParameters=dm.num_dofs)
+
+    def evalPoints(self, x):
+        x = np.asarray(x, dtype=np.float64)
+        flat = x.reshape(-1, x.shape[-1])
+        return np.atleast_1d(self.sFun(flat)).reshape(x.shape[:-1])
 
 
 class smoothedInnerOuterFractionalOrder(singleVariableUnsymmetricFractionalOrder):

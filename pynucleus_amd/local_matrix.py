@@ -211,7 +211,14 @@ class nonlocalTables:
         self.order_type = int(sF.sFun.device_type)
         self.order_params = np.array(sF.sFun.device_params(), dtype=np.float64)
         verts = mesh.vertices[mesh.cells]                                  # [nc, nV, dim]
-        self.cell_smax = np.maximum(sF.evalPoints(verts.mean(axis=1)), sF.evalPoints(verts).max(axis=1))
+        fe = hasattr(sF.sFun, 'vertex_values')                             # feFractionalOrder: a P1 function, values at the vertices
+        if fe:
+            assert sF.sFun.vertex_values.shape[0] == mesh.num_vertices, 'feFractionalOrder: the order must live on the mesh of the assembly'
+            self.order_vertex_values = np.ascontiguousarray(sF.sFun.vertex_values)
+            cv = sF.sFun.cell_values(mesh.cells)
+            self.cell_smax = np.maximum(cv.mean(axis=1), cv.max(axis=1))    # centre and vertices (evalParamsOnSimplices)
+        else:
+            self.cell_smax = np.maximum(sF.evalPoints(verts.mean(axis=1)), sF.evalPoints(verts).max(axis=1))
         self.has_boundary_tables = True
         self.boundaryKernel = bk = kernel.getBoundaryKernel()
         t_b = params.get('target_order', None)
@@ -233,7 +240,11 @@ class nonlocalTables:
         self.bquad_order_diagonal = int(qd_b)
         self._boundary_mesh()
         fv = mesh.vertices[self.bcells]                                     # [nb, dim, dim]
-        self.facet_smax = np.maximum(sF.evalPoints(fv.mean(axis=1)), sF.evalPoints(fv).max(axis=1))
+        if fe:
+            fvv = sF.sFun.cell_values(self.bcells)
+            self.facet_smax = np.maximum(fvv.mean(axis=1), fvv.max(axis=1))
+        else:
+            self.facet_smax = np.maximum(sF.evalPoints(fv.mean(axis=1)), sF.evalPoints(fv).max(axis=1))
         self._pw_rules = None
         # the scaling C(s) over [s.min, s.max] as a Chebyshev series: a polynomial per quadrature point on the device instead
         # of two Gamma functions (the oracle keeps the formula)

@@ -592,3 +592,42 @@ def test_label_blocks_dense(case):
     # repeated assembly on the blocked context gives the same operator
     A2 = b1.getDense()
     assert np.abs(A2.toarray()-A1.toarray()).max() <= 1e-14*scale
+
+
+@pytest.mark.parametrize('case', ['disc_P1', 'disc_P2', 'interval_P1', 'disc_P1_noext'])
+def test_fe_fractional_order_dense(case):
+    """a16: feFractionalOrder (fractionalOrders.pyx:660-668, lookupExtended :541-587) -- the order is a P1 function on the mesh,
+    s(x) per quadrature point.  GPU (s from the cell's vertex values and the barycentric coordinates of the point) == oracle (point
+    location + evaluation, like the reference's cellFinder) entry-wise, same counters; a P1 function that is linear on the whole
+    domain reproduces the linearStep order with the same range exactly."""
+    from pynucleus_amd import disc, interval, PHYSICAL, NO_BOUNDARY, P1_DoFMap, P2_DoFMap, getFractionalKernel, feFractionalOrder, nonlocalTables
+    from pynucleus_amd.builder import nonlocalBuilder
+    from pynucleus_amd.fractionalOrders import linearLeftRightFractionalOrder
+    from oracle.oracle import OracleProblem
+    zeroExterior = case != 'disc_P1_noext'
+    mesh = interval(5) if case.startswith('interval') else disc(3 if case == 'disc_P1' else 2)
+    dm = (P2_DoFMap if case == 'disc_P2' else P1_DoFMap)(mesh, PHYSICAL)
+    dms = P1_DoFMap(mesh, NO_BOUNDARY)                        # the space of the order: P1 on all vertices
+    dofs, cells = np.asarray(dms.dofs), np.asarray(mesh.cells)
+
+    def coefficients(fun):
+        u = np.zeros(dms.num_dofs)
+        u[dofs.ravel()] = fun(mesh.vertices[cells.ravel()])
+        return u
+    # a bumpy order between 0.3 and 0.7
+    u = coefficients(lambda p: 0.5+0.2*np.sin(3.*p[:, 0])*np.cos(2.*p[:, -1]))
+    b = nonlocalBuilder(dm, getFractionalKernel(mesh.dim, feFractionalOrder(u, 0.3, 0.7, dm=dms)), {}, zeroExterior=zeroExterior)
+    A = b.getDense()
+    Aref, cnt, _ = OracleProblem(b.tables).get_dense()
+    got = A.info['counters']
+    for key in ('numCellPairs', 'numAssembledCellPairs', 'numIntegrations', 'numBoundaryPairs', 'numBoundaryIntegrations', 'orders', 'singular'):
+        assert got[key] == cnt[key], (key, got[key], cnt[key])
+    scale = np.abs(Aref).max()
+    assert np.abs(A.toarray()-Aref).max() < TOL*scale, np.abs(A.toarray()-Aref).max()/scale
+    assert np.abs(Aref-Aref.T).max() > 1e-6*scale
+    if case == 'disc_P1':
+        # s(x) = 0.5 + 0.2 x_0 as a P1 function == linearStep(0.1, 0.9, r = 2) (sl + (x - interface + r) (sr - sl) / (2 r))
+        ul = coefficients(lambda p: 0.5+0.2*p[:, 0])
+        A1 = nonlocalBuilder(dm, getFractionalKernel(2, feFractionalOrder(ul, 0.1, 0.9, dm=dms)), {}).getDense().toarray()
+        A2 = OracleProblem(nonlocalTables(dm, getFractionalKernel(2, linearLeftRightFractionalOrder(0.1, 0.9, r=2.)), {})).get_dense()[0]
+        assert np.abs(A1-A2).max() < TOL*np.abs(A2).max()

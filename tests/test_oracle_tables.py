@@ -9,7 +9,8 @@ import numpy as np
 import pytest
 from pynucleus_amd import (disc, interval, uniformSquare, P1_DoFMap, P2_DoFMap, PHYSICAL, NO_BOUNDARY, getFractionalKernel, getKernel,
                            INDICATOR, PERIDYNAMIC)
-from pynucleus_amd.fractionalOrders import variableConstFractionalOrder, leftRightFractionalOrder, layersFractionalOrder
+from pynucleus_amd.fractionalOrders import (variableConstFractionalOrder, leftRightFractionalOrder, layersFractionalOrder,
+                                            innerOuterFractionalOrder, islandsFractionalOrder, sumFractionalOrder)
 from pynucleus_amd.local_matrix import nonlocalTables
 from oracle.oracle import own_tables, OracleProblem
 from oracle import tables as OT
@@ -105,6 +106,9 @@ CASES = {
     'disc_P1_leftRight_nonsym': (lambda: P1_DoFMap(disc(3), PHYSICAL), lambda: getFractionalKernel(2, leftRightFractionalOrder(0.25, 0.75, 0.3, 0.6)), {'target_order': 0.5}, True),
     'disc_P1_layers': (lambda: P1_DoFMap(disc(3), PHYSICAL), lambda: getFractionalKernel(2, LAYERS), {'target_order': 0.5}, True),
     'C5_disc_P2_layers': (lambda: P2_DoFMap(disc(3), PHYSICAL), lambda: getFractionalKernel(2, LAYERS), {'target_order': 0.5}, True),
+    'disc_P1_innerOuter': (lambda: P1_DoFMap(disc(3), PHYSICAL), lambda: getFractionalKernel(2, innerOuterFractionalOrder(2, 0.3, 0.7, 0.45, np.array([0.1, 0.]))), {}, True),
+    'disc_P2_islands_nonsym': (lambda: P2_DoFMap(disc(3), PHYSICAL), lambda: getFractionalKernel(2, islandsFractionalOrder(0.25, 0.75, 0.2, 0.6, 0.4, 0.6)), {}, True),
+    'disc_P1_product': (lambda: P1_DoFMap(disc(3), PHYSICAL), lambda: getFractionalKernel(2, sumFractionalOrder(leftRightFractionalOrder(0.5, 0.9), 1., innerOuterFractionalOrder(2, 0.6, 0.8, 0.5, np.array([0., 0.])), 1.)), {}, True),
     'disc_P2_layers_noexterior': (lambda: P2_DoFMap(disc(2), NO_BOUNDARY), lambda: getFractionalKernel(2, LAYERS), {}, False),
 }
 
