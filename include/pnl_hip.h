@@ -268,6 +268,11 @@ int pnl_h2_upward(pnl_context *ctx, const double *x_dev, double *cup_dev);
 int pnl_h2_interact(pnl_context *ctx, const double *cup_dev, double *cdown_dev);
 int pnl_h2_downward(pnl_context *ctx, double *cdown_dev, double *y_dev);
 int pnl_h2_sizes(pnl_context *ctx, int32_t *out2);
+/* what an H2 operator file stores besides the tree (H2Matrix.HDF5write / HDF5read, clusterMethodCy.pyx:2449-2550): which = 0 the
+ * kernel interpolants K[nfar][M][M] of the plan's admissible pairs, which = 1 the leaf values, V_leaf[ndofs][M] of the plan's leaves
+ * one after the other.  _get copies them to the host, _set replaces what pnl_h2_setup computed (an operator read from a file) */
+int pnl_h2_get(pnl_context *ctx, int which, double *dst_host);
+int pnl_h2_set(pnl_context *ctx, int which, const double *src_host);
 
 /* y = A x for the uploaded pattern (CSR: diag_dev NULL; SSS: lower triangle + diagonal, y = (L + D + L^T) x):
  * CSR_LinearOperator.matvec / SSS_LinearOperator.matvec */

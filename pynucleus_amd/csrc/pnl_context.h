@@ -106,6 +106,7 @@ struct pnl_context {
     DevBuf b_pw_cellsv;
     DevBuf b_pw_csm, b_pw_fsm, b_pw_rule[2][3][4], b_pw_pairs, b_pw_bpairs;
     std::vector<std::vector<int>> h2_levels;   // nodes of every level >= 1
+    long long h2_vtot = 0;                    // doubles of the leaf values V (pnl_h2_get / _set)
     std::vector<size_t> h2_level_off;
     int sp_nnz = -1;                // near-field sparsity pattern (pnl_upload_sparsity)
     unsigned wl_cap = 0;

@@ -2642,6 +2642,7 @@ int pnl_h2_setup(pnl_context *ctx, const pnl_h2_plan *pl) {
     if ((rc = upload(ctx, B[5], pl->leaf_cell_off, (size_t)pl->nleaves+1))) return rc;
     if ((rc = upload(ctx, B[6], pl->leaf_cells, (size_t)pl->leaf_cell_off[pl->nleaves]))) return rc;
     if ((rc = upload(ctx, B[7], voff.data(), voff.size()))) return rc;
+    ctx->h2_vtot = vtot;
     if ((rc = upload(ctx, B[8], pl->far, (size_t)2*pl->nfar))) return rc;
     if ((rc = upload(ctx, B[9], pl->transfer, (size_t)pl->nnodes*M*M))) return rc;
     if ((rc = ensure(ctx, B[10], sizeof(double)*(size_t)std::max<long long>(vtot, 1)))) return rc;
@@ -2714,6 +2715,23 @@ int pnl_h2_matvec(pnl_context *ctx, const double *x, double *y) {
     HIPCHK(ctx, hipGetLastError());
     return PNL_OK;
 }
+
+// kernel interpolants K[nfar][M][M] (which = 0) and leaf values V (which = 1: the blocks V_leaf[ndofs][M] of the plan's leaves, one
+// after the other) between the device and the host: the H2 operator file (clusterMethodCy.pyx:2449-2550) stores them
+static int h2_copy(pnl_context *ctx, int which, double *host, bool to_host) {
+    if (!ctx || !host) return PNL_ERR_INVALID;
+    if (!ctx->have_h2) return fail(ctx, PNL_ERR_STATE, "pnl_h2_setup first");
+    if (which != 0 && which != 1) return fail(ctx, PNL_ERR_INVALID, "pnl_h2_get / _set: which = 0 (interpolants) or 1 (leaf values)");
+    const H2Dev &H = ctx->h2;
+    const size_t n = which == 0 ? (size_t)H.nfar*H.M*H.M : (size_t)ctx->h2_vtot;
+    double *dev = which == 0 ? H.K : H.V;
+    if (n) HIPCHK(ctx, hipMemcpyAsync(to_host ? (void*)host : (void*)dev, to_host ? (const void*)dev : (const void*)host, n*sizeof(double),
+                                      to_host ? hipMemcpyDeviceToHost : hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return PNL_OK;
+}
+int pnl_h2_get(pnl_context *ctx, int which, double *dst_host) { return h2_copy(ctx, which, dst_host, true); }
+int pnl_h2_set(pnl_context *ctx, int which, const double *src_host) { return h2_copy(ctx, which, const_cast<double*>(src_host), false); }
 
 int pnl_h2_sizes(pnl_context *ctx, int32_t *out2) {
     if (!ctx || !out2) return PNL_ERR_INVALID;

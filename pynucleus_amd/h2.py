@@ -154,10 +154,7 @@ class H2Matrix:
             if getattr(self.ctx, '_kernel_epoch', 0) != self._epoch:
                 raise RuntimeError('this H2Matrix belongs to a kernel the builder no longer holds (setKernel was called): '
                                    'its far field cannot be set up again; assemble a new operator')
-            keep = []
-            P = self.plan.as_struct(keep)
-            self.ctx.check(self.ctx.L.pnl_h2_setup(self.ctx.h, C.byref(P)))
-            self.ctx._h2_owner = self
+            self._ensure_setup()
         xd = _as_dev(x, self.device)
         yd = self.Anear.matvec(xd)
         torch.cuda.current_stream(self.device).synchronize()
@@ -177,6 +174,164 @@ class H2Matrix:
     @property
     def diagonal(self):
         return self.Anear.diagonal
+
+    # ---- operator files: the reference's layout (H2Matrix.HDF5write / HDF5read, clusterMethodCy.pyx:2449-2550; tree:
+    # tree_node.HDF5writeNew / HDF5readNew :1575-1760) on any h5py-like group (create_group, create_dataset, attrs, item access)
+    def _ensure_setup(self):
+        if getattr(self.ctx, '_h2_owner', None) is not self:
+            keep = []
+            P = self.plan.as_struct(keep)
+            self.ctx.check(self.ctx.L.pnl_h2_setup(self.ctx.h, C.byref(P)))
+            self.ctx._h2_owner = self
+            if getattr(self, '_stored', None) is not None:
+                for which, a in enumerate(self._stored):
+                    self.ctx.check(self.ctx.L.pnl_h2_set(self.ctx.h, which, a.ctypes.data))
+
+    def farFieldData(self):
+        """(kernel interpolants [nfar, M, M], leaf values as a list of [ndofs, M] blocks in the order of plan.leaf_node)"""
+        self._ensure_setup()
+        pl = self.plan
+        K = np.zeros((pl.far.shape[0], pl.M, pl.M))
+        V = np.zeros((int(pl.leaf_dof_off[-1]), pl.M))
+        self.ctx.check(self.ctx.L.pnl_h2_get(self.ctx.h, 0, K.ctypes.data))
+        self.ctx.check(self.ctx.L.pnl_h2_get(self.ctx.h, 1, V.ctypes.data))
+        return K, [V[pl.leaf_dof_off[l]:pl.leaf_dof_off[l+1]] for l in range(pl.leaf_node.shape[0])]
+
+    def HDF5write(self, node, version=2, Pnear=None, refinementParams=None):
+        if version != 2:
+            raise NotImplementedError('H2 operator files: version 2 (tree_node.HDF5writeNew)')
+        pl = self.plan
+        nodes, nn, dim = pl.nodes, len(pl.nodes), pl.box.shape[1]
+        node.attrs['type'] = 'h2'
+        self.Anear.HDF5write(node.create_group('Anear'))
+        node.attrs['version'] = version
+        tree = node.create_group('tree')
+
+        def graph(g, lists, ncols):
+            indptr = np.zeros(nn+1, dtype=np.int32)
+            indptr[1:] = np.cumsum([len(v) for v in lists])
+            g.create_dataset('indices', data=np.concatenate([np.asarray(v, dtype=np.int32) for v in lists]+[np.zeros(0, dtype=np.int32)]))
+            g.create_dataset('indptr', data=indptr)
+            g.attrs['num_rows'], g.attrs['num_columns'], g.attrs['type'] = nn, int(ncols), 'sparseGraph'
+        kids = [[] for _ in range(nn)]
+        for k in range(nn):
+            if pl.parent[k] >= 0:
+                kids[pl.parent[k]].append(k)
+        graph(tree.create_group('children'), kids, nn)
+        tree.create_dataset('boxes', data=np.ascontiguousarray(pl.box))
+        tree.create_dataset('interpolationOrders', data=np.full(nn, pl.m, dtype=np.int32))
+        tr = tree.create_group('transferOperators')
+        for k in range(nn):
+            if pl.parent[k] >= 0:
+                tr.create_dataset(str(k), data=np.ascontiguousarray(pl.transfer[k]))
+        tree.attrs['valueSize'] = 1
+        graph(tree.create_group('dofs'), [np.asarray(n.dofs) for n in nodes], self.num_rows)
+        cells = [np.asarray(n.cells) if n.is_leaf else np.zeros(0, dtype=np.int32) for n in nodes]
+        graph(tree.create_group('cells'), cells, int(max([c.max() for c in cells if c.shape[0]]+[-1]))+1)
+        K, V = self.farFieldData()
+        vals = tree.create_group('values')
+        for l, k in enumerate(pl.leaf_node):
+            vals.create_dataset(str(int(k)), data=np.ascontiguousarray(V[l][None, :, :]))      # [valueSize, ndofs, M]
+        tree.attrs['dim'] = dim
+        rp = tree.create_group('refinementParams')
+        defaults = dict(maxLevels=200, maxLevelsMixed=200, minSize=1, minMixedSize=1, refType=0, splitEveryDim=False, eta=3.,
+                        farFieldInteractionSize=pl.M, interpolation_order=pl.m, attemptRefinement=True, targetOrder=0., meshDiam=0.,
+                        maxSingularity=0.)
+        defaults.update(refinementParams or {})
+        for key, v in defaults.items():
+            rp.attrs[key] = v
+        g = node.create_group('Pfar')
+        g.create_dataset('kernelInterpolants', data=K.ravel())
+        ids = np.zeros((pl.far.shape[0], 5), dtype=np.int32)
+        ids[:, :2] = pl.far
+        ids[:, 2:4] = pl.M
+        ids[:, 4] = pl.level[pl.far[:, 0]]
+        g.create_dataset('nodeIds', data=ids)
+        if Pnear is not None:
+            g2 = node.create_group('Pnear')
+            for k, cp in enumerate(Pnear):
+                gk = g2.create_group(str(k))
+                gk.attrs['n1'], gk.attrs['n2'] = pl.nid[id(cp.n1)], pl.nid[id(cp.n2)]
+
+    @staticmethod
+    def HDF5read(node, ctx, returnPnear=False):
+        """the operator back on the device of ``ctx`` -- a builder's ``context()`` for the mesh / DoF map the operator was assembled
+        on (the far-field passes run in that context); near field, tree, transfer operators, kernel interpolants and leaf values
+        are the stored ones"""
+        from .linear_operators import CSR_LinearOperator
+        Anear = CSR_LinearOperator.HDF5read(node['Anear'], ctx)
+        tree = node['tree']
+        indptr, indices = np.array(tree['children']['indptr']), np.array(tree['children']['indices'])
+        nn = indptr.shape[0]-1
+        boxes = np.array(tree['boxes'], dtype=np.float64)
+        dip, dix = np.array(tree['dofs']['indptr']), np.array(tree['dofs']['indices'])
+        cip, cix = np.array(tree['cells']['indptr']), np.array(tree['cells']['indices'])
+        orders = np.array(tree['interpolationOrders'])
+        assert (orders == orders[0]).all(), 'one interpolation order for all nodes'
+
+        class stored_node:
+            pass
+        nodes = [stored_node() for _ in range(nn)]
+        for k, n in enumerate(nodes):
+            n.id, n.box = k, boxes[k]
+            n.dofs = np.ascontiguousarray(dix[dip[k]:dip[k+1]], dtype=np.int32)
+            n.cells = np.ascontiguousarray(cix[cip[k]:cip[k+1]], dtype=np.int32)
+            n.children = [nodes[c] for c in indices[indptr[k]:indptr[k+1]]]
+            n.is_leaf = len(n.children) == 0
+            n.parent = None
+        for n in nodes:
+            for c in n.children:
+                c.parent = n
+        root = [n for n in nodes if n.parent is None][0]
+        plan = h2Plan.__new__(h2Plan)
+        flat_nodes, parent, level = h2Plan.flatten(root)
+        plan.nodes, plan.nid = flat_nodes, {id(n): k for k, n in enumerate(flat_nodes)}
+        dim = boxes.shape[1]
+        plan.m, plan.M = int(orders[0]), int(orders[0])**dim
+        plan.parent, plan.level = np.array(parent, dtype=np.int32), np.array(level, dtype=np.int32)
+        plan.nlevels = int(plan.level.max())+1
+        plan.box = np.ascontiguousarray(np.stack([n.box for n in flat_nodes]))
+        leaves = [k for k, n in enumerate(flat_nodes) if n.is_leaf]
+        plan.partial_leaves = False
+        plan.leaf_node = np.array(leaves, dtype=np.int32)
+        plan.leaf_dof_off = np.zeros(len(leaves)+1, dtype=np.int32)
+        plan.leaf_cell_off = np.zeros(len(leaves)+1, dtype=np.int32)
+        plan.leaf_dof_off[1:] = np.cumsum([flat_nodes[k].dofs.shape[0] for k in leaves])
+        plan.leaf_cell_off[1:] = np.cumsum([flat_nodes[k].cells.shape[0] for k in leaves])
+        plan.leaf_dofs = np.concatenate([flat_nodes[k].dofs for k in leaves]).astype(np.int32)
+        plan.leaf_cells = np.concatenate([flat_nodes[k].cells for k in leaves]).astype(np.int32)
+        ids = np.array(node['Pfar']['nodeIds'], dtype=np.int64)
+        new_of_stored = np.array([plan.nid[id(nodes[k])] for k in range(nn)], dtype=np.int32)
+        plan.far = np.ascontiguousarray(new_of_stored[ids[:, :2]].reshape(-1, 2), dtype=np.int32)
+        plan.far_class = None
+        plan.transfer = np.zeros((nn, plan.M, plan.M))
+        for key in tree['transferOperators']:
+            plan.transfer[new_of_stored[int(key)]] = np.array(tree['transferOperators'][key])
+        # pnl_h2_setup wants a volume rule for the leaf values it is about to compute; they are replaced by the stored ones
+        plan.qbary = np.zeros((1, 3)); plan.qbary[0, :dim+1] = 1./(dim+1)
+        plan.qw = np.ones(1)
+        plan.qphi = np.full((1, int(ctx.dofs_per_element)), 1./(dim+1))
+        Pfar = {}
+        for j in range(ids.shape[0]):
+            class pair:
+                pass
+            cp = pair()
+            cp.n1, cp.n2 = nodes[ids[j, 0]], nodes[ids[j, 1]]
+            Pfar.setdefault(int(ids[j, 4]), []).append(cp)
+        op = H2Matrix(Anear, plan, ctx, root, Pfar)
+        K = np.ascontiguousarray(np.array(node['Pfar']['kernelInterpolants'], dtype=np.float64))
+        V = np.ascontiguousarray(np.concatenate([np.array(tree['values'][str(int(nodes.index(flat_nodes[k])))])[0] for k in leaves]))
+        op._stored = (K, V)
+        for which, a in enumerate(op._stored):
+            ctx.check(ctx.L.pnl_h2_set(ctx.h, which, a.ctypes.data))
+        if returnPnear:
+            Pnear = []
+            for key in node['Pnear']:
+                cp = type('pair', (), {})()
+                cp.n1, cp.n2 = nodes[int(node['Pnear'][key].attrs['n1'])], nodes[int(node['Pnear'][key].attrs['n2'])]
+                Pnear.append(cp)
+            return op, Pnear
+        return op
 
     def toarray(self):
         """dense image through N matvecs (tests only)"""

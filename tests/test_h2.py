@@ -184,3 +184,66 @@ def test_dist_op_dense_vs_h2_anchor(s, ref_err):
     rhs = np.asarray(dm.assembleRHS(1.0))
     u, its, res = cg(H, rhs, tol=1e-5, maxiter=200, preconditioner=None)
     assert its <= 20, its                                    # reference: 6 iterations (mass-norm tolerance, meshpy mesh)
+
+
+class _Group(dict):
+    """the part of h5py.Group the operators' HDF5write / HDF5read use (h5py is not installed here)"""
+
+    def __init__(self):
+        super().__init__()
+        self.attrs = {}
+
+    def create_dataset(self, name, data=None, **kwargs):
+        self[name] = np.array(data, copy=True)
+
+    def create_group(self, name):
+        self[name] = _Group()
+        return self[name]
+
+
+@pytest.mark.gpu
+def test_h2_operator_file_round_trip():
+    """SURVEY 8f row 4: the H2 operator in the reference's file layout (H2Matrix.HDF5write / HDF5read, clusterMethodCy.pyx:2449-2550;
+    tree_node.HDF5writeNew :1575-1680): groups Anear / tree (children, boxes, interpolationOrders, transferOperators/<id>, dofs,
+    cells, values/<leaf id>, refinementParams) / Pfar (kernelInterpolants, nodeIds); read back into a fresh builder's context the
+    operator gives the same products to the last bits, with the STORED interpolants and leaf values (a perturbed file shows)"""
+    import torch
+    from pynucleus_amd import disc, P1_DoFMap, PHYSICAL, getFractionalKernel
+    from pynucleus_amd.builder import nonlocalBuilder
+    from pynucleus_amd.h2 import H2Matrix
+    dm = P1_DoFMap(disc(4), PHYSICAL)
+    params = {'target_order': 0.5, 'eta': 3., 'minClusterSize': 16}
+    b = nonlocalBuilder(dm, getFractionalKernel(2, 0.75), params, zeroExterior=True)
+    h2, Pnear = b.getH2(returnNearField=True)
+    g = _Group()
+    h2.HDF5write(g, Pnear=Pnear)
+    assert g.attrs['type'] == 'h2' and g.attrs['version'] == 2
+    tree = g['tree']
+    nn = len(h2.plan.nodes)
+    assert tree['boxes'].shape == (nn, 2, 2) and tree['children']['indptr'].shape[0] == nn+1
+    assert tree['children'].attrs['type'] == 'sparseGraph' and tree.attrs['valueSize'] == 1 and tree.attrs['dim'] == 2
+    assert len(tree['transferOperators']) == nn-1 and len(tree['values']) == h2.plan.leaf_node.shape[0]
+    M = h2.plan.M
+    assert g['Pfar']['nodeIds'].shape == (h2.plan.far.shape[0], 5) and g['Pfar']['kernelInterpolants'].shape[0] == h2.plan.far.shape[0]*M*M
+    assert all(v.shape[0] == 1 and v.shape[2] == M for v in tree['values'].values())
+    assert set(tree['refinementParams'].attrs) >= {'maxLevels', 'minSize', 'eta', 'interpolation_order', 'farFieldInteractionSize'}
+    assert len(g['Pnear']) == len(Pnear)
+    # every DoF in exactly one leaf, the stored dofs of a parent are those of its children
+    leaf_dofs = np.concatenate([tree['dofs']['indices'][tree['dofs']['indptr'][k]:tree['dofs']['indptr'][k+1]]
+                                for k in range(nn) if tree['children']['indptr'][k+1] == tree['children']['indptr'][k]])
+    assert sorted(leaf_dofs.tolist()) == list(range(dm.num_dofs))
+    x = torch.from_numpy(np.random.default_rng(0).standard_normal(dm.num_dofs)).cuda()
+    y = h2.matvec(x).cpu().numpy()
+    b2 = nonlocalBuilder(dm, getFractionalKernel(2, 0.75), params, zeroExterior=True)
+    h2b, Pn2 = H2Matrix.HDF5read(g, b2.context(), returnPnear=True)
+    assert len(Pn2) == len(Pnear)
+    yb = h2b.matvec(x).cpu().numpy()
+    assert np.abs(yb-y).max() <= 1e-13*np.abs(y).max()
+    # the stored far-field data are what the read operator applies
+    g['Pfar']['kernelInterpolants'] *= 2.
+    h2c = H2Matrix.HDF5read(g, b2.context())
+    yc = h2c.matvec(x).cpu().numpy()
+    ynear = h2.Anear.matvec(x).cpu().numpy()
+    assert np.abs((yc-ynear)-2.*(y-ynear)).max() <= 1e-12*np.abs(y).max()
+    # the first operator still works after the context was used by another one (its data come back)
+    assert np.abs(h2b.matvec(x).cpu().numpy()-y).max() <= 1e-13*np.abs(y).max()
