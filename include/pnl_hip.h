@@ -427,6 +427,13 @@ typedef struct {
     const double *R_data_dev;
     const int32_t *P_indptr_dev, *P_indices_dev;
     const double *P_data_dev;
+    /* kind 0: the dense operator A_dev.  kind 1 (the FINEST level only): the H2 operator currently set up in the context
+     * (pnl_h2_setup): near field as full CSR (near_*_dev, n rows) + the far field through pnl_h2_matvec; A_dev is unused,
+     * diag_dev = the diagonal of the near field.  The hierarchies of the reference's drivers put H2 operators on the fine
+     * levels (helpers.py:312-380 with matrixFormat 'H2'). */
+    int32_t kind, pad2;
+    const int32_t *near_indptr_dev, *near_indices_dev;
+    const double *near_data_dev;
 } pnl_mg_level_desc;
 typedef struct pnl_mg pnl_mg;
 /* multigrid.__init__ / setup (:86-235): V cycle, Jacobi smoother with damping omega and presmooth / postsmooth sweeps

@@ -61,7 +61,9 @@ class pnl_order_formula(C.Structure):
 class pnl_mg_level_desc(C.Structure):
     _fields_ = [('n', C.c_int32), ('pad', C.c_int32), ('A_dev', C.c_void_p), ('ldA', C.c_int64), ('diag_dev', C.c_void_p),
                 ('R_indptr_dev', C.c_void_p), ('R_indices_dev', C.c_void_p), ('R_data_dev', C.c_void_p),
-                ('P_indptr_dev', C.c_void_p), ('P_indices_dev', C.c_void_p), ('P_data_dev', C.c_void_p)]
+                ('P_indptr_dev', C.c_void_p), ('P_indices_dev', C.c_void_p), ('P_data_dev', C.c_void_p),
+                ('kind', C.c_int32), ('pad2', C.c_int32), ('near_indptr_dev', C.c_void_p), ('near_indices_dev', C.c_void_p),
+                ('near_data_dev', C.c_void_p)]
 
 
 class pnl_order_function(C.Structure):

@@ -27,7 +27,7 @@ struct pnl_mg {
     int pre = 1, post = 1;
     // per level: invD (omega / diag), rhs, sol, temp
     std::vector<DevBuf> invD, rhs, sol, temp;
-    DevBuf r, p, Ap, z, scal, work;
+    DevBuf r, p, Ap, z, scal, work, h2tmp;
     double last_conv = 0.;          // preconditioned residual norm sqrt(r.Br) at the end of the last pnl_mg_cg
 };
 
@@ -139,6 +139,20 @@ int axpby(pnl_context *ctx, int n, double a, const double *x, double b, double *
     return PNL_OK;
 }
 
+// y = alpha A_l x + beta b with the operator of level l: dense GEMV, or (kind 1, finest level) near-field CSR product + the far
+// field of the H2 operator set up in the context (b may be y; x must not be y)
+int apply_level(pnl_mg *mg, int l, const double *x, double alpha, double beta, const double *b, double *y) {
+    pnl_context *ctx = mg->ctx;
+    const pnl_mg_level_desc &L = mg->lv[l];
+    if (L.kind == 0) return gemv(ctx, L.A_dev, L.ldA, L.n, L.n, x, alpha, beta, b, y);
+    double *t = (double*)mg->h2tmp.p;
+    int rc;
+    if ((rc = csr(ctx, L.n, L.near_indptr_dev, L.near_indices_dev, L.near_data_dev, x, 1., 0., t))) return rc;
+    if ((rc = pnl_h2_matvec(ctx, x, t))) return rc;
+    if (beta != 0. && b != y) HIPCHK(ctx, hipMemcpyAsync(y, b, sizeof(double)*L.n, hipMemcpyDeviceToDevice, ctx->stream));
+    return axpby(ctx, L.n, alpha, t, beta, y);
+}
+
 // synchronous: the scalar is needed on the host (step lengths and the convergence test of the CG / multigrid iterations)
 int dot(pnl_mg *mg, int n, const double *x, const double *y, double *out) {
     pnl_context *ctx = mg->ctx;
@@ -165,7 +179,7 @@ int smooth(pnl_mg *mg, int l, const double *b, double *x, int steps, bool simple
             simple = false;
             continue;
         }
-        if ((rc = gemv(ctx, L.A_dev, L.ldA, L.n, L.n, x, -1., 1., b, res))) return rc;
+        if ((rc = apply_level(mg, l, x, -1., 1., b, res))) return rc;
         if ((rc = update(ctx, L.n, invD, res, x))) return rc;
     }
     return PNL_OK;
@@ -182,7 +196,7 @@ int solve_on_level(pnl_mg *mg, int l, const double *b, double *x, bool simple) {
     if ((rc = smooth(mg, l, b, x, mg->pre, simple))) return rc;
     // residual, restricted to the coarser level
     if (simple && mg->pre == 0) HIPCHK(ctx, hipMemcpyAsync(res, b, sizeof(double)*L.n, hipMemcpyDeviceToDevice, ctx->stream));
-    else if ((rc = gemv(ctx, L.A_dev, L.ldA, L.n, L.n, x, -1., 1., b, res))) return rc;
+    else if ((rc = apply_level(mg, l, x, -1., 1., b, res))) return rc;
     if ((rc = csr(ctx, C.n, L.R_indptr_dev, L.R_indices_dev, L.R_data_dev, res, 1., 0., defect))) return rc;
     HIPCHK(ctx, hipMemsetAsync(solcg, 0, sizeof(double)*C.n, ctx->stream));
     if ((rc = solve_on_level(mg, l-1, defect, solcg, true))) return rc;
@@ -214,7 +228,9 @@ int pnl_mg_create(pnl_context *ctx, int nlevels, const pnl_mg_level_desc *levels
         return ctx ? fail(ctx, PNL_ERR_INVALID, "pnl_mg_create: bad arguments") : PNL_ERR_INVALID;
     for (int l = 0; l < nlevels; l++) {
         const pnl_mg_level_desc &L = levels[l];
-        if (L.n <= 0 || (l > 0 && (!L.A_dev || !L.diag_dev || L.ldA < L.n)))
+        if (L.kind != 0 && !(L.kind == 1 && l == nlevels-1 && l > 0 && L.near_indptr_dev && L.near_indices_dev && L.near_data_dev && L.diag_dev))
+            return fail(ctx, PNL_ERR_INVALID, "pnl_mg_create: level %d: an H2 operator (kind 1) is taken on the finest level only, with its near field", l);
+        if (L.n <= 0 || (l > 0 && L.kind == 0 && (!L.A_dev || !L.diag_dev || L.ldA < L.n)))
             return fail(ctx, PNL_ERR_INVALID, "pnl_mg_create: level %d needs n > 0, the operator and its diagonal", l);
         if (l > 0 && (!L.R_indptr_dev || !L.R_indices_dev || !L.R_data_dev || !L.P_indptr_dev || !L.P_indices_dev || !L.P_data_dev))
             return fail(ctx, PNL_ERR_INVALID, "pnl_mg_create: level %d needs restriction and prolongation", l);
@@ -240,6 +256,7 @@ int pnl_mg_create(pnl_context *ctx, int nlevels, const pnl_mg_level_desc *levels
     if (!rc) rc = ensure(ctx, mg->Ap, nb);
     if (!rc) rc = ensure(ctx, mg->z, nb);
     if (!rc) rc = ensure(ctx, mg->work, nb);
+    if (!rc) rc = ensure(ctx, mg->h2tmp, nb);
     if (!rc) rc = ensure(ctx, mg->scal, 4*sizeof(double));
     if (!rc && hipGetLastError() != hipSuccess) rc = fail(ctx, PNL_ERR_HIP, "pnl_mg_create: launch failed");
     if (rc) { delete mg; return rc; }
@@ -272,7 +289,7 @@ int pnl_mg_solve(pnl_mg *mg, const double *b_dev, double *x_dev, double tol, int
     auto residual_norm = [&](bool simple_res) -> int {
         int r2;
         if (simple_res) HIPCHK(ctx, hipMemcpyAsync(res, b_dev, sizeof(double)*L.n, hipMemcpyDeviceToDevice, ctx->stream));
-        else if ((r2 = gemv(ctx, L.A_dev, L.ldA, L.n, L.n, x_dev, -1., 1., b_dev, res))) return r2;
+        else if ((r2 = apply_level(mg, top, x_dev, -1., 1., b_dev, res))) return r2;
         return dot(mg, L.n, res, res, &n2);
     };
     if (top == 0) {
@@ -312,9 +329,13 @@ int pnl_mg_cg(pnl_mg *mg, const double *A_dev, int64_t ldA, const double *b_dev,
     pnl_context *ctx = mg->ctx;
     const int top = mg->nlevels-1;
     const pnl_mg_level_desc &L = mg->lv[top];
+    const bool h2top = !A_dev && L.kind == 1;
     if (!A_dev) { A_dev = L.A_dev; ldA = L.ldA; }
-    if (!A_dev || ldA < L.n) return fail(ctx, PNL_ERR_INVALID, "pnl_mg_cg: no operator");
+    if (!h2top && (!A_dev || ldA < L.n)) return fail(ctx, PNL_ERR_INVALID, "pnl_mg_cg: no operator");
     const int n = L.n;
+    auto applyA = [&](const double *x, double alpha, double beta, const double *b, double *y) -> int {
+        return h2top ? apply_level(mg, top, x, alpha, beta, b, y) : gemv(ctx, A_dev, ldA, n, n, x, alpha, beta, b, y);
+    };
     double *r = (double*)mg->r.p, *p = (double*)mg->p.p, *Ap = (double*)mg->Ap.p, *z = (double*)mg->z.p;
     int rc;
     auto precond = [&](const double *in, double *out) -> int {
@@ -322,7 +343,7 @@ int pnl_mg_cg(pnl_mg *mg, const double *A_dev, int64_t ldA, const double *b_dev,
         return solve_on_level(mg, top, in, out, true);
     };
     if (x_is_zero) HIPCHK(ctx, hipMemcpyAsync(r, b_dev, sizeof(double)*n, hipMemcpyDeviceToDevice, ctx->stream));
-    else if ((rc = gemv(ctx, A_dev, ldA, n, n, x_dev, -1., 1., b_dev, r))) return rc;
+    else if ((rc = applyA(x_dev, -1., 1., b_dev, r))) return rc;
     if ((rc = precond(r, p))) return rc;
     double betaOld = 0., beta = 0., pAp = 0.;
     if ((rc = dot(mg, n, r, p, &betaOld))) return rc;
@@ -333,14 +354,14 @@ int pnl_mg_cg(pnl_mg *mg, const double *A_dev, int64_t ldA, const double *b_dev,
         int k = 0;
         its = maxiter;
         for (int i = 0; i < maxiter; i++) {
-            if ((rc = gemv(ctx, A_dev, ldA, n, n, p, 1., 0., nullptr, Ap))) return rc;
+            if ((rc = applyA(p, 1., 0., nullptr, Ap))) return rc;
             if ((rc = dot(mg, n, p, Ap, &pAp))) return rc;
             const double alpha = betaOld/pAp;
             if ((rc = axpby(ctx, n, alpha, p, 1., x_dev))) return rc;
             if ((rc = axpby(ctx, n, -alpha, Ap, 1., r))) return rc;
             if (k == 50) {
                 // recalculate the residual to avoid rounding errors (solvers.pyx:412-415)
-                if ((rc = gemv(ctx, A_dev, ldA, n, n, x_dev, -1., 1., b_dev, r))) return rc;
+                if ((rc = applyA(x_dev, -1., 1., b_dev, r))) return rc;
                 k = 0;
             }
             if ((rc = precond(r, z))) return rc;

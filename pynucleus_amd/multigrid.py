@@ -209,12 +209,20 @@ class multigrid:
         self._mg = None
         # every level a dense operator: the cycle runs inside the library.  Otherwise (H2 / sparse levels) the same cycle is
         # driven from here over the operators' device matvecs (vectors stay in HBM, transfer operators through pnl_csr_matvec)
-        self._native = all(isinstance(L['A'], Dense_LinearOperator) for L in levels) and native is not False
+        from .h2 import H2Matrix
+        from .linear_operators import CSR_LinearOperator, SSS_LinearOperator
+        dense_below = all(isinstance(L['A'], Dense_LinearOperator) for L in levels[:-1])
+        top = levels[-1]['A']
+        # an H2 operator on the FINEST level (full CSR near field) runs inside the library cycle too (pnl_mg_level_desc.kind = 1)
+        self._h2_top = top if (isinstance(top, H2Matrix) and len(levels) > 1 and isinstance(top.Anear, CSR_LinearOperator)
+                               and not isinstance(top.Anear, SSS_LinearOperator)) else None
+        self._native = dense_below and (isinstance(top, Dense_LinearOperator) or self._h2_top is not None) and native is not False
         if not self._native:
+            self._h2_top = None
             self._setup_generic(ctx)
             return
         self.ctx = ctx or self.A.ctx
-        self.device = self.A.A.device
+        self.device = self.A.A.device if self._h2_top is None else self.A.device
         # level data in HBM (kept alive by this object: the library only stores the pointers)
         self._keep = []
         descs = []
@@ -223,10 +231,20 @@ class multigrid:
             A.ctx.synchronize()
             d = _lib.pnl_mg_level_desc()
             d.n = A.num_rows
-            d.A_dev = A.A.data_ptr()
-            d.ldA = A.A.stride(0)
-            diag = torch.diagonal(A.A).contiguous().clone()
-            self._keep.append(diag)
+            if A is self._h2_top:
+                near = A.Anear
+                near._bind()
+                ip, ix = near._pattern_dev if near._pattern_dev is not None else (torch.from_numpy(near.indptr).to(self.device),
+                                                                                  torch.from_numpy(near.indices).to(self.device))
+                diag = torch.from_numpy(np.ascontiguousarray(near.diagonal, dtype=np.float64)).to(self.device)
+                self._keep += [ip, ix, diag]
+                d.kind = 1
+                d.near_indptr_dev, d.near_indices_dev, d.near_data_dev = ip.data_ptr(), ix.data_ptr(), near.data_dev.data_ptr()
+            else:
+                d.A_dev = A.A.data_ptr()
+                d.ldA = A.A.stride(0)
+                diag = torch.diagonal(A.A).contiguous().clone()
+                self._keep.append(diag)
             d.diag_dev = diag.data_ptr()
             if l > 0:
                 R, P = _DevCSR(L['R'], self.device), _DevCSR(L['P'], self.device)
@@ -337,6 +355,10 @@ class multigrid:
     def _set_stream(self):
         import torch
         self.ctx.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
+        if getattr(self, '_h2_top', None) is not None:
+            # the library cycle applies the H2 operator that is set up in the context: make it this level's
+            self._h2_top._ensure_setup()
+            self._h2_top.Anear._bind()
 
     def __del__(self):
         try:
@@ -404,6 +426,8 @@ class multigrid:
             return self._ret(b, xd), its, res
         xd = torch.zeros_like(bd) if zero else self._vec(x).clone()
         self._set_stream()
+        if A is not None and not hasattr(A, 'A'):
+            raise NotImplementedError('cg(A=...) inside the library takes a dense operator (the default is the finest level)')
         Aptr, ld = (A.A.data_ptr(), A.A.stride(0)) if A is not None else (None, 0)
         its, res = self.ctx.mg_cg(self._mg, Aptr, ld, bd.data_ptr(), xd.data_ptr(), tol, maxiter, zero)
         return self._ret(b, xd), its, res

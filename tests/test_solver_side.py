@@ -365,7 +365,17 @@ def test_gpu_generic_cycle_equals_the_library_cycle_and_takes_h2_levels():
     from pynucleus_amd.h2 import H2Matrix
     assert isinstance(H2.finest['A'], H2Matrix) and H2.finest['DoFMap'].num_dofs == 2977
     b = np.asarray(H2.finest['DoFMap'].assembleRHS(1.0))
-    x, its, res = multigrid(H2).cg(b, tol=1e-9)
+    mgl, mgg = multigrid(H2), multigrid(H2, native=False)
+    # the H2 operator on the finest level runs INSIDE the library cycle (pnl_mg_level_desc.kind = 1: near-field CSR product + far
+    # field of the operator set up in the context) and does what the operator-agnostic cycle does
+    assert mgl._native and mgl._h2_top is H2.finest['A'] and not mgg._native
+    c1, c2 = mgl.cycle(b), mgg.cycle(b)
+    assert np.abs(c1-c2).max() <= 1e-12*np.abs(c2).max()
+    x, its, res = mgl.cg(b, tol=1e-9)
+    xg, itg, resg = mgg.cg(b, tol=1e-9)
+    assert its == itg and np.abs(x-xg).max() <= 1e-9*np.abs(xg).max()
+    (xs, is_, rs), (xt, it, rt) = mgl.solve(b, tol=1e-9, maxiter=40), mgg.solve(b, tol=1e-9, maxiter=40)
+    assert is_ == it and np.abs(xs-xt).max() <= 1e-9*np.abs(xs).max() and len(rs) == is_+1
     C = 2.**(-2.*s)*gamma(1.)/gamma((2+2.*s)/2.)/gamma(1.+s)
     hs = np.sqrt(abs(b@x-C*np.pi/(s+1)))
     assert abs(hs-0.059725648882225826) <= 1e-2*0.059725648882225826, hs
