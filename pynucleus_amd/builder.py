@@ -244,6 +244,7 @@ class nonlocalBuilder:
         self.mesh = dm.mesh
         self.device = device
         self._ctx = None
+        self._geom_cache = {}
         self.setKernel(kernel, zeroExterior)
 
     def setKernel(self, kernel, zeroExterior=True):
@@ -642,7 +643,13 @@ class nonlocalBuilder:
             def far_class(cp):
                 return int(cls_of[blk[cp.n1.dofs[0]], blk[cp.n2.dofs[0]]])
         else:
-            root, Pnear, Pfar = clusters.getNearFieldClusters(self.dm, rp['eta'], rp['minSize'], rp['maxLevels'])
+            # tree, admissible pairs, near-field tile plan, pattern and far-field plan depend on the mesh and the refinement
+            # parameters only: kept on the builder (a second operator of the same DoFMap -- another kernel through setKernel, a
+            # time step -- starts with the device work)
+            key = ('tree', rp['eta'], rp['minSize'], rp['maxLevels'])
+            if self._geom_cache.get('key') != key:
+                self._geom_cache = {'key': key, 'tree': clusters.getNearFieldClusters(self.dm, rp['eta'], rp['minSize'], rp['maxLevels'])}
+            root, Pnear, Pfar = self._geom_cache['tree']
         rank, size = self._rank_size()
         if sum(len(v) for v in Pfar.values()) == 0:
             h2 = self.getDense()
@@ -679,11 +686,21 @@ class nonlocalBuilder:
         else:
             # full CSR near field by default: its SpMV needs no atomics for the transposed half (0.16 ms against 0.39 ms with
             # SSS at 49k DoFs) and HBM is not the constraint; params['forceUnsymmetric'] = False keeps the reference's SSS
-            Anear = self.assembleClusters(Pnear, forceUnsymmetricMatrix=bool(self.params.get('forceUnsymmetric', True)))
+            # the near field is launched first; the far-field plan is built on the host while the device assembles
+            Anear = self.assembleClusters(Pnear, forceUnsymmetricMatrix=bool(self.params.get('forceUnsymmetric', True)), _defer_info=True)
             m = self.params.get('interpolation_order', None)
             if m is None:
                 m = interpolationOrder(self.kernel, self.mesh, self.tables.target_order)
-            h2 = H2Matrix(Anear, h2Plan(self.dm, root, Pfar, m, far_class), self.context(), root, Pfar)
+            pkey = ('h2plan', id(root), m, far_class is None)
+            if far_class is None and self._geom_cache.get('h2plan_key') == pkey:
+                plan = self._geom_cache['h2plan']
+            else:
+                plan = h2Plan(self.dm, root, Pfar, m, far_class)
+                if far_class is None:
+                    self._geom_cache['h2plan_key'], self._geom_cache['h2plan'] = pkey, plan
+            if getattr(Anear, '_finish', None) is not None:
+                Anear._finish()
+            h2 = H2Matrix(Anear, plan, self.context(), root, Pfar)
         out = (h2,)
         if returnNearField:
             out += (Pnear,)
@@ -692,7 +709,7 @@ class nonlocalBuilder:
         return out if len(out) > 1 else out[0]
 
     def assembleClusters(self, Pnear, forceUnsymmetricMatrix=False, Anear=None, jumps={}, myRoot=None, _clusterBoundary=True,
-                         _globalBoundary=True, _symmetrizeMasks=False, **kwargs):
+                         _globalBoundary=True, _symmetrizeMasks=False, _defer_info=False, **kwargs):
         """Near-field matrix of the cluster pairs Pnear (NA:1663-1964), assembled on the GPU.
 
         Host side: sparsity pattern (getSparseNearField NA:3226-3289), per element-pair 256-bit entry masks
@@ -723,28 +740,50 @@ class nonlocalBuilder:
         dev = torch.device('cuda', ctx.device)
         dm = self.dm
         symmetric = not forceUnsymmetricMatrix
+        cached = self._geom_cache.get('tree') is not None and Pnear is self._geom_cache['tree'][1] and myRoot is None
         if Anear is None:
-            indptr, indices = clusters.getSparseNearField(dm, Pnear, symmetric=symmetric, device=dev)
+            pat_key = ('pattern', symmetric)
+            if cached and pat_key in self._geom_cache:
+                indptr, indices = self._geom_cache[pat_key]
+            else:
+                indptr, indices = clusters.getSparseNearField(dm, Pnear, symmetric=symmetric, device=dev)
+                if cached:
+                    self._geom_cache[pat_key] = (indptr, indices)
             Anear = (SSS_LinearOperator if symmetric else CSR_LinearOperator)(indptr, indices, dm.num_dofs, ctx, dev)
         Anear._bind()
         data_ptr, diag_ptr = Anear._ptrs()
         mode = self.params.get('nearFieldAssembly', 'tiles' if 'maxMasksNNZ' not in self.params else 'masks')
         if mode == 'tiles' and not self.kernel.variable and not self.kernel.finiteHorizon:
             # the GPU's own decomposition: cluster-pair tiles with LDS sub-blocks, no masks (clusters.nearFieldPlan)
-            plan = clusters.nearFieldPlan(dm, Pnear, tile=ctx.tile_cells())
+            tile = ctx.tile_cells()
+            if cached and self._geom_cache.get('nfplan_tile') == tile:
+                plan = self._geom_cache['nfplan']
+            else:
+                plan = clusters.nearFieldPlan(dm, Pnear, tile=tile)
+                if cached:
+                    self._geom_cache['nfplan_tile'], self._geom_cache['nfplan'] = tile, plan
             use_bnd = bool(self.tables.has_boundary_tables and _clusterBoundary)
             ctx.assemble_clusters_tiled(plan, use_bnd, data_ptr, diag_ptr)
-            cnt = ctx.counters()
-            ms = ctx.phase_ms()
-            nitems = plan.bt_cell.shape[0]
-            if use_bnd and not self.zeroExterior and _globalBoundary:
-                cells, facets, bmasks = clusters.globalBoundaryItems(dm, self.tables.bcells)
-                nitems += int(cells.shape[0])
-                ctx.assemble_boundary_masked(cells, facets, bmasks, -1., data_ptr, diag_ptr)
-            ctx.synchronize()
-            self.PLogger.addTimer('interior', 1e-3*ms['total'])
-            Anear.info = dict(counters=dict(cnt, numBoundaryItems=nitems, numTiles=int(plan.tile_chunkA.shape[0])), interior_ms=ms['total'],
-                              phase_ms=ms, mode='tiles')
+            extra = use_bnd and not self.zeroExterior and _globalBoundary
+
+            def finish():
+                # reads the counters (synchronises the stream): deferred by getH2 until its far-field plan is built
+                cnt = ctx.counters()
+                ms = ctx.phase_ms()
+                nitems = plan.bt_cell.shape[0]
+                if extra:
+                    cells, facets, bmasks = clusters.globalBoundaryItems(dm, self.tables.bcells)
+                    nitems += int(cells.shape[0])
+                    ctx.assemble_boundary_masked(cells, facets, bmasks, -1., data_ptr, diag_ptr)
+                ctx.synchronize()
+                self.PLogger.addTimer('interior', 1e-3*ms['total'])
+                Anear.info = dict(counters=dict(cnt, numBoundaryItems=nitems, numTiles=int(plan.tile_chunkA.shape[0])), interior_ms=ms['total'],
+                                  phase_ms=ms, mode='tiles')
+                Anear._finish = None
+            if _defer_info:
+                Anear._finish = finish
+            else:
+                finish()
             return Anear
         maxNNZ = int(self.params.get('maxMasksNNZ', 10000000))
         totals = dict(numCellPairs=0, numAssembledCellPairs=0, numIntegrations=0)
