@@ -32,7 +32,9 @@ static inline double kernel_eval(const nlo_kernel *K, double d2) {
     switch (K->ktype) {
     case 0: return K->scale*pow(d2, K->exponent);
     case 1: return K->scale;
-    default: return K->scale/sqrt(d2);
+    case 2: return K->scale/sqrt(d2);
+    case 3: return K->scale*exp(K->exponent*d2);          /* gaussianKernel1D / 2D, KC:388-416: C exp(-d2 invD), exponent = -invD */
+    default: return K->scale*exp(K->exponent*sqrt(d2));    /* exponentialKernel, KC:448-462: C exp(-a |x-y|), exponent = -a */
     }
 }
 

@@ -110,6 +110,9 @@ def kernel_spec(kernel):
     finite = bool(np.isfinite(kernel.horizonValue))
     spec = dict(kernelType=int(kernel.kernelType), horizon=float(kernel.horizonValue), normalized=bool(getattr(kernel, 'normalized', True)),
                 interaction=int(getattr(kernel.interaction, 'device_id', 0)) if finite else 0)
+    for name in ('variance', 'exponentialRate'):          # Gaussian / exponential kernels: the user's parameter
+        if hasattr(kernel, name):
+            spec[name] = float(getattr(kernel, name))
     s = getattr(kernel, 's', None)
     if s is None:
         return spec

@@ -34,7 +34,7 @@ from itertools import permutations, product
 import numpy as np
 from scipy.special import roots_sh_jacobi, gamma
 
-FRACTIONAL, INDICATOR, PERIDYNAMIC = 0, 1, 2      # ktype codes of nl_oracle.h
+FRACTIONAL, INDICATOR, PERIDYNAMIC, GAUSSIAN, EXPONENTIAL = 0, 1, 2, 3, 4      # ktype codes of nl_oracle.h
 COMMON_VERTEX, COMMON_EDGE, COMMON_FACE = -1, -2, -3
 
 
@@ -249,10 +249,20 @@ def fractional_scaling(dim, s, horizon, normalized):
     return 2.**(2.*s)*s*gamma(s+0.5*dim)/np.pi**(0.5*dim)/gamma(1.-s)*0.5
 
 
-def integrable_scaling(ktype, dim, horizon, normalized):
-    """kernelNormalization.pyx:225-260 (constantIntegrableScaling), interaction ball2"""
+def integrable_scaling(ktype, dim, horizon, normalized, variance=1., rate=1.):
+    """kernelNormalization.pyx:225-290 (constantIntegrableScaling), interaction ball2 / full space"""
+    from math import erf, exp, sqrt, pi
     if not normalized:
         return 0.5
+    if ktype == GAUSSIAN:
+        if dim == 1:
+            return 4.0/sqrt(pi)/(erf(3.0)-6.0*exp(-9.0)/sqrt(pi))/(horizon/3.0)**3/2. if np.isfinite(horizon) else 1.0/sqrt(2.0*pi*variance)/2.
+        return 4.0/pi/(1.0-10.0*exp(-9.0))/(horizon/3.0)**4/2. if np.isfinite(horizon) else 1.0/(2.0*pi*variance)/2.
+    if ktype == EXPONENTIAL:
+        assert dim == 1
+        if np.isfinite(horizon):
+            return rate**3/(2.0-exp(-rate*horizon)*(2.0+2.0*rate*horizon+(rate*horizon)**2))/2.
+        return rate**3/2.0/2.
     if ktype == INDICATOR:
         return 3./horizon**3/2. if dim == 1 else 8./np.pi/horizon**4/2.
     if ktype == PERIDYNAMIC:
@@ -435,6 +445,17 @@ class OracleTables:
         elif ktype == PERIDYNAMIC:
             sing = -1.
             self.kernel = KernelBlock(PERIDYNAMIC, -0.5, integrable_scaling(ktype, dim, horizon, normalized), horizon, spec.get('interaction', 0))
+        elif ktype == GAUSSIAN:
+            # kernelsCy.pyx:388-416, 687-692: C exp(-d2 invD), invD = 1 / (horizon/3)^2 (finite horizon) or 1 / (2 variance^dim)
+            sing = 0.
+            var = float(spec.get('variance', 1.))
+            invD = 1.0/(horizon/3.)**2 if finite else 0.5/var**dim
+            self.kernel = KernelBlock(GAUSSIAN, -invD, integrable_scaling(ktype, dim, horizon, normalized, var), horizon, spec.get('interaction', 0))
+        elif ktype == EXPONENTIAL:
+            # kernelsCy.pyx:448-462: C exp(-a |x-y|)
+            sing = 0.
+            rate = float(spec.get('exponentialRate', 1.))
+            self.kernel = KernelBlock(EXPONENTIAL, -rate, integrable_scaling(ktype, dim, horizon, normalized, 1., rate), horizon, spec.get('interaction', 0))
         else:
             raise NotImplementedError(ktype)
         self.singularityValue = sing

@@ -182,7 +182,9 @@ __device__ __forceinline__ double kern_eval(const DevKernel &k, double d2, const
         // product below 1e-14, three orders under the parity tolerance)
         if (k.ktype == 0) return ltab ? pnl_pow_tab(d2, k, ltab) : k.scale*pnl_exp(k.exponent*pnl_log(d2));
         if (k.ktype == 1) return k.scale;
-        return k.scale/sqrt(d2);
+        if (k.ktype == 2) return k.scale/sqrt(d2);
+        if (k.ktype == 3) return k.scale*pnl_exp(k.exponent*d2);              // Gaussian: exponent = -1 / (2 variance^d) or -9 / horizon^2
+        return k.scale*pnl_exp(k.exponent*sqrt(d2));                          // exponential: exponent = -rate
     }
 }
 

@@ -1893,7 +1893,7 @@ int pnl_select_class(pnl_context *ctx, int k) {
 
 int pnl_set_kernel(pnl_context *ctx, int which, const pnl_kernel *k) {
     if (!ctx || !k || which < 0 || which > 1) return fail(ctx, PNL_ERR_INVALID, "bad kernel arguments");
-    if (k->ktype < 0 || k->ktype > 2) return fail(ctx, PNL_ERR_UNSUPPORTED, "kernel type %d is not implemented", k->ktype);
+    if (k->ktype < 0 || k->ktype > 4) return fail(ctx, PNL_ERR_UNSUPPORTED, "kernel type %d is not implemented", k->ktype);
     if (!std::isinf(k->horizon2) && (k->interaction < 1 || k->interaction > 2 || !(k->horizon2 > 0.)))
         return fail(ctx, PNL_ERR_UNSUPPORTED, "finite horizon: interaction %d is not implemented (1 ball2_retriangulation, 2 ball2_barycenter)",
                     k->interaction);

@@ -22,9 +22,12 @@ from math import gamma as Gamma, pi
 FRACTIONAL = 0
 INDICATOR = 1
 PERIDYNAMIC = 2
+GAUSSIAN = 3
+EXPONENTIAL = 4
 
 _KERNEL_NAMES = {'FRACTIONAL': FRACTIONAL, 'INDICATOR': INDICATOR, 'CONSTANT': INDICATOR,
-                 'PERIDYNAMIC': PERIDYNAMIC, 'INVERSEDISTANCE': PERIDYNAMIC, 'INVERSEOFDISTANCE': PERIDYNAMIC}
+                 'PERIDYNAMIC': PERIDYNAMIC, 'INVERSEDISTANCE': PERIDYNAMIC, 'INVERSEOFDISTANCE': PERIDYNAMIC,
+                 'GAUSSIAN': GAUSSIAN, 'EXPONENTIAL': EXPONENTIAL}
 
 
 def getKernelEnum(kernelTypeString):
@@ -99,7 +102,10 @@ class constantFractionalLaplacianScaling(constantTwoPoint):
 
 
 class constantIntegrableScaling(constantTwoPoint):
-    def __init__(self, kType, interaction, dim, horizon):
+    """kernelNormalization.pyx:225-290"""
+
+    def __init__(self, kType, interaction, dim, horizon, gaussian_variance=1.0, exponentialRate=1.0):
+        from math import erf, exp, sqrt
         self.kType, self.dim, self.horizon = kType, dim, horizon
         if horizon <= 0.:
             value = np.nan
@@ -115,6 +121,20 @@ class constantIntegrableScaling(constantTwoPoint):
                 value = 2./horizon**2/2.
             elif dim == 2:
                 value = 6./pi/horizon**3/2.
+            else:
+                raise NotImplementedError()
+        elif kType == GAUSSIAN:
+            if dim == 1:
+                value = (4.0/sqrt(pi)/(erf(3.0)-6.0*exp(-9.0)/sqrt(pi))/(horizon/3.0)**3/2. if horizon < np.inf
+                         else 1.0/sqrt(2.0*pi*gaussian_variance)/2.)
+            elif dim == 2:
+                value = (4.0/pi/(1.0-10.0*exp(-9.0))/(horizon/3.0)**4/2. if horizon < np.inf else 1.0/(2.0*pi*gaussian_variance)/2.)
+            else:
+                raise NotImplementedError()
+        elif kType == EXPONENTIAL:
+            a = exponentialRate
+            if dim == 1:
+                value = (a**3/(2.0-exp(-a*horizon)*(2.0+2.0*a*horizon+(a*horizon)**2))/2. if horizon < np.inf else a**3/2.0/2.)
             else:
                 raise NotImplementedError()
         else:
@@ -181,8 +201,9 @@ class Kernel:
         self.max_horizon = self.horizonValue if np.isnan(max_horizon) else max_horizon
         self.variable = self.variableOrder = self.variableHorizon = self.variableScaling = self.variableSingularity = False
         self.symmetric = True
-        if kType == INDICATOR:
-            self.singularityValue = 0.
+        self.exponentInverse = None
+        if kType in (INDICATOR, GAUSSIAN, EXPONENTIAL):
+            self.singularityValue = 0.                   # kernelsCy.pyx:649-664
         elif kType == PERIDYNAMIC:
             self.singularityValue = -1. if not boundary else 0.
         elif kType != FRACTIONAL:
@@ -205,7 +226,9 @@ class Kernel:
 
     @property
     def exponent(self):
-        """power of |x-y|^2"""
+        """power of |x-y|^2; Gaussian / exponential kernels: the factor in exp(exponent |x-y|^2) / exp(exponent |x-y|)"""
+        if self.kernelType in (GAUSSIAN, EXPONENTIAL):
+            return -self.exponentInverse
         return 0.5*self.singularityValue
 
     def device_params(self):
@@ -223,6 +246,10 @@ class Kernel:
         d2 = float(((x-y)**2).sum())
         if self.finiteHorizon and not d2 <= self.horizonValue**2:
             return 0.
+        if self.kernelType == GAUSSIAN:
+            return self.scalingValue*np.exp(self.exponent*d2)
+        if self.kernelType == EXPONENTIAL:
+            return self.scalingValue*np.exp(self.exponent*np.sqrt(d2))
         return self.scalingValue*d2**self.exponent
 
     def _integrable_boundary_scaling(self):
@@ -404,12 +431,22 @@ def getIntegrableKernel(dim, kernel, horizon, scaling=None, interaction=None, no
     kType = getKernelEnum(kernel)
     horizonFun = _getHorizon(horizon)
     interaction = _getInteraction(interaction, horizonFun)
+    variance, rate = float(kwargs.get('variance', 1.0)), float(kwargs.get('exponentialRate', 1.0))
     if scaling is None:
         if normalized:
-            scaling = constantIntegrableScaling(kType, interaction, dim, horizonFun.value)
+            scaling = constantIntegrableScaling(kType, interaction, dim, horizonFun.value, variance, rate)
         else:
             scaling = constantTwoPoint(0.5)
-    return Kernel(dim, kType, horizonFun, interaction, scaling, phi, piecewise, boundary, 1, max_horizon)
+    k = Kernel(dim, kType, horizonFun, interaction, scaling, phi, piecewise, boundary, 1, max_horizon)
+    k.normalized = bool(normalized)
+    if kType == GAUSSIAN:
+        # kernelsCy.pyx:687-692: 1 / (horizon / 3)^2 for a finite horizon, 1 / (2 variance^dim) on the full space
+        k.exponentInverse = 1.0/(k.horizonValue/3.)**2 if k.finiteHorizon else 0.5/variance**dim
+        k.variance = variance
+    elif kType == EXPONENTIAL:
+        k.exponentInverse = rate
+        k.exponentialRate = rate
+    return k
 
 
 def getKernel(dim, s=None, horizon=None, scaling=None, interaction=None, normalized=True, piecewise=True, phi=None,
@@ -419,7 +456,8 @@ def getKernel(dim, s=None, horizon=None, scaling=None, interaction=None, normali
         return getFractionalKernel(dim, s, horizon, interaction, scaling, normalized, piecewise, phi, boundary,
                                    max_horizon=max_horizon)
     return getIntegrableKernel(dim, kernel=kType, horizon=horizon, scaling=scaling, interaction=interaction,
-                               normalized=normalized, piecewise=piecewise, phi=phi, max_horizon=max_horizon)
+                               normalized=normalized, piecewise=piecewise, phi=phi, max_horizon=max_horizon, variance=variance,
+                               exponentialRate=exponentialRate)
 
 
 class _kernelFactory:
@@ -436,6 +474,10 @@ class _kernelFactory:
             return getIntegrableKernel(kernel=INDICATOR, **kwargs)
         if n in ('inversedistance', 'inverseofdistance', 'peridynamic'):
             return getIntegrableKernel(kernel=PERIDYNAMIC, **kwargs)
+        if n == 'gaussian':
+            return getIntegrableKernel(kernel=GAUSSIAN, **kwargs)
+        if n == 'exponential':
+            return getIntegrableKernel(kernel=EXPONENTIAL, **kwargs)
         raise NotImplementedError(name)
 
 

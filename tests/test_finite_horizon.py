@@ -124,16 +124,27 @@ def _gpu_sparse(N, delta, kernel, interaction=None, s=None, element='P1', params
     dm = dofmapFactory(element, mesh, NO_BOUNDARY)
     if kernel == 'fractional':
         k = getFractionalKernel(mesh.dim, s, horizon=delta, interaction=interaction)
+    elif kernel in ('gaussian', 'exponential'):
+        k = getKernel(mesh.dim, kernel=kernel, horizon=delta, interaction=interaction, exponentialRate=12.)
     else:
         k = getKernel(mesh.dim, kernel=INDICATOR if kernel == 'indicator' else PERIDYNAMIC, horizon=delta, interaction=interaction)
     return nonlocalBuilder(dm, k, params or {}, zeroExterior=False)
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('case', ['indicator', 'peridynamic', 'barycenter', 'fractional', 'P2', 'interval', 'chunked_csr', 'host_pairs'])
+@pytest.mark.parametrize('case', ['indicator', 'peridynamic', 'barycenter', 'fractional', 'P2', 'interval', 'chunked_csr', 'host_pairs',
+                                  'gaussian', 'gaussian_interval', 'exponential_interval', 'gaussian_P2'])
 def test_gpu_getSparse_vs_oracle(case):
     from oracle.oracle import OracleProblem
-    if case == 'indicator':
+    if case == 'gaussian':                                 # kernelsCy.pyx:388-416: C exp(-|x-y|^2 / (delta/3)^2) inside the horizon
+        b = _gpu_sparse(17, 0.2, 'gaussian')
+    elif case == 'gaussian_interval':
+        b = _gpu_sparse(6, 0.11, 'gaussian', domain='interval')
+    elif case == 'exponential_interval':                   # kernelsCy.pyx:448-462: C exp(-rate |x-y|)
+        b = _gpu_sparse(6, 0.11, 'exponential', domain='interval')
+    elif case == 'gaussian_P2':
+        b = _gpu_sparse(9, 0.3, 'gaussian', element='P2')
+    elif case == 'indicator':
         b = _gpu_sparse(17, 0.2, 'indicator')
     elif case == 'peridynamic':
         b = _gpu_sparse(17, 0.2, 'peridynamic')

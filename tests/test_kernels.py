@@ -76,3 +76,24 @@ def test_divergence_identity():
                 fm = bk(x, y-e)*(x-(y-e))[d]/norm(x-(y-e))
                 div += (fp-fm)/(2*eps)
             assert np.isclose(div, 2*k(x, y), rtol=1e-6)
+
+
+@pytest.mark.parametrize('name,kw', [('gaussian', {}), ('exponential', {'exponentialRate': 30.})])
+def test_integrable_kernel_normalisation_1d(name, kw):
+    """kernelNormalization.pyx:255-275 (constantIntegrableScaling, Gaussian / exponential): the normalised operator acts as
+    -Laplace on quadratics -- (A x^2)_I / int phi_I = -2 away from the boundary layer of width delta (the property the
+    reference's polynomial test problems rest on, nonlocalProblems.py:1447-1473).  Known answer for the new kernel types,
+    independent of any implementation detail."""
+    from pynucleus_amd import interval, P1_DoFMap, NO_BOUNDARY, getKernel
+    from pynucleus_amd.local_matrix import nonlocalTables
+    from oracle.oracle import OracleProblem
+    mesh = interval(6, 0., 1.)
+    dm = P1_DoFMap(mesh, NO_BOUNDARY)
+    A = OracleProblem(nonlocalTables(dm, getKernel(1, kernel=name, horizon=0.2, **kw), {}, False)).get_dense()[0]
+    dofs, cells = np.asarray(dm.dofs), np.asarray(mesh.cells)
+    c = np.zeros(dm.num_dofs)
+    c[dofs.ravel()] = mesh.vertices[cells.ravel(), 0]
+    r = (A@(c*c))/np.asarray(dm.assembleRHS(1.0))
+    inner = np.abs(c-0.5) < 0.5-0.21
+    assert inner.sum() > 10 and np.abs(r[inner]+2.).max() < 1e-5
+    assert np.abs(A-A.T).max() <= 1e-14*np.abs(A).max() and np.abs(A.sum(axis=1)).max() <= 1e-10*np.abs(A).max()

@@ -98,6 +98,9 @@ CASES = {
     'C3_square_constant_delta': (lambda: P1_DoFMap(uniformSquare(9), NO_BOUNDARY), lambda: getKernel(2, kernel=INDICATOR, horizon=0.3), {}, False),
     'square_peridynamic': (lambda: P1_DoFMap(uniformSquare(9), NO_BOUNDARY), lambda: getKernel(2, kernel=PERIDYNAMIC, horizon=0.3), {}, False),
     'square_truncated_fractional': (lambda: P2_DoFMap(uniformSquare(5), NO_BOUNDARY), lambda: getFractionalKernel(2, 0.4, horizon=0.45), {}, False),
+    'square_gaussian': (lambda: P1_DoFMap(uniformSquare(9), NO_BOUNDARY), lambda: getKernel(2, kernel='gaussian', horizon=0.3), {}, False),
+    'interval_gaussian': (lambda: P2_DoFMap(interval(5, 0., 1.), NO_BOUNDARY), lambda: getKernel(1, kernel='gaussian', horizon=0.2), {}, False),
+    'interval_exponential': (lambda: P1_DoFMap(interval(5, 0., 1.), NO_BOUNDARY), lambda: getKernel(1, kernel='exponential', horizon=0.2, exponentialRate=12.), {}, False),
     'interval_constant_delta': (lambda: P1_DoFMap(interval(5, 0., 1.), NO_BOUNDARY), lambda: getKernel(1, kernel=INDICATOR, horizon=0.2), {}, False),
     'interval_truncated_fractional': (lambda: P1_DoFMap(interval(5, 0., 1.), NO_BOUNDARY), lambda: getFractionalKernel(1, 0.3, horizon=0.2), {}, False),
     'interval_varconst': (lambda: P1_DoFMap(interval(5), PHYSICAL), lambda: getFractionalKernel(1, variableConstFractionalOrder(0.75)), {}, True),

@@ -80,6 +80,8 @@ for k in ('k_tile_distant', 'k_tile_pure', 'k_tile_uniform_3_3', 'k_tile_uniform
         entry[k+'_hbm_bytes_per_launch'] = int(1024*(fac*summary[k]['FETCH_SIZE']+summary[k]['WRITE_SIZE']))
         entry[k+'_fetch_size_kb'] = summary[k]['FETCH_SIZE']
         entry[k+'_write_size_kb'] = summary[k]['WRITE_SIZE']
+    if k in summary and 'SQ_INSTS_VALU' in summary[k]:
+        entry[k+'_sq_insts_valu'] = summary[k]['SQ_INSTS_VALU']
 rec['noRef{}'.format(noRef)] = entry
 with open(traffic_fn, 'w') as f:
     json.dump(rec, f, indent=1)
