@@ -235,6 +235,19 @@ __device__ __forceinline__ int quad_order_fast(const DevFormula &F, double h1, d
     return q1 > q2 ? q1 : q2;
 }
 
+// stores into the block-slot storage (written once by the tile kernels, read once by the fold pass) and of the fold pass into A
+#ifndef PNL_SLOT_NT
+#define PNL_SLOT_NT 0
+#endif
+__device__ __forceinline__ void slot_store(double *p, double v) {
+    if (PNL_SLOT_NT) __builtin_nontemporal_store(v, p); else *p = v;
+}
+__device__ __forceinline__ void slot_store2(double *p, double x, double y) {
+    typedef double pnl_d2 __attribute__((ext_vector_type(2)));
+    const pnl_d2 v = {x, y};
+    if (PNL_SLOT_NT) __builtin_nontemporal_store(v, (pnl_d2*)p); else *(pnl_d2*)p = v;
+}
+
 // hardware fp64 adds (global_atomic_add_f64 / ds_add_f64, no CAS loop); built with -munsafe-fp-atomics
 __device__ __forceinline__ void atomic_add_f64(double *p, double v) {
     (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -859,7 +859,7 @@ k_tile_distant(const DevProblem P, const int2 *__restrict__ tiles, double *__res
         double *__restrict__ base = SO.A2+SO.rowoff[ta]+(SO.colbase[tb]-ca);
         for (int t = tid; t < nA*nB; t += NT) {
             const int r = t/nB, c = t-r*nB;
-            base[(long long)r*W+c] = s_acc[r*acc_stride+c];
+            slot_store(base+(long long)r*W+c, s_acc[r*acc_stride+c]);
         }
     } else
     for (int t = tid; t < nA*nB; t += NT) {
@@ -1120,7 +1120,7 @@ k_tile_pure(const DevProblem P, const int2 *__restrict__ tiles, int ntiles, doub
             double *__restrict__ base = SO.A2+SO.rowoff[ta]+(SO.colbase[tb]-ca);
             for (int t = tid; t < nA*nB; t += PNL_NTHREADS) {
                 const int r = t/nB, cc = t-r*nB;
-                base[(long long)r*W+cc] = s_acc[r*acc_stride+cc];
+                slot_store(base+(long long)r*W+cc, s_acc[r*acc_stride+cc]);
             }
         } else if (!(symflush & 64))
         for (int t = tid; t < nA*nB; t += PNL_NTHREADS) {

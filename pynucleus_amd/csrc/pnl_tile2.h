@@ -64,6 +64,7 @@ __host__ __device__ constexpr int uni_rule_size(int dpe, int np) { return 3*np+n
 // with ds_add_f64.  No per-entry walk whose length differs from lane to lane: the kernel was bound by instruction issue
 // (1,050 VALU instructions per wave for 8 entries per thread) as much as by the chain of dependent loads.
 // Tables of a range of 32 DoFs come packed (FoldEntry[1 + PNL_FOLD_TAB], pnl_device.h): header + copies, one load per thread.
+template <bool NT>
 __global__ void __launch_bounds__(256)
 k_fold_mirror(const double *__restrict__ A2, const FoldEntry *__restrict__ tab, const int *__restrict__ cpoff, const int2 *__restrict__ cp,
               const long long *__restrict__ cprow, double *__restrict__ A, long long ldA, int N) {
@@ -149,11 +150,14 @@ k_fold_mirror(const double *__restrict__ A2, const FoldEntry *__restrict__ tab, 
     for (int r = ty; r < 32; r += 8) {
         const int I = bi*32+r, J = bj*32+tx;
         if (I < N && J < N) {
-            if (bi != bj) A[(long long)I*ldA+J] = t1[r][tx]+t2[tx][r];
-            else A[(long long)I*ldA+J] = (r != tx) ? t1[r][tx]+t1[tx][r] : t1[r][tx];
+            const double v = (bi != bj) ? t1[r][tx]+t2[tx][r] : ((r != tx) ? t1[r][tx]+t1[tx][r] : t1[r][tx]);
+            if (NT) __builtin_nontemporal_store(v, A+(long long)I*ldA+J); else A[(long long)I*ldA+J] = v;
         }
         const int I2 = bj*32+r, J2 = bi*32+tx;
-        if (bi != bj && I2 < N && J2 < N) A[(long long)I2*ldA+J2] = t2[r][tx]+t1[tx][r];
+        if (bi != bj && I2 < N && J2 < N) {
+            const double v = t2[r][tx]+t1[tx][r];
+            if (NT) __builtin_nontemporal_store(v, A+(long long)I2*ldA+J2); else A[(long long)I2*ldA+J2] = v;
+        }
     }
 }
 
@@ -403,7 +407,7 @@ k_tile_uniform(const DevProblem P, const int2 *__restrict__ tiles, const int *__
                     double2 v = make_double2(0., 0.);
                     if (cc < nB) { v.x = s_acc[r*acc_stride+cc]; s_acc[r*acc_stride+cc] = 0.; }
                     if (cc+1 < nB) { v.y = s_acc[r*acc_stride+cc+1]; s_acc[r*acc_stride+cc+1] = 0.; }
-                    *(double2*)(row+cc) = v;
+                    slot_store2(row+cc, v.x, v.y);
                 }
             }
         } else if (!(flags & 2))
@@ -1047,7 +1051,7 @@ k_tile_p2(const DevProblem P, const int2 *__restrict__ tiles, const int *__restr
                 double2 v = make_double2(0., 0.);
                 if (cc < nB) { v.x = s_acc[r*acc_stride+cc]; s_acc[r*acc_stride+cc] = 0.; }
                 if (cc+1 < nB) { v.y = s_acc[r*acc_stride+cc+1]; s_acc[r*acc_stride+cc+1] = 0.; }
-                if (!multi) *(double2*)(row+cc) = v;
+                if (!multi) slot_store2(row+cc, v.x, v.y);
                 else {
                     if (v.x != 0.) atomic_add_f64(row+cc, v.x);
                     if (v.y != 0.) atomic_add_f64(row+cc+1, v.y);

@@ -139,7 +139,9 @@ int pnl2_fold_mirror(pnl_context *ctx, const SlotOut &SO, double *A, int64_t ldA
     const long long nb = (ctx->N+31)/32, nbs = (nb+7)/8;
     if (nbs*(nbs+1)/2*64 >= (1ll << 31)) return fail(ctx, PNL_ERR_UNSUPPORTED, "fold pass: %d DoFs exceed the grid size", ctx->N);
     kt_begin(ctx, PNL_K_FOLD_MIRROR);
-    hipLaunchKernelGGL(k_fold_mirror, dim3((unsigned)(nbs*(nbs+1)/2*64)), dim3(256), 0, ctx->stream, (const double*)SO.A2, (const FoldEntry*)ctx->b_foldtab.p, (const int*)ctx->b_cpoff.p,
+    // the matrix is written once and not read again by this pass: non-temporal stores (10.9 -> 10.4 ms at 48,769 DoFs; non-temporal
+    // LOADS of the storage cost 50 %: the 8-byte gathers of neighbouring threads share lines)
+    hipLaunchKernelGGL(k_fold_mirror<true>, dim3((unsigned)(nbs*(nbs+1)/2*64)), dim3(256), 0, ctx->stream, (const double*)SO.A2, (const FoldEntry*)ctx->b_foldtab.p, (const int*)ctx->b_cpoff.p,
                        (const int2*)ctx->b_cpslot.p, (const long long*)ctx->b_cprow.p, A, (long long)ldA, ctx->N);
     kt_end(ctx, PNL_K_FOLD_MIRROR);
     HIPCHK(ctx, hipGetLastError());
