@@ -348,6 +348,11 @@ int pnl_tree_build(int N, int dim, const double *boxes, const int64_t *d2c_ptr, 
 int pnl_tree_build_blocks(int N, int dim, const double *boxes, const int64_t *d2c_ptr, const int32_t *d2c_idx, int nc, double eta,
                           int min_size, int max_levels, int do_admissibility, const int32_t *dof_block, int mixed_block,
                           pnl_tree **out);
+/* ... with the refinement type of the reference (refinementType, NA:3033-3040; tree_node.refine CM:354-663): 0 MEDIAN (the default
+ * of both), 1 GEOMETRIC (the node's box is halved along its longest edge), 2 BARYCENTER (split at the mean of the DoF coordinates) */
+int pnl_tree_build_refined(int N, int dim, const double *boxes, const int64_t *d2c_ptr, const int32_t *d2c_idx, int nc, double eta,
+                           int min_size, int max_levels, int do_admissibility, const int32_t *dof_block, int mixed_block, int ref_type,
+                           pnl_tree **out);
 void pnl_tree_destroy(pnl_tree *T);
 int pnl_tree_sizes(const pnl_tree *T, int64_t *out3);                /* nodes, near pairs, far pairs */
 int pnl_tree_get(const pnl_tree *T, int32_t *range, int32_t *parent, int32_t *children, int32_t *level, double *box, int32_t *perm,

@@ -612,11 +612,21 @@ class nonlocalBuilder:
         return (A, pairs) if returnNearField else A
 
     def getH2RefinementParams(self):
-        """NA:2386-2431: eta, leaf size and depth of the cluster tree from params"""
+        """NA:2979-3046: eta, leaf size, depth and refinement type of the cluster tree from params.  The default leaf size follows
+        the GPU tile (a leaf of about one block of cells keeps the near-field tiles full); params['minClusterSize'] = 'reference'
+        takes the reference's default interpolation_order(h)^dim // 2 (NA:3016-3024), a number takes that number."""
         p = self.params
         N = self.dm.num_dofs
-        return dict(eta=p.get('eta', 3.), maxLevels=p.get('maxLevels', 200),
-                    minSize=p.get('minClusterSize', max(self.dm.dofs_per_element*4, min(64, max(N//16, 8)))))
+        mcs = p.get('minClusterSize', None)
+        if mcs == 'reference':
+            loggamma = abs(np.log(0.25))
+            sing = self.kernel.max_singularity
+            io = max(np.ceil((2*self.tables.target_order+max(-sing, 2))*abs(np.log(self.mesh.h/self.mesh.diam))/loggamma/3.), 2)
+            mcs = int(io**self.mesh.dim//2)
+        elif mcs is None:
+            mcs = max(self.dm.dofs_per_element*4, min(64, max(N//16, 8)))
+        return dict(eta=p.get('eta', 3.), maxLevels=p.get('maxLevels', 200), minSize=int(mcs),
+                    refinementType=p.get('refinementType', 'MEDIAN'))
 
     def getH2(self, returnNearField=False, returnTree=False, **kwargs):
         """NA:3094-3219: cluster tree, admissibility, near field (assembleClusters) and the Chebyshev-interpolated far field,
@@ -637,7 +647,7 @@ class nonlocalBuilder:
             if not self.kernel.symmetric or self.kernel.finiteHorizon:
                 raise NotImplementedError('H2 operator of a non-symmetric or finite-horizon variable order')
             blk, mixed = clusters.dofKernelBlocks(self.dm, self.tables)
-            root, Pnear, Pfar = clusters.getNearFieldClusters(self.dm, rp['eta'], rp['minSize'], rp['maxLevels'], blk, mixed)
+            root, Pnear, Pfar = clusters.getNearFieldClusters(self.dm, rp['eta'], rp['minSize'], rp['maxLevels'], blk, mixed, rp['refinementType'])
             cls_of = self.tables.cls_of
 
             def far_class(cp):
@@ -646,9 +656,9 @@ class nonlocalBuilder:
             # tree, admissible pairs, near-field tile plan, pattern and far-field plan depend on the mesh and the refinement
             # parameters only: kept on the builder (a second operator of the same DoFMap -- another kernel through setKernel, a
             # time step -- starts with the device work)
-            key = ('tree', rp['eta'], rp['minSize'], rp['maxLevels'])
+            key = ('tree', rp['eta'], rp['minSize'], rp['maxLevels'], rp['refinementType'])
             if self._geom_cache.get('key') != key:
-                self._geom_cache = {'key': key, 'tree': clusters.getNearFieldClusters(self.dm, rp['eta'], rp['minSize'], rp['maxLevels'])}
+                self._geom_cache = {'key': key, 'tree': clusters.getNearFieldClusters(self.dm, rp['eta'], rp['minSize'], rp['maxLevels'], refinementType=rp['refinementType'])}
             root, Pnear, Pfar = self._geom_cache['tree']
         rank, size = self._rank_size()
         if sum(len(v) for v in Pfar.values()) == 0:

@@ -49,6 +49,7 @@ struct pnl_tree {
     // variable order: kernel block of every DoF (getKernelBlocksAndJumps NA:2312-2352), mixed_block = the interface DoFs
     std::vector<int32_t> dof_block;
     int mixed_block = -1;
+    int ref_type = 0;                        // refinementType: 0 MEDIAN, 1 GEOMETRIC, 2 BARYCENTER (CM:354-663)
 };
 
 namespace {
@@ -115,14 +116,21 @@ void refine(pnl_tree *T, int k, int minSize, int maxLevels, std::vector<double> 
     for (int d = 0; d < T->dim; d++) { const double e = nd.box[d][1]-nd.box[d][0]; if (e > best) { best = e; ax = d; } }
     xs.resize(n);
     for (int t = 0; t < n; t++) xs[t] = T->coords[(size_t)T->perm[nd.beg+t]*T->dim+ax];
-    std::vector<double> srt(xs);
     double med;
-    if (n & 1) { std::nth_element(srt.begin(), srt.begin()+n/2, srt.end()); med = srt[n/2]; }
-    else {
-        std::nth_element(srt.begin(), srt.begin()+n/2, srt.end());
-        const double hi = srt[n/2];
-        const double lo = *std::max_element(srt.begin(), srt.begin()+n/2);
-        med = (lo+hi)/2.;                    // numpy.median of an even count: mean of the two middle values
+    if (T->ref_type == 1) med = 0.5*(nd.box[ax][0]+nd.box[ax][1]);          // GEOMETRIC: the box is halved (CM:388-390, 606-607)
+    else if (T->ref_type == 2) {                                              // BARYCENTER: the mean of the DoF coordinates (CM:391-398)
+        double sum = 0.;
+        for (int t = 0; t < n; t++) sum += xs[t];
+        med = sum/n;
+    } else {
+        std::vector<double> srt(xs);
+        if (n & 1) { std::nth_element(srt.begin(), srt.begin()+n/2, srt.end()); med = srt[n/2]; }
+        else {
+            std::nth_element(srt.begin(), srt.begin()+n/2, srt.end());
+            const double hi = srt[n/2];
+            const double lo = *std::max_element(srt.begin(), srt.begin()+n/2);
+            med = (lo+hi)/2.;                    // numpy.median of an even count: mean of the two middle values
+        }
     }
     tmp.resize(n);
     int nl = 0;
@@ -184,10 +192,16 @@ int pnl_tree_build(int N, int dim, const double *boxes, const int64_t *d2c_ptr, 
 int pnl_tree_build_blocks(int N, int dim, const double *boxes, const int64_t *d2c_ptr, const int32_t *d2c_idx, int nc, double eta,
                           int min_size, int max_levels, int do_admissibility, const int32_t *dof_block, int mixed_block,
                           pnl_tree **out) {
-    if (!out || N <= 0 || dim < 1 || dim > 3 || !boxes || !d2c_ptr || !d2c_idx) return PNL_ERR_INVALID;
+    return pnl_tree_build_refined(N, dim, boxes, d2c_ptr, d2c_idx, nc, eta, min_size, max_levels, do_admissibility, dof_block, mixed_block, 0, out);
+}
+
+int pnl_tree_build_refined(int N, int dim, const double *boxes, const int64_t *d2c_ptr, const int32_t *d2c_idx, int nc, double eta,
+                           int min_size, int max_levels, int do_admissibility, const int32_t *dof_block, int mixed_block, int ref_type,
+                           pnl_tree **out) {
+    if (!out || N <= 0 || dim < 1 || dim > 3 || !boxes || !d2c_ptr || !d2c_idx || ref_type < 0 || ref_type > 2) return PNL_ERR_INVALID;
     if (dof_block) for (int i = 0; i < N; i++) if (dof_block[i] < 0) return PNL_ERR_INVALID;
     pnl_tree *T = new pnl_tree();
-    T->N = N; T->dim = dim; T->nc = nc;
+    T->N = N; T->dim = dim; T->nc = nc; T->ref_type = ref_type;
     if (dof_block) { T->dof_block.assign(dof_block, dof_block+N); T->mixed_block = mixed_block; }
     T->boxes.assign(boxes, boxes+(size_t)N*dim*2);
     T->coords.resize((size_t)N*dim);

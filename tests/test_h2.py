@@ -247,3 +247,23 @@ def test_h2_operator_file_round_trip():
     assert np.abs((yc-ynear)-2.*(y-ynear)).max() <= 1e-12*np.abs(y).max()
     # the first operator still works after the context was used by another one (its data come back)
     assert np.abs(h2b.matvec(x).cpu().numpy()-y).max() <= 1e-13*np.abs(y).max()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('params', [{'refinementType': 'GEOMETRIC'}, {'refinementType': 'BARYCENTER'}, {'minClusterSize': 'reference'}])
+def test_h2_refinement_parameters(params):
+    """the reference's refinement parameters (NA:2979-3046): refinementType GEOMETRIC / BARYCENTER and the reference's default leaf
+    size interpolation_order(h)^dim // 2 -- whatever the tree, the H2 operator approximates the dense one"""
+    import torch
+    from pynucleus_amd import disc, P1_DoFMap, PHYSICAL, getFractionalKernel
+    from pynucleus_amd.builder import nonlocalBuilder
+    dm = P1_DoFMap(disc(4), PHYSICAL)
+    b = nonlocalBuilder(dm, getFractionalKernel(2, 0.75), dict({'target_order': 0.5, 'eta': 3.}, **params), zeroExterior=True)
+    rp = b.getH2RefinementParams()
+    if 'minClusterSize' in params:
+        assert rp['minSize'] != nonlocalBuilder(dm, getFractionalKernel(2, 0.75), {'target_order': 0.5}).getH2RefinementParams()['minSize']
+    h2 = b.getH2()
+    A = b.getDense()
+    x = torch.from_numpy(np.random.default_rng(1).standard_normal(dm.num_dofs)).cuda()
+    y, yd = h2.matvec(x), A.matvec(x)
+    assert float(torch.linalg.norm(y-yd)/torch.linalg.norm(yd)) < 5e-4

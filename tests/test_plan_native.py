@@ -209,3 +209,49 @@ def test_pattern_nnz_guard():
     finally:
         L.pnl_pattern_set_max_nnz(2**31-1)
     assert L.pnl_pattern_set_max_nnz(0) == 2**31-1          # out-of-range values leave the limit unchanged
+
+
+@pytest.mark.parametrize('refType', ['MEDIAN', 'GEOMETRIC', 'BARYCENTER'])
+def test_refinement_types(refType):
+    """refinementType of the cluster tree (NA:3033-3040, tree_node.refine CM:354-663): MEDIAN / GEOMETRIC / BARYCENTER split points;
+    whatever the split, the leaves partition the DoFs, children partition their parent, near + far pairs tile the DoF x DoF
+    matrix exactly once, and every far pair is admissible (eta dist >= max diam)"""
+    dm = P1_DoFMap(disc(4), PHYSICAL)
+    root, Pnear, Pfar = clusters.getNearFieldClusters(dm, 3., 12, 200, refinementType=refType)
+    N = dm.num_dofs
+    cover = np.zeros((N, N), dtype=np.int32)
+    for cp in Pnear:
+        cover[np.ix_(cp.n1.dofs, cp.n2.dofs)] += 1
+    nfar = 0
+    for lvl, pairs in Pfar.items():
+        for cp in pairs:
+            cover[np.ix_(cp.n1.dofs, cp.n2.dofs)] += 1
+            nfar += 1
+            d = clusters.distBoxes(cp.n1.box, cp.n2.box)
+            diam = max(np.linalg.norm(cp.n1.box[:, 1]-cp.n1.box[:, 0]), np.linalg.norm(cp.n2.box[:, 1]-cp.n2.box[:, 0]))
+            assert 3.*d >= diam-1e-12
+    assert (cover == 1).all() and nfar > 0
+
+    def walk(n):
+        if n.is_leaf:
+            return [n]
+        kids = n.children
+        assert sorted(np.concatenate([k.dofs for k in kids]).tolist()) == sorted(n.dofs.tolist())
+        return [l for k in kids for l in walk(k)]
+    leaves = walk(root)
+    assert sorted(np.concatenate([l.dofs for l in leaves]).tolist()) == list(range(N))
+    if refType == 'GEOMETRIC':
+        # the root is halved along its longest edge
+        ax = int(np.argmax(root.box[:, 1]-root.box[:, 0]))
+        mid = 0.5*(root.box[ax, 0]+root.box[ax, 1])
+        boxes, _ = clusters.getDoFBoxesAndCells(dm)
+        c = 0.5*(boxes[:, ax, 0]+boxes[:, ax, 1])
+        a, b = root.children
+        assert (c[a.dofs] < mid).all() and (c[b.dofs] >= mid).all()
+    if refType == 'BARYCENTER':
+        ax = int(np.argmax(root.box[:, 1]-root.box[:, 0]))
+        boxes, _ = clusters.getDoFBoxesAndCells(dm)
+        c = 0.5*(boxes[:, ax, 0]+boxes[:, ax, 1])
+        a, b = root.children
+        # (the disc is symmetric: coordinates within rounding of the mean may fall on either side)
+        assert (c[a.dofs] < c.mean()+1e-12).all() and (c[b.dofs] >= c.mean()-1e-12).all() and min(len(a.dofs), len(b.dofs)) > 0.3*N
