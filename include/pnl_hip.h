@@ -115,6 +115,11 @@ int pnl_upload_mesh(pnl_context *ctx, int dim, int nv, const double *vertices_ho
  * beyond summation order.  A cell of volume 0 without DoFs is padding inside the mesh: it forms no pair and is not counted.
  * orig = NULL: the numbering of the upload. */
 int pnl_set_cell_order(pnl_context *ctx, int nc, const int32_t *orig_host);
+/* Interaction set = a linear image of the l2 ball: the kernel sees |T (x - y)| instead of |x - y| (ellipse_retriangulation /
+ * ellipse_barycenter = linearTransformInteraction over ball2, interactionDomains.pyx:1393-1630; T = [[cos t / a, -sin t / a],
+ * [sin t / b, cos t / b]] row-major, 2D).  Quadrature points and the cut-element geometry are formed in the transformed
+ * coordinates; cell volumes, h and the centre distance of the order formula stay those of the mesh.  NULL: identity. */
+int pnl_set_interaction_transform(pnl_context *ctx, int dim, const double *T_host);
 /* dofs[nc][dpe] (negative = boundary DoF, dm.dofs), dof_perm_table[(dim+1)!][dpe]
  * (precomputedDoFPermutations, NO:66-109) */
 int pnl_upload_dofmap(pnl_context *ctx, int dpe, int dofs_per_vertex, int dofs_per_edge, int num_dofs,

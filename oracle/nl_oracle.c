@@ -73,6 +73,15 @@ static void simplex_of(const nlo_problem *P, int c, double s[MAXV][2], double ce
     }
     double fac = 1./nV;                         /* NO:116-126 */
     for (int l = 0; l < P->dim; l++) center[l] *= fac;
+    /* linearTransformInteraction (interactionDomains.pyx:1417-1470, 1502-1520): relative position, sub-simplices and the kernel's
+     * distance are those of the simplices transformed by T (everything they enter is a difference x - y); the centre -- the
+     * order formula -- is the mesh's */
+    if (P->has_xform && P->dim == 2)
+        for (int m = 0; m < nV; m++) {
+            const double x = s[m][0], y = s[m][1];
+            s[m][0] = P->xform[0]*x+P->xform[1]*y;
+            s[m][1] = P->xform[2]*x+P->xform[3]*y;
+        }
 }
 
 #define NLO_INTERACT 0

@@ -92,6 +92,9 @@ typedef struct nlo_problem_s {
     const double *pw_keys, *pw_bkeys;
     const double *pw_nodes[3], *pw_w[3], *pw_phi0[3], *pw_phi1[3];
     const double *pw_bnodes[2], *pw_bw[2], *pw_bphi[2];
+    double xform[4];            /* interaction set = linear image of the l2 ball (ellipse domains, interactionDomains.pyx:1393-1630): the
+                                 * kernel and the cut-element geometry see T (x - y); has_xform = 0: identity */
+    int32_t has_xform, pad3;
     const double *pw_vertex_s;  /* pw_type 5 (feFractionalOrder, fractionalOrders.pyx:541-587, 660-668): values of a P1 function at the mesh vertices */
 } nlo_problem;
 

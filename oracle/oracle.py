@@ -58,7 +58,8 @@ class nlo_problem(C.Structure):
                 ('pw_c0', C.c_double), ('pw_bc0', C.c_double), ('pw_nkeys', C.c_int32), ('pw_nbkeys', C.c_int32),
                 ('pw_keys', _P), ('pw_bkeys', _P),
                 ('pw_nodes', _P*3), ('pw_w', _P*3), ('pw_phi0', _P*3), ('pw_phi1', _P*3),
-                ('pw_bnodes', _P*2), ('pw_bw', _P*2), ('pw_bphi', _P*2), ('pw_vertex_s', _P)]
+                ('pw_bnodes', _P*2), ('pw_bw', _P*2), ('pw_bphi', _P*2), ('xform', C.c_double*4), ('has_xform', C.c_int32), ('pad3', C.c_int32),
+                ('pw_vertex_s', _P)]
 
 
 def build():
@@ -110,6 +111,9 @@ def kernel_spec(kernel):
     finite = bool(np.isfinite(kernel.horizonValue))
     spec = dict(kernelType=int(kernel.kernelType), horizon=float(kernel.horizonValue), normalized=bool(getattr(kernel, 'normalized', True)),
                 interaction=int(getattr(kernel.interaction, 'device_id', 0)) if finite else 0)
+    ia = kernel.interaction
+    if all(hasattr(ia, n) for n in ('a', 'b', 'theta')):     # ellipse domains: the user's semi-axes and angle
+        spec['ellipse'] = (float(ia.a), float(ia.b), float(ia.theta))
     for name in ('variance', 'exponentialRate'):          # Gaussian / exponential kernels: the user's parameter
         if hasattr(kernel, name):
             spec[name] = float(getattr(kernel, name))
@@ -183,6 +187,13 @@ class OracleProblem:
         P.vol = ptr(mesh.volVector, np.float64)
         P.h = ptr(mesh.hVector, np.float64)
         P.H0 = T.H0
+        xf = getattr(T, 'interaction_transform', None)
+        if xf is None:
+            xf = getattr(getattr(getattr(T, 'kernel', None), 'interaction', None), 'transform', None)
+        if xf is not None:
+            P.has_xform = 1
+            for i, v in enumerate(np.asarray(xf, dtype=np.float64).ravel()):
+                P.xform[i] = v
         P.dof_perm_table = ptr(T.dof_perm_table, np.int32)
         self.pointwise = bool(getattr(T, 'pointwise', False))
         if not self.pointwise:

@@ -386,6 +386,11 @@ class OracleTables:
         ktype, horizon, normalized = spec['kernelType'], float(spec.get('horizon', np.inf)), bool(spec.get('normalized', True))
         finite = np.isfinite(horizon)
         self.zeroExterior = bool(zeroExterior) and not finite                      # NA:919-922
+        self.interaction_transform = None
+        if spec.get('ellipse') is not None:
+            # ellipse_retriangulation / _barycenter (interactionDomains.pyx:1579-1630): T = [[cos t / a, -sin t / a], [sin t / b, cos t / b]]
+            a, b, th = spec['ellipse']
+            self.interaction_transform = np.array([[np.cos(th)/a, -np.sin(th)/a], [np.sin(th)/b, np.cos(th)/b]])
         verts = np.asarray(mesh.vertices, dtype=np.float64)
         cells = np.asarray(mesh.cells)
         self.H0 = float(np.linalg.norm(verts.max(axis=0)-verts.min(axis=0)))/np.sqrt(8.)   # NO:435, mesh.py:1658-1661

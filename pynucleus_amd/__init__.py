@@ -9,7 +9,7 @@ from .mesh import (mesh1d, mesh2d, simpleInterval, uniformSquare, uniform_disc, 
                    PHYSICAL, NO_BOUNDARY, INTERIOR, INTERIOR_NONOVERLAPPING)
 from .dofmap import P1_DoFMap, P2_DoFMap, dofmapFactory, fe_vector  # noqa: F401
 from .kernels import (getKernel, getFractionalKernel, getIntegrableKernel, kernelFactory,  # noqa: F401
-                      FRACTIONAL, INDICATOR, PERIDYNAMIC, GAUSSIAN, EXPONENTIAL, constFractionalOrder, constant, ball2_retriangulation, ball2_barycenter)
+                      FRACTIONAL, INDICATOR, PERIDYNAMIC, GAUSSIAN, EXPONENTIAL, constFractionalOrder, constant, ball2_retriangulation, ball2_barycenter, ellipse_retriangulation, ellipse_barycenter)
 from .local_matrix import nonlocalTables  # noqa: F401
 from .fractionalOrders import (variableConstFractionalOrder, leftRightFractionalOrder, layersFractionalOrder,  # noqa: F401
                                piecewiseConstantFractionalOrder, constantNonSymFractionalOrder,

@@ -478,6 +478,12 @@ class nonlocalBuilder:
         self.assembleClusters(Pnear, Anear=A, _globalBoundary=False, _clusterBoundary=self.zeroExterior)
         return float(A.data[0])
 
+    def _interaction_vertices(self):
+        """the vertices in the coordinates the interaction set is a ball in (ellipse domains: T x; otherwise the mesh's own)"""
+        T = getattr(self.kernel.interaction, 'transform', None)
+        v = np.asarray(self.mesh.vertices, dtype=np.float64)
+        return v if T is None else np.ascontiguousarray(v @ np.asarray(T).T)
+
     def interactingCellPairs(self):
         """all ordered cell pairs c1 <= c2 that the horizon does not separate for sure: |centre1 - centre2| <= delta + r1 + r2
         with r = largest vertex distance from the centre.  A superset of the pairs getRelativePosition does not call
@@ -485,7 +491,7 @@ class nonlocalBuilder:
         the device drops the REMOTE ones in its classification (NO:515-517), so the assembled entries are the same."""
         from scipy.spatial import cKDTree
         mesh = self.mesh
-        v = mesh.vertices[mesh.cells]
+        v = self._interaction_vertices()[mesh.cells]
         cen = v.mean(axis=1)
         rad = np.sqrt(((v-cen[:, None, :])**2).sum(axis=2)).max(axis=1)
         delta = self.kernel.horizonValue
@@ -520,7 +526,7 @@ class nonlocalBuilder:
         # the pattern depends on the mesh, the DoF map and the horizon only: repeated assemblies reuse it (0.4 s of the 0.47 s
         # of a getSparse call at 129^2 vertices are spent in these sparse products)
         cache = getattr(self, '_sparse_pattern', None)
-        if cache is not None and cache[0] == (symmetric, host_pairs, float(self.kernel.horizonValue)):
+        if cache is not None and cache[0] == (symmetric, host_pairs, float(self.kernel.horizonValue), repr(self.kernel.interaction)):
             indptr, indices, pairs = cache[1]
             return self._assembleSparse(indptr, indices, pairs, symmetric, host_pairs, returnNearField)
         rows = np.repeat(np.arange(nc), dpe)
@@ -538,7 +544,7 @@ class nonlocalBuilder:
             # set of DoF pairs whose patches hold a vertex pair closer than delta; built by libpnl_hip.so (csrc/pnl_plan.hip)
             import ctypes as Ct
             L = _lib.load()
-            verts = np.ascontiguousarray(self.mesh.vertices, dtype=np.float64)
+            verts = np.ascontiguousarray(self._interaction_vertices(), dtype=np.float64)
             mcells = np.ascontiguousarray(self.mesh.cells, dtype=np.int32)
             dofs32 = np.ascontiguousarray(dm.dofs, dtype=np.int32)
             h = Ct.c_void_p()
@@ -554,7 +560,7 @@ class nonlocalBuilder:
             L.pnl_pattern_get(h, indptr.ctypes.data, indices.ctypes.data if indices.shape[0] else None)
             L.pnl_pattern_destroy(h)
             pairs = None
-            self._sparse_pattern = ((symmetric, host_pairs, float(self.kernel.horizonValue)), (indptr, indices, pairs))
+            self._sparse_pattern = ((symmetric, host_pairs, float(self.kernel.horizonValue), repr(self.kernel.interaction)), (indptr, indices, pairs))
             return self._assembleSparse(indptr, indices, pairs, symmetric, host_pairs, returnNearField)
         else:
             # the same pattern through scipy sparse products, G = M Q M^T with M = DoF -> patch vertices (params['patternBuilder']
@@ -562,7 +568,7 @@ class nonlocalBuilder:
             from scipy.spatial import cKDTree
             pairs = None
             nv = self.mesh.num_vertices
-            vp = cKDTree(self.mesh.vertices).query_pairs(self.kernel.horizonValue*(1.+1e-9), output_type='ndarray')
+            vp = cKDTree(self._interaction_vertices()).query_pairs(self.kernel.horizonValue*(1.+1e-9), output_type='ndarray')
             Q = sp.csr_matrix((np.ones(vp.shape[0], dtype=np.int32), (vp[:, 0], vp[:, 1])), shape=(nv, nv))
             Q = Q+Q.T+sp.identity(nv, dtype=np.int32, format='csr')
             B = sp.csr_matrix((np.ones(nc*self.mesh.cells.shape[1], dtype=np.int32),
@@ -574,7 +580,7 @@ class nonlocalBuilder:
             G = sp.tril(G, k=-1, format='csr')
         G.sort_indices()
         indptr, indices = G.indptr.astype(np.int32), G.indices.astype(np.int32)
-        self._sparse_pattern = ((symmetric, host_pairs, float(self.kernel.horizonValue)), (indptr, indices, pairs))
+        self._sparse_pattern = ((symmetric, host_pairs, float(self.kernel.horizonValue), repr(self.kernel.interaction)), (indptr, indices, pairs))
         return self._assembleSparse(indptr, indices, pairs, symmetric, host_pairs, returnNearField)
 
     def _assembleSparse(self, indptr, indices, pairs, symmetric, host_pairs, returnNearField):

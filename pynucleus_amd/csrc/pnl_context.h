@@ -130,7 +130,11 @@ struct pnl_context {
     // tables of the general power (pnl_pow_tab, pnl_common.h), one per (exponent, scale) seen by this context
     struct PowTab { double exponent, scale; DevBuf buf; };
     std::vector<PowTab*> powtabs;
-    struct BlockAgg { double cx, cy, rad, hmax, hmin, Lmin, Lmax; bool full; };
+    // tcx / tcy / trad: centre and radius (cell centres + vertex reach) in the coordinates of the interaction transform
+    struct BlockAgg { double cx, cy, rad, hmax, hmin, Lmin, Lmax; bool full; double tcx, tcy, trad; };
+    // linear transform of the interaction set (ellipse domains, interactionDomains.pyx:1393-1630): the kernel sees |T (x - y)|
+    bool have_xform = false;
+    double xform[4] = {1., 0., 0., 1.};
     std::vector<BlockAgg> blocks;
     hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     hipEvent_t kev[PNL_NUM_KERNEL_SLOTS][2] = {};   // event pair around every tile-kernel launch (pnl_get_kernel_ms)

@@ -88,7 +88,12 @@ int finalize(pnl_context *ctx) {
             if (!dummy[c]) cvid[(size_t)k*ncp+c] = v;
             for (int d = 0; d < dim; d++) {
                 const double x = ctx->vertices[(size_t)v*dim+d];
-                cellv[(size_t)(k*dim+d)*ncp+c] = x;
+                // the quadrature points and the cut-element geometry live in the coordinates of the interaction transform (all
+                // they enter is differences x - y: |T (x - y)|, interactionDomains.pyx:1417-1470); centres, h and volumes -- the order
+                // formula and the measure -- stay those of the mesh
+                double xt = x;
+                if (ctx->have_xform && dim == 2) xt = ctx->xform[2*d]*ctx->vertices[(size_t)v*dim]+ctx->xform[2*d+1]*ctx->vertices[(size_t)v*dim+1];
+                cellv[(size_t)(k*dim+d)*ncp+c] = xt;
                 cen[d] += x;
             }
         }
@@ -296,7 +301,7 @@ int finalize(pnl_context *ctx) {
         for (int c = 0; c < ncp; c++) { clog[c] = std::log(ch[c]); clog[(size_t)ncp+c] = std::fabs(std::log(ch[c]/ctx->H0)); }
         if ((rc = upload(ctx, ctx->b_clog, clog.data(), clog.size()))) return rc;
         // per-block aggregates for the host-side tile classification (uniform tiles)
-        ctx->blocks.assign(nblocks, pnl_context::BlockAgg{0., 0., 0., 0., 0., 0., 0., false});
+        ctx->blocks.assign(nblocks, pnl_context::BlockAgg{0., 0., 0., 0., 0., 0., 0., false, 0., 0., 0.});
         for (int b = 0; b < nblocks; b++) {
             auto &B = ctx->blocks[b];
             const int c0 = b*T, c1 = std::min(nc, (b+1)*T);
@@ -312,6 +317,18 @@ int finalize(pnl_context *ctx) {
                 B.hmin = std::min(B.hmin, ch[c]);
                 B.Lmin = std::min(B.Lmin, clog[(size_t)ncp+c]);
                 B.Lmax = std::max(B.Lmax, clog[(size_t)ncp+c]);
+            }
+            // the same ball around the block in the coordinates of the interaction transform, vertices included
+            B.tcx = B.cx; B.tcy = B.cy; B.trad = B.rad+B.hmax;
+            if (ctx->have_xform && dim == 2) {
+                double tx = 0., ty = 0.;
+                int nvb = 0;
+                for (int c = c0; c < c1; c++) for (int k = 0; k < nV; k++) { tx += cellv[(size_t)(k*dim)*ncp+c]; ty += cellv[(size_t)(k*dim+1)*ncp+c]; nvb++; }
+                B.tcx = tx/nvb; B.tcy = ty/nvb; B.trad = 0.;
+                for (int c = c0; c < c1; c++) for (int k = 0; k < nV; k++) {
+                    const double dx = cellv[(size_t)(k*dim)*ncp+c]-B.tcx, dy = cellv[(size_t)(k*dim+1)*ncp+c]-B.tcy;
+                    B.trad = std::max(B.trad, std::sqrt(dx*dx+dy*dy));
+                }
             }
         }
         ctx->tiles_cached.clear(); ctx->tiles_cb = -1;
@@ -1588,9 +1605,9 @@ int horizon_impl(pnl_context *ctx, SparseOut S) {
     for (int a = 0; a < nbk; a++)
         for (int b = a; b < nbk; b++) {
             const auto &A = ctx->blocks[a], &B = ctx->blocks[b];
-            const double dx = A.cx-B.cx, dy = A.cy-B.cy;
-            // vertices lie within h of their cell's centre
-            if (std::sqrt(dx*dx+dy*dy)-A.rad-B.rad-A.hmax-B.hmax <= delta) tiles.push_back(make_int2(a, b));
+            const double dx = A.tcx-B.tcx, dy = A.tcy-B.tcy;
+            // every vertex of a block lies within trad of (tcx, tcy) (vertices within h of their cell's centre)
+            if (std::sqrt(dx*dx+dy*dy)-A.trad-B.trad <= delta) tiles.push_back(make_int2(a, b));
         }
     if ((rc = upload(ctx, ctx->b_tiles, tiles.data(), tiles.size()))) return rc;
     ctx->tiles_cached.clear(); ctx->tiles_cb = -1;            // b_tiles no longer holds the dense tile list
@@ -1816,6 +1833,16 @@ int pnl_upload_mesh(pnl_context *ctx, int dim, int nv, const double *vertices, i
     ctx->h.assign(h, h+nc);
     ctx->cell_orig.clear();
     ctx->have_mesh = true;
+    ctx->dirty = true;
+    return PNL_OK;
+}
+
+int pnl_set_interaction_transform(pnl_context *ctx, int dim, const double *T) {
+    if (!ctx) return PNL_ERR_INVALID;
+    if (T && dim != 2) return fail(ctx, PNL_ERR_UNSUPPORTED, "interaction transform: 2D only");
+    ctx->have_xform = T != nullptr;
+    for (int i = 0; i < 4; i++) ctx->xform[i] = T ? T[i] : (i == 0 || i == 3 ? 1. : 0.);
+    if (T && !(std::fabs(T[0]*T[3]-T[1]*T[2]) > 0.)) return fail(ctx, PNL_ERR_INVALID, "interaction transform is singular");
     ctx->dirty = true;
     return PNL_OK;
 }

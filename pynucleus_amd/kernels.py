@@ -392,6 +392,36 @@ def _getHorizon(horizon):
     return constant(float(horizon))
 
 
+class ellipse_retriangulation(ball2_retriangulation):
+    """interactionDomains.pyx:1579-1604 (constant a, b, theta): {y: |T (y - x)| <= horizon}, T = [[cos t / a, -sin t / a],
+    [sin t / b, cos t / b]] -- the ellipse with semi-axes a horizon, b horizon turned by theta; one of a, b must be 1.  The kernel
+    is evaluated at the transformed distance |T (x - y)| (linearTransformInteraction.evalPtr :1417-1423)."""
+
+    def __init__(self, horizon, a, b, theta=0.):
+        a, b, theta = float(getattr(a, 'value', a)), float(getattr(b, 'value', b)), float(getattr(theta, 'value', theta))
+        assert a == 1. or b == 1., 'One of the two axes must be equal to 1.'
+        super().__init__(horizon)
+        self.a, self.b, self.theta = a, b, theta
+        self.transform = np.array([[np.cos(theta)/a, -np.sin(theta)/a], [np.sin(theta)/b, np.cos(theta)/b]])
+
+    def __repr__(self):
+        return 'ellipse({}, {}, {}; {})'.format(self.a, self.b, self.theta, self.horizon)
+
+
+class ellipse_barycenter(ball2_barycenter):
+    """interactionDomains.pyx:1606-1630: the same set, cut elements decided by their barycentre"""
+
+    def __init__(self, horizon, a, b, theta=0.):
+        a, b, theta = float(getattr(a, 'value', a)), float(getattr(b, 'value', b)), float(getattr(theta, 'value', theta))
+        assert a == 1. or b == 1., 'One of the two axes must be equal to 1.'
+        super().__init__(horizon)
+        self.a, self.b, self.theta = a, b, theta
+        self.transform = np.array([[np.cos(theta)/a, -np.sin(theta)/a], [np.sin(theta)/b, np.cos(theta)/b]])
+
+    def __repr__(self):
+        return 'ellipse_barycenter({}, {}, {}; {})'.format(self.a, self.b, self.theta, self.horizon)
+
+
 def _getInteraction(interaction, horizon):
     if isinstance(interaction, interactionDomain):
         return interaction
@@ -401,6 +431,11 @@ def _getInteraction(interaction, horizon):
         return ball2_retriangulation(horizon.value)
     if interaction == 'ball2_barycenter':
         return ball2_barycenter(horizon.value)
+    if isinstance(interaction, str) and interaction.startswith('ellipse'):
+        # the drivers' "ellipse(a,b,theta)" / "ellipse_barycenter(a,b,theta)" (nonlocalProblems.py interaction argument)
+        name, args = interaction.split('(', 1)
+        a, b, theta = [float(v) for v in args.rstrip(')').split(',')]
+        return (ellipse_barycenter if 'barycenter' in name else ellipse_retriangulation)(horizon.value, a, b, theta)
     raise NotImplementedError('Interaction: {}'.format(interaction))
 
 

@@ -133,10 +133,23 @@ def _gpu_sparse(N, delta, kernel, interaction=None, s=None, element='P1', params
 
 @pytest.mark.gpu
 @pytest.mark.parametrize('case', ['indicator', 'peridynamic', 'barycenter', 'fractional', 'P2', 'interval', 'chunked_csr', 'host_pairs',
-                                  'gaussian', 'gaussian_interval', 'exponential_interval', 'gaussian_P2'])
+                                  'gaussian', 'gaussian_interval', 'exponential_interval', 'gaussian_P2',
+                                  'ellipse', 'ellipse_rotated_fractional', 'ellipse_barycenter', 'ellipse_P2', 'ellipse_host_pairs'])
 def test_gpu_getSparse_vs_oracle(case):
     from oracle.oracle import OracleProblem
-    if case == 'gaussian':                                 # kernelsCy.pyx:388-416: C exp(-|x-y|^2 / (delta/3)^2) inside the horizon
+    from pynucleus_amd import ellipse_retriangulation, ellipse_barycenter
+    # ellipse domains (interactionDomains.pyx:1393-1630): the l2 ball in the coordinates T x; the kernel sees |T (x - y)|
+    if case == 'ellipse':
+        b = _gpu_sparse(17, 0.2, 'indicator', ellipse_retriangulation(0.2, 0.5, 1.0, 0.))
+    elif case == 'ellipse_rotated_fractional':
+        b = _gpu_sparse(9, 0.45, 'fractional', ellipse_retriangulation(0.45, 1.0, 0.6, 0.4), s=0.4)
+    elif case == 'ellipse_barycenter':
+        b = _gpu_sparse(17, 0.2, 'indicator', ellipse_barycenter(0.2, 1.0, 0.5, 0.3))
+    elif case == 'ellipse_P2':
+        b = _gpu_sparse(9, 0.3, 'peridynamic', ellipse_retriangulation(0.3, 0.7, 1.0, 1.1), element='P2')
+    elif case == 'ellipse_host_pairs':
+        b = _gpu_sparse(17, 0.2, 'indicator', ellipse_retriangulation(0.2, 1.0, 0.5, 0.7), params={'pairList': 'host'})
+    elif case == 'gaussian':                                 # kernelsCy.pyx:388-416: C exp(-|x-y|^2 / (delta/3)^2) inside the horizon
         b = _gpu_sparse(17, 0.2, 'gaussian')
     elif case == 'gaussian_interval':
         b = _gpu_sparse(6, 0.11, 'gaussian', domain='interval')
@@ -265,3 +278,32 @@ def test_gpu_square_poly_dirichlet_anchor():
     l2 = np.sqrt(np.sum(mass*(u-g[inner])**2))
     assert 1e-3 < linf < 3e-2, linf                          # reference: 0.0101
     assert 1e-3 < l2 < 3.6e-2, l2                            # reference: 0.0120
+
+
+def test_ellipse_domain_known_answer():
+    """Ellipse interaction domains (interactionDomains.pyx:1579-1630): with the normalised constant kernel the operator acts on
+    u = x^T H x / 2 as -tr(H M), M = T^-1 T^-T / |det T| the second moments of the set {z: |T z| <= delta} scaled by the constant
+    of the l2 ball (kernelNormalization.pyx:237-239 uses the ball's constant for the ellipses) -- anisotropic diffusion
+    -a b (a^2 u_xx + b^2 u_yy) for theta = 0.  The oracle reproduces it to the accuracy the l2 ball itself reaches on this mesh
+    (the caps the retriangulation leaves out, interactionDomains.pyx:664)."""
+    from pynucleus_amd import uniformSquare, P1_DoFMap, NO_BOUNDARY, getKernel, INDICATOR, ellipse_retriangulation
+    from pynucleus_amd.local_matrix import nonlocalTables
+    from oracle.oracle import OracleProblem
+    mesh = uniformSquare(33)
+    dm = P1_DoFMap(mesh, NO_BOUNDARY)
+    delta = 0.2
+    dofs, cells = np.asarray(dm.dofs), np.asarray(mesh.cells)
+    c = np.zeros((dm.num_dofs, 2))
+    c[dofs.ravel()] = mesh.vertices[cells.ravel()]
+    rhs = np.asarray(dm.assembleRHS(1.0))
+    inner = np.abs(c-0.5).max(axis=1) < 0.5-delta-0.05
+    for a, b, th in ((0.5, 1.0, 0.), (1.0, 0.6, 0.4)):
+        k = getKernel(2, kernel=INDICATOR, horizon=delta, interaction=ellipse_retriangulation(delta, a, b, th))
+        A = OracleProblem(nonlocalTables(dm, k, {}, False)).get_dense()[0]
+        T = k.interaction.transform
+        M = np.linalg.inv(T)@np.linalg.inv(T).T/abs(np.linalg.det(T))
+        for u, H in ((c[:, 0]**2, np.diag([2., 0.])), (c[:, 1]**2, np.diag([0., 2.])), (c[:, 0]*c[:, 1], np.array([[0., 1.], [1., 0.]]))):
+            r = ((A@u)/rhs)[inner]
+            assert abs(r.mean()+np.trace(H@M)) <= 0.015*max(np.abs(M).max(), 1e-300)*2., (a, b, th, r.mean(), -np.trace(H@M))
+        if th == 0.:
+            assert abs(((A@(c[:, 0]**2))/rhs)[inner].mean()+2.*a*b*a*a) < 0.01 and abs(((A@(c[:, 1]**2))/rhs)[inner].mean()+2.*a*b*b*b) < 0.02

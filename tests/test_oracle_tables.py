@@ -61,6 +61,10 @@ def same_tables(P, O, what):
     assert (P.dim, P.dpe, P.qcap) == (O.dim, O.dpe, O.qcap)
     assert P.H0 == pytest.approx(O.H0, rel=TOL)
     assert bool(P.zeroExterior) == bool(O.zeroExterior)
+    pt = getattr(P.kernel.interaction, 'transform', None) if hasattr(P.kernel, 'interaction') else None
+    assert (pt is None) == (O.interaction_transform is None)
+    if pt is not None:
+        close(pt, O.interaction_transform, what+' interaction transform')
     assert np.array_equal(P.dof_perm_table, O.dof_perm_table), what
     close(P.dist_phi, O.dist_phi, what+' shape functions at the distant rules')
     assert np.array_equal(P.bfacet_off, O.bfacet_off)
@@ -101,6 +105,7 @@ CASES = {
     'square_gaussian': (lambda: P1_DoFMap(uniformSquare(9), NO_BOUNDARY), lambda: getKernel(2, kernel='gaussian', horizon=0.3), {}, False),
     'interval_gaussian': (lambda: P2_DoFMap(interval(5, 0., 1.), NO_BOUNDARY), lambda: getKernel(1, kernel='gaussian', horizon=0.2), {}, False),
     'interval_exponential': (lambda: P1_DoFMap(interval(5, 0., 1.), NO_BOUNDARY), lambda: getKernel(1, kernel='exponential', horizon=0.2, exponentialRate=12.), {}, False),
+    'square_ellipse': (lambda: P1_DoFMap(uniformSquare(9), NO_BOUNDARY), lambda: getKernel(2, kernel=INDICATOR, horizon=0.3, interaction='ellipse(0.5,1.0,0.2)'), {}, False),
     'interval_constant_delta': (lambda: P1_DoFMap(interval(5, 0., 1.), NO_BOUNDARY), lambda: getKernel(1, kernel=INDICATOR, horizon=0.2), {}, False),
     'interval_truncated_fractional': (lambda: P1_DoFMap(interval(5, 0., 1.), NO_BOUNDARY), lambda: getFractionalKernel(1, 0.3, horizon=0.2), {}, False),
     'interval_varconst': (lambda: P1_DoFMap(interval(5), PHYSICAL), lambda: getFractionalKernel(1, variableConstFractionalOrder(0.75)), {}, True),
