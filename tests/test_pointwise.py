@@ -122,12 +122,27 @@ def test_nonsym_structure(dim, noRef):
 
 
 def test_host_tables_reject_what_is_not_built():
-    from pynucleus_amd import P2_DoFMap
-    mesh = disc(1)
-    with pytest.raises(NotImplementedError):
-        nonlocalTables(P2_DoFMap(mesh, PHYSICAL), getFractionalKernel(2, constantNonSymFractionalOrder(0.4)), {})
     with pytest.raises(NotImplementedError):
         getFractionalKernel(2, constantNonSymFractionalOrder(0.4), horizon=0.5)
+
+
+def test_pointwise_p2_oracle():
+    """P2 elements for the kernels with an order per quadrature point (round 3; FL2:894-1184 / FL1:410-604 are element-agnostic):
+    with a constant order the non-symmetric P2 operator is the symmetric one -- exactly in 1D (every rule is Gauss-Jacobi), up to
+    the dropped target_order / quad_order_diagonal of the _nonsym constructors in 2D"""
+    from pynucleus_amd import P2_DoFMap
+    s = 0.4
+    dm = P2_DoFMap(interval(4), PHYSICAL)
+    T = nonlocalTables(dm, getFractionalKernel(1, constantNonSymFractionalOrder(s)), {})
+    A = OracleProblem(T).get_dense()[0]
+    A0 = OracleProblem(nonlocalTables(dm, getFractionalKernel(1, s), {'target_order': T.target_order})).get_dense()[0]
+    assert np.abs(A-A0).max() <= 1e-13*np.abs(A0).max()
+    dm = P2_DoFMap(disc(1), PHYSICAL)
+    T = nonlocalTables(dm, getFractionalKernel(2, constantNonSymFractionalOrder(s)), {})
+    A, cnt, _ = OracleProblem(T).get_dense()
+    A0, c0, _ = OracleProblem(nonlocalTables(dm, getFractionalKernel(2, s), {'target_order': T.target_order})).get_dense()
+    assert cnt['numAssembledCellPairs'] == c0['numAssembledCellPairs'] and np.abs(A-A0).max() <= 1e-4*np.abs(A0).max()
+    assert np.abs(A-A.T).max() <= 1e-6*np.abs(A).max()
 
 
 def test_piecewise_nonsymmetric_order_oracle():
