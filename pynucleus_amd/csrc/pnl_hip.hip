@@ -382,7 +382,10 @@ int finalize(pnl_context *ctx) {
         if ((rc = upload(ctx, ctx->b_foldtab, tab.data(), tab.size()))) return rc;
     }
     if ((rc = upload(ctx, ctx->b_perm, ctx->perm_table.data(), ctx->perm_table.size()))) return rc;
+    const bool fresh_counters = !ctx->b_counters.p;
     if ((rc = ensure(ctx, ctx->b_counters, sizeof(unsigned long long)*PNL_NCOUNTERS))) return rc;
+    // pnl_synchronize reads the loss counters of a context that may never assemble (an operator installed by pnl_h2_set)
+    if (fresh_counters) HIPCHK(ctx, hipMemset(ctx->b_counters.p, 0, sizeof(unsigned long long)*PNL_NCOUNTERS));
     if ((rc = ensure(ctx, ctx->b_D, sizeof(double)*(size_t)ncp*(dpe*(dpe+1)/2)))) return rc;
 
     DevProblem &P = ctx->P;
@@ -493,7 +496,7 @@ int launch_pure(pnl_context *ctx, double *A, int64_t ldA, const SlotOut &SO) {
 struct ClassFork {
     pnl_context *ctx;
     hipStream_t main;
-    bool on, used[pnl_context::NAUX] = {false, false, false, false};
+    bool on, used[pnl_context::NAUX] = {};
     hipEvent_t start;
     // from: an event recorded earlier on the caller's stream (the fold pass) -- the side streams start there instead of behind
     // everything the caller's stream holds, so consecutive forked phases run back to back on every side stream
@@ -501,9 +504,25 @@ struct ClassFork {
         : ctx(c), main(c->stream), on(nclasses > 1 && !pnl_tune("PNL_NO_FORK")), start(from ? from : c->ev_fork) {
         if (on && !from) (void)hipEventRecord(ctx->ev_fork, main);
     }
+    // classes of very different weight (three layers: the pairs inside a layer against the few across an interface): heaviest first
+    // onto the least loaded stream, so that two heavy classes do not queue behind each other while a stream of light ones runs dry
+    std::vector<int> slot;
+    void plan(const std::vector<int> &weight) {
+        const int n = (int)weight.size();
+        std::vector<int> order(n);
+        for (int k = 0; k < n; k++) order[k] = k;
+        std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return weight[a] > weight[b]; });
+        long long load[pnl_context::NAUX] = {};
+        slot.assign(n, 0);
+        for (int k : order) {
+            int best = 0;
+            for (int j = 1; j < pnl_context::NAUX; j++) if (load[j] < load[best]) best = j;
+            slot[k] = best; load[best] += std::max(1, weight[k]);
+        }
+    }
     void use(int k) {
         if (!on) return;
-        const int j = k % pnl_context::NAUX;
+        const int j = k < (int)slot.size() ? slot[k] : k % pnl_context::NAUX;
         if (!used[j]) { (void)hipStreamWaitEvent(ctx->aux[j], start, 0); used[j] = true; }
         ctx->stream = ctx->aux[j];
     }
@@ -520,6 +539,27 @@ struct ClassFork {
     }
     ~ClassFork() { join(); }
 };
+
+// dynamic LDS of the work-list kernels: the rule copy (+ for P2 the column sums of the PNL_NTHREADS / 16 pairs of a chunk) of
+// k_worklist_sorted; for P2 the per-lane column sums of k_worklist_lane (eval_distant_blocked)
+template <int DPE>
+static int wl_tab_max(int wl_kb) {
+    // points of the largest rule that is staged; larger rules are read from global memory, point pair by point pair (slow: at 49,152
+    // P2 cells of the 12-sector disc, s = 0.7, 100,000 near pairs take the rules of 240 and 256 points -- 6e9 of the 13e9 kernel values
+    // of the work lists).  P2 (one workgroup per CU for its registers anyway): 320 ... 512 points, 80 + 128 bytes of LDS per point.
+    const int t = (wl_kb*1024)/((4+DPE)*(int)sizeof(double));
+    return wl_csum_lds(DPE) ? std::max(320, std::min(t, 512)) : t;
+}
+template <int DPE>
+static size_t wl_sorted_lds(int tab_max) {
+    return sizeof(double)*((size_t)tab_max*(4+DPE)+(wl_csum_lds(DPE) ? (size_t)(PNL_NTHREADS/16)*tab_max : 0));
+}
+template <typename F>
+static size_t wl_lane_lds(F fun, int dpe, int kt) {
+    const size_t b = wl_lane_blocked(dpe, kt) ? sizeof(double)*PNL_WL_LANE_MAXPTS*PNL_NTHREADS : 0;
+    if (b) (void)hipFuncSetAttribute((const void*)fun, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b);
+    return b;
+}
 
 // counting sort of a work-list region by order, then the sorted evaluation (k_worklist_lane / k_worklist_sorted);
 // region: which copy of the sort buffers to use (passes that may run concurrently need their own)
@@ -540,9 +580,9 @@ int run_worklist(pnl_context *ctx, const int4 *wl, const unsigned *wlc, unsigned
     const int st = 4+DPE;
     // LDS copy of the rule: 18 KB (8 workgroups per CU; rules with more points are read from global memory; 60 KB / 2 workgroups per CU was 0.6 ms slower at 98,304 cells)
     const int wl_kb = pnl_tune("PNL_WL_LDS_KB") ? std::max(4, atoi(pnl_tune("PNL_WL_LDS_KB"))) : 18;
-    const int tab_max = (wl_kb*1024)/(st*(int)sizeof(double));
+    const int tab_max = wl_tab_max<DPE>(wl_kb);
     const int wl_grid = 256*std::max(1, std::min(8, 150/(wl_kb+(KT == 0 ? 3 : 0))));      // KT == 0: + 3 KB of power tables
-    const size_t lds = (size_t)tab_max*st*sizeof(double);
+    const size_t lds = wl_sorted_lds<DPE>(tab_max);
     auto wfun = k_worklist_sorted<DIM, DPE, KT, false>;
     HIPCHK(ctx, hipFuncSetAttribute((const void*)wfun, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int nmin = ctx->wl_lane ? PNL_WL_LANE_MAXPTS+1 : 0;
@@ -551,7 +591,7 @@ int run_worklist(pnl_context *ctx, const int4 *wl, const unsigned *wlc, unsigned
     dbg = pnl_tune("PNL_WL_DBG") ? atoi(pnl_tune("PNL_WL_DBG")) : 0;
 #endif
     if (ctx->wl_lane)
-        hipLaunchKernelGGL((k_worklist_lane<DIM, DPE, KT, false>), dim3(256*4), dim3(PNL_NTHREADS), 0, ctx->stream, ctx->P,
+        hipLaunchKernelGGL((k_worklist_lane<DIM, DPE, KT, false>), dim3(256*4), dim3(PNL_NTHREADS), wl_lane_lds(k_worklist_lane<DIM, DPE, KT, false>, DPE, KT), ctx->stream, ctx->P,
                            (const int4*)wlsorted, (const unsigned*)offs, A, (long long)ldA, (double*)ctx->b_D.p, SparseOut{},
                            dbg | (sym ? 8 : 0), ClusterTiles{});
     hipLaunchKernelGGL(wfun, dim3(wl_grid), dim3(PNL_NTHREADS), lds, ctx->stream, ctx->P, (const int4*)wlsorted,
@@ -812,6 +852,7 @@ int launch_tiles_single(pnl_context *ctx, double *A, int64_t ldA, int cell_begin
     const bool sym = ctx->symflush || ctx->slot_used;
     {
         ClassFork fork(ctx, ncls);
+        if (ncls > pnl_context::NAUX && (int)ctx->cls_n_mixed.size() == ncls) fork.plan(ctx->cls_n_mixed);     // the work lists come from the mixed tiles
         for (int k = 0; k < ncls; k++) {
             ctx->cur = k;
             refresh_tables(ctx);
@@ -927,6 +968,7 @@ int assemble_impl(pnl_context *ctx, double *A, int64_t ldA, int zero_exterior, i
     hipEvent_t const chain = (ctx->fold_event_set && !overlap && !pnl_tune("PNL_NO_OVERLAP")) ? ctx->ev_fold : nullptr;
     {
         ClassFork fork(ctx, ncls*norient, chain);
+        if (norient == 1 && ncls > pnl_context::NAUX && (int)ctx->cls_n_mixed.size() == ncls) fork.plan(ctx->cls_n_mixed);    // as the work lists
         for (int ko = 0; ko < ncls*norient; ko++) {
             ctx->cur = ko/norient; ctx->orient = ko%norient;
             refresh_tables(ctx);
@@ -948,6 +990,7 @@ int assemble_impl(pnl_context *ctx, double *A, int64_t ldA, int zero_exterior, i
         const bool one_pass = bnd_one_pass;
         const bool all_fast = bnd_all_fast;
         ClassFork fork(ctx, ncls, chain);
+        if (ncls > pnl_context::NAUX && (int)ctx->cls_n_mixed.size() == ncls) fork.plan(ctx->cls_n_mixed);
         for (int k = 0; k < ncls; k++) {
             ctx->cur = k;
             refresh_tables(ctx);
@@ -1038,9 +1081,9 @@ int pairs_masked_impl(pnl_context *ctx, int np, const SparseOut &S, bool classif
         const int st = 4+DPE;
         // LDS copy of the rule: see run_worklist (PNL_WL_MP_KB: A/B switch of the sparse path)
         const int wl_kb = pnl_tune("PNL_WL_MP_KB") ? std::max(4, atoi(pnl_tune("PNL_WL_MP_KB"))) : 60;
-        const int tab_max = (wl_kb*1024)/(st*(int)sizeof(double));
+        const int tab_max = wl_tab_max<DPE>(wl_kb);
         const int wl_grid = 256*std::max(1, std::min(8, 150/(wl_kb+(KT == 0 ? 3 : 0))));
-        const size_t lds = (size_t)tab_max*st*sizeof(double);
+        const size_t lds = wl_sorted_lds<DPE>(tab_max);
         auto wfun = k_worklist_sorted<DIM, DPE, KT, true>;
         HIPCHK(ctx, hipFuncSetAttribute((const void*)wfun, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         const int nmin = ctx->wl_lane ? PNL_WL_LANE_MAXPTS+1 : 0;
@@ -1049,7 +1092,7 @@ int pairs_masked_impl(pnl_context *ctx, int np, const SparseOut &S, bool classif
         double *Dbuf = S.masks ? nullptr : (double*)ctx->b_D.p;
         if (Dbuf && !keepD) HIPCHK(ctx, hipMemsetAsync(Dbuf, 0, sizeof(double)*(size_t)ctx->ncp*ND, ctx->stream));      // keepD: the tiles of a finite horizon have been there
         if (ctx->wl_lane)
-            hipLaunchKernelGGL((k_worklist_lane<DIM, DPE, KT, true>), dim3(256*4), dim3(PNL_NTHREADS), 0, ctx->stream, ctx->P,
+            hipLaunchKernelGGL((k_worklist_lane<DIM, DPE, KT, true>), dim3(256*4), dim3(PNL_NTHREADS), wl_lane_lds(k_worklist_lane<DIM, DPE, KT, true>, DPE, KT), ctx->stream, ctx->P,
                                (const int4*)sorted, (const unsigned*)offs, (double*)nullptr, 0ll, Dbuf, S, 0, ClusterTiles{});
         hipLaunchKernelGGL(wfun, dim3(wl_grid), dim3(PNL_NTHREADS), lds, ctx->stream, ctx->P, (const int4*)sorted, (const unsigned*)offs,
                            (const unsigned*)coff, (double*)nullptr, 0ll, Dbuf, tab_max, S, PNL_MAXQ, nmin, ClusterTiles{});
@@ -1168,12 +1211,12 @@ int clusters_tiled_impl(pnl_context *ctx, const pnl_cluster_plan *pl, ClusterTil
         const int st = 4+DPE;
         // LDS copy of the rule: see run_worklist (PNL_WL_CL_KB: A/B switch of the cluster path)
         const int wl_kb = pnl_tune("PNL_WL_CL_KB") ? std::max(4, atoi(pnl_tune("PNL_WL_CL_KB"))) : 18;      // 60 KB / two workgroups per CU: + 4 ms at C4
-        const int tab_max = (wl_kb*1024)/(st*(int)sizeof(double));
-        const size_t wlds = (size_t)tab_max*st*sizeof(double);
+        const int tab_max = wl_tab_max<DPE>(wl_kb);
+        const size_t wlds = wl_sorted_lds<DPE>(tab_max);
         const int wl_grid = 256*std::max(1, std::min(8, 150/(wl_kb+(KT == 0 ? 3 : 0))));
         auto wfun = k_worklist_sorted<DIM, DPE, KT, false>;
         HIPCHK(ctx, hipFuncSetAttribute((const void*)wfun, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wlds));
-        hipLaunchKernelGGL((k_worklist_lane<DIM, DPE, KT, false>), dim3(256*4), dim3(PNL_NTHREADS), 0, ctx->stream, ctx->P,
+        hipLaunchKernelGGL((k_worklist_lane<DIM, DPE, KT, false>), dim3(256*4), dim3(PNL_NTHREADS), wl_lane_lds(k_worklist_lane<DIM, DPE, KT, false>, DPE, KT), ctx->stream, ctx->P,
                            (const int4*)ctx->b_wlsorted.p, (const unsigned*)offs, (double*)nullptr, 0ll, (double*)nullptr, SparseOut{}, 0, CT);
         hipLaunchKernelGGL(wfun, dim3(wl_grid), dim3(PNL_NTHREADS), wlds, ctx->stream, ctx->P, (const int4*)ctx->b_wlsorted.p,
                            (const unsigned*)offs, (const unsigned*)coff, (double*)nullptr, 0ll, (double*)nullptr, tab_max, SparseOut{},
