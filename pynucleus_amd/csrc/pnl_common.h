@@ -139,8 +139,12 @@ __device__ __forceinline__ double pnl_pow_tab(double x, const DevKernel &k, cons
 // KT: 0 general (pow / indicator / peridynamic, horizon test), 1 fractional with exponent -qm/4, qm a run-time (wave-uniform)
 // value, 2 the same with qm == 6 known at compile time (s = 1/2 in 2D): no branch per evaluation, so the compiler
 // interleaves the dependent chains of the independent evaluations of a pair.
+// KT == 3 is not a kernel instantiation of its own: the KT == 0 kernels enter their hot loops with it when the kernel is fractional
+// with power tables in LDS and no horizon (kern_eval_pow_ok) -- the general branch below tests the horizon per lane and switches on
+// the kernel type per evaluation, which costs more than the branches: no two evaluations are ever scheduled together.
 template <int KT>
 __device__ __forceinline__ double kern_eval(const DevKernel &k, double d2, const double *__restrict__ ltab = nullptr) {
+    if (KT == 3) return pnl_pow_tab(d2, k, ltab);
     if (KT == 2) {
         // d2^(-3/2) = r^3 (1 - e)^(-3/2) with r = v_rsq_f64(d2) (~2^-23 relative), e = 1 - d2 r^2 (|e| < 3e-7):
         // r^3 (1 + e (3/2 + 15/8 e)), the next term 35/16 e^3 is below 1e-19; six operations after the rsq, chain depth five
@@ -189,7 +193,20 @@ __device__ __forceinline__ double kern_eval(const DevKernel &k, double d2, const
 }
 
 template <int KT>
-__device__ __forceinline__ double kern_scale(const DevKernel &k) { return KT >= 1 ? k.scale : 1.; }
+__device__ __forceinline__ double kern_scale(const DevKernel &k) { return (KT == 1 || KT == 2) ? k.scale : 1.; }
+// may a KT == 0 kernel run its hot loop with KT == 3 (wave-uniform)?
+__device__ __forceinline__ bool kern_eval_pow_ok(const DevKernel &k, const double *ltab) {
+    return ltab != nullptr && k.ktype == 0 && !(k.horizon2 < 1e300);
+}
+// hot(tag): a generic lambda whose body uses decltype(tag)::value as the KT of its kern_eval calls
+template <int KT> struct KTag { static constexpr int value = KT; };
+template <int KT, typename F>
+__device__ __forceinline__ void kern_dispatch(const DevKernel &k, const double *ltab, F &&hot) {
+    if constexpr (KT == 0) {
+        if (kern_eval_pow_ok(k, ltab)) { hot(KTag<3>{}); return; }
+    }
+    hot(KTag<KT>{});
+}
 
 // distant quadrature order  (FL2:622-642, :1226-1243, FL1:234-253, :646-660)
 __device__ __forceinline__ int quad_order(const DevFormula &F, double H0, double h1, double h2, double d) {
@@ -333,3 +350,210 @@ __device__ __forceinline__ double row16_sum(double v) {
     return v;
 }
 
+// ---- distant pairs, factorised accumulation (see pnl_kernels.h: eval_distant) ---------------------------------------------
+template <int DIM, int DPE>
+struct PairAcc {
+    static constexpr int ND = DPE*(DPE+1)/2;
+    double G[DPE][DPE];
+    double S1[ND], S2[ND];
+    __device__ __forceinline__ void clear() {
+#pragma unroll
+        for (int a = 0; a < DPE; a++)
+#pragma unroll
+            for (int b = 0; b < DPE; b++) G[a][b] = 0.;
+#pragma unroll
+        for (int e = 0; e < ND; e++) { S1[e] = 0.; S2[e] = 0.; }
+    }
+};
+
+// Blocked evaluation for a rule of run-time length (the work-list kernels).  eval_distant_lds above pays the DPE (DPE + 1) / 2
+// FMAs of S2 per point pair (21 for P2: as much as the kernel value itself); here the columns j are walked in blocks of PNL_WL_JB
+// whose column sums c_j = sum_i w_i g_ij stay in registers, the rows i = i_first, i_first + i_step, ... < n inside a block: per
+// point pair the kernel value, one FMA each for the row and the column sum and DPE - 1 for u_b (the shape functions sum to one:
+// u_{DPE-1} = r - sum_b u_b).  G and S1 are linear in the partial row sums of a block and take them once per (i, block), S2 takes
+// the column sums once per block.  The points are x_i - y_j = (a_0 - b_0) + sum_k lambda_k(i) (a_k - a_0) - sum_k lambda_k(j)
+// (b_k - b_0): four FMAs per point pair in 2D.  The columns are unrolled and guarded in groups of four by wave-uniform branches;
+// the caller pads the rule copy to n4 = a multiple of four points with ZERO-WEIGHT copies of point 0 (finite kernel values that
+// enter nothing).  Work per point pair for P2: 14 + kernel value + about 5 amortised, against 56 + kernel value.
+// POWTAB: fractional kernel with the LDS power tables and no horizon -- no branch per evaluation.
+#ifndef PNL_WL_JB
+#define PNL_WL_JB 16        // columns per block (column sums in registers)
+#endif
+#ifndef PNL_WL_JG
+#define PNL_WL_JG 4         // columns per guarded group (1, 2 or 4: the rule copy is padded to a multiple of four points)
+#endif
+// CM: where the column sums of a finished block go.  0: straight into S2 (the accumulators of S2 are live in the hot loop: fine for
+// P1).  P2 carries 78 accumulators per lane, more than the hot loop leaves room for in 256 VGPRs, and the register allocator then
+// serialises every LDS read of the loop behind a wait (measured: issue utilisation 0.14); so the column sums leave through LDS and
+// S2 is formed after the last block, when the registers of the hot loop are free: 1: sc[j * cstride] is private to the lane (one
+// pair per lane), 2: sc[j] is shared by the i_step lanes of the pair (ds_add_f64), which then split the columns among them.
+// ONEBLOCK: the caller guarantees n4 <= PNL_WL_JB (the rules a tile kernel integrates in its lanes): no loop over blocks, S2 comes
+// alive after the hot loop.
+template <int DIM, int DPE, int KT, bool POWTAB, int CM, bool ONEBLOCK = false, int JG = PNL_WL_JG>
+__device__ __forceinline__ void eval_distant_blocked(const DevKernel &kern, const double *__restrict__ tab, int stp, int n, int n4,
+                                                     int i_first, int i_step, const double *av, const double *bv,
+                                                     PairAcc<DIM, DPE> &R, const double *__restrict__ lpow, double *sc, int cstride) {
+    constexpr int JB = PNL_WL_JB;
+    if (CM == 2) {
+        for (int j = i_first; j < n4; j += i_step) sc[j] = 0.;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    double ea[DIM][DIM], eb[DIM][DIM], ab[DIM];
+#pragma unroll
+    for (int d = 0; d < DIM; d++) {
+        ab[d] = av[d]-bv[d];
+#pragma unroll
+        for (int k = 0; k < DIM; k++) { ea[k][d] = av[(k+1)*DIM+d]-av[d]; eb[k][d] = bv[(k+1)*DIM+d]-bv[d]; }
+    }
+#pragma unroll 1
+    for (int j0 = 0; j0 < (ONEBLOCK ? 1 : n4); j0 += JB) {
+        const double *__restrict__ tj0 = tab+j0*stp;
+        double c[JB];
+#pragma unroll
+        for (int jj = 0; jj < JB; jj++) c[jj] = 0.;
+#pragma unroll 1
+        for (int i = i_first; i < n; i += i_step) {
+            const double *__restrict__ ti = tab+i*stp;
+            double t0[DIM];
+#pragma unroll
+            for (int d = 0; d < DIM; d++) {
+                double sx = ab[d];
+#pragma unroll
+                for (int k = 0; k < DIM; k++) sx = __builtin_fma(ti[1+k], ea[k][d], sx);
+                t0[d] = sx;
+            }
+            const double wi = ti[3];
+            double r = 0., u[DPE];
+#pragma unroll
+            for (int b = 0; b < DPE; b++) u[b] = 0.;
+#pragma unroll
+            for (int jq = 0; jq < JB; jq += JG) {
+                if (j0+jq < n4) {
+                    // the JG columns of a group advance together, stage by stage (rule data, distances, table look-ups of the power,
+                    // series, accumulation): every wait for LDS covers JG independent reads.  The empty asm statements pin the loaded
+                    // values where they stand -- left alone, the scheduler sinks each read to its first use and waits for it there.
+                    double lam[JG][DIM], wj[JG], ph[JG][DPE > 1 ? DPE-1 : 1], d2[JG], g[JG];
+#pragma unroll
+                    for (int jj = 0; jj < JG; jj++) {
+                        const double *__restrict__ tj = tj0+(jq+jj)*stp;
+#pragma unroll
+                        for (int k = 0; k < DIM; k++) lam[jj][k] = tj[1+k];
+                        wj[jj] = tj[3];
+#pragma unroll
+                        for (int b = 0; b+1 < DPE; b++) ph[jj][b] = tj[4+b];
+                    }
+#pragma unroll
+                    for (int jj = 0; jj < JG; jj++) {
+#pragma unroll
+                        for (int k = 0; k < DIM; k++) asm volatile("" : "+v"(lam[jj][k]));
+                        asm volatile("" : "+v"(wj[jj]));
+#pragma unroll
+                        for (int b = 0; b+1 < DPE; b++) asm volatile("" : "+v"(ph[jj][b]));
+                    }
+#pragma unroll
+                    for (int jj = 0; jj < JG; jj++) {
+                        double dd = 0.;
+#pragma unroll
+                        for (int d = 0; d < DIM; d++) {
+                            double t = t0[d];
+#pragma unroll
+                            for (int k = 0; k < DIM; k++) t = __builtin_fma(-lam[jj][k], eb[k][d], t);
+                            dd = __builtin_fma(t, t, dd);
+                        }
+                        d2[jj] = dd;
+                    }
+                    if (POWTAB) {
+                        // pnl_pow_tab (pnl_common.h), its three look-ups issued for all columns before the first series
+                        double m[JG], T0[JG], T1[JG], T2[JG];
+#pragma unroll
+                        for (int jj = 0; jj < JG; jj++) {
+                            const int hi = __double2hiint(d2[jj]);
+                            const int j = (hi >> 13) & 127;
+                            const int kx = min(max(((hi >> 20) & 0x7ff)-(1023-96), 0), 127);
+                            m[jj] = __hiloint2double((hi & 0x000fffff) | 0x3ff00000, __double2loint(d2[jj]));
+                            T0[jj] = lpow[j]; T1[jj] = lpow[128+j]; T2[jj] = lpow[256+kx];
+                        }
+#pragma unroll
+                        for (int jj = 0; jj < JG; jj++) { asm volatile("" : "+v"(T0[jj])); asm volatile("" : "+v"(T1[jj])); asm volatile("" : "+v"(T2[jj])); }
+#pragma unroll
+                        for (int jj = 0; jj < JG; jj++) {
+                            const double uu = __builtin_fma(m[jj], T0[jj], -1.0);
+                            double p = kern.pb[5];
+                            p = __builtin_fma(p, uu, kern.pb[4]);
+                            p = __builtin_fma(p, uu, kern.pb[3]);
+                            p = __builtin_fma(p, uu, kern.pb[2]);
+                            p = __builtin_fma(p, uu, kern.pb[1]);
+                            p = __builtin_fma(p, uu, kern.pb[0]);
+                            p = __builtin_fma(p, uu, 1.0);
+                            g[jj] = (T1[jj]*T2[jj])*p;
+                        }
+                    } else {
+#pragma unroll
+                        for (int jj = 0; jj < JG; jj++) g[jj] = kern_eval<KT>(kern, d2[jj], lpow);
+                    }
+#pragma unroll
+                    for (int jj = 0; jj < JG; jj++) {
+                        c[jq+jj] = __builtin_fma(wi, g[jj], c[jq+jj]);
+                        const double gw = g[jj]*wj[jj];
+                        r += gw;
+#pragma unroll
+                        for (int b = 0; b+1 < DPE; b++) u[b] = __builtin_fma(gw, ph[jj][b], u[b]);
+                    }
+                }
+            }
+            u[DPE-1] = r;
+#pragma unroll
+            for (int b = 0; b+1 < DPE; b++) u[DPE-1] -= u[b];
+            int e = 0;
+#pragma unroll
+            for (int a = 0; a < DPE; a++) {
+                const double pa = wi*ti[4+a];
+#pragma unroll
+                for (int b = 0; b < DPE; b++) R.G[a][b] = __builtin_fma(pa, u[b], R.G[a][b]);
+                const double pr = pa*r;
+#pragma unroll
+                for (int b = a; b < DPE; b++) { R.S1[e] = __builtin_fma(pr, ti[4+b], R.S1[e]); e++; }
+            }
+        }
+#pragma unroll
+        for (int jq = 0; jq < JB; jq += JG) {
+            if (j0+jq < n4) {
+#pragma unroll
+                for (int jj = jq; jj < jq+JG; jj++) {
+                    if (CM == 1) sc[(j0+jj)*cstride] = c[jj];
+                    else if (CM == 2) atomic_add_f64(&sc[j0+jj], c[jj]);
+                    else {
+                        const double *__restrict__ tj = tj0+jj*stp;
+                        const double cw = tj[3]*c[jj];
+                        int e = 0;
+#pragma unroll
+                        for (int a = 0; a < DPE; a++) {
+                            const double pc = tj[4+a]*cw;
+#pragma unroll
+                            for (int b = a; b < DPE; b++) { R.S2[e] = __builtin_fma(pc, tj[4+b], R.S2[e]); e++; }
+                        }
+                    }
+                }
+            }
+        }
+    }
+    if (CM != 0) {
+        if (CM == 2) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+#pragma unroll 1
+        for (int j = (CM == 2 ? i_first : 0); j < n; j += (CM == 2 ? i_step : 1)) {
+            const double *__restrict__ tj = tab+j*stp;
+            const double cw = tj[3]*sc[j*(CM == 2 ? 1 : cstride)];
+            int e = 0;
+#pragma unroll
+            for (int a = 0; a < DPE; a++) {
+                const double pc = tj[4+a]*cw;
+#pragma unroll
+                for (int b = a; b < DPE; b++) { R.S2[e] = __builtin_fma(pc, tj[4+b], R.S2[e]); e++; }
+            }
+        }
+    }
+}

@@ -2006,16 +2006,18 @@ int pnl_upload_distant_rules(pnl_context *ctx, int qmax, const int32_t *off, con
         for (int q = 2; q <= qmax && q < 18; q++) {
             const int n = off[q+1]-off[q];
             const bool ok = (n == nA || n == nB || (n > 0 && n <= PNL_GEN_MAXPTS));
-            if (!ok || npts+n > PNL_TT_MAXPTS) continue;
+            const int npad = n;
+            if (!ok || npts+npad > PNL_TT_MAXPTS) continue;
             tn[q] = n; to[q] = npts;
-            for (int i = 0; i < n; i++) {
-                const size_t p = (size_t)off[q]+i;
-                tab.push_back(bary[3*p]); tab.push_back(bary[3*p+1]); tab.push_back(bary[3*p+2]); tab.push_back(w[p]);
+            for (int i = 0; i < npad; i++) {
+                const size_t p = (size_t)off[q]+(i < n ? i : 0);
+                const double wp = i < n ? w[p] : 0.;
+                tab.push_back(bary[3*p]); tab.push_back(bary[3*p+1]); tab.push_back(bary[3*p+2]); tab.push_back(wp);
                 for (int a = 0; a < dpe; a++) tab.push_back(phi[p*dpe+a]);
-                wphi.push_back(w[p]);
-                for (int a = 0; a+1 < dpe; a++) wphi.push_back(w[p]*phi[p*dpe+a]);
+                wphi.push_back(wp);
+                for (int a = 0; a+1 < dpe; a++) wphi.push_back(wp*phi[p*dpe+a]);
             }
-            npts += n; nb++;
+            npts += npad; nb++;
             (void)st;
         }
         if ((rc = upload(ctx, ctx->b_ttn, tn.data(), tn.size()))) return rc;
@@ -2027,9 +2029,10 @@ int pnl_upload_distant_rules(pnl_context *ctx, int qmax, const int32_t *off, con
         std::vector<double> wphif;
         for (int q = 2; q <= qmax && q < 18; q++)
             for (int i = 0; i < tn[q]; i++) {
-                const size_t p = (size_t)off[q]+i;
-                wphif.push_back(w[p]);
-                for (int a = 0; a < dpe; a++) wphif.push_back(w[p]*phi[p*dpe+a]);
+                const size_t p = (size_t)off[q]+(i < tn[q] ? i : 0);
+                const double wp = i < tn[q] ? w[p] : 0.;
+                wphif.push_back(wp);
+                for (int a = 0; a < dpe; a++) wphif.push_back(wp*phi[p*dpe+a]);
             }
         if ((rc = upload(ctx, ctx->b_ttwphif, wphif.data(), wphif.size()))) return rc;
         // rule blocks of the uniform-order tiles (2D, orders 2-4 with 3 or 6 points): bary[n][3], w[n], w phi[n][dpe],

@@ -25,20 +25,7 @@
 //   block22[a,b] =  sum_j phi_a(y_j) phi_b(y_j) (sum_i K_ij)
 //   block12[a,b] = -sum_i phi_a(x_i) sum_j K_ij phi_b(y_j)
 // which is what is accumulated here (same numbers, fewer flops).
-template <int DIM, int DPE>
-struct PairAcc {
-    static constexpr int ND = DPE*(DPE+1)/2;
-    double G[DPE][DPE];
-    double S1[ND], S2[ND];
-    __device__ __forceinline__ void clear() {
-#pragma unroll
-        for (int a = 0; a < DPE; a++)
-#pragma unroll
-            for (int b = 0; b < DPE; b++) G[a][b] = 0.;
-#pragma unroll
-        for (int e = 0; e < ND; e++) { S1[e] = 0.; S2[e] = 0.; }
-    }
-};
+// struct PairAcc: pnl_common.h
 
 // runtime number of points n; rule tables are read with wave-uniform indices (scalar loads)
 template <int DIM, int DPE, int KT>
@@ -231,204 +218,16 @@ __device__ __forceinline__ void eval_distant_lds(const DevProblem &P, const doub
     }
 }
 
-// Blocked evaluation for a rule of run-time length (the work-list kernels).  eval_distant_lds above pays the DPE (DPE + 1) / 2
-// FMAs of S2 per point pair (21 for P2: as much as the kernel value itself); here the columns j are walked in blocks of PNL_WL_JB
-// whose column sums c_j = sum_i w_i g_ij stay in registers, the rows i = i_first, i_first + i_step, ... < n inside a block: per
-// point pair the kernel value, one FMA each for the row and the column sum and DPE - 1 for u_b (the shape functions sum to one:
-// u_{DPE-1} = r - sum_b u_b).  G and S1 are linear in the partial row sums of a block and take them once per (i, block), S2 takes
-// the column sums once per block.  The points are x_i - y_j = (a_0 - b_0) + sum_k lambda_k(i) (a_k - a_0) - sum_k lambda_k(j)
-// (b_k - b_0): four FMAs per point pair in 2D.  The columns are unrolled and guarded in groups of four by wave-uniform branches;
-// the caller pads the rule copy to n4 = a multiple of four points with ZERO-WEIGHT copies of point 0 (finite kernel values that
-// enter nothing).  Work per point pair for P2: 14 + kernel value + about 5 amortised, against 56 + kernel value.
-// POWTAB: fractional kernel with the LDS power tables and no horizon -- no branch per evaluation.
-#ifndef PNL_WL_JB
-#define PNL_WL_JB 16        // columns per block (column sums in registers)
-#endif
-#ifndef PNL_WL_JG
-#define PNL_WL_JG 4         // columns per guarded group (1, 2 or 4: the rule copy is padded to a multiple of four points)
-#endif
-// CM: where the column sums of a finished block go.  0: straight into S2 (the accumulators of S2 are live in the hot loop: fine for
-// P1).  P2 carries 78 accumulators per lane, more than the hot loop leaves room for in 256 VGPRs, and the register allocator then
-// serialises every LDS read of the loop behind a wait (measured: issue utilisation 0.14); so the column sums leave through LDS and
-// S2 is formed after the last block, when the registers of the hot loop are free: 1: sc[j * cstride] is private to the lane (one
-// pair per lane), 2: sc[j] is shared by the i_step lanes of the pair (ds_add_f64), which then split the columns among them.
-template <int DIM, int DPE, int KT, bool POWTAB, int CM>
-__device__ __forceinline__ void eval_distant_blocked(const DevProblem &P, const double *__restrict__ tab, int stp, int n, int n4,
-                                                     int i_first, int i_step, const double *av, const double *bv,
-                                                     PairAcc<DIM, DPE> &R, const double *__restrict__ lpow, double *sc, int cstride) {
-    constexpr int JB = PNL_WL_JB, JG = PNL_WL_JG;
-    if (CM == 2) {
-        for (int j = i_first; j < n4; j += i_step) sc[j] = 0.;
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-    }
-    double ea[DIM][DIM], eb[DIM][DIM], ab[DIM];
-#pragma unroll
-    for (int d = 0; d < DIM; d++) {
-        ab[d] = av[d]-bv[d];
-#pragma unroll
-        for (int k = 0; k < DIM; k++) { ea[k][d] = av[(k+1)*DIM+d]-av[d]; eb[k][d] = bv[(k+1)*DIM+d]-bv[d]; }
-    }
-#pragma unroll 1
-    for (int j0 = 0; j0 < n4; j0 += JB) {
-        const double *__restrict__ tj0 = tab+j0*stp;
-        double c[JB];
-#pragma unroll
-        for (int jj = 0; jj < JB; jj++) c[jj] = 0.;
-#pragma unroll 1
-        for (int i = i_first; i < n; i += i_step) {
-            const double *__restrict__ ti = tab+i*stp;
-            double t0[DIM];
-#pragma unroll
-            for (int d = 0; d < DIM; d++) {
-                double sx = ab[d];
-#pragma unroll
-                for (int k = 0; k < DIM; k++) sx = __builtin_fma(ti[1+k], ea[k][d], sx);
-                t0[d] = sx;
-            }
-            const double wi = ti[3];
-            double r = 0., u[DPE];
-#pragma unroll
-            for (int b = 0; b < DPE; b++) u[b] = 0.;
-#pragma unroll
-            for (int jq = 0; jq < JB; jq += JG) {
-                if (j0+jq < n4) {
-                    // the JG columns of a group advance together, stage by stage (rule data, distances, table look-ups of the power,
-                    // series, accumulation): every wait for LDS covers JG independent reads.  The empty asm statements pin the loaded
-                    // values where they stand -- left alone, the scheduler sinks each read to its first use and waits for it there.
-                    double lam[JG][DIM], wj[JG], ph[JG][DPE > 1 ? DPE-1 : 1], d2[JG], g[JG];
-#pragma unroll
-                    for (int jj = 0; jj < JG; jj++) {
-                        const double *__restrict__ tj = tj0+(jq+jj)*stp;
-#pragma unroll
-                        for (int k = 0; k < DIM; k++) lam[jj][k] = tj[1+k];
-                        wj[jj] = tj[3];
-#pragma unroll
-                        for (int b = 0; b+1 < DPE; b++) ph[jj][b] = tj[4+b];
-                    }
-#pragma unroll
-                    for (int jj = 0; jj < JG; jj++) {
-#pragma unroll
-                        for (int k = 0; k < DIM; k++) asm volatile("" : "+v"(lam[jj][k]));
-                        asm volatile("" : "+v"(wj[jj]));
-#pragma unroll
-                        for (int b = 0; b+1 < DPE; b++) asm volatile("" : "+v"(ph[jj][b]));
-                    }
-#pragma unroll
-                    for (int jj = 0; jj < JG; jj++) {
-                        double dd = 0.;
-#pragma unroll
-                        for (int d = 0; d < DIM; d++) {
-                            double t = t0[d];
-#pragma unroll
-                            for (int k = 0; k < DIM; k++) t = __builtin_fma(-lam[jj][k], eb[k][d], t);
-                            dd = __builtin_fma(t, t, dd);
-                        }
-                        d2[jj] = dd;
-                    }
-                    if (POWTAB) {
-                        // pnl_pow_tab (pnl_common.h), its three look-ups issued for all columns before the first series
-                        double m[JG], T0[JG], T1[JG], T2[JG];
-#pragma unroll
-                        for (int jj = 0; jj < JG; jj++) {
-                            const int hi = __double2hiint(d2[jj]);
-                            const int j = (hi >> 13) & 127;
-                            const int kx = min(max(((hi >> 20) & 0x7ff)-(1023-96), 0), 127);
-                            m[jj] = __hiloint2double((hi & 0x000fffff) | 0x3ff00000, __double2loint(d2[jj]));
-                            T0[jj] = lpow[j]; T1[jj] = lpow[128+j]; T2[jj] = lpow[256+kx];
-                        }
-#pragma unroll
-                        for (int jj = 0; jj < JG; jj++) { asm volatile("" : "+v"(T0[jj])); asm volatile("" : "+v"(T1[jj])); asm volatile("" : "+v"(T2[jj])); }
-#pragma unroll
-                        for (int jj = 0; jj < JG; jj++) {
-                            const double uu = __builtin_fma(m[jj], T0[jj], -1.0);
-                            double p = P.k.pb[5];
-                            p = __builtin_fma(p, uu, P.k.pb[4]);
-                            p = __builtin_fma(p, uu, P.k.pb[3]);
-                            p = __builtin_fma(p, uu, P.k.pb[2]);
-                            p = __builtin_fma(p, uu, P.k.pb[1]);
-                            p = __builtin_fma(p, uu, P.k.pb[0]);
-                            p = __builtin_fma(p, uu, 1.0);
-                            g[jj] = (T1[jj]*T2[jj])*p;
-                        }
-                    } else {
-#pragma unroll
-                        for (int jj = 0; jj < JG; jj++) g[jj] = kern_eval<KT>(P.k, d2[jj], lpow);
-                    }
-#pragma unroll
-                    for (int jj = 0; jj < JG; jj++) {
-                        c[jq+jj] = __builtin_fma(wi, g[jj], c[jq+jj]);
-                        const double gw = g[jj]*wj[jj];
-                        r += gw;
-#pragma unroll
-                        for (int b = 0; b+1 < DPE; b++) u[b] = __builtin_fma(gw, ph[jj][b], u[b]);
-                    }
-                }
-            }
-            u[DPE-1] = r;
-#pragma unroll
-            for (int b = 0; b+1 < DPE; b++) u[DPE-1] -= u[b];
-            int e = 0;
-#pragma unroll
-            for (int a = 0; a < DPE; a++) {
-                const double pa = wi*ti[4+a];
-#pragma unroll
-                for (int b = 0; b < DPE; b++) R.G[a][b] = __builtin_fma(pa, u[b], R.G[a][b]);
-                const double pr = pa*r;
-#pragma unroll
-                for (int b = a; b < DPE; b++) { R.S1[e] = __builtin_fma(pr, ti[4+b], R.S1[e]); e++; }
-            }
-        }
-#pragma unroll
-        for (int jq = 0; jq < JB; jq += JG) {
-            if (j0+jq < n4) {
-#pragma unroll
-                for (int jj = jq; jj < jq+JG; jj++) {
-                    if (CM == 1) sc[(j0+jj)*cstride] = c[jj];
-                    else if (CM == 2) atomic_add_f64(&sc[j0+jj], c[jj]);
-                    else {
-                        const double *__restrict__ tj = tj0+jj*stp;
-                        const double cw = tj[3]*c[jj];
-                        int e = 0;
-#pragma unroll
-                        for (int a = 0; a < DPE; a++) {
-                            const double pc = tj[4+a]*cw;
-#pragma unroll
-                            for (int b = a; b < DPE; b++) { R.S2[e] = __builtin_fma(pc, tj[4+b], R.S2[e]); e++; }
-                        }
-                    }
-                }
-            }
-        }
-    }
-    if (CM != 0) {
-        if (CM == 2) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-        }
-#pragma unroll 1
-        for (int j = (CM == 2 ? i_first : 0); j < n; j += (CM == 2 ? i_step : 1)) {
-            const double *__restrict__ tj = tab+j*stp;
-            const double cw = tj[3]*sc[j*(CM == 2 ? 1 : cstride)];
-            int e = 0;
-#pragma unroll
-            for (int a = 0; a < DPE; a++) {
-                const double pc = tj[4+a]*cw;
-#pragma unroll
-                for (int b = a; b < DPE; b++) { R.S2[e] = __builtin_fma(pc, tj[4+b], R.S2[e]); e++; }
-            }
-        }
-    }
-}
+// eval_distant_blocked: pnl_common.h
 // the evaluator of a work-list kernel: the branch-free power where it applies
 template <int DIM, int DPE, int KT, int CM>
 __device__ __forceinline__ void eval_distant_worklist(const DevProblem &P, const double *__restrict__ tab, int stp, int n, int n4,
                                                       int i_first, int i_step, const double *av, const double *bv,
                                                       PairAcc<DIM, DPE> &R, const double *__restrict__ lpow, double *sc, int cstride) {
     if (KT == 0 && lpow && P.k.ktype == 0 && !(P.k.horizon2 < 1e300))
-        eval_distant_blocked<DIM, DPE, 0, true, CM>(P, tab, stp, n, n4, i_first, i_step, av, bv, R, lpow, sc, cstride);
+        eval_distant_blocked<DIM, DPE, 0, true, CM>(P.k, tab, stp, n, n4, i_first, i_step, av, bv, R, lpow, sc, cstride);
     else
-        eval_distant_blocked<DIM, DPE, KT, false, CM>(P, tab, stp, n, n4, i_first, i_step, av, bv, R, lpow, sc, cstride);
+        eval_distant_blocked<DIM, DPE, KT, false, CM>(P.k, tab, stp, n, n4, i_first, i_step, av, bv, R, lpow, sc, cstride);
 }
 // P2: column sums through LDS (see eval_distant_blocked); bytes of dynamic LDS the one-pair-per-lane kernel needs for them
 __host__ __device__ constexpr bool wl_csum_lds(int dpe) { return dpe > 3; }
@@ -949,6 +748,8 @@ k_tile_distant(const DevProblem P, const int2 *__restrict__ tiles, double *__res
         }
     };
     if (!(abl & 2))
+    kern_dispatch<KT>(P.k, lpow, [&](auto ktag) {
+    constexpr int KTE = decltype(ktag)::value;              // KT, or 3: the branch-free general power (pnl_common.h)
 #pragma unroll 1
     for (int pass = 0; pass < 2; pass++) {
         const int total = __builtin_amdgcn_readfirstlane(s_misc[pass]);
@@ -968,11 +769,12 @@ k_tile_distant(const DevProblem P, const int2 *__restrict__ tiles, double *__res
             PairAcc<DIM, DPE> R;
             R.clear();
             if (!act) continue;
-            if (pass == 0) eval_distant_fixed<DIM, DPE, KT, NA>(P, tab, gwp, av, bv, R, lpow);
-            else eval_distant_fixed<DIM, DPE, KT, NB>(P, tab, gwp, av, bv, R, lpow);
+            if (pass == 0) eval_distant_fixed<DIM, DPE, KTE, NA>(P, tab, gwp, av, bv, R, lpow);
+            else eval_distant_fixed<DIM, DPE, KTE, NB>(P, tab, gwp, av, bv, R, lpow);
             accumulate(R, i, j);
         }
     }
+    });
     // ---- list C: counting sort by order into the (now free) storage of list B, then 64 pairs of one order per wave ----
     const int nC = s_misc[3];
     if (nC && !(abl & 2)) {
@@ -996,6 +798,8 @@ k_tile_distant(const DevProblem P, const int2 *__restrict__ tiles, double *__res
         }
         __syncthreads();
         const int nch = __builtin_amdgcn_readfirstlane(s_misc[0]);
+        kern_dispatch<KT>(P.k, lpow, [&](auto ktag) {
+        constexpr int KTE = decltype(ktag)::value;
 #pragma unroll 1
         for (int ch = wave; ch < nch; ch += NT/64) {
             const int desc = __builtin_amdgcn_readfirstlane(s_chunk[ch]);
@@ -1009,11 +813,12 @@ k_tile_distant(const DevProblem P, const int2 *__restrict__ tiles, double *__res
             PairAcc<DIM, DPE> R;
             R.clear();
             const int nq = __builtin_amdgcn_readfirstlane(s_ttn[q]), to = __builtin_amdgcn_readfirstlane(s_tto[q]);
-            if (nq == NB) eval_distant_fixed<DIM, DPE, KT, NB>(P, s_tt+to*(4+DPE), P.tt_wphi+to*DPE, av, bv, R, lpow);
-            else if (nq == NA) eval_distant_fixed<DIM, DPE, KT, NA>(P, s_tt+to*(4+DPE), P.tt_wphi+to*DPE, av, bv, R, lpow);
-            else eval_distant_lds<DIM, DPE, KT>(P, s_tt+to*(4+DPE), 4+DPE, nq, av, bv, R, lpow);
+            if (nq == NB) eval_distant_fixed<DIM, DPE, KTE, NB>(P, s_tt+to*(4+DPE), P.tt_wphi+to*DPE, av, bv, R, lpow);
+            else if (nq == NA) eval_distant_fixed<DIM, DPE, KTE, NA>(P, s_tt+to*(4+DPE), P.tt_wphi+to*DPE, av, bv, R, lpow);
+            else eval_distant_lds<DIM, DPE, KTE>(P, s_tt+to*(4+DPE), 4+DPE, nq, av, bv, R, lpow);
             if (act) accumulate(R, i, j);
         }
+        });
     }
     if (fh) {
         // ---- pairs cut by the horizon whose order has a packed rule: sub-simplex loops (eval_distant NO:790-847), one pair
@@ -2365,7 +2170,7 @@ k_worklist_lane(const DevProblem P, const int4 *__restrict__ sorted, const unsig
             // (P2, general power: 4.6 -> 3.4 ms at 49,152 cells)
             if constexpr (wl_lane_blocked(DPE, KT))
                 eval_distant_worklist<DIM, DPE, KT, 1>(P, s_rule, STP, n, n4, 0, 1, av, bv, R, lpow, s_csum+tid, PNL_NTHREADS);
-            else eval_distant_lds<DIM, DPE, KT>(P, s_rule, STP, n, av, bv, R, lpow);
+            else kern_dispatch<KT>(P.k, lpow, [&](auto ktag) { eval_distant_lds<DIM, DPE, decltype(ktag)::value>(P, s_rule, STP, n, av, bv, R, lpow); });
         }
         // without masks (getSparse) the diagonal blocks go through the per-cell buffer like in the dense path and are
         // scattered once per cell (k_scatter_diag_sparse): 9 instead of 15 pattern searches per pair.  The sorted list keeps

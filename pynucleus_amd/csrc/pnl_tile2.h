@@ -311,6 +311,8 @@ k_tile_uniform(const DevProblem P, const int2 *__restrict__ tiles, const int *__
         for (int k = 0; k < DPE; k++) sa[k] = s_sa[li*DPE+k];
         const int fa = s_ha[li];
         const double vola = s_vola[li];
+        kern_dispatch<KT>(kk, ptab, [&](auto ktag) {
+        constexpr int KTE = decltype(ktag)::value;          // KT, or 3: the branch-free general power (pnl_common.h)
 #pragma unroll 1
         for (int jj = 0; jj < ITER; jj++) {
             const int j = wave*JW+jj*HALVES+half;
@@ -354,7 +356,7 @@ k_tile_uniform(const DevProblem P, const int2 *__restrict__ tiles, const int *__
                     double d2 = 0.;
 #pragma unroll
                     for (int d = 0; d < DIM; d++) { const double t = x[d]-y[jp][d]; d2 = __builtin_fma(t, t, d2); }
-                    const double g = kern_eval<KT>(kk, d2, ptab);
+                    const double g = kern_eval<KTE>(kk, d2, ptab);
                     r = __builtin_fma(rule[R_W+jp], g, r);
                     c[jp] = __builtin_fma(wi, g, c[jp]);
 #pragma unroll
@@ -388,6 +390,7 @@ k_tile_uniform(const DevProblem P, const int2 *__restrict__ tiles, const int *__
                 if (k >= 0 && k < 3) s_Rb[j*NP+li] = sb2*(k == 0 ? c0 : (k == 1 ? c1 : c2));
             }
         }
+        });
         lds_barrier();
         // ---- the next tile's inputs, then the flush of this one ----
         const int nxt = tile_idx+(int)gridDim.x;
@@ -948,6 +951,8 @@ k_tile_p2(const DevProblem P, const int2 *__restrict__ tiles, const int *__restr
         const int nchB = (totB+63) >> 6, nchA = (totA+63) >> 6, nch = nchC+nchB+nchA;
         const double scale2 = 2.*kern_scale<KT>(kk);
         const double *__restrict__ ptab = (KT == 0 && kk.ptab) ? s_pow : nullptr;
+        kern_dispatch<KT>(kk, ptab, [&](auto ktag) {
+        constexpr int KTE = decltype(ktag)::value;          // KT, or 3: the branch-free general power (pnl_common.h)
 #pragma unroll 1
         while (true) {
             int ch = 0;
@@ -989,24 +994,28 @@ k_tile_p2(const DevProblem P, const int2 *__restrict__ tiles, const int *__restr
             if (q == qB0 || q == qB1) {
                 const int ro = q == qB0 ? 3 : 9;
                 double c[NB];
-                p2_eval_fixed<KT, NB>(kk, tab, P.tt_wphif+to*7, av, bv, vv, act, s_R+(0*TILE+i)*NR+ro, G, c, ptab);
+                p2_eval_fixed<KTE, NB>(kk, tab, P.tt_wphif+to*7, av, bv, vv, act, s_R+(0*TILE+i)*NR+ro, G, c, ptab);
                 if (act)
 #pragma unroll
                     for (int jp = 0; jp < NB; jp++) lds_add_f64(&s_R[(1*TILE+j)*NR+ro+jp], vv*c[jp]);
             } else if (q == qA0) {
                 double c[NA];
-                p2_eval_fixed<KT, NA>(kk, tab, P.tt_wphif+to*7, av, bv, vv, act, s_R+(0*TILE+i)*NR, G, c, ptab);
+                p2_eval_fixed<KTE, NA>(kk, tab, P.tt_wphif+to*7, av, bv, vv, act, s_R+(0*TILE+i)*NR, G, c, ptab);
                 if (act)
 #pragma unroll
                     for (int jp = 0; jp < NA; jp++) lds_add_f64(&s_R[(1*TILE+j)*NR+jp], vv*c[jp]);
             } else {
+                // list C (7 .. 16 points), two sweeps: the second evaluates the kernel values once more for the column sums.  (One
+                // sweep with the blocked evaluator of pnl_common.h -- column sums in registers -- was measured in round 3: G, S1 and
+                // 16 column sums do not fit the 256 VGPRs beside the classification state, 54 .. 170 spilled registers,
+                // general tiles of C5 18.5 -> 18.7 ms.)
                 double Sd[21];
 #pragma unroll
                 for (int e = 0; e < 21; e++) Sd[e] = 0.;
-                p2_eval_lds_sweep1<KT>(kk, tab, nq, av, bv, G, Sd, ptab);
+                p2_eval_lds_sweep1<KTE>(kk, tab, nq, av, bv, G, Sd, ptab);
 #pragma unroll
                 for (int e = 0; e < 21; e++) { if (act) lds_add_f64(&s_D[(0*TILE+i)*ND+e], vv*Sd[e]); Sd[e] = 0.; }
-                p2_eval_lds_sweep2<KT>(kk, tab, nq, av, bv, Sd, ptab);
+                p2_eval_lds_sweep2<KTE>(kk, tab, nq, av, bv, Sd, ptab);
                 if (act)
 #pragma unroll
                     for (int e = 0; e < 21; e++) lds_add_f64(&s_D[(1*TILE+j)*ND+e], vv*Sd[e]);
@@ -1023,6 +1032,7 @@ k_tile_p2(const DevProblem P, const int2 *__restrict__ tiles, const int *__restr
                 for (int b = 0; b < 6; b++) lds_add_f64(&s_acc[sa+sb[b]], -vv*G[a][b]);
             }
         }
+        });
     }
     lds_barrier();
     } while (cmask);   // classes of a multi-class tile
