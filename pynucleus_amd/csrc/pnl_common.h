@@ -145,6 +145,33 @@ __device__ __forceinline__ double pnl_pow_tab(double x, const DevKernel &k, cons
 template <int KT>
 __device__ __forceinline__ double kern_eval(const DevKernel &k, double d2, const double *__restrict__ ltab = nullptr) {
     if (KT == 3) return pnl_pow_tab(d2, k, ltab);
+    if (KT >= 10) {
+        // KT == 1 with the exponent -QM/4 known at compile time (QM = KT - 10; kern_dispatch): the scalar branches and the
+        // square-and-multiply loop of the run-time version below split every evaluation into basic blocks of its own
+        constexpr int QM = KT-10;
+        double r = __builtin_amdgcn_rsq(d2);
+        {
+            const double e = __builtin_fma(-(d2*r), r, 1.0);
+            r = __builtin_fma(r, e*__builtin_fma(0.375, e, 0.5), r);
+        }
+        double base = r;
+        int p = QM/2;
+        if (QM & 1) {
+            double t = __builtin_amdgcn_rsq(r);
+            const double e = __builtin_fma(-(r*t), t, 1.0);
+            t = __builtin_fma(t, e*__builtin_fma(0.375, e, 0.5), t);
+            base = r*t;                                  // d2^(-1/4)
+            p = QM;
+        }
+        double res = (p & 1) ? base : 1.;
+#pragma unroll
+        for (int b = 1; b < 6; b++) {                   // p < 64; the trip count and every test are compile-time constants
+            if ((p >> b) == 0) break;
+            base *= base;
+            if ((p >> b) & 1) res = ((p & ((1 << b)-1)) == 0) ? base : res*base;
+        }
+        return res;
+    }
     if (KT == 2) {
         // d2^(-3/2) = r^3 (1 - e)^(-3/2) with r = v_rsq_f64(d2) (~2^-23 relative), e = 1 - d2 r^2 (|e| < 3e-7):
         // r^3 (1 + e (3/2 + 15/8 e)), the next term 35/16 e^3 is below 1e-19; six operations after the rsq, chain depth five
@@ -193,7 +220,7 @@ __device__ __forceinline__ double kern_eval(const DevKernel &k, double d2, const
 }
 
 template <int KT>
-__device__ __forceinline__ double kern_scale(const DevKernel &k) { return (KT == 1 || KT == 2) ? k.scale : 1.; }
+__device__ __forceinline__ double kern_scale(const DevKernel &k) { return (KT == 1 || KT == 2 || KT >= 10) ? k.scale : 1.; }
 // may a KT == 0 kernel run its hot loop with KT == 3 (wave-uniform)?
 __device__ __forceinline__ bool kern_eval_pow_ok(const DevKernel &k, const double *ltab) {
     return ltab != nullptr && k.ktype == 0 && !(k.horizon2 < 1e300);
@@ -204,6 +231,16 @@ template <int KT, typename F>
 __device__ __forceinline__ void kern_dispatch(const DevKernel &k, const double *ltab, F &&hot) {
     if constexpr (KT == 0) {
         if (kern_eval_pow_ok(k, ltab)) { hot(KTag<3>{}); return; }
+    }
+    if constexpr (KT == 1) {
+        // s = 1/4 and 3/4: 2D d2^(-5/4), d2^(-7/4); 1D d2^(-3/4), d2^(-5/4); (s = 1/2 in 1D: d2^(-1))
+        switch (k.qm) {
+        case 3: hot(KTag<13>{}); return;
+        case 4: hot(KTag<14>{}); return;
+        case 5: hot(KTag<15>{}); return;
+        case 7: hot(KTag<17>{}); return;
+        default: break;
+        }
     }
     hot(KTag<KT>{});
 }

@@ -224,10 +224,10 @@ template <int DIM, int DPE, int KT, int CM>
 __device__ __forceinline__ void eval_distant_worklist(const DevProblem &P, const double *__restrict__ tab, int stp, int n, int n4,
                                                       int i_first, int i_step, const double *av, const double *bv,
                                                       PairAcc<DIM, DPE> &R, const double *__restrict__ lpow, double *sc, int cstride) {
-    if (KT == 0 && lpow && P.k.ktype == 0 && !(P.k.horizon2 < 1e300))
-        eval_distant_blocked<DIM, DPE, 0, true, CM>(P.k, tab, stp, n, n4, i_first, i_step, av, bv, R, lpow, sc, cstride);
-    else
-        eval_distant_blocked<DIM, DPE, KT, false, CM>(P.k, tab, stp, n, n4, i_first, i_step, av, bv, R, lpow, sc, cstride);
+    kern_dispatch<KT>(P.k, lpow, [&](auto ktag) {
+        constexpr int KTE = decltype(ktag)::value;
+        eval_distant_blocked<DIM, DPE, KTE, KTE == 3, CM>(P.k, tab, stp, n, n4, i_first, i_step, av, bv, R, lpow, sc, cstride);
+    });
 }
 // P2: column sums through LDS (see eval_distant_blocked); bytes of dynamic LDS the one-pair-per-lane kernel needs for them
 __host__ __device__ constexpr bool wl_csum_lds(int dpe) { return dpe > 3; }

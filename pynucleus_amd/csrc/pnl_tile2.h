@@ -195,8 +195,11 @@ __host__ __device__ constexpr size_t uniform_fixed_lds(int dpe, int np, int tile
 // the occupancy API how many workgroups that leaves per CU), except the P1 order-2 kernel of a general exponent, which needs 135
 // and is held to 128 so that a fourth workgroup fits (order-2 tiles at 98,304 cells, s = 0.4: 67.1 -> 61.5 ms), and the P1 6-point
 // kernels, held to 168 for the third (the general exponent needs 170: order-3 tiles 38.7 -> 28.7 ms)
+#ifndef PNL_U33K0_WAVES
+#define PNL_U33K0_WAVES 3
+#endif
 template <int DPE, int NP, int KT>
-__global__ void __launch_bounds__(256, (DPE == 3 && NP == 3 && KT == 0) ? 4 : ((DPE == 3 && NP == 6) ? 3 : 2))
+__global__ void __launch_bounds__(256, (DPE == 3 && NP == 3 && KT == 0) ? PNL_U33K0_WAVES : ((DPE == 3 && NP == 6) ? 3 : 2))
 k_tile_uniform(const DevProblem P, const int2 *__restrict__ tiles, const int *__restrict__ tile_cls, const DevKernel *__restrict__ kcls,
                int ntiles, double *__restrict__ A, long long ldA, double *__restrict__ Dglob, int acc_stride, int q_uniform,
                int flags, const double *__restrict__ rule_g, int nUe, const SlotOut SO) {
