@@ -145,6 +145,7 @@ __device__ __forceinline__ double pnl_pow_tab(double x, const DevKernel &k, cons
 template <int KT>
 __device__ __forceinline__ double kern_eval(const DevKernel &k, double d2, const double *__restrict__ ltab = nullptr) {
     if (KT == 3) return pnl_pow_tab(d2, k, ltab);
+    if (KT == 4) return k.scale;                        // constant kernel on a pair that lies inside the horizon (kern_dispatch<0, true>)
     if (KT >= 10) {
         // KT == 1 with the exponent -QM/4 known at compile time (QM = KT - 10; kern_dispatch): the scalar branches and the
         // square-and-multiply loop of the run-time version below split every evaluation into basic blocks of its own
@@ -227,10 +228,16 @@ __device__ __forceinline__ bool kern_eval_pow_ok(const DevKernel &k, const doubl
 }
 // hot(tag): a generic lambda whose body uses decltype(tag)::value as the KT of its kern_eval calls
 template <int KT> struct KTag { static constexpr int value = KT; };
-template <int KT, typename F>
+// INSIDE: the caller knows that every point pair it evaluates lies inside the horizon (the lists of a finite-horizon tile hold the
+// pairs that rel_position classified as interacting; the cut ones take eval_distant_cut) -- the horizon test is void, and the
+// constant kernel needs no distance at all
+template <int KT, bool INSIDE = false, typename F>
 __device__ __forceinline__ void kern_dispatch(const DevKernel &k, const double *ltab, F &&hot) {
     if constexpr (KT == 0) {
-        if (kern_eval_pow_ok(k, ltab)) { hot(KTag<3>{}); return; }
+        if (kern_eval_pow_ok(k, ltab) || (INSIDE && ltab != nullptr && k.ktype == 0)) { hot(KTag<3>{}); return; }
+        if constexpr (INSIDE) {
+            if (k.ktype == 1) { hot(KTag<4>{}); return; }
+        }
     }
     if constexpr (KT == 1) {
         // s = 1/4 and 3/4: 2D d2^(-5/4), d2^(-7/4); 1D d2^(-3/4), d2^(-5/4); (s = 1/2 in 1D: d2^(-1))

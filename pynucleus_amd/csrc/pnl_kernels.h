@@ -748,7 +748,7 @@ k_tile_distant(const DevProblem P, const int2 *__restrict__ tiles, double *__res
         }
     };
     if (!(abl & 2))
-    kern_dispatch<KT>(P.k, lpow, [&](auto ktag) {
+    kern_dispatch<KT, fh>(P.k, lpow, [&](auto ktag) {
     constexpr int KTE = decltype(ktag)::value;              // KT, or 3: the branch-free general power (pnl_common.h)
 #pragma unroll 1
     for (int pass = 0; pass < 2; pass++) {
@@ -798,7 +798,7 @@ k_tile_distant(const DevProblem P, const int2 *__restrict__ tiles, double *__res
         }
         __syncthreads();
         const int nch = __builtin_amdgcn_readfirstlane(s_misc[0]);
-        kern_dispatch<KT>(P.k, lpow, [&](auto ktag) {
+        kern_dispatch<KT, fh>(P.k, lpow, [&](auto ktag) {
         constexpr int KTE = decltype(ktag)::value;
 #pragma unroll 1
         for (int ch = wave; ch < nch; ch += NT/64) {

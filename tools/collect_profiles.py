@@ -31,7 +31,8 @@ def newest(pattern):
 
 def short(name):
     head = name.split('(')[0]
-    n = head.split('<')[0].split()[-1]
+    parts = head.split('<')[0].split()
+    n = parts[-1] if parts else name
     if n == 'k_tile_uniform' and '<' in head:
         # the instantiations are different kernels of the step: <DPE, NP, KT> -> k_tile_uniform_<DPE>_<NP>
         args = [a.strip() for a in head.split('<', 1)[1].rstrip('>').split(',')]
