@@ -18,6 +18,7 @@ an N-vector over RCCL.
 Prints ONE JSON line on rank 0.
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -141,15 +142,19 @@ def extra_configs(dev):
                 ms.append(A.info['phase_ms']['total']); wall.append(t1-t0)
             first = t1-t0 if rep == 0 else first
             del A
-        dev_s, pairs = 1e-3*float(np.mean(ms)), cnt['numAssembledCellPairs']
+        # median of the repetitions: a context of the previous leg that the garbage collector frees late (hipFree of its 20 GB)
+        # would otherwise show up as one slow repetition here
+        dev_s, pairs = 1e-3*float(np.median(ms)), cnt['numAssembledCellPairs']
         fl = flops_from_counters(cnt, dpe)
         res[name] = dict(num_dofs=dm.num_dofs, num_cells=dm.mesh.num_cells, element_pairs=pairs, device_ms=1e3*dev_s,
-                         wall_ms=1e3*float(np.mean(wall)), first_call_ms=1e3*first, pairs_per_s=pairs/dev_s,
+                         wall_ms=1e3*float(np.median(wall)), first_call_ms=1e3*first, pairs_per_s=pairs/dev_s,
                          algorithmic_tflops=fl/dev_s/1e12, frac_fp64_peak=fl/dev_s/1e12/FP64_VECTOR_PEAK_TFLOPS,
                          phases_ms={k: round(v, 3) for k, v in last_ms.items()},
                          kernel_ms={k: round(v, 3) for k, v in b.dense_context().kernel_ms().items()})
         del b
+        gc.collect()
         torch.cuda.empty_cache()
+        sync()
 
     legs = []
     # C5: P2, variable order (3 layers), dense, noRef 6
