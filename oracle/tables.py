@@ -147,18 +147,34 @@ def near_rule_1d_boundary(sigma, qd):
 def element_nodes(dim, order):
     """DoFMaps.pyx: barycentric coordinates of the local DoFs (P1: vertices; P2: vertices, then edges (0,1), (1,2), (0,2))"""
     I = np.eye(dim+1)
+    if order == 0:                                             # P0: the barycentre (DoFMaps.pyx:1794-1801)
+        return np.full((1, dim+1), 1./(dim+1))
     if order == 1:
         return I
+    if order == 3:                                             # P3 on intervals (DoFMaps.pyx:2117-2120)
+        assert dim == 1
+        return np.vstack([I, [[2./3., 1./3.], [1./3., 2./3.]]])
     if dim == 1:
         return np.vstack([I, [[0.5, 0.5]]])
     return np.vstack([I, [[0.5, 0.5, 0.], [0., 0.5, 0.5], [0.5, 0., 0.5]]])
 
 
+def element_layout(dim, order):
+    """(dofs per vertex, dofs per edge) of the element (DoFMap constructors, DoFMaps.pyx:1797, 1880-1890, 2121)"""
+    return (0 if order == 0 else 1), (1 if (order == 2 and dim == 2) else 0)
+
+
 def shape_functions(dim, order, lam):
     """values [dpe, n] of the local shape functions at barycentric points lam[dim+1, n] (DoFMaps.pyx:1854-1960)"""
     lam = np.asarray(lam, dtype=np.float64)
+    if order == 0:
+        return np.ones((1, lam.shape[1]))
     if order == 1:
         return lam[:dim+1].copy()
+    if order == 3:                                             # DoFMaps.pyx:2044-2045 (vertex), :2068-2069 (edge (v1, v2))
+        assert dim == 1
+        l0, l1 = lam[0], lam[1]
+        return np.stack([4.5*l0*(l0-1./3.)*(l0-2./3.), 4.5*l1*(l1-1./3.)*(l1-2./3.), 13.5*l0*l1*(l0-1./3.), 13.5*l1*l0*(l1-1./3.)])
     vert = [lam[k]*(2.*lam[k]-1.) for k in range(dim+1)]
     edges = [(0, 1)] if dim == 1 else [(0, 1), (1, 2), (0, 2)]
     return np.stack(vert+[4.*lam[a]*lam[b] for a, b in edges])
@@ -182,7 +198,7 @@ def merged_psi(dim, order, panel, nodes):
     """FL2:662-811, FL1:255-330: rows = DoFs of the union of the two cells, shared DoFs first.  Returns (psi, phi_x part,
     phi_y part) with psi = px - py."""
     nV = dim+1
-    dpv, dped = 1, (1 if (order == 2 and dim == 2) else 0)
+    dpv, dped = element_layout(dim, order)
     px = shape_functions(dim, order, nodes[:nV])
     py = shape_functions(dim, order, nodes[nV:2*nV])
     dpe = px.shape[0]
@@ -379,7 +395,8 @@ class OracleTables:
         self.dm = dm
         self.dim = dim = int(np.asarray(mesh.vertices).shape[1])
         self.dpe = int(np.asarray(dm.dofs).shape[1])
-        self.order = order = 1 if self.dpe == dim+1 else 2
+        # the element from the number of local DoFs: P0 1, P1 dim+1, P2 3 / 6, P3 on intervals 4
+        self.order = order = {1: 0, dim+1: 1, (3 if dim == 1 else 6): 2, (4 if dim == 1 else 10): 3}[self.dpe]
         self.num_dofs = int(dm.num_dofs)
         self.pointwise = False
         self.spec = spec
@@ -480,7 +497,10 @@ class OracleTables:
             else:
                 qd = qdV = qd_in
             self.quad_order_diagonal, self.quad_order_diagonalV = int(qd), int(qdV)
-            rules = {p: near_rule_2d(p, 2.+sing, int(qd), int(qdV)) for p in (COMMON_FACE, COMMON_EDGE, COMMON_VERTEX)}
+            # FL2:590-598: the integrand cancels two orders of the singularity within an element, and across elements for continuous
+            # elements only (P0: none)
+            across = 0. if order == 0 else 2.
+            rules = {p: near_rule_2d(p, (2. if p == COMMON_FACE else across)+sing, int(qd), int(qdV)) for p in (COMMON_FACE, COMMON_EDGE, COMMON_VERTEX)}
             self.sing_fac = 4.0
             sq = max(-0.5*(sing+2.), 0.)                       # FL2:622-642
             self.qo = Formula((0.5*target+0.5)*np.log(N*self.H0**2), sq-1., 1., sq, 0.4, False)
@@ -493,7 +513,8 @@ class OracleTables:
             if qd_in is None:
                 qd_in = max(np.ceil(((target+2.)*np.log(N*self.H0)+(2.*smax-1.)*logh)/0.8), 2)
             self.quad_order_diagonal = self.quad_order_diagonalV = int(qd_in)
-            rules = {p: near_rule_1d(p, 2.+sing, int(qd_in), 2*order) for p in (COMMON_EDGE, COMMON_VERTEX)}
+            across = 0. if order == 0 else 2.                  # FL1:208-216
+            rules = {p: near_rule_1d(p, (2. if p == COMMON_EDGE else across)+sing, int(qd_in), 2*max(order, 1)) for p in (COMMON_EDGE, COMMON_VERTEX)}
             self.sing_fac = 1.0
             sq = max(-0.5*(sing+1.), 0.)
             self.qo = Formula((target+2.)*np.log(N*self.H0), 2.*sq-1., 0., 2.*sq, 0.8, False)

@@ -394,6 +394,11 @@ __device__ __forceinline__ double row16_sum(double v) {
     return v;
 }
 
+// DoFs per vertex / per edge of the elements the kernels are instantiated for: P0 (one DoF per cell), P1, P2, P3 on intervals
+// (two vertices + two cell DoFs); the merged local DoFs of a touching pair follow from them (FL2:662-811, FL1:255-330)
+__host__ __device__ constexpr int elem_dpv(int dpe) { return dpe == 1 ? 0 : 1; }
+__host__ __device__ constexpr int elem_dped(int dim, int dpe) { return (dim == 2 && dpe == 6) ? 1 : 0; }
+
 // ---- distant pairs, factorised accumulation (see pnl_kernels.h: eval_distant) ---------------------------------------------
 template <int DIM, int DPE>
 struct PairAcc {

@@ -27,10 +27,10 @@ int finalize(pnl_context *ctx) {
     if (!ctx->dirty) return PNL_OK;
     if (!ctx->have_mesh || !ctx->have_dofs) return fail(ctx, PNL_ERR_STATE, "mesh and DoF map must be uploaded first");
     const int dim = ctx->dim, nV = dim+1, nc = ctx->nc, dpe = ctx->dpe;
-    if (!((dim == 2 && (dpe == 3 || dpe == 6)) || (dim == 1 && (dpe == 2 || dpe == 3))))
+    if (!((dim == 2 && (dpe == 3 || dpe == 6)) || (dim == 1 && dpe >= 1 && dpe <= 4)))          // 1D: P0, P1, P2, P3
         return fail(ctx, PNL_ERR_UNSUPPORTED, "unsupported (dim=%d, dofs_per_element=%d)", dim, dpe);
     // P2 blocks hold about twice the DoFs per cell: half the cells per block keep the LDS sub-block in range
-    const int T = ctx->tile = (dpe == 6 || (dim == 1 && dpe == 3)) ? TILE_P2 : TILE_P1;
+    const int T = ctx->tile = (dpe == 6 || (dim == 1 && dpe >= 3)) ? TILE_P2 : TILE_P1;
     const int nblocks = ctx->nblocks = (nc+T-1)/T;
     const int ncp = ctx->ncp = nblocks*T;
     const int NC = nV*dim;
@@ -1323,6 +1323,9 @@ int dispatch(pnl_context *ctx, double *A, int64_t ldA, int zero_exterior, int nt
     if (ctx->dim == 2 && ctx->dpe == 6) return assemble_impl<2, 6, TILE_P2>(ctx, A, ldA, zero_exterior, ntiles, cell_begin, cell_end, flags);
     if (ctx->dim == 1 && ctx->dpe == 2) return assemble_impl<1, 2, TILE_P1>(ctx, A, ldA, zero_exterior, ntiles, cell_begin, cell_end, flags);
     if (ctx->dim == 1 && ctx->dpe == 3) return assemble_impl<1, 3, TILE_P2>(ctx, A, ldA, zero_exterior, ntiles, cell_begin, cell_end, flags);
+    // P0 and P3 on intervals (the reference's fixtures --elementP0 / --elementP3; FL1 is generic in the DoFs per element)
+    if (ctx->dim == 1 && ctx->dpe == 1) return assemble_impl<1, 1, TILE_P1>(ctx, A, ldA, zero_exterior, ntiles, cell_begin, cell_end, flags);
+    if (ctx->dim == 1 && ctx->dpe == 4) return assemble_impl<1, 4, TILE_P2>(ctx, A, ldA, zero_exterior, ntiles, cell_begin, cell_end, flags);
     return fail(ctx, PNL_ERR_UNSUPPORTED, "unsupported (dim=%d, dofs_per_element=%d)", ctx->dim, ctx->dpe);
 }
 

@@ -2282,7 +2282,7 @@ k_singular_pairs(const DevProblem P, const int2 *__restrict__ pairs, int npairs_
                  const unsigned *__restrict__ offs, const ClusterTiles CT) {
     const bool cluster = CT.npairs > 0;          // touching element pairs of cluster pairs: pairs[wid] with cluster pair CT.sing_pair[wid]
     constexpr int NV = DIM+1;
-    constexpr int DPV = 1, DPED = (DIM == 2 && DPE == 6) ? 1 : 0;
+    constexpr int DPV = elem_dpv(DPE), DPED = elem_dped(DIM, DPE);
     constexpr int COMMON = SLOT+1;
     constexpr int ROWS = (COMMON == NV) ? DPE : (COMMON == 1 ? 2*DPE-DPV : 2*DPE-2*DPV-DPED);
     constexpr int NE = ROWS*(ROWS+1)/2;

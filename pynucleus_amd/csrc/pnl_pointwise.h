@@ -977,7 +977,7 @@ template <int DIM, int DPE, int SLOT>
 __global__ void __launch_bounds__(PNL_NTHREADS)
 k_pw_singular(const DevProblem P, const PwDev W, const int4 *__restrict__ pairs, int npairs, double *__restrict__ A, long long ldA,
               int cell_begin, int cell_end) {
-    constexpr int NV = DIM+1, DPV = 1, DPED = (DIM == 2 && DPE == 6) ? 1 : 0;
+    constexpr int NV = DIM+1, DPV = elem_dpv(DPE), DPED = elem_dped(DIM, DPE);
     constexpr int COMMON = SLOT+1;
     // merged local DoFs: shared vertices (and the shared edge) first (FL2:965-1075, FL1:466-530)
     constexpr int ROWS = (COMMON == NV) ? DPE : (COMMON == 1 ? 2*DPE-DPV : 2*DPE-2*DPV-DPED);

@@ -45,8 +45,9 @@ class DoFMap:
         self.dofs_per_face = 0
         self.dofs_per_cell = dofs_per_cell
         self.dofs_per_element = vpe*dofs_per_vertex+epe*self.dofs_per_edge+dofs_per_cell
-        assert dofs_per_vertex in (0, 1) and self.dofs_per_edge in (0, 1) and (dofs_per_cell == 0 or (md == 1 and dofs_per_cell == 1)), \
-            'only P1 / P2 Lagrange maps are implemented'
+        assert dofs_per_vertex in (0, 1) and self.dofs_per_edge in (0, 1) and \
+            (dofs_per_cell == 0 or (md == 1 and dofs_per_cell <= 2) or (dofs_per_vertex == 0 and dofs_per_cell == 1)), \
+            'P0, P1, P2 and (on intervals) P3 maps are implemented'
         cells = mesh.cells
         nc = cells.shape[0]
         MAXI = np.iinfo(INDEX).max
@@ -79,9 +80,9 @@ class DoFMap:
                 lo = np.minimum(c[:, a], c[:, b])
                 hi = np.maximum(c[:, a], c[:, b])
                 ent_keys.append(nvert+lo*nvert+hi)
-        if dofs_per_cell > 0:
-            # DoF in the interior of the cell (P2 on intervals): numbered after the cell's vertices (DoFMaps.pyx:300-305)
-            ent_keys.append(mesh.num_vertices*(mesh.num_vertices+1)+np.arange(nc, dtype=np.int64))
+        for k in range(dofs_per_cell):
+            # DoFs in the interior of the cell (P0; P2 / P3 on intervals): numbered after the cell's vertices (DoFMaps.pyx:300-305)
+            ent_keys.append(mesh.num_vertices*(mesh.num_vertices+1)+dofs_per_cell*np.arange(nc, dtype=np.int64)+k)
         keys = np.stack(ent_keys, axis=1)                     # [nc, slots], cell-major
         flat = keys.reshape(-1)
         is_boundary = np.zeros(flat.shape[0], dtype=bool)
@@ -263,10 +264,48 @@ class P2_DoFMap(DoFMap):
         return np.stack([l0*(2*l0-1), l1*(2*l1-1), l2*(2*l2-1), 4*l0*l1, 4*l1*l2, 4*l0*l2])
 
 
+class P0_DoFMap(DoFMap):
+    """piecewise constants, one DoF per cell at its barycentre (fem/PyNucleus_fem/DoFMaps.pyx:1788-1807); no DoF lies on the boundary"""
+    polynomialOrder = 0
+
+    def __init__(self, mesh, tag=None):
+        assert mesh.manifold_dim in (1, 2)
+        super().__init__(mesh, 0, 0, 1, tag)
+
+    def _set_nodes(self):
+        k = self.mesh.manifold_dim+1
+        self.nodes = np.full((1, k), 1./k, dtype=REAL)
+
+    def evalShapeFunctions(self, bary):
+        return np.ones((1, np.asarray(bary).shape[1]), dtype=REAL)
+
+
+class P3_DoFMap(DoFMap):
+    """continuous piecewise cubics on intervals: the two vertices, then the nodes at 1/3 and 2/3 of the cell
+    (DoFMaps.pyx:2106-2121; shape functions :2044-2045 vertex, :2068-2069 edge (v1, v2) = 13.5 l1 l2 (l1 - 1/3))"""
+    polynomialOrder = 3
+
+    def __init__(self, mesh, tag=None):
+        assert mesh.manifold_dim == 1, 'P3 is implemented on intervals'
+        super().__init__(mesh, 1, 0, 2, tag)
+
+    def _set_nodes(self):
+        self.nodes = np.array([[1., 0.], [0., 1.], [2./3., 1./3.], [1./3., 2./3.]], dtype=REAL)
+
+    def evalShapeFunctions(self, bary):
+        l0, l1 = bary[0], bary[1]
+        return np.stack([4.5*l0*(l0-1./3.)*(l0-2./3.), 4.5*l1*(l1-1./3.)*(l1-2./3.),
+                         13.5*l0*l1*(l0-1./3.), 13.5*l1*l0*(l1-1./3.)])
+
+
 def dofmapFactory(element, mesh, tag=None):
     element = element.upper() if isinstance(element, str) else 'P{}'.format(element)
-    if element == 'P1':
+    if element == 'P0':
+        return P0_DoFMap(mesh, tag)
+    elif element == 'P1':
         return P1_DoFMap(mesh, tag)
     elif element == 'P2':
         return P2_DoFMap(mesh, tag)
+    elif element == 'P3':
+        return P3_DoFMap(mesh, tag)
     raise NotImplementedError(element)

@@ -397,9 +397,10 @@ class nonlocalTables:
         self.quad_order_diagonal, self.quad_order_diagonalV = int(qd), int(qdV)
         sing = kernel.getSingularityValue()
         # singularity cancellation: 2 orders within and (for continuous elements) across elements
+        across = 0. if self.dm.polynomialOrder == 0 else 2.   # FL2:594-598: discontinuous elements cancel nothing across elements
         rules = {COMMON_FACE: singularityCancelationQuadRule2D(COMMON_FACE, 2.+sing, self.quad_order_diagonal, self.quad_order_diagonalV),
-                 COMMON_EDGE: singularityCancelationQuadRule2D(COMMON_EDGE, 2.+sing, self.quad_order_diagonal, self.quad_order_diagonalV),
-                 COMMON_VERTEX: singularityCancelationQuadRule2D(COMMON_VERTEX, 2.+sing, self.quad_order_diagonal, self.quad_order_diagonalV)}
+                 COMMON_EDGE: singularityCancelationQuadRule2D(COMMON_EDGE, across+sing, self.quad_order_diagonal, self.quad_order_diagonalV),
+                 COMMON_VERTEX: singularityCancelationQuadRule2D(COMMON_VERTEX, across+sing, self.quad_order_diagonal, self.quad_order_diagonalV)}
         self.singular = self._psi_tables(rules)
         self.sing_fac = 4.0                                  # FL2:851
         s = max(-0.5*(sing+2), 0.)
@@ -418,8 +419,9 @@ class nonlocalTables:
         self.quad_order_diagonal = self.quad_order_diagonalV = int(quad_order_diagonal)
         sing = kernel.getSingularityValue()
         dm_order = max(self.dm.polynomialOrder, 1)
+        across = 0. if self.dm.polynomialOrder == 0 else 2.   # FL1:212-216
         rules = {COMMON_EDGE: singularityCancelationQuadRule1D(COMMON_EDGE, 2.+sing, self.quad_order_diagonal, 2*dm_order),
-                 COMMON_VERTEX: singularityCancelationQuadRule1D(COMMON_VERTEX, 2.+sing, self.quad_order_diagonal, 2*dm_order)}
+                 COMMON_VERTEX: singularityCancelationQuadRule1D(COMMON_VERTEX, across+sing, self.quad_order_diagonal, 2*dm_order)}
         self.singular = self._psi_tables(rules)
         self.sing_fac = 1.0                                  # FL1:374
         s = max(-0.5*(sing+1), 0.)

@@ -370,8 +370,18 @@ def test_interval_P2_dense(noRef, s, zeroExterior):
     _compare(_build('interval', noRef, s, element='P2', zeroExterior=zeroExterior))
 
 
+@pytest.mark.parametrize('element,noRef,s,zeroExterior', [('P0', 6, 0.25, True), ('P0', 4, 0.4, False), ('P3', 5, 0.25, True),
+                                                          ('P3', 5, 0.75, True), ('P3', 3, 0.4, False)])
+def test_interval_P0_P3_dense(element, noRef, s, zeroExterior):
+    """P0 (one DoF per cell, no cancellation across elements: FL1:212-216) and P3 (two vertices + two cell DoFs) on intervals --
+    the elements of the reference's fixtures --elementP0 / --elementP3; entries and integer counters against the oracle, whose
+    numbers for these elements are pinned to the stored Hs errors (tests/test_oracle_pinning.py)"""
+    _compare(_build('interval', noRef, s, element=element, zeroExterior=zeroExterior))
+
+
 @pytest.mark.parametrize('element,s,noRef,stored', [('P1', 0.25, 6, 0.09611243700804001), ('P2', 0.25, 5, 0.08454379705489531),
-                                                    ('P2', 0.75, 5, 0.03250922885004246)])
+                                                    ('P2', 0.75, 5, 0.03250922885004246), ('P0', 0.25, 6, 0.0863469994893122),
+                                                    ('P3', 0.25, 5, 0.061422967833697564), ('P3', 0.75, 5, 0.02241204241913628)])
 def test_interval_stored_errors_through_the_gpu(element, s, noRef, stored):
     """the reference's stored Hs errors of runFractional --domain interval (reproducible to ~1e-12 without third-party tables)
     through the product path: assembly on the GPU, solve on the host"""

@@ -156,11 +156,13 @@ def test_golden_interval():
 
 
 @pytest.mark.parametrize('element,s,noRef,stored', [('P1', 0.75, 6, 0.04184296289342096), ('P2', 0.25, 5, 0.08454379705489531),
-                                                    ('P2', 0.75, 5, 0.03250922885004246)])
+                                                    ('P2', 0.75, 5, 0.03250922885004246), ('P0', 0.25, 6, 0.0863469994893122),
+                                                    ('P3', 0.25, 5, 0.061422967833697564), ('P3', 0.75, 5, 0.02241204241913628)])
 def test_interval_stored_errors_exact(element, s, noRef, stored):
-    """tests/cache_runFractional.py--domaininterval--sconst(s)--problemconstant--element{P1,P2}--...--matrixFormatdense: in 1D the
-    reference's quadrature is Gauss-Jacobi throughout (reproducible without modepy), and the oracle lands on the stored Hs errors
-    to ~1e-12 relative -- also for P2 (vertex + cell-midpoint DoFs), the only reference numbers that pin the P2 machinery"""
+    """tests/cache_runFractional.py--domaininterval--sconst(s)--problemconstant--element{P0,P1,P2,P3}--...--matrixFormatdense: in 1D
+    the reference's quadrature is Gauss-Jacobi throughout (reproducible without modepy), and the oracle lands on the stored Hs errors
+    to ~1e-12 relative (P3, s = 3/4: 9e-11, the conditioning of the solve) -- also for P2 (vertex + cell-midpoint DoFs), P0 (no
+    cancellation across elements, FL1:212-216) and P3 (two cell DoFs), the only reference numbers that pin those elements"""
     from pynucleus_amd import dofmapFactory
     dm = dofmapFactory(element, driverMesh('interval', noRef), PHYSICAL)
     T = nonlocalTables(dm, getFractionalKernel(1, s), {'target_order': dm.polynomialOrder+1.-s})
