@@ -27,7 +27,7 @@ int finalize(pnl_context *ctx) {
     if (!ctx->dirty) return PNL_OK;
     if (!ctx->have_mesh || !ctx->have_dofs) return fail(ctx, PNL_ERR_STATE, "mesh and DoF map must be uploaded first");
     const int dim = ctx->dim, nV = dim+1, nc = ctx->nc, dpe = ctx->dpe;
-    if (!((dim == 2 && (dpe == 3 || dpe == 6)) || (dim == 1 && dpe >= 1 && dpe <= 4)))          // 1D: P0, P1, P2, P3
+    if (!((dim == 2 && (dpe == 1 || dpe == 3 || dpe == 6)) || (dim == 1 && dpe >= 1 && dpe <= 4)))          // 2D: P0, P1, P2; 1D: P0 .. P3
         return fail(ctx, PNL_ERR_UNSUPPORTED, "unsupported (dim=%d, dofs_per_element=%d)", dim, dpe);
     // P2 blocks hold about twice the DoFs per cell: half the cells per block keep the LDS sub-block in range
     const int T = ctx->tile = (dpe == 6 || (dim == 1 && dpe >= 3)) ? TILE_P2 : TILE_P1;
@@ -1324,6 +1324,7 @@ int dispatch(pnl_context *ctx, double *A, int64_t ldA, int zero_exterior, int nt
     if (ctx->dim == 1 && ctx->dpe == 2) return assemble_impl<1, 2, TILE_P1>(ctx, A, ldA, zero_exterior, ntiles, cell_begin, cell_end, flags);
     if (ctx->dim == 1 && ctx->dpe == 3) return assemble_impl<1, 3, TILE_P2>(ctx, A, ldA, zero_exterior, ntiles, cell_begin, cell_end, flags);
     // P0 and P3 on intervals (the reference's fixtures --elementP0 / --elementP3; FL1 is generic in the DoFs per element)
+    if (ctx->dim == 2 && ctx->dpe == 1) return assemble_impl<2, 1, TILE_P1>(ctx, A, ldA, zero_exterior, ntiles, cell_begin, cell_end, flags);
     if (ctx->dim == 1 && ctx->dpe == 1) return assemble_impl<1, 1, TILE_P1>(ctx, A, ldA, zero_exterior, ntiles, cell_begin, cell_end, flags);
     if (ctx->dim == 1 && ctx->dpe == 4) return assemble_impl<1, 4, TILE_P2>(ctx, A, ldA, zero_exterior, ntiles, cell_begin, cell_end, flags);
     return fail(ctx, PNL_ERR_UNSUPPORTED, "unsupported (dim=%d, dofs_per_element=%d)", ctx->dim, ctx->dpe);
@@ -2494,7 +2495,12 @@ int pnl_assemble_pairs_masked(pnl_context *ctx, int np, const int32_t *pairs, co
             rc = kt ? pairs_masked_impl<2, 3, 1>(ctx, np, S, true, first) : pairs_masked_impl<2, 3, 0>(ctx, np, S, true, first);
         else if (ctx->dim == 2 && ctx->dpe == 6)
             rc = kt ? pairs_masked_impl<2, 6, 1>(ctx, np, S, true, first) : pairs_masked_impl<2, 6, 0>(ctx, np, S, true, first);
+        else if (ctx->dim == 2 && ctx->dpe == 1)
+            rc = kt ? pairs_masked_impl<2, 1, 1>(ctx, np, S, true, first) : pairs_masked_impl<2, 1, 0>(ctx, np, S, true, first);
         else if (ctx->dim == 1 && ctx->dpe == 2) rc = pairs_masked_impl<1, 2, 0>(ctx, np, S, true, first);
+        else if (ctx->dim == 1 && ctx->dpe == 1) rc = pairs_masked_impl<1, 1, 0>(ctx, np, S, true, first);
+        else if (ctx->dim == 1 && ctx->dpe == 3) rc = pairs_masked_impl<1, 3, 0>(ctx, np, S, true, first);
+        else if (ctx->dim == 1 && ctx->dpe == 4) rc = pairs_masked_impl<1, 4, 0>(ctx, np, S, true, first);
         else rc = fail(ctx, PNL_ERR_UNSUPPORTED, "unsupported (dim=%d, dofs_per_element=%d)", ctx->dim, ctx->dpe);
         if (rc) break;
     }
@@ -2516,7 +2522,11 @@ int pnl_assemble_pairs_in_horizon(pnl_context *ctx, double *data, double *diag) 
     const int kt = ctx->P.k.fast ? 1 : 0;
     if (ctx->dim == 2 && ctx->dpe == 3) return kt ? horizon_impl<2, 3, 1>(ctx, S) : horizon_impl<2, 3, 0>(ctx, S);
     if (ctx->dim == 2 && ctx->dpe == 6) return kt ? horizon_impl<2, 6, 1>(ctx, S) : horizon_impl<2, 6, 0>(ctx, S);
+    if (ctx->dim == 2 && ctx->dpe == 1) return kt ? horizon_impl<2, 1, 1>(ctx, S) : horizon_impl<2, 1, 0>(ctx, S);
     if (ctx->dim == 1 && ctx->dpe == 2) return horizon_impl<1, 2, 0>(ctx, S);
+    if (ctx->dim == 1 && ctx->dpe == 1) return horizon_impl<1, 1, 0>(ctx, S);
+    if (ctx->dim == 1 && ctx->dpe == 3) return horizon_impl<1, 3, 0>(ctx, S);
+    if (ctx->dim == 1 && ctx->dpe == 4) return horizon_impl<1, 4, 0>(ctx, S);
     return fail(ctx, PNL_ERR_UNSUPPORTED, "unsupported (dim=%d, dofs_per_element=%d)", ctx->dim, ctx->dpe);
 }
 
@@ -2542,7 +2552,11 @@ int pnl_assemble_boundary_masked(pnl_context *ctx, int ni, const int32_t *cells,
     if (ni == 0) return PNL_OK;
     if (ctx->dim == 2 && ctx->dpe == 3) return boundary_masked_impl<2, 3>(ctx, ni, fac, S);
     if (ctx->dim == 2 && ctx->dpe == 6) return boundary_masked_impl<2, 6>(ctx, ni, fac, S);
+    if (ctx->dim == 2 && ctx->dpe == 1) return boundary_masked_impl<2, 1>(ctx, ni, fac, S);
     if (ctx->dim == 1 && ctx->dpe == 2) return boundary_masked_impl<1, 2>(ctx, ni, fac, S);
+    if (ctx->dim == 1 && ctx->dpe == 1) return boundary_masked_impl<1, 1>(ctx, ni, fac, S);
+    if (ctx->dim == 1 && ctx->dpe == 3) return boundary_masked_impl<1, 3>(ctx, ni, fac, S);
+    if (ctx->dim == 1 && ctx->dpe == 4) return boundary_masked_impl<1, 4>(ctx, ni, fac, S);
     return fail(ctx, PNL_ERR_UNSUPPORTED, "unsupported (dim=%d, dofs_per_element=%d)", ctx->dim, ctx->dpe);
 }
 
@@ -2658,6 +2672,16 @@ int pnl_assemble_clusters_tiled(pnl_context *ctx, const pnl_cluster_plan *pl, in
     if (dim == 1 && dpe == 2)
         return kt ? clusters_tiled_impl<1, 2, TILE_P1, 1>(ctx, pl, CT, cluster_boundary, d_cell, d_pair, sing_dev, sing_pair_dev, pair_foff, fvid, fgeo, maxf, bt_cell, bt_facet, bt_slot)
                   : clusters_tiled_impl<1, 2, TILE_P1, 0>(ctx, pl, CT, cluster_boundary, d_cell, d_pair, sing_dev, sing_pair_dev, pair_foff, fvid, fgeo, maxf, bt_cell, bt_facet, bt_slot);
+    // P0 (intervals and triangles), P2 and P3 on intervals
+#define PNL_CT(D_, E_, T_) \
+    if (dim == D_ && dpe == E_) \
+        return kt ? clusters_tiled_impl<D_, E_, T_, 1>(ctx, pl, CT, cluster_boundary, d_cell, d_pair, sing_dev, sing_pair_dev, pair_foff, fvid, fgeo, maxf, bt_cell, bt_facet, bt_slot) \
+                  : clusters_tiled_impl<D_, E_, T_, 0>(ctx, pl, CT, cluster_boundary, d_cell, d_pair, sing_dev, sing_pair_dev, pair_foff, fvid, fgeo, maxf, bt_cell, bt_facet, bt_slot);
+    PNL_CT(2, 1, TILE_P1)
+    PNL_CT(1, 1, TILE_P1)
+    PNL_CT(1, 3, TILE_P2)
+    PNL_CT(1, 4, TILE_P2)
+#undef PNL_CT
     return fail(ctx, PNL_ERR_UNSUPPORTED, "unsupported (dim=%d, dofs_per_element=%d)", dim, dpe);
 }
 
@@ -2749,6 +2773,10 @@ int pnl_h2_setup(pnl_context *ctx, const pnl_h2_plan *pl) {
     if (dim == 2 && ctx->dpe == 3) hipLaunchKernelGGL((k_h2_leaf_values<2, 3>), dim3(pl->nleaves), dim3(PNL_NTHREADS), 0, ctx->stream, ctx->P, H, pl->nq, qb, qw, qp);
     else if (dim == 2 && ctx->dpe == 6) hipLaunchKernelGGL((k_h2_leaf_values<2, 6>), dim3(pl->nleaves), dim3(PNL_NTHREADS), 0, ctx->stream, ctx->P, H, pl->nq, qb, qw, qp);
     else if (dim == 1 && ctx->dpe == 2) hipLaunchKernelGGL((k_h2_leaf_values<1, 2>), dim3(pl->nleaves), dim3(PNL_NTHREADS), 0, ctx->stream, ctx->P, H, pl->nq, qb, qw, qp);
+    else if (dim == 2 && ctx->dpe == 1) hipLaunchKernelGGL((k_h2_leaf_values<2, 1>), dim3(pl->nleaves), dim3(PNL_NTHREADS), 0, ctx->stream, ctx->P, H, pl->nq, qb, qw, qp);
+    else if (dim == 1 && ctx->dpe == 1) hipLaunchKernelGGL((k_h2_leaf_values<1, 1>), dim3(pl->nleaves), dim3(PNL_NTHREADS), 0, ctx->stream, ctx->P, H, pl->nq, qb, qw, qp);
+    else if (dim == 1 && ctx->dpe == 3) hipLaunchKernelGGL((k_h2_leaf_values<1, 3>), dim3(pl->nleaves), dim3(PNL_NTHREADS), 0, ctx->stream, ctx->P, H, pl->nq, qb, qw, qp);
+    else if (dim == 1 && ctx->dpe == 4) hipLaunchKernelGGL((k_h2_leaf_values<1, 4>), dim3(pl->nleaves), dim3(PNL_NTHREADS), 0, ctx->stream, ctx->P, H, pl->nq, qb, qw, qp);
     else return fail(ctx, PNL_ERR_UNSUPPORTED, "unsupported (dim=%d, dofs_per_element=%d)", dim, ctx->dpe);
     if (pl->nfar > 0) {
         const DevKernel *kcls = nullptr;

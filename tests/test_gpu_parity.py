@@ -379,6 +379,28 @@ def test_interval_P0_P3_dense(element, noRef, s, zeroExterior):
     _compare(_build('interval', noRef, s, element=element, zeroExterior=zeroExterior))
 
 
+@pytest.mark.parametrize('noRef,s,zeroExterior', [(2, 0.25, True), (3, 0.4, True), (3, 0.3, False)])
+def test_disc_P0_dense(noRef, s, zeroExterior):
+    """P0 on triangles (the reference's fixture --domaindisc--elementP0): touching pairs merge no DoFs, their rules cancel nothing
+    across elements"""
+    _compare(_build('disc', noRef, s, element='P0', zeroExterior=zeroExterior, params={'target_order': 0.5}))
+
+
+def test_disc_P0_stored_error_through_the_gpu():
+    """runFractional --domain disc --s const(0.25) --element P0 --matrixFormat dense: stored Hs error 0.1403179566911808 (4.3e-6:
+    the triangle rules, like the P1 pin) with the matrix assembled on the GPU, 6144 DoFs"""
+    from math import gamma
+    from pynucleus_amd import driverMesh, PHYSICAL, dofmapFactory, getFractionalKernel, nonlocalBuilder
+    s = 0.25
+    dm = dofmapFactory('P0', driverMesh('disc', 5), PHYSICAL)
+    A = nonlocalBuilder(dm, getFractionalKernel(2, s), {}).getDense().toarray()
+    b = np.asarray(dm.assembleRHS(1.0))
+    u = np.linalg.solve(A, b)
+    C = 2.**(-2.*s)*gamma(1.)/gamma((2+2.*s)/2.)/gamma(1.+s)          # u = C (1 - |x|^2)^s, (f, u) = C pi / (s + 1)
+    hs = np.sqrt(abs(b@u-C*np.pi/(s+1.)))
+    assert abs(hs-0.1403179566911808) <= 1e-5*0.1403179566911808, hs
+
+
 @pytest.mark.parametrize('element,s,noRef,stored', [('P1', 0.25, 6, 0.09611243700804001), ('P2', 0.25, 5, 0.08454379705489531),
                                                     ('P2', 0.75, 5, 0.03250922885004246), ('P0', 0.25, 6, 0.0863469994893122),
                                                     ('P3', 0.25, 5, 0.061422967833697564), ('P3', 0.75, 5, 0.02241204241913628)])

@@ -47,7 +47,8 @@ def test_oracle_far_field_plus_dense_near_blocks_approximates_dense():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize('noRef,s,element,domain', [(3, 0.75, 'P1', 'disc'), (4, 0.25, 'P1', 'disc'), (2, 0.5, 'P2', 'disc'),
-                                                    (6, 0.75, 'P1', 'interval')])
+                                                    (6, 0.75, 'P1', 'interval'), (6, 0.25, 'P0', 'interval'), (5, 0.75, 'P3', 'interval'),
+                                                    (5, 0.25, 'P2', 'interval'), (3, 0.25, 'P0', 'disc')])
 def test_gpu_h2_far_field_vs_oracle_and_dense(noRef, s, element, domain):
     from pynucleus_amd.builder import nonlocalBuilder
     from pynucleus_amd.quadrature import simplexXiaoGimbutas
@@ -139,15 +140,21 @@ def test_stored_hs_errors_dense_and_h2():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('domain,s,noRef,stored', [('interval', 0.25, 6, 0.0961124909768421), ('disc', 0.25, 5, 0.18185981625380002)])
-def test_stored_hs_errors_h2(domain, s, noRef, stored):
-    """tests/cache_runFractional.py--domain{interval,disc}--sconst(0.25)--problemconstant--elementP1--solvercg-mg--matrixFormatH2"""
+@pytest.mark.parametrize('domain,s,noRef,stored,element', [('interval', 0.25, 6, 0.0961124909768421, 'P1'), ('disc', 0.25, 5, 0.18185981625380002, 'P1'),
+                                                           ('interval', 0.25, 6, 0.0862450787545702, 'P0'), ('interval', 0.25, 5, 0.061426533383912074, 'P3'),
+                                                           ('interval', 0.75, 5, 0.02241176678332564, 'P3'), ('disc', 0.25, 5, 0.13190712640577038, 'P0')])
+def test_stored_hs_errors_h2(domain, s, noRef, stored, element):
+    """tests/cache_runFractional.py--domain{interval,disc}--sconst(s)--problemconstant--element{P0,P1,P3}--solvercg-mg--matrixFormatH2"""
     from math import gamma, pi, sqrt
-    from pynucleus_amd import driverMesh, P1_DoFMap, PHYSICAL, getFractionalKernel, nonlocalBuilder
+    from pynucleus_amd import driverMesh, dofmapFactory, PHYSICAL, getFractionalKernel, nonlocalBuilder
     from pynucleus_amd.solvers import cg
     dim = 1 if domain == 'interval' else 2
-    dm = P1_DoFMap(driverMesh(domain, noRef), PHYSICAL)
-    params = {'target_order': 2.-s, 'eta': 1.} if dim == 1 else {'target_order': 0.5, 'eta': 3.}
+    dm = dofmapFactory(element, driverMesh(domain, noRef), PHYSICAL)
+    params = {'target_order': dm.polynomialOrder+1.-s, 'eta': 1.} if dim == 1 else {'target_order': 0.5, 'eta': 3.}
+    if dim == 2 and element == 'P0':
+        # 6144 DoFs with interpolation order 4: the Hs error depends on the leaf size at the per-cent level (0.1349 with this package's
+        # default leaves, 0.1316 with the reference's interpolation_order^dim // 2 (NA:3016-3024), 0.1403 dense or with order 8)
+        params['minClusterSize'] = 'reference'
     builder = nonlocalBuilder(dm, getFractionalKernel(dim, s), params)
     b = np.asarray(dm.assembleRHS(1.0))
     C = 2.**(-2.*s)*gamma(dim/2.)/gamma((dim+2.*s)/2.)/gamma(1.+s)

@@ -86,6 +86,21 @@ def test_variable_order_structure():
     assert np.abs(A1-A0).max() == 0.
 
 
+def test_disc_P0_stored_hs_error_s025():
+    """runFractional --domain disc --s const(0.25) --element P0 --matrixFormat dense (noRef 5, N = 6144 cells): stored Hs error
+    0.1403179566911808; P0 has no cancellation across elements (FL2:594-598), every cell is a DoF"""
+    from pynucleus_amd import dofmapFactory
+    s = 0.25
+    dm = dofmapFactory('P0', driverMesh('disc', 5), PHYSICAL)
+    assert dm.num_dofs == 6144 and dm.num_boundary_dofs == 0
+    A, cnt, _ = OracleProblem(nonlocalTables(dm, getFractionalKernel(2, s), {})).get_dense()
+    b = np.asarray(dm.assembleRHS(1.0))
+    u = np.linalg.solve(A, b)
+    hs = np.sqrt(abs(b@u-exact_hs_squared(2, s)[1]))
+    assert abs(hs-0.1403179566911808) <= 1e-5*0.1403179566911808, hs         # observed 4.3e-6 (triangle rules, as for P1)
+    assert np.abs(A-A.T).max() == 0. and cnt['numAssembledCellPairs'] == 6144*6145//2
+
+
 def test_disc_stored_hs_error_s025():
     """runFractional --domain disc --s const(0.25) --element P1 --matrixFormat dense (noRef 5, N = 2977):
     stored Hs error 0.1839933908571473"""
