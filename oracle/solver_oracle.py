@@ -80,6 +80,40 @@ def build_restriction_P2(dm_coarse, dm_fine):
     return R
 
 
+# buildRestriction_1D_P3 (restriction_1D_P3.pxi:50-76): coarse local DoF -> [(child, fine local DoF, weight)]
+_R_P3_1D = {0: [(0, 0, 1.0), (0, 1, -0.0625), (0, 2, 0.3125), (1, 3, 0.0625)],
+            1: [(0, 1, -0.0625), (0, 2, 0.0625), (1, 1, 1.0), (1, 3, 0.3125)],
+            2: [(0, 1, 0.5625), (0, 2, 0.9375), (0, 3, 1.0), (1, 3, -0.3125)],
+            3: [(0, 1, 0.5625), (0, 2, -0.3125), (1, 2, 1.0), (1, 3, 0.9375)]}
+
+
+def build_restriction_P3(dm_coarse, dm_fine):
+    assert dm_coarse.mesh.manifold_dim == 1
+    R = np.zeros((dm_coarse.num_dofs, dm_fine.num_dofs))
+    for c in range(dm_coarse.mesh.num_cells):
+        for loc, entries in _R_P3_1D.items():
+            I = dm_coarse.dofs[c, loc]
+            if I < 0:
+                continue
+            for child, floc, w in entries:
+                J = dm_fine.dofs[2*c+child, floc]
+                if J >= 0:
+                    R[I, J] = w
+    return R
+
+
+def build_restriction_P0(dm_coarse, dm_fine):
+    """buildRestriction_{1,2}D_P0 (restriction_1D_P0.pxi:18-38, restriction_2D_P0.pxi): weight 1 to every child of the cell"""
+    nchild = 2 if dm_coarse.mesh.manifold_dim == 1 else 4
+    R = np.zeros((dm_coarse.num_dofs, dm_fine.num_dofs))
+    for c in range(dm_coarse.mesh.num_cells):
+        I = dm_coarse.dofs[c, 0]
+        if I >= 0:
+            for child in range(nchild):
+                R[I, dm_fine.dofs[nchild*c+child, 0]] = 1.0
+    return R
+
+
 class Multigrid:
     """levels[l] = {'A': dense operator, 'R': restriction to level l-1, 'P': prolongation from it}; level 0 = coarsest."""
 

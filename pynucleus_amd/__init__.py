@@ -7,7 +7,7 @@ of the reference interface: meshes, DoF maps, kernels and nonlocalBuilder.
 """
 from .mesh import (mesh1d, mesh2d, simpleInterval, uniformSquare, uniform_disc, disc, interval, driverMesh,  # noqa: F401
                    PHYSICAL, NO_BOUNDARY, INTERIOR, INTERIOR_NONOVERLAPPING)
-from .dofmap import P1_DoFMap, P2_DoFMap, dofmapFactory, fe_vector  # noqa: F401
+from .dofmap import P0_DoFMap, P1_DoFMap, P2_DoFMap, P3_DoFMap, dofmapFactory, fe_vector  # noqa: F401
 from .kernels import (getKernel, getFractionalKernel, getIntegrableKernel, kernelFactory,  # noqa: F401
                       FRACTIONAL, INDICATOR, PERIDYNAMIC, GAUSSIAN, EXPONENTIAL, constFractionalOrder, constant, ball2_retriangulation, ball2_barycenter, ellipse_retriangulation, ellipse_barycenter)
 from .local_matrix import nonlocalTables  # noqa: F401

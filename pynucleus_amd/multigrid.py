@@ -128,8 +128,8 @@ class fractionalHierarchy:
         from .dofmap import dofmapFactory
         from .mesh import PHYSICAL
         from .builder import nonlocalBuilder
-        if element not in ('P1', 'P2'):
-            raise NotImplementedError('hierarchies are built for P1 and P2 elements (restriction_*_P1.pxi, _P2.pxi); got {}'.format(element))
+        if element not in ('P0', 'P1', 'P2', 'P3'):
+            raise NotImplementedError('hierarchies are built for P0 .. P3 elements (restriction_*_P{{0,1,2,3}}.pxi); got {}'.format(element))
         self.kernel, self.params = kernel, dict(params or {})
         mesh = mesh if mesh is not None else _seed_mesh(domain)
         self.levels = []
