@@ -43,8 +43,12 @@ enum pnl_status {
 };
 
 /* PNL_GAUSSIAN: scale exp(exponent |x-y|^2), exponent = -1/(horizon/3)^2 or -1/(2 variance^dim) (kernelsCy.pyx:388-416, 687-692);
- * PNL_EXPONENTIAL: scale exp(exponent |x-y|), exponent = -rate (kernelsCy.pyx:448-462) */
-enum pnl_kernel_type { PNL_FRACTIONAL = 0, PNL_INDICATOR = 1, PNL_PERIDYNAMIC = 2, PNL_GAUSSIAN = 3, PNL_EXPONENTIAL = 4 };
+ * PNL_EXPONENTIAL: scale exp(exponent |x-y|), exponent = -rate (kernelsCy.pyx:448-462);
+ * PNL_GAUSSIAN_BOUNDARY / PNL_EXPONENTIAL_BOUNDARY: their Gauss-theorem twins on the full space, to be set as the boundary kernel
+ * (kernelsCy.pyx:418-477): 1D scale sqrt(pi / -exponent) erfc(sqrt(-exponent) |x-y|), 2D scale exp(exponent |x-y|^2) / (-exponent |x-y|);
+ * 2 scale exp(exponent |x-y|) / -exponent */
+enum pnl_kernel_type { PNL_FRACTIONAL = 0, PNL_INDICATOR = 1, PNL_PERIDYNAMIC = 2, PNL_GAUSSIAN = 3, PNL_EXPONENTIAL = 4,
+                       PNL_GAUSSIAN_BOUNDARY = 5, PNL_EXPONENTIAL_BOUNDARY = 6 };
 
 /* gamma(x,y) = scale * (|x-y|^2)^exponent inside |x-y|^2 <= horizon2 (inf: everywhere).
  * Replaces the opaque c_kernel_params block + kernelFun pointer (kernel_params.pxi:8-30,

@@ -34,7 +34,13 @@ static inline double kernel_eval(const nlo_kernel *K, double d2) {
     case 1: return K->scale;
     case 2: return K->scale/sqrt(d2);
     case 3: return K->scale*exp(K->exponent*d2);          /* gaussianKernel1D / 2D, KC:388-416: C exp(-d2 invD), exponent = -invD */
-    default: return K->scale*exp(K->exponent*sqrt(d2));    /* exponentialKernel, KC:448-462: C exp(-a |x-y|), exponent = -a */
+    case 4: return K->scale*exp(K->exponent*sqrt(d2));     /* exponentialKernel, KC:448-462: C exp(-a |x-y|), exponent = -a */
+    /* Gauss-theorem twins on the full space; gammainc(a, x) = Gamma(a) gammaincc(a, x) (KC:39-40): Gamma(1/2, z) = sqrt(pi) erfc(sqrt z),
+     * Gamma(1, z) = exp(-z).  5: gaussianKernel1Dboundary KC:418-430, 7: gaussianKernel2Dboundary KC:433-445 (oracle.py picks by
+     * dimension), 6: exponentialKernelBoundary KC:463-477 */
+    case 5: return K->scale*sqrt(1./(d2*-K->exponent))*(sqrt(M_PI)*erfc(sqrt(d2*-K->exponent)))*sqrt(d2);
+    case 7: return K->scale*(1./(d2*-K->exponent))*exp(K->exponent*d2)*sqrt(d2);
+    default: return 2.0*K->scale*exp(K->exponent*sqrt(d2))/(-K->exponent);
     }
 }
 

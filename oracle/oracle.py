@@ -99,7 +99,10 @@ def lib():
 
 def _kern(k):
     p = k.device_params()
-    return nlo_kernel(p['ktype'], p.get('interaction', 0), p['exponent'], p['scale'], p['horizon2'])
+    ktype = p['ktype']
+    if ktype == 5 and p.get('dim', 1) == 2:
+        ktype = 7                                          # Gaussian boundary kernel in 2D (nl_oracle.c kernel_eval: by dimension)
+    return nlo_kernel(ktype, p.get('interaction', 0), p['exponent'], p['scale'], p['horizon2'])
 
 
 def _qo(f):

@@ -525,14 +525,20 @@ class OracleTables:
             self.singular[p] = Rule(nodes, w, psi, p0, p1)
 
         # ---- the Gauss-theorem twin for Omega x Omega^c (NA:953-955; kernelsCy.pyx:1982-2010: same s, phi = 1/s, one power less)
-        self.has_boundary_tables = ktype == FRACTIONAL and not finite
+        self.has_boundary_tables = ktype in (FRACTIONAL, GAUSSIAN, EXPONENTIAL) and not finite
         if self.zeroExterior and not self.has_boundary_tables:
-            raise NotImplementedError('zeroExterior needs a fractional kernel')
+            raise NotImplementedError('zeroExterior needs a fractional, Gaussian or exponential kernel on the full space')
         if not self.has_boundary_tables:
             return
-        bsing = 1.-dim-2.*s
-        self.boundaryKernel = KernelBlock(FRACTIONAL, 0.5*bsing, self.kernel.scale/s, horizon)
-        bmin_sing, bmax_sing = (bsing, bsing) if _sing_range is None else (1.-dim-2.*_sing_range[0], 1.-dim-2.*_sing_range[1])
+        if ktype == FRACTIONAL:
+            bsing = 1.-dim-2.*s
+            self.boundaryKernel = KernelBlock(FRACTIONAL, 0.5*bsing, self.kernel.scale/s, horizon)
+        else:
+            # kernelsCy.pyx:1194-1218: the same type, scaling and exponentInverse with boundary = True; kernelFun :418-477 (block ids 5 / 7
+            # Gaussian in 1D / 2D, 6 exponential: nl_oracle.c kernel_eval); singularity 0 (:657-664)
+            bsing = 0.
+            self.boundaryKernel = KernelBlock((5 if dim == 1 else 7) if ktype == GAUSSIAN else 6, self.kernel.exponent, self.kernel.scale, horizon)
+        bmin_sing, bmax_sing = (bsing, bsing) if (_sing_range is None or ktype != FRACTIONAL) else (1.-dim-2.*_sing_range[0], 1.-dim-2.*_sing_range[1])
         bt = params.get('target_order', None)
         bqd = params.get('quad_order_diagonal', None)
         if dim == 2:

@@ -139,6 +139,10 @@ __device__ __forceinline__ double pnl_pow_tab(double x, const DevKernel &k, cons
 // KT: 0 general (pow / indicator / peridynamic, horizon test), 1 fractional with exponent -qm/4, qm a run-time (wave-uniform)
 // value, 2 the same with qm == 6 known at compile time (s = 1/2 in 2D): no branch per evaluation, so the compiler
 // interleaves the dependent chains of the independent evaluations of a pair.
+// erfc of the device library, kept out of line: it is evaluated by one boundary kernel (Gaussian, 1D) and would otherwise be inlined
+// into the general branch of every KT == 0 hot loop (library 9.3 -> 13.3 MB, compile 3.2 -> 5.2 min)
+__device__ __noinline__ static double pnl_erfc(double x) { return erfc(x); }
+
 // KT == 3 is not a kernel instantiation of its own: the KT == 0 kernels enter their hot loops with it when the kernel is fractional
 // with power tables in LDS and no horizon (kern_eval_pow_ok) -- the general branch below tests the horizon per lane and switches on
 // the kernel type per evaluation, which costs more than the branches: no two evaluations are ever scheduled together.
@@ -216,7 +220,14 @@ __device__ __forceinline__ double kern_eval(const DevKernel &k, double d2, const
         if (k.ktype == 1) return k.scale;
         if (k.ktype == 2) return k.scale/sqrt(d2);
         if (k.ktype == 3) return k.scale*pnl_exp(k.exponent*d2);              // Gaussian: exponent = -1 / (2 variance^d) or -9 / horizon^2
-        return k.scale*pnl_exp(k.exponent*sqrt(d2));                          // exponential: exponent = -rate
+        if (k.ktype == 4) return k.scale*pnl_exp(k.exponent*sqrt(d2));        // exponential: exponent = -rate
+        // Gauss-theorem twins of the integrable kernels on the full space (kernelsCy.pyx:418-477; gammainc(a, x) there is the
+        // unnormalised upper incomplete Gamma function, :39-40): 5 Gaussian 1D, 6 exponential; 7 / 8 the 2D forms with the
+        // 1 / |x-y| of the normal factor folded in (DevProblem::bkn)
+        if (k.ktype == 5) return k.scale*sqrt(3.14159265358979323846/(-k.exponent))*pnl_erfc(sqrt(-k.exponent*d2));
+        if (k.ktype == 6) return 2.*k.scale*pnl_exp(k.exponent*sqrt(d2))/(-k.exponent);
+        if (k.ktype == 7) return k.scale*pnl_exp(k.exponent*d2)/(-k.exponent*d2);
+        return 2.*k.scale*pnl_exp(k.exponent*sqrt(d2))/(-k.exponent*sqrt(d2));
     }
 }
 

@@ -436,6 +436,8 @@ void refresh_tables(pnl_context *ctx) {
         if (ctx->dim == 2 && kn.ktype == PNL_FRACTIONAL) kn.exponent -= 0.5;
         P.bkn = to_dev(kn, ctx->dim);
         if (ctx->dim == 2 && kn.ktype != PNL_FRACTIONAL) P.bkn.fast = 0;
+        if (ctx->dim == 2 && kn.ktype == PNL_GAUSSIAN_BOUNDARY) P.bkn.ktype = 7;        // kern_eval (pnl_common.h): folded 2D forms
+        if (ctx->dim == 2 && kn.ktype == PNL_EXPONENTIAL_BOUNDARY) P.bkn.ktype = 8;
     }
     P.qo = to_dev(ctx->C().form[0]);
     P.bqo = to_dev(ctx->C().form[1]);
@@ -1967,7 +1969,7 @@ int pnl_select_class(pnl_context *ctx, int k) {
 
 int pnl_set_kernel(pnl_context *ctx, int which, const pnl_kernel *k) {
     if (!ctx || !k || which < 0 || which > 1) return fail(ctx, PNL_ERR_INVALID, "bad kernel arguments");
-    if (k->ktype < 0 || k->ktype > 4) return fail(ctx, PNL_ERR_UNSUPPORTED, "kernel type %d is not implemented", k->ktype);
+    if (k->ktype < 0 || k->ktype > PNL_EXPONENTIAL_BOUNDARY) return fail(ctx, PNL_ERR_UNSUPPORTED, "kernel type %d is not implemented", k->ktype);
     if (!std::isinf(k->horizon2) && (k->interaction < 1 || k->interaction > 2 || !(k->horizon2 > 0.)))
         return fail(ctx, PNL_ERR_UNSUPPORTED, "finite horizon: interaction %d is not implemented (1 ball2_retriangulation, 2 ball2_barycenter)",
                     k->interaction);

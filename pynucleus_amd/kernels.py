@@ -24,6 +24,9 @@ INDICATOR = 1
 PERIDYNAMIC = 2
 GAUSSIAN = 3
 EXPONENTIAL = 4
+# device ids of the Gauss-theorem twins of the integrable kernels on the full space (kernelsCy.pyx:418-477)
+GAUSSIAN_BOUNDARY = 5
+EXPONENTIAL_BOUNDARY = 6
 
 _KERNEL_NAMES = {'FRACTIONAL': FRACTIONAL, 'INDICATOR': INDICATOR, 'CONSTANT': INDICATOR,
                  'PERIDYNAMIC': PERIDYNAMIC, 'INVERSEDISTANCE': PERIDYNAMIC, 'INVERSEOFDISTANCE': PERIDYNAMIC,
@@ -234,7 +237,10 @@ class Kernel:
     def device_params(self):
         """POD block handed to pnl_set_kernel: (type, dim, exponent, scale, horizon^2)."""
         h2 = self.horizonValue**2 if self.finiteHorizon else np.inf
-        return dict(ktype=int(self.kernelType), dim=self.dim, exponent=float(self.exponent),
+        ktype = int(self.kernelType)
+        if self.boundary and self.kernelType in (GAUSSIAN, EXPONENTIAL):
+            ktype = GAUSSIAN_BOUNDARY if self.kernelType == GAUSSIAN else EXPONENTIAL_BOUNDARY
+        return dict(ktype=ktype, dim=self.dim, exponent=float(self.exponent),
                     scale=float(self.scalingValue), horizon2=float(h2), boundary=bool(self.boundary),
                     interaction=int(getattr(self.interaction, 'device_id', 0)) if self.finiteHorizon else 0)
 
@@ -247,8 +253,17 @@ class Kernel:
         if self.finiteHorizon and not d2 <= self.horizonValue**2:
             return 0.
         if self.kernelType == GAUSSIAN:
+            if self.boundary:
+                # kernelsCy.pyx:418-445 with gammainc(a, x) = Gamma(a) * gammaincc(a, x) (:39-40): Gamma(1/2, z) = sqrt(pi) erfc(sqrt z),
+                # Gamma(1, z) = exp(-z)
+                from scipy.special import erfc
+                z = d2*self.exponentInverse
+                return self.scalingValue*(np.sqrt(np.pi/self.exponentInverse)*erfc(np.sqrt(z)) if self.dim == 1
+                                          else np.exp(-z)/(self.exponentInverse*np.sqrt(d2)))
             return self.scalingValue*np.exp(self.exponent*d2)
         if self.kernelType == EXPONENTIAL:
+            if self.boundary:
+                return 2.0*self.scalingValue*np.exp(self.exponent*np.sqrt(d2))/self.exponentInverse      # kernelsCy.pyx:463-477
             return self.scalingValue*np.exp(self.exponent*np.sqrt(d2))
         return self.scalingValue*d2**self.exponent
 
@@ -259,10 +274,18 @@ class Kernel:
         raise NotImplementedError()
 
     def getBoundaryKernel(self):
-        raise NotImplementedError()
+        """kernelsCy.pyx:1194-1218: the same type with boundary = True, the same scaling and exponentInverse"""
+        if self.kernelType not in (GAUSSIAN, EXPONENTIAL) or self.finiteHorizon:
+            raise NotImplementedError('Gauss-theorem twin of kernel type {} / a finite horizon'.format(self.kernelType))
+        k = getIntegrableKernel(self.dim, self.kernelType, self.horizon, scaling=self.scaling, phi=self.phi, piecewise=self.piecewise,
+                                boundary=True, variance=getattr(self, 'variance', 1.0), exponentialRate=getattr(self, 'exponentialRate', 1.0))
+        k.exponentInverse = self.exponentInverse
+        k.normalized = getattr(self, 'normalized', True)
+        return k
 
     def __repr__(self):
-        name = {FRACTIONAL: 'fractional', INDICATOR: 'indicator', PERIDYNAMIC: 'peridynamic'}[self.kernelType]
+        name = {FRACTIONAL: 'fractional', INDICATOR: 'indicator', PERIDYNAMIC: 'peridynamic', GAUSSIAN: 'gaussian',
+                EXPONENTIAL: 'exponential'}[self.kernelType]
         return 'kernel({}{}, {}, {})'.format(name, '-boundary' if self.boundary else '', self.interaction, self.scalingValue)
 
 

@@ -17,7 +17,7 @@ import numpy as np
 from .quadrature import (COMMON_VERTEX, COMMON_EDGE, COMMON_FACE, simplexXiaoGimbutas, simplexDuffyTransformation,
                          singularityCancelationQuadRule1D, singularityCancelationQuadRule1D_boundary,
                          singularityCancelationQuadRule2D, singularityCancelationQuadRule2D_boundary)
-from .kernels import FRACTIONAL
+from .kernels import GAUSSIAN, EXPONENTIAL, FRACTIONAL
 
 MAX_PANEL = 120       # nonlocalOperator.pyx:107
 QCAP_DEFAULT = 60     # highest distant order we tabulate up-front (the reference adds rules lazily)
@@ -124,9 +124,10 @@ class nonlocalTables:
         self._distant_rules(qcap)
         # surface integrals (NA:953-955): the Gauss-theorem twin is built whenever it exists, not only for zeroExterior --
         # the cluster-local boundary term of assembleClusters (NA:1842-1889) needs it too
-        self.has_boundary_tables = kernel.kernelType == FRACTIONAL and not kernel.finiteHorizon
+        # (the integrable kernels of the full space, Gaussian and exponential, have one as well: kernelsCy.pyx:418-477)
+        self.has_boundary_tables = kernel.kernelType in (FRACTIONAL, GAUSSIAN, EXPONENTIAL) and not kernel.finiteHorizon
         if self.zeroExterior and not self.has_boundary_tables:
-            raise NotImplementedError('zeroExterior needs a fractional kernel')
+            raise NotImplementedError('zeroExterior needs a fractional, Gaussian or exponential kernel on the full space')
         if self.has_boundary_tables:
             bk = kernel.getBoundaryKernel()
             if (kernel.min_singularity, kernel.max_singularity) != (sing, sing):

@@ -663,3 +663,43 @@ def test_fe_fractional_order_dense(case):
         A1 = nonlocalBuilder(dm, getFractionalKernel(2, feFractionalOrder(ul, 0.1, 0.9, dm=dms)), {}).getDense().toarray()
         A2 = OracleProblem(nonlocalTables(dm, getFractionalKernel(2, linearLeftRightFractionalOrder(0.1, 0.9, r=2.)), {})).get_dense()[0]
         assert np.abs(A1-A2).max() < TOL*np.abs(A2).max()
+
+
+@pytest.mark.parametrize('case', ['gaussian_1d', 'exponential_1d', 'gaussian_1d_P2', 'gaussian_2d', 'exponential_noext'])
+def test_full_space_integrable_kernels_dense(case):
+    """Gaussian / exponential kernels on the full space (kernelsCy.pyx:388-477): interior pairs with the branchy general kern_eval,
+    exterior term with the Gauss-theorem twins PNL_GAUSSIAN_BOUNDARY / PNL_EXPONENTIAL_BOUNDARY (erfc in 1D; in 2D the 1/|x-y| of the
+    normal factor is folded in); entries and counters against the oracle"""
+    from pynucleus_amd import disc, interval, PHYSICAL, dofmapFactory, getKernel
+    from pynucleus_amd.builder import nonlocalBuilder
+    name = case.split('_')[0]
+    kw = {'variance': 0.1} if name == 'gaussian' else {'exponentialRate': 8.}
+    if case.endswith('2d'):
+        if name == 'exponential':
+            pytest.skip('the exponential kernel is normalised in 1D only (kernelNormalization.pyx:275-282)')
+        mesh, element = disc(2), 'P1'
+    else:
+        mesh, element = interval(5), ('P2' if case.endswith('P2') else 'P1')
+    dm = dofmapFactory(element, mesh, PHYSICAL)
+    k = getKernel(mesh.dim, kernel=name, horizon=np.inf, **kw)
+    _compare(nonlocalBuilder(dm, k, {}, zeroExterior=not case.endswith('noext')))
+
+
+@pytest.mark.parametrize('name,kw,stored_l2,stored_linf', [('gaussian', {'variance': 0.1}, 0.0029565447289171816, 0.006737946999085467),
+                                                           ('exponential', {'exponentialRate': 8.}, 0.00025530396949181036, 0.00033546262790251185)])
+def test_full_space_integrable_fixtures_through_the_gpu(name, kw, stored_l2, stored_linf):
+    """tests/cache_runNonlocal.py--domaininterval--kernelType{gaussian,exponential}--...--matrixFormatH2--...--interactionfullSpace--horizoninf
+    through the product path, dense and H2 (the stored runs are H2): 'Linf error interpolated' to the last digits, 'L2 error
+    interpolated' to 1e-6 / 1e-4 dense and H2"""
+    from pynucleus_amd import driverMesh, P1_DoFMap, PHYSICAL, NO_BOUNDARY, getKernel
+    from pynucleus_amd.builder import nonlocalBuilder
+    from test_kernels import full_space_errors
+    mesh = driverMesh('interval', 8)
+    dm, dmA = P1_DoFMap(mesh, PHYSICAL), P1_DoFMap(mesh, NO_BOUNDARY)
+    k = getKernel(1, kernel=name, horizon=np.inf, **kw)
+    b = nonlocalBuilder(dm, k, {})
+    l2, linf = full_space_errors(name, kw, k, dm, dmA, b.getDense().toarray())
+    assert abs(l2-stored_l2) <= (1e-6 if name == 'gaussian' else 1e-4)*stored_l2 and abs(linf-stored_linf) <= 1e-11*stored_linf, (l2, linf)
+    H = b.getH2()
+    l2h, linfh = full_space_errors(name, kw, k, dm, dmA, H.toarray())
+    assert abs(l2h-stored_l2) <= 1e-4*stored_l2 and abs(linfh-stored_linf) <= 1e-8*stored_linf, (l2h, linfh)
