@@ -146,7 +146,11 @@ __device__ __noinline__ static double pnl_erfc(double x) { return erfc(x); }
 // KT == 3 is not a kernel instantiation of its own: the KT == 0 kernels enter their hot loops with it when the kernel is fractional
 // with power tables in LDS and no horizon (kern_eval_pow_ok) -- the general branch below tests the horizon per lane and switches on
 // the kernel type per evaluation, which costs more than the branches: no two evaluations are ever scheduled together.
-template <int KT>
+// BND: the kernel may be a Gauss-theorem twin of an integrable kernel (types 5 .. 8: only boundary kernels are).  Their formulas --
+// erfc above all -- stay out of the kernels that integrate element pairs: the register allocation of a kernel is the maximum over
+// its paths, and with them in the general branch k_worklist_sorted<2, 3, 0> went from 240 VGPRs to 256 + 56 AGPRs, i.e. from two
+// waves per SIMD to one, also for the fractional kernels that never take that branch (8.5 instead of 6.1 ms at 98,304 cells, s = 0.4).
+template <int KT, bool BND = false>
 __device__ __forceinline__ double kern_eval(const DevKernel &k, double d2, const double *__restrict__ ltab = nullptr) {
     if (KT == 3) return pnl_pow_tab(d2, k, ltab);
     if (KT == 4) return k.scale;                        // constant kernel on a pair that lies inside the horizon (kern_dispatch<0, true>)
@@ -220,7 +224,7 @@ __device__ __forceinline__ double kern_eval(const DevKernel &k, double d2, const
         if (k.ktype == 1) return k.scale;
         if (k.ktype == 2) return k.scale/sqrt(d2);
         if (k.ktype == 3) return k.scale*pnl_exp(k.exponent*d2);              // Gaussian: exponent = -1 / (2 variance^d) or -9 / horizon^2
-        if (k.ktype == 4) return k.scale*pnl_exp(k.exponent*sqrt(d2));        // exponential: exponent = -rate
+        if (k.ktype == 4 || !BND) return k.scale*pnl_exp(k.exponent*sqrt(d2));       // exponential: exponent = -rate
         // Gauss-theorem twins of the integrable kernels on the full space (kernelsCy.pyx:418-477; gammainc(a, x) there is the
         // unnormalised upper incomplete Gamma function, :39-40): 5 Gaussian 1D, 6 exponential; 7 / 8 the 2D forms with the
         // 1 / |x-y| of the normal factor folded in (DevProblem::bkn)

@@ -224,10 +224,22 @@ template <int DIM, int DPE, int KT, int CM>
 __device__ __forceinline__ void eval_distant_worklist(const DevProblem &P, const double *__restrict__ tab, int stp, int n, int n4,
                                                       int i_first, int i_step, const double *av, const double *bv,
                                                       PairAcc<DIM, DPE> &R, const double *__restrict__ lpow, double *sc, int cstride) {
-    kern_dispatch<KT>(P.k, lpow, [&](auto ktag) {
-        constexpr int KTE = decltype(ktag)::value;
-        eval_distant_blocked<DIM, DPE, KTE, KTE == 3, CM>(P.k, tab, stp, n, n4, i_first, i_step, av, bv, R, lpow, sc, cstride);
-    });
+    // kern_dispatch spelled out: through the generic lambda (captures by reference) the callers took 40 .. 70 registers more --
+    // k_worklist_sorted<2, 3, 0> 256 VGPRs + 32 AGPRs instead of 240, one wave per SIMD instead of two
+#define PNL_WL_EVAL(KTE, PT) eval_distant_blocked<DIM, DPE, KTE, PT, CM>(P.k, tab, stp, n, n4, i_first, i_step, av, bv, R, lpow, sc, cstride)
+    if constexpr (KT == 0) {
+        if (kern_eval_pow_ok(P.k, lpow)) PNL_WL_EVAL(3, true);
+        else PNL_WL_EVAL(0, false);
+    } else if constexpr (KT == 1) {
+        switch (P.k.qm) {
+        case 3: PNL_WL_EVAL(13, false); break;
+        case 4: PNL_WL_EVAL(14, false); break;
+        case 5: PNL_WL_EVAL(15, false); break;
+        case 7: PNL_WL_EVAL(17, false); break;
+        default: PNL_WL_EVAL(1, false); break;
+        }
+    } else PNL_WL_EVAL(KT, false);
+#undef PNL_WL_EVAL
 }
 // P2: column sums through LDS (see eval_distant_blocked); bytes of dynamic LDS the one-pair-per-lane kernel needs for them
 __host__ __device__ constexpr bool wl_csum_lds(int dpe) { return dpe > 3; }
@@ -2590,7 +2602,7 @@ k_boundary_distant(const DevProblem P, double *__restrict__ Dglob, int cell_begi
                     if (DIM == 2) nw = __builtin_fma(nrm[d], wv, nw);
                 }
                 if (DIM != 2) nw = 1.;
-                r = __builtin_fma(fw[m]*nw, kern_eval<KT>(bkn, d2), r);
+                r = __builtin_fma(fw[m]*nw, kern_eval<KT, true>(bkn, d2), r);
             }
             r *= w[k]*vol;
             int e = 0;
@@ -2707,7 +2719,7 @@ k_boundary_singular(const DevProblem P, const int2 *__restrict__ pairs, int npai
             if (DIM == 2) nw = __builtin_fma(nrm[d], wv, nw);
         }
         if (DIM != 2) nw = 1.;
-        const double t = w[m]*nw*kern_eval<KT>(P.bkn, d2);
+        const double t = w[m]*nw*kern_eval<KT, true>(P.bkn, d2);
         double ps[DPE];
 #pragma unroll
         for (int r = 0; r < DPE; r++) ps[r] = PHI[(size_t)r*M+m];
@@ -2918,7 +2930,7 @@ k_boundary_items(const DevProblem P, const double *__restrict__ verts, const int
                     if (DIM == 2) nw = __builtin_fma(nrm[d], wv, nw);
                 }
                 if (DIM != 2) nw = 1.;
-                const double t = (P.w[off+i]*P.fw[foff+m])*nw*kern_eval<KT>(bkn, d2);
+                const double t = (P.w[off+i]*P.fw[foff+m])*nw*kern_eval<KT, true>(bkn, d2);
                 int e = 0;
 #pragma unroll
                 for (int a = 0; a < DPE; a++) {
@@ -2974,7 +2986,7 @@ k_boundary_items(const DevProblem P, const double *__restrict__ verts, const int
                     if (DIM == 2) nw = __builtin_fma(nrm[d], wv, nw);
                 }
                 if (DIM != 2) nw = 1.;
-                const double t = w[m]*nw*kern_eval<KT>(bkn, d2);
+                const double t = w[m]*nw*kern_eval<KT, true>(bkn, d2);
                 double ps[DPE];
 #pragma unroll
                 for (int r = 0; r < DPE; r++) ps[r] = PHI[(size_t)r*M+m];
@@ -3164,7 +3176,7 @@ k_cluster_boundary(const DevProblem P, const double *__restrict__ verts, const i
                     if (DIM == 2) nw = __builtin_fma(nrm[dd], wv, nw);
                 }
                 if (DIM != 2) nw = 1.;
-                r = __builtin_fma(fw[m]*nw, kern_eval<KT>(P.bkn, d2), r);
+                r = __builtin_fma(fw[m]*nw, kern_eval<KT, true>(P.bkn, d2), r);
             }
             r *= w[i]*vol;
             int e = 0;
