@@ -408,8 +408,10 @@ int finalize(pnl_context *ctx) {
 // Tables of pnl_pow_tab for x^exponent * scale (long double on the host, rounded once):  x = 2^k m, m in [1, 2), j = top seven
 // fraction bits of m, c_j = 1 / fl(1 / (1 + (j + 1/2) / 128)), u = m fl(1/c_j) - 1 (one FMA, |u| <= 2^-8):
 //   x^e = 2^(e k) c_j^e (1 + u)^e.
-static const double *pow_table(pnl_context *ctx, const DevKernel &k) {
-    if (k.ktype != PNL_FRACTIONAL || k.fast || pnl_tune("PNL_NO_POWTAB")) return nullptr;
+// also_fast: tables for an exponent -qm/4 as well -- a launch over the tiles of SEVERAL order classes runs the KT == 0 kernels for
+// all of them, and a class without tables falls into the general branch there (exp(e ln x) behind the per-lane horizon test)
+static const double *pow_table(pnl_context *ctx, const DevKernel &k, bool also_fast = false) {
+    if (k.ktype != PNL_FRACTIONAL || (k.fast && !also_fast) || pnl_tune("PNL_NO_POWTAB")) return nullptr;
     for (auto *t : ctx->powtabs) if (t->exponent == k.exponent && t->scale == k.scale) return (const double*)t->buf.p;
     std::vector<double> tab(PNL_POW_TAB_DOUBLES);
     for (int j = 0; j < 128; j++) {
@@ -816,6 +818,10 @@ int launch_tiles_single(pnl_context *ctx, double *A, int64_t ldA, int cell_begin
         all_half = all_half && ctx->P.k.fast && ctx->P.k.qm == 6;
     }
     const int kt = (all_half && !pnl_tune("PNL_NO_KT2")) ? 2 : (all_fast ? 1 : 0);
+    if (kt == 0)
+        // three layers with s = 0.3 .. 0.7: the class s = 1/2 (half of the pairs) is a "fast" kernel without tables of its own
+        for (int k = 0; k < ncls; k++)
+            if (!ctx->kcls_host[k].ptab) ctx->kcls_host[k].ptab = pow_table(ctx, ctx->kcls_host[k], true);
     if ((rc = ensure(ctx, ctx->b_kcls, sizeof(DevKernel)*ncls))) return rc;
     if ((rc = ensure(ctx, ctx->b_fcls, sizeof(DevFormula)*ncls))) return rc;
     HIPCHK(ctx, hipMemcpyAsync(ctx->b_kcls.p, ctx->kcls_host.data(), sizeof(DevKernel)*ncls, hipMemcpyHostToDevice, ctx->stream));
