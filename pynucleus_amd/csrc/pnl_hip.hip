@@ -989,7 +989,10 @@ int assemble_impl(pnl_context *ctx, double *A, int64_t ldA, int zero_exterior, i
     ctx->orient = 0;
     if (overlap) {
         HIPCHK(ctx, hipEventRecord(ctx->ev_join[0], ctx->aux[0]));
-        HIPCHK(ctx, hipStreamWaitEvent(ctx->aux[1], ctx->ev_fold, 0));
+        // the boundary term only adds to the per-cell diagonal blocks (b_D, scattered into A at the very end): its stream starts
+        // behind the zero fill of that buffer, not behind the fold -- the kernels run in the slack of the tile kernels instead of in
+        // the window after the fold
+        HIPCHK(ctx, hipStreamWaitEvent(ctx->aux[1], pnl_tune("PNL_BND_AFTER_FOLD") ? ctx->ev_fold : ctx->ev[0], 0));
         ctx->stream = zero_exterior ? ctx->aux[1] : main_stream;
     } else HIPCHK(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
     if (zero_exterior) {
