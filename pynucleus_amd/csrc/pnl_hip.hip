@@ -917,6 +917,45 @@ int assemble_impl(pnl_context *ctx, double *A, int64_t ldA, int zero_exterior, i
         HIPCHK(ctx, hipMemcpyAsync(ctx->b_bkcls.p, bk.data(), sizeof(DevKernel)*ncls, hipMemcpyHostToDevice, ctx->stream));
         HIPCHK(ctx, hipMemcpyAsync(ctx->b_bfcls.p, bf.data(), sizeof(DevFormula)*ncls, hipMemcpyHostToDevice, ctx->stream));
     }
+    // Omega x Omega^c.  Variable order: the distant (cell, facet) pairs of ALL classes in one launch with per-class kernel /
+    // order-formula tables, the touching pairs per class (their rules are per class).  chain: fork over the side streams from that
+    // event (the order classes' streams after a fold); nullptr: everything on ctx->stream
+    auto boundary_term = [&](hipEvent_t chain) -> int {
+        int rcb;
+        ClassFork fork(ctx, chain ? ncls : 1, chain);
+        if (chain && ncls > pnl_context::NAUX && (int)ctx->cls_n_mixed.size() == ncls) fork.plan(ctx->cls_n_mixed);
+        for (int k = 0; k < ncls; k++) {
+            ctx->cur = k;
+            refresh_tables(ctx);
+            if (!ctx->have_boundary || !ctx->C().have_kernel[1] || !ctx->C().have_form[1]) {
+                ctx->cur = 0;
+                return fail(ctx, PNL_ERR_STATE, "zero_exterior needs boundary facets, boundary kernel and order formula");
+            }
+            if (chain) fork.use(k);
+            if (bnd_one_pass && k == 0 &&
+                (rcb = launch_boundary<DIM, DPE, 0>(ctx, cell_begin, cell_end, 1, (const DevKernel*)ctx->b_bkcls.p, (const DevFormula*)ctx->b_bfcls.p,
+                                                    bnd_all_fast))) { ctx->cur = 0; return rcb; }
+            if (chain) fork.use(k);
+            if ((rcb = launch_boundary<DIM, DPE, 0>(ctx, cell_begin, cell_end, bnd_one_pass ? 2 : 3))) { ctx->cur = 0; return rcb; }
+        }
+        ctx->cur = 0;
+        return PNL_OK;
+    };
+    // The boundary term only adds to the per-cell diagonal blocks (b_D, scattered into A at the very end) and never touches A: it
+    // runs on a side stream from the start, behind the zero fill of that buffer and the class tables, in the slack of the tile
+    // kernels instead of in the window after the fold (P1 s = 0.4: 136.5 -> 134.6 ms; C5: the 2-3 ms that were exposed at the end)
+    const bool early_bnd = zero_exterior && !pnl_tune("PNL_BND_AFTER_FOLD");
+    if (early_bnd) {
+        hipStream_t const caller = ctx->stream;
+        HIPCHK(ctx, hipEventRecord(ctx->ev_join[3], caller));
+        HIPCHK(ctx, hipStreamWaitEvent(ctx->aux[1], ctx->ev_join[3], 0));
+        ctx->stream = ctx->aux[1];
+        rc = boundary_term(nullptr);
+        ctx->stream = caller;
+        if (rc) return rc;
+        HIPCHK(ctx, hipEventRecord(ctx->ev_join[1], ctx->aux[1]));
+        refresh_tables(ctx);
+    }
     // a piecewise-constant variable order is assembled class by class: every pass sees the kernel, order formula and
     // singular rules of one order value and skips the pairs of the other classes in its classification
     const int norient = ctx->nonsym ? 2 : 1;
@@ -989,44 +1028,16 @@ int assemble_impl(pnl_context *ctx, double *A, int64_t ldA, int zero_exterior, i
     ctx->orient = 0;
     if (overlap) {
         HIPCHK(ctx, hipEventRecord(ctx->ev_join[0], ctx->aux[0]));
-        // the boundary term only adds to the per-cell diagonal blocks (b_D, scattered into A at the very end): its stream starts
-        // behind the zero fill of that buffer, not behind the fold -- the kernels run in the slack of the tile kernels instead of in
-        // the window after the fold
-        HIPCHK(ctx, hipStreamWaitEvent(ctx->aux[1], pnl_tune("PNL_BND_AFTER_FOLD") ? ctx->ev_fold : ctx->ev[0], 0));
-        ctx->stream = zero_exterior ? ctx->aux[1] : main_stream;
+        ctx->stream = main_stream;
     } else HIPCHK(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
-    if (zero_exterior) {
-        // variable order: the distant (cell, facet) pairs of ALL classes in one launch with per-class kernel / order-formula
-        // tables; the touching pairs per class (their rules are per class), on side streams
-        const bool one_pass = bnd_one_pass;
-        const bool all_fast = bnd_all_fast;
-        ClassFork fork(ctx, ncls, chain);
-        if (ncls > pnl_context::NAUX && (int)ctx->cls_n_mixed.size() == ncls) fork.plan(ctx->cls_n_mixed);
-        for (int k = 0; k < ncls; k++) {
-            ctx->cur = k;
-            refresh_tables(ctx);
-            if (!ctx->have_boundary || !ctx->C().have_kernel[1] || !ctx->C().have_form[1]) {
-                ctx->cur = 0;
-                return fail(ctx, PNL_ERR_STATE, "zero_exterior needs boundary facets, boundary kernel and order formula");
-            }
-            if (chain) fork.use(k);
-            if (one_pass && k == 0 &&
-                (rc = launch_boundary<DIM, DPE, 0>(ctx, cell_begin, cell_end, 1, (const DevKernel*)ctx->b_bkcls.p, (const DevFormula*)ctx->b_bfcls.p,
-                                                   all_fast))) { ctx->cur = 0; return rc; }
-            fork.use(k);
-            if ((rc = launch_boundary<DIM, DPE, 0>(ctx, cell_begin, cell_end, one_pass ? 2 : 3))) { ctx->cur = 0; return rc; }
-        }
-    }
+    if (zero_exterior && !early_bnd && (rc = boundary_term(chain))) return rc;
     ctx->cur = 0;
     if (overlap) {
-        if (zero_exterior) {
-            HIPCHK(ctx, hipEventRecord(ctx->ev_join[1], ctx->aux[1]));
-            HIPCHK(ctx, hipStreamWaitEvent(main_stream, ctx->ev_join[1], 0));
-        }
         HIPCHK(ctx, hipStreamWaitEvent(main_stream, ctx->ev_join[0], 0));
         ctx->stream = main_stream;
         HIPCHK(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
     }
+    if (early_bnd) HIPCHK(ctx, hipStreamWaitEvent(main_stream, ctx->ev_join[1], 0));        // the boundary term (side stream, from the start)
     HIPCHK(ctx, hipEventRecord(ctx->ev[4], ctx->stream));
     if (ctx->slab_rows == 0) {
         const long long nt = (long long)ctx->nc*DPE*DPE;
