@@ -34,6 +34,7 @@ struct pnl_context {
     // recorded behind the fold + mirror pass of a block-slot assembly: from here on A only receives atomic adds, so the touching
     // pairs and the boundary term run on side streams next to the work-list kernels (one order class)
     hipEvent_t ev_fold = nullptr;
+    hipEvent_t ev_bnd = nullptr;             // zero fill of the diagonal-block buffer + class tables of the boundary term are in the stream
     bool fold_event_set = false;
     std::string err;
     // host copies

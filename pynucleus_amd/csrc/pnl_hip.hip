@@ -884,6 +884,9 @@ bool slot_eligible(const pnl_context *ctx, int cell_begin, int cell_end, int fla
            !(flags & (PNL_FLAG_NO_MIRROR | PNL_FLAG_SYMMETRIC_FLUSH));
 }
 
+#ifndef PNL_BND_MODE_DEFAULT
+#define PNL_BND_MODE_DEFAULT 1
+#endif
 template <int DIM, int DPE, int TILE>
 int assemble_impl(pnl_context *ctx, double *A, int64_t ldA, int zero_exterior, int ntiles, int cell_begin, int cell_end, int flags) {
     int rc;
@@ -941,19 +944,27 @@ int assemble_impl(pnl_context *ctx, double *A, int64_t ldA, int zero_exterior, i
         ctx->cur = 0;
         return PNL_OK;
     };
-    // The boundary term only adds to the per-cell diagonal blocks (b_D, scattered into A at the very end) and never touches A: it
-    // runs on a side stream from the start, behind the zero fill of that buffer and the class tables, in the slack of the tile
-    // kernels instead of in the window after the fold (P1 s = 0.4: 136.5 -> 134.6 ms; C5: the 2-3 ms that were exposed at the end)
-    const bool early_bnd = zero_exterior && !pnl_tune("PNL_BND_AFTER_FOLD");
-    if (early_bnd) {
+    // The boundary term only adds to the per-cell diagonal blocks (b_D, scattered into A at the very end) and never touches A, so
+    // its stream needs nothing but the zero fill of that buffer and the class tables.  PNL_BND_MODE 1: side stream 1 behind that
+    // event, SUBMITTED after the tile and work-list kernels (the dispatcher takes the older kernels first: the boundary kernels
+    // fill their slack); 2: submitted first (measured: its waves then sit in front of the tile kernels, P1 s = 0.4 138 -> 173 ms);
+    // 0: behind the fold (one class: side stream 1, several: forked over the class streams)
+    const int bnd_mode = !zero_exterior ? -1 : pnl_tune("PNL_BND_MODE") ? atoi(pnl_tune("PNL_BND_MODE")) : PNL_BND_MODE_DEFAULT;
+    bool bnd_side = false;
+    auto boundary_side = [&](hipEvent_t after) -> int {
         hipStream_t const caller = ctx->stream;
-        HIPCHK(ctx, hipEventRecord(ctx->ev_join[3], caller));
-        HIPCHK(ctx, hipStreamWaitEvent(ctx->aux[1], ctx->ev_join[3], 0));
+        HIPCHK(ctx, hipStreamWaitEvent(ctx->aux[1], after, 0));
         ctx->stream = ctx->aux[1];
-        rc = boundary_term(nullptr);
+        const int rcb = boundary_term(nullptr);
         ctx->stream = caller;
-        if (rc) return rc;
+        if (rcb) return rcb;
         HIPCHK(ctx, hipEventRecord(ctx->ev_join[1], ctx->aux[1]));
+        bnd_side = true;
+        return PNL_OK;
+    };
+    if (bnd_mode > 0) HIPCHK(ctx, hipEventRecord(ctx->ev_bnd, ctx->stream));
+    if (bnd_mode == 2) {
+        if ((rc = boundary_side(ctx->ev_bnd))) return rc;
         refresh_tables(ctx);
     }
     // a piecewise-constant variable order is assembled class by class: every pass sees the kernel, order formula and
@@ -1030,14 +1041,16 @@ int assemble_impl(pnl_context *ctx, double *A, int64_t ldA, int zero_exterior, i
         HIPCHK(ctx, hipEventRecord(ctx->ev_join[0], ctx->aux[0]));
         ctx->stream = main_stream;
     } else HIPCHK(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
-    if (zero_exterior && !early_bnd && (rc = boundary_term(chain))) return rc;
+    if (bnd_mode == 1 || (bnd_mode == 0 && overlap)) rc = boundary_side(bnd_mode == 1 ? ctx->ev_bnd : ctx->ev_fold);
+    else if (bnd_mode == 0) rc = boundary_term(chain);
+    if (rc) return rc;
     ctx->cur = 0;
     if (overlap) {
         HIPCHK(ctx, hipStreamWaitEvent(main_stream, ctx->ev_join[0], 0));
         ctx->stream = main_stream;
         HIPCHK(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
     }
-    if (early_bnd) HIPCHK(ctx, hipStreamWaitEvent(main_stream, ctx->ev_join[1], 0));        // the boundary term (side stream, from the start)
+    if (bnd_side) HIPCHK(ctx, hipStreamWaitEvent(main_stream, ctx->ev_join[1], 0));
     HIPCHK(ctx, hipEventRecord(ctx->ev[4], ctx->stream));
     if (ctx->slab_rows == 0) {
         const long long nt = (long long)ctx->nc*DPE*DPE;
@@ -1813,6 +1826,7 @@ int pnl_create(int device_id, pnl_context **out) {
         if ((e0 = hipStreamCreateWithFlags(&st, hipStreamNonBlocking)) != hipSuccess) { delete ctx; return hiperr("hipStreamCreateWithFlags", e0); }
     if (hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess) { delete ctx; return PNL_ERR_HIP; }
     if (hipEventCreateWithFlags(&ctx->ev_fold, hipEventDisableTiming) != hipSuccess) { delete ctx; return PNL_ERR_HIP; }
+    if (hipEventCreateWithFlags(&ctx->ev_bnd, hipEventDisableTiming) != hipSuccess) { delete ctx; return PNL_ERR_HIP; }
     for (auto &e : ctx->ev_join)
         if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { delete ctx; return PNL_ERR_HIP; }
     for (auto &e : ctx->ev)
@@ -1843,6 +1857,7 @@ void pnl_destroy(pnl_context *ctx) {
     for (auto &st : ctx->aux) if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_fold) (void)hipEventDestroy(ctx->ev_fold);
+    if (ctx->ev_bnd) (void)hipEventDestroy(ctx->ev_bnd);
     for (auto *t : ctx->powtabs) delete t;
     ctx->powtabs.clear();
     for (auto &e : ctx->ev_join) if (e) (void)hipEventDestroy(e);
