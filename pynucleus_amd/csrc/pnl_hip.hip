@@ -1298,16 +1298,41 @@ int clusters_tiled_impl(pnl_context *ctx, const pnl_cluster_plan *pl, ClusterTil
     if (cluster_boundary && pl->num_dslots > 0 && pl->nfacets > 0) {
         if (!ctx->C().have_kernel[1] || !ctx->C().have_form[1]) return fail(ctx, PNL_ERR_STATE, "boundary kernel and order formula must be set");
         // few cells (those of cellsInter), many facets each: small facet chunks give the parallelism
-        const int per = pnl_tune("PNL_CB_PER") ? atoi(pnl_tune("PNL_CB_PER")) : 2;
+        // (measured at C4, 9.9e6 pairs / 5.0e8 point pairs: all in place 9.0 ms; list for > 48 point pairs 4.7 ms, > 200: 4.1 ms,
+        // > 200 with 4 facets per chunk 3.2 ms, > 1000: 5.4 ms)
+        const int per = pnl_tune("PNL_CB_PER") ? atoi(pnl_tune("PNL_CB_PER")) : 4;
         const dim3 grid((pl->num_dslots+PNL_NTHREADS-1)/PNL_NTHREADS, (maxf+per-1)/per);
         const double *verts = (const double*)ctx->b_vertices.p;
+        // (cell, facet) pairs with more than `defer` point pairs: list of items for k_boundary_items (one per wave); pairs that do
+        // not fit into the list are integrated in place
+        const int defer = pnl_tune("PNL_CB_DEFER") ? atoi(pnl_tune("PNL_CB_DEFER")) : 200;
+        const unsigned cap = defer > 0 ? 1u << 22 : 0u;
+        int *dcells = nullptr, *dfacets = nullptr;
+        unsigned *dslots = nullptr, *dcount = nullptr;
+        if (cap) {
+            if ((rc = ensure(ctx, ctx->b_bdefer, sizeof(int)*(size_t)cap*(3+DIM)+sizeof(unsigned)))) return rc;
+            dcells = (int*)ctx->b_bdefer.p; dfacets = dcells+cap; dslots = (unsigned*)(dfacets+(size_t)cap*DIM);
+            dcount = (unsigned*)((int*)(dslots+cap)+cap);
+            HIPCHK(ctx, hipMemsetAsync(dcount, 0, sizeof(unsigned), ctx->stream));
+        }
         if (ctx->P.bkn.fast)
             hipLaunchKernelGGL((k_cluster_boundary<DIM, DPE, 1>), grid, dim3(PNL_NTHREADS), 0, ctx->stream, ctx->P, verts, d_cell, d_pair,
-                               pl->num_dslots, pair_foff, fvid, fgeo, pl->nfacets, CT.D, per);
+                               pl->num_dslots, pair_foff, fvid, fgeo, pl->nfacets, CT.D, per, defer, dcells, dfacets, dslots, dcount, cap);
         else
             hipLaunchKernelGGL((k_cluster_boundary<DIM, DPE, 0>), grid, dim3(PNL_NTHREADS), 0, ctx->stream, ctx->P, verts, d_cell, d_pair,
-                               pl->num_dslots, pair_foff, fvid, fgeo, pl->nfacets, CT.D, per);
+                               pl->num_dslots, pair_foff, fvid, fgeo, pl->nfacets, CT.D, per, defer, dcells, dfacets, dslots, dcount, cap);
         HIPCHK(ctx, hipGetLastError());
+        if (cap) {
+            if (ctx->P.bkn.fast)
+                hipLaunchKernelGGL((k_boundary_items<DIM, DPE, 1>), dim3(256*8), dim3(PNL_NTHREADS), 0, ctx->stream, ctx->P, verts,
+                                   (const int*)dcells, (const int*)dfacets, (const unsigned*)dslots, (int)cap, 1., SparseOut{}, CT.D,
+                                   (const unsigned*)dcount, (const int*)nullptr, (const DevKernel*)nullptr, (const DevFormula*)nullptr);
+            else
+                hipLaunchKernelGGL((k_boundary_items<DIM, DPE, 0>), dim3(256*8), dim3(PNL_NTHREADS), 0, ctx->stream, ctx->P, verts,
+                                   (const int*)dcells, (const int*)dfacets, (const unsigned*)dslots, (int)cap, 1., SparseOut{}, CT.D,
+                                   (const unsigned*)dcount, (const int*)nullptr, (const DevKernel*)nullptr, (const DevFormula*)nullptr);
+            HIPCHK(ctx, hipGetLastError());
+        }
         if (pl->n_btouch > 0) {
             for (int s = 0; s < DIM; s++)
                 if (!ctx->C().have_sing[1][s]) return fail(ctx, PNL_ERR_STATE, "boundary singular rule for %d common vertices not uploaded", s+1);

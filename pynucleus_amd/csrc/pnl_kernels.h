@@ -3099,7 +3099,8 @@ template <int DIM, int DPE, int KT>
 __global__ void __launch_bounds__(PNL_NTHREADS)
 k_cluster_boundary(const DevProblem P, const double *__restrict__ verts, const int *__restrict__ d_cell, const int *__restrict__ d_pair,
                    int nd, const int *__restrict__ pair_foff, const int *__restrict__ fvid, const double *__restrict__ fgeo, int nftot,
-                   double *__restrict__ D, int facets_per_chunk) {
+                   double *__restrict__ D, int facets_per_chunk, int defer_evals, int *__restrict__ dcells, int *__restrict__ dfacets,
+                   unsigned *__restrict__ dslots, unsigned *__restrict__ dcount, unsigned dcap) {
     constexpr int NV = DIM+1, NC = NV*DIM, NF = DIM, ND = DPE*(DPE+1)/2;
     const int d = blockIdx.x*PNL_NTHREADS+threadIdx.x;
     if (d >= nd) return;
@@ -3146,6 +3147,18 @@ k_cluster_boundary(const DevProblem P, const double *__restrict__ verts, const i
         if (q > P.qmax || q > PNL_MAXQ) { overflow++; continue; }
         const int off = P.off[q], n = P.off[q+1]-off;
         const int foff = P.foff[q], nf = P.foff[q+1]-foff;
+        // the cells of a near-field cluster pair are close to its facets: pairs with many point pairs go one per wave through
+        // k_boundary_items (as in k_boundary_distant) instead of keeping the other 63 lanes of this wave waiting
+        if (dcells && n*nf > defer_evals) {
+            const unsigned idx = atomicAdd(dcount, 1u);
+            if (idx < dcap) {
+                dcells[idx] = cc;
+                dslots[idx] = (unsigned)d;
+#pragma unroll
+                for (int m = 0; m < NF; m++) dfacets[(size_t)idx*NF+m] = fvd[m];
+                continue;
+            }
+        }
         const double *__restrict__ bary = P.bary+3*(size_t)off;
         const double *__restrict__ w = P.w+off;
         const double *__restrict__ phi = P.phi+(size_t)off*DPE;
@@ -3253,6 +3266,14 @@ k_h2_leaf_values(const DevProblem P, const H2Dev H, int nq, const double *__rest
     const int *cells = H.leaf_cells+H.leaf_cell_off[lf];
     const int ncl = H.leaf_cell_off[lf+1]-H.leaf_cell_off[lf];
     double *V = H.V+H.leaf_val_off[lf];
+    // Chebyshev nodes of the leaf's box, once per workgroup (the cosines were 3/4 of the kernel: 5.2 -> 1.x ms at 49k DoFs)
+    constexpr int MAXM = 64;
+    __shared__ double s_node[DIM][MAXM];
+    const bool tab = H.m <= MAXM;
+    if (tab) {
+        for (int t = threadIdx.x; t < DIM*H.m; t += PNL_NTHREADS) s_node[t/H.m][t % H.m] = cheb_node(bx[2*(t/H.m)], bx[2*(t/H.m)+1], H.m, t % H.m);
+        __syncthreads();
+    }
     for (int t = threadIdx.x; t < ncl*H.M; t += PNL_NTHREADS) {
         const int c = cells[t/H.M], alpha = t % H.M;
         int lcl[DPE];
@@ -3278,7 +3299,15 @@ k_h2_leaf_values(const DevProblem P, const H2Dev H, int nq, const double *__rest
                 double x = 0.;
 #pragma unroll
                 for (int v = 0; v < NV; v++) x = __builtin_fma(qbary[3*j+v], P.cellv[(size_t)(v*DIM+d)*P.ncp+c], x);
-                L *= lagrange1d(bx[2*d], bx[2*d+1], H.m, aa % H.m, x);
+                const int l = aa % H.m;
+                if (tab) {
+                    // lagrange1d with the nodes from the table: the same operations in the same order
+                    const double xl = s_node[d][l];
+                    double v = 1.;
+                    for (int k = 0; k < H.m; k++)
+                        if (k != l) { const double xk = s_node[d][k]; v *= (x-xk)/(xl-xk); }
+                    L *= v;
+                } else L *= lagrange1d(bx[2*d], bx[2*d+1], H.m, l, x);
                 aa /= H.m;
             }
             const double wl = vol*qw[j]*L;
