@@ -195,7 +195,7 @@ def extra_configs(dev):
         dm = P1_DoFMap(mesh, PHYSICAL)
         b = nonlocalBuilder(dm, getFractionalKernel(2, 0.75), {'target_order': 0.5, 'eta': 3.}, zeroExterior=True)
         walls = []
-        for rep in range(2):
+        for rep in range(3):
             sync(); t0 = time.perf_counter()
             h2 = b.getH2()
             sync(); walls.append(time.perf_counter()-t0)
