@@ -97,7 +97,8 @@ struct pnl_context {
     H2Dev h2;
     bool have_h2 = false;
     // non-symmetric kernels with an order per quadrature point (pnl_set_order_function)
-    bool have_tile_order = false;     // permuted cell tables for the tile kernels (finalize)
+    bool have_tile_order = false;     // permuted cell tables for the tile kernels (finalize starts the search, tile_order_ready ends it)
+    struct TileOrderJob *tile_job = nullptr;
     DevBuf b_cellv_t, b_cdof_t, b_cslot_t, b_Dt;    // b_Dt: diagonal blocks in the tile kernels' local order
     PwDev pw;
     bool have_pw = false, have_pw_rules[2][3] = {{false, false, false}, {false, false, false}};

@@ -18,7 +18,51 @@
 #include <thread>
 #include "pnl_context.h"
 
+// vertex order of the cells for the tile kernels (see finalize): search on host threads, tables on first use
+struct TileOrderJob {
+    std::vector<int> cells, lperm;
+    int nc = 0, T = 0, nblocks = 0, ncp = 0, dim = 0, dpe = 0;
+    std::vector<double> cellv;
+    std::vector<int32_t> cdof;
+    std::vector<int16_t> cslot;
+    std::thread worker;
+};
+
 namespace {
+
+
+void tile_order_drop(pnl_context *ctx) {
+    if (!ctx->tile_job) return;
+    if (ctx->tile_job->worker.joinable()) ctx->tile_job->worker.join();
+    delete ctx->tile_job;
+    ctx->tile_job = nullptr;
+}
+
+int tile_order_ready(pnl_context *ctx) {
+    TileOrderJob *job = ctx->tile_job;
+    if (!job) return PNL_OK;
+    if (job->worker.joinable()) job->worker.join();
+    const int nV = job->dim+1, NC = nV*job->dim, ncp = job->ncp, dpe = job->dpe, dim = job->dim;
+    std::vector<double> cellv_t((size_t)NC*ncp, 0.);
+    std::vector<int32_t> cdof_t((size_t)dpe*ncp, -1);
+    std::vector<int16_t> cslot_t((size_t)dpe*ncp, -1);
+    for (int c = 0; c < job->nc; c++)
+        for (int k = 0; k < nV; k++) {
+            const int src = job->lperm[(size_t)c*nV+k];
+            for (int d = 0; d < dim; d++) cellv_t[(size_t)(k*dim+d)*ncp+c] = job->cellv[(size_t)(src*dim+d)*ncp+c];
+            cdof_t[(size_t)k*ncp+c] = job->cdof[(size_t)src*ncp+c];
+            cslot_t[(size_t)k*ncp+c] = job->cslot[(size_t)src*ncp+c];
+        }
+    int rc2;
+    if ((rc2 = upload(ctx, ctx->b_cellv_t, cellv_t.data(), cellv_t.size()))) return rc2;
+    if ((rc2 = upload(ctx, ctx->b_cdof_t, cdof_t.data(), cdof_t.size()))) return rc2;
+    if ((rc2 = upload(ctx, ctx->b_cslot_t, cslot_t.data(), cslot_t.size()))) return rc2;
+    if ((rc2 = ensure(ctx, ctx->b_Dt, sizeof(double)*(size_t)ncp*(dpe*(dpe+1)/2)))) return rc2;
+    ctx->have_tile_order = true;
+    delete job;
+    ctx->tile_job = nullptr;
+    return PNL_OK;
+}
 
 // Build everything derived from mesh + DoF map: padded SoA cell arrays, per-block unique DoF lists,
 // touching cell pairs (NO:311-323 shared-vertex test, done once through the vertex->cell adjacency),
@@ -40,12 +84,24 @@ int finalize(pnl_context *ctx) {
     // order, their rules are not invariant).  The tile kernels read a copy of the cell tables in which the order is chosen
     // per cell so that within a block of T cells a vertex appears at every local position about equally often: the lanes of
     // a ds_add_f64 then hit the same LDS address ~2.3 instead of ~4.3 times (greedy + local search).
-    std::vector<int> lperm((size_t)nc*nV);
-    for (int c = 0; c < nc; c++) for (int k = 0; k < nV; k++) lperm[(size_t)c*nV+k] = k;
+    // The search runs on host threads of its own (0.24 s on one thread at 98,304 cells, 30-50 ms on eight) and is waited for by the
+    // first dense assembly (tile_order_ready): the near-field / H2 path never reads the permuted tables, and a dense assembly
+    // overlaps it with the rest of this function and with the uploads of rules and kernels.
     const bool reorder = dpe == nV && dim == 2 && !pnl_tune("PNL_NO_REORDER");
+    tile_order_drop(ctx);
     if (reorder) {
+        TileOrderJob *job = new TileOrderJob;
+        ctx->tile_job = job;
+        job->cells = ctx->cells;
+        job->nc = nc; job->T = T; job->nblocks = nblocks; job->ncp = ncp; job->dim = dim; job->dpe = dpe;
+        job->lperm.resize((size_t)nc*nV);
+        for (int c = 0; c < nc; c++) for (int k = 0; k < nV; k++) job->lperm[(size_t)c*nV+k] = k;
+        job->worker = std::thread([job]() {
         static const int perms[6][3] = {{0, 1, 2}, {1, 2, 0}, {2, 0, 1}, {0, 2, 1}, {2, 1, 0}, {1, 0, 2}};
-        // the blocks are independent: a few host threads (0.24 s on one thread at 98,304 cells)
+        const int nc = job->nc, T = job->T, nblocks = job->nblocks;
+        const std::vector<int> &cells = job->cells;
+        std::vector<int> &lperm = job->lperm;
+        // the blocks are independent: a few host threads
         const int nthr = (int)std::max(1u, std::min(8u, std::thread::hardware_concurrency()));
         std::vector<std::thread> pool;
         for (int th = 0; th < nthr; th++) pool.emplace_back([&, th]() {
@@ -56,18 +112,19 @@ int finalize(pnl_context *ctx) {
             // greedy pass, then a few sweeps of local search (every cell re-chooses its order given all the others)
             for (int sweep = 0; sweep < 5; sweep++)
                 for (int c = b*T; c < std::min(nc, (b+1)*T); c++) {
-                    if (sweep) for (int k = 0; k < 3; k++) add(ctx->cells[(size_t)c*3+lperm[(size_t)c*3+k]], k, -1);
+                    if (sweep) for (int k = 0; k < 3; k++) add(cells[(size_t)c*3+lperm[(size_t)c*3+k]], k, -1);
                     int best = 0, bestmax = 1 << 30, bestsum = 1 << 30;
                     for (int p = 0; p < 6; p++) {
                         int mx = 0, sum = 0;
-                        for (int k = 0; k < 3; k++) { const int g = get(ctx->cells[(size_t)c*3+perms[p][k]], k); mx = std::max(mx, g); sum += g*g; }
+                        for (int k = 0; k < 3; k++) { const int g = get(cells[(size_t)c*3+perms[p][k]], k); mx = std::max(mx, g); sum += g*g; }
                         if (mx < bestmax || (mx == bestmax && sum < bestsum)) { best = p; bestmax = mx; bestsum = sum; }
                     }
-                    for (int k = 0; k < 3; k++) { lperm[(size_t)c*3+k] = perms[best][k]; add(ctx->cells[(size_t)c*3+perms[best][k]], k, 1); }
+                    for (int k = 0; k < 3; k++) { lperm[(size_t)c*3+k] = perms[best][k]; add(cells[(size_t)c*3+perms[best][k]], k, 1); }
                 }
         }
         });
         for (auto &t : pool) t.join();
+        });
     }
     // Cells of volume ZERO are padding inside the mesh (builder.label_blocks: a block of cells that would straddle an interface
     // of a piecewise-constant order is split into one block per label, filled up with zero-volume copies of its own cells).
@@ -135,25 +192,9 @@ int finalize(pnl_context *ctx) {
                 if (g >= 0) cslot[(size_t)k*ncp+c] = (int16_t)(std::lower_bound(L.begin(), L.end(), g)-L.begin());
             }
     }
-    // permuted copies for the tile kernels
-    ctx->have_tile_order = reorder;
-    if (reorder) {
-        std::vector<double> cellv_t((size_t)NC*ncp, 0.);
-        std::vector<int32_t> cdof_t((size_t)dpe*ncp, -1);
-        std::vector<int16_t> cslot_t((size_t)dpe*ncp, -1);
-        for (int c = 0; c < nc; c++)
-            for (int k = 0; k < nV; k++) {
-                const int src = lperm[(size_t)c*nV+k];
-                for (int d = 0; d < dim; d++) cellv_t[(size_t)(k*dim+d)*ncp+c] = cellv[(size_t)(src*dim+d)*ncp+c];
-                cdof_t[(size_t)k*ncp+c] = cdof[(size_t)src*ncp+c];
-                cslot_t[(size_t)k*ncp+c] = cslot[(size_t)src*ncp+c];
-            }
-        int rc2;
-        if ((rc2 = upload(ctx, ctx->b_cellv_t, cellv_t.data(), cellv_t.size()))) return rc2;
-        if ((rc2 = upload(ctx, ctx->b_cdof_t, cdof_t.data(), cdof_t.size()))) return rc2;
-        if ((rc2 = upload(ctx, ctx->b_cslot_t, cslot_t.data(), cslot_t.size()))) return rc2;
-        if ((rc2 = ensure(ctx, ctx->b_Dt, sizeof(double)*(size_t)ncp*(dpe*(dpe+1)/2)))) return rc2;
-    }
+    // permuted copies for the tile kernels: built and uploaded by tile_order_ready once the search above has finished
+    ctx->have_tile_order = false;
+    if (reorder) { ctx->tile_job->cellv = cellv; ctx->tile_job->cdof = cdof; ctx->tile_job->cslot = cslot; }
     // touching cell pairs via vertex -> cells adjacency
     std::vector<int> vptr(ctx->nv+1, 0);
     for (int c = 0; c < nc; c++)
@@ -1884,6 +1925,7 @@ void pnl_destroy(pnl_context *ctx) {
     for (auto &pr : ctx->kev)
         for (auto &e : pr)
             if (e) (void)hipEventDestroy(e);
+    tile_order_drop(ctx);
     for (auto &st : ctx->aux) if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_fold) (void)hipEventDestroy(ctx->ev_fold);
@@ -2398,6 +2440,7 @@ int pnl_assemble_dense(pnl_context *ctx, double *A, int64_t ldA, int zero_exteri
     int rc;
     if ((rc = check_ready(ctx))) return rc;
     if ((rc = finalize(ctx))) return rc;
+    if ((rc = tile_order_ready(ctx))) return rc;
     if (!A || ldA < (ctx->slab_rows ? ctx->slab_cols : ctx->N)) return fail(ctx, PNL_ERR_INVALID, "bad output matrix (ldA=%lld, num_dofs=%d)", (long long)ldA, ctx->N);
     if (cell_begin < 0 || cell_end > ctx->nc || cell_begin > cell_end) return fail(ctx, PNL_ERR_INVALID, "bad cell range");
     if ((rc = slab_prepare(ctx, A, flags, cell_begin, cell_end))) return rc;
@@ -2467,6 +2510,7 @@ int pnl_assemble_dense_tiles(pnl_context *ctx, double *A, int64_t ldA, int zero_
     int rc;
     if ((rc = check_ready(ctx))) return rc;
     if ((rc = finalize(ctx))) return rc;
+    if ((rc = tile_order_ready(ctx))) return rc;
     if (!A || ldA < (ctx->slab_rows ? ctx->slab_cols : ctx->N) || ntiles < 0 || (ntiles && !tiles_host)) return fail(ctx, PNL_ERR_INVALID, "bad arguments");
     if (cell_begin < 0 || cell_end > ctx->nc || cell_begin > cell_end) return fail(ctx, PNL_ERR_INVALID, "bad cell range");
     if ((rc = slab_prepare(ctx, A, flags, cell_begin, cell_end))) return rc;
