@@ -926,7 +926,7 @@ bool slot_eligible(const pnl_context *ctx, int cell_begin, int cell_end, int fla
 }
 
 #ifndef PNL_BND_MODE_DEFAULT
-#define PNL_BND_MODE_DEFAULT 0
+#define PNL_BND_MODE_DEFAULT 3
 #endif
 template <int DIM, int DPE, int TILE>
 int assemble_impl(pnl_context *ctx, double *A, int64_t ldA, int zero_exterior, int ntiles, int cell_begin, int cell_end, int flags) {
@@ -986,14 +986,16 @@ int assemble_impl(pnl_context *ctx, double *A, int64_t ldA, int zero_exterior, i
         return PNL_OK;
     };
     // The boundary term only adds to the per-cell diagonal blocks (b_D, scattered into A at the very end) and never touches A, so
-    // its stream needs nothing but the zero fill of that buffer and the class tables.  PNL_BND_MODE 0 (default): behind the fold (one
-    // class: side stream 1, several: forked over the class streams), next to the work-list kernels.  1: side stream 1 behind the
-    // zero fill, submitted after the tile and work-list kernels; 2: submitted first.  Measured: as soon as the boundary kernels are
-    // READY while the tile kernels still have workgroups to place, their workgroups take CU slots in front of them and the tile
-    // phase loses more than the boundary term costs (mode 2, P1 s = 0.4: 138 -> 173 ms).  Mode 1 wins 0.5-2 ms when the host waits
-    // for every assembly (the launches of the boundary kernels arrive late) and loses 12 ms of 103 in a loop of assemblies without
-    // a host synchronisation in between (everything is queued ahead, so it behaves like mode 2); a lowest-priority stream recovers
-    // half of that.  Hence mode 0.
+    // its stream needs nothing but the zero fill of that buffer and the class tables.  PNL_BND_MODE 3 (default): side stream 1 behind
+    // the LAST TILE KERNEL, i.e. next to the fold pass -- the fold is bound by HBM (VALU issue utilisation 0.4), the boundary kernels by
+    // latency and arithmetic, and nothing else can run there (everything else adds into A, which the fold overwrites): P2 39.9 -> 39.3
+    // ms, C5 52.2 -> 51.6, headline 103.3 -> 102.9 in bench.py's queued loop.  0: behind the fold (one class: side stream 1, several:
+    // forked over the class streams), next to the work-list kernels.  1: behind the zero fill, submitted after the tile and
+    // work-list kernels; 2: submitted first.  Measured: as soon as the boundary kernels are READY while the tile kernels still have
+    // workgroups to place, their workgroups take CU slots in front of them and the tile phase loses more than the boundary term
+    // costs (mode 2, P1 s = 0.4: 138 -> 173 ms).  Mode 1 wins 0.5-2 ms when the host waits for every assembly (the launches of the
+    // boundary kernels arrive late) and loses 12 ms of 103 in a loop of assemblies without a host synchronisation in between
+    // (everything is queued ahead, so it behaves like mode 2); a lowest-priority stream recovers half of that.
     const int bnd_mode = !zero_exterior ? -1 : pnl_tune("PNL_BND_MODE") ? atoi(pnl_tune("PNL_BND_MODE")) : PNL_BND_MODE_DEFAULT;
     bool bnd_side = false;
     auto boundary_side = [&](hipEvent_t after) -> int {
@@ -1087,8 +1089,9 @@ int assemble_impl(pnl_context *ctx, double *A, int64_t ldA, int zero_exterior, i
         HIPCHK(ctx, hipEventRecord(ctx->ev_join[0], ctx->aux[0]));
         ctx->stream = main_stream;
     } else HIPCHK(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
-    if (bnd_mode == 1 || (bnd_mode == 0 && overlap)) rc = boundary_side(bnd_mode ? ctx->ev_bnd : ctx->ev_fold);
-    else if (bnd_mode == 0) rc = boundary_term(chain);
+    if (bnd_mode == 3 && ctx->fold_event_set) rc = boundary_side(ctx->ev[6]);          // next to the fold pass (ev[6]: tile kernels done)
+    else if (bnd_mode == 1 || ((bnd_mode == 0 || bnd_mode == 3) && overlap)) rc = boundary_side(bnd_mode == 1 ? ctx->ev_bnd : ctx->ev_fold);
+    else if (bnd_mode == 0 || bnd_mode == 3) rc = boundary_term(chain);
     if (rc) return rc;
     ctx->cur = 0;
     if (overlap) {
