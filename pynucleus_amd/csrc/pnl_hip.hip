@@ -1066,7 +1066,14 @@ int assemble_impl(pnl_context *ctx, double *A, int64_t ldA, int zero_exterior, i
     // fold, next to the work-list kernels on the caller's stream -- everything after the fold only adds with atomics.  The
     // phase timers then show what is left of them after the work list ("singular"), the boundary phase reads 0
     hipStream_t const main_stream = ctx->stream;
-    const bool overlap = ctx->fold_event_set && ncls*norient == 1 && !pnl_tune("PNL_NO_OVERLAP");
+    // without a fold pass (row slabs of a rank, 1D, P0) the same holds from here on: the touching pairs and the boundary term add
+    // with atomics and run side by side
+    bool fold_like = ctx->fold_event_set;
+    if (!fold_like && ncls*norient == 1 && zero_exterior && !pnl_tune("PNL_NO_OVERLAP")) {
+        HIPCHK(ctx, hipEventRecord(ctx->ev_fold, ctx->stream));
+        fold_like = true;
+    }
+    const bool overlap = fold_like && ncls*norient == 1 && !pnl_tune("PNL_NO_OVERLAP");
     struct StreamGuard { pnl_context *c; hipStream_t s; ~StreamGuard() { c->stream = s; } } stream_guard{ctx, main_stream};
     if (overlap) { HIPCHK(ctx, hipStreamWaitEvent(ctx->aux[0], ctx->ev_fold, 0)); ctx->stream = ctx->aux[0]; }
     // several classes behind a fold pass: the side streams of the touching pairs and of the boundary term start at the fold
