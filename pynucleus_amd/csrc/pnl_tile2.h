@@ -64,6 +64,9 @@ __host__ __device__ constexpr int uni_rule_size(int dpe, int np) { return 3*np+n
 // with ds_add_f64.  No per-entry walk whose length differs from lane to lane: the kernel was bound by instruction issue
 // (1,050 VALU instructions per wave for 8 entries per thread) as much as by the chain of dependent loads.
 // Tables of a range of 32 DoFs come packed (FoldEntry[1 + PNL_FOLD_TAB], pnl_device.h): header + copies, one load per thread.
+#ifndef PNL_FOLD_FLAT
+#define PNL_FOLD_FLAT 1
+#endif
 template <bool NT>
 __global__ void __launch_bounds__(256)
 k_fold_mirror(const double *__restrict__ A2, const FoldEntry *__restrict__ tab, const int *__restrict__ cpoff, const int2 *__restrict__ cp,
@@ -98,6 +101,35 @@ k_fold_mirror(const double *__restrict__ A2, const FoldEntry *__restrict__ tab, 
     __syncthreads();
     const int n0 = (int)s_tab[0][0].off, n1 = (int)s_tab[1][0].off;
     if (n0 <= PNL_FOLD_TAB && n1 <= PNL_FOLD_TAB) {
+#if PNL_FOLD_FLAT
+        // the nr x nc candidates of an image as ONE index range over the 256 threads, eight independent loads in flight per thread:
+        // the (ty, tx) grid left the lanes tx >= nc - 32 of the second column sweep idle (nc is about 42) and had five or six loads
+        // per thread in flight
+#pragma unroll
+        for (int g = 0; g < 2; g++) {                                   // g = 0: rows of range 0 -> t1, g = 1: rows of range 1 -> t2
+            if (g && bi == bj) break;
+            const int nr = g ? n1 : n0, nc = g ? n0 : n1;
+            double *__restrict__ tf = g ? &t2[0][0] : &t1[0][0];
+            const unsigned total = (unsigned)(nr*nc), inv = ((1u << 20)+(unsigned)nc-1u)/(unsigned)nc;     // idx / nc exactly for idx < 4096, nc <= 64
+            for (unsigned base = 0; base < total; base += 8*256) {
+                double v[8];
+                int dst[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const unsigned idx = base+256u*u+(unsigned)tid;
+                    dst[u] = -1;
+                    v[u] = 0.;
+                    if (idx < total) {
+                        const unsigned ci = (idx*inv) >> 20, cj = idx-ci*(unsigned)nc;
+                        const FoldEntry rw = s_tab[g][1+ci], col = s_tab[1-g][1+cj];
+                        if ((col.ar >> 5) >= (rw.ar >> 5)) { v[u] = A2[rw.off+col.cy]; dst[u] = (rw.ar & 31)*33+(col.ar & 31); }
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 8; u++) if (dst[u] >= 0) lds_add_f64(tf+dst[u], v[u]);
+            }
+        }
+#else
 #pragma unroll
         for (int g = 0; g < 2; g++) {                                   // g = 0: rows of range 0 -> t1, g = 1: rows of range 1 -> t2
             if (g && bi == bj) break;
@@ -124,6 +156,7 @@ k_fold_mirror(const double *__restrict__ A2, const FoldEntry *__restrict__ tab, 
                 }
             }
         }
+#endif
     } else {
         // more copies than the packed table holds: per-entry walk over the lists in global memory
         auto gather = [&](int br, int bc, double (*t)[33]) {
