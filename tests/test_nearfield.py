@@ -179,6 +179,20 @@ def test_gpu_near_field_vs_oracle(noRef, s, element, symmetric, mode):
 
 
 @pytest.mark.gpu
+def test_gpu_near_field_heavy_boundary_pairs():
+    """target_order 3.5 makes the cluster-local Gauss-theorem term expensive (444 point pairs per (cell, facet) pair on average
+    at noRef 3): most pairs exceed the 200 point pairs above which k_cluster_boundary hands them to k_boundary_items (one pair
+    per wave) instead of integrating them in its lane -- both routes against the oracle's loop (NA:1842-1889)"""
+    from pynucleus_amd import clusters
+    b = _gpu_builder(3, 0.75, params={'target_order': 3.5}, mode='tiles')
+    root, Pnear, Pfar = clusters.getNearFieldClusters(b.dm, eta=3., minClusterSize=8)
+    Anear, Aref = _gpu_vs_oracle(b, Pnear, True)
+    c = Anear.info['counters']
+    assert c['numBoundaryIntegrations'] > 200*c['numBoundaryPairs'] > 0
+    assert np.abs(Anear.toarray()-Aref).max() <= 1e-11*np.abs(Aref).max()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('mode', ['tiles', 'masks'])
 def test_gpu_covering_cluster_equals_gpu_dense(mode):
     from pynucleus_amd import clusters
