@@ -179,6 +179,27 @@ def test_gpu_near_field_vs_oracle(noRef, s, element, symmetric, mode):
 
 
 @pytest.mark.gpu
+def test_gpu_dense_after_near_field_on_one_builder():
+    """the vertex order of the dense tile kernels is searched on host threads and joined by the first DENSE assembly
+    (finalize / tile_order_ready); the near-field path never waits for it.  Either order of the two calls on one builder
+    gives the operators a fresh builder gives."""
+    import torch
+    from pynucleus_amd import clusters
+    b = _gpu_builder(4, 0.75, params={'target_order': 0.5})
+    h2, Pnear = b.getH2(returnNearField=True)
+    near = h2.Anear.toarray() if hasattr(h2.Anear, 'toarray') else None
+    A = b.getDense().toarray()
+    b2 = _gpu_builder(4, 0.75, params={'target_order': 0.5})
+    A2 = b2.getDense().toarray()
+    h2b = b2.getH2()
+    assert np.abs(A-A2).max() <= 1e-13*np.abs(A2).max()
+    if near is not None:
+        assert np.abs(near-h2b.Anear.toarray()).max() <= 1e-13*np.abs(near).max()
+    x = torch.from_numpy(np.random.default_rng(3).standard_normal(b.dm.num_dofs)).cuda()
+    assert np.abs((h2.matvec(x)-h2b.matvec(x)).cpu().numpy()).max() <= 1e-12*np.abs(A2).max()*np.abs(x.cpu().numpy()).max()
+
+
+@pytest.mark.gpu
 def test_gpu_near_field_heavy_boundary_pairs():
     """target_order 3.5 makes the cluster-local Gauss-theorem term expensive (444 point pairs per (cell, facet) pair on average
     at noRef 3): most pairs exceed the 200 point pairs above which k_cluster_boundary hands them to k_boundary_items (one pair
