@@ -703,3 +703,33 @@ def test_full_space_integrable_fixtures_through_the_gpu(name, kw, stored_l2, sto
     H = b.getH2()
     l2h, linfh = full_space_errors(name, kw, k, dm, dmA, H.toarray())
     assert abs(l2h-stored_l2) <= 1e-4*stored_l2 and abs(linfh-stored_linf) <= 1e-8*stored_linf, (l2h, linfh)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('element', ['P1', 'P2'])
+def test_queued_assemblies_equal_a_single_one(element):
+    """bench.py queues its steps without a host synchronisation in between: the side streams of a step (touching pairs, boundary
+    term next to the fold pass) must be joined before the next step clears the per-cell diagonal blocks.  Three queued assemblies
+    into one matrix leave what a single one leaves (block-slot path: every entry is overwritten)."""
+    import torch
+    from pynucleus_amd import disc, PHYSICAL, dofmapFactory, getFractionalKernel
+    from pynucleus_amd.builder import nonlocalBuilder
+    mesh = disc(5 if element == 'P1' else 4)
+    dm = dofmapFactory(element, mesh, PHYSICAL)
+    b = nonlocalBuilder(dm, getFractionalKernel(2, 0.5), {'target_order': 0.5}, zeroExterior=True)
+    ctx = b.context()
+    N, nc = dm.num_dofs, mesh.num_cells
+    dev = torch.device('cuda', ctx.device)
+    overwrites = ctx.dense_overwrites(0, nc)
+
+    def run(k):
+        A = torch.zeros((N, N), dtype=torch.float64, device=dev)
+        for _ in range(k):
+            if not overwrites:
+                A.zero_()
+            ctx.assemble_dense(A.data_ptr(), A.stride(0), True, 0, nc)
+        torch.cuda.synchronize(dev)
+        return A.cpu().numpy()
+    one, three = run(1), run(3)
+    assert np.abs(one-one.T).max() <= 1e-13*np.abs(one).max()
+    assert np.abs(three-one).max() <= 1e-13*np.abs(one).max()
