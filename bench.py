@@ -418,38 +418,45 @@ def c4_distributed_leg(args, world, rank, dev, sync):
     from pynucleus_amd.builder import nonlocalBuilder
     from pynucleus_amd.solvers import cg
     red_dev = dev if os.environ.get('PNL_BENCH_BACKEND', 'nccl') == 'nccl' else torch.device('cpu')
+    # phase 1 has no collective (row-sharded near field, dealt far field): a rank may fail here alone, so the ranks AGREE on the
+    # outcome before anybody enters a collective -- one failing rank must not leave the others waiting in an all-reduce
+    err, h2, walls = None, None, []
     try:
         dm = P1_DoFMap(disc(args.noRef, sectors=args.sectors), PHYSICAL)
         b4 = nonlocalBuilder(dm, getFractionalKernel(2, 0.75), {'target_order': 0.5, 'eta': 3.}, zeroExterior=True, comm=True)
-        walls = []
         for rep in range(2):
             sync(); t0 = time.perf_counter()
             h2 = b4.getH2()
             sync(); walls.append(time.perf_counter()-t0)
-        c = h2.info.get('counters', {})
-        near_ms = gather_ranks(h2.info.get('interior_ms', 0.), world, red_dev)
-        pairs = gather_ranks(c.get('numAssembledCellPairs', 0), world, red_dev)
-        nnz = gather_ranks(h2.local.nnz, world, red_dev)
-        x = torch.from_numpy(np.random.default_rng(0).standard_normal(dm.num_dofs)).to(dev)
-        for _ in range(3):
-            y = h2.matvec(x)
-        sync(); t0 = time.perf_counter()
-        for _ in range(20):
-            y = h2.matvec(x)
-        sync()
-        mv = max(gather_ranks((time.perf_counter()-t0)/20, world, red_dev))
-        rhs = torch.from_numpy(np.asarray(dm.assembleRHS(1.0))).to(dev)
-        sync(); t0 = time.perf_counter()
-        u, its, res = cg(h2, rhs, tol=1e-8, maxiter=2000)
-        sync()
-        t_cg = max(gather_ranks(time.perf_counter()-t0, world, red_dev))
-        return dict(num_dofs=dm.num_dofs, getH2_first_ms=1e3*max(gather_ranks(walls[0], world, red_dev)),
-                    getH2_ms=1e3*max(gather_ranks(walls[-1], world, red_dev)), near_field_device_ms_per_rank=[round(v, 3) for v in near_ms],
-                    near_field_element_pairs_per_rank=[int(v) for v in pairs], near_field_element_pairs=int(sum(pairs)),
-                    near_field_nnz_per_rank=[int(v) for v in nnz], pairs_per_s=sum(pairs)/(1e-3*max(near_ms)) if max(near_ms) > 0 else 0.,
-                    matvec_ms=1e3*mv, cg_jacobi_iterations=int(its), cg_jacobi_ms=1e3*t_cg, cg_residual=float(res[-1]))
-    except Exception as e:                                   # the headline line survives a failing leg (every rank fails alike)
-        return dict(error=repr(e))
+    except Exception as e:
+        err = repr(e)
+    failed = [r for r, v in enumerate(gather_ranks(0. if err is None else 1., world, red_dev)) if v]
+    if failed:
+        return dict(error=err if err is not None else 'assembly failed on ranks {}'.format(failed), failed_ranks=failed)
+    # phase 2 is collective throughout (matvec, CG, the gathers): an exception here ends this rank with a non-zero exit and the
+    # launcher ends the job -- never swallowed
+    c = h2.info.get('counters', {})
+    near_ms = gather_ranks(h2.info.get('interior_ms', 0.), world, red_dev)
+    pairs = gather_ranks(c.get('numAssembledCellPairs', 0), world, red_dev)
+    nnz = gather_ranks(h2.local.nnz, world, red_dev)
+    x = torch.from_numpy(np.random.default_rng(0).standard_normal(dm.num_dofs)).to(dev)
+    for _ in range(3):
+        y = h2.matvec(x)
+    sync(); t0 = time.perf_counter()
+    for _ in range(20):
+        y = h2.matvec(x)
+    sync()
+    mv = max(gather_ranks((time.perf_counter()-t0)/20, world, red_dev))
+    rhs = torch.from_numpy(np.asarray(dm.assembleRHS(1.0))).to(dev)
+    sync(); t0 = time.perf_counter()
+    u, its, res = cg(h2, rhs, tol=1e-8, maxiter=2000)
+    sync()
+    t_cg = max(gather_ranks(time.perf_counter()-t0, world, red_dev))
+    return dict(num_dofs=dm.num_dofs, getH2_first_ms=1e3*max(gather_ranks(walls[0], world, red_dev)),
+                getH2_ms=1e3*max(gather_ranks(walls[-1], world, red_dev)), near_field_device_ms_per_rank=[round(v, 3) for v in near_ms],
+                near_field_element_pairs_per_rank=[int(v) for v in pairs], near_field_element_pairs=int(sum(pairs)),
+                near_field_nnz_per_rank=[int(v) for v in nnz], pairs_per_s=sum(pairs)/(1e-3*max(near_ms)) if max(near_ms) > 0 else 0.,
+                matvec_ms=1e3*mv, cg_jacobi_iterations=int(its), cg_jacobi_ms=1e3*t_cg, cg_residual=float(res[-1]))
 
 
 def main():

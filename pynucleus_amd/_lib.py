@@ -354,6 +354,7 @@ class Context:
         self.check(self.L.pnl_assemble_pairs_in_horizon(self.h, C.c_void_p(data_ptr), C.c_void_p(diag_ptr) if diag_ptr else None))
 
     def assemble_dense_pointwise(self, A_ptr, ldA, zero_exterior, cell_begin, cell_end):
+        self.assembly_epoch = getattr(self, 'assembly_epoch', 0)+1     # host snapshots of dense operators are stale now
         pairs, bpairs = self._pw_pairs
         self.check(self.L.pnl_assemble_dense_pointwise(self.h, C.c_void_p(A_ptr), int(ldA), int(bool(zero_exterior)), int(cell_begin),
                                                        int(cell_end), pairs.shape[0], pairs.ctypes.data, bpairs.shape[0],
@@ -366,6 +367,7 @@ class Context:
         self.check(self.L.pnl_synchronize(self.h))
 
     def assemble_dense(self, A_ptr, ldA, zero_exterior, cell_begin, cell_end, flags=0):
+        self.assembly_epoch = getattr(self, 'assembly_epoch', 0)+1     # host snapshots of dense operators are stale now
         self.check(self.L.pnl_assemble_dense(self.h, C.c_void_p(A_ptr), int(ldA), int(bool(zero_exterior)), int(cell_begin),
                                              int(cell_end), int(flags)))
 
@@ -389,6 +391,7 @@ class Context:
         return rc
 
     def assemble_dense_tiles(self, A_ptr, ldA, zero_exterior, tiles, cell_begin, cell_end, flags=0):
+        self.assembly_epoch = getattr(self, 'assembly_epoch', 0)+1     # host snapshots of dense operators are stale now
         t, pt = _hp(tiles, np.int32)
         self.check(self.L.pnl_assemble_dense_tiles(self.h, C.c_void_p(A_ptr), int(ldA), int(bool(zero_exterior)), t.shape[0], pt,
                                                    int(cell_begin), int(cell_end), int(flags)))

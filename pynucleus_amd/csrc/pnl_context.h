@@ -255,6 +255,9 @@ inline DevProblem tile_problem(const pnl_context *ctx) {
 inline void kt_begin(pnl_context *ctx, int slot) { (void)hipEventRecord(ctx->kev[slot][0], ctx->stream); }
 inline void kt_end(pnl_context *ctx, int slot) { (void)hipEventRecord(ctx->kev[slot][1], ctx->stream); ctx->kev_set[slot] = true; }
 
+// pnl_hip.hip: joins the vertex-order search finalize() started and uploads the permuted cell tables (sets have_tile_order)
+int pnl_tile_order_ready(pnl_context *ctx);
+
 // pnl_tile2.hip
 int pnl2_launch_uniform(pnl_context *ctx, int kt, const DevProblem &Pt, const int2 *tiles, const int *tile_cls, int ntiles, int q,
                         double *A, int64_t ldA, double *Dglob, const SlotOut &SO);

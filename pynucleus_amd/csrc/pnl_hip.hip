@@ -38,6 +38,14 @@ void tile_order_drop(pnl_context *ctx) {
     ctx->tile_job = nullptr;
 }
 
+int tile_order_ready(pnl_context *ctx);
+}  // namespace
+
+// other translation units (pnl_slab.hip): the Dt half of the per-cell diagonal blocks exists iff the permuted tables do; a context
+// that was finalized again since the assembly (setKernel, pnl_set_cell_order) holds the flag false until the job is joined
+int pnl_tile_order_ready(pnl_context *ctx) { return tile_order_ready(ctx); }
+
+namespace {
 int tile_order_ready(pnl_context *ctx) {
     TileOrderJob *job = ctx->tile_job;
     if (!job) return PNL_OK;
@@ -1844,21 +1852,25 @@ int horizon_impl(pnl_context *ctx, SparseOut S) {
 }  // namespace
 
 // ---- options (pnl_context.h: pnl_tune) --------------------------------------------------------------------------------------
+#include <deque>
 #include <map>
 #include <mutex>
 namespace {
 std::mutex g_opt_mutex;
-std::map<std::string, std::string> g_options;
+// values are interned and never freed: a pointer pnl_tune() handed out stays valid while another thread sets or erases the option
+// (the set of distinct values a process names is small)
+std::map<std::string, const std::string*> g_options;
+std::deque<std::string> g_option_values;
 // the options a product build accepts: the hooks through which the parity tests reach the alternative code paths, and the
 // diagnostics line
-const char *const k_product_options[] = {"PNL_WL_FRAC", "PNL_FH_NOTILES", "PNL_NO_POWTAB", "PNL_VERBOSE", "PNL_PLAN_TIMING"};
+const char *const k_product_options[] = {"PNL_WL_FRAC", "PNL_FH_NOTILES", "PNL_NO_POWTAB", "PNL_VERBOSE", "PNL_PLAN_TIMING", "PNL_PLAN_THREADS"};
 }  // namespace
 
 const char *pnl_tune(const char *name) {
     {
         std::lock_guard<std::mutex> lk(g_opt_mutex);
         auto it = g_options.find(name);
-        if (it != g_options.end()) return it->second.c_str();      // std::map nodes are stable; values change only through pnl_set_option
+        if (it != g_options.end()) return it->second->c_str();
     }
 #ifdef PNL_TUNING
     return getenv(name);
@@ -1885,8 +1897,12 @@ int pnl_set_option(const char *name, const char *value) {
     if (!known) return PNL_ERR_UNSUPPORTED;
 #endif
     std::lock_guard<std::mutex> lk(g_opt_mutex);
-    if (value) g_options[name] = value;
-    else g_options.erase(name);
+    if (value) {
+        const std::string *v = nullptr;
+        for (const std::string &have : g_option_values) if (have == value) { v = &have; break; }
+        if (!v) { g_option_values.emplace_back(value); v = &g_option_values.back(); }     // deque: earlier elements do not move
+        g_options[name] = v;
+    } else g_options.erase(name);
     return PNL_OK;
 }
 

@@ -317,9 +317,9 @@ int pnl_h2_transfer_matrices(int nnodes, int dim, int m, const double *box, cons
 
 }  // extern "C"
 
-// threads of the planning loops: the host cores this process may use, at most 16 (PNL_PLAN_THREADS overrides)
+// threads of the planning loops: the host cores this process may use, at most 16 (pnl_set_option("PNL_PLAN_THREADS", n) overrides)
 static int plan_threads() {
-    if (const char *e = getenv("PNL_PLAN_THREADS")) return std::max(1, atoi(e));
+    if (const char *e = pnl_tune("PNL_PLAN_THREADS")) return std::max(1, atoi(e));
     int n = (int)std::thread::hardware_concurrency();
     cpu_set_t set;
     if (sched_getaffinity(0, sizeof(set), &set) == 0) n = std::min(n > 0 ? n : 1, CPU_COUNT(&set));

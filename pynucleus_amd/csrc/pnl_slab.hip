@@ -131,6 +131,7 @@ int pnl_diag_blocks_size(pnl_context *ctx) {
 int pnl_get_diag_blocks(pnl_context *ctx, double *dst) {
     if (!ctx || !dst) return PNL_ERR_INVALID;
     if (!ctx->b_D.p) return fail(ctx, PNL_ERR_STATE, "nothing assembled yet");
+    { const int rc = pnl_tile_order_ready(ctx); if (rc) return rc; }
     const size_t n = (size_t)ctx->ncp*(ctx->dpe*(ctx->dpe+1)/2);
     HIPCHK(ctx, hipMemcpyAsync(dst, ctx->b_D.p, sizeof(double)*n, hipMemcpyDeviceToDevice, ctx->stream));
     if (ctx->have_tile_order) HIPCHK(ctx, hipMemcpyAsync(dst+n, ctx->b_Dt.p, sizeof(double)*n, hipMemcpyDeviceToDevice, ctx->stream));
@@ -142,6 +143,7 @@ int pnl_slab_matvec(pnl_context *ctx, const double *slab, int64_t ld, const doub
     if (!ctx || !slab || !x || !y) return PNL_ERR_INVALID;
     if (ctx->slab_rows <= 0) return fail(ctx, PNL_ERR_STATE, "no row slab set (pnl_set_row_slab)");
     const int nrows = ctx->slab_rows, ncols = ctx->slab_cols;
+    { const int rc = pnl_tile_order_ready(ctx); if (rc) return rc; }
     if (ld < ncols) return fail(ctx, PNL_ERR_INVALID, "slab leading dimension %lld < %d columns", (long long)ld, ncols);
     hipStream_t st = ctx->stream;
     HIPCHK(ctx, hipMemsetAsync(y, 0, sizeof(double)*ctx->N, st));
@@ -167,6 +169,7 @@ int pnl_slab_diagonal(pnl_context *ctx, const double *slab, int64_t ld, const do
     if (!ctx || !slab || !diag) return PNL_ERR_INVALID;
     if (ctx->slab_rows <= 0) return fail(ctx, PNL_ERR_STATE, "no row slab set (pnl_set_row_slab)");
     const int nrows = ctx->slab_rows;
+    { const int rc = pnl_tile_order_ready(ctx); if (rc) return rc; }
     hipStream_t st = ctx->stream;
     HIPCHK(ctx, hipMemsetAsync(diag, 0, sizeof(double)*ctx->N, st));
     hipLaunchKernelGGL(k_slab_diag, dim3((nrows+PNL_NTHREADS-1)/PNL_NTHREADS), dim3(PNL_NTHREADS), 0, st, slab, (long long)ld, nrows,

@@ -150,11 +150,7 @@ class H2Matrix:
     def matvec(self, x, y=None):
         import torch
         from .linear_operators import _as_dev
-        if getattr(self.ctx, '_h2_owner', None) is not self:
-            if getattr(self.ctx, '_kernel_epoch', 0) != self._epoch:
-                raise RuntimeError('this H2Matrix belongs to a kernel the builder no longer holds (setKernel was called): '
-                                   'its far field cannot be set up again; assemble a new operator')
-            self._ensure_setup()
+        self._ensure_setup()
         xd = _as_dev(x, self.device)
         yd = self.Anear.matvec(xd)
         torch.cuda.current_stream(self.device).synchronize()
@@ -178,7 +174,13 @@ class H2Matrix:
     # ---- operator files: the reference's layout (H2Matrix.HDF5write / HDF5read, clusterMethodCy.pyx:2449-2550; tree:
     # tree_node.HDF5writeNew / HDF5readNew :1575-1760) on any h5py-like group (create_group, create_dataset, attrs, item access)
     def _ensure_setup(self):
+        """make this operator the one whose far field is set up in the context (matvec, the multigrid cycle, farFieldData and
+        HDF5write all come through here).  An operator whose kernel the builder no longer holds cannot be set up again from the
+        context's tables -- unless its interpolants and leaf values are stored (HDF5read), which need no kernel."""
         if getattr(self.ctx, '_h2_owner', None) is not self:
+            if getattr(self, '_stored', None) is None and getattr(self.ctx, '_kernel_epoch', 0) != self._epoch:
+                raise RuntimeError('this H2Matrix belongs to a kernel the builder no longer holds (setKernel was called): '
+                                   'its far field cannot be set up again; assemble a new operator')
             keep = []
             P = self.plan.as_struct(keep)
             self.ctx.check(self.ctx.L.pnl_h2_setup(self.ctx.h, C.byref(P)))

@@ -29,9 +29,22 @@ class Dense_LinearOperator:
     # reference API -------------------------------------------------------
     @property
     def data(self):
-        """the matrix as a numpy array: a fresh copy from HBM on every access (the device block may be assembled into again)"""
-        self.ctx.synchronize()
-        return self.A.cpu().numpy()
+        """the matrix as a numpy array: a snapshot of the device block, copied from HBM once and again only after the context
+        ran another dense assembly (the block may have been assembled into again; Context.assembly_epoch) or after
+        invalidate() / refresh() -- indexing A.data[i, j] in a loop does not move 8 N^2 bytes per access"""
+        epoch = getattr(self.ctx, 'assembly_epoch', 0)
+        if getattr(self, '_host', None) is None or self._host_epoch != epoch:
+            self.ctx.synchronize()
+            self._host, self._host_epoch = self.A.cpu().numpy(), epoch
+        return self._host
+
+    def invalidate(self):
+        """drop the host snapshot (the device block was changed outside the context's assembly calls)"""
+        self._host = None
+
+    def refresh(self):
+        self.invalidate()
+        return self.data
 
     def toarray(self):
         return self.data

@@ -89,9 +89,12 @@ def test_options_are_explicit_not_environment(monkeypatch):
     assert L.pnl_set_option(b'PNL_NO_SLOT', b'1') == _lib.PNL_ERR_UNSUPPORTED
     with pytest.raises(_lib.PnlError):
         _lib.set_option('PNL_UNI_PER_CU', 1)
-    # no getenv on the assembly path of the product sources (the planner's thread count is the one deployment knob)
+    # the planner's thread count is an option like the others
+    assert L.pnl_set_option(b'PNL_PLAN_THREADS', b'2') == 0
+    assert L.pnl_set_option(b'PNL_PLAN_THREADS', None) == 0
+    # no getenv with a literal name anywhere in the product sources (pnl_tune's fallback of the tuning builds takes a variable)
     import glob
     for fn in glob.glob(os.path.join(ROOT, 'pynucleus_amd', 'csrc', '*.h*')):
         src = open(fn).read()
         calls = re.findall(r'\bgetenv\("([A-Z_0-9]+)"\)', src)
-        assert set(calls) <= {'PNL_PLAN_THREADS'}, (fn, calls)
+        assert not calls, (fn, calls)

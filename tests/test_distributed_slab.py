@@ -173,3 +173,25 @@ def test_row_slab_operator_over_rccl_single_rank():
     assert r['pairs'] == r['ref_pairs']
     assert r['e_mv'] < TOL and r['e_full'] < TOL and r['e_diag'] < TOL, r
     assert r['e_solve'] < 1e-7, r
+
+
+@pytest.mark.gpu
+def test_row_slab_operator_survives_refinalize():
+    """a slab operator keeps the tile kernels' half of its per-cell diagonal blocks (scattered through the permuted
+    DoF table) after the context was finalized again -- setKernel + getH2 re-upload the tables and leave the permuted copies to
+    the next dense assembly; the slab products join that job themselves"""
+    import torch
+    from pynucleus_amd import disc, P1_DoFMap, PHYSICAL, getFractionalKernel
+    from pynucleus_amd.builder import nonlocalBuilder
+    from pynucleus_amd.linear_operators import DistributedSlab_LinearOperator
+    dm = P1_DoFMap(disc(4), PHYSICAL)
+    builder = nonlocalBuilder(dm, getFractionalKernel(2, 0.5), {'target_order': 0.5}, zeroExterior=True)
+    op = DistributedSlab_LinearOperator.assemble(builder, 0, 1, None)
+    x = np.random.default_rng(3).standard_normal(dm.num_dofs)
+    y0, d0 = op.matvec(x), np.array(op.diagonal)
+    A = builder.getDense().toarray()
+    assert np.abs(y0-A@x).max() < TOL*np.abs(A@x).max()
+    builder.setKernel(getFractionalKernel(2, 0.75), True)
+    builder.getH2()                                          # finalizes the context again; no dense assembly follows
+    y1, d1 = op.matvec(x), np.array(op.diagonal)
+    assert np.abs(y1-y0).max() == 0. and np.abs(d1-d0).max() == 0.
