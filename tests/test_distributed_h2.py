@@ -31,9 +31,9 @@ def test_subtree_owners_partition_the_tree():
         assert counts.max() <= 2.5*dm.num_dofs/size+64
 
 
-def _worker(rank, world, port, out, noRef, s):
+def _worker(rank, world, port, out, noRef, s, backend='gloo'):
     try:
-        _worker_body(rank, world, port, out, noRef, s)
+        _worker_body(rank, world, port, out, noRef, s, backend)
     except BaseException as e:
         import traceback
         out.put(dict(error='rank {}: {}\n{}'.format(rank, repr(e), traceback.format_exc())))
@@ -42,13 +42,18 @@ def _worker(rank, world, port, out, noRef, s):
         os._exit(1)
 
 
-def _worker_body(rank, world, port, out, noRef, s):
+def _worker_body(rank, world, port, out, noRef, s, backend='gloo'):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     import torch
     import torch.distributed as dist
-    dist.init_process_group('gloo', rank=rank, world_size=world)
-    torch.cuda.set_device(0)
+    # RCCL: one card per rank; the gloo rehearsal keeps every rank on the one card of the test box
+    gpu = rank if backend == 'nccl' else 0
+    torch.cuda.set_device(gpu)
+    if backend == 'nccl':
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', gpu))
+    else:
+        dist.init_process_group('gloo', rank=rank, world_size=world)
     from pynucleus_amd import disc, P1_DoFMap, PHYSICAL, getFractionalKernel, clusters
     from pynucleus_amd.builder import nonlocalBuilder
     from pynucleus_amd.distributed_h2 import DistributedH2Matrix_localData
@@ -83,7 +88,7 @@ def _worker_body(rank, world, port, out, noRef, s):
     uref = np.linalg.solve(Aref, rhs)
     e_solve = float(np.abs(np.asarray(u)-uref).max()/np.abs(uref).max())
     stats = torch.tensor([float(op.owned.shape[0]), float(op.num_ghosts), float(op.num_ghost_clusters), float(op.num_far_pairs),
-                          float(op.local.nnz)], dtype=torch.float64)
+                          float(op.local.nnz)], dtype=torch.float64, device='cuda' if backend == 'nccl' else 'cpu')
     gathered = [torch.zeros_like(stats) for _ in range(world)]
     dist.all_gather(gathered, stats)
     if rank == 0:
@@ -121,3 +126,29 @@ def test_halo_h2_operator(world, noRef, s):
     # of the global-data operator for the coefficient part
     assert (st[:, 1] < N).all()
     assert r['top'] < 8*world
+
+
+@pytest.mark.gpu
+def test_halo_h2_operator_over_rccl_two_ranks():
+    """the halo exchange (all-to-all of ghost entries and cluster coefficients, all-reduce of the shared top nodes) over RCCL
+    between two cards; skipped on a one-card box, where the gloo tests above run the same code"""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip('needs 2 GPUs, this box has {}'.format(torch.cuda.device_count()))
+    import torch.multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    out = ctx.Queue()
+    port = 29700+(os.getpid()+977) % 2000
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, out, 4, 0.75, 'nccl')) for r in range(2)]
+    for p in procs:
+        p.start()
+    r = out.get(timeout=240)
+    if 'error' in r:
+        for p in procs:
+            p.kill()
+        raise AssertionError(r['error'])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert r['e_mv'] < TOL and r['e_own'] < TOL, r
+    assert r['e_solve'] < 1e-7, r

@@ -78,9 +78,11 @@ def _slab_worker_body(rank, world, port, out, element, noRef, backend='gloo'):
     os.environ['MASTER_PORT'] = str(port)
     import torch
     import torch.distributed as dist
-    torch.cuda.set_device(0)
+    # RCCL needs one card per rank; the gloo rehearsal puts every rank on the one card of the test box
+    gpu = rank if (backend == 'nccl' and world > 1) else 0
+    torch.cuda.set_device(gpu)
     if backend == 'nccl':
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', 0))
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', gpu))
     else:
         dist.init_process_group('gloo', rank=rank, world_size=world)
     from pynucleus_amd import disc, P1_DoFMap, P2_DoFMap, PHYSICAL, getFractionalKernel
@@ -110,7 +112,7 @@ def _slab_worker_body(rank, world, port, out, element, noRef, backend='gloo'):
     # the whole matrix (N local products, summed over the ranks)
     e_full = float(np.abs(op.toarray()-Aref).max()/scale)
     e_diag = float(np.abs(op.diagonal-np.diag(Aref)).max()/scale)
-    cdev = torch.device('cuda', 0) if backend == 'nccl' else torch.device('cpu')
+    cdev = torch.device('cuda', gpu) if backend == 'nccl' else torch.device('cpu')
     pairs = torch.tensor([op.info['counters']['numAssembledCellPairs']], dtype=torch.float64, device=cdev)
     dist.all_reduce(pairs)
     byt = torch.tensor([float(op.local_bytes()), float(op.rowdofs.shape[0])], dtype=torch.float64, device=cdev)
@@ -195,3 +197,36 @@ def test_row_slab_operator_survives_refinalize():
     builder.getH2()                                          # finalizes the context again; no dense assembly follows
     y1, d1 = op.matvec(x), np.array(op.diagonal)
     assert np.abs(y1-y0).max() == 0. and np.abs(d1-d0).max() == 0.
+
+
+def _gpu_count():
+    import torch
+    return torch.cuda.device_count()          # counting devices does not initialise the GPU in this process
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('world,element,noRef', [(2, 'P1', 4), (2, 'P2layers', 3)])
+def test_row_slab_operator_over_rccl_two_ranks(world, element, noRef):
+    """the N > 1 path over RCCL itself -- one rank per card, init_process_group('nccl'), broadcast / all-reduce /
+    all-gather of device tensors between two GPUs -- under pytest, so that the first multi-GPU node exercises it here and not only
+    in bench.py.  Skipped on a box with one card (the gloo tests above cover the same code with every rank on that card)."""
+    if _gpu_count() < world:
+        pytest.skip('needs {} GPUs, this box has {}'.format(world, _gpu_count()))
+    import torch.multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    out = ctx.Queue()
+    port = 29700+(os.getpid()+1213+len(element)) % 2000
+    procs = [ctx.Process(target=_slab_worker, args=(r, world, port, out, element, noRef, 'nccl')) for r in range(world)]
+    for p in procs:
+        p.start()
+    r = out.get(timeout=300)
+    if 'error' in r:
+        for p in procs:
+            p.kill()
+        raise AssertionError(r['error'])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert r['pairs'] == r['ref_pairs']
+    assert r['e_mv'] < TOL and r['e_full'] < TOL and r['e_diag'] < TOL, r
+    assert r['e_solve'] < 1e-7, r
