@@ -325,6 +325,20 @@ int pnl_upload_pointwise_rules(pnl_context *ctx, int which, int panel, int nkeys
  * = (cell, boundary facet, common, key).  Distant pairs are found and classified on the device. */
 int pnl_assemble_dense_pointwise(pnl_context *ctx, double *A, int64_t ldA, int zero_exterior, int cell_begin, int cell_end,
                                  int npairs, const int32_t *pairs, int nbpairs, const int32_t *bpairs);
+/* near field of these kernels: the masked element-pair loop of assembleClusters with symmetricCells == symmetricLocalMatrix == False
+ * (nonlocalAssembly_{SCALAR}.pxi:1776-1840: masks over cellsUnion x cellsUnion :322-349, getElemElemMask :425-440, scatter
+ * addToMatrixElemElemMasked :520-532).  pairs[np][2]: ORDERED cell pairs, each evaluated in its own orientation (swapCells is the
+ * listing of (c2, c1)); masks[np][4]: bit p (2 dpe) + q of the 256-bit MASK_t requests local entry (p, q); rule[np]: -1 for a pair
+ * without a common vertex (classified on the device), otherwise the key of the pair's near rule (pnl_upload_pointwise_rules);
+ * data: unsymmetric CSR over the uploaded pattern (pnl_upload_sparsity), entries absent from it are dropped (addToEntry). */
+int pnl_assemble_pairs_masked_pointwise(pnl_context *ctx, int np, const int32_t *pairs, const uint64_t *masks, const int32_t *rule,
+                                        double *data);
+/* cluster exterior of these kernels (local_matrix_surface with the pointwise boundary kernel, nonlocalAssembly_{SCALAR}.pxi:1966-2028;
+ * the global Omega x Omega^c term :2126-2156 with fac = -1): items (cell, facet vertex ids[dim], mask over the dpe (dpe+1)/2 entries)
+ * as pnl_assemble_boundary_masked, plus rule[ni] (-1: no common vertex, else the key of the boundary near rule) and sv[ni], the
+ * largest order over the centres and vertices of cell and facet (evalParamsOnSimplices, kernelsCy.pyx:1825-1846). */
+int pnl_assemble_boundary_masked_pointwise(pnl_context *ctx, int ni, const int32_t *cells, const int32_t *facets, const uint32_t *masks,
+                                           const int32_t *rule, const double *sv, double fac, double *data, double *diag);
 
 /* counters of the last assemble call (synchronises the stream) */
 int pnl_get_counters(pnl_context *ctx, int64_t *out, int n);

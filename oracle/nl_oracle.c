@@ -1306,10 +1306,21 @@ int nlo_assemble_boundary_masked(const nlo_problem *P, int ni, const int32_t *ce
     for (int t = 0; t < ni; t++) {
         const int c1 = cells[t];
         Q.bcells = facets+(size_t)t*dim;
-        int panel = nlo_panel_boundary(&Q, c1, 0, perm1, perm2, perm);
+        int panel;
+        if (P->pw_type) {
+            /* order per quadrature point: local_matrix_surface with the pointwise boundary kernel, s(x) at x in the cell; no
+             * shift of the facet centre for orders of one variable (surfaceIntegralNeedsShift, NA:1966) */
+            double sv;
+            panel = panel_boundary_pw(&Q, c1, 0, perm1, perm2, perm, &sv);
+            if (panel >= 1 && (panel > P->qmax || P->dist_off[panel+1] == P->dist_off[panel]
+                               || P->bfacet_off[panel+1] == P->bfacet_off[panel])) return -(2000+panel);
+            eval_boundary_pw(&Q, c1, 0, panel, sv, perm1, perm2, perm, contrib, &nevals);
+        } else {
+        panel = nlo_panel_boundary(&Q, c1, 0, perm1, perm2, perm);
         if (panel >= 1 && (panel > P->qmax || P->dist_off[panel+1] == P->dist_off[panel]
                            || P->bfacet_off[panel+1] == P->bfacet_off[panel])) return -(2000+panel);
         nlo_eval_boundary(&Q, c1, 0, panel, perm1, perm2, perm, contrib, &nevals);
+        }
         const uint32_t mask = masks[t];
         int k = 0;                                  /* NA:534-546 addToMatrixElemSymMasked */
         for (int p = 0; p < dpe; p++) {
@@ -1325,6 +1336,56 @@ int nlo_assemble_boundary_masked(const nlo_problem *P, int ni, const int32_t *ce
                 k++;
             }
         }
+    }
+    return 0;
+}
+
+/* NA:1812-1832 with symmetricCells == symmetricLocalMatrix == False (non-symmetric kernels): the masks hold ORDERED cell pairs --
+ * buildMasksForClusters walks cellsUnion x cellsUnion (NA:322-349) -- with one bit per entry of the (2 dpe)^2 local matrix,
+ * k = p (2 dpe) + q (getElemElemMask NA:425-440); every listed pair is evaluated in ITS orientation (setCell1 / setCell2, the
+ * kernel parameters of that orientation) and scattered with fac = 1 by addToMatrixElemElemMasked (NA:520-532) into CSR.
+ * Orders per quadrature point: the _nonsym local matrices; piecewise-constant non-symmetric orders: the symmetric local matrix
+ * of the class of (label c1, label c2), stored in full (as nlo_get_dense_nonsym). */
+int nlo_assemble_pairs_masked_nonsym(const nlo_problem *P, int np, const int32_t *pairs, const uint64_t *masks, const int32_t *indptr,
+                                     const int32_t *indices, double *data, int64_t *counters) {
+    const int dpe = P->dpe, n2 = 2*dpe;
+    if (dpe > MAXDPE || (!P->pw_type && !P->nclasses)) return -1;
+    const int piecewise = !P->pw_type;
+    double contrib[4*MAXDPE*MAXDPE], csym[MAXE];
+    int perm1[MAXV], perm2[MAXV], perm[2*MAXDPE], ld[2*MAXDPE];
+    memset(counters, 0, sizeof(int64_t)*NLO_NUM_COUNTERS);
+    for (int t = 0; t < np; t++) {
+        const int a = pairs[2*t], b = pairs[2*t+1];
+        const uint64_t *mask = masks+4*(size_t)t;
+        counters[0]++;
+        double sv, s1[MAXV][2], s2[MAXV][2], ce[2];
+        const int panel = panel_nonsym(P, a, b, perm1, perm2, perm, &sv);
+        if (panel >= 1 && (panel > P->qmax || P->dist_off[panel+1] == P->dist_off[panel])) return -(1000+panel);
+        counters[1]++;
+        int skip = 1;
+        for (int p = 0; p < dpe; p++) { ld[p] = P->dofs[a*dpe+p]; ld[dpe+p] = P->dofs[b*dpe+p]; skip = skip && ld[p] < 0 && ld[dpe+p] < 0; }
+        if (skip) continue;
+        if (panel >= 1) counters[8+panel]++; else counters[8+NLO_MAX_ORDER+(-panel-1)]++;
+        simplex_of(P, a, s1, ce);
+        simplex_of(P, b, s2, ce);
+        if (piecewise) {
+            nlo_eval(P, a, b, panel, perm1, perm2, perm, csym, &counters[2]);
+            int k = 0;
+            for (int p = 0; p < n2; p++)
+                for (int q = p; q < n2; q++) { contrib[p*n2+q] = csym[k]; contrib[q*n2+p] = csym[k]; k++; }
+        } else if (panel >= 1) {
+            eval_distant_nonsym(P, s1, s2, P->vol[a]*P->vol[b], panel, contrib);
+            const int n = P->dist_off[panel+1]-P->dist_off[panel];
+            counters[2] += (int64_t)n*n;
+        } else
+            eval_singular_nonsym(P, s1, s2, P->vol[a]*P->vol[b], -panel-1, pw_key(P->pw_keys, P->pw_nkeys, sv), perm1, perm2, perm,
+                                 contrib, &counters[2]);
+        int k = 0;
+        for (int p = 0; p < n2; p++)
+            for (int q = 0; q < n2; q++) {
+                if ((mask[k >> 6] >> (k & 63)) & 1) sparse_add(indptr, indices, data, NULL, ld[p], ld[q], contrib[k]);
+                k++;
+            }
     }
     return 0;
 }

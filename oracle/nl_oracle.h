@@ -130,4 +130,8 @@ int nlo_assemble_pairs_masked(const nlo_problem *P, int np, const int32_t *pairs
  * items (cell, facet vertex ids[dim], mask over the dpe(dpe+1)/2 entries), scatter NA:534-546 */
 int nlo_assemble_boundary_masked(const nlo_problem *P, int ni, const int32_t *cells, const int32_t *facets, const uint32_t *masks,
                                  double fac, const int32_t *indptr, const int32_t *indices, double *data, double *diag);
+/* the same loop for non-symmetric kernels (symmetricCells == symmetricLocalMatrix == False): ORDERED pairs, masks over the
+ * (2 dpe)^2 entries (k = p (2 dpe) + q), unsymmetric CSR only; counters as nlo_get_dense_nonsym (NLO_NUM_COUNTERS entries) */
+int nlo_assemble_pairs_masked_nonsym(const nlo_problem *P, int np, const int32_t *pairs, const uint64_t *masks, const int32_t *indptr,
+                                     const int32_t *indices, double *data, int64_t *counters);
 #endif

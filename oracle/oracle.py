@@ -91,6 +91,8 @@ def lib():
         L.nlo_pw_svalue.argtypes = [C.POINTER(nlo_problem), C.c_int, C.c_int]
         L.nlo_assemble_pairs_masked.restype = C.c_int
         L.nlo_assemble_pairs_masked.argtypes = [C.POINTER(nlo_problem), C.c_int, _P, _P, _P, _P, _P, _P, _P]
+        L.nlo_assemble_pairs_masked_nonsym.restype = C.c_int
+        L.nlo_assemble_pairs_masked_nonsym.argtypes = [C.POINTER(nlo_problem), C.c_int, _P, _P, _P, _P, _P, _P]
         L.nlo_assemble_boundary_masked.restype = C.c_int
         L.nlo_assemble_boundary_masked.argtypes = [C.POINTER(nlo_problem), C.c_int, _P, _P, _P, C.c_double, _P, _P, _P, _P]
         _LIB = L
@@ -336,6 +338,38 @@ class OracleProblem:
             if rc:
                 raise RuntimeError('oracle failed with code {}'.format(rc))
         return data, diag, dict(numCellPairs=int(cnt[0]), numAssembledCellPairs=int(cnt[1]), numIntegrations=int(cnt[2]))
+
+
+    def assemble_clusters_nonsym(self, pairs, masks, bcells, bfacets, bmasks, indptr, indices, global_boundary=None):
+        """non-symmetric kernels (order per quadrature point, or a non-symmetric piecewise-constant table): ORDERED pairs with masks
+        over the (2 dpe)^2 local entries (nlo_assemble_pairs_masked_nonsym) + cluster-local boundary items with the kernel's
+        boundary twin into unsymmetric CSR; returns (data, counters)"""
+        data = np.zeros(indices.shape[0])
+        pairs = np.ascontiguousarray(pairs, dtype=np.int32)
+        masks = np.ascontiguousarray(masks, dtype=np.uint64)
+        indptr = np.ascontiguousarray(indptr, dtype=np.int32)
+        indices = np.ascontiguousarray(indices, dtype=np.int32)
+        cnt = np.zeros(NLO_NUM_COUNTERS, dtype=np.int64)
+        rc = lib().nlo_assemble_pairs_masked_nonsym(C.byref(self.P), pairs.shape[0], pairs.ctypes.data, masks.ctypes.data,
+                                                    indptr.ctypes.data, indices.ctypes.data, data.ctypes.data, cnt.ctypes.data)
+        if rc:
+            raise RuntimeError('oracle failed with code {}'.format(rc))
+        items = [(bcells, bfacets, bmasks, 1.)]
+        if global_boundary is not None:
+            items.append(global_boundary)
+        for cc, ff, mm, fac in items:
+            cc = np.ascontiguousarray(cc, dtype=np.int32)
+            ff = np.ascontiguousarray(ff, dtype=np.int32)
+            mm = np.ascontiguousarray(mm, dtype=np.uint32)
+            if cc.shape[0] == 0:
+                continue
+            rc = lib().nlo_assemble_boundary_masked(C.byref(self.P), cc.shape[0], cc.ctypes.data, ff.ctypes.data, mm.ctypes.data,
+                                                    float(fac), indptr.ctypes.data, indices.ctypes.data, data.ctypes.data, None)
+            if rc:
+                raise RuntimeError('oracle failed with code {}'.format(rc))
+        hist = {q: int(cnt[8+q]) for q in range(NLO_MAX_ORDER) if cnt[8+q]}
+        sing = {-1-k: int(cnt[8+NLO_MAX_ORDER+k]) for k in range(3)}
+        return data, dict(numCellPairs=int(cnt[0]), numAssembledCellPairs=int(cnt[1]), numIntegrations=int(cnt[2]), orders=hist, singular=sing)
 
 
 # -- variable order: kernel blocks, interfaces and the boundary items of assembleClusters -----------------------------------

@@ -30,6 +30,7 @@ EXPORTS = ['pnl_create', 'pnl_destroy', 'pnl_error_string', 'pnl_version', 'pnl_
            'pnl_assemble_dense_tiles', 'pnl_get_counters', 'pnl_get_phase_ms', 'pnl_get_kernel_ms', 'pnl_tree_build', 'pnl_tree_build_blocks', 'pnl_tree_build_refined', 'pnl_tree_destroy', 'pnl_tree_sizes', 'pnl_tree_get', 'pnl_tree_node_cells', 'pnl_h2_transfer_matrices', 'pnl_nfplan_build', 'pnl_nfplan_destroy', 'pnl_nfplan_sizes', 'pnl_nfplan_get', 'pnl_horizon_pattern', 'pnl_near_pattern', 'pnl_pattern_set_max_nnz', 'pnl_set_option', 'pnl_set_cell_order', 'pnl_set_interaction_transform', 'pnl_set_order_vertex_values', 'pnl_h2_get', 'pnl_h2_set', 'pnl_pattern_nnz', 'pnl_pattern_get', 'pnl_pattern_destroy', 'pnl_set_row_slab', 'pnl_diag_blocks_size', 'pnl_get_diag_blocks', 'pnl_slab_matvec', 'pnl_slab_diagonal', 'pnl_gemv', 'pnl_cg_jacobi',
            'pnl_inv_diagonal', 'pnl_set_classes', 'pnl_select_class', 'pnl_upload_sparsity', 'pnl_upload_sparsity_device', 'pnl_assemble_pairs_masked', 'pnl_assemble_boundary_masked', 'pnl_assemble_clusters_tiled', 'pnl_h2_setup', 'pnl_h2_matvec', 'pnl_h2_upward', 'pnl_h2_interact', 'pnl_h2_downward', 'pnl_h2_sizes', 'pnl_spmv',
            'pnl_assemble_pairs_in_horizon', 'pnl_set_nonsymmetric', 'pnl_set_order_function', 'pnl_upload_pointwise_rules', 'pnl_assemble_dense_pointwise',
+           'pnl_assemble_pairs_masked_pointwise', 'pnl_assemble_boundary_masked_pointwise',
            'pnl_gemv_axpby', 'pnl_csr_matvec', 'pnl_mg_create', 'pnl_mg_destroy', 'pnl_mg_cycle', 'pnl_mg_solve', 'pnl_mg_cg', 'pnl_theta_step']
 
 
@@ -191,6 +192,8 @@ def load():
     L.pnl_set_order_function.argtypes = [vp, C.POINTER(pnl_order_function), vp, vp, dbl, dbl, dbl, dbl]
     L.pnl_upload_pointwise_rules.argtypes = [vp, i32, i32, i32, i32, i32, vp, vp, vp, vp]
     L.pnl_assemble_dense_pointwise.argtypes = [vp, vp, i64, i32, i32, i32, i32, vp, i32, vp]
+    L.pnl_assemble_pairs_masked_pointwise.argtypes = [vp, i32, vp, vp, vp, vp]
+    L.pnl_assemble_boundary_masked_pointwise.argtypes = [vp, i32, vp, vp, vp, vp, vp, dbl, vp, vp]
     for name in EXPORTS:
         f = getattr(L, name)
         if name in ('pnl_pattern_nnz', 'pnl_pattern_set_max_nnz'):
@@ -299,19 +302,7 @@ class Context:
             if int(T.order_type) == 5:
                 vs, pvs = _hp(T.order_vertex_values, np.float64)
                 self.check(L.pnl_set_order_vertex_values(h, vs.shape[0], pvs))
-            R = T.pw_rules()
-            for slot, (nodes, ww, phi0, phi1) in R['rules'].items():
-                n, pn = _hp(nodes, np.float64)
-                w_, pw_ = _hp(ww, np.float64)
-                a0, p0 = _hp(phi0, np.float64)
-                a1, p1 = _hp(phi1, np.float64)
-                self.check(L.pnl_upload_pointwise_rules(h, PNL_INTERIOR, -(slot+1), n.shape[0], w_.shape[1], a0.shape[1], pn, pw_, p0, p1))
-            for slot, (nodes, ww, phi) in R['brules'].items():
-                n, pn = _hp(nodes, np.float64)
-                w_, pw_ = _hp(ww, np.float64)
-                a0, p0 = _hp(phi, np.float64)
-                self.check(L.pnl_upload_pointwise_rules(h, PNL_BOUNDARY, -(slot+1), n.shape[0], w_.shape[1], a0.shape[1], pn, pw_, p0, None))
-            self._pw_pairs = (np.ascontiguousarray(R['pairs'], dtype=np.int32), np.ascontiguousarray(R['bpairs'], dtype=np.int32))
+            self.upload_pointwise_rules(T)
             return
         classes = getattr(T, 'classes', None)
         if classes:
@@ -340,6 +331,25 @@ class Context:
                     ps, pps = _hp(r.psi, np.float64)
                     self.check(L.pnl_upload_singular_rule(h, PNL_BOUNDARY, panel, r.num_nodes, r.rows, pn, pww, pps, float(Tk.bsing_fac)))
         self.check(L.pnl_select_class(h, 0))
+
+    def upload_pointwise_rules(self, T):
+        """near rules of a kernel with an order per quadrature point, keyed by the distinct orders of the touching pairs (again after
+        nonlocalTables.need_boundary_keys extended the boundary keys)"""
+        L, h = self.L, self.h
+        R = T.pw_rules()
+        for slot, (nodes, ww, phi0, phi1) in R['rules'].items():
+            n, pn = _hp(nodes, np.float64)
+            w_, pw_ = _hp(ww, np.float64)
+            a0, p0 = _hp(phi0, np.float64)
+            a1, p1 = _hp(phi1, np.float64)
+            self.check(L.pnl_upload_pointwise_rules(h, PNL_INTERIOR, -(slot+1), n.shape[0], w_.shape[1], a0.shape[1], pn, pw_, p0, p1))
+        for slot, (nodes, ww, phi) in R['brules'].items():
+            n, pn = _hp(nodes, np.float64)
+            w_, pw_ = _hp(ww, np.float64)
+            a0, p0 = _hp(phi, np.float64)
+            self.check(L.pnl_upload_pointwise_rules(h, PNL_BOUNDARY, -(slot+1), n.shape[0], w_.shape[1], a0.shape[1], pn, pw_, p0, None))
+        self._pw_pairs = (np.ascontiguousarray(R['pairs'], dtype=np.int32), np.ascontiguousarray(R['bpairs'], dtype=np.int32))
+        self._pw_keys = (np.ascontiguousarray(R['keys']), np.ascontiguousarray(R['bkeys']))
 
     def _set_kernel(self, which, kernel, formula):
         p = kernel.device_params()
@@ -417,6 +427,25 @@ class Context:
         assert p.ndim == 2 and p.shape[1] == 2
         self.check(self.L.pnl_assemble_pairs_masked(self.h, p.shape[0], pp, pm, C.c_void_p(data_ptr),
                                                     C.c_void_p(diag_ptr) if diag_ptr else None))
+
+    def assemble_pairs_masked_pointwise(self, pairs, masks, rule, data_ptr):
+        """near field of a kernel with an order per quadrature point: ORDERED pairs, masks over the (2 dpe)^2 local entries,
+        rule[t] = -1 (no common vertex) or the key of the touching pair's near rule"""
+        p, pp = _hp(pairs, np.int32)
+        m, pm = _hp(masks, np.uint64)
+        r, pr = _hp(rule, np.int32)
+        assert p.ndim == 2 and p.shape[1] == 2 and m.shape == (p.shape[0], 4) and r.shape == (p.shape[0],)
+        self.check(self.L.pnl_assemble_pairs_masked_pointwise(self.h, p.shape[0], pp, pm, pr, C.c_void_p(data_ptr)))
+
+    def assemble_boundary_masked_pointwise(self, cells, facets, masks, rule, sv, fac, data_ptr, diag_ptr=None):
+        c, pc = _hp(cells, np.int32)
+        f, pf = _hp(facets, np.int32)
+        m, pm = _hp(masks, np.uint32)
+        r, pr = _hp(rule, np.int32)
+        s_, ps = _hp(sv, np.float64)
+        assert f.shape[0] == c.shape[0] == m.shape[0] == r.shape[0] == s_.shape[0]
+        self.check(self.L.pnl_assemble_boundary_masked_pointwise(self.h, c.shape[0], pc, pf, pm, pr, ps, float(fac), C.c_void_p(data_ptr),
+                                                                 C.c_void_p(diag_ptr) if diag_ptr else None))
 
     def select_class(self, k):
         """variable order: the kernel class the next pnl_assemble_boundary_masked integrates with"""

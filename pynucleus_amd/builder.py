@@ -640,14 +640,19 @@ class nonlocalBuilder:
         Without an admissible pair the dense operator is returned (the reference's assembleDenseWhenH2Fails branch).  With a
         communicator (row-sharded near field) the near-field operator alone is returned: the far field is not
         distributed yet."""
-        self._symmetric_only('getH2')
         if self._single_order_twin() is not None:
             return self._single_order_twin().getH2(returnNearField, returnTree, **kwargs)
         from . import clusters
         from .h2 import h2Plan, H2Matrix, interpolationOrder
         rp = self.getH2RefinementParams()
         far_class = None
-        if self.kernel.variable:
+        pointwise = bool(getattr(self.tables, 'pointwise', False))
+        if pointwise and self.comm is not None:
+            raise NotImplementedError('distributed H2 operator of a kernel with an order per quadrature point')
+        if pointwise and hasattr(self.kernel.s.sFun, 'vertex_values'):
+            # the far field evaluates s at interpolation nodes, which needs the reference's cell finder for a finite element order
+            raise NotImplementedError('H2 operator of an order given as a finite element function')
+        if self.kernel.variable and not pointwise:
             # kernel blocks (getKernelBlocksAndJumps NA:2312-2352): clusters of one block each, the interface DoFs stay in the near
             # field; the far field between two clusters uses the order between their blocks
             if not self.kernel.symmetric or self.kernel.finiteHorizon:
@@ -732,7 +737,8 @@ class nonlocalBuilder:
         (buildMasksForClusters NA:260-391) and the item list of the cluster-local Gauss-theorem term
         (NA:1842-1889).  Device side: classification, quadrature and masked scatter into CSR / SSS.
         Without zeroExterior the global Omega x Omega^c term is subtracted again (NA:1896-1913)."""
-        self._symmetric_only('assembleClusters')
+        if getattr(self.tables, 'pointwise', False):
+            return self._assembleClustersPointwise(Pnear, Anear, myRoot, _clusterBoundary, _globalBoundary)
         if self._single_order_twin() is not None:
             return self._single_order_twin().assembleClusters(Pnear, forceUnsymmetricMatrix, Anear, jumps, myRoot, _clusterBoundary,
                                                               _globalBoundary, _symmetrizeMasks, **kwargs)
@@ -839,6 +845,82 @@ class nonlocalBuilder:
             self.PLogger.addValue(k, v)
         self.PLogger.addTimer('interior', 1e-3*ms_total)
         Anear.info = dict(counters=dict(totals, orders=hist, singular=sing, numBoundaryItems=nitems), interior_ms=ms_total)
+        return Anear
+
+
+    def _assembleClustersPointwise(self, Pnear, Anear=None, myRoot=None, clusterBoundary=True, globalBoundary=True):
+        """assembleClusters for the non-symmetric kernels with an order per quadrature point (NA:1776-1840 with symmetricCells ==
+        symmetricLocalMatrix == False; cluster exterior NA:1966-2028 with local_matrix_surface = the pointwise boundary kernel, no
+        shift of the facet centre and no interface terms for orders of one variable, NA:1966, 2623): every ORDERED element pair of
+        cellsUnion x cellsUnion with a mask over its (2 dpe)^2 local entries, evaluated in its own orientation, into unsymmetric CSR."""
+        import torch
+        from . import clusters
+        from .linear_operators import CSR_LinearOperator
+        if myRoot is not None or self.comm is not None:
+            raise NotImplementedError('distributed near field of a kernel with an order per quadrature point')
+        ctx = self.context()
+        dev = torch.device('cuda', ctx.device)
+        dm, T = self.dm, self.tables
+        if Anear is None:
+            indptr, indices = clusters.getSparseNearField(dm, Pnear, symmetric=False, device=dev)
+            Anear = CSR_LinearOperator(indptr, indices, dm.num_dofs, ctx, dev)
+        Anear._bind()
+        data_ptr, diag_ptr = Anear._ptrs()
+        assert diag_ptr is None, 'non-symmetric kernels need unsymmetric (CSR) storage'
+        mcells = np.asarray(self.mesh.cells)
+        # cluster exterior (and, for the regional operator, the global term with -1): items and the orders of the touching ones first --
+        # their near rules are keyed by the pair's order and may not be among the rules of the domain boundary
+        groups = []
+        if T.has_boundary_tables and clusterBoundary:
+            groups.append((1., clusters.clusterBoundaryItems(dm, Pnear)))
+        if T.has_boundary_tables and clusterBoundary and not self.zeroExterior and globalBoundary:
+            groups.append((-1., clusters.globalBoundaryItems(dm, T.bcells)))
+        prepared = []
+        for fac, (cells, facets, bmasks) in groups:
+            sv = np.maximum(T.cell_smax[cells], T.facet_order(facets)) if cells.shape[0] else np.zeros(0)
+            common = (mcells[cells][:, :, None] == facets[:, None, :]).any(axis=2).sum(axis=1) if cells.shape[0] else np.zeros(0, dtype=np.int64)
+            prepared.append((fac, cells, facets, bmasks, sv, common > 0))
+        touching_sv = [sv[t] for _, _, _, _, sv, t in prepared if sv.shape[0]]
+        if touching_sv and T.need_boundary_keys(np.concatenate(touching_sv)):
+            ctx.upload_pointwise_rules(T)
+        keys, bkeys = ctx._pw_keys
+        maxNNZ = int(self.params.get('maxMasksNNZ', 10000000))
+        totals = dict(numCellPairs=0, numAssembledCellPairs=0, numIntegrations=0)
+        hist, sing = {}, {}
+        ms_total = 0.
+        for pairs, masks in clusters.iterMasksForClustersNonsym(dm, Pnear, maxNNZ):
+            touching = (mcells[pairs[:, 0]][:, :, None] == mcells[pairs[:, 1]][:, None, :]).any(axis=(1, 2))
+            rule = np.full(pairs.shape[0], -1, dtype=np.int32)
+            svp = np.maximum(T.cell_smax[pairs[touching, 0]], T.cell_smax[pairs[touching, 1]])
+            k = np.searchsorted(keys, svp)
+            assert (k < keys.shape[0]).all() and (keys[np.minimum(k, keys.shape[0]-1)] == svp).all(), 'touching pair without a near rule'
+            rule[touching] = k
+            ctx.assemble_pairs_masked_pointwise(pairs, masks, rule, data_ptr)
+            cnt = ctx.counters()
+            for kk in totals:
+                totals[kk] += cnt[kk]
+            for q, c in cnt['orders'].items():
+                hist[q] = hist.get(q, 0)+c
+            for q, c in cnt['singular'].items():
+                sing[q] = sing.get(q, 0)+c
+            ms_total += ctx.phase_ms()['total']
+        nitems = 0
+        for fac, cells, facets, bmasks, sv, touching in prepared:
+            if cells.shape[0] == 0:
+                continue
+            rule = np.full(cells.shape[0], -1, dtype=np.int32)
+            k = np.searchsorted(bkeys, sv[touching])
+            assert (k < bkeys.shape[0]).all() and (bkeys[np.minimum(k, bkeys.shape[0]-1)] == sv[touching]).all()
+            rule[touching] = k
+            ctx.assemble_boundary_masked_pointwise(cells, facets, bmasks, rule, sv, fac, data_ptr, None)
+            nitems += int(cells.shape[0])
+        ctx.synchronize()
+        self.PLogger.addValue('useSymmetricCells', False)
+        self.PLogger.addValue('useSymmetricLocalMatrix', False)
+        for kk, v in totals.items():
+            self.PLogger.addValue(kk, v)
+        self.PLogger.addTimer('interior', 1e-3*ms_total)
+        Anear.info = dict(counters=dict(totals, orders=hist, singular=sing, numBoundaryItems=nitems), interior_ms=ms_total, mode='masks')
         return Anear
 
 

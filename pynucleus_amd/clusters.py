@@ -510,6 +510,51 @@ def iterMasksForClusters(dm, Pnear, maxNNZ=10000000, symmetrize=False):
         yield _mergeMasks(keys, masks, nc)
 
 
+def _masksOfClusterPairNonsym(dm, cp):
+    """(keys = c1*nc + c2 over ORDERED pairs, mask words) requested by one near-field cluster pair for a non-symmetric local matrix:
+    buildMasksForClusters with useSymmetricCells == symmetricLocalMatrix == False (NA:322-349) walks cellsUnion x cellsUnion, keeps
+    the pairs whose 2 dpe local DoFs hold a DoF of n1 and a DoF of n2, and sets bit p (2 dpe) + q when local DoF p lies in n1 and
+    local DoF q in n2 (getElemElemMask NA:425-440)."""
+    dpe = dm.dofs_per_element
+    n2 = 2*dpe
+    assert n2*n2 <= 256
+    nc = dm.mesh.num_cells
+    in1 = np.zeros(dm.num_dofs+1, dtype=bool)
+    in2 = np.zeros(dm.num_dofs+1, dtype=bool)
+    in1[cp.n1.dofs] = True
+    in2[cp.n2.dofs] = True
+    cu = np.asarray(cp.cellsUnion)
+    d = np.where(dm.dofs[cu] >= 0, dm.dofs[cu], dm.num_dofs)
+    m1, m2 = in1[d], in2[d]                                       # [ncu, dpe]
+    a1, a2 = m1.any(axis=1), m2.any(axis=1)
+    ok = (a1[:, None] | a1[None, :]) & (a2[:, None] | a2[None, :])
+    ii, jj = np.nonzero(ok)
+    cm1 = np.concatenate([m1[ii], m1[jj]], axis=1)                # cellMask1 over the 2 dpe local DoFs of (c1, c2)
+    cm2 = np.concatenate([m2[ii], m2[jj]], axis=1)
+    bits = (cm1[:, :, None] & cm2[:, None, :]).reshape(ii.shape[0], n2*n2)
+    full = np.zeros((ii.shape[0], 256), dtype=np.uint8)
+    full[:, :n2*n2] = bits
+    words = np.packbits(full, axis=1, bitorder='little').view(np.uint64).reshape(-1, 4)
+    return cu[ii].astype(np.int64)*nc+cu[jj], words
+
+
+def iterMasksForClustersNonsym(dm, Pnear, maxNNZ=10000000):
+    """yields (pairs[np, 2] ORDERED, masks[np, 4] uint64 over the (2 dpe)^2 local entries) for consecutive groups of cluster pairs
+    of about maxNNZ element pairs: the chunked loop NA:1786-1791 for non-symmetric kernels (masks of one group OR-merged)"""
+    nc = dm.mesh.num_cells
+    keys, masks, n = [], [], 0
+    for cp in Pnear:
+        k, m = _masksOfClusterPairNonsym(dm, cp)
+        keys.append(k)
+        masks.append(m)
+        n += k.shape[0]
+        if n > maxNNZ:
+            yield _mergeMasks(keys, masks, nc)
+            keys, masks, n = [], [], 0
+    if keys:
+        yield _mergeMasks(keys, masks, nc)
+
+
 def buildMasksForClusters(dm, Pnear, symmetrize=False):
     """all cluster pairs in one group"""
     out = list(iterMasksForClusters(dm, Pnear, maxNNZ=1 << 62, symmetrize=symmetrize))

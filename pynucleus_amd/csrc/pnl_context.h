@@ -258,6 +258,10 @@ inline void kt_end(pnl_context *ctx, int slot) { (void)hipEventRecord(ctx->kev[s
 // pnl_hip.hip: joins the vertex-order search finalize() started and uploads the permuted cell tables (sets have_tile_order)
 int pnl_tile_order_ready(pnl_context *ctx);
 
+// pnl_hip.hip / pnl_pwnear.hip: kernels with an order per quadrature point
+int pnl_pw_prepare(pnl_context *ctx, int need_boundary);
+int pnl_pw_h2_interp(pnl_context *ctx);
+
 // pnl_tile2.hip
 int pnl2_launch_uniform(pnl_context *ctx, int kt, const DevProblem &Pt, const int2 *tiles, const int *tile_cls, int ntiles, int q,
                         double *A, int64_t ldA, double *Dglob, const SlotOut &SO);

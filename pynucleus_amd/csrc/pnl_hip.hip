@@ -1722,7 +1722,7 @@ int pointwise_impl(pnl_context *ctx, double *A, int64_t ldA, int zero_exterior, 
             hipLaunchKernelGGL((k_pw_lane<DIM>), dim3(256*2), dim3(PNL_NTHREADS), 0, ctx->stream, P, W, (const int4*)ctx->b_wlsorted.p,
                                (const unsigned*)offs, A, (long long)ldA, (double*)ctx->b_D.p);
         hipLaunchKernelGGL(kfun, dim3(256*4), dim3(PNL_NTHREADS), lds, ctx->stream, P, W, (const int4*)ctx->b_wlsorted.p,
-                           (const unsigned*)offs, A, (long long)ldA, (double*)ctx->b_D.p, tab_max, lane_kernel ? PNL_PW_LANE_MAXPTS+1 : 0);
+                           (const unsigned*)offs, A, (long long)ldA, (double*)ctx->b_D.p, tab_max, lane_kernel ? PNL_PW_LANE_MAXPTS+1 : 0, PwNear{});
         HIPCHK(ctx, hipGetLastError());
     }
     HIPCHK(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
@@ -1730,10 +1730,10 @@ int pointwise_impl(pnl_context *ctx, double *A, int64_t ldA, int zero_exterior, 
     if (npairs > 0) {
         const unsigned grid = (unsigned)((2ll*npairs*64+PNL_NTHREADS-1)/PNL_NTHREADS);
         const int4 *pp = (const int4*)ctx->b_pw_pairs.p;
-        hipLaunchKernelGGL((k_pw_singular<DIM, DPE, 0>), dim3(grid), dim3(PNL_NTHREADS), 0, ctx->stream, P, W, pp, npairs, A, (long long)ldA, cell_begin, cell_end);
-        hipLaunchKernelGGL((k_pw_singular<DIM, DPE, 1>), dim3(grid), dim3(PNL_NTHREADS), 0, ctx->stream, P, W, pp, npairs, A, (long long)ldA, cell_begin, cell_end);
+        hipLaunchKernelGGL((k_pw_singular<DIM, DPE, 0>), dim3(grid), dim3(PNL_NTHREADS), 0, ctx->stream, P, W, pp, npairs, A, (long long)ldA, cell_begin, cell_end, PwNear{}, (const int*)nullptr);
+        hipLaunchKernelGGL((k_pw_singular<DIM, DPE, 1>), dim3(grid), dim3(PNL_NTHREADS), 0, ctx->stream, P, W, pp, npairs, A, (long long)ldA, cell_begin, cell_end, PwNear{}, (const int*)nullptr);
         if (DIM == 2)
-            hipLaunchKernelGGL((k_pw_singular<DIM, DPE, (DIM == 2 ? 2 : 1)>), dim3(grid), dim3(PNL_NTHREADS), 0, ctx->stream, P, W, pp, npairs, A, (long long)ldA, cell_begin, cell_end);
+            hipLaunchKernelGGL((k_pw_singular<DIM, DPE, (DIM == 2 ? 2 : 1)>), dim3(grid), dim3(PNL_NTHREADS), 0, ctx->stream, P, W, pp, npairs, A, (long long)ldA, cell_begin, cell_end, PwNear{}, (const int*)nullptr);
         HIPCHK(ctx, hipGetLastError());
     }
     HIPCHK(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
@@ -2825,10 +2825,16 @@ int pnl_assemble_clusters_tiled(pnl_context *ctx, const pnl_cluster_plan *pl, in
 int pnl_h2_setup(pnl_context *ctx, const pnl_h2_plan *pl) {
     if (!ctx || !pl) return PNL_ERR_INVALID;
     int rc;
+    if (ctx->have_pw) {
+        // order per quadrature point: no kernel block of a class, the order function evaluates s(x) (pnl_pwnear.hip)
+        if (ctx->pw.type == 5) return fail(ctx, PNL_ERR_UNSUPPORTED, "H2 far field of an order given as a finite element function");
+        if ((rc = pnl_pw_prepare(ctx, 0))) return rc;
+    } else {
     if ((rc = check_ready(ctx))) return rc;
     if ((rc = finalize(ctx))) return rc;
     refresh_tables(ctx);
     if (!std::isinf(ctx->C().kern[0].horizon2)) return fail(ctx, PNL_ERR_UNSUPPORTED, "H2 far field: infinite horizon only");
+    }
     if (ctx->nlab > 0 && (ctx->nonsym || (pl->nfar > 0 && !pl->far_class)))
         return fail(ctx, PNL_ERR_UNSUPPORTED, "H2 far field of a variable order: symmetric order table and a kernel class per admissible pair");
     if (pl->far_class)
@@ -2925,6 +2931,10 @@ int pnl_h2_setup(pnl_context *ctx, const pnl_h2_plan *pl) {
             if ((rc = upload(ctx, B[19], pl->far_class, (size_t)pl->nfar))) return rc;
             kcls = (const DevKernel*)B[18].p; fcls = (const int*)B[19].p;
         }
+        if (ctx->have_pw) {
+            // order per quadrature point: the kernel with the order at the nodes of the row cluster (pnl_pwnear.hip)
+            if ((rc = pnl_pw_h2_interp(ctx))) return rc;
+        } else
         if (dim == 2) hipLaunchKernelGGL((k_h2_kernel_interp<2>), dim3(pl->nfar), dim3(PNL_NTHREADS), 0, ctx->stream, ctx->P, H, kcls, fcls);
         else hipLaunchKernelGGL((k_h2_kernel_interp<1>), dim3(pl->nfar), dim3(PNL_NTHREADS), 0, ctx->stream, ctx->P, H, kcls, fcls);
     }
@@ -3112,9 +3122,12 @@ int pnl_upload_pointwise_rules(pnl_context *ctx, int which, int panel, int nkeys
 }
 
 
-int pnl_assemble_dense_pointwise(pnl_context *ctx, double *A, int64_t ldA, int zero_exterior, int cell_begin, int cell_end,
-                                 int npairs, const int32_t *pairs, int nbpairs, const int32_t *bpairs) {
-    if (!ctx) return PNL_ERR_INVALID;
+}  // extern "C"
+
+// what every assembly with an order per quadrature point needs before its first launch (pnl_assemble_dense_pointwise here, the
+// near-field entry points in pnl_pwnear.hip): padded cell tables, the per-cell / per-facet largest orders and the vertex values of
+// a P1 order function on the device, the distant rules in the problem description
+int pnl_pw_prepare(pnl_context *ctx, int need_boundary) {
     int rc;
     if (!ctx->have_pw || !ctx->have_rules) return fail(ctx, PNL_ERR_STATE, "order function and distant rules must be set before assembling");
     if ((rc = finalize(ctx))) return rc;
@@ -3129,17 +3142,38 @@ int pnl_assemble_dense_pointwise(pnl_context *ctx, double *A, int64_t ldA, int z
     }
     if (!(ctx->dpe == ctx->dim+1 || (ctx->dim == 2 && ctx->dpe == 6) || (ctx->dim == 1 && ctx->dpe == 3)))
         return fail(ctx, PNL_ERR_UNSUPPORTED, "pointwise variable orders: P1 and P2 elements");
-    if (!A || ldA < ctx->N) return fail(ctx, PNL_ERR_INVALID, "bad output matrix (ldA=%lld, num_dofs=%d)", (long long)ldA, ctx->N);
-    if (cell_begin < 0 || cell_end > ctx->nc || cell_begin > cell_end) return fail(ctx, PNL_ERR_INVALID, "bad cell range");
-    if (npairs < 0 || nbpairs < 0 || (npairs && !pairs) || (nbpairs && !bpairs)) return fail(ctx, PNL_ERR_INVALID, "bad pair lists");
     for (int s = 0; s <= ctx->dim; s++)
         if (!ctx->have_pw_rules[0][s]) return fail(ctx, PNL_ERR_STATE, "pointwise rule for %d common vertices not uploaded", s+1);
-    if (zero_exterior) {
+    if (need_boundary) {
         if (!ctx->have_boundary || (int)ctx->pw_facet_smax.size() != ctx->nb)
-            return fail(ctx, PNL_ERR_STATE, "zero_exterior needs boundary facets and their orders");
+            return fail(ctx, PNL_ERR_STATE, "the boundary term needs boundary facets and their orders");
         for (int s = 0; s < ctx->dim; s++)
             if (!ctx->have_pw_rules[1][s]) return fail(ctx, PNL_ERR_STATE, "pointwise boundary rule for %d common vertices not uploaded", s+1);
     }
+    std::vector<double> sm(ctx->ncp, 0.);
+    std::copy(ctx->pw_cell_smax.begin(), ctx->pw_cell_smax.end(), sm.begin());
+    if ((rc = upload(ctx, ctx->b_pw_csm, sm.data(), sm.size()))) return rc;
+    if ((rc = upload(ctx, ctx->b_pw_fsm, ctx->pw_facet_smax.data(), ctx->pw_facet_smax.size()))) return rc;
+    ctx->pw.cell_smax = (const double*)ctx->b_pw_csm.p; ctx->pw.facet_smax = (const double*)ctx->b_pw_fsm.p;
+    DevProblem &P = ctx->P;
+    P.qmax = ctx->qmax;
+    P.off = (const int*)ctx->b_off.p; P.bary = (const double*)ctx->b_bary.p; P.w = (const double*)ctx->b_w.p;
+    P.phi = (const double*)ctx->b_phi.p; P.foff = (const int*)ctx->b_foff.p; P.fbary = (const double*)ctx->b_fbary.p;
+    P.fw = (const double*)ctx->b_fw.p;
+    P.cur_class = -1;
+    return PNL_OK;
+}
+
+extern "C" {
+
+int pnl_assemble_dense_pointwise(pnl_context *ctx, double *A, int64_t ldA, int zero_exterior, int cell_begin, int cell_end,
+                                 int npairs, const int32_t *pairs, int nbpairs, const int32_t *bpairs) {
+    if (!ctx) return PNL_ERR_INVALID;
+    int rc;
+    if ((rc = pnl_pw_prepare(ctx, zero_exterior))) return rc;
+    if (!A || ldA < ctx->N) return fail(ctx, PNL_ERR_INVALID, "bad output matrix (ldA=%lld, num_dofs=%d)", (long long)ldA, ctx->N);
+    if (cell_begin < 0 || cell_end > ctx->nc || cell_begin > cell_end) return fail(ctx, PNL_ERR_INVALID, "bad cell range");
+    if (npairs < 0 || nbpairs < 0 || (npairs && !pairs) || (nbpairs && !bpairs)) return fail(ctx, PNL_ERR_INVALID, "bad pair lists");
     for (int t = 0; t < npairs; t++) {
         const int32_t *q = pairs+4*(size_t)t;
         if (q[0] < 0 || q[1] < q[0] || q[1] >= ctx->nc || q[2] < 1 || q[2] > ctx->dim+1 || q[3] < 0 || q[3] >= ctx->pw_nkeys[0])
@@ -3150,15 +3184,8 @@ int pnl_assemble_dense_pointwise(pnl_context *ctx, double *A, int64_t ldA, int z
         if (q[0] < 0 || q[0] >= ctx->nc || q[1] < 0 || q[1] >= ctx->nb || q[2] < 1 || q[2] > ctx->dim || q[3] < 0 || q[3] >= ctx->pw_nkeys[1])
             return fail(ctx, PNL_ERR_INVALID, "bad touching cell/facet pair %d", t);
     }
-    {
-        std::vector<double> sm(ctx->ncp, 0.);
-        std::copy(ctx->pw_cell_smax.begin(), ctx->pw_cell_smax.end(), sm.begin());
-        if ((rc = upload(ctx, ctx->b_pw_csm, sm.data(), sm.size()))) return rc;
-        if ((rc = upload(ctx, ctx->b_pw_fsm, ctx->pw_facet_smax.data(), ctx->pw_facet_smax.size()))) return rc;
-        if ((rc = upload(ctx, ctx->b_pw_pairs, pairs, (size_t)4*npairs))) return rc;
-        if ((rc = upload(ctx, ctx->b_pw_bpairs, bpairs, (size_t)4*nbpairs))) return rc;
-        ctx->pw.cell_smax = (const double*)ctx->b_pw_csm.p; ctx->pw.facet_smax = (const double*)ctx->b_pw_fsm.p;
-    }
+    if ((rc = upload(ctx, ctx->b_pw_pairs, pairs, (size_t)4*npairs))) return rc;
+    if ((rc = upload(ctx, ctx->b_pw_bpairs, bpairs, (size_t)4*nbpairs))) return rc;
     unsigned long long visited = 0;
     for (long long c = cell_begin; c < cell_end; c++) visited += (unsigned long long)(ctx->nc-c);
     ctx->visited_pairs = visited; ctx->visited_is_assembled = false;

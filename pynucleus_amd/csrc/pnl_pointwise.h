@@ -14,6 +14,28 @@
 
 // struct PwDev: pnl_device.h
 
+// Near field of these kernels (assembleClusters, NA:1812-1832 with symmetricCells == symmetricLocalMatrix == False): the work
+// items are ORDERED cell pairs -- buildMasksForClusters walks cellsUnion x cellsUnion (NA:322-349) --, item t carries a mask over the
+// (2 dpe)^2 entries of its local matrix (bit p (2 dpe) + q, getElemElemMask NA:425-440) and is scattered with fac = 1 into an
+// unsymmetric CSR pattern by addToMatrixElemElemMasked (NA:520-532); entries absent from the pattern are dropped (addToEntry).
+struct PwNear {
+    const int *indptr, *indices;
+    double *data;
+    const unsigned long long *masks;     // [items][4]
+};
+
+__device__ __forceinline__ void pw_near_add(const PwNear &S, const unsigned long long *mask, int bit, int I, int J, double v) {
+    if (I < 0 || J < 0 || !((mask[bit >> 6] >> (bit & 63)) & 1ull)) return;
+    int lo = S.indptr[I];
+    const int end = S.indptr[I+1];
+    int hi = end;
+    while (lo < hi) {
+        const int mid = (lo+hi) >> 1;
+        if (S.indices[mid] < J) lo = mid+1; else hi = mid;
+    }
+    if (lo < end && S.indices[lo] == J) atomic_add_f64(&S.data[lo], v);
+}
+
 template <int DIM>
 __device__ __forceinline__ double pw_order(const PwDev &W, const double *x) {
     const double *p = W.p;
@@ -158,10 +180,11 @@ __global__ void k_pw_stats(const DevProblem P, const unsigned *__restrict__ hist
 // per point pair: L = ln d2 once, K1 = w_i w_j C(s(x_i)) exp(e(x_i) L), K2 = w_i w_j C(s(y_j)) exp(e(y_j) L);
 // order and scaling of the points of the second cell are computed once per pair and kept in LDS.
 #define PNL_PW_MAXPTS 128
-template <int DIM, int DPE>
+// NEAR: entries (c1, c2, item, n | order << 16) of ORDERED pairs, the local matrix of this orientation alone, masked CSR scatter
+template <int DIM, int DPE, bool NEAR = false>
 __global__ void __launch_bounds__(PNL_NTHREADS)
 k_pw_distant(const DevProblem P, const PwDev W, const int4 *__restrict__ sorted, const unsigned *__restrict__ offs,
-             double *__restrict__ A, long long ldA, double *__restrict__ Dglob, int tab_max_pts, int nmin) {
+             double *__restrict__ A, long long ldA, double *__restrict__ Dglob, int tab_max_pts, int nmin, const PwNear NR = PwNear{}) {
     constexpr int NV = DIM+1, NC = NV*DIM, ND = DPE*(DPE+1)/2, NG = DPE*DPE, NACC = 2*NG+2*ND, LPP = 16,
                   PPC = PNL_NTHREADS/LPP, NREP = (NACC+LPP-1)/LPP, ST = 4+DPE;
     extern __shared__ double s_mem[];            // rule [tab_max_pts][ST], then per pair of the chunk [PPC][tab_max_pts][2]: e(y_j), w_j C(y_j)
@@ -315,6 +338,34 @@ k_pw_distant(const DevProblem P, const PwDev W, const int4 *__restrict__ sorted,
             const double s = row16_sum(acc[e]);
             mine[e/LPP] = (sub == (e & (LPP-1))) ? s : mine[e/LPP];
         }
+        if constexpr (NEAR) {
+            if (valid) {
+                const double vv = P.cvol[c1]*P.cvol[c2];
+                const unsigned long long *mask = NR.masks+4*(size_t)ent.z;
+                constexpr int N2 = 2*DPE;
+#pragma unroll
+                for (int rep = 0; rep < NREP; rep++) {
+                    const int e = sub+LPP*rep;
+                    const double val = mine[rep];
+                    if (e < NG) {                                   // XY: row a of c1, column b of c2
+                        const int a = e/DPE, b = e-a*DPE;
+                        pw_near_add(NR, mask, a*N2+DPE+b, P.cdof[(size_t)a*P.ncp+c1], P.cdof[(size_t)b*P.ncp+c2], -vv*val);
+                    } else if (e < 2*NG) {                          // YX: row a of c2, column b of c1
+                        const int a = (e-NG)/DPE, b = (e-NG)-a*DPE;
+                        pw_near_add(NR, mask, (DPE+a)*N2+b, P.cdof[(size_t)a*P.ncp+c2], P.cdof[(size_t)b*P.ncp+c1], -vv*val);
+                    } else if (e < NACC) {                          // XX / YY: symmetric blocks, entry (a, b) and (b, a)
+                        const bool second = e >= 2*NG+ND;
+                        const int k = e-2*NG-(second ? ND : 0), cc = second ? c2 : c1, sh = second ? DPE : 0;
+                        int a = 0, rem = k;
+                        while (rem >= DPE-a) { rem -= DPE-a; a++; }
+                        const int b = a+rem;
+                        const int I = P.cdof[(size_t)a*P.ncp+cc], J = P.cdof[(size_t)b*P.ncp+cc];
+                        pw_near_add(NR, mask, (sh+a)*N2+sh+b, I, J, vv*val);
+                        if (a != b) pw_near_add(NR, mask, (sh+b)*N2+sh+a, J, I, vv*val);
+                    }
+                }
+            }
+        } else
         if (valid) {
             const double vv = 2.*P.cvol[c1]*P.cvol[c2];          // both orientations (see the header of this file)
 #pragma unroll
@@ -973,10 +1024,11 @@ k_pw_lane(const DevProblem P, const PwDev W, const int4 *__restrict__ sorted, co
 
 // ---- touching pairs (FL2:1133-1184, FL1:548-604): one wave per (pair, orientation), rule of the pair's order key ------
 // pairs[t] = (c1 <= c2, common, key); full (rows x rows) non-symmetric local matrix, scatter NA:222-253
-template <int DIM, int DPE, int SLOT>
+// NEAR: pairs[t] = (c1, c2, common, key) of item t, ORDERED (one wave per item, this orientation alone), masked CSR scatter
+template <int DIM, int DPE, int SLOT, bool NEAR = false>
 __global__ void __launch_bounds__(PNL_NTHREADS)
 k_pw_singular(const DevProblem P, const PwDev W, const int4 *__restrict__ pairs, int npairs, double *__restrict__ A, long long ldA,
-              int cell_begin, int cell_end) {
+              int cell_begin, int cell_end, const PwNear NR = PwNear{}, const int *__restrict__ item_of = nullptr) {
     constexpr int NV = DIM+1, DPV = elem_dpv(DPE), DPED = elem_dped(DIM, DPE);
     constexpr int COMMON = SLOT+1;
     // merged local DoFs: shared vertices (and the shared edge) first (FL2:965-1075, FL1:466-530)
@@ -986,12 +1038,12 @@ k_pw_singular(const DevProblem P, const PwDev W, const int4 *__restrict__ pairs,
     constexpr int NGRP = ROWS > 8 ? 2 : 1, RG = (ROWS+NGRP-1)/NGRP, NE = RG*ROWS;
     const int lane = threadIdx.x & 63;
     const int wid = (blockIdx.x*PNL_NTHREADS+threadIdx.x) >> 6;
-    if (wid >= 2*npairs) return;
-    const int4 pr = pairs[wid >> 1];
+    if (wid >= (NEAR ? npairs : 2*npairs)) return;
+    const int4 pr = pairs[NEAR ? wid : wid >> 1];
     if (pr.z != COMMON) return;
-    const int orient = wid & 1;
+    const int orient = NEAR ? 0 : wid & 1;
     const int p1 = __builtin_amdgcn_readfirstlane(pr.x), p2 = __builtin_amdgcn_readfirstlane(pr.y);
-    if (p1 < cell_begin || p1 >= cell_end) return;
+    if (!NEAR && (p1 < cell_begin || p1 >= cell_end)) return;
     if (orient && p1 == p2) return;
     const int c1 = orient ? p2 : p1, c2 = orient ? p1 : p2;
     const int key = __builtin_amdgcn_readfirstlane(pr.w);
@@ -1136,6 +1188,13 @@ k_pw_singular(const DevProblem P, const PwDev W, const int4 *__restrict__ pairs,
                 gi = (myI == k) ? g : gi;
                 gj = (myJ == k) ? g : gj;
             }
+            if constexpr (NEAR) {
+                // local (unmerged) indices of the entry: row perm[myI], column perm[myJ] of the (2 dpe)^2 local matrix
+                int li = 0, lj = 0;
+#pragma unroll
+                for (int k = 0; k < 2*DPE; k++) { li = (myI == k) ? perm[k] : li; lj = (myJ == k) ? perm[k] : lj; }
+                pw_near_add(NR, NR.masks+4*(size_t)item_of[wid], li*(2*DPE)+lj, gi, gj, mine[rep]*vol);
+            } else
             if (gi >= 0 && gj >= 0) atomic_add_f64(&A[(long long)gi*ldA+gj], mine[rep]*vol);
         }
     }
@@ -1396,5 +1455,306 @@ k_pw_boundary_singular(const DevProblem P, const PwDev W, const int4 *__restrict
     if (lane == 0) {
         atomicAdd(&P.counters[3], 1ull);
         atomicAdd(&P.counters[4], (unsigned long long)M);
+    }
+}
+
+// ---- near field (assembleClusters / getH2 with these kernels) -------------------------------------------------------------
+// distant items of the masked list: thread per item t = (c1, c2) ORDERED, without a common vertex (the host lists the touching
+// items apart, with the key of their near rule); entry (c1, c2, t, n | order << 16) of the work list
+template <int DIM, int DPE>
+__global__ void __launch_bounds__(PNL_NTHREADS)
+k_pw_classify_near(const DevProblem P, const PwDev W, const int *__restrict__ pairs, const int *__restrict__ item_of, int nitems,
+                   int4 *__restrict__ wl, unsigned *__restrict__ wl_count, unsigned wl_cap) {
+    constexpr int NV = DIM+1;
+    const int t = blockIdx.x*PNL_NTHREADS+threadIdx.x;
+    bool push = false;
+    int c1 = 0, c2 = 0, q = 0, off = 0, n = 0, item = 0;
+    if (t < nitems) {
+        item = item_of[t];
+        c1 = pairs[2*(size_t)item]; c2 = pairs[2*(size_t)item+1];
+        bool shared = false;
+#pragma unroll
+        for (int a = 0; a < NV; a++)
+#pragma unroll
+            for (int b = 0; b < NV; b++) shared = shared || (P.cvid[(size_t)a*P.ncp+c1] == P.cvid[(size_t)b*P.ncp+c2]);
+        if (shared) atomicAdd(&P.counters[5], 1ull);                // a touching pair in the distant list: the call fails (pnl_synchronize)
+        else {
+            double d2 = 0.;
+#pragma unroll
+            for (int d = 0; d < DIM; d++) { const double u = P.ccen[(size_t)d*P.ncp+c1]-P.ccen[(size_t)d*P.ncp+c2]; d2 += u*u; }
+            const DevFormula F = pw_formula(W, DIM, fmax(W.cell_smax[c1], W.cell_smax[c2]));
+            q = quad_order(F, P.H0, P.ch[c1], P.ch[c2], sqrt(d2));
+            if (q > P.qmax || q > PNL_MAXQ) atomicAdd(&P.counters[5], 1ull);
+            else { off = P.off[q]; n = P.off[q+1]-off; push = n > 0; if (!push) atomicAdd(&P.counters[5], 1ull); }
+        }
+    }
+    (void)off;
+    const unsigned long long m = __ballot(push);
+    if (m) {
+        const int lane = threadIdx.x & 63;
+        unsigned base = 0;
+        if (lane == __builtin_ctzll(m)) base = atomicAdd(wl_count, (unsigned)__popcll(m));
+        base = __shfl(base, __builtin_ctzll(m));
+        if (push) {
+            const unsigned pos = base+__popcll(m & ((1ull << lane)-1ull));
+            if (pos < wl_cap) wl[pos] = make_int4(c1, c2, item, n | (q << 16));
+        }
+    }
+}
+
+// statistics of the near-field work list: pairs per order, kernel evaluations of ONE orientation per item
+__global__ void k_pw_stats_near(const DevProblem P, const unsigned *__restrict__ hist) {
+    const int q = threadIdx.x;
+    if (q < 2 || q > P.qmax || q > PNL_MAXQ) return;
+    const unsigned long long c = hist[q];
+    if (!c) return;
+    const unsigned long long n = (unsigned long long)(P.off[q+1]-P.off[q]);
+    atomicAdd(&P.counters[8+q], c);
+    atomicAdd(&P.counters[1], c);
+    atomicAdd(&P.counters[2], c*n*n);
+}
+
+// Gauss-theorem term over explicit (cell, facet) items with the pointwise boundary kernel C(s(x))/s(x) |x-y|^(1-d-2 s(x)), x in the
+// cell: the cluster exterior of assembleClusters (local_matrix_surface, NA:1966-2028; no shift of the facet centre for orders of
+// one variable) and the global Omega x Omega^c term with fac = -1 (NA:2126-2156).  One wave per item; rule[t] = -1: distant pair,
+// order from the pair's largest order sv[t] (FL2:1226-1243 / FL1:644-660); otherwise the key of the near rule (FL2:1255-1314,
+// FL1:672-712).  Scatter NA:534-546 (addToMatrixElemSymMasked) into CSR / SSS.
+template <int DIM, int DPE>
+__global__ void __launch_bounds__(PNL_NTHREADS)
+k_pw_boundary_items(const DevProblem P, const PwDev W, const double *__restrict__ verts, const int *__restrict__ cells,
+                    const int *__restrict__ facets, const unsigned *__restrict__ masks, const int *__restrict__ rule,
+                    const double *__restrict__ svs, int ni, double fac, const SparseOut S) {
+    constexpr int NV = DIM+1, NF = DIM, ND = DPE*(DPE+1)/2;
+    const int lane = threadIdx.x & 63;
+    const int nwaves = gridDim.x*(PNL_NTHREADS/64);
+    unsigned long long npairs = 0, nevals = 0;
+    for (int wid = (blockIdx.x*PNL_NTHREADS+threadIdx.x) >> 6; wid < ni; wid += nwaves) {
+        const int c1 = __builtin_amdgcn_readfirstlane(cells[wid]);
+        const unsigned mask = (unsigned)__builtin_amdgcn_readfirstlane((int)masks[wid]);
+        const int key = __builtin_amdgcn_readfirstlane(rule[wid]);
+        int fvid[NF];
+        double fv[NF][DIM], cv[NV][DIM], csv[NV];
+#pragma unroll
+        for (int k = 0; k < NF; k++) {
+            fvid[k] = __builtin_amdgcn_readfirstlane(facets[(size_t)wid*NF+k]);
+#pragma unroll
+            for (int d = 0; d < DIM; d++) fv[k][d] = verts[(size_t)fvid[k]*DIM+d];
+        }
+#pragma unroll
+        for (int k = 0; k < NV; k++) {
+#pragma unroll
+            for (int d = 0; d < DIM; d++) cv[k][d] = P.cellv[(size_t)(k*DIM+d)*P.ncp+c1];
+            csv[k] = W.type == 5 ? W.cell_sv[(size_t)k*W.sv_stride+c1] : 0.;
+        }
+        int perm1[NV], perm2[NF], perm[DPE];
+#pragma unroll
+        for (int k = 0; k < NV; k++) perm1[k] = k;
+#pragma unroll
+        for (int k = 0; k < NF; k++) perm2[k] = k;
+#pragma unroll
+        for (int k = 0; k < DPE; k++) perm[k] = k;
+        int mask1 = 0, mask2 = 0, common = 0;
+        for (int a = 0; a < NV; a++) {
+            const int v1 = P.cvid[(size_t)a*P.ncp+c1];
+            for (int b = 0; b < NF; b++) {
+                if (mask2 & (1 << b)) continue;
+                if (v1 == fvid[b]) {
+                    perm1[common] = a; perm2[common] = b;
+                    mask1 += (1 << a); mask2 += (1 << b);
+                    common++;
+                    break;
+                }
+            }
+        }
+        double nrm[DIM], vol2 = 1.;
+#pragma unroll
+        for (int d = 0; d < DIM; d++) nrm[d] = 0.;
+        if (DIM == 2) {
+            nrm[0] = fv[1][1]-fv[0][1];
+            nrm[1] = fv[0][0]-fv[1][0];
+            const double inv = 1./sqrt(nrm[0]*nrm[0]+nrm[1]*nrm[1]);
+            nrm[0] *= inv; nrm[1] *= inv;
+            vol2 = sqrt((fv[1][0]-fv[0][0])*(fv[1][0]-fv[0][0])+(fv[1][1]-fv[0][1])*(fv[1][1]-fv[0][1]));
+        }
+        double acc[ND];
+#pragma unroll
+        for (int e = 0; e < ND; e++) acc[e] = 0.;
+        double vol;
+        if (common == 0) {
+            double dc2 = 0.;
+#pragma unroll
+            for (int d = 0; d < DIM; d++) {
+                double fc = 0.;
+#pragma unroll
+                for (int k = 0; k < NF; k++) fc += fv[k][d];
+                const double u = P.ccen[(size_t)d*P.ncp+c1]-fc*(1./NF);
+                dc2 += u*u;
+            }
+            const DevFormula F = pw_formula_boundary(W, DIM, svs[wid]);
+            const int q = quad_order(F, P.H0, P.ch[c1], vol2, sqrt(dc2));
+            if (key >= 0 || q > P.qmax || q > PNL_MAXQ || P.off[q+1] == P.off[q] || P.foff[q+1] == P.foff[q]) {
+                if (lane == 0) atomicAdd(&P.counters[5], 1ull);
+                continue;
+            }
+            const int off = P.off[q], n = P.off[q+1]-off, foff = P.foff[q], nf = P.foff[q+1]-foff;
+            for (int k = lane; k < n*nf; k += 64) {
+                const int i = k/nf, m = k-i*nf;
+                double d2 = 0., nw = 0., x[DIM], lam[NV];
+#pragma unroll
+                for (int t = 0; t < NV; t++) lam[t] = P.bary[3*(size_t)(off+i)+t];
+#pragma unroll
+                for (int d = 0; d < DIM; d++) {
+                    double xx = 0., y = 0.;
+#pragma unroll
+                    for (int t = 0; t < NV; t++) xx = __builtin_fma(lam[t], cv[t][d], xx);
+#pragma unroll
+                    for (int t = 0; t < NF; t++) y = __builtin_fma(P.fbary[2*(size_t)(foff+m)+t], fv[t][d], y);
+                    x[d] = xx;
+                    const double wv = y-xx;
+                    d2 = __builtin_fma(wv, wv, d2);
+                    if (DIM == 2) nw = __builtin_fma(nrm[d], wv, nw);
+                }
+                if (DIM != 2) nw = 1.;
+                const double sx = pw_order_at<DIM>(W, x, lam, csv);
+                const double ex = 0.5*(1-DIM)-sx-(DIM == 2 ? 0.5 : 0.);
+                const double t = (P.w[off+i]*P.fw[foff+m])*nw*pw_scaling<DIM>(W, sx, true)*pnl_exp(ex*pnl_log(d2));
+                int e = 0;
+#pragma unroll
+                for (int a = 0; a < DPE; a++) {
+                    const double ta = t*P.phi[(size_t)(off+i)*DPE+a];
+#pragma unroll
+                    for (int b = a; b < DPE; b++) { acc[e] = __builtin_fma(ta, P.phi[(size_t)(off+i)*DPE+b], acc[e]); e++; }
+                }
+            }
+            vol = P.cvol[c1]*vol2;
+            nevals += (unsigned long long)n*nf;
+        } else {
+            if (key < 0 || common > NF) {
+                if (lane == 0) atomicAdd(&P.counters[5], 1ull);
+                continue;
+            }
+            int i = 0;
+            for (int k = common; k < NV; k++) { while (mask1 & (1 << i)) i++; perm1[k] = i; mask1 += (1 << i); }
+            i = 0;
+            for (int k = common; k < NF; k++) { while (mask2 & (1 << i)) i++; perm2[k] = i; mask2 += (1 << i); }
+            const int *t1 = P.perm_table+perm_rank(perm1, NV)*DPE;
+            for (int k = 0; k < DPE; k++) perm[k] = t1[k];
+            double s1[NV][DIM], s2[NF][DIM], sv1[NV];
+#pragma unroll
+            for (int k = 0; k < NV; k++) {
+                double sa = 0.;
+#pragma unroll
+                for (int d = 0; d < DIM; d++) {
+                    double a = 0.;
+#pragma unroll
+                    for (int m = 0; m < NV; m++) a = (perm1[k] == m) ? cv[m][d] : a;
+                    s1[k][d] = a;
+                }
+#pragma unroll
+                for (int m = 0; m < NV; m++) sa = (perm1[k] == m) ? csv[m] : sa;
+                sv1[k] = sa;
+            }
+#pragma unroll
+            for (int k = 0; k < NF; k++)
+#pragma unroll
+                for (int d = 0; d < DIM; d++) {
+                    double b = 0.;
+#pragma unroll
+                    for (int m = 0; m < NF; m++) b = (perm2[k] == m) ? fv[m][d] : b;
+                    s2[k][d] = b;
+                }
+            const int slot = common-1;
+            const int M = W.bM[slot];
+            const double *__restrict__ nodes = W.bnodes[slot]+(size_t)key*(NV+NF)*M;
+            const double *__restrict__ w = W.bw[slot]+(size_t)key*M;
+            const double *__restrict__ PHI = W.bphi[slot]+(size_t)key*DPE*M;
+            for (int m = lane; m < M; m += 64) {
+                double x[DIM], d2 = 0., nw = 0., lx[NV];
+#pragma unroll
+                for (int k = 0; k < NV; k++) lx[k] = nodes[(size_t)k*M+m];
+#pragma unroll
+                for (int d = 0; d < DIM; d++) {
+                    double xx = 0., y = 0.;
+#pragma unroll
+                    for (int k = 0; k < NV; k++) xx = __builtin_fma(s1[k][d], lx[k], xx);
+#pragma unroll
+                    for (int k = 0; k < NF; k++) y = __builtin_fma(s2[k][d], nodes[(size_t)(NV+k)*M+m], y);
+                    x[d] = xx;
+                    const double wv = xx-y;
+                    d2 = __builtin_fma(wv, wv, d2);
+                    if (DIM == 2) nw = __builtin_fma(nrm[d], wv, nw);
+                }
+                if (DIM != 2) nw = 1.;
+                const double sx = pw_order_at<DIM>(W, x, lx, sv1);
+                const double ex = 0.5*(1-DIM)-sx-(DIM == 2 ? 0.5 : 0.);
+                const double t = w[m]*nw*pw_scaling<DIM>(W, sx, true)*pnl_exp(ex*pnl_log(d2));
+                double ps[DPE];
+#pragma unroll
+                for (int r = 0; r < DPE; r++) ps[r] = PHI[(size_t)r*M+m];
+                int e = 0;
+#pragma unroll
+                for (int I = 0; I < DPE; I++) {
+                    const double tI = t*ps[I];
+#pragma unroll
+                    for (int J = I; J < DPE; J++) { acc[e] = __builtin_fma(tI, ps[J], acc[e]); e++; }
+                }
+            }
+            vol = (DIM == 2) ? W.bfac*P.cvol[c1]*vol2 : W.bfac*P.cvol[c1];
+            nevals += (unsigned long long)M;
+        }
+        npairs++;
+        double mine = 0.;
+        int myI = 0, myJ = 0;
+        {
+            int e = 0;
+#pragma unroll
+            for (int I = 0; I < DPE; I++)
+#pragma unroll
+                for (int J = I; J < DPE; J++) {
+                    const double s = wave_sum(acc[e]);
+                    if (lane == e) { mine = s; myI = I; myJ = J; }
+                    e++;
+                }
+        }
+        if (lane < ND) {
+            int i = 0, j = 0;
+#pragma unroll
+            for (int k = 0; k < DPE; k++) { i = (myI == k) ? perm[k] : i; j = (myJ == k) ? perm[k] : j; }
+            const int lo = min(i, j), hi = max(i, j);
+            const int kk = DPE*lo-(lo*(lo+1) >> 1)+hi;
+            if ((mask >> kk) & 1u) {
+                const int I = P.cdof[(size_t)lo*P.ncp+c1], J = P.cdof[(size_t)hi*P.ncp+c1];
+                const double v = fac*vol*mine;
+                if (lo == hi) sparse_add(S, I, I, v);
+                else { sparse_add(S, I, J, v); sparse_add(S, J, I, v); }
+            }
+        }
+    }
+    if (lane == 0 && npairs) {
+        atomicAdd(&P.counters[3], npairs);
+        atomicAdd(&P.counters[4], nevals);
+    }
+}
+
+// far field of these kernels (assembleFarFieldInteractions, clusterMethodCy.pyx:2153-2238 with kernel.variable: evalParamsPtr(x, y)
+// before evalPtr): K[i][j] = -2 C(s(x_i)) |x_i - y_j|^(-d-2 s(x_i)), x_i the Chebyshev nodes of the ROW cluster n1
+template <int DIM>
+__global__ void __launch_bounds__(PNL_NTHREADS)
+k_h2_kernel_interp_pw(const H2Dev H, const PwDev W) {
+    const int pr = blockIdx.x, n1 = H.far[2*pr], n2 = H.far[2*pr+1];
+    const double *b1 = H.box+(size_t)n1*DIM*2, *b2 = H.box+(size_t)n2*DIM*2;
+    for (int t = threadIdx.x; t < H.M*H.M; t += PNL_NTHREADS) {
+        const int i = t/H.M, j = t-i*H.M;
+        double d2 = 0., x[DIM];
+        int ii = i, jj = j;
+#pragma unroll
+        for (int d = 0; d < DIM; d++) {
+            x[d] = cheb_node(b1[2*d], b1[2*d+1], H.m, ii % H.m);
+            const double y = cheb_node(b2[2*d], b2[2*d+1], H.m, jj % H.m);
+            ii /= H.m; jj /= H.m;
+            d2 += (x[d]-y)*(x[d]-y);
+        }
+        const double s = pw_order<DIM>(W, x);
+        H.K[(size_t)pr*H.M*H.M+t] = -2.*pw_scaling<DIM>(W, s, false)*pnl_exp((-0.5*DIM-s)*pnl_log(d2));
     }
 }

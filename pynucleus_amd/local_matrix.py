@@ -302,7 +302,10 @@ class nonlocalTables:
         sv = np.maximum(self.cell_smax[pairs[:, 0]], self.cell_smax[pairs[:, 1]])
         keys, kidx = np.unique(sv, return_inverse=True)
         bsv = np.maximum(self.cell_smax[bpairs[:, 0]], self.facet_smax[bpairs[:, 1]])
-        bkeys, bkidx = np.unique(bsv, return_inverse=True)
+        # + the orders of touching (cell, facet) items that are not domain-boundary facets (cluster exterior of the near field)
+        extra = getattr(self, '_pw_extra_bkeys', None)
+        bkeys = np.unique(bsv) if extra is None else np.unique(np.concatenate([bsv, extra]))
+        bkidx = np.searchsorted(bkeys, bsv)
         rules = {}
         dm_order = max(self.dm.polynomialOrder, 1)
         for slot in range(nV):
@@ -341,6 +344,29 @@ class nonlocalTables:
                               pairs=np.ascontiguousarray(np.column_stack([pairs, kidx])[po].astype(np.int32)),
                               bpairs=np.ascontiguousarray(np.column_stack([bpairs, bkidx])[bo].astype(np.int32)))
         return self._pw_rules
+
+    def facet_order(self, facets):
+        """largest order over the centre and the vertices of facets given by their vertex ids [n, dim] (the facet's share of
+        evalParamsOnSimplices, KC:1825-1846)"""
+        sF = self.kernel.s
+        facets = np.asarray(facets)
+        if hasattr(sF.sFun, 'vertex_values'):
+            fvv = sF.sFun.cell_values(facets)
+            return np.maximum(fvv.mean(axis=1), fvv.max(axis=1))
+        fv = self.dm.mesh.vertices[facets]
+        return np.maximum(sF.evalPoints(fv.mean(axis=1)), sF.evalPoints(fv).max(axis=1))
+
+    def need_boundary_keys(self, sv):
+        """make sure the boundary near rules exist for the orders sv (touching items of the near field's cluster exterior); True when
+        the rule tables were rebuilt -- their key indices changed, a context must upload them again"""
+        sv = np.unique(np.asarray(sv, dtype=np.float64))
+        R = self.pw_rules()
+        if np.isin(sv, R['bkeys']).all():
+            return False
+        have = getattr(self, '_pw_extra_bkeys', None)
+        self._pw_extra_bkeys = sv if have is None else np.unique(np.concatenate([have, sv]))
+        self._pw_rules = None
+        return True
 
     def class_of_pair(self, c1, c2):
         return int(self.cls_of[self.cell_labels[c1], self.cell_labels[c2]])

@@ -196,7 +196,8 @@ def test_row_slab_operator_survives_refinalize():
     builder.setKernel(getFractionalKernel(2, 0.75), True)
     builder.getH2()                                          # finalizes the context again; no dense assembly follows
     y1, d1 = op.matvec(x), np.array(op.diagonal)
-    assert np.abs(y1-y0).max() == 0. and np.abs(d1-d0).max() == 0.
+    # the same sums in another atomic order: rounding only (without the fix the tile kernels' half of the diagonal blocks is missing: 1e-2)
+    assert np.abs(y1-y0).max() < 1e-13*np.abs(y0).max() and np.abs(d1-d0).max() < 1e-13*np.abs(d0).max()
 
 
 def _gpu_count():
