@@ -95,6 +95,8 @@ enum pnl_counter {
  *   "PNL_WL_FRAC"     capacity of the device work lists as a fraction of the candidate pairs (tests force the overflow report),
  *   "PNL_FH_NOTILES"  finite horizon: every pair through the per-pair pipeline instead of the block tiles,
  *   "PNL_NO_POWTAB"   general exponent: exp(e ln x) instead of the table-driven power,
+ *   "PNL_BND_OLD"     Omega x Omega^c term: the per-pair kernel instead of the tiled one (2D),
+ *   "PNL_PLAN_THREADS" host threads of the planner,
  *   "PNL_VERBOSE", "PNL_PLAN_TIMING"   diagnostics on stderr,
  * and returns PNL_ERR_UNSUPPORTED for any other name.  A tuning build (make EXTRA=-DPNL_TUNING; pnl_version says so) accepts every
  * name and falls back to the environment: the A/B switches named in DESIGN.md live there. */

@@ -542,3 +542,32 @@ def assemble_clusters_variable(op, pairs, masks, groups, indptr, indices, symmet
         if rc:
             raise RuntimeError('oracle failed with code {}'.format(rc))
     return data, diag, dict(numCellPairs=int(cnt[0]), numAssembledCellPairs=int(cnt[1]), numIntegrations=int(cnt[2]))
+
+
+def assemble_clusters_variable_nonsym(op, pairs, masks, groups, indptr, indices):
+    """piecewise-constant order with a NON-symmetric table: ORDERED element pairs with masks over the (2 dpe)^2 local entries, each
+    evaluated with the class of its orientation (nlo_assemble_pairs_masked_nonsym), plus the boundary items grouped as (class, fac,
+    cells, facets, masks) like assemble_clusters_variable; unsymmetric CSR.  Returns (data, counters)."""
+    data = np.zeros(indices.shape[0])
+    pairs = np.ascontiguousarray(pairs, dtype=np.int32)
+    masks = np.ascontiguousarray(masks, dtype=np.uint64)
+    indptr = np.ascontiguousarray(indptr, dtype=np.int32)
+    indices = np.ascontiguousarray(indices, dtype=np.int32)
+    cnt = np.zeros(NLO_NUM_COUNTERS, dtype=np.int64)
+    rc = lib().nlo_assemble_pairs_masked_nonsym(C.byref(op.P), pairs.shape[0], pairs.ctypes.data, masks.ctypes.data, indptr.ctypes.data,
+                                                indices.ctypes.data, data.ctypes.data, cnt.ctypes.data)
+    if rc:
+        raise RuntimeError('oracle failed with code {}'.format(rc))
+    for k, fac, cc, ff, mm in groups:
+        cc = np.ascontiguousarray(cc, dtype=np.int32)
+        ff = np.ascontiguousarray(ff, dtype=np.int32)
+        mm = np.ascontiguousarray(mm, dtype=np.uint32)
+        if cc.shape[0] == 0:
+            continue
+        rc = lib().nlo_assemble_boundary_masked(C.byref(op._class_problems[k].P), cc.shape[0], cc.ctypes.data, ff.ctypes.data,
+                                                mm.ctypes.data, float(fac), indptr.ctypes.data, indices.ctypes.data, data.ctypes.data, None)
+        if rc:
+            raise RuntimeError('oracle failed with code {}'.format(rc))
+    hist = {q: int(cnt[8+q]) for q in range(NLO_MAX_ORDER) if cnt[8+q]}
+    sing = {-1-k: int(cnt[8+NLO_MAX_ORDER+k]) for k in range(3)}
+    return data, dict(numCellPairs=int(cnt[0]), numAssembledCellPairs=int(cnt[1]), numIntegrations=int(cnt[2]), orders=hist, singular=sing)

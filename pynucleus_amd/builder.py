@@ -655,8 +655,10 @@ class nonlocalBuilder:
         if self.kernel.variable and not pointwise:
             # kernel blocks (getKernelBlocksAndJumps NA:2312-2352): clusters of one block each, the interface DoFs stay in the near
             # field; the far field between two clusters uses the order between their blocks
-            if not self.kernel.symmetric or self.kernel.finiteHorizon:
-                raise NotImplementedError('H2 operator of a non-symmetric or finite-horizon variable order')
+            # (a non-symmetric order table s(l1, l2) != s(l2, l1) changes nothing here: cluster pairs are ordered, every one takes the
+            # class of its orientation; the near field runs both orientations of every element pair, pnl_assemble_pairs_masked)
+            if self.kernel.finiteHorizon:
+                raise NotImplementedError('H2 operator of a finite-horizon variable order')
             blk, mixed = clusters.dofKernelBlocks(self.dm, self.tables)
             root, Pnear, Pfar = clusters.getNearFieldClusters(self.dm, rp['eta'], rp['minSize'], rp['maxLevels'], blk, mixed, rp['refinementType'])
             cls_of = self.tables.cls_of
@@ -742,8 +744,12 @@ class nonlocalBuilder:
         if self._single_order_twin() is not None:
             return self._single_order_twin().assembleClusters(Pnear, forceUnsymmetricMatrix, Anear, jumps, myRoot, _clusterBoundary,
                                                               _globalBoundary, _symmetrizeMasks, **kwargs)
-        if self.kernel.variable and (not self.kernel.symmetric or self.kernel.finiteHorizon):
-            raise NotImplementedError('near field of a non-symmetric or finite-horizon variable order')
+        if self.kernel.variable and self.kernel.finiteHorizon:
+            raise NotImplementedError('near field of a finite-horizon variable order')
+        if self.kernel.variable and not self.kernel.symmetric:
+            # both orientations of every element pair write both (I, J) and (J, I) of their entries: unsymmetric storage (the operator
+            # itself is symmetric only if the table is)
+            forceUnsymmetricMatrix = True
         import torch
         from . import clusters
         from .linear_operators import CSR_LinearOperator, SSS_LinearOperator

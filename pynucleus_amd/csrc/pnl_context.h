@@ -110,6 +110,7 @@ struct pnl_context {
     std::vector<std::vector<int>> h2_levels;   // nodes of every level >= 1
     long long h2_vtot = 0;                    // doubles of the leaf values V (pnl_h2_get / _set)
     std::vector<size_t> h2_level_off;
+    std::vector<int32_t> rule_off, frule_off;   // host copies of the distant-rule offsets (cell points, facet points) per order
     int sp_nnz = -1;                // near-field sparsity pattern (pnl_upload_sparsity)
     unsigned wl_cap = 0;
     int tile = TILE_P1, nblocks = 0, ncp = 0, nU = 0;

@@ -14,6 +14,7 @@
 #include "pnl_hip.h"
 #include "pnl_kernels.h"
 #include "pnl_pointwise.h"
+#include "pnl_bndtile.h"
 
 #include <thread>
 #include "pnl_context.h"
@@ -803,7 +804,34 @@ int launch_boundary(pnl_context *ctx, int cell_begin, int cell_end, int what = 3
             HIPCHK(ctx, hipMemsetAsync(dcount, 0, sizeof(unsigned), ctx->stream));
         }
         const bool fast = bkcls ? all_fast : (ctx->P.bkn.fast != 0);
-        if (fast)
+        bool tiled = false;
+        if constexpr (DIM == 2) {
+            // tiled kernel (pnl_bndtile.h): 256 cells per workgroup, facets in LDS chunks of 64, rules up to order qi in LDS
+            const int qi = std::min(PNL_BT_QI, ctx->qmax);
+            if (!pnl_tune("PNL_BND_OLD") && qi >= 2 && (int)ctx->rule_off.size() > qi+1) {
+                const int npts = ctx->rule_off[qi+1]-ctx->rule_off[2], nfp = ctx->frule_off[qi+1]-ctx->frule_off[2];
+                const int ncls = bkcls ? (int)ctx->cls.size() : 0;
+                const BndTileLds LY = bnd_tile_layout(npts, nfp, 4+DPE, ncls);
+                const size_t lds = sizeof(double)*(size_t)LY.total;
+                if (lds <= 64*1024) {
+                    // facet blocks: enough workgroups to fill the chip (a rank's share of the cells may be small), whole chunks of 64
+                    const int nfb = (ctx->nb+PNL_BT_FB-1)/PNL_BT_FB;
+                    const int want = pnl_tune("PNL_BT_WG") ? atoi(pnl_tune("PNL_BT_WG")) : 2048;
+                    const int gy = std::max(1, std::min(nfb, (want+gx-1)/gx));
+                    const int per_block = ((nfb+gy-1)/gy)*PNL_BT_FB;
+                    const int gyy = (ctx->nb+per_block-1)/per_block;
+                    auto launch = [&](auto kfun) {
+                        (void)hipFuncSetAttribute((const void*)kfun, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                        hipLaunchKernelGGL(kfun, dim3(gx, gyy), dim3(PNL_NTHREADS), lds, ctx->stream, ctx->P, (double*)ctx->b_D.p, cell_begin,
+                                           cell_end, per_block, qi, bkcls, bfcls, ncls, defer, dcells, dfacets, dslots, dcount, cap, dcls);
+                    };
+                    if (fast) launch(k_boundary_tile<DIM, DPE, 1>); else launch(k_boundary_tile<DIM, DPE, 0>);
+                    tiled = true;
+                }
+            }
+        }
+        if (tiled) {}
+        else if (fast)
             hipLaunchKernelGGL((k_boundary_distant<DIM, DPE, 1>), dim3(gx, chunks), dim3(PNL_NTHREADS), 0, ctx->stream, ctx->P,
                                (double*)ctx->b_D.p, cell_begin, cell_end, per, bkcls, bfcls, defer, dcells, dfacets, dslots, dcount, cap, dcls);
         else
@@ -1863,7 +1891,7 @@ std::map<std::string, const std::string*> g_options;
 std::deque<std::string> g_option_values;
 // the options a product build accepts: the hooks through which the parity tests reach the alternative code paths, and the
 // diagnostics line
-const char *const k_product_options[] = {"PNL_WL_FRAC", "PNL_FH_NOTILES", "PNL_NO_POWTAB", "PNL_VERBOSE", "PNL_PLAN_TIMING", "PNL_PLAN_THREADS"};
+const char *const k_product_options[] = {"PNL_WL_FRAC", "PNL_FH_NOTILES", "PNL_NO_POWTAB", "PNL_VERBOSE", "PNL_PLAN_TIMING", "PNL_PLAN_THREADS", "PNL_BND_OLD"};
 }  // namespace
 
 const char *pnl_tune(const char *name) {
@@ -2126,6 +2154,7 @@ int pnl_upload_distant_rules(pnl_context *ctx, int qmax, const int32_t *off, con
         return fail(ctx, PNL_ERR_INVALID, "bad rule arguments (2 <= qmax <= %d)", PNL_MAXQ);
     const int total = off[qmax+1], ftotal = foff[qmax+1];
     int rc;
+    ctx->rule_off.assign(off, off+qmax+2); ctx->frule_off.assign(foff, foff+qmax+2);
     if ((rc = upload(ctx, ctx->b_off, off, (size_t)qmax+2))) return rc;
     if ((rc = upload(ctx, ctx->b_bary, bary, (size_t)total*3))) return rc;
     if ((rc = upload(ctx, ctx->b_w, w, (size_t)total))) return rc;
@@ -2612,7 +2641,6 @@ int pnl_assemble_pairs_masked(pnl_context *ctx, int np, const int32_t *pairs, co
     int rc;
     if ((rc = upload(ctx, ctx->b_mp_pairs, pairs, (size_t)2*np))) return rc;
     if (masks && (rc = upload(ctx, ctx->b_mp_masks, masks, (size_t)4*np))) return rc;
-    if (ctx->nlab > 0 && ctx->nonsym) return fail(ctx, PNL_ERR_UNSUPPORTED, "cluster assembly with a non-symmetric order table");
     if (!std::isinf(ctx->C().kern[0].horizon2) && ctx->qmax > PNL_CUT_SHIFT)
         return fail(ctx, PNL_ERR_UNSUPPORTED, "finite horizon: upload distant rules up to order %d at most", PNL_CUT_SHIFT);
     SparseOut S;
@@ -2623,11 +2651,17 @@ int pnl_assemble_pairs_masked(pnl_context *ctx, int np, const int32_t *pairs, co
     if (np == 0) return PNL_OK;
     // variable order (piecewise constant, symmetric table): the pair list once per class, k_mp_classify keeps the pairs of the
     // class (the interface terms of NA:1966-2156 are boundary items, pnl_assemble_boundary_masked after pnl_select_class)
+    // non-symmetric class table (NA:1776-1840 with symmetricCells == False): the listed pairs (c1 <= c2) once per orientation, each
+    // with the class of its orientation and half the kernel (the machinery applies the factor 2 of the symmetric case); the masks
+    // of (c1, c2) and (c2, c1) request the same DoF pairs, so the list of the symmetric case serves both
     const int ncls = ctx->nlab > 0 ? (int)ctx->cls.size() : 1, cur0 = ctx->cur;
-    for (int k = 0; k < ncls; k++) {
+    const int norient = (ctx->nlab > 0 && ctx->nonsym) ? 2 : 1;
+    for (int ko = 0; ko < ncls*norient; ko++) {
+        const int k = ko/norient;
+        ctx->orient = ko%norient;
         if (ctx->nlab > 0) { ctx->cur = k; refresh_tables(ctx); }
         const int kt = ctx->P.k.fast ? 1 : 0;
-        const bool first = k == 0;
+        const bool first = ko == 0;
         if (ctx->dim == 2 && ctx->dpe == 3)
             rc = kt ? pairs_masked_impl<2, 3, 1>(ctx, np, S, true, first) : pairs_masked_impl<2, 3, 0>(ctx, np, S, true, first);
         else if (ctx->dim == 2 && ctx->dpe == 6)
@@ -2641,7 +2675,8 @@ int pnl_assemble_pairs_masked(pnl_context *ctx, int np, const int32_t *pairs, co
         else rc = fail(ctx, PNL_ERR_UNSUPPORTED, "unsupported (dim=%d, dofs_per_element=%d)", ctx->dim, ctx->dpe);
         if (rc) break;
     }
-    ctx->cur = cur0;
+    ctx->cur = cur0; ctx->orient = 0;
+    if (norient > 1) refresh_tables(ctx);
     return rc;
 }
 
@@ -2835,8 +2870,10 @@ int pnl_h2_setup(pnl_context *ctx, const pnl_h2_plan *pl) {
     refresh_tables(ctx);
     if (!std::isinf(ctx->C().kern[0].horizon2)) return fail(ctx, PNL_ERR_UNSUPPORTED, "H2 far field: infinite horizon only");
     }
-    if (ctx->nlab > 0 && (ctx->nonsym || (pl->nfar > 0 && !pl->far_class)))
-        return fail(ctx, PNL_ERR_UNSUPPORTED, "H2 far field of a variable order: symmetric order table and a kernel class per admissible pair");
+    // (the admissible pairs are ORDERED -- (n1, n2) and (n2, n1) are two entries, each with the class of its orientation -- so a
+    // non-symmetric order table needs nothing beyond its far_class)
+    if (ctx->nlab > 0 && pl->nfar > 0 && !pl->far_class)
+        return fail(ctx, PNL_ERR_UNSUPPORTED, "H2 far field of a variable order: a kernel class per admissible pair is needed");
     if (pl->far_class)
         for (int i = 0; i < pl->nfar; i++)
             if (pl->far_class[i] < 0 || pl->far_class[i] >= (int)ctx->cls.size()) return fail(ctx, PNL_ERR_INVALID, "far pair %d: bad kernel class", i);

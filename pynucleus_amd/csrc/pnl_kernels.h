@@ -1713,8 +1713,10 @@ k_mp_classify(const DevProblem P, const int *__restrict__ pairs, int npairs, int
     bool any = false;
 #pragma unroll
     for (int k = 0; k < DPE; k++) any = any || P.cdof[(size_t)k*P.ncp+c1] >= 0 || P.cdof[(size_t)k*P.ncp+c2] >= 0;
-    // variable order: one pass per class, a pair belongs to the class of its two labels (symmetric class table)
-    if (P.cur_class >= 0 && P.cls_of[P.clabel[c1]*P.nlab+P.clabel[c2]] != P.cur_class) any = false;
+    // variable order: one pass per class, a pair belongs to the class of its two labels; a non-symmetric class table runs two passes
+    // per class (DevProblem::orient): the second one takes the class of (label c2, label c1) and leaves identical pairs out
+    if (P.cur_class >= 0 && P.cls_of[P.orient ? P.clabel[c2]*P.nlab+P.clabel[c1] : P.clabel[c1]*P.nlab+P.clabel[c2]] != P.cur_class) any = false;
+    if (P.orient && c1 == c2) any = false;
     int key = 0, off = 0, n = 0;
     if (any) {
         int common = 0;
@@ -2322,6 +2324,8 @@ k_singular_pairs(const DevProblem P, const int2 *__restrict__ pairs, int npairs_
     if (SPARSE) {
         pidx = __builtin_amdgcn_readfirstlane(sorted[seg0+wid].x);
         pr = make_int2(S.pairs[2*pidx], S.pairs[2*pidx+1]);
+        // second orientation of a non-symmetric order table (swapCells, NA:1418): the singular rules are not symmetric under the swap
+        if (P.orient) pr = make_int2(pr.y, pr.x);
     } else pr = pairs[wid];
     const int c1 = __builtin_amdgcn_readfirstlane(pr.x), c2 = __builtin_amdgcn_readfirstlane(pr.y);
     // the cell range of the MPI-style split applies to the smaller cell number (cellNo1 of the reference loop; the lists of
@@ -2460,6 +2464,8 @@ k_singular_pairs(const DevProblem P, const int2 *__restrict__ pairs, int npairs_
             int pi = 0, pj = 0;
 #pragma unroll
             for (int k = 0; k < 2*DPE; k++) { pi = (myI[rep] == k) ? perm[k] : pi; pj = (myJ[rep] == k) ? perm[k] : pj; }
+            // the masks are indexed in the local numbering of the LISTED pair (c1 <= c2): undo the swap of the second orientation
+            if (P.orient) { pi = pi < DPE ? pi+DPE : pi-DPE; pj = pj < DPE ? pj+DPE : pj-DPE; }
             const int lo = min(pi, pj), hi = max(pi, pj);
             const int glo = (lo == pi) ? gi : gj, ghi = (lo == pi) ? gj : gi;
             sparse_add_sym(S, S.masks ? S.masks+4*(size_t)pidx : nullptr, 2*DPE, lo, hi, glo, ghi, v);
