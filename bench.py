@@ -368,7 +368,7 @@ def operator_leg(args, world, rank, dev, red_dev, backend, builder, ctx, dm, A, 
     from pynucleus_amd.solvers import cg
     N = dm.num_dofs
     if world == 1:
-        op = Dense_LinearOperator(A, ctx)
+        op = Dense_LinearOperator(A, ctx, symmetric=True)       # s = const: a symmetric operator, applied from its upper triangle
         local_bytes = 8*N*int(A.stride(0))
     else:
         rows, cols = slab_maps
@@ -400,9 +400,9 @@ def operator_leg(args, world, rank, dev, red_dev, backend, builder, ctx, dm, A, 
     dms = gather_ranks(device_ms, world, red_dev)
     lb = gather_ranks(local_bytes, world, red_dev)
     energy = float(torch.dot(b, u))
-    return dict(matvec_ms=1e3*mv, matvec_algorithmic_GBs=8.*N*N/mv/1e9 if world == 1 else sum(lb)/mv/1e9,
-                matvec_note=('k_gemv on the N x N block: 8 N^2 bytes per product' if world == 1 else
-                             'local one-sided slab products (A\' x and A\'^T x) + one all-reduce of the N-vector ({} backend); GB/s = bytes of all slabs / time'.format(backend)),
+    return dict(matvec_ms=1e3*mv, matvec_algorithmic_GBs=4.*N*N/mv/1e9 if world == 1 else sum(lb)/mv/1e9,
+                matvec_note=('k_gemv_two_sided on the upper triangle of the symmetric N x N block: 4 N^2 bytes per product (A x and A^T x in one sweep)' if world == 1 else
+                             'local one-sided slab products (A\' x and A\'^T x in ONE sweep) + one all-reduce of the N-vector ({} backend); GB/s = bytes of all slabs / time'.format(backend)),
                 cg_jacobi_iterations=int(its), cg_jacobi_ms=1e3*t_cg, cg_residual=res_final, energy_b_dot_u=energy,
                 device_ms_per_rank=[round(v, 3) for v in dms], device_ms_min=min(dms), device_ms_max=max(dms),
                 operator_bytes_per_rank=[int(v) for v in lb], operator_bytes_total=int(sum(lb)))

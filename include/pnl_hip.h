@@ -428,7 +428,9 @@ int pnl_slab_diagonal(pnl_context *ctx, const double *slab_dev, int64_t ld, cons
 
 /* ---- adjacent solve path: Dense_LinearOperator.matvec (dgemv, DenseLinearOperator_{SCALAR}.pxi:14-18)
  *      and cg_solver + jacobi (base/PyNucleus_base/solvers.pyx:363-444, 229-245) ------------------- */
-/* y = A x (n x n, row-major, leading dimension ldA); symmetric_half: y = (A + A^T) x for PNL_FLAG_NO_MIRROR storage */
+/* y = A x (n x n, row-major, leading dimension ldA); symmetric_half = 1: y = (A + A^T) x for PNL_FLAG_NO_MIRROR storage;
+ * symmetric_half = 2: A is stored in full and is symmetric -- the upper triangle is read once for both A x and A^T x (4 n^2 bytes
+ * instead of 8 n^2: a GEMV is bound by HBM).  pnl_cg_jacobi always reads the upper triangle (CG needs a symmetric operator). */
 int pnl_gemv(pnl_context *ctx, const double *A_dev, int64_t ldA, int n, const double *x_dev, double *y_dev,
              int symmetric_half);
 /* Jacobi-preconditioned CG on A x = b; x_dev holds the initial guess and the result.

@@ -416,7 +416,7 @@ class nonlocalBuilder:
         self.PLogger.addTimer('zeroExterior', 1e-3*ms['boundary'])
         info = dict(counters=cnt, phase_ms=ms)
         if size == 1:
-            return Dense_LinearOperator(A, ctx, info)
+            return Dense_LinearOperator(A, ctx, info, symmetric=not pointwise)
         group = None if self.comm is True else self.comm
         op = DistributedDense_LinearOperator(A, ctx, group, info)
         return op if distributed else op.reduce()

@@ -28,8 +28,9 @@ __host__ __device__ inline BndTileLds bnd_tile_layout(int npts, int nfp, int st,
     L.rule = 0;
     L.frule = L.rule+npts*st;
     L.facets = L.frule+nfp*3;
-    L.ints = L.facets+10*PNL_BT_FB;                                  // float lh2[FB], int fvid[2][FB], int blab[FB]: 4 FB words = 2 FB doubles
-    L.cls = L.ints+2*PNL_BT_FB;
+    L.facets += L.facets & 1;                                        // 16-byte alignment of everything behind (int4 table)
+    L.ints = L.facets+10*PNL_BT_FB;                                  // float lh2[FB], int fvid[2][FB], int blab[FB]: 4 FB words = 2 FB doubles;
+    L.cls = L.ints+2*PNL_BT_FB+2*(PNL_BT_QI+1);                      // then int4 qtab[QI+1]: points, rule offset, facet points, facet-rule offset per order
     L.total = L.cls+ncls*(int)((sizeof(DevKernel)+sizeof(DevFormula)+7)/8);
     return L;
 }
@@ -67,6 +68,7 @@ k_boundary_tile(const DevProblem P, double *__restrict__ Dglob, int cell_begin, 
     double *s_rule = s_mem+LY.rule, *s_fr = s_mem+LY.frule, *s_fd = s_mem+LY.facets;
     float *s_lh2 = (float*)(s_mem+LY.ints);
     int *s_fvid = (int*)(s_lh2+FB), *s_blab = s_fvid+2*FB;
+    int4 *s_qtab = (int4*)(s_mem+LY.ints+2*FB);          // per order q <= qi: (n, rule offset in s_rule, nf, offset in s_fr): one LDS read per pair
     DevKernel *s_bk = (DevKernel*)(s_mem+LY.cls);
     DevFormula *s_bf = (DevFormula*)(s_bk+(bkcls ? ncls : 0));
     for (int t = tid; t < npts*ST; t += PNL_NTHREADS) {
@@ -79,6 +81,8 @@ k_boundary_tile(const DevProblem P, double *__restrict__ Dglob, int cell_begin, 
     }
     if (bkcls)
         for (int t = tid; t < ncls; t += PNL_NTHREADS) { s_bk[t] = bkcls[t]; s_bf[t] = bfcls[t]; }
+    for (int t = tid; t <= PNL_BT_QI; t += PNL_NTHREADS)
+        s_qtab[t] = (t >= 2 && t <= qi) ? make_int4(P.off[t+1]-P.off[t], P.off[t]-roff0, P.foff[t+1]-P.foff[t], P.foff[t]-foff0) : make_int4(0, 0, 0, 0);
     const int c = cell_begin+blockIdx.x*PNL_NTHREADS+tid;
     bool active = c < cell_end;
     const int cc = active ? c : cell_begin;
@@ -136,7 +140,9 @@ k_boundary_tile(const DevProblem P, double *__restrict__ Dglob, int cell_begin, 
             const double vol2 = s_fd[8*FB+j], Ld2 = s_fd[9*FB+j];
             const int q = quad_order_fast(bqo, h1, vol2, lh1, s_lh2[j], L1, (float)Ld2, Ld1, Ld2, __builtin_fma(u1, u1, u0*u0));
             if (q > P.qmax || q > PNL_MAXQ) { overflow++; continue; }
-            const int n = P.off[q+1]-P.off[q], nf = P.foff[q+1]-P.foff[q];
+            int n, nf, ro = 0, fo = 0;
+            if (q <= qi) { const int4 qt = s_qtab[q]; n = qt.x; ro = qt.y; nf = qt.z; fo = qt.w; }
+            else { n = P.off[q+1]-P.off[q]; nf = P.foff[q+1]-P.foff[q]; }
             if (q > qi || (dcells && n*nf > defer_evals)) {
                 // beyond the staged rules, or a rule of hundreds of point pairs next to the boundary: one per wave (k_boundary_items)
                 const unsigned idx = dcells ? atomicAdd(dcount, 1u) : dcap;
@@ -176,7 +182,6 @@ k_boundary_tile(const DevProblem P, double *__restrict__ Dglob, int cell_begin, 
             }
             npairs++;
             nevals += (unsigned long long)n*nf;
-            const int ro = P.off[q]-roff0, fo = P.foff[q]-foff0;
             const double vs = vol2*kern_scale<KT>(bkn);
             // s = 1/2 in 2D: the Gauss-theorem kernel with the 1 / |y - x| of the normal factor folded in is d2^(-3/2), exponent known at
             // compile time (kern_eval<2>: no branch per evaluation); wave-uniform test

@@ -263,6 +263,11 @@ int pnl_tile_order_ready(pnl_context *ctx);
 int pnl_pw_prepare(pnl_context *ctx, int need_boundary);
 int pnl_pw_h2_interp(pnl_context *ctx);
 
+// pnl_gemv2.hip: one pass over a row-major block for both A x and A^T x
+int pnl_launch_gemv_symmetric(pnl_context *ctx, const double *A, long long ldA, int n, const double *x, double *y);
+int pnl_launch_slab_two_sided(pnl_context *ctx, const double *slab, long long ld, int nrows, int ncols, const int *rowdof, const int *coldof,
+                              const double *x, double *y);
+
 // pnl_tile2.hip
 int pnl2_launch_uniform(pnl_context *ctx, int kt, const DevProblem &Pt, const int2 *tiles, const int *tile_cls, int ntiles, int q,
                         double *A, int64_t ldA, double *Dglob, const SlotOut &SO);

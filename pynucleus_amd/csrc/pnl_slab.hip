@@ -148,10 +148,8 @@ int pnl_slab_matvec(pnl_context *ctx, const double *slab, int64_t ld, const doub
     hipStream_t st = ctx->stream;
     HIPCHK(ctx, hipMemsetAsync(y, 0, sizeof(double)*ctx->N, st));
     const int *rowdof = (const int*)ctx->b_rowdof.p, *coldof = (const int*)ctx->b_coldof.p;
-    hipLaunchKernelGGL(k_slab_gemv, dim3((nrows+3)/4), dim3(PNL_NTHREADS), 0, st, slab, (long long)ld, nrows, ncols, rowdof, coldof, x, y);
-    const int rows = 128;
-    hipLaunchKernelGGL(k_slab_gemv_t, dim3((ncols+PNL_NTHREADS-1)/PNL_NTHREADS, (nrows+rows-1)/rows), dim3(PNL_NTHREADS), 0, st, slab,
-                       (long long)ld, nrows, ncols, rowdof, coldof, x, y, rows);
+    // A' x and A'^T x in ONE sweep over the slab (pnl_gemv2.hip); k_slab_gemv / k_slab_gemv_t above are the two-sweep form
+    { const int rc = pnl_launch_slab_two_sided(ctx, slab, (long long)ld, nrows, ncols, rowdof, coldof, x, y); if (rc) return rc; }
     if (dblocks) {
         const size_t n = (size_t)ctx->ncp*(ctx->dpe*(ctx->dpe+1)/2);
         const int nt = ctx->nc*ctx->dpe;

@@ -17,7 +17,7 @@ def _as_dev(x, device):
 
 
 class Dense_LinearOperator:
-    def __init__(self, A_dev, ctx, info=None):
+    def __init__(self, A_dev, ctx, info=None, symmetric=False):
         # row-major with a leading dimension >= number of columns (the builder pads rows to 64-byte lines)
         assert A_dev.dtype == torch.float64 and A_dev.stride(1) == 1 and A_dev.stride(0) >= A_dev.shape[1]
         self.A = A_dev
@@ -25,6 +25,9 @@ class Dense_LinearOperator:
         self.num_rows, self.num_columns = A_dev.shape
         self.shape = (self.num_rows, self.num_columns)
         self.info = info or {}
+        # a symmetric operator is applied from its upper triangle alone (4 N^2 bytes per product instead of 8 N^2); set by the builder
+        # for symmetric kernels only -- the block itself always holds the full matrix, like the reference's
+        self.symmetric = bool(symmetric) and self.num_rows == self.num_columns
 
     # reference API -------------------------------------------------------
     @property
@@ -61,7 +64,7 @@ class Dense_LinearOperator:
         assert xd.shape[0] == self.num_columns
         yd = torch.empty(self.num_rows, dtype=torch.float64, device=dev)
         torch.cuda.current_stream(dev).synchronize()
-        self.ctx.gemv(self.A.data_ptr(), self.A.stride(0), self.num_rows, xd.data_ptr(), yd.data_ptr())
+        self.ctx.gemv(self.A.data_ptr(), self.A.stride(0), self.num_rows, xd.data_ptr(), yd.data_ptr(), 2 if self.symmetric else 0)
         self.ctx.synchronize()
         if isinstance(x, torch.Tensor):
             if y is not None:

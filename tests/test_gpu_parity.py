@@ -733,3 +733,34 @@ def test_queued_assemblies_equal_a_single_one(element):
     one, three = run(1), run(3)
     assert np.abs(one-one.T).max() <= 1e-13*np.abs(one).max()
     assert np.abs(three-one).max() <= 1e-13*np.abs(one).max()
+
+
+@pytest.mark.parametrize('case', ['P1_s0.5', 'P1_s0.3', 'P2_s0.75', 'P1_layers', 'P2_layers', 'P1_gaussian'])
+def test_boundary_tiled_equals_per_pair_kernel(case):
+    """Omega x Omega^c term of the dense path (NA:1430-1448): the tiled kernel (256 cells per workgroup, facets and rules in LDS, row sums
+    of orders 2 and 3 in registers; pnl_bndtile.h) against the per-pair kernel (option PNL_BND_OLD) -- the same operator to rounding,
+    the same numbers of boundary pairs and boundary kernel evaluations; both are compared with the oracle by the other tests of this
+    file, every one of which assembles with zeroExterior"""
+    from pynucleus_amd import disc, PHYSICAL, dofmapFactory, getFractionalKernel, getKernel, _lib
+    from pynucleus_amd.builder import nonlocalBuilder
+    from pynucleus_amd.fractionalOrders import layersFractionalOrder
+    element = case[:2]
+    if case.endswith('layers'):
+        order = layersFractionalOrder(2, np.array([-1., -0.3, 0.3, 1.]), np.array([[0.3, 0.4, 0.5], [0.4, 0.5, 0.6], [0.5, 0.6, 0.7]]))
+        kernel = getFractionalKernel(2, order)
+    elif case.endswith('gaussian'):
+        kernel = getKernel(2, kernel='gaussian', horizon=np.inf, variance=0.1)
+    else:
+        kernel = getFractionalKernel(2, float(case.split('_s')[1]))
+    dm = dofmapFactory(element, disc(4 if element == 'P1' else 3), PHYSICAL)
+    out = {}
+    try:
+        for old in (False, True):
+            _lib.set_option('PNL_BND_OLD', 1 if old else None)
+            A = nonlocalBuilder(dm, kernel, {'target_order': 0.5}, zeroExterior=True).getDense()
+            out[old] = (A.toarray(), A.info['counters'])
+    finally:
+        _lib.set_option('PNL_BND_OLD', None)
+    (A0, c0), (A1, c1) = out[False], out[True]
+    assert c0['numBoundaryPairs'] == c1['numBoundaryPairs'] > 0 and c0['numBoundaryIntegrations'] == c1['numBoundaryIntegrations']
+    assert np.abs(A0-A1).max() < 1e-13*np.abs(A1).max()
