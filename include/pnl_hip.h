@@ -168,6 +168,9 @@ int pnl_upload_boundary(pnl_context *ctx, int nb, const int32_t *bcells_host);
  * pattern.  Replaces the loops
  * NA:1150-1200 over the cells of the covering cluster pairs (clusterMethodCy.pyx:4139-4194). */
 int pnl_assemble_pairs_in_horizon(pnl_context *ctx, double *data, double *diag);
+/* the same for the pairs whose FIRST cell lies in [cell_begin, cell_end): the reference's split of cellNo1 over ranks
+ * (nonlocalAssembly_{SCALAR}.pxi:1280-1285); the parts of a partition add up to the operator (atomic adds into data / diag) */
+int pnl_assemble_pairs_in_horizon_range(pnl_context *ctx, double *data_dev, double *diag_dev, int cell_begin, int cell_end);
 
 /* ---- the hot path --------------------------------------------------------------------------- */
 /* nonlocalBuilder.getDense (NA:1262-1473): accumulates the operator into A_dev[num_dofs][ldA]

@@ -29,7 +29,7 @@ EXPORTS = ['pnl_create', 'pnl_destroy', 'pnl_error_string', 'pnl_version', 'pnl_
            'pnl_upload_singular_rule', 'pnl_upload_boundary', 'pnl_assemble_dense', 'pnl_dense_overwrites', 'pnl_block_row_costs', 'pnl_tile_cells',
            'pnl_assemble_dense_tiles', 'pnl_get_counters', 'pnl_get_phase_ms', 'pnl_get_kernel_ms', 'pnl_tree_build', 'pnl_tree_build_blocks', 'pnl_tree_build_refined', 'pnl_tree_destroy', 'pnl_tree_sizes', 'pnl_tree_get', 'pnl_tree_node_cells', 'pnl_h2_transfer_matrices', 'pnl_nfplan_build', 'pnl_nfplan_destroy', 'pnl_nfplan_sizes', 'pnl_nfplan_get', 'pnl_horizon_pattern', 'pnl_near_pattern', 'pnl_pattern_set_max_nnz', 'pnl_set_option', 'pnl_set_cell_order', 'pnl_set_interaction_transform', 'pnl_set_order_vertex_values', 'pnl_h2_get', 'pnl_h2_set', 'pnl_pattern_nnz', 'pnl_pattern_get', 'pnl_pattern_destroy', 'pnl_set_row_slab', 'pnl_diag_blocks_size', 'pnl_get_diag_blocks', 'pnl_slab_matvec', 'pnl_slab_diagonal', 'pnl_gemv', 'pnl_cg_jacobi',
            'pnl_inv_diagonal', 'pnl_set_classes', 'pnl_select_class', 'pnl_upload_sparsity', 'pnl_upload_sparsity_device', 'pnl_assemble_pairs_masked', 'pnl_assemble_boundary_masked', 'pnl_assemble_clusters_tiled', 'pnl_h2_setup', 'pnl_h2_matvec', 'pnl_h2_upward', 'pnl_h2_interact', 'pnl_h2_downward', 'pnl_h2_sizes', 'pnl_spmv',
-           'pnl_assemble_pairs_in_horizon', 'pnl_set_nonsymmetric', 'pnl_set_order_function', 'pnl_upload_pointwise_rules', 'pnl_assemble_dense_pointwise',
+           'pnl_assemble_pairs_in_horizon', 'pnl_assemble_pairs_in_horizon_range', 'pnl_set_nonsymmetric', 'pnl_set_order_function', 'pnl_upload_pointwise_rules', 'pnl_assemble_dense_pointwise',
            'pnl_assemble_pairs_masked_pointwise', 'pnl_assemble_boundary_masked_pointwise',
            'pnl_gemv_axpby', 'pnl_csr_matvec', 'pnl_mg_create', 'pnl_mg_destroy', 'pnl_mg_cycle', 'pnl_mg_solve', 'pnl_mg_cg', 'pnl_theta_step']
 
@@ -189,6 +189,7 @@ def load():
     L.pnl_h2_downward.argtypes = [vp, vp, vp]
     L.pnl_h2_sizes.argtypes = [vp, vp]
     L.pnl_assemble_pairs_in_horizon.argtypes = [vp, vp, vp]
+    L.pnl_assemble_pairs_in_horizon_range.argtypes = [vp, vp, vp, i32, i32]
     L.pnl_set_order_function.argtypes = [vp, C.POINTER(pnl_order_function), vp, vp, dbl, dbl, dbl, dbl]
     L.pnl_upload_pointwise_rules.argtypes = [vp, i32, i32, i32, i32, i32, vp, vp, vp, vp]
     L.pnl_assemble_dense_pointwise.argtypes = [vp, vp, i64, i32, i32, i32, i32, vp, i32, vp]
@@ -359,9 +360,14 @@ class Context:
         self.check(self.L.pnl_set_order_formula(self.h, which, C.byref(f)))
 
     # -- hot path --------------------------------------------------------
-    def assemble_pairs_in_horizon(self, data_ptr, diag_ptr):
-        """finite horizon: candidate pairs generated on the device (no host pair list, no masks)"""
-        self.check(self.L.pnl_assemble_pairs_in_horizon(self.h, C.c_void_p(data_ptr), C.c_void_p(diag_ptr) if diag_ptr else None))
+    def assemble_pairs_in_horizon(self, data_ptr, diag_ptr, cell_begin=None, cell_end=None):
+        """finite horizon: candidate pairs generated on the device (no host pair list, no masks); with a range only the pairs whose
+        first cell lies in [cell_begin, cell_end) (the reference's cellNo1 split)"""
+        if cell_begin is None:
+            self.check(self.L.pnl_assemble_pairs_in_horizon(self.h, C.c_void_p(data_ptr), C.c_void_p(diag_ptr) if diag_ptr else None))
+        else:
+            self.check(self.L.pnl_assemble_pairs_in_horizon_range(self.h, C.c_void_p(data_ptr), C.c_void_p(diag_ptr) if diag_ptr else None,
+                                                                  int(cell_begin), int(cell_end)))
 
     def assemble_dense_pointwise(self, A_ptr, ldA, zero_exterior, cell_begin, cell_end):
         self.assembly_epoch = getattr(self, 'assembly_epoch', 0)+1     # host snapshots of dense operators are stale now

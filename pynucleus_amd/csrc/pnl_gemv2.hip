@@ -64,18 +64,24 @@ k_gemv_two_sided(const double *__restrict__ S, long long ld, int nrows, int ncol
                 cacc[2*k+1] = __builtin_fma(v[k].y, xr, cacc[2*k+1]);
             }
         } else {
+            // blocks on the diagonal (dense) / where a row DoF can be a column DoF (slab), and the ragged right edge: the same 16-byte
+            // loads where both entries exist, the triangle / diagonal conditions as selects (the entries below the diagonal of the full
+            // matrix are there to be loaded, they just do not count)
+            const bool al = ((((uintptr_t)a) & 15) == 0);
 #pragma unroll
-            for (int k = 0; k < 8; k++)
-#pragma unroll
-                for (int h = 0; h < 2; h++) {
-                    const int jj = J[2*k+h];
-                    if (jj < 0) continue;
-                    const bool first = SLAB ? true : jj >= I, second = SLAB ? jj != I : jj > I;
-                    if (!first) continue;
-                    const double v = a[128*k+h];
-                    rs = __builtin_fma(v, xc[2*k+h], rs);
-                    if (second) cacc[2*k+h] = __builtin_fma(v, xr, cacc[2*k+h]);
-                }
+            for (int k = 0; k < 8; k++) {
+                const int j0 = c0+2*lane+128*k;
+                double2 v = make_double2(0., 0.);
+                if (al && j0+1 < cend) v = *(const double2*)(a+128*k);
+                else { if (j0 < cend) v.x = a[128*k]; if (j0+1 < cend) v.y = a[128*k+1]; }
+                const int ja = J[2*k], jb = J[2*k+1];
+                const double fa = (SLAB ? true : ja >= I) ? v.x : 0., fb = (SLAB ? true : jb >= I) ? v.y : 0.;
+                const double sa = (SLAB ? ja != I : ja > I) ? v.x : 0., sb = (SLAB ? jb != I : jb > I) ? v.y : 0.;
+                rs = __builtin_fma(fa, xc[2*k], rs);
+                rs = __builtin_fma(fb, xc[2*k+1], rs);
+                cacc[2*k] = __builtin_fma(sa, xr, cacc[2*k]);
+                cacc[2*k+1] = __builtin_fma(sb, xr, cacc[2*k+1]);
+            }
         }
         rs = wave_sum(rs);
         if (lane == 0 && rs != 0.) atomic_add_f64(&y[I], rs);

@@ -1796,13 +1796,16 @@ int pointwise_impl(pnl_context *ctx, double *A, int64_t ldA, int zero_exterior, 
 // getSparse without a host pair list: block tiles the horizon can reach -> k_fh_pairs -> the sorted pipeline of the masked path
 namespace {
 template <int DIM, int DPE, int KT>
-int horizon_impl(pnl_context *ctx, SparseOut S) {
+int horizon_impl(pnl_context *ctx, SparseOut S, int cell_begin, int cell_end) {
     int rc;
     const int T = ctx->tile, nbk = ctx->nblocks;
     const double delta = std::sqrt(ctx->C().kern[0].horizon2);
+    const bool whole = cell_begin <= 0 && cell_end >= ctx->nc;
     std::vector<int2> tiles;
     for (int a = 0; a < nbk; a++)
         for (int b = a; b < nbk; b++) {
+            // a range of first cells (the reference's cellNo1 split, NA:1280-1285): only block rows that hold one
+            if ((a+1)*T <= cell_begin || a*T >= cell_end) continue;
             const auto &A = ctx->blocks[a], &B = ctx->blocks[b];
             const double dx = A.tcx-B.tcx, dy = A.tcy-B.tcy;
             // every vertex of a block lies within trad of (tcx, tcy) (vertices within h of their cell's centre)
@@ -1829,6 +1832,7 @@ int horizon_impl(pnl_context *ctx, SparseOut S) {
     const int acc_stride = acc_stride_of(ctx->nU, TS::fixed_bytes);
     const size_t lds = TS::fixed_bytes+sizeof(double)*(size_t)(ctx->nU+1)*acc_stride;
     const bool use_tiles = T == TILE && lds <= 160*1024 && !pnl_tune("PNL_FH_NOTILES");
+    if (!use_tiles && !whole) return fail(ctx, PNL_ERR_UNSUPPORTED, "a range of first cells needs the tile route of the finite-horizon assembly");
     ctx->visited_is_assembled = use_tiles;
     for (size_t t0 = 0; t0 < tiles.size(); t0 += chunk_tiles) {
         const int nt = (int)std::min(chunk_tiles, tiles.size()-t0);
@@ -1847,7 +1851,7 @@ int horizon_impl(pnl_context *ctx, SparseOut S) {
             CT.wl_ds = (int2*)ctx->b_mp_pairs.p;                   // the pairs of the far-list entries
             const int grid = std::min(nt, 256*std::max(per_cu, 1));
             hipLaunchKernelGGL(kfun, dim3(grid), dim3(tile_threads(DPE, KT, true)), lds, ctx->stream, ctx->P, (const int2*)ctx->b_tiles.p+t0,
-                               (double*)nullptr, 0ll, (double*)ctx->b_D.p, 0, ctx->nc, acc_stride, (int4*)ctx->b_mp_wl.p,
+                               (double*)nullptr, 0ll, (double*)ctx->b_D.p, std::max(cell_begin, 0), std::min(cell_end, ctx->nc), acc_stride, (int4*)ctx->b_mp_wl.p,
                                (unsigned*)ctx->b_wlcount.p, (unsigned)cap, 0, nt, CT, (unsigned*)ctx->b_tilectr.p, SlotOut{});
         } else
             hipLaunchKernelGGL((k_fh_pairs<DIM, DPE>), dim3(nt), dim3(PNL_NTHREADS), 0, ctx->stream, ctx->P, (const int2*)ctx->b_tiles.p+t0, T,
@@ -2681,7 +2685,12 @@ int pnl_assemble_pairs_masked(pnl_context *ctx, int np, const int32_t *pairs, co
 }
 
 int pnl_assemble_pairs_in_horizon(pnl_context *ctx, double *data, double *diag) {
+    return pnl_assemble_pairs_in_horizon_range(ctx, data, diag, 0, ctx ? ctx->nc : 0);
+}
+
+int pnl_assemble_pairs_in_horizon_range(pnl_context *ctx, double *data, double *diag, int cell_begin, int cell_end) {
     if (!ctx) return PNL_ERR_INVALID;
+    if (cell_begin < 0 || cell_end > ctx->nc || cell_begin > cell_end) return fail(ctx, PNL_ERR_INVALID, "bad cell range");
     int rc;
     if ((rc = check_ready(ctx))) return rc;
     if ((rc = finalize(ctx))) return rc;
@@ -2692,13 +2701,13 @@ int pnl_assemble_pairs_in_horizon(pnl_context *ctx, double *data, double *diag) 
     if ((rc = sparse_ready(ctx, data, diag, S))) return rc;
     HIPCHK(ctx, hipMemsetAsync(ctx->b_counters.p, 0, sizeof(unsigned long long)*PNL_NCOUNTERS, ctx->stream));
     const int kt = ctx->P.k.fast ? 1 : 0;
-    if (ctx->dim == 2 && ctx->dpe == 3) return kt ? horizon_impl<2, 3, 1>(ctx, S) : horizon_impl<2, 3, 0>(ctx, S);
-    if (ctx->dim == 2 && ctx->dpe == 6) return kt ? horizon_impl<2, 6, 1>(ctx, S) : horizon_impl<2, 6, 0>(ctx, S);
-    if (ctx->dim == 2 && ctx->dpe == 1) return kt ? horizon_impl<2, 1, 1>(ctx, S) : horizon_impl<2, 1, 0>(ctx, S);
-    if (ctx->dim == 1 && ctx->dpe == 2) return horizon_impl<1, 2, 0>(ctx, S);
-    if (ctx->dim == 1 && ctx->dpe == 1) return horizon_impl<1, 1, 0>(ctx, S);
-    if (ctx->dim == 1 && ctx->dpe == 3) return horizon_impl<1, 3, 0>(ctx, S);
-    if (ctx->dim == 1 && ctx->dpe == 4) return horizon_impl<1, 4, 0>(ctx, S);
+    if (ctx->dim == 2 && ctx->dpe == 3) return kt ? horizon_impl<2, 3, 1>(ctx, S, cell_begin, cell_end) : horizon_impl<2, 3, 0>(ctx, S, cell_begin, cell_end);
+    if (ctx->dim == 2 && ctx->dpe == 6) return kt ? horizon_impl<2, 6, 1>(ctx, S, cell_begin, cell_end) : horizon_impl<2, 6, 0>(ctx, S, cell_begin, cell_end);
+    if (ctx->dim == 2 && ctx->dpe == 1) return kt ? horizon_impl<2, 1, 1>(ctx, S, cell_begin, cell_end) : horizon_impl<2, 1, 0>(ctx, S, cell_begin, cell_end);
+    if (ctx->dim == 1 && ctx->dpe == 2) return horizon_impl<1, 2, 0>(ctx, S, cell_begin, cell_end);
+    if (ctx->dim == 1 && ctx->dpe == 1) return horizon_impl<1, 1, 0>(ctx, S, cell_begin, cell_end);
+    if (ctx->dim == 1 && ctx->dpe == 3) return horizon_impl<1, 3, 0>(ctx, S, cell_begin, cell_end);
+    if (ctx->dim == 1 && ctx->dpe == 4) return horizon_impl<1, 4, 0>(ctx, S, cell_begin, cell_end);
     return fail(ctx, PNL_ERR_UNSUPPORTED, "unsupported (dim=%d, dofs_per_element=%d)", ctx->dim, ctx->dpe);
 }
 
