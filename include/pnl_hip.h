@@ -381,6 +381,11 @@ int pnl_tree_build_blocks(int N, int dim, const double *boxes, const int64_t *d2
 int pnl_tree_build_refined(int N, int dim, const double *boxes, const int64_t *d2c_ptr, const int32_t *d2c_idx, int nc, double eta,
                            int min_size, int max_levels, int do_admissibility, const int32_t *dof_block, int mixed_block, int ref_type,
                            pnl_tree **out);
+/* the same structure with refinement (MEDIAN / GEOMETRIC) and admissibility run ON THE DEVICE as level-synchronous sweeps
+ * (clusterMethodCy.pyx:354-663, 4046-4136; csrc/pnl_plan_dev.hip): same nodes, same lists in the same order as pnl_tree_build_refined;
+ * kernel blocks and the BARYCENTER split: PNL_ERR_UNSUPPORTED (use the host planner).  Uses the current HIP device. */
+int pnl_tree_build_device(int N, int dim, const double *boxes, const int64_t *d2c_ptr, const int32_t *d2c_idx, int nc, double eta,
+                          int min_size, int max_levels, int do_admissibility, int ref_type, pnl_tree **out);
 void pnl_tree_destroy(pnl_tree *T);
 int pnl_tree_sizes(const pnl_tree *T, int64_t *out3);                /* nodes, near pairs, far pairs */
 int pnl_tree_get(const pnl_tree *T, int32_t *range, int32_t *parent, int32_t *children, int32_t *level, double *box, int32_t *perm,

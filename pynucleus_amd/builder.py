@@ -670,6 +670,11 @@ class nonlocalBuilder:
             # parameters only: kept on the builder (a second operator of the same DoFMap -- another kernel through setKernel, a
             # time step -- starts with the device work)
             key = ('tree', rp['eta'], rp['minSize'], rp['maxLevels'], rp['refinementType'])
+            # ... and on the DoF map itself (at most two parameter sets): a NEW builder on the same DoF map -- another kernel, the next
+            # operator of a parameter study -- finds tree, tile plan, pattern and far-field plan there and starts with the device work
+            store = self.dm.__dict__.setdefault('_pnl_geom', {}) if self.params.get('cacheGeometry', True) else {}
+            if self._geom_cache.get('key') != key and key in store:
+                self._geom_cache = store[key]
             if self._geom_cache.get('key') != key:
                 # a new builder: the library's own set-up of the mesh (padded cell tables, adjacency lists: 16-19 ms at 98,304 cells)
                 # runs on a host thread while this one builds the tree -- the two share nothing (ctypes releases the GIL)
@@ -684,10 +689,14 @@ class nonlocalBuilder:
                 th = threading.Thread(target=warm)
                 th.start()
                 try:
-                    tree = clusters.getNearFieldClusters(self.dm, rp['eta'], rp['minSize'], rp['maxLevels'], refinementType=rp['refinementType'])
+                    tree = clusters.getNearFieldClusters(self.dm, rp['eta'], rp['minSize'], rp['maxLevels'], refinementType=rp['refinementType'],
+                                                         planner=self.params.get('planner', 'device'))
                 finally:
                     th.join()
                 self._geom_cache = {'key': key, 'tree': tree}
+                while len(store) >= 2:
+                    store.pop(next(iter(store)))
+                store[key] = self._geom_cache
             root, Pnear, Pfar = self._geom_cache['tree']
         rank, size = self._rank_size()
         if sum(len(v) for v in Pfar.values()) == 0:
@@ -786,7 +795,7 @@ class nonlocalBuilder:
         symmetric = not forceUnsymmetricMatrix
         cached = self._geom_cache.get('tree') is not None and Pnear is self._geom_cache['tree'][1] and myRoot is None
         if Anear is None:
-            pat_key = ('pattern', symmetric)
+            pat_key = ('pattern', symmetric, ctx.device)          # device arrays: per device
             if cached and pat_key in self._geom_cache:
                 indptr, indices = self._geom_cache[pat_key]
             else:

@@ -144,7 +144,7 @@ REFINEMENT_TYPES = {'median': 0, 'MEDIAN': 0, 'geometric': 1, 'GEOMETRIC': 1, 'b
 
 
 class _nativeTree:
-    def __init__(self, dm, eta, minSize, maxLevels, mode, dof_block=None, mixed_block=-1, refinementType='MEDIAN'):
+    def __init__(self, dm, eta, minSize, maxLevels, mode, dof_block=None, mixed_block=-1, refinementType='MEDIAN', planner='host'):
         import ctypes as C
         from . import _lib
         L = _lib.load()
@@ -157,9 +157,21 @@ class _nativeTree:
         ix = np.ascontiguousarray(idx, dtype=np.int32)
         h = C.c_void_p()
         self.dof_block = None if dof_block is None else np.ascontiguousarray(dof_block, dtype=np.int32)
-        rc = L.pnl_tree_build_refined(N, dim, b.ctypes.data, p.ctypes.data, ix.ctypes.data, dm.mesh.num_cells, float(eta), int(minSize),
-                                      int(maxLevels), int(mode), None if dof_block is None else self.dof_block.ctypes.data,
-                                      int(mixed_block), REFINEMENT_TYPES[refinementType], C.byref(h))
+        rc = _lib.PNL_ERR_UNSUPPORTED
+        self.planner = 'host'
+        if planner == 'device' and dof_block is None:
+            # refinement and admissibility as level-synchronous sweeps on the GPU (csrc/pnl_plan_dev.hip): the same tree and lists; what
+            # it does not take (BARYCENTER split) falls through to the host loops
+            rc = L.pnl_tree_build_device(N, dim, b.ctypes.data, p.ctypes.data, ix.ctypes.data, dm.mesh.num_cells, float(eta), int(minSize),
+                                         int(maxLevels), int(mode), REFINEMENT_TYPES[refinementType], C.byref(h))
+            if rc == 0:
+                self.planner = 'device'
+            elif rc != _lib.PNL_ERR_UNSUPPORTED:
+                raise RuntimeError('pnl_tree_build_device failed: {}'.format(rc))
+        if rc == _lib.PNL_ERR_UNSUPPORTED:
+            rc = L.pnl_tree_build_refined(N, dim, b.ctypes.data, p.ctypes.data, ix.ctypes.data, dm.mesh.num_cells, float(eta), int(minSize),
+                                          int(maxLevels), int(mode), None if dof_block is None else self.dof_block.ctypes.data,
+                                          int(mixed_block), REFINEMENT_TYPES[refinementType], C.byref(h))
         if rc:
             raise RuntimeError('pnl_tree_build failed: {}'.format(rc))
         self.h = h
@@ -311,7 +323,7 @@ def dofKernelBlocks(dm, T):
     return blk.astype(np.int32), L
 
 
-def getNearFieldClusters(dm, eta=3., minClusterSize=None, maxLevels=200, dof_block=None, mixed_block=-1, refinementType='MEDIAN'):
+def getNearFieldClusters(dm, eta=3., minClusterSize=None, maxLevels=200, dof_block=None, mixed_block=-1, refinementType='MEDIAN', planner='host'):
     """(root, Pnear, Pfar) for dm; both orientations (n1,n2) and (n2,n1) of off-diagonal pairs are listed, like the
     reference's recursion from (root, root).  dof_block / mixed_block (dofKernelBlocks): clusters are split by kernel block
     before anything else and only pairs of single-block clusters can be admissible (variable orders, NA:2619-2640)."""
@@ -320,7 +332,7 @@ def getNearFieldClusters(dm, eta=3., minClusterSize=None, maxLevels=200, dof_blo
     if dof_block is not None and not _use_native():
         raise NotImplementedError('cluster trees by kernel block: native planner only')
     if _use_native():
-        T = _nativeTree(dm, eta, minClusterSize, maxLevels, 1, dof_block, mixed_block, refinementType)
+        T = _nativeTree(dm, eta, minClusterSize, maxLevels, 1, dof_block, mixed_block, refinementType, planner)
         T.load_cells(np.unique(T.near))
         Pnear = [nearFieldClusterPair(T.node(a), T.node(b)) for a, b in T.near]
         Pfar = {}

@@ -26,31 +26,7 @@
 
 extern "C++" const char *pnl_tune(const char *name);     // pnl_hip.hip: options set through pnl_set_option
 
-namespace {
-
-struct PNode {
-    int beg, end, parent, child[2], level;
-    int block;                               // kernel block of all DoFs of the node, -1: several blocks (never admissible)
-    double box[3][2];
-};
-
-}  // namespace
-
-struct pnl_tree {
-    int N = 0, dim = 0, nc = 0;
-    std::vector<int32_t> perm;               // DoFs: node k owns perm[beg:end), ascending inside a LEAF; children are sub-ranges
-    std::vector<PNode> nodes;
-    std::vector<int32_t> near, far;          // [n][2], [n][3] (n1, n2, level)
-    // cells of the nodes that occur in near-field pairs or are leaves (CSR over `cell_nodes`)
-    std::vector<int32_t> cell_nodes, cell_off, cells;
-    std::vector<int64_t> d2c_ptr;
-    std::vector<int32_t> d2c_idx;
-    std::vector<double> boxes, coords;
-    // variable order: kernel block of every DoF (getKernelBlocksAndJumps NA:2312-2352), mixed_block = the interface DoFs
-    std::vector<int32_t> dof_block;
-    int mixed_block = -1;
-    int ref_type = 0;                        // refinementType: 0 MEDIAN, 1 GEOMETRIC, 2 BARYCENTER (CM:354-663)
-};
+#include "pnl_plan.h"
 
 namespace {
 
@@ -61,20 +37,9 @@ int block_of_range(const pnl_tree *T, int beg, int end) {
     return b;
 }
 
-double dist_boxes(const PNode &a, const PNode &b, int dim) {
-    double s = 0.;
-    for (int d = 0; d < dim; d++) {
-        const double gap = std::max(0., std::max(a.box[d][0]-b.box[d][1], b.box[d][0]-a.box[d][1]));
-        s += gap*gap;
-    }
-    return std::sqrt(s);
-}
+double dist_boxes(const PNode &a, const PNode &b, int dim) { return pnl_dist_boxes(a.box, b.box, dim); }
 
-double diam_box(const PNode &a, int dim) {
-    double s = 0.;
-    for (int d = 0; d < dim; d++) { const double e = a.box[d][1]-a.box[d][0]; s += e*e; }
-    return std::sqrt(s);
-}
+double diam_box(const PNode &a, int dim) { return pnl_diam_box(a.box, dim); }
 
 void set_box(pnl_tree *T, PNode &n) {
     for (int d = 0; d < T->dim; d++) { n.box[d][0] = INFINITY; n.box[d][1] = -INFINITY; }
@@ -222,6 +187,32 @@ int pnl_tree_build_refined(int N, int dim, const double *boxes, const int64_t *d
     if (do_admissibility >= 0)
         for (size_t k = 0; k < T->nodes.size(); k++) refine(T, (int)k, min_size, max_levels, xs, tmp);
     if (do_admissibility > 0) admissible_rec(T, 0, 0, eta, max_levels, 0);
+    *out = T;
+    return PNL_OK;
+}
+
+// the same tree and lists, refined and classified on the device (pnl_plan_dev.hip): MEDIAN / GEOMETRIC refinement of a constant-order
+// kernel's DoFs (kernel blocks and the BARYCENTER split stay with the host loops above: PNL_ERR_UNSUPPORTED)
+int pnl_tree_build_device(int N, int dim, const double *boxes, const int64_t *d2c_ptr, const int32_t *d2c_idx, int nc, double eta,
+                          int min_size, int max_levels, int do_admissibility, int ref_type, pnl_tree **out) {
+    if (!out || N <= 0 || dim < 1 || dim > 3 || !boxes || !d2c_ptr || !d2c_idx || ref_type < 0 || ref_type > 2) return PNL_ERR_INVALID;
+    if (ref_type == 2) return PNL_ERR_UNSUPPORTED;
+    pnl_tree *T = new pnl_tree();
+    T->N = N; T->dim = dim; T->nc = nc; T->ref_type = ref_type;
+    T->boxes.assign(boxes, boxes+(size_t)N*dim*2);
+    T->coords.resize((size_t)N*dim);
+    for (int i = 0; i < N; i++) for (int d = 0; d < dim; d++) T->coords[(size_t)i*dim+d] = (boxes[((size_t)i*dim+d)*2]+boxes[((size_t)i*dim+d)*2+1])/2.;
+    T->d2c_ptr.assign(d2c_ptr, d2c_ptr+N+1);
+    T->d2c_idx.assign(d2c_idx, d2c_idx+d2c_ptr[N]);
+    T->perm.resize(N);
+    std::iota(T->perm.begin(), T->perm.end(), 0);
+    PNode root;
+    root.beg = 0; root.end = N; root.parent = -1; root.child[0] = root.child[1] = -1; root.level = 0;
+    root.block = 0;
+    set_box(T, root);
+    T->nodes.push_back(root);
+    const int rc = pnl_tree_fill_device(T, eta, min_size, max_levels, do_admissibility);
+    if (rc) { delete T; return rc; }
     *out = T;
     return PNL_OK;
 }

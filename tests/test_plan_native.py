@@ -255,3 +255,45 @@ def test_refinement_types(refType):
         a, b = root.children
         # (the disc is symmetric: coordinates within rounding of the mean may fall on either side)
         assert (c[a.dofs] < c.mean()+1e-12).all() and (c[b.dofs] >= c.mean()-1e-12).all() and min(len(a.dofs), len(b.dofs)) > 0.3*N
+
+
+# ---- planner on the device (csrc/pnl_plan_dev.hip): refinement and admissibility as level-synchronous sweeps ---------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize('domain,noRef,element,eta,minSize,refinementType',
+                         [('disc', 4, 'P1', 3., 8, 'MEDIAN'), ('disc', 6, 'P1', 3., 64, 'MEDIAN'), ('disc', 5, 'P2', 1.5, 24, 'MEDIAN'),
+                          ('square', 5, 'P1', 3., 8, 'MEDIAN'), ('square', 5, 'P1', 2., 5, 'GEOMETRIC'), ('interval', 9, 'P1', 1., 4, 'MEDIAN'),
+                          ('disc', 5, 'P1', 3., 16, 'GEOMETRIC'), ('disc', 7, 'P1', 3., 64, 'MEDIAN')])
+def test_device_planner_equals_host_planner(domain, noRef, element, eta, minSize, refinementType):
+    """tree_node.refine (clusterMethodCy.pyx:354-663) and getAdmissibleClusters (:4046-4136) on the device -- the same
+    tree (node ranges, parents, children, levels, boxes, DoF permutation) and the same near / far lists IN THE SAME ORDER as the host
+    planner, entry for entry; the structured square puts cluster pairs exactly on the admissibility threshold (both planners evaluate
+    the box metrics without FMA contraction), GEOMETRIC splits leave unbalanced trees"""
+    from pynucleus_amd import disc, interval, uniformSquare, PHYSICAL, dofmapFactory, clusters
+    mesh = {'disc': lambda: disc(noRef), 'interval': lambda: interval(noRef), 'square': lambda: uniformSquare(2**noRef+1, None, -1., -1., 1., 1.)}[domain]()
+    dm = dofmapFactory(element, mesh, PHYSICAL)
+    H = clusters._nativeTree(dm, eta, minSize, 200, 1, refinementType=refinementType, planner='host')
+    D = clusters._nativeTree(dm, eta, minSize, 200, 1, refinementType=refinementType, planner='device')
+    assert H.planner == 'host' and D.planner == 'device'
+    for name in ('range', 'parent', 'children', 'level', 'perm'):
+        assert np.array_equal(getattr(H, name), getattr(D, name)), name
+    assert np.array_equal(H.box, D.box)
+    assert H.near.shape[0] > 0 and np.array_equal(H.near, D.near)
+    assert np.array_equal(H.far, D.far)
+    if domain != 'interval':
+        assert H.far.shape[0] > 0
+
+
+@pytest.mark.gpu
+def test_device_planner_feeds_getH2():
+    """getH2 with params['planner'] = 'device' (the default) and 'host': the same operator"""
+    from pynucleus_amd import disc, P1_DoFMap, PHYSICAL, getFractionalKernel
+    from pynucleus_amd.builder import nonlocalBuilder
+    out = []
+    for planner in ('device', 'host'):
+        dm = P1_DoFMap(disc(4), PHYSICAL)
+        b = nonlocalBuilder(dm, getFractionalKernel(2, 0.75), {'eta': 3., 'minClusterSize': 8, 'planner': planner}, zeroExterior=True)
+        H = b.getH2()
+        x = np.cos(0.37*np.arange(dm.num_dofs))
+        out.append((H.matvec(x), np.asarray(H.Anear.indptr), np.asarray(H.Anear.indices), H.info['numFarPairs']))
+    assert np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][2], out[1][2]) and out[0][3] == out[1][3]
+    assert np.abs(out[0][0]-out[1][0]).max() < 1e-13*np.abs(out[1][0]).max()
