@@ -617,6 +617,16 @@ class nonlocalBuilder:
         A.info = dict(counters=totals, interior_ms=ms_total, num_candidate_pairs=int(pairs.shape[0]) if pairs is not None else totals['numCellPairs'])
         return (A, pairs) if returnNearField else A
 
+    def _planner(self):
+        """'host' (C++ loops, csrc/pnl_plan.hip) or 'device' (level-synchronous sweeps on the GPU, csrc/pnl_plan_dev.hip) for the cluster
+        tree and the admissible pairs -- the same tree and lists either way.  params['planner']; by default the device from 2^18 DoFs
+        on: at 48,769 DoFs the host loops take 4.5 ms, the sweeps 10 ms (two dozen small launches per level), and the first call of a
+        process loads the sort / scan kernels (0.25 s)"""
+        p = self.params.get('planner', 'auto')
+        if p == 'auto':
+            return 'device' if self.dm.num_dofs >= (1 << 18) else 'host'
+        return p
+
     def getH2RefinementParams(self):
         """NA:2979-3046: eta, leaf size, depth and refinement type of the cluster tree from params.  The default leaf size follows
         the GPU tile (a leaf of about one block of cells keeps the near-field tiles full); params['minClusterSize'] = 'reference'
@@ -690,7 +700,7 @@ class nonlocalBuilder:
                 th.start()
                 try:
                     tree = clusters.getNearFieldClusters(self.dm, rp['eta'], rp['minSize'], rp['maxLevels'], refinementType=rp['refinementType'],
-                                                         planner=self.params.get('planner', 'device'))
+                                                         planner=self._planner())
                 finally:
                     th.join()
                 self._geom_cache = {'key': key, 'tree': tree}

@@ -285,7 +285,7 @@ def test_device_planner_equals_host_planner(domain, noRef, element, eta, minSize
 
 @pytest.mark.gpu
 def test_device_planner_feeds_getH2():
-    """getH2 with params['planner'] = 'device' (the default) and 'host': the same operator"""
+    """getH2 with params['planner'] = 'device' and 'host': the same operator"""
     from pynucleus_amd import disc, P1_DoFMap, PHYSICAL, getFractionalKernel
     from pynucleus_amd.builder import nonlocalBuilder
     out = []
