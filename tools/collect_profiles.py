@@ -4,7 +4,7 @@
   <tag>_bench_noRef<N>_kernel_stats.csv rocprofv3 --kernel-trace --stats of the same command
   <tag>_pmc_summary_noRef<N>.json      mean counter value per dispatch and kernel (separate --pmc passes)
   pmc_traffic.json                     HBM bytes per launch of the tile kernels, corrected as MI355X_MICROARCH.md prescribes
-usage: tools/collect_profiles.py <tag> <noRef>"""
+usage: tools/collect_profiles.py <tag> <noRef> [sectors]"""
 import collections
 import csv
 import glob
@@ -14,13 +14,15 @@ import shutil
 import sys
 
 tag, noRef = sys.argv[1], sys.argv[2]
+sectors = int(sys.argv[3]) if len(sys.argv) > 3 else 6
+sfx = '' if sectors == 6 else '_s{}'.format(sectors)
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-src = os.path.join(root, 'gpurun_out', tag)
+src = os.path.join(root, 'gpurun_out', tag+sfx)
 dst = os.path.join(root, 'profiles')
-shutil.copy(os.path.join(src, 'bench_noRef{}.json'.format(noRef)), os.path.join(dst, '{}_bench_noRef{}.json'.format(tag, noRef)))
+shutil.copy(os.path.join(src, 'bench_noRef{}{}.json'.format(noRef, sfx)), os.path.join(dst, '{}_bench_noRef{}{}.json'.format(tag, noRef, sfx)))
 stats = sorted(glob.glob(os.path.join(src, 'stats', '*', '*kernel_stats.csv')), key=os.path.getmtime)[-1:]
 if stats:
-    shutil.copy(stats[0], os.path.join(dst, '{}_bench_noRef{}_kernel_stats.csv'.format(tag, noRef)))
+    shutil.copy(stats[0], os.path.join(dst, '{}_bench_noRef{}{}_kernel_stats.csv'.format(tag, noRef, sfx)))
 
 
 def newest(pattern):
@@ -55,7 +57,7 @@ for d in ('pmc_fetch', 'pmc_write', 'pmc_tcc', 'pmc_sq'):
         for k in agg:
             for c, v in agg[k].items():
                 summary[k][c] = v/max(1, len(calls[k]))
-with open(os.path.join(dst, '{}_pmc_summary_noRef{}.json'.format(tag, noRef)), 'w') as f:
+with open(os.path.join(dst, '{}_pmc_summary_noRef{}{}.json'.format(tag, noRef, sfx)), 'w') as f:
     json.dump(summary, f, indent=1, sort_keys=True)
 
 traffic_fn = os.path.join(dst, 'pmc_traffic.json')
@@ -72,7 +74,7 @@ with open(os.path.join(root, 'pynucleus_amd', 'libpnl_hip.so'), 'rb') as f:
 sys.path.insert(0, root)
 from pynucleus_amd._lib import source_sha16
 entry = {'tag': tag, 'lib_sha16': lib_sha, 'src_sha16': source_sha16()}
-for k in ('k_tile_distant', 'k_tile_pure', 'k_tile_uniform_3_3', 'k_tile_uniform_3_6', 'k_tile_uniform_6_3', 'k_tile_uniform_6_6', 'k_tile_p2', 'k_fold_mirror'):
+for k in ('k_tile_distant', 'k_tile_pure', 'k_tile_uniform_3_3', 'k_tile_uniform_3_6', 'k_tile_uniform_6_3', 'k_tile_uniform_6_6', 'k_tile_p2', 'k_fold_mirror', 'k_boundary_tile', 'k_gemv_two_sided'):
     if k in summary and 'FETCH_SIZE' in summary[k] and 'WRITE_SIZE' in summary[k]:
         # FETCH_SIZE x 2 for the tile kernels (their known input volume, ~13 KB of cell data per tile, matches the doubled value);
         # the fold pass reads every stored entry of the block-slot storage exactly once with 8-byte gathers -- a known byte count
@@ -83,7 +85,7 @@ for k in ('k_tile_distant', 'k_tile_pure', 'k_tile_uniform_3_3', 'k_tile_uniform
         entry[k+'_write_size_kb'] = summary[k]['WRITE_SIZE']
     if k in summary and 'SQ_INSTS_VALU' in summary[k]:
         entry[k+'_sq_insts_valu'] = summary[k]['SQ_INSTS_VALU']
-rec['noRef{}'.format(noRef)] = entry
+rec['noRef{}{}'.format(noRef, sfx)] = entry
 with open(traffic_fn, 'w') as f:
     json.dump(rec, f, indent=1)
 print(json.dumps(entry, indent=1))
