@@ -12,7 +12,7 @@ from .kernels import (getKernel, getFractionalKernel, getIntegrableKernel, kerne
                       FRACTIONAL, INDICATOR, PERIDYNAMIC, GAUSSIAN, EXPONENTIAL, constFractionalOrder, constant, ball2_retriangulation, ball2_barycenter, ellipse_retriangulation, ellipse_barycenter)
 from .local_matrix import nonlocalTables  # noqa: F401
 from .fractionalOrders import (variableConstFractionalOrder, leftRightFractionalOrder, layersFractionalOrder,  # noqa: F401
-                               piecewiseConstantFractionalOrder, constantNonSymFractionalOrder,
+                               piecewiseConstantFractionalOrder, lambdaFractionalOrder, constantNonSymFractionalOrder,
                                smoothedLeftRightFractionalOrder, linearLeftRightFractionalOrder,
                                smoothedInnerOuterFractionalOrder, feFractionalOrder, innerOuterFractionalOrder,
                                islandsFractionalOrder, sumFractionalOrder)

@@ -351,9 +351,14 @@ class nonlocalBuilder:
         separate and all-reduces the N-vector in matvec instead."""
         import torch
         from .linear_operators import Dense_LinearOperator, DistributedDense_LinearOperator
-        if trySparsification:
-            # NA:1287-1348, 1451-1469 (cluster-based compression of the dense loop) is not built: refuse instead of ignoring
-            raise NotImplementedError('getDense(trySparsification=True) is not implemented; use getSparse / getH2')
+        sparsificationThreshold = 0.8                                # NA:1274
+        if trySparsification and distributed:
+            raise NotImplementedError('getDense(trySparsification=True, distributed=True)')
+        if (trySparsification and self._rank_size()[1] == 1 and not self.zeroExterior and self.kernel.finiteHorizon
+                and self.mesh.volume*(1.-sparsificationThreshold) > self.kernel.horizonValue**self.mesh.dim):
+            # NA:1287-1348: a horizon that is small against the domain -- the operator is assembled into the sparsity pattern of the
+            # element pairs getPanelType does not ignore (SSS for a symmetric local matrix), which is what getSparse builds and fills
+            return self.getSparse()
         if self.kernel.finiteHorizon:
             # the reference's all-pairs loop visits every pair and ignores the REMOTE ones; the same matrix is obtained from
             # the pairs within the horizon (getSparse), stored densely
@@ -372,7 +377,8 @@ class nonlocalBuilder:
             if S.symmetric:
                 A[cols, rows] = data
                 A.diagonal().copy_(S.diag_dev)
-            return Dense_LinearOperator(A, ctx, S.info)
+            op = Dense_LinearOperator(A, ctx, S.info, symmetric=bool(S.symmetric))
+            return self._sparsified(op, sparsificationThreshold) if trySparsification else op
         ctx = self.context()
         if getattr(ctx, '_slab_owner', None) is not None:
             ctx.set_row_slab(np.zeros(0, dtype=np.int32), np.zeros(0, dtype=np.int32))   # a row slab of an earlier distributed operator
@@ -416,10 +422,34 @@ class nonlocalBuilder:
         self.PLogger.addTimer('zeroExterior', 1e-3*ms['boundary'])
         info = dict(counters=cnt, phase_ms=ms)
         if size == 1:
-            return Dense_LinearOperator(A, ctx, info, symmetric=not pointwise)
+            op = Dense_LinearOperator(A, ctx, info, symmetric=not pointwise)
+            return self._sparsified(op, sparsificationThreshold) if trySparsification else op
         group = None if self.comm is True else self.comm
         op = DistributedDense_LinearOperator(A, ctx, group, info)
         return op if distributed else op.reduce()
+
+    def _sparsified(self, op, threshold):
+        """NA:1451-1469: the dense operator becomes a CSR operator when more than `threshold` of its entries are explicit zeros.  The
+        reference counts zeros row by row and stops at the first row that is not mostly zero; the ratio is taken over the rows counted."""
+        import torch
+        from .linear_operators import CSR_LinearOperator
+        op.ctx.synchronize()
+        A = op.A
+        N = A.shape[0]
+        zeros_row = (A == 0.).sum(dim=1)
+        dense_rows = torch.nonzero(zeros_row <= threshold*A.shape[1])
+        nr = int(dense_rows[0].item())+1 if dense_rows.numel() else N
+        ratio = float(zeros_row[:nr].sum().item())/float(nr)/float(A.shape[1])
+        if not ratio > threshold:
+            return op
+        nz = torch.nonzero(A != 0.)                                  # CSR_LinearOperator.from_dense: row-major, sorted columns
+        counts = torch.bincount(nz[:, 0], minlength=N)
+        indptr = torch.zeros(N+1, dtype=torch.int32, device=A.device)
+        indptr[1:] = torch.cumsum(counts, 0).to(torch.int32)
+        S = CSR_LinearOperator(indptr, nz[:, 1].to(torch.int32), N, op.ctx, A.device)
+        S.data_dev[:nz.shape[0]] = A[nz[:, 0], nz[:, 1]]
+        S.info = dict(op.info, sparsified_from_dense=ratio)
+        return S
 
     def tiles_for_rank(self, rank, size):
         """block-tile pairs (ta <= tb) of the upper block triangle owned by `rank`: the list is ordered by

@@ -1895,7 +1895,9 @@ std::map<std::string, const std::string*> g_options;
 std::deque<std::string> g_option_values;
 // the options a product build accepts: the hooks through which the parity tests reach the alternative code paths, and the
 // diagnostics line
-const char *const k_product_options[] = {"PNL_WL_FRAC", "PNL_FH_NOTILES", "PNL_NO_POWTAB", "PNL_VERBOSE", "PNL_PLAN_TIMING", "PNL_PLAN_THREADS", "PNL_BND_OLD"};
+const char *const k_product_options[] = {"PNL_WL_FRAC", "PNL_FH_NOTILES", "PNL_NO_POWTAB", "PNL_VERBOSE", "PNL_PLAN_TIMING", "PNL_PLAN_THREADS", "PNL_BND_OLD",
+                                         // profiling: every phase on the caller's stream, one after the other (per-kernel times that add up)
+                                         "PNL_NO_OVERLAP", "PNL_NO_FORK"};
 }  // namespace
 
 const char *pnl_tune(const char *name) {

@@ -179,6 +179,63 @@ class piecewiseConstantFractionalOrder(variableFractionalOrder):
 # The reference switches such kernels to piecewise=False (kernels.py:147-149): gamma(x, y) = C(s(x)) |x-y|^(-d-2 s(x)).
 # Every function knows its device encoding (type id + up to 6 parameters, include/pnl_hip.h pnl_order_function).
 
+class lambdaFractionalOrder(variableFractionalOrder):
+    """fractionalOrders.pyx:176-201: s(x, y) given by a Python callable.  The reference calls it per element pair at the two cell
+    centres (evalParams, NO:509-513); a callable cannot run on the device, so it is TABULATED on the host: the points the assembly
+    asks about (cell centres, facet centres) are grouped into labels -- two points share a label when the callable cannot tell them
+    apart against the representatives of all labels, in either argument -- and the order becomes a table sVals[label(x), label(y)]
+    like every other piecewise-constant order.  A callable that is not piecewise constant yields one label per point and is refused
+    beyond maxLabels."""
+
+    def __init__(self, dim, smin, smax, symmetric, fun, maxLabels=64):
+        self.dim, self.fun, self.maxLabels = int(dim), fun, int(maxLabels)
+        self.min, self.max, self.symmetric = float(smin), float(smax), bool(symmetric)
+        self._reps = []                                  # one representative point per label
+        self.sVals = np.zeros((0, 0))
+
+    def _sig(self, p):
+        return tuple(float(self.fun(p, r)) for r in self._reps)+tuple(float(self.fun(r, p)) for r in self._reps)
+
+    def _rebuild(self):
+        L = len(self._reps)
+        self.sVals = np.array([[float(self.fun(self._reps[a], self._reps[b])) for b in range(L)] for a in range(L)]).reshape(L, L)
+        if L:
+            assert self.sVals.min() >= self.min-1e-12 and self.sVals.max() <= self.max+1e-12, 'the callable leaves [smin, smax]'
+
+    def labels(self, points):
+        pts = np.atleast_2d(np.asarray(points, dtype=np.float64))
+        while True:
+            sigs = {self._sig(r)+(float(self.fun(r, r)),): l for l, r in enumerate(self._reps)}
+            lab = np.full(pts.shape[0], -1, dtype=np.int32)
+            grew = False
+            for i, p in enumerate(pts):
+                l = sigs.get(self._sig(p)+(float(self.fun(p, p)),))
+                if l is None:
+                    # the representatives so far cannot place p: a new label, and every signature has one more column
+                    if len(self._reps) >= self.maxLabels:
+                        raise NotImplementedError('lambdaFractionalOrder: more than {} distinct labels -- the callable is not piecewise '
+                                                  'constant on the mesh (orders evaluated per quadrature point: singleVariableUnsymmetric'
+                                                  'FractionalOrder)'.format(self.maxLabels))
+                    self._reps.append(np.array(p, copy=True))
+                    grew = True
+                    break
+                lab[i] = l
+            if not grew:
+                break
+        self._rebuild()
+        return lab
+
+    @property
+    def numLabels(self):
+        return len(self._reps)
+
+    def __call__(self, x, y):
+        return float(self.fun(np.asarray(x, dtype=float), np.asarray(y, dtype=float)))
+
+    def spec(self):
+        return ('lambda', self.sVals.copy())
+
+
 class extendedFunction:
     device_type = 0
 

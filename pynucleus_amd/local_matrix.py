@@ -149,6 +149,11 @@ class nonlocalTables:
         carry the label of their centre and cls_of[label1, label2] names the class of a pair."""
         sFun = kernel.s
         mesh = dm.mesh
+        if hasattr(sFun, '_reps'):
+            # lambdaFractionalOrder: the callable is tabulated over the points the assembly will ask about (cell centres, centres of the
+            # boundary facets) before the table of its values is read
+            surf = mesh.get_surface_mesh()
+            sFun.labels(np.concatenate([mesh.vertices[mesh.cells].mean(axis=1), mesh.vertices[np.asarray(surf.cells)].mean(axis=1)]))
         vals = np.unique(sFun.sVals)
         self.class_s = vals
         self.cls_of = np.searchsorted(vals, sFun.sVals).astype(np.int32)          # [L, L]

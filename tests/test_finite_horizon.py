@@ -307,3 +307,26 @@ def test_ellipse_domain_known_answer():
             assert abs(r.mean()+np.trace(H@M)) <= 0.015*max(np.abs(M).max(), 1e-300)*2., (a, b, th, r.mean(), -np.trace(H@M))
         if th == 0.:
             assert abs(((A@(c[:, 0]**2))/rhs)[inner].mean()+2.*a*b*a*a) < 0.01 and abs(((A@(c[:, 1]**2))/rhs)[inner].mean()+2.*a*b*b*b) < 0.02
+
+
+@pytest.mark.gpu
+def test_gpu_getDense_trySparsification():
+    """getDense(trySparsification=True) (NA:1287-1348, 1451-1469): a horizon that is small against the domain is assembled into the
+    sparsity pattern directly (the reference returns an SSS operator), a larger one densely and converted to CSR when more than 80 % of
+    the entries are explicit zeros; the operators equal the dense one"""
+    from pynucleus_amd.linear_operators import SSS_LinearOperator, CSR_LinearOperator, Dense_LinearOperator
+    b = _gpu_sparse(17, 0.2, 'indicator')                      # volume 1: 0.2 > 0.2^2 -> sparse from the start
+    D = b.getDense().toarray()
+    S = b.getDense(trySparsification=True)
+    assert isinstance(S, SSS_LinearOperator)
+    assert np.abs(S.toarray()-D).max() <= 1e-13*np.abs(D).max()
+    b = _gpu_sparse(33, 0.45, 'indicator')                     # 0.2 < 0.2025: dense first; the horizon still leaves most entries zero? no: stays dense
+    D = b.getDense()
+    S = b.getDense(trySparsification=True)
+    zero_ratio = float((D.toarray() == 0.).mean())
+    assert isinstance(S, CSR_LinearOperator if zero_ratio > 0.8 else Dense_LinearOperator)
+    assert np.abs(S.toarray()-D.toarray()).max() <= 1e-13*np.abs(D.toarray()).max()
+    b = _gpu_sparse(33, 0.1, 'indicator', domain='interval')   # 1D: volume 2 (interval(-1, 1)): 0.4 > 0.1 -> sparse from the start
+    S = b.getDense(trySparsification=True)
+    assert isinstance(S, SSS_LinearOperator)
+    assert np.abs(S.toarray()-b.getDense().toarray()).max() <= 1e-13

@@ -764,3 +764,22 @@ def test_boundary_tiled_equals_per_pair_kernel(case):
     (A0, c0), (A1, c1) = out[False], out[True]
     assert c0['numBoundaryPairs'] == c1['numBoundaryPairs'] > 0 and c0['numBoundaryIntegrations'] == c1['numBoundaryIntegrations']
     assert np.abs(A0-A1).max() < 1e-13*np.abs(A1).max()
+
+
+def test_lambda_fractional_order_dense_and_h2():
+    """lambdaFractionalOrder (fractionalOrders.pyx:176-201), tabulated on the host: the callable that restates leftRight(0.25, 0.75, 0.3, 0.6)
+    assembles the operator of leftRightFractionalOrder -- dense (both orientations of the non-symmetric table) and through getH2"""
+    from pynucleus_amd import disc, P1_DoFMap, PHYSICAL, getFractionalKernel
+    from pynucleus_amd.builder import nonlocalBuilder
+    from pynucleus_amd.fractionalOrders import lambdaFractionalOrder, leftRightFractionalOrder
+    dm = P1_DoFMap(disc(3), PHYSICAL)
+    ref = leftRightFractionalOrder(0.25, 0.75, 0.3, 0.6)
+    lam = lambdaFractionalOrder(2, 0.25, 0.75, False, lambda x, y: [[0.25, 0.3], [0.6, 0.75]][int(x[0] >= 0.)][int(y[0] >= 0.)])
+    out = []
+    for order in (ref, lam):
+        b = nonlocalBuilder(dm, getFractionalKernel(2, order), {'eta': 3., 'minClusterSize': 8}, zeroExterior=True)
+        A = b.getDense().toarray()
+        x = np.cos(0.37*np.arange(dm.num_dofs))
+        out.append((A, b.getH2().matvec(x)))
+    assert np.abs(out[0][0]-out[1][0]).max() < 1e-13*np.abs(out[0][0]).max()
+    assert np.abs(out[0][1]-out[1][1]).max() < 1e-12*np.abs(out[0][1]).max()

@@ -162,3 +162,34 @@ def full_space_errors(name, kw, k, dm, dmA, A):
     uA[np.array([int(np.argmin(np.abs(XA-x))) for x in XI])] = u
     e = uA-np.array([sol([x]) for x in XA])
     return float(np.sqrt(e@(dmA.assembleMass()@e))), float(np.abs(e).max())
+
+
+def test_lambda_fractional_order_is_tabulated():
+    """lambdaFractionalOrder (fractionalOrders.pyx:176-201): a Python callable s(x, y), evaluated per element pair at the cell centres.
+    It is tabulated on the host into labels + a table; a callable that restates leftRight / layers yields exactly their tables
+    (classes, class of every label pair, cell and facet labels up to the numbering of the labels)"""
+    from pynucleus_amd import disc, interval, P1_DoFMap, PHYSICAL, getFractionalKernel
+    from pynucleus_amd.fractionalOrders import lambdaFractionalOrder, leftRightFractionalOrder, layersFractionalOrder
+    from pynucleus_amd.local_matrix import nonlocalTables
+    for mesh, ref, fun, sym in ((disc(2), leftRightFractionalOrder(0.25, 0.75, 0.3, 0.6),
+                                 lambda x, y: [[0.25, 0.3], [0.6, 0.75]][int(x[0] >= 0.)][int(y[0] >= 0.)], False),
+                                (interval(5), layersFractionalOrder(1, np.array([-1., -0.5, 0., 1.]), np.array([[0.3, 0.4, 0.5], [0.4, 0.5, 0.6], [0.5, 0.6, 0.7]])),
+                                 lambda x, y: [[0.3, 0.4, 0.5], [0.4, 0.5, 0.6], [0.5, 0.6, 0.7]][int(x[0] > -0.5)+int(x[0] > 0.)][int(y[0] > -0.5)+int(y[0] > 0.)], True)):
+        dm = P1_DoFMap(mesh, PHYSICAL)
+        dim = mesh.dim
+        k0 = getFractionalKernel(dim, ref)
+        k1 = getFractionalKernel(dim, lambdaFractionalOrder(dim, ref.min, ref.max, sym, fun))
+        assert k1.variable and k1.symmetric == sym
+        T0, T1 = nonlocalTables(dm, k0, {}, True), nonlocalTables(dm, k1, {}, True)
+        assert np.allclose(T0.class_s, T1.class_s, atol=1e-15)
+        # the same class for every pair of cells / (cell, facet), whatever the labels are called
+        c0 = T0.cls_of[T0.cell_labels[:, None], T0.cell_labels[None, :]]
+        c1 = T1.cls_of[T1.cell_labels[:, None], T1.cell_labels[None, :]]
+        assert np.array_equal(c0, c1)
+        f0 = T0.cls_of[T0.cell_labels[:, None], T0.facet_labels[None, :]]
+        f1 = T1.cls_of[T1.cell_labels[:, None], T1.facet_labels[None, :]]
+        assert np.array_equal(f0, f1)
+    # not piecewise constant: refused
+    dm = P1_DoFMap(disc(2), PHYSICAL)
+    with pytest.raises(NotImplementedError):
+        nonlocalTables(dm, getFractionalKernel(2, lambdaFractionalOrder(2, 0.2, 0.8, True, lambda x, y: 0.5+0.1*(x[0]+y[0]), maxLabels=16)), {}, True)

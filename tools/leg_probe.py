@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """One bench leg, three repetitions, one line 'LEG <name> {json}' (device ms, phases, kernel ms, SURVEY 8(d) fraction of the fp64 peak).
-Used under rocprofv3 by tools/profile_legs.sh.   usage: leg_probe.py c3|c4|c5|c5big|p2|s04|big|head [noRef]"""
+Used under rocprofv3 by tools/profile_legs.sh.   usage: leg_probe.py c3|c4|c5|c5big|p2|s04|big|head [noRef] [serial]"""
 import json
 import os
 import sys
@@ -14,7 +14,12 @@ from pynucleus_amd.fractionalOrders import layersFractionalOrder
 import bench
 
 what = sys.argv[1]
-size = int(sys.argv[2]) if len(sys.argv) > 2 else None
+size = int(sys.argv[2]) if len(sys.argv) > 2 and sys.argv[2].isdigit() else None
+if 'serial' in sys.argv[2:]:
+    # one stream, one phase after the other: the per-kernel durations of a rocprofv3 trace then add up to the device time
+    from pynucleus_amd import _lib
+    _lib.set_option('PNL_NO_OVERLAP', 1)
+    _lib.set_option('PNL_NO_FORK', 1)
 PEAK = bench.FP64_VECTOR_PEAK_TFLOPS
 
 
