@@ -326,7 +326,7 @@ def test_gpu_getDense_trySparsification():
     zero_ratio = float((D.toarray() == 0.).mean())
     assert isinstance(S, CSR_LinearOperator if zero_ratio > 0.8 else Dense_LinearOperator)
     assert np.abs(S.toarray()-D.toarray()).max() <= 1e-13*np.abs(D.toarray()).max()
-    b = _gpu_sparse(33, 0.1, 'indicator', domain='interval')   # 1D: volume 2 (interval(-1, 1)): 0.4 > 0.1 -> sparse from the start
+    b = _gpu_sparse(6, 0.1, 'indicator', domain='interval')    # 1D, 64 cells on (-1, 1): volume 2, 0.4 > 0.1 -> sparse from the start
     S = b.getDense(trySparsification=True)
     assert isinstance(S, SSS_LinearOperator)
     assert np.abs(S.toarray()-b.getDense().toarray()).max() <= 1e-13
