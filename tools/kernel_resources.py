@@ -22,7 +22,7 @@ with tempfile.TemporaryDirectory() as tmp:
             rows.append([g('name'), g('vgpr_count'), g('agpr_count'), g('private_segment_fixed_size'), g('group_segment_fixed_size')])
         names = subprocess.run(['c++filt'], input='\n'.join(r[0] for r in rows), capture_output=True, text=True).stdout.split('\n')
         for d, r in zip(names, rows):
-            short = re.sub(r'\(.*', '', d).replace('void ', '').replace('(anonymous namespace)::', '')
+            short = re.sub(r'\(.*', '', d.replace('(anonymous namespace)::', '')).replace('void ', '')
             if want and not any(w in short for w in want):
                 continue
             print('{:14s} {:60s} vgpr {:>3s} agpr {:>3s} scratch {:>4s} B  static LDS {:>6s} B'.format(obj, short[:60], r[1], r[2], r[3], r[4]))
