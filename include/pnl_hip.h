@@ -473,7 +473,8 @@ typedef struct {
     /* kind 0: the dense operator A_dev.  kind 1 (the FINEST level only): the H2 operator currently set up in the context
      * (pnl_h2_setup): near field as full CSR (near_*_dev, n rows) + the far field through pnl_h2_matvec; A_dev is unused,
      * diag_dev = the diagonal of the near field.  The hierarchies of the reference's drivers put H2 operators on the fine
-     * levels (helpers.py:312-380 with matrixFormat 'H2'). */
+     * levels (helpers.py:312-380 with matrixFormat 'H2').  kind 2: the dense operator A_dev is SYMMETRIC and stored in full; its
+     * products read the upper triangle only (the two-sided sweep of pnl_gemv with symmetric_half = 2). */
     int32_t kind, pad2;
     const int32_t *near_indptr_dev, *near_indices_dev;
     const double *near_data_dev;

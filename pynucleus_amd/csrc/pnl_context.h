@@ -264,7 +264,8 @@ int pnl_pw_prepare(pnl_context *ctx, int need_boundary);
 int pnl_pw_h2_interp(pnl_context *ctx);
 
 // pnl_gemv2.hip: one pass over a row-major block for both A x and A^T x
-int pnl_launch_gemv_symmetric(pnl_context *ctx, const double *A, long long ldA, int n, const double *x, double *y);
+int pnl_launch_gemv_symmetric(pnl_context *ctx, const double *A, long long ldA, int n, const double *x, double alpha, double beta,
+                              const double *b, double *y);
 int pnl_launch_slab_two_sided(pnl_context *ctx, const double *slab, long long ld, int nrows, int ncols, const int *rowdof, const int *coldof,
                               const double *x, double *y);
 

@@ -44,7 +44,7 @@ __host__ __device__ inline long long g2_upper_blocks(int nrb, int ncb) {
 template <bool SLAB>
 __global__ void __launch_bounds__(PNL_NTHREADS, 4)
 k_gemv_two_sided(const double *__restrict__ S, long long ld, int nrows, int ncols, const int *__restrict__ rowdof,
-                 const int *__restrict__ coldof, const double *__restrict__ x, double *__restrict__ y) {
+                 const int *__restrict__ coldof, const double *__restrict__ x, double alpha, double *__restrict__ y) {
     __shared__ double s_row[4][G2_RB];
     int bi = blockIdx.y, ci = blockIdx.x;
     if (!SLAB) g2_upper_block(blockIdx.x, (ncols+G2_CB-1)/G2_CB, bi, ci);
@@ -117,22 +117,35 @@ k_gemv_two_sided(const double *__restrict__ S, long long ld, int nrows, int ncol
     // this wave owns its columns: their sums leave from registers
 #pragma unroll
     for (int k = 0; k < 16; k++)
-        if (J[k] >= 0 && cacc[k] != 0.) atomic_add_f64(&y[J[k]], cacc[k]);
+        if (J[k] >= 0 && cacc[k] != 0.) atomic_add_f64(&y[J[k]], alpha*cacc[k]);
     __syncthreads();
     if (tid < rend-r0) {
         const double s = (s_row[0][tid]+s_row[1][tid])+(s_row[2][tid]+s_row[3][tid]);
-        if (s != 0.) atomic_add_f64(&y[SLAB ? rowdof[r0+tid] : r0+tid], s);
+        if (s != 0.) atomic_add_f64(&y[SLAB ? rowdof[r0+tid] : r0+tid], alpha*s);
     }
+}
+
+// y = beta b  (b may be y)
+__global__ void __launch_bounds__(PNL_NTHREADS)
+k_g2_scaled_copy(int n, double beta, const double *b, double *y) {
+    const int i = blockIdx.x*PNL_NTHREADS+threadIdx.x;
+    if (i < n) y[i] = beta*b[i];
 }
 
 }  // namespace
 
-// y = A x for a symmetric matrix stored in full: reads the upper triangle only (y is zeroed here)
-int pnl_launch_gemv_symmetric(pnl_context *ctx, const double *A, long long ldA, int n, const double *x, double *y) {
-    HIPCHK(ctx, hipMemsetAsync(y, 0, sizeof(double)*(size_t)n, ctx->stream));
+// y = alpha A x + beta b for a symmetric matrix stored in full: reads the upper triangle only (b may be y or, with beta = 0, null;
+// x must not be y)
+int pnl_launch_gemv_symmetric(pnl_context *ctx, const double *A, long long ldA, int n, const double *x, double alpha, double beta,
+                              const double *b, double *y) {
+    if (beta == 0. || !b) HIPCHK(ctx, hipMemsetAsync(y, 0, sizeof(double)*(size_t)n, ctx->stream));
+    else if (!(b == y && beta == 1.)) {
+        hipLaunchKernelGGL(k_g2_scaled_copy, dim3((n+PNL_NTHREADS-1)/PNL_NTHREADS), dim3(PNL_NTHREADS), 0, ctx->stream, n, beta, b, y);
+        HIPCHK(ctx, hipGetLastError());
+    }
     const int nrb = (n+G2_RB-1)/G2_RB, ncb = (n+G2_CB-1)/G2_CB;
     hipLaunchKernelGGL((k_gemv_two_sided<false>), dim3((unsigned)g2_upper_blocks(nrb, ncb)), dim3(PNL_NTHREADS), 0, ctx->stream, A, ldA, n, n,
-                       (const int*)nullptr, (const int*)nullptr, x, y);
+                       (const int*)nullptr, (const int*)nullptr, x, alpha, y);
     HIPCHK(ctx, hipGetLastError());
     return PNL_OK;
 }
@@ -141,7 +154,7 @@ int pnl_launch_gemv_symmetric(pnl_context *ctx, const double *A, long long ldA, 
 int pnl_launch_slab_two_sided(pnl_context *ctx, const double *slab, long long ld, int nrows, int ncols, const int *rowdof, const int *coldof,
                               const double *x, double *y) {
     hipLaunchKernelGGL((k_gemv_two_sided<true>), dim3((ncols+G2_CB-1)/G2_CB, (nrows+G2_RB-1)/G2_RB), dim3(PNL_NTHREADS), 0, ctx->stream, slab, ld,
-                       nrows, ncols, rowdof, coldof, x, y);
+                       nrows, ncols, rowdof, coldof, x, 1., y);
     HIPCHK(ctx, hipGetLastError());
     return PNL_OK;
 }

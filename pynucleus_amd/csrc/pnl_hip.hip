@@ -3292,7 +3292,7 @@ int pnl_get_kernel_ms(pnl_context *ctx, float *out, int n) {
 int pnl_gemv(pnl_context *ctx, const double *A, int64_t ldA, int n, const double *x, double *y, int symmetric_half) {
     if (!ctx || !A || !x || !y || n <= 0 || ldA < n) return fail(ctx, PNL_ERR_INVALID, "bad gemv arguments");
     // 2: A is stored in full and is symmetric -- its upper triangle is read once for both A x and A^T x (4 n^2 bytes, pnl_gemv2.hip)
-    if (symmetric_half == 2) return pnl_launch_gemv_symmetric(ctx, A, (long long)ldA, n, x, y);
+    if (symmetric_half == 2) return pnl_launch_gemv_symmetric(ctx, A, (long long)ldA, n, x, 1., 0., nullptr, y);
     hipLaunchKernelGGL(k_gemv, dim3((n+3)/4), dim3(PNL_NTHREADS), 0, ctx->stream, A, (long long)ldA, n, x, y);
     HIPCHK(ctx, hipGetLastError());
     if (symmetric_half) {
@@ -3322,7 +3322,7 @@ int pnl_cg_jacobi(pnl_context *ctx, const double *A, int64_t ldA, int n, const d
     double hs[4];
     // solvers.pyx:363-444 with the Jacobi preconditioner (:229-245); convergence in the preconditioner norm
     // CG needs a symmetric operator: every product reads the upper triangle only (pnl_gemv2.hip; 4 n^2 bytes instead of 8 n^2)
-    auto gemv = [&](const double *v, double *out) { return pnl_launch_gemv_symmetric(ctx, A, (long long)ldA, n, v, out); };
+    auto gemv = [&](const double *v, double *out) { return pnl_launch_gemv_symmetric(ctx, A, (long long)ldA, n, v, 1., 0., nullptr, out); };
     hipLaunchKernelGGL(k_diag_inv, dim3(gv), dim3(PNL_NTHREADS), 0, st, A, (long long)ldA, n, dinv);
     if ((rc = gemv(x, Ap))) return rc;
     hipLaunchKernelGGL(k_cg_init, dim3(gv), dim3(PNL_NTHREADS), 0, st, b, (const double*)Ap, (const double*)dinv, n, r, p);

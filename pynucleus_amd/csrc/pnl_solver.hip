@@ -145,6 +145,7 @@ int apply_level(pnl_mg *mg, int l, const double *x, double alpha, double beta, c
     pnl_context *ctx = mg->ctx;
     const pnl_mg_level_desc &L = mg->lv[l];
     if (L.kind == 0) return gemv(ctx, L.A_dev, L.ldA, L.n, L.n, x, alpha, beta, b, y);
+    if (L.kind == 2) return pnl_launch_gemv_symmetric(ctx, L.A_dev, L.ldA, L.n, x, alpha, beta, b, y);
     double *t = (double*)mg->h2tmp.p;
     int rc;
     if ((rc = csr(ctx, L.n, L.near_indptr_dev, L.near_indices_dev, L.near_data_dev, x, 1., 0., t))) return rc;
@@ -228,9 +229,9 @@ int pnl_mg_create(pnl_context *ctx, int nlevels, const pnl_mg_level_desc *levels
         return ctx ? fail(ctx, PNL_ERR_INVALID, "pnl_mg_create: bad arguments") : PNL_ERR_INVALID;
     for (int l = 0; l < nlevels; l++) {
         const pnl_mg_level_desc &L = levels[l];
-        if (L.kind != 0 && !(L.kind == 1 && l == nlevels-1 && l > 0 && L.near_indptr_dev && L.near_indices_dev && L.near_data_dev && L.diag_dev))
+        if (L.kind != 0 && L.kind != 2 && !(L.kind == 1 && l == nlevels-1 && l > 0 && L.near_indptr_dev && L.near_indices_dev && L.near_data_dev && L.diag_dev))
             return fail(ctx, PNL_ERR_INVALID, "pnl_mg_create: level %d: an H2 operator (kind 1) is taken on the finest level only, with its near field", l);
-        if (L.n <= 0 || (l > 0 && L.kind == 0 && (!L.A_dev || !L.diag_dev || L.ldA < L.n)))
+        if (L.n <= 0 || (l > 0 && L.kind != 1 && (!L.A_dev || !L.diag_dev || L.ldA < L.n)))
             return fail(ctx, PNL_ERR_INVALID, "pnl_mg_create: level %d needs n > 0, the operator and its diagonal", l);
         if (l > 0 && (!L.R_indptr_dev || !L.R_indices_dev || !L.R_data_dev || !L.P_indptr_dev || !L.P_indices_dev || !L.P_data_dev))
             return fail(ctx, PNL_ERR_INVALID, "pnl_mg_create: level %d needs restriction and prolongation", l);
@@ -330,11 +331,12 @@ int pnl_mg_cg(pnl_mg *mg, const double *A_dev, int64_t ldA, const double *b_dev,
     const int top = mg->nlevels-1;
     const pnl_mg_level_desc &L = mg->lv[top];
     const bool h2top = !A_dev && L.kind == 1;
+    const bool own = !A_dev || (A_dev == L.A_dev && ldA == L.ldA);      // the finest level's own operator (it may be symmetric: kind 2)
     if (!A_dev) { A_dev = L.A_dev; ldA = L.ldA; }
     if (!h2top && (!A_dev || ldA < L.n)) return fail(ctx, PNL_ERR_INVALID, "pnl_mg_cg: no operator");
     const int n = L.n;
     auto applyA = [&](const double *x, double alpha, double beta, const double *b, double *y) -> int {
-        return h2top ? apply_level(mg, top, x, alpha, beta, b, y) : gemv(ctx, A_dev, ldA, n, n, x, alpha, beta, b, y);
+        return (h2top || (own && L.kind == 2)) ? apply_level(mg, top, x, alpha, beta, b, y) : gemv(ctx, A_dev, ldA, n, n, x, alpha, beta, b, y);
     };
     double *r = (double*)mg->r.p, *p = (double*)mg->p.p, *Ap = (double*)mg->Ap.p, *z = (double*)mg->z.p;
     int rc;

@@ -243,6 +243,10 @@ class multigrid:
             else:
                 d.A_dev = A.A.data_ptr()
                 d.ldA = A.A.stride(0)
+                # a symmetric dense level is applied from its upper triangle (half the HBM bytes); below 8192 rows the
+                # one-sided kernel's grid fills the chip better
+                if getattr(A, 'symmetric', False) and A.num_rows >= 8192:
+                    d.kind = 2
                 diag = torch.diagonal(A.A).contiguous().clone()
                 self._keep.append(diag)
             d.diag_dev = diag.data_ptr()
