@@ -295,6 +295,21 @@ __device__ __forceinline__ int quad_order_exact(const DevFormula &F, double h1, 
     return q1 > q2 ? q1 : q2;
 }
 
+// the fp32 evaluation alone: -1 where it is within 2e-4 of a change of the order (the caller then evaluates quad_order_exact)
+__device__ __forceinline__ int quad_order_try(const DevFormula &F, float lh1, float lh2, float L1, float L2, double d2) {
+    const float ld = 0.5f*0.69314718056f*__builtin_amdgcn_logf((float)d2);
+    const float logdh1 = ld-lh1, logdh2 = ld-lh2;
+    const float Lm = fmaxf(L1, L2);
+    const float n1 = F.clip ? fmaxf(logdh1, 0.f) : logdh1, n2 = F.clip ? fmaxf(logdh2, 0.f) : logdh2;
+    const float c0 = (float)F.c0, a = (float)F.a, b = (float)F.b, e = (float)F.e, den0 = (float)F.den0;
+    const float a1 = (c0+a*L2+b*Lm-e*n2)*__builtin_amdgcn_rcpf(fmaxf(logdh1, 0.f)+den0);
+    const float a2 = (c0+a*L1+b*Lm-e*n1)*__builtin_amdgcn_rcpf(fmaxf(logdh2, 0.f)+den0);
+    const float r1 = rintf(a1), r2 = rintf(a2);
+    const bool risky = (a1 > 1.5f && fabsf(a1-r1) < 2e-4f) || (a2 > 1.5f && fabsf(a2-r2) < 2e-4f) || !(a1 == a1) || !(a2 == a2);
+    const int q1 = (int)fmaxf(ceilf(a1), 2.f), q2 = (int)fmaxf(ceilf(a2), 2.f);
+    return risky ? -1 : (q1 > q2 ? q1 : q2);
+}
+
 __device__ __forceinline__ int quad_order_fast(const DevFormula &F, double h1, double h2, float lh1, float lh2,
                                                float L1, float L2, double Ld1, double Ld2, double d2) {
     const float ld = 0.5f*0.69314718056f*__builtin_amdgcn_logf((float)d2);

@@ -32,7 +32,7 @@ struct DevProblem {
     const double *cellv;        // [(dim+1)*dim][ncp] vertex coordinates of each cell
     const double *ccen;         // [dim][ncp] cell centres
     const double *cvol, *ch;    // [ncp]
-    const double *clog;         // [2][ncp]: ln h, |ln(h/H0)| (inputs of the order formula, FL2:622-642)
+    const double *clog;         // [3][ncp]: ln h, |ln(h/H0)| (inputs of the order formula, FL2:622-642), radius centre -- vertex
     const int *cvid;            // [dim+1][ncp] vertex ids (-1-l for padding cells)
     const int *cdof;            // [dpe][ncp] global DoF ids (negative = boundary / padding)
     const short *cslot;         // [dpe][ncp] slot of the DoF in its block's unique-DoF list (-1 if none)

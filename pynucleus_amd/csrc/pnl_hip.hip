@@ -347,8 +347,20 @@ int finalize(pnl_context *ctx) {
     if ((rc = upload(ctx, ctx->b_cvol, cvol.data(), cvol.size()))) return rc;
     if ((rc = upload(ctx, ctx->b_ch, ch.data(), ch.size()))) return rc;
     {
-        std::vector<double> clog((size_t)2*ncp, 0.);
+        std::vector<double> clog((size_t)3*ncp, 0.);
         for (int c = 0; c < ncp; c++) { clog[c] = std::log(ch[c]); clog[(size_t)ncp+c] = std::fabs(std::log(ch[c]/ctx->H0)); }
+        // third row: the largest distance centre -- vertex of the cell in mesh coordinates, rounded up.  Two cells that share a
+        // vertex have their centres within the sum of these radii: the tile kernels compare vertex ids only for such pairs
+        for (int c = 0; c < nc; c++) {
+            double r2 = 0.;
+            for (int k = 0; k < nV; k++) {
+                const int v = ctx->cells[(size_t)c*nV+k];
+                double t2 = 0.;
+                for (int d = 0; d < dim; d++) { const double t = ctx->vertices[(size_t)v*dim+d]-ccen[(size_t)d*ncp+c]; t2 += t*t; }
+                r2 = std::max(r2, t2);
+            }
+            clog[(size_t)2*ncp+c] = std::sqrt(r2)*(1.+1e-5);
+        }
         if ((rc = upload(ctx, ctx->b_clog, clog.data(), clog.size()))) return rc;
         // per-block aggregates for the host-side tile classification (uniform tiles)
         ctx->blocks.assign(nblocks, pnl_context::BlockAgg{0., 0., 0., 0., 0., 0., 0., false, 0., 0., 0.});

@@ -345,8 +345,8 @@ struct TileSmem {
     static constexpr int o_cnt = o_vid+2*NV*TILE;          // [PNL_MAXQ+2]
     static constexpr int o_cur = o_cnt+PNL_MAXQ+2;         // [PNL_MAXQ+2]
     static constexpr int o_misc = o_cur+PNL_MAXQ+2;        // [4]: list length, work-list base, #eligible buckets
-    static constexpr int o_el = o_misc+4;                  // [2][16]: order and list end of the populated eligible buckets
-    static constexpr int o_lh = o_el+32;                   // float [2][2][TILE]: ln h, |ln(h/H0)|
+    static constexpr int o_cf = o_misc+4;                  // int2 [2][TILE]: bit 0 real cell, bit 1 has a DoF; radius centre -- vertex (float)
+    static constexpr int o_lh = o_cf+4*TILE;               // float [2][2][TILE]: ln h, |ln(h/H0)|
     static constexpr int o_ttn = o_lh+4*TILE;          // [PNL_MAXQ+2] points of order q if the tile kernel integrates it, else 0
     static constexpr int o_tto = o_ttn+PNL_MAXQ+2;         // [PNL_MAXQ+2] its offset (points) in the table blob
     static constexpr int o_chunk = o_tto+PNL_MAXQ+2;       // [PNL_GEN_MAXCHUNKS] list C chunks: order << 20 | start << 7 | count-1
@@ -449,7 +449,8 @@ k_tile_distant(const DevProblem P, const int2 *__restrict__ tiles, double *__res
     short *s_short = (short*)(s_int+S::n_int);
     double *s_acc = (double*)(s_short+(S::n_short+3)/4*4);   // [nA][acc_stride]
     double *s_v = s_dbl+S::o_v, *s_cen = s_dbl+S::o_cen, *s_vol = s_dbl+S::o_vol, *s_h = s_dbl+S::o_h, *s_D = s_dbl+S::o_D;
-    int *s_vid = s_int+S::o_vid, *s_cnt = s_int+S::o_cnt, *s_cur = s_int+S::o_cur, *s_misc = s_int+S::o_misc, *s_el = s_int+S::o_el;
+    int *s_vid = s_int+S::o_vid, *s_cnt = s_int+S::o_cnt, *s_cur = s_int+S::o_cur, *s_misc = s_int+S::o_misc;
+    int2 *s_cf = (int2*)(s_int+S::o_cf);
     short *s_slot = s_short+S::o_slot;
     unsigned short *s_list = (unsigned short*)(s_short+S::o_list);
     float *s_lh = (float*)(s_int+S::o_lh);
@@ -509,14 +510,23 @@ k_tile_distant(const DevProblem P, const int2 *__restrict__ tiles, double *__res
         s_Ld[side*TILE+l] = Ld;
         s_lh[(side*2+0)*TILE+l] = (float)lh;
         s_lh[(side*2+1)*TILE+l] = (float)Ld;
+        int vid0 = -1;
 #pragma unroll
-        for (int k = 0; k < NV; k++) s_vid[(side*NV+k)*TILE+l] = real ? P.cvid[(size_t)k*P.ncp+c] : -1-k;
+        for (int k = 0; k < NV; k++) {
+            const int v = real ? P.cvid[(size_t)k*P.ncp+c] : -1-k;
+            s_vid[(side*NV+k)*TILE+l] = v;
+            vid0 = k == 0 ? v : vid0;
+        }
+        bool has_dof = false;
 #pragma unroll
         for (int k = 0; k < DPE; k++) {
             // boundary DoFs (no slot) are sent to a trash row / column of the LDS sub-block: no branches in the hot loop
             const short sl = CLUSTER ? (real ? CT.chunk_slot[((size_t)(side ? tb : ta)*DPE+k)*TILE+l] : (short)-1) : P.cslot[(size_t)k*P.ncp+c];
             s_slot[(side*DPE+k)*TILE+l] = sl >= 0 ? sl : (short)(side ? nB : nA);
+            has_dof = has_dof || sl >= 0;
         }
+        // what the classification reads per cell: one 8-byte word (padding and volume-zero cells carry negative vertex ids)
+        s_cf[side*TILE+l] = make_int2((vid0 >= 0 ? 1 : 0) | (has_dof ? 2 : 0), __float_as_int((float)P.clog[2*(size_t)P.ncp+c]));
     }
     for (int t = tid; t < (nA+1)*acc_stride; t += NT) s_acc[t] = 0.;
     for (int t = tid; t < 2*TILE*ND; t += NT) s_D[t] = 0.;
@@ -536,36 +546,60 @@ k_tile_distant(const DevProblem P, const int2 *__restrict__ tiles, double *__res
     const int lane = tid & 63;
     const unsigned long long lt = (1ull << lane)-1ull;
     int cnt234[3] = {0, 0, 0};
+    // The workgroup size is a multiple of the tile edge: a thread keeps its cell j of block b for the whole tile, so what depends
+    // on j alone is read once.  Two passes: the first computes (list, order key) of every pair of the thread -- 16 bits each, kept
+    // in registers -- and counts the wave's pairs per list on the scalar unit; then ONE reservation per wave and list (instead
+    // of one returning LDS atomic per list and 64 pairs), and the second pass writes the entries.  Vertex ids are compared only
+    // where the centres are within the sum of the two radii (a handful of pairs per tile away from the diagonal).
+    static_assert(NT%TILE == 0 && PAIRS%NT == 0 && PER_THREAD <= 16, "tile workgroup: whole rows of the tile per sweep");
+    constexpr int ROWS = NT/TILE, NG = (PER_THREAD+3)/4;
+    const int j = tid%TILE, row0 = tid/TILE;
+    double cenb[DIM];
+#pragma unroll
+    for (int d = 0; d < DIM; d++) cenb[d] = s_cen[(1*DIM+d)*TILE+j];
+    const int2 cfb = s_cf[TILE+j];
+    const float lhb = s_lh[2*TILE+j], Llb = s_lh[3*TILE+j];
+    const int labb = (!CLUSTER && P.cur_class >= 0) ? P.clabel[tb*TILE+j] : 0;
+    int nw0 = 0, nw1 = 0, nw2 = 0, nw3 = 0;                // this wave's pairs in list A, list B, the far list, list C
+    unsigned long long recs[NG];
+#pragma unroll
+    for (int g = 0; g < NG; g++) {
+    recs[g] = 0ull;
 #pragma unroll 2
-    for (int it = 0; it < PER_THREAD; it++) {
-        const int praw = it*NT+tid;
-        const bool inside = (PAIRS%NT == 0) || praw < PAIRS;
-        const int p = inside ? praw : 0;
-        const int j = p%TILE, i = (p/TILE+PNL_DIAG_MULT*j)%TILE;
+    for (int it4 = 0; it4 < (PER_THREAD-4*g < 4 ? PER_THREAD-4*g : 4); it4++) {
+        const int r = (4*g+it4)*ROWS+row0;
+        const int i = (r+PNL_DIAG_MULT*j)%TILE;
         int q = 0, fkey = 0;
-        const int va0 = s_vid[(0*NV+0)*TILE+i], vb0 = s_vid[(1*NV+0)*TILE+j];
+        const int2 cfa = s_cf[i];
         const int ca = ta*TILE+i;
         // dense: upper triangle of the cell pairs, a-cells of the caller's range.  Cluster tiles: n1 == n2 -> unordered pairs
         // once (chunk pair a <= b); n1 != n2 -> every ordered pair (X in n1.cells, Y in n2.cells); identical cells share all
         // vertices and are left to the touching-pair lists like every other touching pair
-        bool ok = inside && (va0 >= 0) && (vb0 >= 0) && !(abl & 8) &&
+        bool ok = (cfa.x & cfb.x & 1) && !(abl & 8) &&
                   (CLUSTER ? (!sym || ta < tb || i < j) : ((ta < tb || i < j || (fh && i == j)) && (ca >= cell_begin) && (ca < cell_end)));
         // variable order: this launch assembles the pairs of one order class only
         if (!CLUSTER && P.cur_class >= 0 && ok) {
-            const int la = P.clabel[ca], lb = P.clabel[tb*TILE+j];
-            ok = P.cls_of[P.orient ? lb*P.nlab+la : la*P.nlab+lb] == P.cur_class;
+            const int la = P.clabel[ca];
+            ok = P.cls_of[P.orient ? labb*P.nlab+la : la*P.nlab+labb] == P.cur_class;
         }
         if (ok) {
             // NA:138-150: skip pairs with boundary DoFs only;  NO:311-323: shared vertices -> singular pair
-            bool any_dof = false, shared = false;
+            const bool any_dof = ((cfa.x | cfb.x) & 2) != 0;
+            double d2 = 0.;
 #pragma unroll
-            for (int k = 0; k < DPE; k++)
-                any_dof = any_dof || (s_slot[(0*DPE+k)*TILE+i] < nA) || (s_slot[(1*DPE+k)*TILE+j] < nB);
+            for (int d = 0; d < DIM; d++) {
+                const double t = s_cen[(0*DIM+d)*TILE+i]-cenb[d];
+                d2 += t*t;
+            }
+            bool shared = false;
+            const float rs = __int_as_float(cfa.y)+__int_as_float(cfb.y);
+            if ((float)d2 <= rs*rs) {
 #pragma unroll
-            for (int k = 0; k < NV; k++) {
-                const int va = s_vid[(0*NV+k)*TILE+i];
+                for (int k = 0; k < NV; k++) {
+                    const int va = s_vid[(0*NV+k)*TILE+i];
 #pragma unroll
-                for (int m = 0; m < NV; m++) shared = shared || (va == s_vid[(1*NV+m)*TILE+j]);
+                    for (int m = 0; m < NV; m++) shared = shared || (va == s_vid[(1*NV+m)*TILE+j]);
+                }
             }
             // finite horizon (getSparse): REMOTE pairs are dropped, pairs CUT by the horizon and touching pairs go to the
             // sorted sparse pipeline through the far list (keys order + PNL_CUT_SHIFT / 121 + shared vertices - 1, like
@@ -587,15 +621,11 @@ k_tile_distant(const DevProblem P, const int2 *__restrict__ tiles, double *__res
                 }
             }
             if (any_dof && !shared && rel != PNL_REMOTE) {
-                double d2 = 0.;
-#pragma unroll
-                for (int d = 0; d < DIM; d++) {
-                    const double t = s_cen[(0*DIM+d)*TILE+i]-s_cen[(1*DIM+d)*TILE+j];
-                    d2 += t*t;
-                }
                 if (abl & 16) q = 2;
-                else q = quad_order_fast(P.qo, s_h[i], s_h[TILE+j], s_lh[i], s_lh[2*TILE+j], s_lh[TILE+i], s_lh[3*TILE+j],
-                                         s_Ld[i], s_Ld[TILE+j], d2);
+                else {
+                    q = quad_order_try(P.qo, s_lh[i], lhb, s_lh[TILE+i], Llb, d2);
+                    if (q < 0) q = quad_order_exact(P.qo, s_h[i], s_h[TILE+j], s_Ld[i], s_Ld[TILE+j], sqrt(d2));
+                }
                 if (q > P.qmax || q > PNL_MAXQ) { overflow++; q = 0; }
                 else if (rel == PNL_CUT) {
                     if (q > PNL_CUT_SHIFT || P.off[q+1]-P.off[q] > PNL_WL_LANE_MAXPTS) { overflow++; q = 0; }
@@ -609,41 +639,52 @@ k_tile_distant(const DevProblem P, const int2 *__restrict__ tiles, double *__res
         const int key = fkey ? fkey : q;
         const int cls = !key ? 0 : (fkey ? 4 : (q == qA0 ? 1 : (q == qB0 ? 2 : (nq > 0 ? 3 : 4))));
         const int qs = (fh && cls == 4) ? 0 : q;         // finite horizon: the sparse pipeline counts what it is handed
+        if (!(abl & 32)) {
         cnt234[0] += __popcll(__ballot(qs == 2)); cnt234[1] += __popcll(__ballot(qs == 3)); cnt234[2] += __popcll(__ballot(qs == 4));
         wave_bucket_add(s_cnt, qs > 4 ? qs : 0, false);
-        const unsigned short ent = (unsigned short)(p | ((q-2) << 12));
-        // one returning atomic per class and wave
-        const unsigned long long mA = __ballot(cls == 1), mB = __ballot(cls == 2), mC = __ballot(cls == 3), mF = __ballot(cls == 4);
-        if (mC) {
-            int base = 0;
-            const int leader = __ffsll((long long)mC)-1;
-            if (lane == leader) base = atomicAdd(&s_misc[3], __popcll(mC));
-            base = __builtin_amdgcn_readlane(base, leader);
-            if (cls == 3) s_list[PAIRS-1-(base+__popcll(mC & lt))] = ent;
         }
-        if (mA) {
-            int base = 0;
-            const int leader = __ffsll((long long)mA)-1;
-            if (lane == leader) base = atomicAdd(&s_misc[0], __popcll(mA));
-            base = __builtin_amdgcn_readlane(base, leader);
-            if (cls == 1) s_list[base+__popcll(mA & lt)] = ent;
-        }
-        if (mB) {
-            int base = 0;
-            const int leader = __ffsll((long long)mB)-1;
-            if (lane == leader) base = atomicAdd(&s_misc[1], __popcll(mB));
-            base = __builtin_amdgcn_readlane(base, leader);
-            if (cls == 2) s_l32[base+__popcll(mB & lt)] = ent;
-        }
-        if (mF) {
-            int base = 0;
-            const int leader = __ffsll((long long)mF)-1;
-            if (lane == leader) base = atomicAdd(&s_misc[2], __popcll(mF));
-            base = __builtin_amdgcn_readlane(base, leader);
-            // finite horizon: cut pairs whose order has a packed rule are integrated in this tile (bit 20), not exported
-            if (cls == 4) s_l32[PAIRS-1-(base+__popcll(mF & lt))] = p | (key << 12) |
-                                                                    ((fh && fkey > PNL_CUT_SHIFT+1 && fkey < 121 && nq > 0) ? (1 << 20) : 0);
-        }
+        nw0 += __popcll(__ballot(cls == 1)); nw1 += __popcll(__ballot(cls == 2));
+        nw2 += __popcll(__ballot(cls == 4)); nw3 += __popcll(__ballot(cls == 3));
+        // finite horizon: cut pairs whose order has a packed rule are integrated in this tile (bit 11 -> bit 20 of the entry)
+        const unsigned rec = (unsigned)cls | ((unsigned)key << 3) | ((fh && fkey > PNL_CUT_SHIFT+1 && fkey < 121 && nq > 0) ? (1u << 11) : 0u);
+        recs[g] |= (unsigned long long)rec << (16*it4);
+    }
+    }
+    {
+        int mybase = 0;
+        const int mine = lane == 0 ? nw0 : (lane == 1 ? nw1 : (lane == 2 ? nw2 : nw3));
+        if (lane < 4 && mine) mybase = atomicAdd(&s_misc[lane], mine);
+        int bA = __builtin_amdgcn_readlane(mybase, 0), bB = __builtin_amdgcn_readlane(mybase, 1);
+        int bF = __builtin_amdgcn_readlane(mybase, 2), bC = __builtin_amdgcn_readlane(mybase, 3);
+        if (!(abl & 128))
+#pragma unroll
+        for (int g = 0; g < NG; g++)
+#pragma unroll
+            for (int it4 = 0; it4 < (PER_THREAD-4*g < 4 ? PER_THREAD-4*g : 4); it4++) {
+                const unsigned rec = (unsigned)(recs[g] >> (16*it4)) & 0xffffu;
+                const int cls = rec & 7, key = (rec >> 3) & 255;
+                const int p = ((4*g+it4)*ROWS+row0)*TILE+j;
+                if (nw0) {
+                    const unsigned long long m = __ballot(cls == 1);
+                    if (cls == 1) s_list[bA+__popcll(m & lt)] = (unsigned short)(p | ((qA0-2) << 12));
+                    bA += __popcll(m);
+                }
+                if (nw1) {
+                    const unsigned long long m = __ballot(cls == 2);
+                    if (cls == 2) s_l32[bB+__popcll(m & lt)] = p | ((qB0-2) << 12);
+                    bB += __popcll(m);
+                }
+                if (nw3) {
+                    const unsigned long long m = __ballot(cls == 3);
+                    if (cls == 3) s_list[PAIRS-1-(bC+__popcll(m & lt))] = (unsigned short)(p | ((key-2) << 12));
+                    bC += __popcll(m);
+                }
+                if (nw2) {
+                    const unsigned long long m = __ballot(cls == 4);
+                    if (cls == 4) s_l32[PAIRS-1-(bF+__popcll(m & lt))] = p | (key << 12) | ((rec & (1u << 11)) ? (1 << 20) : 0);
+                    bF += __popcll(m);
+                }
+            }
     }
     if (overflow) atomicAdd(&P.counters[5], (unsigned long long)overflow);
     if (lane == 0) {
@@ -654,6 +695,21 @@ k_tile_distant(const DevProblem P, const int2 *__restrict__ tiles, double *__res
     // next tile of this workgroup (every thread has read the previous value before the barrier above; the barrier at the end
     // of the tile publishes this one)
     if (tid == 0) s_tile_next = (int)(gridDim.x+atomicAdd(tile_ctr, 1u));
+    // list C: counting sort by order into the free middle of the 32-bit list (behind list B, before the far list), chunks of 64
+    // pairs of ONE order, highest order first.  s_cnt[0] = number of these chunks, s_cnt[1] = the chunk queue of the evaluation
+    const int nC = __builtin_amdgcn_readfirstlane(s_misc[3]), nBl = __builtin_amdgcn_readfirstlane(s_misc[1]);
+    if (nC && tid == 64 && !(abl & 2)) {
+        int run = 0, nch = 0;
+        for (int q = min(17, P.qmax); q >= 2; q--) {
+            const int nq = s_ttn[q], c = s_cnt[q];
+            if (!c || nq == 0 || q == qA0 || q == qB0) continue;
+            s_cur[q] = run;
+            for (int st = 0; st < c && nch < PNL_GEN_MAXCHUNKS; st += 64) s_chunk[nch++] = (q << 20) | ((run+st) << 7) | (min(64, c-st)-1);
+            run += c;
+        }
+        s_cnt[0] = nch;
+    }
+    bool published = false;                                // has a barrier followed the chunk table (workgroup-uniform)
     {
         // far pairs: one reservation in the global work list per tile, then a coalesced copy
         const int nF = s_misc[2];
@@ -685,6 +741,7 @@ k_tile_distant(const DevProblem P, const int2 *__restrict__ tiles, double *__res
         } else if (nF) {
             if (tid == 0) s_cur[0] = (int)atomicAdd(wl_count, (unsigned)nF);
             __syncthreads();
+            published = true;
             const unsigned base = (unsigned)s_cur[0];
             for (int t = tid; t < nF; t += NT) {
                 const int ent = s_l32[PAIRS-1-t];
@@ -759,79 +816,62 @@ k_tile_distant(const DevProblem P, const int2 *__restrict__ tiles, double *__res
             }
         }
     };
-    if (!(abl & 2))
-    kern_dispatch<KT, fh>(P.k, lpow, [&](auto ktag) {
-    constexpr int KTE = decltype(ktag)::value;              // KT, or 3: the branch-free general power (pnl_common.h)
-#pragma unroll 1
-    for (int pass = 0; pass < 2; pass++) {
-        const int total = __builtin_amdgcn_readfirstlane(s_misc[pass]);
-#pragma unroll 1
-        for (int c0 = wave*64; c0 < total; c0 += NT) {
-            const int idx = c0+lane;
-            const bool act = idx < total;
-            const int ent = act ? (pass == 0 ? (int)s_list[idx] : s_l32[idx]) : 0;
-            const int p = ent & 4095;
-            const int j = p%TILE, i = (p/TILE+PNL_DIAG_MULT*j)%TILE;
-            const int q = pass == 0 ? qA0 : qB0, to = __builtin_amdgcn_readfirstlane(s_tto[q]);
-            const double *tab = s_tt+to*(4+DPE);
-            const double *__restrict__ gwp = P.tt_wphi+to*DPE;
-            double av[NC], bv[NC];
-#pragma unroll
-            for (int k = 0; k < NC; k++) { av[k] = s_v[(0*NC+k)*TILE+i]; bv[k] = s_v[(1*NC+k)*TILE+j]; }
-            PairAcc<DIM, DPE> R;
-            R.clear();
-            if (!act) continue;
-            if (pass == 0) eval_distant_fixed<DIM, DPE, KTE, NA>(P, tab, gwp, av, bv, R, lpow);
-            else eval_distant_fixed<DIM, DPE, KTE, NB>(P, tab, gwp, av, bv, R, lpow);
-            accumulate(R, i, j);
-        }
-    }
-    });
-    // ---- list C: counting sort by order into the (now free) storage of list B, then 64 pairs of one order per wave ----
-    const int nC = s_misc[3];
     if (nC && !(abl & 2)) {
-        __syncthreads();
-        if (tid == 0) {
-            int run = 0, nch = 0;
-            for (int q = 2; q < 18 && q <= P.qmax; q++) {
-                const int nq = s_ttn[q], c = s_cnt[q];
-                if (!c || nq == 0 || q == qA0 || q == qB0) continue;
-                s_cur[q] = run;
-                for (int st = 0; st < c && nch < PNL_GEN_MAXCHUNKS; st += 64) s_chunk[nch++] = (q << 20) | ((run+st) << 7) | (min(64, c-st)-1);
-                run += c;
-            }
-            s_misc[0] = nch;
-        }
-        __syncthreads();
+        if (!published) __syncthreads();
         for (int t = tid; t < nC; t += NT) {
             const int ent = s_list[PAIRS-1-t];
             const int q = (ent >> 12)+2;
-            s_l32[atomicAdd(&s_cur[q], 1)] = ent & 4095;
+            s_l32[nBl+atomicAdd(&s_cur[q], 1)] = ent & 4095;
         }
         __syncthreads();
-        const int nch = __builtin_amdgcn_readfirstlane(s_misc[0]);
-        kern_dispatch<KT, fh>(P.k, lpow, [&](auto ktag) {
-        constexpr int KTE = decltype(ktag)::value;
-#pragma unroll 1
-        for (int ch = wave; ch < nch; ch += NT/64) {
-            const int desc = __builtin_amdgcn_readfirstlane(s_chunk[ch]);
-            const int q = desc >> 20, start = (desc >> 7) & 8191, cnt = (desc & 127)+1;
-            const bool act = lane < cnt;
-            const int p = s_l32[start+(act ? lane : 0)];
-            const int j = p%TILE, i = (p/TILE+PNL_DIAG_MULT*j)%TILE;
-            double av[NC], bv[NC];
-#pragma unroll
-            for (int k = 0; k < NC; k++) { av[k] = s_v[(0*NC+k)*TILE+i]; bv[k] = s_v[(1*NC+k)*TILE+j]; }
-            PairAcc<DIM, DPE> R;
-            R.clear();
-            const int nq = __builtin_amdgcn_readfirstlane(s_ttn[q]), to = __builtin_amdgcn_readfirstlane(s_tto[q]);
-            if (nq == NB) eval_distant_fixed<DIM, DPE, KTE, NB>(P, s_tt+to*(4+DPE), P.tt_wphi+to*DPE, av, bv, R, lpow);
-            else if (nq == NA) eval_distant_fixed<DIM, DPE, KTE, NA>(P, s_tt+to*(4+DPE), P.tt_wphi+to*DPE, av, bv, R, lpow);
-            else eval_distant_lds<DIM, DPE, KTE>(P, s_tt+to*(4+DPE), 4+DPE, nq, av, bv, R, lpow);
-            if (act) accumulate(R, i, j);
-        }
-        });
     }
+    // One queue of 64-pair chunks for the three lists, the expensive ones first (list C from its highest order down, then list B,
+    // then list A); a wave takes the next chunk when it is done with its last one -- no barrier between the lists, and the few
+    // chunks of high orders no longer decide when the tile ends
+    if (!(abl & 2))
+    kern_dispatch<KT, fh>(P.k, lpow, [&](auto ktag) {
+    constexpr int KTE = decltype(ktag)::value;              // KT, or 3: the branch-free general power (pnl_common.h)
+    const int nAl = __builtin_amdgcn_readfirstlane(s_misc[0]);
+    const int nchC = nC ? __builtin_amdgcn_readfirstlane(s_cnt[0]) : 0, nchB = (nBl+63) >> 6, nchA = (nAl+63) >> 6;
+    const int total = nchC+nchB+nchA;
+#pragma unroll 1
+    for (;;) {
+        int c = 0;
+        if (lane == 0) c = atomicAdd(&s_cnt[1], 1);
+        c = __builtin_amdgcn_readfirstlane(c);
+        if (c >= total) break;
+        int q, p;
+        bool act;
+        if (c < nchC) {
+            const int desc = __builtin_amdgcn_readfirstlane(s_chunk[c]);
+            const int start = (desc >> 7) & 8191, cnt = (desc & 127)+1;
+            q = desc >> 20;
+            act = lane < cnt;
+            p = s_l32[nBl+start+(act ? lane : 0)];
+        } else if (c < nchC+nchB) {
+            const int idx = (c-nchC)*64+lane;
+            q = qB0;
+            act = idx < nBl;
+            p = s_l32[act ? idx : 0] & 4095;
+        } else {
+            const int idx = (c-nchC-nchB)*64+lane;
+            q = qA0;
+            act = idx < nAl;
+            p = (int)s_list[act ? idx : 0] & 4095;
+        }
+        const int j = p%TILE, i = (p/TILE+PNL_DIAG_MULT*j)%TILE;
+        double av[NC], bv[NC];
+#pragma unroll
+        for (int k = 0; k < NC; k++) { av[k] = s_v[(0*NC+k)*TILE+i]; bv[k] = s_v[(1*NC+k)*TILE+j]; }
+        PairAcc<DIM, DPE> R;
+        R.clear();
+        const int nq = __builtin_amdgcn_readfirstlane(s_ttn[q]), to = __builtin_amdgcn_readfirstlane(s_tto[q]);
+        if (nq == NB) eval_distant_fixed<DIM, DPE, KTE, NB>(P, s_tt+to*(4+DPE), P.tt_wphi+to*DPE, av, bv, R, lpow);
+        else if (nq == NA) eval_distant_fixed<DIM, DPE, KTE, NA>(P, s_tt+to*(4+DPE), P.tt_wphi+to*DPE, av, bv, R, lpow);
+        else eval_distant_lds<DIM, DPE, KTE>(P, s_tt+to*(4+DPE), 4+DPE, nq, av, bv, R, lpow);
+        if (act) accumulate(R, i, j);
+    }
+    });
     if (fh) {
         // ---- pairs cut by the horizon whose order has a packed rule: sub-simplex loops (eval_distant NO:790-847), one pair
         // per lane, into the same LDS sub-block; the far list still holds them (bit 20)
