@@ -339,6 +339,11 @@ __device__ __forceinline__ void slot_store2(double *p, double x, double y) {
     if (PNL_SLOT_NT) __builtin_nontemporal_store(v, (pnl_d2*)p); else *(pnl_d2*)p = v;
 }
 
+// workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every global atomic / store of the wave
+// (s_waitcnt vmcnt(0)): the flush of a tile would have to retire before the next tile may start.  The tile kernels below
+// never read global memory that the same launch writes, so their barriers only have to order the LDS.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // hardware fp64 adds (global_atomic_add_f64 / ds_add_f64, no CAS loop); built with -munsafe-fp-atomics
 __device__ __forceinline__ void atomic_add_f64(double *p, double v) {
     (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -279,6 +279,6 @@ int pnl2_fold_mirror(pnl_context *ctx, const SlotOut &SO, double *A, int64_t ldA
 inline SlotOut slot_out(const pnl_context *ctx) {
     SlotOut SO;
     SO.A2 = (double*)ctx->b_slotA.p; SO.rowoff = (const long long*)ctx->b_srowoff.p; SO.colbase = (const int*)ctx->b_scolbase.p;
-    SO.S = ctx->slot_S; SO.pad = 0;
+    SO.S = ctx->slot_S; SO.nU = ctx->nU;
     return SO;
 }

@@ -131,5 +131,5 @@ struct SlotOut {
     double *A2;                 // block-slot storage (nullptr: flush with atomics into A)
     const long long *rowoff;    // [nblocks]
     const int *colbase;         // [nblocks+1], multiples of 8
-    int S, pad;
+    int S, nU;                  // nU: the largest number of DoFs of a block (rows of the LDS sub-block of the tile kernels)
 };

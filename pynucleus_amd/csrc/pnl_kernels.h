@@ -482,13 +482,10 @@ k_tile_distant(const DevProblem P, const int2 *__restrict__ tiles, double *__res
     // persistent workgroups: the first tile by block index, every further one from a global counter (heavy tiles come first in
     // the list and tile costs differ by an order of magnitude: a static stride leaves 14 % of the wave slots idle at the end)
     __shared__ int s_tile_next;
-#pragma unroll 1
-    for (int tile_idx = blockIdx.x; tile_idx < ntiles; tile_idx = s_tile_next) {
-    // dense: (block a, block b) of consecutive cells; cluster tiles: (chunk of n1.cells, chunk of n2.cells) of a cluster pair
+    // cell data of both blocks of a tile -> LDS
+    auto stage = [&](int tile_idx) {
     const int ta = CLUSTER ? CT.chunkA[tile_idx] : tiles[tile_idx].x, tb = CLUSTER ? CT.chunkB[tile_idx] : tiles[tile_idx].y;
     const int nA = CLUSTER ? CT.chunk_ndof[ta] : P.blk_ndof[ta], nB = CLUSTER ? CT.chunk_ndof[tb] : P.blk_ndof[tb];
-    const bool sym = CLUSTER ? (CT.flags[tile_idx] & 1) != 0 : true;
-
     // ---- stage cell data of both blocks in LDS (SoA: conflict-free per-lane reads) -------------
     for (int t = tid; t < 2*TILE; t += NT) {
         const int side = t/TILE, l = t%TILE;
@@ -528,10 +525,30 @@ k_tile_distant(const DevProblem P, const int2 *__restrict__ tiles, double *__res
         // what the classification reads per cell: one 8-byte word (padding and volume-zero cells carry negative vertex ids)
         s_cf[side*TILE+l] = make_int2((vid0 >= 0 ? 1 : 0) | (has_dof ? 2 : 0), __float_as_int((float)P.clog[2*(size_t)P.ncp+c]));
     }
-    for (int t = tid; t < (nA+1)*acc_stride; t += NT) s_acc[t] = 0.;
-    for (int t = tid; t < 2*TILE*ND; t += NT) s_D[t] = 0.;
-    for (int t = tid; t < 2*(PNL_MAXQ+2)+4; t += NT) s_cnt[t] = 0;    // s_cnt, s_cur and s_misc are adjacent
-    __syncthreads();
+    };
+    // Dense tiles into the block-slot storage run as a software pipeline: the cell data of the NEXT tile is staged before the flush
+    // of this one is issued (a load issued behind the stores would wait for all of them), the flush zeroes the accumulators it has
+    // read, and the barriers order the LDS only -- no wave waits for the stores of a tile to retire.
+    const bool pipe = !CLUSTER && !fh && SO.A2 != nullptr && !(abl & 256);
+    if (pipe) {
+        for (int t = tid; t < (SO.nU+1)*acc_stride; t += NT) s_acc[t] = 0.;
+        for (int t = tid; t < 2*TILE*ND; t += NT) s_D[t] = 0.;
+        for (int t = tid; t < 2*(PNL_MAXQ+2)+4; t += NT) s_cnt[t] = 0;
+        if ((int)blockIdx.x < ntiles) stage(blockIdx.x);
+    }
+#pragma unroll 1
+    for (int tile_idx = blockIdx.x; tile_idx < ntiles; tile_idx = s_tile_next) {
+    // dense: (block a, block b) of consecutive cells; cluster tiles: (chunk of n1.cells, chunk of n2.cells) of a cluster pair
+    const int ta = CLUSTER ? CT.chunkA[tile_idx] : tiles[tile_idx].x, tb = CLUSTER ? CT.chunkB[tile_idx] : tiles[tile_idx].y;
+    const int nA = CLUSTER ? CT.chunk_ndof[ta] : P.blk_ndof[ta], nB = CLUSTER ? CT.chunk_ndof[tb] : P.blk_ndof[tb];
+    const bool sym = CLUSTER ? (CT.flags[tile_idx] & 1) != 0 : true;
+    if (!pipe) {
+        stage(tile_idx);
+        for (int t = tid; t < (nA+1)*acc_stride; t += NT) s_acc[t] = 0.;
+        for (int t = tid; t < 2*TILE*ND; t += NT) s_D[t] = 0.;
+        for (int t = tid; t < 2*(PNL_MAXQ+2)+4; t += NT) s_cnt[t] = 0;    // s_cnt, s_cur and s_misc are adjacent
+    }
+    lds_barrier();
 
     // ---- classification ------------------------------------------------------------------------
     // pair p -> (i, j) along wrapped diagonals: consecutive lanes get distinct a-cells AND distinct
@@ -691,10 +708,11 @@ k_tile_distant(const DevProblem P, const int2 *__restrict__ tiles, double *__res
 #pragma unroll
         for (int k = 0; k < 3; k++) if (cnt234[k]) atomicAdd(&s_cnt[2+k], cnt234[k]);
     }
-    __syncthreads();
+    lds_barrier();
     // next tile of this workgroup (every thread has read the previous value before the barrier above; the barrier at the end
     // of the tile publishes this one)
-    if (tid == 0) s_tile_next = (int)(gridDim.x+atomicAdd(tile_ctr, 1u));
+    int next_tile = 0;                                    // asked for here, published behind the evaluation: the counter's latency is hidden
+    if (tid == 0) next_tile = (int)(gridDim.x+atomicAdd(tile_ctr, 1u));
     // list C: counting sort by order into the free middle of the 32-bit list (behind list B, before the far list), chunks of 64
     // pairs of ONE order, highest order first.  s_cnt[0] = number of these chunks, s_cnt[1] = the chunk queue of the evaluation
     const int nC = __builtin_amdgcn_readfirstlane(s_misc[3]), nBl = __builtin_amdgcn_readfirstlane(s_misc[1]);
@@ -740,7 +758,7 @@ k_tile_distant(const DevProblem P, const int2 *__restrict__ tiles, double *__res
             }
         } else if (nF) {
             if (tid == 0) s_cur[0] = (int)atomicAdd(wl_count, (unsigned)nF);
-            __syncthreads();
+            lds_barrier();
             published = true;
             const unsigned base = (unsigned)s_cur[0];
             for (int t = tid; t < nF; t += NT) {
@@ -817,13 +835,13 @@ k_tile_distant(const DevProblem P, const int2 *__restrict__ tiles, double *__res
         }
     };
     if (nC && !(abl & 2)) {
-        if (!published) __syncthreads();
+        if (!published) lds_barrier();
         for (int t = tid; t < nC; t += NT) {
             const int ent = s_list[PAIRS-1-t];
             const int q = (ent >> 12)+2;
             s_l32[nBl+atomicAdd(&s_cur[q], 1)] = ent & 4095;
         }
-        __syncthreads();
+        lds_barrier();
     }
     // One queue of 64-pair chunks for the three lists, the expensive ones first (list C from its highest order down, then list B,
     // then list A); a wave takes the next chunk when it is done with its last one -- no barrier between the lists, and the few
@@ -907,9 +925,40 @@ k_tile_distant(const DevProblem P, const int2 *__restrict__ tiles, double *__res
         }
         if (ncutp) { atomicAdd(&P.counters[1], ncutp); atomicAdd(&P.counters[2], ncute); }
     }
-    __syncthreads();
+    if (tid == 0) s_tile_next = next_tile;
+    lds_barrier();
 
     // ---- flush: sub-block of A' (rows = DoFs of block a, cols = DoFs of block b) and diagonal blocks ----
+    if (pipe) {
+        const int nx = s_tile_next;
+        if (nx < ntiles) stage(nx);
+        for (int t = tid; t < 2*(PNL_MAXQ+2)+4; t += NT) s_cnt[t] = 0;
+        if (!(abl & 4)) {
+        // this tile owns its nA x nB sub-block of the storage: plain stores of every entry; rows 0 .. nA (the last one collects the
+        // DoFs without a slot) of the LDS sub-block are read and zeroed
+        const int ca = SO.colbase[ta], W = SO.S-ca;
+        double *__restrict__ base = SO.A2+SO.rowoff[ta]+(SO.colbase[tb]-ca);
+        const unsigned inv = 0xFFFFFFFFu/(unsigned)acc_stride+1u;          // t / acc_stride = umulhi(t, inv) for t < 2^32 / acc_stride
+        for (int t = tid; t < (nA+1)*acc_stride; t += NT) {
+            const int r = (int)__umulhi((unsigned)t, inv), c = t-r*acc_stride;
+            const double v = s_acc[t];
+            s_acc[t] = 0.;
+            if (r < nA && c < nB) slot_store(base+(long long)r*W+c, v);
+        }
+        for (int t = tid; t < 2*TILE*ND; t += NT) {
+            const double v = s_D[t];
+            s_D[t] = 0.;
+            if (v != 0.) {
+                const int side = t/(TILE*ND), rem = t-side*TILE*ND;
+                const int c = (side ? tb : ta)*TILE+rem/ND;
+                atomic_add_f64(&Dglob[(size_t)c*ND+rem%ND], v);
+            }
+        }
+        } else {
+            for (int t = tid; t < (nA+1)*acc_stride; t += NT) s_acc[t] = 0.;
+            for (int t = tid; t < 2*TILE*ND; t += NT) s_D[t] = 0.;
+        }
+    } else {
     const int *__restrict__ dofA = CLUSTER ? CT.chunk_dofs+(size_t)ta*CT.chunk_stride : P.blk_dofs+(size_t)ta*P.blk_stride;
     const int *__restrict__ dofB = CLUSTER ? CT.chunk_dofs+(size_t)tb*CT.chunk_stride : P.blk_dofs+(size_t)tb*P.blk_stride;
     if (!(abl & 4)) {
@@ -960,7 +1009,8 @@ k_tile_distant(const DevProblem P, const int2 *__restrict__ tiles, double *__res
         }
     }
     }
-    __syncthreads();
+    }
+    lds_barrier();
     }   // tile loop
 #pragma unroll
     for (int r = 0; r < (PNL_MAXQ+NT)/NT; r++) {

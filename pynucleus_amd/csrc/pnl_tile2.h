@@ -206,11 +206,6 @@ k_zero_slot_tiles(const SlotOut SO, const int2 *__restrict__ tiles, const int *_
     }
 }
 
-// workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every global atomic / store of the wave
-// (s_waitcnt vmcnt(0)): the flush of a tile would have to retire before the next tile may start.  The tile kernels below
-// never read global memory that the same launch writes, so their barriers only have to order the LDS.
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-
 // LDS of k_tile_uniform in bytes without the sub-block of A' (host and device agree through this function)
 // dof_lists: the global DoF numbers of both blocks, double-buffered (the flush into A in DoF numbering; the block-slot storage
 // does not need them: 1.4 KB that let the P2 kernels of a general exponent keep their power tables next to the second workgroup)
