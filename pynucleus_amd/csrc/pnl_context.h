@@ -226,6 +226,12 @@ inline DevFormula to_dev(const pnl_order_formula &f) {
 // tests use to reach the alternative code paths).  Tuning builds (make EXTRA=-DPNL_TUNING) accept every name and fall back to the
 // environment, which is how the A/B measurements of DESIGN.md were made.  Returns the value string or nullptr.
 const char *pnl_tune(const char *name);
+// grid of a persistent tile kernel, capped by the option PNL_TILE_WGS (tests)
+inline int pnl_grid_cap(int grid) {
+    const char *e = pnl_tune("PNL_TILE_WGS");
+    const int cap = e ? atoi(e) : 0;
+    return cap > 0 ? std::max(1, std::min(grid, cap)) : grid;
+}
 
 // row stride of the LDS sub-block: nU + 1 columns (+1: trash column / row for boundary DoFs); PNL_ACC_PAD=m rounds it up
 // to 1 mod m so that consecutive rows start in different LDS banks

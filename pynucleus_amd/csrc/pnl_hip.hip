@@ -543,7 +543,7 @@ int launch_pure(pnl_context *ctx, double *A, int64_t ldA, const SlotOut &SO) {
     (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)kfun, PNL_NTHREADS, lds);
     if (pnl_tune("PNL_VERBOSE")) fprintf(stderr, "[pnl] uniform tiles=%d of %d, lds=%zu bytes, occupancy API: %d blocks/CU\n", ctx->n_pure,
                                        ctx->n_pure+ctx->n_mixed, lds, per_cu);
-    const int grid = std::min(ctx->n_pure, 256*std::max(per_cu, 1));
+    const int grid = pnl_grid_cap(std::min(ctx->n_pure, 256*std::max(per_cu, 1)));
     int pure_abl = 0;
 #ifdef PNL_DEBUG_ABLATE
     pure_abl = pnl_tune("PNL_PURE_ABL") ? atoi(pnl_tune("PNL_PURE_ABL")) : 0;
@@ -728,13 +728,15 @@ int launch_tiles(pnl_context *ctx, int wl_slot, double *A, int64_t ldA, int cell
     int per_cu = 2;
     (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)kfun, tile_threads(DPE, KT), lds);
     const int grid_mult = pnl_tune("PNL_GRID_MULT") ? atoi(pnl_tune("PNL_GRID_MULT")) : 1;
-    const int grid = std::min(ntiles, 256*std::max(per_cu, 1)*std::max(grid_mult, 1));
+    const int grid = pnl_grid_cap(std::min(ntiles, 256*std::max(per_cu, 1)*std::max(grid_mult, 1)));
+    SlotOut SOk = SO;
+    SOk.nU = ctx->nU;                                       // rows of the LDS sub-block (also without the block-slot storage)
     kt_begin(ctx, PNL_K_TILE_GENERAL);
     if (grid > 0)
         hipLaunchKernelGGL(kfun, dim3(grid), dim3(tile_threads(DPE, KT)), lds, ctx->stream, tile_problem(ctx), (const int2*)ctx->b_tiles.p+ctx->tile_off, A,
                            (long long)ldA, (double*)(ctx->have_tile_order ? ctx->b_Dt.p : ctx->b_D.p), cell_begin, cell_end, acc_stride, (int4*)ctx->b_wl.p,
                            wlc, ctx->wl_cap_each, ctx->ablate | (ctx->symflush ? 256 : 0), ntiles, ClusterTiles{},
-                           (unsigned*)ctx->b_tilectr.p, SO);
+                           (unsigned*)ctx->b_tilectr.p, SOk);
     kt_end(ctx, PNL_K_TILE_GENERAL);
     HIPCHK(ctx, hipGetLastError());
     HIPCHK(ctx, hipEventRecord(ctx->ev[6], ctx->stream));
@@ -1318,7 +1320,7 @@ int clusters_tiled_impl(pnl_context *ctx, const pnl_cluster_plan *pl, ClusterTil
         (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)kfun, tile_threads(DPE, KT), lds);
         if (pnl_tune("PNL_VERBOSE")) fprintf(stderr, "[pnl] cluster tiles=%d nU=%d lds=%zu bytes, occupancy API: %d blocks/CU\n", pl->ntiles,
                                            pl->chunk_stride, lds, per_cu);
-        const int grid = std::min(pl->ntiles, 256*std::max(per_cu, 1));
+        const int grid = pnl_grid_cap(std::min(pl->ntiles, 256*std::max(per_cu, 1)));
         hipLaunchKernelGGL(kfun, dim3(grid), dim3(tile_threads(DPE, KT)), lds, ctx->stream, ctx->P, (const int2*)nullptr, (double*)nullptr, 0ll,
                            (double*)nullptr, 0, ctx->nc, acc_stride, (int4*)ctx->b_wl.p, (unsigned*)ctx->b_wlcount.p, ctx->wl_cap, 0,
                            pl->ntiles, CT, (unsigned*)ctx->b_tilectr.p, SlotOut{});
@@ -1712,7 +1714,7 @@ int pointwise_impl(pnl_context *ctx, double *A, int64_t ldA, int zero_exterior, 
         HIPCHK(ctx, hipFuncSetAttribute((const void*)tfun, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         int per_cu = 1;
         (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)tfun, PNL_NTHREADS, lds);
-        const int grid = std::min((int)uniform.size(), 256*std::max(per_cu, 1));
+        const int grid = pnl_grid_cap(std::min((int)uniform.size(), 256*std::max(per_cu, 1)));
         hipLaunchKernelGGL(tfun, dim3(grid), dim3(PNL_NTHREADS), lds, ctx->stream, P, W, (const int2*)ctx->b_tiles.p+mixed.size(),
                            (int)uniform.size(), A, (long long)ldA, (double*)ctx->b_D.p, acc_stride);
         HIPCHK(ctx, hipGetLastError());
@@ -1730,7 +1732,7 @@ int pointwise_impl(pnl_context *ctx, double *A, int64_t ldA, int zero_exterior, 
         HIPCHK(ctx, hipFuncSetAttribute((const void*)mfun, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         int per_cu = 1;
         (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)mfun, PNL_NTHREADS, lds);
-        const int grid = std::min((int)mixed.size(), 256*std::max(per_cu, 1));
+        const int grid = pnl_grid_cap(std::min((int)mixed.size(), 256*std::max(per_cu, 1)));
         if ((rc = ensure(ctx, ctx->b_tilectr, sizeof(unsigned)))) return rc;
         HIPCHK(ctx, hipMemsetAsync(ctx->b_tilectr.p, 0, sizeof(unsigned), ctx->stream));
         hipLaunchKernelGGL(mfun, dim3(grid), dim3(PNL_NTHREADS), lds, ctx->stream, P, W, (const int2*)ctx->b_tiles.p, (int)mixed.size(), A,
@@ -1861,10 +1863,12 @@ int horizon_impl(pnl_context *ctx, SparseOut S, int cell_begin, int cell_end) {
             ClusterTiles CT{};
             CT.S = S;
             CT.wl_ds = (int2*)ctx->b_mp_pairs.p;                   // the pairs of the far-list entries
-            const int grid = std::min(nt, 256*std::max(per_cu, 1));
+            SlotOut SOk{};
+            SOk.nU = ctx->nU;                                      // rows of the LDS sub-block
+            const int grid = pnl_grid_cap(std::min(nt, 256*std::max(per_cu, 1)));
             hipLaunchKernelGGL(kfun, dim3(grid), dim3(tile_threads(DPE, KT, true)), lds, ctx->stream, ctx->P, (const int2*)ctx->b_tiles.p+t0,
                                (double*)nullptr, 0ll, (double*)ctx->b_D.p, std::max(cell_begin, 0), std::min(cell_end, ctx->nc), acc_stride, (int4*)ctx->b_mp_wl.p,
-                               (unsigned*)ctx->b_wlcount.p, (unsigned)cap, 0, nt, CT, (unsigned*)ctx->b_tilectr.p, SlotOut{});
+                               (unsigned*)ctx->b_wlcount.p, (unsigned)cap, 0, nt, CT, (unsigned*)ctx->b_tilectr.p, SOk);
         } else
             hipLaunchKernelGGL((k_fh_pairs<DIM, DPE>), dim3(nt), dim3(PNL_NTHREADS), 0, ctx->stream, ctx->P, (const int2*)ctx->b_tiles.p+t0, T,
                                (int2*)ctx->b_mp_pairs.p, (int4*)ctx->b_mp_wl.p, (unsigned*)ctx->b_wlcount.p, (unsigned)cap);
@@ -1909,7 +1913,10 @@ std::deque<std::string> g_option_values;
 // diagnostics line
 const char *const k_product_options[] = {"PNL_WL_FRAC", "PNL_FH_NOTILES", "PNL_NO_POWTAB", "PNL_VERBOSE", "PNL_PLAN_TIMING", "PNL_PLAN_THREADS", "PNL_BND_OLD",
                                          // profiling: every phase on the caller's stream, one after the other (per-kernel times that add up)
-                                         "PNL_NO_OVERLAP", "PNL_NO_FORK"};
+                                         "PNL_NO_OVERLAP", "PNL_NO_FORK",
+                                         // tests: at most this many workgroups of a persistent tile kernel (every workgroup then walks
+                                         // many tiles at test sizes: the pipelined tile loops against the oracle)
+                                         "PNL_TILE_WGS"};
 }  // namespace
 
 const char *pnl_tune(const char *name) {

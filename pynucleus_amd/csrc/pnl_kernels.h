@@ -526,12 +526,13 @@ k_tile_distant(const DevProblem P, const int2 *__restrict__ tiles, double *__res
         s_cf[side*TILE+l] = make_int2((vid0 >= 0 ? 1 : 0) | (has_dof ? 2 : 0), __float_as_int((float)P.clog[2*(size_t)P.ncp+c]));
     }
     };
-    // Dense tiles into the block-slot storage run as a software pipeline: the cell data of the NEXT tile is staged before the flush
-    // of this one is issued (a load issued behind the stores would wait for all of them), the flush zeroes the accumulators it has
-    // read, and the barriers order the LDS only -- no wave waits for the stores of a tile to retire.
-    const bool pipe = !CLUSTER && !fh && SO.A2 != nullptr && !(abl & 256);
+    // The tiles of a workgroup run as a software pipeline: the cell data of the NEXT tile is staged before the flush of this one is
+    // issued (a load issued behind the stores / atomics would wait for all of them), the flush zeroes the accumulators it has
+    // read, and the barriers order the LDS only -- no wave waits for the flush of a tile to retire.  (Not with
+    // PNL_FLAG_SYMMETRIC_FLUSH, whose second sweep reads the sub-block again.)
+    const bool pipe = !(abl & 256);
     if (pipe) {
-        for (int t = tid; t < (SO.nU+1)*acc_stride; t += NT) s_acc[t] = 0.;
+        for (int t = tid; t < ((CLUSTER ? CT.chunk_stride : SO.nU)+1)*acc_stride; t += NT) s_acc[t] = 0.;
         for (int t = tid; t < 2*TILE*ND; t += NT) s_D[t] = 0.;
         for (int t = tid; t < 2*(PNL_MAXQ+2)+4; t += NT) s_cnt[t] = 0;
         if ((int)blockIdx.x < ntiles) stage(blockIdx.x);
@@ -931,33 +932,51 @@ k_tile_distant(const DevProblem P, const int2 *__restrict__ tiles, double *__res
     // ---- flush: sub-block of A' (rows = DoFs of block a, cols = DoFs of block b) and diagonal blocks ----
     if (pipe) {
         const int nx = s_tile_next;
+        // diagonal blocks: read and zeroed; cluster tiles before the next tile's slots replace s_dslot
+        auto flush_D = [&]() {
+            for (int t = tid; t < 2*TILE*ND; t += NT) {
+                const double v = s_D[t];
+                s_D[t] = 0.;
+                if (v != 0. && !(abl & 4)) {
+                    const int side = t/(TILE*ND), rem = t-side*TILE*ND;
+                    if (CLUSTER) {
+                        const int ds = s_dslot[side*TILE+rem/ND];
+                        if (ds >= 0) atomic_add_f64(&CT.D[(size_t)ds*ND+rem%ND], v);
+                    } else {
+                        const int c = (side ? tb : ta)*TILE+rem/ND;
+                        atomic_add_f64(&Dglob[(size_t)c*ND+rem%ND], v);
+                    }
+                }
+            }
+        };
+        if (CLUSTER) { flush_D(); lds_barrier(); }             // every wave has read s_dslot before the next tile's slots arrive
         if (nx < ntiles) stage(nx);
         for (int t = tid; t < 2*(PNL_MAXQ+2)+4; t += NT) s_cnt[t] = 0;
-        if (!(abl & 4)) {
-        // this tile owns its nA x nB sub-block of the storage: plain stores of every entry; rows 0 .. nA (the last one collects the
-        // DoFs without a slot) of the LDS sub-block are read and zeroed
-        const int ca = SO.colbase[ta], W = SO.S-ca;
-        double *__restrict__ base = SO.A2+SO.rowoff[ta]+(SO.colbase[tb]-ca);
+        // rows 0 .. nA (the last one collects the DoFs without a slot) of the LDS sub-block are read and zeroed.  Block-slot storage
+        // (pnl_tile2.h): this tile owns its nA x nB sub-block of the storage, plain stores of every entry
+        const bool slots = !CLUSTER && !fh && SO.A2 != nullptr;
+        const int ca = slots ? SO.colbase[ta] : 0, W = slots ? SO.S-ca : 0;
+        double *__restrict__ base = slots ? SO.A2+SO.rowoff[ta]+(SO.colbase[tb]-ca) : nullptr;
+        const int *__restrict__ dofA = CLUSTER ? CT.chunk_dofs+(size_t)ta*CT.chunk_stride : P.blk_dofs+(size_t)ta*P.blk_stride;
+        const int *__restrict__ dofB = CLUSTER ? CT.chunk_dofs+(size_t)tb*CT.chunk_stride : P.blk_dofs+(size_t)tb*P.blk_stride;
         const unsigned inv = 0xFFFFFFFFu/(unsigned)acc_stride+1u;          // t / acc_stride = umulhi(t, inv) for t < 2^32 / acc_stride
         for (int t = tid; t < (nA+1)*acc_stride; t += NT) {
             const int r = (int)__umulhi((unsigned)t, inv), c = t-r*acc_stride;
             const double v = s_acc[t];
             s_acc[t] = 0.;
-            if (r < nA && c < nB) slot_store(base+(long long)r*W+c, v);
-        }
-        for (int t = tid; t < 2*TILE*ND; t += NT) {
-            const double v = s_D[t];
-            s_D[t] = 0.;
-            if (v != 0.) {
-                const int side = t/(TILE*ND), rem = t-side*TILE*ND;
-                const int c = (side ? tb : ta)*TILE+rem/ND;
-                atomic_add_f64(&Dglob[(size_t)c*ND+rem%ND], v);
+            if (r < nA && c < nB && !(abl & 4)) {
+                if (slots) slot_store(base+(long long)r*W+c, v);
+                else if (v != 0.) {
+                    if (CLUSTER || fh) {
+                        // entry (I in n1, J in n2) of the near-field matrix and its mirror image (SSS keeps the one with I > J, a
+                        // rank-local CSR the ones of its own blocks: addToEntry semantics)
+                        sparse_add(CT.S, dofA[r], dofB[c], v);
+                        sparse_add(CT.S, dofB[c], dofA[r], v);
+                    } else atomic_add_f64(&A[pnl_row(P, dofA[r])*ldA+pnl_col(P, dofB[c])], v);
+                }
             }
         }
-        } else {
-            for (int t = tid; t < (nA+1)*acc_stride; t += NT) s_acc[t] = 0.;
-            for (int t = tid; t < 2*TILE*ND; t += NT) s_D[t] = 0.;
-        }
+        if (!CLUSTER) flush_D();
     } else {
     const int *__restrict__ dofA = CLUSTER ? CT.chunk_dofs+(size_t)ta*CT.chunk_stride : P.blk_dofs+(size_t)ta*P.blk_stride;
     const int *__restrict__ dofB = CLUSTER ? CT.chunk_dofs+(size_t)tb*CT.chunk_stride : P.blk_dofs+(size_t)tb*P.blk_stride;

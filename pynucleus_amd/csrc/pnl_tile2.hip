@@ -51,7 +51,7 @@ int launch_uniform_t(pnl_context *ctx, const DevProblem &Pt, const int2 *tiles, 
     }
     HIPCHK(ctx, hipFuncSetAttribute((const void*)kfun, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int per_cu = resident(lds);
-    const int grid = std::min(ntiles, 256*per_cu);
+    const int grid = pnl_grid_cap(std::min(ntiles, 256*per_cu));
     if (pnl_tune("PNL_VERBOSE"))
         fprintf(stderr, "[pnl] uniform tiles of order %d: %d, dpe=%d np=%d kt=%d lds=%zu bytes (%d per CU), acc_stride=%d\n", q, ntiles, DPE,
                 NP, KT, lds, per_cu, acc_stride);
@@ -92,7 +92,7 @@ int launch_p2_t(pnl_context *ctx, const int2 *tiles, const int *tile_cls, int nt
     auto kfun = k_tile_p2<KT>;
     HIPCHK(ctx, hipFuncSetAttribute((const void*)kfun, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     // two tiles per workgroup are taken by block index, the rest through tickets: a grid of at most ntiles / 2 workgroups
-    const int grid = std::max(1, std::min((ntiles+1)/2, 256));
+    const int grid = pnl_grid_cap(std::max(1, std::min((ntiles+1)/2, 256)));
     if (pnl_tune("PNL_VERBOSE")) fprintf(stderr, "[pnl] P2 general tiles=%d nU=%d kt=%d lds=%zu bytes acc_stride=%d\n", ntiles, ctx->nU, KT, lds, stride);
     kt_begin(ctx, PNL_K_TILE_GENERAL);
     hipLaunchKernelGGL(kfun, dim3(grid), dim3(P2_NT), lds, ctx->stream, ctx->P, tiles, tile_cls, (const DevKernel*)ctx->b_kcls.p,

@@ -2,6 +2,9 @@
 
 Reference test being mirrored: tests/test_nearField.py (dense matrix vs near-field assembly with cluster pairs covering
 all matrix blocks; 2D tolerances epsAbsDense = 5e-3, epsRelDense = 3e-2, lines 32-41)."""
+import os
+import sys
+
 import numpy as np
 import pytest
 
@@ -383,3 +386,38 @@ def test_gpu_assemble_clusters_by_subtree(mode):
         total += P
     assert seen == len(Pnear)
     assert np.abs(total-full).max() <= 1e-12*scale
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('case', ['dense_P1', 'dense_P2', 'near_P1', 'near_P1_unsym', 'sparse_P1', 'sparse_fractional'])
+def test_gpu_tile_loops_with_two_workgroups_against_the_oracle(case):
+    """The tile kernels are persistent: a workgroup walks many tiles (the cell data of the next tile is staged before the flush of the
+    current one, the flush zeroes the accumulators it has read, the barriers order the LDS only).  At test sizes every workgroup
+    gets ONE tile; the option PNL_TILE_WGS caps the grid at two workgroups, so the tile loops themselves -- dense, cluster tiles
+    of the near field, finite-horizon tiles -- are compared with the oracle entry by entry."""
+    from oracle.oracle import OracleProblem
+    from pynucleus_amd import _lib, clusters
+    sys.path.insert(0, os.path.dirname(__file__))
+    try:
+        _lib.set_option('PNL_TILE_WGS', 2)
+        if case.startswith('dense'):
+            b = _gpu_builder(4 if case == 'dense_P1' else 3, 0.5, element=case[-2:], params={'target_order': 0.5})
+            A = b.getDense()
+            Aref, cnt, _ = OracleProblem(b.tables).get_dense()
+            for key in ('numAssembledCellPairs', 'numIntegrations', 'orders', 'singular'):
+                assert A.info['counters'][key] == cnt[key], key
+            assert np.abs(A.toarray()-Aref).max() <= 1e-11*np.abs(Aref).max()
+        elif case.startswith('near'):
+            b = _gpu_builder(4, 0.75, mode='tiles')
+            root, Pnear, Pfar = clusters.getNearFieldClusters(b.dm, eta=3., minClusterSize=8)
+            Anear, Aref = _gpu_vs_oracle(b, Pnear, symmetric=(case == 'near_P1'))
+            assert np.abs(Anear.toarray()-Aref).max() <= 1e-11*np.abs(Aref).max()
+        else:
+            from test_finite_horizon import _gpu_sparse
+            b = _gpu_sparse(17, 0.2, 'indicator') if case == 'sparse_P1' else _gpu_sparse(9, 0.45, 'fractional', s=0.4)
+            A = b.getSparse()
+            Aref, cnt, _ = OracleProblem(b.tables).get_dense()
+            assert np.abs(A.toarray()-Aref).max() <= 1e-11*np.abs(Aref).max()
+            assert A.info['counters']['numAssembledCellPairs'] == cnt['numAssembledCellPairs']
+    finally:
+        _lib.set_option('PNL_TILE_WGS', None)
