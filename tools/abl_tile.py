@@ -21,8 +21,10 @@ for rep in range(4):
     if rep:
         tot.append(A.info['phase_ms']['total'])
         gen.append(b.dense_context().kernel_ms()['tile_general'])
+        A0 = A.info['phase_ms']
     del A
 print('PNL_ABLATE', os.environ.get('PNL_ABLATE', '0'), 'total_ms %.2f' % float(np.median(tot)), 'tile_general_ms %.2f' % float(np.median(gen)))
+print('phases', {k: round(v, 2) for k, v in A0.items()}, 'kernels', {k: round(v, 2) for k, v in b.dense_context().kernel_ms().items()})
 if os.environ.get('PNL_VERBOSE'):
     A = b.getDense()
     print('orders', A.info['counters']['orders'], 'pairs', A.info['counters']['numAssembledCellPairs'])
