@@ -3449,29 +3449,38 @@ k_h2_up_leaves(const H2Dev H, const double *__restrict__ x) {
     }
 }
 
+// y[i] += sum_j B[i][j] x[j] for a row-major M x M block, one wave: the lanes run over the COLUMNS, so a row is read as contiguous
+// segments (a lane per row reads with a stride of M doubles: 64 cache lines per load), one wave reduction per row; lane i keeps row i and
+// the results leave as one coalesced set of atomics per 64 rows
+__device__ __forceinline__ void h2_block_matvec_add(const double *__restrict__ B, int M, const double *__restrict__ x, double *__restrict__ y) {
+    const int lane = threadIdx.x & 63;
+    for (int i0 = 0; i0 < M; i0 += 64) {
+        double mine = 0.;
+        const int rows = min(64, M-i0);
+        for (int ii = 0; ii < rows; ii++) {
+            const double *__restrict__ row = B+(size_t)(i0+ii)*M;
+            double s = 0.;
+            for (int j = lane; j < M; j += 64) s = __builtin_fma(row[j], x[j], s);
+            s = wave_sum(s);
+            mine = (lane == ii) ? s : mine;
+        }
+        if (lane < rows) atomic_add_f64(&y[i0+lane], mine);
+    }
+}
+
 // upward pass, one level: cup[parent] += T_child cup[child] for the nodes of the level (list of children)
 __global__ void __launch_bounds__(64)
 k_h2_up_level(const H2Dev H, const int *__restrict__ nodes, int n) {
     const int c = nodes[blockIdx.x], p = H.parent[c];
     (void)n;
-    const double *T = H.T+(size_t)c*H.M*H.M;
-    for (int i = threadIdx.x; i < H.M; i += 64) {
-        double s = 0.;
-        for (int j = 0; j < H.M; j++) s = __builtin_fma(T[(size_t)i*H.M+j], H.cup[(size_t)c*H.M+j], s);
-        atomic_add_f64(&H.cup[(size_t)p*H.M+i], s);
-    }
+    h2_block_matvec_add(H.T+(size_t)c*H.M*H.M, H.M, H.cup+(size_t)c*H.M, H.cup+(size_t)p*H.M);
 }
 
 // far field: cdown[n1] += K cup[n2]
 __global__ void __launch_bounds__(64)
 k_h2_far(const H2Dev H) {
     const int pr = blockIdx.x, n1 = H.far[2*pr], n2 = H.far[2*pr+1];
-    const double *K = H.K+(size_t)pr*H.M*H.M;
-    for (int i = threadIdx.x; i < H.M; i += 64) {
-        double s = 0.;
-        for (int j = 0; j < H.M; j++) s = __builtin_fma(K[(size_t)i*H.M+j], H.cup[(size_t)n2*H.M+j], s);
-        atomic_add_f64(&H.cdown[(size_t)n1*H.M+i], s);
-    }
+    h2_block_matvec_add(H.K+(size_t)pr*H.M*H.M, H.M, H.cup+(size_t)n2*H.M, H.cdown+(size_t)n1*H.M);
 }
 
 // downward pass, one level: cdown[child] += T_child^T cdown[parent]

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """One bench leg, three repetitions, one line 'LEG <name> {json}' (device ms, phases, kernel ms, SURVEY 8(d) fraction of the fp64 peak).
-Used under rocprofv3 by tools/profile_legs.sh.   usage: leg_probe.py c3|c4|c5|c5big|p2|s04|big|head [noRef] [serial]"""
+Used under rocprofv3 by tools/profile_legs.sh.   usage: leg_probe.py c3|c4|h2mv|c5|c5big|p2|s04|big|head [noRef] [serial]"""
 import json
 import os
 import sys
@@ -70,6 +70,19 @@ elif what == 'c3':
           frac_fp64_peak=round(fl/ms/1e9/PEAK, 4), pairs=c['numAssembledCellPairs'], evals=c['numIntegrations'],
           phases_ms={k: round(v, 3) for k, v in A.info.get('phase_ms', {}).items()},
           kernel_ms={k: round(v, 3) for k, v in b.dense_context().kernel_ms().items() if v})), flush=True)
+elif what == 'h2mv':
+    # the H2 matvec of C4 (near-field CSR product + upward pass, far-field interactions, downward pass): 200 products
+    dm = P1_DoFMap(disc(size or 7), PHYSICAL)
+    b = nonlocalBuilder(dm, getFractionalKernel(2, 0.75), {'target_order': 0.5, 'eta': 3.}, zeroExterior=True)
+    h2 = b.getH2()
+    x = torch.from_numpy(np.random.default_rng(0).standard_normal(dm.num_dofs)).cuda()
+    for _ in range(5):
+        y = h2.matvec(x)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(200):
+        y = h2.matvec(x)
+    torch.cuda.synchronize(); dt = (time.perf_counter()-t0)/200
+    print('LEG', 'H2_matvec_noRef{}'.format(size or 7), json.dumps(dict(num_dofs=dm.num_dofs, matvec_ms=round(1e3*dt, 4), near_nnz=int(h2.Anear.nnz))), flush=True)
 elif what == 'c4':
     dm = P1_DoFMap(disc(size or 7), PHYSICAL)
     b = nonlocalBuilder(dm, getFractionalKernel(2, 0.75), {'target_order': 0.5, 'eta': 3.}, zeroExterior=True)
