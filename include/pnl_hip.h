@@ -256,7 +256,8 @@ int pnl_assemble_clusters_tiled(pnl_context *ctx, const pnl_cluster_plan *plan, 
  * for the root) and a volume quadrature rule for the leaf values.  pnl_h2_setup evaluates on the device the kernel
  * interpolants -2 gamma(xi_i, eta_j) of every admissible pair (assembleFarFieldInteractions :2153-2238) and the leaf values
  * int phi_I L_alpha (enterLeafValues :1205-1325).  pnl_h2_matvec adds the far field to y: upward pass, interactions,
- * downward pass (H2Matrix.matvec :2269-2295 without the near-field term, which is pnl_spmv).  Tensor index
+ * downward pass (H2Matrix.matvec :2269-2295 without the near-field term, which is pnl_spmv).  A kernel with a finite horizon (l2 ball)
+ * is taken if every admissible pair lies inside the horizon (pnl_tree_build_horizon).  Tensor index
  * alpha = alpha_0 + m alpha_1 (coordinate 0 fastest), M = m^dim. */
 typedef struct {
     int32_t nnodes, nleaves, nfar, m, nlevels, nq;
@@ -383,6 +384,13 @@ int pnl_tree_build_blocks(int N, int dim, const double *boxes, const int64_t *d2
 int pnl_tree_build_refined(int N, int dim, const double *boxes, const int64_t *d2c_ptr, const int32_t *d2c_idx, int nc, double eta,
                            int min_size, int max_levels, int do_admissibility, const int32_t *dof_block, int mixed_block, int ref_type,
                            pnl_tree **out);
+/* ... for a kernel with a finite horizon (getAdmissibleClusters, clusterMethodCy.pyx:4069-4090, 4115, 4131-4135, with distBoxes /
+ * maxDistBoxes of the l2 ball, interactionDomains.pyx:304-337): cluster pairs farther apart than the horizon are dropped, pairs the
+ * horizon may cut stay in the near field, near-field children are merged into one block only if the block fits into the horizon.
+ * horizon = INFINITY: pnl_tree_build_refined */
+int pnl_tree_build_horizon(int N, int dim, const double *boxes, const int64_t *d2c_ptr, const int32_t *d2c_idx, int nc, double eta,
+                           int min_size, int max_levels, int do_admissibility, const int32_t *dof_block, int mixed_block, int ref_type,
+                           double horizon, pnl_tree **out);
 /* the same structure with refinement (MEDIAN / GEOMETRIC) and admissibility run ON THE DEVICE as level-synchronous sweeps
  * (clusterMethodCy.pyx:354-663, 4046-4136; csrc/pnl_plan_dev.hip): same nodes, same lists in the same order as pnl_tree_build_refined;
  * kernel blocks and the BARYCENTER split: PNL_ERR_UNSUPPORTED (use the host planner).  Uses the current HIP device. */

@@ -27,7 +27,7 @@ PNL_NUM_COUNTERS = 134
 EXPORTS = ['pnl_create', 'pnl_destroy', 'pnl_error_string', 'pnl_version', 'pnl_set_stream', 'pnl_synchronize',
            'pnl_upload_mesh', 'pnl_upload_dofmap', 'pnl_set_kernel', 'pnl_set_order_formula', 'pnl_upload_distant_rules',
            'pnl_upload_singular_rule', 'pnl_upload_boundary', 'pnl_assemble_dense', 'pnl_dense_overwrites', 'pnl_block_row_costs', 'pnl_tile_cells',
-           'pnl_assemble_dense_tiles', 'pnl_get_counters', 'pnl_get_phase_ms', 'pnl_get_kernel_ms', 'pnl_tree_build', 'pnl_tree_build_blocks', 'pnl_tree_build_refined', 'pnl_tree_build_device', 'pnl_tree_destroy', 'pnl_tree_sizes', 'pnl_tree_get', 'pnl_tree_node_cells', 'pnl_h2_transfer_matrices', 'pnl_nfplan_build', 'pnl_nfplan_destroy', 'pnl_nfplan_sizes', 'pnl_nfplan_get', 'pnl_horizon_pattern', 'pnl_near_pattern', 'pnl_pattern_set_max_nnz', 'pnl_set_option', 'pnl_set_cell_order', 'pnl_set_interaction_transform', 'pnl_set_order_vertex_values', 'pnl_h2_get', 'pnl_h2_set', 'pnl_pattern_nnz', 'pnl_pattern_get', 'pnl_pattern_destroy', 'pnl_set_row_slab', 'pnl_diag_blocks_size', 'pnl_get_diag_blocks', 'pnl_slab_matvec', 'pnl_slab_diagonal', 'pnl_gemv', 'pnl_cg_jacobi',
+           'pnl_assemble_dense_tiles', 'pnl_get_counters', 'pnl_get_phase_ms', 'pnl_get_kernel_ms', 'pnl_tree_build', 'pnl_tree_build_blocks', 'pnl_tree_build_refined', 'pnl_tree_build_horizon', 'pnl_tree_build_device', 'pnl_tree_destroy', 'pnl_tree_sizes', 'pnl_tree_get', 'pnl_tree_node_cells', 'pnl_h2_transfer_matrices', 'pnl_nfplan_build', 'pnl_nfplan_destroy', 'pnl_nfplan_sizes', 'pnl_nfplan_get', 'pnl_horizon_pattern', 'pnl_near_pattern', 'pnl_pattern_set_max_nnz', 'pnl_set_option', 'pnl_set_cell_order', 'pnl_set_interaction_transform', 'pnl_set_order_vertex_values', 'pnl_h2_get', 'pnl_h2_set', 'pnl_pattern_nnz', 'pnl_pattern_get', 'pnl_pattern_destroy', 'pnl_set_row_slab', 'pnl_diag_blocks_size', 'pnl_get_diag_blocks', 'pnl_slab_matvec', 'pnl_slab_diagonal', 'pnl_gemv', 'pnl_cg_jacobi',
            'pnl_inv_diagonal', 'pnl_set_classes', 'pnl_select_class', 'pnl_upload_sparsity', 'pnl_upload_sparsity_device', 'pnl_assemble_pairs_masked', 'pnl_assemble_boundary_masked', 'pnl_assemble_clusters_tiled', 'pnl_h2_setup', 'pnl_h2_matvec', 'pnl_h2_upward', 'pnl_h2_interact', 'pnl_h2_downward', 'pnl_h2_sizes', 'pnl_spmv',
            'pnl_assemble_pairs_in_horizon', 'pnl_assemble_pairs_in_horizon_range', 'pnl_set_nonsymmetric', 'pnl_set_order_function', 'pnl_upload_pointwise_rules', 'pnl_assemble_dense_pointwise',
            'pnl_assemble_pairs_masked_pointwise', 'pnl_assemble_boundary_masked_pointwise',
@@ -135,6 +135,7 @@ def load():
     L.pnl_tree_build.argtypes = [i32, i32, vp, vp, vp, i32, dbl, i32, i32, i32, C.POINTER(vp)]
     L.pnl_tree_build_blocks.argtypes = [i32, i32, vp, vp, vp, i32, dbl, i32, i32, i32, vp, i32, C.POINTER(vp)]
     L.pnl_tree_build_refined.argtypes = [i32, i32, vp, vp, vp, i32, dbl, i32, i32, i32, vp, i32, i32, C.POINTER(vp)]
+    L.pnl_tree_build_horizon.argtypes = [i32, i32, vp, vp, vp, i32, dbl, i32, i32, i32, vp, i32, i32, dbl, C.POINTER(vp)]
     L.pnl_tree_build_device.argtypes = [i32, i32, vp, vp, vp, i32, dbl, i32, i32, i32, i32, C.POINTER(vp)]
     L.pnl_tree_destroy.argtypes = [vp]
     L.pnl_tree_destroy.restype = None

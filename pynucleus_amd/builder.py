@@ -709,7 +709,13 @@ class nonlocalBuilder:
             # tree, admissible pairs, near-field tile plan, pattern and far-field plan depend on the mesh and the refinement
             # parameters only: kept on the builder (a second operator of the same DoFMap -- another kernel through setKernel, a
             # time step -- starts with the device work)
-            key = ('tree', rp['eta'], rp['minSize'], rp['maxLevels'], rp['refinementType'])
+            horizon = np.inf
+            if self.kernel.finiteHorizon:
+                # getAdmissibleClusters with the horizon of the l2 ball (clusterMethodCy.pyx:4069-4090): far-field pairs lie inside it
+                if not self.tables.has_boundary_tables:
+                    raise NotImplementedError('H2 operator of a finite horizon: fractional kernels of constant order with the l2 ball')
+                horizon = float(self.kernel.horizonValue)
+            key = ('tree', rp['eta'], rp['minSize'], rp['maxLevels'], rp['refinementType'], horizon)
             # ... and on the DoF map itself (at most two parameter sets): a NEW builder on the same DoF map -- another kernel, the next
             # operator of a parameter study -- finds tree, tile plan, pattern and far-field plan there and starts with the device work
             store = self.dm.__dict__.setdefault('_pnl_geom', {}) if self.params.get('cacheGeometry', True) else {}
@@ -730,7 +736,7 @@ class nonlocalBuilder:
                 th.start()
                 try:
                     tree = clusters.getNearFieldClusters(self.dm, rp['eta'], rp['minSize'], rp['maxLevels'], refinementType=rp['refinementType'],
-                                                         planner=self._planner())
+                                                         planner=self._planner(), horizon=horizon)
                 finally:
                     th.join()
                 self._geom_cache = {'key': key, 'tree': tree}
@@ -739,6 +745,8 @@ class nonlocalBuilder:
                 store[key] = self._geom_cache
             root, Pnear, Pfar = self._geom_cache['tree']
         rank, size = self._rank_size()
+        if size > 1 and self.kernel.finiteHorizon:
+            raise NotImplementedError('distributed H2 operator of a finite horizon')
         if sum(len(v) for v in Pfar.values()) == 0:
             h2 = self.getDense()
         elif size > 1 and self.params.get('localFarFieldIndexing', False):
@@ -907,7 +915,11 @@ class nonlocalBuilder:
             cells, facets, bmasks = clusters.clusterBoundaryItems(dm, Pnear, symmetrize=_symmetrizeMasks)
             nitems = int(cells.shape[0])
             ctx.assemble_boundary_masked(cells, facets, bmasks, 1., data_ptr, diag_ptr)
-            if not self.zeroExterior and _globalBoundary:
+            if self.kernel.finiteHorizon and _globalBoundary:
+                # NA:1915-1940: the cluster exteriors were integrated with the full-space twin; what lies beyond the horizon is a
+                # constant per point -- the surface of the ball times the twin's value at the horizon -- times the mass matrix
+                self._subtractBeyondHorizon(Anear)
+            elif not self.zeroExterior and _globalBoundary:
                 cells, facets, bmasks = clusters.globalBoundaryItems(dm, self.tables.bcells)
                 nitems += int(cells.shape[0])
                 ctx.assemble_boundary_masked(cells, facets, bmasks, -1., data_ptr, diag_ptr)
@@ -918,6 +930,45 @@ class nonlocalBuilder:
         Anear.info = dict(counters=dict(totals, orders=hist, singular=sing, numBoundaryItems=nitems), interior_ms=ms_total)
         return Anear
 
+
+    def _subtractBeyondHorizon(self, Anear):
+        """Anear -= vol * Gamma_b(horizon) * M on the pattern of the near field (NA:1915-1940: vol = 2 in 1D, 2 pi horizon in 2D, Gamma_b the
+        boundary twin of the full-space kernel, M the mass matrix with the rule of degree 2 the reference takes)"""
+        import torch
+        import scipy.sparse as sp
+        from .quadrature import simplexXiaoGimbutas
+        from .linear_operators import SSS_LinearOperator
+        dm, dim, delta = self.dm, self.mesh.dim, float(self.kernel.horizonValue)
+        if dim not in (1, 2):
+            raise NotImplementedError('near field of a finite horizon in {}D'.format(dim))
+        vol = 2. if dim == 1 else 2.*np.pi*delta
+        x, y = np.zeros(dim), np.zeros(dim)
+        y[0] = delta
+        coeff = -vol*float(self.tables.boundaryKernel(x, y))
+        M = (coeff*dm.assembleMass(simplexXiaoGimbutas(2, dim, dim))).tocoo()
+        n = dm.num_dofs
+        indptr, indices = np.asarray(Anear.indptr), np.asarray(Anear.indices)
+        pos = sp.csr_matrix((np.arange(1, indices.shape[0]+1, dtype=np.int64), indices, indptr), shape=(n, n))
+        sym = isinstance(Anear, SSS_LinearOperator)
+        Anear._bind()
+        dev = Anear.data_dev.device
+        self.context().synchronize()
+        if sym:
+            off = M.row > M.col                              # SSS: strict lower triangle + diagonal
+            dg = M.row == M.col
+            d = np.zeros(n)
+            np.add.at(d, M.row[dg], M.data[dg])
+            Anear.diag_dev += torch.from_numpy(d).to(dev)
+        else:
+            off = np.ones(M.row.shape[0], dtype=bool)
+        r, c, v = M.row[off], M.col[off], M.data[off]
+        p = np.asarray(pos[r, c]).reshape(-1)
+        if (p == 0).any():
+            raise RuntimeError('the near field does not hold every pair of DoFs that share a cell')
+        upd = torch.zeros(indices.shape[0], dtype=torch.float64)
+        upd.index_add_(0, torch.from_numpy(p-1), torch.from_numpy(np.ascontiguousarray(v)))
+        Anear.data_dev[:indices.shape[0]] += upd.to(dev)
+        torch.cuda.current_stream(dev).synchronize()
 
     def _assembleClustersPointwise(self, Pnear, Anear=None, myRoot=None, clusterBoundary=True, globalBoundary=True):
         """assembleClusters for the non-symmetric kernels with an order per quadrature point (NA:1776-1840 with symmetricCells ==

@@ -144,7 +144,8 @@ REFINEMENT_TYPES = {'median': 0, 'MEDIAN': 0, 'geometric': 1, 'GEOMETRIC': 1, 'b
 
 
 class _nativeTree:
-    def __init__(self, dm, eta, minSize, maxLevels, mode, dof_block=None, mixed_block=-1, refinementType='MEDIAN', planner='host'):
+    def __init__(self, dm, eta, minSize, maxLevels, mode, dof_block=None, mixed_block=-1, refinementType='MEDIAN', planner='host',
+                 horizon=np.inf):
         import ctypes as C
         from . import _lib
         L = _lib.load()
@@ -159,7 +160,7 @@ class _nativeTree:
         self.dof_block = None if dof_block is None else np.ascontiguousarray(dof_block, dtype=np.int32)
         rc = _lib.PNL_ERR_UNSUPPORTED
         self.planner = 'host'
-        if planner == 'device' and dof_block is None:
+        if planner == 'device' and dof_block is None and not np.isfinite(horizon):
             # refinement and admissibility as level-synchronous sweeps on the GPU (csrc/pnl_plan_dev.hip): the same tree and lists; what
             # it does not take (BARYCENTER split) falls through to the host loops
             rc = L.pnl_tree_build_device(N, dim, b.ctypes.data, p.ctypes.data, ix.ctypes.data, dm.mesh.num_cells, float(eta), int(minSize),
@@ -169,9 +170,9 @@ class _nativeTree:
             elif rc != _lib.PNL_ERR_UNSUPPORTED:
                 raise RuntimeError('pnl_tree_build_device failed: {}'.format(rc))
         if rc == _lib.PNL_ERR_UNSUPPORTED:
-            rc = L.pnl_tree_build_refined(N, dim, b.ctypes.data, p.ctypes.data, ix.ctypes.data, dm.mesh.num_cells, float(eta), int(minSize),
+            rc = L.pnl_tree_build_horizon(N, dim, b.ctypes.data, p.ctypes.data, ix.ctypes.data, dm.mesh.num_cells, float(eta), int(minSize),
                                           int(maxLevels), int(mode), None if dof_block is None else self.dof_block.ctypes.data,
-                                          int(mixed_block), REFINEMENT_TYPES[refinementType], C.byref(h))
+                                          int(mixed_block), REFINEMENT_TYPES[refinementType], float(horizon), C.byref(h))
         if rc:
             raise RuntimeError('pnl_tree_build failed: {}'.format(rc))
         self.h = h
@@ -277,10 +278,29 @@ def getTree(dm, native=None):
     return root
 
 
-def getAdmissibleClusters(n1, n2, eta, minSize, maxLevels, Pfar, Pnear, level=0):
-    """clusterMethodCy.pyx:4046-4136 for an infinite horizon; returns whether far-field pairs were added below"""
+def maxDistBoxes(b1, b2):
+    """interactionDomain.maxDistBoxes (interactionDomains.pyx:325-337), as written there"""
+    s = 0.
+    for i in range(b1.shape[0]):
+        lo, hi = (b2[i, 0], b1[i, 1]) if b1[i, 0] > b2[i, 0] else (b1[i, 0], b2[i, 1])
+        s += max(hi-lo, 0.)**2
+    return float(np.sqrt(s))
+
+
+def getAdmissibleClusters(n1, n2, eta, minSize, maxLevels, Pfar, Pnear, level=0, horizon=np.inf):
+    """clusterMethodCy.pyx:4046-4136; returns whether far-field pairs were added below.  Finite horizon (l2 ball, :4069-4090): cluster
+    pairs farther apart than the horizon do not interact, pairs the horizon may cut stay in the near field, near-field children
+    are merged into one block only if the block fits into the horizon (:4131-4135)"""
     dist = distBoxes(n1.box, n2.box)
     admissible = eta*dist >= max(diamBox(n1.box), diamBox(n2.box))
+    finite = np.isfinite(horizon)
+    diamUnion = 0.
+    if finite:
+        if dist > horizon:
+            return True
+        if horizon <= maxDistBoxes(n1.box, n2.box):
+            admissible = False
+        diamUnion = diamBox(np.stack([np.minimum(n1.box[:, 0], n2.box[:, 0]), np.maximum(n1.box[:, 1], n2.box[:, 1])], axis=1))
     lenNear = len(Pnear)
     added = False
     if admissible:
@@ -293,15 +313,15 @@ def getAdmissibleClusters(n1, n2, eta, minSize, maxLevels, Pfar, Pnear, level=0)
         return False
     elif n1.is_leaf:
         for t2 in n2.children:
-            added |= getAdmissibleClusters(n1, t2, eta, minSize, maxLevels, Pfar, Pnear, level+1)
+            added |= getAdmissibleClusters(n1, t2, eta, minSize, maxLevels, Pfar, Pnear, level+1, horizon)
     elif n2.is_leaf:
         for t1 in n1.children:
-            added |= getAdmissibleClusters(t1, n2, eta, minSize, maxLevels, Pfar, Pnear, level+1)
+            added |= getAdmissibleClusters(t1, n2, eta, minSize, maxLevels, Pfar, Pnear, level+1, horizon)
     else:
         for t1 in n1.children:
             for t2 in n2.children:
-                added |= getAdmissibleClusters(t1, t2, eta, minSize, maxLevels, Pfar, Pnear, level+1)
-    if not added:
+                added |= getAdmissibleClusters(t1, t2, eta, minSize, maxLevels, Pfar, Pnear, level+1, horizon)
+    if not added and (not finite or diamUnion < horizon):
         # no far-field pair below: keep the whole block as one near-field pair (CM:4131-4135)
         del Pnear[lenNear:]
         Pnear.append(nearFieldClusterPair(n1, n2))
@@ -323,7 +343,8 @@ def dofKernelBlocks(dm, T):
     return blk.astype(np.int32), L
 
 
-def getNearFieldClusters(dm, eta=3., minClusterSize=None, maxLevels=200, dof_block=None, mixed_block=-1, refinementType='MEDIAN', planner='host'):
+def getNearFieldClusters(dm, eta=3., minClusterSize=None, maxLevels=200, dof_block=None, mixed_block=-1, refinementType='MEDIAN', planner='host',
+                         horizon=np.inf):
     """(root, Pnear, Pfar) for dm; both orientations (n1,n2) and (n2,n1) of off-diagonal pairs are listed, like the
     reference's recursion from (root, root).  dof_block / mixed_block (dofKernelBlocks): clusters are split by kernel block
     before anything else and only pairs of single-block clusters can be admissible (variable orders, NA:2619-2640)."""
@@ -332,7 +353,7 @@ def getNearFieldClusters(dm, eta=3., minClusterSize=None, maxLevels=200, dof_blo
     if dof_block is not None and not _use_native():
         raise NotImplementedError('cluster trees by kernel block: native planner only')
     if _use_native():
-        T = _nativeTree(dm, eta, minClusterSize, maxLevels, 1, dof_block, mixed_block, refinementType, planner)
+        T = _nativeTree(dm, eta, minClusterSize, maxLevels, 1, dof_block, mixed_block, refinementType, planner, horizon)
         T.load_cells(np.unique(T.near))
         Pnear = [nearFieldClusterPair(T.node(a), T.node(b)) for a, b in T.near]
         Pfar = {}
@@ -343,7 +364,7 @@ def getNearFieldClusters(dm, eta=3., minClusterSize=None, maxLevels=200, dof_blo
         raise NotImplementedError('refinementType {}: native planner only'.format(refinementType))
     root = getTree(dm)
     Pnear, Pfar = [], {}
-    getAdmissibleClusters(root, root, eta, minClusterSize, maxLevels, Pfar, Pnear)
+    getAdmissibleClusters(root, root, eta, minClusterSize, maxLevels, Pfar, Pnear, 0, horizon)
     for cp in Pnear:
         cp.set_cells()
     return root, Pnear, Pfar

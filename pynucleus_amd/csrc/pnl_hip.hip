@@ -2898,7 +2898,20 @@ int pnl_h2_setup(pnl_context *ctx, const pnl_h2_plan *pl) {
     if ((rc = check_ready(ctx))) return rc;
     if ((rc = finalize(ctx))) return rc;
     refresh_tables(ctx);
-    if (!std::isinf(ctx->C().kern[0].horizon2)) return fail(ctx, PNL_ERR_UNSUPPORTED, "H2 far field: infinite horizon only");
+    // finite horizon: every admissible pair must lie inside it (pnl_tree_build_horizon drops the pairs beyond the horizon and keeps the
+    // ones it may cut in the near field, clusterMethodCy.pyx:4069-4090); the interpolants are those of the kernel itself
+    if (!std::isinf(ctx->C().kern[0].horizon2)) {
+        if (ctx->have_xform) return fail(ctx, PNL_ERR_UNSUPPORTED, "H2 far field of a finite horizon: l2 ball only");
+        if (!pl->box || (pl->nfar > 0 && !pl->far)) return PNL_ERR_INVALID;
+        const double h2 = ctx->C().kern[0].horizon2;
+        for (int p = 0; p < pl->nfar; p++) {
+            const double *a = pl->box+(size_t)pl->far[2*p]*ctx->dim*2, *b = pl->box+(size_t)pl->far[2*p+1]*ctx->dim*2;
+            double d2 = 0.;
+            for (int d = 0; d < ctx->dim; d++) { const double e = std::max(a[2*d+1]-b[2*d], b[2*d+1]-a[2*d]); d2 += e*e; }
+            if (d2 > h2*(1.+1e-12))
+                return fail(ctx, PNL_ERR_INVALID, "H2 far field: the clusters of admissible pair %d reach beyond the horizon", p);
+        }
+    }
     }
     // (the admissible pairs are ORDERED -- (n1, n2) and (n2, n1) are two entries, each with the class of its orientation -- so a
     // non-symmetric order table needs nothing beyond its far_class)

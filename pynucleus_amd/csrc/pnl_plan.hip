@@ -116,12 +116,40 @@ void refine(pnl_tree *T, int k, int minSize, int maxLevels, std::vector<double> 
     }
 }
 
-bool admissible_rec(pnl_tree *T, int n1, int n2, double eta, int maxLevels, int level) {
+// interactionDomain.maxDistBoxes (interactionDomains.pyx:325-337), as written there
+double max_dist_boxes(const PNode &a, const PNode &b, int dim) {
+    double s = 0.;
+    for (int d = 0; d < dim; d++) {
+        const bool first = a.box[d][0] > b.box[d][0];
+        const double b1 = first ? b.box[d][0] : a.box[d][0], a2 = first ? a.box[d][1] : b.box[d][1];
+        const double e = std::max(a2-b1, 0.);
+        s += e*e;
+    }
+    return std::sqrt(s);
+}
+
+// horizon < inf (CM:4074-4090, 4115, 4131-4135): pairs of clusters farther apart than the horizon do not interact (reported as
+// "far field added" so that they are not merged into a near-field block), pairs the horizon may cut stay in the near field, and
+// near-field children are merged into one block only if the block fits into the horizon
+bool admissible_rec(pnl_tree *T, int n1, int n2, double eta, int maxLevels, int level, double horizon) {
     const PNode &a = T->nodes[n1], &b = T->nodes[n2];
     const double dist = dist_boxes(a, b, T->dim);
     // clusters of one kernel block each; the interface block stays in the near field (mixed_node, CM:4038)
     const bool pure = a.block >= 0 && b.block >= 0 && a.block != T->mixed_block && b.block != T->mixed_block;
-    if (pure && eta*dist >= std::max(diam_box(a, T->dim), diam_box(b, T->dim))) {
+    bool seems = pure && eta*dist >= std::max(diam_box(a, T->dim), diam_box(b, T->dim));
+    const bool finite = horizon < INFINITY;
+    double diamUnion = 0.;
+    if (finite) {
+        if (dist > horizon) return true;
+        if (horizon <= max_dist_boxes(a, b, T->dim)) seems = false;
+        double s = 0.;
+        for (int d = 0; d < T->dim; d++) {
+            const double e = std::max(a.box[d][1], b.box[d][1])-std::min(a.box[d][0], b.box[d][0]);
+            s += e*e;
+        }
+        diamUnion = std::sqrt(s);
+    }
+    if (seems) {
         T->far.push_back(n1); T->far.push_back(n2); T->far.push_back(level);
         return true;
     }
@@ -133,11 +161,11 @@ bool admissible_rec(pnl_tree *T, int n1, int n2, double eta, int maxLevels, int 
     }
     bool added = false;
     const int c1[2] = {a.child[0], a.child[1]}, c2[2] = {b.child[0], b.child[1]};
-    if (leaf1) { for (int j = 0; j < 2; j++) added |= admissible_rec(T, n1, c2[j], eta, maxLevels, level+1); }
-    else if (leaf2) { for (int i = 0; i < 2; i++) added |= admissible_rec(T, c1[i], n2, eta, maxLevels, level+1); }
+    if (leaf1) { for (int j = 0; j < 2; j++) added |= admissible_rec(T, n1, c2[j], eta, maxLevels, level+1, horizon); }
+    else if (leaf2) { for (int i = 0; i < 2; i++) added |= admissible_rec(T, c1[i], n2, eta, maxLevels, level+1, horizon); }
     else
-        for (int i = 0; i < 2; i++) for (int j = 0; j < 2; j++) added |= admissible_rec(T, c1[i], c2[j], eta, maxLevels, level+1);
-    if (!added) {
+        for (int i = 0; i < 2; i++) for (int j = 0; j < 2; j++) added |= admissible_rec(T, c1[i], c2[j], eta, maxLevels, level+1, horizon);
+    if (!added && (!finite || diamUnion < horizon)) {
         // no far-field pair below: keep the whole block as one near-field pair (CM:4131-4135)
         T->near.resize(lenNear);
         T->near.push_back(n1); T->near.push_back(n2);
@@ -163,6 +191,14 @@ int pnl_tree_build_blocks(int N, int dim, const double *boxes, const int64_t *d2
 int pnl_tree_build_refined(int N, int dim, const double *boxes, const int64_t *d2c_ptr, const int32_t *d2c_idx, int nc, double eta,
                            int min_size, int max_levels, int do_admissibility, const int32_t *dof_block, int mixed_block, int ref_type,
                            pnl_tree **out) {
+    return pnl_tree_build_horizon(N, dim, boxes, d2c_ptr, d2c_idx, nc, eta, min_size, max_levels, do_admissibility, dof_block, mixed_block,
+                                  ref_type, INFINITY, out);
+}
+
+int pnl_tree_build_horizon(int N, int dim, const double *boxes, const int64_t *d2c_ptr, const int32_t *d2c_idx, int nc, double eta,
+                           int min_size, int max_levels, int do_admissibility, const int32_t *dof_block, int mixed_block, int ref_type,
+                           double horizon, pnl_tree **out) {
+    if (!(horizon > 0.)) return PNL_ERR_INVALID;
     if (!out || N <= 0 || dim < 1 || dim > 3 || !boxes || !d2c_ptr || !d2c_idx || ref_type < 0 || ref_type > 2) return PNL_ERR_INVALID;
     if (dof_block) for (int i = 0; i < N; i++) if (dof_block[i] < 0) return PNL_ERR_INVALID;
     pnl_tree *T = new pnl_tree();
@@ -186,7 +222,7 @@ int pnl_tree_build_refined(int N, int dim, const double *boxes, const int64_t *d
     std::vector<int32_t> tmp;
     if (do_admissibility >= 0)
         for (size_t k = 0; k < T->nodes.size(); k++) refine(T, (int)k, min_size, max_levels, xs, tmp);
-    if (do_admissibility > 0) admissible_rec(T, 0, 0, eta, max_levels, 0);
+    if (do_admissibility > 0) admissible_rec(T, 0, 0, eta, max_levels, 0, horizon);
     *out = T;
     return PNL_OK;
 }

@@ -176,9 +176,9 @@ class DoFMap:
         np.add.at(b, self.dofs[m], loc[m])
         return fe_vector(b, self)
 
-    def assembleMass(self):
+    def assembleMass(self, qr=None):
         import scipy.sparse as sp
-        qr = self._volume_rule()
+        qr = self._volume_rule() if qr is None else qr
         phi = self.evalShapeFunctions(qr.nodes)
         Mloc = np.einsum('n,pn,qn->pq', qr.weights, phi, phi)
         nc, dpe = self.dofs.shape

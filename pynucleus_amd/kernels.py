@@ -384,6 +384,15 @@ class FractionalKernel(Kernel):
         return getFractionalKernel(self.dim, s, horizon, interaction, scaling, self.normalized, self.piecewise,
                                    None, self.boundary)
 
+    def getFullSpaceKernel(self):
+        """getModifiedKernel(horizon = inf) (kernelsCy.pyx:1085-1107) for a constant order: the same kernel on the full space with the
+        SAME scaling (the normalisation of the finite horizon is kept); the cluster method integrates cluster exteriors with its
+        boundary twin (NA:953-955)"""
+        if self.variable:
+            raise NotImplementedError('full-space twin of a variable-order kernel')
+        return FractionalKernel(self.dim, self.s, None, None, self.scalingPrePhi, phi=self.phi, piecewise=self.piecewise, boundary=self.boundary,
+                                normalized=self.normalized)
+
     def getBoundaryKernel(self):
         """Kernel obtained by eliminating the exterior via Gauss' theorem:
         Gamma_b = (C/s) |x-y|^{-(d-1)-2s}."""

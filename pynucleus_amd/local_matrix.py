@@ -17,7 +17,7 @@ import numpy as np
 from .quadrature import (COMMON_VERTEX, COMMON_EDGE, COMMON_FACE, simplexXiaoGimbutas, simplexDuffyTransformation,
                          singularityCancelationQuadRule1D, singularityCancelationQuadRule1D_boundary,
                          singularityCancelationQuadRule2D, singularityCancelationQuadRule2D_boundary)
-from .kernels import GAUSSIAN, EXPONENTIAL, FRACTIONAL
+from .kernels import GAUSSIAN, EXPONENTIAL, FRACTIONAL, ball2_retriangulation
 
 MAX_PANEL = 120       # nonlocalOperator.pyx:107
 QCAP_DEFAULT = 60     # highest distant order we tabulate up-front (the reference adds rules lazily)
@@ -125,11 +125,16 @@ class nonlocalTables:
         # surface integrals (NA:953-955): the Gauss-theorem twin is built whenever it exists, not only for zeroExterior --
         # the cluster-local boundary term of assembleClusters (NA:1842-1889) needs it too
         # (the integrable kernels of the full space, Gaussian and exponential, have one as well: kernelsCy.pyx:418-477)
-        self.has_boundary_tables = kernel.kernelType in (FRACTIONAL, GAUSSIAN, EXPONENTIAL) and not kernel.finiteHorizon
+        # finite horizon, fractional kernel of constant order: the near field of the cluster method (NA:953-955, 1842-1889, 1915-1940) integrates
+        # the exterior of a cluster pair with the twin of the SAME kernel on the full space (getModifiedKernel(horizon = inf), same
+        # scaling) and subtracts the part beyond the horizon as a multiple of the mass matrix
+        fh_near = kernel.finiteHorizon and kernel.kernelType == FRACTIONAL and not kernel.variable and isinstance(kernel.interaction, ball2_retriangulation) \
+            and not hasattr(kernel.interaction, 'transform')
+        self.has_boundary_tables = (kernel.kernelType in (FRACTIONAL, GAUSSIAN, EXPONENTIAL) and not kernel.finiteHorizon) or fh_near
         if self.zeroExterior and not self.has_boundary_tables:
             raise NotImplementedError('zeroExterior needs a fractional, Gaussian or exponential kernel on the full space')
         if self.has_boundary_tables:
-            bk = kernel.getBoundaryKernel()
+            bk = kernel.getFullSpaceKernel().getBoundaryKernel() if fh_near else kernel.getBoundaryKernel()
             if (kernel.min_singularity, kernel.max_singularity) != (sing, sing):
                 # class table of a variable-order kernel: the boundary twin inherits the range of singularities too
                 bk.min_singularity, bk.max_singularity = kernel.min_singularity+1., kernel.max_singularity+1.

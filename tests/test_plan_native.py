@@ -297,3 +297,45 @@ def test_device_planner_feeds_getH2():
         out.append((H.matvec(x), np.asarray(H.Anear.indptr), np.asarray(H.Anear.indices), H.info['numFarPairs']))
     assert np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][2], out[1][2]) and out[0][3] == out[1][3]
     assert np.abs(out[0][0]-out[1][0]).max() < 1e-13*np.abs(out[1][0]).max()
+
+
+@pytest.mark.parametrize('domain,N,horizon', [('square', 17, 0.3), ('square', 33, 0.15), ('interval', 8, 0.2), ('interval', 8, 1.0)])
+def test_native_planner_with_a_finite_horizon_equals_numpy(domain, N, horizon):
+    """getAdmissibleClusters with the horizon of the l2 ball (clusterMethodCy.pyx:4069-4090, 4131-4135): cluster pairs beyond the horizon
+    are dropped, pairs it may cut stay in the near field, near-field children merge only inside the horizon -- the C++ planner
+    (pnl_tree_build_horizon) and the Python restatement give the same ordered lists; every admissible pair lies inside the horizon and
+    no near / far pair lies beyond it"""
+    from pynucleus_amd import uniformSquare, NO_BOUNDARY
+    dm = P1_DoFMap(uniformSquare(N) if domain == 'square' else interval(N), NO_BOUNDARY)
+    old = os.environ.get('PNL_PLAN')
+    out = {}
+    try:
+        for mode in ('numpy', 'native'):
+            os.environ['PNL_PLAN'] = mode
+            out[mode] = clusters.getNearFieldClusters(dm, 3., 4, 200, horizon=horizon)
+    finally:
+        if old is None:
+            os.environ.pop('PNL_PLAN', None)
+        else:
+            os.environ['PNL_PLAN'] = old
+    (r0, n0, f0), (r1, n1, f1) = out['numpy'], out['native']
+    assert len(n0) == len(n1) > 0
+    for a, b in zip(n0, n1):
+        assert np.array_equal(a.n1.dofs, b.n1.dofs) and np.array_equal(a.n2.dofs, b.n2.dofs)
+    assert sorted(f0) == sorted(f1)
+    for lvl in f0:
+        assert [(tuple(a.n1.dofs), tuple(a.n2.dofs)) for a in f0[lvl]] == [(tuple(b.n1.dofs), tuple(b.n2.dofs)) for b in f1[lvl]]
+        for cp in f1[lvl]:
+            assert clusters.maxDistBoxes(np.asarray(cp.n1.box), np.asarray(cp.n2.box)) < horizon
+    for cp in n1:
+        assert clusters.distBoxes(np.asarray(cp.n1.box), np.asarray(cp.n2.box)) <= horizon
+    if domain == 'interval':
+        assert sum(len(v) for v in f1.values()) > 0
+    # the blocks of the near and far pairs tile what interacts: every pair of DoFs closer than the horizon is covered exactly once
+    cover = np.zeros((dm.num_dofs, dm.num_dofs), dtype=np.int32)
+    for cp in list(n1)+[c for v in f1.values() for c in v]:
+        cover[np.ix_(np.asarray(cp.n1.dofs), np.asarray(cp.n2.dofs))] += 1
+    assert cover.max() == 1
+    c = dm.getDoFCoordinates()
+    d = np.sqrt(((c[:, None, :]-c[None, :, :])**2).sum(axis=2))
+    assert cover[d < horizon-2.*dm.mesh.h].min() == 1
