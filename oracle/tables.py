@@ -527,7 +527,7 @@ class OracleTables:
         # ---- the Gauss-theorem twin for Omega x Omega^c (NA:953-955; kernelsCy.pyx:1982-2010: same s, phi = 1/s, one power less)
         # finite horizon, fractional kernel of constant order, l2 ball: the cluster method integrates the exterior of a cluster pair with the
         # twin of the SAME kernel on the full space -- getModifiedKernel(horizon = inf) keeps the scaling (NA:953-955, kernelsCy.pyx:1085-1107)
-        fh_near = finite and ktype == FRACTIONAL and _sing_range is None and spec.get('interaction', 0) == 1 and spec.get('ellipse') is None
+        fh_near = finite and ktype == FRACTIONAL and spec.get('interaction', 0) == 1 and spec.get('ellipse') is None
         self.has_boundary_tables = (ktype in (FRACTIONAL, GAUSSIAN, EXPONENTIAL) and not finite) or fh_near
         if self.zeroExterior and not self.has_boundary_tables:
             raise NotImplementedError('zeroExterior needs a fractional, Gaussian or exponential kernel on the full space')
@@ -535,7 +535,10 @@ class OracleTables:
             return
         if ktype == FRACTIONAL:
             bsing = 1.-dim-2.*s
-            self.boundaryKernel = KernelBlock(FRACTIONAL, 0.5*bsing, self.kernel.scale/s, np.inf if fh_near else horizon)
+            # (a class of a piecewise-constant order -- _sing_range is set -- keeps the TRUNCATED twin: NA:1966-2156 integrate with
+            # kernel.getBoundaryKernel(), facets beyond the horizon drop out)
+            self.boundaryKernel = KernelBlock(FRACTIONAL, 0.5*bsing, self.kernel.scale/s, np.inf if (fh_near and _sing_range is None) else horizon,
+                                              spec.get('interaction', 0) if (fh_near and _sing_range is not None) else 0)
         else:
             # kernelsCy.pyx:1194-1218: the same type, scaling and exponentInverse with boundary = True; kernelFun :418-477 (block ids 5 / 7
             # Gaussian in 1D / 2D, 6 exponential: nl_oracle.c kernel_eval); singularity 0 (:657-664)

@@ -697,10 +697,14 @@ class nonlocalBuilder:
             # field; the far field between two clusters uses the order between their blocks
             # (a non-symmetric order table s(l1, l2) != s(l2, l1) changes nothing here: cluster pairs are ordered, every one takes the
             # class of its orientation; the near field runs both orientations of every element pair, pnl_assemble_pairs_masked)
+            horizon = np.inf
             if self.kernel.finiteHorizon:
-                raise NotImplementedError('H2 operator of a finite-horizon variable order')
+                if not self.tables.has_boundary_tables:
+                    raise NotImplementedError('H2 operator of a finite-horizon variable order: fractional kernels with the l2 ball')
+                horizon = float(self.kernel.horizonValue)
             blk, mixed = clusters.dofKernelBlocks(self.dm, self.tables)
-            root, Pnear, Pfar = clusters.getNearFieldClusters(self.dm, rp['eta'], rp['minSize'], rp['maxLevels'], blk, mixed, rp['refinementType'])
+            root, Pnear, Pfar = clusters.getNearFieldClusters(self.dm, rp['eta'], rp['minSize'], rp['maxLevels'], blk, mixed, rp['refinementType'],
+                                                              horizon=horizon)
             cls_of = self.tables.cls_of
 
             def far_class(cp):
@@ -817,8 +821,8 @@ class nonlocalBuilder:
         if self._single_order_twin() is not None:
             return self._single_order_twin().assembleClusters(Pnear, forceUnsymmetricMatrix, Anear, jumps, myRoot, _clusterBoundary,
                                                               _globalBoundary, _symmetrizeMasks, **kwargs)
-        if self.kernel.variable and self.kernel.finiteHorizon:
-            raise NotImplementedError('near field of a finite-horizon variable order')
+        if self.kernel.variable and self.kernel.finiteHorizon and not self.tables.has_boundary_tables:
+            raise NotImplementedError('near field of a finite-horizon variable order: fractional kernels with the l2 ball')
         if self.kernel.variable and not self.kernel.symmetric:
             # both orientations of every element pair write both (I, J) and (J, I) of their entries: unsymmetric storage (the operator
             # itself is symmetric only if the table is)
@@ -905,12 +909,16 @@ class nonlocalBuilder:
         if self.tables.has_boundary_tables and self.kernel.variable:
             # piecewise-constant order: cluster exterior with the order of the region outside every facet, the interfaces of
             # the order, the global term -- one launch per (kernel class, sign) (NA:1966-2156)
-            for k, fac, cells, facets, bmasks in clusters.variableBoundaryItems(dm, Pnear, self.tables, self.zeroExterior, _symmetrizeMasks,
-                                                                                _clusterBoundary, _globalBoundary):
+            # (a finite horizon: cluster surfaces and interfaces with the TRUNCATED twins of the classes -- facets beyond the horizon give
+            # zero --, no global Omega x Omega^c term to take back; what lies beyond the horizon is subtracted below)
+            for k, fac, cells, facets, bmasks in clusters.variableBoundaryItems(dm, Pnear, self.tables, self.zeroExterior or self.kernel.finiteHorizon,
+                                                                                _symmetrizeMasks, _clusterBoundary, _globalBoundary):
                 ctx.select_class(k)
                 ctx.assemble_boundary_masked(cells, facets, bmasks, fac, data_ptr, diag_ptr)
                 nitems += int(cells.shape[0])
             ctx.select_class(0)
+            if self.kernel.finiteHorizon and _globalBoundary:
+                self._subtractBeyondHorizon(Anear)
         elif self.tables.has_boundary_tables and _clusterBoundary:
             cells, facets, bmasks = clusters.clusterBoundaryItems(dm, Pnear, symmetrize=_symmetrizeMasks)
             nitems = int(cells.shape[0])
@@ -944,8 +952,36 @@ class nonlocalBuilder:
         vol = 2. if dim == 1 else 2.*np.pi*delta
         x, y = np.zeros(dim), np.zeros(dim)
         y[0] = delta
-        coeff = -vol*float(self.tables.boundaryKernel(x, y))
-        M = (coeff*dm.assembleMass(simplexXiaoGimbutas(2, dim, dim))).tocoo()
+        qr = simplexXiaoGimbutas(2, dim, dim)
+        if not self.kernel.variable:
+            coeff = -vol*float(self.tables.boundaryKernelFull(x, y))
+            M = (coeff*dm.assembleMass(qr)).tocoo()
+        else:
+            # piecewise-constant order (NA:2143-2156, horizonSurfaceIntegral nonlocalAssembly.pyx:132-175): the surface of the ball by
+            # 2 points (1D) / 10 points of the circle (2D), the order between the point and each of them
+            T = self.tables
+            gam = np.array([float(c.boundaryKernelFull(x, y)) for c in T.classes])
+            mesh = self.mesh
+            v = mesh.vertices[mesh.cells]
+            xq = np.einsum('kn,ckd->cnd', qr.nodes, v)                          # [nc, nq, dim]
+            if dim == 1:
+                off, w = np.array([[delta], [-delta]]), np.array([1., 1.])
+            else:
+                th = 2.*np.pi*np.arange(10)/10.
+                off, w = delta*np.stack([np.cos(th), np.sin(th)], axis=1), np.full(10, 2.*np.pi/10.*delta)
+            sFun = self.kernel.s
+            lx = np.asarray(sFun.labels(xq.reshape(-1, dim))).reshape(xq.shape[:2])
+            coef = np.zeros(xq.shape[:2])
+            for k in range(off.shape[0]):
+                ly = np.asarray(sFun.labels((xq+off[k]).reshape(-1, dim))).reshape(xq.shape[:2])
+                coef -= w[k]*gam[np.asarray(T.cls_of)[lx, ly]]
+            phi = dm.evalShapeFunctions(qr.nodes)
+            loc = np.einsum('cn,n,pn,qn->cpq', coef, qr.weights, phi, phi)*mesh.volVector[:, None, None]
+            dpe = dm.dofs.shape[1]
+            I = np.repeat(dm.dofs[:, :, None], dpe, axis=2)
+            J = np.repeat(dm.dofs[:, None, :], dpe, axis=1)
+            m = (I >= 0) & (J >= 0)
+            M = sp.csr_matrix((loc[m], (I[m], J[m])), shape=(dm.num_dofs, dm.num_dofs)).tocoo()
         n = dm.num_dofs
         indptr, indices = np.asarray(Anear.indptr), np.asarray(Anear.indices)
         pos = sp.csr_matrix((np.arange(1, indices.shape[0]+1, dtype=np.int64), indices, indptr), shape=(n, n))

@@ -2906,8 +2906,14 @@ int pnl_h2_setup(pnl_context *ctx, const pnl_h2_plan *pl) {
         const double h2 = ctx->C().kern[0].horizon2;
         for (int p = 0; p < pl->nfar; p++) {
             const double *a = pl->box+(size_t)pl->far[2*p]*ctx->dim*2, *b = pl->box+(size_t)pl->far[2*p+1]*ctx->dim*2;
+            // maxDistBoxes as the reference writes it (interactionDomains.pyx:325-337): what its admissibility test compares with the
+            // horizon; interpolation nodes that do lie beyond the horizon get the kernel value 0 there and here (kern_eval)
             double d2 = 0.;
-            for (int d = 0; d < ctx->dim; d++) { const double e = std::max(a[2*d+1]-b[2*d], b[2*d+1]-a[2*d]); d2 += e*e; }
+            for (int d = 0; d < ctx->dim; d++) {
+                const bool first = a[2*d] > b[2*d];
+                const double e = std::max((first ? a[2*d+1] : b[2*d+1])-(first ? b[2*d] : a[2*d]), 0.);
+                d2 += e*e;
+            }
             if (d2 > h2*(1.+1e-12))
                 return fail(ctx, PNL_ERR_INVALID, "H2 far field: the clusters of admissible pair %d reach beyond the horizon", p);
         }

@@ -399,7 +399,7 @@ class FractionalKernel(Kernel):
         if self.variable:
             return FractionalKernel(self.dim, self.s, None if self.pointwise else self.horizon, None, None, phi=None,
                                     piecewise=self.piecewise, boundary=True, normalized=self.normalized)
-        return FractionalKernel(self.dim, self.s, self.horizon, None, self.scalingPrePhi,
+        return FractionalKernel(self.dim, self.s, self.horizon, self.interaction if self.finiteHorizon else None, self.scalingPrePhi,
                                 phi=constantTwoPoint(1./self.sValue), piecewise=self.piecewise, boundary=True,
                                 normalized=self.normalized)
 

@@ -134,7 +134,14 @@ class nonlocalTables:
         if self.zeroExterior and not self.has_boundary_tables:
             raise NotImplementedError('zeroExterior needs a fractional, Gaussian or exponential kernel on the full space')
         if self.has_boundary_tables:
-            bk = kernel.getFullSpaceKernel().getBoundaryKernel() if fh_near else kernel.getBoundaryKernel()
+            bk = kernel.getBoundaryKernel()
+            if fh_near:
+                # a class of a piecewise-constant order keeps the TRUNCATED twin (NA:1966-2156 integrate cluster surfaces and interfaces
+                # with local_matrix_surface = kernel.getBoundaryKernel(): facets beyond the horizon drop out); the full-space twin gives
+                # the value on the sphere (horizonSurfaceIntegral, nonlocalAssembly.pyx:132-175)
+                self.boundaryKernelFull = kernel.getFullSpaceKernel().getBoundaryKernel()
+                if not params.get('_classOfVariable', False):
+                    bk = self.boundaryKernelFull
             if (kernel.min_singularity, kernel.max_singularity) != (sing, sing):
                 # class table of a variable-order kernel: the boundary twin inherits the range of singularities too
                 bk.min_singularity, bk.max_singularity = kernel.min_singularity+1., kernel.max_singularity+1.
@@ -169,6 +176,8 @@ class nonlocalTables:
         cparams = dict(params or {})
         if not kernel.symmetric:
             cparams['_nonsymInterior'] = True
+        if kernel.finiteHorizon:
+            cparams['_classOfVariable'] = True
         self.classes = [nonlocalTables(dm, kernel.constantOrderKernel(sv), cparams, zeroExterior, qcap) for sv in vals]
         c0 = self.classes[0]
         for name in ('dm', 'dim', 'dpe', 'num_dofs', 'hmin', 'H0', 'dof_perm_table', 'qcap', 'zeroExterior', 'has_boundary_tables',

@@ -339,7 +339,7 @@ def _beyond_horizon_correction(tables, indptr, indices, symmetric):
     dm, dim, delta = tables.dm, tables.dim, float(tables.kernel.horizonValue)
     x, y = np.zeros(dim), np.zeros(dim)
     y[0] = delta
-    coeff = -(2. if dim == 1 else 2.*np.pi*delta)*float(tables.boundaryKernel(x, y))
+    coeff = -(2. if dim == 1 else 2.*np.pi*delta)*float(tables.boundaryKernelFull(x, y))
     M = (coeff*dm.assembleMass(simplexXiaoGimbutas(2, dim, dim))).toarray()
     rows = np.repeat(np.arange(dm.num_dofs), np.diff(indptr))
     return M[rows, indices], (np.diag(M).copy() if symmetric else None)

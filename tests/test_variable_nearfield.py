@@ -393,3 +393,150 @@ def test_gpu_nonsym_var_h2_vs_dense(order, domain, noRef):
     # exterior and interface terms take s(cell -> outside) alone where the element pairs use both orientations (see
     # test_oracle_nonsym_var_cluster_matches_dense); observed 0.4e-2 (square) ... 4e-2 (disc, interval)
     assert np.abs(y-yd).max() < 1e-1*np.abs(yd).max()
+
+
+# ---- piecewise-constant order with a finite horizon (NA:1966-2156) -----------------------------------------------------------------
+def _fh_setup(order, N, delta, domain='square'):
+    from pynucleus_amd import uniformSquare, interval, NO_BOUNDARY, P1_DoFMap, getFractionalKernel
+    mesh = uniformSquare(N, None, -1., -1., 1., 1.) if domain == 'square' else interval(N)
+    dm = P1_DoFMap(mesh, NO_BOUNDARY)
+    return dm, getFractionalKernel(mesh.dim, _order(order, mesh.dim), horizon=delta)
+
+
+def _beyond_horizon_variable(T, indptr, indices, symmetric):
+    """horizonSurfaceIntegral (nonlocalAssembly.pyx:132-175) times the mass matrix, restated with plain loops over cells and points:
+    coeff(x) = -sum_k w_k Gamma_b(x, x + horizon e_k) with the order between x and every one of the 2 (1D) / 10 (2D) points"""
+    from pynucleus_amd.quadrature import simplexXiaoGimbutas
+    dm, dim, delta = T.dm, T.dim, float(T.kernel.horizonValue)
+    mesh, sFun = dm.mesh, T.kernel.s
+    qr = simplexXiaoGimbutas(2, dim, dim)
+    phi = dm.evalShapeFunctions(qr.nodes)
+    if dim == 1:
+        pts, w = [np.array([delta]), np.array([-delta])], [1., 1.]
+    else:
+        pts = [delta*np.array([np.cos(2.*np.pi*k/10.), np.sin(2.*np.pi*k/10.)]) for k in range(10)]
+        w = [2.*np.pi/10.*delta]*10
+    x0, y0 = np.zeros(dim), np.zeros(dim)
+    y0[0] = delta
+    gam = [float(c.boundaryKernelFull(x0, y0)) for c in T.classes]
+    n = dm.num_dofs
+    M = np.zeros((n, n))
+    for c in range(mesh.num_cells):
+        v = mesh.vertices[mesh.cells[c]]
+        for q in range(qr.nodes.shape[1]):
+            x = qr.nodes[:, q]@v
+            lx = int(sFun.labels(x[None, :])[0])
+            coeff = 0.
+            for p, wk in zip(pts, w):
+                coeff -= wk*gam[int(T.cls_of[lx, int(sFun.labels((x+p)[None, :])[0])])]
+            for a in range(dm.dofs.shape[1]):
+                for b in range(dm.dofs.shape[1]):
+                    I, J = dm.dofs[c, a], dm.dofs[c, b]
+                    if I >= 0 and J >= 0:
+                        M[I, J] += mesh.volVector[c]*qr.weights[q]*coeff*phi[a, q]*phi[b, q]
+    rows = np.repeat(np.arange(n), np.diff(indptr))
+    return M[rows, indices], (np.diag(M).copy() if symmetric else None)
+
+
+def _oracle_near_fh(T, Pnear, symmetric):
+    from pynucleus_amd import clusters
+    from oracle.oracle import OracleProblem, assemble_clusters_variable
+    dm = T.dm
+    indptr, indices = clusters.getSparseNearField(dm, Pnear, symmetric=symmetric)
+    pairs, masks = clusters.buildMasksForClusters(dm, Pnear)
+    groups = clusters.variableBoundaryItems(dm, Pnear, T, True)           # no global Omega x Omega^c term (NA:2110 vs 2143)
+    data, diag, cnt = assemble_clusters_variable(OracleProblem(T), pairs, masks, groups, indptr, indices, symmetric)
+    cd, cdiag = _beyond_horizon_variable(T, indptr, indices, symmetric)
+    return indptr, indices, data+cd, (diag+cdiag if symmetric else None)
+
+
+@pytest.mark.parametrize('order,domain,N,delta', [('layers', 'interval', 6, 0.3), ('leftRight', 'interval', 6, 0.6), ('leftRight', 'square', 33, 0.5)])
+def test_oracle_var_finite_horizon_near_field_reproduces_the_dense_entries(order, domain, N, delta):
+    """piecewise-constant order with a finite horizon, the near field as the cluster method builds it: element pairs per class with the
+    truncated kernel, cluster surfaces and interfaces with the TRUNCATED twin of every class (facets beyond the horizon drop out),
+    minus the sphere term with the order between the point and the points of the sphere -- against the oracle's dense operator on
+    the DoF pairs whose horizon stays inside the mesh"""
+    from pynucleus_amd import clusters
+    from pynucleus_amd.local_matrix import nonlocalTables
+    from oracle.oracle import OracleProblem
+    dm, kernel = _fh_setup(order, N, delta, domain)
+    T = nonlocalTables(dm, kernel, {}, zeroExterior=False)
+    assert T.has_boundary_tables and not T.zeroExterior
+    assert all(c.boundaryKernel.finiteHorizon and not c.boundaryKernelFull.finiteHorizon for c in T.classes)
+    blk, mixed = clusters.dofKernelBlocks(dm, T)
+    root, Pnear, Pfar = clusters.getNearFieldClusters(dm, 3., 4, 200, blk, mixed, horizon=delta)
+    indptr, indices, data, _ = _oracle_near_fh(T, Pnear, False)
+    D = OracleProblem(T).get_dense()[0]
+    n = dm.num_dofs
+    A = np.zeros((n, n))
+    A[np.repeat(np.arange(n), np.diff(indptr)), indices] = data
+    c = dm.getDoFCoordinates()
+    inner = np.where(np.all(np.abs(c) < 1.-delta-3.*dm.mesh.h, axis=1))[0]
+    assert inner.size > 0
+    blkx = np.ix_(inner, inner)
+    stored = A[blkx] != 0.
+    assert stored.any()
+    # tests/test_nearField.py: epsAbsDense = 7e-3 (1D) / 5e-3 (2D) with a finite horizon, absolute
+    # (2D: the truncated twin is integrated over facets the horizon cuts with plain Gauss rules, like the reference: h = 0.09 here)
+    assert np.abs((A-D)[blkx][stored]).max() <= (7e-3 if dm.mesh.dim == 1 else 6e-3)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('order,domain,N,delta,symmetric', [('leftRight', 'square', 9, 0.6, True), ('layers', 'square', 9, 0.45, False),
+                                                           ('layers', 'interval', 6, 0.3, True)])
+def test_gpu_var_finite_horizon_near_field_vs_oracle(order, domain, N, delta, symmetric):
+    """assembleClusters of a piecewise-constant order with a finite horizon on the GPU == oracle entry-wise"""
+    from pynucleus_amd import clusters
+    from pynucleus_amd.builder import nonlocalBuilder
+    dm, kernel = _fh_setup(order, N, delta, domain)
+    b = nonlocalBuilder(dm, kernel, {}, zeroExterior=False)
+    dm, T = b.dm, b.tables
+    blk, mixed = clusters.dofKernelBlocks(dm, T)
+    root, Pnear, Pfar = clusters.getNearFieldClusters(dm, 3., 4, 200, blk, mixed, horizon=delta)
+    Anear = b.assembleClusters(Pnear, forceUnsymmetricMatrix=not symmetric)
+    indptr, indices, data, diag = _oracle_near_fh(T, Pnear, symmetric)
+    assert np.array_equal(Anear.indptr, indptr) and np.array_equal(Anear.indices, indices)
+    scale = np.abs(data).max()
+    assert np.abs(Anear.data-data).max() <= 1e-11*scale
+    if symmetric:
+        assert np.abs(Anear.diagonal-diag).max() <= 1e-11*max(scale, np.abs(diag).max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('order,domain,N,delta', [('leftRight', 'square', 33, 0.7), ('layers', 'interval', 9, 0.5)])
+def test_gpu_var_finite_horizon_h2(order, domain, N, delta):
+    """getH2 of a piecewise-constant order with a finite horizon: admissible pairs inside the horizon, by kernel block; the far field
+    against the oracle (kernel parameters at the interpolation nodes), the near field against the oracle, and in 1D the product
+    against the oracle's dense operator on the DoFs whose horizon stays inside the mesh"""
+    import torch
+    from pynucleus_amd.builder import nonlocalBuilder
+    from pynucleus_amd.quadrature import simplexXiaoGimbutas
+    from pynucleus_amd.h2 import H2Matrix
+    from oracle import h2_oracle
+    from oracle.oracle import OracleProblem
+    dm, kernel = _fh_setup(order, N, delta, domain)
+    b = nonlocalBuilder(dm, kernel, {'eta': 3., 'minClusterSize': 4}, zeroExterior=False)
+    dm = b.dm                                      # (cells grouped by label: the builder's own DoF map)
+    h2, Pnear, root = b.getH2(returnNearField=True, returnTree=True)
+    assert isinstance(h2, H2Matrix) and h2.plan.far.shape[0] > 0
+    m = h2.plan.m
+    qr = simplexXiaoGimbutas(m+dm.polynomialOrder+1, dm.mesh.dim, dm.mesh.dim)
+    F = h2_oracle.far_field_dense(dm, _var_kernel_fun(b.kernel), root, h2.Pfar, m, qr)
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal(dm.num_dofs)
+    far_gpu = h2.matvec(x)-h2.Anear.matvec(x)
+    assert np.abs(far_gpu-F@x).max() <= 1e-11*np.abs(F).max()*dm.num_dofs
+    indptr, indices, data, _ = _oracle_near_fh(b.tables, Pnear, False)
+    near = h2.Anear.toarray()
+    ref = np.zeros_like(near)
+    ref[np.repeat(np.arange(dm.num_dofs), np.diff(indptr)), indices] = data
+    assert np.abs(near-ref).max() <= 1e-11*np.abs(ref).max()
+    if domain == 'interval':
+        D = OracleProblem(b.tables).get_dense()[0]
+        c = dm.getDoFCoordinates()
+        inner = np.all(np.abs(c) < 1.-delta-4.*dm.mesh.h, axis=1)
+        assert inner.sum() > 8
+        x = np.zeros(dm.num_dofs)
+        x[inner] = rng.standard_normal(int(inner.sum()))
+        y = h2.matvec(torch.from_numpy(x).cuda()).cpu().numpy()
+        assert np.linalg.norm((y-D@x)[inner]) <= 3e-2*np.linalg.norm((D@x)[inner])
