@@ -821,8 +821,8 @@ class nonlocalBuilder:
         if self._single_order_twin() is not None:
             return self._single_order_twin().assembleClusters(Pnear, forceUnsymmetricMatrix, Anear, jumps, myRoot, _clusterBoundary,
                                                               _globalBoundary, _symmetrizeMasks, **kwargs)
-        if self.kernel.variable and self.kernel.finiteHorizon and not self.tables.has_boundary_tables:
-            raise NotImplementedError('near field of a finite-horizon variable order: fractional kernels with the l2 ball')
+        if self.kernel.variable and self.kernel.finiteHorizon and (not self.tables.has_boundary_tables or not self.kernel.symmetric):
+            raise NotImplementedError('near field of a finite-horizon variable order: fractional kernels with the l2 ball and a symmetric table')
         if self.kernel.variable and not self.kernel.symmetric:
             # both orientations of every element pair write both (I, J) and (J, I) of their entries: unsymmetric storage (the operator
             # itself is symmetric only if the table is)

@@ -1845,7 +1845,10 @@ int horizon_impl(pnl_context *ctx, SparseOut S, int cell_begin, int cell_end) {
     using TS = TileSmem<DIM, DPE, TILE, KT == 0>;
     const int acc_stride = acc_stride_of(ctx->nU, TS::fixed_bytes);
     const size_t lds = TS::fixed_bytes+sizeof(double)*(size_t)(ctx->nU+1)*acc_stride;
-    const bool use_tiles = T == TILE && lds <= 160*1024 && !pnl_tune("PNL_FH_NOTILES");
+    // piecewise-constant order: the candidate pairs of a chunk once (k_fh_pairs), then the sorted pipeline once per order class and
+    // orientation, whose classification keeps the pairs of the class (like pnl_assemble_pairs_masked)
+    const bool var = ctx->nlab > 0;
+    const bool use_tiles = T == TILE && lds <= 160*1024 && !pnl_tune("PNL_FH_NOTILES") && !var;
     if (!use_tiles && !whole) return fail(ctx, PNL_ERR_UNSUPPORTED, "a range of first cells needs the tile route of the finite-horizon assembly");
     ctx->visited_is_assembled = use_tiles;
     for (size_t t0 = 0; t0 < tiles.size(); t0 += chunk_tiles) {
@@ -1878,6 +1881,17 @@ int horizon_impl(pnl_context *ctx, SparseOut S, int cell_begin, int cell_end) {
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
         if (np > cap) return fail(ctx, PNL_ERR_STATE, "far list of the finite-horizon tiles overflowed (%u > %zu)", np, cap);
         total += np;
+        if (np && var) {
+            const int ncls = (int)ctx->cls.size(), norient = ctx->nonsym ? 2 : 1, cur0 = ctx->cur;
+            for (int ko = 0; ko < ncls*norient && !rc; ko++) {
+                ctx->cur = ko/norient; ctx->orient = ko%norient;
+                refresh_tables(ctx);
+                rc = pairs_masked_impl<DIM, DPE, 0>(ctx, (int)np, S, true, false, false);
+            }
+            ctx->cur = cur0; ctx->orient = 0;
+            refresh_tables(ctx);
+            if (rc) return rc;
+        } else
         if (np && (rc = pairs_masked_impl<DIM, DPE, KT>(ctx, (int)np, S, false, false, use_tiles))) return rc;
         if (!np && use_tiles) {
             // no far entries in this chunk: the diagonal blocks of its tiles still have to reach the matrix
@@ -2715,7 +2729,9 @@ int pnl_assemble_pairs_in_horizon_range(pnl_context *ctx, double *data, double *
     int rc;
     if ((rc = check_ready(ctx))) return rc;
     if ((rc = finalize(ctx))) return rc;
-    if (ctx->nlab > 0) return fail(ctx, PNL_ERR_UNSUPPORTED, "finite horizon with a variable order");
+    // (a non-symmetric order table would need the pairs the horizon cuts re-triangulated with the roles of the two cells swapped in the
+    // second orientation, NA:1418 swapCells: the cut evaluation of the sorted pipeline takes the listed order)
+    if (ctx->nlab > 0 && ctx->nonsym) return fail(ctx, PNL_ERR_UNSUPPORTED, "finite horizon with a non-symmetric order table");
     if (std::isinf(ctx->C().kern[0].horizon2)) return fail(ctx, PNL_ERR_STATE, "pnl_assemble_pairs_in_horizon needs a finite horizon");
     if (ctx->qmax > PNL_CUT_SHIFT) return fail(ctx, PNL_ERR_UNSUPPORTED, "finite horizon: upload distant rules up to order %d at most", PNL_CUT_SHIFT);
     SparseOut S;

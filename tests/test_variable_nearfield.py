@@ -540,3 +540,24 @@ def test_gpu_var_finite_horizon_h2(order, domain, N, delta):
         x[inner] = rng.standard_normal(int(inner.sum()))
         y = h2.matvec(torch.from_numpy(x).cuda()).cpu().numpy()
         assert np.linalg.norm((y-D@x)[inner]) <= 3e-2*np.linalg.norm((D@x)[inner])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('order,domain,N,delta', [('leftRight', 'square', 9, 0.6), ('layers', 'square', 17, 0.3), ('layers', 'interval', 6, 0.3)])
+def test_gpu_var_finite_horizon_sparse_and_dense_vs_oracle(order, domain, N, delta):
+    """getSparse / getDense of a piecewise-constant order with a finite horizon (NA:1062-1260 with the class of every element pair): the
+    candidate pairs once per order class through the sorted pipeline; GPU == oracle"""
+    from pynucleus_amd.builder import nonlocalBuilder
+    from oracle.oracle import OracleProblem
+    dm, kernel = _fh_setup(order, N, delta, domain)
+    b = nonlocalBuilder(dm, kernel, {}, zeroExterior=False)
+    Aref, cnt, _ = OracleProblem(b.tables).get_dense()
+    D = b.getDense()
+    assert np.abs(D.toarray()-Aref).max() <= 1e-11*np.abs(Aref).max()
+    A = b.getSparse()
+    assert np.abs(A.toarray()-Aref).max() <= 1e-11*np.abs(Aref).max()
+    assert A.info['counters']['numAssembledCellPairs'] == cnt['numAssembledCellPairs']
+    # a non-symmetric table needs the cut pairs re-triangulated with swapped roles in the second orientation: refused
+    dm2, k2 = _fh_setup('leftRightNS', 9, 0.6, 'square')
+    with pytest.raises(NotImplementedError):
+        nonlocalBuilder(dm2, k2, {}, zeroExterior=False).getDense()
