@@ -233,8 +233,12 @@ class nonlocalBuilder:
     def __init__(self, dm, kernel, params={}, zeroExterior=True, comm=None, PLogger=None, dm2=None, device=None, **kwargs):
         if 'boundary' in kwargs:
             zeroExterior = kwargs.pop('boundary')           # deprecated alias, NA:888-890
+        # two DoFMaps (NA:879-901, 1366-1375): the rows are the DoFs of dm, the columns those of dm2 -- like the reference, the operator
+        # is assembled over the combined map (dm.combine(dm2): the DoFs of dm first) and the block rows x columns is kept
+        self._dm_pair = None
         if dm2 is not None:
-            raise NotImplementedError('assembly with two DoFMaps')
+            self._dm_pair = (int(dm.num_dofs), int(dm2.num_dofs))
+            dm = dm.combine(dm2)
         self.PLogger = PLogger if PLogger is not None else FakePLogger()
         self.comm = comm
         self.params = dict(params)
@@ -342,6 +346,17 @@ class nonlocalBuilder:
 
     # ------------------------------------------------------------------
     def getDense(self, trySparsification=False, distributed=False):
+        """NA:1262-1473; with two DoFMaps the block (DoFs of dm) x (DoFs of dm2) of the operator over the combined map (NA:1366-1375)"""
+        if self._dm_pair is None:
+            return self._getDense(trySparsification, distributed)
+        if trySparsification or distributed:
+            raise NotImplementedError('two DoFMaps: getDense() on one GPU')
+        from .linear_operators import Dense_LinearOperator
+        full = self._getDense()
+        n1, n2 = self._dm_pair
+        return Dense_LinearOperator(full.A[:n1, n1:n1+n2], full.ctx, full.info, symmetric=False)
+
+    def _getDense(self, trySparsification=False, distributed=False):
         """Assemble the dense operator on the GPU (NA:1262-1473).
 
         comm=None: full matrix on this GPU.  With a torch.distributed group as comm the element pairs
@@ -541,6 +556,8 @@ class nonlocalBuilder:
         (REMOTE / INTERACT / CUT, getRelativePosition), integrated (cut pairs through the sub-simplex loops NO:790-847) and
         scattered without masks into the sparsity pattern of all DoF pairs that share such an element pair.  Symmetric
         storage (SSS) unless params['forceUnsymmetric']."""
+        if self._dm_pair is not None:
+            raise NotImplementedError('two DoFMaps: getDense only')
         self._symmetric_only('getSparse')
         import torch
         import scipy.sparse as sp
@@ -680,6 +697,8 @@ class nonlocalBuilder:
         Without an admissible pair the dense operator is returned (the reference's assembleDenseWhenH2Fails branch).  With a
         communicator (row-sharded near field) the near-field operator alone is returned: the far field is not
         distributed yet."""
+        if self._dm_pair is not None:
+            raise NotImplementedError('two DoFMaps: getDense only')
         if self._single_order_twin() is not None:
             return self._single_order_twin().getH2(returnNearField, returnTree, **kwargs)
         from . import clusters
@@ -816,6 +835,8 @@ class nonlocalBuilder:
         (buildMasksForClusters NA:260-391) and the item list of the cluster-local Gauss-theorem term
         (NA:1842-1889).  Device side: classification, quadrature and masked scatter into CSR / SSS.
         Without zeroExterior the global Omega x Omega^c term is subtracted again (NA:1896-1913)."""
+        if self._dm_pair is not None:
+            raise NotImplementedError('two DoFMaps: getDense only')
         if getattr(self.tables, 'pointwise', False):
             return self._assembleClustersPointwise(Pnear, Anear, myRoot, _clusterBoundary, _globalBoundary)
         if self._single_order_twin() is not None:

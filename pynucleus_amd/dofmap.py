@@ -128,6 +128,29 @@ class DoFMap:
     def _set_nodes(self):
         raise NotImplementedError()
 
+    def getComplementDoFMap(self):
+        """DoFMaps.pyx getComplementDoFMap: the same element on the same mesh with the roles swapped -- its DoFs are the boundary DoFs
+        of this map (boundary DoF -1-k becomes DoF k), the DoFs of this map are its boundary"""
+        import copy
+        dmc = copy.copy(self)
+        dmc.dofs = np.ascontiguousarray((-1-self.dofs).astype(self.dofs.dtype))
+        dmc.num_dofs, dmc.num_boundary_dofs = int(self.num_boundary_dofs), int(self.num_dofs)
+        return dmc
+
+    def combine(self, other):
+        """DoFMaps.pyx combine: one map over the DoFs of both (those of ``self`` first, then those of ``other``); the two maps live on the
+        same mesh with the same element and share no DoF"""
+        import copy
+        assert type(self) is type(other) and self.dofs.shape == other.dofs.shape
+        assert self.mesh is other.mesh or np.array_equal(self.mesh.cells, other.mesh.cells)
+        assert not ((self.dofs >= 0) & (other.dofs >= 0)).any(), 'the two DoFMaps share DoFs'
+        dmc = copy.copy(self)
+        d = np.where(self.dofs >= 0, self.dofs, np.where(other.dofs >= 0, self.num_dofs+other.dofs, self.dofs))
+        dmc.dofs = np.ascontiguousarray(d.astype(self.dofs.dtype))
+        dmc.num_dofs = int(self.num_dofs+other.num_dofs)
+        dmc.num_boundary_dofs = int(len(np.unique(d[d < 0])))
+        return dmc
+
     def cell2dof(self, cellNo, perCellNo):
         return int(self.dofs[cellNo, perCellNo])
 

@@ -64,7 +64,11 @@ class Dense_LinearOperator:
         assert xd.shape[0] == self.num_columns
         yd = torch.empty(self.num_rows, dtype=torch.float64, device=dev)
         torch.cuda.current_stream(dev).synchronize()
-        self.ctx.gemv(self.A.data_ptr(), self.A.stride(0), self.num_rows, xd.data_ptr(), yd.data_ptr(), 2 if self.symmetric else 0)
+        if self.num_rows == self.num_columns:
+            self.ctx.gemv(self.A.data_ptr(), self.A.stride(0), self.num_rows, xd.data_ptr(), yd.data_ptr(), 2 if self.symmetric else 0)
+        else:
+            # a rectangular block (two DoFMaps): y = 1 * A x + 0 * b
+            self.ctx.gemv_axpby(self.A.data_ptr(), self.A.stride(0), self.num_rows, self.num_columns, xd.data_ptr(), 1., 0., None, yd.data_ptr())
         self.ctx.synchronize()
         if isinstance(x, torch.Tensor):
             if y is not None:

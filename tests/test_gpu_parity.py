@@ -785,3 +785,30 @@ def test_lambda_fractional_order_dense_and_h2():
     # the labels are numbered in the order the tabulation meets them: the kernel blocks hang under the tree in another order, another
     # (equally valid) tree -- the two H2 operators agree to the accuracy of the far-field interpolation
     assert np.abs(out[0][1]-out[1][1]).max() < 1e-4*np.abs(out[0][1]).max()
+
+
+@pytest.mark.parametrize('element,domain,noRef,s', [('P1', 'disc', 3, 0.75), ('P1', 'interval', 5, 0.25), ('P2', 'disc', 2, 0.5)])
+def test_two_dofmaps_dense_block(element, domain, noRef, s):
+    """nonlocalBuilder(dm, kernel, dm2=dmBC).getDense() (NA:879-901, 1366-1375; examples/example_InfHorizonDirichlet.py): the block
+    (interior DoFs) x (boundary DoFs) of the operator over the combined map, against the oracle's operator of that map"""
+    import torch
+    from pynucleus_amd import disc, interval, PHYSICAL, dofmapFactory, getFractionalKernel
+    from pynucleus_amd.builder import nonlocalBuilder
+    from pynucleus_amd.local_matrix import nonlocalTables
+    from oracle.oracle import OracleProblem
+    mesh = disc(noRef) if domain == 'disc' else interval(noRef)
+    dm = dofmapFactory(element, mesh, PHYSICAL)
+    dmBC = dm.getComplementDoFMap()
+    kernel = getFractionalKernel(mesh.dim, s)
+    B = nonlocalBuilder(dm, kernel, {'target_order': 0.5} if domain == 'disc' else {}, zeroExterior=True, dm2=dmBC).getDense()
+    assert B.shape == (dm.num_dofs, dmBC.num_dofs)
+    both = dm.combine(dmBC)
+    Aref = OracleProblem(nonlocalTables(both, kernel, {'target_order': 0.5} if domain == 'disc' else {}, zeroExterior=True)).get_dense()[0]
+    ref = Aref[:dm.num_dofs, dm.num_dofs:]
+    assert np.abs(B.toarray()-ref).max() <= TOL*np.abs(Aref).max()
+    x = np.random.default_rng(4).standard_normal(dmBC.num_dofs)
+    assert np.abs(B*x-ref@x).max() <= 1e-11*np.abs(Aref).max()*dmBC.num_dofs
+    y = B.matvec(torch.from_numpy(x).cuda())
+    assert np.abs(y.cpu().numpy()-ref@x).max() <= 1e-11*np.abs(Aref).max()*dmBC.num_dofs
+    with pytest.raises(NotImplementedError):
+        nonlocalBuilder(dm, kernel, {}, zeroExterior=True, dm2=dmBC).getH2()

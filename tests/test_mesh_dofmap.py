@@ -124,3 +124,25 @@ def test_label_blocks_partition():
     # one label: nothing to do
     dm = P1_DoFMap(disc(3), PHYSICAL)
     assert label_blocks(dm, np.zeros(dm.mesh.num_cells, dtype=np.int32)) is dm
+
+
+@pytest.mark.parametrize('element,domain', [('P1', 'disc'), ('P2', 'disc'), ('P1', 'interval'), ('P0', 'disc')])
+def test_complement_and_combined_dofmaps(element, domain):
+    """getComplementDoFMap / combine (DoFMaps.pyx): the complement numbers exactly the boundary DoFs, the combined map the DoFs of both
+    (the first map's first), and equals the map without boundary up to the numbering"""
+    from pynucleus_amd import disc, interval, PHYSICAL, NO_BOUNDARY, dofmapFactory
+    mesh = disc(2) if domain == 'disc' else interval(4)
+    dm = dofmapFactory(element, mesh, PHYSICAL)
+    dmc = dm.getComplementDoFMap()
+    assert dmc.num_dofs == dm.num_boundary_dofs and dmc.num_boundary_dofs == dm.num_dofs
+    assert ((dm.dofs >= 0) != (dmc.dofs >= 0)).all()
+    both = dm.combine(dmc)
+    allm = dofmapFactory(element, mesh, NO_BOUNDARY)
+    assert both.num_dofs == dm.num_dofs+dmc.num_dofs == allm.num_dofs and (both.dofs >= 0).all()
+    assert np.array_equal(both.dofs[dm.dofs >= 0], dm.dofs[dm.dofs >= 0])
+    assert np.array_equal(both.dofs[dmc.dofs >= 0], dm.num_dofs+dmc.dofs[dmc.dofs >= 0])
+    # the same partition of the local DoFs into global ones as the map without boundary
+    rel = {}
+    for a, b in zip(both.dofs.ravel(), allm.dofs.ravel()):
+        assert rel.setdefault(int(a), int(b)) == int(b)
+    assert len(set(rel.values())) == allm.num_dofs
