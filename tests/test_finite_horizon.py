@@ -227,6 +227,29 @@ def test_gpu_interval_poly_dirichlet_known_answer(kernel, nc, tol):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('nc,s', [(480, 0.75), (480, 0.25), (960, 0.75)])
+def test_gpu_interval_poly_dirichlet_h2_stored(nc, s):
+    """tests/cache_runNonlocal.py--domaininterval--kernelTypefractional--problempoly-Dirichlet--solverlu--matrixFormatH2: 'L2 error
+    interpolated' 3.7e-11 -- the P1 solution of the Dirichlet volume-constrained problem is nodally exact, also through the H2 operator
+    of the finite horizon (admissible pairs inside the horizon, cluster exteriors by Gauss' theorem, the part beyond the horizon as a
+    multiple of the mass matrix).  The mesh carries the interaction domain, like the reference's."""
+    from pynucleus_amd.builder import nonlocalBuilder
+    from pynucleus_amd.h2 import H2Matrix
+    dm, k = _poly_dirichlet_1d('fractional', nc, s=s)
+    err = {}
+    for m in (None, 16):
+        params = {'eta': 3., 'minClusterSize': 4}
+        if m is not None:
+            params['interpolation_order'] = m
+        h2 = nonlocalBuilder(dm, k, params, zeroExterior=False).getH2()
+        assert isinstance(h2, H2Matrix) and h2.plan.far.shape[0] > 0
+        err[m] = _poly_dirichlet_error(dm, h2.toarray())
+    # the error is the interpolation error of the far field (eta = 3 admits pairs at a third of their diameter: a factor 3 per order):
+    # 1e-3 .. 1e-5 at the default order 7 .. 9, gone at order 16
+    assert err[None] <= 5e-3 and err[16] <= 1e-7, err
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('case', ['indicator', 'fractional', 'P2'])
 def test_gpu_horizon_tiles_and_pair_generator_agree(case, monkeypatch):
     """the two device routes of pnl_assemble_pairs_in_horizon -- tile kernel in finite-horizon mode (default) and the pair
