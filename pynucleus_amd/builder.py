@@ -523,6 +523,63 @@ class nonlocalBuilder:
         self.assembleClusters(Pnear, Anear=A, _globalBoundary=False, _clusterBoundary=self.zeroExterior)
         return float(A.data[0])
 
+    # -- the reference's remaining builder methods (thin: the work is in clusters.py / the methods above) ----------------------------
+    def getDiagonalCluster(self):
+        """NA:2291-2309: the diagonal through the cluster pairs ({I}, {I}) -- what getDiagonal does here for every kernel"""
+        return self.getDiagonal()
+
+    def getEntryCluster(self, I, J):
+        """NA:1475-1537: one entry through the cluster pair of the two supports -- what getEntry does here"""
+        return self.getEntry(I, J)
+
+    def getTree(self):
+        """NA:2541-2664 (one rank): root of the cluster tree over the DoFs"""
+        from . import clusters
+        return clusters.getTree(self.dm)
+
+    def getAdmissibleClusters(self):
+        """NA:2666-2905 (one rank): (Pnear, Pfar) for the kernel's horizon and the refinement parameters of getH2RefinementParams; a
+        piecewise-constant order splits the clusters by kernel block first"""
+        from . import clusters
+        rp = self.getH2RefinementParams()
+        blk = mixed = None
+        if self.kernel.variable and not getattr(self.tables, 'pointwise', False):
+            blk, mixed = clusters.dofKernelBlocks(self.dm, self.tables)
+        horizon = float(self.kernel.horizonValue) if self.kernel.finiteHorizon else np.inf
+        root, Pnear, Pfar = clusters.getNearFieldClusters(self.dm, rp['eta'], rp['minSize'], rp['maxLevels'], blk, -1 if mixed is None else mixed,
+                                                          rp['refinementType'], horizon=horizon)
+        return Pnear, Pfar
+
+    def getCoveringClusters(self):
+        """NA:2907-2981 for the whole mesh as one cluster pair: Pnear = [(root, root)]"""
+        from . import clusters
+        return clusters.coveringCluster(self.dm)[1]
+
+    def getKernelBlocksAndJumps(self):
+        """NA:2312-2384: blocks = {order of the cells around a DoF: set of DoFs}, key INTERFACE_DOF (numpy.inf) for the DoFs on an interface
+        of the order; jumps = {(cell, cell) sorted: the vertex (1D) / the sorted vertex pair (2D) they share} for neighbouring cells of
+        different order (the reference encodes both as 64-bit integers)"""
+        if not (self.kernel.variable and not getattr(self.tables, 'pointwise', False)):
+            return {float(getattr(self.kernel, 'sValue', np.nan)): set(range(self.dm.num_dofs))}, {}
+        from . import clusters
+        T, dm, mesh = self.tables, self.dm, self.mesh
+        lab = np.asarray(T.cell_labels)
+        sv = np.asarray(self.kernel.s.sVals)
+        order_of_label = np.array([sv[l, l] for l in range(sv.shape[0])])
+        blk, mixed = clusters.dofKernelBlocks(dm, T)
+        blocks = {}
+        for d, b in enumerate(blk):
+            blocks.setdefault(np.inf if b == mixed else float(order_of_label[b]), set()).add(d)
+        fv, keys, nbr = clusters.facetTables(mesh)
+        jumps = {}
+        for c in range(mesh.num_cells):
+            for j in range(nbr.shape[1]):
+                c2 = int(nbr[c, j])
+                if c2 > c and order_of_label[lab[c]] != order_of_label[lab[c2]]:
+                    f = tuple(sorted(int(v) for v in fv[c, j]))
+                    jumps[(c, c2)] = f[0] if mesh.dim == 1 else f
+        return blocks, jumps
+
     def _interaction_vertices(self):
         """the vertices in the coordinates the interaction set is a ball in (ellipse domains: T x; otherwise the mesh's own)"""
         T = getattr(self.kernel.interaction, 'transform', None)
