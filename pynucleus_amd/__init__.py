@@ -5,7 +5,7 @@ hand-written HIP kernels for gfx950 behind a C-ABI shared library
 (include/pnl_hip.h, pynucleus_amd/csrc/).  This package is the host-side mirror
 of the reference interface: meshes, DoF maps, kernels and nonlocalBuilder.
 """
-from .mesh import (mesh1d, mesh2d, simpleInterval, uniformSquare, uniform_disc, disc, interval, driverMesh,  # noqa: F401
+from .mesh import (mesh1d, mesh2d, simpleInterval, uniformSquare, uniform_disc, disc, interval, driverMesh, intervalWithInteraction,  # noqa: F401
                    PHYSICAL, NO_BOUNDARY, INTERIOR, INTERIOR_NONOVERLAPPING)
 from .dofmap import P0_DoFMap, P1_DoFMap, P2_DoFMap, P3_DoFMap, dofmapFactory, fe_vector  # noqa: F401
 from .kernels import (getKernel, getFractionalKernel, getIntegrableKernel, kernelFactory,  # noqa: F401

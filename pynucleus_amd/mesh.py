@@ -354,6 +354,23 @@ def interval(noRef=0, a=-1., b=1.):
     return mesh
 
 
+def intervalWithInteraction(a, b, horizon, h=None, strictInteraction=True):
+    """[a, b] in cells of size <= h with a collar of width `horizon` on both sides, the collar in as many cells of (at most) the
+    interior size as cover it (PyNucleus_fem/mesh.py:229-256; strictInteraction=False rounds the collar up to whole cells)."""
+    h = horizon if h is None else h
+    n = int((b-a)/h)
+    n += n*h < b-a
+    inner = np.linspace(a, b, n+1)
+    hi = inner[1]-inner[0]
+    k = int(horizon/hi)
+    k += k*hi < horizon-1e-8
+    if not strictInteraction:
+        horizon = k*hi
+    nodes = np.concatenate((np.linspace(a-horizon, a, k+1)[:-1], inner, np.linspace(b, b+horizon, k+1)[1:]))
+    cells = np.stack((np.arange(nodes.size-1), np.arange(1, nodes.size)), axis=1).astype(INDEX)
+    return mesh1d(np.ascontiguousarray(nodes[:, None], dtype=REAL), cells)
+
+
 def driverMesh(domain, noRef):
     """Mesh of the reference's runFractional driver for `--domain domain --noRef noRef`: the factory mesh is
     refined until a P1 space with PHYSICAL boundary has a DoF (nonlocalProblems.py:209-212) and then noRef
