@@ -18,27 +18,6 @@
 #pragma once
 #include "pnl_common.h"
 
-// ---- group reductions ------------------------------------------------------------------------------------------------
-// three sums over groups of W = 32 or 64 consecutive lanes at once; the results are returned in every lane of the group.
-// (wave_sum3 of pnl_common.h with quad broadcasts instead of readlanes; W = 32 stops before the half-wave swap.)
-template <int W>
-__device__ __forceinline__ void group_sum3(double a, double b, double c, double &A, double &B, double &C) {
-    const int lane = threadIdx.x & 63;
-    const bool o1 = (lane & 1) != 0, o2 = (lane & 2) != 0;
-    double x = o1 ? b : a;
-    x += dpp_get<0xB1>(o1 ? a : b);            // quad_perm [1,0,3,2]
-    const double y = c+dpp_get<0xB1>(c);
-    double z = o2 ? y : x;
-    z += dpp_get<0x4E>(o2 ? x : y);            // quad_perm [2,3,0,1]: lane & 3 = 0: quad sum of a, 1: of b, 2 and 3: of c
-    z += dpp_get<0x124>(z);                    // row_ror:4
-    z += dpp_get<0x128>(z);                    // row_ror:8
-    z = add_xor16(z);
-    if (W == 64) z = add_xor32(z);
-    A = dpp_get<0x00>(z);                      // quad_perm [0,0,0,0]
-    B = dpp_get<0x55>(z);                      // quad_perm [1,1,1,1]
-    C = dpp_get<0xAA>(z);                      // quad_perm [2,2,2,2]
-}
-
 // layout of a uniform-tile rule block (doubles): bary[NP][3], w[NP], w phi[NP][DPE], w phi_a phi_b[ND][NP]
 __host__ __device__ constexpr int uni_rule_size(int dpe, int np) { return 3*np+np+np*dpe+(dpe*(dpe+1)/2)*np; }
 
@@ -210,7 +189,7 @@ k_zero_slot_tiles(const SlotOut SO, const int2 *__restrict__ tiles, const int *_
 // dof_lists: the global DoF numbers of both blocks, double-buffered (the flush into A in DoF numbering; the block-slot storage
 // does not need them: 1.4 KB that let the P2 kernels of a general exponent keep their power tables next to the second workgroup)
 __host__ __device__ constexpr size_t uniform_fixed_lds(int dpe, int np, int tile, int nUe, bool dof_lists = true) {
-    return sizeof(double)*(size_t)(tile*np*2+tile*6+2*tile+2*tile*np+tile*np+(dpe*(dpe+1)/2)*np)
+    return sizeof(double)*(size_t)(tile*np*2+tile*6+2*tile+tile*np+tile*np+(dpe*(dpe+1)/2)*np)
            +sizeof(int)*(size_t)(2*tile*dpe+2*tile+(dof_lists ? 4*nUe : 0));
 }
 
@@ -244,8 +223,8 @@ k_tile_uniform(const DevProblem P, const int2 *__restrict__ tiles, const int *__
     double *s_av = s_y+TILE*NP*DIM;                      // [TILE][NC] vertices of the a-cells
     double *s_vola = s_av+TILE*NC;                       // [TILE]
     double *s_volb = s_vola+TILE;                        // [TILE]
-    double *s_Ra = s_volb+TILE;                          // [2][TILE][NP] row sums of the a-cells, scaled (ping-pong over tiles)
-    double *s_Rb = s_Ra+2*TILE*NP;                       // [TILE][NP] column sums of the b-cells, scaled
+    double *s_Ra = s_volb+TILE;                          // [TILE][NP] row sums of the a-cells, scaled
+    double *s_Rb = s_Ra+TILE*NP;                         // [TILE][NP] column sums of the b-cells, scaled
     double *s_PP = s_Rb+TILE*NP;                         // [ND][NP] w phi_a phi_b at the points
     int *s_slotb = (int*)(s_PP+ND*NP);                   // [TILE][DPE] column of the sub-block (trash column nUe)
     int *s_sa = s_slotb+TILE*DPE;                        // [TILE][DPE] row offset in the sub-block (trash row nUe)
@@ -319,7 +298,7 @@ k_tile_uniform(const DevProblem P, const int2 *__restrict__ tiles, const int *__
     // tables of the general power: of P.k, or of the kernel class of the tile (copied when the class changes, by stage())
     if (have_pow && !tile_cls) { cur_ptab = P.k.ptab; pnl_pow_tab_fill(s_pow, cur_ptab, tid, NT); }
     for (int t = tid; t < (nUe+1)*acc_stride; t += NT) s_acc[t] = 0.;
-    for (int t = tid; t < 2*TILE*NP; t += NT) s_Ra[t] = 0.;
+    for (int t = tid; t < 2*TILE*NP; t += NT) s_Ra[t] = 0.;        // s_Ra and s_Rb
     stage(tile_idx, 0);
     lds_barrier();
 #pragma unroll 1
@@ -332,7 +311,7 @@ k_tile_uniform(const DevProblem P, const int2 *__restrict__ tiles, const int *__
         if (tile_cls) kk = kcls[(tile_cls[tile_idx] & 0xffff) >> 1];
         const double scale2 = 2.*kern_scale<KT>(kk);
         const double *__restrict__ ptab = (have_pow && kk.ptab) ? s_pow : nullptr;
-        double *__restrict__ Ra = s_Ra+buf*TILE*NP;
+        double *__restrict__ Ra = s_Ra;
         // a side: lane = cell li (both halves of a P2 wave hold the same cells)
         double av[NC];
 #pragma unroll
@@ -344,9 +323,13 @@ k_tile_uniform(const DevProblem P, const int2 *__restrict__ tiles, const int *__
         const double vola = s_vola[li];
         kern_dispatch<KT>(kk, ptab, [&](auto ktag) {
         constexpr int KTE = decltype(ktag)::value;          // KT, or 3: the branch-free general power (pnl_common.h)
+        // lane li meets cell (jb + li) mod TILE of block b at step jb: every lane of a group has a b-cell of its own, so the column
+        // sums go to s_Rb with conflict-free ds_add_f64 (a reduction over the lanes cost 46 of the 302 instructions per pair of the
+        // 3-point kernel), and two lanes add to the same entry of the sub-block only if their cells share the row DoF AND the column DoF
+        double racc[NP == 3 ? 3 : 1] = {};
 #pragma unroll 1
         for (int jj = 0; jj < ITER; jj++) {
-            const int j = wave*JW+jj*HALVES+half;
+            const int j = (wave*JW+jj*HALVES+half+li) & (TILE-1);
             double y[NP][DIM];
 #pragma unroll
             for (int jp = 0; jp < NP; jp++)
@@ -393,7 +376,8 @@ k_tile_uniform(const DevProblem P, const int2 *__restrict__ tiles, const int *__
 #pragma unroll
                     for (int b = 0; b < DPE; b++) u[b] = __builtin_fma(g, rule[R_WPH+jp*DPE+b], u[b]);
                 }
-                lds_add_f64(&Ra[li*NP+ip], vv*r);
+                if (NP == 3) racc[NP == 3 ? ip : 0] = __builtin_fma(vv, r, racc[NP == 3 ? ip : 0]);
+                else lds_add_f64(&Ra[li*NP+ip], vv*r);
 #pragma unroll
                 for (int a = 0; a < DPE; a++) {
                     const double pa = rule[R_WPH+ip*DPE+a];
@@ -410,16 +394,13 @@ k_tile_uniform(const DevProblem P, const int2 *__restrict__ tiles, const int *__
                     for (int a = 0; a < DPE; a++) lds_add_f64(&s_acc[sa[a]+sb], -vv*G[a][b]);
                 }
             } else if (G[0][0]+G[1][2]+G[DPE-1][DPE-1] == 1.2345e300) s_acc[0] = vv;
-            // column sums over the cells i of the group -> scaled column sums of cell j (this group owns cell j: plain stores)
-            const double sb2 = scale2*s_volb[j];
-            const double wa = valid ? vola : 0.;
+            // scaled column sums of cell j
 #pragma unroll
-            for (int g3 = 0; g3 < NP; g3 += 3) {
-                double c0, c1, c2;
-                group_sum3<TILE>(wa*c[g3], wa*c[g3+1], wa*c[g3+2], c0, c1, c2);
-                const int k = li-g3;
-                if (k >= 0 && k < 3) s_Rb[j*NP+li] = sb2*(k == 0 ? c0 : (k == 1 ? c1 : c2));
-            }
+            for (int jp = 0; jp < NP; jp++) lds_add_f64(&s_Rb[j*NP+jp], vv*c[jp]);
+        }
+        if (NP == 3) {
+#pragma unroll
+            for (int ip = 0; ip < (NP == 3 ? 3 : 1); ip++) lds_add_f64(&Ra[li*NP+ip], racc[ip]);
         }
         });
         lds_barrier();
@@ -472,16 +453,27 @@ k_tile_uniform(const DevProblem P, const int2 *__restrict__ tiles, const int *__
                 }
             }
         if (flags & 2) for (int t = tid; t < (nUe+1)*acc_stride; t += NT) s_acc[t] = 0.;
-        // diagonal blocks of both sides from the scaled row / column sums
-        for (int t = tid; t < 2*TILE*ND; t += NT) {
-            const int side = t/(TILE*ND), rem = t-side*TILE*ND, cl = rem/ND, e = rem-cl*ND;
-            const double *__restrict__ R = side ? s_Rb+cl*NP : Ra+cl*NP;
-            double v = 0.;
+        // diagonal blocks of both sides from the scaled row / column sums: PARTS neighbouring lanes share a (side, cell), read its sums
+        // with one instruction and zero them with a later one (LDS operations of a wave complete in order), each takes every
+        // PARTS-th entry
+        {
+            constexpr int PARTS = NT/(2*TILE);
+            static_assert(PARTS*2*TILE == NT && 64%PARTS == 0, "one (side, cell) per group of PARTS lanes");
+            const int item = tid/PARTS, part = tid-item*PARTS, side = item/TILE, cl = item-side*TILE;
+            double *__restrict__ R = (side ? s_Rb : s_Ra)+cl*NP;
+            double Rv[NP];
 #pragma unroll
-            for (int ip = 0; ip < NP; ip++) v = __builtin_fma(s_PP[e*NP+ip], R[ip], v);
-            if (v != 0.) atomic_add_f64(&Dglob[(size_t)((side ? tb : ta)*TILE+cl)*ND+e], v);
+            for (int ip = 0; ip < NP; ip++) Rv[ip] = R[ip];
+#pragma unroll
+            for (int ip = 0; ip < NP; ip++) if (ip%PARTS == part) R[ip] = 0.;
+#pragma unroll 1
+            for (int e = part; e < ND; e += PARTS) {
+                double v = 0.;
+#pragma unroll
+                for (int ip = 0; ip < NP; ip++) v = __builtin_fma(s_PP[e*NP+ip], Rv[ip], v);
+                if (v != 0.) atomic_add_f64(&Dglob[(size_t)((side ? tb : ta)*TILE+cl)*ND+e], v);
+            }
         }
-        for (int t = tid; t < TILE*NP; t += NT) s_Ra[(buf^1)*TILE*NP+t] = 0.;
         if (!more) break;
         lds_barrier();
         tile_idx = nxt; buf ^= 1;
