@@ -184,11 +184,18 @@ __device__ __forceinline__ double kern_eval(const DevKernel &k, double d2, const
     if (KT == 2) {
         // d2^(-3/2) = r^3 (1 - e)^(-3/2) with r = v_rsq_f64(d2) (~2^-23 relative), e = 1 - d2 r^2 (|e| < 3e-7):
         // r^3 (1 + e (3/2 + 15/8 e)), the next term 35/16 e^3 is below 1e-19; six operations after the rsq, chain depth five
+        // 3/2 is no inline constant: as an immediate the compiler rebuilds it in a register pair for every evaluation (v_fmac wants
+        // the addend in its destination: two v_mov per kernel value, 18 of the 270 instructions per pair of the 3-point tile loop);
+        // an opaque loop-invariant register pair makes it one v_fma
+        // an opaque loop-invariant register pair and the three-address form spelled out make it one v_fma
+        double c15 = 1.5, p;
+        asm("" : "+v"(c15));
         const double r = __builtin_amdgcn_rsq(d2);
         const double t = r*r;
         const double e = __builtin_fma(-d2, t, 1.0);
         const double g0 = r*t;
-        return __builtin_fma(g0, e*__builtin_fma(1.875, e, 1.5), g0);
+        asm("v_fma_f64 %0, %1, %2, %3" : "=v"(p) : "v"(e), "s"(1.875), "v"(c15));
+        return __builtin_fma(g0, e*p, g0);
     } else if (KT == 1) {
         // exponent = -qm/4 (s a multiple of 1/4 in 1D / 2D): d2^(-1/2) from v_rsq_f64 (~2^-23 relative) + one Halley step
         // (cubic: r (1 + e/2 + 3 e^2/8), e = 1 - d2 r^2, five operations for full precision), for odd qm one more refined

@@ -189,8 +189,12 @@ k_zero_slot_tiles(const SlotOut SO, const int2 *__restrict__ tiles, const int *_
 // dof_lists: the global DoF numbers of both blocks, double-buffered (the flush into A in DoF numbering; the block-slot storage
 // does not need them: 1.4 KB that let the P2 kernels of a general exponent keep their power tables next to the second workgroup)
 __host__ __device__ constexpr size_t uniform_fixed_lds(int dpe, int np, int tile, int nUe, bool dof_lists = true) {
-    return sizeof(double)*(size_t)(tile*np*2+tile*6+2*tile+tile*np+tile*np+(dpe*(dpe+1)/2)*np)
-           +sizeof(int)*(size_t)(2*tile*dpe+2*tile+(dof_lists ? 4*nUe : 0));
+    // per-cell rows have odd strides (in doubles / ints): the lanes of a wave read the rows of 64 different cells
+    // (P1; the P2 kernels, two workgroups of just under 80 KB per CU, keep compact rows and the vertices of the a-cells)
+    return dpe == 3 ? sizeof(double)*(size_t)(2*tile*(np*2+1)+2*tile+2*tile*(np|1)+(dpe*(dpe+1)/2)*np)
+                      +sizeof(int)*(size_t)(2*tile*(dpe|1)+2*tile+(dof_lists ? 4*nUe : 0))
+                    : sizeof(double)*(size_t)(tile*np*2+tile*6+2*tile+2*tile*np+(dpe*(dpe+1)/2)*np)
+                      +sizeof(int)*(size_t)(2*tile*dpe+2*tile+(dof_lists ? 4*nUe : 0));
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -206,7 +210,7 @@ __host__ __device__ constexpr size_t uniform_fixed_lds(int dpe, int np, int tile
 #define PNL_U33K0_WAVES 3
 #endif
 template <int DPE, int NP, int KT>
-__global__ void __launch_bounds__(256, (DPE == 3 && NP == 3 && KT == 0) ? PNL_U33K0_WAVES : ((DPE == 3 && NP == 6) ? 3 : 2))
+__global__ void __launch_bounds__(256, (DPE == 3 && NP == 3) ? (KT == 0 ? PNL_U33K0_WAVES : (KT == 2 ? 4 : 2)) : ((DPE == 3 && NP == 6) ? 3 : 2))
 k_tile_uniform(const DevProblem P, const int2 *__restrict__ tiles, const int *__restrict__ tile_cls, const DevKernel *__restrict__ kcls,
                int ntiles, double *__restrict__ A, long long ldA, double *__restrict__ Dglob, int acc_stride, int q_uniform,
                int flags, const double *__restrict__ rule_g, int nUe, const SlotOut SO) {
@@ -214,21 +218,28 @@ k_tile_uniform(const DevProblem P, const int2 *__restrict__ tiles, const int *__
     constexpr int DIM = 2, NV = 3, NC = 6, ND = DPE*(DPE+1)/2, NT = 256, NW = NT/64;
     constexpr int TILE = DPE == 6 ? 32 : 64, HALVES = 64/TILE, JW = TILE/NW, ITER = JW/HALVES;
     constexpr int R_BARY = 0, R_W = 3*NP, R_WPH = R_W+NP, R_PP = R_WPH+NP*DPE;
+    // row strides of the per-cell LDS arrays: odd, so that lanes reading the rows of different cells hit different banks
+    constexpr bool XPTS = DPE == 3;                      // a side: quadrature points (P1) or vertices (P2) in LDS
+    constexpr int PS = XPTS ? NP*DIM+1 : NP*DIM, RS = XPTS ? (NP|1) : NP, SS = XPTS ? (DPE|1) : DPE, XS = XPTS ? PS : NC;
+    // P1 (64 lanes = 64 cells): the data of the b-cell and its column sums TRAVEL from lane to lane (DPP wave rotation by one lane per
+    // step) instead of being read from and added to LDS for every pair; the LDS pipe of a CU was 80-90 % busy with 24 instructions per
+    // pair (12 ds_add_f64, the reads of a b-cell of its own per lane), the VALU 63 %.  P2 (two half-waves of 32 cells) reads per lane.
+    constexpr bool TRAVEL = (TILE == 64);
     const pnl_const_f64_ptr rule = (pnl_const_f64_ptr)(unsigned long long)rule_g;
 #ifndef PNL_DEBUG_ABLATE
     flags &= 1;                                          // the other bits skip work (debug builds only)
 #endif
     extern __shared__ double smem[];
-    double *s_y = smem;                                  // [TILE][NP*DIM] quadrature points of the b-cells
-    double *s_av = s_y+TILE*NP*DIM;                      // [TILE][NC] vertices of the a-cells
-    double *s_vola = s_av+TILE*NC;                       // [TILE]
+    double *s_y = smem;                                  // [TILE][PS] quadrature points of the b-cells
+    double *s_x = s_y+TILE*PS;                           // [TILE][XS] quadrature points (P2: vertices) of the a-cells
+    double *s_vola = s_x+TILE*XS;                        // [TILE]
     double *s_volb = s_vola+TILE;                        // [TILE]
     double *s_Ra = s_volb+TILE;                          // [TILE][NP] row sums of the a-cells, scaled
-    double *s_Rb = s_Ra+TILE*NP;                         // [TILE][NP] column sums of the b-cells, scaled
-    double *s_PP = s_Rb+TILE*NP;                         // [ND][NP] w phi_a phi_b at the points
+    double *s_Rb = s_Ra+TILE*RS;                         // [TILE][RS] column sums of the b-cells, scaled
+    double *s_PP = s_Rb+TILE*RS;                         // [ND][NP] w phi_a phi_b at the points
     int *s_slotb = (int*)(s_PP+ND*NP);                   // [TILE][DPE] column of the sub-block (trash column nUe)
-    int *s_sa = s_slotb+TILE*DPE;                        // [TILE][DPE] row offset in the sub-block (trash row nUe)
-    int *s_ha = s_sa+TILE*DPE;                           // [TILE] has-a-DoF flags
+    int *s_sa = s_slotb+TILE*SS;                         // [TILE][SS] row offset in the sub-block (trash row nUe)
+    int *s_ha = s_sa+TILE*SS;                            // [TILE] has-a-DoF flags
     int *s_hb = s_ha+TILE;
     int *s_dof = s_hb+TILE;                              // [2][2][nUe] global DoFs of both blocks (ping-pong over tiles);
     const bool dof_lists = SO.A2 == nullptr;             // not with the block-slot storage (uniform_fixed_lds)
@@ -259,7 +270,10 @@ k_tile_uniform(const DevProblem P, const int2 *__restrict__ tiles, const int *__
             for (int k = 0; k < DPE; k++) { sl[k] = P.cslot[(size_t)k*P.ncp+c]; any |= (sl[k] >= 0); }
             // bit 1: a real cell (zero-volume padding cells inside the mesh carry negative vertex ids: their pairs do not exist)
             any |= (P.cvid[c] >= 0) ? 2 : 0;
-            if (bside) {
+            // the points of both sides are formed here, once per cell and tile: as loaded values they stay in registers over the
+            // pair loop (points recomputed from the vertices are rematerialised inside it when registers get tight)
+            double *__restrict__ pts = (bside ? s_y : s_x)+l*PS;
+            if (bside || XPTS) {
 #pragma unroll
                 for (int jp = 0; jp < NP; jp++)
 #pragma unroll
@@ -267,17 +281,20 @@ k_tile_uniform(const DevProblem P, const int2 *__restrict__ tiles, const int *__
                         double sy = 0.;
 #pragma unroll
                         for (int k = 0; k < NV; k++) sy = __builtin_fma(rule[R_BARY+3*jp+k], v[k*DIM+d], sy);
-                        s_y[l*NP*DIM+jp*DIM+d] = sy;
+                        pts[jp*DIM+d] = sy;
                     }
-                s_volb[l] = vol; s_hb[l] = any;
-#pragma unroll
-                for (int k = 0; k < DPE; k++) s_slotb[l*DPE+k] = sl[k] >= 0 ? sl[k] : nUe;
             } else {
 #pragma unroll
-                for (int k = 0; k < NC; k++) s_av[l*NC+k] = v[k];
+                for (int k = 0; k < NC; k++) s_x[l*XS+k] = v[k];
+            }
+            if (bside) {
+                s_volb[l] = vol; s_hb[l] = any;
+#pragma unroll
+                for (int k = 0; k < DPE; k++) s_slotb[l*SS+k] = sl[k] >= 0 ? sl[k] : nUe;
+            } else {
                 s_vola[l] = vol; s_ha[l] = any;
 #pragma unroll
-                for (int k = 0; k < DPE; k++) s_sa[l*DPE+k] = (sl[k] >= 0 ? sl[k] : nUe)*acc_stride;
+                for (int k = 0; k < DPE; k++) s_sa[l*SS+k] = (sl[k] >= 0 ? sl[k] : nUe)*acc_stride;
             }
         }
         const int *__restrict__ dofA = P.blk_dofs+(size_t)tl.x*P.blk_stride;
@@ -298,7 +315,7 @@ k_tile_uniform(const DevProblem P, const int2 *__restrict__ tiles, const int *__
     // tables of the general power: of P.k, or of the kernel class of the tile (copied when the class changes, by stage())
     if (have_pow && !tile_cls) { cur_ptab = P.k.ptab; pnl_pow_tab_fill(s_pow, cur_ptab, tid, NT); }
     for (int t = tid; t < (nUe+1)*acc_stride; t += NT) s_acc[t] = 0.;
-    for (int t = tid; t < 2*TILE*NP; t += NT) s_Ra[t] = 0.;        // s_Ra and s_Rb
+    for (int t = tid; t < 2*TILE*RS; t += NT) s_Ra[t] = 0.;        // s_Ra and s_Rb
     stage(tile_idx, 0);
     lds_barrier();
 #pragma unroll 1
@@ -313,12 +330,21 @@ k_tile_uniform(const DevProblem P, const int2 *__restrict__ tiles, const int *__
         const double *__restrict__ ptab = (have_pow && kk.ptab) ? s_pow : nullptr;
         double *__restrict__ Ra = s_Ra;
         // a side: lane = cell li (both halves of a P2 wave hold the same cells)
-        double av[NC];
+        double xa[NP == 3 ? 3 : 1][DIM];                 // P1, 3 points: in registers; 6 points: read per row of the rule
+        double av[XPTS ? 1 : NC];                        // P2: the vertices, the points are formed per row of the rule
+        if (XPTS && NP == 3) {
 #pragma unroll
-        for (int k = 0; k < NC; k++) av[k] = s_av[li*NC+k];
+            for (int ip = 0; ip < (NP == 3 ? 3 : 1); ip++)
+#pragma unroll
+                for (int d = 0; d < DIM; d++) xa[ip][d] = s_x[li*XS+ip*DIM+d];
+        }
+        if (!XPTS) {
+#pragma unroll
+            for (int k = 0; k < NC; k++) av[XPTS ? 0 : k] = s_x[li*XS+k];
+        }
         int sa[DPE];
 #pragma unroll
-        for (int k = 0; k < DPE; k++) sa[k] = s_sa[li*DPE+k];
+        for (int k = 0; k < DPE; k++) sa[k] = s_sa[li*SS+k];
         const int fa = s_ha[li];
         const double vola = s_vola[li];
         kern_dispatch<KT>(kk, ptab, [&](auto ktag) {
@@ -327,19 +353,44 @@ k_tile_uniform(const DevProblem P, const int2 *__restrict__ tiles, const int *__
         // sums go to s_Rb with conflict-free ds_add_f64 (a reduction over the lanes cost 46 of the 302 instructions per pair of the
         // 3-point kernel), and two lanes add to the same entry of the sub-block only if their cells share the row DoF AND the column DoF
         double racc[NP == 3 ? 3 : 1] = {};
-#pragma unroll 1
-        for (int jj = 0; jj < ITER; jj++) {
-            const int j = (wave*JW+jj*HALVES+half+li) & (TILE-1);
-            double y[NP][DIM];
+        // the b-cell this lane currently meets: index, points, flags, volume, columns of its DoFs, travelling column sums
+        int j = (wave*JW+half+li) & (TILE-1);
+        double y[NP][DIM], volb_j, cacc[TRAVEL ? NP : 1] = {};
+        int fb, sbj[DPE];
+        auto load_b = [&]() {
 #pragma unroll
             for (int jp = 0; jp < NP; jp++)
 #pragma unroll
-                for (int d = 0; d < DIM; d++) y[jp][d] = s_y[j*NP*DIM+jp*DIM+d];
+                for (int d = 0; d < DIM; d++) y[jp][d] = s_y[j*PS+jp*DIM+d];
+            fb = s_hb[j];
+            volb_j = s_volb[j];
+#pragma unroll
+            for (int b = 0; b < DPE; b++) sbj[b] = s_slotb[j*SS+b];
+        };
+        if (TRAVEL) load_b();
+#pragma unroll 1
+        for (int jj = 0; jj < ITER; jj++) {
+            if (!TRAVEL) { j = (wave*JW+jj*HALVES+half+li) & (TILE-1); load_b(); }
+            else if (jj) {
+                // one lane on: whichever way the rotation goes, the wave meets 16 consecutive cells of block b per lane, and the index
+                // travels with the data
+                constexpr int ROT = 0x134;                 // wave_rol:1
+                j = __builtin_amdgcn_update_dpp(0, j, ROT, 0xf, 0xf, true);
+                fb = __builtin_amdgcn_update_dpp(0, fb, ROT, 0xf, 0xf, true);
+                volb_j = dpp_get<ROT>(volb_j);
+#pragma unroll
+                for (int b = 0; b < DPE; b++) sbj[b] = __builtin_amdgcn_update_dpp(0, sbj[b], ROT, 0xf, 0xf, true);
+#pragma unroll
+                for (int jp = 0; jp < NP; jp++) {
+                    cacc[TRAVEL ? jp : 0] = dpp_get<ROT>(cacc[TRAVEL ? jp : 0]);
+#pragma unroll
+                    for (int d = 0; d < DIM; d++) y[jp][d] = dpp_get<ROT>(y[jp][d]);
+                }
+            }
             // NA:138-150: pairs with boundary DoFs only are skipped; pairs that hold a padding cell do not exist
-            const int fb = s_hb[j];
             const bool valid = (((fa | fb) & 1) != 0) && (((fa & fb) & 2) != 0);
             npairs += (unsigned long long)__popcll(__ballot(valid));
-            const double volb = valid ? s_volb[j] : 0.;
+            const double volb = valid ? volb_j : 0.;
             // NA:1405-1410: symmetric cell pairs count twice
             const double vv = scale2*vola*volb;
             double c[NP], G[DPE][DPE];
@@ -356,10 +407,12 @@ k_tile_uniform(const DevProblem P, const int2 *__restrict__ tiles, const int *__
                 double x[DIM];
 #pragma unroll
                 for (int d = 0; d < DIM; d++) {
-                    double sx = 0.;
+                    if (!XPTS) {
+                        double sx = 0.;
 #pragma unroll
-                    for (int k = 0; k < NV; k++) sx = __builtin_fma(rule[R_BARY+3*ip+k], av[k*DIM+d], sx);
-                    x[d] = sx;
+                        for (int k = 0; k < NV; k++) sx = __builtin_fma(rule[R_BARY+3*ip+k], av[XPTS ? 0 : k*DIM+d], sx);
+                        x[d] = sx;
+                    } else x[d] = NP == 3 ? xa[NP == 3 ? ip : 0][d] : s_x[li*XS+ip*DIM+d];
                 }
                 const double wi = rule[R_W+ip];
                 double r = 0., u[DPE];
@@ -377,7 +430,7 @@ k_tile_uniform(const DevProblem P, const int2 *__restrict__ tiles, const int *__
                     for (int b = 0; b < DPE; b++) u[b] = __builtin_fma(g, rule[R_WPH+jp*DPE+b], u[b]);
                 }
                 if (NP == 3) racc[NP == 3 ? ip : 0] = __builtin_fma(vv, r, racc[NP == 3 ? ip : 0]);
-                else lds_add_f64(&Ra[li*NP+ip], vv*r);
+                else lds_add_f64(&Ra[li*RS+ip], vv*r);
 #pragma unroll
                 for (int a = 0; a < DPE; a++) {
                     const double pa = rule[R_WPH+ip*DPE+a];
@@ -389,18 +442,26 @@ k_tile_uniform(const DevProblem P, const int2 *__restrict__ tiles, const int *__
             if (!(flags & 4)) {
 #pragma unroll
                 for (int b = 0; b < DPE; b++) {
-                    const int sb = s_slotb[j*DPE+b];
+                    const int sb = sbj[b];
 #pragma unroll
                     for (int a = 0; a < DPE; a++) lds_add_f64(&s_acc[sa[a]+sb], -vv*G[a][b]);
                 }
             } else if (G[0][0]+G[1][2]+G[DPE-1][DPE-1] == 1.2345e300) s_acc[0] = vv;
             // scaled column sums of cell j
 #pragma unroll
-            for (int jp = 0; jp < NP; jp++) lds_add_f64(&s_Rb[j*NP+jp], vv*c[jp]);
+            for (int jp = 0; jp < NP; jp++) {
+                if (TRAVEL) cacc[TRAVEL ? jp : 0] = __builtin_fma(vv, c[jp], cacc[TRAVEL ? jp : 0]);
+                else lds_add_f64(&s_Rb[j*RS+jp], vv*c[jp]);
+            }
+        }
+        if (TRAVEL) {
+            // the sums that travelled through this wave's lanes, now at the lane that met cell j last
+#pragma unroll
+            for (int jp = 0; jp < NP; jp++) lds_add_f64(&s_Rb[j*RS+jp], cacc[TRAVEL ? jp : 0]);
         }
         if (NP == 3) {
 #pragma unroll
-            for (int ip = 0; ip < (NP == 3 ? 3 : 1); ip++) lds_add_f64(&Ra[li*NP+ip], racc[ip]);
+            for (int ip = 0; ip < (NP == 3 ? 3 : 1); ip++) lds_add_f64(&Ra[li*RS+ip], racc[ip]);
         }
         });
         lds_barrier();
@@ -460,7 +521,7 @@ k_tile_uniform(const DevProblem P, const int2 *__restrict__ tiles, const int *__
             constexpr int PARTS = NT/(2*TILE);
             static_assert(PARTS*2*TILE == NT && 64%PARTS == 0, "one (side, cell) per group of PARTS lanes");
             const int item = tid/PARTS, part = tid-item*PARTS, side = item/TILE, cl = item-side*TILE;
-            double *__restrict__ R = (side ? s_Rb : s_Ra)+cl*NP;
+            double *__restrict__ R = (side ? s_Rb : s_Ra)+cl*RS;
             double Rv[NP];
 #pragma unroll
             for (int ip = 0; ip < NP; ip++) Rv[ip] = R[ip];

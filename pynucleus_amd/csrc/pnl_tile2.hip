@@ -14,7 +14,7 @@ int launch_uniform_t(pnl_context *ctx, const DevProblem &Pt, const int2 *tiles, 
     // sub-block [nUe+1][acc_stride]: rows in different LDS banks (stride = 1 mod 32 doubles) if two workgroups still share a CU,
     // else an odd stride
     int acc_stride = nUe+1;
-    while (acc_stride % 32 != 1) acc_stride++;
+    while (acc_stride % 32 != 1) acc_stride++;                      // (other odd residues mod 32 measured: no difference)
     if (fixed+sizeof(double)*(size_t)(nUe+1)*acc_stride > 80*1024) acc_stride = (nUe+1) | 1;
     size_t lds = fixed+sizeof(double)*(size_t)(nUe+1)*acc_stride;
     if (lds > 160*1024)
