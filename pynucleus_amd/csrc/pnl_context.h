@@ -94,6 +94,9 @@ struct pnl_context {
     std::vector<DevFormula> bfcls_host;
     std::vector<DevFormula> fcls_host;
     int uni_off[5] = {-1, -1, -1, -1, -1}, uni_np[5] = {0, 0, 0, 0, 0};
+    // the 3-point rule of P1 has equal weights and shape values w phi_b(y_j) = A + B delta_bj (points reordered to make it so):
+    // k_tile_uniform<3, 3, KT, true> forms the cross block from row, column and total sums of the nine kernel values
+    bool uni_struct[5] = {false, false, false, false, false};
     H2Dev h2;
     bool have_h2 = false;
     // non-symmetric kernels with an order per quadrature point (pnl_set_order_function)

@@ -2250,12 +2250,35 @@ int pnl_upload_distant_rules(pnl_context *ctx, int qmax, const int32_t *off, con
             const int n = off[q+1]-off[q];
             if (n != 3 && n != 6) continue;
             ctx->uni_off[q] = (int)uni.size(); ctx->uni_np[q] = n;
-            for (int i = 0; i < n; i++) for (int k2 = 0; k2 < 3; k2++) uni.push_back(bary[3*((size_t)off[q]+i)+k2]);
-            for (int i = 0; i < n; i++) uni.push_back(w[off[q]+i]);
-            for (int i = 0; i < n; i++) for (int a = 0; a < dpe; a++) uni.push_back(w[off[q]+i]*phi[((size_t)off[q]+i)*dpe+a]);
+            // point order of the block: P1 with three points of equal weight whose shape values are A + B delta(b, sigma(i)) for a
+            // permutation sigma (the symmetric degree-2 rule) -> the points in the order sigma^-1, so that w phi_b(y_i) = A + B delta_bi
+            std::vector<int> ord(n);
+            for (int i = 0; i < n; i++) ord[i] = i;
+            ctx->uni_struct[q] = false;
+            if (n == 3 && dpe == 3) {
+                int sig[3] = {-1, -1, -1};
+                bool ok = w[off[q]] == w[off[q]+1] && w[off[q]] == w[off[q]+2];
+                for (int i = 0; i < 3 && ok; i++) {
+                    const double *ph = &phi[((size_t)off[q]+i)*dpe];
+                    int big = 0;
+                    for (int b = 1; b < 3; b++) if (ph[b] > ph[big]) big = b;
+                    sig[i] = big;
+                    for (int b = 0; b < 3; b++)
+                        ok = ok && ph[b] == (b == big ? phi[(size_t)off[q]*dpe+sig[0]] : phi[(size_t)off[q]*dpe+(sig[0]+1)%3]);
+                }
+                ok = ok && sig[0] != sig[1] && sig[0] != sig[2] && sig[1] != sig[2];
+                if (ok) {
+                    for (int i = 0; i < 3; i++) ord[sig[i]] = i;
+                    ctx->uni_struct[q] = true;
+                }
+            }
+            auto pt = [&](int i) { return (size_t)off[q]+ord[i]; };
+            for (int i = 0; i < n; i++) for (int k2 = 0; k2 < 3; k2++) uni.push_back(bary[3*pt(i)+k2]);
+            for (int i = 0; i < n; i++) uni.push_back(w[pt(i)]);
+            for (int i = 0; i < n; i++) for (int a = 0; a < dpe; a++) uni.push_back(w[pt(i)]*phi[pt(i)*dpe+a]);
             for (int a = 0; a < dpe; a++)
                 for (int b = a; b < dpe; b++)
-                    for (int i = 0; i < n; i++) uni.push_back(w[off[q]+i]*phi[((size_t)off[q]+i)*dpe+a]*phi[((size_t)off[q]+i)*dpe+b]);
+                    for (int i = 0; i < n; i++) uni.push_back(w[pt(i)]*phi[pt(i)*dpe+a]*phi[pt(i)*dpe+b]);
         }
         if ((rc = upload(ctx, ctx->b_uni, uni.data(), uni.size()))) return rc;
         ctx->tiles_cached.clear(); ctx->tiles_forms.clear();

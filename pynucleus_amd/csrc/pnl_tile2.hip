@@ -5,7 +5,7 @@
 
 namespace {
 
-template <int DPE, int NP, int KT>
+template <int DPE, int NP, int KT, bool STRUCT = false>
 int launch_uniform_t(pnl_context *ctx, const DevProblem &Pt, const int2 *tiles, const int *tile_cls, int ntiles, int q, double *A,
                      int64_t ldA, double *Dglob, const SlotOut &SO) {
     constexpr int TILE = DPE == 6 ? 32 : 64;
@@ -24,7 +24,7 @@ int launch_uniform_t(pnl_context *ctx, const DevProblem &Pt, const int2 *tiles, 
     // exponent 36.4 -> 28.8 ms at 98,304 cells, s = 1/2: 17.8 -> 17.2; order-2 tiles of s = 1/2 with four: 42.8 -> 41.3 ms);
     // P2: two workgroups of 80 KB
     const size_t cap_cu = (size_t)std::max(1, pnl_tune("PNL_UNI_PER_CU") ? atoi(pnl_tune("PNL_UNI_PER_CU")) : 4);
-    auto kfun = k_tile_uniform<DPE, NP, KT>;
+    auto kfun = k_tile_uniform<DPE, NP, KT, STRUCT>;
     HIPCHK(ctx, hipFuncSetAttribute((const void*)kfun, hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::min<size_t>(160*1024, lds+sizeof(double)*PNL_POW_TAB_DOUBLES)));
     // workgroups that are really resident per CU (LDS and registers): the tile loop strides by the grid, a workgroup that has
     // to wait for a slot would start its share of the tiles late
@@ -53,8 +53,8 @@ int launch_uniform_t(pnl_context *ctx, const DevProblem &Pt, const int2 *tiles, 
     const int per_cu = resident(lds);
     const int grid = pnl_grid_cap(std::min(ntiles, 256*per_cu));
     if (pnl_tune("PNL_VERBOSE"))
-        fprintf(stderr, "[pnl] uniform tiles of order %d: %d, dpe=%d np=%d kt=%d lds=%zu bytes (%d per CU), acc_stride=%d\n", q, ntiles, DPE,
-                NP, KT, lds, per_cu, acc_stride);
+        fprintf(stderr, "[pnl] uniform tiles of order %d: %d, dpe=%d np=%d kt=%d struct=%d lds=%zu bytes (%d per CU), acc_stride=%d\n", q, ntiles, DPE,
+                NP, KT, (int)STRUCT, lds, per_cu, acc_stride);
     int uni_abl = 0;
 #ifdef PNL_DEBUG_ABLATE
     uni_abl = pnl_tune("PNL_UNI_ABL") ? atoi(pnl_tune("PNL_UNI_ABL")) : 0;
@@ -71,6 +71,13 @@ int launch_uniform_t(pnl_context *ctx, const DevProblem &Pt, const int2 *tiles, 
 template <int DPE, int NP>
 int launch_uniform_kt(pnl_context *ctx, int kt, const DevProblem &Pt, const int2 *tiles, const int *tile_cls, int ntiles, int q,
                       double *A, int64_t ldA, double *Dglob, const SlotOut &SO) {
+    if constexpr (DPE == 3 && NP == 3) {
+        if (ctx->uni_struct[q]) {
+            if (kt == 2) return launch_uniform_t<DPE, NP, 2, true>(ctx, Pt, tiles, tile_cls, ntiles, q, A, ldA, Dglob, SO);
+            if (kt == 1) return launch_uniform_t<DPE, NP, 1, true>(ctx, Pt, tiles, tile_cls, ntiles, q, A, ldA, Dglob, SO);
+            return launch_uniform_t<DPE, NP, 0, true>(ctx, Pt, tiles, tile_cls, ntiles, q, A, ldA, Dglob, SO);
+        }
+    }
     if (kt == 2) return launch_uniform_t<DPE, NP, 2>(ctx, Pt, tiles, tile_cls, ntiles, q, A, ldA, Dglob, SO);
     if (kt == 1) return launch_uniform_t<DPE, NP, 1>(ctx, Pt, tiles, tile_cls, ntiles, q, A, ldA, Dglob, SO);
     return launch_uniform_t<DPE, NP, 0>(ctx, Pt, tiles, tile_cls, ntiles, q, A, ldA, Dglob, SO);
