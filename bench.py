@@ -625,7 +625,12 @@ def main():
     step_s = elapsed/args.steps
     whole_flops = flops_from_counters(cnt, 3) if world == 1 else None
     roofline = dict(bound='fp64_valu', kernel=dominant, achieved=achieved, peak=FP64_VECTOR_PEAK_TFLOPS, unit='TFLOP/s',
-                    frac=achieved/FP64_VECTOR_PEAK_TFLOPS, traffic=traffic, traffic_note=traffic_note, algorithmic_flops_per_launch=dom_flops,
+                    frac=achieved/FP64_VECTOR_PEAK_TFLOPS,
+                    frac_note='achieved counts the flop of the reference\'s evaluation per pair (SURVEY 8(d): 759 for an order-2 P1 pair); the kernel '
+                              'forms the same local matrix from row / column sums of the kernel values in about 200 VALU instructions per pair, so frac '
+                              'can exceed 1; valu_issue_util is the executed-instruction view (at the nominal 2.4 GHz; under fp64 load the clock '
+                              'sustains about 1.7 GHz, tools/probes/valu_rate_probe.hip: 5.67 nominal cycles per v_fma_f64 of a wave)',
+                    traffic=traffic, traffic_note=traffic_note, algorithmic_flops_per_launch=dom_flops,
                     valu_issue_util=valu_util, valu_issue_note=valu_note,
                     whole_step_frac=(whole_flops/step_s/1e12/FP64_VECTOR_PEAK_TFLOPS) if whole_flops else None,
                     whole_step_algorithmic_flops=whole_flops,
