@@ -20,6 +20,9 @@ if 'serial' in sys.argv[2:]:
     from pynucleus_amd import _lib
     _lib.set_option('PNL_NO_OVERLAP', 1)
     _lib.set_option('PNL_NO_FORK', 1)
+if os.environ.get('PNL_PROBE_VERBOSE'):
+    from pynucleus_amd import _lib
+    _lib.set_option('PNL_VERBOSE', 1)                  # LDS bytes and resident workgroups per CU of the tile launches on stderr
 PEAK = bench.FP64_VECTOR_PEAK_TFLOPS
 
 
