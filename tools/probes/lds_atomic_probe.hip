@@ -18,7 +18,8 @@ __global__ void __launch_bounds__(256) k_probe(double *out, int iters, int patte
     if (pattern == 0) base = wave*64+lane;
     else if (pattern == 1) base = (lane*65+wave) % (NEL-16);
     else if (pattern == 2) base = ((lane >> 1)*65+wave) % (NEL-16);
-    else base = wave;
+    else if (pattern == 3) base = wave;
+    else base = (lane*(pattern-3)+wave) % (NEL-64);            // pattern 4 + k: lane stride k+1 doubles (bank structure)
     double v = 1.0+tid, acc = 0.;
     float vf = 1.f+tid;
     float *sf = (float*)s;
@@ -65,6 +66,9 @@ int main() {
         run<3>("ds_read_b64", out, p);
         run<4>("read+add+write", out, p);
     }
+    // lane strides 1, 2, 4, 8, 16, 32, 64 doubles and 3, 5, 17, 33
+    const int strides[] = {1, 2, 4, 8, 16, 32, 64, 3, 5, 17, 33};
+    for (int k = 0; k < 11; k++) run<0>("ds_add_f64 stride", out, 3+strides[k]);
     hipFree(out);
     return 0;
 }
