@@ -2272,6 +2272,37 @@ int pnl_upload_distant_rules(pnl_context *ctx, int qmax, const int32_t *off, con
                     ctx->uni_struct[q] = true;
                 }
             }
+            // six points in two orbits of three (the symmetric 6-point rules of degree 3 / 4): per orbit equal weights and shape values
+            // A_o + B_o delta(b, sigma(i)) -> the points in the order orbit 0 (positions 0, 1, 2), orbit 1 (positions 0, 1, 2)
+            if (n == 6 && dpe == 3) {
+                int big[6], orb[6], norb = 0;
+                double ow[2] = {0., 0.}, ohi[2] = {0., 0.}, olo[2] = {0., 0.};
+                bool ok = true;
+                for (int i = 0; i < 6 && ok; i++) {
+                    const double *ph = &phi[((size_t)off[q]+i)*dpe];
+                    // the distinguished coordinate of a point (x, x, 1 - 2 x): the one that differs from the other two
+                    int d = -1;
+                    if (ph[0] == ph[1] && ph[0] != ph[2]) d = 2;
+                    else if (ph[0] == ph[2] && ph[0] != ph[1]) d = 1;
+                    else if (ph[1] == ph[2] && ph[0] != ph[1]) d = 0;
+                    if (d < 0) { ok = false; break; }
+                    big[i] = d;
+                    const double hi = ph[d], lo = ph[(d+1)%3], wi = w[off[q]+i];
+                    int o = -1;
+                    for (int t = 0; t < norb; t++) if (ow[t] == wi && ohi[t] == hi && olo[t] == lo) o = t;
+                    if (o < 0) { if (norb == 2) { ok = false; break; } o = norb++; ow[o] = wi; ohi[o] = hi; olo[o] = lo; }
+                    orb[i] = o;
+                }
+                if (ok && norb == 2) {
+                    int seen[2][3] = {{0, 0, 0}, {0, 0, 0}};
+                    for (int i = 0; i < 6; i++) seen[orb[i]][big[i]]++;
+                    for (int o = 0; o < 2; o++) for (int d = 0; d < 3; d++) ok = ok && seen[o][d] == 1;
+                    if (ok) {
+                        for (int i = 0; i < 6; i++) ord[3*orb[i]+big[i]] = i;
+                        ctx->uni_struct[q] = true;
+                    }
+                }
+            }
             auto pt = [&](int i) { return (size_t)off[q]+ord[i]; };
             for (int i = 0; i < n; i++) for (int k2 = 0; k2 < 3; k2++) uni.push_back(bary[3*pt(i)+k2]);
             for (int i = 0; i < n; i++) uni.push_back(w[pt(i)]);

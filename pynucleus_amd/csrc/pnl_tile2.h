@@ -213,6 +213,9 @@ __host__ __device__ constexpr size_t uniform_fixed_lds(int dpe, int np, int tile
 // g_ab = gamma(x_a, y_b), their row sums s_a, column sums c_b and total S, the cross block is
 //   G[a][b] = B^2 g_ab + A B (s_a + c_b) + A^2 S
 // -- 49 instead of 87 instructions per pair behind the kernel values.
+// STRUCT with six points: two orbits of three points, w phi_b(y_j) = A_o + B_o delta(b, j mod 3) in orbit o = j / 3: per row of the rule
+// the orbit sums s_0, s_1 of the kernel values give r = w_0 s_0 + w_1 s_1 and u_b = A_0 s_0 + A_1 s_1 + B_0 g_b + B_1 g_{3+b}
+// (14 instead of 24 instructions per row).
 template <int DPE, int NP, int KT, bool STRUCT = false>
 __global__ void __launch_bounds__(256, (DPE == 3 && NP == 3) ? (KT == 0 ? PNL_U33K0_WAVES : (KT == 2 ? 4 : 2)) : ((DPE == 3 && NP == 6) ? 3 : 2))
 k_tile_uniform(const DevProblem P, const int2 *__restrict__ tiles, const int *__restrict__ tile_cls, const DevKernel *__restrict__ kcls,
@@ -397,8 +400,8 @@ k_tile_uniform(const DevProblem P, const int2 *__restrict__ tiles, const int *__
             const double volb = valid ? volb_j : 0.;
             // NA:1405-1410: symmetric cell pairs count twice
             const double vv = scale2*vola*volb;
-            if constexpr (STRUCT) {
-                static_assert(!STRUCT || (DPE == 3 && NP == 3 && TRAVEL && XPTS), "the structured rule: P1, three points");
+            static_assert(!STRUCT || (DPE == 3 && TRAVEL && XPTS), "the structured rules: P1");
+            if constexpr (STRUCT && NP == 3) {
                 double g[3][3];
 #pragma unroll
                 for (int a = 0; a < 3; a++)
@@ -457,6 +460,24 @@ k_tile_uniform(const DevProblem P, const int2 *__restrict__ tiles, const int *__
                 double r = 0., u[DPE];
 #pragma unroll
                 for (int b = 0; b < DPE; b++) u[b] = 0.;
+                if constexpr (STRUCT && NP == 6) {
+                    double g[NP];
+#pragma unroll
+                    for (int jp = 0; jp < NP; jp++) {
+                        double d2 = 0.;
+#pragma unroll
+                        for (int d = 0; d < DIM; d++) { const double t = x[d]-y[jp][d]; d2 = __builtin_fma(t, t, d2); }
+                        g[jp] = kern_eval<KTE>(kk, d2, ptab);
+                        c[jp] = __builtin_fma(wi, g[jp], c[jp]);
+                    }
+                    const double s0 = (g[0]+g[1])+g[2], s1 = (g[3]+g[4])+g[NP-1];
+                    const double A0 = rule[R_WPH+1], B0 = rule[R_WPH]-rule[R_WPH+1];
+                    const double A1 = rule[R_WPH+3*DPE+1], B1 = rule[R_WPH+3*DPE]-rule[R_WPH+3*DPE+1];
+                    r = __builtin_fma(rule[R_W], s0, rule[R_W+3]*s1);
+                    const double base = __builtin_fma(A0, s0, A1*s1);
+#pragma unroll
+                    for (int b = 0; b < DPE; b++) u[b] = __builtin_fma(B0, g[b], __builtin_fma(B1, g[NP == 6 ? 3+b : 0], base));
+                } else {
 #pragma unroll
                 for (int jp = 0; jp < NP; jp++) {
                     double d2 = 0.;
@@ -467,6 +488,7 @@ k_tile_uniform(const DevProblem P, const int2 *__restrict__ tiles, const int *__
                     c[jp] = __builtin_fma(wi, g, c[jp]);
 #pragma unroll
                     for (int b = 0; b < DPE; b++) u[b] = __builtin_fma(g, rule[R_WPH+jp*DPE+b], u[b]);
+                }
                 }
                 if (NP == 3) racc[NP == 3 ? ip : 0] = __builtin_fma(vv, r, racc[NP == 3 ? ip : 0]);
                 else lds_add_f64(&Ra[li*RS+ip], vv*r);

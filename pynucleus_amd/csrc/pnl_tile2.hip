@@ -71,7 +71,7 @@ int launch_uniform_t(pnl_context *ctx, const DevProblem &Pt, const int2 *tiles, 
 template <int DPE, int NP>
 int launch_uniform_kt(pnl_context *ctx, int kt, const DevProblem &Pt, const int2 *tiles, const int *tile_cls, int ntiles, int q,
                       double *A, int64_t ldA, double *Dglob, const SlotOut &SO) {
-    if constexpr (DPE == 3 && NP == 3) {
+    if constexpr (DPE == 3) {
         if (ctx->uni_struct[q]) {
             if (kt == 2) return launch_uniform_t<DPE, NP, 2, true>(ctx, Pt, tiles, tile_cls, ntiles, q, A, ldA, Dglob, SO);
             if (kt == 1) return launch_uniform_t<DPE, NP, 1, true>(ctx, Pt, tiles, tile_cls, ntiles, q, A, ldA, Dglob, SO);
