@@ -98,6 +98,8 @@ enum pnl_counter {
  *   "PNL_BND_OLD"     Omega x Omega^c term: the per-pair kernel instead of the tiled one (2D),
  *   "PNL_PLAN_THREADS" host threads of the planner,
  *   "PNL_TILE_WGS"    at most this many workgroups per persistent tile kernel (tests: every workgroup then walks many tiles),
+ *   "PNL_UNI_GENERIC" uniform-order tiles: the evaluator for arbitrary rules also where the rule has the orbit structure of the
+ *                     symmetric 3- and 6-point rules (tests: both evaluators against each other),
  *   "PNL_NO_OVERLAP", "PNL_NO_FORK"   profiling: no side streams, every phase on the caller's stream one after the other,
  *   "PNL_VERBOSE", "PNL_PLAN_TIMING"   diagnostics on stderr,
  * and returns PNL_ERR_UNSUPPORTED for any other name.  A tuning build (make EXTRA=-DPNL_TUNING; pnl_version says so) accepts every

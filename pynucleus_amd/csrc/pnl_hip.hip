@@ -1930,7 +1930,7 @@ const char *const k_product_options[] = {"PNL_WL_FRAC", "PNL_FH_NOTILES", "PNL_N
                                          "PNL_NO_OVERLAP", "PNL_NO_FORK",
                                          // tests: at most this many workgroups of a persistent tile kernel (every workgroup then walks
                                          // many tiles at test sizes: the pipelined tile loops against the oracle)
-                                         "PNL_TILE_WGS"};
+                                         "PNL_TILE_WGS", "PNL_UNI_GENERIC"};
 }  // namespace
 
 const char *pnl_tune(const char *name) {

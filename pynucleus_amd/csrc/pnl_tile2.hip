@@ -72,7 +72,7 @@ template <int DPE, int NP>
 int launch_uniform_kt(pnl_context *ctx, int kt, const DevProblem &Pt, const int2 *tiles, const int *tile_cls, int ntiles, int q,
                       double *A, int64_t ldA, double *Dglob, const SlotOut &SO) {
     if constexpr (DPE == 3) {
-        if (ctx->uni_struct[q]) {
+        if (ctx->uni_struct[q] && !pnl_tune("PNL_UNI_GENERIC")) {
             if (kt == 2) return launch_uniform_t<DPE, NP, 2, true>(ctx, Pt, tiles, tile_cls, ntiles, q, A, ldA, Dglob, SO);
             if (kt == 1) return launch_uniform_t<DPE, NP, 1, true>(ctx, Pt, tiles, tile_cls, ntiles, q, A, ldA, Dglob, SO);
             return launch_uniform_t<DPE, NP, 0, true>(ctx, Pt, tiles, tile_cls, ntiles, q, A, ldA, Dglob, SO);

@@ -421,3 +421,28 @@ def test_gpu_tile_loops_with_two_workgroups_against_the_oracle(case):
             assert A.info['counters']['numAssembledCellPairs'] == cnt['numAssembledCellPairs']
     finally:
         _lib.set_option('PNL_TILE_WGS', None)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('s', [0.5, 0.75, 0.4])
+def test_gpu_uniform_tiles_structured_and_generic_evaluators_agree(s):
+    """The uniform-order tile kernels of P1 evaluate the symmetric 3- and 6-point rules through their orbit structure (w phi_b(y_j) =
+    A_o + B_o delta: cross blocks from row / column / orbit sums of the kernel values); the option PNL_UNI_GENERIC sends the same tiles
+    through the evaluator for arbitrary rules.  Same matrix to rounding, same pair counts, and both orders occur in uniform tiles."""
+    from pynucleus_amd import _lib
+    b = _gpu_builder(6, s, params={'target_order': 0.5})           # 24,576 cells: uniform tiles of orders 2 and 3
+    A = b.getDense()
+    D1, cnt1 = A.toarray().copy(), A.info['counters']
+    del A
+    uni = cnt1.get('uniformTilePairsByOrder', {})
+    assert uni.get(2, 0) > 0 and uni.get(3, 0) > 0, uni
+    try:
+        _lib.set_option('PNL_UNI_GENERIC', 1)
+        b2 = _gpu_builder(6, s, params={'target_order': 0.5})
+        A2 = b2.getDense()
+        D2, cnt2 = A2.toarray(), A2.info['counters']
+    finally:
+        _lib.set_option('PNL_UNI_GENERIC', None)
+    assert cnt1['numAssembledCellPairs'] == cnt2['numAssembledCellPairs'] and cnt1['orders'] == cnt2['orders']
+    assert np.abs(D1-D2).max() <= 1e-13*np.abs(D1).max()
+    assert np.abs(D1-D2).max() > 0.                       # two evaluators, not one
