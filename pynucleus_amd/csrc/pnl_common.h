@@ -150,6 +150,24 @@ __device__ __noinline__ static double pnl_erfc(double x) { return erfc(x); }
 // erfc above all -- stay out of the kernels that integrate element pairs: the register allocation of a kernel is the maximum over
 // its paths, and with them in the general branch k_worklist_sorted<2, 3, 0> went from 240 VGPRs to 256 + 56 AGPRs, i.e. from two
 // waves per SIMD to one, also for the fractional kernels that never take that branch (8.5 instead of 6.1 ms at 98,304 cells, s = 0.4).
+// d2^(-QM/4) for odd QM (s = 1/4, 3/4 in 1D / 2D): y = d2^(-1/4) from the single-precision pipeline (v_log_f32, v_exp_f32: |1 - d2 y^4| =
+// e < 5e-6 for d2 in [1e-10, 8]), then y^QM (1 - e)^(-QM/4) with the series to e^2 (the next term is below 4e-16).  Two quarter-rate
+// single-precision operations and 8-9 double-precision ones instead of two v_rsq_f64 (17.7 cycles per wave each) with a cubic
+// correction each and the integer power: 88 instead of 126 cycles per kernel value for QM = 7 (tools/probes/valu_rate_probe.hip).
+template <int QM>
+__device__ __forceinline__ double pnl_pow_quarter_odd(double d2) {
+    static_assert(QM == 3 || QM == 5 || QM == 7, "exponents -3/4, -5/4, -7/4");
+    const double y = (double)__builtin_amdgcn_exp2f(-0.25f*__builtin_amdgcn_logf((float)d2));
+    const double y2 = y*y, y4 = y2*y2;
+    const double e = __builtin_fma(-d2, y4, 1.0);
+    const double P = QM == 3 ? y2*y : (QM == 5 ? y4*y : (y4*y2)*y);
+    // c1 + c2 e with c1 = QM/4 from an opaque register pair and the three-address v_fma spelled out (see KT == 2 below)
+    double c1 = 0.25*QM, q;
+    asm("" : "+v"(c1));
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(q) : "v"(e), "s"(0.25*QM*(0.25*QM+1.)*0.5), "v"(c1));
+    return __builtin_fma(P, e*q, P);
+}
+
 template <int KT, bool BND = false>
 __device__ __forceinline__ double kern_eval(const DevKernel &k, double d2, const double *__restrict__ ltab = nullptr) {
     if (KT == 3) return pnl_pow_tab(d2, k, ltab);
@@ -158,6 +176,7 @@ __device__ __forceinline__ double kern_eval(const DevKernel &k, double d2, const
         // KT == 1 with the exponent -QM/4 known at compile time (QM = KT - 10; kern_dispatch): the scalar branches and the
         // square-and-multiply loop of the run-time version below split every evaluation into basic blocks of its own
         constexpr int QM = KT-10;
+        if constexpr (QM == 3 || QM == 5 || QM == 7) return pnl_pow_quarter_odd<(QM == 3 || QM == 5 || QM == 7) ? QM : 3>(d2);
         double r = __builtin_amdgcn_rsq(d2);
         {
             const double e = __builtin_fma(-(d2*r), r, 1.0);
@@ -186,7 +205,6 @@ __device__ __forceinline__ double kern_eval(const DevKernel &k, double d2, const
         // r^3 (1 + e (3/2 + 15/8 e)), the next term 35/16 e^3 is below 1e-19; six operations after the rsq, chain depth five
         // 3/2 is no inline constant: as an immediate the compiler rebuilds it in a register pair for every evaluation (v_fmac wants
         // the addend in its destination: two v_mov per kernel value, 18 of the 270 instructions per pair of the 3-point tile loop);
-        // an opaque loop-invariant register pair makes it one v_fma
         // an opaque loop-invariant register pair and the three-address form spelled out make it one v_fma
         double c15 = 1.5, p;
         asm("" : "+v"(c15));
@@ -201,12 +219,15 @@ __device__ __forceinline__ double kern_eval(const DevKernel &k, double d2, const
         // (cubic: r (1 + e/2 + 3 e^2/8), e = 1 - d2 r^2, five operations for full precision), for odd qm one more refined
         // rsqrt gives d2^(-1/4); then an integer power.  A few ulp instead of libm's pow at 1/8 of the cost.  The scale is
         // applied once per pair (kern_scale); qm is wave-uniform, the branches are scalar.
+        int p = k.qm;
+        if (p == 7) return pnl_pow_quarter_odd<7>(d2);   // wave-uniform branches
+        if (p == 5) return pnl_pow_quarter_odd<5>(d2);
+        if (p == 3) return pnl_pow_quarter_odd<3>(d2);
         double r = __builtin_amdgcn_rsq(d2);
         {
             const double e = __builtin_fma(-(d2*r), r, 1.0);
             r = __builtin_fma(r, e*__builtin_fma(0.375, e, 0.5), r);
         }
-        int p = k.qm;
         if (p == 6) return (r*r)*r;                      // s = 1/2 in 2D
         double base = r;
         if (p & 1) {
